@@ -1,0 +1,203 @@
+"""Pin the CPU oracle against golden vectors captured from the reference (CPU only).
+
+The reference has no tests/fixtures of its own; tests/golden/*.npz were
+produced by importing it in the build container (tests/golden/make_golden.py).
+"""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from css_amd.utils import synthetic as syn
+
+from conftest import GOLDEN
+
+
+def rnd(shape, seed, scale=1.0):
+    return torch.from_numpy((scale * np.random.RandomState(seed).standard_normal(shape)).astype(np.float32))
+
+
+def close(a, b, atol, rtol=0.0):
+    a = torch.as_tensor(np.asarray(a)).double()
+    b = torch.as_tensor(np.asarray(b)).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    assert bool((err <= tol).all()), f"max err {err.max().item():.3e} (tol {atol}+{rtol}*|b|)"
+
+
+def test_keys_match_reference():
+    keys = json.load(open(os.path.join(GOLDEN, "keys.json")))
+    assert [[k, list(s)] for k, s in syn.conformer_shapes().items()] == keys["conformer_base"]
+    assert [[k, list(s)] for k, s in syn.blstm_shapes().items()] == keys["blstm_default"]
+
+
+def test_stft_features(golden):
+    g = golden("stft.npz")
+    n_short = 512 + 256 * 19
+    mix, src = syn.synthetic_sources(2, n_short, seed=3)
+    x7 = syn.synthetic_multichannel(src, n_ch=7, seed=3)
+    assert abs(float(mix.double().sum()) - float(g["mix_sum"])) < 1e-9
+    assert abs(float(x7.double().sum()) - float(g["x7_sum"])) < 1e-9
+    mag, f, re, im = oracle.feature.feature_extractor(mix)
+    close(re, g["re1"], 2e-5)
+    close(im, g["im1"], 2e-5)
+    close(mag, g["mag1"], 2e-5)
+    close(f, g["f1"], 2e-4)
+    mag7, f7, re7, im7 = oracle.feature.feature_extractor(x7, ipd_index="1,0;2,0;3,0;4,0;5,0;6,0")
+    close(re7, g["re7"], 2e-5)
+    close(im7, g["im7"], 2e-5)
+    close(mag7, g["mag7"], 2e-5)
+    close(f7[:, :257], g["f7"][:, :257], 2e-4)
+    # IPD is an angle: compare on the circle (atan2 branch cut) and away from ill-conditioned points
+    d = torch.as_tensor(g["f7"][:, 257:]).double() - f7[:, 257:].double()
+    d = torch.atan2(torch.sin(d), torch.cos(d)).abs()
+    assert float(d.mean()) < 1e-4 and float((d > 1e-2).double().mean()) < 1e-3
+    mixw, _ = syn.synthetic_sources(1, 38656, seed=4)
+    magw, fw, _, _ = oracle.feature.feature_extractor(mixw)
+    assert magw.shape == (1, 257, 150)
+    close(magw, g["magw"], 2e-5)
+    close(fw, g["fw"], 2e-4)
+
+
+def test_stft_matches_torch_stft():
+    x = rnd((2, 4096), 5, 0.1)
+    mag, pha, re, im = oracle.feature.stft(x)
+    ref = torch.stft(x, 512, 256, window=torch.hann_window(512), center=False, return_complex=True)
+    close(re, ref.real, 1e-5)
+    close(im, ref.imag, 1e-5)
+
+
+def test_istft_roundtrip():
+    x = rnd((2, 256 * 20), 6, 0.1)
+    spec = torch.stft(x, 512, 256, window=torch.hann_window(512), center=True, return_complex=True)
+    y = oracle.feature.istft_center(spec.real, spec.imag, 512, 256, length=x.shape[-1])
+    ref = torch.istft(spec, 512, 256, window=torch.hann_window(512), center=True, length=x.shape[-1])
+    close(y, ref, 1e-5)
+    close(y[:, 256:-256], x[:, 256:-256], 1e-5)
+
+
+D, H, FFN, KS = 256, 4, 1024, 33
+
+
+def _sd(shapes, seed, prefix=""):
+    return {prefix + k: v for k, v in syn.fill_state_dict(shapes, seed).items()}
+
+
+def test_conformer_submodules(golden):
+    g = golden("conformer.npz")
+    x = rnd((2, 64, D), 11)
+    assert abs(float(x.double().sum()) - float(g["x_sum"])) < 1e-9
+    full = syn.conformer_shapes(num_blocks=1)
+    pre = "conformer.encoders.0."
+    ffn_shapes = {k[len(pre + "feed_forward_in."):]: s for k, s in full.items() if k.startswith(pre + "feed_forward_in.")}
+    sd = _sd(ffn_shapes, 21, "ffn.")
+    close(oracle.conformer.feed_forward(x, sd, "ffn"), g["ffn"], 2e-5)
+
+    pe = syn.synth_tensor("pe_k.weight", (2000, D // H), 22)
+    pos_k = oracle.conformer.rel_pos_table(pe, 64)
+    mha_shapes = {k[len(pre + "self_attn."):]: s for k, s in full.items() if k.startswith(pre + "self_attn.")}
+    sd = _sd(mha_shapes, 23, "mha.")
+    close(oracle.conformer.attention(x, sd, "mha", H, pos_k), g["mha"], 2e-5)
+
+    conv_shapes = {k[len(pre + "conv."):]: s for k, s in full.items() if k.startswith(pre + "conv.")}
+    sd = _sd(conv_shapes, 24, "cv.")
+    close(oracle.conformer.conv_module(x, sd, "cv", KS), g["conv_eval"], 2e-5)
+    close(oracle.conformer.conv_module(x, sd, "cv", KS, training_bn=True), g["conv_trainbn"], 5e-5)
+
+    lay_shapes = {k[len(pre):]: s for k, s in full.items() if k.startswith(pre)}
+    sd = _sd(lay_shapes, 25, "l.")
+    close(oracle.conformer.encoder_layer(x, sd, "l", H, KS, pos_k), g["layer"], 5e-5)
+
+
+@pytest.mark.parametrize("nb", [2, 16])
+def test_conformer_full(golden, nb):
+    g = golden("conformer.npz")
+    f_in = rnd((2, 100, 257), 12).abs()
+    assert abs(float(f_in.double().sum()) - float(g["f_sum"])) < 1e-9
+    tg = rnd((2, 2, 100, 257), 13).abs() * 0.5
+    sd = syn.fill_state_dict(syn.conformer_shapes(num_blocks=nb), 30 + nb)
+    y_pred, masks = oracle.conformer.forward(f_in, sd, num_blocks=nb)
+    close(torch.stack(masks, 0), g[f"masks_b{nb}"], 2e-4)
+    loss = oracle.pit.mse_objective(y_pred, tg[:, 0], tg[:, 1])
+    assert abs(float(loss) - float(g[f"loss_b{nb}"])) < 1e-5 * max(1.0, float(g[f"loss_b{nb}"]))
+
+
+def test_conformer_long_clamp(golden):
+    g = golden("conformer.npz")
+    sd = syn.fill_state_dict(syn.conformer_shapes(num_blocks=1), 41)
+    f_long = rnd((1, 1100, 257), 14).abs()
+    _, masks = oracle.conformer.forward(f_long, sd, num_blocks=1)
+    m = torch.stack(masks, 0)
+    close(m[:, :, :40], g["masks_long_head"], 2e-4)
+    close(m[:, :, -40:], g["masks_long_tail"], 2e-4)
+    assert int(g["seven_ch_runs"]) == 0  # reference forward raises for idim != num_bins (documented quirk)
+
+
+def test_blstm(golden):
+    g = golden("blstm.npz")
+    sd = syn.fill_state_dict(syn.blstm_shapes(hidden_dim=64, num_layers=2), 50)
+    fb = rnd((2, 30, 257), 16).abs()
+    y_pred, masks = oracle.blstm.forward(fb, sd, num_layers=2)
+    close(torch.stack(masks, 0), g["masks"], 5e-5)
+    close(y_pred, g["y_pred"], 5e-5)
+
+
+def test_pit(golden):
+    g = golden("pit.npz")
+    for K in (2, 3):
+        est = rnd((K, 40, 257), 60 + K).abs()
+        tgt = rnd((K, 40, 257), 70 + K).abs()
+        l, p = oracle.pit.pit_mse(est, tgt, return_permutation=True)
+        assert abs(float(l) - float(g[f"loss_k{K}"])) < 1e-6
+        assert list(p) == list(g[f"perm_k{K}"])
+        rot = list(range(1, K)) + [0]
+        est2 = tgt[rot] + 0.01 * rnd((K, 40, 257), 80 + K)
+        l2, p2 = oracle.pit.pit_mse(est2, tgt, return_permutation=True)
+        assert abs(float(l2) - float(g[f"loss_rot_k{K}"])) < 1e-7
+        assert list(p2) == list(g[f"perm_rot_k{K}"])
+        # pairwise-SSE formulation (what the HIP kernel computes) gives the same minimum
+        Dm = oracle.pit.pairwise_sse(est, tgt)
+        import itertools
+        cands = [sum(Dm[pp[i], i] for i in range(K)) / (K * 40 * 257) for pp in itertools.permutations(range(K))]
+        assert abs(float(min(cands)) - float(l)) < 1e-6
+
+
+def _stitch_inputs():
+    W, Fb, Tw, hop = 6, 257, 150, 50
+    total = hop * (W - 1) + Tw
+    base = rnd((Fb, total, 3), 90).abs()
+    base = base / base.sum(-1, keepdim=True)
+    magl = rnd((Fb, total), 91).abs()
+    flips = [0, 1, 1, 0, 1, 0]
+    masks, mags = [], []
+    for w in range(W):
+        m = base[:, w * hop:w * hop + Tw].clone() + 0.02 * rnd((Fb, Tw, 3), 100 + w).abs()
+        if flips[w]:
+            m = m[:, :, [1, 0, 2]]
+        masks.append(m)
+        mags.append(magl[:, w * hop:w * hop + Tw])
+    return torch.stack(masks), torch.stack(mags), hop
+
+
+def test_stitcher(golden):
+    g = golden("stitcher.npz")
+    masks, mags, hop = _stitch_inputs()
+    margin = oracle.stitcher.stitch_margin(2.4, 0.8, 256)
+    assert margin == int(g["margin"]) == 100
+    perm = oracle.stitcher.get_stitch(mags, masks, margin)
+    assert np.array_equal(np.array(perm), g["perm"])
+    r1, r2, rn = oracle.stitcher.get_connect(perm, masks, hop)
+    close(r1, g["res1"], 1e-6)
+    close(r2, g["res2"], 1e-6)
+    close(rn, g["noise"], 1e-6)
+
+
+def test_lr_trace():
+    tr = json.load(open(os.path.join(GOLDEN, "trainer.json")))
+    got = oracle.schedule.lr_trace(1e-3, 10, warmup=4, fixed=2, decay=0.1, min_lr=1e-9)
+    assert np.allclose(got, tr["lr_trace"], rtol=1e-12, atol=0)
