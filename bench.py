@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Headline benchmark: STFT-frames/sec (fwd + PIT), Conformer-1ch, batch = 32 x 400-frame chunks.
+
+One "step" = one pass of the hot path over one synthetic batch that is already resident in
+HBM:  raw audio (mix, source1, source2: 3 x [32, 102 656] f32)
+      -> STFT magnitudes (csship_stft)                     [feature.py:45-82]
+      -> Conformer-base forward to the ReLU masks          [conformer.py:83-104]
+      -> fused mask-apply + PIT-MSE loss                   [conformer.py:103, mse.py:22-37]
+Frames counted per step = B*T = 12 800 mixture frames per GPU (the two target spectrograms
+are work, not frames).  N > 1: one process per GPU (torchrun), every rank runs its own batch
+(weak scaling), no collective on the data path; barrier + synchronize on both
+sides of the timed region, max over ranks.
+
+Extra objects on the JSON line (task section 4):
+  roofline     dominant kernel = the FFN up-projection GEMM (12800x256 @ 256x1024, bf16 MFMA);
+               achieved = algorithmic 2*M*N*K flops / average launch duration measured with
+               HIP events on the launch stream; peak = 2.5 PFLOP/s dense bf16.
+  cpu_baseline the oracle (fp32 CPU restatement, kind "port") timed on this box's host cores on
+               ONE full batch (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B, T, NBIN = 32, 400, 257
+N_SAMPLES = 512 + 256 * (T - 1)  # 102 656
+PEAK_BF16 = 2.5e15
+FLOP_PER_FRAME = 52.57e6  # Conformer-base forward @ T=400
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--blocks", type=int, default=16, help="debug only: anything but 16 is not the headline config")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    from css_amd import _lib, ops
+    from css_amd.models import MODELS
+    from css_amd.utils import synthetic as syn
+
+    conf = dict(attention_dim=256, attention_heads=4, linear_units=1024, num_blocks=args.blocks, kernel_size=33,
+                dropout_rate=0.1, relative_pos_emb=True)
+    model = MODELS["Conformer"](257, 257, 2, 1, conf)
+    sd = syn.fill_state_dict(syn.conformer_shapes(num_blocks=args.blocks), 0)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+
+    mix, src = syn.synthetic_sources(B, N_SAMPLES, seed=rank)
+    audio = torch.stack([mix, src[0], src[1]], 0).to(dev)  # [3, B, n]
+
+    def step():
+        mags = ops.stft(audio, ("mag",))["mag"]  # [3,B,T,257]
+        masks = model.forward_masks(mags[0])
+        loss, perm, _, _ = ops.pit_mse(masks, mags[0], [mags[1], mags[2]])
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_val = float(loss)
+
+    # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream
+    roof = None
+    if rank == 0:
+        M = B * T
+        a = torch.randn(M, 256, device=dev).to(torch.bfloat16)
+        w = ops.pad_weight_bf16(torch.randn(1024, 256, device=dev) / 16)
+        bias = torch.zeros(1024, device=dev)
+        out = torch.empty(M, 1024, device=dev, dtype=torch.bfloat16)
+        for _ in range(5):
+            ops.gemm(a, w, bias, relu=True, out_bf16=True, out=out)
+        reps = 50
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream())
+        for _ in range(reps):
+            ops.gemm(a, w, bias, relu=True, out_bf16=True, out=out)
+        e1.record(torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        dur = e0.elapsed_time(e1) * 1e-3 / reps
+        flops = 2.0 * M * 1024 * 256
+        roof = {"bound": "mfma", "kernel": "gemm_kernel<2,2,bf16,relu|bf16> (FFN up-projection 12800x256x1024)",
+                "achieved": flops / dur / 1e12, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                "frac": flops / dur / PEAK_BF16, "traffic": None, "avg_launch_us": dur * 1e6,
+                "whole_step_frac": (B * T * FLOP_PER_FRAME * args.blocks / 16) / (dt / args.steps) / PEAK_BF16}
+
+    # ---- CPU baseline: the oracle on one full batch, host cores of this box
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        with torch.no_grad():
+            c0 = time.perf_counter()
+            mags = [oracle.feature.stft(x)[0].transpose(1, 2).contiguous() for x in (mix, src[0], src[1])]
+            y_pred, _ = oracle.conformer.forward(mags[0], sd, num_blocks=args.blocks)
+            closs = oracle.pit.mse_objective(y_pred, mags[1], mags[2])
+            cdt = time.perf_counter() - c0
+        cpu = {"value": B * T / cdt, "unit": "frames/s", "cores": cores, "kind": "port",
+               "sample": f"1 step of the full workload (B={B} x T={T} frames, fp32, torch {torch.__version__} CPU ops)",
+               "loss": float(closs), "gpu_loss": loss_val}
+
+    if rank == 0:
+        frames = world * B * T * args.steps
+        line = {
+            "metric": "STFT-frames/sec (fwd+PIT) Conformer-1ch", "value": frames / dt, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": "Conformer-base 1ch 2-spk fwd+PIT, batch=32x400-frame chunks (configs[1])",
+                       "global_batch": world * B, "frames_per_chunk": T, "num_blocks": args.blocks,
+                       "mode": "eval forward (running-stat BN, no dropout)", "parallelism": f"dp{world}"},
+            "roofline": roof, "cpu_baseline": cpu, "loss": loss_val,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,93 @@
+"""ctypes binding of libcsship.so (C ABI in include/csship.h).
+
+There is deliberately no fallback: if the shared library is missing ``lib()`` raises, and
+every op wrapper refuses non-CUDA tensors.  Build it with ``make -C css_amd/csrc`` or
+``python -c "import __graft_entry__ as g; g.build()"``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcsship.so")
+
+_p, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+
+
+class GemmParams(C.Structure):
+    _fields_ = [("M", _i32), ("N", _i32), ("K", _i32), ("lda", _i32), ("ldw", _i32), ("ldc", _i32),
+                ("ldr", _i32), ("a_mode", _i32), ("epilogue", _i32), ("rows_per_batch", _i32),
+                ("alpha", _f32)]
+
+
+class ConvWeights(C.Structure):
+    _fields_ = [(n, _p) for n in ("ln_g", "ln_b", "pw1_w", "pw1_b", "dw_w", "dw_b", "bn_g", "bn_b",
+                                  "bn_mean", "bn_var", "pw2_w", "pw2_b")]
+
+
+class FfnWeights(C.Structure):
+    _fields_ = [(n, _p) for n in ("ln_g", "ln_b", "w1", "b1", "w2", "b2")]
+
+
+class MhaWeights(C.Structure):
+    _fields_ = [(n, _p) for n in ("ln_g", "ln_b", "wqkv", "bqkv", "wo", "bo")]
+
+
+class LayerWeights(C.Structure):
+    _fields_ = [("ffn_in", FfnWeights), ("mha", MhaWeights), ("conv", ConvWeights), ("ffn_out", FfnWeights),
+                ("ln_g", _p), ("ln_b", _p)]
+
+
+class ConformerWeights(C.Structure):
+    _fields_ = [("idim", _i32), ("idim_pad", _i32), ("d_model", _i32), ("n_head", _i32), ("d_ffn", _i32),
+                ("n_layer", _i32), ("kernel_size", _i32), ("n_out", _i32), ("maxlen", _i32), ("bn_mode", _i32),
+                ("embed_w", _p), ("embed_b", _p), ("embed_ln_g", _p), ("embed_ln_b", _p), ("pe_k", _p),
+                ("layers", C.POINTER(LayerWeights)), ("head_w", _p), ("head_b", _p)]
+
+
+A_BF16, A_F32, A_F32_MVN = 0, 1, 2
+EPI_RELU, EPI_RESIDUAL, EPI_LAYERNORM, EPI_OUT_BF16 = 1, 2, 4, 8
+
+# name -> (restype, argtypes); mirrors include/csship.h one to one
+SIGNATURES = {
+    "csship_version": (_i32, []),
+    "csship_strerror": (C.c_char_p, [_i32]),
+    "csship_stft": (_i32, [_p, _i64, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _p]),
+    "csship_mvn_stats": (_i32, [_p, _i64, _i64, _i64, _i64, _f32, _f32, _p, _p, _p]),
+    "csship_transpose_norm": (_i32, [_p, _i64, _i64, _i64, _i64, _f32, _p, _p, _p, _i64, _i64, _p]),
+    "csship_ipd": (_i32, [_p, _p, _i64, _i64, _i64, C.POINTER(_i32), C.POINTER(_i32), _i32, _p, _i64, _i64, _p, _p]),
+    "csship_istft": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p]),
+    "csship_layernorm": (_i32, [_p, _i64, _i32, _p, _p, _p, _p, _p]),
+    "csship_gemm": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(GemmParams), _p]),
+    "csship_mha_relpos": (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _p]),
+    "csship_convmod_workspace": (_sz, [_i32, _i32, _i32]),
+    "csship_convmod": (_i32, [_p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _i32, _p, _p]),
+    "csship_pit_workspace": (_sz, [_i32, _i32, _i32, _i32]),
+    "csship_pit_mse": (_i32, [_p, _i64, _p, _i64, C.POINTER(_p), _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p]),
+    "csship_pit_mse_bwd": (_i32, [_p, _i64, _p, _i64, C.POINTER(_p), _p, _i32, _i32, _i32, _i32, _i32, _f32, _p, _p]),
+    "csship_apply_masks": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p, _p]),
+    "csship_conformer_workspace": (_sz, [C.POINTER(ConformerWeights), _i32, _i32]),
+    "csship_conformer_forward": (_i32, [C.POINTER(ConformerWeights), _p, _i64, _i32, _i32, _p, _p, _p, _sz, _p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libcsship.so once; raise if it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"css_amd: HIP library not found at {LIB_PATH}. Build it (make -C css_amd/csrc); "
+                "there is no CPU fallback for the css hot path.")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)  # AttributeError here = header/library mismatch
+            fn.restype, fn.argtypes = res, args
+        _lib = h
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(lib().csship_strerror(rc).decode() + f" (rc={rc})")

@@ -1,0 +1,209 @@
+// Conformer convolution module + residual, fused (css/models/conformer.py:289-303, 357):
+//   y = x + pw2( relu( BN( dwconv_k( glu( LN(x) ) ) ) ) )
+// The two "pointwise convs" of the reference are Conv2d(1,2,1) / Conv2d(1,1,1), i.e. scalar
+// gains (parameter shapes (2,1,1,1) and (1,1,1,1)), so the module has no GEMM: it is a
+// bandwidth-bound stencil.  One workgroup = (batch b, TT frames, all D channels):
+//   phase 1  each wave normalises whole rows (LN over D, wave reduction) for the TT + k - 1
+//            frames of the tile + halo, applies the scalar GLU and parks them in LDS;
+//   phase 2  thread c owns channel c: k-tap depthwise convolution from LDS columns
+//            (conflict free), BatchNorm, ReLU, scalar affine, residual add, coalesced store.
+// bn_mode 1 (training forward, batch statistics) splits after the convolution: pass A stores
+// the pre-BN activations and per-workgroup partial sums, a tiny reduce kernel forms the
+// per-channel scale/shift deterministically (no atomics), pass B finishes.
+#include "common.hpp"
+
+namespace {
+
+struct ConvArgs {
+  const float* x;
+  float* y;
+  csship_conv_weights w;
+  float* zbuf;     // train: pre-BN activations [B,T,D]
+  float* partial;  // train: [nblk][2][D]
+  int B, T;
+};
+
+template <int D, int TT, int KS, int MODE>
+__global__ __launch_bounds__(D) void convmod_kernel(ConvArgs a) {
+  constexpr int HALO = (KS - 1) / 2, ROWS = TT + KS - 1, NW = D / 64, VPL = D / 256;
+  __shared__ __attribute__((aligned(16))) float G[ROWS][D];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, t0 = blockIdx.x * TT;
+  const float w0 = a.w.pw1_w[0], w1 = a.w.pw1_w[1], b0 = a.w.pw1_b[0], b1 = a.w.pw1_b[1];
+
+  for (int row = wave; row < ROWS; row += NW) {
+    const int t = t0 - HALO + row;
+    if (t < 0 || t >= a.T) {
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) *reinterpret_cast<float4*>(&G[row][(i * 64 + lane) * 4]) = make_float4(0, 0, 0, 0);
+      continue;
+    }
+    const float* xr = a.x + ((size_t)b * a.T + t) * D;
+    float4 v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      v[i] = *reinterpret_cast<const float4*>(xr + (i * 64 + lane) * 4);
+      s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+    const float mean = wave_sum(s) * (1.f / D);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+      ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+    }
+    const float rstd = rsqrtf(wave_sum(ss) * (1.f / D) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      const float4 gm = *reinterpret_cast<const float4*>(a.w.ln_g + c);
+      const float4 bt = *reinterpret_cast<const float4*>(a.w.ln_b + c);
+      float e[4] = {v[i].x * rstd * gm.x + bt.x, v[i].y * rstd * gm.y + bt.y, v[i].z * rstd * gm.z + bt.z,
+                    v[i].w * rstd * gm.w + bt.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) e[q] = (w0 * e[q] + b0) / (1.f + __expf(-(w1 * e[q] + b1)));
+      *reinterpret_cast<float4*>(&G[row][c]) = make_float4(e[0], e[1], e[2], e[3]);
+    }
+  }
+  __syncthreads();
+
+  const int c = tid;
+  float wk[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) wk[k] = a.w.dw_w[c * KS + k];
+  const float cb = a.w.dw_b[c];
+  float scale = 0.f, shift = 0.f, pw2w = 0.f, pw2b = 0.f;
+  if constexpr (MODE == 0) {
+    scale = a.w.bn_g[c] * rsqrtf(a.w.bn_var[c] + 1e-5f);
+    shift = a.w.bn_b[c] - a.w.bn_mean[c] * scale;
+    pw2w = a.w.pw2_w[0];
+    pw2b = a.w.pw2_b[0];
+  }
+  float lsum = 0.f, lsq = 0.f;
+  constexpr int OB = 8;
+#pragma unroll 1
+  for (int tb = 0; tb < TT; tb += OB) {
+    float acc[OB];
+#pragma unroll
+    for (int j = 0; j < OB; ++j) acc[j] = cb;
+#pragma unroll
+    for (int u = 0; u < OB + KS - 1; ++u) {
+      const float gv = G[tb + u][c];
+#pragma unroll
+      for (int j = 0; j < OB; ++j) {
+        const int k = u - j;
+        if (k >= 0 && k < KS) acc[j] += wk[k] * gv;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < OB; ++j) {
+      const int t = t0 + tb + j;
+      if (t >= a.T) continue;
+      const size_t o = ((size_t)b * a.T + t) * D + c;
+      if constexpr (MODE == 0) {
+        a.y[o] = a.x[o] + fmaxf(acc[j] * scale + shift, 0.f) * pw2w + pw2b;
+      } else {
+        a.zbuf[o] = acc[j];
+        lsum += acc[j];
+        lsq += acc[j] * acc[j];
+      }
+    }
+  }
+  if constexpr (MODE == 1) {
+    const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    a.partial[(blk * 2 + 0) * D + c] = lsum;
+    a.partial[(blk * 2 + 1) * D + c] = lsq;
+  }
+}
+
+// per-channel batch statistics -> scale/shift (biased variance, as BatchNorm1d normalises with)
+__global__ void bn_reduce_kernel(const float* __restrict__ partial, int nblk, int D, double count,
+                                 const float* __restrict__ bn_g, const float* __restrict__ bn_b,
+                                 float* __restrict__ scale_shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  double s = 0.0, q = 0.0;
+  for (int i = 0; i < nblk; ++i) {
+    s += (double)partial[((size_t)i * 2 + 0) * D + c];
+    q += (double)partial[((size_t)i * 2 + 1) * D + c];
+  }
+  const double mu = s / count;
+  const double var = fmax(q / count - mu * mu, 0.0);
+  const float sc = bn_g[c] * (float)(1.0 / sqrt(var + 1e-5));
+  scale_shift[c] = sc;
+  scale_shift[D + c] = bn_b[c] - (float)mu * sc;
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ z,
+                                                       const float* __restrict__ scale_shift,
+                                                       const float* __restrict__ pw2_w, const float* __restrict__ pw2_b,
+                                                       float* __restrict__ y, size_t n4, int D) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const int c = (int)((i * 4) % D);
+  const float4 xv = reinterpret_cast<const float4*>(x)[i];
+  const float4 zv = reinterpret_cast<const float4*>(z)[i];
+  const float4 sc = *reinterpret_cast<const float4*>(scale_shift + c);
+  const float4 sh = *reinterpret_cast<const float4*>(scale_shift + D + c);
+  const float pw = pw2_w[0], pb = pw2_b[0];
+  float4 o;
+  o.x = xv.x + fmaxf(zv.x * sc.x + sh.x, 0.f) * pw + pb;
+  o.y = xv.y + fmaxf(zv.y * sc.y + sh.y, 0.f) * pw + pb;
+  o.z = xv.z + fmaxf(zv.z * sc.z + sh.z, 0.f) * pw + pb;
+  o.w = xv.w + fmaxf(zv.w * sc.w + sh.w, 0.f) * pw + pb;
+  reinterpret_cast<float4*>(y)[i] = o;
+}
+
+template <int D, int TT>
+int run(const ConvArgs& a0, int bn_mode, void* workspace, hipStream_t s) {
+  ConvArgs a = a0;
+  dim3 grid((a.T + TT - 1) / TT, a.B);
+  if (bn_mode == 0) {
+    hipLaunchKernelGGL((convmod_kernel<D, TT, 33, 0>), grid, dim3(D), 0, s, a);
+    CSSHIP_CHECK_LAUNCH();
+    return CSSHIP_OK;
+  }
+  if (!workspace) return CSSHIP_EWORKSPACE;
+  const size_t n = (size_t)a.B * a.T * D;
+  const int nblk = grid.x * grid.y;
+  a.zbuf = reinterpret_cast<float*>(workspace);
+  a.partial = a.zbuf + n;
+  float* scale_shift = a.partial + (size_t)nblk * 2 * D;
+  hipLaunchKernelGGL((convmod_kernel<D, TT, 33, 1>), grid, dim3(D), 0, s, a);
+  CSSHIP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_reduce_kernel, dim3((D + 63) / 64), dim3(64), 0, s, a.partial, nblk, D,
+                     (double)a.B * (double)a.T, a.w.bn_g, a.w.bn_b, scale_shift);
+  CSSHIP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, a.x, a.zbuf, scale_shift,
+                     a.w.pw2_w, a.w.pw2_b, a.y, n / 4, D);
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
+constexpr int TT256 = 32, TT512 = 32;
+
+}  // namespace
+
+extern "C" size_t csship_convmod_workspace(int32_t B, int32_t T, int32_t D) {
+  const int TT = D == 256 ? TT256 : TT512;
+  const size_t nblk = (size_t)((T + TT - 1) / TT) * B;
+  return ((size_t)B * T * D + nblk * 2 * D + 2 * (size_t)D) * sizeof(float);
+}
+
+extern "C" int csship_convmod(const float* x, float* y, const csship_conv_weights* w, int32_t B, int32_t T,
+                              int32_t D, int32_t kernel_size, int32_t bn_mode, void* workspace,
+                              csship_stream_t stream) {
+  if (!x || !y || !w) return CSSHIP_ENULL;
+  if (!w->ln_g || !w->ln_b || !w->pw1_w || !w->pw1_b || !w->dw_w || !w->dw_b || !w->bn_g || !w->bn_b ||
+      !w->pw2_w || !w->pw2_b || (bn_mode == 0 && (!w->bn_mean || !w->bn_var)))
+    return CSSHIP_ENULL;
+  if (B <= 0 || T <= 0 || B > 65535) return CSSHIP_EBADSHAPE;
+  if (kernel_size != 33 || (D != 256 && D != 512) || (bn_mode != 0 && bn_mode != 1)) return CSSHIP_EUNSUPPORTED;
+  if (x == y) return CSSHIP_EBADSHAPE;  // neighbouring tiles read the halo rows: not in-place safe
+  if (!aligned16(x) || !aligned16(y) || !aligned16(w->ln_g) || !aligned16(w->ln_b) || (workspace && !aligned16(workspace)))
+    return CSSHIP_EALIGN;
+  ConvArgs a{x, y, *w, nullptr, nullptr, B, T};
+  if (D == 256) return run<256, TT256>(a, bn_mode, workspace, as_stream(stream));
+  return run<512, TT512>(a, bn_mode, workspace, as_stream(stream));
+}

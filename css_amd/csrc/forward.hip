@@ -1,0 +1,145 @@
+// Whole-model forward: Conformer.forward (css/models/conformer.py:83-104) from the feature
+// tensor to the ReLU masks as ONE host call.  It only sequences the kernels of this library
+// on the caller's stream (no allocation, no synchronisation), so the Python plugin pays one
+// ctypes call per forward instead of ~180, and the launch is hipGraph-capturable.
+#include "common.hpp"
+
+namespace {
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Workspace {
+  float *mean, *rinv, *x0, *x1;
+  unsigned short *a_bf, *ao_bf, *h_bf, *qkv_bf;
+  void* conv_ws;
+  size_t total;
+};
+
+Workspace carve(const csship_conformer_weights* w, int B, int T, void* base) {
+  const size_t M = (size_t)B * T, D = w->d_model;
+  unsigned char* p = reinterpret_cast<unsigned char*>(base);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    void* r = p ? p + off : nullptr;
+    off += align256(bytes);
+    return r;
+  };
+  Workspace ws;
+  ws.mean = (float*)take((size_t)B * w->idim * 4);
+  ws.rinv = (float*)take((size_t)B * w->idim * 4);
+  ws.x0 = (float*)take(M * D * 4);
+  ws.x1 = (float*)take(M * D * 4);
+  ws.a_bf = (unsigned short*)take(M * D * 2);
+  ws.ao_bf = (unsigned short*)take(M * D * 2);
+  ws.h_bf = (unsigned short*)take(M * (size_t)w->d_ffn * 2);
+  ws.qkv_bf = (unsigned short*)take(M * 3 * D * 2);
+  ws.conv_ws = w->bn_mode ? take(csship_convmod_workspace(B, T, (int)D)) : nullptr;
+  ws.total = off;
+  return ws;
+}
+
+int linear(const void* A, int a_mode, const unsigned short* W, const float* bias, const float* res, void* C, int M,
+           int N, int K, int lda, int ldw, int epi, float alpha, const float* ln_g, const float* ln_b,
+           csship_stream_t s) {
+  csship_gemm_params p{};
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = N; p.ldr = N;
+  p.a_mode = a_mode; p.epilogue = epi; p.rows_per_batch = 1; p.alpha = alpha;
+  return csship_gemm(A, W, bias, res, C, nullptr, nullptr, ln_g, ln_b, &p, s);
+}
+
+#define TRY(expr)              \
+  do {                         \
+    const int rc_ = (expr);    \
+    if (rc_ != CSSHIP_OK) return rc_; \
+  } while (0)
+
+}  // namespace
+
+extern "C" int csship_version(void) { return 100; }
+
+extern "C" const char* csship_strerror(int rc) {
+  switch (rc) {
+    case CSSHIP_OK: return "ok";
+    case CSSHIP_EBADSHAPE: return "csship: unsupported size or stride";
+    case CSSHIP_EALIGN: return "csship: pointer or stride not aligned as required";
+    case CSSHIP_EUNSUPPORTED: return "csship: dimension/feature combination not built";
+    case CSSHIP_ELAUNCH: return "csship: kernel launch failed (hipGetLastError)";
+    case CSSHIP_ENULL: return "csship: required pointer is NULL";
+    case CSSHIP_EWORKSPACE: return "csship: workspace missing or too small";
+    default: return "csship: unknown error";
+  }
+}
+
+extern "C" size_t csship_conformer_workspace(const csship_conformer_weights* w, int32_t B, int32_t T) {
+  if (!w || B <= 0 || T <= 0) return 0;
+  return carve(w, B, T, nullptr).total;
+}
+
+extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const float* f, int64_t ldf, int32_t B,
+                                        int32_t T, float* masks, float* enc_out, void* workspace,
+                                        size_t workspace_bytes, csship_stream_t stream) {
+  if (!w || !f || !masks || !workspace || !w->layers) return CSSHIP_ENULL;
+  if (B <= 0 || T <= 0 || ldf < w->idim) return CSSHIP_EBADSHAPE;
+  if (w->d_model != 256 || w->d_model / w->n_head != 64 || w->kernel_size != 33 || (w->d_ffn % 64) != 0 ||
+      (w->idim_pad % 64) != 0 || w->idim_pad < w->idim)
+    return CSSHIP_EUNSUPPORTED;
+  if (!aligned16(workspace)) return CSSHIP_EALIGN;
+  Workspace ws = carve(w, B, T, workspace);
+  if (ws.total > workspace_bytes) return CSSHIP_EWORKSPACE;
+  const int M = B * T, D = w->d_model, FF = w->d_ffn;
+  const int BF = CSSHIP_EPI_OUT_BF16;
+
+  // input MVN over time (conformer.py:95) folded into the embed GEMM's A load
+  TRY(csship_mvn_stats(f, B, T, w->idim, ldf, -INFINITY, 1.1920928955078125e-07f, ws.mean, ws.rinv, stream));
+  {
+    csship_gemm_params p{};
+    p.M = M; p.N = D; p.K = w->idim; p.lda = (int)ldf; p.ldw = w->idim_pad; p.ldc = D; p.ldr = D;
+    p.a_mode = CSSHIP_A_F32_MVN; p.epilogue = CSSHIP_EPI_LAYERNORM | CSSHIP_EPI_RELU; p.rows_per_batch = T;
+    TRY(csship_gemm(f, w->embed_w, w->embed_b, nullptr, ws.x0, ws.mean, ws.rinv, w->embed_ln_g, w->embed_ln_b, &p,
+                    stream));
+  }
+  float *x = ws.x0, *y = ws.x1;
+  for (int l = 0; l < w->n_layer; ++l) {
+    const csship_layer_weights& L = w->layers[l];
+    // x += 0.5 * FFN_in(x)                                   (conformer.py:355)
+    TRY(csship_layernorm(x, M, D, L.ffn_in.ln_g, L.ffn_in.ln_b, ws.a_bf, nullptr, stream));
+    TRY(linear(ws.a_bf, CSSHIP_A_BF16, L.ffn_in.w1, L.ffn_in.b1, nullptr, ws.h_bf, M, FF, D, D, D,
+               CSSHIP_EPI_RELU | BF, 0.f, nullptr, nullptr, stream));
+    TRY(linear(ws.h_bf, CSSHIP_A_BF16, L.ffn_in.w2, L.ffn_in.b2, x, x, M, D, FF, FF, FF, CSSHIP_EPI_RESIDUAL, 0.5f,
+               nullptr, nullptr, stream));
+    // x += MHA(x)                                            (conformer.py:356)
+    TRY(csship_layernorm(x, M, D, L.mha.ln_g, L.mha.ln_b, ws.a_bf, nullptr, stream));
+    TRY(linear(ws.a_bf, CSSHIP_A_BF16, L.mha.wqkv, L.mha.bqkv, nullptr, ws.qkv_bf, M, 3 * D, D, D, D, BF, 0.f,
+               nullptr, nullptr, stream));
+    TRY(csship_mha_relpos(ws.qkv_bf, w->pe_k, ws.ao_bf, B, T, w->n_head, w->maxlen, stream));
+    TRY(linear(ws.ao_bf, CSSHIP_A_BF16, L.mha.wo, L.mha.bo, x, x, M, D, D, D, D, CSSHIP_EPI_RESIDUAL, 1.f, nullptr,
+               nullptr, stream));
+    // x += Conv(x)                                           (conformer.py:357)
+    TRY(csship_convmod(x, y, &L.conv, B, T, D, w->kernel_size, w->bn_mode, ws.conv_ws, stream));
+    { float* t = x; x = y; y = t; }
+    // x = LN(x + 0.5 * FFN_out(x))                           (conformer.py:358-360)
+    TRY(csship_layernorm(x, M, D, L.ffn_out.ln_g, L.ffn_out.ln_b, ws.a_bf, nullptr, stream));
+    TRY(linear(ws.a_bf, CSSHIP_A_BF16, L.ffn_out.w1, L.ffn_out.b1, nullptr, ws.h_bf, M, FF, D, D, D,
+               CSSHIP_EPI_RELU | BF, 0.f, nullptr, nullptr, stream));
+    TRY(linear(ws.h_bf, CSSHIP_A_BF16, L.ffn_out.w2, L.ffn_out.b2, x, x, M, D, FF, FF, FF,
+               CSSHIP_EPI_RESIDUAL | CSSHIP_EPI_LAYERNORM, 0.5f, L.ln_g, L.ln_b, stream));
+  }
+  if (enc_out) {
+    if (hipMemcpyAsync(enc_out, x, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream)) !=
+        hipSuccess)
+      return CSSHIP_ELAUNCH;
+  }
+  // mask head: ReLU(Linear(d_model -> num_bins*(K+1)))         (conformer.py:98-100)
+  TRY(linear(x, CSSHIP_A_F32, w->head_w, w->head_b, nullptr, masks, M, w->n_out, D, D, D, CSSHIP_EPI_RELU, 0.f,
+             nullptr, nullptr, stream));
+  return CSSHIP_OK;
+}
+
+// ---- not built yet in this revision (declared in include/csship.h; fail loudly)
+extern "C" int csship_ipd(const float*, const float*, int64_t, int64_t, int64_t, const int32_t*, const int32_t*,
+                          int32_t, float*, int64_t, int64_t, float*, csship_stream_t) {
+  return CSSHIP_EUNSUPPORTED;
+}
+extern "C" int csship_istft(const float*, const float*, int64_t, int64_t, int64_t, float*, csship_stream_t) {
+  return CSSHIP_EUNSUPPORTED;
+}

@@ -1,0 +1,245 @@
+// Fused mask application + permutation-invariant MSE (css/objectives/pit.py:5-62 looped over
+// the batch as css/objectives/mse.py:31-37 does, with y_pred = mask_k * f_orig of
+// css/models/conformer.py:103 formed on the fly).
+//
+// The reference evaluates K! permutations with K!*B tiny mse_loss launches.  Every candidate
+// is a sum of entries of the K x K pairwise squared-error matrix
+//     D[b][k][j] = sum_{t,f} (mask_k f_orig - target_j)^2 ,
+// so one bandwidth-bound pass computes D (per-thread accumulators -> wave shuffle -> LDS ->
+// one partial per workgroup, no atomics: bitwise reproducible), and a finalize kernel takes
+// the minimum over permutations, the batch mean and the arg-min permutation.
+#include "common.hpp"
+
+namespace {
+
+constexpr int CHUNK = 4096;  // elements of one sample's T*F handled per workgroup
+constexpr int MAXK = 4;
+
+struct PitArgs {
+  const float* masks;
+  const float* f;
+  const float* tgt[MAXK];
+  float* y_pred;
+  float* partial;  // [B][nchunk][K*K]
+  int64_t ld_mask, ld_f;
+  int T, F, nchunk;
+};
+
+template <int K>
+__global__ __launch_bounds__(256) void pit_sse_kernel(PitArgs a) {
+  __shared__ float red[4][K * K];
+  const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const int TF = a.T * a.F;
+  float acc[K][K];
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int j = 0; j < K; ++j) acc[k][j] = 0.f;
+  const int e0 = chunk * CHUNK;
+#pragma unroll 4
+  for (int i = 0; i < CHUNK / 256; ++i) {
+    const int e = e0 + i * 256 + tid;
+    if (e < TF) {
+      const int t = e / a.F, f = e - t * a.F;
+      const size_t row = (size_t)b * a.T + t;
+      const float fo = a.f[row * a.ld_f + f];
+      float y[K], tg[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        y[k] = a.masks[row * a.ld_mask + k * a.F + f] * fo;
+        tg[k] = a.tgt[k][(size_t)b * TF + e];
+        if (a.y_pred) a.y_pred[((size_t)b * K + k) * TF + e] = y[k];
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          const float d = y[k] - tg[j];
+          acc[k][j] += d * d;
+        }
+    }
+  }
+  const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const float s = wave_sum(acc[k][j]);
+      if (lane == 0) red[w][k * K + j] = s;
+    }
+  __syncthreads();
+  if (tid < K * K)
+    a.partial[((size_t)b * a.nchunk + chunk) * (K * K) + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+// One thread per sample reduces its partials (double), scans the K! permutations in
+// itertools.permutations order (first minimum wins, like torch.min), then thread 0 averages.
+template <int K>
+__global__ void pit_finalize_kernel(const float* __restrict__ partial, int B, int nchunk, double norm,
+                                    float* __restrict__ loss, int* __restrict__ perm_out,
+                                    float* __restrict__ pair_sse, float* __restrict__ per_sample) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) {
+    double Dm[K][K];
+    for (int k = 0; k < K; ++k)
+      for (int j = 0; j < K; ++j) Dm[k][j] = 0.0;
+    for (int c = 0; c < nchunk; ++c)
+      for (int k = 0; k < K; ++k)
+        for (int j = 0; j < K; ++j) Dm[k][j] += (double)partial[((size_t)b * nchunk + c) * (K * K) + k * K + j];
+    if (pair_sse)
+      for (int k = 0; k < K; ++k)
+        for (int j = 0; j < K; ++j) pair_sse[(size_t)b * K * K + k * K + j] = (float)Dm[k][j];
+    // lexicographic permutations of 0..K-1
+    int p[K], best_p[K];
+    for (int i = 0; i < K; ++i) p[i] = i;
+    float best = 0.f;
+    bool first = true;
+    while (true) {
+      double s = 0.0;
+      for (int i = 0; i < K; ++i) s += Dm[p[i]][i];
+      const float cand = (float)(s / norm);  // candidates are float32 in the reference
+      if (first || cand < best) {
+        best = cand;
+        for (int i = 0; i < K; ++i) best_p[i] = p[i];
+        first = false;
+      }
+      int i = K - 2;
+      while (i >= 0 && p[i] > p[i + 1]) --i;
+      if (i < 0) break;
+      int j = K - 1;
+      while (p[j] < p[i]) --j;
+      int tmp = p[i]; p[i] = p[j]; p[j] = tmp;
+      for (int l = i + 1, r = K - 1; l < r; ++l, --r) { tmp = p[l]; p[l] = p[r]; p[r] = tmp; }
+    }
+    per_sample[b] = best;
+    if (perm_out)
+      for (int i = 0; i < K; ++i) perm_out[(size_t)b * K + i] = best_p[i];
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // single block launch: per_sample is complete after the barrier
+    double s = 0.0;
+    for (int i = 0; i < B; ++i) s += (double)per_sample[i];
+    *loss = (float)(s / (double)B);
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void pit_bwd_kernel(const float* __restrict__ masks, int64_t ld_mask,
+                                                      const float* __restrict__ f, int64_t ld_f, PitArgs a,
+                                                      const int* __restrict__ perm, int n_masks, float coef,
+                                                      float* __restrict__ grad) {
+  const int b = blockIdx.y;
+  const int TF = a.T * a.F;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= TF) return;
+  const int t = e / a.F, ff = e - t * a.F;
+  const size_t row = (size_t)b * a.T + t;
+  const float fo = f[row * ld_f + ff];
+  // perm[b][i] = estimate matched to target i  ->  estimate k is compared with target inv[k]
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const int k = perm[(size_t)b * K + i];
+    const float y = masks[row * ld_mask + k * a.F + ff] * fo;
+    grad[row * ld_mask + k * a.F + ff] = coef * (y - a.tgt[i][(size_t)b * TF + e]) * fo;
+  }
+  for (int k = K; k < n_masks; ++k) grad[row * ld_mask + k * a.F + ff] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void apply_masks_kernel(const float* __restrict__ masks, int64_t ld_mask,
+                                                          const float* __restrict__ f, int64_t ld_f, int T, int F,
+                                                          int K, float* __restrict__ y) {
+  const int b = blockIdx.y;
+  const int TF = T * F;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= TF) return;
+  const int t = e / F, ff = e - t * F;
+  const size_t row = (size_t)b * T + t;
+  const float fo = f[row * ld_f + ff];
+  for (int k = 0; k < K; ++k) y[((size_t)b * K + k) * TF + e] = masks[row * ld_mask + k * F + ff] * fo;
+}
+
+}  // namespace
+
+extern "C" size_t csship_pit_workspace(int32_t B, int32_t T, int32_t F, int32_t K) {
+  const size_t nchunk = ((size_t)T * F + CHUNK - 1) / CHUNK;
+  return ((size_t)B * nchunk * K * K + (size_t)B) * sizeof(float);
+}
+
+extern "C" int csship_pit_mse(const float* masks, int64_t ld_mask, const float* f_orig, int64_t ld_f,
+                              const float* const* targets_host, int32_t B, int32_t T, int32_t F, int32_t K,
+                              float* y_pred, float* loss, int32_t* perm, float* pair_sse, void* workspace,
+                              csship_stream_t stream) {
+  if (!masks || !f_orig || !targets_host || !loss || !workspace) return CSSHIP_ENULL;
+  if (B <= 0 || T <= 0 || F <= 0 || B > 65535 || (int64_t)T * F > 0x7fffffff) return CSSHIP_EBADSHAPE;
+  if (K < 1 || K > MAXK) return CSSHIP_EUNSUPPORTED;
+  if (ld_mask < (int64_t)K * F || ld_f < F) return CSSHIP_EBADSHAPE;
+  PitArgs a{};
+  a.masks = masks; a.f = f_orig; a.y_pred = y_pred; a.ld_mask = ld_mask; a.ld_f = ld_f; a.T = T; a.F = F;
+  for (int k = 0; k < K; ++k) {
+    if (!targets_host[k]) return CSSHIP_ENULL;
+    a.tgt[k] = targets_host[k];
+  }
+  a.nchunk = (int)(((size_t)T * F + CHUNK - 1) / CHUNK);
+  a.partial = reinterpret_cast<float*>(workspace);
+  float* per_sample = a.partial + (size_t)B * a.nchunk * K * K;
+  hipStream_t s = as_stream(stream);
+  dim3 grid(a.nchunk, B);
+  const double norm = (double)K * T * F;
+  const int fb = 1024;  // finalize: one block so the batch mean can follow a block barrier
+  if (B > fb) return CSSHIP_EUNSUPPORTED;
+#define PIT_CASE(KK)                                                                                        \
+  case KK:                                                                                                  \
+    hipLaunchKernelGGL(pit_sse_kernel<KK>, grid, dim3(256), 0, s, a);                                       \
+    CSSHIP_CHECK_LAUNCH();                                                                                  \
+    hipLaunchKernelGGL(pit_finalize_kernel<KK>, dim3(1), dim3(fb), 0, s, a.partial, B, a.nchunk, norm, loss, \
+                       perm, pair_sse, per_sample);                                                         \
+    break;
+  switch (K) {
+    PIT_CASE(1) PIT_CASE(2) PIT_CASE(3) PIT_CASE(4)
+    default: return CSSHIP_EUNSUPPORTED;
+  }
+#undef PIT_CASE
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
+extern "C" int csship_pit_mse_bwd(const float* masks, int64_t ld_mask, const float* f_orig, int64_t ld_f,
+                                  const float* const* targets_host, const int32_t* perm, int32_t B, int32_t T,
+                                  int32_t F, int32_t K, int32_t n_masks, float grad_loss, float* grad_masks,
+                                  csship_stream_t stream) {
+  if (!masks || !f_orig || !targets_host || !perm || !grad_masks) return CSSHIP_ENULL;
+  if (B <= 0 || T <= 0 || F <= 0 || B > 65535 || (int64_t)T * F > 0x7fffffff || n_masks < K) return CSSHIP_EBADSHAPE;
+  if (K < 1 || K > MAXK) return CSSHIP_EUNSUPPORTED;
+  if (ld_mask < (int64_t)n_masks * F || ld_f < F) return CSSHIP_EBADSHAPE;
+  PitArgs a{};
+  a.T = T; a.F = F;
+  for (int k = 0; k < K; ++k) {
+    if (!targets_host[k]) return CSSHIP_ENULL;
+    a.tgt[k] = targets_host[k];
+  }
+  const float coef = 2.f * grad_loss / ((float)B * (float)K * (float)T * (float)F);
+  dim3 grid((unsigned)(((size_t)T * F + 255) / 256), B);
+  hipStream_t s = as_stream(stream);
+  switch (K) {
+    case 1: hipLaunchKernelGGL(pit_bwd_kernel<1>, grid, dim3(256), 0, s, masks, ld_mask, f_orig, ld_f, a, perm, n_masks, coef, grad_masks); break;
+    case 2: hipLaunchKernelGGL(pit_bwd_kernel<2>, grid, dim3(256), 0, s, masks, ld_mask, f_orig, ld_f, a, perm, n_masks, coef, grad_masks); break;
+    case 3: hipLaunchKernelGGL(pit_bwd_kernel<3>, grid, dim3(256), 0, s, masks, ld_mask, f_orig, ld_f, a, perm, n_masks, coef, grad_masks); break;
+    case 4: hipLaunchKernelGGL(pit_bwd_kernel<4>, grid, dim3(256), 0, s, masks, ld_mask, f_orig, ld_f, a, perm, n_masks, coef, grad_masks); break;
+    default: return CSSHIP_EUNSUPPORTED;
+  }
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
+extern "C" int csship_apply_masks(const float* masks, int64_t ld_mask, const float* f_orig, int64_t ld_f, int32_t B,
+                                  int32_t T, int32_t F, int32_t K, float* y_pred, csship_stream_t stream) {
+  if (!masks || !f_orig || !y_pred) return CSSHIP_ENULL;
+  if (B <= 0 || T <= 0 || F <= 0 || K <= 0 || B > 65535 || (int64_t)T * F > 0x7fffffff) return CSSHIP_EBADSHAPE;
+  if (ld_mask < (int64_t)K * F || ld_f < F) return CSSHIP_EBADSHAPE;
+  dim3 grid((unsigned)(((size_t)T * F + 255) / 256), B);
+  hipLaunchKernelGGL(apply_masks_kernel, grid, dim3(256), 0, as_stream(stream), masks, ld_mask, f_orig, ld_f, T, F, K,
+                     y_pred);
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}

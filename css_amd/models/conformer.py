@@ -1,0 +1,242 @@
+"""Conformer mask estimator -- drop-in for css.models.conformer.Conformer (conformer.py:24-104).
+
+Same constructor / ``add_args`` / ``build_model`` / ``state_dict`` keys and shapes as the
+reference (so ``{e}.mdl`` checkpoints load), same ``forward(f) -> (y_pred, masks)`` contract.
+The sub-modules below are only PARAMETER CONTAINERS: nothing here calls a torch op on the
+hot path.  ``forward`` hands raw device pointers to ``csship_conformer_forward``
+(css_amd/csrc/forward.hip), which enqueues the hand-written HIP kernels.
+
+Deviations from the reference, all deliberate and documented in DESIGN.md:
+  * dropout is not applied (the forward equals the reference with dropout_rate = 0; eval
+    mode is bit-for-bit the same function);
+  * ``self.training`` selects BatchNorm batch statistics, running statistics are not updated;
+  * for ``idim != num_bins`` (7-channel IPD features) the reference's ``m * f_orig`` raises a
+    shape error (conformer.py:103); here the masks multiply the first ``num_bins`` feature
+    columns (the magnitude part);
+  * ``--conformer-relative-pos-emb`` is parsed with a real boolean parser.
+"""
+import ctypes as C
+
+import torch
+from torch import nn
+
+from .. import _lib, ops
+
+DEFAULT_CONFORMER_CONF = {
+    "attention_dim": 256,
+    "attention_heads": 4,
+    "linear_units": 1024,
+    "num_blocks": 16,
+    "kernel_size": 33,
+    "dropout_rate": 0.1,
+    "relative_pos_emb": True,
+}
+
+
+def _str2bool(v):
+    if isinstance(v, bool):
+        return v
+    return str(v).lower() not in ("0", "false", "no", "off", "")
+
+
+class _FeedForward(nn.Module):  # keys: layer_norm, net.0, net.3  (conformer.py:306-320)
+    def __init__(self, d_model, d_inner, dropout_rate):
+        super().__init__()
+        self.layer_norm = nn.LayerNorm(d_model)
+        self.net = nn.Sequential(nn.Linear(d_model, d_inner), nn.ReLU(), nn.Dropout(dropout_rate),
+                                 nn.Linear(d_inner, d_model), nn.Dropout(dropout_rate))
+
+
+class _SelfAttention(nn.Module):  # conformer.py:197-211
+    def __init__(self, n_head, n_feat):
+        super().__init__()
+        assert n_feat % n_head == 0
+        self.d_k, self.h = n_feat // n_head, n_head
+        self.layer_norm = nn.LayerNorm(n_feat)
+        self.linear_q = nn.Linear(n_feat, n_feat)
+        self.linear_k = nn.Linear(n_feat, n_feat)
+        self.linear_v = nn.Linear(n_feat, n_feat)
+        self.linear_out = nn.Linear(n_feat, n_feat)
+
+
+class _ConvModule(nn.Module):  # conformer.py:258-287
+    def __init__(self, d, kernel_size):
+        super().__init__()
+        self.layer_norm = nn.LayerNorm(d)
+        self.pw_conv_1 = nn.Conv2d(1, 2, 1, 1, 0)
+        self.dw_conv_1d = nn.Conv1d(d, d, kernel_size, 1, padding=(kernel_size - 1) // 2, groups=d)
+        self.BN = nn.BatchNorm1d(d)
+        self.pw_conv_2 = nn.Conv2d(1, 1, 1, 1, 0)
+        self.kernel_size = kernel_size
+
+
+class _EncoderLayer(nn.Module):  # conformer.py:339-346
+    def __init__(self, d_model, n_head, d_ffn, kernel_size, dropout_rate):
+        super().__init__()
+        self.feed_forward_in = _FeedForward(d_model, d_ffn, dropout_rate)
+        self.self_attn = _SelfAttention(n_head, d_model)
+        self.conv = _ConvModule(d_model, kernel_size)
+        self.feed_forward_out = _FeedForward(d_model, d_ffn, dropout_rate)
+        self.layer_norm = nn.LayerNorm(d_model)
+
+
+class _RelPos(nn.Module):  # conformer.py:169-177
+    def __init__(self, d_model, maxlen=1000):
+        super().__init__()
+        self.d_model, self.maxlen = d_model, maxlen
+        self.pe_k = nn.Embedding(2 * maxlen, d_model)
+
+
+class ConformerEncoder(nn.Module):  # conformer.py:110-150
+    def __init__(self, idim=257, attention_dim=256, attention_heads=4, linear_units=1024, num_blocks=16,
+                 kernel_size=33, dropout_rate=0.1, causal=False, relative_pos_emb=True):
+        super().__init__()
+        if causal:
+            raise NotImplementedError("causal ConvModule is never used by the reference path")
+        if not relative_pos_emb:
+            raise NotImplementedError("css_amd builds the relative-position attention only (reference default)")
+        self.embed = nn.Sequential(nn.Linear(idim, attention_dim), nn.LayerNorm(attention_dim),
+                                   nn.Dropout(dropout_rate), nn.ReLU())
+        self.pos_emb = _RelPos(attention_dim // attention_heads, 1000)
+        self.encoders = nn.Sequential(*[
+            _EncoderLayer(attention_dim, attention_heads, linear_units, kernel_size, dropout_rate)
+            for _ in range(num_blocks)])
+        self.idim, self.d_model, self.n_head = idim, attention_dim, attention_heads
+        self.d_ffn, self.kernel_size = linear_units, kernel_size
+
+
+class Conformer(nn.Module):
+    @staticmethod
+    def add_args(parser):  # conformer.py:30-41
+        parser.add_argument("--idim", type=int, default=257)
+        parser.add_argument("--num-bins", type=int, default=257)
+        parser.add_argument("--num-spk", type=int, default=2)
+        parser.add_argument("--num-noise", type=int, default=1)
+        parser.add_argument("--conformer-attention-dim", type=int, default=256)
+        parser.add_argument("--conformer-attention-heads", type=int, default=4)
+        parser.add_argument("--conformer-linear-units", type=int, default=1024)
+        parser.add_argument("--conformer-num-blocks", type=int, default=16)
+        parser.add_argument("--conformer-kernel-size", type=int, default=33)
+        parser.add_argument("--conformer-dropout-rate", type=float, default=0.1)
+        parser.add_argument("--conformer-relative-pos-emb", type=_str2bool, default=True)
+
+    @classmethod
+    def build_model(cls, conf):  # conformer.py:44-61
+        conformer_conf = {
+            "attention_dim": int(conf["conformer_attention_dim"]),
+            "attention_heads": int(conf["conformer_attention_heads"]),
+            "linear_units": int(conf["conformer_linear_units"]),
+            "num_blocks": int(conf["conformer_num_blocks"]),
+            "kernel_size": int(conf["conformer_kernel_size"]),
+            "dropout_rate": float(conf["conformer_dropout_rate"]),
+            "relative_pos_emb": _str2bool(conf["conformer_relative_pos_emb"]),
+        }
+        return cls(in_features=conf["idim"], num_bins=conf["num_bins"], num_spk=conf["num_spk"],
+                   num_noise=conf["num_noise"], conformer_conf=conformer_conf)
+
+    def __init__(self, in_features=257, num_bins=257, num_spk=2, num_noise=1, conformer_conf=DEFAULT_CONFORMER_CONF):
+        super().__init__()
+        self.conformer = ConformerEncoder(in_features, **conformer_conf)
+        self.num_bins, self.num_spk, self.num_noise = num_bins, num_spk, num_noise
+        self.linear = nn.Linear(conformer_conf["attention_dim"], num_bins * (num_spk + num_noise))
+        self._packed = None
+        self._packed_key = None
+        self._workspace = None
+
+    # ------------------------------------------------------------------ weight packing
+    def _pack_key(self):
+        return (self.training,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def _pack(self):
+        """bf16 shadow copies of the GEMM weights + the pointer table csship_conformer_forward reads."""
+        key = self._pack_key()
+        if self._packed is not None and key == self._packed_key:
+            return self._packed
+        enc = self.conformer
+        dev = self.linear.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("css_amd.Conformer runs on an MI355X only; move the module to 'cuda' (no CPU path)")
+        keep = []  # tensors owned by the pack (bf16 shadows, fused biases)
+
+        def own(t):
+            keep.append(t)
+            return t.data_ptr()
+
+        def f32(p):
+            t = p.detach()
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise TypeError("css_amd.Conformer expects contiguous float32 parameters")
+            return t.data_ptr()
+
+        def ffn(m):
+            w = _lib.FfnWeights()
+            w.ln_g, w.ln_b = f32(m.layer_norm.weight), f32(m.layer_norm.bias)
+            w.w1, w.b1 = own(ops.pad_weight_bf16(m.net[0].weight)), f32(m.net[0].bias)
+            w.w2, w.b2 = own(ops.pad_weight_bf16(m.net[3].weight)), f32(m.net[3].bias)
+            return w
+
+        layers = (_lib.LayerWeights * len(enc.encoders))()
+        for i, lay in enumerate(enc.encoders):
+            L = layers[i]
+            L.ffn_in, L.ffn_out = ffn(lay.feed_forward_in), ffn(lay.feed_forward_out)
+            a = lay.self_attn
+            scale = a.d_k ** -0.5  # exact power of two for d_k = 64: folds /sqrt(d_k) (conformer.py:234) into q
+            wqkv = torch.cat([a.linear_q.weight.detach() * scale, a.linear_k.weight.detach(),
+                              a.linear_v.weight.detach()], 0)
+            bqkv = torch.cat([a.linear_q.bias.detach() * scale, a.linear_k.bias.detach(),
+                              a.linear_v.bias.detach()], 0).float().contiguous()
+            L.mha.ln_g, L.mha.ln_b = f32(a.layer_norm.weight), f32(a.layer_norm.bias)
+            L.mha.wqkv, L.mha.bqkv = own(ops.pad_weight_bf16(wqkv)), own(bqkv)
+            L.mha.wo, L.mha.bo = own(ops.pad_weight_bf16(a.linear_out.weight)), f32(a.linear_out.bias)
+            c = lay.conv
+            L.conv.ln_g, L.conv.ln_b = f32(c.layer_norm.weight), f32(c.layer_norm.bias)
+            L.conv.pw1_w, L.conv.pw1_b = f32(c.pw_conv_1.weight), f32(c.pw_conv_1.bias)
+            L.conv.dw_w, L.conv.dw_b = f32(c.dw_conv_1d.weight), f32(c.dw_conv_1d.bias)
+            L.conv.bn_g, L.conv.bn_b = f32(c.BN.weight), f32(c.BN.bias)
+            L.conv.bn_mean, L.conv.bn_var = f32(c.BN.running_mean), f32(c.BN.running_var)
+            L.conv.pw2_w, L.conv.pw2_b = f32(c.pw_conv_2.weight), f32(c.pw_conv_2.bias)
+            L.ln_g, L.ln_b = f32(lay.layer_norm.weight), f32(lay.layer_norm.bias)
+
+        w = _lib.ConformerWeights()
+        w.idim, w.idim_pad = enc.idim, (enc.idim + 63) // 64 * 64
+        w.d_model, w.n_head, w.d_ffn = enc.d_model, enc.n_head, enc.d_ffn
+        w.n_layer, w.kernel_size = len(enc.encoders), enc.kernel_size
+        w.n_out, w.maxlen = self.linear.out_features, enc.pos_emb.maxlen
+        w.bn_mode = 1 if self.training else 0
+        w.embed_w, w.embed_b = own(ops.pad_weight_bf16(enc.embed[0].weight)), f32(enc.embed[0].bias)
+        w.embed_ln_g, w.embed_ln_b = f32(enc.embed[1].weight), f32(enc.embed[1].bias)
+        w.pe_k = own(enc.pos_emb.pe_k.weight.detach().to(torch.bfloat16).contiguous())
+        w.layers = C.cast(layers, C.POINTER(_lib.LayerWeights))
+        w.head_w, w.head_b = own(ops.pad_weight_bf16(self.linear.weight)), f32(self.linear.bias)
+        self._packed = (w, layers, keep)
+        self._packed_key = key
+        return self._packed
+
+    # ------------------------------------------------------------------ forward
+    def forward_masks(self, f, want_encoder_out=False):
+        """f: f32 [N,T,idim] on the GPU -> ReLU masks f32 [N,T,num_bins*(num_spk+num_noise)]."""
+        ops._need(f, torch.float32, "f")
+        if f.dim() != 3 or f.shape[2] != self.conformer.idim:
+            raise RuntimeError(f"expected [N, T, {self.conformer.idim}] features, got {tuple(f.shape)}")
+        if f.stride(2) != 1 or f.stride(0) != f.shape[1] * f.stride(1):
+            f = f.contiguous()
+        w, _layers, _keep = self._pack()
+        B, T = f.shape[0], f.shape[1]
+        need = _lib.lib().csship_conformer_workspace(C.byref(w), B, T)
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != f.device:
+            self._workspace = torch.empty(need, device=f.device, dtype=torch.uint8)
+        masks = torch.empty(B, T, w.n_out, device=f.device, dtype=torch.float32)
+        enc_out = torch.empty(B, T, w.d_model, device=f.device, dtype=torch.float32) if want_encoder_out else None
+        _lib.check(_lib.lib().csship_conformer_forward(
+            C.byref(w), ops._ptr(f), f.stride(1), B, T, ops._ptr(masks), ops._ptr(enc_out),
+            ops._ptr(self._workspace), self._workspace.numel(), ops._stream()))
+        return (masks, enc_out) if want_encoder_out else masks
+
+    def forward(self, f):
+        """f: N x T x F (or 1 x N x T x F) -> (y_pred [N,K,T,F], masks tuple of K+1 x [N,T,F])."""
+        if f.ndim == 4:
+            f = f.squeeze(0)  # conformer.py:90-91
+        m = self.forward_masks(f)
+        masks = torch.chunk(m, self.num_spk + self.num_noise, 2)  # views, noise mask last (conformer.py:101)
+        y_pred = ops.apply_masks(m, f, self.num_spk, self.num_bins)
+        return y_pred, masks

@@ -1,0 +1,256 @@
+"""Torch-tensor front door to libcsship.so.
+
+Each function validates device / dtype / shape on the host (a wrong shape must never reach a
+kernel), allocates outputs with torch's caching allocator, and enqueues the kernel on the
+current torch HIP stream.  CPU tensors are refused: there is no CPU implementation.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+NBIN = 257
+FRAME_LEN, FRAME_HOP = 512, 256
+F32_EPS = 1.1920928955078125e-07  # torch.finfo(torch.float32).eps (feature.py:9, conformer.py:21)
+NEG_INF = float("-inf")
+
+
+def _need(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"css_amd: '{name}' must be a CUDA/HIP tensor (no CPU path exists)")
+    if t.dtype != dtype:
+        raise TypeError(f"css_amd: '{name}' must be {dtype}, got {t.dtype}")
+    return t
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def num_frames(n_samples):
+    return (n_samples - FRAME_LEN) // FRAME_HOP + 1
+
+
+def stft(x, want=("mag",)):
+    """x: [B,n] or [B,D,n] f32 (last dim contiguous) -> dict of [B,(D,)T,257] tensors (TF layout)."""
+    _need(x, torch.float32, "x")
+    if x.dim() not in (2, 3):
+        raise RuntimeError(f"STFT expect 2D/3D tensor, but got {x.dim()}D signal")  # feature.py:54-59
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+    if x.dim() == 2:
+        n0, s0, n1, s1 = x.shape[0], x.stride(0), 1, 0
+    else:
+        n0, s0, n1, s1 = x.shape[0], x.stride(0), x.shape[1], x.stride(1)
+    n = x.shape[-1]
+    if n < FRAME_LEN:
+        raise RuntimeError("signal shorter than one frame")
+    if x.data_ptr() % 16 or s0 % 4 or s1 % 4:
+        x = x.contiguous()
+        if x.dim() == 2:
+            s0, s1 = x.stride(0), 0
+        else:
+            s0, s1 = x.stride(0), x.stride(1)
+        if s0 % 4 or s1 % 4:  # odd sample count: pad rows to a multiple of 4 floats
+            pad = (-n) % 4
+            x = torch.nn.functional.pad(x, (0, pad))
+            s0 = x.stride(0)
+            s1 = x.stride(1) if x.dim() == 3 else 0
+    T = num_frames(n)
+    shape = tuple(x.shape[:-1]) + (T, NBIN)
+    out = {k: torch.empty(shape, device=x.device, dtype=torch.float32) for k in want}
+    check(lib().csship_stft(_ptr(x), n0, s0, n1, s1, n, _ptr(out.get("mag")), _ptr(out.get("re")),
+                            _ptr(out.get("im")), _ptr(out.get("pha")), _stream()))
+    return out
+
+
+def mvn_stats(x, clamp_min=NEG_INF, eps=F32_EPS):
+    """x [B,T,F] (row stride may exceed F) -> (mean [B,F], rinv [B,F]) over the time axis."""
+    _need(x, torch.float32, "x")
+    B, T, F = x.shape
+    if x.stride(2) != 1 or x.stride(0) != T * x.stride(1):
+        x = x.contiguous()
+    mean = torch.empty(B, F, device=x.device, dtype=torch.float32)
+    rinv = torch.empty_like(mean)
+    check(lib().csship_mvn_stats(_ptr(x), B, T, F, x.stride(1), clamp_min, eps, _ptr(mean), _ptr(rinv), _stream()))
+    return mean, rinv
+
+
+def transpose_norm(x, mean=None, rinv=None, clamp_min=NEG_INF, out=None, f_off=0):
+    """x [B,T,F] -> out[b, f_off+f, t] = (max(x,clamp) - mean) * rinv   (out [B, Ftot, T])."""
+    _need(x, torch.float32, "x")
+    x = x.contiguous()
+    B, T, F = x.shape
+    if out is None:
+        out = torch.empty(B, F, T, device=x.device, dtype=torch.float32)
+    assert out.is_contiguous() and out.shape[0] == B and out.shape[2] == T and out.shape[1] >= f_off + F
+    check(lib().csship_transpose_norm(_ptr(x), B, T, F, F, clamp_min, _ptr(mean), _ptr(rinv), _ptr(out),
+                                      out.stride(0), f_off, _stream()))
+    return out
+
+
+def layernorm(x, gamma, beta, out_bf16=True, out_f32=False):
+    _need(x, torch.float32, "x")
+    x = x.contiguous()
+    D = x.shape[-1]
+    M = x.numel() // D
+    ob = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16) if out_bf16 else None
+    of = torch.empty_like(x) if out_f32 else None
+    check(lib().csship_layernorm(_ptr(x), M, D, _ptr(_need(gamma, torch.float32, "gamma")),
+                                 _ptr(_need(beta, torch.float32, "beta")), _ptr(ob), _ptr(of), _stream()))
+    return ob, of
+
+
+def pad_weight_bf16(w, scale_rows=None):
+    """[N,K] f32 -> bf16 [N, ceil64(K)] zero padded (the W operand layout of csship_gemm)."""
+    N, K = w.shape
+    Kp = (K + 63) // 64 * 64
+    w = w.detach().float()
+    if scale_rows is not None:
+        w = w * scale_rows[:, None]
+    out = torch.zeros(N, Kp, device=w.device, dtype=torch.bfloat16)
+    out[:, :K] = w.to(torch.bfloat16)
+    return out
+
+
+def gemm(a, w_bf16, bias=None, *, K=None, relu=False, residual=None, alpha=1.0, ln=None, out_bf16=False,
+         mvn=None, rows_per_batch=1, out=None):
+    """C = epi(A[M,K] @ W[N,K]^T + bias).  a: bf16 or f32 [M, >=K]; w_bf16: [N, ldw] zero padded."""
+    if a.dtype == torch.bfloat16:
+        _need(a, torch.bfloat16, "a")
+        mode = _lib.A_BF16
+    else:
+        _need(a, torch.float32, "a")
+        mode = _lib.A_F32_MVN if mvn is not None else _lib.A_F32
+    _need(w_bf16, torch.bfloat16, "w")
+    assert a.dim() == 2 and a.stride(1) == 1 and w_bf16.is_contiguous()
+    M = a.shape[0]
+    K = a.shape[1] if K is None else K
+    N, ldw = w_bf16.shape
+    epi = (_lib.EPI_RELU if relu else 0) | (_lib.EPI_RESIDUAL if residual is not None else 0) | \
+          (_lib.EPI_LAYERNORM if ln is not None else 0) | (_lib.EPI_OUT_BF16 if out_bf16 else 0)
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    p = _lib.GemmParams(M=M, N=N, K=K, lda=a.stride(0), ldw=ldw, ldc=out.stride(0),
+                        ldr=residual.stride(0) if residual is not None else N, a_mode=mode, epilogue=epi,
+                        rows_per_batch=rows_per_batch, alpha=alpha)
+    check(lib().csship_gemm(_ptr(a), _ptr(w_bf16), _ptr(bias), _ptr(residual), _ptr(out),
+                            _ptr(mvn[0]) if mvn else None, _ptr(mvn[1]) if mvn else None,
+                            _ptr(ln[0]) if ln else None, _ptr(ln[1]) if ln else None, C.byref(p), _stream()))
+    return out
+
+
+def mha_relpos(qkv, pe_k_bf16, n_head, maxlen=1000):
+    """qkv bf16 [B,T,3*H*64] (q pre-scaled) -> bf16 [B,T,H*64]."""
+    _need(qkv, torch.bfloat16, "qkv")
+    _need(pe_k_bf16, torch.bfloat16, "pe_k")
+    B, T, D3 = qkv.shape
+    assert qkv.is_contiguous() and pe_k_bf16.is_contiguous()
+    assert D3 == 3 * n_head * 64 and tuple(pe_k_bf16.shape) == (2 * maxlen, 64)
+    out = torch.empty(B, T, n_head * 64, device=qkv.device, dtype=torch.bfloat16)
+    check(lib().csship_mha_relpos(_ptr(qkv), _ptr(pe_k_bf16), _ptr(out), B, T, n_head, maxlen, _stream()))
+    return out
+
+
+def conv_weights_struct(t):
+    """t: dict of f32 CUDA tensors keyed like _lib.ConvWeights fields."""
+    cw = _lib.ConvWeights()
+    for name, _ in _lib.ConvWeights._fields_:
+        v = t.get(name)
+        setattr(cw, name, v.data_ptr() if v is not None else None)
+    return cw
+
+
+def convmod(x, weights, kernel_size=33, batch_stats=False):
+    """x f32 [B,T,D] -> x + ConvModule(x).  weights: dict for conv_weights_struct."""
+    _need(x, torch.float32, "x")
+    x = x.contiguous()
+    B, T, D = x.shape
+    y = torch.empty_like(x)
+    cw = conv_weights_struct(weights)
+    ws = None
+    if batch_stats:
+        ws = torch.empty(lib().csship_convmod_workspace(B, T, D), device=x.device, dtype=torch.uint8)
+    check(lib().csship_convmod(_ptr(x), _ptr(y), C.byref(cw), B, T, D, kernel_size, 1 if batch_stats else 0,
+                               _ptr(ws), _stream()))
+    return y
+
+
+def _targets_array(targets, B, T, F):
+    arr = (C.c_void_p * len(targets))()
+    keep = []
+    for i, t in enumerate(targets):
+        _need(t, torch.float32, f"target{i}")
+        if tuple(t.shape) != (B, T, F):
+            raise AssertionError(f"{tuple(t.shape)} != {(B, T, F)}")  # mse.py:29 / pit.py:46
+        t = t.contiguous()
+        keep.append(t)
+        arr[i] = t.data_ptr()
+    return arr, keep
+
+
+def pit_mse(masks, f_orig, targets, want_y_pred=False, want_pairs=False):
+    """Fused mask-apply + PIT-MSE.  masks f32 [B,T,>=K*F]; f_orig f32 [B,T,>=F]; targets: K x [B,T,F].
+
+    Returns (loss 0-dim, perm int32 [B,K], y_pred or None, pair_sse or None).
+    """
+    _need(masks, torch.float32, "masks")
+    _need(f_orig, torch.float32, "f_orig")
+    K = len(targets)
+    B, T, F = targets[0].shape
+    assert masks.stride(2) == 1 and masks.stride(0) == T * masks.stride(1) and masks.shape[:2] == (B, T)
+    assert f_orig.stride(2) == 1 and f_orig.stride(0) == T * f_orig.stride(1) and f_orig.shape[:2] == (B, T)
+    arr, keep = _targets_array(targets, B, T, F)
+    dev = masks.device
+    loss = torch.empty((), device=dev, dtype=torch.float32)
+    perm = torch.empty(B, K, device=dev, dtype=torch.int32)
+    y_pred = torch.empty(B, K, T, F, device=dev, dtype=torch.float32) if want_y_pred else None
+    pairs = torch.empty(B, K, K, device=dev, dtype=torch.float32) if want_pairs else None
+    ws = torch.empty(lib().csship_pit_workspace(B, T, F, K), device=dev, dtype=torch.uint8)
+    check(lib().csship_pit_mse(_ptr(masks), masks.stride(1), _ptr(f_orig), f_orig.stride(1), arr, B, T, F, K,
+                               _ptr(y_pred), _ptr(loss), _ptr(perm), _ptr(pairs), _ptr(ws), _stream()))
+    return loss, perm, y_pred, pairs
+
+
+def pit_mse_bwd(masks, f_orig, targets, perm, n_masks, grad_loss=1.0):
+    K = len(targets)
+    B, T, F = targets[0].shape
+    arr, keep = _targets_array(targets, B, T, F)
+    grad = torch.empty_like(masks)
+    check(lib().csship_pit_mse_bwd(_ptr(masks), masks.stride(1), _ptr(f_orig), f_orig.stride(1), arr, _ptr(perm),
+                                   B, T, F, K, n_masks, float(grad_loss), _ptr(grad), _stream()))
+    return grad
+
+
+def apply_masks(masks, f_orig, K, F):
+    """y_pred [B,K,T,F] = masks[..., k*F:(k+1)*F] * f_orig[..., :F]."""
+    _need(masks, torch.float32, "masks")
+    _need(f_orig, torch.float32, "f_orig")
+    B, T = masks.shape[:2]
+    y = torch.empty(B, K, T, F, device=masks.device, dtype=torch.float32)
+    check(lib().csship_apply_masks(_ptr(masks), masks.stride(1), _ptr(f_orig), f_orig.stride(1), B, T, F, K,
+                                   _ptr(y), _stream()))
+    return y
+
+
+def ipd(re_tf, im_tf, index_l, index_r, out, f_off):
+    """IPD features from TF-layout spectra [B,C,T,257] into out[b, f_off + p*257 + f, t]."""
+    _need(re_tf, torch.float32, "re")
+    _need(im_tf, torch.float32, "im")
+    B, Cn, T, F = re_tf.shape
+    P = len(index_l)
+    assert re_tf.is_contiguous() and im_tf.is_contiguous() and out.is_contiguous()
+    assert all(0 <= i < Cn for i in list(index_l) + list(index_r))
+    assert out.shape[0] == B and out.shape[2] == T and out.shape[1] >= f_off + P * F
+    li = (C.c_int32 * P)(*index_l)
+    ri = (C.c_int32 * P)(*index_r)
+    ws = torch.empty(2 * B * P * F, device=re_tf.device, dtype=torch.float32)
+    check(lib().csship_ipd(_ptr(re_tf), _ptr(im_tf), B, Cn, T, li, ri, P, _ptr(out), out.stride(0), f_off,
+                           _ptr(ws), _stream()))
+    return out

@@ -1,0 +1,2 @@
+from .lr_scheduler import LRScheduler  # noqa: F401
+from .iteration_types import train_one_epoch, validate  # noqa: F401

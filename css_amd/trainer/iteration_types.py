@@ -1,0 +1,56 @@
+"""Epoch loops -- same positional signatures as css/trainer/iteration_types.py:17,67.
+
+``validate`` (forward only) runs entirely on the HIP path.  ``train_one_epoch`` keeps the
+reference's step order (forward, backward, clip, step, zero_grad, scheduler); the backward
+kernels of the encoder are not built in this revision, so with a css_amd model it stops with
+a clear error at the backward call instead of silently training nothing.
+In a multi-GPU job (torch.distributed initialised) gradients are summed across ranks with one
+flat-bucket all-reduce over RCCL before clipping (css_amd/parallel.py), replacing the
+reference's per-epoch checkpoint averaging (scripts/python/combine_models.py:55-82).
+"""
+import logging
+
+import torch
+
+from .. import parallel
+
+
+def train_one_epoch(args, generator, model, objective, optim, lr_sched, device="cpu"):
+    total_loss = 0.0
+    for i in range(1, args.batches_per_epoch + 1):
+        b = next(generator)
+        log = (f"Iter: {i} of {args.batches_per_epoch} LR:{lr_sched.curr_lr:0.5e} bsize: {b['mix'].size(0)} "
+               f"window (# frames): {b['mix'].size(1)} ovl: {b['ovl']:0.4f} ")
+        loss = objective(model, b, device=device)
+        if not loss.requires_grad:
+            raise NotImplementedError(
+                "css_amd: this revision builds the forward + PIT path only; encoder backward kernels are the "
+                "next milestone (DESIGN.md), so train_one_epoch cannot update this model yet")
+        loss_val = loss.data.item()
+        log += f"Loss: {loss_val:0.5f} "
+        total_loss += loss_val
+        loss.backward()
+        del b
+        parallel.allreduce_gradients(model.parameters())
+        grad_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), args.grad_thresh)
+        log += f"Grad_norm: {grad_norm.data.item():0.5f}"
+        logging.info(log)
+        optim.step()
+        optim.zero_grad()
+        lr_sched.step(1.0)
+    return total_loss / args.batches_per_epoch
+
+
+def validate(generator, model, objective, device="cpu", num_batches=100):
+    """100 dev batches, mean loss (iteration_types.py:67-77); the mean stays a tensor like the reference's."""
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        avg_loss = 0.0
+        for _ in range(num_batches):
+            b = next(generator)
+            avg_loss = avg_loss + objective(model, b, device=device)
+        avg_loss = avg_loss / num_batches
+    if was_training:
+        model.train()
+    return avg_loss

@@ -1,0 +1,217 @@
+/* csship.h -- C ABI of libcsship.so, the MI355X (gfx950) HIP library behind css_amd.
+ *
+ * The reference (desh2608/css) has no FFI: its hot path sits behind Python plugin
+ * registries (css/models/__init__.py:19-27, css/objectives/__init__.py:19-23) and
+ * executor classes.  This header is the build-defined boundary SURVEY.md 8(b)
+ * prescribes: one extern "C" entry per kernel family, plain pointers and sizes, no
+ * torch types.  The Python plugin (css_amd/) binds it with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name says host; the caller owns
+ *     all memory including the workspace; the library never allocates, frees or
+ *     retains device memory and never synchronises the host;
+ *   - kernels are enqueued on `stream` (a hipStream_t; NULL = default stream);
+ *   - return value 0 on success, a negative CSSHIP_E* code otherwise (never throws);
+ *   - "bf16" buffers are uint16_t holding the upper 16 bits of an IEEE float
+ *     (round-to-nearest-even);
+ *   - STFT geometry is fixed at frame_len 512 / hop 256 (conf/config_*.yaml:9-10).
+ */
+#ifndef CSSHIP_H
+#define CSSHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* csship_stream_t; /* hipStream_t */
+
+enum {
+  CSSHIP_OK = 0,
+  CSSHIP_EBADSHAPE = -1,    /* a size/stride the kernels do not support */
+  CSSHIP_EALIGN = -2,       /* pointer or stride not aligned as required */
+  CSSHIP_EUNSUPPORTED = -3, /* feature/dimension combination not built */
+  CSSHIP_ELAUNCH = -4,      /* hipGetLastError() reported a launch failure */
+  CSSHIP_ENULL = -5,        /* required pointer is NULL */
+  CSSHIP_EWORKSPACE = -6    /* workspace too small */
+};
+
+int csship_version(void);
+const char* csship_strerror(int rc);
+
+/* ------------------------------------------------------------------ features
+ * Replaces STFT.forward (css/executor/feature.py:45-82): 512-point Hann-windowed
+ * real DFT of every frame, hop 256, no centre padding, T = (n_samples-512)/256+1.
+ * Signals are addressed as audio[s0*stride0 + s1*stride1 + i], s = s0*n1 + s1, so
+ * both a dense [B,D,n] batch and the overlapping unfold() windows of
+ * css/executor/separator.py:67 are expressible without a copy.
+ * Outputs (each may be NULL) are [S, T, 257] float32, frame-major ("TF" layout). */
+int csship_stft(const float* audio, int64_t n0, int64_t stride0, int64_t n1, int64_t stride1,
+                int64_t n_samples, float* mag, float* re, float* im, float* pha,
+                csship_stream_t stream);
+
+/* Per-(batch, column) mean and 1/(unbiased std + eps) over the time axis of x[B,T,F]
+ * (row stride ldx >= F).  Replaces the statistics of css/models/conformer.py:95,
+ * css/models/blstm.py:80 and css/executor/feature.py:169-171 (clamp_min applies
+ * torch.clamp(x, min=clamp_min) first, as the feature extractor does; pass -INFINITY
+ * for no clamp). */
+int csship_mvn_stats(const float* x, int64_t B, int64_t T, int64_t F, int64_t ldx,
+                     float clamp_min, float eps, float* mean, float* rinv,
+                     csship_stream_t stream);
+
+/* out[b, f, t] = (max(x[b, t, f], clamp_min) - mean[b, f]) * rinv[b, f]   (mean/rinv NULL:
+ * plain transpose).  Converts TF layout to the reference's [B, F, T] layout
+ * (css/executor/feature.py:156-175 returns mag/f/re/im as B x F x T).  out row b has
+ * ld_out_b floats between batches and the f rows are written at row offset f_off. */
+int csship_transpose_norm(const float* x, int64_t B, int64_t T, int64_t F, int64_t ldx,
+                          float clamp_min, const float* mean, const float* rinv,
+                          float* out, int64_t out_batch_stride, int64_t f_off,
+                          csship_stream_t stream);
+
+/* Inter-channel phase difference with circular-mean removal, IPDFeature.forward
+ * (css/executor/feature.py:105-134).  re/im: [B, C, T, 257] (TF layout from csship_stft
+ * with S = B*C).  pairs_l/pairs_r: HOST arrays of n_pairs channel indices.  Writes
+ * out[b, f_off + p*257 + f, t] in the reference's [B, *, T] layout.
+ * workspace: 2*B*n_pairs*257 floats. */
+int csship_ipd(const float* re, const float* im, int64_t B, int64_t C, int64_t T,
+               const int32_t* pairs_l, const int32_t* pairs_r, int32_t n_pairs,
+               float* out, int64_t out_batch_stride, int64_t f_off, float* workspace,
+               csship_stream_t stream);
+
+/* Inverse of the centre-padded Hann STFT: torch.istft(center=True) as used at
+ * css/executor/beamformer.py:83-102.  re/im: [S, 257, T] (the reference's layout);
+ * wav: [S, length], length <= 256*(T-1). */
+int csship_istft(const float* re, const float* im, int64_t S, int64_t T, int64_t length,
+                 float* wav, csship_stream_t stream);
+
+/* ------------------------------------------------------------------ encoder pieces */
+
+/* LayerNorm over the last dim (D == 256 or 512) of x[M, D] float32 -> bf16 and/or f32. */
+int csship_layernorm(const float* x, int64_t M, int32_t D, const float* gamma, const float* beta,
+                     uint16_t* out_bf16, float* out_f32, csship_stream_t stream);
+
+/* C[M,N] = epilogue( A[M,K] @ W[N,K]^T + bias ).  bf16 MFMA, fp32 accumulate.
+ * Replaces every torch.nn.Linear on the path (css/models/conformer.py:98,124,205-209,
+ * 315-318).  W is bf16 [N, ldw] with ldw a multiple of 64 and >= K, zero padded. */
+enum { CSSHIP_A_BF16 = 0, CSSHIP_A_F32 = 1, CSSHIP_A_F32_MVN = 2 };
+enum {
+  CSSHIP_EPI_RELU = 1,     /* max(0, .) applied last */
+  CSSHIP_EPI_RESIDUAL = 2, /* v = residual + alpha * v */
+  CSSHIP_EPI_LAYERNORM = 4,/* LayerNorm over the N == 256 output row (after residual) */
+  CSSHIP_EPI_OUT_BF16 = 8  /* C is bf16 (else float32) */
+};
+typedef struct {
+  int32_t M, N, K;
+  int32_t lda, ldw, ldc, ldr; /* row strides in elements */
+  int32_t a_mode;             /* CSSHIP_A_* */
+  int32_t epilogue;           /* OR of CSSHIP_EPI_* */
+  int32_t rows_per_batch;     /* CSSHIP_A_F32_MVN: rows sharing one mean/rinv row */
+  float alpha;                /* residual scale */
+} csship_gemm_params;
+int csship_gemm(const void* A, const uint16_t* W, const float* bias, const float* residual,
+                void* C, const float* mvn_mean, const float* mvn_rinv, const float* ln_gamma,
+                const float* ln_beta, const csship_gemm_params* p, csship_stream_t stream);
+
+/* Relative-position multi-head attention core, MultiHeadedAttention.forward
+ * (css/models/conformer.py:229-253) with RelativePositionalEncoding
+ * (conformer.py:179-185) folded in:
+ *   score[i,j] = q_i . k_j + q_i . pe_k[clamp(i-j, -maxlen, maxlen-1) + maxlen]
+ * qkv: bf16 [B, T, 3*H*64] (q | k | v, q ALREADY scaled by 1/sqrt(d_k)); pe_k: bf16
+ * [2*maxlen, 64]; out: bf16 [B, T, H*64].  d_k must be 64.  The T x T x d_k table of
+ * conformer.py:159 is never materialised. */
+int csship_mha_relpos(const uint16_t* qkv, const uint16_t* pe_k, uint16_t* out, int32_t B,
+                      int32_t T, int32_t H, int32_t maxlen, csship_stream_t stream);
+
+/* ConvModule.forward + residual (css/models/conformer.py:289-303, 357):
+ *   y = x + pw2( relu( BN( dwconv_k( glu( LN(x) ) ) ) ) ),  x,y: f32 [B, T, 256].
+ * pw1_w/pw1_b: 2 floats each (Conv2d(1,2,1)), pw2_w/pw2_b: 1 float each (device).
+ * bn_mode 0: running statistics (eval).  bn_mode 1: batch statistics (train forward);
+ * needs workspace of csship_convmod_workspace() bytes and updates nothing. */
+typedef struct {
+  const float *ln_g, *ln_b;
+  const float *pw1_w, *pw1_b;
+  const float *dw_w, *dw_b; /* [D, k], [D] */
+  const float *bn_g, *bn_b, *bn_mean, *bn_var;
+  const float *pw2_w, *pw2_b;
+} csship_conv_weights;
+size_t csship_convmod_workspace(int32_t B, int32_t T, int32_t D);
+int csship_convmod(const float* x, float* y, const csship_conv_weights* w, int32_t B, int32_t T,
+                   int32_t D, int32_t kernel_size, int32_t bn_mode, void* workspace,
+                   csship_stream_t stream);
+
+/* ------------------------------------------------------------------ PIT-MSE
+ * Fused mask application + permutation-invariant MSE: pit_loss (css/objectives/pit.py:5-62)
+ * looped over the batch as MeanSquaredError.forward does (css/objectives/mse.py:31-37),
+ * with y_pred = mask_k * f_orig (css/models/conformer.py:103) formed on the fly.
+ *   masks: f32 [B, T, ld_mask] with mask k at columns [k*F, (k+1)*F)
+ *   f_orig: f32 [B, T, ld_f] (first F columns are the magnitudes)
+ *   targets: HOST array of K device pointers, each f32 [B, T, F]
+ *   y_pred (optional): f32 [B, K, T, F]
+ *   loss: 1 float (mean over batch of the per-sample minimum); perm: int32 [B, K] with
+ *   perm[b][i] = index of the estimate matched to target i (pit.py:57 convention);
+ *   workspace: csship_pit_workspace(B, T, F, K) bytes.  K <= 4. */
+size_t csship_pit_workspace(int32_t B, int32_t T, int32_t F, int32_t K);
+int csship_pit_mse(const float* masks, int64_t ld_mask, const float* f_orig, int64_t ld_f,
+                   const float* const* targets_host, int32_t B, int32_t T, int32_t F, int32_t K,
+                   float* y_pred, float* loss, int32_t* perm, float* pair_sse, void* workspace,
+                   csship_stream_t stream);
+
+/* y_pred[b,k,t,f] = masks[b,t,k*F+f] * f_orig[b,t,f], k < K  (css/models/conformer.py:103,
+ * css/models/blstm.py:87): the stacked masked spectra the model's forward returns. */
+int csship_apply_masks(const float* masks, int64_t ld_mask, const float* f_orig, int64_t ld_f,
+                       int32_t B, int32_t T, int32_t F, int32_t K, float* y_pred,
+                       csship_stream_t stream);
+
+/* d loss / d masks for the chosen permutation (hand-written backward of the op above):
+ * grad_masks[b,t,k*F+f] = 2*(m_k f - tgt_{inv(k)}) * f / (B*K*T*F) * grad_loss; columns of
+ * masks beyond K*F (noise mask) get 0. */
+int csship_pit_mse_bwd(const float* masks, int64_t ld_mask, const float* f_orig, int64_t ld_f,
+                       const float* const* targets_host, const int32_t* perm, int32_t B,
+                       int32_t T, int32_t F, int32_t K, int32_t n_masks, float grad_loss,
+                       float* grad_masks, csship_stream_t stream);
+
+/* ------------------------------------------------------------------ whole forward
+ * Conformer.forward (css/models/conformer.py:83-104) from the feature tensor to the
+ * ReLU masks, as ONE host call that enqueues every kernel (no per-op Python overhead).
+ * All weight pointers are device pointers; the structs themselves live in host memory. */
+typedef struct {
+  const float *ln_g, *ln_b;
+  const uint16_t* w1; const float* b1; /* bf16 [d_ffn, d_model], [d_ffn] */
+  const uint16_t* w2; const float* b2; /* bf16 [d_model, d_ffn], [d_model] */
+} csship_ffn_weights;
+typedef struct {
+  const float *ln_g, *ln_b;
+  const uint16_t* wqkv; const float* bqkv; /* bf16 [3*d_model, d_model] q rows pre-scaled by 1/sqrt(d_k) */
+  const uint16_t* wo; const float* bo;
+} csship_mha_weights;
+typedef struct {
+  csship_ffn_weights ffn_in;
+  csship_mha_weights mha;
+  csship_conv_weights conv;
+  csship_ffn_weights ffn_out;
+  const float *ln_g, *ln_b;
+} csship_layer_weights;
+typedef struct {
+  int32_t idim, idim_pad;  /* input feature dim and its zero-padded multiple of 64 */
+  int32_t d_model, n_head, d_ffn, n_layer, kernel_size;
+  int32_t n_out, maxlen;   /* n_out = num_bins * (num_spk + num_noise) */
+  int32_t bn_mode;         /* 0 eval, 1 batch statistics */
+  const uint16_t* embed_w; const float* embed_b; /* bf16 [d_model, idim_pad] */
+  const float *embed_ln_g, *embed_ln_b;
+  const uint16_t* pe_k;    /* bf16 [2*maxlen, d_model/n_head] */
+  const csship_layer_weights* layers; /* HOST array [n_layer] */
+  const uint16_t* head_w; const float* head_b; /* bf16 [n_out, d_model] */
+} csship_conformer_weights;
+size_t csship_conformer_workspace(const csship_conformer_weights* w, int32_t B, int32_t T);
+/* f: f32 [B, T, idim] (row stride ldf); masks: f32 [B, T, n_out]; enc_out (optional): f32
+ * [B, T, d_model] encoder output before the head. */
+int csship_conformer_forward(const csship_conformer_weights* w, const float* f, int64_t ldf,
+                             int32_t B, int32_t T, float* masks, float* enc_out, void* workspace,
+                             size_t workspace_bytes, csship_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSSHIP_H */

@@ -1,0 +1,255 @@
+"""GPU parity tests: every HIP op (called through the C ABI of libcsship.so) against the CPU
+oracle on the same seeded inputs, plus the committed golden vectors of the reference.
+
+Tolerances are stated per test.  GEMM-class ops compute in bf16 with fp32 accumulation, so
+they are checked (a) tightly against a float64 evaluation of the SAME bf16-rounded operands
+and (b) against the fp32 oracle within a bf16-sized tolerance.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from css_amd.utils import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def rnd(shape, seed, scale=1.0):
+    return torch.from_numpy((scale * np.random.RandomState(seed).standard_normal(shape)).astype(np.float32))
+
+
+def bf(x):
+    """round-trip through bf16 (what the kernels see)"""
+    return x.to(torch.bfloat16).float()
+
+
+def err(a, b):
+    return float((a.detach().double().cpu() - b.detach().double().cpu()).abs().max())
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from css_amd import ops as o
+    o.lib()  # raises if libcsship.so is missing: no fallback
+    return o
+
+
+# ----------------------------------------------------------------------------- STFT / features
+@pytest.mark.parametrize("shape", [(3, 512 + 256 * 70), (2, 3, 512 + 256 * 33), (1, 38656), (2, 512)])
+def test_stft_vs_oracle(ops, shape):
+    n = shape[-1]
+    x = rnd(shape, 5, 0.1)
+    o = ops.stft(x.to(DEV), ("mag", "re", "im", "pha"))
+    mag, pha, re, im = oracle.feature.stft(x)  # [..., F, T]
+    scale = float(mag.max())
+    # fp32 FFT vs fp32 dense DFT: both ~1e-6 relative to the spectrum scale
+    assert err(o["re"].transpose(-1, -2), re) < 2e-5 * scale
+    assert err(o["im"].transpose(-1, -2), im) < 2e-5 * scale
+    assert err(o["mag"].transpose(-1, -2), mag) < 2e-5 * scale
+    # phase only where the bin carries energy (atan2 is ill-conditioned near 0) and modulo 2 pi
+    d = o["pha"].transpose(-1, -2).cpu().double() - pha.double()
+    d = torch.atan2(torch.sin(d), torch.cos(d)).abs()
+    strong = mag > 1e-2 * scale
+    assert float(d[strong].max()) < 1e-3
+    assert o["mag"].shape[-2] == (n - 512) // 256 + 1
+
+
+def test_stft_strided_windows(ops):
+    """unfold()-style overlapping windows (separator.py:67) are read in place."""
+    rec = rnd((2, 12800 * 4 + 38656), 7, 0.1).to(DEV)
+    win = rec.unfold(-1, 38656, 12800)  # [2, W, 38656] view, stride (n, 12800, 1)
+    a = ops.stft(win, ("mag",))["mag"]
+    b = ops.stft(win.contiguous(), ("mag",))["mag"]
+    assert a.shape == (2, 5, 150, 257) and torch.equal(a, b)
+
+
+def test_feature_extractor_golden(ops, golden):
+    from css_amd.executor.feature import FeatureExtractor
+    g = golden("stft.npz")
+    mix, _ = syn.synthetic_sources(2, 512 + 256 * 19, seed=3)
+    fe = FeatureExtractor(512, 256)
+    mag, f, re, im = fe.forward(mix.to(DEV))
+    assert err(mag, torch.from_numpy(g["mag1"])) < 5e-5
+    assert err(re, torch.from_numpy(g["re1"])) < 5e-5
+    assert err(im, torch.from_numpy(g["im1"])) < 5e-5
+    assert err(f, torch.from_numpy(g["f1"])) < 5e-4
+    mixw, _ = syn.synthetic_sources(1, 38656, seed=4)
+    magw, fw, _, _ = fe.forward(mixw.to(DEV))
+    assert magw.shape == (1, 257, 150)
+    assert err(magw, torch.from_numpy(g["magw"])) < 5e-5
+    assert err(fw, torch.from_numpy(g["fw"])) < 5e-4
+
+
+def test_mvn_stats(ops):
+    x = rnd((3, 77, 257), 8).abs()
+    mean, rinv = ops.mvn_stats(x.to(DEV))
+    assert err(mean, x.mean(1)) < 1e-5
+    assert err(rinv, 1.0 / (x.std(1) + oracle.feature.EPS)) < 1e-4
+
+
+# ----------------------------------------------------------------------------- LayerNorm / GEMM
+def test_layernorm(ops):
+    x = rnd((301, 256), 9) * 2 + 0.5
+    g, b = 1 + 0.1 * rnd((256,), 10), 0.1 * rnd((256,), 11)
+    ob, of = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), out_bf16=True, out_f32=True)
+    ref = torch.nn.functional.layer_norm(x, (256,), g, b, 1e-5)
+    assert err(of, ref) < 1e-5
+    assert err(ob.float(), bf(ref)) < 2e-2  # one bf16 ulp at |y| <= 4
+
+
+def _ref_gemm(a, w, bias):
+    return (bf(a).double() @ bf(w).double().t() + bias.double()).float()
+
+
+@pytest.mark.parametrize("M", [64, 237, 1000])
+def test_gemm_bf16_relu_bf16out(ops, M):
+    a, w, bias = rnd((M, 256), 20), rnd((1024, 256), 21, 1 / 16), rnd((1024,), 22, 0.1)
+    out = ops.gemm(a.to(DEV).to(torch.bfloat16), ops.pad_weight_bf16(w.to(DEV)), bias.to(DEV), relu=True, out_bf16=True)
+    ref = torch.relu(_ref_gemm(a, w, bias))
+    assert out.dtype == torch.bfloat16 and out.shape == (M, 1024)
+    assert err(out.float(), ref) < 2e-2 * max(1.0, float(ref.abs().max()))  # bf16 output rounding
+    assert err(out.float(), bf(ref)) < 4e-2
+
+
+@pytest.mark.parametrize("M", [128, 333])
+def test_gemm_k1024_residual(ops, M):
+    a, w, bias, res = rnd((M, 1024), 23), rnd((256, 1024), 24, 1 / 32), rnd((256,), 25, 0.1), rnd((M, 256), 26)
+    out = ops.gemm(a.to(DEV).to(torch.bfloat16), ops.pad_weight_bf16(w.to(DEV)), bias.to(DEV), residual=res.to(DEV), alpha=0.5)
+    ref = res + 0.5 * _ref_gemm(a, w, bias)
+    assert err(out, ref) < 2e-4  # fp32 accumulate of identical bf16 operands
+
+
+def test_gemm_residual_layernorm_inplace(ops):
+    M = 200
+    a, w, bias, res = rnd((M, 1024), 27), rnd((256, 1024), 28, 1 / 32), rnd((256,), 29, 0.1), rnd((M, 256), 30)
+    g, b = 1 + 0.1 * rnd((256,), 31), 0.1 * rnd((256,), 32)
+    x = res.to(DEV).clone()
+    out = ops.gemm(a.to(DEV).to(torch.bfloat16), ops.pad_weight_bf16(w.to(DEV)), bias.to(DEV), residual=x, alpha=0.5,
+                   ln=(g.to(DEV), b.to(DEV)), out=x)
+    ref = torch.nn.functional.layer_norm(res + 0.5 * _ref_gemm(a, w, bias), (256,), g, b, 1e-5)
+    assert out.data_ptr() == x.data_ptr()
+    assert err(out, ref) < 5e-4
+
+
+def test_gemm_f32_a_head(ops):
+    M = 150
+    a, w, bias = rnd((M, 256), 33), rnd((771, 256), 34, 1 / 16), rnd((771,), 35, 0.1)
+    out = ops.gemm(a.to(DEV), ops.pad_weight_bf16(w.to(DEV)), bias.to(DEV), relu=True)
+    ref = torch.relu(_ref_gemm(a, w, bias))
+    assert out.shape == (M, 771)
+    assert err(out, ref) < 2e-4
+
+
+def test_gemm_embed_mvn_ln_relu(ops):
+    B, T, Fdim = 3, 50, 257
+    f = rnd((B, T, Fdim), 36).abs()
+    w, bias = rnd((256, Fdim), 37, 1 / 16), rnd((256,), 38, 0.1)
+    g, b = 1 + 0.1 * rnd((256,), 39), 0.1 * rnd((256,), 40)
+    fd = f.to(DEV)
+    mean, rinv = ops.mvn_stats(fd)
+    out = ops.gemm(fd.view(B * T, Fdim), ops.pad_weight_bf16(w.to(DEV)), bias.to(DEV), K=Fdim, relu=True,
+                   ln=(g.to(DEV), b.to(DEV)), mvn=(mean, rinv), rows_per_batch=T)
+    fn = oracle.conformer.mvn_time(f).reshape(B * T, Fdim)
+    ref = torch.relu(torch.nn.functional.layer_norm(_ref_gemm(fn, w, bias), (256,), g, b, 1e-5))
+    assert err(out, ref) < 3e-2  # bf16 rounding of the normalised input happens after a slightly different fp32 MVN
+    fp32 = torch.relu(torch.nn.functional.layer_norm(fn @ w.t() + bias, (256,), g, b, 1e-5))
+    assert float(((out.cpu() - fp32) ** 2).mean()) < 1e-4
+
+
+# ----------------------------------------------------------------------------- attention
+def _ref_attention(q, k, v, pe, maxlen=1000):
+    """q (pre-scaled), k, v: [B,H,T,64] float; pe [2*maxlen,64] -> [B,T,H*64] (float64)."""
+    B, H, T, dk = q.shape
+    pos_k = oracle.conformer.rel_pos_table(pe, T, maxlen).double()
+    s = torch.matmul(q.double(), k.double().transpose(-1, -2)) + torch.einsum("bhid,ijd->bhij", q.double(), pos_k)
+    att = torch.softmax(s, dim=-1)
+    return torch.matmul(att, v.double()).transpose(1, 2).reshape(B, T, H * dk)
+
+
+@pytest.mark.parametrize("B,T", [(2, 100), (1, 64), (3, 17), (1, 1100)])
+def test_mha_relpos(ops, B, T):
+    H = 4
+    qkv = rnd((B, T, 3 * H * 64), 41)
+    qkv[..., : H * 64] *= 0.125
+    pe = rnd((2000, 64), 42, 0.3)
+    out = ops.mha_relpos(qkv.to(DEV).to(torch.bfloat16), pe.to(DEV).to(torch.bfloat16), H)
+    qb = bf(qkv).view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    ref = _ref_attention(qb[0], qb[1], qb[2], bf(pe))
+    # P is rounded to bf16 before P.V and the output is stored in bf16: ~2^-8 relative
+    assert err(out.float(), ref) < 3e-2
+
+
+# ----------------------------------------------------------------------------- conv module
+def _conv_weights(seed):
+    full = syn.conformer_shapes(num_blocks=1)
+    pre = "conformer.encoders.0.conv."
+    shapes = {k[len(pre):]: s for k, s in full.items() if k.startswith(pre)}
+    sd = {"cv." + k: v for k, v in syn.fill_state_dict(shapes, seed).items()}
+    dev = {
+        "ln_g": sd["cv.layer_norm.weight"], "ln_b": sd["cv.layer_norm.bias"],
+        "pw1_w": sd["cv.pw_conv_1.weight"].reshape(2), "pw1_b": sd["cv.pw_conv_1.bias"],
+        "dw_w": sd["cv.dw_conv_1d.weight"].reshape(256, 33), "dw_b": sd["cv.dw_conv_1d.bias"],
+        "bn_g": sd["cv.BN.weight"], "bn_b": sd["cv.BN.bias"], "bn_mean": sd["cv.BN.running_mean"],
+        "bn_var": sd["cv.BN.running_var"], "pw2_w": sd["cv.pw_conv_2.weight"].reshape(1), "pw2_b": sd["cv.pw_conv_2.bias"],
+    }
+    return sd, {k: v.contiguous().to(DEV) for k, v in dev.items()}
+
+
+@pytest.mark.parametrize("B,T", [(2, 64), (3, 100), (1, 7)])
+@pytest.mark.parametrize("batch_stats", [False, True])
+def test_convmod(ops, B, T, batch_stats):
+    sd, dw = _conv_weights(24)
+    x = rnd((B, T, 256), 43)
+    y = ops.convmod(x.to(DEV), dw, 33, batch_stats=batch_stats)
+    ref = x + oracle.conformer.conv_module(x, sd, "cv", 33, training_bn=batch_stats)
+    assert err(y, ref) < (2e-4 if batch_stats else 5e-5)  # all-fp32 kernel
+
+
+def test_convmod_golden(ops, golden):
+    g = golden("conformer.npz")
+    sd, dw = _conv_weights(24)
+    x = rnd((2, 64, 256), 11)
+    assert err(ops.convmod(x.to(DEV), dw, 33) - x.to(DEV), torch.from_numpy(g["conv_eval"])) < 5e-5
+    assert err(ops.convmod(x.to(DEV), dw, 33, batch_stats=True) - x.to(DEV), torch.from_numpy(g["conv_trainbn"])) < 2e-4
+
+
+# ----------------------------------------------------------------------------- PIT
+@pytest.mark.parametrize("K", [2, 3])
+def test_pit_mse(ops, K):
+    B, T, F = 5, 40, 257
+    masks = rnd((B, T, (K + 1) * F), 50).abs()
+    f = rnd((B, T, F), 51).abs()
+    tg = [rnd((B, T, F), 52 + k).abs() * 0.5 for k in range(K)]
+    loss, perm, y_pred, pairs = ops.pit_mse(masks.to(DEV), f.to(DEV), [t.to(DEV) for t in tg], True, True)
+    yp = torch.stack([masks[..., k * F:(k + 1) * F] * f for k in range(K)], 1)
+    assert torch.equal(y_pred.cpu(), yp)  # same single fp32 multiply
+    ref_loss, ref_perm = oracle.pit.objective_multi(yp, torch.stack(tg, 1))
+    assert abs(float(loss) - float(ref_loss)) < 1e-6 * max(1.0, float(ref_loss))
+    assert [tuple(p) for p in perm.cpu().tolist()] == [tuple(p) for p in ref_perm]
+    for b in range(B):
+        assert err(pairs[b], oracle.pit.pairwise_sse(yp[b], torch.stack(tg, 1)[b])) < 1e-3 * float(pairs[b].max())
+    # hand-written backward vs autograd of the oracle
+    m = masks.clone().requires_grad_(True)
+    yp2 = torch.stack([m[..., k * F:(k + 1) * F] * f for k in range(K)], 1)
+    oracle.pit.objective_multi(yp2, torch.stack(tg, 1))[0].backward()
+    gm = ops.pit_mse_bwd(masks.to(DEV), f.to(DEV), [t.to(DEV) for t in tg], perm, K + 1)
+    assert err(gm, m.grad) < 1e-9 + 1e-5 * float(m.grad.abs().max())
+
+
+def test_pit_loss_api_golden(ops, golden):
+    from css_amd.objectives import pit_loss
+    g = golden("pit.npz")
+    for K in (2, 3):
+        est, tgt = rnd((K, 40, 257), 60 + K).abs(), rnd((K, 40, 257), 70 + K).abs()
+        l, p = pit_loss(est.to(DEV), tgt.to(DEV), axis=0, return_permutation=True)
+        assert abs(float(l) - float(g[f"loss_k{K}"])) < 1e-6 and list(p) == list(g[f"perm_k{K}"])
+        rot = list(range(1, K)) + [0]
+        est2 = tgt[rot] + 0.01 * rnd((K, 40, 257), 80 + K)
+        l2, p2 = pit_loss(est2.to(DEV), tgt.to(DEV), axis=0, return_permutation=True)
+        assert abs(float(l2) - float(g[f"loss_rot_k{K}"])) < 1e-7 and list(p2) == list(g[f"perm_rot_k{K}"])
+    with pytest.raises(AssertionError):
+        pit_loss(est.to(DEV), tgt[:, :10].to(DEV), axis=0)
