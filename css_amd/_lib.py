@@ -46,6 +46,7 @@ class ConformerWeights(C.Structure):
 
 A_BF16, A_F32, A_F32_MVN = 0, 1, 2
 EPI_RELU, EPI_RESIDUAL, EPI_LAYERNORM, EPI_OUT_BF16 = 1, 2, 4, 8
+PRO_LN, PRO_BF16, PRO_F32 = 0, 1, 2
 
 # name -> (restype, argtypes); mirrors include/csship.h one to one
 SIGNATURES = {
@@ -58,6 +59,8 @@ SIGNATURES = {
     "csship_istft": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p]),
     "csship_layernorm": (_i32, [_p, _i64, _i32, _p, _p, _p, _p, _p]),
     "csship_gemm": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(GemmParams), _p]),
+    "csship_ffn_fused": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _p]),
+    "csship_panel_linear": (_i32, [_p, _i32, _p, _p, _p, _p, _p, _i64, _f32, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "csship_mha_relpos": (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "csship_convmod_workspace": (_sz, [_i32, _i32, _i32]),
     "csship_convmod": (_i32, [_p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _i32, _p, _p]),

@@ -10,7 +10,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Workspace {
   float *mean, *rinv, *x0, *x1;
-  unsigned short *a_bf, *ao_bf, *h_bf, *qkv_bf;
+  unsigned short *ao_bf, *qkv_bf;
   void* conv_ws;
   size_t total;
 };
@@ -29,22 +29,11 @@ Workspace carve(const csship_conformer_weights* w, int B, int T, void* base) {
   ws.rinv = (float*)take((size_t)B * w->idim * 4);
   ws.x0 = (float*)take(M * D * 4);
   ws.x1 = (float*)take(M * D * 4);
-  ws.a_bf = (unsigned short*)take(M * D * 2);
   ws.ao_bf = (unsigned short*)take(M * D * 2);
-  ws.h_bf = (unsigned short*)take(M * (size_t)w->d_ffn * 2);
   ws.qkv_bf = (unsigned short*)take(M * 3 * D * 2);
   ws.conv_ws = w->bn_mode ? take(csship_convmod_workspace(B, T, (int)D)) : nullptr;
   ws.total = off;
   return ws;
-}
-
-int linear(const void* A, int a_mode, const unsigned short* W, const float* bias, const float* res, void* C, int M,
-           int N, int K, int lda, int ldw, int epi, float alpha, const float* ln_g, const float* ln_b,
-           csship_stream_t s) {
-  csship_gemm_params p{};
-  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = N; p.ldr = N;
-  p.a_mode = a_mode; p.epilogue = epi; p.rows_per_batch = 1; p.alpha = alpha;
-  return csship_gemm(A, W, bias, res, C, nullptr, nullptr, ln_g, ln_b, &p, s);
 }
 
 #define TRY(expr)              \
@@ -80,14 +69,13 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
                                         size_t workspace_bytes, csship_stream_t stream) {
   if (!w || !f || !masks || !workspace || !w->layers) return CSSHIP_ENULL;
   if (B <= 0 || T <= 0 || ldf < w->idim) return CSSHIP_EBADSHAPE;
-  if (w->d_model != 256 || w->d_model / w->n_head != 64 || w->kernel_size != 33 || (w->d_ffn % 64) != 0 ||
+  if (w->d_model != 256 || w->d_model / w->n_head != 64 || w->kernel_size != 33 || (w->d_ffn % 256) != 0 ||
       (w->idim_pad % 64) != 0 || w->idim_pad < w->idim)
     return CSSHIP_EUNSUPPORTED;
   if (!aligned16(workspace)) return CSSHIP_EALIGN;
   Workspace ws = carve(w, B, T, workspace);
   if (ws.total > workspace_bytes) return CSSHIP_EWORKSPACE;
   const int M = B * T, D = w->d_model, FF = w->d_ffn;
-  const int BF = CSSHIP_EPI_OUT_BF16;
 
   // input MVN over time (conformer.py:95) folded into the embed GEMM's A load
   TRY(csship_mvn_stats(f, B, T, w->idim, ldf, -INFINITY, 1.1920928955078125e-07f, ws.mean, ws.rinv, stream));
@@ -102,27 +90,20 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
   for (int l = 0; l < w->n_layer; ++l) {
     const csship_layer_weights& L = w->layers[l];
     // x += 0.5 * FFN_in(x)                                   (conformer.py:355)
-    TRY(csship_layernorm(x, M, D, L.ffn_in.ln_g, L.ffn_in.ln_b, ws.a_bf, nullptr, stream));
-    TRY(linear(ws.a_bf, CSSHIP_A_BF16, L.ffn_in.w1, L.ffn_in.b1, nullptr, ws.h_bf, M, FF, D, D, D,
-               CSSHIP_EPI_RELU | BF, 0.f, nullptr, nullptr, stream));
-    TRY(linear(ws.h_bf, CSSHIP_A_BF16, L.ffn_in.w2, L.ffn_in.b2, x, x, M, D, FF, FF, FF, CSSHIP_EPI_RESIDUAL, 0.5f,
-               nullptr, nullptr, stream));
+    TRY(csship_ffn_fused(x, x, L.ffn_in.ln_g, L.ffn_in.ln_b, L.ffn_in.w1, L.ffn_in.b1, L.ffn_in.w2, L.ffn_in.b2,
+                         nullptr, nullptr, M, D, FF, 0.5f, stream));
     // x += MHA(x)                                            (conformer.py:356)
-    TRY(csship_layernorm(x, M, D, L.mha.ln_g, L.mha.ln_b, ws.a_bf, nullptr, stream));
-    TRY(linear(ws.a_bf, CSSHIP_A_BF16, L.mha.wqkv, L.mha.bqkv, nullptr, ws.qkv_bf, M, 3 * D, D, D, D, BF, 0.f,
-               nullptr, nullptr, stream));
+    TRY(csship_panel_linear(x, CSSHIP_PRO_LN, L.mha.ln_g, L.mha.ln_b, L.mha.wqkv, L.mha.bqkv, nullptr, 0, 0.f,
+                            ws.qkv_bf, 3 * D, M, 3 * D, D, CSSHIP_EPI_OUT_BF16, stream));
     TRY(csship_mha_relpos(ws.qkv_bf, w->pe_k, ws.ao_bf, B, T, w->n_head, w->maxlen, stream));
-    TRY(linear(ws.ao_bf, CSSHIP_A_BF16, L.mha.wo, L.mha.bo, x, x, M, D, D, D, D, CSSHIP_EPI_RESIDUAL, 1.f, nullptr,
-               nullptr, stream));
+    TRY(csship_panel_linear(ws.ao_bf, CSSHIP_PRO_BF16, nullptr, nullptr, L.mha.wo, L.mha.bo, x, D, 1.f, x, D, M, D,
+                            D, CSSHIP_EPI_RESIDUAL, stream));
     // x += Conv(x)                                           (conformer.py:357)
     TRY(csship_convmod(x, y, &L.conv, B, T, D, w->kernel_size, w->bn_mode, ws.conv_ws, stream));
     { float* t = x; x = y; y = t; }
     // x = LN(x + 0.5 * FFN_out(x))                           (conformer.py:358-360)
-    TRY(csship_layernorm(x, M, D, L.ffn_out.ln_g, L.ffn_out.ln_b, ws.a_bf, nullptr, stream));
-    TRY(linear(ws.a_bf, CSSHIP_A_BF16, L.ffn_out.w1, L.ffn_out.b1, nullptr, ws.h_bf, M, FF, D, D, D,
-               CSSHIP_EPI_RELU | BF, 0.f, nullptr, nullptr, stream));
-    TRY(linear(ws.h_bf, CSSHIP_A_BF16, L.ffn_out.w2, L.ffn_out.b2, x, x, M, D, FF, FF, FF,
-               CSSHIP_EPI_RESIDUAL | CSSHIP_EPI_LAYERNORM, 0.5f, L.ln_g, L.ln_b, stream));
+    TRY(csship_ffn_fused(x, x, L.ffn_out.ln_g, L.ffn_out.ln_b, L.ffn_out.w1, L.ffn_out.b1, L.ffn_out.w2,
+                         L.ffn_out.b2, L.ln_g, L.ln_b, M, D, FF, 0.5f, stream));
   }
   if (enc_out) {
     if (hipMemcpyAsync(enc_out, x, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream)) !=
@@ -130,8 +111,8 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
       return CSSHIP_ELAUNCH;
   }
   // mask head: ReLU(Linear(d_model -> num_bins*(K+1)))         (conformer.py:98-100)
-  TRY(linear(x, CSSHIP_A_F32, w->head_w, w->head_b, nullptr, masks, M, w->n_out, D, D, D, CSSHIP_EPI_RELU, 0.f,
-             nullptr, nullptr, stream));
+  TRY(csship_panel_linear(x, CSSHIP_PRO_F32, nullptr, nullptr, w->head_w, w->head_b, nullptr, 0, 0.f, masks,
+                          w->n_out, M, w->n_out, D, CSSHIP_EPI_RELU, stream));
   return CSSHIP_OK;
 }
 

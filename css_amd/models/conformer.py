@@ -171,8 +171,8 @@ class Conformer(nn.Module):
         def ffn(m):
             w = _lib.FfnWeights()
             w.ln_g, w.ln_b = f32(m.layer_norm.weight), f32(m.layer_norm.bias)
-            w.w1, w.b1 = own(ops.pad_weight_bf16(m.net[0].weight)), f32(m.net[0].bias)
-            w.w2, w.b2 = own(ops.pad_weight_bf16(m.net[3].weight)), f32(m.net[3].bias)
+            w.w1, w.b1 = own(ops.pack_frag(m.net[0].weight)), f32(m.net[0].bias)
+            w.w2, w.b2 = own(ops.pack_frag(m.net[3].weight)), f32(m.net[3].bias)
             return w
 
         layers = (_lib.LayerWeights * len(enc.encoders))()
@@ -186,8 +186,8 @@ class Conformer(nn.Module):
             bqkv = torch.cat([a.linear_q.bias.detach() * scale, a.linear_k.bias.detach(),
                               a.linear_v.bias.detach()], 0).float().contiguous()
             L.mha.ln_g, L.mha.ln_b = f32(a.layer_norm.weight), f32(a.layer_norm.bias)
-            L.mha.wqkv, L.mha.bqkv = own(ops.pad_weight_bf16(wqkv)), own(bqkv)
-            L.mha.wo, L.mha.bo = own(ops.pad_weight_bf16(a.linear_out.weight)), f32(a.linear_out.bias)
+            L.mha.wqkv, L.mha.bqkv = own(ops.pack_frag(wqkv)), own(bqkv)
+            L.mha.wo, L.mha.bo = own(ops.pack_frag(a.linear_out.weight)), f32(a.linear_out.bias)
             c = lay.conv
             L.conv.ln_g, L.conv.ln_b = f32(c.layer_norm.weight), f32(c.layer_norm.bias)
             L.conv.pw1_w, L.conv.pw1_b = f32(c.pw_conv_1.weight), f32(c.pw_conv_1.bias)
@@ -207,7 +207,7 @@ class Conformer(nn.Module):
         w.embed_ln_g, w.embed_ln_b = f32(enc.embed[1].weight), f32(enc.embed[1].bias)
         w.pe_k = own(enc.pos_emb.pe_k.weight.detach().to(torch.bfloat16).contiguous())
         w.layers = C.cast(layers, C.POINTER(_lib.LayerWeights))
-        w.head_w, w.head_b = own(ops.pad_weight_bf16(self.linear.weight)), f32(self.linear.bias)
+        w.head_w, w.head_b = own(ops.pack_frag(self.linear.weight)), f32(self.linear.bias)
         self._packed = (w, layers, keep)
         self._packed_key = key
         return self._packed

@@ -254,3 +254,50 @@ def ipd(re_tf, im_tf, index_l, index_r, out, f_off):
     check(lib().csship_ipd(_ptr(re_tf), _ptr(im_tf), B, Cn, T, li, ri, P, _ptr(out), out.stride(0), f_off,
                            _ptr(ws), _stream()))
     return out
+
+
+def pack_frag(w):
+    """[R, K] float -> bf16 in MFMA fragment order (include/csship.h, "row-panel kernels").
+
+    Blocks [ceil(R/16)][K/32], block(rt, ks)[lane = 16*g + m][j] = W[16*rt + m][32*ks + 8*g + j].
+    """
+    R, K = w.shape
+    assert K % 32 == 0
+    Rp = (R + 15) // 16 * 16
+    wp = torch.zeros(Rp, K, device=w.device, dtype=torch.float32)
+    wp[:R] = w.detach().float()
+    wp = wp.view(Rp // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4)  # [rt, ks, g, m, j]
+    return wp.contiguous().to(torch.bfloat16).view(-1)
+
+
+def ffn_fused(x, ln, w1p, b1, w2p, b2, d_ffn, alpha=0.5, final_ln=None, out=None):
+    """out = x + alpha * FFN(LN(x)) [-> LN]; x f32 [M,256]; w1p/w2p from pack_frag."""
+    _need(x, torch.float32, "x")
+    assert x.dim() == 2 and x.is_contiguous()
+    M, D = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().csship_ffn_fused(_ptr(x), _ptr(out), _ptr(ln[0]), _ptr(ln[1]), _ptr(w1p), _ptr(b1), _ptr(w2p),
+                                 _ptr(b2), _ptr(final_ln[0]) if final_ln else None,
+                                 _ptr(final_ln[1]) if final_ln else None, M, D, d_ffn, alpha, _stream()))
+    return out
+
+
+def panel_linear(a, wp, bias, N, *, ln=None, relu=False, residual=None, alpha=1.0, out_bf16=False, out=None):
+    """out[M,N] = epi(pro(a)[M,256] @ W^T + bias); a: f32 (LN if ln given, else rounded) or bf16 [M,256]."""
+    assert a.dim() == 2 and a.is_contiguous() and a.shape[1] == 256
+    M = a.shape[0]
+    if a.dtype == torch.bfloat16:
+        pro = _lib.PRO_BF16
+    else:
+        _need(a, torch.float32, "a")
+        pro = _lib.PRO_LN if ln is not None else _lib.PRO_F32
+    epi = (_lib.EPI_RELU if relu else 0) | (_lib.EPI_RESIDUAL if residual is not None else 0) | \
+          (_lib.EPI_OUT_BF16 if out_bf16 else 0)
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    check(lib().csship_panel_linear(_ptr(a), pro, _ptr(ln[0]) if ln else None, _ptr(ln[1]) if ln else None,
+                                    _ptr(wp), _ptr(bias), _ptr(residual),
+                                    residual.stride(0) if residual is not None else 0, alpha, _ptr(out),
+                                    out.stride(0), M, N, 256, epi, _stream()))
+    return out

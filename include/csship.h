@@ -114,6 +114,34 @@ int csship_gemm(const void* A, const uint16_t* W, const float* bias, const float
                 void* C, const float* mvn_mean, const float* mvn_rinv, const float* ln_gamma,
                 const float* ln_beta, const csship_gemm_params* p, csship_stream_t stream);
 
+/* ---- row-panel kernels (css_amd/csrc/panel.hip), d_model == 256.
+ * Weights for these entry points are bf16 in MFMA FRAGMENT ORDER ("packed"): a matrix
+ * W[R, K] (R output features, K % 32 == 0) is stored as blocks [ceil(R/16)][K/32], each
+ * block 64 lanes x 8 bf16 = 1 KB with
+ *     block(rt, ks)[lane = 16*g + m][j] = W[16*rt + m][32*ks + 8*g + j]   (zero beyond R),
+ * which is exactly one wave's A-operand fragment of v_mfma_f32_16x16x32_bf16
+ * (css_amd.ops.pack_frag builds it).
+ *
+ * csship_ffn_fused: out = x + alpha * FeedForward(x), optionally followed by a LayerNorm
+ * (css/models/conformer.py:322-326 with the residuals of :355/:358 and the block-final
+ * LayerNorm of :360) as ONE kernel; x/out f32 [M, 256] (out may alias x);
+ * w1_packed from [d_ffn, 256], w2_packed from [256, d_ffn]; d_ffn % 256 == 0. */
+int csship_ffn_fused(const float* x, float* out, const float* ln_g, const float* ln_b,
+                     const uint16_t* w1_packed, const float* b1, const uint16_t* w2_packed,
+                     const float* b2, const float* final_ln_g, const float* final_ln_b,
+                     int32_t M, int32_t d_model, int32_t d_ffn, float alpha,
+                     csship_stream_t stream);
+
+/* csship_panel_linear: out[M, N] = epi( pro(a)[M, 256] @ W[N, 256]^T + bias ).
+ * prologue: LayerNorm of f32 rows (pre-LN of MultiHeadedAttention, conformer.py:222),
+ * bf16 rows as they are, or f32 rows rounded to bf16.  epilogue: OR of CSSHIP_EPI_RELU,
+ * CSSHIP_EPI_RESIDUAL (f32 residual, N % 4 == 0; out may alias it), CSSHIP_EPI_OUT_BF16. */
+enum { CSSHIP_PRO_LN = 0, CSSHIP_PRO_BF16 = 1, CSSHIP_PRO_F32 = 2 };
+int csship_panel_linear(const void* a, int32_t prologue, const float* ln_g, const float* ln_b,
+                        const uint16_t* w_packed, const float* bias, const float* residual,
+                        int64_t ldr, float alpha, void* out, int64_t ldo, int32_t M, int32_t N,
+                        int32_t d_model, int32_t epilogue, csship_stream_t stream);
+
 /* Relative-position multi-head attention core, MultiHeadedAttention.forward
  * (css/models/conformer.py:229-253) with RelativePositionalEncoding
  * (conformer.py:179-185) folded in:
@@ -178,13 +206,13 @@ int csship_pit_mse_bwd(const float* masks, int64_t ld_mask, const float* f_orig,
  * All weight pointers are device pointers; the structs themselves live in host memory. */
 typedef struct {
   const float *ln_g, *ln_b;
-  const uint16_t* w1; const float* b1; /* bf16 [d_ffn, d_model], [d_ffn] */
-  const uint16_t* w2; const float* b2; /* bf16 [d_model, d_ffn], [d_model] */
+  const uint16_t* w1; const float* b1; /* PACKED bf16 from [d_ffn, d_model]; f32 [d_ffn] */
+  const uint16_t* w2; const float* b2; /* PACKED bf16 from [d_model, d_ffn]; f32 [d_model] */
 } csship_ffn_weights;
 typedef struct {
   const float *ln_g, *ln_b;
-  const uint16_t* wqkv; const float* bqkv; /* bf16 [3*d_model, d_model] q rows pre-scaled by 1/sqrt(d_k) */
-  const uint16_t* wo; const float* bo;
+  const uint16_t* wqkv; const float* bqkv; /* PACKED bf16 from [3*d_model, d_model], q rows pre-scaled by 1/sqrt(d_k) */
+  const uint16_t* wo; const float* bo;     /* PACKED bf16 from [d_model, d_model] */
 } csship_mha_weights;
 typedef struct {
   csship_ffn_weights ffn_in;
@@ -198,11 +226,11 @@ typedef struct {
   int32_t d_model, n_head, d_ffn, n_layer, kernel_size;
   int32_t n_out, maxlen;   /* n_out = num_bins * (num_spk + num_noise) */
   int32_t bn_mode;         /* 0 eval, 1 batch statistics */
-  const uint16_t* embed_w; const float* embed_b; /* bf16 [d_model, idim_pad] */
+  const uint16_t* embed_w; const float* embed_b; /* ROW-MAJOR bf16 [d_model, idim_pad] (csship_gemm layout) */
   const float *embed_ln_g, *embed_ln_b;
   const uint16_t* pe_k;    /* bf16 [2*maxlen, d_model/n_head] */
   const csship_layer_weights* layers; /* HOST array [n_layer] */
-  const uint16_t* head_w; const float* head_b; /* bf16 [n_out, d_model] */
+  const uint16_t* head_w; const float* head_b; /* PACKED bf16 from [n_out, d_model] */
 } csship_conformer_weights;
 size_t csship_conformer_workspace(const csship_conformer_weights* w, int32_t B, int32_t T);
 /* f: f32 [B, T, idim] (row stride ldf); masks: f32 [B, T, n_out]; enc_out (optional): f32

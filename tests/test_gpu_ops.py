@@ -160,6 +160,56 @@ def test_gemm_embed_mvn_ln_relu(ops):
     assert float(((out.cpu() - fp32) ** 2).mean()) < 1e-4
 
 
+# ----------------------------------------------------------------------------- row-panel kernels
+def _ln_ref(x, g, b):
+    return torch.nn.functional.layer_norm(x, (256,), g, b, 1e-5)
+
+
+@pytest.mark.parametrize("M", [64, 200, 1000])
+@pytest.mark.parametrize("final_ln", [False, True])
+def test_ffn_fused(ops, M, final_ln):
+    x = rnd((M, 256), 90) * 1.5
+    g, b = 1 + 0.1 * rnd((256,), 91), 0.1 * rnd((256,), 92)
+    w1, b1 = rnd((1024, 256), 93, 1 / 16), rnd((1024,), 94, 0.1)
+    w2, b2 = rnd((256, 1024), 95, 1 / 32), rnd((256,), 96, 0.1)
+    fg, fb = 1 + 0.1 * rnd((256,), 97), 0.1 * rnd((256,), 98)
+    d = lambda t: t.to(DEV)  # noqa: E731
+    xd = d(x).clone()
+    out = ops.ffn_fused(xd, (d(g), d(b)), ops.pack_frag(d(w1)), d(b1), ops.pack_frag(d(w2)), d(b2), 1024, 0.5,
+                        final_ln=(d(fg), d(fb)) if final_ln else None, out=xd)  # in place, like the encoder
+    h = bf(torch.relu(_ref_gemm(_ln_ref(x, g, b), w1, b1)))
+    ref = x + 0.5 * _ref_gemm(h, w2, b2)
+    if final_ln:
+        ref = _ln_ref(ref, fg, fb)
+    assert out.data_ptr() == xd.data_ptr()
+    assert err(out, ref) < 2e-3  # same bf16 roundings as the kernel; fp32 accumulation order differs
+    fp32 = x + 0.5 * (torch.relu(_ln_ref(x, g, b) @ w1.t() + b1) @ w2.t() + b2)
+    if final_ln:
+        fp32 = _ln_ref(fp32, fg, fb)
+    assert float(((out.cpu() - fp32) ** 2).mean()) < 1e-4
+
+
+@pytest.mark.parametrize("M,N", [(130, 768), (64, 256), (333, 771)])
+def test_panel_linear(ops, M, N):
+    x = rnd((M, 256), 100) * 1.5
+    g, b = 1 + 0.1 * rnd((256,), 101), 0.1 * rnd((256,), 102)
+    w, bias = rnd((N, 256), 103, 1 / 16), rnd((N,), 104, 0.1)
+    d = lambda t: t.to(DEV)  # noqa: E731
+    wp = ops.pack_frag(d(w))
+    # LN prologue, bf16 out (QKV projection)
+    out = ops.panel_linear(d(x), wp, d(bias), N, ln=(d(g), d(b)), out_bf16=True)
+    ref = _ref_gemm(_ln_ref(x, g, b), w, bias)
+    assert out.shape == (M, N) and err(out.float(), bf(ref)) < 4e-2
+    # f32 prologue + ReLU, f32 out (mask head; odd N exercises the scalar-store tail)
+    out = ops.panel_linear(d(x), wp, d(bias), N, relu=True)
+    assert err(out, torch.relu(_ref_gemm(x, w, bias))) < 5e-4
+    if N == 256:  # bf16 prologue + residual in place (attention output projection)
+        a = rnd((M, 256), 105)
+        res = d(x).clone()
+        out = ops.panel_linear(d(a).to(torch.bfloat16), wp, d(bias), N, residual=res, alpha=1.0, out=res)
+        assert err(out, x + _ref_gemm(a, w, bias)) < 5e-4
+
+
 # ----------------------------------------------------------------------------- attention
 def _ref_attention(q, k, v, pe, maxlen=1000):
     """q (pre-scaled), k, v: [B,H,T,64] float; pe [2*maxlen,64] -> [B,T,H*64] (float64)."""
