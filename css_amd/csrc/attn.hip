@@ -5,17 +5,22 @@
 //     score[i,j] = q_i.k_j + q_i.pe[clamp(i-j,-maxlen,maxlen-1)+maxlen]      (q pre-scaled)
 //     out[i]     = softmax_j(score[i,:]) @ v
 //
-// Layout of the computation (one 256-thread workgroup = 4 waves per (b, h, 64 queries);
-// wave w owns 16 queries):
+// One 256-thread workgroup = 4 waves per (b, h, 64 queries); wave w owns 16 queries.
 //   * everything is computed TRANSPOSED so the softmax'd tile is already the MFMA B
 //     operand of the P.V product (no LDS round trip for P):
 //         S^T[j,i]  = K_tile[j,:]  . Q[i,:]      4 x (16 keys x 16 queries) per 64-key tile
 //         Pb^T[c,i] = PE_band[c,:] . Q[i,:]      5 x (16 rel. offsets x 16 queries)
 //         O^T[d,i] += V^T[d,j] P^T[j,i]          V^T fragments come from ds_read_b64_tr_b16
-//   * the position term only depends on i-j: for a 16-query x 64-key block the 79
-//     distinct offsets form a band c = 15 - a + jl (a = query in block, jl = key in tile);
-//     the band product is one more MFMA chain against rows of pe_k staged in LDS, then
-//     skew-read from a per-wave fp32 scratch (the "rel-shift" without a T x T x d_k table).
+//   * the position term only depends on i-j: for a 16-query x 64-key block the 79 distinct
+//     offsets form a band c = 15 - a + jl (a = query in block, jl = key in tile).  Because
+//     query blocks and key tiles start at multiples of 16, every band tile is one ALIGNED,
+//     REVERSED block of 16 consecutive pe rows; the host packs those blocks in MFMA fragment
+//     order with the clamp baked in (css_amd.ops.pack_relpos), so the band operand is a
+//     coalesced 1 KB global->VGPR load per fragment: no LDS staging, no per-element clamp.
+//     The band product is skew-read from a per-wave fp32 scratch (the "rel-shift" without a
+//     T x T x d_k table);
+//   * K/V tiles are register-prefetched one tile ahead (issue-early / write-late), V is kept
+//     in a 32-byte-group XOR swizzle that makes the transposed reads conflict free;
 //   * online softmax over key tiles; key padding mask is always None on this path
 //     (conformer.py:97), only the T tail of the last tile is masked.
 #include "common.hpp"
@@ -25,13 +30,15 @@ namespace {
 constexpr int PS = 80;  // per-wave band scratch row stride (floats)
 constexpr float LOG2E = 1.4426950408889634f;
 
+DEV int v_off(int row, int chunk) {  // 16-byte chunk of a 128-byte V row; 32-byte groups XOR (row>>1)&3
+  return row * 128 + ((((chunk >> 1) ^ ((row >> 1) & 3)) << 1) | (chunk & 1)) * 16;
+}
+
 __global__ __launch_bounds__(256) void mha_relpos_kernel(const unsigned short* __restrict__ qkv,
-                                                         const unsigned short* __restrict__ pe,
-                                                         unsigned short* __restrict__ out, int B, int T,
-                                                         int H, int maxlen) {
+                                                         const bf16x8* __restrict__ pe_packed, int q_min, int q_max,
+                                                         unsigned short* __restrict__ out, int B, int T, int H) {
   __shared__ __attribute__((aligned(16))) unsigned char sK[64 * 128];
   __shared__ __attribute__((aligned(16))) unsigned char sV[64 * 128];
-  __shared__ __attribute__((aligned(16))) unsigned char sPE[128 * 128];
   __shared__ __attribute__((aligned(16))) float sP[4 * 16 * PS];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -50,31 +57,54 @@ __global__ __launch_bounds__(256) void mha_relpos_kernel(const unsigned short* _
     qf[1] = *reinterpret_cast<const bf16x8*>(qrow + 32 + 8 * g);
   }
 
-  f32x4 o[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run = -1e30f, l_run = 0.f;
-  float* Pw = sP + w * 16 * PS;
-
-  for (int j0 = 0; j0 < T; j0 += 64) {
-    __syncthreads();  // everyone is done reading the previous tile
-    // ---- stage K and V tiles (64 keys x 64 dims) and the 128-row band of pe_k
+  // K/V staging: thread owns chunks (row = idx>>3, c = idx&7), idx = tid + 256*i
+  uint4 kreg[2], vreg[2];
+  auto load_kv = [&](int j0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int idx = tid + 256 * i, row = idx >> 3, c = idx & 7;
       const int jj = min(j0 + row, T - 1);
       const unsigned short* src = qkv + (base_b + jj) * D3 + h * 64 + c * 8;
-      *reinterpret_cast<uint4*>(sK + tile_off(row, c)) = *reinterpret_cast<const uint4*>(src + D);
-      *reinterpret_cast<uint4*>(sV + row * 128 + c * 16) = *reinterpret_cast<const uint4*>(src + 2 * D);
+      kreg[i] = *reinterpret_cast<const uint4*>(src + D);
+      vreg[i] = *reinterpret_cast<const uint4*>(src + 2 * D);
     }
-    const int rel_lo = i0 - j0 - 63;
+  };
+  auto store_kv = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = tid + 256 * i, rr = idx >> 3, c = idx & 7;
-      const int prow = min(max(rel_lo + rr, -maxlen), maxlen - 1) + maxlen;
-      *reinterpret_cast<uint4*>(sPE + tile_off(rr, c)) = *reinterpret_cast<const uint4*>(pe + (size_t)prow * 64 + c * 8);
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i, row = idx >> 3, c = idx & 7;
+      *reinterpret_cast<uint4*>(sK + tile_off(row, c)) = kreg[i];
+      *reinterpret_cast<uint4*>(sV + v_off(row, c)) = vreg[i];
     }
-    __syncthreads();
+  };
+  // band fragments of key tile j0: band tile t covers rel = 16*q + 15 - m, q = (i0w - j0)/16 - t
+  bf16x8 pf[2][5];
+  auto load_pe = [&](int j0) {
+    const int qb = (i0w - j0) / 16;  // exact: both are multiples of 16
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      const int qi = min(max(qb - t, q_min), q_max) - q_min;
+      pf[0][t] = pe_packed[((size_t)qi * 2 + 0) * 64 + lane];
+      pf[1][t] = pe_packed[((size_t)qi * 2 + 1) * 64 + lane];
+    }
+  };
+
+  f32x4 o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -1e30f, l_run = 0.f;
+  float* Pw = sP + w * 16 * PS;
+  const int q4 = n >> 2, p4 = n & 3;
+
+  load_kv(0);
+  load_pe(0);
+  store_kv();
+  __syncthreads();
+
+  for (int j0 = 0; j0 < T; j0 += 64) {
+    const bool more = j0 + 64 < T;
+    if (more) load_kv(j0 + 64);  // in flight during this tile's compute
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- S^T = K Q^T and the position band Pb^T = PE_band Q^T
     f32x4 s[4], pb[5];
@@ -89,14 +119,15 @@ __global__ __launch_bounds__(256) void mha_relpos_kernel(const unsigned short* _
         const bf16x8 a = *reinterpret_cast<const bf16x8*>(sK + tile_off(16 * t + n, ks * 4 + g));
         s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], s[t], 0, 0, 0);
       }
-#pragma unroll
-      for (int t = 0; t < 5; ++t) {
-        // band column c = 16t + m  <->  rel = (i0w - j0) + 15 - c  <->  staged row 78 + 16w - c
-        const int rr = max(78 + 16 * w - 16 * t - n, 0);
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(sPE + tile_off(rr, ks * 4 + g));
-        pb[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], pb[t], 0, 0, 0);
-      }
     }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int t = 0; t < 5; ++t) pb[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ks][t], qf[ks], pb[t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) load_pe(j0 + 64);  // next tile's band operands arrive during softmax + P.V
+    __builtin_amdgcn_sched_barrier(0);
+
     // band -> per-wave scratch Pw[query n][c], c = 16t + 4g + r
 #pragma unroll
     for (int t = 0; t < 5; ++t) *reinterpret_cast<f32x4*>(Pw + n * PS + 16 * t + 4 * g) = pb[t];
@@ -119,13 +150,14 @@ __global__ __launch_bounds__(256) void mha_relpos_kernel(const unsigned short* _
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f((m_run - m_new) * LOG2E);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+    const float mscaled = m_new * LOG2E;
     float psum = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = exp2f((s[t][r] - m_new) * LOG2E);
+        const float p = __builtin_amdgcn_exp2f(s[t][r] * LOG2E - mscaled);
         s[t][r] = p;
         psum += p;
       }
@@ -135,7 +167,6 @@ __global__ __launch_bounds__(256) void mha_relpos_kernel(const unsigned short* _
     for (int i = 0; i < 4; ++i) o[i] *= alpha;
 
     // ---- O^T += V^T P^T.  k index of the MFMA <-> key j = 32ks + 16*(e>>2) + 4g + (e&3)
-    const int q4 = n >> 2, p4 = n & 3;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 pbf;
@@ -144,16 +175,23 @@ __global__ __launch_bounds__(256) void mha_relpos_kernel(const unsigned short* _
         pbf[e] = (__bf16)s[2 * ks][e];
         pbf[4 + e] = (__bf16)s[2 * ks + 1][e];
       }
+      const int r0 = 32 * ks + 4 * g + q4, r1 = r0 + 16;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const int col_b = (16 * dt + 4 * p4) * 2;
-        const unsigned char* a0 = sV + (32 * ks + 4 * g + q4) * 128 + col_b;
-        const unsigned char* a1 = a0 + 16 * 128;
+        // 4 bf16 (8 B) at column 16dt + 4p4 of rows r0 / r1: chunk 2dt + (p4>>1), half-chunk p4&1
+        const unsigned char* a0 = sV + v_off(r0, 2 * dt + (p4 >> 1)) + (p4 & 1) * 8;
+        const unsigned char* a1 = sV + v_off(r1, 2 * dt + (p4 >> 1)) + (p4 & 1) * 8;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a1));
         const s16x8 av = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), pbf, o[dt], 0, 0, 0);
       }
+    }
+
+    if (more) {
+      __syncthreads();  // everyone is done reading this tile's K/V
+      store_kv();
+      __syncthreads();
     }
   }
 
@@ -176,13 +214,14 @@ __global__ __launch_bounds__(256) void mha_relpos_kernel(const unsigned short* _
 
 }  // namespace
 
-extern "C" int csship_mha_relpos(const uint16_t* qkv, const uint16_t* pe_k, uint16_t* out, int32_t B,
-                                 int32_t T, int32_t H, int32_t maxlen, csship_stream_t stream) {
-  if (!qkv || !pe_k || !out) return CSSHIP_ENULL;
-  if (B <= 0 || T <= 0 || H <= 0 || maxlen <= 0 || B > 65535 || H > 65535) return CSSHIP_EBADSHAPE;
-  if (!aligned16(qkv) || !aligned16(pe_k) || !aligned8(out)) return CSSHIP_EALIGN;
+extern "C" int csship_mha_relpos(const uint16_t* qkv, const uint16_t* pe_packed, int32_t q_min, int32_t q_max,
+                                 uint16_t* out, int32_t B, int32_t T, int32_t H, csship_stream_t stream) {
+  if (!qkv || !pe_packed || !out) return CSSHIP_ENULL;
+  if (B <= 0 || T <= 0 || H <= 0 || q_max < q_min || B > 65535 || H > 65535) return CSSHIP_EBADSHAPE;
+  if (!aligned16(qkv) || !aligned16(pe_packed) || !aligned8(out)) return CSSHIP_EALIGN;
   dim3 grid((T + 63) / 64, H, B);
-  hipLaunchKernelGGL(mha_relpos_kernel, grid, dim3(256), 0, as_stream(stream), qkv, pe_k, out, B, T, H, maxlen);
+  hipLaunchKernelGGL(mha_relpos_kernel, grid, dim3(256), 0, as_stream(stream), qkv,
+                     reinterpret_cast<const bf16x8*>(pe_packed), q_min, q_max, out, B, T, H);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }

@@ -95,7 +95,7 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
     // x += MHA(x)                                            (conformer.py:356)
     TRY(csship_panel_linear(x, CSSHIP_PRO_LN, L.mha.ln_g, L.mha.ln_b, L.mha.wqkv, L.mha.bqkv, nullptr, 0, 0.f,
                             ws.qkv_bf, 3 * D, M, 3 * D, D, CSSHIP_EPI_OUT_BF16, stream));
-    TRY(csship_mha_relpos(ws.qkv_bf, w->pe_k, ws.ao_bf, B, T, w->n_head, w->maxlen, stream));
+    TRY(csship_mha_relpos(ws.qkv_bf, w->pe_k, w->pe_q_min, w->pe_q_max, ws.ao_bf, B, T, w->n_head, stream));
     TRY(csship_panel_linear(ws.ao_bf, CSSHIP_PRO_BF16, nullptr, nullptr, L.mha.wo, L.mha.bo, x, D, 1.f, x, D, M, D,
                             D, CSSHIP_EPI_RESIDUAL, stream));
     // x += Conv(x)                                           (conformer.py:357)

@@ -28,73 +28,113 @@ constexpr int PANEL_BYTES = BM * DM * 2;
 
 DEV int panel_off(int row, int chunk) { return row * 512 + ((chunk ^ (row & 15)) << 4); }
 
+// Optional in-kernel phase stamps (diagnostic only; nullptr in normal operation): wave 0 of every
+// workgroup stores s_memrealtime (100 MHz) at up to 8 phase boundaries.
+unsigned long long* g_stamps = nullptr;
+DEV void stamp(unsigned long long* st, int slot) {
+  if (st != nullptr && threadIdx.x == 0) st[(size_t)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+}
+
+constexpr int PD = 4;  // weight prefetch distance in k-steps (ring of PD fragment sets per wave)
+
 // acc[t][rt] += W(tile0+t)[16 x 256] . panel^T[256 x 16 rows of tile rt]
 //   w: this lane's pointer at block (tile0, k-step 0); block (t, ks) is at w[(t*tstride + ks)*64].
-//   wq: weight fragments of k-steps 0 and 1, prefetched by the caller; on return it holds k-steps
-//   0 and 1 of the NEXT stream (wn / nstride), so the global-load pipeline never drains.
+//   wq: weight fragments of k-steps 0..PD-1, prefetched by the caller; on return it holds k-steps
+//   0..PD-1 of the NEXT stream (wn / nstride), so the global-load pipeline never drains.
+//   hipcc otherwise sinks the prefetch loads down to their first use (and waits on them at once):
+//   sched_barrier(0) pins "issue loads for k-step ks+PD" ahead of the LDS reads + MFMAs of ks.
 template <int NT>
 DEV void mma_pass(f32x4 (&acc)[NT][4], const unsigned char* panel, int n, int g, int nt, const bf16x8* w, int tstride,
-                  const bf16x8* wn, int nstride, int nnt, bf16x8 (&wq)[2][NT]) {
+                  const bf16x8* wn, int nstride, int nnt, bf16x8 (&wq)[PD][NT]) {
+  // LDS operand fragments are double buffered by hand: the reads of k-step ks+1 are issued before the
+  // MFMAs of k-step ks, so one wave alone keeps the matrix pipe fed while its reads are in flight.
+  bf16x8 xa[2][4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) xa[0][rt] = *reinterpret_cast<const bf16x8*>(panel + panel_off(rt * 16 + n, g));
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     bf16x8 wc[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) wc[t] = wq[ks & 1][t];
-    if (ks + 2 < KS) {
+    for (int t = 0; t < NT; ++t) wc[t] = wq[ks % PD][t];
+    if (ks + PD < KS) {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
-        if (t < nt) wq[ks & 1][t] = w[(size_t)(t * tstride + ks + 2) * 64];
+        if (t < nt) wq[ks % PD][t] = w[(size_t)(t * tstride + ks + PD) * 64];
     } else {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
-        if (t < nnt) wq[ks & 1][t] = wn[(size_t)(t * nstride + ks + 2 - KS) * 64];
+        if (t < nnt) wq[ks % PD][t] = wn[(size_t)(t * nstride + ks + PD - KS) * 64];
     }
-    bf16x8 xa[4];
+    if (ks + 1 < KS) {
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) xa[rt] = *reinterpret_cast<const bf16x8*>(panel + panel_off(rt * 16 + n, ks * 4 + g));
+      for (int rt = 0; rt < 4; ++rt)
+        xa[(ks + 1) & 1][rt] = *reinterpret_cast<const bf16x8*>(panel + panel_off(rt * 16 + n, (ks + 1) * 4 + g));
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
       if (t < nt) {
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[t], xa[rt], acc[t][rt], 0, 0, 0);
+        for (int rt = 0; rt < 4; ++rt)
+          acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[t], xa[ks & 1][rt], acc[t][rt], 0, 0, 0);
       }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
 template <int NT>
-DEV void prefetch2(bf16x8 (&wq)[2][NT], const bf16x8* w, int tstride, int nt) {
+DEV void prefetch_first(bf16x8 (&wq)[PD][NT], const bf16x8* w, int tstride, int nt) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
-    if (t < nt) {
-      wq[0][t] = w[(size_t)(t * tstride) * 64];
-      wq[1][t] = w[(size_t)(t * tstride + 1) * 64];
-    }
+  for (int k = 0; k < PD; ++k)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      if (t < nt) wq[k][t] = w[(size_t)(t * tstride + k) * 64];
+  __builtin_amdgcn_sched_barrier(0);
 }
 
-// ---- panel prologues (all NW waves cooperate; rows >= M are clamped, never stored later)
-template <int NW>
-DEV void load_panel_ln(unsigned char* panel, const float* x, int m0, int M, const float* gam, const float* bet, int wave,
-                       int lane) {
-  const float4 gm = *reinterpret_cast<const float4*>(gam + lane * 4);
-  const float4 bt = *reinterpret_cast<const float4*>(bet + lane * 4);
-  for (int r = wave; r < BM; r += NW) {
-    const int row = min(m0 + r, M - 1);
-    float4 v = *reinterpret_cast<const float4*>(x + (size_t)row * DM + lane * 4);
-    const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.f / DM);
-    v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
-    const float rstd = rsqrtf(wave_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) * (1.f / DM) + 1e-5f);
-    const uint2 pk = make_uint2(pack_bf2(v.x * rstd * gm.x + bt.x, v.y * rstd * gm.y + bt.y),
-                                pack_bf2(v.z * rstd * gm.z + bt.z, v.w * rstd * gm.w + bt.w));
-    *reinterpret_cast<uint2*>(panel + panel_off(r, lane >> 1) + (lane & 1) * 8) = pk;
-  }
+// ---- panel prologues.  Thread (row = tid>>3, part = tid&7) owns 32 elements of one row: float4 pieces
+// (i*8 + part), i = 0..7, so the 8 lanes of a row read one full 128-byte line per load instruction and
+// the LayerNorm statistics need only 3 shuffle steps (xor 1, 2, 4).  Requires NW*64 == 8*BM threads.
+DEV float sum8(float v) {
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  return v;
 }
-template <int NW>
-DEV void load_panel_f32(unsigned char* panel, const float* x, int m0, int M, int wave, int lane) {
-  for (int r = wave; r < BM; r += NW) {
-    const int row = min(m0 + r, M - 1);
-    const float4 v = *reinterpret_cast<const float4*>(x + (size_t)row * DM + lane * 4);
-    *reinterpret_cast<uint2*>(panel + panel_off(r, lane >> 1) + (lane & 1) * 8) =
-        make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+template <bool LN>
+DEV void load_panel_rows(unsigned char* panel, const float* x, int m0, int M, const float* gam, const float* bet,
+                         int tid) {
+  const int r = tid >> 3, part = tid & 7;
+  const int row = min(m0 + r, M - 1);
+  const float* xr = x + (size_t)row * DM;
+  float4 v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(xr + (i * 8 + part) * 4);
+  if constexpr (LN) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    const float mean = sum8(s) * (1.f / DM);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+      ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float rstd = rsqrtf(sum8(ss) * (1.f / DM) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4 gm = *reinterpret_cast<const float4*>(gam + (i * 8 + part) * 4);
+      const float4 bt = *reinterpret_cast<const float4*>(bet + (i * 8 + part) * 4);
+      v[i].x = v[i].x * rstd * gm.x + bt.x; v[i].y = v[i].y * rstd * gm.y + bt.y;
+      v[i].z = v[i].z * rstd * gm.z + bt.z; v[i].w = v[i].w * rstd * gm.w + bt.w;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c4 = i * 8 + part;  // float4 index within the row = 8-byte bf16 piece index
+    *reinterpret_cast<uint2*>(panel + panel_off(r, c4 >> 1) + (c4 & 1) * 8) =
+        make_uint2(pack_bf2(v[i].x, v[i].y), pack_bf2(v[i].z, v[i].w));
   }
 }
 template <int NW>
@@ -106,51 +146,32 @@ DEV void load_panel_bf16(unsigned char* panel, const unsigned short* a, int m0, 
   }
 }
 
-// ---- per-row LayerNorm over the 256 features held as v[t][rt][r] by the NW waves of the group.
-// Lane (g, n): rows rt*16 + n, features (wave*NT + t)*16 + 4g + r.
-template <int NW, int NT>
-DEV void row_layernorm(f32x4 (&v)[NT][4], float* red /* [NW][64] */, int wave, int g, int n, const float* gam,
-                       const float* bet, int f0) {
-  float mean[4], rstd[4];
+// ---- staged epilogue.  The transposed accumulators are parked in an fp32 LDS tile Ys[64 rows][YS]
+// (one 256-feature block per pass); after a barrier thread (row = tid>>3, part = tid&7) finishes 32
+// elements of ONE row: residual, LayerNorm statistics (in-lane sums + 3 shuffles), conversion, and
+// global stores in which the 8 lanes of a row cover whole 128-byte lines.
+constexpr int YS = 260;                // row stride in floats: 1040 B, consecutive rows shift by one 16-B slot
+constexpr int YS_BYTES = BM * YS * 4;  // 66 560 B
+
+template <int NT, bool RELU>
+DEV void park_tiles(float* ys, const f32x4 (&acc)[NT][4], int nt, int col0, int g, int n, const float4 (&bias)[NT]) {
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
+  for (int t = 0; t < NT; ++t)
+    if (t < nt) {
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-      float s = 0.f;
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float d = pass == 0 ? v[t][rt][r] : v[t][rt][r] - mean[rt];
-          s += pass == 0 ? d : d * d;
-        }
-      s += __shfl_xor(s, 16);
-      s += __shfl_xor(s, 32);
-      if (g == 0) red[wave * 64 + rt * 16 + n] = s;
+      for (int rt = 0; rt < 4; ++rt) {
+        float4 v = make_float4(acc[t][rt][0] + bias[t].x, acc[t][rt][1] + bias[t].y, acc[t][rt][2] + bias[t].z,
+                               acc[t][rt][3] + bias[t].w);
+        if constexpr (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<float4*>(ys + (rt * 16 + n) * YS + col0 + t * 16 + 4 * g) = v;
+      }
     }
-    __syncthreads();
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-      float s = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) s += red[w * 64 + rt * 16 + n];
-      s *= (1.f / DM);
-      if (pass == 0) mean[rt] = s; else rstd[rt] = rsqrtf(s + 1e-5f);
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const float4 gm = *reinterpret_cast<const float4*>(gam + f0 + t * 16 + 4 * g);
-    const float4 bt = *reinterpret_cast<const float4*>(bet + f0 + t * 16 + 4 * g);
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-      v[t][rt][0] = (v[t][rt][0] - mean[rt]) * rstd[rt] * gm.x + bt.x;
-      v[t][rt][1] = (v[t][rt][1] - mean[rt]) * rstd[rt] * gm.y + bt.y;
-      v[t][rt][2] = (v[t][rt][2] - mean[rt]) * rstd[rt] * gm.z + bt.z;
-      v[t][rt][3] = (v[t][rt][3] - mean[rt]) * rstd[rt] * gm.w + bt.w;
-    }
-  }
+}
+
+DEV float4 load_bias4(const float* bias, int f, int N) {
+  if (bias == nullptr) return make_float4(0.f, 0.f, 0.f, 0.f);
+  if (f + 3 < N) return *reinterpret_cast<const float4*>(bias + f);
+  return make_float4(f < N ? bias[f] : 0.f, f + 1 < N ? bias[f + 1] : 0.f, f + 2 < N ? bias[f + 2] : 0.f, 0.f);
 }
 
 // =============================================================================== fused FFN
@@ -165,14 +186,17 @@ struct FfnArgs {
   const float *fin_g, *fin_b;
   int M, FF;
   float alpha;
+  unsigned long long* stamps;
 };
 
 template <int NW, bool FINAL_LN>
 __global__ __launch_bounds__(NW * 64) void ffn_kernel(FfnArgs a) {
+  static_assert(NW * 64 == 8 * BM, "row phases assume 8 lanes per panel row");
   constexpr int NT = 16 / NW;  // 16-feature tiles per wave per 256-feature pass
   __shared__ __attribute__((aligned(16))) unsigned char Xs[PANEL_BYTES];
-  __shared__ __attribute__((aligned(16))) unsigned char Hs[2][PANEL_BYTES];
-  __shared__ float red[NW * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char Hraw[YS_BYTES];  // 2 hidden panels, later the Ys tile
+  unsigned char* const Hs0 = Hraw;
+  unsigned char* const Hs1 = Hraw + PANEL_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15;
   const int m0 = blockIdx.x * BM;
   const int nchunk = a.FF / DM, ks2 = a.FF / 32;
@@ -181,11 +205,13 @@ __global__ __launch_bounds__(NW * 64) void ffn_kernel(FfnArgs a) {
   // W2 chunk c -> output tiles wave*NT + t, k-steps 8c.. (tile stride FF/32 blocks)
   const bf16x8* w1s = a.w1 + (size_t)(wave * NT) * KS * 64 + lane;
   const bf16x8* w2s = a.w2 + (size_t)(wave * NT) * ks2 * 64 + lane;
-  bf16x8 wq[2][NT];
-  prefetch2<NT>(wq, w1s, KS, NT);  // in flight during the LN prologue
+  bf16x8 wq[PD][NT];
+  stamp(a.stamps, 0);
+  prefetch_first<NT>(wq, w1s + (size_t)(blockIdx.x % nchunk) * 16 * KS * 64, KS, NT);  // in flight during the LN prologue
 
-  load_panel_ln<NW>(Xs, a.x, m0, a.M, a.ln_g, a.ln_b, wave, lane);
+  load_panel_rows<true>(Xs, a.x, m0, a.M, a.ln_g, a.ln_b, tid);
   __syncthreads();
+  stamp(a.stamps, 1);
 
   f32x4 o[NT][4];
 #pragma unroll
@@ -193,58 +219,86 @@ __global__ __launch_bounds__(NW * 64) void ffn_kernel(FfnArgs a) {
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) o[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int c = 0; c < nchunk; ++c) {
+  // every workgroup walks the hidden chunks in a different rotation, so the 200 panels do not all pull
+  // the same weight lines through the same L2 channel at the same moment (the sum over chunks commutes)
+  const int rot = blockIdx.x % nchunk;
+  for (int ci = 0; ci < nchunk; ++ci) {
+    const int c = (ci + rot) % nchunk;
     f32x4 h[NT][4];
+    float4 bb[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
+      bb[t] = *reinterpret_cast<const float4*>(a.b1 + c * DM + (wave * NT + t) * 16 + 4 * g);  // ahead of the MFMA loop
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) h[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     const bf16x8* w1c = w1s + (size_t)c * 16 * KS * 64;
     const bf16x8* w2c = w2s + (size_t)c * KS * 64;
     mma_pass<NT>(h, Xs, n, g, NT, w1c, KS, w2c, ks2, NT, wq);
     // hidden = relu(h + b1) -> bf16 -> Hs[c&1][row][wave's 16*NT columns]
-    unsigned char* hs = Hs[c & 1];
+    unsigned char* hs = (ci & 1) ? Hs1 : Hs0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int hc = (wave * NT + t) * 16 + 4 * g;  // column within the chunk
-      const float4 bb = *reinterpret_cast<const float4*>(a.b1 + c * DM + hc);
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
-        const uint2 pk = make_uint2(pack_bf2(fmaxf(h[t][rt][0] + bb.x, 0.f), fmaxf(h[t][rt][1] + bb.y, 0.f)),
-                                    pack_bf2(fmaxf(h[t][rt][2] + bb.z, 0.f), fmaxf(h[t][rt][3] + bb.w, 0.f)));
+        const uint2 pk = make_uint2(pack_bf2(fmaxf(h[t][rt][0] + bb[t].x, 0.f), fmaxf(h[t][rt][1] + bb[t].y, 0.f)),
+                                    pack_bf2(fmaxf(h[t][rt][2] + bb[t].z, 0.f), fmaxf(h[t][rt][3] + bb[t].w, 0.f)));
         *reinterpret_cast<uint2*>(hs + panel_off(rt * 16 + n, hc >> 3) + (hc & 7) * 2) = pk;
       }
     }
     __syncthreads();
-    const bf16x8* w1n = (c + 1 < nchunk) ? w1c + (size_t)16 * KS * 64 : w1s;  // last: harmless re-read
+    const bf16x8* w1n = w1s + (size_t)((c + 1) % nchunk) * 16 * KS * 64;  // after the last chunk: harmless re-read
     mma_pass<NT>(o, hs, n, g, NT, w2c, ks2, w1n, KS, NT, wq);
   }
+  stamp(a.stamps, 2);
 
-  // out = x + alpha * (o + b2)  [-> LayerNorm]
-  const int f0 = wave * NT * 16;
+  // ---- epilogue: out = x + alpha * (o + b2)  [-> LayerNorm], row-wise through the Ys tile
+  const int r = tid >> 3, part = tid & 7;
+  const int row = m0 + r, rowc = min(row, a.M - 1);
+  float4 xr[8];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const float4 bb = *reinterpret_cast<const float4*>(a.b2 + f0 + t * 16 + 4 * g);
+  for (int i = 0; i < 8; ++i) xr[i] = *reinterpret_cast<const float4*>(a.x + (size_t)rowc * DM + (i * 8 + part) * 4);
+  float4 b2v[NT];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-      const int row = min(m0 + rt * 16 + n, a.M - 1);
-      const float4 xr = *reinterpret_cast<const float4*>(a.x + (size_t)row * DM + f0 + t * 16 + 4 * g);
-      o[t][rt][0] = xr.x + a.alpha * (o[t][rt][0] + bb.x);
-      o[t][rt][1] = xr.y + a.alpha * (o[t][rt][1] + bb.y);
-      o[t][rt][2] = xr.z + a.alpha * (o[t][rt][2] + bb.z);
-      o[t][rt][3] = xr.w + a.alpha * (o[t][rt][3] + bb.w);
+  for (int t = 0; t < NT; ++t) b2v[t] = *reinterpret_cast<const float4*>(a.b2 + (wave * NT + t) * 16 + 4 * g);
+  __syncthreads();  // every wave is done reading the hidden panels
+  float* ys = reinterpret_cast<float*>(Hraw);
+  park_tiles<NT, false>(ys, o, NT, wave * NT * 16, g, n, b2v);
+  __syncthreads();
+  stamp(a.stamps, 3);
+  float4 v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float4 y = *reinterpret_cast<const float4*>(ys + r * YS + (i * 8 + part) * 4);
+    v[i] = make_float4(xr[i].x + a.alpha * y.x, xr[i].y + a.alpha * y.y, xr[i].z + a.alpha * y.z, xr[i].w + a.alpha * y.w);
+  }
+  if constexpr (FINAL_LN) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    const float mean = sum8(s) * (1.f / DM);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+      ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float rstd = rsqrtf(sum8(ss) * (1.f / DM) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4 gm = *reinterpret_cast<const float4*>(a.fin_g + (i * 8 + part) * 4);
+      const float4 bt = *reinterpret_cast<const float4*>(a.fin_b + (i * 8 + part) * 4);
+      v[i].x = v[i].x * rstd * gm.x + bt.x; v[i].y = v[i].y * rstd * gm.y + bt.y;
+      v[i].z = v[i].z * rstd * gm.z + bt.z; v[i].w = v[i].w * rstd * gm.w + bt.w;
     }
   }
-  if constexpr (FINAL_LN) row_layernorm<NW, NT>(o, red, wave, g, n, a.fin_g, a.fin_b, f0);
+  stamp(a.stamps, 4);
+  if (row < a.M) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-      const int row = m0 + rt * 16 + n;
-      if (row < a.M)
-        *reinterpret_cast<float4*>(a.out + (size_t)row * DM + f0 + t * 16 + 4 * g) =
-            make_float4(o[t][rt][0], o[t][rt][1], o[t][rt][2], o[t][rt][3]);
-    }
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(a.out + (size_t)row * DM + (i * 8 + part) * 4) = v[i];
+  }
+  stamp(a.stamps, 5);
 }
 
 // =============================================================================== panel linear
@@ -258,84 +312,103 @@ struct LinArgs {
   int M, N;
   int64_t ldo, ldr;
   float alpha;
+  unsigned long long* stamps;
 };
 
 template <int NW, int PRO, int EPI>
 __global__ __launch_bounds__(NW * 64) void panel_linear_kernel(LinArgs a) {
+  static_assert(NW * 64 == 8 * BM, "row phases assume 8 lanes per panel row");
   constexpr int NT = 16 / NW;
+  constexpr bool RELU = (EPI & CSSHIP_EPI_RELU) != 0, RES = (EPI & CSSHIP_EPI_RESIDUAL) != 0,
+                 OBF = (EPI & CSSHIP_EPI_OUT_BF16) != 0;
   __shared__ __attribute__((aligned(16))) unsigned char Xs[PANEL_BYTES];
+  __shared__ __attribute__((aligned(16))) float Ys[BM * YS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15;
   const int m0 = blockIdx.x * BM;
   const int ntiles = (a.N + 15) / 16;
-  const int tpw = (ntiles + NW - 1) / NW;  // contiguous tile range per wave
-  const int tbeg = wave * tpw, tend = min(tbeg + tpw, ntiles);
+  const int npass = (ntiles + 15) / 16;  // each pass: the workgroup covers 256 consecutive features
 
-  bf16x8 wq[2][NT];
+  bf16x8 wq[PD][NT];
   const bf16x8* wbase = a.w + lane;
-  {
-    const int nt0 = max(0, min(NT, tend - tbeg));
-    prefetch2<NT>(wq, wbase + (size_t)tbeg * KS * 64, KS, nt0);
-  }
-  if constexpr (PRO == CSSHIP_PRO_LN) load_panel_ln<NW>(Xs, reinterpret_cast<const float*>(a.a), m0, a.M, a.ln_g, a.ln_b, wave, lane);
-  else if constexpr (PRO == CSSHIP_PRO_F32) load_panel_f32<NW>(Xs, reinterpret_cast<const float*>(a.a), m0, a.M, wave, lane);
+  stamp(a.stamps, 0);
+  prefetch_first<NT>(wq, wbase + (size_t)(wave * NT) * KS * 64, KS, max(0, min(NT, ntiles - wave * NT)));
+  if constexpr (PRO == CSSHIP_PRO_LN) load_panel_rows<true>(Xs, reinterpret_cast<const float*>(a.a), m0, a.M, a.ln_g, a.ln_b, tid);
+  else if constexpr (PRO == CSSHIP_PRO_F32) load_panel_rows<false>(Xs, reinterpret_cast<const float*>(a.a), m0, a.M, nullptr, nullptr, tid);
   else load_panel_bf16<NW>(Xs, reinterpret_cast<const unsigned short*>(a.a), m0, a.M, tid);
   __syncthreads();
+  stamp(a.stamps, 1);
 
-  for (int t0 = tbeg; t0 < tend; t0 += NT) {
-    const int nt = min(NT, tend - t0);
-    const int nnt = max(0, min(NT, tend - (t0 + NT)));
+  const int r = tid >> 3, part = tid & 7;
+  const int row = m0 + r;
+  const bool vec_ok = OBF ? ((a.ldo & 7) == 0) : ((a.ldo & 3) == 0);
+
+  for (int p = 0; p < npass; ++p) {
+    const int tile0 = p * 16 + wave * NT;
+    const int nt = max(0, min(NT, ntiles - tile0));
+    const int nnt = max(0, min(NT, ntiles - (tile0 + 16)));
+    float4 bb[NT];
     f32x4 acc[NT][4];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
+      bb[t] = load_bias4(a.bias, (tile0 + t) * 16 + 4 * g, a.N);
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) acc[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bf16x8* wc = wbase + (size_t)t0 * KS * 64;
-    mma_pass<NT>(acc, Xs, n, g, nt, wc, KS, wc + (size_t)NT * KS * 64, KS, nnt, wq);
+    }
+    const bf16x8* wc = wbase + (size_t)tile0 * KS * 64;
+    mma_pass<NT>(acc, Xs, n, g, nt, wc, KS, wc + (size_t)16 * KS * 64, KS, nnt, wq);
+    if (p == 0) stamp(a.stamps, 2);
+    park_tiles<NT, RELU>(Ys, acc, nt, wave * NT * 16, g, n, bb);
+    __syncthreads();
+    const int f0 = p * 256, ncols = min(256, a.N - f0);
+    if (vec_ok && (ncols & 7) == 0) {
+      if (row < a.M) {
+        if constexpr (OBF) {
+          unsigned short* o = reinterpret_cast<unsigned short*>(a.out) + (size_t)row * a.ldo + f0;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      if (t >= nt) continue;
-      const int f = (t0 + t) * 16 + 4 * g;  // 4 consecutive features f..f+3
-      float bb[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bb[r] = (a.bias && f + r < a.N) ? a.bias[f + r] : 0.f;
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-        const int row = m0 + rt * 16 + n;
-        if (row >= a.M) continue;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[t][rt][r] + bb[r];
-        if constexpr ((EPI & CSSHIP_EPI_RESIDUAL) != 0) {  // N == ldr-aligned 256-wide residual stream
-          const float4 xr = *reinterpret_cast<const float4*>(a.res + (size_t)row * a.ldr + f);
-          v[0] = xr.x + a.alpha * v[0]; v[1] = xr.y + a.alpha * v[1];
-          v[2] = xr.z + a.alpha * v[2]; v[3] = xr.w + a.alpha * v[3];
-        }
-        if constexpr ((EPI & CSSHIP_EPI_RELU) != 0) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        }
-        if constexpr ((EPI & CSSHIP_EPI_OUT_BF16) != 0) {
-          unsigned short* o = reinterpret_cast<unsigned short*>(a.out) + (size_t)row * a.ldo + f;
-          if (f + 3 < a.N && (a.ldo & 3) == 0) {
-            *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (f + r < a.N) o[r] = f2bf(v[r]);
+          for (int i = 0; i < 4; ++i) {
+            const int c = (i * 8 + part) * 8;
+            if (c < ncols) {
+              float4 y0 = *reinterpret_cast<const float4*>(Ys + r * YS + c);
+              float4 y1 = *reinterpret_cast<const float4*>(Ys + r * YS + c + 4);
+              if constexpr (RES) {
+                const float4 x0 = *reinterpret_cast<const float4*>(a.res + (size_t)row * a.ldr + f0 + c);
+                const float4 x1 = *reinterpret_cast<const float4*>(a.res + (size_t)row * a.ldr + f0 + c + 4);
+                y0 = make_float4(x0.x + a.alpha * y0.x, x0.y + a.alpha * y0.y, x0.z + a.alpha * y0.z, x0.w + a.alpha * y0.w);
+                y1 = make_float4(x1.x + a.alpha * y1.x, x1.y + a.alpha * y1.y, x1.z + a.alpha * y1.z, x1.w + a.alpha * y1.w);
+              }
+              *reinterpret_cast<uint4*>(o + c) = make_uint4(pack_bf2(y0.x, y0.y), pack_bf2(y0.z, y0.w), pack_bf2(y1.x, y1.y), pack_bf2(y1.z, y1.w));
+            }
           }
         } else {
-          float* o = reinterpret_cast<float*>(a.out) + (size_t)row * a.ldo + f;
-          if (f + 3 < a.N && (a.ldo & 3) == 0) {
-            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-          } else {
+          float* o = reinterpret_cast<float*>(a.out) + (size_t)row * a.ldo + f0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (f + r < a.N) o[r] = v[r];
+          for (int i = 0; i < 8; ++i) {
+            const int c = (i * 8 + part) * 4;
+            if (c < ncols) {
+              float4 y = *reinterpret_cast<const float4*>(Ys + r * YS + c);
+              if constexpr (RES) {
+                const float4 x0 = *reinterpret_cast<const float4*>(a.res + (size_t)row * a.ldr + f0 + c);
+                y = make_float4(x0.x + a.alpha * y.x, x0.y + a.alpha * y.y, x0.z + a.alpha * y.z, x0.w + a.alpha * y.w);
+              }
+              *reinterpret_cast<float4*>(o + c) = y;
+            }
           }
         }
       }
+    } else {  // unaligned rows (e.g. the 771-wide mask head): element-wise, still lane-contiguous
+      for (int idx = tid; idx < BM * 256; idx += NW * 64) {
+        const int rr = idx >> 8, c = idx & 255;
+        if (c < ncols && m0 + rr < a.M) {
+          float y = Ys[rr * YS + c];
+          if constexpr (RES) y = a.res[(size_t)(m0 + rr) * a.ldr + f0 + c] + a.alpha * y;
+          if constexpr (OBF) reinterpret_cast<unsigned short*>(a.out)[(size_t)(m0 + rr) * a.ldo + f0 + c] = f2bf(y);
+          else reinterpret_cast<float*>(a.out)[(size_t)(m0 + rr) * a.ldo + f0 + c] = y;
+        }
+      }
     }
+    if (p + 1 < npass) __syncthreads();  // Ys is re-parked by the next pass
   }
+  stamp(a.stamps, 5);
 }
 
 constexpr int NWAVES = 8;
@@ -361,7 +434,7 @@ extern "C" int csship_ffn_fused(const float* x, float* out, const float* ln_g, c
       !aligned16(ln_b) || !aligned16(b1) || !aligned16(b2) || (final_ln_g && (!aligned16(final_ln_g) || !aligned16(final_ln_b))))
     return CSSHIP_EALIGN;
   FfnArgs a{x, out, ln_g, ln_b, reinterpret_cast<const bf16x8*>(w1_packed), b1,
-            reinterpret_cast<const bf16x8*>(w2_packed), b2, final_ln_g, final_ln_b, M, d_ffn, alpha};
+            reinterpret_cast<const bf16x8*>(w2_packed), b2, final_ln_g, final_ln_b, M, d_ffn, alpha, g_stamps};
   dim3 grid((M + BM - 1) / BM), block(NWAVES * 64);
   if (final_ln_g) hipLaunchKernelGGL((ffn_kernel<NWAVES, true>), grid, block, 0, as_stream(stream), a);
   else hipLaunchKernelGGL((ffn_kernel<NWAVES, false>), grid, block, 0, as_stream(stream), a);
@@ -380,7 +453,7 @@ extern "C" int csship_panel_linear(const void* a, int32_t prologue, const float*
   if (prologue == CSSHIP_PRO_LN && (!ln_g || !ln_b || !aligned16(ln_g) || !aligned16(ln_b))) return CSSHIP_ENULL;
   if ((epilogue & CSSHIP_EPI_RESIDUAL) && (!residual || !aligned16(residual) || (ldr & 3) != 0 || ldr < N || (N & 3) != 0))
     return CSSHIP_EALIGN;
-  LinArgs la{a, ln_g, ln_b, reinterpret_cast<const bf16x8*>(w_packed), bias, residual, out, M, N, ldo, ldr, alpha};
+  LinArgs la{a, ln_g, ln_b, reinterpret_cast<const bf16x8*>(w_packed), bias, residual, out, M, N, ldo, ldr, alpha, g_stamps};
   hipStream_t s = as_stream(stream);
   const int key = prologue * 16 + epilogue;
   switch (key) {
@@ -394,3 +467,7 @@ extern "C" int csship_panel_linear(const void* a, int32_t prologue, const float*
     default: return CSSHIP_EUNSUPPORTED;
   }
 }
+
+// Diagnostic only (not part of include/csship.h): device buffer of [n_workgroups][8] u64 that the
+// panel kernels fill with s_memrealtime phase stamps; pass NULL to switch stamping off.
+extern "C" void csship_debug_stamps(void* device_buffer) { g_stamps = reinterpret_cast<unsigned long long*>(device_buffer); }

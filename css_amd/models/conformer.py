@@ -201,11 +201,12 @@ class Conformer(nn.Module):
         w.idim, w.idim_pad = enc.idim, (enc.idim + 63) // 64 * 64
         w.d_model, w.n_head, w.d_ffn = enc.d_model, enc.n_head, enc.d_ffn
         w.n_layer, w.kernel_size = len(enc.encoders), enc.kernel_size
-        w.n_out, w.maxlen = self.linear.out_features, enc.pos_emb.maxlen
+        w.n_out = self.linear.out_features
+        pe_packed, w.pe_q_min, w.pe_q_max = ops.pack_relpos(enc.pos_emb.pe_k.weight, enc.pos_emb.maxlen)
         w.bn_mode = 1 if self.training else 0
         w.embed_w, w.embed_b = own(ops.pad_weight_bf16(enc.embed[0].weight)), f32(enc.embed[0].bias)
         w.embed_ln_g, w.embed_ln_b = f32(enc.embed[1].weight), f32(enc.embed[1].bias)
-        w.pe_k = own(enc.pos_emb.pe_k.weight.detach().to(torch.bfloat16).contiguous())
+        w.pe_k = own(pe_packed)
         w.layers = C.cast(layers, C.POINTER(_lib.LayerWeights))
         w.head_w, w.head_b = own(ops.pack_frag(self.linear.weight)), f32(self.linear.bias)
         self._packed = (w, layers, keep)

@@ -146,15 +146,29 @@ def gemm(a, w_bf16, bias=None, *, K=None, relu=False, residual=None, alpha=1.0, 
     return out
 
 
-def mha_relpos(qkv, pe_k_bf16, n_head, maxlen=1000):
-    """qkv bf16 [B,T,3*H*64] (q pre-scaled) -> bf16 [B,T,H*64]."""
+def pack_relpos(pe_k, maxlen=1000):
+    """pe_k [2*maxlen, 64] -> (packed bf16, q_min, q_max) for csship_mha_relpos (layout: include/csship.h)."""
+    assert tuple(pe_k.shape) == (2 * maxlen, 64)
+    q_min = -((maxlen + 15) // 16) - 2   # 16*q_min + 15 <= -maxlen: the whole block clamps low
+    q_max = (maxlen + 15) // 16 + 1      # 16*q_max >= maxlen - 1: the whole block clamps high
+    q = torch.arange(q_min, q_max + 1, device=pe_k.device)
+    m = torch.arange(16, device=pe_k.device)
+    rel = (16 * q[:, None] + 15 - m[None, :]).clamp(-maxlen, maxlen - 1) + maxlen  # [nq, 16]
+    blk = pe_k.detach().float()[rel]                      # [nq, m, 64]
+    blk = blk.view(-1, 16, 2, 4, 8).permute(0, 2, 3, 1, 4)  # [nq, ks, g, m, j]
+    return blk.contiguous().to(torch.bfloat16).view(-1), int(q_min), int(q_max)
+
+
+def mha_relpos(qkv, pe_pack, n_head):
+    """qkv bf16 [B,T,3*H*64] (q pre-scaled), pe_pack = pack_relpos(pe_k) -> bf16 [B,T,H*64]."""
     _need(qkv, torch.bfloat16, "qkv")
-    _need(pe_k_bf16, torch.bfloat16, "pe_k")
+    packed, q_min, q_max = pe_pack
+    _need(packed, torch.bfloat16, "pe_packed")
     B, T, D3 = qkv.shape
-    assert qkv.is_contiguous() and pe_k_bf16.is_contiguous()
-    assert D3 == 3 * n_head * 64 and tuple(pe_k_bf16.shape) == (2 * maxlen, 64)
+    assert qkv.is_contiguous() and packed.is_contiguous()
+    assert D3 == 3 * n_head * 64 and packed.numel() == (q_max - q_min + 1) * 2 * 512
     out = torch.empty(B, T, n_head * 64, device=qkv.device, dtype=torch.bfloat16)
-    check(lib().csship_mha_relpos(_ptr(qkv), _ptr(pe_k_bf16), _ptr(out), B, T, n_head, maxlen, _stream()))
+    check(lib().csship_mha_relpos(_ptr(qkv), _ptr(packed), q_min, q_max, _ptr(out), B, T, n_head, _stream()))
     return out
 
 

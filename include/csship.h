@@ -146,11 +146,15 @@ int csship_panel_linear(const void* a, int32_t prologue, const float* ln_g, cons
  * (css/models/conformer.py:229-253) with RelativePositionalEncoding
  * (conformer.py:179-185) folded in:
  *   score[i,j] = q_i . k_j + q_i . pe_k[clamp(i-j, -maxlen, maxlen-1) + maxlen]
- * qkv: bf16 [B, T, 3*H*64] (q | k | v, q ALREADY scaled by 1/sqrt(d_k)); pe_k: bf16
- * [2*maxlen, 64]; out: bf16 [B, T, H*64].  d_k must be 64.  The T x T x d_k table of
- * conformer.py:159 is never materialised. */
-int csship_mha_relpos(const uint16_t* qkv, const uint16_t* pe_k, uint16_t* out, int32_t B,
-                      int32_t T, int32_t H, int32_t maxlen, csship_stream_t stream);
+ * qkv: bf16 [B, T, 3*H*64] (q | k | v, q ALREADY scaled by 1/sqrt(d_k)); out: bf16
+ * [B, T, H*64]; d_k must be 64.  The T x T x d_k table of conformer.py:159 is never
+ * materialised.  pe_packed holds pe_k as reversed, aligned 16-row blocks in MFMA fragment
+ * order with the clamp baked in: for q in [q_min, q_max], ks in {0,1}
+ *   block(q, ks)[lane = 16*g + m][j] = pe_k[clamp(16*q + 15 - m, -maxlen, maxlen-1) + maxlen][32*ks + 8*g + j]
+ * at pe_packed + ((q - q_min)*2 + ks) * 512 bf16.  Block q_min must be entirely below the
+ * clamp and block q_max entirely above it (css_amd.ops.pack_relpos builds it). */
+int csship_mha_relpos(const uint16_t* qkv, const uint16_t* pe_packed, int32_t q_min, int32_t q_max,
+                      uint16_t* out, int32_t B, int32_t T, int32_t H, csship_stream_t stream);
 
 /* ConvModule.forward + residual (css/models/conformer.py:289-303, 357):
  *   y = x + pw2( relu( BN( dwconv_k( glu( LN(x) ) ) ) ) ),  x,y: f32 [B, T, 256].
@@ -224,11 +228,12 @@ typedef struct {
 typedef struct {
   int32_t idim, idim_pad;  /* input feature dim and its zero-padded multiple of 64 */
   int32_t d_model, n_head, d_ffn, n_layer, kernel_size;
-  int32_t n_out, maxlen;   /* n_out = num_bins * (num_spk + num_noise) */
+  int32_t n_out;           /* num_bins * (num_spk + num_noise) */
+  int32_t pe_q_min, pe_q_max; /* block range of pe_k (csship_mha_relpos) */
   int32_t bn_mode;         /* 0 eval, 1 batch statistics */
   const uint16_t* embed_w; const float* embed_b; /* ROW-MAJOR bf16 [d_model, idim_pad] (csship_gemm layout) */
   const float *embed_ln_g, *embed_ln_b;
-  const uint16_t* pe_k;    /* bf16 [2*maxlen, d_model/n_head] */
+  const uint16_t* pe_k;    /* PACKED relative-position blocks (csship_mha_relpos) */
   const csship_layer_weights* layers; /* HOST array [n_layer] */
   const uint16_t* head_w; const float* head_b; /* PACKED bf16 from [n_out, d_model] */
 } csship_conformer_weights;

@@ -220,13 +220,13 @@ def _ref_attention(q, k, v, pe, maxlen=1000):
     return torch.matmul(att, v.double()).transpose(1, 2).reshape(B, T, H * dk)
 
 
-@pytest.mark.parametrize("B,T", [(2, 100), (1, 64), (3, 17), (1, 1100)])
+@pytest.mark.parametrize("B,T", [(2, 100), (1, 64), (3, 17), (2, 400), (1, 1100), (1, 2300)])
 def test_mha_relpos(ops, B, T):
     H = 4
     qkv = rnd((B, T, 3 * H * 64), 41)
     qkv[..., : H * 64] *= 0.125
     pe = rnd((2000, 64), 42, 0.3)
-    out = ops.mha_relpos(qkv.to(DEV).to(torch.bfloat16), pe.to(DEV).to(torch.bfloat16), H)
+    out = ops.mha_relpos(qkv.to(DEV).to(torch.bfloat16), ops.pack_relpos(pe.to(DEV)), H)
     qb = bf(qkv).view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
     ref = _ref_attention(qb[0], qb[1], qb[2], bf(pe))
     # P is rounded to bf16 before P.V and the output is stored in bf16: ~2^-8 relative
