@@ -27,14 +27,14 @@
 
 namespace {
 
-constexpr int PS = 80;  // per-wave band scratch row stride (floats)
+constexpr int PS = 84;  // per-wave band scratch row stride (floats): 336 B rows -> 8 consecutive rows hit 8 distinct 16-B slots
 constexpr float LOG2E = 1.4426950408889634f;
 
 DEV int v_off(int row, int chunk) {  // 16-byte chunk of a 128-byte V row; 32-byte groups XOR (row>>1)&3
   return row * 128 + ((((chunk >> 1) ^ ((row >> 1) & 3)) << 1) | (chunk & 1)) * 16;
 }
 
-__global__ __launch_bounds__(256) void mha_relpos_kernel(const unsigned short* __restrict__ qkv,
+__global__ __launch_bounds__(256, 4) void mha_relpos_kernel(const unsigned short* __restrict__ qkv,
                                                          const bf16x8* __restrict__ pe_packed, int q_min, int q_max,
                                                          unsigned short* __restrict__ out, int B, int T, int H) {
   __shared__ __attribute__((aligned(16))) unsigned char sK[64 * 128];
@@ -57,37 +57,36 @@ __global__ __launch_bounds__(256) void mha_relpos_kernel(const unsigned short* _
     qf[1] = *reinterpret_cast<const bf16x8*>(qrow + 32 + 8 * g);
   }
 
-  // K/V staging: thread owns chunks (row = idx>>3, c = idx&7), idx = tid + 256*i
-  uint4 kreg[2], vreg[2];
-  auto load_kv = [&](int j0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = tid + 256 * i, row = idx >> 3, c = idx & 7;
-      const int jj = min(j0 + row, T - 1);
-      const unsigned short* src = qkv + (base_b + jj) * D3 + h * 64 + c * 8;
-      kreg[i] = *reinterpret_cast<const uint4*>(src + D);
-      vreg[i] = *reinterpret_cast<const uint4*>(src + 2 * D);
-    }
-  };
-  auto store_kv = [&]() {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = tid + 256 * i, row = idx >> 3, c = idx & 7;
-      *reinterpret_cast<uint4*>(sK + tile_off(row, c)) = kreg[i];
-      *reinterpret_cast<uint4*>(sV + v_off(row, c)) = vreg[i];
-    }
-  };
+  // K/V staging: thread owns chunks (row = idx>>3, c = idx&7), idx = tid and tid + 256.  Named registers
+  // (not arrays captured by a lambda: those are demoted to scratch memory and serialise the prefetch).
+  const int srow0 = tid >> 3, srow1 = srow0 + 32, sc = tid & 7;
+  uint4 kreg0, kreg1, vreg0, vreg1;
+#define ATTN_LOAD_KV(J0)                                                                              \
+  {                                                                                                   \
+    const unsigned short* s0_ = qkv + (base_b + min((J0) + srow0, T - 1)) * D3 + h * 64 + sc * 8;   \
+    const unsigned short* s1_ = qkv + (base_b + min((J0) + srow1, T - 1)) * D3 + h * 64 + sc * 8;   \
+    kreg0 = *reinterpret_cast<const uint4*>(s0_ + D);                                                 \
+    vreg0 = *reinterpret_cast<const uint4*>(s0_ + 2 * D);                                             \
+    kreg1 = *reinterpret_cast<const uint4*>(s1_ + D);                                                 \
+    vreg1 = *reinterpret_cast<const uint4*>(s1_ + 2 * D);                                             \
+  }
+#define ATTN_STORE_KV()                                                       \
+  {                                                                           \
+    *reinterpret_cast<uint4*>(sK + tile_off(srow0, sc)) = kreg0;              \
+    *reinterpret_cast<uint4*>(sK + tile_off(srow1, sc)) = kreg1;              \
+    *reinterpret_cast<uint4*>(sV + v_off(srow0, sc)) = vreg0;                 \
+    *reinterpret_cast<uint4*>(sV + v_off(srow1, sc)) = vreg1;                 \
+  }
   // band fragments of key tile j0: band tile t covers rel = 16*q + 15 - m, q = (i0w - j0)/16 - t
-  bf16x8 pf[2][5];
-  auto load_pe = [&](int j0) {
-    const int qb = (i0w - j0) / 16;  // exact: both are multiples of 16
-#pragma unroll
-    for (int t = 0; t < 5; ++t) {
-      const int qi = min(max(qb - t, q_min), q_max) - q_min;
-      pf[0][t] = pe_packed[((size_t)qi * 2 + 0) * 64 + lane];
-      pf[1][t] = pe_packed[((size_t)qi * 2 + 1) * 64 + lane];
-    }
-  };
+  bf16x8 pf0[5], pf1[5];
+#define ATTN_LOAD_PE(PF, KSI, J0)                                                 \
+  {                                                                               \
+    const int qb_ = (i0w - (J0)) / 16; /* exact: both are multiples of 16 */      \
+    _Pragma("unroll") for (int t = 0; t < 5; ++t) {                               \
+      const int qi_ = min(max(qb_ - t, q_min), q_max) - q_min;                    \
+      PF[t] = pe_packed[((size_t)qi_ * 2 + (KSI)) * 64 + lane];                   \
+    }                                                                             \
+  }
 
   f32x4 o[4];
 #pragma unroll
@@ -96,16 +95,15 @@ __global__ __launch_bounds__(256) void mha_relpos_kernel(const unsigned short* _
   float* Pw = sP + w * 16 * PS;
   const int q4 = n >> 2, p4 = n & 3;
 
-  load_kv(0);
-  load_pe(0);
-  store_kv();
+  ATTN_LOAD_KV(0)
+  ATTN_LOAD_PE(pf0, 0, 0)
+  ATTN_STORE_KV()
   __syncthreads();
 
   for (int j0 = 0; j0 < T; j0 += 64) {
     const bool more = j0 + 64 < T;
-    if (more) load_kv(j0 + 64);  // in flight during this tile's compute
+    ATTN_LOAD_PE(pf1, 1, j0)  // second half of this tile's band operands: lands during K.Q^T
     __builtin_amdgcn_sched_barrier(0);
-
     // ---- S^T = K Q^T and the position band Pb^T = PE_band Q^T
     f32x4 s[4], pb[5];
 #pragma unroll
@@ -121,11 +119,11 @@ __global__ __launch_bounds__(256) void mha_relpos_kernel(const unsigned short* _
       }
     }
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int t = 0; t < 5; ++t) pb[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf0[t], qf[0], pb[t], 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < 5; ++t) pb[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ks][t], qf[ks], pb[t], 0, 0, 0);
+    for (int t = 0; t < 5; ++t) pb[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf1[t], qf[1], pb[t], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if (more) load_pe(j0 + 64);  // next tile's band operands arrive during softmax + P.V
+    if (more) ATTN_LOAD_KV(j0 + 64)  // next K/V tile: in flight during softmax + P.V, written to LDS after them
     __builtin_amdgcn_sched_barrier(0);
 
     // band -> per-wave scratch Pw[query n][c], c = 16t + 4g + r
@@ -143,7 +141,7 @@ __global__ __launch_bounds__(256) void mha_relpos_kernel(const unsigned short* _
       for (int r = 0; r < 4; ++r) {
         const int jl = 16 * t + 4 * g + r;
         float v = s[t][r] + Pw[n * PS + 15 - n + jl];
-        v = (j0 + jl < T) ? v : -1e30f;
+        if (!more) v = (j0 + jl < T) ? v : -1e30f;  // only the last key tile has a tail
         s[t][r] = v;
         mx = fmaxf(mx, v);
       }
@@ -189,8 +187,10 @@ __global__ __launch_bounds__(256) void mha_relpos_kernel(const unsigned short* _
     }
 
     if (more) {
+      ATTN_LOAD_PE(pf0, 0, j0 + 64)  // first half of the next tile's band operands; lands during the barriers
+      __builtin_amdgcn_sched_barrier(0);
       __syncthreads();  // everyone is done reading this tile's K/V
-      store_kv();
+      ATTN_STORE_KV()
       __syncthreads();
     }
   }
