@@ -12,9 +12,10 @@ are work, not frames).  N > 1: one process per GPU (torchrun), every rank runs i
 sides of the timed region, max over ranks.
 
 Extra objects on the JSON line (task section 4):
-  roofline     dominant kernel = the FFN up-projection GEMM (12800x256 @ 256x1024, bf16 MFMA);
-               achieved = algorithmic 2*M*N*K flops / average launch duration measured with
-               HIP events on the launch stream; peak = 2.5 PFLOP/s dense bf16.
+  roofline     dominant kernel = the fused FeedForward (ffn_kernel: 32 launches per step, MFMA
+               bound); achieved = algorithmic 4*M*256*1024 flops / average launch duration
+               measured with HIP events on the launch stream; peak = 2.5 PFLOP/s dense bf16.
+               roofline.stft carries the HBM-bound front end the same way (2 052 B/frame).
   cpu_baseline the oracle (fp32 CPU restatement, kind "port") timed on this box's host cores on
                ONE full batch (rank 0, N = 1 only).
 """
@@ -96,35 +97,56 @@ def main():
         dt = float(t.item())
     loss_val = float(loss)
 
-    # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream
+    # ---- roofline of the dominant kernel (the fused FeedForward, 32 launches per step), measured live with
+    # HIP events recorded on the stream the kernel is launched on (torch's current stream)
     roof = None
     if rank == 0:
         M = B * T
-        a = torch.randn(M, 256, device=dev).to(torch.bfloat16)
-        w = ops.pad_weight_bf16(torch.randn(1024, 256, device=dev) / 16)
-        bias = torch.zeros(1024, device=dev)
-        out = torch.empty(M, 1024, device=dev, dtype=torch.bfloat16)
+        x = torch.randn(M, 256, device=dev)
+        g1, b0 = torch.ones(256, device=dev), torch.zeros(256, device=dev)
+        w1 = ops.pack_frag(torch.randn(1024, 256, device=dev) / 16)
+        w2 = ops.pack_frag(torch.randn(256, 1024, device=dev) / 32)
+        b1, b2 = torch.zeros(1024, device=dev), torch.zeros(256, device=dev)
+        out = torch.empty_like(x)
+        run = lambda: ops.ffn_fused(x, (g1, b0), w1, b1, w2, b2, 1024, 0.5, final_ln=(g1, b0), out=out)  # noqa: E731
         for _ in range(5):
-            ops.gemm(a, w, bias, relu=True, out_bf16=True, out=out)
+            run()
         reps = 50
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream())
         for _ in range(reps):
-            ops.gemm(a, w, bias, relu=True, out_bf16=True, out=out)
+            run()
         e1.record(torch.cuda.current_stream())
         torch.cuda.synchronize()
         dur = e0.elapsed_time(e1) * 1e-3 / reps
-        flops = 2.0 * M * 1024 * 256
-        roof = {"bound": "mfma", "kernel": "gemm_kernel<2,2,bf16,relu|bf16> (FFN up-projection 12800x256x1024)",
+        flops = 4.0 * M * 256 * 1024  # two GEMMs of 2*M*256*1024 each (26.84 GFLOP per layer / 2)
+        roof = {"bound": "mfma", "kernel": "ffn_kernel<8,true> (LN -> 256x1024 -> ReLU -> 1024x256 -> +res -> LN, M=12800)",
                 "achieved": flops / dur / 1e12, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                 "frac": flops / dur / PEAK_BF16, "traffic": None, "avg_launch_us": dur * 1e6,
                 "whole_step_frac": (B * T * FLOP_PER_FRAME * args.blocks / 16) / (dt / args.steps) / PEAK_BF16}
+        # HBM-bound front end for reference (north_star asks for the STFT roofline too)
+        for _ in range(3):
+            ops.stft(audio, ("mag",))
+        e0.record(torch.cuda.current_stream())
+        for _ in range(20):
+            ops.stft(audio, ("mag",))
+        e1.record(torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        sd_ = e0.elapsed_time(e1) * 1e-3 / 20
+        nfr = 3 * B * T
+        roof["stft"] = {"bound": "hbm", "achieved": nfr * 2052 / sd_ / 1e9, "peak": 8000.0, "unit": "GB/s",
+                        "frac": nfr * 2052 / sd_ / 8.0e12, "avg_launch_us": sd_ * 1e6,
+                        "bytes_per_frame": 2052}
 
     # ---- CPU baseline: the oracle on one full batch, host cores of this box
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle
-        cores = os.cpu_count() or 1
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        cores = max(1, min(cores, int(os.environ.get("CSS_CPU_THREADS", "16"))))  # the GPU box shares its host cores
         torch.set_num_threads(cores)
         with torch.no_grad():
             c0 = time.perf_counter()

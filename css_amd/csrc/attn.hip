@@ -36,7 +36,8 @@ DEV int v_off(int row, int chunk) {  // 16-byte chunk of a 128-byte V row; 32-by
 
 __global__ __launch_bounds__(256, 4) void mha_relpos_kernel(const unsigned short* __restrict__ qkv,
                                                          const bf16x8* __restrict__ pe_packed, int q_min, int q_max,
-                                                         unsigned short* __restrict__ out, int B, int T, int H) {
+                                                         unsigned short* __restrict__ out, int B, int T, int H,
+                                                            unsigned long long* stamps) {
   __shared__ __attribute__((aligned(16))) unsigned char sK[64 * 128];
   __shared__ __attribute__((aligned(16))) unsigned char sV[64 * 128];
   __shared__ __attribute__((aligned(16))) float sP[4 * 16 * PS];
@@ -95,11 +96,13 @@ __global__ __launch_bounds__(256, 4) void mha_relpos_kernel(const unsigned short
   float* Pw = sP + w * 16 * PS;
   const int q4 = n >> 2, p4 = n & 3;
 
+  stamp(stamps, 0);
   ATTN_LOAD_KV(0)
   ATTN_LOAD_PE(pf0, 0, 0)
   ATTN_STORE_KV()
   __syncthreads();
 
+  stamp(stamps, 1);
   for (int j0 = 0; j0 < T; j0 += 64) {
     const bool more = j0 + 64 < T;
     ATTN_LOAD_PE(pf1, 1, j0)  // second half of this tile's band operands: lands during K.Q^T
@@ -195,6 +198,7 @@ __global__ __launch_bounds__(256, 4) void mha_relpos_kernel(const unsigned short
     }
   }
 
+  stamp(stamps, 2);
   float l = l_run;
   l += __shfl_xor(l, 16);
   l += __shfl_xor(l, 32);
@@ -221,7 +225,7 @@ extern "C" int csship_mha_relpos(const uint16_t* qkv, const uint16_t* pe_packed,
   if (!aligned16(qkv) || !aligned16(pe_packed) || !aligned8(out)) return CSSHIP_EALIGN;
   dim3 grid((T + 63) / 64, H, B);
   hipLaunchKernelGGL(mha_relpos_kernel, grid, dim3(256), 0, as_stream(stream), qkv,
-                     reinterpret_cast<const bf16x8*>(pe_packed), q_min, q_max, out, B, T, H);
+                     reinterpret_cast<const bf16x8*>(pe_packed), q_min, q_max, out, B, T, H, g_csship_stamps);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }

@@ -41,3 +41,13 @@ static inline hipStream_t as_stream(csship_stream_t s) { return reinterpret_cast
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
+
+// Optional in-kernel phase stamps (diagnostic only; nullptr in normal operation): thread 0 of every
+// workgroup stores s_memrealtime (100 MHz) at up to 8 phase boundaries.  Set by csship_debug_stamps().
+extern unsigned long long* g_csship_stamps;
+DEV void stamp(unsigned long long* st, int slot) {
+  if (st != nullptr && threadIdx.x == 0) {
+    const size_t wg = (size_t)blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
+    st[wg * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+  }
+}

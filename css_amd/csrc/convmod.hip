@@ -21,54 +21,73 @@ struct ConvArgs {
   float* zbuf;     // train: pre-BN activations [B,T,D]
   float* partial;  // train: [nblk][2][D]
   int B, T;
+  unsigned long long* stamps;
 };
 
 template <int D, int TT, int KS, int MODE>
-__global__ __launch_bounds__(D) void convmod_kernel(ConvArgs a) {
-  constexpr int HALO = (KS - 1) / 2, ROWS = TT + KS - 1, NW = D / 64, VPL = D / 256;
+__global__ __launch_bounds__(2 * D) void convmod_kernel(ConvArgs a) {
+  constexpr int HALO = (KS - 1) / 2, ROWS = TT + KS - 1, NTHR = 2 * D;
   __shared__ __attribute__((aligned(16))) float G[ROWS][D];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   const int b = blockIdx.y, t0 = blockIdx.x * TT;
+  stamp(a.stamps, 0);
   const float w0 = a.w.pw1_w[0], w1 = a.w.pw1_w[1], b0 = a.w.pw1_b[0], b1 = a.w.pw1_b[1];
 
-  for (int row = wave; row < ROWS; row += NW) {
+  // phase 1: LPR = D/32 lanes per row (each lane 32 channels as 8 float4 pieces, the lanes of a row cover
+  // whole 128-byte lines per load); LayerNorm statistics = in-lane sums + log2(LPR) shuffles.
+  constexpr int LPR = D / 32, RPB = NTHR / LPR;  // rows per batch of the workgroup (64 for D = 256)
+  const int part = tid % LPR;
+  for (int r0 = 0; r0 < ROWS; r0 += RPB) {
+    const int row = r0 + tid / LPR;
+    if (row >= ROWS) break;
     const int t = t0 - HALO + row;
-    if (t < 0 || t >= a.T) {
+    const bool inside = t >= 0 && t < a.T;
+    const float* xr = a.x + ((size_t)b * a.T + (inside ? t : 0)) * D;
+    float4 v[8];
 #pragma unroll
-      for (int i = 0; i < VPL; ++i) *reinterpret_cast<float4*>(&G[row][(i * 64 + lane) * 4]) = make_float4(0, 0, 0, 0);
-      continue;
-    }
-    const float* xr = a.x + ((size_t)b * a.T + t) * D;
-    float4 v[VPL];
+    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(xr + (i * LPR + part) * 4);
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-      v[i] = *reinterpret_cast<const float4*>(xr + (i * 64 + lane) * 4);
-      s += v[i].x + v[i].y + v[i].z + v[i].w;
-    }
-    const float mean = wave_sum(s) * (1.f / D);
+    for (int i = 0; i < 8; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o);
+    const float mean = s * (1.f / D);
     float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
+    for (int i = 0; i < 8; ++i) {
       v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
-      ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+      ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
     }
-    const float rstd = rsqrtf(wave_sum(ss) * (1.f / D) + 1e-5f);
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-      const int c = (i * 64 + lane) * 4;
+    for (int o = 1; o < LPR; o <<= 1) ss += __shfl_xor(ss, o);
+    const float rstd = rsqrtf(ss * (1.f / D) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = (i * LPR + part) * 4;
       const float4 gm = *reinterpret_cast<const float4*>(a.w.ln_g + c);
       const float4 bt = *reinterpret_cast<const float4*>(a.w.ln_b + c);
       float e[4] = {v[i].x * rstd * gm.x + bt.x, v[i].y * rstd * gm.y + bt.y, v[i].z * rstd * gm.z + bt.z,
                     v[i].w * rstd * gm.w + bt.w};
+      // scalar GLU (w0 e + b0) * sigmoid(w1 e + b1); v_rcp_f32 (1 ulp) instead of an IEEE divide
 #pragma unroll
-      for (int q = 0; q < 4; ++q) e[q] = (w0 * e[q] + b0) / (1.f + __expf(-(w1 * e[q] + b1)));
+      for (int q = 0; q < 4; ++q)
+        e[q] = inside ? (w0 * e[q] + b0) * __builtin_amdgcn_rcpf(1.f + __expf(-(w1 * e[q] + b1))) : 0.f;
       *reinterpret_cast<float4*>(&G[row][c]) = make_float4(e[0], e[1], e[2], e[3]);
     }
   }
-  __syncthreads();
 
-  const int c = tid;
+  // phase 2: two threads per channel, each TT/2 consecutive frames
+  const int c = tid % D, half = tid / D;
+  constexpr int TH = TT / 2, OB = 8;
+  const int tb0 = half * TH;
+  float xres[TH];  // residual rows, fetched while phase 1 of the other waves finishes
+  if constexpr (MODE == 0) {
+#pragma unroll
+    for (int j = 0; j < TH; ++j) {
+      const int t = min(t0 + tb0 + j, a.T - 1);
+      xres[j] = a.x[((size_t)b * a.T + t) * D + c];
+    }
+  }
   float wk[KS];
 #pragma unroll
   for (int k = 0; k < KS; ++k) wk[k] = a.w.dw_w[c * KS + k];
@@ -80,10 +99,12 @@ __global__ __launch_bounds__(D) void convmod_kernel(ConvArgs a) {
     pw2w = a.w.pw2_w[0];
     pw2b = a.w.pw2_b[0];
   }
+  __syncthreads();
+  stamp(a.stamps, 1);
   float lsum = 0.f, lsq = 0.f;
-  constexpr int OB = 8;
-#pragma unroll 1
-  for (int tb = 0; tb < TT; tb += OB) {
+#pragma unroll
+  for (int blk = 0; blk < TH / OB; ++blk) {
+    const int tb = tb0 + blk * OB;
     float acc[OB];
 #pragma unroll
     for (int j = 0; j < OB; ++j) acc[j] = cb;
@@ -102,7 +123,7 @@ __global__ __launch_bounds__(D) void convmod_kernel(ConvArgs a) {
       if (t >= a.T) continue;
       const size_t o = ((size_t)b * a.T + t) * D + c;
       if constexpr (MODE == 0) {
-        a.y[o] = a.x[o] + fmaxf(acc[j] * scale + shift, 0.f) * pw2w + pw2b;
+        a.y[o] = xres[blk * OB + j] + fmaxf(acc[j] * scale + shift, 0.f) * pw2w + pw2b;
       } else {
         a.zbuf[o] = acc[j];
         lsum += acc[j];
@@ -110,8 +131,9 @@ __global__ __launch_bounds__(D) void convmod_kernel(ConvArgs a) {
       }
     }
   }
+  stamp(a.stamps, 3);
   if constexpr (MODE == 1) {
-    const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const size_t blk = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + half;
     a.partial[(blk * 2 + 0) * D + c] = lsum;
     a.partial[(blk * 2 + 1) * D + c] = lsq;
   }
@@ -160,17 +182,17 @@ int run(const ConvArgs& a0, int bn_mode, void* workspace, hipStream_t s) {
   ConvArgs a = a0;
   dim3 grid((a.T + TT - 1) / TT, a.B);
   if (bn_mode == 0) {
-    hipLaunchKernelGGL((convmod_kernel<D, TT, 33, 0>), grid, dim3(D), 0, s, a);
+    hipLaunchKernelGGL((convmod_kernel<D, TT, 33, 0>), grid, dim3(2 * D), 0, s, a);
     CSSHIP_CHECK_LAUNCH();
     return CSSHIP_OK;
   }
   if (!workspace) return CSSHIP_EWORKSPACE;
   const size_t n = (size_t)a.B * a.T * D;
-  const int nblk = grid.x * grid.y;
+  const int nblk = grid.x * grid.y * 2;  // two half-tiles per workgroup
   a.zbuf = reinterpret_cast<float*>(workspace);
   a.partial = a.zbuf + n;
   float* scale_shift = a.partial + (size_t)nblk * 2 * D;
-  hipLaunchKernelGGL((convmod_kernel<D, TT, 33, 1>), grid, dim3(D), 0, s, a);
+  hipLaunchKernelGGL((convmod_kernel<D, TT, 33, 1>), grid, dim3(2 * D), 0, s, a);
   CSSHIP_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_reduce_kernel, dim3((D + 63) / 64), dim3(64), 0, s, a.partial, nblk, D,
                      (double)a.B * (double)a.T, a.w.bn_g, a.w.bn_b, scale_shift);
@@ -187,7 +209,7 @@ constexpr int TT256 = 32, TT512 = 32;
 
 extern "C" size_t csship_convmod_workspace(int32_t B, int32_t T, int32_t D) {
   const int TT = D == 256 ? TT256 : TT512;
-  const size_t nblk = (size_t)((T + TT - 1) / TT) * B;
+  const size_t nblk = (size_t)((T + TT - 1) / TT) * B * 2;
   return ((size_t)B * T * D + nblk * 2 * D + 2 * (size_t)D) * sizeof(float);
 }
 
@@ -203,7 +225,7 @@ extern "C" int csship_convmod(const float* x, float* y, const csship_conv_weight
   if (x == y) return CSSHIP_EBADSHAPE;  // neighbouring tiles read the halo rows: not in-place safe
   if (!aligned16(x) || !aligned16(y) || !aligned16(w->ln_g) || !aligned16(w->ln_b) || (workspace && !aligned16(workspace)))
     return CSSHIP_EALIGN;
-  ConvArgs a{x, y, *w, nullptr, nullptr, B, T};
+  ConvArgs a{x, y, *w, nullptr, nullptr, B, T, g_csship_stamps};
   if (D == 256) return run<256, TT256>(a, bn_mode, workspace, as_stream(stream));
   return run<512, TT512>(a, bn_mode, workspace, as_stream(stream));
 }

@@ -44,6 +44,13 @@ Workspace carve(const csship_conformer_weights* w, int B, int T, void* base) {
 
 }  // namespace
 
+unsigned long long* g_csship_stamps = nullptr;
+// Diagnostic only (not part of include/csship.h): device buffer of [n_workgroups][8] u64 that instrumented
+// kernels fill with s_memrealtime phase stamps; pass NULL to switch stamping off.
+extern "C" void csship_debug_stamps(void* device_buffer) {
+  g_csship_stamps = reinterpret_cast<unsigned long long*>(device_buffer);
+}
+
 extern "C" int csship_version(void) { return 100; }
 
 extern "C" const char* csship_strerror(int rc) {

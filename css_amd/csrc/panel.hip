@@ -28,13 +28,6 @@ constexpr int PANEL_BYTES = BM * DM * 2;
 
 DEV int panel_off(int row, int chunk) { return row * 512 + ((chunk ^ (row & 15)) << 4); }
 
-// Optional in-kernel phase stamps (diagnostic only; nullptr in normal operation): wave 0 of every
-// workgroup stores s_memrealtime (100 MHz) at up to 8 phase boundaries.
-unsigned long long* g_stamps = nullptr;
-DEV void stamp(unsigned long long* st, int slot) {
-  if (st != nullptr && threadIdx.x == 0) st[(size_t)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memrealtime();
-}
-
 constexpr int PD = 4;  // weight prefetch distance in k-steps (ring of PD fragment sets per wave)
 
 // acc[t][rt] += W(tile0+t)[16 x 256] . panel^T[256 x 16 rows of tile rt]
@@ -434,7 +427,7 @@ extern "C" int csship_ffn_fused(const float* x, float* out, const float* ln_g, c
       !aligned16(ln_b) || !aligned16(b1) || !aligned16(b2) || (final_ln_g && (!aligned16(final_ln_g) || !aligned16(final_ln_b))))
     return CSSHIP_EALIGN;
   FfnArgs a{x, out, ln_g, ln_b, reinterpret_cast<const bf16x8*>(w1_packed), b1,
-            reinterpret_cast<const bf16x8*>(w2_packed), b2, final_ln_g, final_ln_b, M, d_ffn, alpha, g_stamps};
+            reinterpret_cast<const bf16x8*>(w2_packed), b2, final_ln_g, final_ln_b, M, d_ffn, alpha, g_csship_stamps};
   dim3 grid((M + BM - 1) / BM), block(NWAVES * 64);
   if (final_ln_g) hipLaunchKernelGGL((ffn_kernel<NWAVES, true>), grid, block, 0, as_stream(stream), a);
   else hipLaunchKernelGGL((ffn_kernel<NWAVES, false>), grid, block, 0, as_stream(stream), a);
@@ -453,7 +446,7 @@ extern "C" int csship_panel_linear(const void* a, int32_t prologue, const float*
   if (prologue == CSSHIP_PRO_LN && (!ln_g || !ln_b || !aligned16(ln_g) || !aligned16(ln_b))) return CSSHIP_ENULL;
   if ((epilogue & CSSHIP_EPI_RESIDUAL) && (!residual || !aligned16(residual) || (ldr & 3) != 0 || ldr < N || (N & 3) != 0))
     return CSSHIP_EALIGN;
-  LinArgs la{a, ln_g, ln_b, reinterpret_cast<const bf16x8*>(w_packed), bias, residual, out, M, N, ldo, ldr, alpha, g_stamps};
+  LinArgs la{a, ln_g, ln_b, reinterpret_cast<const bf16x8*>(w_packed), bias, residual, out, M, N, ldo, ldr, alpha, g_csship_stamps};
   hipStream_t s = as_stream(stream);
   const int key = prologue * 16 + epilogue;
   switch (key) {
@@ -468,6 +461,3 @@ extern "C" int csship_panel_linear(const void* a, int32_t prologue, const float*
   }
 }
 
-// Diagnostic only (not part of include/csship.h): device buffer of [n_workgroups][8] u64 that the
-// panel kernels fill with s_memrealtime phase stamps; pass NULL to switch stamping off.
-extern "C" void csship_debug_stamps(void* device_buffer) { g_stamps = reinterpret_cast<unsigned long long*>(device_buffer); }

@@ -1,0 +1,166 @@
+"""CPU-side tests: C-ABI surface, host-side packing/layout logic, trainer utilities, data parallel helpers
+(gloo, world_size 2).  No kernel is launched here."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+
+
+def test_abi_exports_every_declared_symbol():
+    """libcsship.so must export exactly the entry points include/csship.h declares."""
+    from css_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "csship.h")).read()
+    declared = set(re.findall(r"\b(csship_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 18
+    assert os.path.exists(_lib.LIB_PATH), "build the library first (python -c 'import __graft_entry__ as g; g.build()')"
+    h = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(h, name), f"{name} declared in csship.h but not exported"
+    assert declared == set(_lib.SIGNATURES), "ctypes signature table and header disagree"
+    lib = _lib.lib()
+    assert lib.csship_version() >= 100
+    assert b"NULL" in lib.csship_strerror(-5)
+
+
+def test_null_and_shape_errors_need_no_gpu():
+    """Argument validation happens on the host before any launch: safe to call without a GPU."""
+    from css_amd import _lib
+    lib = _lib.lib()
+    assert lib.csship_stft(None, 1, 0, 1, 0, 1024, None, None, None, None, None) == -5
+    assert lib.csship_mvn_stats(None, 1, 1, 1, 1, 0.0, 0.0, None, None, None) == -5
+    p = _lib.GemmParams(M=0, N=1, K=1)
+    assert lib.csship_gemm(ctypes.c_void_p(16), ctypes.c_void_p(16), None, None, ctypes.c_void_p(16), None, None,
+                           None, None, ctypes.byref(p), None) == -1
+
+
+def test_ops_refuse_cpu_tensors():
+    from css_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.stft(torch.zeros(1, 1024))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.mvn_stats(torch.zeros(1, 4, 257))
+    from css_amd.objectives import pit_loss
+    with pytest.raises(RuntimeError):
+        pit_loss(torch.zeros(2, 4, 8), torch.zeros(2, 4, 8), axis=0)
+
+
+def test_pack_frag_layout():
+    """block(rt, ks)[16*g + m][j] == W[16*rt + m][32*ks + 8*g + j], zero beyond R (include/csship.h)."""
+    from css_amd import ops
+    R, K = 40, 64
+    w = torch.arange(R * K, dtype=torch.float32).reshape(R, K) / 8.0  # exactly representable in bf16? keep small
+    w = (torch.arange(R)[:, None] * 1.0 + torch.arange(K)[None, :] * 0.0078125).float()
+    p = ops.pack_frag(w).float().view(3, 2, 64, 8)
+    wb = w.to(torch.bfloat16).float()
+    for rt, ks, g, m, j in [(0, 0, 0, 0, 0), (1, 1, 3, 15, 7), (2, 0, 2, 7, 3), (2, 1, 1, 8, 0)]:
+        r, k = 16 * rt + m, 32 * ks + 8 * g + j
+        want = wb[r, k] if r < R else 0.0
+        assert float(p[rt, ks, 16 * g + m, j]) == float(want)
+
+
+def test_pack_relpos_blocks():
+    from css_amd import ops
+    maxlen = 1000
+    pe = torch.randn(2 * maxlen, 64)
+    packed, qmin, qmax = ops.pack_relpos(pe, maxlen)
+    nq = qmax - qmin + 1
+    blk = packed.float().view(nq, 2, 64, 8)
+    peb = pe.to(torch.bfloat16).float()
+    for q, ks, g, m, j in [(0, 0, 0, 0, 0), (-3, 1, 2, 5, 7), (62, 0, 3, 15, 1), (qmin, 1, 1, 1, 1), (qmax, 0, 0, 9, 2)]:
+        rel = min(max(16 * q + 15 - m, -maxlen), maxlen - 1)
+        assert float(blk[q - qmin, ks, 16 * g + m, j]) == float(peb[rel + maxlen, 32 * ks + 8 * g + j])
+    # the end blocks are entirely clamped (kernel clamps q into [qmin, qmax])
+    assert 16 * qmin + 15 <= -maxlen and 16 * qmax >= maxlen - 1
+
+
+def test_model_registry_and_state_dict():
+    from css_amd.models import MODELS, build_model
+    keys = json.load(open(os.path.join(GOLDEN, "keys.json")))["conformer_base"]
+    import argparse
+    ap = argparse.ArgumentParser()
+    MODELS["Conformer"].add_args(ap)
+    conf = vars(ap.parse_args(["--conformer-relative-pos-emb", "true"]))
+    m = build_model("Conformer", conf)
+    assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == keys
+    with pytest.raises(RuntimeError, match="MI355X|cuda|CUDA"):
+        m(torch.zeros(1, 8, 257))  # CPU module: must fail loudly, never fall back
+
+
+def test_lr_scheduler_matches_reference_trace():
+    from css_amd.trainer import LRScheduler
+    tr = json.load(open(os.path.join(GOLDEN, "trainer.json")))
+    opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1e-3)
+    sch = LRScheduler(opt, types.SimpleNamespace(warmup=4, decay=0.1, fixed=2, min_lr=1e-9))
+    got = []
+    for _ in range(10):
+        got.append(sch.curr_lr)
+        sch.step(1.0)
+    assert np.allclose(got, tr["lr_trace"], rtol=1e-12, atol=0)
+    st = sch.state_dict()
+    sch2 = LRScheduler(opt, types.SimpleNamespace(warmup=0, decay=0.0, fixed=0, min_lr=0.0))
+    sch2.load_state_dict(st)
+    assert sch2.state_dict() == st
+
+
+def test_shard_range_partitions():
+    from css_amd.parallel import shard_range
+    for n in (0, 1, 7, 747, 1000):
+        for ws in (1, 2, 3, 8):
+            spans = [shard_range(n, r, ws) for r in range(ws)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(ws - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_average_parameters():
+    from css_amd.parallel import average_parameters
+    a = {"w": torch.tensor([1.0, 3.0]), "n": torch.tensor(4)}
+    b = {"w": torch.tensor([3.0, 5.0]), "n": torch.tensor(6)}
+    out = average_parameters([a, b])
+    assert torch.equal(out["w"], torch.tensor([2.0, 4.0])) and int(out["n"]) == 5 and out["n"].dtype == torch.int64
+
+
+WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["CSS_ROOT"])
+from css_amd import parallel
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, ws = dist.get_rank(), dist.get_world_size()
+torch.manual_seed(0)
+model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+data = torch.randn(8, 8); tgt = torch.randn(8, 4)
+# single-process big-batch gradient
+model.zero_grad(); torch.nn.functional.mse_loss(model(data), tgt).backward()
+ref = [p.grad.clone() for p in model.parameters()]
+# this rank's shard, then one flat all-reduce (mean)
+lo, hi = parallel.shard_range(8, rank, ws)
+model.zero_grad(); torch.nn.functional.mse_loss(model(data[lo:hi]), tgt[lo:hi]).backward()
+parallel.allreduce_gradients(model.parameters(), average=True)
+ok = all(torch.allclose(p.grad, r, atol=1e-6) for p, r in zip(model.parameters(), ref))
+# window gather
+local = torch.arange(lo, hi, dtype=torch.float32)[:, None].repeat(1, 3)
+full = parallel.gather_windows(local, 8, rank, ws)
+ok = ok and torch.equal(full[:, 0], torch.arange(8, dtype=torch.float32))
+dist.destroy_process_group()
+sys.exit(0 if ok else 3)
+"""
+
+
+def test_gradient_allreduce_gloo_world2(tmp_path):
+    """N-rank flat-bucket all-reduce == single-process big-batch gradient (equal shards, mean loss)."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, CSS_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
+    rcs = [p.wait(timeout=120) for p in procs]
+    assert rcs == [0, 0]
