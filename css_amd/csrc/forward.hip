@@ -72,10 +72,10 @@ extern "C" size_t csship_conformer_workspace(const csship_conformer_weights* w, 
 }
 
 extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const float* f, int64_t ldf, int32_t B,
-                                        int32_t T, float* masks, float* enc_out, void* workspace,
+                                        int32_t T, float* masks, int64_t ld_masks, float* enc_out, void* workspace,
                                         size_t workspace_bytes, csship_stream_t stream) {
   if (!w || !f || !masks || !workspace || !w->layers) return CSSHIP_ENULL;
-  if (B <= 0 || T <= 0 || ldf < w->idim) return CSSHIP_EBADSHAPE;
+  if (B <= 0 || T <= 0 || ldf < w->idim || ld_masks < w->n_out) return CSSHIP_EBADSHAPE;
   if (w->d_model != 256 || w->d_model / w->n_head != 64 || w->kernel_size != 33 || (w->d_ffn % 256) != 0 ||
       (w->idim_pad % 64) != 0 || w->idim_pad < w->idim)
     return CSSHIP_EUNSUPPORTED;
@@ -119,15 +119,6 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
   }
   // mask head: ReLU(Linear(d_model -> num_bins*(K+1)))         (conformer.py:98-100)
   TRY(csship_panel_linear(x, CSSHIP_PRO_F32, nullptr, nullptr, w->head_w, w->head_b, nullptr, 0, 0.f, masks,
-                          w->n_out, M, w->n_out, D, CSSHIP_EPI_RELU, stream));
+                          ld_masks, M, w->n_out, D, CSSHIP_EPI_RELU, stream));
   return CSSHIP_OK;
-}
-
-// ---- not built yet in this revision (declared in include/csship.h; fail loudly)
-extern "C" int csship_ipd(const float*, const float*, int64_t, int64_t, int64_t, const int32_t*, const int32_t*,
-                          int32_t, float*, int64_t, int64_t, float*, csship_stream_t) {
-  return CSSHIP_EUNSUPPORTED;
-}
-extern "C" int csship_istft(const float*, const float*, int64_t, int64_t, int64_t, float*, csship_stream_t) {
-  return CSSHIP_EUNSUPPORTED;
 }

@@ -44,31 +44,58 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
-// ---- per-(b, column) mean and 1/(unbiased std + eps) over T.  Workgroup = (b, 64 columns);
-// wave w walks rows t = w, w+4, ...; two passes (mean, centred sum of squares) like torch.
-__global__ __launch_bounds__(256) void mvn_stats_kernel(const float* __restrict__ x, int T, int F, int64_t ldx,
-                                                        float clamp_min, float eps, float* __restrict__ mean,
-                                                        float* __restrict__ rinv) {
-  __shared__ float red[4][64];
+// ---- per-(b, column) mean and 1/(unbiased std + eps) over T.  Workgroup = (b, 64 columns), 8 waves;
+// wave w walks rows t = w, w+8, ... with 8 independent loads in flight; two passes (mean, centred sum
+// of squares) like torch, the second one served from L2.
+constexpr int MV_W = 8;
+__global__ __launch_bounds__(MV_W * 64) void mvn_stats_kernel(const float* __restrict__ x, int T, int F, int64_t ldx,
+                                                             float clamp_min, float eps, float* __restrict__ mean,
+                                                             float* __restrict__ rinv) {
+  __shared__ float red[MV_W][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int b = blockIdx.y, f = blockIdx.x * 64 + lane;
   const bool ok = f < F;
   const float* xb = x + (size_t)b * T * ldx + (ok ? f : 0);
   float s = 0.f;
-  for (int t = w; t < T; t += 4) s += fmaxf(xb[(size_t)t * ldx], clamp_min);
+  int t = w;
+  for (; t + 7 * MV_W < T; t += 8 * MV_W) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = xb[(size_t)(t + i * MV_W) * ldx];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += fmaxf(v[i], clamp_min);
+  }
+  for (; t < T; t += MV_W) s += fmaxf(xb[(size_t)t * ldx], clamp_min);
   red[w][lane] = s;
   __syncthreads();
-  const float mu = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)T;
+  float mu = 0.f;
+#pragma unroll
+  for (int i = 0; i < MV_W; ++i) mu += red[i][lane];
+  mu /= (float)T;
   __syncthreads();
   float ss = 0.f;
-  for (int t = w; t < T; t += 4) {
+  t = w;
+  for (; t + 7 * MV_W < T; t += 8 * MV_W) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = xb[(size_t)(t + i * MV_W) * ldx];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float d = fmaxf(v[i], clamp_min) - mu;
+      ss += d * d;
+    }
+  }
+  for (; t < T; t += MV_W) {
     const float d = fmaxf(xb[(size_t)t * ldx], clamp_min) - mu;
     ss += d * d;
   }
   red[w][lane] = ss;
   __syncthreads();
   if (w == 0 && ok) {
-    const float var = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)(T - 1);
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < MV_W; ++i) var += red[i][lane];
+    var /= (float)(T - 1);
     mean[(size_t)b * F + f] = mu;
     rinv[(size_t)b * F + f] = 1.f / (sqrtf(var) + eps);
   }
@@ -125,7 +152,7 @@ extern "C" int csship_mvn_stats(const float* x, int64_t B, int64_t T, int64_t F,
   if (!x || !mean || !rinv) return CSSHIP_ENULL;
   if (B <= 0 || T <= 0 || F <= 0 || ldx < F || B > 65535) return CSSHIP_EBADSHAPE;
   dim3 grid((unsigned)((F + 63) / 64), (unsigned)B);
-  hipLaunchKernelGGL(mvn_stats_kernel, grid, dim3(256), 0, as_stream(stream), x, (int)T, (int)F, ldx, clamp_min, eps,
+  hipLaunchKernelGGL(mvn_stats_kernel, grid, dim3(MV_W * 64), 0, as_stream(stream), x, (int)T, (int)F, ldx, clamp_min, eps,
                      mean, rinv);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;

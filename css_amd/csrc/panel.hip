@@ -353,14 +353,14 @@ __global__ __launch_bounds__(NW * 64) void panel_linear_kernel(LinArgs a) {
     park_tiles<NT, RELU>(Ys, acc, nt, wave * NT * 16, g, n, bb);
     __syncthreads();
     const int f0 = p * 256, ncols = min(256, a.N - f0);
-    if (vec_ok && (ncols & 7) == 0) {
+    if (vec_ok) {  // rows are 16-byte aligned: vector stores, scalar tail for ncols % 8 != 0
       if (row < a.M) {
         if constexpr (OBF) {
           unsigned short* o = reinterpret_cast<unsigned short*>(a.out) + (size_t)row * a.ldo + f0;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int c = (i * 8 + part) * 8;
-            if (c < ncols) {
+            if (c + 7 < ncols) {
               float4 y0 = *reinterpret_cast<const float4*>(Ys + r * YS + c);
               float4 y1 = *reinterpret_cast<const float4*>(Ys + r * YS + c + 4);
               if constexpr (RES) {
@@ -370,6 +370,12 @@ __global__ __launch_bounds__(NW * 64) void panel_linear_kernel(LinArgs a) {
                 y1 = make_float4(x1.x + a.alpha * y1.x, x1.y + a.alpha * y1.y, x1.z + a.alpha * y1.z, x1.w + a.alpha * y1.w);
               }
               *reinterpret_cast<uint4*>(o + c) = make_uint4(pack_bf2(y0.x, y0.y), pack_bf2(y0.z, y0.w), pack_bf2(y1.x, y1.y), pack_bf2(y1.z, y1.w));
+            } else {
+              for (int e = c; e < min(c + 8, ncols); ++e) {
+                float y = Ys[r * YS + e];
+                if constexpr (RES) y = a.res[(size_t)row * a.ldr + f0 + e] + a.alpha * y;
+                o[e] = f2bf(y);
+              }
             }
           }
         } else {
@@ -377,13 +383,19 @@ __global__ __launch_bounds__(NW * 64) void panel_linear_kernel(LinArgs a) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const int c = (i * 8 + part) * 4;
-            if (c < ncols) {
+            if (c + 3 < ncols) {
               float4 y = *reinterpret_cast<const float4*>(Ys + r * YS + c);
               if constexpr (RES) {
                 const float4 x0 = *reinterpret_cast<const float4*>(a.res + (size_t)row * a.ldr + f0 + c);
                 y = make_float4(x0.x + a.alpha * y.x, x0.y + a.alpha * y.y, x0.z + a.alpha * y.z, x0.w + a.alpha * y.w);
               }
               *reinterpret_cast<float4*>(o + c) = y;
+            } else {
+              for (int e = c; e < min(c + 4, ncols); ++e) {
+                float y = Ys[r * YS + e];
+                if constexpr (RES) y = a.res[(size_t)row * a.ldr + f0 + e] + a.alpha * y;
+                o[e] = y;
+              }
             }
           }
         }

@@ -1,0 +1,243 @@
+// Inter-channel phase difference features (css/executor/feature.py:105-134) and the inverse STFT used
+// after beamforming (torch.istft(center=True, hann) at css/executor/beamformer.py:83-102).
+#include "common.hpp"
+
+namespace {
+
+constexpr int NBIN = 257;
+
+// cos / sin of (phase_l - phase_r) from the complex spectra, without atan2/cos/sin round trips:
+//   e^{i(pl - pr)} = u_l * conj(u_r),  u = (re, im)/|.|   (|.| = 0 -> phase 0 like atan2(0, 0))
+DEV void unit_phase(float re, float im, float& c, float& s) {
+  const float m2 = re * re + im * im;
+  if (m2 > 0.f) {
+    const float r = rsqrtf(m2);
+    c = re * r;
+    s = im * r;
+  } else {
+    c = 1.f;
+    s = 0.f;
+  }
+}
+DEV void phase_diff(float rl, float il, float rr, float ir, float& yr, float& yi) {
+  float cl, sl, cr, sr;
+  unit_phase(rl, il, cl, sl);
+  unit_phase(rr, ir, cr, sr);
+  yr = cl * cr + sl * sr;
+  yi = sl * cr - cl * sr;
+}
+
+struct Pairs {
+  int l[16], r[16];
+};
+
+// pass 1: time means of cos / sin per (b, pair, bin).  Workgroup = (64 bins, pair, b), 8 waves over t.
+__global__ __launch_bounds__(512) void ipd_mean_kernel(const float* __restrict__ re, const float* __restrict__ im,
+                                                       int C, int T, Pairs pr, float* __restrict__ means /*[B,P,2,257]*/) {
+  __shared__ float red[2][8][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int f = blockIdx.x * 64 + lane, p = blockIdx.y, b = blockIdx.z, P = gridDim.y;
+  const bool ok = f < NBIN;
+  const size_t cl = ((size_t)b * C + pr.l[p]) * T, cr = ((size_t)b * C + pr.r[p]) * T;
+  float sr = 0.f, si = 0.f;
+  for (int t = w; t < T; t += 8) {
+    if (ok) {
+      const size_t ol = (cl + t) * NBIN + f, orr = (cr + t) * NBIN + f;
+      float yr, yi;
+      phase_diff(re[ol], im[ol], re[orr], im[orr], yr, yi);
+      sr += yr;
+      si += yi;
+    }
+  }
+  red[0][w][lane] = sr;
+  red[1][w][lane] = si;
+  __syncthreads();
+  if (w == 0 && ok) {
+    float a = 0.f, c = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      a += red[0][i][lane];
+      c += red[1][i][lane];
+    }
+    means[(((size_t)b * P + p) * 2 + 0) * NBIN + f] = a / (float)T;
+    means[(((size_t)b * P + p) * 2 + 1) * NBIN + f] = c / (float)T;
+  }
+}
+
+// pass 2: ipd = atan2(sin - mean sin, cos - mean cos), written transposed ([.., bin, t]) through a 32x32 tile
+__global__ __launch_bounds__(256) void ipd_out_kernel(const float* __restrict__ re, const float* __restrict__ im, int C,
+                                                      int T, Pairs pr, int P, const float* __restrict__ means,
+                                                      float* __restrict__ out, int64_t out_bs, int64_t f_off) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int bp = blockIdx.z, b = bp / P, p = bp % P;
+  const int t0 = blockIdx.y * 32, f0 = blockIdx.x * 32;
+  const size_t cl = ((size_t)b * C + pr.l[p]) * T, cr = ((size_t)b * C + pr.r[p]) * T;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t = t0 + ty + 8 * i, f = f0 + tx;
+    float v = 0.f;
+    if (t < T && f < NBIN) {
+      const size_t ol = (cl + t) * NBIN + f, orr = (cr + t) * NBIN + f;
+      float yr, yi;
+      phase_diff(re[ol], im[ol], re[orr], im[orr], yr, yi);
+      const float mr = means[(((size_t)b * P + p) * 2 + 0) * NBIN + f];
+      const float mi = means[(((size_t)b * P + p) * 2 + 1) * NBIN + f];
+      v = atan2f(yi - mi, yr - mr);
+    }
+    tile[ty + 8 * i][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = f0 + ty + 8 * i, t = t0 + tx;
+    if (t < T && f < NBIN) out[(size_t)b * out_bs + (f_off + (size_t)p * NBIN + f) * T + t] = tile[tx][ty + 8 * i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------ iSTFT
+// One wave per frame: 512-point inverse real FFT as conj(FFT256(conj(Z)))/256 with
+//   Z[k] = Xe[k] + i Xo[k],  Xe = (X[k] + conj X[256-k])/2,  Xo = (X[k] - conj X[256-k])/2 * e^{+2 pi i k/512},
+// using the same in-register radix-4 + 6 shuffle radix-2 DIF stages as the forward STFT.  A workgroup
+// owns output samples of FBI consecutive hops; it synthesises FBI+1 windowed frames into LDS, overlap-adds
+// and divides by the Hann^2 envelope (torch.istft semantics, center=True: 256 samples trimmed on the left).
+constexpr int FBI = 16;
+
+struct cplx {
+  float x, y;
+};
+DEV cplx cmul(cplx a, cplx b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+DEV cplx cis_pi(float t) {
+  cplx r;
+  sincospif(t, &r.y, &r.x);
+  return r;
+}
+
+__global__ __launch_bounds__(256) void istft_kernel(const float* __restrict__ re, const float* __restrict__ im, int T,
+                                                    int64_t length, float* __restrict__ wav) {
+  __shared__ float sre[NBIN][FBI + 2], sim[NBIN][FBI + 2];  // spectra of frames t0-1 .. t0+FBI-1, [bin][frame]
+  __shared__ __attribute__((aligned(16))) float frames[FBI + 1][512];  // windowed time frames
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  const int64_t s = blockIdx.y;
+  const int t0 = blockIdx.x * FBI;  // hop index: this workgroup writes padded samples [256*t0, 256*(t0+FBI))
+
+  for (int i = tid; i < NBIN * (FBI + 1); i += 256) {
+    const int k = i / (FBI + 1), j = i % (FBI + 1);
+    const int t = t0 - 1 + j;
+    const bool ok = t >= 0 && t < T;
+    sre[k][j] = ok ? re[((size_t)s * NBIN + k) * T + t] : 0.f;
+    sim[k][j] = ok ? im[((size_t)s * NBIN + k) * T + t] : 0.f;
+  }
+  cplx tw1[4], tws[6], twp[4];
+  float win[8];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int n = 2 * (4 * (int)(__brev((unsigned)l) >> 26) + q);  // output sample pair index of reg q (natural order)
+    win[2 * q] = 0.5f - 0.5f * cospif((float)n * (1.f / 256.f));
+    win[2 * q + 1] = 0.5f - 0.5f * cospif((float)(n + 1) * (1.f / 256.f));
+    tw1[q] = cis_pi(-(float)(l * q) * (1.f / 128.f));
+    twp[q] = cis_pi((float)(l + 64 * q) * (1.f / 256.f));  // e^{+2 pi i k/512}, k = l + 64q
+  }
+#pragma unroll
+  for (int st = 0; st < 6; ++st) {
+    const int half = 32 >> st, m = 2 * half, p = l & (m - 1);
+    tws[st] = (p >= half) ? cis_pi(-2.f * (float)(p - half) / (float)m) : cplx{1.f, 0.f};
+  }
+  const int kbr = (int)(__brev((unsigned)l) >> 26);
+  __syncthreads();
+
+  for (int j = w; j < FBI + 1; j += 4) {
+    const int t = t0 - 1 + j;
+    if (t < 0 || t >= T) {  // frame outside the signal contributes nothing
+      for (int i = l; i < 512; i += 64) frames[j][i] = 0.f;
+      continue;
+    }
+    // conj(Z[k]) for k = l + 64q
+    cplx z[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = l + 64 * q, kc = 256 - k;  // kc in 1..256
+      const cplx A = {sre[k][j], sim[k][j]}, Bc = {sre[kc][j], -sim[kc][j]};
+      const cplx E = {0.5f * (A.x + Bc.x), 0.5f * (A.y + Bc.y)};
+      const cplx O = cmul({0.5f * (A.x - Bc.x), 0.5f * (A.y - Bc.y)}, twp[q]);
+      // Z = E + i O ;  conj(Z) = (E.x - O.y, -(E.y + O.x))
+      z[q] = {E.x - O.y, -(E.y + O.x)};
+    }
+    const cplx a02 = {z[0].x + z[2].x, z[0].y + z[2].y}, s02 = {z[0].x - z[2].x, z[0].y - z[2].y};
+    const cplx a13 = {z[1].x + z[3].x, z[1].y + z[3].y}, s13 = {z[1].x - z[3].x, z[1].y - z[3].y};
+    cplx u[4];
+    u[0] = {a02.x + a13.x, a02.y + a13.y};
+    u[1] = cmul({s02.x + s13.y, s02.y - s13.x}, tw1[1]);
+    u[2] = cmul({a02.x - a13.x, a02.y - a13.y}, tw1[2]);
+    u[3] = cmul({s02.x - s13.y, s02.y + s13.x}, tw1[3]);
+#pragma unroll
+    for (int st = 0; st < 6; ++st) {
+      const int half = 32 >> st;
+      const bool upper = (l & half) != 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ox = __shfl_xor(u[r].x, half), oy = __shfl_xor(u[r].y, half);
+        const cplx d = upper ? cplx{ox - u[r].x, oy - u[r].y} : cplx{u[r].x + ox, u[r].y + oy};
+        u[r] = cmul(d, tws[st]);
+      }
+    }
+    // lane l, reg r: FFT(conj Z)[n], n = 4*brev6(l) + r ;  z[n] = conj(.)/256 ;  x[2n] = Re, x[2n+1] = Im
+    float4 o0, o1;
+    o0.x = u[0].x * (1.f / 256.f) * win[0]; o0.y = -u[0].y * (1.f / 256.f) * win[1];
+    o0.z = u[1].x * (1.f / 256.f) * win[2]; o0.w = -u[1].y * (1.f / 256.f) * win[3];
+    o1.x = u[2].x * (1.f / 256.f) * win[4]; o1.y = -u[2].y * (1.f / 256.f) * win[5];
+    o1.z = u[3].x * (1.f / 256.f) * win[6]; o1.w = -u[3].y * (1.f / 256.f) * win[7];
+    *reinterpret_cast<float4*>(&frames[j][8 * kbr]) = o0;
+    *reinterpret_cast<float4*>(&frames[j][8 * kbr + 4]) = o1;
+  }
+  __syncthreads();
+  // overlap-add: padded sample p = 256*(t0 + h) + i gets frame (t0+h) [i] and frame (t0+h-1) [i + 256]
+  for (int idx = tid; idx < FBI * 256; idx += 256) {
+    const int h = idx >> 8, i = idx & 255;
+    const int64_t n = (int64_t)256 * (t0 + h) + i - 256;  // output index after trimming the centre padding
+    if (n < 0 || n >= length) continue;
+    const int tc = t0 + h, tp = tc - 1;
+    float acc = 0.f, env = 0.f;
+    const float w0 = 0.5f - 0.5f * cospif((float)i * (1.f / 256.f));
+    const float w1 = 0.5f - 0.5f * cospif((float)(i + 256) * (1.f / 256.f));
+    if (tc < T) { acc += frames[h + 1][i]; env += w0 * w0; }
+    if (tp >= 0 && tp < T) { acc += frames[h][i + 256]; env += w1 * w1; }
+    wav[(size_t)s * length + n] = acc / env;
+  }
+}
+
+}  // namespace
+
+extern "C" int csship_ipd(const float* re, const float* im, int64_t B, int64_t C, int64_t T, const int32_t* pairs_l,
+                          const int32_t* pairs_r, int32_t n_pairs, float* out, int64_t out_batch_stride, int64_t f_off,
+                          float* workspace, csship_stream_t stream) {
+  if (!re || !im || !pairs_l || !pairs_r || !out || !workspace) return CSSHIP_ENULL;
+  if (B <= 0 || C <= 0 || T <= 0 || n_pairs <= 0 || B * n_pairs > 65535 || (T + 31) / 32 > 65535) return CSSHIP_EBADSHAPE;
+  if (n_pairs > 16) return CSSHIP_EUNSUPPORTED;
+  Pairs pr{};
+  for (int i = 0; i < n_pairs; ++i) {
+    if (pairs_l[i] < 0 || pairs_l[i] >= C || pairs_r[i] < 0 || pairs_r[i] >= C) return CSSHIP_EBADSHAPE;
+    pr.l[i] = pairs_l[i];
+    pr.r[i] = pairs_r[i];
+  }
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(ipd_mean_kernel, dim3((NBIN + 63) / 64, n_pairs, (unsigned)B), dim3(512), 0, s, re, im, (int)C,
+                     (int)T, pr, workspace);
+  CSSHIP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(ipd_out_kernel, dim3((NBIN + 31) / 32, (unsigned)((T + 31) / 32), (unsigned)(B * n_pairs)),
+                     dim3(256), 0, s, re, im, (int)C, (int)T, pr, n_pairs, workspace, out, out_batch_stride, f_off);
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
+extern "C" int csship_istft(const float* re, const float* im, int64_t S, int64_t T, int64_t length, float* wav,
+                            csship_stream_t stream) {
+  if (!re || !im || !wav) return CSSHIP_ENULL;
+  if (S <= 0 || T <= 0 || length <= 0 || length > 256 * (T - 1) || S > 65535) return CSSHIP_EBADSHAPE;
+  // padded output index range [256, 256 + length): hops 1 .. (255 + length)/256
+  const int64_t nhop = (256 + length + 255) / 256;
+  hipLaunchKernelGGL(istft_kernel, dim3((unsigned)((nhop + FBI - 1) / FBI), (unsigned)S), dim3(256), 0, as_stream(stream),
+                     re, im, (int)T, length, wav);
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}

@@ -226,10 +226,11 @@ class Conformer(nn.Module):
         need = _lib.lib().csship_conformer_workspace(C.byref(w), B, T)
         if self._workspace is None or self._workspace.numel() < need or self._workspace.device != f.device:
             self._workspace = torch.empty(need, device=f.device, dtype=torch.uint8)
-        masks = torch.empty(B, T, w.n_out, device=f.device, dtype=torch.float32)
+        ld = (w.n_out + 3) // 4 * 4  # 16-byte aligned rows (771 -> 772): vector stores in the head kernel
+        masks = torch.empty(B, T, ld, device=f.device, dtype=torch.float32)[:, :, :w.n_out]
         enc_out = torch.empty(B, T, w.d_model, device=f.device, dtype=torch.float32) if want_encoder_out else None
         _lib.check(_lib.lib().csship_conformer_forward(
-            C.byref(w), ops._ptr(f), f.stride(1), B, T, ops._ptr(masks), ops._ptr(enc_out),
+            C.byref(w), ops._ptr(f), f.stride(1), B, T, ops._ptr(masks), masks.stride(1), ops._ptr(enc_out),
             ops._ptr(self._workspace), self._workspace.numel(), ops._stream()))
         return (masks, enc_out) if want_encoder_out else masks
 

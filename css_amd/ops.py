@@ -315,3 +315,17 @@ def panel_linear(a, wp, bias, N, *, ln=None, relu=False, residual=None, alpha=1.
                                     residual.stride(0) if residual is not None else 0, alpha, _ptr(out),
                                     out.stride(0), M, N, 256, epi, _stream()))
     return out
+
+
+def istft(re, im, length=None):
+    """re/im f32 [S, 257, T] (the reference's [B, F, T] layout) -> wav [S, length]; torch.istft(center=True, hann)."""
+    _need(re, torch.float32, "re")
+    _need(im, torch.float32, "im")
+    re, im = re.contiguous(), im.contiguous()
+    S, F, T = re.shape
+    assert F == NBIN and im.shape == re.shape
+    if length is None:
+        length = FRAME_HOP * (T - 1)
+    wav = torch.empty(S, length, device=re.device, dtype=torch.float32)
+    check(lib().csship_istft(_ptr(re), _ptr(im), S, T, length, _ptr(wav), _stream()))
+    return wav

@@ -238,11 +238,12 @@ typedef struct {
   const uint16_t* head_w; const float* head_b; /* PACKED bf16 from [n_out, d_model] */
 } csship_conformer_weights;
 size_t csship_conformer_workspace(const csship_conformer_weights* w, int32_t B, int32_t T);
-/* f: f32 [B, T, idim] (row stride ldf); masks: f32 [B, T, n_out]; enc_out (optional): f32
- * [B, T, d_model] encoder output before the head. */
+/* f: f32 [B, T, idim] (row stride ldf); masks: f32 [B, T, n_out] with row stride ld_masks >= n_out
+ * (a multiple of 4 enables vector stores); enc_out (optional): f32 [B, T, d_model] encoder output
+ * before the head. */
 int csship_conformer_forward(const csship_conformer_weights* w, const float* f, int64_t ldf,
-                             int32_t B, int32_t T, float* masks, float* enc_out, void* workspace,
-                             size_t workspace_bytes, csship_stream_t stream);
+                             int32_t B, int32_t T, float* masks, int64_t ld_masks, float* enc_out,
+                             void* workspace, size_t workspace_bytes, csship_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -84,6 +84,46 @@ def test_feature_extractor_golden(ops, golden):
     assert err(fw, torch.from_numpy(g["fw"])) < 5e-4
 
 
+def test_feature_extractor_7ch_ipd_golden(ops, golden):
+    from css_amd.executor.feature import FeatureExtractor
+    g = golden("stft.npz")
+    _, src = syn.synthetic_sources(2, 512 + 256 * 19, seed=3)
+    x7 = syn.synthetic_multichannel(src, n_ch=7, seed=3)
+    fe = FeatureExtractor(512, 256, ipd_index="1,0;2,0;3,0;4,0;5,0;6,0")
+    mag, f, re, im = fe.forward(x7.to(DEV))
+    assert f.shape == (2, 1799, 20) and re.shape == (2, 7, 257, 20)
+    assert err(mag, torch.from_numpy(g["mag7"])) < 5e-5
+    assert err(re, torch.from_numpy(g["re7"])) < 5e-5 and err(im, torch.from_numpy(g["im7"])) < 5e-5
+    assert err(f[:, :257], torch.from_numpy(g["f7"][:, :257])) < 5e-4
+    # IPD is an angle: compare on the circle.  atan2(yi - mean, yr - mean) is ill-conditioned where the centred
+    # vector is short (angle error ~ rounding / radius), so the bound is on error x radius, with the radius
+    # taken from the oracle; plus a plain bound on all well-conditioned points.
+    d = f[:, 257:].cpu().double() - torch.from_numpy(g["f7"][:, 257:]).double()
+    d = torch.atan2(torch.sin(d), torch.cos(d)).abs()
+    _, pha, _, _ = oracle.feature.stft(x7)
+    li, ri = oracle.feature.parse_ipd_index("1,0;2,0;3,0;4,0;5,0;6,0")
+    dl = (pha[:, li] - pha[:, ri]).double()
+    c, sn = torch.cos(dl), torch.sin(dl)
+    radius = torch.sqrt((c - c.mean(-1, keepdim=True)) ** 2 + (sn - sn.mean(-1, keepdim=True)) ** 2).reshape(2, -1, 20)
+    # measured: median 3e-7, max 9e-5 (low-magnitude bins: phase error = STFT abs error / |X|)
+    e = d * radius
+    assert float(e.flatten().quantile(0.99)) < 2e-5 and float(e.max()) < 3e-4
+    assert float(d[radius > 1e-2].max()) < 2e-2
+
+
+@pytest.mark.parametrize("T,length", [(20, None), (152, 38656), (33, 5000)])
+def test_istft(ops, T, length):
+    n = 256 * (T - 1)
+    x = rnd((3, n), 77, 0.1)
+    spec = torch.stft(x, 512, 256, window=torch.hann_window(512), center=True, return_complex=True)  # [3,257,T]
+    assert spec.shape[-1] == T
+    y = ops.istft(spec.real.contiguous().to(DEV), spec.imag.contiguous().to(DEV), length)
+    ref = torch.istft(spec, 512, 256, window=torch.hann_window(512), center=True, length=length)
+    assert y.shape == ref.shape
+    assert err(y, ref) < 2e-6 * 512  # f32 FFT round-off on signals of amplitude ~0.1
+    assert err(y, oracle.feature.istft_center(spec.real, spec.imag, 512, 256, length=y.shape[-1])) < 1e-5
+
+
 def test_mvn_stats(ops):
     x = rnd((3, 77, 257), 8).abs()
     mean, rinv = ops.mvn_stats(x.to(DEV))
