@@ -69,6 +69,8 @@ SIGNATURES = {
     "csship_pit_mse": (_i32, [_p, _i64, _p, _i64, C.POINTER(_p), _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p]),
     "csship_pit_mse_bwd": (_i32, [_p, _i64, _p, _i64, C.POINTER(_p), _p, _i32, _i32, _i32, _i32, _i32, _f32, _p, _p]),
     "csship_apply_masks": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p, _p]),
+    "csship_stitch_similarity": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _p, _p]),
+    "csship_stitch_connect": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _f32, _p, _p]),
     "csship_conformer_workspace": (_sz, [C.POINTER(ConformerWeights), _i32, _i32]),
     "csship_conformer_forward": (_i32, [C.POINTER(ConformerWeights), _p, _i64, _i32, _i32, _p, _i64, _p, _p, _sz, _p]),
 }

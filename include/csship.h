@@ -204,6 +204,16 @@ int csship_pit_mse_bwd(const float* masks, int64_t ld_mask, const float* f_orig,
                        int32_t T, int32_t F, int32_t K, int32_t n_masks, float grad_loss,
                        float* grad_masks, csship_stream_t stream);
 
+/* ------------------------------------------------------------------ stitching
+ * Stitcher.get_stitch / get_connect (css/executor/stitcher.py:14-110).
+ *   mags: f32 [W, F, T]; masks: f32 [W, F, T, 3] (spk1, spk2, noise);
+ *   sim:  f32 [W-1, 4] = S[i][j] at index 2*i + j (keep if S00 + S11 >= S01 + S10);
+ *   state: int32 [W] running swap parity per window; out: f32 [3, F, hop*(W-1) + T]. */
+int csship_stitch_similarity(const float* mags, const float* masks, int32_t W, int32_t F, int32_t T,
+                             int32_t margin, float* sim, csship_stream_t stream);
+int csship_stitch_connect(const float* masks, const int32_t* state, int32_t W, int32_t F, int32_t T,
+                          int32_t hop, float wta_floor, float* out, csship_stream_t stream);
+
 /* ------------------------------------------------------------------ whole forward
  * Conformer.forward (css/models/conformer.py:83-104) from the feature tensor to the
  * ReLU masks, as ONE host call that enqueues every kernel (no per-op Python overhead).
