@@ -59,6 +59,8 @@ SIGNATURES = {
     "csship_ipd": (_i32, [_p, _p, _i64, _i64, _i64, C.POINTER(_i32), C.POINTER(_i32), _i32, _p, _i64, _i64, _p, _p]),
     "csship_istft": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p]),
     "csship_layernorm": (_i32, [_p, _i64, _i32, _p, _p, _p, _p, _p]),
+    "csship_layernorm_relu": (_i32, [_p, _i64, _i32, _p, _p, _i32, _p, _p, _p]),
+    "csship_lstm_bidir": (_i32, [_p, _p, _p, _i32, _i32, _i32, _p]),
     "csship_gemm": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(GemmParams), _p]),
     "csship_ffn_fused": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _p]),
     "csship_panel_linear": (_i32, [_p, _i32, _p, _p, _p, _p, _p, _i64, _f32, _p, _i64, _i32, _i32, _i32, _i32, _p]),

@@ -44,6 +44,32 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
+// ---- LayerNorm for any D (BLSTM widths): one wave per row, strided scalar accesses, optional ReLU
+__global__ __launch_bounds__(256) void layernorm_any_kernel(const float* __restrict__ x, int64_t M, int D,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int relu,
+                                                            unsigned short* __restrict__ out_bf, float* __restrict__ out_f) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + row * D;
+  float s = 0.f;
+  for (int c = lane; c < D; c += 64) s += xr[c];
+  const float mean = wave_sum(s) / (float)D;
+  float ss = 0.f;
+  for (int c = lane; c < D; c += 64) {
+    const float d = xr[c] - mean;
+    ss += d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)D + 1e-5f);
+  for (int c = lane; c < D; c += 64) {
+    float y = (xr[c] - mean) * rstd * gamma[c] + beta[c];
+    if (relu) y = fmaxf(y, 0.f);
+    if (out_f) out_f[row * D + c] = y;
+    if (out_bf) out_bf[row * D + c] = f2bf(y);
+  }
+}
+
 // ---- per-(b, column) mean and 1/(unbiased std + eps) over T.  Workgroup = (b, 64 columns), 8 waves;
 // wave w walks rows t = w, w+8, ... with 8 independent loads in flight; two passes (mean, centred sum
 // of squares) like torch, the second one served from L2.
@@ -129,10 +155,22 @@ __global__ __launch_bounds__(256) void transpose_norm_kernel(const float* __rest
 
 }  // namespace
 
+extern "C" int csship_layernorm_relu(const float* x, int64_t M, int32_t D, const float* gamma, const float* beta,
+                                     int32_t relu, uint16_t* out_bf16, float* out_f32, csship_stream_t stream) {
+  if (!x || !gamma || !beta || (!out_bf16 && !out_f32)) return CSSHIP_ENULL;
+  if (M <= 0 || D <= 0) return CSSHIP_EBADSHAPE;
+  dim3 grid((unsigned)((M + 3) / 4));
+  hipLaunchKernelGGL(layernorm_any_kernel, grid, dim3(256), 0, as_stream(stream), x, M, D, gamma, beta, relu, out_bf16,
+                     out_f32);
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
 extern "C" int csship_layernorm(const float* x, int64_t M, int32_t D, const float* gamma, const float* beta,
                                 uint16_t* out_bf16, float* out_f32, csship_stream_t stream) {
   if (!x || !gamma || !beta || (!out_bf16 && !out_f32)) return CSSHIP_ENULL;
   if (M <= 0) return CSSHIP_EBADSHAPE;
+  if (D != 256 && D != 512) return csship_layernorm_relu(x, M, D, gamma, beta, 0, out_bf16, out_f32, stream);
   if (!aligned16(x) || !aligned16(gamma) || !aligned16(beta) || (out_f32 && !aligned16(out_f32)) ||
       (out_bf16 && !aligned8(out_bf16)))
     return CSSHIP_EALIGN;

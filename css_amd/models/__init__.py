@@ -1,8 +1,9 @@
 """Model registry -- same shape as css/models/__init__.py:19-27 (MODELS dict + build_model)."""
-from . import conformer
+from . import blstm, conformer
 
 MODELS = {
     "Conformer": conformer.Conformer,
+    "BLSTM": blstm.BLSTM,
 }
 
 

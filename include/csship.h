@@ -92,6 +92,19 @@ int csship_istft(const float* re, const float* im, int64_t S, int64_t T, int64_t
 int csship_layernorm(const float* x, int64_t M, int32_t D, const float* gamma, const float* beta,
                      uint16_t* out_bf16, float* out_f32, csship_stream_t stream);
 
+/* LayerNorm for any D, optionally followed by ReLU (BLSTM embed: Linear + LayerNorm + ReLU,
+ * css/models/blstm.py:105-110; BLSTMLayer LayerNorm, blstm.py:146). */
+int csship_layernorm_relu(const float* x, int64_t M, int32_t D, const float* gamma, const float* beta,
+                          int32_t relu, uint16_t* out_bf16, float* out_f32, csship_stream_t stream);
+
+/* Bidirectional LSTM recurrence (torch.nn.LSTM(bidirectional=True, batch_first=True), zero initial state,
+ * gate order i,f,g,o; css/models/blstm.py:139-145).  gx: f32 [B, T, 2, 4H] = x W_ih^T + b_ih + b_hh for
+ * (forward, reverse); whh_packed: both directions' W_hh [4H, H] in MFMA fragment order (csship_ffn_fused
+ * layout, K zero padded to a multiple of 32), direction-major; out: f32 [B, T, 2H] (forward | reverse).
+ * H % 16 == 0, and H % 128 == 0 when H > 128. */
+int csship_lstm_bidir(const float* gx, const uint16_t* whh_packed, float* out, int32_t B, int32_t T,
+                      int32_t H, csship_stream_t stream);
+
 /* C[M,N] = epilogue( A[M,K] @ W[N,K]^T + bias ).  bf16 MFMA, fp32 accumulate.
  * Replaces every torch.nn.Linear on the path (css/models/conformer.py:98,124,205-209,
  * 315-318).  W is bf16 [N, ldw] with ldw a multiple of 64 and >= K, zero padded. */

@@ -113,3 +113,32 @@ def test_no_cpu_path():
                                                    relative_pos_emb=True))
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 10, 257))
+
+
+def test_blstm_golden(golden):
+    """config[0] shape class: BLSTM 1ch 2-spk (tiny hidden size) vs the reference golden masks / y_pred."""
+    from css_amd.models import MODELS
+    g = golden("blstm.npz")
+    m = MODELS["BLSTM"](257, 257, 2, 1, dict(hidden_dim=64, num_layers=2, dropout_rate=0.1))
+    m.load_state_dict(syn.fill_state_dict(syn.blstm_shapes(hidden_dim=64, num_layers=2), 50))
+    m = m.to(DEV).eval()
+    fb = rnd((2, 30, 257), 16).abs()
+    y_pred, masks = m(fb.to(DEV))
+    mse = mask_mse(torch.stack(masks, 0), torch.from_numpy(g["masks"]))
+    print(f"[parity] BLSTM tiny: mask MSE vs reference {mse:.3e}")
+    assert mse < 1e-4 and mask_mse(y_pred, torch.from_numpy(g["y_pred"])) < 1e-4
+
+
+def test_blstm_default_width_vs_oracle():
+    """CLI-default width (hdim 1024 -> H = 512 per direction: streamed W_hh, 4 unit tiles per wave), 1 layer."""
+    from css_amd.models import MODELS
+    m = MODELS["BLSTM"](257, 257, 2, 1, dict(hidden_dim=1024, num_layers=1, dropout_rate=0.1))
+    sd = syn.fill_state_dict(syn.blstm_shapes(hidden_dim=1024, num_layers=1), 52)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    fb = rnd((3, 40, 257), 17).abs()
+    _, masks = m(fb.to(DEV))
+    _, o_masks = oracle.blstm.forward(fb, sd, num_layers=1)
+    mse = mask_mse(torch.stack(masks, 0), torch.stack(o_masks, 0))
+    print(f"[parity] BLSTM hdim 1024: mask MSE vs oracle {mse:.3e}")
+    assert mse < 1e-4
