@@ -94,23 +94,25 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
                     stream));
   }
   float *x = ws.x0, *y = ws.x1;
+  // row-local operators are chained per 64-row panel (csship_encoder_chain):
+  //   [FFN_out(l-1) + block LN] -> FFN_in(l) -> pre-LN + q/k/v projection(l)
   for (int l = 0; l < w->n_layer; ++l) {
     const csship_layer_weights& L = w->layers[l];
-    // x += 0.5 * FFN_in(x)                                   (conformer.py:355)
-    TRY(csship_ffn_fused(x, x, L.ffn_in.ln_g, L.ffn_in.ln_b, L.ffn_in.w1, L.ffn_in.b1, L.ffn_in.w2, L.ffn_in.b2,
-                         nullptr, nullptr, M, D, FF, 0.5f, stream));
+    const csship_layer_weights* P = l > 0 ? &w->layers[l - 1] : nullptr;
+    TRY(csship_encoder_chain(x, x, P ? &P->ffn_out : nullptr, P ? P->ln_g : nullptr, P ? P->ln_b : nullptr, &L.ffn_in,
+                             L.mha.ln_g, L.mha.ln_b, L.mha.wqkv, L.mha.bqkv, ws.qkv_bf, M, D, FF, 3 * D, stream));
     // x += MHA(x)                                            (conformer.py:356)
-    TRY(csship_panel_linear(x, CSSHIP_PRO_LN, L.mha.ln_g, L.mha.ln_b, L.mha.wqkv, L.mha.bqkv, nullptr, 0, 0.f,
-                            ws.qkv_bf, 3 * D, M, 3 * D, D, CSSHIP_EPI_OUT_BF16, stream));
     TRY(csship_mha_relpos(ws.qkv_bf, w->pe_k, w->pe_q_min, w->pe_q_max, ws.ao_bf, B, T, w->n_head, stream));
     TRY(csship_panel_linear(ws.ao_bf, CSSHIP_PRO_BF16, nullptr, nullptr, L.mha.wo, L.mha.bo, x, D, 1.f, x, D, M, D,
                             D, CSSHIP_EPI_RESIDUAL, stream));
     // x += Conv(x)                                           (conformer.py:357)
     TRY(csship_convmod(x, y, &L.conv, B, T, D, w->kernel_size, w->bn_mode, ws.conv_ws, stream));
     { float* t = x; x = y; y = t; }
-    // x = LN(x + 0.5 * FFN_out(x))                           (conformer.py:358-360)
-    TRY(csship_ffn_fused(x, x, L.ffn_out.ln_g, L.ffn_out.ln_b, L.ffn_out.w1, L.ffn_out.b1, L.ffn_out.w2,
-                         L.ffn_out.b2, L.ln_g, L.ln_b, M, D, FF, 0.5f, stream));
+  }
+  {  // x = LN(x + 0.5 * FFN_out(x)) of the last block          (conformer.py:358-360)
+    const csship_layer_weights& L = w->layers[w->n_layer - 1];
+    TRY(csship_encoder_chain(x, x, &L.ffn_out, L.ln_g, L.ln_b, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, M, D,
+                             FF, 0, stream));
   }
   if (enc_out) {
     if (hipMemcpyAsync(enc_out, x, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream)) !=

@@ -416,6 +416,198 @@ __global__ __launch_bounds__(NW * 64) void panel_linear_kernel(LinArgs a) {
   stamp(a.stamps, 5);
 }
 
+// =============================================================================== encoder chain
+// FFN_out(l-1) [+ block LayerNorm]  ->  FFN_in(l)  ->  pre-LN + q/k/v projection(l), all for one 64-row
+// panel that never leaves the CU between the stages: the residual rows live in registers (thread
+// (row = tid>>3, part = tid&7) owns 32 elements as 8 float4), activations in LDS, only weights stream in.
+// Saves, per encoder block, two launches and two panel prologue/epilogue round trips through L2.
+struct FfnW {
+  const float *ln_g, *ln_b;
+  const bf16x8* w1;
+  const float* b1;
+  const bf16x8* w2;
+  const float* b2;
+};
+struct ChainArgs {
+  const float* x;
+  float* xout;
+  FfnW fa;                      // stage A: FFN + residual + final LayerNorm (fin_g/fin_b)
+  const float *fin_g, *fin_b;
+  FfnW fb;                      // stage B: FFN + residual
+  const float *qln_g, *qln_b;   // stage C: LayerNorm -> [M,768] bf16
+  const bf16x8* wqkv;
+  const float* bqkv;
+  unsigned short* qkv;
+  int M, FF, NQKV;
+  float alpha;
+};
+
+// LayerNorm of the register rows -> bf16 activation panel in LDS
+DEV void rows_to_panel(unsigned char* panel, const float4 (&v)[8], const float* gam, const float* bet, int r, int part) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float mean = sum8(s) * (1.f / DM);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+    ss += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+  }
+  const float rstd = rsqrtf(sum8(ss) * (1.f / DM) + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c4 = i * 8 + part;
+    const float4 gm = *reinterpret_cast<const float4*>(gam + c4 * 4);
+    const float4 bt = *reinterpret_cast<const float4*>(bet + c4 * 4);
+    *reinterpret_cast<uint2*>(panel + panel_off(r, c4 >> 1) + (c4 & 1) * 8) =
+        make_uint2(pack_bf2((v[i].x - mean) * rstd * gm.x + bt.x, (v[i].y - mean) * rstd * gm.y + bt.y),
+                   pack_bf2((v[i].z - mean) * rstd * gm.z + bt.z, (v[i].w - mean) * rstd * gm.w + bt.w));
+  }
+}
+
+// one FeedForward on the register rows: v <- v + alpha * FFN(LN(v))  [-> LayerNorm(fin)]
+template <int NW, bool FINAL_LN>
+DEV void ffn_stage(float4 (&v)[8], unsigned char* Xs, unsigned char* Hraw, const FfnW& f, const float* fin_g,
+                   const float* fin_b, int FF, float alpha, int tid, int rot) {
+  constexpr int NT = 16 / NW;
+  const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15, r = tid >> 3, part = tid & 7;
+  const int nchunk = FF / DM, ks2 = FF / 32;
+  unsigned char* const Hs0 = Hraw;
+  unsigned char* const Hs1 = Hraw + PANEL_BYTES;
+  const bf16x8* w1s = f.w1 + (size_t)(wave * NT) * KS * 64 + lane;
+  const bf16x8* w2s = f.w2 + (size_t)(wave * NT) * ks2 * 64 + lane;
+  bf16x8 wq[PD][NT];
+  prefetch_first<NT>(wq, w1s + (size_t)(rot % nchunk) * 16 * KS * 64, KS, NT);
+  rows_to_panel(Xs, v, f.ln_g, f.ln_b, r, part);
+  __syncthreads();  // also: every wave has left the previous stage's Ys reads
+  f32x4 o[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) o[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int ci = 0; ci < nchunk; ++ci) {
+    const int c = (ci + rot) % nchunk;
+    f32x4 h[NT][4];
+    float4 bb[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      bb[t] = *reinterpret_cast<const float4*>(f.b1 + c * DM + (wave * NT + t) * 16 + 4 * g);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) h[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const bf16x8* w1c = w1s + (size_t)c * 16 * KS * 64;
+    const bf16x8* w2c = w2s + (size_t)c * KS * 64;
+    mma_pass<NT>(h, Xs, n, g, NT, w1c, KS, w2c, ks2, NT, wq);
+    unsigned char* hs = (ci & 1) ? Hs1 : Hs0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int hc = (wave * NT + t) * 16 + 4 * g;
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        const uint2 pk = make_uint2(pack_bf2(fmaxf(h[t][rt][0] + bb[t].x, 0.f), fmaxf(h[t][rt][1] + bb[t].y, 0.f)),
+                                    pack_bf2(fmaxf(h[t][rt][2] + bb[t].z, 0.f), fmaxf(h[t][rt][3] + bb[t].w, 0.f)));
+        *reinterpret_cast<uint2*>(hs + panel_off(rt * 16 + n, hc >> 3) + (hc & 7) * 2) = pk;
+      }
+    }
+    __syncthreads();
+    const bf16x8* w1n = w1s + (size_t)((c + 1) % nchunk) * 16 * KS * 64;
+    mma_pass<NT>(o, hs, n, g, NT, w2c, ks2, w1n, KS, NT, wq);
+  }
+  float4 b2v[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) b2v[t] = *reinterpret_cast<const float4*>(f.b2 + (wave * NT + t) * 16 + 4 * g);
+  __syncthreads();  // every wave is done reading the hidden panels
+  float* ys = reinterpret_cast<float*>(Hraw);
+  park_tiles<NT, false>(ys, o, NT, wave * NT * 16, g, n, b2v);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float4 y = *reinterpret_cast<const float4*>(ys + r * YS + (i * 8 + part) * 4);
+    v[i] = make_float4(v[i].x + alpha * y.x, v[i].y + alpha * y.y, v[i].z + alpha * y.z, v[i].w + alpha * y.w);
+  }
+  if constexpr (FINAL_LN) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    const float mean = sum8(s) * (1.f / DM);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+      ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float rstd = rsqrtf(sum8(ss) * (1.f / DM) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4 gm = *reinterpret_cast<const float4*>(fin_g + (i * 8 + part) * 4);
+      const float4 bt = *reinterpret_cast<const float4*>(fin_b + (i * 8 + part) * 4);
+      v[i].x = v[i].x * rstd * gm.x + bt.x; v[i].y = v[i].y * rstd * gm.y + bt.y;
+      v[i].z = v[i].z * rstd * gm.z + bt.z; v[i].w = v[i].w * rstd * gm.w + bt.w;
+    }
+  }
+}
+
+template <int NW, bool HAS_A, bool HAS_B, bool HAS_C>
+__global__ __launch_bounds__(NW * 64) void chain_kernel(ChainArgs a) {
+  static_assert(NW * 64 == 8 * BM, "row phases assume 8 lanes per panel row");
+  constexpr int NT = 16 / NW;
+  __shared__ __attribute__((aligned(16))) unsigned char Xs[PANEL_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char Hraw[YS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15;
+  const int r = tid >> 3, part = tid & 7;
+  const int m0 = blockIdx.x * BM, row = m0 + r, rowc = min(row, a.M - 1);
+  float4 v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(a.x + (size_t)rowc * DM + (i * 8 + part) * 4);
+  if constexpr (HAS_A) ffn_stage<NW, true>(v, Xs, Hraw, a.fa, a.fin_g, a.fin_b, a.FF, a.alpha, tid, blockIdx.x);
+  if constexpr (HAS_B) ffn_stage<NW, false>(v, Xs, Hraw, a.fb, nullptr, nullptr, a.FF, a.alpha, tid, blockIdx.x + 2);
+  if (row < a.M) {  // the residual stream the attention output projection adds to
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(a.xout + (size_t)row * DM + (i * 8 + part) * 4) = v[i];
+  }
+  if constexpr (HAS_C) {
+    const int ntiles = (a.NQKV + 15) / 16, npass = (ntiles + 15) / 16;
+    bf16x8 wq[PD][NT];
+    const bf16x8* wbase = a.wqkv + lane;
+    prefetch_first<NT>(wq, wbase + (size_t)(wave * NT) * KS * 64, KS, max(0, min(NT, ntiles - wave * NT)));
+    rows_to_panel(Xs, v, a.qln_g, a.qln_b, r, part);
+    __syncthreads();
+    float* Ys = reinterpret_cast<float*>(Hraw);
+    for (int p = 0; p < npass; ++p) {
+      const int tile0 = p * 16 + wave * NT;
+      const int nt = max(0, min(NT, ntiles - tile0));
+      const int nnt = max(0, min(NT, ntiles - (tile0 + 16)));
+      float4 bb[NT];
+      f32x4 acc[NT][4];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        bb[t] = load_bias4(a.bqkv, (tile0 + t) * 16 + 4 * g, a.NQKV);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      const bf16x8* wc = wbase + (size_t)tile0 * KS * 64;
+      mma_pass<NT>(acc, Xs, n, g, nt, wc, KS, wc + (size_t)16 * KS * 64, KS, nnt, wq);
+      park_tiles<NT, false>(Ys, acc, nt, wave * NT * 16, g, n, bb);
+      __syncthreads();
+      const int f0 = p * 256, ncols = min(256, a.NQKV - f0);  // NQKV % 8 == 0 (checked on the host)
+      if (row < a.M) {
+        unsigned short* o = a.qkv + (size_t)row * a.NQKV + f0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int c = (i * 8 + part) * 8;
+          if (c + 7 < ncols) {
+            const float4 y0 = *reinterpret_cast<const float4*>(Ys + r * YS + c);
+            const float4 y1 = *reinterpret_cast<const float4*>(Ys + r * YS + c + 4);
+            *reinterpret_cast<uint4*>(o + c) = make_uint4(pack_bf2(y0.x, y0.y), pack_bf2(y0.z, y0.w), pack_bf2(y1.x, y1.y), pack_bf2(y1.z, y1.w));
+          }
+        }
+      }
+      if (p + 1 < npass) __syncthreads();
+    }
+  }
+}
+
 constexpr int NWAVES = 8;
 
 template <int PRO, int EPI>
@@ -473,3 +665,33 @@ extern "C" int csship_panel_linear(const void* a, int32_t prologue, const float*
   }
 }
 
+
+extern "C" int csship_encoder_chain(const float* x, float* x_out, const csship_ffn_weights* ffn_a,
+                                    const float* final_ln_g, const float* final_ln_b, const csship_ffn_weights* ffn_b,
+                                    const float* qkv_ln_g, const float* qkv_ln_b, const uint16_t* wqkv_packed,
+                                    const float* bqkv, uint16_t* qkv_out, int32_t M, int32_t d_model, int32_t d_ffn,
+                                    int32_t n_qkv, csship_stream_t stream) {
+  if (!x || !x_out) return CSSHIP_ENULL;
+  if (M <= 0) return CSSHIP_EBADSHAPE;
+  if (d_model != DM || d_ffn <= 0 || (d_ffn % DM) != 0) return CSSHIP_EUNSUPPORTED;
+  const bool A = ffn_a != nullptr, Bs = ffn_b != nullptr, Cq = wqkv_packed != nullptr;
+  if (A && (!final_ln_g || !final_ln_b)) return CSSHIP_ENULL;
+  if (Cq && (!qkv_ln_g || !qkv_ln_b || !qkv_out || n_qkv <= 0 || (n_qkv % 8) != 0)) return CSSHIP_EBADSHAPE;
+  if (!aligned16(x) || !aligned16(x_out) || (Cq && (!aligned16(wqkv_packed) || !aligned16(qkv_out)))) return CSSHIP_EALIGN;
+  ChainArgs a{};
+  a.x = x; a.xout = x_out; a.M = M; a.FF = d_ffn; a.NQKV = n_qkv; a.alpha = 0.5f;
+  auto conv = [](const csship_ffn_weights* w) {
+    return FfnW{w->ln_g, w->ln_b, reinterpret_cast<const bf16x8*>(w->w1), w->b1, reinterpret_cast<const bf16x8*>(w->w2), w->b2};
+  };
+  if (A) { a.fa = conv(ffn_a); a.fin_g = final_ln_g; a.fin_b = final_ln_b; }
+  if (Bs) a.fb = conv(ffn_b);
+  if (Cq) { a.qln_g = qkv_ln_g; a.qln_b = qkv_ln_b; a.wqkv = reinterpret_cast<const bf16x8*>(wqkv_packed); a.bqkv = bqkv; a.qkv = qkv_out; }
+  dim3 grid((M + BM - 1) / BM), block(NWAVES * 64);
+  hipStream_t s = as_stream(stream);
+  if (A && Bs && Cq) hipLaunchKernelGGL((chain_kernel<NWAVES, true, true, true>), grid, block, 0, s, a);
+  else if (!A && Bs && Cq) hipLaunchKernelGGL((chain_kernel<NWAVES, false, true, true>), grid, block, 0, s, a);
+  else if (A && !Bs && !Cq) hipLaunchKernelGGL((chain_kernel<NWAVES, true, false, false>), grid, block, 0, s, a);
+  else return CSSHIP_EUNSUPPORTED;
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}

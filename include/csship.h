@@ -155,6 +155,21 @@ int csship_panel_linear(const void* a, int32_t prologue, const float* ln_g, cons
                         int64_t ldr, float alpha, void* out, int64_t ldo, int32_t M, int32_t N,
                         int32_t d_model, int32_t epilogue, csship_stream_t stream);
 
+/* csship_encoder_chain: the row-local operators between two attention/convolution stages as ONE kernel:
+ *   [ffn_a != NULL]  x = LayerNorm_final( x + 0.5 FFN_a(x) )      FFN_out of block l-1 (conformer.py:358-360)
+ *   [ffn_b != NULL]  x = x + 0.5 FFN_b(x)                         FFN_in of block l   (conformer.py:355)
+ *   x_out <- x
+ *   [wqkv != NULL]   qkv_out = bf16( LayerNorm_qkv(x) @ Wqkv^T + bqkv )   (conformer.py:222-225)
+ * Supported combinations: (a,b,qkv), (b,qkv), (a).  FFN weight structs are defined below
+ * (csship_ffn_weights, packed layout); x_out may alias x. */
+struct csship_ffn_weights_s;
+int csship_encoder_chain(const float* x, float* x_out, const struct csship_ffn_weights_s* ffn_a,
+                         const float* final_ln_g, const float* final_ln_b,
+                         const struct csship_ffn_weights_s* ffn_b, const float* qkv_ln_g,
+                         const float* qkv_ln_b, const uint16_t* wqkv_packed, const float* bqkv,
+                         uint16_t* qkv_out, int32_t M, int32_t d_model, int32_t d_ffn, int32_t n_qkv,
+                         csship_stream_t stream);
+
 /* Relative-position multi-head attention core, MultiHeadedAttention.forward
  * (css/models/conformer.py:229-253) with RelativePositionalEncoding
  * (conformer.py:179-185) folded in:
@@ -231,7 +246,7 @@ int csship_stitch_connect(const float* masks, const int32_t* state, int32_t W, i
  * Conformer.forward (css/models/conformer.py:83-104) from the feature tensor to the
  * ReLU masks, as ONE host call that enqueues every kernel (no per-op Python overhead).
  * All weight pointers are device pointers; the structs themselves live in host memory. */
-typedef struct {
+typedef struct csship_ffn_weights_s {
   const float *ln_g, *ln_b;
   const uint16_t* w1; const float* b1; /* PACKED bf16 from [d_ffn, d_model]; f32 [d_ffn] */
   const uint16_t* w2; const float* b2; /* PACKED bf16 from [d_model, d_ffn]; f32 [d_model] */
