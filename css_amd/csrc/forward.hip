@@ -77,7 +77,7 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
   if (!w || !f || !masks || !workspace || !w->layers) return CSSHIP_ENULL;
   if (B <= 0 || T <= 0 || ldf < w->idim || ld_masks < w->n_out) return CSSHIP_EBADSHAPE;
   if (w->d_model != 256 || w->d_model / w->n_head != 64 || w->kernel_size != 33 || (w->d_ffn % 256) != 0 ||
-      (w->idim_pad % 64) != 0 || w->idim_pad < w->idim)
+      (w->idim_pad % 256) != 0 || w->idim_pad < w->idim)
     return CSSHIP_EUNSUPPORTED;
   if (!aligned16(workspace)) return CSSHIP_EALIGN;
   Workspace ws = carve(w, B, T, workspace);
@@ -86,13 +86,8 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
 
   // input MVN over time (conformer.py:95) folded into the embed GEMM's A load
   TRY(csship_mvn_stats(f, B, T, w->idim, ldf, -INFINITY, 1.1920928955078125e-07f, ws.mean, ws.rinv, stream));
-  {
-    csship_gemm_params p{};
-    p.M = M; p.N = D; p.K = w->idim; p.lda = (int)ldf; p.ldw = w->idim_pad; p.ldc = D; p.ldr = D;
-    p.a_mode = CSSHIP_A_F32_MVN; p.epilogue = CSSHIP_EPI_LAYERNORM | CSSHIP_EPI_RELU; p.rows_per_batch = T;
-    TRY(csship_gemm(f, w->embed_w, w->embed_b, nullptr, ws.x0, ws.mean, ws.rinv, w->embed_ln_g, w->embed_ln_b, &p,
-                    stream));
-  }
+  TRY(csship_embed(f, ldf, ws.mean, ws.rinv, w->embed_w, w->embed_b, w->embed_ln_g, w->embed_ln_b, ws.x0, B, T, w->idim,
+                   D, stream));
   float *x = ws.x0, *y = ws.x1;
   // row-local operators are chained per 64-row panel (csship_encoder_chain):
   //   [FFN_out(l-1) + block LN] -> FFN_in(l) -> pre-LN + q/k/v projection(l)

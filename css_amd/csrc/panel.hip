@@ -608,6 +608,88 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(ChainArgs a) {
   }
 }
 
+// =============================================================================== embed
+// x0 = ReLU(LayerNorm(Linear(MVN_time(f))))   (css/models/conformer.py:95 + :124-129)
+// f: [B,T,idim] f32 with arbitrary idim (257, 1799): the input MVN is applied while the panel is built,
+// K is walked in 256-column chunks (weights packed with K zero-padded to a multiple of 256).
+struct EmbedArgs {
+  const float* f;
+  const float *mean, *rinv;  // [B, idim]
+  const bf16x8* w;           // packed [16][Kp/32][64]
+  const float* bias;
+  const float *ln_g, *ln_b;
+  float* out;
+  int M, T, idim, Kp;
+  int64_t ldf;
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void embed_kernel(EmbedArgs a) {
+  static_assert(NW * 64 == 8 * BM, "row phases assume 8 lanes per panel row");
+  constexpr int NT = 16 / NW;
+  __shared__ __attribute__((aligned(16))) unsigned char Xs[PANEL_BYTES];
+  __shared__ __attribute__((aligned(16))) float Ys[BM * YS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15;
+  const int r = tid >> 3, part = tid & 7;
+  const int m0 = blockIdx.x * BM, row = m0 + r, rowc = min(row, a.M - 1);
+  const int nkc = a.Kp / DM, kst = a.Kp / 32;
+  const float* fr = a.f + (size_t)rowc * a.ldf;
+  const size_t sb = (size_t)(rowc / a.T) * a.idim;
+  const bf16x8* wbase = a.w + (size_t)(wave * NT) * kst * 64 + lane;
+  bf16x8 wq[PD][NT];
+  prefetch_first<NT>(wq, wbase, kst, NT);
+  f32x4 acc[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) acc[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int kc = 0; kc < nkc; ++kc) {
+    if (kc > 0) __syncthreads();  // the previous chunk's panel has been consumed
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c4 = i * 8 + part, k = kc * DM + c4 * 4;
+      float e[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) e[q] = (k + q < a.idim) ? (fr[k + q] - a.mean[sb + k + q]) * a.rinv[sb + k + q] : 0.f;
+      *reinterpret_cast<uint2*>(Xs + panel_off(r, c4 >> 1) + (c4 & 1) * 8) = make_uint2(pack_bf2(e[0], e[1]), pack_bf2(e[2], e[3]));
+    }
+    __syncthreads();
+    const bf16x8* wc = wbase + (size_t)kc * KS * 64;
+    mma_pass<NT>(acc, Xs, n, g, NT, wc, kst, (kc + 1 < nkc) ? wc + (size_t)KS * 64 : wbase, kst, NT, wq);
+  }
+  float4 bb[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) bb[t] = *reinterpret_cast<const float4*>(a.bias + (wave * NT + t) * 16 + 4 * g);
+  park_tiles<NT, false>(Ys, acc, NT, wave * NT * 16, g, n, bb);
+  __syncthreads();
+  float4 v[8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    v[i] = *reinterpret_cast<const float4*>(Ys + r * YS + (i * 8 + part) * 4);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = sum8(s) * (1.f / DM);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+    ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+  }
+  const float rstd = rsqrtf(sum8(ss) * (1.f / DM) + 1e-5f);
+  if (row < a.M) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = (i * 8 + part) * 4;
+      const float4 gm = *reinterpret_cast<const float4*>(a.ln_g + c);
+      const float4 bt = *reinterpret_cast<const float4*>(a.ln_b + c);
+      *reinterpret_cast<float4*>(a.out + (size_t)row * DM + c) =
+          make_float4(fmaxf(v[i].x * rstd * gm.x + bt.x, 0.f), fmaxf(v[i].y * rstd * gm.y + bt.y, 0.f),
+                      fmaxf(v[i].z * rstd * gm.z + bt.z, 0.f), fmaxf(v[i].w * rstd * gm.w + bt.w, 0.f));
+    }
+  }
+}
+
 constexpr int NWAVES = 8;
 
 template <int PRO, int EPI>
@@ -692,6 +774,20 @@ extern "C" int csship_encoder_chain(const float* x, float* x_out, const csship_f
   else if (!A && Bs && Cq) hipLaunchKernelGGL((chain_kernel<NWAVES, false, true, true>), grid, block, 0, s, a);
   else if (A && !Bs && !Cq) hipLaunchKernelGGL((chain_kernel<NWAVES, true, false, false>), grid, block, 0, s, a);
   else return CSSHIP_EUNSUPPORTED;
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
+extern "C" int csship_embed(const float* f, int64_t ldf, const float* mvn_mean, const float* mvn_rinv,
+                            const uint16_t* w_packed, const float* bias, const float* ln_g, const float* ln_b, float* out,
+                            int32_t B, int32_t T, int32_t idim, int32_t d_model, csship_stream_t stream) {
+  if (!f || !mvn_mean || !mvn_rinv || !w_packed || !bias || !ln_g || !ln_b || !out) return CSSHIP_ENULL;
+  if (B <= 0 || T <= 0 || idim <= 0 || ldf < idim) return CSSHIP_EBADSHAPE;
+  if (d_model != DM) return CSSHIP_EUNSUPPORTED;
+  if (!aligned16(w_packed) || !aligned16(out) || !aligned16(bias) || !aligned16(ln_g) || !aligned16(ln_b)) return CSSHIP_EALIGN;
+  const int Kp = (idim + DM - 1) / DM * DM;
+  EmbedArgs a{f, mvn_mean, mvn_rinv, reinterpret_cast<const bf16x8*>(w_packed), bias, ln_g, ln_b, out, B * T, T, idim, Kp, ldf};
+  hipLaunchKernelGGL((embed_kernel<NWAVES>), dim3((B * T + BM - 1) / BM), dim3(NWAVES * 64), 0, as_stream(stream), a);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }

@@ -1,6 +1,6 @@
 // Inter-channel phase difference features (css/executor/feature.py:105-134) and the inverse STFT used
 // after beamforming (torch.istft(center=True, hann) at css/executor/beamformer.py:83-102).
-#include "common.hpp"
+#include "fft.hpp"
 
 namespace {
 
@@ -103,16 +103,6 @@ __global__ __launch_bounds__(256) void ipd_out_kernel(const float* __restrict__ 
 // and divides by the Hann^2 envelope (torch.istft semantics, center=True: 256 samples trimmed on the left).
 constexpr int FBI = 16;
 
-struct cplx {
-  float x, y;
-};
-DEV cplx cmul(cplx a, cplx b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
-DEV cplx cis_pi(float t) {
-  cplx r;
-  sincospif(t, &r.y, &r.x);
-  return r;
-}
-
 __global__ __launch_bounds__(256) void istft_kernel(const float* __restrict__ re, const float* __restrict__ im, int T,
                                                     int64_t length, float* __restrict__ wav) {
   __shared__ float sre[NBIN][FBI + 2], sim[NBIN][FBI + 2];  // spectra of frames t0-1 .. t0+FBI-1, [bin][frame]
@@ -130,19 +120,7 @@ __global__ __launch_bounds__(256) void istft_kernel(const float* __restrict__ re
   }
   cplx tw1[4], tws[6], twp[4];
   float win[8];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int n = 2 * (4 * (int)(__brev((unsigned)l) >> 26) + q);  // output sample pair index of reg q (natural order)
-    win[2 * q] = 0.5f - 0.5f * cospif((float)n * (1.f / 256.f));
-    win[2 * q + 1] = 0.5f - 0.5f * cospif((float)(n + 1) * (1.f / 256.f));
-    tw1[q] = cis_pi(-(float)(l * q) * (1.f / 128.f));
-    twp[q] = cis_pi((float)(l + 64 * q) * (1.f / 256.f));  // e^{+2 pi i k/512}, k = l + 64q
-  }
-#pragma unroll
-  for (int st = 0; st < 6; ++st) {
-    const int half = 32 >> st, m = 2 * half, p = l & (m - 1);
-    tws[st] = (p >= half) ? cis_pi(-2.f * (float)(p - half) / (float)m) : cplx{1.f, 0.f};
-  }
+  fft_load_consts(1, l, win, tw1, tws, twp);
   const int kbr = (int)(__brev((unsigned)l) >> 26);
   __syncthreads();
 
@@ -163,24 +141,8 @@ __global__ __launch_bounds__(256) void istft_kernel(const float* __restrict__ re
       // Z = E + i O ;  conj(Z) = (E.x - O.y, -(E.y + O.x))
       z[q] = {E.x - O.y, -(E.y + O.x)};
     }
-    const cplx a02 = {z[0].x + z[2].x, z[0].y + z[2].y}, s02 = {z[0].x - z[2].x, z[0].y - z[2].y};
-    const cplx a13 = {z[1].x + z[3].x, z[1].y + z[3].y}, s13 = {z[1].x - z[3].x, z[1].y - z[3].y};
     cplx u[4];
-    u[0] = {a02.x + a13.x, a02.y + a13.y};
-    u[1] = cmul({s02.x + s13.y, s02.y - s13.x}, tw1[1]);
-    u[2] = cmul({a02.x - a13.x, a02.y - a13.y}, tw1[2]);
-    u[3] = cmul({s02.x - s13.y, s02.y + s13.x}, tw1[3]);
-#pragma unroll
-    for (int st = 0; st < 6; ++st) {
-      const int half = 32 >> st;
-      const bool upper = (l & half) != 0;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float ox = __shfl_xor(u[r].x, half), oy = __shfl_xor(u[r].y, half);
-        const cplx d = upper ? cplx{ox - u[r].x, oy - u[r].y} : cplx{u[r].x + ox, u[r].y + oy};
-        u[r] = cmul(d, tws[st]);
-      }
-    }
+    fft256_wave(z, u, tw1, tws, l);
     // lane l, reg r: FFT(conj Z)[n], n = 4*brev6(l) + r ;  z[n] = conj(.)/256 ;  x[2n] = Re, x[2n+1] = Im
     float4 o0, o1;
     o0.x = u[0].x * (1.f / 256.f) * win[0]; o0.y = -u[0].y * (1.f / 256.f) * win[1];

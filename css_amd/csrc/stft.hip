@@ -7,29 +7,20 @@
 //   * 512 real points are packed as 256 complex z[n] = x[2n] + i x[2n+1]; lane l holds
 //     z[l], z[l+64], z[l+128], z[l+192]: one radix-4 butterfly in registers, then four
 //     independent 64-point FFTs ACROSS the lanes as 6 radix-2 DIF stages whose partner
-//     exchange is a wavefront shuffle (lane ^ 32, 16, ... 1) -- no LDS traffic;
+//     exchange is a wavefront shuffle done with DPP / v_permlane{16,32}_swap (fft.hpp): no LDS;
 //   * the bit-reversed result goes through a 2 KB per-wave LDS scratch once, for the
 //     Z[k] / conj(Z[256-k]) pairing of the real-FFT post-pass and natural-order output;
 //   * magnitude / re / im / phase are written frame-major ([S,T,257]), 64 consecutive bins
 //     per store instruction.
 // HBM-bound: 1024 B read + 1028 B written per frame for the magnitude path.
-#include "common.hpp"
+#include "fft.hpp"
 
 namespace {
 
-constexpr int FB = 32;  // frames per workgroup (8 per wave)
+constexpr int FB = 16;  // frames per workgroup (4 per wave): 25 KB LDS -> 6 workgroups per CU
 constexpr int NBIN = 257;
 
-struct cplx {
-  float x, y;
-};
-DEV cplx cmul(cplx a, cplx b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
-DEV cplx cis_pi(float t) {  // exp(i*pi*t)
-  cplx r;
-  sincospif(t, &r.y, &r.x);
-  return r;
-}
-
+template <bool MAG_ONLY>
 __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ audio, int64_t n1, int64_t stride0,
                                                    int64_t stride1, int64_t n_samples, int T,
                                                    float* __restrict__ mag, float* __restrict__ re,
@@ -59,20 +50,7 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ aud
   // ---- per-lane constants (window, twiddles)
   float win[8];
   cplx tw1[4], tws[6], twp[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int n = 2 * (l + 64 * q);
-    win[2 * q] = 0.5f - 0.5f * cospif((float)n * (1.f / 256.f));
-    win[2 * q + 1] = 0.5f - 0.5f * cospif((float)(n + 1) * (1.f / 256.f));
-    tw1[q] = cis_pi(-(float)(l * q) * (1.f / 128.f));              // W256^(l*q)
-    twp[q] = cis_pi(-(float)(l + 64 * q) * (1.f / 256.f));         // W512^k, k = l + 64q
-  }
-#pragma unroll
-  for (int st = 0; st < 6; ++st) {
-    const int half = 32 >> st, m = 2 * half;
-    const int p = l & (m - 1);
-    tws[st] = (p >= half) ? cis_pi(-2.f * (float)(p - half) / (float)m) : cplx{1.f, 0.f};
-  }
+  fft_load_consts(0, l, win, tw1, tws, twp);
   const int kbr = (int)(__brev((unsigned)l) >> 26);  // 6-bit reversal
   __syncthreads();
 
@@ -88,26 +66,8 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ aud
       const float2 v = *reinterpret_cast<const float2*>(fx + 2 * (l + 64 * q));
       z[q] = {v.x * win[2 * q], v.y * win[2 * q + 1]};
     }
-    // radix-4 over q (W4 = -i), then twiddle W256^(l*r)
-    const cplx a02 = {z[0].x + z[2].x, z[0].y + z[2].y}, s02 = {z[0].x - z[2].x, z[0].y - z[2].y};
-    const cplx a13 = {z[1].x + z[3].x, z[1].y + z[3].y}, s13 = {z[1].x - z[3].x, z[1].y - z[3].y};
     cplx u[4];
-    u[0] = {a02.x + a13.x, a02.y + a13.y};
-    u[1] = cmul({s02.x + s13.y, s02.y - s13.x}, tw1[1]);  // (z0-z2) - i(z1-z3)
-    u[2] = cmul({a02.x - a13.x, a02.y - a13.y}, tw1[2]);
-    u[3] = cmul({s02.x - s13.y, s02.y + s13.x}, tw1[3]);  // (z0-z2) + i(z1-z3)
-    // four 64-point radix-2 DIF FFTs across the lanes
-#pragma unroll
-    for (int st = 0; st < 6; ++st) {
-      const int half = 32 >> st;
-      const bool upper = (l & half) != 0;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float ox = __shfl_xor(u[r].x, half), oy = __shfl_xor(u[r].y, half);
-        const cplx d = upper ? cplx{ox - u[r].x, oy - u[r].y} : cplx{u[r].x + ox, u[r].y + oy};
-        u[r] = cmul(d, tws[st]);
-      }
-    }
+    fft256_wave(z, u, tw1, tws, l);
     // lane l, reg r holds Z[4*brev6(l) + r]
     *reinterpret_cast<float4*>(&zs[4 * kbr]) = make_float4(u[0].x, u[0].y, u[1].x, u[1].y);
     *reinterpret_cast<float4*>(&zs[4 * kbr + 2]) = make_float4(u[2].x, u[2].y, u[3].x, u[3].y);
@@ -125,18 +85,24 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ aud
       const cplx O = {0.5f * Dd.y, -0.5f * Dd.x};
       const cplx WO = cmul(twp[q], O);
       const float xr = E.x + WO.x, xi = E.y + WO.y;
-      if (mag) mag[orow + k] = sqrtf(xr * xr + xi * xi);
-      if (re) re[orow + k] = xr;
-      if (im) im[orow + k] = xi;
-      if (pha) pha[orow + k] = atan2f(xi, xr);
+      if constexpr (MAG_ONLY) {
+        mag[orow + k] = __builtin_amdgcn_sqrtf(xr * xr + xi * xi);  // v_sqrt_f32, 1 ulp
+      } else {
+        if (mag) mag[orow + k] = __builtin_amdgcn_sqrtf(xr * xr + xi * xi);
+        if (re) re[orow + k] = xr;
+        if (im) im[orow + k] = xi;
+        if (pha) pha[orow + k] = atan2f(xi, xr);
+      }
     }
     if (l == 0) {  // Nyquist bin k = 256: X = Re Z[0] - Im Z[0]
       const cplx A = zs[0];
       const float xr = A.x - A.y;
-      if (mag) mag[orow + 256] = fabsf(xr);
-      if (re) re[orow + 256] = xr;
-      if (im) im[orow + 256] = 0.f;
-      if (pha) pha[orow + 256] = atan2f(0.f, xr);
+      if (MAG_ONLY || mag) mag[orow + 256] = fabsf(xr);
+      if constexpr (!MAG_ONLY) {
+        if (re) re[orow + 256] = xr;
+        if (im) im[orow + 256] = 0.f;
+        if (pha) pha[orow + 256] = atan2f(0.f, xr);
+      }
     }
     __builtin_amdgcn_wave_barrier();  // scratch is rewritten by the next frame
   }
@@ -154,8 +120,12 @@ extern "C" int csship_stft(const float* audio, int64_t n0, int64_t stride0, int6
   const int64_t S = n0 * n1;
   if (S > 65535 || T > 0x7fffffff / 256) return CSSHIP_EBADSHAPE;
   dim3 grid((unsigned)((T + FB - 1) / FB), (unsigned)S);
-  hipLaunchKernelGGL(stft_kernel, grid, dim3(256), 0, as_stream(stream), audio, n1, stride0, stride1, n_samples,
-                     (int)T, mag, re, im, pha);
+  if (mag && !re && !im && !pha)
+    hipLaunchKernelGGL(stft_kernel<true>, grid, dim3(256), 0, as_stream(stream), audio, n1, stride0, stride1, n_samples,
+                       (int)T, mag, re, im, pha);
+  else
+    hipLaunchKernelGGL(stft_kernel<false>, grid, dim3(256), 0, as_stream(stream), audio, n1, stride0, stride1,
+                       n_samples, (int)T, mag, re, im, pha);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }

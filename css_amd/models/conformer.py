@@ -198,13 +198,15 @@ class Conformer(nn.Module):
             L.ln_g, L.ln_b = f32(lay.layer_norm.weight), f32(lay.layer_norm.bias)
 
         w = _lib.ConformerWeights()
-        w.idim, w.idim_pad = enc.idim, (enc.idim + 63) // 64 * 64
+        w.idim, w.idim_pad = enc.idim, (enc.idim + 255) // 256 * 256
         w.d_model, w.n_head, w.d_ffn = enc.d_model, enc.n_head, enc.d_ffn
         w.n_layer, w.kernel_size = len(enc.encoders), enc.kernel_size
         w.n_out = self.linear.out_features
         pe_packed, w.pe_q_min, w.pe_q_max = ops.pack_relpos(enc.pos_emb.pe_k.weight, enc.pos_emb.maxlen)
         w.bn_mode = 1 if self.training else 0
-        w.embed_w, w.embed_b = own(ops.pad_weight_bf16(enc.embed[0].weight)), f32(enc.embed[0].bias)
+        ew = torch.zeros(enc.d_model, w.idim_pad, device=dev)
+        ew[:, :enc.idim] = enc.embed[0].weight.detach().float()
+        w.embed_w, w.embed_b = own(ops.pack_frag(ew)), f32(enc.embed[0].bias)
         w.embed_ln_g, w.embed_ln_b = f32(enc.embed[1].weight), f32(enc.embed[1].bias)
         w.pe_k = own(pe_packed)
         w.layers = C.cast(layers, C.POINTER(_lib.LayerWeights))

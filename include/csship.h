@@ -170,6 +170,14 @@ int csship_encoder_chain(const float* x, float* x_out, const struct csship_ffn_w
                          uint16_t* qkv_out, int32_t M, int32_t d_model, int32_t d_ffn, int32_t n_qkv,
                          csship_stream_t stream);
 
+/* csship_embed: x0 = ReLU(LayerNorm(Linear(MVN_time(f))))  (css/models/conformer.py:95, 124-129) as one
+ * row-panel kernel; f f32 [B, T, idim] (row stride ldf, any idim); mvn_mean / mvn_rinv from
+ * csship_mvn_stats; w_packed = fragment-packed [256, Kp] with Kp = idim rounded up to 256 (zero padded);
+ * out f32 [B*T, 256]. */
+int csship_embed(const float* f, int64_t ldf, const float* mvn_mean, const float* mvn_rinv,
+                 const uint16_t* w_packed, const float* bias, const float* ln_g, const float* ln_b,
+                 float* out, int32_t B, int32_t T, int32_t idim, int32_t d_model, csship_stream_t stream);
+
 /* Relative-position multi-head attention core, MultiHeadedAttention.forward
  * (css/models/conformer.py:229-253) with RelativePositionalEncoding
  * (conformer.py:179-185) folded in:
@@ -269,7 +277,7 @@ typedef struct {
   int32_t n_out;           /* num_bins * (num_spk + num_noise) */
   int32_t pe_q_min, pe_q_max; /* block range of pe_k (csship_mha_relpos) */
   int32_t bn_mode;         /* 0 eval, 1 batch statistics */
-  const uint16_t* embed_w; const float* embed_b; /* ROW-MAJOR bf16 [d_model, idim_pad] (csship_gemm layout) */
+  const uint16_t* embed_w; const float* embed_b; /* PACKED bf16 from [d_model, idim_pad], idim_pad = idim rounded up to 256 */
   const float *embed_ln_g, *embed_ln_b;
   const uint16_t* pe_k;    /* PACKED relative-position blocks (csship_mha_relpos) */
   const csship_layer_weights* layers; /* HOST array [n_layer] */
