@@ -40,7 +40,7 @@ class LayerWeights(C.Structure):
 class ConformerWeights(C.Structure):
     _fields_ = [("idim", _i32), ("idim_pad", _i32), ("d_model", _i32), ("n_head", _i32), ("d_ffn", _i32),
                 ("n_layer", _i32), ("kernel_size", _i32), ("n_out", _i32), ("pe_q_min", _i32), ("pe_q_max", _i32),
-                ("bn_mode", _i32),
+                ("bn_mode", _i32), ("fuse_conv", _i32),
                 ("embed_w", _p), ("embed_b", _p), ("embed_ln_g", _p), ("embed_ln_b", _p), ("pe_k", _p),
                 ("layers", C.POINTER(LayerWeights)), ("head_w", _p), ("head_b", _p)]
 
@@ -65,7 +65,9 @@ SIGNATURES = {
     "csship_ffn_fused": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _p]),
     "csship_panel_linear": (_i32, [_p, _i32, _p, _p, _p, _p, _p, _i64, _f32, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "csship_embed": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
-    "csship_encoder_chain": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
+    "csship_outproj_glu": (_i32, [_p, _p, _p, _p, _p, C.POINTER(ConvWeights), _p, _i32, _i32, _p]),
+    "csship_encoder_chain": (_i32, [_p, _p, _p, C.POINTER(ConvWeights), _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32,
+                                     _i32, _i32, _i32, _p]),
     "csship_mha_relpos": (_i32, [_p, _p, _i32, _i32, _p, _i32, _i32, _i32, _p]),
     "csship_convmod_workspace": (_sz, [_i32, _i32, _i32]),
     "csship_convmod": (_i32, [_p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _i32, _p, _p]),

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(2 * D) void convmod_kernel(ConvArgs a) {
   }
   float wk[KS];
 #pragma unroll
-  for (int k = 0; k < KS; ++k) wk[k] = a.w.dw_w[c * KS + k];
+  for (int k = 0; k < KS; ++k) wk[k] = a.w.dw_w[k * D + c];  // [k][D]: lanes read consecutive floats
   const float cb = a.w.dw_b[c];
   float scale = 0.f, shift = 0.f, pw2w = 0.f, pw2b = 0.f;
   if constexpr (MODE == 0) {

@@ -89,25 +89,45 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
   TRY(csship_embed(f, ldf, ws.mean, ws.rinv, w->embed_w, w->embed_b, w->embed_ln_g, w->embed_ln_b, ws.x0, B, T, w->idim,
                    D, stream));
   float *x = ws.x0, *y = ws.x1;
-  // row-local operators are chained per 64-row panel (csship_encoder_chain):
-  //   [FFN_out(l-1) + block LN] -> FFN_in(l) -> pre-LN + q/k/v projection(l)
-  for (int l = 0; l < w->n_layer; ++l) {
-    const csship_layer_weights& L = w->layers[l];
-    const csship_layer_weights* P = l > 0 ? &w->layers[l - 1] : nullptr;
-    TRY(csship_encoder_chain(x, x, P ? &P->ffn_out : nullptr, P ? P->ln_g : nullptr, P ? P->ln_b : nullptr, &L.ffn_in,
-                             L.mha.ln_g, L.mha.ln_b, L.mha.wqkv, L.mha.bqkv, ws.qkv_bf, M, D, FF, 3 * D, stream));
-    // x += MHA(x)                                            (conformer.py:356)
-    TRY(csship_mha_relpos(ws.qkv_bf, w->pe_k, w->pe_q_min, w->pe_q_max, ws.ao_bf, B, T, w->n_head, stream));
-    TRY(csship_panel_linear(ws.ao_bf, CSSHIP_PRO_BF16, nullptr, nullptr, L.mha.wo, L.mha.bo, x, D, 1.f, x, D, M, D,
-                            D, CSSHIP_EPI_RESIDUAL, stream));
-    // x += Conv(x)                                           (conformer.py:357)
-    TRY(csship_convmod(x, y, &L.conv, B, T, D, w->kernel_size, w->bn_mode, ws.conv_ws, stream));
-    { float* t = x; x = y; y = t; }
-  }
-  {  // x = LN(x + 0.5 * FFN_out(x)) of the last block          (conformer.py:358-360)
+  if (w->bn_mode == 0 && w->fuse_conv != 0) {
+    // optional (measured slower at B=32 x T=400: 83 vs 75 us per block): 3 launches per block.  Row-local operators are chained per 64-row panel (csship_encoder_chain):
+    //   [conv back half(l-1) -> FFN_out(l-1) + block LN] -> FFN_in(l) -> pre-LN + q/k/v projection(l)
+    float* gbuf = y;  // glu(LN_conv(x)) rows handed from the output projection to the next chain
+    TRY(csship_encoder_chain(x, x, nullptr, nullptr, T, nullptr, nullptr, nullptr, &w->layers[0].ffn_in,
+                             w->layers[0].mha.ln_g, w->layers[0].mha.ln_b, w->layers[0].mha.wqkv,
+                             w->layers[0].mha.bqkv, ws.qkv_bf, M, D, FF, 3 * D, stream));
+    for (int l = 0; l < w->n_layer; ++l) {
+      const csship_layer_weights& L = w->layers[l];
+      TRY(csship_mha_relpos(ws.qkv_bf, w->pe_k, w->pe_q_min, w->pe_q_max, ws.ao_bf, B, T, w->n_head, stream));
+      TRY(csship_outproj_glu(ws.ao_bf, L.mha.wo, L.mha.bo, x, x, &L.conv, gbuf, M, D, stream));
+      if (l + 1 < w->n_layer) {
+        const csship_layer_weights& N = w->layers[l + 1];
+        TRY(csship_encoder_chain(x, x, gbuf, &L.conv, T, &L.ffn_out, L.ln_g, L.ln_b, &N.ffn_in, N.mha.ln_g, N.mha.ln_b,
+                                 N.mha.wqkv, N.mha.bqkv, ws.qkv_bf, M, D, FF, 3 * D, stream));
+      } else {
+        TRY(csship_encoder_chain(x, x, gbuf, &L.conv, T, &L.ffn_out, L.ln_g, L.ln_b, nullptr, nullptr, nullptr, nullptr,
+                                 nullptr, nullptr, M, D, FF, 0, stream));
+      }
+    }
+  } else {
+    // default: 4 launches per block.  The conv module is a separate op (in training mode BatchNorm batch
+    // statistics need a grid-wide reduction between conv and ReLU anyway); FFN_out(l-1) + LN -> FFN_in(l) ->
+    // q/k/v projection(l) are chained per 64-row panel
+    for (int l = 0; l < w->n_layer; ++l) {
+      const csship_layer_weights& L = w->layers[l];
+      const csship_layer_weights* P = l > 0 ? &w->layers[l - 1] : nullptr;
+      TRY(csship_encoder_chain(x, x, nullptr, nullptr, T, P ? &P->ffn_out : nullptr, P ? P->ln_g : nullptr,
+                               P ? P->ln_b : nullptr, &L.ffn_in, L.mha.ln_g, L.mha.ln_b, L.mha.wqkv, L.mha.bqkv,
+                               ws.qkv_bf, M, D, FF, 3 * D, stream));
+      TRY(csship_mha_relpos(ws.qkv_bf, w->pe_k, w->pe_q_min, w->pe_q_max, ws.ao_bf, B, T, w->n_head, stream));
+      TRY(csship_panel_linear(ws.ao_bf, CSSHIP_PRO_BF16, nullptr, nullptr, L.mha.wo, L.mha.bo, x, D, 1.f, x, D, M, D,
+                              D, CSSHIP_EPI_RESIDUAL, stream));
+      TRY(csship_convmod(x, y, &L.conv, B, T, D, w->kernel_size, w->bn_mode, ws.conv_ws, stream));
+      { float* t = x; x = y; y = t; }
+    }
     const csship_layer_weights& L = w->layers[w->n_layer - 1];
-    TRY(csship_encoder_chain(x, x, &L.ffn_out, L.ln_g, L.ln_b, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, M, D,
-                             FF, 0, stream));
+    TRY(csship_encoder_chain(x, x, nullptr, nullptr, T, &L.ffn_out, L.ln_g, L.ln_b, nullptr, nullptr, nullptr, nullptr,
+                             nullptr, nullptr, M, D, FF, 0, stream));
   }
   if (enc_out) {
     if (hipMemcpyAsync(enc_out, x, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream)) !=

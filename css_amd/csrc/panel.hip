@@ -306,6 +306,10 @@ struct LinArgs {
   int64_t ldo, ldr;
   float alpha;
   unsigned long long* stamps;
+  // optional conv-module front half fused into the residual epilogue (N == 256):
+  //   g = glu(LayerNorm_conv(out_row))   (css/models/conformer.py:291-293)
+  const float *cln_g, *cln_b, *pw1_w, *pw1_b;
+  float* g_out;
 };
 
 template <int NW, int PRO, int EPI>
@@ -380,9 +384,11 @@ __global__ __launch_bounds__(NW * 64) void panel_linear_kernel(LinArgs a) {
           }
         } else {
           float* o = reinterpret_cast<float*>(a.out) + (size_t)row * a.ldo + f0;
+          float4 vrow[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const int c = (i * 8 + part) * 4;
+            vrow[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (c + 3 < ncols) {
               float4 y = *reinterpret_cast<const float4*>(Ys + r * YS + c);
               if constexpr (RES) {
@@ -390,11 +396,39 @@ __global__ __launch_bounds__(NW * 64) void panel_linear_kernel(LinArgs a) {
                 y = make_float4(x0.x + a.alpha * y.x, x0.y + a.alpha * y.y, x0.z + a.alpha * y.z, x0.w + a.alpha * y.w);
               }
               *reinterpret_cast<float4*>(o + c) = y;
+              vrow[i] = y;
             } else {
               for (int e = c; e < min(c + 4, ncols); ++e) {
                 float y = Ys[r * YS + e];
                 if constexpr (RES) y = a.res[(size_t)row * a.ldr + f0 + e] + a.alpha * y;
                 o[e] = y;
+              }
+            }
+          }
+          if constexpr (RES) {
+            if (a.g_out != nullptr) {  // N == 256: vrow is the whole new residual row
+              float s = 0.f;
+#pragma unroll
+              for (int i = 0; i < 8; ++i) s += (vrow[i].x + vrow[i].y) + (vrow[i].z + vrow[i].w);
+              const float mean = sum8(s) * (1.f / DM);
+              float ss = 0.f;
+#pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                vrow[i].x -= mean; vrow[i].y -= mean; vrow[i].z -= mean; vrow[i].w -= mean;
+                ss += (vrow[i].x * vrow[i].x + vrow[i].y * vrow[i].y) + (vrow[i].z * vrow[i].z + vrow[i].w * vrow[i].w);
+              }
+              const float rstd = rsqrtf(sum8(ss) * (1.f / DM) + 1e-5f);
+              const float w0 = a.pw1_w[0], w1 = a.pw1_w[1], b0 = a.pw1_b[0], b1 = a.pw1_b[1];
+#pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                const int c = (i * 8 + part) * 4;
+                const float4 gm = *reinterpret_cast<const float4*>(a.cln_g + c);
+                const float4 bt = *reinterpret_cast<const float4*>(a.cln_b + c);
+                float e[4] = {vrow[i].x * rstd * gm.x + bt.x, vrow[i].y * rstd * gm.y + bt.y,
+                              vrow[i].z * rstd * gm.z + bt.z, vrow[i].w * rstd * gm.w + bt.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) e[q] = (w0 * e[q] + b0) * __builtin_amdgcn_rcpf(1.f + __expf(-(w1 * e[q] + b1)));
+                *reinterpret_cast<float4*>(a.g_out + (size_t)row * DM + c) = make_float4(e[0], e[1], e[2], e[3]);
               }
             }
           }
@@ -428,9 +462,15 @@ struct FfnW {
   const bf16x8* w2;
   const float* b2;
 };
+struct ConvW {
+  const float *dw_w, *dw_b, *bn_g, *bn_b, *bn_mean, *bn_var, *pw2_w, *pw2_b;
+};
 struct ChainArgs {
   const float* x;
   float* xout;
+  const float* g;  // HAS_CONV: glu(LN(x)) rows from the attention output projection [M, 256]
+  ConvW cv;
+  int T;
   FfnW fa;                      // stage A: FFN + residual + final LayerNorm (fin_g/fin_b)
   const float *fin_g, *fin_b;
   FfnW fb;                      // stage B: FFN + residual
@@ -548,18 +588,93 @@ DEV void ffn_stage(float4 (&v)[8], unsigned char* Xs, unsigned char* Hraw, const
   }
 }
 
-template <int NW, bool HAS_A, bool HAS_B, bool HAS_C>
+template <int NW, bool HAS_CONV, bool HAS_A, bool HAS_B, bool HAS_C>
 __global__ __launch_bounds__(NW * 64) void chain_kernel(ChainArgs a) {
   static_assert(NW * 64 == 8 * BM, "row phases assume 8 lanes per panel row");
   constexpr int NT = 16 / NW;
-  __shared__ __attribute__((aligned(16))) unsigned char Xs[PANEL_BYTES];
-  __shared__ __attribute__((aligned(16))) unsigned char Hraw[YS_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[PANEL_BYTES + YS_BYTES];
+  unsigned char* const Xs = smem;
+  unsigned char* const Hraw = smem + PANEL_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15;
   const int r = tid >> 3, part = tid & 7;
   const int m0 = blockIdx.x * BM, row = m0 + r, rowc = min(row, a.M - 1);
   float4 v[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(a.x + (size_t)rowc * DM + (i * 8 + part) * 4);
+  if constexpr (HAS_CONV) {
+    // x <- x + pw2(relu(BN(dwconv_33(g))))   (css/models/conformer.py:294-301, 357) for this panel's 64 rows.
+    // g rows m0-16 .. m0+79 are staged in LDS (the panel + hidden regions are still free); thread
+    // (channel c, half) walks 32 consecutive rows; taps that leave the row's own utterance are masked
+    // (rows are flattened (b, t), a panel may straddle a batch boundary).
+    constexpr int KSZ = 33, HALO = 16, GROWS = BM + KSZ - 1;  // 96 rows x 1 KB = 96 KB
+    static_assert(GROWS * DM * 4 <= PANEL_BYTES + YS_BYTES, "g tile must fit the panel + hidden regions");
+    float* Gs = reinterpret_cast<float*>(smem);
+    for (int i = tid; i < GROWS * (DM / 4); i += NW * 64) {
+      const int gr = i / (DM / 4), c4 = i % (DM / 4);
+      const int m = m0 - HALO + gr;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m >= 0 && m < a.M) val = *reinterpret_cast<const float4*>(a.g + (size_t)m * DM + c4 * 4);
+      *reinterpret_cast<float4*>(Gs + gr * DM + c4 * 4) = val;
+    }
+    const int c = tid % DM, half = tid / DM;
+    float wk[KSZ];
+#pragma unroll
+    for (int k = 0; k < KSZ; ++k) wk[k] = a.cv.dw_w[k * DM + c];  // [k][D]: lanes read consecutive floats
+    const float cb = a.cv.dw_b[c];
+    const float scale = a.cv.bn_g[c] * rsqrtf(a.cv.bn_var[c] + 1e-5f);
+    const float shift = a.cv.bn_b[c] - a.cv.bn_mean[c] * scale;
+    const float pw2w = a.cv.pw2_w[0], pw2b = a.cv.pw2_b[0];
+    __syncthreads();
+    float yout[32];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+      const int tb = half * 32 + blk * 8;      // first output row of the block within the panel
+      const int tfirst = (m0 + tb) % a.T;      // its frame index inside the utterance (uniform)
+      const bool interior = tfirst >= HALO && tfirst + 7 + HALO < a.T;  // no tap of the block leaves the utterance
+      float acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = cb;
+      if (interior) {
+#pragma unroll
+        for (int u = 0; u < 8 + KSZ - 1; ++u) {
+          const float gv = Gs[(tb + u) * DM + c];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int k = u - j;
+            if (k >= 0 && k < KSZ) acc[j] += wk[k] * gv;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8 + KSZ - 1; ++u) {
+          const float gv = Gs[(tb + u) * DM + c];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int k = u - j;
+            if (k >= 0 && k < KSZ) {
+              int tj = tfirst + j;             // frame of output j (the block itself may wrap into the next utterance)
+              if (tj >= a.T) tj -= a.T;
+              const int tt = tj + k - HALO;    // frame the tap reads
+              if (tt >= 0 && tt < a.T) acc[j] += wk[k] * gv;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) yout[blk * 8 + j] = fmaxf(acc[j] * scale + shift, 0.f) * pw2w + pw2b;
+    }
+    __syncthreads();  // all taps read: the region is re-used as the [row][channel] exchange tile
+    float* ys = reinterpret_cast<float*>(Hraw);
+#pragma unroll
+    for (int j = 0; j < 32; ++j) ys[(half * 32 + j) * YS + c] = yout[j];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4 y = *reinterpret_cast<const float4*>(ys + r * YS + (i * 8 + part) * 4);
+      v[i] = make_float4(v[i].x + y.x, v[i].y + y.y, v[i].z + y.z, v[i].w + y.w);
+    }
+    __syncthreads();  // ys is overwritten by the first FFN stage's hidden panel
+  }
   if constexpr (HAS_A) ffn_stage<NW, true>(v, Xs, Hraw, a.fa, a.fin_g, a.fin_b, a.FF, a.alpha, tid, blockIdx.x);
   if constexpr (HAS_B) ffn_stage<NW, false>(v, Xs, Hraw, a.fb, nullptr, nullptr, a.FF, a.alpha, tid, blockIdx.x + 2);
   if (row < a.M) {  // the residual stream the attention output projection adds to
@@ -732,7 +847,8 @@ extern "C" int csship_panel_linear(const void* a, int32_t prologue, const float*
   if (prologue == CSSHIP_PRO_LN && (!ln_g || !ln_b || !aligned16(ln_g) || !aligned16(ln_b))) return CSSHIP_ENULL;
   if ((epilogue & CSSHIP_EPI_RESIDUAL) && (!residual || !aligned16(residual) || (ldr & 3) != 0 || ldr < N || (N & 3) != 0))
     return CSSHIP_EALIGN;
-  LinArgs la{a, ln_g, ln_b, reinterpret_cast<const bf16x8*>(w_packed), bias, residual, out, M, N, ldo, ldr, alpha, g_csship_stamps};
+  LinArgs la{a, ln_g, ln_b, reinterpret_cast<const bf16x8*>(w_packed), bias, residual, out, M, N, ldo, ldr, alpha,
+             g_csship_stamps, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipStream_t s = as_stream(stream);
   const int key = prologue * 16 + epilogue;
   switch (key) {
@@ -748,11 +864,12 @@ extern "C" int csship_panel_linear(const void* a, int32_t prologue, const float*
 }
 
 
-extern "C" int csship_encoder_chain(const float* x, float* x_out, const csship_ffn_weights* ffn_a,
-                                    const float* final_ln_g, const float* final_ln_b, const csship_ffn_weights* ffn_b,
-                                    const float* qkv_ln_g, const float* qkv_ln_b, const uint16_t* wqkv_packed,
-                                    const float* bqkv, uint16_t* qkv_out, int32_t M, int32_t d_model, int32_t d_ffn,
-                                    int32_t n_qkv, csship_stream_t stream) {
+extern "C" int csship_encoder_chain(const float* x, float* x_out, const float* conv_g, const csship_conv_weights* conv_w,
+                                    int32_t T, const csship_ffn_weights* ffn_a, const float* final_ln_g,
+                                    const float* final_ln_b, const csship_ffn_weights* ffn_b, const float* qkv_ln_g,
+                                    const float* qkv_ln_b, const uint16_t* wqkv_packed, const float* bqkv,
+                                    uint16_t* qkv_out, int32_t M, int32_t d_model, int32_t d_ffn, int32_t n_qkv,
+                                    csship_stream_t stream) {
   if (!x || !x_out) return CSSHIP_ENULL;
   if (M <= 0) return CSSHIP_EBADSHAPE;
   if (d_model != DM || d_ffn <= 0 || (d_ffn % DM) != 0) return CSSHIP_EUNSUPPORTED;
@@ -760,8 +877,12 @@ extern "C" int csship_encoder_chain(const float* x, float* x_out, const csship_f
   if (A && (!final_ln_g || !final_ln_b)) return CSSHIP_ENULL;
   if (Cq && (!qkv_ln_g || !qkv_ln_b || !qkv_out || n_qkv <= 0 || (n_qkv % 8) != 0)) return CSSHIP_EBADSHAPE;
   if (!aligned16(x) || !aligned16(x_out) || (Cq && (!aligned16(wqkv_packed) || !aligned16(qkv_out)))) return CSSHIP_EALIGN;
+  const bool CV = conv_g != nullptr;
+  if (CV && (!conv_w || T <= 0 || !aligned16(conv_g) || conv_g == x_out)) return CSSHIP_EBADSHAPE;
   ChainArgs a{};
-  a.x = x; a.xout = x_out; a.M = M; a.FF = d_ffn; a.NQKV = n_qkv; a.alpha = 0.5f;
+  a.x = x; a.xout = x_out; a.M = M; a.FF = d_ffn; a.NQKV = n_qkv; a.alpha = 0.5f; a.g = conv_g; a.T = T;
+  if (CV) a.cv = ConvW{conv_w->dw_w, conv_w->dw_b, conv_w->bn_g, conv_w->bn_b, conv_w->bn_mean, conv_w->bn_var,
+                       conv_w->pw2_w, conv_w->pw2_b};
   auto conv = [](const csship_ffn_weights* w) {
     return FfnW{w->ln_g, w->ln_b, reinterpret_cast<const bf16x8*>(w->w1), w->b1, reinterpret_cast<const bf16x8*>(w->w2), w->b2};
   };
@@ -770,9 +891,11 @@ extern "C" int csship_encoder_chain(const float* x, float* x_out, const csship_f
   if (Cq) { a.qln_g = qkv_ln_g; a.qln_b = qkv_ln_b; a.wqkv = reinterpret_cast<const bf16x8*>(wqkv_packed); a.bqkv = bqkv; a.qkv = qkv_out; }
   dim3 grid((M + BM - 1) / BM), block(NWAVES * 64);
   hipStream_t s = as_stream(stream);
-  if (A && Bs && Cq) hipLaunchKernelGGL((chain_kernel<NWAVES, true, true, true>), grid, block, 0, s, a);
-  else if (!A && Bs && Cq) hipLaunchKernelGGL((chain_kernel<NWAVES, false, true, true>), grid, block, 0, s, a);
-  else if (A && !Bs && !Cq) hipLaunchKernelGGL((chain_kernel<NWAVES, true, false, false>), grid, block, 0, s, a);
+  if (!CV && A && Bs && Cq) hipLaunchKernelGGL((chain_kernel<NWAVES, false, true, true, true>), grid, block, 0, s, a);
+  else if (!CV && !A && Bs && Cq) hipLaunchKernelGGL((chain_kernel<NWAVES, false, false, true, true>), grid, block, 0, s, a);
+  else if (!CV && A && !Bs && !Cq) hipLaunchKernelGGL((chain_kernel<NWAVES, false, true, false, false>), grid, block, 0, s, a);
+  else if (CV && A && Bs && Cq) hipLaunchKernelGGL((chain_kernel<NWAVES, true, true, true, true>), grid, block, 0, s, a);
+  else if (CV && A && !Bs && !Cq) hipLaunchKernelGGL((chain_kernel<NWAVES, true, true, false, false>), grid, block, 0, s, a);
   else return CSSHIP_EUNSUPPORTED;
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
@@ -790,4 +913,19 @@ extern "C" int csship_embed(const float* f, int64_t ldf, const float* mvn_mean, 
   hipLaunchKernelGGL((embed_kernel<NWAVES>), dim3((B * T + BM - 1) / BM), dim3(NWAVES * 64), 0, as_stream(stream), a);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
+}
+
+extern "C" int csship_outproj_glu(const uint16_t* attn_out, const uint16_t* wo_packed, const float* bo, const float* x,
+                                  float* x_out, const csship_conv_weights* conv_w, float* g_out, int32_t M,
+                                  int32_t d_model, csship_stream_t stream) {
+  if (!attn_out || !wo_packed || !x || !x_out || !conv_w || !g_out) return CSSHIP_ENULL;
+  if (!conv_w->ln_g || !conv_w->ln_b || !conv_w->pw1_w || !conv_w->pw1_b) return CSSHIP_ENULL;
+  if (M <= 0) return CSSHIP_EBADSHAPE;
+  if (d_model != DM) return CSSHIP_EUNSUPPORTED;
+  if (!aligned16(attn_out) || !aligned16(wo_packed) || !aligned16(x) || !aligned16(x_out) || !aligned16(g_out) ||
+      !aligned16(conv_w->ln_g) || !aligned16(conv_w->ln_b))
+    return CSSHIP_EALIGN;
+  LinArgs la{attn_out, nullptr, nullptr, reinterpret_cast<const bf16x8*>(wo_packed), bo, x, x_out, M, DM, DM, DM, 1.f,
+             g_csship_stamps, conv_w->ln_g, conv_w->ln_b, conv_w->pw1_w, conv_w->pw1_b, g_out};
+  return launch_linear<CSSHIP_PRO_BF16, CSSHIP_EPI_RESIDUAL>(la, as_stream(stream));
 }

@@ -145,7 +145,7 @@ class Conformer(nn.Module):
 
     # ------------------------------------------------------------------ weight packing
     def _pack_key(self):
-        return (self.training,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (self.training, getattr(self, "fuse_conv", False)) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def _pack(self):
         """bf16 shadow copies of the GEMM weights + the pointer table csship_conformer_forward reads."""
@@ -191,7 +191,8 @@ class Conformer(nn.Module):
             c = lay.conv
             L.conv.ln_g, L.conv.ln_b = f32(c.layer_norm.weight), f32(c.layer_norm.bias)
             L.conv.pw1_w, L.conv.pw1_b = f32(c.pw_conv_1.weight), f32(c.pw_conv_1.bias)
-            L.conv.dw_w, L.conv.dw_b = f32(c.dw_conv_1d.weight), f32(c.dw_conv_1d.bias)
+            dw_t = c.dw_conv_1d.weight.detach().float().view(enc.d_model, -1).t().contiguous()  # [k, D]
+            L.conv.dw_w, L.conv.dw_b = own(dw_t), f32(c.dw_conv_1d.bias)
             L.conv.bn_g, L.conv.bn_b = f32(c.BN.weight), f32(c.BN.bias)
             L.conv.bn_mean, L.conv.bn_var = f32(c.BN.running_mean), f32(c.BN.running_var)
             L.conv.pw2_w, L.conv.pw2_b = f32(c.pw_conv_2.weight), f32(c.pw_conv_2.bias)
@@ -204,6 +205,7 @@ class Conformer(nn.Module):
         w.n_out = self.linear.out_features
         pe_packed, w.pe_q_min, w.pe_q_max = ops.pack_relpos(enc.pos_emb.pe_k.weight, enc.pos_emb.maxlen)
         w.bn_mode = 1 if self.training else 0
+        w.fuse_conv = 1 if getattr(self, "fuse_conv", False) else 0
         ew = torch.zeros(enc.d_model, w.idim_pad, device=dev)
         ew[:, :enc.idim] = enc.embed[0].weight.detach().float()
         w.embed_w, w.embed_b = own(ops.pack_frag(ew)), f32(enc.embed[0].bias)

@@ -155,20 +155,32 @@ int csship_panel_linear(const void* a, int32_t prologue, const float* ln_g, cons
                         int64_t ldr, float alpha, void* out, int64_t ldo, int32_t M, int32_t N,
                         int32_t d_model, int32_t epilogue, csship_stream_t stream);
 
-/* csship_encoder_chain: the row-local operators between two attention/convolution stages as ONE kernel:
+/* csship_outproj_glu: attention output projection + residual, and the front half of the conv module on the
+ * fresh row:  x_out = x + attn_out @ Wo^T + bo  (conformer.py:254,356);  g_out = glu(LayerNorm_conv(x_out))
+ * (conformer.py:291-293).  attn_out bf16 [M,256]; x, x_out, g_out f32 [M,256] (x_out may alias x). */
+struct csship_conv_weights_s;
+int csship_outproj_glu(const uint16_t* attn_out, const uint16_t* wo_packed, const float* bo, const float* x,
+                       float* x_out, const struct csship_conv_weights_s* conv_w, float* g_out, int32_t M,
+                       int32_t d_model, csship_stream_t stream);
+
+/* csship_encoder_chain: the row-local operators between two attention stages as ONE kernel, per 64-row panel:
+ *   [conv_g != NULL] x = x + pw2(relu(BN_eval(dwconv_33(conv_g))))   back half of the conv module of block l-1
+ *                    (conformer.py:294-301,357; conv_g from csship_outproj_glu; T = frames per utterance,
+ *                    taps never cross an utterance.  Only conv_g is read with halo rows, x is row-local:
+ *                    x_out may alias x but not conv_g)
  *   [ffn_a != NULL]  x = LayerNorm_final( x + 0.5 FFN_a(x) )      FFN_out of block l-1 (conformer.py:358-360)
  *   [ffn_b != NULL]  x = x + 0.5 FFN_b(x)                         FFN_in of block l   (conformer.py:355)
  *   x_out <- x
  *   [wqkv != NULL]   qkv_out = bf16( LayerNorm_qkv(x) @ Wqkv^T + bqkv )   (conformer.py:222-225)
- * Supported combinations: (a,b,qkv), (b,qkv), (a).  FFN weight structs are defined below
- * (csship_ffn_weights, packed layout); x_out may alias x. */
+ * Supported combinations: (a,b,qkv), (b,qkv), (a), (conv,a,b,qkv), (conv,a). */
 struct csship_ffn_weights_s;
-int csship_encoder_chain(const float* x, float* x_out, const struct csship_ffn_weights_s* ffn_a,
-                         const float* final_ln_g, const float* final_ln_b,
-                         const struct csship_ffn_weights_s* ffn_b, const float* qkv_ln_g,
-                         const float* qkv_ln_b, const uint16_t* wqkv_packed, const float* bqkv,
-                         uint16_t* qkv_out, int32_t M, int32_t d_model, int32_t d_ffn, int32_t n_qkv,
-                         csship_stream_t stream);
+int csship_encoder_chain(const float* x, float* x_out, const float* conv_g,
+                         const struct csship_conv_weights_s* conv_w, int32_t T,
+                         const struct csship_ffn_weights_s* ffn_a, const float* final_ln_g,
+                         const float* final_ln_b, const struct csship_ffn_weights_s* ffn_b,
+                         const float* qkv_ln_g, const float* qkv_ln_b, const uint16_t* wqkv_packed,
+                         const float* bqkv, uint16_t* qkv_out, int32_t M, int32_t d_model, int32_t d_ffn,
+                         int32_t n_qkv, csship_stream_t stream);
 
 /* csship_embed: x0 = ReLU(LayerNorm(Linear(MVN_time(f))))  (css/models/conformer.py:95, 124-129) as one
  * row-panel kernel; f f32 [B, T, idim] (row stride ldf, any idim); mvn_mean / mvn_rinv from
@@ -197,10 +209,10 @@ int csship_mha_relpos(const uint16_t* qkv, const uint16_t* pe_packed, int32_t q_
  * pw1_w/pw1_b: 2 floats each (Conv2d(1,2,1)), pw2_w/pw2_b: 1 float each (device).
  * bn_mode 0: running statistics (eval).  bn_mode 1: batch statistics (train forward);
  * needs workspace of csship_convmod_workspace() bytes and updates nothing. */
-typedef struct {
+typedef struct csship_conv_weights_s {
   const float *ln_g, *ln_b;
   const float *pw1_w, *pw1_b;
-  const float *dw_w, *dw_b; /* [D, k], [D] */
+  const float *dw_w, *dw_b; /* depthwise taps TRANSPOSED to [k, D] (coalesced per-channel reads), bias [D] */
   const float *bn_g, *bn_b, *bn_mean, *bn_var;
   const float *pw2_w, *pw2_b;
 } csship_conv_weights;
@@ -277,6 +289,7 @@ typedef struct {
   int32_t n_out;           /* num_bins * (num_spk + num_noise) */
   int32_t pe_q_min, pe_q_max; /* block range of pe_k (csship_mha_relpos) */
   int32_t bn_mode;         /* 0 eval, 1 batch statistics */
+  int32_t fuse_conv;       /* eval only: 1 = conv module fused into csship_outproj_glu + csship_encoder_chain */
   const uint16_t* embed_w; const float* embed_b; /* PACKED bf16 from [d_model, idim_pad], idim_pad = idim rounded up to 256 */
   const float *embed_ln_g, *embed_ln_b;
   const uint16_t* pe_k;    /* PACKED relative-position blocks (csship_mha_relpos) */

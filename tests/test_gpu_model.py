@@ -99,6 +99,20 @@ def test_conformer_three_speakers_7ch_dims():
     assert mask_mse(torch.cat(masks, 2), ref) < 1e-4
 
 
+def test_fused_conv_path_matches():
+    """Optional eval path: conv module split over csship_outproj_glu + csship_encoder_chain (panels straddle
+    utterance boundaries: T = 70, 64-row panels)."""
+    m, sd = build(2, 32)
+    f = rnd((3, 70, 257), 21).abs().to(DEV)
+    ref = m.forward_masks(f).clone()
+    m.fuse_conv = True
+    got = m.forward_masks(f)
+    m.fuse_conv = False
+    assert mask_mse(got, ref) < 1e-6
+    o = oracle.conformer.forward(f.cpu(), sd, num_blocks=2)[1]
+    assert mask_mse(got, torch.cat(o, 2)) < 1e-4
+
+
 def test_train_mode_batch_stats():
     m, sd = build(1, 41)
     m.train()

@@ -282,7 +282,7 @@ def _conv_weights(seed):
     dev = {
         "ln_g": sd["cv.layer_norm.weight"], "ln_b": sd["cv.layer_norm.bias"],
         "pw1_w": sd["cv.pw_conv_1.weight"].reshape(2), "pw1_b": sd["cv.pw_conv_1.bias"],
-        "dw_w": sd["cv.dw_conv_1d.weight"].reshape(256, 33), "dw_b": sd["cv.dw_conv_1d.bias"],
+        "dw_w": sd["cv.dw_conv_1d.weight"].reshape(256, 33).t(), "dw_b": sd["cv.dw_conv_1d.bias"],
         "bn_g": sd["cv.BN.weight"], "bn_b": sd["cv.BN.bias"], "bn_mean": sd["cv.BN.running_mean"],
         "bn_var": sd["cv.BN.running_var"], "pw2_w": sd["cv.pw_conv_2.weight"].reshape(1), "pw2_b": sd["cv.pw_conv_2.bias"],
     }

@@ -81,7 +81,7 @@ def bench_conv():
     pre = "conformer.encoders.0.conv."
     sd = syn.fill_state_dict({k[len(pre):]: s for k, s in full.items() if k.startswith(pre)}, 1)
     w = {"ln_g": sd["layer_norm.weight"], "ln_b": sd["layer_norm.bias"], "pw1_w": sd["pw_conv_1.weight"].reshape(2),
-         "pw1_b": sd["pw_conv_1.bias"], "dw_w": sd["dw_conv_1d.weight"].reshape(256, 33), "dw_b": sd["dw_conv_1d.bias"],
+         "pw1_b": sd["pw_conv_1.bias"], "dw_w": sd["dw_conv_1d.weight"].reshape(256, 33).t(), "dw_b": sd["dw_conv_1d.bias"],
          "bn_g": sd["BN.weight"], "bn_b": sd["BN.bias"], "bn_mean": sd["BN.running_mean"], "bn_var": sd["BN.running_var"],
          "pw2_w": sd["pw_conv_2.weight"].reshape(1), "pw2_b": sd["pw_conv_2.bias"]}
     w = {k: v.contiguous().to(DEV) for k, v in w.items()}

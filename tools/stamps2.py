@@ -22,7 +22,7 @@ def report(name, fn, nph, nwg):
 full = syn.conformer_shapes(num_blocks=1); pre = "conformer.encoders.0.conv."
 sd = syn.fill_state_dict({k[len(pre):]: v for k, v in full.items() if k.startswith(pre)}, 1)
 w = {"ln_g": sd["layer_norm.weight"], "ln_b": sd["layer_norm.bias"], "pw1_w": sd["pw_conv_1.weight"].reshape(2),
-     "pw1_b": sd["pw_conv_1.bias"], "dw_w": sd["dw_conv_1d.weight"].reshape(256, 33), "dw_b": sd["dw_conv_1d.bias"],
+     "pw1_b": sd["pw_conv_1.bias"], "dw_w": sd["dw_conv_1d.weight"].reshape(256, 33).t(), "dw_b": sd["dw_conv_1d.bias"],
      "bn_g": sd["BN.weight"], "bn_b": sd["BN.bias"], "bn_mean": sd["BN.running_mean"], "bn_var": sd["BN.running_var"],
      "pw2_w": sd["pw_conv_2.weight"].reshape(1), "pw2_b": sd["pw_conv_2.bias"]}
 w = {k: v.contiguous().to(DEV) for k, v in w.items()}
