@@ -42,7 +42,8 @@ __global__ __launch_bounds__(256, 4) void mha_relpos_kernel(const unsigned short
   __shared__ __attribute__((aligned(16))) unsigned char sV[64 * 128];
   __shared__ __attribute__((aligned(16))) float sP[4 * 16 * PS];
 
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps block indices / addresses scalar
   const int g = lane >> 4, n = lane & 15;
   const int i0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
   const int D = H * 64, D3 = 3 * D;
@@ -60,16 +61,25 @@ __global__ __launch_bounds__(256, 4) void mha_relpos_kernel(const unsigned short
 
   // K/V staging: thread owns chunks (row = idx>>3, c = idx&7), idx = tid and tid + 256.  Named registers
   // (not arrays captured by a lambda: those are demoted to scratch memory and serialise the prefetch).
+  // Per-lane base pointers are formed once; a key tile only adds a uniform offset (tail tile: clamped rows).
   const int srow0 = tid >> 3, srow1 = srow0 + 32, sc = tid & 7;
+  const unsigned short* kv0 = qkv + (base_b + srow0) * D3 + h * 64 + sc * 8 + D;
+  const unsigned short* kv1 = qkv + (base_b + srow1) * D3 + h * 64 + sc * 8 + D;
   uint4 kreg0, kreg1, vreg0, vreg1;
-#define ATTN_LOAD_KV(J0)                                                                              \
-  {                                                                                                   \
-    const unsigned short* s0_ = qkv + (base_b + min((J0) + srow0, T - 1)) * D3 + h * 64 + sc * 8;   \
-    const unsigned short* s1_ = qkv + (base_b + min((J0) + srow1, T - 1)) * D3 + h * 64 + sc * 8;   \
-    kreg0 = *reinterpret_cast<const uint4*>(s0_ + D);                                                 \
-    vreg0 = *reinterpret_cast<const uint4*>(s0_ + 2 * D);                                             \
-    kreg1 = *reinterpret_cast<const uint4*>(s1_ + D);                                                 \
-    vreg1 = *reinterpret_cast<const uint4*>(s1_ + 2 * D);                                             \
+#define ATTN_LOAD_KV(J0)                                                                                  \
+  {                                                                                                       \
+    const unsigned short *s0_, *s1_;                                                                      \
+    if ((J0) + 64 <= T) { /* uniform: whole tile inside the utterance */                                  \
+      s0_ = kv0 + (size_t)(J0) * D3;                                                                      \
+      s1_ = kv1 + (size_t)(J0) * D3;                                                                      \
+    } else {                                                                                              \
+      s0_ = qkv + (base_b + min((J0) + srow0, T - 1)) * D3 + h * 64 + sc * 8 + D;                         \
+      s1_ = qkv + (base_b + min((J0) + srow1, T - 1)) * D3 + h * 64 + sc * 8 + D;                         \
+    }                                                                                                     \
+    kreg0 = *reinterpret_cast<const uint4*>(s0_);                                                         \
+    vreg0 = *reinterpret_cast<const uint4*>(s0_ + D);                                                     \
+    kreg1 = *reinterpret_cast<const uint4*>(s1_);                                                         \
+    vreg1 = *reinterpret_cast<const uint4*>(s1_ + D);                                                     \
   }
 #define ATTN_STORE_KV()                                                       \
   {                                                                           \
@@ -78,14 +88,15 @@ __global__ __launch_bounds__(256, 4) void mha_relpos_kernel(const unsigned short
     *reinterpret_cast<uint4*>(sV + v_off(srow0, sc)) = vreg0;                 \
     *reinterpret_cast<uint4*>(sV + v_off(srow1, sc)) = vreg1;                 \
   }
-  // band fragments of key tile j0: band tile t covers rel = 16*q + 15 - m, q = (i0w - j0)/16 - t
+  // band fragments of key tile j0: band tile t covers rel = 16*q + 15 - m, q = (i0w - j0)/16 - t (scalar)
   bf16x8 pf0[5], pf1[5];
+  const bf16x8* pe_lane = pe_packed + lane;
 #define ATTN_LOAD_PE(PF, KSI, J0)                                                 \
   {                                                                               \
     const int qb_ = (i0w - (J0)) / 16; /* exact: both are multiples of 16 */      \
     _Pragma("unroll") for (int t = 0; t < 5; ++t) {                               \
       const int qi_ = min(max(qb_ - t, q_min), q_max) - q_min;                    \
-      PF[t] = pe_packed[((size_t)qi_ * 2 + (KSI)) * 64 + lane];                   \
+      PF[t] = pe_lane[(size_t)(qi_ * 2 + (KSI)) * 64];                            \
     }                                                                             \
   }
 
@@ -94,6 +105,7 @@ __global__ __launch_bounds__(256, 4) void mha_relpos_kernel(const unsigned short
   for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -1e30f, l_run = 0.f;
   float* Pw = sP + w * 16 * PS;
+  const float* Pr = Pw + n * PS + 15 - n + 4 * g;  // this lane's skewed read base: + 16t + r
   const int q4 = n >> 2, p4 = n & 3;
 
   stamp(stamps, 0);
@@ -105,14 +117,30 @@ __global__ __launch_bounds__(256, 4) void mha_relpos_kernel(const unsigned short
   stamp(stamps, 1);
   for (int j0 = 0; j0 < T; j0 += 64) {
     const bool more = j0 + 64 < T;
-    ATTN_LOAD_PE(pf1, 1, j0)  // second half of this tile's band operands: lands during K.Q^T
+    ATTN_LOAD_PE(pf1, 1, j0)  // second half of this tile's band operands: lands during the first band MFMAs
     __builtin_amdgcn_sched_barrier(0);
-    // ---- S^T = K Q^T and the position band Pb^T = PE_band Q^T
-    f32x4 s[4], pb[5];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- position band Pb^T = PE_band Q^T  -> per-wave scratch Pw[query n][c], c = 16t + 4g + r
+    f32x4 pb[5];
 #pragma unroll
     for (int t = 0; t < 5; ++t) pb[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 5; ++t) pb[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf0[t], qf[0], pb[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 5; ++t) pb[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf1[t], qf[1], pb[t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) ATTN_LOAD_KV(j0 + 64)  // next K/V tile: in flight during S, softmax and P.V; written to LDS after them
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 5; ++t) *reinterpret_cast<f32x4*>(Pw + n * PS + 16 * t + 4 * g) = pb[t];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- S^T = bias (skew-read of the band, as the accumulator's initial value) + K Q^T
+    f32x4 s[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) s[t] = f32x4{Pr[16 * t], Pr[16 * t + 1], Pr[16 * t + 2], Pr[16 * t + 3]};
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -121,37 +149,22 @@ __global__ __launch_bounds__(256, 4) void mha_relpos_kernel(const unsigned short
         s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], s[t], 0, 0, 0);
       }
     }
+    if (!more) {  // only the last key tile has a tail: real branch (uniform), no selects on the main path
 #pragma unroll
-    for (int t = 0; t < 5; ++t) pb[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf0[t], qf[0], pb[t], 0, 0, 0);
+      for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int t = 0; t < 5; ++t) pb[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf1[t], qf[1], pb[t], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (more) ATTN_LOAD_KV(j0 + 64)  // next K/V tile: in flight during softmax + P.V, written to LDS after them
-    __builtin_amdgcn_sched_barrier(0);
+        for (int r = 0; r < 4; ++r)
+          if (j0 + 16 * t + 4 * g + r >= T) s[t][r] = -1e30f;
+      asm volatile("" ::: "memory");
+    }
 
-    // band -> per-wave scratch Pw[query n][c], c = 16t + 4g + r
+    // ---- online softmax (query i = lane&15; keys spread over regs and g)
+    float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
 #pragma unroll
-    for (int t = 0; t < 5; ++t) *reinterpret_cast<f32x4*>(Pw + n * PS + 16 * t + 4 * g) = pb[t];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    // ---- scores, tail mask, online softmax (query i = lane&15; keys spread over regs and g)
-    float mx = -1e30f;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int jl = 16 * t + 4 * g + r;
-        float v = s[t][r] + Pw[n * PS + 15 - n + jl];
-        if (!more) v = (j0 + jl < T) ? v : -1e30f;  // only the last key tile has a tail
-        s[t][r] = v;
-        mx = fmaxf(mx, v);
-      }
+    for (int t = 1; t < 4; ++t) mx = fmaxf(mx, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
     const float mscaled = m_new * LOG2E;
     float psum = 0.f;
 #pragma unroll
@@ -162,10 +175,14 @@ __global__ __launch_bounds__(256, 4) void mha_relpos_kernel(const unsigned short
         s[t][r] = p;
         psum += p;
       }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
+    if (__any(m_new != m_run)) {  // rescale only when some query's running maximum moved
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+      l_run *= alpha;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] *= alpha;
+      for (int i = 0; i < 4; ++i) o[i] *= alpha;
+      m_run = m_new;
+    }
+    l_run += psum;
 
     // ---- O^T += V^T P^T.  k index of the MFMA <-> key j = 32ks + 16*(e>>2) + 4g + (e&3)
 #pragma unroll
