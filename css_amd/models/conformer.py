@@ -219,7 +219,70 @@ class Conformer(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward_masks(self, f, want_encoder_out=False):
-        """f: f32 [N,T,idim] on the GPU -> ReLU masks f32 [N,T,num_bins*(num_spk+num_noise)]."""
+        """f: f32 [N,T,idim] on the GPU -> ReLU masks f32 [N,T,num_bins*(num_spk+num_noise)].
+
+        Under autograd (grad enabled and trainable parameters) the result carries a grad_fn whose backward is
+        the stop-gap of css_amd/autograd.py; the values are the HIP kernels' either way."""
+        if (not want_encoder_out and torch.is_grad_enabled()
+                and any(p.requires_grad for p in self.parameters())):
+            from ..autograd import masks_for_training
+            return masks_for_training(self, f)
+        return self._forward_masks_hip(f, want_encoder_out)
+
+    # ------------------------------------------------------------------ backward stop-gap (see css_amd/autograd.py)
+    def _twin_forward_masks(self, f):
+        """Differentiable fp32 PyTorch-ROCm restatement of conformer.py:83-104 (dropout off), used ONLY to
+        back-propagate; BatchNorm follows self.training and updates its running statistics like the reference."""
+        import math
+        import torch.nn.functional as F
+        enc = self.conformer
+        eps = torch.finfo(torch.float32).eps
+        x = (f - f.mean(-2, keepdim=True)) / (f.std(-2, keepdim=True) + eps)
+        x = F.relu(enc.embed[1](enc.embed[0](x)))
+        B, T, D = x.shape
+        H = enc.n_head
+        dk = D // H
+        idx = torch.arange(T, device=x.device)
+        rel = (idx[:, None] - idx[None, :]).clamp(-enc.pos_emb.maxlen, enc.pos_emb.maxlen - 1) + enc.pos_emb.maxlen
+        pos_k = enc.pos_emb.pe_k(rel)  # [T,T,dk]
+        for lay in enc.encoders:
+            def ffn(m, h):
+                return m.net[3](F.relu(m.net[0](m.layer_norm(h))))
+            x = x + 0.5 * ffn(lay.feed_forward_in, x)
+            a = lay.self_attn
+            h = a.layer_norm(x)
+            q = a.linear_q(h).view(B, T, H, dk).transpose(1, 2)
+            k = a.linear_k(h).view(B, T, H, dk).transpose(1, 2)
+            v = a.linear_v(h).view(B, T, H, dk).transpose(1, 2)
+            sc = (torch.matmul(q, k.transpose(-1, -2)) + torch.einsum("bhid,ijd->bhij", q, pos_k)) / math.sqrt(dk)
+            ctxv = torch.matmul(torch.softmax(sc, -1), v).transpose(1, 2).reshape(B, T, D)
+            x = x + a.linear_out(ctxv)
+            c = lay.conv
+            h = c.layer_norm(x)
+            w1, b1 = c.pw_conv_1.weight.view(2), c.pw_conv_1.bias
+            g = (w1[0] * h + b1[0]) * torch.sigmoid(w1[1] * h + b1[1])            # [B,T,D]
+            # depthwise conv as unfold + contraction, BatchNorm written out: plain tensor ops only (no MIOpen
+            # kernel search on the first call)
+            ksz = c.kernel_size
+            gp = F.pad(g, (0, 0, ksz // 2, ksz // 2)).unfold(1, ksz, 1)             # [B,T,D,k]
+            y = (gp * c.dw_conv_1d.weight.view(1, 1, D, ksz)).sum(-1) + c.dw_conv_1d.bias
+            if self.training:
+                mu, var = y.mean((0, 1)), y.var((0, 1), unbiased=False)
+                with torch.no_grad():
+                    nel = y.shape[0] * y.shape[1]
+                    c.BN.running_mean.mul_(0.9).add_(0.1 * mu)
+                    c.BN.running_var.mul_(0.9).add_(0.1 * var * nel / max(nel - 1, 1))
+                    c.BN.num_batches_tracked += 1
+            else:
+                mu, var = c.BN.running_mean, c.BN.running_var
+            y = (y - mu) * torch.rsqrt(var + c.BN.eps) * c.BN.weight + c.BN.bias
+            y = F.relu(y) * c.pw_conv_2.weight.view(()) + c.pw_conv_2.bias.view(())
+            x = x + y
+            x = x + 0.5 * ffn(lay.feed_forward_out, x)
+            x = lay.layer_norm(x)
+        return F.relu(self.linear(x))
+
+    def _forward_masks_hip(self, f, want_encoder_out=False):
         ops._need(f, torch.float32, "f")
         if f.dim() != 3 or f.shape[2] != self.conformer.idim:
             raise RuntimeError(f"expected [N, T, {self.conformer.idim}] features, got {tuple(f.shape)}")

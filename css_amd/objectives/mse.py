@@ -39,7 +39,11 @@ class MeanSquaredError(torch.nn.Module):
             F = model.num_bins
             assert model.num_spk == 2, "MeanSquaredError hard-codes two sources (mse.py:27-28)"
             assert tuple(y1.shape) == (B, T, F), f"{(B, 2, T, F)} != {tuple(torch.stack((y1, y2), 1).shape)}"
-            loss, perm, _, _ = ops.pit_mse(masks, xs, [y1, y2])
+            if masks.requires_grad:  # training: hand-written PIT backward w.r.t. the masks
+                from ..autograd import PitMse
+                loss, perm = PitMse.apply(masks, xs, model.num_spk + model.num_noise, y1, y2)
+            else:
+                loss, perm, _, _ = ops.pit_mse(masks, xs, [y1, y2])
         else:  # any other nn.Module returning (y_pred, masks) or y_pred
             out = model(xs)
             y_pred = out[0] if isinstance(out, (tuple, list)) else out

@@ -236,7 +236,8 @@ def pit_mse_bwd(masks, f_orig, targets, perm, n_masks, grad_loss=1.0):
     K = len(targets)
     B, T, F = targets[0].shape
     arr, keep = _targets_array(targets, B, T, F)
-    grad = torch.empty_like(masks)
+    # same (possibly padded) row stride as the masks: the kernel addresses both with ld_mask
+    grad = torch.empty_strided(masks.shape, masks.stride(), device=masks.device, dtype=masks.dtype)
     check(lib().csship_pit_mse_bwd(_ptr(masks), masks.stride(1), _ptr(f_orig), f_orig.stride(1), arr, _ptr(perm),
                                    B, T, F, K, n_masks, float(grad_loss), _ptr(grad), _stream()))
     return grad

@@ -1,9 +1,9 @@
 """Epoch loops -- same positional signatures as css/trainer/iteration_types.py:17,67.
 
 ``validate`` (forward only) runs entirely on the HIP path.  ``train_one_epoch`` keeps the
-reference's step order (forward, backward, clip, step, zero_grad, scheduler); the backward
-kernels of the encoder are not built in this revision, so with a css_amd model it stops with
-a clear error at the backward call instead of silently training nothing.
+reference's step order (forward, backward, clip, step, zero_grad, scheduler).  Forward and the
+PIT backward are HIP kernels; the encoder backward is the stop-gap of css_amd/autograd.py
+(PyTorch-ROCm restatement used only to back-propagate) until the backward kernels exist.
 In a multi-GPU job (torch.distributed initialised) gradients are summed across ranks with one
 flat-bucket all-reduce over RCCL before clipping (css_amd/parallel.py), replacing the
 reference's per-epoch checkpoint averaging (scripts/python/combine_models.py:55-82).
@@ -23,9 +23,7 @@ def train_one_epoch(args, generator, model, objective, optim, lr_sched, device="
                f"window (# frames): {b['mix'].size(1)} ovl: {b['ovl']:0.4f} ")
         loss = objective(model, b, device=device)
         if not loss.requires_grad:
-            raise NotImplementedError(
-                "css_amd: this revision builds the forward + PIT path only; encoder backward kernels are the "
-                "next milestone (DESIGN.md), so train_one_epoch cannot update this model yet")
+            raise RuntimeError("css_amd: loss has no grad_fn (model parameters frozen or grad disabled)")
         loss_val = loss.data.item()
         log += f"Loss: {loss_val:0.5f} "
         total_loss += loss_val
