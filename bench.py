@@ -12,9 +12,11 @@ are work, not frames).  N > 1: one process per GPU (torchrun), every rank runs i
 sides of the timed region, max over ranks.
 
 Extra objects on the JSON line (task section 4):
-  roofline     dominant kernel = the fused FeedForward (ffn_kernel: 32 launches per step, MFMA
-               bound); achieved = algorithmic 4*M*256*1024 flops / average launch duration
-               measured with HIP events on the launch stream; peak = 2.5 PFLOP/s dense bf16.
+  roofline     dominant kernel = the encoder chain (chain_kernel: FFN_out+LN -> FFN_in -> LN+QKV,
+               15 launches per step, MFMA bound); achieved = algorithmic flops (2 x 4*M*256*1024 +
+               2*M*256*768) / average launch duration measured with HIP events on the launch
+               stream; peak = 2.5 PFLOP/s dense bf16; traffic = HBM bytes per launch from the
+               rocprofv3 PMC pass committed under profiles/ (null if absent).
                roofline.stft carries the HBM-bound front end the same way (2 052 B/frame).
   cpu_baseline the oracle (fp32 CPU restatement, kind "port") timed on this box's host cores on
                ONE full batch (rank 0, N = 1 only).
@@ -104,11 +106,14 @@ def main():
         M = B * T
         x = torch.randn(M, 256, device=dev)
         g1, b0 = torch.ones(256, device=dev), torch.zeros(256, device=dev)
-        w1 = ops.pack_frag(torch.randn(1024, 256, device=dev) / 16)
-        w2 = ops.pack_frag(torch.randn(256, 1024, device=dev) / 32)
-        b1, b2 = torch.zeros(1024, device=dev), torch.zeros(256, device=dev)
+
+        def ffn_w():
+            return ((g1, b0), ops.pack_frag(torch.randn(1024, 256, device=dev) / 16), torch.zeros(1024, device=dev),
+                    ops.pack_frag(torch.randn(256, 1024, device=dev) / 32), torch.zeros(256, device=dev))
+        fa, fb = ffn_w(), ffn_w()
+        wq, bq = ops.pack_frag(torch.randn(768, 256, device=dev) / 16), torch.zeros(768, device=dev)
         out = torch.empty_like(x)
-        run = lambda: ops.ffn_fused(x, (g1, b0), w1, b1, w2, b2, 1024, 0.5, final_ln=(g1, b0), out=out)  # noqa: E731
+        run = lambda: ops.encoder_chain(x, 1024, ffn_a=fa, final_ln=(g1, b0), ffn_b=fb, qkv=((g1, b0), wq, bq, 768), out=out)  # noqa: E731
         for _ in range(5):
             run()
         reps = 50
@@ -119,10 +124,18 @@ def main():
         e1.record(torch.cuda.current_stream())
         torch.cuda.synchronize()
         dur = e0.elapsed_time(e1) * 1e-3 / reps
-        flops = 4.0 * M * 256 * 1024  # two GEMMs of 2*M*256*1024 each (26.84 GFLOP per layer / 2)
-        roof = {"bound": "mfma", "kernel": "ffn_kernel<8,true> (LN -> 256x1024 -> ReLU -> 1024x256 -> +res -> LN, M=12800)",
+        # two FeedForwards (4*M*256*1024 each) + the q/k/v projection (2*M*256*768): SURVEY.md 8(d) per-layer figures
+        flops = 2 * 4.0 * M * 256 * 1024 + 2.0 * M * 256 * 768
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath):
+            for name, rec in json.load(open(tpath)).items():
+                if name.startswith("chain_kernel<8, false, true, true, true>"):
+                    traffic = rec["hbm_bytes_per_launch"]
+        roof = {"bound": "mfma", "kernel": "chain_kernel<8,0,1,1,1> (FFN_out+LN -> FFN_in -> LN+QKV, M=12800; 15 launches/step)",
                 "achieved": flops / dur / 1e12, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                "frac": flops / dur / PEAK_BF16, "traffic": None, "avg_launch_us": dur * 1e6,
+                "frac": flops / dur / PEAK_BF16, "traffic": traffic, "avg_launch_us": dur * 1e6,
+                "flops_per_launch": flops,
                 "whole_step_frac": (B * T * FLOP_PER_FRAME * args.blocks / 16) / (dt / args.steps) / PEAK_BF16}
         # HBM-bound front end for reference (north_star asks for the STFT roofline too)
         for _ in range(3):

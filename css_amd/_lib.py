@@ -66,8 +66,8 @@ SIGNATURES = {
     "csship_panel_linear": (_i32, [_p, _i32, _p, _p, _p, _p, _p, _i64, _f32, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "csship_embed": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "csship_outproj_glu": (_i32, [_p, _p, _p, _p, _p, C.POINTER(ConvWeights), _p, _i32, _i32, _p]),
-    "csship_encoder_chain": (_i32, [_p, _p, _p, C.POINTER(ConvWeights), _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32,
-                                     _i32, _i32, _i32, _p]),
+    "csship_encoder_chain": (_i32, [_p, _p, _p, C.POINTER(ConvWeights), _i32, C.POINTER(FfnWeights), _p, _p,
+                                     C.POINTER(FfnWeights), _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "csship_mha_relpos": (_i32, [_p, _p, _i32, _i32, _p, _i32, _i32, _i32, _p]),
     "csship_convmod_workspace": (_sz, [_i32, _i32, _i32]),
     "csship_convmod": (_i32, [_p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _i32, _p, _p]),

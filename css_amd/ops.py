@@ -330,3 +330,31 @@ def istft(re, im, length=None):
     wav = torch.empty(S, length, device=re.device, dtype=torch.float32)
     check(lib().csship_istft(_ptr(re), _ptr(im), S, T, length, _ptr(wav), _stream()))
     return wav
+
+
+def _ffn_struct(ln, w1p, b1, w2p, b2):
+    w = _lib.FfnWeights()
+    w.ln_g, w.ln_b, w.w1, w.b1, w.w2, w.b2 = (t.data_ptr() for t in (ln[0], ln[1], w1p, b1, w2p, b2))
+    return w
+
+
+def encoder_chain(x, d_ffn, ffn_a=None, final_ln=None, ffn_b=None, qkv=None, out=None):
+    """csship_encoder_chain on x f32 [M,256].  ffn_a / ffn_b: (ln=(g,b), w1p, b1, w2p, b2) with packed weights;
+    final_ln: (g, b) applied after ffn_a; qkv: (ln=(g,b), wqkv_packed, bqkv, n_qkv).  Returns (x_out, qkv_bf16|None)."""
+    _need(x, torch.float32, "x")
+    assert x.dim() == 2 and x.is_contiguous() and x.shape[1] == 256
+    M = x.shape[0]
+    if out is None:
+        out = torch.empty_like(x)
+    fa = _ffn_struct(*ffn_a) if ffn_a is not None else None
+    fb = _ffn_struct(*ffn_b) if ffn_b is not None else None
+    q_out, n_qkv = None, 0
+    if qkv is not None:
+        n_qkv = qkv[3]
+        q_out = torch.empty(M, n_qkv, device=x.device, dtype=torch.bfloat16)
+    check(lib().csship_encoder_chain(
+        _ptr(x), _ptr(out), None, None, 1, C.byref(fa) if fa is not None else None,
+        _ptr(final_ln[0]) if final_ln else None, _ptr(final_ln[1]) if final_ln else None,
+        C.byref(fb) if fb is not None else None, _ptr(qkv[0][0]) if qkv else None, _ptr(qkv[0][1]) if qkv else None,
+        _ptr(qkv[1]) if qkv else None, _ptr(qkv[2]) if qkv else None, _ptr(q_out), M, 256, d_ffn, n_qkv, _stream()))
+    return out, q_out

@@ -250,6 +250,27 @@ def test_panel_linear(ops, M, N):
         assert err(out, x + _ref_gemm(a, w, bias)) < 5e-4
 
 
+def test_encoder_chain(ops):
+    """FFN_out + LN -> FFN_in -> LN + QKV projection in one kernel == the three separate kernels."""
+    M = 300
+    x = rnd((M, 256), 110) * 1.5
+    d = lambda t: t.to(DEV)  # noqa: E731
+    def ffn_w(seed):
+        return ((d(1 + 0.1 * rnd((256,), seed)), d(0.1 * rnd((256,), seed + 1))), ops.pack_frag(d(rnd((1024, 256), seed + 2, 1 / 16))),
+                d(rnd((1024,), seed + 3, 0.1)), ops.pack_frag(d(rnd((256, 1024), seed + 4, 1 / 32))), d(rnd((256,), seed + 5, 0.1)))
+    fa, fb = ffn_w(120), ffn_w(130)
+    fin = (d(1 + 0.1 * rnd((256,), 140)), d(0.1 * rnd((256,), 141)))
+    qln = (d(1 + 0.1 * rnd((256,), 142)), d(0.1 * rnd((256,), 143)))
+    wq, bq = ops.pack_frag(d(rnd((768, 256), 144, 1 / 16))), d(rnd((768,), 145, 0.1))
+    xo, qkv = ops.encoder_chain(d(x), 1024, ffn_a=fa, final_ln=fin, ffn_b=fb, qkv=(qln, wq, bq, 768))
+    r1 = ops.ffn_fused(d(x), fa[0], fa[1], fa[2], fa[3], fa[4], 1024, 0.5, final_ln=fin)
+    r2 = ops.ffn_fused(r1, fb[0], fb[1], fb[2], fb[3], fb[4], 1024, 0.5)
+    rq = ops.panel_linear(r2, wq, bq, 768, ln=qln, out_bf16=True)
+    assert err(xo, r2) < 1e-3        # same arithmetic; hidden-chunk rotation differs between the kernels
+    assert err(qkv.float(), rq.float()) < 6e-2  # bf16 outputs of O(4) values: one ulp = 3e-2
+    assert float(((qkv.float() - rq.float()) ** 2).mean()) < 1e-5
+
+
 # ----------------------------------------------------------------------------- attention
 def _ref_attention(q, k, v, pe, maxlen=1000):
     """q (pre-scaled), k, v: [B,H,T,64] float; pe [2*maxlen,64] -> [B,T,H*64] (float64)."""
