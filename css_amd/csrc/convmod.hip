@@ -139,22 +139,35 @@ __global__ __launch_bounds__(2 * D) void convmod_kernel(ConvArgs a) {
   }
 }
 
-// per-channel batch statistics -> scale/shift (biased variance, as BatchNorm1d normalises with)
-__global__ void bn_reduce_kernel(const float* __restrict__ partial, int nblk, int D, double count,
-                                 const float* __restrict__ bn_g, const float* __restrict__ bn_b,
-                                 float* __restrict__ scale_shift) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= D) return;
+// per-channel batch statistics -> scale/shift (biased variance, as BatchNorm1d normalises with).
+// Workgroup = 64 channels x 16 waves; wave w sums partials w, w+16, ... in double, then one LDS reduction.
+__global__ __launch_bounds__(1024) void bn_reduce_kernel(const float* __restrict__ partial, int nblk, int D, double count,
+                                                         const float* __restrict__ bn_g, const float* __restrict__ bn_b,
+                                                         float* __restrict__ scale_shift) {
+  __shared__ double red[2][16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   double s = 0.0, q = 0.0;
-  for (int i = 0; i < nblk; ++i) {
-    s += (double)partial[((size_t)i * 2 + 0) * D + c];
-    q += (double)partial[((size_t)i * 2 + 1) * D + c];
+  if (c < D)
+    for (int i = w; i < nblk; i += 16) {
+      s += (double)partial[((size_t)i * 2 + 0) * D + c];
+      q += (double)partial[((size_t)i * 2 + 1) * D + c];
+    }
+  red[0][w][lane] = s;
+  red[1][w][lane] = q;
+  __syncthreads();
+  if (w == 0 && c < D) {
+    s = q = 0.0;
+    for (int i = 0; i < 16; ++i) {
+      s += red[0][i][lane];
+      q += red[1][i][lane];
+    }
+    const double mu = s / count;
+    const double var = fmax(q / count - mu * mu, 0.0);
+    const float sc = bn_g[c] * (float)(1.0 / sqrt(var + 1e-5));
+    scale_shift[c] = sc;
+    scale_shift[D + c] = bn_b[c] - (float)mu * sc;
   }
-  const double mu = s / count;
-  const double var = fmax(q / count - mu * mu, 0.0);
-  const float sc = bn_g[c] * (float)(1.0 / sqrt(var + 1e-5));
-  scale_shift[c] = sc;
-  scale_shift[D + c] = bn_b[c] - (float)mu * sc;
 }
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ z,
@@ -194,7 +207,7 @@ int run(const ConvArgs& a0, int bn_mode, void* workspace, hipStream_t s) {
   float* scale_shift = a.partial + (size_t)nblk * 2 * D;
   hipLaunchKernelGGL((convmod_kernel<D, TT, 33, 1>), grid, dim3(2 * D), 0, s, a);
   CSSHIP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_reduce_kernel, dim3((D + 63) / 64), dim3(64), 0, s, a.partial, nblk, D,
+  hipLaunchKernelGGL(bn_reduce_kernel, dim3((D + 63) / 64), dim3(1024), 0, s, a.partial, nblk, D,
                      (double)a.B * (double)a.T, a.w.bn_g, a.w.bn_b, scale_shift);
   CSSHIP_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, a.x, a.zbuf, scale_shift,
