@@ -71,6 +71,7 @@ SIGNATURES = {
     "csship_mha_relpos": (_i32, [_p, _p, _i32, _i32, _p, _i32, _i32, _i32, _p]),
     "csship_convmod_workspace": (_sz, [_i32, _i32, _i32]),
     "csship_convmod": (_i32, [_p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _i32, _p, _p]),
+    "csship_conv_from_glu": (_i32, [_p, _p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _p]),
     "csship_pit_workspace": (_sz, [_i32, _i32, _i32, _i32]),
     "csship_pit_mse": (_i32, [_p, _i64, _p, _i64, C.POINTER(_p), _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p]),
     "csship_pit_mse_bwd": (_i32, [_p, _i64, _p, _i64, C.POINTER(_p), _p, _i32, _i32, _i32, _i32, _i32, _f32, _p, _p]),

@@ -18,13 +18,14 @@ struct ConvArgs {
   const float* x;
   float* y;
   csship_conv_weights w;
+  const float* g;  // FROMG: glu(LN(x)) rows [B,T,D]
   float* zbuf;     // train: pre-BN activations [B,T,D]
   float* partial;  // train: [nblk][2][D]
   int B, T;
   unsigned long long* stamps;
 };
 
-template <int D, int TT, int KS, int MODE>
+template <int D, int TT, int KS, int MODE, bool FROMG>
 __global__ __launch_bounds__(2 * D) void convmod_kernel(ConvArgs a) {
   constexpr int HALO = (KS - 1) / 2, ROWS = TT + KS - 1, NTHR = 2 * D;
   __shared__ __attribute__((aligned(16))) float G[ROWS][D];
@@ -37,6 +38,15 @@ __global__ __launch_bounds__(2 * D) void convmod_kernel(ConvArgs a) {
   // whole 128-byte lines per load); LayerNorm statistics = in-lane sums + log2(LPR) shuffles.
   constexpr int LPR = D / 32, RPB = NTHR / LPR;  // rows per batch of the workgroup (64 for D = 256)
   const int part = tid % LPR;
+  if constexpr (FROMG) {  // g = glu(LayerNorm(x)) was produced by csship_outproj_glu: plain tile + halo load
+    for (int i = tid; i < ROWS * (D / 4); i += NTHR) {
+      const int row = i / (D / 4), c4 = i % (D / 4);
+      const int t = t0 - HALO + row;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t >= 0 && t < a.T) v = *reinterpret_cast<const float4*>(a.g + ((size_t)b * a.T + t) * D + c4 * 4);
+      *reinterpret_cast<float4*>(&G[row][c4 * 4]) = v;
+    }
+  } else
   for (int r0 = 0; r0 < ROWS; r0 += RPB) {
     const int row = r0 + tid / LPR;
     if (row >= ROWS) break;
@@ -195,7 +205,8 @@ int run(const ConvArgs& a0, int bn_mode, void* workspace, hipStream_t s) {
   ConvArgs a = a0;
   dim3 grid((a.T + TT - 1) / TT, a.B);
   if (bn_mode == 0) {
-    hipLaunchKernelGGL((convmod_kernel<D, TT, 33, 0>), grid, dim3(2 * D), 0, s, a);
+    if (a.g != nullptr) hipLaunchKernelGGL((convmod_kernel<D, TT, 33, 0, true>), grid, dim3(2 * D), 0, s, a);
+    else hipLaunchKernelGGL((convmod_kernel<D, TT, 33, 0, false>), grid, dim3(2 * D), 0, s, a);
     CSSHIP_CHECK_LAUNCH();
     return CSSHIP_OK;
   }
@@ -205,7 +216,7 @@ int run(const ConvArgs& a0, int bn_mode, void* workspace, hipStream_t s) {
   a.zbuf = reinterpret_cast<float*>(workspace);
   a.partial = a.zbuf + n;
   float* scale_shift = a.partial + (size_t)nblk * 2 * D;
-  hipLaunchKernelGGL((convmod_kernel<D, TT, 33, 1>), grid, dim3(2 * D), 0, s, a);
+  hipLaunchKernelGGL((convmod_kernel<D, TT, 33, 1, false>), grid, dim3(2 * D), 0, s, a);
   CSSHIP_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_reduce_kernel, dim3((D + 63) / 64), dim3(1024), 0, s, a.partial, nblk, D,
                      (double)a.B * (double)a.T, a.w.bn_g, a.w.bn_b, scale_shift);
@@ -238,7 +249,19 @@ extern "C" int csship_convmod(const float* x, float* y, const csship_conv_weight
   if (x == y) return CSSHIP_EBADSHAPE;  // neighbouring tiles read the halo rows: not in-place safe
   if (!aligned16(x) || !aligned16(y) || !aligned16(w->ln_g) || !aligned16(w->ln_b) || (workspace && !aligned16(workspace)))
     return CSSHIP_EALIGN;
-  ConvArgs a{x, y, *w, nullptr, nullptr, B, T, g_csship_stamps};
+  ConvArgs a{x, y, *w, nullptr, nullptr, nullptr, B, T, g_csship_stamps};
   if (D == 256) return run<256, TT256>(a, bn_mode, workspace, as_stream(stream));
   return run<512, TT512>(a, bn_mode, workspace, as_stream(stream));
+}
+
+extern "C" int csship_conv_from_glu(const float* x, const float* g, float* y, const csship_conv_weights* w, int32_t B,
+                                    int32_t T, int32_t D, int32_t kernel_size, csship_stream_t stream) {
+  if (!x || !g || !y || !w) return CSSHIP_ENULL;
+  if (!w->dw_w || !w->dw_b || !w->bn_g || !w->bn_b || !w->bn_mean || !w->bn_var || !w->pw2_w || !w->pw2_b) return CSSHIP_ENULL;
+  if (B <= 0 || T <= 0 || B > 65535) return CSSHIP_EBADSHAPE;
+  if (kernel_size != 33 || (D != 256 && D != 512)) return CSSHIP_EUNSUPPORTED;
+  if (!aligned16(x) || !aligned16(g) || !aligned16(y) || g == y) return CSSHIP_EALIGN;
+  ConvArgs a{x, y, *w, g, nullptr, nullptr, B, T, g_csship_stamps};
+  if (D == 256) return run<256, TT256>(a, 0, nullptr, as_stream(stream));
+  return run<512, TT512>(a, 0, nullptr, as_stream(stream));
 }

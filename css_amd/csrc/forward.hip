@@ -89,7 +89,7 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
   TRY(csship_embed(f, ldf, ws.mean, ws.rinv, w->embed_w, w->embed_b, w->embed_ln_g, w->embed_ln_b, ws.x0, B, T, w->idim,
                    D, stream));
   float *x = ws.x0, *y = ws.x1;
-  if (w->bn_mode == 0 && w->fuse_conv != 0) {
+  if (w->bn_mode == 0 && w->fuse_conv == 1) {
     // optional (measured slower at B=32 x T=400: 83 vs 75 us per block): 3 launches per block.  Row-local operators are chained per 64-row panel (csship_encoder_chain):
     //   [conv back half(l-1) -> FFN_out(l-1) + block LN] -> FFN_in(l) -> pre-LN + q/k/v projection(l)
     float* gbuf = y;  // glu(LN_conv(x)) rows handed from the output projection to the next chain
@@ -120,10 +120,16 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
                                P ? P->ln_b : nullptr, &L.ffn_in, L.mha.ln_g, L.mha.ln_b, L.mha.wqkv, L.mha.bqkv,
                                ws.qkv_bf, M, D, FF, 3 * D, stream));
       TRY(csship_mha_relpos(ws.qkv_bf, w->pe_k, w->pe_q_min, w->pe_q_max, ws.ao_bf, B, T, w->n_head, stream));
-      TRY(csship_panel_linear(ws.ao_bf, CSSHIP_PRO_BF16, nullptr, nullptr, L.mha.wo, L.mha.bo, x, D, 1.f, x, D, M, D,
-                              D, CSSHIP_EPI_RESIDUAL, stream));
-      TRY(csship_convmod(x, y, &L.conv, B, T, D, w->kernel_size, w->bn_mode, ws.conv_ws, stream));
-      { float* t = x; x = y; y = t; }
+      if (w->bn_mode == 0 && w->fuse_conv == 2) {
+        // optional (28.4 vs 27.2 us): x += out-proj(attn); g = glu(LN_conv(x)) in the same epilogue; conv back half from g
+        TRY(csship_outproj_glu(ws.ao_bf, L.mha.wo, L.mha.bo, x, x, &L.conv, y, M, D, stream));
+        TRY(csship_conv_from_glu(x, y, x, &L.conv, B, T, D, w->kernel_size, stream));
+      } else {
+        TRY(csship_panel_linear(ws.ao_bf, CSSHIP_PRO_BF16, nullptr, nullptr, L.mha.wo, L.mha.bo, x, D, 1.f, x, D, M, D,
+                                D, CSSHIP_EPI_RESIDUAL, stream));
+        TRY(csship_convmod(x, y, &L.conv, B, T, D, w->kernel_size, w->bn_mode, ws.conv_ws, stream));
+        { float* t = x; x = y; y = t; }
+      }
     }
     const csship_layer_weights& L = w->layers[w->n_layer - 1];
     TRY(csship_encoder_chain(x, x, nullptr, nullptr, T, &L.ffn_out, L.ln_g, L.ln_b, nullptr, nullptr, nullptr, nullptr,

@@ -205,7 +205,7 @@ class Conformer(nn.Module):
         w.n_out = self.linear.out_features
         pe_packed, w.pe_q_min, w.pe_q_max = ops.pack_relpos(enc.pos_emb.pe_k.weight, enc.pos_emb.maxlen)
         w.bn_mode = 1 if self.training else 0
-        w.fuse_conv = 1 if getattr(self, "fuse_conv", False) else 0
+        w.fuse_conv = int(getattr(self, "fuse_conv", 0))
         ew = torch.zeros(enc.d_model, w.idim_pad, device=dev)
         ew[:, :enc.idim] = enc.embed[0].weight.detach().float()
         w.embed_w, w.embed_b = own(ops.pack_frag(ew)), f32(enc.embed[0].bias)

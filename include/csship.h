@@ -221,6 +221,12 @@ int csship_convmod(const float* x, float* y, const csship_conv_weights* w, int32
                    int32_t D, int32_t kernel_size, int32_t bn_mode, void* workspace,
                    csship_stream_t stream);
 
+/* Back half of the conv module from a precomputed g = glu(LayerNorm_conv(x)) (csship_outproj_glu):
+ *   y = x + pw2( relu( BN_eval( dwconv_k(g) ) ) ).  x, g, y: f32 [B, T, D]; y may alias x (x is read
+ * row-locally) but not g (neighbouring tiles read halo rows of g). */
+int csship_conv_from_glu(const float* x, const float* g, float* y, const csship_conv_weights* w, int32_t B,
+                         int32_t T, int32_t D, int32_t kernel_size, csship_stream_t stream);
+
 /* ------------------------------------------------------------------ PIT-MSE
  * Fused mask application + permutation-invariant MSE: pit_loss (css/objectives/pit.py:5-62)
  * looped over the batch as MeanSquaredError.forward does (css/objectives/mse.py:31-37),
@@ -289,7 +295,8 @@ typedef struct {
   int32_t n_out;           /* num_bins * (num_spk + num_noise) */
   int32_t pe_q_min, pe_q_max; /* block range of pe_k (csship_mha_relpos) */
   int32_t bn_mode;         /* 0 eval, 1 batch statistics */
-  int32_t fuse_conv;       /* eval only: 1 = conv module fused into csship_outproj_glu + csship_encoder_chain */
+  int32_t fuse_conv;       /* eval only: 0 = separate conv module (default, fastest at B=32 x T=400); 1 = conv fused into
+                            * csship_outproj_glu + csship_encoder_chain; 2 = csship_outproj_glu + csship_conv_from_glu */
   const uint16_t* embed_w; const float* embed_b; /* PACKED bf16 from [d_model, idim_pad], idim_pad = idim rounded up to 256 */
   const float *embed_ln_g, *embed_ln_b;
   const uint16_t* pe_k;    /* PACKED relative-position blocks (csship_mha_relpos) */

@@ -105,12 +105,12 @@ def test_fused_conv_path_matches():
     m, sd = build(2, 32)
     f = rnd((3, 70, 257), 21).abs().to(DEV)
     ref = m.forward_masks(f).clone()
-    m.fuse_conv = True
-    got = m.forward_masks(f)
-    m.fuse_conv = False
-    assert mask_mse(got, ref) < 1e-6
-    o = oracle.conformer.forward(f.cpu(), sd, num_blocks=2)[1]
-    assert mask_mse(got, torch.cat(o, 2)) < 1e-4
+    o = torch.cat(oracle.conformer.forward(f.cpu(), sd, num_blocks=2)[1], 2)
+    for mode in (1, 2):  # 1: conv inside the chain kernel; 2: out-proj + GLU, then conv from g
+        m.fuse_conv = mode
+        got = m.forward_masks(f)
+        assert mask_mse(got, ref) < 1e-6 and mask_mse(got, o) < 1e-4
+    m.fuse_conv = 0
 
 
 def test_train_mode_batch_stats():
