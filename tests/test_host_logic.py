@@ -164,3 +164,29 @@ def test_gradient_allreduce_gloo_world2(tmp_path):
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
     rcs = [p.wait(timeout=120) for p in procs]
     assert rcs == [0, 0]
+
+
+def test_checkpoint_roundtrip_and_combine(tmp_path):
+    """Reference on-disk format: keys of train.py:304-317, averaging of combine_models.py:55-82."""
+    from css_amd.models import MODELS
+    from css_amd.trainer import LRScheduler
+    from css_amd.utils import checkpoint as ck
+    conf = dict(attention_dim=256, attention_heads=4, linear_units=1024, num_blocks=1, kernel_size=33,
+                dropout_rate=0.1, relative_pos_emb=True)
+    a, b = MODELS["Conformer"](257, 257, 2, 1, conf), MODELS["Conformer"](257, 257, 2, 1, conf)
+    opt = torch.optim.Adam(a.parameters(), lr=1e-3)
+    sch = LRScheduler(opt, types.SimpleNamespace(warmup=4, decay=0.1, fixed=2, min_lr=1e-9))
+    pa, pb = str(tmp_path / "3.1.mdl"), str(tmp_path / "3.2.mdl")
+    ck.save_checkpoint(pa, a, None, opt, sch, epoch=2, loss=0.5)
+    ck.save_checkpoint(pb, b, None, None, None, epoch=2, loss=0.6)
+    saved = torch.load(pa)
+    assert set(saved) == {"model", "objective", "optimizer", "lr_sched", "epoch", "loss"}
+    assert ck.epoch_checkpoints(str(tmp_path), 3) == [pa, pb]
+    out = ck.combine_models(str(tmp_path / "3.mdl"), [pa, pb])
+    avg = torch.load(out)["model"]
+    k = "conformer.encoders.0.self_attn.linear_q.weight"
+    assert torch.allclose(avg[k], (a.state_dict()[k] + b.state_dict()[k]) / 2)
+    assert avg["conformer.encoders.0.conv.BN.num_batches_tracked"].dtype == torch.int64
+    c = MODELS["Conformer"](257, 257, 2, 1, conf)
+    assert ck.load_checkpoint(out, c) == 2
+    assert torch.equal(c.state_dict()[k], avg[k])
