@@ -40,7 +40,7 @@ class LayerWeights(C.Structure):
 class ConformerWeights(C.Structure):
     _fields_ = [("idim", _i32), ("idim_pad", _i32), ("d_model", _i32), ("n_head", _i32), ("d_ffn", _i32),
                 ("n_layer", _i32), ("kernel_size", _i32), ("n_out", _i32), ("pe_q_min", _i32), ("pe_q_max", _i32),
-                ("bn_mode", _i32), ("fuse_conv", _i32),
+                ("bn_mode", _i32), ("generic", _i32), ("fuse_conv", _i32),
                 ("embed_w", _p), ("embed_b", _p), ("embed_ln_g", _p), ("embed_ln_b", _p), ("pe_k", _p),
                 ("layers", C.POINTER(LayerWeights)), ("head_w", _p), ("head_b", _p)]
 

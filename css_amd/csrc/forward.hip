@@ -11,6 +11,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct Workspace {
   float *mean, *rinv, *x0, *x1;
   unsigned short *ao_bf, *qkv_bf;
+  unsigned short *a_bf, *h_bf;  // generic (d_model != 256) path only
   void* conv_ws;
   size_t total;
 };
@@ -31,6 +32,8 @@ Workspace carve(const csship_conformer_weights* w, int B, int T, void* base) {
   ws.x1 = (float*)take(M * D * 4);
   ws.ao_bf = (unsigned short*)take(M * D * 2);
   ws.qkv_bf = (unsigned short*)take(M * 3 * D * 2);
+  ws.a_bf = w->generic ? (unsigned short*)take(M * D * 2) : nullptr;
+  ws.h_bf = w->generic ? (unsigned short*)take(M * (size_t)w->d_ffn * 2) : nullptr;
   ws.conv_ws = w->bn_mode ? take(csship_convmod_workspace(B, T, (int)D)) : nullptr;
   ws.total = off;
   return ws;
@@ -41,6 +44,55 @@ Workspace carve(const csship_conformer_weights* w, int B, int T, void* base) {
     const int rc_ = (expr);    \
     if (rc_ != CSSHIP_OK) return rc_; \
   } while (0)
+
+// C = epi(A @ W^T + bias) through the classic tiled GEMM (row-major bf16 weights, K padded to 64)
+int tiled_linear(const void* A, int a_mode, const uint16_t* W, const float* bias, const float* res, void* C, int M, int N,
+                 int K, int lda, int epi, float alpha, csship_stream_t s) {
+  csship_gemm_params p{};
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = (K + 63) / 64 * 64; p.ldc = N; p.ldr = N;
+  p.a_mode = a_mode; p.epilogue = epi; p.rows_per_batch = 1; p.alpha = alpha;
+  return csship_gemm(A, W, bias, res, C, nullptr, nullptr, nullptr, nullptr, &p, s);
+}
+
+// Any-width encoder (e.g. Conformer-large: d_model 512, 8 heads, ffn 2048): the same operators as the tuned
+// d_model = 256 path, unfused, built from the size-generic kernels.  Weights are ROW-MAJOR bf16 here.
+int forward_generic(const csship_conformer_weights* w, const float* f, int64_t ldf, int B, int T, float* masks,
+                    int64_t ld_masks, float* enc_out, const Workspace& ws, csship_stream_t stream) {
+  const int M = B * T, D = w->d_model, FF = w->d_ffn;
+  const int BF = CSSHIP_EPI_OUT_BF16;
+  TRY(csship_mvn_stats(f, B, T, w->idim, ldf, -INFINITY, 1.1920928955078125e-07f, ws.mean, ws.rinv, stream));
+  {
+    csship_gemm_params p{};
+    p.M = M; p.N = D; p.K = w->idim; p.lda = (int)ldf; p.ldw = w->idim_pad; p.ldc = D; p.ldr = D;
+    p.a_mode = CSSHIP_A_F32_MVN; p.epilogue = 0; p.rows_per_batch = T;
+    TRY(csship_gemm(f, w->embed_w, w->embed_b, nullptr, ws.x1, ws.mean, ws.rinv, nullptr, nullptr, &p, stream));
+    TRY(csship_layernorm_relu(ws.x1, M, D, w->embed_ln_g, w->embed_ln_b, 1, nullptr, ws.x0, stream));
+  }
+  float *x = ws.x0, *y = ws.x1;
+  for (int l = 0; l < w->n_layer; ++l) {
+    const csship_layer_weights& L = w->layers[l];
+    TRY(csship_layernorm(x, M, D, L.ffn_in.ln_g, L.ffn_in.ln_b, ws.a_bf, nullptr, stream));
+    TRY(tiled_linear(ws.a_bf, CSSHIP_A_BF16, L.ffn_in.w1, L.ffn_in.b1, nullptr, ws.h_bf, M, FF, D, D, CSSHIP_EPI_RELU | BF, 0.f, stream));
+    TRY(tiled_linear(ws.h_bf, CSSHIP_A_BF16, L.ffn_in.w2, L.ffn_in.b2, x, x, M, D, FF, FF, CSSHIP_EPI_RESIDUAL, 0.5f, stream));
+    TRY(csship_layernorm(x, M, D, L.mha.ln_g, L.mha.ln_b, ws.a_bf, nullptr, stream));
+    TRY(tiled_linear(ws.a_bf, CSSHIP_A_BF16, L.mha.wqkv, L.mha.bqkv, nullptr, ws.qkv_bf, M, 3 * D, D, D, BF, 0.f, stream));
+    TRY(csship_mha_relpos(ws.qkv_bf, w->pe_k, w->pe_q_min, w->pe_q_max, ws.ao_bf, B, T, w->n_head, stream));
+    TRY(tiled_linear(ws.ao_bf, CSSHIP_A_BF16, L.mha.wo, L.mha.bo, x, x, M, D, D, D, CSSHIP_EPI_RESIDUAL, 1.f, stream));
+    TRY(csship_convmod(x, y, &L.conv, B, T, D, w->kernel_size, w->bn_mode, ws.conv_ws, stream));
+    { float* t = x; x = y; y = t; }
+    TRY(csship_layernorm(x, M, D, L.ffn_out.ln_g, L.ffn_out.ln_b, ws.a_bf, nullptr, stream));
+    TRY(tiled_linear(ws.a_bf, CSSHIP_A_BF16, L.ffn_out.w1, L.ffn_out.b1, nullptr, ws.h_bf, M, FF, D, D, CSSHIP_EPI_RELU | BF, 0.f, stream));
+    TRY(tiled_linear(ws.h_bf, CSSHIP_A_BF16, L.ffn_out.w2, L.ffn_out.b2, x, x, M, D, FF, FF, CSSHIP_EPI_RESIDUAL, 0.5f, stream));
+    TRY(csship_layernorm(x, M, D, L.ln_g, L.ln_b, nullptr, y, stream));
+    { float* t = x; x = y; y = t; }
+  }
+  if (enc_out && hipMemcpyAsync(enc_out, x, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream)) != hipSuccess)
+    return CSSHIP_ELAUNCH;
+  csship_gemm_params p{};
+  p.M = M; p.N = w->n_out; p.K = D; p.lda = D; p.ldw = (D + 63) / 64 * 64; p.ldc = (int)ld_masks; p.ldr = (int)ld_masks;
+  p.a_mode = CSSHIP_A_F32; p.epilogue = CSSHIP_EPI_RELU; p.rows_per_batch = 1;
+  return csship_gemm(x, w->head_w, w->head_b, nullptr, masks, nullptr, nullptr, nullptr, nullptr, &p, stream);
+}
 
 }  // namespace
 
@@ -76,12 +128,16 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
                                         size_t workspace_bytes, csship_stream_t stream) {
   if (!w || !f || !masks || !workspace || !w->layers) return CSSHIP_ENULL;
   if (B <= 0 || T <= 0 || ldf < w->idim || ld_masks < w->n_out) return CSSHIP_EBADSHAPE;
-  if (w->d_model != 256 || w->d_model / w->n_head != 64 || w->kernel_size != 33 || (w->d_ffn % 256) != 0 ||
-      (w->idim_pad % 256) != 0 || w->idim_pad < w->idim)
+  if (w->d_model / w->n_head != 64 || w->kernel_size != 33 || w->idim_pad < w->idim) return CSSHIP_EUNSUPPORTED;
+  if (w->generic) {
+    if ((w->d_model != 256 && w->d_model != 512) || (w->d_ffn % 64) != 0 || (w->idim_pad % 64) != 0) return CSSHIP_EUNSUPPORTED;
+  } else if (w->d_model != 256 || (w->d_ffn % 256) != 0 || (w->idim_pad % 256) != 0) {
     return CSSHIP_EUNSUPPORTED;
+  }
   if (!aligned16(workspace)) return CSSHIP_EALIGN;
   Workspace ws = carve(w, B, T, workspace);
   if (ws.total > workspace_bytes) return CSSHIP_EWORKSPACE;
+  if (w->generic) return forward_generic(w, f, ldf, B, T, masks, ld_masks, enc_out, ws, stream);
   const int M = B * T, D = w->d_model, FF = w->d_ffn;
 
   // input MVN over time (conformer.py:95) folded into the embed GEMM's A load

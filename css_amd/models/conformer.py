@@ -145,7 +145,7 @@ class Conformer(nn.Module):
 
     # ------------------------------------------------------------------ weight packing
     def _pack_key(self):
-        return (self.training, getattr(self, "fuse_conv", False)) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (self.training, getattr(self, "fuse_conv", False), getattr(self, "force_generic", False)) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def _pack(self):
         """bf16 shadow copies of the GEMM weights + the pointer table csship_conformer_forward reads."""
@@ -157,6 +157,8 @@ class Conformer(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError("css_amd.Conformer runs on an MI355X only; move the module to 'cuda' (no CPU path)")
         keep = []  # tensors owned by the pack (bf16 shadows, fused biases)
+        generic = enc.d_model != 256 or bool(getattr(self, "force_generic", False))
+        packw = ops.pad_weight_bf16 if generic else ops.pack_frag  # row-major (any width) vs MFMA fragment order
 
         def own(t):
             keep.append(t)
@@ -171,8 +173,8 @@ class Conformer(nn.Module):
         def ffn(m):
             w = _lib.FfnWeights()
             w.ln_g, w.ln_b = f32(m.layer_norm.weight), f32(m.layer_norm.bias)
-            w.w1, w.b1 = own(ops.pack_frag(m.net[0].weight)), f32(m.net[0].bias)
-            w.w2, w.b2 = own(ops.pack_frag(m.net[3].weight)), f32(m.net[3].bias)
+            w.w1, w.b1 = own(packw(m.net[0].weight)), f32(m.net[0].bias)
+            w.w2, w.b2 = own(packw(m.net[3].weight)), f32(m.net[3].bias)
             return w
 
         layers = (_lib.LayerWeights * len(enc.encoders))()
@@ -186,8 +188,8 @@ class Conformer(nn.Module):
             bqkv = torch.cat([a.linear_q.bias.detach() * scale, a.linear_k.bias.detach(),
                               a.linear_v.bias.detach()], 0).float().contiguous()
             L.mha.ln_g, L.mha.ln_b = f32(a.layer_norm.weight), f32(a.layer_norm.bias)
-            L.mha.wqkv, L.mha.bqkv = own(ops.pack_frag(wqkv)), own(bqkv)
-            L.mha.wo, L.mha.bo = own(ops.pack_frag(a.linear_out.weight)), f32(a.linear_out.bias)
+            L.mha.wqkv, L.mha.bqkv = own(packw(wqkv)), own(bqkv)
+            L.mha.wo, L.mha.bo = own(packw(a.linear_out.weight)), f32(a.linear_out.bias)
             c = lay.conv
             L.conv.ln_g, L.conv.ln_b = f32(c.layer_norm.weight), f32(c.layer_norm.bias)
             L.conv.pw1_w, L.conv.pw1_b = f32(c.pw_conv_1.weight), f32(c.pw_conv_1.bias)
@@ -199,7 +201,8 @@ class Conformer(nn.Module):
             L.ln_g, L.ln_b = f32(lay.layer_norm.weight), f32(lay.layer_norm.bias)
 
         w = _lib.ConformerWeights()
-        w.idim, w.idim_pad = enc.idim, (enc.idim + 255) // 256 * 256
+        w.generic = 1 if generic else 0
+        w.idim, w.idim_pad = enc.idim, ((enc.idim + 63) // 64 * 64 if generic else (enc.idim + 255) // 256 * 256)
         w.d_model, w.n_head, w.d_ffn = enc.d_model, enc.n_head, enc.d_ffn
         w.n_layer, w.kernel_size = len(enc.encoders), enc.kernel_size
         w.n_out = self.linear.out_features
@@ -208,11 +211,11 @@ class Conformer(nn.Module):
         w.fuse_conv = int(getattr(self, "fuse_conv", 0))
         ew = torch.zeros(enc.d_model, w.idim_pad, device=dev)
         ew[:, :enc.idim] = enc.embed[0].weight.detach().float()
-        w.embed_w, w.embed_b = own(ops.pack_frag(ew)), f32(enc.embed[0].bias)
+        w.embed_w, w.embed_b = own(packw(ew)), f32(enc.embed[0].bias)
         w.embed_ln_g, w.embed_ln_b = f32(enc.embed[1].weight), f32(enc.embed[1].bias)
         w.pe_k = own(pe_packed)
         w.layers = C.cast(layers, C.POINTER(_lib.LayerWeights))
-        w.head_w, w.head_b = own(ops.pack_frag(self.linear.weight)), f32(self.linear.bias)
+        w.head_w, w.head_b = own(packw(self.linear.weight)), f32(self.linear.bias)
         self._packed = (w, layers, keep)
         self._packed_key = key
         return self._packed

@@ -295,6 +295,8 @@ typedef struct {
   int32_t n_out;           /* num_bins * (num_spk + num_noise) */
   int32_t pe_q_min, pe_q_max; /* block range of pe_k (csship_mha_relpos) */
   int32_t bn_mode;         /* 0 eval, 1 batch statistics */
+  int32_t generic;         /* 0: tuned d_model = 256 path, PACKED weights as documented per field; 1: any-width
+                            * unfused path (d_model 256 or 512), ALL Linear weights ROW-MAJOR bf16 [N, K padded to 64] */
   int32_t fuse_conv;       /* eval only: 0 = separate conv module (default, fastest at B=32 x T=400); 1 = conv fused into
                             * csship_outproj_glu + csship_encoder_chain; 2 = csship_outproj_glu + csship_conv_from_glu */
   const uint16_t* embed_w; const float* embed_b; /* PACKED bf16 from [d_model, idim_pad], idim_pad = idim rounded up to 256 */

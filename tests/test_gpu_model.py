@@ -99,6 +99,34 @@ def test_conformer_three_speakers_7ch_dims():
     assert mask_mse(torch.cat(masks, 2), ref) < 1e-4
 
 
+def test_conformer_large_dims_generic_path():
+    """config 5 shape class: Conformer-large widths (d_model 512, 8 heads, ffn 2048), 3 speakers + noise head,
+    through the any-width path of csship_conformer_forward (2 blocks), vs the oracle."""
+    from css_amd.models import MODELS
+    conf = dict(attention_dim=512, attention_heads=8, linear_units=2048, num_blocks=2, kernel_size=33,
+                dropout_rate=0.1, relative_pos_emb=True)
+    m = MODELS["Conformer"](257, 257, 3, 1, conf)
+    sd = syn.fill_state_dict(syn.conformer_shapes(num_spk=3, attention_dim=512, attention_heads=8, linear_units=2048,
+                                                  num_blocks=2), 77)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    f = rnd((2, 90, 257), 31).abs()
+    y_pred, masks = m(f.to(DEV))
+    assert len(masks) == 4 and y_pred.shape == (2, 3, 90, 257)
+    _, o = oracle.conformer.forward(f, sd, num_spk=3, n_head=8, num_blocks=2)
+    mse = mask_mse(torch.stack(masks), torch.stack(o))
+    print(f"[parity] Conformer-large dims (2 blocks, 4 masks): mask MSE vs oracle {mse:.3e}")
+    assert mse < 1e-4
+    # the same generic path at base width agrees with the tuned path
+    mb, sdb = build(2, 32)
+    fb = rnd((2, 70, 257), 33).abs().to(DEV)
+    ref = mb.forward_masks(fb).clone()
+    mb.force_generic = True
+    got = mb.forward_masks(fb)
+    mb.force_generic = False
+    assert mask_mse(got, ref) < 2e-5
+
+
 def test_fused_conv_path_matches():
     """Optional eval path: conv module split over csship_outproj_glu + csship_encoder_chain (panels straddle
     utterance boundaries: T = 70, 64-row panels)."""
