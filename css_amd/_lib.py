@@ -45,7 +45,16 @@ class ConformerWeights(C.Structure):
                 ("layers", C.POINTER(LayerWeights)), ("head_w", _p), ("head_b", _p)]
 
 
+class BgemmParams(C.Structure):
+    _fields_ = [("M", _i32), ("N", _i32), ("K", _i32), ("lda", _i64), ("ldb", _i64), ("ldc", _i64), ("ldaux", _i64),
+                ("a_kmajor", _i32), ("b_kmajor", _i32), ("a_f32", _i32), ("b_f32", _i32), ("epilogue", _i32),
+                ("batch1", _i32), ("batch2", _i32), ("splits", _i32),
+                ("sA1", _i64), ("sA2", _i64), ("sB1", _i64), ("sB2", _i64), ("sC1", _i64), ("sC2", _i64),
+                ("alpha", _f32)]
+
+
 A_BF16, A_F32, A_F32_MVN = 0, 1, 2
+BEPI_OUT_BF16, BEPI_MASK_POS, BEPI_ADD = 1, 2, 4
 EPI_RELU, EPI_RESIDUAL, EPI_LAYERNORM, EPI_OUT_BF16 = 1, 2, 4, 8
 PRO_LN, PRO_BF16, PRO_F32 = 0, 1, 2
 
@@ -78,6 +87,10 @@ SIGNATURES = {
     "csship_apply_masks": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p, _p]),
     "csship_stitch_similarity": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "csship_stitch_connect": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _f32, _p, _p]),
+    "csship_bgemm_workspace": (_sz, [C.POINTER(BgemmParams)]),
+    "csship_bgemm": (_i32, [_p, _p, _p, _p, _p, C.POINTER(BgemmParams), _p, _sz, _p]),
+    "csship_colsum_workspace": (_sz, [_i64, _i32]),
+    "csship_colsum": (_i32, [_p, _i32, _i64, _i32, _i64, _p, _p, _sz, _p]),
     "csship_conformer_workspace": (_sz, [C.POINTER(ConformerWeights), _i32, _i32]),
     "csship_conformer_forward": (_i32, [C.POINTER(ConformerWeights), _p, _i64, _i32, _i32, _p, _i64, _p, _p, _sz, _p]),
 }

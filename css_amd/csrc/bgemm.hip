@@ -1,0 +1,337 @@
+// Batched bf16 MFMA GEMM for the backward pass:  C[z] = epi(alpha * opA(A[z]) . opB(B[z])).
+//
+// The backward of every Linear / attention product on the path (css/models/conformer.py:98,124,205-209,
+// 229-253,315-318 under torch.autograd in the reference) is one of four operand layouts
+//     dX = dY . W          A reduction-contiguous,  B reduction-STRIDED (W stays [N, K] row-major)
+//     dW = dY^T . X        both operands reduction-strided (the reduction runs over the B*T rows)
+//     dP = dO . V^T        both contiguous ("NT", like gemm.hip)
+// so ONE kernel takes either layout per operand: a contiguous operand is staged as [row][k] (XOR-swizzled
+// 128-byte rows, fragments by ds_read_b128); a strided operand is staged exactly as it lies in memory,
+// [k][row] with 256-byte rows, and the MFMA fragment is produced by the LDS transposing read
+// ds_read_b64_tr_b16 - no transposed copies of activations or weights exist anywhere.
+// 128x128 output tile, 4 waves of 64x64 (4x4 v_mfma_f32_16x16x32_bf16), BK = 64, register-staged double
+// buffering.  Long reductions (dW: K = B*T = 12 800) are split over blockIdx.z into fp32 slabs that a
+// second kernel sums in a fixed order (deterministic, no atomics).  fp32 operands are rounded to bf16
+// on load.  Batches use a two-level index z = z1 * nb2 + z2 (batch, head).
+#include "common.hpp"
+
+namespace {
+
+struct BgemmArgs {
+  const void* A;
+  const void* B;
+  void* C;
+  const float* bias;
+  const void* aux;
+  int M, N, K;
+  int64_t lda, ldb, ldc, ldaux;
+  int nb2, splits, k_per_split;
+  int64_t sA1, sA2, sB1, sB2, sC1, sC2, slab;
+  int a_f32, b_f32, epi;
+  float alpha;
+};
+
+constexpr int BK = 64;
+constexpr int STAGE = 256 * 128;  // A image (16 KB) + B image (16 KB)
+
+// reduction-strided image: row = k (256 B = 128 operand rows), 32-byte group g of row k at ((g ^ key(k)) << 5).
+// A half-wave's transposing read touches k rows {8a..8a+3, 8a+8..8a+11}: 8 distinct keys -> conflict free.
+DEV int km_off(int k, int grp) { return k * 256 + ((grp ^ ((k & 3) | (((k >> 3) & 1) << 2))) << 5); }
+
+template <bool F32>
+DEV uint4 load8(const void* base, int64_t off, int n_valid) {  // 8 consecutive elements -> 8 bf16
+  if constexpr (F32) {
+    const float* p = reinterpret_cast<const float*>(base) + off;
+    if (n_valid >= 8) {
+      const float4 x0 = *reinterpret_cast<const float4*>(p);
+      const float4 x1 = *reinterpret_cast<const float4*>(p + 4);
+      return make_uint4(pack_bf2(x0.x, x0.y), pack_bf2(x0.z, x0.w), pack_bf2(x1.x, x1.y), pack_bf2(x1.z, x1.w));
+    }
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = e < n_valid ? p[e] : 0.f;
+    return make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+  } else {
+    const unsigned short* p = reinterpret_cast<const unsigned short*>(base) + off;
+    if (n_valid >= 8) return *reinterpret_cast<const uint4*>(p);
+    unsigned short v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = e < n_valid ? p[e] : (unsigned short)0;
+    return make_uint4(v[0] | ((unsigned)v[1] << 16), v[2] | ((unsigned)v[3] << 16), v[4] | ((unsigned)v[5] << 16),
+                      v[6] | ((unsigned)v[7] << 16));
+  }
+}
+
+// one operand's 128 x 64 tile -> 4 x 16 bytes per thread.  rows: tile's first operand row, nrows: operand rows,
+// k0/kend: reduction range of this tile.
+template <bool KM>
+DEV void load_operand(const void* base, bool f32, int64_t ld, int row0, int nrows, int k0, int kend, int tid,
+                      uint4 (&r)[4]) {
+  if constexpr (!KM) {
+    const int srow = tid >> 3, k = k0 + (tid & 7) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = row0 + srow + 32 * i;
+      const int nv = (row < nrows) ? kend - k : 0;
+      if (nv <= 0) r[i] = make_uint4(0, 0, 0, 0);
+      else r[i] = f32 ? load8<true>(base, (int64_t)row * ld + k, nv) : load8<false>(base, (int64_t)row * ld + k, nv);
+    }
+  } else {
+    const int krow = tid >> 4, col = row0 + (tid & 15) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + krow + 16 * i;
+      const int nv = (k < kend) ? nrows - col : 0;
+      if (nv <= 0) r[i] = make_uint4(0, 0, 0, 0);
+      else r[i] = f32 ? load8<true>(base, (int64_t)k * ld + col, nv) : load8<false>(base, (int64_t)k * ld + col, nv);
+    }
+  }
+}
+
+template <bool KM>
+DEV void store_operand(unsigned char* img, int tid, const uint4 (&r)[4]) {
+  if constexpr (!KM) {
+    const int srow = tid >> 3, sc = tid & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(img + tile_off(srow + 32 * i, sc)) = r[i];
+  } else {
+    const int krow = tid >> 4, ch = tid & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<uint4*>(img + km_off(krow + 16 * i, ch >> 1) + (ch & 1) * 16) = r[i];
+  }
+}
+
+// fragment of operand rows [r0, r0+16) for k-step ks (32 reduction indices) of the staged tile
+template <bool KM>
+DEV bf16x8 read_frag(const unsigned char* img, int r0, int ks, int lane) {
+  const int lg = lane >> 4, ln = lane & 15;
+  if constexpr (!KM) {
+    return *reinterpret_cast<const bf16x8*>(img + tile_off(r0 + ln, ks * 4 + lg));
+  } else {
+    const int k = ks * 32 + 8 * lg + (ln >> 2);
+    const unsigned char* a0 = img + km_off(k, r0 >> 4) + (ln & 3) * 8;  // key(k) == key(k + 4)
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * 256));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+  }
+}
+
+template <bool A_KM, bool B_KM>
+__global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lg = lane >> 4, ln = lane & 15;
+  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+  const int z = blockIdx.z / g.splits, split = blockIdx.z % g.splits;
+  const int z1 = z / g.nb2, z2 = z % g.nb2;
+  const int kbeg = split * g.k_per_split, kend = min(g.K, kbeg + g.k_per_split);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  const bool af32 = g.a_f32 != 0, bf32 = g.b_f32 != 0;
+  const void* Ab = reinterpret_cast<const unsigned char*>(g.A) + (z1 * g.sA1 + z2 * g.sA2) * (af32 ? 4 : 2);
+  const void* Bb = reinterpret_cast<const unsigned char*>(g.B) + (z1 * g.sB1 + z2 * g.sB2) * (bf32 ? 4 : 2);
+
+  uint4 ra[4], rb[4];
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) {
+    load_operand<A_KM>(Ab, af32, g.lda, m0, g.M, kbeg, kend, tid, ra);
+    load_operand<B_KM>(Bb, bf32, g.ldb, n0, g.N, kbeg, kend, tid, rb);
+    store_operand<A_KM>(smem, tid, ra);
+    store_operand<B_KM>(smem + 128 * 128, tid, rb);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) {
+      load_operand<A_KM>(Ab, af32, g.lda, m0, g.M, kbeg + (kt + 1) * BK, kend, tid, ra);
+      load_operand<B_KM>(Bb, bf32, g.ldb, n0, g.N, kbeg + (kt + 1) * BK, kend, tid, rb);
+    }
+    const unsigned char* as = smem + (kt & 1) * STAGE;
+    const unsigned char* bs = as + 128 * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = read_frag<A_KM>(as, wm * 64 + i * 16, ks, lane);
+        bf[i] = read_frag<B_KM>(bs, wn * 64 + i * 16, ks, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      unsigned char* nx = smem + ((kt + 1) & 1) * STAGE;
+      store_operand<A_KM>(nx, tid, ra);
+      store_operand<B_KM>(nx + 128 * 128, tid, rb);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue.  acc[i][j][r]: row = m0 + wm*64 + i*16 + lg*4 + r, col = n0 + wn*64 + j*16 + ln
+  const int64_t coff = z1 * g.sC1 + z2 * g.sC2 + (int64_t)split * g.slab;
+  const bool to_slab = g.splits > 1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = n0 + wn * 64 + j * 16 + ln;
+    if (col >= g.N) continue;
+    const float bias = (!to_slab && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 64 + i * 16 + lg * 4 + r;
+        if (row >= g.M) continue;
+        float v = acc[i][j][r];
+        if (to_slab) {
+          reinterpret_cast<float*>(g.C)[coff + (int64_t)row * g.N + col] = v;
+          continue;
+        }
+        v = g.alpha * v + bias;
+        const int64_t xo = z1 * g.sC1 + z2 * g.sC2;  // aux shares C's batch strides
+        if (g.epi & CSSHIP_BEPI_MASK_POS) {
+          if (!(bf2f(reinterpret_cast<const unsigned short*>(g.aux)[xo + (int64_t)row * g.ldaux + col]) > 0.f)) v = 0.f;
+        }
+        if (g.epi & CSSHIP_BEPI_ADD) v += reinterpret_cast<const float*>(g.aux)[xo + (int64_t)row * g.ldaux + col];
+        if (g.epi & CSSHIP_BEPI_OUT_BF16)
+          reinterpret_cast<unsigned short*>(g.C)[coff + (int64_t)row * g.ldc + col] = f2bf(v);
+        else
+          reinterpret_cast<float*>(g.C)[coff + (int64_t)row * g.ldc + col] = v;
+      }
+  }
+}
+
+// out[r, c] = alpha * sum_s slab[s][r, c] (+ bias[c]) (+ add[r, c]); fixed summation order
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int S, int64_t n, int N,
+                                                          int64_t ldc, float alpha, const float* __restrict__ bias,
+                                                          const float* add, int64_t ldadd, float* out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < S; ++k) s += slabs[(int64_t)k * n + i];
+  const int64_t r = i / N, c = i % N;
+  float v = alpha * s;
+  if (bias) v += bias[c];
+  if (add) v += add[r * ldadd + c];
+  out[r * ldc + c] = v;
+}
+
+// ---- column sums of a [M, N] f32 / bf16 matrix (bias gradients): stage 1 = per-slice partials, stage 2 = slab_reduce
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x, int f32, int64_t M, int N, int64_t ld,
+                                                     int rows_per_wg, float* __restrict__ part) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_wg, r1 = min(M, r0 + rows_per_wg);
+  float s = 0.f;
+  if (c < N) {
+    if (f32) {
+      const float* p = reinterpret_cast<const float*>(x);
+      for (int64_t r = r0 + w; r < r1; r += 4) s += p[r * ld + c];
+    } else {
+      const unsigned short* p = reinterpret_cast<const unsigned short*>(x);
+      for (int64_t r = r0 + w; r < r1; r += 4) s += bf2f(p[r * ld + c]);
+    }
+  }
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && c < N) part[(int64_t)blockIdx.y * N + c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+
+int pick_splits(const csship_bgemm_params* p) {
+  if (p->splits > 0) return p->splits;
+  const int64_t tiles = (int64_t)((p->M + 127) / 128) * ((p->N + 127) / 128) * p->batch1 * p->batch2;
+  const int kt = (p->K + BK - 1) / BK;
+  if (tiles >= 128 || kt < 8 || p->batch1 * p->batch2 != 1 || (p->epilogue & ~CSSHIP_BEPI_ADD) != 0) return 1;
+  int s = (int)((384 + tiles - 1) / tiles);
+  if (s > kt / 2) s = kt / 2;
+  return s < 1 ? 1 : s;
+}
+
+}  // namespace
+
+extern "C" size_t csship_bgemm_workspace(const csship_bgemm_params* p) {
+  if (!p) return 0;
+  const int s = pick_splits(p);
+  return s > 1 ? (size_t)s * p->M * p->N * sizeof(float) : 0;
+}
+
+extern "C" int csship_bgemm(const void* A, const void* B, void* C, const float* bias, const void* aux,
+                            const csship_bgemm_params* p, void* workspace, size_t workspace_bytes,
+                            csship_stream_t stream) {
+  if (!A || !B || !C || !p) return CSSHIP_ENULL;
+  if (p->M <= 0 || p->N <= 0 || p->K <= 0 || p->batch1 <= 0 || p->batch2 <= 0) return CSSHIP_EBADSHAPE;
+  if ((p->epilogue & (CSSHIP_BEPI_MASK_POS | CSSHIP_BEPI_ADD)) && !aux) return CSSHIP_ENULL;
+  if ((p->epilogue & CSSHIP_BEPI_MASK_POS) && (p->epilogue & CSSHIP_BEPI_ADD)) return CSSHIP_EUNSUPPORTED;
+  // vector loads: rows of 8 bf16 / 4+4 f32 must be 16-byte aligned
+  const int64_t amod = p->a_f32 ? 4 : 8, bmod = p->b_f32 ? 4 : 8;
+  if (!aligned16(A) || !aligned16(B) || (p->lda % amod) || (p->ldb % bmod) || (p->sA1 % amod) || (p->sA2 % amod) ||
+      (p->sB1 % bmod) || (p->sB2 % bmod))
+    return CSSHIP_EALIGN;
+  if (p->lda < (p->a_kmajor ? p->M : p->K) || p->ldb < (p->b_kmajor ? p->N : p->K) || p->ldc < p->N)
+    return CSSHIP_EBADSHAPE;
+  const int splits = pick_splits(p);
+  const int64_t nz = (int64_t)p->batch1 * p->batch2 * splits;
+  if (nz > 65535) return CSSHIP_EBADSHAPE;
+  if (splits > 1) {
+    if (p->batch1 * p->batch2 != 1 || (p->epilogue & ~CSSHIP_BEPI_ADD) != 0) return CSSHIP_EUNSUPPORTED;
+    if (!workspace || workspace_bytes < (size_t)splits * p->M * p->N * sizeof(float)) return CSSHIP_EWORKSPACE;
+  }
+  BgemmArgs a{};
+  a.A = A; a.B = B; a.bias = bias; a.aux = aux;
+  a.C = splits > 1 ? workspace : C;
+  a.M = p->M; a.N = p->N; a.K = p->K;
+  a.lda = p->lda; a.ldb = p->ldb; a.ldc = p->ldc; a.ldaux = p->ldaux;
+  a.nb2 = p->batch2; a.splits = splits;
+  const int kt = (p->K + BK - 1) / BK;
+  a.k_per_split = ((kt + splits - 1) / splits) * BK;
+  a.sA1 = p->sA1; a.sA2 = p->sA2; a.sB1 = p->sB1; a.sB2 = p->sB2; a.sC1 = p->sC1; a.sC2 = p->sC2;
+  a.slab = (int64_t)p->M * p->N;
+  a.a_f32 = p->a_f32; a.b_f32 = p->b_f32; a.epi = p->epilogue; a.alpha = p->alpha;
+  dim3 grid((p->N + 127) / 128, (p->M + 127) / 128, (unsigned)nz);
+  hipStream_t s = as_stream(stream);
+  if (p->a_kmajor && p->b_kmajor) hipLaunchKernelGGL((bgemm_kernel<true, true>), grid, dim3(256), 0, s, a);
+  else if (p->a_kmajor) hipLaunchKernelGGL((bgemm_kernel<true, false>), grid, dim3(256), 0, s, a);
+  else if (p->b_kmajor) hipLaunchKernelGGL((bgemm_kernel<false, true>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((bgemm_kernel<false, false>), grid, dim3(256), 0, s, a);
+  CSSHIP_CHECK_LAUNCH();
+  if (splits > 1) {
+    const int64_t n = (int64_t)p->M * p->N;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                       reinterpret_cast<const float*>(workspace), splits, n, p->N, p->ldc, p->alpha, bias,
+                       (p->epilogue & CSSHIP_BEPI_ADD) ? reinterpret_cast<const float*>(aux) : nullptr, p->ldaux,
+                       reinterpret_cast<float*>(C));
+    CSSHIP_CHECK_LAUNCH();
+  }
+  return CSSHIP_OK;
+}
+
+extern "C" size_t csship_colsum_workspace(int64_t M, int32_t N) {
+  const int slices = (int)((M + 255) / 256);
+  return (size_t)slices * N * sizeof(float);
+}
+
+extern "C" int csship_colsum(const void* x, int32_t x_is_f32, int64_t M, int32_t N, int64_t ld, float* out,
+                             void* workspace, size_t workspace_bytes, csship_stream_t stream) {
+  if (!x || !out || !workspace) return CSSHIP_ENULL;
+  if (M <= 0 || N <= 0 || ld < N) return CSSHIP_EBADSHAPE;
+  const int slices = (int)((M + 255) / 256);
+  if (slices > 65535) return CSSHIP_EBADSHAPE;
+  if (workspace_bytes < (size_t)slices * N * sizeof(float)) return CSSHIP_EWORKSPACE;
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, slices), dim3(256), 0, s, x, x_is_f32, M, N, ld, 256,
+                     reinterpret_cast<float*>(workspace));
+  CSSHIP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, s,
+                     reinterpret_cast<const float*>(workspace), slices, (int64_t)N, N, (int64_t)N, 1.f, nullptr,
+                     nullptr, (int64_t)0, out);
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}

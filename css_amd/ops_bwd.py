@@ -1,0 +1,100 @@
+"""Torch-tensor front door to the backward kernels of libcsship.so (the ``_bwd`` twins).
+
+Same rules as ``ops.py``: HIP tensors only, shapes validated on the host, outputs from torch's caching
+allocator, launches on the current stream.  The reference obtains these gradients from torch.autograd.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, lib
+from .ops import _need, _ptr, _stream
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, dev):
+    """Scratch reused across calls on one stream (kernels on a stream run in order)."""
+    key = (dev, torch.cuda.current_stream().cuda_stream)
+    t = _ws_cache.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+        _ws_cache[key] = t
+    return t
+
+
+def _as4(t, name):
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"css_amd: '{name}' must be float32 or bfloat16")
+    if not t.is_cuda:
+        raise RuntimeError(f"css_amd: '{name}' must be a CUDA/HIP tensor (no CPU path exists)")
+    if t.dim() == 2:
+        t = t[None, None]
+    elif t.dim() == 3:
+        t = t[None]
+    if t.dim() != 4 or t.stride(-1) != 1:
+        raise RuntimeError(f"css_amd: '{name}' must be [.., rows, cols] with contiguous columns")
+    return t
+
+
+def bgemm(a, b, *, a_kmajor=False, b_kmajor=False, out=None, out_bf16=False, alpha=1.0, bias=None, mask_pos=None,
+          add=None, splits=0):
+    """C = alpha * opA(a) @ opB(b)^T-style product, batched over leading dims.
+
+    a: [.., M, K] (or [.., K, M] when a_kmajor); b: [.., N, K] (or [.., K, N] when b_kmajor); result [.., M, N].
+    mask_pos: bf16 [.., M, N], zeroes the result where it is <= 0; add: f32 [.., M, N] added to the result.
+    """
+    squeeze = a.dim()
+    a4, b4 = _as4(a, "a"), _as4(b, "b")
+    b1, b2 = max(a4.shape[0], b4.shape[0]), max(a4.shape[1], b4.shape[1])
+    M, K = (a4.shape[3], a4.shape[2]) if a_kmajor else (a4.shape[2], a4.shape[3])
+    N, Kb = (b4.shape[3], b4.shape[2]) if b_kmajor else (b4.shape[2], b4.shape[3])
+    if K != Kb:
+        raise RuntimeError(f"css_amd: bgemm reduction mismatch {K} vs {Kb}")
+
+    def bstr(t):
+        return (t.stride(0) if t.shape[0] > 1 else 0, t.stride(1) if t.shape[1] > 1 else 0)
+
+    if out is None:
+        out = torch.empty((b1, b2, M, N), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=a.device)
+        out_ret = out.reshape((M, N)) if squeeze == 2 else (out[0] if squeeze == 3 else out)
+    else:
+        out_ret = out
+        out = _as4(out, "out")
+        if out.shape[-2:] != (M, N):
+            raise RuntimeError("css_amd: bgemm out shape")
+        out_bf16 = out.dtype == torch.bfloat16
+    aux = None
+    epi = _lib.BEPI_OUT_BF16 if out_bf16 else 0
+    if mask_pos is not None:
+        aux = _as4(_need(mask_pos, torch.bfloat16, "mask_pos"), "mask_pos")
+        epi |= _lib.BEPI_MASK_POS
+    if add is not None:
+        aux = _as4(_need(add, torch.float32, "add"), "add")
+        epi |= _lib.BEPI_ADD
+    if aux is not None and (aux.shape[-2:] != (M, N) or bstr(aux) != bstr(out)):
+        raise RuntimeError("css_amd: bgemm aux must have the output's shape and batch strides")
+    p = _lib.BgemmParams(M=M, N=N, K=K, lda=a4.stride(2), ldb=b4.stride(2), ldc=out.stride(2),
+                         ldaux=aux.stride(2) if aux is not None else 0,
+                         a_kmajor=int(a_kmajor), b_kmajor=int(b_kmajor), a_f32=int(a4.dtype == torch.float32),
+                         b_f32=int(b4.dtype == torch.float32), epilogue=epi, batch1=b1, batch2=b2, splits=splits,
+                         sA1=bstr(a4)[0], sA2=bstr(a4)[1], sB1=bstr(b4)[0], sB2=bstr(b4)[1],
+                         sC1=bstr(out)[0], sC2=bstr(out)[1], alpha=float(alpha))
+    nws = lib().csship_bgemm_workspace(C.byref(p))
+    ws = _workspace(nws, a.device) if nws else None
+    check(lib().csship_bgemm(_ptr(a4), _ptr(b4), _ptr(out), _ptr(bias), _ptr(aux), C.byref(p), _ptr(ws), nws, _stream()))
+    return out_ret
+
+
+def colsum(x):
+    """Column sums of a [M, N] f32/bf16 matrix (row stride free) -> f32 [N]."""
+    if x.dim() != 2 or x.stride(1) != 1 or not x.is_cuda:
+        raise RuntimeError("css_amd: colsum expects a HIP [M, N] matrix with contiguous columns")
+    M, N = x.shape
+    out = torch.empty(N, dtype=torch.float32, device=x.device)
+    nws = lib().csship_colsum_workspace(M, N)
+    ws = _workspace(nws, x.device)
+    check(lib().csship_colsum(_ptr(x), int(x.dtype == torch.float32), M, N, x.stride(0), _ptr(out), _ptr(ws), nws,
+                              _stream()))
+    return out

@@ -313,6 +313,42 @@ int csship_conformer_forward(const csship_conformer_weights* w, const float* f, 
                              int32_t B, int32_t T, float* masks, int64_t ld_masks, float* enc_out,
                              void* workspace, size_t workspace_bytes, csship_stream_t stream);
 
+/* ======================================================================================
+ * Backward pass ("_bwd twins").  The reference gets these from torch.autograd over the ops of
+ * css/models/conformer.py; here every gradient is an explicit kernel.
+ * ====================================================================================== */
+
+/* ---- csship_bgemm (css_amd/csrc/bgemm.hip): batched C[z] = epi(alpha * opA(A[z]) . opB(B[z])), bf16 MFMA,
+ * f32 accumulate.  C is [M, N]; the reduction has length K.  An operand is either reduction-contiguous
+ * (A: [M, K] rows, B: [N, K] rows) or reduction-strided / "kmajor" (A: [K, M], B: [K, N]) - so dX = dY.W uses the
+ * forward's [N, K] weight as a kmajor B, and dW = dY^T.X takes both activations kmajor; nothing is transposed in
+ * memory.  f32 operands are rounded to bf16 on load.  Row strides: multiples of 8 (bf16) / 4 (f32) elements.
+ * Batch index z = z1 * batch2 + z2 with element strides s?1 / s?2 (aux shares C's).  splits: 0 = choose
+ * (long reductions with few output tiles are split into f32 slabs in the workspace and summed in a fixed order),
+ * splits > 1 needs batch1 * batch2 == 1 and an f32 output without CSSHIP_BEPI_MASK_POS. */
+enum {
+  CSSHIP_BEPI_OUT_BF16 = 1, /* C is bf16 (else f32) */
+  CSSHIP_BEPI_MASK_POS = 2, /* v = aux_bf16[row, col] > 0 ? v : 0   (ReLU backward) */
+  CSSHIP_BEPI_ADD = 4       /* v += aux_f32[row, col]               (gradient accumulation; aux may alias C) */
+};
+typedef struct {
+  int32_t M, N, K;
+  int64_t lda, ldb, ldc, ldaux;
+  int32_t a_kmajor, b_kmajor, a_f32, b_f32;
+  int32_t epilogue;         /* OR of CSSHIP_BEPI_* */
+  int32_t batch1, batch2, splits;
+  int64_t sA1, sA2, sB1, sB2, sC1, sC2;
+  float alpha;
+} csship_bgemm_params;
+size_t csship_bgemm_workspace(const csship_bgemm_params* p);
+int csship_bgemm(const void* A, const void* B, void* C, const float* bias, const void* aux,
+                 const csship_bgemm_params* p, void* workspace, size_t workspace_bytes, csship_stream_t stream);
+
+/* out[c] = sum_r x[r, c] for x f32 or bf16 [M, N] (row stride ld): the bias gradient of a Linear. */
+size_t csship_colsum_workspace(int64_t M, int32_t N);
+int csship_colsum(const void* x, int32_t x_is_f32, int64_t M, int32_t N, int64_t ld, float* out,
+                  void* workspace, size_t workspace_bytes, csship_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
