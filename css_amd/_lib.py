@@ -50,7 +50,7 @@ class BgemmParams(C.Structure):
                 ("a_kmajor", _i32), ("b_kmajor", _i32), ("a_f32", _i32), ("b_f32", _i32), ("epilogue", _i32),
                 ("batch1", _i32), ("batch2", _i32), ("splits", _i32),
                 ("sA1", _i64), ("sA2", _i64), ("sB1", _i64), ("sB2", _i64), ("sC1", _i64), ("sC2", _i64),
-                ("alpha", _f32)]
+                ("sX1", _i64), ("sX2", _i64), ("alpha", _f32)]
 
 
 A_BF16, A_F32, A_F32_MVN = 0, 1, 2
@@ -90,7 +90,13 @@ SIGNATURES = {
     "csship_bgemm_workspace": (_sz, [C.POINTER(BgemmParams)]),
     "csship_bgemm": (_i32, [_p, _p, _p, _p, _p, C.POINTER(BgemmParams), _p, _sz, _p]),
     "csship_colsum_workspace": (_sz, [_i64, _i32]),
-    "csship_colsum": (_i32, [_p, _i32, _i64, _i32, _i64, _p, _p, _sz, _p]),
+    "csship_colsum": (_i32, [_p, _i32, _i64, _i32, _i64, _f32, _p, _p, _sz, _p]),
+    "csship_layernorm_bwd_workspace": (_sz, [_i64, _i32]),
+    "csship_layernorm_bwd": (_i32, [_p, _p, _p, _p, _p, _i32, _i64, _i32, _p, _p, _p, _sz, _p]),
+    "csship_relu_bwd": (_i32, [_p, _i64, _p, _i64, _i64, _i32, _p, _i64, _p]),
+    "csship_mvn_apply": (_i32, [_p, _i64, _i64, _i64, _i64, _f32, _p, _p, _p, _i64, _p]),
+    "csship_relpos_softmax": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p]),
+    "csship_relpos_softmax_bwd": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _i32, _p]),
     "csship_conformer_workspace": (_sz, [C.POINTER(ConformerWeights), _i32, _i32]),
     "csship_conformer_forward": (_i32, [C.POINTER(ConformerWeights), _p, _i64, _i32, _i32, _p, _i64, _p, _p, _sz, _p]),
 }

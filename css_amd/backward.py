@@ -1,0 +1,118 @@
+"""Operator backwards of the Conformer path, composed from the HIP kernels behind ``ops_bwd`` / ``ops``.
+
+The reference gets all of these from torch.autograd over css/models/conformer.py; here each operator has an explicit
+backward built from: the batched MFMA GEMM (csship_bgemm: dX = dY.W, dW = dY^T.X, attention products), LayerNorm /
+ReLU / softmax backward row kernels, and column sums for the biases.  Nothing in this file computes on the CPU and
+nothing falls back to torch arithmetic beyond gathers / scatters of parameter-sized tensors.
+"""
+import torch
+
+from . import ops, ops_bwd as ob
+
+BF = torch.bfloat16
+
+
+def linear_bwd(dy, x, w_bf, *, need_dx=True, dx_bf16=False, alpha=1.0):
+    """y = x @ w^T + b.  dy: [M, N] f32/bf16, x: [M, K] f32/bf16, w_bf: bf16 [N, K] -> (dx, dw, db)."""
+    dw = ob.bgemm(dy, x, a_kmajor=True, b_kmajor=True, alpha=alpha)
+    db = ob.colsum(dy, alpha)
+    dx = ob.bgemm(dy, w_bf, b_kmajor=True, alpha=alpha, out_bf16=dx_bf16) if need_dx else None
+    return dx, dw, db
+
+
+def head_bwd(dmasks, masks, x, w_bf):
+    """masks = relu(x @ w^T + b) (conformer.py:98-99).  dmasks/masks: f32 [M, n_out] (row stride free)."""
+    dz = ob.relu_bwd(dmasks, masks)
+    return linear_bwd(dz, x, w_bf)
+
+
+def ffn_bwd(x, dy, ln_g, ln_b, b1, w1_bf, w2_bf, alpha=0.5):
+    """out = x + alpha * (relu(LN(x) @ w1^T + b1) @ w2^T + b2)  (conformer.py:322-326 with the half-step residual).
+
+    x, dy: f32 [M, 256].  Returns dx and the parameter gradients (ln_g, ln_b, w1, b1, w2, b2).
+    The hidden activations are recomputed (LN + first Linear), not stored by the forward.
+    """
+    a, _ = ops.layernorm(x, ln_g, ln_b)
+    h = ops.gemm(a, w1_bf, b1, relu=True, out_bf16=True)
+    dw2 = ob.bgemm(dy, h, a_kmajor=True, b_kmajor=True, alpha=alpha)
+    db2 = ob.colsum(dy, alpha)
+    dh = ob.bgemm(dy, w2_bf, b_kmajor=True, alpha=alpha, mask_pos=h, out_bf16=True)
+    da, dw1, db1 = linear_bwd(dh, a, w1_bf)
+    dx, dg, dbeta = ob.layernorm_bwd(x, da, ln_g, ln_b, dx_add=dy)
+    return dx, (dg, dbeta, dw1, db1, dw2, db2)
+
+
+def relpos_window(pe_table_bf, T, maxlen):
+    """rows of the relative-position table seen by a length-T sequence: window[r] = pe[clamp(r - (T-1)) + maxlen]
+    (conformer.py:157-159,179-185), zero padded to a multiple of 8 rows.  Returns (window bf16 [W, d_k], index)."""
+    idx = (torch.arange(2 * T - 1, device=pe_table_bf.device) - (T - 1)).clamp(-maxlen, maxlen - 1) + maxlen
+    W = (2 * T - 1 + 7) // 8 * 8
+    win = torch.zeros((W, pe_table_bf.shape[1]), dtype=BF, device=pe_table_bf.device)
+    win[:2 * T - 1] = pe_table_bf[idx]
+    return win, idx
+
+
+def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000):
+    """Backward of o = softmax(q k^T + q pe[i-j]^T) v (conformer.py:229-253; q already carries 1/sqrt(d_k)).
+
+    qkv: bf16 [B, T, 3*H*64]; dao: bf16 [B*T, H*64] (gradient of the head-concatenated output).
+    Returns dqkv bf16 [B, T, 3*H*64] and dpe f32 [2*maxlen, 64].  Scores are re-materialised per (b, h)
+    ([B,H,T,T] fits HBM comfortably at these lengths) so every product is one batched GEMM.
+    """
+    B, T, _ = qkv.shape
+    H = n_head
+    g = qkv.view(B, T, 3, H, 64)
+    q, k, v = (g[:, :, i].permute(0, 2, 1, 3) for i in range(3))  # [B,H,T,64] strided views
+    win, idx = relpos_window(pe_table_bf, T, maxlen)
+    W = win.shape[0]
+    s = ob.bgemm(q, k)                                   # q k^T            [B,H,T,T]
+    rel = ob.bgemm(q, win[None, None])                   # q pe_window^T    [B,H,T,W]
+    p = ob.relpos_softmax(s, rel, T)                     # bf16 [B,H,T,Tp]
+    do = dao.view(B, T, H, 64).permute(0, 2, 1, 3)
+    dp = ob.bgemm(do, v)                                 # dO v^T           [B,H,T,T]
+    ds, dsk = ob.relpos_softmax_bwd(p, dp, T, W)         # dS, and dS skewed onto the window axis [B,T,H,W]
+    dqkv = torch.empty_like(qkv)
+    dq, dk, dv = (dqkv.view(B, T, 3, H, 64)[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    ob.bgemm(p[..., :T], do, a_kmajor=True, b_kmajor=True, out=dv)      # dV = P^T dO
+    ob.bgemm(ds[..., :T], q, a_kmajor=True, b_kmajor=True, out=dk)      # dK = dS^T q
+    dq1 = ob.bgemm(ds[..., :T], k, b_kmajor=True)                       # dS k
+    ob.bgemm(dsk.permute(0, 2, 1, 3), win[None, None], b_kmajor=True, add=dq1, out=dq)   # + dS_skew pe_window
+    q_rows = g[:, :, 0].reshape(B * T * H, 64)                          # rows ordered (b, t, h) like dsk
+    dwin = ob.bgemm(dsk.view(B * T * H, W), q_rows, a_kmajor=True, b_kmajor=True)        # [W, 64]
+    dpe = torch.zeros((2 * maxlen, 64), dtype=torch.float32, device=qkv.device)
+    dpe.index_add_(0, idx, dwin[:2 * T - 1])
+    return dqkv, dpe
+
+
+def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_scale=0.125):
+    """out = x + attention(LN(x)) @ wo^T + bo  (conformer.py:213-254,356).
+
+    wqkv_bf holds the q rows already multiplied by q_scale (as the forward uses them); the returned dwqkv / dbqkv are
+    gradients of the UNSCALED parameters.  Returns dx and (ln_g, ln_b, wqkv, bqkv, wo, bo, pe) gradients.
+    """
+    D = x.shape[1]
+    dao, dwo, dbo = linear_bwd(dy, ao, wo_bf, dx_bf16=True)
+    B = qkv.shape[0]
+    dqkv, dpe = mha_core_bwd(qkv, dao, pe_table_bf, n_head)
+    dq2 = dqkv.view(-1, 3 * D)
+    a, _ = ops.layernorm(x, ln_g, ln_b)
+    dw = torch.empty((3 * D, D), dtype=torch.float32, device=x.device)
+    db = torch.empty(3 * D, dtype=torch.float32, device=x.device)
+    ob.bgemm(dq2[:, :D], a, a_kmajor=True, b_kmajor=True, alpha=q_scale, out=dw[:D])
+    ob.bgemm(dq2[:, D:], a, a_kmajor=True, b_kmajor=True, out=dw[D:])
+    db[:D] = ob.colsum(dq2[:, :D], q_scale)
+    db[D:] = ob.colsum(dq2[:, D:])
+    da = ob.bgemm(dq2, wqkv_bf, b_kmajor=True)
+    dx, dg, dbeta = ob.layernorm_bwd(x, da, ln_g, ln_b, dx_add=dy)
+    return dx, (dg, dbeta, dw, db, dwo, dbo, dpe)
+
+
+def embed_bwd(f, dy, mean, rinv, w_bf_pad, bias, ln_g, ln_b):
+    """x = relu(LN(MVN(f) @ w^T + b)) (conformer.py:95,124-129).  f: f32 [B,T,idim]; dy: f32 [M, D].
+    w_bf_pad: bf16 [D, pad8(idim)].  Returns (dw [D, idim], db, dln_g, dln_b); the input needs no gradient."""
+    B, T, F = f.shape
+    fn = ob.mvn_apply(f, mean, rinv, w_bf_pad.shape[1])                  # bf16 [M, Kp]
+    e = ob.bgemm(fn, w_bf_pad, bias=bias)                                # pre-LN activations, recomputed
+    de, dg, dbeta = ob.layernorm_bwd(e, dy, ln_g, ln_b, relu=True)
+    dw = ob.bgemm(de, fn, a_kmajor=True, b_kmajor=True)[:, :F]
+    return dw, ob.colsum(de), dg, dbeta

@@ -26,7 +26,7 @@ struct BgemmArgs {
   int M, N, K;
   int64_t lda, ldb, ldc, ldaux;
   int nb2, splits, k_per_split;
-  int64_t sA1, sA2, sB1, sB2, sC1, sC2, slab;
+  int64_t sA1, sA2, sB1, sB2, sC1, sC2, sX1, sX2, slab;
   int a_f32, b_f32, epi;
   float alpha;
 };
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
           continue;
         }
         v = g.alpha * v + bias;
-        const int64_t xo = z1 * g.sC1 + z2 * g.sC2;  // aux shares C's batch strides
+        const int64_t xo = z1 * g.sX1 + z2 * g.sX2;
         if (g.epi & CSSHIP_BEPI_MASK_POS) {
           if (!(bf2f(reinterpret_cast<const unsigned short*>(g.aux)[xo + (int64_t)row * g.ldaux + col]) > 0.f)) v = 0.f;
         }
@@ -257,6 +257,14 @@ int pick_splits(const csship_bgemm_params* p) {
 
 }  // namespace
 
+int launch_slab_reduce(const float* slabs, int S, int64_t n, int N, int64_t ldc, float alpha, const float* bias,
+                       const float* add, int64_t ldadd, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slabs, S, n, N, ldc, alpha,
+                     bias, add, ldadd, out);
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
 extern "C" size_t csship_bgemm_workspace(const csship_bgemm_params* p) {
   if (!p) return 0;
   const int s = pick_splits(p);
@@ -292,7 +300,7 @@ extern "C" int csship_bgemm(const void* A, const void* B, void* C, const float* 
   a.nb2 = p->batch2; a.splits = splits;
   const int kt = (p->K + BK - 1) / BK;
   a.k_per_split = ((kt + splits - 1) / splits) * BK;
-  a.sA1 = p->sA1; a.sA2 = p->sA2; a.sB1 = p->sB1; a.sB2 = p->sB2; a.sC1 = p->sC1; a.sC2 = p->sC2;
+  a.sA1 = p->sA1; a.sA2 = p->sA2; a.sB1 = p->sB1; a.sB2 = p->sB2; a.sC1 = p->sC1; a.sC2 = p->sC2; a.sX1 = p->sX1; a.sX2 = p->sX2;
   a.slab = (int64_t)p->M * p->N;
   a.a_f32 = p->a_f32; a.b_f32 = p->b_f32; a.epi = p->epilogue; a.alpha = p->alpha;
   dim3 grid((p->N + 127) / 128, (p->M + 127) / 128, (unsigned)nz);
@@ -318,7 +326,7 @@ extern "C" size_t csship_colsum_workspace(int64_t M, int32_t N) {
   return (size_t)slices * N * sizeof(float);
 }
 
-extern "C" int csship_colsum(const void* x, int32_t x_is_f32, int64_t M, int32_t N, int64_t ld, float* out,
+extern "C" int csship_colsum(const void* x, int32_t x_is_f32, int64_t M, int32_t N, int64_t ld, float alpha, float* out,
                              void* workspace, size_t workspace_bytes, csship_stream_t stream) {
   if (!x || !out || !workspace) return CSSHIP_ENULL;
   if (M <= 0 || N <= 0 || ld < N) return CSSHIP_EBADSHAPE;
@@ -330,7 +338,7 @@ extern "C" int csship_colsum(const void* x, int32_t x_is_f32, int64_t M, int32_t
                      reinterpret_cast<float*>(workspace));
   CSSHIP_CHECK_LAUNCH();
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, s,
-                     reinterpret_cast<const float*>(workspace), slices, (int64_t)N, N, (int64_t)N, 1.f, nullptr,
+                     reinterpret_cast<const float*>(workspace), slices, (int64_t)N, N, (int64_t)N, alpha, nullptr,
                      nullptr, (int64_t)0, out);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;

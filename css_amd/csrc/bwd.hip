@@ -1,0 +1,225 @@
+// Row kernels of the backward pass: LayerNorm backward (+ optional fused ReLU backward), ReLU backward,
+// MVN materialisation for the embed weight gradient, and the relative-position softmax forward/backward that
+// brackets the attention GEMMs of bgemm.hip.  All HBM/L2-bound, one wave per row.
+#include "common.hpp"
+
+namespace {
+
+// ---- LayerNorm backward over D = 256*VPL.  y = (x - mu) * rstd * gamma + beta  [-> ReLU if relu]
+//   dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma   (+ dx_add)
+//   dgamma = sum_rows dy * xhat,  dbeta = sum_rows dy   -> per-workgroup partials, summed by launch_slab_reduce
+template <int VPL>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* dx_add, int relu, int64_t M, int rows_per_wg,
+                                                     float* dx, float* __restrict__ part) {
+  constexpr int D = 256 * VPL;
+  __shared__ float red[4][2 * D];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg, r1 = min(M, r0 + rows_per_wg);
+  float4 gm[VPL], bt[VPL], ag[VPL], ab[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    gm[i] = *reinterpret_cast<const float4*>(gamma + (i * 64 + lane) * 4);
+    bt[i] = *reinterpret_cast<const float4*>(beta + (i * 64 + lane) * 4);
+    ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int64_t row = r0 + w; row < r1; row += 4) {
+    float4 v[VPL], d[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      v[i] = *reinterpret_cast<const float4*>(x + row * D + (i * 64 + lane) * 4);
+      d[i] = *reinterpret_cast<const float4*>(dy + row * D + (i * 64 + lane) * 4);
+      s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+    const float mean = wave_sum(s) * (1.f / D);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+      ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+    }
+    const float rstd = rsqrtf(wave_sum(ss) * (1.f / D) + 1e-5f);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      v[i].x *= rstd; v[i].y *= rstd; v[i].z *= rstd; v[i].w *= rstd;  // xhat
+      if (relu) {
+        if (!(v[i].x * gm[i].x + bt[i].x > 0.f)) d[i].x = 0.f;
+        if (!(v[i].y * gm[i].y + bt[i].y > 0.f)) d[i].y = 0.f;
+        if (!(v[i].z * gm[i].z + bt[i].z > 0.f)) d[i].z = 0.f;
+        if (!(v[i].w * gm[i].w + bt[i].w > 0.f)) d[i].w = 0.f;
+      }
+      ag[i].x += d[i].x * v[i].x; ag[i].y += d[i].y * v[i].y; ag[i].z += d[i].z * v[i].z; ag[i].w += d[i].w * v[i].w;
+      ab[i].x += d[i].x; ab[i].y += d[i].y; ab[i].z += d[i].z; ab[i].w += d[i].w;
+      d[i].x *= gm[i].x; d[i].y *= gm[i].y; d[i].z *= gm[i].z; d[i].w *= gm[i].w;  // g
+      s1 += d[i].x + d[i].y + d[i].z + d[i].w;
+      s2 += d[i].x * v[i].x + d[i].y * v[i].y + d[i].z * v[i].z + d[i].w * v[i].w;
+    }
+    s1 = wave_sum(s1) * (1.f / D);
+    s2 = wave_sum(s2) * (1.f / D);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int64_t o = row * D + (i * 64 + lane) * 4;
+      float4 r;
+      r.x = rstd * (d[i].x - s1 - v[i].x * s2);
+      r.y = rstd * (d[i].y - s1 - v[i].y * s2);
+      r.z = rstd * (d[i].z - s1 - v[i].z * s2);
+      r.w = rstd * (d[i].w - s1 - v[i].w * s2);
+      if (dx_add) {
+        const float4 a = *reinterpret_cast<const float4*>(dx_add + o);
+        r.x += a.x; r.y += a.y; r.z += a.z; r.w += a.w;
+      }
+      *reinterpret_cast<float4*>(dx + o) = r;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    *reinterpret_cast<float4*>(&red[w][(i * 64 + lane) * 4]) = ag[i];
+    *reinterpret_cast<float4*>(&red[w][D + (i * 64 + lane) * 4]) = ab[i];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * D; c += 256)
+    part[(int64_t)blockIdx.x * 2 * D + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+}
+
+// ---- dz = dy where y > 0 else 0 (2-D, row strides); workgroup = 256 columns of one row
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dy, int64_t ldd,
+                                                       const float* __restrict__ y, int64_t ldy, int N, int cblocks,
+                                                       float* __restrict__ out, int64_t ldo) {
+  const int64_t row = blockIdx.x / cblocks;
+  const int c = (blockIdx.x % cblocks) * 256 + threadIdx.x;
+  if (c < N) out[row * ldo + c] = y[row * ldy + c] > 0.f ? dy[row * ldd + c] : 0.f;
+}
+
+// ---- out_bf16[b*T + t, f] = (max(x, clamp) - mean[b, f]) * rinv[b, f], zero padded to ldo columns
+__global__ __launch_bounds__(256) void mvn_apply_kernel(const float* __restrict__ x, int T, int F, int64_t ldx,
+                                                        float clamp_min, const float* __restrict__ mean,
+                                                        const float* __restrict__ rinv,
+                                                        unsigned short* __restrict__ out, int ldo, int cblocks) {
+  const int64_t row = blockIdx.x / cblocks;
+  const int b = (int)(row / T);
+  const int c = (blockIdx.x % cblocks) * 256 + threadIdx.x;
+  if (c >= ldo) return;
+  float v = 0.f;
+  if (c < F) v = (fmaxf(x[row * ldx + c], clamp_min) - mean[(size_t)b * F + c]) * rinv[(size_t)b * F + c];
+  out[row * ldo + c] = f2bf(v);
+}
+
+// ---- P[z, i, j] = softmax_j(S[z, i, j] + R[z, i, i - j + T - 1]); one wave per row; bf16 out, zero padded to ldp
+__global__ __launch_bounds__(256) void relpos_softmax_kernel(const float* __restrict__ sqk, int64_t lds,
+                                                             const float* __restrict__ rel, int64_t ldr, int64_t nrows,
+                                                             int T, unsigned short* __restrict__ p, int64_t ldp) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // z*T + i
+  if (row >= nrows) return;
+  const int i = (int)(row % T);
+  const float* s = sqk + row * lds;
+  const float* r = rel + row * ldr + i + T - 1;
+  float mx = -INFINITY;
+  for (int j = lane; j < T; j += 64) mx = fmaxf(mx, s[j] + r[-j]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < T; j += 64) sum += __expf(s[j] + r[-j] - mx);
+  const float inv = 1.f / wave_sum(sum);
+  for (int j = lane; j < ldp; j += 64) p[row * ldp + j] = j < T ? f2bf(__expf(s[j] + r[-j] - mx) * inv) : (unsigned short)0;
+}
+
+// ---- dS = P o (dP - sum_j P dP); also its skewed copy dSk[b, i, h, r] = dS[b, h, i, i + T - 1 - r] (0 outside)
+__global__ __launch_bounds__(256) void relpos_softmax_bwd_kernel(const unsigned short* __restrict__ p, int64_t ldp,
+                                                                 const float* __restrict__ dp, int64_t ldd, int B, int H,
+                                                                 int T, unsigned short* __restrict__ ds,
+                                                                 unsigned short* __restrict__ dsk, int W) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b*H + h)*T + i
+  if (row >= (int64_t)B * H * T) return;
+  const int i = (int)(row % T), h = (int)((row / T) % H), b = (int)(row / ((int64_t)T * H));
+  const unsigned short* pr = p + row * ldp;
+  const float* dr = dp + row * ldd;
+  float dot = 0.f;
+  for (int j = lane; j < T; j += 64) dot += bf2f(pr[j]) * dr[j];
+  dot = wave_sum(dot);
+  for (int j = lane; j < ldp; j += 64) ds[row * ldp + j] = j < T ? f2bf(bf2f(pr[j]) * (dr[j] - dot)) : (unsigned short)0;
+  unsigned short* sk = dsk + (((int64_t)b * T + i) * H + h) * W;
+  for (int r = lane; r < W; r += 64) {
+    const int j = i + T - 1 - r;
+    sk[r] = (j >= 0 && j < T) ? f2bf(bf2f(pr[j]) * (dr[j] - dot)) : (unsigned short)0;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t csship_layernorm_bwd_workspace(int64_t M, int32_t D) {
+  return (size_t)((M + 63) / 64) * 2 * D * sizeof(float);
+}
+
+extern "C" int csship_layernorm_bwd(const float* x, const float* dy, const float* gamma, const float* beta,
+                                    const float* dx_add, int32_t relu, int64_t M, int32_t D, float* dx,
+                                    float* dgamma_dbeta, void* workspace, size_t workspace_bytes,
+                                    csship_stream_t stream) {
+  if (!x || !dy || !gamma || !beta || !dx || !dgamma_dbeta || !workspace) return CSSHIP_ENULL;
+  if (M <= 0) return CSSHIP_EBADSHAPE;
+  if (D != 256 && D != 512 && D != 1024) return CSSHIP_EUNSUPPORTED;
+  if (!aligned16(x) || !aligned16(dy) || !aligned16(dx) || !aligned16(gamma) || !aligned16(beta) ||
+      (dx_add && !aligned16(dx_add)))
+    return CSSHIP_EALIGN;
+  const int nwg = (int)((M + 63) / 64);
+  if (workspace_bytes < (size_t)nwg * 2 * D * sizeof(float)) return CSSHIP_EWORKSPACE;
+  hipStream_t s = as_stream(stream);
+  float* part = reinterpret_cast<float*>(workspace);
+  if (D == 256)
+    hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(nwg), dim3(256), 0, s, x, dy, gamma, beta, dx_add, relu, M, 64, dx, part);
+  else if (D == 512)
+    hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(nwg), dim3(256), 0, s, x, dy, gamma, beta, dx_add, relu, M, 64, dx, part);
+  else
+    hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nwg), dim3(256), 0, s, x, dy, gamma, beta, dx_add, relu, M, 64, dx, part);
+  CSSHIP_CHECK_LAUNCH();
+  return launch_slab_reduce(part, nwg, 2 * (int64_t)D, 2 * D, 2 * (int64_t)D, 1.f, nullptr, nullptr, 0, dgamma_dbeta, s);
+}
+
+extern "C" int csship_relu_bwd(const float* dy, int64_t ld_dy, const float* y, int64_t ld_y, int64_t M, int32_t N,
+                               float* out, int64_t ld_out, csship_stream_t stream) {
+  if (!dy || !y || !out) return CSSHIP_ENULL;
+  const int cblocks = (N + 255) / 256;
+  if (M <= 0 || N <= 0 || ld_dy < N || ld_y < N || ld_out < N || M * cblocks > 0x7fffffff) return CSSHIP_EBADSHAPE;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)(M * cblocks)), dim3(256), 0, as_stream(stream), dy, ld_dy, y, ld_y,
+                     N, cblocks, out, ld_out);
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
+extern "C" int csship_mvn_apply(const float* x, int64_t B, int64_t T, int64_t F, int64_t ldx, float clamp_min,
+                                const float* mean, const float* rinv, uint16_t* out_bf16, int64_t ld_out,
+                                csship_stream_t stream) {
+  if (!x || !mean || !rinv || !out_bf16) return CSSHIP_ENULL;
+  const int cblocks = (int)((ld_out + 255) / 256);
+  if (B <= 0 || T <= 0 || F <= 0 || ldx < F || ld_out < F || B * T * cblocks > 0x7fffffff) return CSSHIP_EBADSHAPE;
+  hipLaunchKernelGGL(mvn_apply_kernel, dim3((unsigned)(B * T * cblocks)), dim3(256), 0, as_stream(stream), x, (int)T,
+                     (int)F, ldx, clamp_min, mean, rinv, out_bf16, (int)ld_out, cblocks);
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
+extern "C" int csship_relpos_softmax(const float* s_qk, int64_t ld_s, const float* rel, int64_t ld_rel, int32_t B,
+                                     int32_t H, int32_t T, uint16_t* p_bf16, int64_t ld_p, csship_stream_t stream) {
+  if (!s_qk || !rel || !p_bf16) return CSSHIP_ENULL;
+  if (B <= 0 || H <= 0 || T <= 0 || ld_s < T || ld_rel < 2 * T - 1 || ld_p < T) return CSSHIP_EBADSHAPE;
+  const int64_t nrows = (int64_t)B * H * T;
+  hipLaunchKernelGGL(relpos_softmax_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, as_stream(stream), s_qk,
+                     ld_s, rel, ld_rel, nrows, T, p_bf16, ld_p);
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
+extern "C" int csship_relpos_softmax_bwd(const uint16_t* p_bf16, int64_t ld_p, const float* dp, int64_t ld_dp,
+                                         int32_t B, int32_t H, int32_t T, uint16_t* ds_bf16, uint16_t* ds_skew_bf16,
+                                         int32_t W, csship_stream_t stream) {
+  if (!p_bf16 || !dp || !ds_bf16 || !ds_skew_bf16) return CSSHIP_ENULL;
+  if (B <= 0 || H <= 0 || T <= 0 || ld_p < T || ld_dp < T || W < 2 * T - 1) return CSSHIP_EBADSHAPE;
+  const int64_t nrows = (int64_t)B * H * T;
+  hipLaunchKernelGGL(relpos_softmax_bwd_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, as_stream(stream),
+                     p_bf16, ld_p, dp, ld_dp, B, H, T, ds_bf16, ds_skew_bf16, W);
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}

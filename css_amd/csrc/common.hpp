@@ -42,6 +42,10 @@ static inline hipStream_t as_stream(csship_stream_t s) { return reinterpret_cast
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
 
+// out[r, c] = alpha * sum_s slabs[s][r*N + c] (+ bias[c]) (+ add[r*ldadd + c]), fixed order (bgemm.hip)
+int launch_slab_reduce(const float* slabs, int S, int64_t n, int N, int64_t ldc, float alpha, const float* bias,
+                       const float* add, int64_t ldadd, float* out, hipStream_t s);
+
 // Optional in-kernel phase stamps (diagnostic only; nullptr in normal operation): thread 0 of every
 // workgroup stores s_memrealtime (100 MHz) at up to 8 phase boundaries.  Set by csship_debug_stamps().
 extern unsigned long long* g_csship_stamps;

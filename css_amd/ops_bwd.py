@@ -73,28 +73,96 @@ def bgemm(a, b, *, a_kmajor=False, b_kmajor=False, out=None, out_bf16=False, alp
     if add is not None:
         aux = _as4(_need(add, torch.float32, "add"), "add")
         epi |= _lib.BEPI_ADD
-    if aux is not None and (aux.shape[-2:] != (M, N) or bstr(aux) != bstr(out)):
-        raise RuntimeError("css_amd: bgemm aux must have the output's shape and batch strides")
+    if aux is not None and aux.shape[-2:] != (M, N):
+        raise RuntimeError("css_amd: bgemm aux must have the output's shape")
     p = _lib.BgemmParams(M=M, N=N, K=K, lda=a4.stride(2), ldb=b4.stride(2), ldc=out.stride(2),
                          ldaux=aux.stride(2) if aux is not None else 0,
                          a_kmajor=int(a_kmajor), b_kmajor=int(b_kmajor), a_f32=int(a4.dtype == torch.float32),
                          b_f32=int(b4.dtype == torch.float32), epilogue=epi, batch1=b1, batch2=b2, splits=splits,
                          sA1=bstr(a4)[0], sA2=bstr(a4)[1], sB1=bstr(b4)[0], sB2=bstr(b4)[1],
-                         sC1=bstr(out)[0], sC2=bstr(out)[1], alpha=float(alpha))
+                         sC1=bstr(out)[0], sC2=bstr(out)[1],
+                         sX1=bstr(aux)[0] if aux is not None else 0, sX2=bstr(aux)[1] if aux is not None else 0,
+                         alpha=float(alpha))
     nws = lib().csship_bgemm_workspace(C.byref(p))
     ws = _workspace(nws, a.device) if nws else None
     check(lib().csship_bgemm(_ptr(a4), _ptr(b4), _ptr(out), _ptr(bias), _ptr(aux), C.byref(p), _ptr(ws), nws, _stream()))
     return out_ret
 
 
-def colsum(x):
-    """Column sums of a [M, N] f32/bf16 matrix (row stride free) -> f32 [N]."""
+def colsum(x, alpha=1.0):
+    """alpha * column sums of a [M, N] f32/bf16 matrix (row stride free) -> f32 [N]."""
     if x.dim() != 2 or x.stride(1) != 1 or not x.is_cuda:
         raise RuntimeError("css_amd: colsum expects a HIP [M, N] matrix with contiguous columns")
     M, N = x.shape
     out = torch.empty(N, dtype=torch.float32, device=x.device)
     nws = lib().csship_colsum_workspace(M, N)
     ws = _workspace(nws, x.device)
-    check(lib().csship_colsum(_ptr(x), int(x.dtype == torch.float32), M, N, x.stride(0), _ptr(out), _ptr(ws), nws,
-                              _stream()))
+    check(lib().csship_colsum(_ptr(x), int(x.dtype == torch.float32), M, N, x.stride(0), float(alpha), _ptr(out),
+                              _ptr(ws), nws, _stream()))
     return out
+
+
+def layernorm_bwd(x, dy, gamma, beta, dx_add=None, relu=False, out=None):
+    """Backward of y = LayerNorm(x) [-> ReLU]: returns (dx (+ dx_add), dgamma, dbeta).  x, dy: f32 [M, D] dense."""
+    _need(x, torch.float32, "x"), _need(dy, torch.float32, "dy")
+    M, D = x.shape
+    if not (x.is_contiguous() and dy.is_contiguous()) or dy.shape != x.shape:
+        raise RuntimeError("css_amd: layernorm_bwd expects dense [M, D] x and dy")
+    dx = torch.empty_like(x) if out is None else out
+    gb = torch.empty((2, D), dtype=torch.float32, device=x.device)
+    nws = lib().csship_layernorm_bwd_workspace(M, D)
+    ws = _workspace(nws, x.device)
+    check(lib().csship_layernorm_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(beta), _ptr(dx_add), int(relu), M, D, _ptr(dx),
+                                     _ptr(gb), _ptr(ws), nws, _stream()))
+    return dx, gb[0], gb[1]
+
+
+def relu_bwd(dy, y, out=None):
+    """dy where y > 0 else 0; 2-D f32 with free row strides."""
+    _need(dy, torch.float32, "dy"), _need(y, torch.float32, "y")
+    if dy.dim() != 2 or dy.shape != y.shape or dy.stride(1) != 1 or y.stride(1) != 1:
+        raise RuntimeError("css_amd: relu_bwd expects matching 2-D tensors")
+    out = torch.empty_strided(dy.shape, dy.stride(), dtype=dy.dtype, device=dy.device) if out is None else out
+    check(lib().csship_relu_bwd(_ptr(dy), dy.stride(0), _ptr(y), y.stride(0), dy.shape[0], dy.shape[1], _ptr(out),
+                                out.stride(0), _stream()))
+    return out
+
+
+def mvn_apply(f, mean, rinv, ld_out=None):
+    """bf16 [B*T, ld_out] = MVN(f) (zero padded columns) for f f32 [B, T, F]."""
+    _need(f, torch.float32, "f")
+    B, T, F = f.shape
+    if f.stride(2) != 1 or f.stride(0) != T * f.stride(1):
+        f = f.contiguous()
+    ld_out = (F + 7) // 8 * 8 if ld_out is None else ld_out
+    out = torch.empty((B * T, ld_out), dtype=torch.bfloat16, device=f.device)
+    check(lib().csship_mvn_apply(_ptr(f), B, T, F, f.stride(1), float("-inf"), _ptr(mean), _ptr(rinv), _ptr(out), ld_out,
+                                 _stream()))
+    return out
+
+
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+def relpos_softmax(s_qk, rel, T):
+    """s_qk f32 [B,H,T,>=T], rel f32 [B,H,T,>=2T-1] (dense) -> P bf16 [B,H,T,pad8(T)] (zero padded)."""
+    B, H = s_qk.shape[:2]
+    if not (s_qk.is_contiguous() and rel.is_contiguous()):
+        raise RuntimeError("css_amd: relpos_softmax expects dense inputs")
+    p = torch.empty((B, H, T, _pad8(T)), dtype=torch.bfloat16, device=s_qk.device)
+    check(lib().csship_relpos_softmax(_ptr(s_qk), s_qk.shape[3], _ptr(rel), rel.shape[3], B, H, T, _ptr(p), p.shape[3],
+                                      _stream()))
+    return p
+
+
+def relpos_softmax_bwd(p, dp, T, W):
+    """P bf16 [B,H,T,ldp], dP f32 [B,H,T,ldd] -> dS bf16 [B,H,T,ldp], dS_skew bf16 [B,T,H,W]."""
+    B, H = p.shape[:2]
+    if not (p.is_contiguous() and dp.is_contiguous()):
+        raise RuntimeError("css_amd: relpos_softmax_bwd expects dense inputs")
+    ds = torch.empty_like(p)
+    dsk = torch.empty((B, T, H, W), dtype=torch.bfloat16, device=p.device)
+    check(lib().csship_relpos_softmax_bwd(_ptr(p), p.shape[3], _ptr(dp), dp.shape[3], B, H, T, _ptr(ds), _ptr(dsk), W,
+                                          _stream()))
+    return ds, dsk

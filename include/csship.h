@@ -323,7 +323,7 @@ int csship_conformer_forward(const csship_conformer_weights* w, const float* f, 
  * (A: [M, K] rows, B: [N, K] rows) or reduction-strided / "kmajor" (A: [K, M], B: [K, N]) - so dX = dY.W uses the
  * forward's [N, K] weight as a kmajor B, and dW = dY^T.X takes both activations kmajor; nothing is transposed in
  * memory.  f32 operands are rounded to bf16 on load.  Row strides: multiples of 8 (bf16) / 4 (f32) elements.
- * Batch index z = z1 * batch2 + z2 with element strides s?1 / s?2 (aux shares C's).  splits: 0 = choose
+ * Batch index z = z1 * batch2 + z2 with element strides s?1 / s?2 (sX* for aux).  splits: 0 = choose
  * (long reductions with few output tiles are split into f32 slabs in the workspace and summed in a fixed order),
  * splits > 1 needs batch1 * batch2 == 1 and an f32 output without CSSHIP_BEPI_MASK_POS. */
 enum {
@@ -337,17 +337,44 @@ typedef struct {
   int32_t a_kmajor, b_kmajor, a_f32, b_f32;
   int32_t epilogue;         /* OR of CSSHIP_BEPI_* */
   int32_t batch1, batch2, splits;
-  int64_t sA1, sA2, sB1, sB2, sC1, sC2;
+  int64_t sA1, sA2, sB1, sB2, sC1, sC2, sX1, sX2; /* sX*: aux */
   float alpha;
 } csship_bgemm_params;
 size_t csship_bgemm_workspace(const csship_bgemm_params* p);
 int csship_bgemm(const void* A, const void* B, void* C, const float* bias, const void* aux,
                  const csship_bgemm_params* p, void* workspace, size_t workspace_bytes, csship_stream_t stream);
 
-/* out[c] = sum_r x[r, c] for x f32 or bf16 [M, N] (row stride ld): the bias gradient of a Linear. */
+/* out[c] = alpha * sum_r x[r, c] for x f32 or bf16 [M, N] (row stride ld): the bias gradient of a Linear. */
 size_t csship_colsum_workspace(int64_t M, int32_t N);
-int csship_colsum(const void* x, int32_t x_is_f32, int64_t M, int32_t N, int64_t ld, float* out,
+int csship_colsum(const void* x, int32_t x_is_f32, int64_t M, int32_t N, int64_t ld, float alpha, float* out,
                   void* workspace, size_t workspace_bytes, csship_stream_t stream);
+
+/* ---- row kernels of the backward pass (css_amd/csrc/bwd.hip)
+ * csship_layernorm_bwd: y = LayerNorm(x) [then ReLU if relu != 0]; given dy returns dx (+ dx_add, may alias dx or dy)
+ * and dgamma_dbeta = f32 [2, D] (dgamma row, dbeta row).  D in {256, 512, 1024}; x, dy, dx f32 [M, D] dense. */
+size_t csship_layernorm_bwd_workspace(int64_t M, int32_t D);
+int csship_layernorm_bwd(const float* x, const float* dy, const float* gamma, const float* beta,
+                         const float* dx_add, int32_t relu, int64_t M, int32_t D, float* dx,
+                         float* dgamma_dbeta, void* workspace, size_t workspace_bytes, csship_stream_t stream);
+/* out = dy where y > 0, else 0 (mask head ReLU, conformer.py:99); 2-D with row strides; out may alias dy. */
+int csship_relu_bwd(const float* dy, int64_t ld_dy, const float* y, int64_t ld_y, int64_t M, int32_t N,
+                    float* out, int64_t ld_out, csship_stream_t stream);
+/* out_bf16[b*T + t, :] = MVN(x) as csship_mvn_stats defines it, zero padded to ld_out columns: the activation operand
+ * of the embed weight gradient. */
+int csship_mvn_apply(const float* x, int64_t B, int64_t T, int64_t F, int64_t ldx, float clamp_min,
+                     const float* mean, const float* rinv, uint16_t* out_bf16, int64_t ld_out,
+                     csship_stream_t stream);
+/* Attention backward brackets (conformer.py:229-253 under autograd).  With z = (b, h):
+ * csship_relpos_softmax: P[z,i,j] = softmax_j(s_qk[z,i,j] + rel[z,i, i-j+T-1]) where rel = q . pe_window^T,
+ *   pe_window[r] = pe_k[clamp(r-(T-1))] ; bf16 out, columns T..ld_p-1 zeroed.
+ * csship_relpos_softmax_bwd: dS = P o (dP - rowsum(P o dP)) as bf16 [B,H,T,ld_p] and its skewed copy
+ *   ds_skew[b, i, h, r] = dS[b, h, i, i+T-1-r] (bf16 [B,T,H,W], W >= 2T-1, zero outside), which turns the
+ *   relative-position gradients (dq += dS_skew . pe_window, dpe_window = dS_skew^T . q) into plain GEMMs. */
+int csship_relpos_softmax(const float* s_qk, int64_t ld_s, const float* rel, int64_t ld_rel, int32_t B,
+                          int32_t H, int32_t T, uint16_t* p_bf16, int64_t ld_p, csship_stream_t stream);
+int csship_relpos_softmax_bwd(const uint16_t* p_bf16, int64_t ld_p, const float* dp, int64_t ld_dp,
+                              int32_t B, int32_t H, int32_t T, uint16_t* ds_bf16, uint16_t* ds_skew_bf16,
+                              int32_t W, csship_stream_t stream);
 
 #ifdef __cplusplus
 }

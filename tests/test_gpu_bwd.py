@@ -24,6 +24,11 @@ def relerr(got, ref):
     return float((got.detach().double().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
 
 
+def froerr(got, ref):
+    ref = ref.double()
+    return float((got.detach().double().cpu() - ref).norm() / ref.norm().clamp_min(1e-30))
+
+
 @pytest.fixture(scope="module")
 def ob():
     assert torch.cuda.is_available(), "GPU tests need an MI355X"
@@ -115,3 +120,131 @@ def test_colsum(ob):
         x = rnd((M, ld), 10).to(DEV).to(dt)[:, :N]
         got = ob.colsum(x)
         assert relerr(got, x.float().cpu().double().sum(0)) < 1e-5
+
+
+def test_layernorm_bwd_and_relu_bwd(ob):
+    for D, relu in ((256, False), (512, False), (256, True), (1024, False)):
+        M = 333
+        x, dy = rnd((M, D), 11).double(), rnd((M, D), 12).double()
+        g, b = (1 + 0.1 * rnd((D,), 13)).double(), (0.1 * rnd((D,), 14)).double()
+        add = rnd((M, D), 15)
+        xr = x.clone().requires_grad_(True)
+        gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-5)
+        if relu:
+            y = torch.relu(y)
+        y.backward(dy)
+        dx, dg, db = ob.layernorm_bwd(x.float().to(DEV), dy.float().to(DEV), g.float().to(DEV), b.float().to(DEV),
+                                      dx_add=add.to(DEV), relu=relu)
+        assert relerr(dx, xr.grad + add.double()) < 2e-5
+        assert relerr(dg, gr.grad) < 2e-5 and relerr(db, br.grad) < 2e-5
+    y = rnd((50, 771), 16)
+    dyy = rnd((50, 772), 17).to(DEV)[:, :771]
+    got = ob.relu_bwd(dyy, y.to(DEV))
+    assert torch.equal(got.cpu(), torch.where(y > 0, dyy.cpu(), torch.zeros(())))
+
+
+def test_ffn_and_head_backward(ob):
+    """gradients of the FeedForward block and of the mask head vs float64 autograd of the oracle formulas"""
+    from css_amd import backward as bw, ops
+    M, D, FF = 500, 256, 1024
+    x, dy = rnd((M, D), 21), rnd((M, D), 22, 0.1)
+    P = {"g": 1 + 0.1 * rnd((D,), 23), "b": 0.1 * rnd((D,), 24), "w1": rnd((FF, D), 25, 0.06), "b1": rnd((FF,), 26, 0.1),
+         "w2": rnd((D, FF), 27, 0.03), "b2": rnd((D,), 28, 0.1)}
+    R = {k: v.double().requires_grad_(True) for k, v in P.items()}
+    xr = x.double().requires_grad_(True)
+    a = torch.nn.functional.layer_norm(xr, (D,), R["g"], R["b"], 1e-5)
+    out = xr + 0.5 * (torch.relu(a @ R["w1"].T + R["b1"]) @ R["w2"].T + R["b2"])
+    out.backward(dy.double())
+    G = {k: v.to(DEV) for k, v in P.items()}
+    dx, grads = bw.ffn_bwd(x.to(DEV), dy.to(DEV), G["g"], G["b"], G["b1"],
+                           G["w1"].to(torch.bfloat16), G["w2"].to(torch.bfloat16), 0.5)
+    # (a) vs float64 autograd: bf16 rounding plus ReLU units whose pre-activation sign flips under rounding
+    # (a few flipped units move single elements by several %, so this check uses the Frobenius norm)
+    assert froerr(dx, xr.grad) < 6e-2
+    for got, k in zip(grads, ("g", "b", "w1", "b1", "w2", "b2")):
+        assert froerr(got, R[k].grad) < 6e-2, k
+    # (b) tight: float64 evaluation of the SAME rounded operands (a, h, dy, dh rounded to bf16 where the kernels do)
+    xd = x.double().requires_grad_(True)
+    gd, bd = P["g"].double().requires_grad_(True), P["b"].double().requires_grad_(True)
+    a_full = torch.nn.functional.layer_norm(xd, (D,), gd, bd, 1e-5)
+    a_b = bf(a_full.detach().float()).double()
+    w1b, w2b, dyb = bf(P["w1"]).double(), bf(P["w2"]).double(), bf(dy).double()
+    h_b = bf(torch.relu(a_b @ w1b.T + P["b1"].double()).float()).double()
+    dh = bf((0.5 * (dyb @ w2b) * (h_b > 0)).float()).double()
+    want = {"w2": 0.5 * dyb.T @ h_b, "b2": 0.5 * dy.double().sum(0), "w1": dh.T @ a_b, "b1": dh.sum(0)}
+    a_full.backward(bf((dh @ w1b).float()).double() * 0 + dh @ w1b)
+    want.update({"g": gd.grad, "b": bd.grad})
+    tol = 2e-3  # h / a recomputed on the GPU may differ from this emulation by one bf16 ulp in a few elements
+    assert relerr(dx, xd.grad + dy.double()) < tol
+    for got, k in zip(grads, ("g", "b", "w1", "b1", "w2", "b2")):
+        assert relerr(got, want[k]) < tol, k
+    tol = 5e-2
+    # mask head
+    N = 771
+    w, b = rnd((N, D), 31, 0.06), rnd((N,), 32, 0.1)
+    xe = rnd((M, D), 33)
+    wr, br, xr = w.double().requires_grad_(True), b.double().requires_grad_(True), xe.double().requires_grad_(True)
+    masks = torch.relu(xr @ wr.T + br)
+    dm = rnd((M, N), 34, 0.1)
+    masks.backward(dm.double())
+    mg = torch.zeros((M, 772), device=DEV)[:, :N]
+    mg.copy_(masks.detach().float())
+    dmg = torch.zeros((M, 772), device=DEV)[:, :N]
+    dmg.copy_(dm)
+    dx, dw, db = bw.head_bwd(dmg, mg, xe.to(DEV), w.to(DEV).to(torch.bfloat16))
+    assert froerr(dx, xr.grad) < tol and froerr(dw, wr.grad) < tol and froerr(db, br.grad) < tol
+
+
+def _attn_ref(x, P, T, H, maxlen=1000):
+    """float64 restatement of conformer.py:213-254 + the residual of :356 (q scaled by 1/8 as in the reference)"""
+    B = x.shape[0]
+    D = x.shape[-1]
+    a = torch.nn.functional.layer_norm(x, (D,), P["g"], P["b"], 1e-5)
+    qkv = a @ P["wqkv"].T + P["bqkv"]
+    q, k, v = (qkv[..., i * D:(i + 1) * D].reshape(B, T, H, 64).transpose(1, 2) for i in range(3))
+    pos = (torch.arange(T)[:, None] - torch.arange(T)[None, :]).clamp(-maxlen, maxlen - 1) + maxlen
+    pk = P["pe"][pos]                                        # [T,T,64]
+    s = (q @ k.transpose(-1, -2) + torch.einsum("bhid,ijd->bhij", q, pk)) / 8.0
+    o = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, T, D)
+    return x + o @ P["wo"].T + P["bo"]
+
+
+def test_attention_backward(ob):
+    from css_amd import backward as bw, ops
+    B, T, H, D = 2, 90, 4, 256
+    x = rnd((B, T, D), 41)
+    P = {"g": 1 + 0.1 * rnd((D,), 42), "b": 0.1 * rnd((D,), 43), "wqkv": rnd((3 * D, D), 44, 0.08),
+         "bqkv": rnd((3 * D,), 45, 0.1), "wo": rnd((D, D), 46, 0.06), "bo": rnd((D,), 47, 0.1),
+         "pe": rnd((2000, 64), 48, 0.3)}
+    R = {k: v.double().requires_grad_(True) for k, v in P.items()}
+    xr = x.double().requires_grad_(True)
+    dy = rnd((B, T, D), 49, 0.1)
+    _attn_ref(xr, R, T, H).backward(dy.double())
+    # forward on the GPU exactly as the model does it (q rows pre-scaled)
+    G = {k: v.to(DEV) for k, v in P.items()}
+    ws = G["wqkv"].clone()
+    ws[:D] *= 0.125
+    bs = G["bqkv"].clone()
+    bs[:D] *= 0.125
+    x2 = x.to(DEV).view(B * T, D)
+    qkv = ops.panel_linear(x2, ops.pack_frag(ws), bs, 3 * D, ln=(G["g"], G["b"]), out_bf16=True).view(B, T, 3 * D)
+    ao = ops.mha_relpos(qkv, ops.pack_relpos(G["pe"]), H)
+    dx, grads = bw.mha_bwd(x2, dy.to(DEV).view(B * T, D), qkv, ao.view(B * T, D), G["g"], G["b"],
+                           ws.to(torch.bfloat16), G["wo"].to(torch.bfloat16), G["pe"].to(torch.bfloat16), H)
+    tol = 5e-2  # vs float64 autograd of the unrounded formula
+    assert froerr(dx.view(B, T, D), xr.grad) < tol
+    for got, k in zip(grads, ("g", "b", "wqkv", "bqkv", "wo", "bo", "pe")):
+        assert froerr(got, R[k].grad) < tol, k
+    # tight check of the attention core on the SAME bf16 q/k/v/pe/dO: only P and dS are rounded inside
+    dao = rnd((B * T, D), 50, 0.1).to(DEV).to(torch.bfloat16)
+    dqkv, dpe = bw.mha_core_bwd(qkv, dao, G["pe"].to(torch.bfloat16), H)
+    qd = qkv.float().cpu().double().requires_grad_(True)
+    ped = bf(P["pe"]).double().requires_grad_(True)
+    q, k, v = (qd[..., i * D:(i + 1) * D].reshape(B, T, H, 64).transpose(1, 2) for i in range(3))
+    pos = (torch.arange(T)[:, None] - torch.arange(T)[None, :]) + 1000
+    sc = q @ k.transpose(-1, -2) + torch.einsum("bhid,ijd->bhij", q, ped[pos])
+    o = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(B * T, D)
+    o.backward(dao.float().cpu().double())
+    assert relerr(dqkv.float(), qd.grad) < 1e-2
+    assert relerr(dpe, ped.grad) < 1e-2
