@@ -20,7 +20,8 @@ struct ConvArgs {
   csship_conv_weights w;
   const float* g;  // FROMG: glu(LN(x)) rows [B,T,D]
   float* zbuf;     // train: pre-BN activations [B,T,D]
-  float* partial;  // train: [nblk][2][D]
+  float* partial;  // train: [nblk][2][D]; MODE 2: [nblk][KS+1][D]
+  const float* dc; // MODE 2: gradient wrt the depthwise-conv output [B,T,D]
   int B, T;
   unsigned long long* stamps;
 };
@@ -98,10 +99,35 @@ __global__ __launch_bounds__(2 * D) void convmod_kernel(ConvArgs a) {
       xres[j] = a.x[((size_t)b * a.T + t) * D + c];
     }
   }
+  if constexpr (MODE == 2) {
+    // weight-gradient pass: d dw_w[k][c] = sum_t dc[t][c] * g[t + k - HALO][c] over this half tile, from registers
+    __syncthreads();
+    float gv[TH + KS - 1], dcv[TH];
+#pragma unroll
+    for (int u = 0; u < TH + KS - 1; ++u) gv[u] = G[tb0 + u][c];
+    float sdc = 0.f;
+#pragma unroll
+    for (int j = 0; j < TH; ++j) {
+      const int t = t0 + tb0 + j;
+      dcv[j] = t < a.T ? a.dc[((size_t)b * a.T + t) * D + c] : 0.f;
+      sdc += dcv[j];
+    }
+    const size_t blk = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + half;
+    float* out = a.partial + blk * (KS + 1) * D + c;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int j = 0; j < TH; ++j) sacc += dcv[j] * gv[j + k];
+      out[k * D] = sacc;
+    }
+    out[KS * D] = sdc;
+    return;
+  }
   float wk[KS];
 #pragma unroll
-  for (int k = 0; k < KS; ++k) wk[k] = a.w.dw_w[k * D + c];  // [k][D]: lanes read consecutive floats
-  const float cb = a.w.dw_b[c];
+  for (int k = 0; k < KS; ++k) wk[k] = a.w.dw_w[(MODE == 3 ? KS - 1 - k : k) * D + c];  // [k][D]; MODE 3: flipped taps
+  const float cb = MODE == 3 ? 0.f : a.w.dw_b[c];
   float scale = 0.f, shift = 0.f, pw2w = 0.f, pw2b = 0.f;
   if constexpr (MODE == 0) {
     scale = a.w.bn_g[c] * rsqrtf(a.w.bn_var[c] + 1e-5f);
@@ -134,6 +160,8 @@ __global__ __launch_bounds__(2 * D) void convmod_kernel(ConvArgs a) {
       const size_t o = ((size_t)b * a.T + t) * D + c;
       if constexpr (MODE == 0) {
         a.y[o] = xres[blk * OB + j] + fmaxf(acc[j] * scale + shift, 0.f) * pw2w + pw2b;
+      } else if constexpr (MODE == 3) {
+        a.y[o] = acc[j];  // dg = correlation of dc with the flipped taps
       } else {
         a.zbuf[o] = acc[j];
         lsum += acc[j];
@@ -177,6 +205,8 @@ __global__ __launch_bounds__(1024) void bn_reduce_kernel(const float* __restrict
     const float sc = bn_g[c] * (float)(1.0 / sqrt(var + 1e-5));
     scale_shift[c] = sc;
     scale_shift[D + c] = bn_b[c] - (float)mu * sc;
+    scale_shift[2 * D + c] = (float)mu;   // batch mean / biased variance: running statistics and the backward
+    scale_shift[3 * D + c] = (float)var;
   }
 }
 
@@ -229,12 +259,240 @@ int run(const ConvArgs& a0, int bn_mode, void* workspace, hipStream_t s) {
 
 constexpr int TT256 = 32, TT512 = 32;
 
+// ---------------------------------------------------------------------------------------------
+// Backward (training forward = bn_mode 1; z = pre-BN activations and stats = [sc | sh | mean | var] are the
+// forward's workspace).  With zh = z*sc + sh, r = relu(zh), y = x + r*w3 + b3:
+//   pass A   per channel S1 = sum dzh, S2 = sum dzh * zn  (dzh = dy*w3*[zh > 0], zn = (z - mean)*rstd); scalars
+//            d w3 = sum dy*r, d b3 = sum dy                        -> partials, fixed-order reduce
+//   pass A'  dc = sc * (dzh - S1/n - zn * S2/n)                    (BatchNorm backward with batch statistics)
+//   pass B1  dg = dc (*) flipped taps                              (convmod_kernel MODE 3)
+//   pass B2  d dw_w, d dw_b partials from g (recomputed) and dc    (convmod_kernel MODE 2)
+//   pass C   row kernel: GLU backward + LayerNorm backward + residual -> dx, d ln, d pw1
+template <int D>
+__global__ __launch_bounds__(D) void conv_bn_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                              const float* __restrict__ stats,
+                                                              const float* __restrict__ pw2_w, int64_t M,
+                                                              int rows_per_wg, float* __restrict__ part) {
+  __shared__ float red[2][D / 64];
+  const int c = threadIdx.x;
+  const float sc = stats[c], sh = stats[D + c], mu = stats[2 * D + c], rstd = rsqrtf(stats[3 * D + c] + 1e-5f);
+  const float w3 = pw2_w[0];
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg, r1 = min(M, r0 + rows_per_wg);
+  float s1 = 0.f, s2 = 0.f, dw3 = 0.f, db3 = 0.f;
+  for (int64_t r = r0; r < r1; ++r) {
+    const float d = dy[r * D + c], zz = z[r * D + c];
+    const float zh = zz * sc + sh;
+    const float dzh = zh > 0.f ? d * w3 : 0.f;
+    s1 += dzh;
+    s2 += dzh * (zz - mu) * rstd;
+    dw3 += d * fmaxf(zh, 0.f);
+    db3 += d;
+  }
+  float* out = part + (int64_t)blockIdx.x * (2 * D + 2);
+  out[c] = s1;
+  out[D + c] = s2;
+  dw3 = wave_sum(dw3);
+  db3 = wave_sum(db3);
+  if ((c & 63) == 0) { red[0][c >> 6] = dw3; red[1][c >> 6] = db3; }
+  __syncthreads();
+  if (c == 0) {
+    float a0 = 0.f, a1 = 0.f;
+    for (int i = 0; i < D / 64; ++i) { a0 += red[0][i]; a1 += red[1][i]; }
+    out[2 * D] = a0;
+    out[2 * D + 1] = a1;
+  }
+}
+
+__global__ __launch_bounds__(256) void conv_bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                                const float* __restrict__ stats,
+                                                                const float* __restrict__ sums,
+                                                                const float* __restrict__ pw2_w, float inv_n, size_t n4,
+                                                                int D, float* __restrict__ dc) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const int c = (int)((i * 4) % D);
+  const float4 d = reinterpret_cast<const float4*>(dy)[i];
+  const float4 zz = reinterpret_cast<const float4*>(z)[i];
+  const float w3 = pw2_w[0];
+  const float dv[4] = {d.x, d.y, d.z, d.w}, zv[4] = {zz.x, zz.y, zz.z, zz.w};
+  float o[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float sc = stats[c + q], sh = stats[D + c + q], mu = stats[2 * D + c + q];
+    const float rstd = rsqrtf(stats[3 * D + c + q] + 1e-5f);
+    const float zh = zv[q] * sc + sh;
+    const float dzh = zh > 0.f ? dv[q] * w3 : 0.f;
+    o[q] = sc * (dzh - sums[c + q] * inv_n - (zv[q] - mu) * rstd * sums[D + c + q] * inv_n);
+  }
+  reinterpret_cast<float4*>(dc)[i] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// pass C: one wave per row.  a = LN(x); g = (w0 a + b0) * sigmoid(w1 a + b1); given dg: da, then LayerNorm backward,
+// dx = dy + ...; partials [nwg][2D + 4]: d ln_g | d ln_b | d w0, d w1, d b0, d b1
+template <int VPL>
+__global__ __launch_bounds__(256) void glu_ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dg,
+                                                         const float* __restrict__ dy, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ pw1_w,
+                                                         const float* __restrict__ pw1_b, int64_t M, int rows_per_wg,
+                                                         float* __restrict__ dx, float* __restrict__ part) {
+  constexpr int D = 256 * VPL;
+  __shared__ float red[4][2 * D + 4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float w0 = pw1_w[0], w1 = pw1_w[1], b0 = pw1_b[0], b1 = pw1_b[1];
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg, r1 = min(M, r0 + rows_per_wg);
+  float gm[VPL][4], bt[VPL][4], ag[VPL][4], ab[VPL][4];
+  float sw0 = 0.f, sw1 = 0.f, sb0 = 0.f, sb1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const float4 g4 = *reinterpret_cast<const float4*>(gamma + (i * 64 + lane) * 4);
+    const float4 b4 = *reinterpret_cast<const float4*>(beta + (i * 64 + lane) * 4);
+    gm[i][0] = g4.x; gm[i][1] = g4.y; gm[i][2] = g4.z; gm[i][3] = g4.w;
+    bt[i][0] = b4.x; bt[i][1] = b4.y; bt[i][2] = b4.z; bt[i][3] = b4.w;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ag[i][q] = ab[i][q] = 0.f;
+  }
+  for (int64_t row = r0 + w; row < r1; row += 4) {
+    float v[VPL][4], d[VPL][4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const float4 xv = *reinterpret_cast<const float4*>(x + row * D + (i * 64 + lane) * 4);
+      const float4 gv = *reinterpret_cast<const float4*>(dg + row * D + (i * 64 + lane) * 4);
+      v[i][0] = xv.x; v[i][1] = xv.y; v[i][2] = xv.z; v[i][3] = xv.w;
+      d[i][0] = gv.x; d[i][1] = gv.y; d[i][2] = gv.z; d[i][3] = gv.w;
+      s += (xv.x + xv.y) + (xv.z + xv.w);
+    }
+    const float mean = wave_sum(s) * (1.f / D);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[i][q] -= mean;
+        ss += v[i][q] * v[i][q];
+      }
+    const float rstd = rsqrtf(wave_sum(ss) * (1.f / D) + 1e-5f);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float xh = v[i][q] * rstd;
+        const float a = xh * gm[i][q] + bt[i][q];
+        const float u = w0 * a + b0;
+        const float sg = 1.f / (1.f + __expf(-(w1 * a + b1)));
+        const float du = d[i][q] * sg;
+        const float dv = d[i][q] * u * sg * (1.f - sg);
+        sw0 += du * a; sb0 += du; sw1 += dv * a; sb1 += dv;
+        const float da = du * w0 + dv * w1;
+        ag[i][q] += da * xh;
+        ab[i][q] += da;
+        const float gg = da * gm[i][q];
+        v[i][q] = xh;
+        d[i][q] = gg;
+        s1 += gg;
+        s2 += gg * xh;
+      }
+    s1 = wave_sum(s1) * (1.f / D);
+    s2 = wave_sum(s2) * (1.f / D);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int64_t o = row * D + (i * 64 + lane) * 4;
+      const float4 a = *reinterpret_cast<const float4*>(dy + o);
+      float4 r;
+      r.x = a.x + rstd * (d[i][0] - s1 - v[i][0] * s2);
+      r.y = a.y + rstd * (d[i][1] - s1 - v[i][1] * s2);
+      r.z = a.z + rstd * (d[i][2] - s1 - v[i][2] * s2);
+      r.w = a.w + rstd * (d[i][3] - s1 - v[i][3] * s2);
+      *reinterpret_cast<float4*>(dx + o) = r;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VPL; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      red[w][(i * 64 + lane) * 4 + q] = ag[i][q];
+      red[w][D + (i * 64 + lane) * 4 + q] = ab[i][q];
+    }
+  sw0 = wave_sum(sw0); sw1 = wave_sum(sw1); sb0 = wave_sum(sb0); sb1 = wave_sum(sb1);
+  if (lane == 0) { red[w][2 * D] = sw0; red[w][2 * D + 1] = sw1; red[w][2 * D + 2] = sb0; red[w][2 * D + 3] = sb1; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * D + 4; c += 256)
+    part[(int64_t)blockIdx.x * (2 * D + 4) + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+}
+
+struct BwdLayout {  // carve of the backward workspace (floats)
+  size_t dc, dg, part, sums, total;
+  int nwg_rows, nblk;
+};
+BwdLayout bwd_layout(int B, int T, int D, int TT) {
+  BwdLayout L{};
+  const size_t n = (size_t)B * T * D;
+  L.nwg_rows = (int)(((size_t)B * T + 63) / 64);
+  L.nblk = ((T + TT - 1) / TT) * B * 2;
+  const size_t p = (size_t)L.nwg_rows * (2 * D + 4) > (size_t)L.nblk * 34 * D ? (size_t)L.nwg_rows * (2 * D + 4)
+                                                                             : (size_t)L.nblk * 34 * D;
+  L.dc = 0; L.dg = n; L.part = 2 * n; L.sums = 2 * n + p; L.total = L.sums + 34 * (size_t)D;
+  return L;
+}
+
+template <int D, int TT>
+int run_bwd(const float* x, const float* dy, const csship_conv_weights& w, int B, int T, const float* fwd_ws, float* dx,
+            const csship_conv_grads& g, float* ws, hipStream_t s) {
+  const BwdLayout L = bwd_layout(B, T, D, TT);
+  const int64_t M = (int64_t)B * T;
+  const size_t n = (size_t)M * D;
+  const float* z = fwd_ws;
+  const int fwd_nblk = ((T + TT - 1) / TT) * B * 2;
+  const float* stats = fwd_ws + n + (size_t)fwd_nblk * 2 * D;
+  float *dc = ws + L.dc, *dg = ws + L.dg, *part = ws + L.part, *sums = ws + L.sums;
+  // pass A
+  hipLaunchKernelGGL((conv_bn_bwd_stats_kernel<D>), dim3(L.nwg_rows), dim3(D), 0, s, dy, z, stats, w.pw2_w, M, 64, part);
+  CSSHIP_CHECK_LAUNCH();
+  int rc = launch_slab_reduce(part, L.nwg_rows, 2 * D + 2, 2 * D + 2, 2 * D + 2, 1.f, nullptr, nullptr, 0, sums, s);
+  if (rc) return rc;
+  if (hipMemcpyAsync(g.bn_b, sums, D * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(g.bn_g, sums + D, D * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(g.pw2_w, sums + 2 * D, sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(g.pw2_b, sums + 2 * D + 1, sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+    return CSSHIP_ELAUNCH;
+  // pass A'
+  hipLaunchKernelGGL(conv_bn_bwd_apply_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, dy, z, stats, sums,
+                     w.pw2_w, 1.f / (float)M, n / 4, D, dc);
+  CSSHIP_CHECK_LAUNCH();
+  // pass B1 / B2 on the forward's tile structure
+  dim3 grid((T + TT - 1) / TT, B);
+  ConvArgs a{x, dg, w, dc, nullptr, nullptr, nullptr, B, T, nullptr};
+  hipLaunchKernelGGL((convmod_kernel<D, TT, 33, 3, true>), grid, dim3(2 * D), 0, s, a);
+  CSSHIP_CHECK_LAUNCH();
+  ConvArgs a2{x, nullptr, w, nullptr, nullptr, part, dc, B, T, nullptr};
+  hipLaunchKernelGGL((convmod_kernel<D, TT, 33, 2, false>), grid, dim3(2 * D), 0, s, a2);
+  CSSHIP_CHECK_LAUNCH();
+  rc = launch_slab_reduce(part, L.nblk, (int64_t)34 * D, 34 * D, (int64_t)34 * D, 1.f, nullptr, nullptr, 0, sums, s);
+  if (rc) return rc;
+  if (hipMemcpyAsync(g.dw_w, sums, (size_t)33 * D * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(g.dw_b, sums + 33 * D, D * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+    return CSSHIP_ELAUNCH;
+  // pass C
+  hipLaunchKernelGGL((glu_ln_bwd_kernel<D / 256>), dim3(L.nwg_rows), dim3(256), 0, s, x, dg, dy, w.ln_g, w.ln_b, w.pw1_w,
+                     w.pw1_b, M, 64, dx, part);
+  CSSHIP_CHECK_LAUNCH();
+  rc = launch_slab_reduce(part, L.nwg_rows, 2 * D + 4, 2 * D + 4, 2 * D + 4, 1.f, nullptr, nullptr, 0, sums, s);
+  if (rc) return rc;
+  if (hipMemcpyAsync(g.ln_g, sums, D * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(g.ln_b, sums + D, D * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(g.pw1_w, sums + 2 * D, 2 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(g.pw1_b, sums + 2 * D + 2, 2 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+    return CSSHIP_ELAUNCH;
+  return CSSHIP_OK;
+}
+
 }  // namespace
 
 extern "C" size_t csship_convmod_workspace(int32_t B, int32_t T, int32_t D) {
   const int TT = D == 256 ? TT256 : TT512;
   const size_t nblk = (size_t)((T + TT - 1) / TT) * B * 2;
-  return ((size_t)B * T * D + nblk * 2 * D + 2 * (size_t)D) * sizeof(float);
+  return ((size_t)B * T * D + nblk * 2 * D + 4 * (size_t)D) * sizeof(float);
 }
 
 extern "C" int csship_convmod(const float* x, float* y, const csship_conv_weights* w, int32_t B, int32_t T,
@@ -249,7 +507,7 @@ extern "C" int csship_convmod(const float* x, float* y, const csship_conv_weight
   if (x == y) return CSSHIP_EBADSHAPE;  // neighbouring tiles read the halo rows: not in-place safe
   if (!aligned16(x) || !aligned16(y) || !aligned16(w->ln_g) || !aligned16(w->ln_b) || (workspace && !aligned16(workspace)))
     return CSSHIP_EALIGN;
-  ConvArgs a{x, y, *w, nullptr, nullptr, nullptr, B, T, g_csship_stamps};
+  ConvArgs a{x, y, *w, nullptr, nullptr, nullptr, nullptr, B, T, g_csship_stamps};
   if (D == 256) return run<256, TT256>(a, bn_mode, workspace, as_stream(stream));
   return run<512, TT512>(a, bn_mode, workspace, as_stream(stream));
 }
@@ -261,7 +519,31 @@ extern "C" int csship_conv_from_glu(const float* x, const float* g, float* y, co
   if (B <= 0 || T <= 0 || B > 65535) return CSSHIP_EBADSHAPE;
   if (kernel_size != 33 || (D != 256 && D != 512)) return CSSHIP_EUNSUPPORTED;
   if (!aligned16(x) || !aligned16(g) || !aligned16(y) || g == y) return CSSHIP_EALIGN;
-  ConvArgs a{x, y, *w, g, nullptr, nullptr, B, T, g_csship_stamps};
+  ConvArgs a{x, y, *w, g, nullptr, nullptr, nullptr, B, T, g_csship_stamps};
   if (D == 256) return run<256, TT256>(a, 0, nullptr, as_stream(stream));
   return run<512, TT512>(a, 0, nullptr, as_stream(stream));
+}
+
+extern "C" size_t csship_convmod_bwd_workspace(int32_t B, int32_t T, int32_t D) {
+  return bwd_layout(B, T, D, D == 256 ? TT256 : TT512).total * sizeof(float);
+}
+
+extern "C" int csship_convmod_bwd(const float* x, const float* dy, const csship_conv_weights* w, int32_t B, int32_t T,
+                                  int32_t D, int32_t kernel_size, const void* fwd_workspace, float* dx,
+                                  const csship_conv_grads* grads, void* workspace, size_t workspace_bytes,
+                                  csship_stream_t stream) {
+  if (!x || !dy || !w || !fwd_workspace || !dx || !grads || !workspace) return CSSHIP_ENULL;
+  if (!w->ln_g || !w->ln_b || !w->pw1_w || !w->pw1_b || !w->dw_w || !w->dw_b || !w->pw2_w) return CSSHIP_ENULL;
+  if (!grads->ln_g || !grads->ln_b || !grads->pw1_w || !grads->pw1_b || !grads->dw_w || !grads->dw_b || !grads->bn_g ||
+      !grads->bn_b || !grads->pw2_w || !grads->pw2_b)
+    return CSSHIP_ENULL;
+  if (B <= 0 || T <= 0 || B > 65535) return CSSHIP_EBADSHAPE;
+  if (kernel_size != 33 || (D != 256 && D != 512)) return CSSHIP_EUNSUPPORTED;
+  if (!aligned16(x) || !aligned16(dy) || !aligned16(dx) || !aligned16(fwd_workspace) || !aligned16(workspace))
+    return CSSHIP_EALIGN;
+  if (workspace_bytes < csship_convmod_bwd_workspace(B, T, D)) return CSSHIP_EWORKSPACE;
+  const float* fw = reinterpret_cast<const float*>(fwd_workspace);
+  float* ws = reinterpret_cast<float*>(workspace);
+  if (D == 256) return run_bwd<256, TT256>(x, dy, *w, B, T, fw, dx, *grads, ws, as_stream(stream));
+  return run_bwd<512, TT512>(x, dy, *w, B, T, fw, dx, *grads, ws, as_stream(stream));
 }

@@ -181,8 +181,10 @@ def conv_weights_struct(t):
     return cw
 
 
-def convmod(x, weights, kernel_size=33, batch_stats=False):
-    """x f32 [B,T,D] -> x + ConvModule(x).  weights: dict for conv_weights_struct."""
+def convmod(x, weights, kernel_size=33, batch_stats=False, return_workspace=False):
+    """x f32 [B,T,D] -> x + ConvModule(x).  weights: dict for conv_weights_struct.
+    return_workspace (batch_stats only): also return the workspace the backward needs (pre-BN activations; its last
+    4*D floats are scale | shift | batch mean | biased batch variance)."""
     _need(x, torch.float32, "x")
     x = x.contiguous()
     B, T, D = x.shape
@@ -193,7 +195,7 @@ def convmod(x, weights, kernel_size=33, batch_stats=False):
         ws = torch.empty(lib().csship_convmod_workspace(B, T, D), device=x.device, dtype=torch.uint8)
     check(lib().csship_convmod(_ptr(x), _ptr(y), C.byref(cw), B, T, D, kernel_size, 1 if batch_stats else 0,
                                _ptr(ws), _stream()))
-    return y
+    return (y, ws) if return_workspace else y
 
 
 def _targets_array(targets, B, T, F):

@@ -166,3 +166,31 @@ def relpos_softmax_bwd(p, dp, T, W):
     check(lib().csship_relpos_softmax_bwd(_ptr(p), p.shape[3], _ptr(dp), dp.shape[3], B, H, T, _ptr(ds), _ptr(dsk), W,
                                           _stream()))
     return ds, dsk
+
+
+CONV_GRAD_FIELDS = ("ln_g", "ln_b", "pw1_w", "pw1_b", "dw_w", "dw_b", "bn_g", "bn_b", "pw2_w", "pw2_b")
+
+
+def convmod_bwd(x, dy, weights, fwd_ws, kernel_size=33):
+    """Backward of ops.convmod(x, weights, batch_stats=True).  x, dy f32 [B,T,D]; fwd_ws: that call's workspace.
+    Returns dx and a dict of f32 gradients keyed like the weights dict (dw_w as [k, D])."""
+    from .ops import conv_weights_struct
+    _need(x, torch.float32, "x"), _need(dy, torch.float32, "dy")
+    x, dy = x.contiguous(), dy.contiguous()
+    B, T, D = x.shape
+    sizes = {"ln_g": D, "ln_b": D, "pw1_w": 2, "pw1_b": 2, "dw_w": kernel_size * D, "dw_b": D, "bn_g": D, "bn_b": D,
+             "pw2_w": 1, "pw2_b": 1}
+    flat = torch.empty(sum((n + 3) // 4 * 4 for n in sizes.values()), dtype=torch.float32, device=x.device)
+    grads, off = {}, 0
+    for k in CONV_GRAD_FIELDS:
+        grads[k] = flat[off:off + sizes[k]]
+        off += (sizes[k] + 3) // 4 * 4
+    cg = _lib.ConvGrads(**{k: C.c_void_p(grads[k].data_ptr()) for k in CONV_GRAD_FIELDS})
+    cw = conv_weights_struct(weights)
+    dx = torch.empty_like(x)
+    nws = lib().csship_convmod_bwd_workspace(B, T, D)
+    ws = _workspace(nws, x.device)
+    check(lib().csship_convmod_bwd(_ptr(x), _ptr(dy), C.byref(cw), B, T, D, kernel_size, _ptr(fwd_ws), _ptr(dx),
+                                   C.byref(cg), _ptr(ws), nws, _stream()))
+    grads["dw_w"] = grads["dw_w"].view(kernel_size, D)
+    return dx, grads

@@ -376,6 +376,20 @@ int csship_relpos_softmax_bwd(const uint16_t* p_bf16, int64_t ld_p, const float*
                               int32_t B, int32_t H, int32_t T, uint16_t* ds_bf16, uint16_t* ds_skew_bf16,
                               int32_t W, csship_stream_t stream);
 
+/* ---- csship_convmod_bwd (css_amd/csrc/convmod.hip): backward of csship_convmod run with bn_mode = 1.
+ * fwd_workspace is that forward call's workspace, untouched since (it holds the pre-BatchNorm activations and the
+ * batch statistics: after the call its last 4*D floats are [scale | shift | batch mean | biased batch variance]).
+ * dx = dy + (gradient through the module); parameter gradients go to the f32 buffers named in grads, laid out like
+ * the forward's csship_conv_weights (dw_w is [k, D], pw1_w / pw1_b hold 2 floats, pw2_w / pw2_b 1). */
+typedef struct {
+  float *ln_g, *ln_b, *pw1_w, *pw1_b, *dw_w, *dw_b, *bn_g, *bn_b, *pw2_w, *pw2_b;
+} csship_conv_grads;
+size_t csship_convmod_bwd_workspace(int32_t B, int32_t T, int32_t D);
+int csship_convmod_bwd(const float* x, const float* dy, const csship_conv_weights* w, int32_t B, int32_t T,
+                       int32_t D, int32_t kernel_size, const void* fwd_workspace, float* dx,
+                       const csship_conv_grads* grads, void* workspace, size_t workspace_bytes,
+                       csship_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

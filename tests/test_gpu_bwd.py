@@ -248,3 +248,43 @@ def test_attention_backward(ob):
     o.backward(dao.float().cpu().double())
     assert relerr(dqkv.float(), qd.grad) < 1e-2
     assert relerr(dpe, ped.grad) < 1e-2
+
+
+def test_convmod_backward(ob):
+    """ConvModule backward (LN -> scalar GLU -> depthwise conv -> batch-stat BatchNorm -> ReLU -> affine, + residual)
+    vs float64 autograd of the same formula (conformer.py:289-303,357).  All-f32 kernels: tight tolerance."""
+    import torch.nn.functional as F
+    from css_amd import ops
+    for B, T, D in ((3, 77, 256), (2, 50, 512)):
+        K = 33
+        x = rnd((B, T, D), 61)
+        dy = rnd((B, T, D), 62, 0.1)
+        P = {"ln_g": 1 + 0.1 * rnd((D,), 63), "ln_b": 0.1 * rnd((D,), 64), "pw1_w": torch.tensor([0.9, -0.7]),
+             "pw1_b": torch.tensor([0.1, 0.2]), "dw": rnd((D, K), 65, 0.2), "dw_b": 0.1 * rnd((D,), 66),
+             "bn_g": 1 + 0.1 * rnd((D,), 67), "bn_b": 0.1 * rnd((D,), 68), "pw2_w": torch.tensor([1.3]),
+             "pw2_b": torch.tensor([-0.2])}
+        R = {k: v.double().requires_grad_(True) for k, v in P.items()}
+        xr = x.double().requires_grad_(True)
+        a = F.layer_norm(xr, (D,), R["ln_g"], R["ln_b"], 1e-5)
+        g = (a * R["pw1_w"][0] + R["pw1_b"][0]) * torch.sigmoid(a * R["pw1_w"][1] + R["pw1_b"][1])
+        c = F.conv1d(g.transpose(1, 2), R["dw"][:, None, :], R["dw_b"], padding=K // 2, groups=D)
+        mu, var = c.mean((0, 2), keepdim=True), c.var((0, 2), unbiased=False, keepdim=True)
+        zh = (c - mu) / torch.sqrt(var + 1e-5) * R["bn_g"][None, :, None] + R["bn_b"][None, :, None]
+        y = xr + (torch.relu(zh) * R["pw2_w"] + R["pw2_b"]).transpose(1, 2)
+        y.backward(dy.double())
+        W = {k: v.to(DEV) for k, v in P.items() if k != "dw"}
+        W["dw_w"] = P["dw"].T.contiguous().to(DEV)                      # the forward takes the taps as [k, D]
+        yg, fws = ops.convmod(x.to(DEV), W, K, batch_stats=True, return_workspace=True)
+        assert relerr(yg, y.detach()) < 1e-5
+        stats = fws.view(torch.float32)[-4 * D:]
+        assert relerr(stats[2 * D:3 * D], mu.detach().flatten()) < 1e-5
+        assert relerr(stats[3 * D:], var.detach().flatten()) < 1e-5
+        dx, grads = ob.convmod_bwd(x.to(DEV), dy.to(DEV), W, fws, K)
+        assert relerr(dx, xr.grad) < 2e-4
+        ref = {k: R[k].grad for k in P if k != "dw"}
+        ref["dw_w"] = R["dw"].grad.T
+        for k, v in ref.items():
+            if k == "dw_b":  # analytically zero under batch-stat BatchNorm (the mean is subtracted right after)
+                assert float(grads[k].abs().max()) < 1e-5
+            else:
+                assert relerr(grads[k], v) < 2e-4, k
