@@ -380,7 +380,7 @@ int csship_relpos_softmax_bwd(const uint16_t* p_bf16, int64_t ld_p, const float*
  * fwd_workspace is that forward call's workspace, untouched since (it holds the pre-BatchNorm activations and the
  * batch statistics: after the call its last 4*D floats are [scale | shift | batch mean | biased batch variance]).
  * dx = dy + (gradient through the module); parameter gradients go to the f32 buffers named in grads, laid out like
- * the forward's csship_conv_weights (dw_w is [k, D], pw1_w / pw1_b hold 2 floats, pw2_w / pw2_b 1). */
+ * the forward's weight struct: dw_w is [k, D], pw1_w / pw1_b hold 2 floats, pw2_w / pw2_b 1. */
 typedef struct {
   float *ln_g, *ln_b, *pw1_w, *pw1_b, *dw_w, *dw_b, *bn_g, *bn_b, *pw2_w, *pw2_b;
 } csship_conv_grads;
