@@ -2,14 +2,19 @@
 
 Forward values ALWAYS come from the HIP kernels.  Backward:
   * PIT-MSE -> masks: hand-written kernel (csship_pit_mse_bwd);
-  * masks -> parameters: STOP-GAP.  The encoder backward kernels are not written yet, so the gradient is
-    obtained by re-evaluating a differentiable PyTorch-ROCm restatement of the model ("twin", GPU torch ops,
-    fp32) and back-propagating grad_masks through it (SURVEY.md 7, step 5 allows exactly this stop-gap).
-    The twin never produces a forward result that is returned to the caller.
+  * masks -> parameters, Conformer with d_model = 256 (``ConformerTrain``): explicit HIP backward of every operator
+    (css_amd/backward.py: batched MFMA GEMMs, LayerNorm / softmax / ConvModule backward kernels).  The training
+    forward runs operator by operator (same kernels as inference, minus the cross-operator chaining) and keeps each
+    operator's input; hidden activations are recomputed in the backward;
+  * other shapes (Conformer-large widths, BLSTM): STOP-GAP ``MasksWithTwinBackward`` - the gradient is obtained by
+    re-evaluating a differentiable PyTorch-ROCm restatement of the model ("twin", GPU torch ops, fp32) and
+    back-propagating grad_masks through it.  The twin never produces a forward result that is returned.
 """
 import torch
 
-from . import ops
+from . import backward as bw, ops, ops_bwd as ob
+
+BF = torch.bfloat16
 
 
 class PitMse(torch.autograd.Function):
@@ -54,6 +59,146 @@ class MasksWithTwinBackward(torch.autograd.Function):
         return (None, None) + full
 
 
+class ConformerTrain(torch.autograd.Function):
+    """masks = Conformer(f) in training mode (BatchNorm batch statistics, running statistics updated, no dropout)
+    with the explicit HIP backward.  d_model = 256, d_k = 64, kernel 33 (the tuned panel kernels)."""
+
+    @staticmethod
+    def forward(ctx, model, f, *params):
+        enc = model.conformer
+        D, H, FF, K = enc.d_model, enc.n_head, enc.d_ffn, enc.kernel_size
+        B, T, F = f.shape
+        M = B * T
+        f = f.contiguous()
+        mean, rinv = ops.mvn_stats(f)
+        S = {"f": f, "mean": mean, "rinv": rinv, "layers": []}
+        we = enc.embed[0].weight.detach()
+        Kp = (F + 7) // 8 * 8
+        we_bf = torch.zeros((D, Kp), dtype=BF, device=f.device)
+        we_bf[:, :F] = we
+        fn = ob.mvn_apply(f, mean, rinv, Kp)
+        e = ob.bgemm(fn, we_bf, bias=enc.embed[0].bias.detach())
+        _, x = ops.layernorm_relu(e, enc.embed[1].weight.detach(), enc.embed[1].bias.detach())
+        S["we_bf"] = we_bf
+        pe = enc.pos_emb.pe_k.weight.detach()
+        pe_pack = ops.pack_relpos(pe, enc.pos_emb.maxlen)
+        S["pe_bf"] = pe.to(BF)
+        for lay in enc.encoders:
+            L = {}
+
+            def ffn(m, xin, tag):
+                w1, w2 = m.net[0].weight.detach(), m.net[3].weight.detach()
+                L[tag] = (xin, w1.to(BF), w2.to(BF))
+                return ops.ffn_fused(xin, (m.layer_norm.weight.detach(), m.layer_norm.bias.detach()), ops.pack_frag(w1),
+                                     m.net[0].bias.detach(), ops.pack_frag(w2), m.net[3].bias.detach(), FF, 0.5)
+
+            x1 = ffn(lay.feed_forward_in, x, "ffn_in")
+            a = lay.self_attn
+            scale = a.d_k ** -0.5
+            wqkv = torch.cat([a.linear_q.weight.detach() * scale, a.linear_k.weight.detach(), a.linear_v.weight.detach()], 0)
+            bqkv = torch.cat([a.linear_q.bias.detach() * scale, a.linear_k.bias.detach(), a.linear_v.bias.detach()], 0)
+            wo = a.linear_out.weight.detach()
+            qkv = ops.panel_linear(x1, ops.pack_frag(wqkv), bqkv, 3 * D,
+                                   ln=(a.layer_norm.weight.detach(), a.layer_norm.bias.detach()), out_bf16=True)
+            ao = ops.mha_relpos(qkv.view(B, T, 3 * D), pe_pack, H).view(M, D)
+            x2 = ops.panel_linear(ao, ops.pack_frag(wo), a.linear_out.bias.detach(), D, residual=x1)
+            L["mha"] = (x1, qkv, ao, wqkv.to(BF), wo.to(BF), scale)
+            c = lay.conv
+            W = {"ln_g": c.layer_norm.weight.detach(), "ln_b": c.layer_norm.bias.detach(),
+                 "pw1_w": c.pw_conv_1.weight.detach().view(2), "pw1_b": c.pw_conv_1.bias.detach(),
+                 "dw_w": c.dw_conv_1d.weight.detach().view(D, K).t().contiguous(), "dw_b": c.dw_conv_1d.bias.detach(),
+                 "bn_g": c.BN.weight.detach(), "bn_b": c.BN.bias.detach(),
+                 "pw2_w": c.pw_conv_2.weight.detach().view(1), "pw2_b": c.pw_conv_2.bias.detach()}
+            x3, fws = ops.convmod(x2.view(B, T, D), W, K, batch_stats=True, return_workspace=True)
+            x3 = x3.view(M, D)
+            L["conv"] = (x2, W, fws)
+            stats = fws.view(torch.float32)[-4 * D:]
+            with torch.no_grad():  # BatchNorm1d bookkeeping (momentum 0.1, unbiased running variance)
+                c.BN.running_mean.mul_(0.9).add_(stats[2 * D:3 * D], alpha=0.1)
+                c.BN.running_var.mul_(0.9).add_(stats[3 * D:], alpha=0.1 * M / max(M - 1, 1))
+                c.BN.num_batches_tracked += 1
+            x4 = ffn(lay.feed_forward_out, x3, "ffn_out")
+            _, x = ops.layernorm(x4, lay.layer_norm.weight.detach(), lay.layer_norm.bias.detach(), out_bf16=False,
+                                 out_f32=True)
+            L["x4"] = x4
+            S["layers"].append(L)
+        n_out = model.linear.out_features
+        wh = model.linear.weight.detach()
+        ld = (n_out + 3) // 4 * 4
+        masks = torch.empty((M, ld), dtype=torch.float32, device=f.device)[:, :n_out]
+        ops.panel_linear(x, ops.pack_frag(wh), model.linear.bias.detach(), n_out, relu=True, out=masks)
+        S.update(e=e, x_enc=x, masks=masks, wh_bf=wh.to(BF))
+        ctx.model, ctx.S = model, S
+        return masks.view(B, T, n_out)
+
+    @staticmethod
+    def backward(ctx, grad_masks):
+        model, S = ctx.model, ctx.S
+        ctx.S = None  # release the saved activations with this call
+        enc = model.conformer
+        D, H = enc.d_model, enc.n_head
+        B, T, F = S["f"].shape
+        M = B * T
+        G = {}  # parameter -> gradient
+
+        def put(p, g):
+            g = g.reshape(p.shape)
+            G[p] = G[p] + g if p in G else g
+
+        masks = S["masks"]
+        dm = grad_masks.reshape(M, -1)
+        if dm.stride(1) != 1 or dm.stride(0) % 4:
+            buf = torch.empty_strided(masks.shape, masks.stride(), dtype=torch.float32, device=masks.device)
+            buf.copy_(dm)
+            dm = buf
+        dx, dw, db = bw.head_bwd(dm, masks, S["x_enc"], S["wh_bf"])
+        put(model.linear.weight, dw), put(model.linear.bias, db)
+        for lay, L in zip(reversed(list(enc.encoders)), reversed(S["layers"])):
+            dx, dg, dbeta = ob.layernorm_bwd(L["x4"], dx, lay.layer_norm.weight.detach(), lay.layer_norm.bias.detach())
+            put(lay.layer_norm.weight, dg), put(lay.layer_norm.bias, dbeta)
+
+            def ffn_b(m, tag, dy):
+                xin, w1_bf, w2_bf = L[tag]
+                dxo, g = bw.ffn_bwd(xin, dy, m.layer_norm.weight.detach(), m.layer_norm.bias.detach(),
+                                    m.net[0].bias.detach(), w1_bf, w2_bf, 0.5)
+                for p, gv in zip((m.layer_norm.weight, m.layer_norm.bias, m.net[0].weight, m.net[0].bias,
+                                  m.net[3].weight, m.net[3].bias), g):
+                    put(p, gv)
+                return dxo
+
+            dx = ffn_b(lay.feed_forward_out, "ffn_out", dx)
+            x2, W, fws = L["conv"]
+            c = lay.conv
+            dx3, g = ob.convmod_bwd(x2.view(B, T, D), dx.view(B, T, D), W, fws, enc.kernel_size)
+            dx = dx3.view(M, D)
+            put(c.layer_norm.weight, g["ln_g"]), put(c.layer_norm.bias, g["ln_b"])
+            put(c.pw_conv_1.weight, g["pw1_w"]), put(c.pw_conv_1.bias, g["pw1_b"])
+            put(c.dw_conv_1d.weight, g["dw_w"].t()), put(c.dw_conv_1d.bias, g["dw_b"])
+            put(c.BN.weight, g["bn_g"]), put(c.BN.bias, g["bn_b"])
+            put(c.pw_conv_2.weight, g["pw2_w"]), put(c.pw_conv_2.bias, g["pw2_b"])
+            x1, qkv, ao, wqkv_bf, wo_bf, scale = L["mha"]
+            a = lay.self_attn
+            dx, g = bw.mha_bwd(x1, dx, qkv.view(B, T, 3 * D), ao, a.layer_norm.weight.detach(),
+                               a.layer_norm.bias.detach(), wqkv_bf, wo_bf, S["pe_bf"], H, scale)
+            dg, dbeta, dwqkv, dbqkv, dwo, dbo, dpe = g
+            put(a.layer_norm.weight, dg), put(a.layer_norm.bias, dbeta)
+            for i, lin in enumerate((a.linear_q, a.linear_k, a.linear_v)):
+                put(lin.weight, dwqkv[i * D:(i + 1) * D]), put(lin.bias, dbqkv[i * D:(i + 1) * D])
+            put(a.linear_out.weight, dwo), put(a.linear_out.bias, dbo)
+            put(enc.pos_emb.pe_k.weight, dpe)
+            dx = ffn_b(lay.feed_forward_in, "ffn_in", dx)
+            L.clear()
+        dwe, dbe, dg, dbeta = bw.embed_bwd(S["f"], dx, S["mean"], S["rinv"], S["we_bf"], enc.embed[0].bias.detach(),
+                                           enc.embed[1].weight.detach(), enc.embed[1].bias.detach(), e=S["e"])
+        put(enc.embed[0].weight, dwe), put(enc.embed[0].bias, dbe)
+        put(enc.embed[1].weight, dg), put(enc.embed[1].bias, dbeta)
+        return (None, None) + tuple(G.get(p) if p.requires_grad else None for p in model.parameters())
+
+
 def masks_for_training(model, f):
     params = tuple(model.parameters())
+    enc = getattr(model, "conformer", None)
+    if enc is not None and enc.d_model == 256 and enc.d_model // enc.n_head == 64 and enc.kernel_size == 33 \
+            and model.training and not getattr(model, "force_twin_backward", False):
+        return ConformerTrain.apply(model, f, *params)
     return MasksWithTwinBackward.apply(model, f, *params)

@@ -107,6 +107,19 @@ def layernorm(x, gamma, beta, out_bf16=True, out_f32=False):
     return ob, of
 
 
+def layernorm_relu(x, gamma, beta, relu=True, out_bf16=False, out_f32=True):
+    """LayerNorm over the last dim (any width) followed by an optional ReLU -> (bf16 or None, f32 or None)."""
+    _need(x, torch.float32, "x")
+    x = x.contiguous()
+    D = x.shape[-1]
+    M = x.numel() // D
+    ob = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16) if out_bf16 else None
+    of = torch.empty_like(x) if out_f32 else None
+    check(lib().csship_layernorm_relu(_ptr(x), M, D, _ptr(_need(gamma, torch.float32, "gamma")),
+                                      _ptr(_need(beta, torch.float32, "beta")), int(relu), _ptr(ob), _ptr(of), _stream()))
+    return ob, of
+
+
 def pad_weight_bf16(w, scale_rows=None):
     """[N,K] f32 -> bf16 [N, ceil64(K)] zero padded (the W operand layout of csship_gemm)."""
     N, K = w.shape
