@@ -208,16 +208,31 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
   }
 }
 
-// out[r, c] = alpha * sum_s slab[s][r, c] (+ bias[c]) (+ add[r, c]); fixed summation order
+// out[r, c] = alpha * sum_s slab[s][r, c] (+ bias[c]) (+ add[r, c]); fixed summation order.
+// Workgroup = 64 consecutive elements x 4 waves; wave w adds slabs w, w+4, ... with four loads in flight, then one
+// LDS reduction - short outputs with many slabs (LayerNorm / bias partials) no longer serialise on one thread.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int S, int64_t n, int N,
                                                           int64_t ldc, float alpha, const float* __restrict__ bias,
                                                           const float* add, int64_t ldadd, float* out) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int k = 0; k < S; ++k) s += slabs[(int64_t)k * n + i];
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    int k = w;
+    for (; k + 12 < S; k += 16) {
+      s0 += slabs[(int64_t)k * n + i];
+      s1 += slabs[(int64_t)(k + 4) * n + i];
+      s2 += slabs[(int64_t)(k + 8) * n + i];
+      s3 += slabs[(int64_t)(k + 12) * n + i];
+    }
+    for (; k < S; k += 4) s0 += slabs[(int64_t)k * n + i];
+  }
+  red[w][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (w != 0 || i >= n) return;
   const int64_t r = i / N, c = i % N;
-  float v = alpha * s;
+  float v = alpha * ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
   if (bias) v += bias[c];
   if (add) v += add[r * ldadd + c];
   out[r * ldc + c] = v;
@@ -259,7 +274,7 @@ int pick_splits(const csship_bgemm_params* p) {
 
 int launch_slab_reduce(const float* slabs, int S, int64_t n, int N, int64_t ldc, float alpha, const float* bias,
                        const float* add, int64_t ldadd, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slabs, S, n, N, ldc, alpha,
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, slabs, S, n, N, ldc, alpha,
                      bias, add, ldadd, out);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
@@ -312,11 +327,9 @@ extern "C" int csship_bgemm(const void* A, const void* B, void* C, const float* 
   CSSHIP_CHECK_LAUNCH();
   if (splits > 1) {
     const int64_t n = (int64_t)p->M * p->N;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
-                       reinterpret_cast<const float*>(workspace), splits, n, p->N, p->ldc, p->alpha, bias,
-                       (p->epilogue & CSSHIP_BEPI_ADD) ? reinterpret_cast<const float*>(aux) : nullptr, p->ldaux,
-                       reinterpret_cast<float*>(C));
-    CSSHIP_CHECK_LAUNCH();
+    return launch_slab_reduce(reinterpret_cast<const float*>(workspace), splits, n, p->N, p->ldc, p->alpha, bias,
+                              (p->epilogue & CSSHIP_BEPI_ADD) ? reinterpret_cast<const float*>(aux) : nullptr,
+                              p->ldaux, reinterpret_cast<float*>(C), s);
   }
   return CSSHIP_OK;
 }
@@ -337,9 +350,6 @@ extern "C" int csship_colsum(const void* x, int32_t x_is_f32, int64_t M, int32_t
   hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, slices), dim3(256), 0, s, x, x_is_f32, M, N, ld, 256,
                      reinterpret_cast<float*>(workspace));
   CSSHIP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, s,
-                     reinterpret_cast<const float*>(workspace), slices, (int64_t)N, N, (int64_t)N, alpha, nullptr,
-                     nullptr, (int64_t)0, out);
-  CSSHIP_CHECK_LAUNCH();
-  return CSSHIP_OK;
+  return launch_slab_reduce(reinterpret_cast<const float*>(workspace), slices, (int64_t)N, N, (int64_t)N, alpha, nullptr,
+                            nullptr, 0, out, s);
 }

@@ -2,7 +2,8 @@
 
 ``validate`` (forward only) runs entirely on the HIP path.  ``train_one_epoch`` keeps the
 reference's step order (forward, backward, clip, step, zero_grad, scheduler).  Forward and the
-PIT backward are HIP kernels; the encoder backward is the stop-gap of css_amd/autograd.py
+PIT backward are HIP kernels; the Conformer (d_model 256) backward is explicit HIP kernels too, other models use
+the torch-autograd stop-gap of css_amd/autograd.py
 (PyTorch-ROCm restatement used only to back-propagate) until the backward kernels exist.
 In a multi-GPU job (torch.distributed initialised) gradients are summed across ranks with one
 flat-bucket all-reduce over RCCL before clipping (css_amd/parallel.py), replacing the

@@ -1,0 +1,51 @@
+"""Training-step timing at the headline shape (Conformer-base, 32 x 400 frames): HIP forward + PIT + explicit HIP
+backward (+ Adam), and the torch-autograd stop-gap for comparison.  Usage: python tools/bench_train.py [--twin]"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from css_amd.models import MODELS  # noqa: E402
+from css_amd.objectives import OBJECTIVES  # noqa: E402
+from css_amd.utils import synthetic as syn  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--twin", action="store_true")
+ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--blocks", type=int, default=16)
+a = ap.parse_args()
+dev = "cuda"
+conf = dict(attention_dim=256, attention_heads=4, linear_units=1024, num_blocks=a.blocks, kernel_size=33,
+            dropout_rate=0.1, relative_pos_emb=True)
+m = MODELS["Conformer"](257, 257, 2, 1, conf)
+m.load_state_dict(syn.fill_state_dict(syn.conformer_shapes(num_blocks=a.blocks), 0))
+m = m.to(dev).train()
+m.force_twin_backward = a.twin
+obj = OBJECTIVES["MSE"].build_objective({})
+opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+g = torch.Generator().manual_seed(0)
+batch = {k: (torch.rand((32, 400, 257), generator=g) * s).to(dev) for k, s in (("mix", 1.0), ("source1", 0.5), ("source2", 0.5))}
+
+
+def step():
+    opt.zero_grad(set_to_none=True)
+    loss = obj(m, batch, device=dev)
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(m.parameters(), 5.0)
+    opt.step()
+    return loss
+
+
+for _ in range(2):
+    step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(a.steps):
+    loss = step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / a.steps
+print(f"train step ({'twin' if a.twin else 'hip'} backward, {a.blocks} blocks): {dt * 1e3:.1f} ms  "
+      f"= {12800 / dt / 1e6:.3f} M frames/s   loss {float(loss):.5f}   peak mem {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB")
