@@ -24,10 +24,6 @@ class ConvWeights(C.Structure):
                                   "bn_mean", "bn_var", "pw2_w", "pw2_b")]
 
 
-class ConvGrads(C.Structure):
-    _fields_ = [(n, _p) for n in ("ln_g", "ln_b", "pw1_w", "pw1_b", "dw_w", "dw_b", "bn_g", "bn_b", "pw2_w", "pw2_b")]
-
-
 class FfnWeights(C.Structure):
     _fields_ = [(n, _p) for n in ("ln_g", "ln_b", "w1", "b1", "w2", "b2")]
 
@@ -102,8 +98,8 @@ SIGNATURES = {
     "csship_relpos_softmax": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p]),
     "csship_relpos_softmax_bwd": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _i32, _p]),
     "csship_convmod_bwd_workspace": (_sz, [_i32, _i32, _i32]),
-    "csship_convmod_bwd": (_i32, [_p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _p, _p, C.POINTER(ConvGrads),
-                                   _p, _sz, _p]),
+    "csship_convmod_bwd": (_i32, [_p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
+    "csship_pack_weight": (_i32, [_p, _i32, _i32, _i64, _f32, _p, _i64, _p, _i32, _p]),
     "csship_conformer_workspace": (_sz, [C.POINTER(ConformerWeights), _i32, _i32]),
     "csship_conformer_forward": (_i32, [C.POINTER(ConformerWeights), _p, _i64, _i32, _i32, _p, _i64, _p, _p, _sz, _p]),
 }

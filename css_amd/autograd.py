@@ -72,10 +72,8 @@ class ConformerTrain(torch.autograd.Function):
         f = f.contiguous()
         mean, rinv = ops.mvn_stats(f)
         S = {"f": f, "mean": mean, "rinv": rinv, "layers": []}
-        we = enc.embed[0].weight.detach()
         Kp = (F + 7) // 8 * 8
-        we_bf = torch.zeros((D, Kp), dtype=BF, device=f.device)
-        we_bf[:, :F] = we
+        we_bf, _ = ob.pack_weight(enc.embed[0].weight.detach(), want_row_major=True)
         fn = ob.mvn_apply(f, mean, rinv, Kp)
         e = ob.bgemm(fn, we_bf, bias=enc.embed[0].bias.detach())
         _, x = ops.layernorm_relu(e, enc.embed[1].weight.detach(), enc.embed[1].bias.detach())
@@ -87,22 +85,27 @@ class ConformerTrain(torch.autograd.Function):
             L = {}
 
             def ffn(m, xin, tag):
-                w1, w2 = m.net[0].weight.detach(), m.net[3].weight.detach()
-                L[tag] = (xin, w1.to(BF), w2.to(BF))
-                return ops.ffn_fused(xin, (m.layer_norm.weight.detach(), m.layer_norm.bias.detach()), ops.pack_frag(w1),
-                                     m.net[0].bias.detach(), ops.pack_frag(w2), m.net[3].bias.detach(), FF, 0.5)
+                w1_bf, w1p = ob.pack_weight(m.net[0].weight.detach(), want_row_major=True, want_frag=True)
+                w2_bf, w2p = ob.pack_weight(m.net[3].weight.detach(), want_row_major=True, want_frag=True)
+                L[tag] = (xin, w1_bf, w2_bf)
+                return ops.ffn_fused(xin, (m.layer_norm.weight.detach(), m.layer_norm.bias.detach()), w1p,
+                                     m.net[0].bias.detach(), w2p, m.net[3].bias.detach(), FF, 0.5)
 
             x1 = ffn(lay.feed_forward_in, x, "ffn_in")
             a = lay.self_attn
             scale = a.d_k ** -0.5
-            wqkv = torch.cat([a.linear_q.weight.detach() * scale, a.linear_k.weight.detach(), a.linear_v.weight.detach()], 0)
+            wqkv_bf = torch.empty((3 * D, D), dtype=BF, device=f.device)
+            wqkv_p = torch.empty(3 * D * D, dtype=BF, device=f.device)
+            for i, lin in enumerate((a.linear_q, a.linear_k, a.linear_v)):
+                ob.pack_weight(lin.weight.detach(), scale=scale if i == 0 else 1.0, row_major=wqkv_bf, frag=wqkv_p,
+                               row0=i * D)
             bqkv = torch.cat([a.linear_q.bias.detach() * scale, a.linear_k.bias.detach(), a.linear_v.bias.detach()], 0)
-            wo = a.linear_out.weight.detach()
-            qkv = ops.panel_linear(x1, ops.pack_frag(wqkv), bqkv, 3 * D,
+            wo_bf, wo_p = ob.pack_weight(a.linear_out.weight.detach(), want_row_major=True, want_frag=True)
+            qkv = ops.panel_linear(x1, wqkv_p, bqkv, 3 * D,
                                    ln=(a.layer_norm.weight.detach(), a.layer_norm.bias.detach()), out_bf16=True)
             ao = ops.mha_relpos(qkv.view(B, T, 3 * D), pe_pack, H).view(M, D)
-            x2 = ops.panel_linear(ao, ops.pack_frag(wo), a.linear_out.bias.detach(), D, residual=x1)
-            L["mha"] = (x1, qkv, ao, wqkv.to(BF), wo.to(BF), scale)
+            x2 = ops.panel_linear(ao, wo_p, a.linear_out.bias.detach(), D, residual=x1)
+            L["mha"] = (x1, qkv, ao, wqkv_bf, wo_bf, scale)
             c = lay.conv
             W = {"ln_g": c.layer_norm.weight.detach(), "ln_b": c.layer_norm.bias.detach(),
                  "pw1_w": c.pw_conv_1.weight.detach().view(2), "pw1_b": c.pw_conv_1.bias.detach(),
@@ -123,11 +126,11 @@ class ConformerTrain(torch.autograd.Function):
             L["x4"] = x4
             S["layers"].append(L)
         n_out = model.linear.out_features
-        wh = model.linear.weight.detach()
+        wh_bf, wh_p = ob.pack_weight(model.linear.weight.detach(), want_row_major=True, want_frag=True)
         ld = (n_out + 3) // 4 * 4
         masks = torch.empty((M, ld), dtype=torch.float32, device=f.device)[:, :n_out]
-        ops.panel_linear(x, ops.pack_frag(wh), model.linear.bias.detach(), n_out, relu=True, out=masks)
-        S.update(e=e, x_enc=x, masks=masks, wh_bf=wh.to(BF))
+        ops.panel_linear(x, wh_p, model.linear.bias.detach(), n_out, relu=True, out=masks)
+        S.update(e=e, x_enc=x, masks=masks, wh_bf=wh_bf)
         ctx.model, ctx.S = model, S
         return masks.view(B, T, n_out)
 
@@ -153,6 +156,8 @@ class ConformerTrain(torch.autograd.Function):
             dm = buf
         dx, dw, db = bw.head_bwd(dm, masks, S["x_enc"], S["wh_bf"])
         put(model.linear.weight, dw), put(model.linear.bias, db)
+        window = bw.relpos_window(S["pe_bf"], T, enc.pos_emb.maxlen)
+        dwin = None
         for lay, L in zip(reversed(list(enc.encoders)), reversed(S["layers"])):
             dx, dg, dbeta = ob.layernorm_bwd(L["x4"], dx, lay.layer_norm.weight.detach(), lay.layer_norm.bias.detach())
             put(lay.layer_norm.weight, dg), put(lay.layer_norm.bias, dbeta)
@@ -179,15 +184,18 @@ class ConformerTrain(torch.autograd.Function):
             x1, qkv, ao, wqkv_bf, wo_bf, scale = L["mha"]
             a = lay.self_attn
             dx, g = bw.mha_bwd(x1, dx, qkv.view(B, T, 3 * D), ao, a.layer_norm.weight.detach(),
-                               a.layer_norm.bias.detach(), wqkv_bf, wo_bf, S["pe_bf"], H, scale)
-            dg, dbeta, dwqkv, dbqkv, dwo, dbo, dpe = g
+                               a.layer_norm.bias.detach(), wqkv_bf, wo_bf, S["pe_bf"], H, scale, window=window)
+            dg, dbeta, dwqkv, dbqkv, dwo, dbo, dw_l = g
+            dwin = dw_l if dwin is None else dwin.add_(dw_l)
             put(a.layer_norm.weight, dg), put(a.layer_norm.bias, dbeta)
             for i, lin in enumerate((a.linear_q, a.linear_k, a.linear_v)):
                 put(lin.weight, dwqkv[i * D:(i + 1) * D]), put(lin.bias, dbqkv[i * D:(i + 1) * D])
             put(a.linear_out.weight, dwo), put(a.linear_out.bias, dbo)
-            put(enc.pos_emb.pe_k.weight, dpe)
             dx = ffn_b(lay.feed_forward_in, "ffn_in", dx)
             L.clear()
+        dpe = torch.zeros_like(enc.pos_emb.pe_k.weight)
+        dpe.index_add_(0, window[1], dwin[:2 * T - 1])
+        put(enc.pos_emb.pe_k.weight, dpe)
         dwe, dbe, dg, dbeta = bw.embed_bwd(S["f"], dx, S["mean"], S["rinv"], S["we_bf"], enc.embed[0].bias.detach(),
                                            enc.embed[1].weight.detach(), enc.embed[1].bias.detach(), e=S["e"])
         put(enc.embed[0].weight, dwe), put(enc.embed[0].bias, dbe)

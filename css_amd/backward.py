@@ -52,7 +52,7 @@ def relpos_window(pe_table_bf, T, maxlen):
     return win, idx
 
 
-def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000):
+def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000, window=None):
     """Backward of o = softmax(q k^T + q pe[i-j]^T) v (conformer.py:229-253; q already carries 1/sqrt(d_k)).
 
     qkv: bf16 [B, T, 3*H*64]; dao: bf16 [B*T, H*64] (gradient of the head-concatenated output).
@@ -63,7 +63,7 @@ def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000):
     H = n_head
     g = qkv.view(B, T, 3, H, 64)
     q, k, v = (g[:, :, i].permute(0, 2, 1, 3) for i in range(3))  # [B,H,T,64] strided views
-    win, idx = relpos_window(pe_table_bf, T, maxlen)
+    win, idx = relpos_window(pe_table_bf, T, maxlen) if window is None else window
     W = win.shape[0]
     s = ob.bgemm(q, k)                                   # q k^T            [B,H,T,T]
     rel = ob.bgemm(q, win[None, None])                   # q pe_window^T    [B,H,T,W]
@@ -79,21 +79,24 @@ def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000):
     ob.bgemm(dsk.permute(0, 2, 1, 3), win[None, None], b_kmajor=True, add=dq1, out=dq)   # + dS_skew pe_window
     q_rows = g[:, :, 0].reshape(B * T * H, 64)                          # rows ordered (b, t, h) like dsk
     dwin = ob.bgemm(dsk.view(B * T * H, W), q_rows, a_kmajor=True, b_kmajor=True)        # [W, 64]
+    if window is not None:
+        return dqkv, dwin  # the caller accumulates window gradients over the layers and scatters once
     dpe = torch.zeros((2 * maxlen, 64), dtype=torch.float32, device=qkv.device)
     dpe.index_add_(0, idx, dwin[:2 * T - 1])
     return dqkv, dpe
 
 
-def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_scale=0.125):
+def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_scale=0.125, window=None):
     """out = x + attention(LN(x)) @ wo^T + bo  (conformer.py:213-254,356).
 
     wqkv_bf holds the q rows already multiplied by q_scale (as the forward uses them); the returned dwqkv / dbqkv are
-    gradients of the UNSCALED parameters.  Returns dx and (ln_g, ln_b, wqkv, bqkv, wo, bo, pe) gradients.
+    gradients of the UNSCALED parameters.  Returns dx and (ln_g, ln_b, wqkv, bqkv, wo, bo, pe) gradients; with
+    ``window`` (from relpos_window) the last one is the gradient of the window rows instead of the whole table.
     """
     D = x.shape[1]
     dao, dwo, dbo = linear_bwd(dy, ao, wo_bf, dx_bf16=True)
     B = qkv.shape[0]
-    dqkv, dpe = mha_core_bwd(qkv, dao, pe_table_bf, n_head)
+    dqkv, dpe = mha_core_bwd(qkv, dao, pe_table_bf, n_head, window=window)
     dq2 = dqkv.view(-1, 3 * D)
     a, _ = ops.layernorm(x, ln_g, ln_b)
     dw = torch.empty((3 * D, D), dtype=torch.float32, device=x.device)

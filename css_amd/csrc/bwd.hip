@@ -148,7 +148,45 @@ __global__ __launch_bounds__(256) void relpos_softmax_bwd_kernel(const unsigned 
   }
 }
 
+// ---- weight shadows: f32 [R, K] (row stride lds) -> bf16 row-major [.., ld_rm] and/or MFMA fragment order, rows
+// scaled by `scale`; one thread per 8 consecutive k.  Fragment layout as in include/csship.h:
+// block(rt, ks)[16*g + m][j] = W[16*rt + m][32*ks + 8*g + j], rows beyond R are zero.
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, int R, int K, int64_t lds,
+                                                          float scale, unsigned short* __restrict__ rm, int64_t ld_rm,
+                                                          unsigned short* __restrict__ frag, int row0, int Kp) {
+  const int kc = Kp / 8;  // chunks per (padded) row
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int Rp = (R + 15) / 16 * 16;
+  if (i >= (int64_t)Rp * kc) return;
+  const int r = (int)(i / kc), k = (int)(i % kc) * 8;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (r < R && k + e < K) ? w[(int64_t)r * lds + k + e] * scale : 0.f;
+  const uint4 o = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+  if (rm && r < R && k < ld_rm) *reinterpret_cast<uint4*>(rm + (int64_t)(row0 + r) * ld_rm + k) = o;
+  if (frag) {
+    const int rr = row0 + r;
+    const int64_t blk = (int64_t)(rr / 16) * (Kp / 32) + k / 32;
+    *reinterpret_cast<uint4*>(frag + (blk * 64 + ((k % 32) / 8) * 16 + (rr % 16)) * 8) = o;
+  }
+}
+
 }  // namespace
+
+extern "C" int csship_pack_weight(const float* w, int32_t R, int32_t K, int64_t ld_w, float scale,
+                                  uint16_t* row_major_bf16, int64_t ld_row_major, uint16_t* frag_packed_bf16,
+                                  int32_t dst_row0, csship_stream_t stream) {
+  if (!w || (!row_major_bf16 && !frag_packed_bf16)) return CSSHIP_ENULL;
+  if (R <= 0 || K <= 0 || ld_w < K || dst_row0 < 0) return CSSHIP_EBADSHAPE;
+  const int Kp = frag_packed_bf16 ? (K + 31) / 32 * 32 : (K + 7) / 8 * 8;
+  if (row_major_bf16 && (ld_row_major < Kp || (ld_row_major % 8) != 0 || !aligned16(row_major_bf16))) return CSSHIP_EALIGN;
+  if (frag_packed_bf16 && ((dst_row0 % 16) != 0 || !aligned16(frag_packed_bf16))) return CSSHIP_EALIGN;
+  const int64_t n = (int64_t)((R + 15) / 16 * 16) * (Kp / 8);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), w, R, K, ld_w,
+                     scale, row_major_bf16, ld_row_major, frag_packed_bf16, dst_row0, Kp);
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
 
 extern "C" size_t csship_layernorm_bwd_workspace(int64_t M, int32_t D) {
   return (size_t)((M + 63) / 64) * 2 * D * sizeof(float);

@@ -432,32 +432,31 @@ BwdLayout bwd_layout(int B, int T, int D, int TT) {
   L.nblk = ((T + TT - 1) / TT) * B * 2;
   const size_t p = (size_t)L.nwg_rows * (2 * D + 4) > (size_t)L.nblk * 34 * D ? (size_t)L.nwg_rows * (2 * D + 4)
                                                                              : (size_t)L.nblk * 34 * D;
-  L.dc = 0; L.dg = n; L.part = 2 * n; L.sums = 2 * n + p; L.total = L.sums + 34 * (size_t)D;
+  L.dc = 0; L.dg = n; L.part = 2 * n; L.sums = 2 * n + p; L.total = L.sums;
   return L;
 }
 
 template <int D, int TT>
 int run_bwd(const float* x, const float* dy, const csship_conv_weights& w, int B, int T, const float* fwd_ws, float* dx,
-            const csship_conv_grads& g, float* ws, hipStream_t s) {
+            float* grads, float* ws, hipStream_t s) {
   const BwdLayout L = bwd_layout(B, T, D, TT);
   const int64_t M = (int64_t)B * T;
   const size_t n = (size_t)M * D;
   const float* z = fwd_ws;
   const int fwd_nblk = ((T + TT - 1) / TT) * B * 2;
   const float* stats = fwd_ws + n + (size_t)fwd_nblk * 2 * D;
-  float *dc = ws + L.dc, *dg = ws + L.dg, *part = ws + L.part, *sums = ws + L.sums;
+  float *dc = ws + L.dc, *dg = ws + L.dg, *part = ws + L.part;
+  // grads layout (CSSHIP_CONV_GRADS_*): [bn_b D | bn_g D | pw2_w 1 | pw2_b 1 | pad 2][dw_w 33*D | dw_b D][ln_g D | ln_b D | pw1_w 2 | pw1_b 2]
+  float* gA = grads;
+  float* gB = grads + 2 * D + 4;
+  float* gC = gB + 34 * D;
   // pass A
   hipLaunchKernelGGL((conv_bn_bwd_stats_kernel<D>), dim3(L.nwg_rows), dim3(D), 0, s, dy, z, stats, w.pw2_w, M, 64, part);
   CSSHIP_CHECK_LAUNCH();
-  int rc = launch_slab_reduce(part, L.nwg_rows, 2 * D + 2, 2 * D + 2, 2 * D + 2, 1.f, nullptr, nullptr, 0, sums, s);
+  int rc = launch_slab_reduce(part, L.nwg_rows, 2 * D + 2, 2 * D + 2, 2 * D + 2, 1.f, nullptr, nullptr, 0, gA, s);
   if (rc) return rc;
-  if (hipMemcpyAsync(g.bn_b, sums, D * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess ||
-      hipMemcpyAsync(g.bn_g, sums + D, D * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess ||
-      hipMemcpyAsync(g.pw2_w, sums + 2 * D, sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess ||
-      hipMemcpyAsync(g.pw2_b, sums + 2 * D + 1, sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
-    return CSSHIP_ELAUNCH;
   // pass A'
-  hipLaunchKernelGGL(conv_bn_bwd_apply_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, dy, z, stats, sums,
+  hipLaunchKernelGGL(conv_bn_bwd_apply_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, dy, z, stats, gA,
                      w.pw2_w, 1.f / (float)M, n / 4, D, dc);
   CSSHIP_CHECK_LAUNCH();
   // pass B1 / B2 on the forward's tile structure
@@ -468,23 +467,13 @@ int run_bwd(const float* x, const float* dy, const csship_conv_weights& w, int B
   ConvArgs a2{x, nullptr, w, nullptr, nullptr, part, dc, B, T, nullptr};
   hipLaunchKernelGGL((convmod_kernel<D, TT, 33, 2, false>), grid, dim3(2 * D), 0, s, a2);
   CSSHIP_CHECK_LAUNCH();
-  rc = launch_slab_reduce(part, L.nblk, (int64_t)34 * D, 34 * D, (int64_t)34 * D, 1.f, nullptr, nullptr, 0, sums, s);
+  rc = launch_slab_reduce(part, L.nblk, (int64_t)34 * D, 34 * D, (int64_t)34 * D, 1.f, nullptr, nullptr, 0, gB, s);
   if (rc) return rc;
-  if (hipMemcpyAsync(g.dw_w, sums, (size_t)33 * D * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess ||
-      hipMemcpyAsync(g.dw_b, sums + 33 * D, D * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
-    return CSSHIP_ELAUNCH;
   // pass C
   hipLaunchKernelGGL((glu_ln_bwd_kernel<D / 256>), dim3(L.nwg_rows), dim3(256), 0, s, x, dg, dy, w.ln_g, w.ln_b, w.pw1_w,
                      w.pw1_b, M, 64, dx, part);
   CSSHIP_CHECK_LAUNCH();
-  rc = launch_slab_reduce(part, L.nwg_rows, 2 * D + 4, 2 * D + 4, 2 * D + 4, 1.f, nullptr, nullptr, 0, sums, s);
-  if (rc) return rc;
-  if (hipMemcpyAsync(g.ln_g, sums, D * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess ||
-      hipMemcpyAsync(g.ln_b, sums + D, D * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess ||
-      hipMemcpyAsync(g.pw1_w, sums + 2 * D, 2 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess ||
-      hipMemcpyAsync(g.pw1_b, sums + 2 * D + 2, 2 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
-    return CSSHIP_ELAUNCH;
-  return CSSHIP_OK;
+  return launch_slab_reduce(part, L.nwg_rows, 2 * D + 4, 2 * D + 4, 2 * D + 4, 1.f, nullptr, nullptr, 0, gC, s);
 }
 
 }  // namespace
@@ -530,13 +519,10 @@ extern "C" size_t csship_convmod_bwd_workspace(int32_t B, int32_t T, int32_t D) 
 
 extern "C" int csship_convmod_bwd(const float* x, const float* dy, const csship_conv_weights* w, int32_t B, int32_t T,
                                   int32_t D, int32_t kernel_size, const void* fwd_workspace, float* dx,
-                                  const csship_conv_grads* grads, void* workspace, size_t workspace_bytes,
+                                  float* grads, void* workspace, size_t workspace_bytes,
                                   csship_stream_t stream) {
   if (!x || !dy || !w || !fwd_workspace || !dx || !grads || !workspace) return CSSHIP_ENULL;
   if (!w->ln_g || !w->ln_b || !w->pw1_w || !w->pw1_b || !w->dw_w || !w->dw_b || !w->pw2_w) return CSSHIP_ENULL;
-  if (!grads->ln_g || !grads->ln_b || !grads->pw1_w || !grads->pw1_b || !grads->dw_w || !grads->dw_b || !grads->bn_g ||
-      !grads->bn_b || !grads->pw2_w || !grads->pw2_b)
-    return CSSHIP_ENULL;
   if (B <= 0 || T <= 0 || B > 65535) return CSSHIP_EBADSHAPE;
   if (kernel_size != 33 || (D != 256 && D != 512)) return CSSHIP_EUNSUPPORTED;
   if (!aligned16(x) || !aligned16(dy) || !aligned16(dx) || !aligned16(fwd_workspace) || !aligned16(workspace))
@@ -544,6 +530,6 @@ extern "C" int csship_convmod_bwd(const float* x, const float* dy, const csship_
   if (workspace_bytes < csship_convmod_bwd_workspace(B, T, D)) return CSSHIP_EWORKSPACE;
   const float* fw = reinterpret_cast<const float*>(fwd_workspace);
   float* ws = reinterpret_cast<float*>(workspace);
-  if (D == 256) return run_bwd<256, TT256>(x, dy, *w, B, T, fw, dx, *grads, ws, as_stream(stream));
-  return run_bwd<512, TT512>(x, dy, *w, B, T, fw, dx, *grads, ws, as_stream(stream));
+  if (D == 256) return run_bwd<256, TT256>(x, dy, *w, B, T, fw, dx, grads, ws, as_stream(stream));
+  return run_bwd<512, TT512>(x, dy, *w, B, T, fw, dx, grads, ws, as_stream(stream));
 }

@@ -168,9 +168,6 @@ def relpos_softmax_bwd(p, dp, T, W):
     return ds, dsk
 
 
-CONV_GRAD_FIELDS = ("ln_g", "ln_b", "pw1_w", "pw1_b", "dw_w", "dw_b", "bn_g", "bn_b", "pw2_w", "pw2_b")
-
-
 def convmod_bwd(x, dy, weights, fwd_ws, kernel_size=33):
     """Backward of ops.convmod(x, weights, batch_stats=True).  x, dy f32 [B,T,D]; fwd_ws: that call's workspace.
     Returns dx and a dict of f32 gradients keyed like the weights dict (dw_w as [k, D])."""
@@ -178,19 +175,32 @@ def convmod_bwd(x, dy, weights, fwd_ws, kernel_size=33):
     _need(x, torch.float32, "x"), _need(dy, torch.float32, "dy")
     x, dy = x.contiguous(), dy.contiguous()
     B, T, D = x.shape
-    sizes = {"ln_g": D, "ln_b": D, "pw1_w": 2, "pw1_b": 2, "dw_w": kernel_size * D, "dw_b": D, "bn_g": D, "bn_b": D,
-             "pw2_w": 1, "pw2_b": 1}
-    flat = torch.empty(sum((n + 3) // 4 * 4 for n in sizes.values()), dtype=torch.float32, device=x.device)
-    grads, off = {}, 0
-    for k in CONV_GRAD_FIELDS:
-        grads[k] = flat[off:off + sizes[k]]
-        off += (sizes[k] + 3) // 4 * 4
-    cg = _lib.ConvGrads(**{k: C.c_void_p(grads[k].data_ptr()) for k in CONV_GRAD_FIELDS})
+    flat = torch.empty(38 * D + 8, dtype=torch.float32, device=x.device)
     cw = conv_weights_struct(weights)
     dx = torch.empty_like(x)
     nws = lib().csship_convmod_bwd_workspace(B, T, D)
     ws = _workspace(nws, x.device)
     check(lib().csship_convmod_bwd(_ptr(x), _ptr(dy), C.byref(cw), B, T, D, kernel_size, _ptr(fwd_ws), _ptr(dx),
-                                   C.byref(cg), _ptr(ws), nws, _stream()))
-    grads["dw_w"] = grads["dw_w"].view(kernel_size, D)
+                                   _ptr(flat), _ptr(ws), nws, _stream()))
+    o = 2 * D + 4
+    grads = {"bn_b": flat[:D], "bn_g": flat[D:2 * D], "pw2_w": flat[2 * D:2 * D + 1], "pw2_b": flat[2 * D + 1:2 * D + 2],
+             "dw_w": flat[o:o + kernel_size * D].view(kernel_size, D), "dw_b": flat[o + 33 * D:o + 34 * D],
+             "ln_g": flat[o + 34 * D:o + 35 * D], "ln_b": flat[o + 35 * D:o + 36 * D],
+             "pw1_w": flat[o + 36 * D:o + 36 * D + 2], "pw1_b": flat[o + 36 * D + 2:o + 36 * D + 4]}
     return dx, grads
+
+
+def pack_weight(w, *, scale=1.0, row_major=None, frag=None, row0=0, want_row_major=False, want_frag=False):
+    """One-launch bf16 shadows of a Linear weight w f32 [R, K]: row-major (rows row0.. of ``row_major``) and / or MFMA
+    fragment order (rows row0.. of ``frag``).  Allocates what is asked for and not given.  Returns (row_major, frag)."""
+    _need(w, torch.float32, "w")
+    R, K = w.shape
+    if w.stride(1) != 1:
+        w = w.contiguous()
+    if want_row_major and row_major is None:
+        row_major = torch.empty((R, (K + 7) // 8 * 8), dtype=torch.bfloat16, device=w.device)
+    if want_frag and frag is None:
+        frag = torch.empty(((R + 15) // 16 * 16) * ((K + 31) // 32 * 32), dtype=torch.bfloat16, device=w.device)
+    check(lib().csship_pack_weight(_ptr(w), R, K, w.stride(0), float(scale), _ptr(row_major),
+                                   row_major.stride(0) if row_major is not None else 0, _ptr(frag), row0, _stream()))
+    return row_major, frag

@@ -379,16 +379,23 @@ int csship_relpos_softmax_bwd(const uint16_t* p_bf16, int64_t ld_p, const float*
 /* ---- csship_convmod_bwd (css_amd/csrc/convmod.hip): backward of csship_convmod run with bn_mode = 1.
  * fwd_workspace is that forward call's workspace, untouched since (it holds the pre-BatchNorm activations and the
  * batch statistics: after the call its last 4*D floats are [scale | shift | batch mean | biased batch variance]).
- * dx = dy + (gradient through the module); parameter gradients go to the f32 buffers named in grads, laid out like
- * the forward's weight struct: dw_w is [k, D], pw1_w / pw1_b hold 2 floats, pw2_w / pw2_b 1. */
-typedef struct {
-  float *ln_g, *ln_b, *pw1_w, *pw1_b, *dw_w, *dw_b, *bn_g, *bn_b, *pw2_w, *pw2_b;
-} csship_conv_grads;
+ * dx = dy + (gradient through the module).  The parameter gradients are written to ONE f32 buffer `grads` of
+ * 38*D + 8 floats, laid out (offsets in floats):
+ *   0: bn_b[D]   D: bn_g[D]   2D: pw2_w   2D+1: pw2_b   (2D+2, 2D+3 unused)
+ *   2D+4: dw_w[k=33][D]   35D+4: dw_b[D]
+ *   36D+4: ln_g[D]   37D+4: ln_b[D]   38D+4: pw1_w[2]   38D+6: pw1_b[2] */
 size_t csship_convmod_bwd_workspace(int32_t B, int32_t T, int32_t D);
 int csship_convmod_bwd(const float* x, const float* dy, const csship_conv_weights* w, int32_t B, int32_t T,
                        int32_t D, int32_t kernel_size, const void* fwd_workspace, float* dx,
-                       const csship_conv_grads* grads, void* workspace, size_t workspace_bytes,
-                       csship_stream_t stream);
+                       float* grads, void* workspace, size_t workspace_bytes, csship_stream_t stream);
+
+/* Weight shadows for one Linear in ONE launch: f32 w[R, K] (row stride ld_w), every element times `scale`, written
+ * as bf16 row-major rows dst_row0.. of a [.., ld_row_major] matrix (optional; the kmajor operand of csship_bgemm)
+ * and/or in MFMA fragment order (optional; rows dst_row0.. of the packed matrix, dst_row0 % 16 == 0, K rounded up to
+ * 32, rows rounded up to 16 with zeros).  Fused q/k/v weights are three calls with dst_row0 = 0, D, 2D. */
+int csship_pack_weight(const float* w, int32_t R, int32_t K, int64_t ld_w, float scale,
+                       uint16_t* row_major_bf16, int64_t ld_row_major, uint16_t* frag_packed_bf16,
+                       int32_t dst_row0, csship_stream_t stream);
 
 #ifdef __cplusplus
 }
