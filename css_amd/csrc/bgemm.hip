@@ -246,13 +246,27 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x,
   const int c = blockIdx.x * 64 + lane;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_wg, r1 = min(M, r0 + rows_per_wg);
   float s = 0.f;
-  if (c < N) {
+  if (c < N) {  // 8 independent loads in flight per lane
     if (f32) {
-      const float* p = reinterpret_cast<const float*>(x);
-      for (int64_t r = r0 + w; r < r1; r += 4) s += p[r * ld + c];
+      const float* p = reinterpret_cast<const float*>(x) + c;
+      int64_t r = r0 + w;
+      for (; r + 28 < r1; r += 32) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = p[(r + 4 * i) * ld];
+        s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+      }
+      for (; r < r1; r += 4) s += p[r * ld];
     } else {
-      const unsigned short* p = reinterpret_cast<const unsigned short*>(x);
-      for (int64_t r = r0 + w; r < r1; r += 4) s += bf2f(p[r * ld + c]);
+      const unsigned short* p = reinterpret_cast<const unsigned short*>(x) + c;
+      int64_t r = r0 + w;
+      for (; r + 28 < r1; r += 32) {
+        unsigned short v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = p[(r + 4 * i) * ld];
+        s += ((bf2f(v[0]) + bf2f(v[1])) + (bf2f(v[2]) + bf2f(v[3]))) + ((bf2f(v[4]) + bf2f(v[5])) + (bf2f(v[6]) + bf2f(v[7])));
+      }
+      for (; r < r1; r += 4) s += bf2f(p[r * ld]);
     }
   }
   red[w][lane] = s;
@@ -335,7 +349,7 @@ extern "C" int csship_bgemm(const void* A, const void* B, void* C, const float* 
 }
 
 extern "C" size_t csship_colsum_workspace(int64_t M, int32_t N) {
-  const int slices = (int)((M + 255) / 256);
+  const int slices = (int)((M + 127) / 128);
   return (size_t)slices * N * sizeof(float);
 }
 
@@ -343,11 +357,11 @@ extern "C" int csship_colsum(const void* x, int32_t x_is_f32, int64_t M, int32_t
                              void* workspace, size_t workspace_bytes, csship_stream_t stream) {
   if (!x || !out || !workspace) return CSSHIP_ENULL;
   if (M <= 0 || N <= 0 || ld < N) return CSSHIP_EBADSHAPE;
-  const int slices = (int)((M + 255) / 256);
+  const int slices = (int)((M + 127) / 128);
   if (slices > 65535) return CSSHIP_EBADSHAPE;
   if (workspace_bytes < (size_t)slices * N * sizeof(float)) return CSSHIP_EWORKSPACE;
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, slices), dim3(256), 0, s, x, x_is_f32, M, N, ld, 256,
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, slices), dim3(256), 0, s, x, x_is_f32, M, N, ld, 128,
                      reinterpret_cast<float*>(workspace));
   CSSHIP_CHECK_LAUNCH();
   return launch_slab_reduce(reinterpret_cast<const float*>(workspace), slices, (int64_t)N, N, (int64_t)N, alpha, nullptr,

@@ -1,9 +1,13 @@
 // 256-point complex FFT on one 64-lane wave (4 points per lane), shared by the STFT and iSTFT kernels.
-// Lane l holds z[l], z[l+64], z[l+128], z[l+192]: one radix-4 butterfly in registers, then four independent
-// 64-point FFTs ACROSS the lanes as 6 radix-2 DIF stages.  The partner exchange lane ^ h is done in the
-// VALU/crossbar without LDS addresses: DPP quad_perm (h = 1, 2), row_half_mirror + quad reverse (h = 4),
-// row_ror:8 (h = 8) and the gfx950 v_permlane16_swap / v_permlane32_swap (h = 16, 32).
-// Output: lane l, register r holds Z[4*brev6(l) + r].
+// Radix-4 decimation in frequency, 4 stages, every butterfly in registers.  With n = n0 + 4 n1 + 16 n2 + 64 n3 and
+// k = k0 + 4 k1 + 16 k2 + 64 k3, lane l starts as (n0, n1, n2) holding register q = n3, i.e. z[l + 64 q].  Between
+// stages the register index is exchanged with one base-4 digit of the lane index (a 4x4 transpose across 4 lanes):
+//   digit n2 (lane bits 4,5): v_permlane32_swap + v_permlane16_swap = 8 instructions, no LDS, no selects;
+//   digits n1, n0: through a 2 KB per-wave LDS scratch (4 ds_write_b64 + 4 ds_read_b64 each, padded row strides
+//   68 / 65 make both conflict free).
+// 3 twiddle multiplies per stage from the build-time table.  Replaces the earlier radix-4 + 6 radix-2 shuffle stages
+// (~225 -> ~110 VALU instructions per frame for the transform itself).
+// Output: lane l = (k2, k1, k0) (k2 in bits 0-1), register r = k3 holds Z[fft_out_index(l) + 64 r].
 #pragma once
 #include "common.hpp"
 
@@ -59,46 +63,75 @@ DEV void fft_load_consts(int which, int l, float (&win)[8], cplx (&tw1)[4], cplx
   for (int q = 0; q < 4; ++q) twp[q] = {c[26 + 2 * q], c[27 + 2 * q]};
 }
 
-// per-lane twiddles for the 6 cross-lane stages (block size m = 64, 32, ..., 2)
-DEV void fft_stage_twiddles(cplx (&tws)[6], int l) {
-#pragma unroll
-  for (int st = 0; st < 6; ++st) {
-    const int half = 32 >> st, m = 2 * half, p = l & (m - 1);
-    tws[st] = (p >= half) ? cis_pi(-2.f * (float)(p - half) / (float)m) : cplx{1.f, 0.f};
-  }
-}
+DEV int fft_out_index(int l) { return ((l >> 4) & 3) | (l & 12) | ((l & 3) << 4); }  // k0 + 4 k1 + 16 k2
 
-template <int H>
-DEV void fft_stage(cplx (&u)[4], cplx tw, int l) {
-  const float sg = (l & H) ? -1.f : 1.f;  // lower lane: a + b ; upper lane: (a - b) seen from b's side = other - mine
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const float ox = lane_xor<H>(u[r].x, l), oy = lane_xor<H>(u[r].y, l);
-    const cplx d = {fmaf(u[r].x, sg, ox), fmaf(u[r].y, sg, oy)};
-    if constexpr (H == 1) {
-      u[r] = d;  // block size 2: twiddle W_2^0 = 1
-    } else if constexpr (H == 2) {
-      // block size 4: twiddle is 1 except at position 3 (l & 3 == 3), where it is W_4^1 = -i: (x, y) -> (y, -x)
-      const bool rot = (l & 3) == 3;
-      u[r] = {rot ? d.y : d.x, rot ? -d.x : d.y};
-    } else {
-      u[r] = cmul(d, tw);
-    }
-  }
-}
+constexpr int FFT_SCRATCH = 4 * 68;  // cplx entries of per-wave LDS scratch
 
-// z[q] = input point l + 64q; tw1[q] = W256^(l*q)
-DEV void fft256_wave(const cplx (&z)[4], cplx (&u)[4], const cplx (&tw1)[4], const cplx (&tws)[6], int l) {
-  const cplx a02 = {z[0].x + z[2].x, z[0].y + z[2].y}, s02 = {z[0].x - z[2].x, z[0].y - z[2].y};
-  const cplx a13 = {z[1].x + z[3].x, z[1].y + z[3].y}, s13 = {z[1].x - z[3].x, z[1].y - z[3].y};
+DEV void radix4_dif(cplx (&u)[4]) {  // y_k = sum_n x_n (-i)^(n k)
+  const cplx a02 = {u[0].x + u[2].x, u[0].y + u[2].y}, s02 = {u[0].x - u[2].x, u[0].y - u[2].y};
+  const cplx a13 = {u[1].x + u[3].x, u[1].y + u[3].y}, s13 = {u[1].x - u[3].x, u[1].y - u[3].y};
   u[0] = {a02.x + a13.x, a02.y + a13.y};
-  u[1] = cmul({s02.x + s13.y, s02.y - s13.x}, tw1[1]);  // (z0-z2) - i(z1-z3)
-  u[2] = cmul({a02.x - a13.x, a02.y - a13.y}, tw1[2]);
-  u[3] = cmul({s02.x - s13.y, s02.y + s13.x}, tw1[3]);  // (z0-z2) + i(z1-z3)
-  fft_stage<32>(u, tws[0], l);
-  fft_stage<16>(u, tws[1], l);
-  fft_stage<8>(u, tws[2], l);
-  fft_stage<4>(u, tws[3], l);
-  fft_stage<2>(u, tws[4], l);
-  fft_stage<1>(u, tws[5], l);
+  u[1] = {s02.x + s13.y, s02.y - s13.x};  // (x0-x2) - i(x1-x3)
+  u[2] = {a02.x - a13.x, a02.y - a13.y};
+  u[3] = {s02.x - s13.y, s02.y + s13.x};  // (x0-x2) + i(x1-x3)
+}
+
+// 2x2 block transposes between a register pair and one lane bit: a' = [a.low | b.low], b' = [a.high | b.high]
+DEV void swap32(float& a, float& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+  const unsigned r0 = r[0], r1 = r[1];  // extract first: bit_cast applied directly to r[1] reads element 0 (hipcc 7.2)
+  a = __uint_as_float(r0);
+  b = __uint_as_float(r1);
+}
+DEV void swap16(float& a, float& b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  a = __uint_as_float(r0);
+  b = __uint_as_float(r1);
+}
+
+DEV void fft_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// z[q] = input point l + 64q; tw1[q] = W256^(l q); tws[0..2] = W64^((l & 15) k), tws[3..5] = W16^((l & 3) k), k = 1..3;
+// zs: this wave's LDS scratch (FFT_SCRATCH entries).  u may alias z.
+DEV void fft256_wave(const cplx (&z)[4], cplx (&u)[4], const cplx (&tw1)[4], const cplx (&tws)[6], cplx* zs, int l) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) u[q] = z[q];
+  radix4_dif(u);  // over n3 -> k0
+#pragma unroll
+  for (int q = 1; q < 4; ++q) u[q] = cmul(u[q], tw1[q]);
+  // register k0 <-> lane digit n2
+  swap32(u[0].x, u[2].x); swap32(u[0].y, u[2].y); swap32(u[1].x, u[3].x); swap32(u[1].y, u[3].y);
+  swap16(u[0].x, u[1].x); swap16(u[0].y, u[1].y); swap16(u[2].x, u[3].x); swap16(u[2].y, u[3].y);
+  radix4_dif(u);  // over n2 -> k1
+#pragma unroll
+  for (int q = 1; q < 4; ++q) u[q] = cmul(u[q], tws[q - 1]);
+  // register k1 <-> lane digit n1
+#pragma unroll
+  for (int r = 0; r < 4; ++r) zs[r * 68 + l] = u[r];
+  fft_wave_sync();
+  {
+    const int base = ((l >> 2) & 3) * 68 + (l & ~12);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) u[j] = zs[base + 4 * j];
+  }
+  radix4_dif(u);  // over n1 -> k2
+#pragma unroll
+  for (int q = 1; q < 4; ++q) u[q] = cmul(u[q], tws[2 + q]);
+  fft_wave_sync();
+  // register k2 <-> lane digit n0
+#pragma unroll
+  for (int r = 0; r < 4; ++r) zs[r * 65 + l] = u[r];
+  fft_wave_sync();
+  {
+    const int base = (l & 3) * 65 + (l & ~3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) u[j] = zs[base + j];
+  }
+  radix4_dif(u);  // over n0 -> k3
+  fft_wave_sync();
 }

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void ipd_out_kernel(const float* __restrict__ 
 // ------------------------------------------------------------------------------------------ iSTFT
 // One wave per frame: 512-point inverse real FFT as conj(FFT256(conj(Z)))/256 with
 //   Z[k] = Xe[k] + i Xo[k],  Xe = (X[k] + conj X[256-k])/2,  Xo = (X[k] - conj X[256-k])/2 * e^{+2 pi i k/512},
-// using the same in-register radix-4 + 6 shuffle radix-2 DIF stages as the forward STFT.  A workgroup
+// using the same radix-4 wave FFT as the forward STFT (fft.hpp).  A workgroup
 // owns output samples of FBI consecutive hops; it synthesises FBI+1 windowed frames into LDS, overlap-adds
 // and divides by the Hann^2 envelope (torch.istft semantics, center=True: 256 samples trimmed on the left).
 constexpr int FBI = 16;
@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256) void istft_kernel(const float* __restrict__ re
                                                     int64_t length, float* __restrict__ wav) {
   __shared__ float sre[NBIN][FBI + 2], sim[NBIN][FBI + 2];  // spectra of frames t0-1 .. t0+FBI-1, [bin][frame]
   __shared__ __attribute__((aligned(16))) float frames[FBI + 1][512];  // windowed time frames
+  __shared__ __attribute__((aligned(16))) cplx sz[4][FFT_SCRATCH];
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
   const int64_t s = blockIdx.y;
   const int t0 = blockIdx.x * FBI;  // hop index: this workgroup writes padded samples [256*t0, 256*(t0+FBI))
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void istft_kernel(const float* __restrict__ re
   cplx tw1[4], tws[6], twp[4];
   float win[8];
   fft_load_consts(1, l, win, tw1, tws, twp);
-  const int kbr = (int)(__brev((unsigned)l) >> 26);
+  const int ko = fft_out_index(l);
   __syncthreads();
 
   for (int j = w; j < FBI + 1; j += 4) {
@@ -142,15 +143,12 @@ __global__ __launch_bounds__(256) void istft_kernel(const float* __restrict__ re
       z[q] = {E.x - O.y, -(E.y + O.x)};
     }
     cplx u[4];
-    fft256_wave(z, u, tw1, tws, l);
-    // lane l, reg r: FFT(conj Z)[n], n = 4*brev6(l) + r ;  z[n] = conj(.)/256 ;  x[2n] = Re, x[2n+1] = Im
-    float4 o0, o1;
-    o0.x = u[0].x * (1.f / 256.f) * win[0]; o0.y = -u[0].y * (1.f / 256.f) * win[1];
-    o0.z = u[1].x * (1.f / 256.f) * win[2]; o0.w = -u[1].y * (1.f / 256.f) * win[3];
-    o1.x = u[2].x * (1.f / 256.f) * win[4]; o1.y = -u[2].y * (1.f / 256.f) * win[5];
-    o1.z = u[3].x * (1.f / 256.f) * win[6]; o1.w = -u[3].y * (1.f / 256.f) * win[7];
-    *reinterpret_cast<float4*>(&frames[j][8 * kbr]) = o0;
-    *reinterpret_cast<float4*>(&frames[j][8 * kbr + 4]) = o1;
+    fft256_wave(z, u, tw1, tws, sz[w], l);
+    // lane l, reg r: FFT(conj Z)[n], n = ko + 64 r ;  z[n] = conj(.)/256 ;  x[2n] = Re, x[2n+1] = Im
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      *reinterpret_cast<float2*>(&frames[j][2 * (ko + 64 * r)]) =
+          make_float2(u[r].x * (1.f / 256.f) * win[2 * r], -u[r].y * (1.f / 256.f) * win[2 * r + 1]);
   }
   __syncthreads();
   // overlap-add: padded sample p = 256*(t0 + h) + i gets frame (t0+h) [i] and frame (t0+h-1) [i + 256]

@@ -5,10 +5,9 @@
 //   * a workgroup stages (FB+1)*256 contiguous samples in LDS with coalesced 16-byte loads
 //     (consecutive frames overlap by 50 %, so every sample is read from HBM once);
 //   * 512 real points are packed as 256 complex z[n] = x[2n] + i x[2n+1]; lane l holds
-//     z[l], z[l+64], z[l+128], z[l+192]: one radix-4 butterfly in registers, then four
-//     independent 64-point FFTs ACROSS the lanes as 6 radix-2 DIF stages whose partner
-//     exchange is a wavefront shuffle done with DPP / v_permlane{16,32}_swap (fft.hpp): no LDS;
-//   * the bit-reversed result goes through a 2 KB per-wave LDS scratch once, for the
+//     z[l], z[l+64], z[l+128], z[l+192]: four radix-4 stages in registers, the register <-> lane
+//     regrouping between them by v_permlane{32,16}_swap and a 2 KB per-wave LDS scratch (fft.hpp);
+//   * the digit-reversed result goes through the same scratch once more, for the
 //     Z[k] / conj(Z[256-k]) pairing of the real-FFT post-pass and natural-order output;
 //   * magnitude / re / im / phase are written frame-major ([S,T,257]), 64 consecutive bins
 //     per store instruction.
@@ -26,7 +25,7 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ aud
                                                    float* __restrict__ mag, float* __restrict__ re,
                                                    float* __restrict__ im, float* __restrict__ pha) {
   __shared__ __attribute__((aligned(16))) float sx[(FB + 1) * 256];
-  __shared__ __attribute__((aligned(16))) cplx sz[4][256];
+  __shared__ __attribute__((aligned(16))) cplx sz[4][FFT_SCRATCH];
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
   const int64_t s = blockIdx.y;
   const int t0 = blockIdx.x * FB;
@@ -51,7 +50,7 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ aud
   float win[8];
   cplx tw1[4], tws[6], twp[4];
   fft_load_consts(0, l, win, tw1, tws, twp);
-  const int kbr = (int)(__brev((unsigned)l) >> 26);  // 6-bit reversal
+  const int ko = fft_out_index(l);
   __syncthreads();
 
   cplx* zs = sz[w];
@@ -67,13 +66,11 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ aud
       z[q] = {v.x * win[2 * q], v.y * win[2 * q + 1]};
     }
     cplx u[4];
-    fft256_wave(z, u, tw1, tws, l);
-    // lane l, reg r holds Z[4*brev6(l) + r]
-    *reinterpret_cast<float4*>(&zs[4 * kbr]) = make_float4(u[0].x, u[0].y, u[1].x, u[1].y);
-    *reinterpret_cast<float4*>(&zs[4 * kbr + 2]) = make_float4(u[2].x, u[2].y, u[3].x, u[3].y);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    fft256_wave(z, u, tw1, tws, zs, l);
+    // lane l, reg r holds Z[ko + 64 r]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zs[ko + 64 * r] = u[r];
+    fft_wave_sync();
     // real-FFT post pass: X[k] = E + W512^k O, E = (Z[k]+conj Z[256-k])/2, O = -i (Z[k]-conj Z[256-k])/2
     const size_t orow = ((size_t)s * T + t) * NBIN;
 #pragma unroll
