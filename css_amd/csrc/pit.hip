@@ -12,7 +12,7 @@
 
 namespace {
 
-constexpr int CHUNK = 4096;  // elements of one sample's T*F handled per workgroup
+constexpr int CHUNK = 2048;  // elements of one sample's T*F handled per workgroup
 constexpr int MAXK = 4;
 
 struct PitArgs {
@@ -36,11 +36,14 @@ __global__ __launch_bounds__(256) void pit_sse_kernel(PitArgs a) {
 #pragma unroll
     for (int j = 0; j < K; ++j) acc[k][j] = 0.f;
   const int e0 = chunk * CHUNK;
-#pragma unroll 4
+  // (t, f) of this thread's first element by one division; afterwards e advances by 256 per step: f += 256 with
+  // at most F-sized wraps (no per-element division)
+  int t = (e0 + tid) / a.F, f = (e0 + tid) - t * a.F;
+  const int dt = 256 / a.F, df = 256 - dt * a.F;
+#pragma unroll 8
   for (int i = 0; i < CHUNK / 256; ++i) {
     const int e = e0 + i * 256 + tid;
     if (e < TF) {
-      const int t = e / a.F, f = e - t * a.F;
       const size_t row = (size_t)b * a.T + t;
       const float fo = a.f[row * a.ld_f + f];
       float y[K], tg[K];
@@ -58,6 +61,12 @@ __global__ __launch_bounds__(256) void pit_sse_kernel(PitArgs a) {
           acc[k][j] += d * d;
         }
     }
+    t += dt;
+    f += df;
+    if (f >= a.F) {
+      f -= a.F;
+      ++t;
+    }
   }
   const int lane = tid & 63, w = tid >> 6;
 #pragma unroll
@@ -72,20 +81,31 @@ __global__ __launch_bounds__(256) void pit_sse_kernel(PitArgs a) {
     a.partial[((size_t)b * a.nchunk + chunk) * (K * K) + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
-// One thread per sample reduces its partials (double), scans the K! permutations in
-// itertools.permutations order (first minimum wins, like torch.min), then thread 0 averages.
+// Eight lanes per sample reduce its partials (double, fixed order), one of them scans the K! permutations in
+// itertools.permutations order (first minimum wins, like torch.min), then thread 0 averages.  Single workgroup.
 template <int K>
-__global__ void pit_finalize_kernel(const float* __restrict__ partial, int B, int nchunk, double norm,
-                                    float* __restrict__ loss, int* __restrict__ perm_out,
-                                    float* __restrict__ pair_sse, float* __restrict__ per_sample) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < B) {
-    double Dm[K][K];
-    for (int k = 0; k < K; ++k)
-      for (int j = 0; j < K; ++j) Dm[k][j] = 0.0;
-    for (int c = 0; c < nchunk; ++c)
+__global__ __launch_bounds__(256) void pit_finalize_kernel(const float* __restrict__ partial, int B, int nchunk,
+                                                           double norm, float* __restrict__ loss,
+                                                           int* __restrict__ perm_out, float* __restrict__ pair_sse,
+                                                           float* __restrict__ per_sample) {
+  for (int b0 = 0; b0 < B; b0 += 32) {
+  const int b = b0 + (threadIdx.x >> 3), part = threadIdx.x & 7;
+  double Dm[K][K];
+  for (int k = 0; k < K; ++k)
+    for (int j = 0; j < K; ++j) Dm[k][j] = 0.0;
+  if (b < B)
+    for (int c = part; c < nchunk; c += 8)
       for (int k = 0; k < K; ++k)
         for (int j = 0; j < K; ++j) Dm[k][j] += (double)partial[((size_t)b * nchunk + c) * (K * K) + k * K + j];
+  for (int k = 0; k < K; ++k)
+    for (int j = 0; j < K; ++j) {
+      double v = Dm[k][j];
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 4);
+      Dm[k][j] = v;
+    }
+  if (b < B && part == 0) {
     if (pair_sse)
       for (int k = 0; k < K; ++k)
         for (int j = 0; j < K; ++j) pair_sse[(size_t)b * K * K + k * K + j] = (float)Dm[k][j];
@@ -114,6 +134,7 @@ __global__ void pit_finalize_kernel(const float* __restrict__ partial, int B, in
     per_sample[b] = best;
     if (perm_out)
       for (int i = 0; i < K; ++i) perm_out[(size_t)b * K + i] = best_p[i];
+  }
   }
   __syncthreads();
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -186,8 +207,7 @@ extern "C" int csship_pit_mse(const float* masks, int64_t ld_mask, const float* 
   hipStream_t s = as_stream(stream);
   dim3 grid(a.nchunk, B);
   const double norm = (double)K * T * F;
-  const int fb = 1024;  // finalize: one block so the batch mean can follow a block barrier
-  if (B > fb) return CSSHIP_EUNSUPPORTED;
+  const int fb = 256;  // finalize: one block (32 samples per pass) so the batch mean can follow a block barrier
 #define PIT_CASE(KK)                                                                                        \
   case KK:                                                                                                  \
     hipLaunchKernelGGL(pit_sse_kernel<KK>, grid, dim3(256), 0, s, a);                                       \

@@ -2,8 +2,9 @@
 // no centre padding.  The reference evaluates it as a dense conv1d against a 514x512 DFT
 // matrix (0.53 MFLOP/frame); here each frame is a real FFT computed by ONE 64-lane wave:
 //
-//   * a workgroup stages (FB+1)*256 contiguous samples in LDS with coalesced 16-byte loads
-//     (consecutive frames overlap by 50 %, so every sample is read from HBM once);
+//   * a wave walks FW consecutive frames of one signal; consecutive frames overlap by 50 %, so the wave keeps the
+//     second half of the previous frame in registers and loads only the 256 new samples (two 8-byte loads per
+//     lane, issued one frame ahead): every sample is read from HBM once, with no LDS staging and no barrier;
 //   * 512 real points are packed as 256 complex z[n] = x[2n] + i x[2n+1]; lane l holds
 //     z[l], z[l+64], z[l+128], z[l+192]: four radix-4 stages in registers, the register <-> lane
 //     regrouping between them by v_permlane{32,16}_swap and a 2 KB per-wave LDS scratch (fft.hpp);
@@ -16,7 +17,8 @@
 
 namespace {
 
-constexpr int FB = 16;  // frames per workgroup (4 per wave): 25 KB LDS -> 6 workgroups per CU
+constexpr int FW = 8;        // consecutive frames per wave
+constexpr int FB = 4 * FW;   // frames per workgroup (4 waves): 8.5 KB LDS (FFT scratch only)
 constexpr int NBIN = 257;
 
 template <bool MAG_ONLY>
@@ -24,59 +26,49 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ aud
                                                    int64_t stride1, int64_t n_samples, int T,
                                                    float* __restrict__ mag, float* __restrict__ re,
                                                    float* __restrict__ im, float* __restrict__ pha) {
-  __shared__ __attribute__((aligned(16))) float sx[(FB + 1) * 256];
   __shared__ __attribute__((aligned(16))) cplx sz[4][FFT_SCRATCH];
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
   const int64_t s = blockIdx.y;
-  const int t0 = blockIdx.x * FB;
-  const float* sig = audio + (s / n1) * stride0 + (s % n1) * stride1;
-
-  // ---- stage samples [t0*256, t0*256 + (FB+1)*256)
-  const int64_t base = (int64_t)t0 * 256;
-  for (int i = tid * 4; i < (FB + 1) * 256; i += 1024) {
-    const int64_t idx = base + i;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (idx + 3 < n_samples) {
-      v = *reinterpret_cast<const float4*>(sig + idx);
-    } else {
-      if (idx + 0 < n_samples) v.x = sig[idx + 0];
-      if (idx + 1 < n_samples) v.y = sig[idx + 1];
-      if (idx + 2 < n_samples) v.z = sig[idx + 2];
-    }
-    *reinterpret_cast<float4*>(sx + i) = v;
-  }
+  const int tw0 = blockIdx.x * FB + w * FW;  // this wave's first frame
+  if (tw0 >= T) return;                      // wave-uniform
+  const int nf = min(FW, T - tw0);
+  const float* sig = audio + (s / n1) * stride0 + (s % n1) * stride1 + (int64_t)tw0 * 256;
 
   // ---- per-lane constants (window, twiddles)
   float win[8];
   cplx tw1[4], tws[6], twp[4];
   fft_load_consts(0, l, win, tw1, tws, twp);
-  const int ko = fft_out_index(l);
-  __syncthreads();
+  // natural-order scratch image padded by one entry per 16 (slot(k) = k + k/16): the digit-reversed writes of a
+  // 16-lane group then touch 16 distinct 8-byte slots of the 128-byte bank row instead of 4
+  const int ko = fft_out_index(l), kos = ko + (ko >> 4);
 
+  // raw[q] = samples 2(l+64q), 2(l+64q)+1 of the current frame; q = 2, 3 become q = 0, 1 of the next frame
+  float2 raw[4], nxt[2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) raw[q] = *reinterpret_cast<const float2*>(sig + 2 * (l + 64 * q));
   cplx* zs = sz[w];
-  for (int fi = 0; fi < FB / 4; ++fi) {
-    const int fl = w * (FB / 4) + fi;
-    const int t = t0 + fl;
-    if (t >= T) break;  // wave-uniform
-    const float* fx = sx + fl * 256;
+  for (int fi = 0; fi < nf; ++fi) {
+    const int t = tw0 + fi;
+    if (fi + 1 < nf) {  // the 256 new samples of frame t + 1 (all inside the signal for a valid frame)
+      nxt[0] = *reinterpret_cast<const float2*>(sig + (int64_t)(fi + 1) * 256 + 256 + 2 * l);
+      nxt[1] = *reinterpret_cast<const float2*>(sig + (int64_t)(fi + 1) * 256 + 256 + 2 * (l + 64));
+    }
     cplx z[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float2 v = *reinterpret_cast<const float2*>(fx + 2 * (l + 64 * q));
-      z[q] = {v.x * win[2 * q], v.y * win[2 * q + 1]};
-    }
+    for (int q = 0; q < 4; ++q) z[q] = {raw[q].x * win[2 * q], raw[q].y * win[2 * q + 1]};
     cplx u[4];
     fft256_wave(z, u, tw1, tws, zs, l);
     // lane l, reg r holds Z[ko + 64 r]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) zs[ko + 64 * r] = u[r];
+    for (int r = 0; r < 4; ++r) zs[kos + 68 * r] = u[r];
     fft_wave_sync();
     // real-FFT post pass: X[k] = E + W512^k O, E = (Z[k]+conj Z[256-k])/2, O = -i (Z[k]-conj Z[256-k])/2
     const size_t orow = ((size_t)s * T + t) * NBIN;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int k = l + 64 * q;
-      const cplx A = zs[k], Bv = zs[(256 - k) & 255];
+      const int kc = (256 - k) & 255;
+      const cplx A = zs[k + (k >> 4)], Bv = zs[kc + (kc >> 4)];
       const cplx E = {0.5f * (A.x + Bv.x), 0.5f * (A.y - Bv.y)};
       const cplx Dd = {A.x - Bv.x, A.y + Bv.y};
       const cplx O = {0.5f * Dd.y, -0.5f * Dd.x};
@@ -101,7 +93,11 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ aud
         if (pha) pha[orow + 256] = atan2f(0.f, xr);
       }
     }
-    __builtin_amdgcn_wave_barrier();  // scratch is rewritten by the next frame
+    fft_wave_sync();  // scratch is rewritten by the next frame
+    raw[0] = raw[2];
+    raw[1] = raw[3];
+    raw[2] = nxt[0];
+    raw[3] = nxt[1];
   }
 }
 
