@@ -150,6 +150,21 @@ def main():
         roof["stft"] = {"bound": "hbm", "achieved": nfr * 2052 / sd_ / 1e9, "peak": 8000.0, "unit": "GB/s",
                         "frac": nfr * 2052 / sd_ / 8.0e12, "avg_launch_us": sd_ * 1e6,
                         "bytes_per_frame": 2052}
+        # mask application + PIT-MSE (pit_sse + finalize launches), SURVEY 8(d): 6 168 B/frame minus the noise mask
+        mags_ = ops.stft(audio, ("mag",))["mag"]
+        masks_ = model.forward_masks(mags_[0])
+        for _ in range(3):
+            ops.pit_mse(masks_, mags_[0], [mags_[1], mags_[2]])
+        e0.record(torch.cuda.current_stream())
+        for _ in range(20):
+            ops.pit_mse(masks_, mags_[0], [mags_[1], mags_[2]])
+        e1.record(torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        pd_ = e0.elapsed_time(e1) * 1e-3 / 20
+        pit_bytes = 5 * 257 * 4
+        roof["pit"] = {"bound": "hbm", "achieved": B * T * pit_bytes / pd_ / 1e9, "peak": 8000.0, "unit": "GB/s",
+                       "frac": B * T * pit_bytes / pd_ / 8.0e12, "avg_launch_us": pd_ * 1e6,
+                       "bytes_per_frame": pit_bytes}
 
     # ---- CPU baseline: the oracle on one full batch, host cores of this box
     cpu = None
