@@ -6,7 +6,9 @@ Forward values ALWAYS come from the HIP kernels.  Backward:
     (css_amd/backward.py: batched MFMA GEMMs, LayerNorm / softmax / ConvModule backward kernels).  The training
     forward runs operator by operator (same kernels as inference, minus the cross-operator chaining) and keeps each
     operator's input; hidden activations are recomputed in the backward;
-  * other shapes (Conformer-large widths, BLSTM): STOP-GAP ``MasksWithTwinBackward`` - the gradient is obtained by
+  * masks -> parameters, BLSTM (``BlstmTrain``): back-propagation-through-time kernel for the recurrence, the same
+    GEMM / LayerNorm backward kernels for the rest;
+  * other shapes (Conformer-large widths, eval-mode BatchNorm): STOP-GAP ``MasksWithTwinBackward`` - the gradient is obtained by
     re-evaluating a differentiable PyTorch-ROCm restatement of the model ("twin", GPU torch ops, fp32) and
     back-propagating grad_masks through it.  The twin never produces a forward result that is returned.
 """
@@ -203,10 +205,111 @@ class ConformerTrain(torch.autograd.Function):
         return (None, None) + tuple(G.get(p) if p.requires_grad else None for p in model.parameters())
 
 
+class BlstmTrain(torch.autograd.Function):
+    """masks = BLSTM(f) (blstm.py:68-88, dropout off) with the explicit HIP backward: BPTT kernel for the recurrence,
+    batched GEMMs / column sums for every weight and input gradient, LayerNorm / ReLU backward kernels."""
+
+    @staticmethod
+    def forward(ctx, model, f, *params):
+        enc = model.blstm
+        h = enc.hidden_dim
+        H = h // 2
+        B, T, F = f.shape
+        M = B * T
+        f = f.contiguous()
+        mean, rinv = ops.mvn_stats(f)
+        Kp = (F + 7) // 8 * 8
+        we_bf, _ = ob.pack_weight(enc.embed[0].weight.detach(), want_row_major=True)
+        fn = ob.mvn_apply(f, mean, rinv, Kp)
+        e = ob.bgemm(fn, we_bf, bias=enc.embed[0].bias.detach())
+        _, x = ops.layernorm_relu(e, enc.embed[1].weight.detach(), enc.embed[1].bias.detach())
+        S = {"f": f, "mean": mean, "rinv": rinv, "we_bf": we_bf, "e": e, "layers": []}
+        Hp = (H + 31) // 32 * 32
+        for lay in enc.encoders:
+            l = lay.lstm
+            w_ih_bf = torch.empty((8 * H, h), dtype=BF, device=f.device)
+            whh_p = torch.empty(2 * 4 * H * Hp, dtype=BF, device=f.device)
+            whhT_p = torch.empty(2 * H * 4 * H, dtype=BF, device=f.device)
+            for d, sfx in enumerate(("", "_reverse")):
+                ob.pack_weight(getattr(l, "weight_ih_l0" + sfx).detach(), row_major=w_ih_bf, row0=d * 4 * H)
+                whh = getattr(l, "weight_hh_l0" + sfx).detach()
+                ob.pack_weight(whh, frag=whh_p, row0=d * 4 * H)
+                ob.pack_weight(whh.t().contiguous(), frag=whhT_p, row0=d * H)
+            bias = torch.cat([l.bias_ih_l0.detach() + l.bias_hh_l0.detach(),
+                              l.bias_ih_l0_reverse.detach() + l.bias_hh_l0_reverse.detach()], 0)
+            gx = ob.bgemm(x, w_ih_bf, bias=bias)                       # [M, 8H] = (dir, 4H)
+            y, gates, c = ob.lstm_bidir_train(gx, whh_p, B, T, H)
+            S["layers"].append({"x": x, "y": y, "gates": gates, "c": c, "w_ih_bf": w_ih_bf, "whhT_p": whhT_p})
+            _, x = ops.layernorm_relu(y.view(M, h), lay.layer_norm.weight.detach(), lay.layer_norm.bias.detach(),
+                                      relu=False)
+        n_out = model.linear.out_features
+        wh_bf, _ = ob.pack_weight(model.linear.weight.detach(), want_row_major=True)
+        ld = (n_out + 3) // 4 * 4
+        z = torch.empty((M, ld), dtype=torch.float32, device=f.device)[:, :n_out]
+        ob.bgemm(x, wh_bf, bias=model.linear.bias.detach(), out=z)
+        masks = torch.relu_(z)  # elementwise clamp on the GEMM output; values == the eval path's fused epilogue
+        S.update(x_last=x, masks=masks, wh_bf=wh_bf)
+        ctx.model, ctx.S = model, S
+        return masks.view(B, T, n_out)
+
+    @staticmethod
+    def backward(ctx, grad_masks):
+        model, S = ctx.model, ctx.S
+        ctx.S = None
+        enc = model.blstm
+        h = enc.hidden_dim
+        H = h // 2
+        B, T, F = S["f"].shape
+        M = B * T
+        G = {}
+
+        def put(p, g):
+            G[p] = g.reshape(p.shape)
+
+        masks = S["masks"]
+        dm = grad_masks.reshape(M, -1)
+        if dm.stride(1) != 1 or dm.stride(0) % 4:
+            buf = torch.empty_strided(masks.shape, masks.stride(), dtype=torch.float32, device=masks.device)
+            buf.copy_(dm)
+            dm = buf
+        dx, dw, db = bw.head_bwd(dm, masks, S["x_last"], S["wh_bf"])
+        put(model.linear.weight, dw), put(model.linear.bias, db)
+        for lay, L in zip(reversed(list(enc.encoders)), reversed(S["layers"])):
+            y = L["y"]
+            dy, dg, dbeta = ob.layernorm_bwd(y.view(M, h), dx, lay.layer_norm.weight.detach(), lay.layer_norm.bias.detach())
+            put(lay.layer_norm.weight, dg), put(lay.layer_norm.bias, dbeta)
+            dgates = ob.lstm_bidir_bwd(L["gates"], L["c"], dy.view(B, T, h), L["whhT_p"])
+            dg2 = dgates.view(M, 8 * H)
+            dwih = ob.bgemm(dg2, L["x"], a_kmajor=True, b_kmajor=True)       # [8H, h]
+            dbias = ob.colsum(dg2)
+            dx = ob.bgemm(dg2, L["w_ih_bf"], b_kmajor=True)                   # [M, h]
+            yp = torch.zeros_like(y)                                          # h_{t-1} of each direction
+            yp[:, 1:, :H] = y[:, :-1, :H]
+            yp[:, :-1, H:] = y[:, 1:, H:]
+            yp2 = yp.view(M, 2 * H)
+            l = lay.lstm
+            for d, sfx in enumerate(("", "_reverse")):
+                dwhh = ob.bgemm(dg2[:, d * 4 * H:(d + 1) * 4 * H], yp2[:, d * H:(d + 1) * H], a_kmajor=True, b_kmajor=True)
+                put(getattr(l, "weight_ih_l0" + sfx), dwih[d * 4 * H:(d + 1) * 4 * H])
+                put(getattr(l, "weight_hh_l0" + sfx), dwhh)
+                put(getattr(l, "bias_ih_l0" + sfx), dbias[d * 4 * H:(d + 1) * 4 * H])
+                put(getattr(l, "bias_hh_l0" + sfx), dbias[d * 4 * H:(d + 1) * 4 * H])
+            L.clear()
+        dwe, dbe, dg, dbeta = bw.embed_bwd(S["f"], dx, S["mean"], S["rinv"], S["we_bf"], enc.embed[0].bias.detach(),
+                                           enc.embed[1].weight.detach(), enc.embed[1].bias.detach(), e=S["e"])
+        put(enc.embed[0].weight, dwe), put(enc.embed[0].bias, dbe)
+        put(enc.embed[1].weight, dg), put(enc.embed[1].bias, dbeta)
+        return (None, None) + tuple(G.get(p) if p.requires_grad else None for p in model.parameters())
+
+
 def masks_for_training(model, f):
     params = tuple(model.parameters())
     enc = getattr(model, "conformer", None)
     if enc is not None and enc.d_model == 256 and enc.d_model // enc.n_head == 64 and enc.kernel_size == 33 \
             and model.training and not getattr(model, "force_twin_backward", False):
         return ConformerTrain.apply(model, f, *params)
+    if hasattr(model, "blstm") and not getattr(model, "force_twin_backward", False):
+        H = model.blstm.hidden_dim // 2
+        if H % 16 == 0 and (H <= 128 or H % 128 == 0) and H <= 512 and model.blstm.hidden_dim <= 1024:
+            return BlstmTrain.apply(model, f, *params)
     return MasksWithTwinBackward.apply(model, f, *params)

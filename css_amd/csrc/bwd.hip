@@ -84,6 +84,69 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     part[(int64_t)blockIdx.x * 2 * D + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
 
+// ---- the same for any D <= 1024 (BLSTM widths): lane owns columns lane, lane + 64, ...; scalar accesses
+__global__ __launch_bounds__(256) void ln_bwd_any_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* dx_add, int relu, int64_t M, int D, int rows_per_wg,
+                                                         float* dx, float* __restrict__ part) {
+  constexpr int MAXC = 16;
+  extern __shared__ float red_any[];  // [4][2 * D]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg, r1 = min(M, r0 + rows_per_wg);
+  float ag[MAXC], ab[MAXC];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) ag[i] = ab[i] = 0.f;
+  for (int64_t row = r0 + w; row < r1; row += 4) {
+    const float* xr = x + row * D;
+    const float* dr = dy + row * D;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s += xr[c];
+    const float mean = wave_sum(s) / (float)D;
+    float ss = 0.f;
+    for (int c = lane; c < D; c += 64) {
+      const float d = xr[c] - mean;
+      ss += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)D + 1e-5f);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = i * 64 + lane;
+      if (c < D) {
+        const float xh = (xr[c] - mean) * rstd;
+        float d = dr[c];
+        if (relu && !(xh * gamma[c] + beta[c] > 0.f)) d = 0.f;
+        ag[i] += d * xh;
+        ab[i] += d;
+        const float gg = d * gamma[c];
+        s1 += gg;
+        s2 += gg * xh;
+      }
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+    for (int c = lane; c < D; c += 64) {
+      const float xh = (xr[c] - mean) * rstd;
+      float d = dr[c];
+      if (relu && !(xh * gamma[c] + beta[c] > 0.f)) d = 0.f;
+      float r = rstd * (d * gamma[c] - s1 - xh * s2);
+      if (dx_add) r += dx_add[row * D + c];
+      dx[row * D + c] = r;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = i * 64 + lane;
+    if (c < D) {
+      red_any[w * 2 * D + c] = ag[i];
+      red_any[w * 2 * D + D + c] = ab[i];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * D; c += 256)
+    part[(int64_t)blockIdx.x * 2 * D + c] = red_any[c] + red_any[2 * D + c] + red_any[4 * D + c] + red_any[6 * D + c];
+}
+
 // ---- dz = dy where y > 0 else 0 (2-D, row strides); workgroup = 256 columns of one row
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dy, int64_t ldd,
                                                        const float* __restrict__ y, int64_t ldy, int N, int cblocks,
@@ -198,15 +261,19 @@ extern "C" int csship_layernorm_bwd(const float* x, const float* dy, const float
                                     csship_stream_t stream) {
   if (!x || !dy || !gamma || !beta || !dx || !dgamma_dbeta || !workspace) return CSSHIP_ENULL;
   if (M <= 0) return CSSHIP_EBADSHAPE;
-  if (D != 256 && D != 512 && D != 1024) return CSSHIP_EUNSUPPORTED;
-  if (!aligned16(x) || !aligned16(dy) || !aligned16(dx) || !aligned16(gamma) || !aligned16(beta) ||
-      (dx_add && !aligned16(dx_add)))
+  if (D <= 0 || D > 1024) return CSSHIP_EUNSUPPORTED;
+  const bool fast = D == 256 || D == 512 || D == 1024;
+  if (fast && (!aligned16(x) || !aligned16(dy) || !aligned16(dx) || !aligned16(gamma) || !aligned16(beta) ||
+               (dx_add && !aligned16(dx_add))))
     return CSSHIP_EALIGN;
   const int nwg = (int)((M + 63) / 64);
   if (workspace_bytes < (size_t)nwg * 2 * D * sizeof(float)) return CSSHIP_EWORKSPACE;
   hipStream_t s = as_stream(stream);
   float* part = reinterpret_cast<float*>(workspace);
-  if (D == 256)
+  if (!fast)
+    hipLaunchKernelGGL(ln_bwd_any_kernel, dim3(nwg), dim3(256), (size_t)8 * D * sizeof(float), s, x, dy, gamma, beta, dx_add,
+                       relu, M, D, 64, dx, part);
+  else if (D == 256)
     hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(nwg), dim3(256), 0, s, x, dy, gamma, beta, dx_add, relu, M, 64, dx, part);
   else if (D == 512)
     hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(nwg), dim3(256), 0, s, x, dy, gamma, beta, dx_add, relu, M, 64, dx, part);

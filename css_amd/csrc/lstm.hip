@@ -17,6 +17,8 @@ struct LstmArgs {
   const float* gx;     // [B, T, 2, 4H]
   const bf16x8* whh;   // packed per direction: [2][4H/16][Hp/32][64]
   float* out;          // [B, T, 2H]
+  float* gates_out;    // optional (training): activated gates i,f,g,o  [B, T, 2, 4H]
+  float* c_out;        // optional (training): cell states            [B, T, 2, H]
   int B, T, H, Hp, nw; // Hp = H rounded up to 32
 };
 
@@ -68,17 +70,26 @@ __global__ __launch_bounds__(512) void lstm_kernel(LstmArgs a) {
         }
     }
     float* orow = a.out + ((size_t)brow * a.T + t) * 2 * H + dir * H;
+    const size_t srow = ((size_t)brow * a.T + t) * 2 + dir;
 #pragma unroll
     for (int u = 0; u < UT; ++u) {
       float hv[4];
+      const int un = unit0 + 16 * u + 4 * g;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float ig = sigmoidf_fast(acc[u][0][r]), fg = sigmoidf_fast(acc[u][1][r]);
         const float gg = tanhf_fast(acc[u][2][r]), og = sigmoidf_fast(acc[u][3][r]);
         c[u][r] = fg * c[u][r] + ig * gg;
         hv[r] = og * tanhf_fast(c[u][r]);
+        acc[u][0][r] = ig; acc[u][1][r] = fg; acc[u][2][r] = gg; acc[u][3][r] = og;
       }
-      const int un = unit0 + 16 * u + 4 * g;
+      if (a.gates_out && bvalid) {  // saved for the backward pass
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(a.gates_out + srow * 4 * H + q * H + un) =
+              make_float4(acc[u][q][0], acc[u][q][1], acc[u][q][2], acc[u][q][3]);
+        *reinterpret_cast<float4*>(a.c_out + srow * H + un) = make_float4(c[u][0], c[u][1], c[u][2], c[u][3]);
+      }
       *reinterpret_cast<uint2*>(hout + n * rstride + un * 2) = make_uint2(pack_bf2(hv[0], hv[1]), pack_bf2(hv[2], hv[3]));
       if (bvalid) *reinterpret_cast<float4*>(orow + un) = make_float4(hv[0], hv[1], hv[2], hv[3]);
     }
@@ -86,10 +97,151 @@ __global__ __launch_bounds__(512) void lstm_kernel(LstmArgs a) {
   }
 }
 
+// ---- backward of the recurrence (BPTT).  Mirrors the forward: workgroup = (16 batch rows, direction), wave w owns
+// H/NW hidden units; per step (walking time against the forward order)
+//   dh^T[unit][batch] = dy_t + W_hh^T[unit rows][4H] . dgates_{next}^T      (MFMA, W_hh^T streamed, dgates panel in LDS)
+//   cell / gate derivatives lane-local from the saved activated gates and cell states,
+//   dgates_t (pre-activation gradients of i,f,g,o) -> LDS panel for the next step and global for the weight GEMMs
+// (dW_ih, dW_hh, db, dx are plain GEMMs / column sums over dgates afterwards).
+struct LstmBwdArgs {
+  const float* gates;  // [B, T, 2, 4H] activated
+  const float* c;      // [B, T, 2, H]
+  const float* dy;     // [B, T, 2H]
+  const bf16x8* whhT;  // packed per direction from W_hh^T [H, 4H]: [2][H/16][4H/32][64]
+  float* dgates;       // [B, T, 2, 4H]
+  int B, T, H;
+};
+
+template <int UT>
+__global__ __launch_bounds__(512) void lstm_bwd_kernel(LstmBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];  // 2 panels [16][4H] bf16, rows padded by 16 B
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, n = lane & 15;
+  const int dir = blockIdx.y, b0 = blockIdx.x * 16;
+  const int H = a.H, KS4 = 4 * H / 32, rstride = 4 * H * 2 + 16;
+  const int panel_bytes = 16 * rstride;
+  const int brow = min(b0 + n, a.B - 1);
+  const bool bvalid = b0 + n < a.B;
+  const int unit0 = w * UT * 16;
+  for (int i = tid; i < 2 * panel_bytes / 4; i += blockDim.x) reinterpret_cast<unsigned*>(hsm)[i] = 0u;
+  float dc[UT][4];
+#pragma unroll
+  for (int u = 0; u < UT; ++u)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dc[u][r] = 0.f;
+  const bf16x8* wbase = a.whhT + (size_t)dir * (H / 16) * KS4 * 64 + lane;
+  __syncthreads();
+
+  for (int step = 0; step < a.T; ++step) {
+    const int t = dir == 0 ? a.T - 1 - step : step;            // against the forward order
+    const int tp = dir == 0 ? t - 1 : t + 1;                   // the forward pass's previous step
+    const bool has_prev = tp >= 0 && tp < a.T;
+    const unsigned char* din = hsm + (step & 1) * panel_bytes;
+    unsigned char* dout = hsm + ((step + 1) & 1) * panel_bytes;
+    const size_t srow = ((size_t)brow * a.T + t) * 2 + dir;
+    const size_t prow = ((size_t)brow * a.T + (has_prev ? tp : t)) * 2 + dir;
+    f32x4 acc[UT];
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+      const float4 v = *reinterpret_cast<const float4*>(a.dy + ((size_t)brow * a.T + t) * 2 * H + dir * H + unit0 + 16 * u + 4 * g);
+      acc[u] = f32x4{v.x, v.y, v.z, v.w};
+    }
+    for (int ks = 0; ks < KS4; ++ks) {
+      const bf16x8 db = *reinterpret_cast<const bf16x8*>(din + n * rstride + (ks * 4 + g) * 16);
+#pragma unroll
+      for (int u = 0; u < UT; ++u) {
+        const bf16x8 wf = wbase[((size_t)(unit0 / 16 + u) * KS4 + ks) * 64];
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, db, acc[u], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+      const int un = unit0 + 16 * u + 4 * g;
+      float4 gq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gq[q] = *reinterpret_cast<const float4*>(a.gates + srow * 4 * H + q * H + un);
+      const float4 ct = *reinterpret_cast<const float4*>(a.c + srow * H + un);
+      float4 cp = *reinterpret_cast<const float4*>(a.c + prow * H + un);
+      if (!has_prev) cp = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float iv[4] = {gq[0].x, gq[0].y, gq[0].z, gq[0].w}, fv[4] = {gq[1].x, gq[1].y, gq[1].z, gq[1].w};
+      const float gv[4] = {gq[2].x, gq[2].y, gq[2].z, gq[2].w}, ov[4] = {gq[3].x, gq[3].y, gq[3].z, gq[3].w};
+      const float cv[4] = {ct.x, ct.y, ct.z, ct.w}, pv[4] = {cp.x, cp.y, cp.z, cp.w};
+      float da[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float dh = acc[u][r];
+        const float tc = tanhf_fast(cv[r]);
+        const float dcc = dc[u][r] + dh * ov[r] * (1.f - tc * tc);
+        da[0][r] = dcc * gv[r] * iv[r] * (1.f - iv[r]);
+        da[1][r] = dcc * pv[r] * fv[r] * (1.f - fv[r]);
+        da[2][r] = dcc * iv[r] * (1.f - gv[r] * gv[r]);
+        da[3][r] = dh * tc * ov[r] * (1.f - ov[r]);
+        dc[u][r] = dcc * fv[r];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        *reinterpret_cast<uint2*>(dout + n * rstride + (q * H + un) * 2) =
+            make_uint2(pack_bf2(da[q][0], da[q][1]), pack_bf2(da[q][2], da[q][3]));
+        if (bvalid)
+          *reinterpret_cast<float4*>(a.dgates + srow * 4 * H + q * H + un) = make_float4(da[q][0], da[q][1], da[q][2], da[q][3]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
+
+extern "C" int csship_lstm_bidir_bwd(const float* gates, const float* c, const float* dy, const uint16_t* whhT_packed,
+                                     float* dgates, int32_t B, int32_t T, int32_t H, csship_stream_t stream) {
+  if (!gates || !c || !dy || !whhT_packed || !dgates) return CSSHIP_ENULL;
+  if (B <= 0 || T <= 0 || H <= 0) return CSSHIP_EBADSHAPE;
+  if ((H % 16) != 0) return CSSHIP_EUNSUPPORTED;
+  if (!aligned16(gates) || !aligned16(c) || !aligned16(dy) || !aligned16(whhT_packed) || !aligned16(dgates)) return CSSHIP_EALIGN;
+  int nw = H / 16, ut = 1;
+  if (nw > 8) {
+    if (H % 128) return CSSHIP_EUNSUPPORTED;
+    nw = 8;
+    ut = H / 128;
+  }
+  LstmBwdArgs a{gates, c, dy, reinterpret_cast<const bf16x8*>(whhT_packed), dgates, B, T, H};
+  const size_t lds = 2 * 16 * (size_t)(4 * H * 2 + 16);
+  if (lds > 160 * 1024) return CSSHIP_EUNSUPPORTED;
+  dim3 grid((B + 15) / 16, 2), block(nw * 64);
+  hipStream_t s = as_stream(stream);
+#define LSTM_BWD_CASE(U)                                                                                     \
+  case U:                                                                                                    \
+    if (lds > 64 * 1024 &&                                                                                   \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<U>),                              \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)             \
+      return CSSHIP_ELAUNCH;                                                                                 \
+    hipLaunchKernelGGL(lstm_bwd_kernel<U>, grid, block, lds, s, a);                                          \
+    break;
+  switch (ut) {
+    LSTM_BWD_CASE(1) LSTM_BWD_CASE(2) LSTM_BWD_CASE(4)
+    default: return CSSHIP_EUNSUPPORTED;
+  }
+#undef LSTM_BWD_CASE
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
+static int lstm_forward(const float* gx, const uint16_t* whh_packed, float* out, float* gates_out, float* c_out,
+                        int32_t B, int32_t T, int32_t H, csship_stream_t stream);
 
 extern "C" int csship_lstm_bidir(const float* gx, const uint16_t* whh_packed, float* out, int32_t B, int32_t T,
                                  int32_t H, csship_stream_t stream) {
+  return lstm_forward(gx, whh_packed, out, nullptr, nullptr, B, T, H, stream);
+}
+
+extern "C" int csship_lstm_bidir_train(const float* gx, const uint16_t* whh_packed, float* out, float* gates_out,
+                                       float* c_out, int32_t B, int32_t T, int32_t H, csship_stream_t stream) {
+  if (!gates_out || !c_out) return CSSHIP_ENULL;
+  if (!aligned16(gates_out) || !aligned16(c_out)) return CSSHIP_EALIGN;
+  return lstm_forward(gx, whh_packed, out, gates_out, c_out, B, T, H, stream);
+}
+
+static int lstm_forward(const float* gx, const uint16_t* whh_packed, float* out, float* gates_out, float* c_out,
+                        int32_t B, int32_t T, int32_t H, csship_stream_t stream) {
   if (!gx || !whh_packed || !out) return CSSHIP_ENULL;
   if (B <= 0 || T <= 0 || H <= 0) return CSSHIP_EBADSHAPE;
   if ((H % 16) != 0) return CSSHIP_EUNSUPPORTED;
@@ -101,7 +253,7 @@ extern "C" int csship_lstm_bidir(const float* gx, const uint16_t* whh_packed, fl
     ut = H / 128;
   }
   const int Hp = (H + 31) / 32 * 32;
-  LstmArgs a{gx, reinterpret_cast<const bf16x8*>(whh_packed), out, B, T, H, Hp, nw};
+  LstmArgs a{gx, reinterpret_cast<const bf16x8*>(whh_packed), out, gates_out, c_out, B, T, H, Hp, nw};
   const size_t lds = 2 * 16 * (size_t)(Hp * 2 + 16);
   dim3 grid((B + 15) / 16, 2), block(nw * 64);
   hipStream_t s = as_stream(stream);

@@ -204,3 +204,23 @@ def pack_weight(w, *, scale=1.0, row_major=None, frag=None, row0=0, want_row_maj
     check(lib().csship_pack_weight(_ptr(w), R, K, w.stride(0), float(scale), _ptr(row_major),
                                    row_major.stride(0) if row_major is not None else 0, _ptr(frag), row0, _stream()))
     return row_major, frag
+
+
+def lstm_bidir_train(gx, whh_packed, B, T, H):
+    """BLSTM recurrence that also returns what the backward needs: (y [B,T,2H], gates [B,T,2,4H], c [B,T,2,H])."""
+    _need(gx, torch.float32, "gx")
+    dev = gx.device
+    y = torch.empty((B, T, 2 * H), dtype=torch.float32, device=dev)
+    gates = torch.empty((B, T, 2, 4 * H), dtype=torch.float32, device=dev)
+    c = torch.empty((B, T, 2, H), dtype=torch.float32, device=dev)
+    check(lib().csship_lstm_bidir_train(_ptr(gx), _ptr(whh_packed), _ptr(y), _ptr(gates), _ptr(c), B, T, H, _stream()))
+    return y, gates, c
+
+
+def lstm_bidir_bwd(gates, c, dy, whhT_packed):
+    """Back-propagation through time: dy f32 [B,T,2H] -> dgates f32 [B,T,2,4H] (gradient wrt pre-activation gates)."""
+    B, T, _, H4 = gates.shape
+    dy = dy.contiguous()
+    dg = torch.empty_like(gates)
+    check(lib().csship_lstm_bidir_bwd(_ptr(gates), _ptr(c), _ptr(dy), _ptr(whhT_packed), _ptr(dg), B, T, H4 // 4, _stream()))
+    return dg

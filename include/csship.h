@@ -351,7 +351,8 @@ int csship_colsum(const void* x, int32_t x_is_f32, int64_t M, int32_t N, int64_t
 
 /* ---- row kernels of the backward pass (css_amd/csrc/bwd.hip)
  * csship_layernorm_bwd: y = LayerNorm(x) [then ReLU if relu != 0]; given dy returns dx (+ dx_add, may alias dx or dy)
- * and dgamma_dbeta = f32 [2, D] (dgamma row, dbeta row).  D in {256, 512, 1024}; x, dy, dx f32 [M, D] dense. */
+ * and dgamma_dbeta = f32 [2, D] (dgamma row, dbeta row).  D <= 1024 (vector path for 256 / 512 / 1024); x, dy, dx
+ * f32 [M, D] dense. */
 size_t csship_layernorm_bwd_workspace(int64_t M, int32_t D);
 int csship_layernorm_bwd(const float* x, const float* dy, const float* gamma, const float* beta,
                          const float* dx_add, int32_t relu, int64_t M, int32_t D, float* dx,
@@ -396,6 +397,17 @@ int csship_convmod_bwd(const float* x, const float* dy, const csship_conv_weight
 int csship_pack_weight(const float* w, int32_t R, int32_t K, int64_t ld_w, float scale,
                        uint16_t* row_major_bf16, int64_t ld_row_major, uint16_t* frag_packed_bf16,
                        int32_t dst_row0, csship_stream_t stream);
+
+/* ---- BLSTM recurrence, training (css_amd/csrc/lstm.hip).  csship_lstm_bidir_train = csship_lstm_bidir that also keeps
+ * the activated gates (i, f, g, o; f32 [B, T, 2, 4H]) and the cell states (f32 [B, T, 2, H]).
+ * csship_lstm_bidir_bwd: back-propagation through time.  dy: f32 [B, T, 2H]; whhT_packed: both directions'
+ * W_hh^T [H, 4H] in MFMA fragment order, direction-major; dgates: f32 [B, T, 2, 4H] = gradient wrt the
+ * pre-activation gates, from which dW_ih, dW_hh, the bias gradients and dx follow as plain GEMMs / column sums
+ * (csship_bgemm, csship_colsum).  H % 16 == 0, H % 128 == 0 above 128, H <= 512. */
+int csship_lstm_bidir_train(const float* gx, const uint16_t* whh_packed, float* out, float* gates_out,
+                            float* c_out, int32_t B, int32_t T, int32_t H, csship_stream_t stream);
+int csship_lstm_bidir_bwd(const float* gates, const float* c, const float* dy, const uint16_t* whhT_packed,
+                          float* dgates, int32_t B, int32_t T, int32_t H, csship_stream_t stream);
 
 #ifdef __cplusplus
 }
