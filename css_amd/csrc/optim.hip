@@ -1,0 +1,110 @@
+// Gradient-norm clipping + Adam on flat buffers (the optimiser step of css/trainer/iteration_types.py:17-64:
+// torch.nn.utils.clip_grad_norm_ then torch.optim.Adam.step in the reference, ~60 foreach launches and a host sync
+// for the norm).  Two launches, no host round trip: the clip coefficient is read from device memory.
+//   1. sqnorm: per-workgroup partial sums of g^2 (fixed order) -> one-workgroup reduce -> norm
+//   2. adam:   c = min(1, max_norm / (norm + 1e-6)); g' = c g; m, v moments; p -= lr (m/bc1) / (sqrt(v/bc2) + eps)
+//      (skipped entirely when the norm is not finite, like the reference's isnan guard around optimizer.step()).
+#include "common.hpp"
+
+namespace {
+
+constexpr int SQ_ELEMS = 8192;  // elements per workgroup of the norm pass
+
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ part) {
+  __shared__ float red[4];
+  const int64_t base = (int64_t)blockIdx.x * SQ_ELEMS;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < SQ_ELEMS / 1024; ++i) {
+    const int64_t e = base + (int64_t)(i * 256 + threadIdx.x) * 4;
+    if (e + 3 < n) {
+      const float4 v = *reinterpret_cast<const float4*>(g + e);
+      s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    } else {
+      for (int64_t k = e; k < n; ++k) s += g[k] * g[k];
+    }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(1024) void norm_finish_kernel(const float* __restrict__ part, int np, float* __restrict__ norm) {
+  __shared__ double red[16];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < np; i += 1024) s += (double)part[i];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < 16; ++i) t += red[i];
+    *norm = (float)sqrt(t);
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, const float* __restrict__ norm,
+                                                   float max_norm, float lr, float b1, float b2, float eps, float bc1,
+                                                   float bc2, float weight_decay) {
+  const float nv = *norm;
+  if (!(nv <= 3.0e38f)) return;  // NaN / inf gradient: skip the step (uniform)
+  const float c = max_norm > 0.f ? fminf(1.f, max_norm / (nv + 1e-6f)) : 1.f;
+  const float step = lr / bc1, rbc2 = 1.f / sqrtf(bc2);
+  const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e >= n) return;
+  if (e + 3 < n) {
+    float4 pv = *reinterpret_cast<float4*>(p + e), mv = *reinterpret_cast<float4*>(m + e), vv = *reinterpret_cast<float4*>(v + e);
+    const float4 gv = *reinterpret_cast<const float4*>(g + e);
+    float pa[4] = {pv.x, pv.y, pv.z, pv.w}, ma[4] = {mv.x, mv.y, mv.z, mv.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+    const float ga[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float gg = ga[q] * c + weight_decay * pa[q];
+      ma[q] = b1 * ma[q] + (1.f - b1) * gg;
+      va[q] = b2 * va[q] + (1.f - b2) * gg * gg;
+      pa[q] -= step * ma[q] / (sqrtf(va[q]) * rbc2 + eps);
+    }
+    *reinterpret_cast<float4*>(p + e) = make_float4(pa[0], pa[1], pa[2], pa[3]);
+    *reinterpret_cast<float4*>(m + e) = make_float4(ma[0], ma[1], ma[2], ma[3]);
+    *reinterpret_cast<float4*>(v + e) = make_float4(va[0], va[1], va[2], va[3]);
+  } else {
+    for (int64_t k = e; k < n; ++k) {
+      const float gg = g[k] * c + weight_decay * p[k];
+      m[k] = b1 * m[k] + (1.f - b1) * gg;
+      v[k] = b2 * v[k] + (1.f - b2) * gg * gg;
+      p[k] -= step * m[k] / (sqrtf(v[k]) * rbc2 + eps);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t csship_adam_clip_workspace(int64_t n) {
+  return (size_t)((n + SQ_ELEMS - 1) / SQ_ELEMS) * sizeof(float);
+}
+
+extern "C" int csship_adam_clip(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                float max_norm, float lr, float beta1, float beta2, float eps, int64_t step,
+                                float weight_decay, float* grad_norm, void* workspace, size_t workspace_bytes,
+                                csship_stream_t stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !grad_norm || !workspace) return CSSHIP_ENULL;
+  if (n <= 0 || step <= 0) return CSSHIP_EBADSHAPE;
+  if (!aligned16(params) || !aligned16(grads) || !aligned16(exp_avg) || !aligned16(exp_avg_sq)) return CSSHIP_EALIGN;
+  const int64_t np = (n + SQ_ELEMS - 1) / SQ_ELEMS;
+  if (workspace_bytes < (size_t)np * sizeof(float)) return CSSHIP_EWORKSPACE;
+  if (np > 0x7fffffff || (n + 1023) / 1024 > 0x7fffffff) return CSSHIP_EBADSHAPE;
+  hipStream_t s = as_stream(stream);
+  float* part = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)np), dim3(256), 0, s, grads, n, part);
+  CSSHIP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(norm_finish_kernel, dim3(1), dim3(1024), 0, s, part, (int)np, grad_norm);
+  CSSHIP_CHECK_LAUNCH();
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, n,
+                     grad_norm, max_norm, lr, beta1, beta2, eps, bc1, bc2, weight_decay);
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}

@@ -1,0 +1,73 @@
+"""Fused gradient clipping + Adam (csship_adam_clip) on flat parameter / gradient buffers.
+
+``FusedAdam`` re-homes every parameter of the model as a view into ONE flat f32 buffer and gives every parameter a
+persistent ``.grad`` view into a second one.  The step is then three kernel launches with no host synchronisation,
+and the flat gradient buffer is the all-reduce bucket of ``css_amd.parallel`` (no gather / scatter copies).
+It follows torch.optim.Adam's update rule and ``param_groups`` protocol (``LRScheduler`` sets ``group["lr"]``), so it
+drops into ``train_one_epoch`` in place of ``torch.optim.Adam`` + ``clip_grad_norm_``.
+"""
+import torch
+
+from ._lib import check, lib
+from .ops import _ptr, _stream
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=0.0):
+        params = [p for p in params]
+        if not params:
+            raise ValueError("FusedAdam got an empty parameter list")
+        if any((not p.is_cuda) or p.dtype != torch.float32 for p in params):
+            raise RuntimeError("css_amd.FusedAdam needs float32 parameters on the GPU (no CPU path exists)")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_norm=max_norm))
+        dev = params[0].device
+        offs, n = [], 0
+        for p in params:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4  # 16-byte aligned segments
+        self._n = n
+        self.flat_param = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grad_norm = torch.zeros((), dtype=torch.float32, device=dev)
+        self._ws = torch.empty(max(lib().csship_adam_clip_workspace(n), 16), dtype=torch.uint8, device=dev)
+        self._step = 0
+        with torch.no_grad():
+            for p, o in zip(params, offs):
+                seg = self.flat_param[o:o + p.numel()].view(p.shape)
+                seg.copy_(p.data)
+                p.data = seg
+                p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+
+    def zero_grad(self, set_to_none=False):
+        """Gradients stay views of the flat buffer (set_to_none is ignored): one fill."""
+        self.flat_grad.zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None, max_norm=None):
+        """Clip to ``max_norm`` (default: the constructor's; <= 0 disables) and apply one Adam step.
+        Returns the pre-clip gradient norm as a 0-dim device tensor (no synchronisation)."""
+        if closure is not None:
+            raise RuntimeError("css_amd.FusedAdam does not take a closure")
+        g = self.param_groups[0]
+        self._step += 1
+        mn = g["max_norm"] if max_norm is None else max_norm
+        check(lib().csship_adam_clip(_ptr(self.flat_param), _ptr(self.flat_grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
+                                     self._n, float(mn), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+                                     float(g["eps"]), self._step, float(g["weight_decay"]), _ptr(self.grad_norm),
+                                     _ptr(self._ws), self._ws.numel(), _stream()))
+        return self.grad_norm
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["fused"] = {"step": self._step, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq}
+        return sd
+
+    def load_state_dict(self, sd):
+        fused = sd.get("fused")
+        super().load_state_dict({k: v for k, v in sd.items() if k != "fused"})
+        if fused is not None:
+            self._step = int(fused["step"])
+            self.exp_avg.copy_(fused["exp_avg"])
+            self.exp_avg_sq.copy_(fused["exp_avg_sq"])

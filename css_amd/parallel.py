@@ -40,6 +40,15 @@ def allreduce_gradients(params, average=True):
         off += n
 
 
+def allreduce_flat(flat, average=True):
+    """The same on a gradient buffer that is already flat (css_amd.optim.FusedAdam.flat_grad): no copies."""
+    if not is_distributed():
+        return
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if average:
+        flat /= dist.get_world_size()
+
+
 def average_parameters(models_state_dicts):
     """combine_models.py:55-82 equivalent: elementwise mean of state dicts (scalar buffers keep dtype)."""
     n = len(models_state_dicts)

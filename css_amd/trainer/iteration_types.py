@@ -30,11 +30,15 @@ def train_one_epoch(args, generator, model, objective, optim, lr_sched, device="
         total_loss += loss_val
         loss.backward()
         del b
-        parallel.allreduce_gradients(model.parameters())
-        grad_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), args.grad_thresh)
+        if hasattr(optim, "flat_grad"):  # css_amd.optim.FusedAdam: the flat gradient buffer is the all-reduce bucket
+            parallel.allreduce_flat(optim.flat_grad)
+            grad_norm = optim.step(max_norm=args.grad_thresh)  # clip + Adam in one pass, norm stays on the device
+        else:
+            parallel.allreduce_gradients(model.parameters())
+            grad_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), args.grad_thresh)
+            optim.step()
         log += f"Grad_norm: {grad_norm.data.item():0.5f}"
         logging.info(log)
-        optim.step()
         optim.zero_grad()
         lr_sched.step(1.0)
     return total_loss / args.batches_per_epoch

@@ -409,6 +409,17 @@ int csship_lstm_bidir_train(const float* gx, const uint16_t* whh_packed, float* 
 int csship_lstm_bidir_bwd(const float* gates, const float* c, const float* dy, const uint16_t* whhT_packed,
                           float* dgates, int32_t B, int32_t T, int32_t H, csship_stream_t stream);
 
+/* ---- csship_adam_clip (css_amd/csrc/optim.hip): clip_grad_norm_(max_norm) followed by one Adam step
+ * (iteration_types.py:17-64) on FLAT f32 buffers of n elements (parameters, gradients, first and second moments), in
+ * three launches with no host round trip.  grad_norm (device f32) receives the total 2-norm before clipping; a
+ * non-finite norm skips the update.  max_norm <= 0 disables clipping; step is the 1-based Adam step count;
+ * weight_decay is torch.optim.Adam's L2 form. */
+size_t csship_adam_clip_workspace(int64_t n);
+int csship_adam_clip(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                     float max_norm, float lr, float beta1, float beta2, float eps, int64_t step,
+                     float weight_decay, float* grad_norm, void* workspace, size_t workspace_bytes,
+                     csship_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

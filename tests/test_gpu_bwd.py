@@ -288,3 +288,33 @@ def test_convmod_backward(ob):
                 assert float(grads[k].abs().max()) < 1e-5
             else:
                 assert relerr(grads[k], v) < 2e-4, k
+
+
+def test_fused_adam_clip_matches_torch():
+    """csship_adam_clip (clip_grad_norm_ + Adam on flat buffers) vs torch.optim.Adam + clip_grad_norm_, 5 steps,
+    clipping active on some steps; and the non-finite-gradient guard."""
+    from css_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    shapes = [(257, 33), (1000,), (3, 5, 7), (1,), (64, 64)]
+    ref = [torch.nn.Parameter(rnd(s, 70 + i).to(DEV)) for i, s in enumerate(shapes)]
+    mine = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    o_ref = torch.optim.Adam(ref, lr=3e-3, betas=(0.9, 0.98), eps=1e-8)
+    o_mine = FusedAdam(mine, lr=3e-3, betas=(0.9, 0.98), eps=1e-8)
+    for step in range(5):
+        scale = 10.0 if step % 2 == 0 else 0.01   # norm above / below the threshold
+        for i, (a, b) in enumerate(zip(ref, mine)):
+            g = rnd(a.shape, 100 + 10 * step + i, scale).to(DEV)
+            a.grad = g.clone()
+            b.grad.copy_(g)
+        n_ref = torch.nn.utils.clip_grad_norm_(ref, 5.0)
+        o_ref.step()
+        n_mine = o_mine.step(max_norm=5.0)
+        assert abs(float(n_ref) - float(n_mine)) < 1e-4 * float(n_ref)
+        for a, b in zip(ref, mine):
+            assert float((a - b).abs().max()) < 2e-6
+        o_mine.zero_grad()
+        assert all(float(b.grad.abs().max()) == 0.0 for b in mine)
+    before = [b.detach().clone() for b in mine]
+    mine[0].grad[0, 0] = float("nan")
+    o_mine.step(max_norm=5.0)
+    assert all(torch.equal(x, b.detach()) for x, b in zip(before, mine))   # skipped

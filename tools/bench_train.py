@@ -14,6 +14,7 @@ from css_amd.utils import synthetic as syn  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--twin", action="store_true")
+ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam + clip_grad_norm_ instead of FusedAdam")
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--blocks", type=int, default=16)
 a = ap.parse_args()
@@ -25,16 +26,24 @@ m.load_state_dict(syn.fill_state_dict(syn.conformer_shapes(num_blocks=a.blocks),
 m = m.to(dev).train()
 m.force_twin_backward = a.twin
 obj = OBJECTIVES["MSE"].build_objective({})
-opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+if a.torch_adam:
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+else:
+    from css_amd.optim import FusedAdam
+    opt = FusedAdam(m.parameters(), lr=1e-4, max_norm=5.0)
 g = torch.Generator().manual_seed(0)
 batch = {k: (torch.rand((32, 400, 257), generator=g) * s).to(dev) for k, s in (("mix", 1.0), ("source1", 0.5), ("source2", 0.5))}
 
 
 def step():
-    opt.zero_grad(set_to_none=True)
+    if a.torch_adam:
+        opt.zero_grad(set_to_none=True)
+    else:
+        opt.zero_grad()
     loss = obj(m, batch, device=dev)
     loss.backward()
-    torch.nn.utils.clip_grad_norm_(m.parameters(), 5.0)
+    if a.torch_adam:
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 5.0)
     opt.step()
     return loss
 
