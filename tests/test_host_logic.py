@@ -147,6 +147,11 @@ lo, hi = parallel.shard_range(8, rank, ws)
 model.zero_grad(); torch.nn.functional.mse_loss(model(data[lo:hi]), tgt[lo:hi]).backward()
 parallel.allreduce_gradients(model.parameters(), average=True)
 ok = all(torch.allclose(p.grad, r, atol=1e-6) for p, r in zip(model.parameters(), ref))
+# the same through an already-flat gradient buffer (what css_amd.optim.FusedAdam hands to the collective)
+model.zero_grad(); torch.nn.functional.mse_loss(model(data[lo:hi]), tgt[lo:hi]).backward()
+flat = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+parallel.allreduce_flat(flat, average=True)
+ok = ok and torch.allclose(flat, torch.cat([r.reshape(-1) for r in ref]), atol=1e-6)
 # window gather
 local = torch.arange(lo, hi, dtype=torch.float32)[:, None].repeat(1, 3)
 full = parallel.gather_windows(local, 8, rank, ws)
