@@ -78,6 +78,8 @@ SIGNATURES = {
     "csship_encoder_chain": (_i32, [_p, _p, _p, C.POINTER(ConvWeights), _i32, C.POINTER(FfnWeights), _p, _p,
                                      C.POINTER(FfnWeights), _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "csship_mha_relpos": (_i32, [_p, _p, _i32, _i32, _p, _i32, _i32, _i32, _p]),
+    "csship_mha_relpos_train": (_i32, [_p, _p, _i32, _i32, _p, _p, _i32, _i32, _i32, _p]),
+    "csship_mha_relpos_probs": (_i32, [_p, _p, _i32, _i32, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "csship_convmod_workspace": (_sz, [_i32, _i32, _i32]),
     "csship_convmod": (_i32, [_p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _i32, _p, _p]),
     "csship_conv_from_glu": (_i32, [_p, _p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _p]),

@@ -83,6 +83,7 @@ class ConformerTrain(torch.autograd.Function):
         pe = enc.pos_emb.pe_k.weight.detach()
         pe_pack = ops.pack_relpos(pe, enc.pos_emb.maxlen)
         S["pe_bf"] = pe.to(BF)
+        S["pe_pack"] = pe_pack
         for lay in enc.encoders:
             L = {}
 
@@ -105,9 +106,10 @@ class ConformerTrain(torch.autograd.Function):
             wo_bf, wo_p = ob.pack_weight(a.linear_out.weight.detach(), want_row_major=True, want_frag=True)
             qkv = ops.panel_linear(x1, wqkv_p, bqkv, 3 * D,
                                    ln=(a.layer_norm.weight.detach(), a.layer_norm.bias.detach()), out_bf16=True)
-            ao = ops.mha_relpos(qkv.view(B, T, 3 * D), pe_pack, H).view(M, D)
+            ao, lse = ops.mha_relpos_train(qkv.view(B, T, 3 * D), pe_pack, H)
+            ao = ao.view(M, D)
             x2 = ops.panel_linear(ao, wo_p, a.linear_out.bias.detach(), D, residual=x1)
-            L["mha"] = (x1, qkv, ao, wqkv_bf, wo_bf, scale)
+            L["mha"] = (x1, qkv, ao, wqkv_bf, wo_bf, scale, lse)
             c = lay.conv
             W = {"ln_g": c.layer_norm.weight.detach(), "ln_b": c.layer_norm.bias.detach(),
                  "pw1_w": c.pw_conv_1.weight.detach().view(2), "pw1_b": c.pw_conv_1.bias.detach(),
@@ -183,10 +185,11 @@ class ConformerTrain(torch.autograd.Function):
             put(c.dw_conv_1d.weight, g["dw_w"].t()), put(c.dw_conv_1d.bias, g["dw_b"])
             put(c.BN.weight, g["bn_g"]), put(c.BN.bias, g["bn_b"])
             put(c.pw_conv_2.weight, g["pw2_w"]), put(c.pw_conv_2.bias, g["pw2_b"])
-            x1, qkv, ao, wqkv_bf, wo_bf, scale = L["mha"]
+            x1, qkv, ao, wqkv_bf, wo_bf, scale, lse = L["mha"]
             a = lay.self_attn
             dx, g = bw.mha_bwd(x1, dx, qkv.view(B, T, 3 * D), ao, a.layer_norm.weight.detach(),
-                               a.layer_norm.bias.detach(), wqkv_bf, wo_bf, S["pe_bf"], H, scale, window=window)
+                               a.layer_norm.bias.detach(), wqkv_bf, wo_bf, S["pe_bf"], H, scale, window=window,
+                               probs=(S["pe_pack"], lse))
             dg, dbeta, dwqkv, dbqkv, dwo, dbo, dw_l = g
             dwin = dw_l if dwin is None else dwin.add_(dw_l)
             put(a.layer_norm.weight, dg), put(a.layer_norm.bias, dbeta)

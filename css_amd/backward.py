@@ -52,7 +52,7 @@ def relpos_window(pe_table_bf, T, maxlen):
     return win, idx
 
 
-def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000, window=None):
+def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000, window=None, probs=None):
     """Backward of o = softmax(q k^T + q pe[i-j]^T) v (conformer.py:229-253; q already carries 1/sqrt(d_k)).
 
     qkv: bf16 [B, T, 3*H*64]; dao: bf16 [B*T, H*64] (gradient of the head-concatenated output).
@@ -65,9 +65,12 @@ def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000, window=None):
     q, k, v = (g[:, :, i].permute(0, 2, 1, 3) for i in range(3))  # [B,H,T,64] strided views
     win, idx = relpos_window(pe_table_bf, T, maxlen) if window is None else window
     W = win.shape[0]
-    s = ob.bgemm(q, k)                                   # q k^T            [B,H,T,T]
-    rel = ob.bgemm(q, win[None, None])                   # q pe_window^T    [B,H,T,W]
-    p = ob.relpos_softmax(s, rel, T)                     # bf16 [B,H,T,Tp]
+    if probs is not None:   # (pe_pack, lse) from the training forward: one attention-shaped kernel recomputes P
+        p = ops.mha_relpos_probs(qkv, probs[0], probs[1], H)
+    else:                   # generic route: materialise the scores and the window products, then a row softmax
+        s = ob.bgemm(q, k)                               # q k^T            [B,H,T,T]
+        rel = ob.bgemm(q, win[None, None])               # q pe_window^T    [B,H,T,W]
+        p = ob.relpos_softmax(s, rel, T)                 # bf16 [B,H,T,Tp]
     do = dao.view(B, T, H, 64).permute(0, 2, 1, 3)
     dp = ob.bgemm(do, v)                                 # dO v^T           [B,H,T,T]
     ds, dsk = ob.relpos_softmax_bwd(p, dp, T, W)         # dS, and dS skewed onto the window axis [B,T,H,W]
@@ -86,7 +89,7 @@ def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000, window=None):
     return dqkv, dpe
 
 
-def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_scale=0.125, window=None):
+def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_scale=0.125, window=None, probs=None):
     """out = x + attention(LN(x)) @ wo^T + bo  (conformer.py:213-254,356).
 
     wqkv_bf holds the q rows already multiplied by q_scale (as the forward uses them); the returned dwqkv / dbqkv are
@@ -96,7 +99,7 @@ def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_s
     D = x.shape[1]
     dao, dwo, dbo = linear_bwd(dy, ao, wo_bf, dx_bf16=True)
     B = qkv.shape[0]
-    dqkv, dpe = mha_core_bwd(qkv, dao, pe_table_bf, n_head, window=window)
+    dqkv, dpe = mha_core_bwd(qkv, dao, pe_table_bf, n_head, window=window, probs=probs)
     dq2 = dqkv.view(-1, 3 * D)
     a, _ = ops.layernorm(x, ln_g, ln_b)
     dw = torch.empty((3 * D, D), dtype=torch.float32, device=x.device)

@@ -34,10 +34,15 @@ DEV int v_off(int row, int chunk) {  // 16-byte chunk of a 128-byte V row; 32-by
   return row * 128 + ((((chunk >> 1) ^ ((row >> 1) & 3)) << 1) | (chunk & 1)) * 16;
 }
 
+// PROBS = false: the attention itself (optionally also the per-row log-sum-exp, for the backward pass).
+// PROBS = true: no P.V; the normalised probabilities P[b,h,i,j] = exp(score - lse[b,h,i]) are written out as bf16
+// [B,H,T,ldp] - the backward's recomputation of the softmax, with the same band machinery and no [T,T] f32 buffers.
+template <bool PROBS>
 __global__ __launch_bounds__(256, 4) void mha_relpos_kernel(const unsigned short* __restrict__ qkv,
                                                          const bf16x8* __restrict__ pe_packed, int q_min, int q_max,
                                                          unsigned short* __restrict__ out, int B, int T, int H,
-                                                            unsigned long long* stamps) {
+                                                            unsigned long long* stamps, float* __restrict__ lse,
+                                                            int64_t ldp) {
   __shared__ __attribute__((aligned(16))) unsigned char sK[64 * 128];
   __shared__ __attribute__((aligned(16))) unsigned char sV[64 * 128];
   __shared__ __attribute__((aligned(16))) float sP[4 * 16 * PS];
@@ -77,16 +82,20 @@ __global__ __launch_bounds__(256, 4) void mha_relpos_kernel(const unsigned short
       s1_ = qkv + (base_b + min((J0) + srow1, T - 1)) * D3 + h * 64 + sc * 8 + D;                         \
     }                                                                                                     \
     kreg0 = *reinterpret_cast<const uint4*>(s0_);                                                         \
-    vreg0 = *reinterpret_cast<const uint4*>(s0_ + D);                                                     \
     kreg1 = *reinterpret_cast<const uint4*>(s1_);                                                         \
-    vreg1 = *reinterpret_cast<const uint4*>(s1_ + D);                                                     \
+    if constexpr (!PROBS) {                                                                               \
+      vreg0 = *reinterpret_cast<const uint4*>(s0_ + D);                                                   \
+      vreg1 = *reinterpret_cast<const uint4*>(s1_ + D);                                                   \
+    }                                                                                                     \
   }
 #define ATTN_STORE_KV()                                                       \
   {                                                                           \
     *reinterpret_cast<uint4*>(sK + tile_off(srow0, sc)) = kreg0;              \
     *reinterpret_cast<uint4*>(sK + tile_off(srow1, sc)) = kreg1;              \
-    *reinterpret_cast<uint4*>(sV + v_off(srow0, sc)) = vreg0;                 \
-    *reinterpret_cast<uint4*>(sV + v_off(srow1, sc)) = vreg1;                 \
+    if constexpr (!PROBS) {                                                   \
+      *reinterpret_cast<uint4*>(sV + v_off(srow0, sc)) = vreg0;               \
+      *reinterpret_cast<uint4*>(sV + v_off(srow1, sc)) = vreg1;               \
+    }                                                                         \
   }
   // band fragments of key tile j0: band tile t covers rel = 16*q + 15 - m, q = (i0w - j0)/16 - t (scalar)
   bf16x8 pf0[5], pf1[5];
@@ -104,6 +113,8 @@ __global__ __launch_bounds__(256, 4) void mha_relpos_kernel(const unsigned short
 #pragma unroll
   for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -1e30f, l_run = 0.f;
+  float lse2 = 0.f;  // PROBS: this lane's query log-sum-exp in log2 units
+  if constexpr (PROBS) lse2 = lse[((size_t)b * H + h) * T + min(i0w + n, T - 1)] * LOG2E;
   float* Pw = sP + w * 16 * PS;
   const float* Pr = Pw + n * PS + 15 - n + 4 * g;  // this lane's skewed read base: + 16t + r
   const int q4 = n >> 2, p4 = n & 3;
@@ -158,6 +169,20 @@ __global__ __launch_bounds__(256, 4) void mha_relpos_kernel(const unsigned short
       asm volatile("" ::: "memory");
     }
 
+    if constexpr (PROBS) {  // P = exp(score - lse), 4 consecutive keys per store; the T tail is exactly 0
+      const int qi_ = i0w + n;
+      if (qi_ < T) {
+        unsigned short* prow = out + (((size_t)b * H + h) * T + qi_) * ldp + j0 + 4 * g;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if (j0 + 16 * t + 4 * g + 3 < ldp) {
+            uint2 v;
+            v.x = pack_bf2(__builtin_amdgcn_exp2f(s[t][0] * LOG2E - lse2), __builtin_amdgcn_exp2f(s[t][1] * LOG2E - lse2));
+            v.y = pack_bf2(__builtin_amdgcn_exp2f(s[t][2] * LOG2E - lse2), __builtin_amdgcn_exp2f(s[t][3] * LOG2E - lse2));
+            *reinterpret_cast<uint2*>(prow + 16 * t) = v;
+          }
+      }
+    } else {
     // ---- online softmax (query i = lane&15; keys spread over regs and g)
     float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
 #pragma unroll
@@ -205,6 +230,7 @@ __global__ __launch_bounds__(256, 4) void mha_relpos_kernel(const unsigned short
         o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), pbf, o[dt], 0, 0, 0);
       }
     }
+    }  // !PROBS
 
     if (more) {
       ATTN_LOAD_PE(pf0, 0, j0 + 64)  // first half of the next tile's band operands; lands during the barriers
@@ -216,11 +242,13 @@ __global__ __launch_bounds__(256, 4) void mha_relpos_kernel(const unsigned short
   }
 
   stamp(stamps, 2);
+  if constexpr (PROBS) return;
   float l = l_run;
   l += __shfl_xor(l, 16);
   l += __shfl_xor(l, 32);
   const float inv = 1.f / l;
   const int qi = i0w + n;
+  if (lse != nullptr && qi < T && g == 0) lse[((size_t)b * H + h) * T + qi] = m_run + __logf(l);
   if (qi < T) {
     unsigned short* orow = out + (base_b + qi) * D + h * 64;
 #pragma unroll
@@ -241,8 +269,36 @@ extern "C" int csship_mha_relpos(const uint16_t* qkv, const uint16_t* pe_packed,
   if (B <= 0 || T <= 0 || H <= 0 || q_max < q_min || B > 65535 || H > 65535) return CSSHIP_EBADSHAPE;
   if (!aligned16(qkv) || !aligned16(pe_packed) || !aligned8(out)) return CSSHIP_EALIGN;
   dim3 grid((T + 63) / 64, H, B);
-  hipLaunchKernelGGL(mha_relpos_kernel, grid, dim3(256), 0, as_stream(stream), qkv,
-                     reinterpret_cast<const bf16x8*>(pe_packed), q_min, q_max, out, B, T, H, g_csship_stamps);
+  hipLaunchKernelGGL(mha_relpos_kernel<false>, grid, dim3(256), 0, as_stream(stream), qkv,
+                     reinterpret_cast<const bf16x8*>(pe_packed), q_min, q_max, out, B, T, H, g_csship_stamps, nullptr,
+                     (int64_t)0);
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
+extern "C" int csship_mha_relpos_train(const uint16_t* qkv, const uint16_t* pe_packed, int32_t q_min, int32_t q_max,
+                                       uint16_t* out, float* lse, int32_t B, int32_t T, int32_t H,
+                                       csship_stream_t stream) {
+  if (!qkv || !pe_packed || !out || !lse) return CSSHIP_ENULL;
+  if (B <= 0 || T <= 0 || H <= 0 || q_max < q_min || B > 65535 || H > 65535) return CSSHIP_EBADSHAPE;
+  if (!aligned16(qkv) || !aligned16(pe_packed) || !aligned8(out)) return CSSHIP_EALIGN;
+  dim3 grid((T + 63) / 64, H, B);
+  hipLaunchKernelGGL(mha_relpos_kernel<false>, grid, dim3(256), 0, as_stream(stream), qkv,
+                     reinterpret_cast<const bf16x8*>(pe_packed), q_min, q_max, out, B, T, H, nullptr, lse, (int64_t)0);
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
+extern "C" int csship_mha_relpos_probs(const uint16_t* qkv, const uint16_t* pe_packed, int32_t q_min, int32_t q_max,
+                                       const float* lse, uint16_t* p_bf16, int64_t ld_p, int32_t B, int32_t T, int32_t H,
+                                       csship_stream_t stream) {
+  if (!qkv || !pe_packed || !lse || !p_bf16) return CSSHIP_ENULL;
+  if (B <= 0 || T <= 0 || H <= 0 || q_max < q_min || B > 65535 || H > 65535 || ld_p < T) return CSSHIP_EBADSHAPE;
+  if (!aligned16(qkv) || !aligned16(pe_packed) || !aligned8(p_bf16) || (ld_p % 4) != 0) return CSSHIP_EALIGN;
+  dim3 grid((T + 63) / 64, H, B);
+  hipLaunchKernelGGL(mha_relpos_kernel<true>, grid, dim3(256), 0, as_stream(stream), qkv,
+                     reinterpret_cast<const bf16x8*>(pe_packed), q_min, q_max, p_bf16, B, T, H, nullptr,
+                     const_cast<float*>(lse), ld_p);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }

@@ -185,6 +185,32 @@ def mha_relpos(qkv, pe_pack, n_head):
     return out
 
 
+def mha_relpos_train(qkv, pe_pack, n_head):
+    """mha_relpos that also returns the per-row log-sum-exp f32 [B,H,T] (saved for the backward)."""
+    _need(qkv, torch.bfloat16, "qkv")
+    packed, q_min, q_max = pe_pack
+    B, T, D3 = qkv.shape
+    assert qkv.is_contiguous() and D3 == 3 * n_head * 64
+    out = torch.empty(B, T, n_head * 64, device=qkv.device, dtype=torch.bfloat16)
+    lse = torch.empty(B, n_head, T, device=qkv.device, dtype=torch.float32)
+    check(lib().csship_mha_relpos_train(_ptr(qkv), _ptr(packed), q_min, q_max, _ptr(out), _ptr(lse), B, T, n_head,
+                                        _stream()))
+    return out, lse
+
+
+def mha_relpos_probs(qkv, pe_pack, lse, n_head):
+    """softmax probabilities bf16 [B,H,T,pad8(T)] recomputed from q, k, the packed position table and lse."""
+    _need(qkv, torch.bfloat16, "qkv"), _need(lse, torch.float32, "lse")
+    packed, q_min, q_max = pe_pack
+    B, T, D3 = qkv.shape
+    assert qkv.is_contiguous() and lse.is_contiguous() and D3 == 3 * n_head * 64
+    ldp = (T + 7) // 8 * 8
+    p = torch.empty(B, n_head, T, ldp, device=qkv.device, dtype=torch.bfloat16)
+    check(lib().csship_mha_relpos_probs(_ptr(qkv), _ptr(packed), q_min, q_max, _ptr(lse), _ptr(p), ldp, B, T, n_head,
+                                        _stream()))
+    return p
+
+
 def conv_weights_struct(t):
     """t: dict of f32 CUDA tensors keyed like _lib.ConvWeights fields."""
     cw = _lib.ConvWeights()

@@ -349,6 +349,16 @@ size_t csship_colsum_workspace(int64_t M, int32_t N);
 int csship_colsum(const void* x, int32_t x_is_f32, int64_t M, int32_t N, int64_t ld, float alpha, float* out,
                   void* workspace, size_t workspace_bytes, csship_stream_t stream);
 
+/* ---- attention, training (css_amd/csrc/attn.hip).  csship_mha_relpos_train = csship_mha_relpos that also returns
+ * lse[b, h, i] = log sum_j exp(score[i, j]) (f32 [B, H, T]).  csship_mha_relpos_probs recomputes the softmax for the
+ * backward pass: p[b, h, i, j] = exp(score[i, j] - lse[b, h, i]) as bf16 [B, H, T, ld_p] (ld_p >= T, ld_p % 4 == 0;
+ * columns T..ld_p-1 are written as exact zeros up to the last multiple of 4 below ld_p). */
+int csship_mha_relpos_train(const uint16_t* qkv, const uint16_t* pe_packed, int32_t q_min, int32_t q_max,
+                            uint16_t* out, float* lse, int32_t B, int32_t T, int32_t H, csship_stream_t stream);
+int csship_mha_relpos_probs(const uint16_t* qkv, const uint16_t* pe_packed, int32_t q_min, int32_t q_max,
+                            const float* lse, uint16_t* p_bf16, int64_t ld_p, int32_t B, int32_t T, int32_t H,
+                            csship_stream_t stream);
+
 /* ---- row kernels of the backward pass (css_amd/csrc/bwd.hip)
  * csship_layernorm_bwd: y = LayerNorm(x) [then ReLU if relu != 0]; given dy returns dx (+ dx_add, may alias dx or dy)
  * and dgamma_dbeta = f32 [2, D] (dgamma row, dbeta row).  D <= 1024 (vector path for 256 / 512 / 1024); x, dy, dx

@@ -318,3 +318,28 @@ def test_fused_adam_clip_matches_torch():
     mine[0].grad[0, 0] = float("nan")
     o_mine.step(max_norm=5.0)
     assert all(torch.equal(x, b.detach()) for x, b in zip(before, mine))   # skipped
+
+
+def test_attention_probs_recompute(ob):
+    """csship_mha_relpos_train's log-sum-exp and csship_mha_relpos_probs' P vs the materialised route
+    (q k^T + window GEMM + row softmax), incl. a T that is not a multiple of the 64-key tile."""
+    from css_amd import backward as bw, ops
+    for B, T, H in ((2, 90, 4), (1, 200, 8)):
+        qkv = rnd((B, T, 3 * H * 64), 81, 0.6).to(DEV).to(torch.bfloat16)
+        pe = rnd((2000, 64), 82, 0.3).to(DEV)
+        pack = ops.pack_relpos(pe)
+        ao0 = ops.mha_relpos(qkv, pack, H)
+        ao, lse = ops.mha_relpos_train(qkv, pack, H)
+        assert torch.equal(ao0, ao)
+        p = ops.mha_relpos_probs(qkv, pack, lse, H)
+        g = qkv.view(B, T, 3, H, 64)
+        q, k = (g[:, :, i].permute(0, 2, 1, 3) for i in range(2))
+        win, _ = bw.relpos_window(pe.to(torch.bfloat16), T, 1000)
+        s = ob.bgemm(q, k)
+        rel = ob.bgemm(q, win[None, None])
+        pref = ob.relpos_softmax(s, rel, T)
+        assert float((p[..., :T].float() - pref[..., :T].float()).abs().max()) < 4e-3   # bf16 ulp of values <= 1
+        assert float(p[..., T:].float().abs().max()) == 0.0 if p.shape[3] > T else True
+        # lse against float64
+        sc = s.double().cpu() + torch.stack([rel.double().cpu()[:, :, i, i + T - 1 - torch.arange(T)] for i in range(T)], 2)
+        assert float((lse.double().cpu() - torch.logsumexp(sc, -1)).abs().max()) < 2e-3
