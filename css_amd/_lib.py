@@ -78,6 +78,8 @@ SIGNATURES = {
     "csship_encoder_chain": (_i32, [_p, _p, _p, C.POINTER(ConvWeights), _i32, C.POINTER(FfnWeights), _p, _p,
                                      C.POINTER(FfnWeights), _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "csship_mha_relpos": (_i32, [_p, _p, _i32, _i32, _p, _i32, _i32, _i32, _p]),
+    "csship_ffn_bwd_workspace": (_sz, [_i32]),
+    "csship_ffn_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _p, _sz, _p]),
     "csship_mha_relpos_train": (_i32, [_p, _p, _i32, _i32, _p, _p, _i32, _i32, _i32, _p]),
     "csship_mha_relpos_probs": (_i32, [_p, _p, _i32, _i32, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "csship_convmod_workspace": (_sz, [_i32, _i32, _i32]),
@@ -105,7 +107,7 @@ SIGNATURES = {
     "csship_lstm_bidir_train": (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p]),
     "csship_lstm_bidir_bwd": (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p]),
     "csship_adam_clip_workspace": (_sz, [_i64]),
-    "csship_adam_clip": (_i32, [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _f32, _p, _p, _sz, _p]),
+    "csship_adam_clip": (_i32, [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _f32, _p, _p, _p, _sz, _p]),
     "csship_conformer_workspace": (_sz, [C.POINTER(ConformerWeights), _i32, _i32]),
     "csship_conformer_forward": (_i32, [C.POINTER(ConformerWeights), _p, _i64, _i32, _i32, _p, _i64, _p, _p, _sz, _p]),
 }

@@ -88,9 +88,13 @@ class ConformerTrain(torch.autograd.Function):
             L = {}
 
             def ffn(m, xin, tag):
-                w1_bf, w1p = ob.pack_weight(m.net[0].weight.detach(), want_row_major=True, want_frag=True)
-                w2_bf, w2p = ob.pack_weight(m.net[3].weight.detach(), want_row_major=True, want_frag=True)
-                L[tag] = (xin, w1_bf, w2_bf)
+                w1, w2 = m.net[0].weight.detach(), m.net[3].weight.detach()
+                _, w1p = ob.pack_weight(w1, want_frag=True)
+                _, w2p = ob.pack_weight(w2, want_frag=True)
+                # fragment-packed transposes for the fused backward kernel
+                _, w1tp = ob.pack_weight(w1.t().contiguous(), want_frag=True)
+                _, w2tp = ob.pack_weight(w2.t().contiguous(), want_frag=True)
+                L[tag] = (xin, w1p, w2tp, w1tp)
                 return ops.ffn_fused(xin, (m.layer_norm.weight.detach(), m.layer_norm.bias.detach()), w1p,
                                      m.net[0].bias.detach(), w2p, m.net[3].bias.detach(), FF, 0.5)
 
@@ -167,9 +171,9 @@ class ConformerTrain(torch.autograd.Function):
             put(lay.layer_norm.weight, dg), put(lay.layer_norm.bias, dbeta)
 
             def ffn_b(m, tag, dy):
-                xin, w1_bf, w2_bf = L[tag]
-                dxo, g = bw.ffn_bwd(xin, dy, m.layer_norm.weight.detach(), m.layer_norm.bias.detach(),
-                                    m.net[0].bias.detach(), w1_bf, w2_bf, 0.5)
+                xin, w1p, w2tp, w1tp = L[tag]
+                dxo, g = bw.ffn_bwd_fused(xin, dy, m.layer_norm.weight.detach(), m.layer_norm.bias.detach(),
+                                          m.net[0].bias.detach(), w1p, w2tp, w1tp, enc.d_ffn, 0.5)
                 for p, gv in zip((m.layer_norm.weight, m.layer_norm.bias, m.net[0].weight, m.net[0].bias,
                                   m.net[3].weight, m.net[3].bias), g):
                     put(p, gv)

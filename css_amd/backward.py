@@ -42,6 +42,18 @@ def ffn_bwd(x, dy, ln_g, ln_b, b1, w1_bf, w2_bf, alpha=0.5):
     return dx, (dg, dbeta, dw1, db1, dw2, db2)
 
 
+def ffn_bwd_fused(x, dy, ln_g, ln_b, b1, w1p, w2tp, w1tp, d_ffn, alpha=0.5):
+    """ffn_bwd with the activation side in ONE row-panel kernel (d_model = 256): LN + hidden recompute, masked dh,
+    da and the LayerNorm backward never leave the CU; the four weight / bias gradients are GEMMs / column sums over
+    the B*T rows.  w1p / w2tp / w1tp: fragment-packed W1, W2^T, W1^T."""
+    dx, dg, dbeta, a, h, dh = ob.ffn_bwd(x, dy, ln_g, ln_b, w1p, b1, w2tp, w1tp, d_ffn, alpha)
+    dw2 = ob.bgemm(dy, h, a_kmajor=True, b_kmajor=True, alpha=alpha)
+    db2 = ob.colsum(dy, alpha)
+    dw1 = ob.bgemm(dh, a, a_kmajor=True, b_kmajor=True)
+    db1 = ob.colsum(dh)
+    return dx, (dg, dbeta, dw1, db1, dw2, db2)
+
+
 def relpos_window(pe_table_bf, T, maxlen):
     """rows of the relative-position table seen by a length-T sequence: window[r] = pe[clamp(r - (T-1)) + maxlen]
     (conformer.py:157-159,179-185), zero padded to a multiple of 8 rows.  Returns (window bf16 [W, d_k], index)."""

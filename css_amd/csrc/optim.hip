@@ -48,7 +48,12 @@ __global__ __launch_bounds__(1024) void norm_finish_kernel(const float* __restri
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, const float* __restrict__ norm,
                                                    float max_norm, float lr, float b1, float b2, float eps, float bc1,
-                                                   float bc2, float weight_decay) {
+                                                   float bc2, float weight_decay, const float* __restrict__ hyper) {
+  if (hyper) {  // {lr, 1 - beta1^t, 1 - beta2^t} from device memory: a captured graph is replayed with new values
+    lr = hyper[0];
+    bc1 = hyper[1];
+    bc2 = hyper[2];
+  }
   const float nv = *norm;
   if (!(nv <= 3.0e38f)) return;  // NaN / inf gradient: skip the step (uniform)
   const float c = max_norm > 0.f ? fminf(1.f, max_norm / (nv + 1e-6f)) : 1.f;
@@ -88,10 +93,10 @@ extern "C" size_t csship_adam_clip_workspace(int64_t n) {
 
 extern "C" int csship_adam_clip(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                                 float max_norm, float lr, float beta1, float beta2, float eps, int64_t step,
-                                float weight_decay, float* grad_norm, void* workspace, size_t workspace_bytes,
-                                csship_stream_t stream) {
+                                float weight_decay, const float* hyper_dev, float* grad_norm, void* workspace,
+                                size_t workspace_bytes, csship_stream_t stream) {
   if (!params || !grads || !exp_avg || !exp_avg_sq || !grad_norm || !workspace) return CSSHIP_ENULL;
-  if (n <= 0 || step <= 0) return CSSHIP_EBADSHAPE;
+  if (n <= 0 || (step <= 0 && !hyper_dev)) return CSSHIP_EBADSHAPE;
   if (!aligned16(params) || !aligned16(grads) || !aligned16(exp_avg) || !aligned16(exp_avg_sq)) return CSSHIP_EALIGN;
   const int64_t np = (n + SQ_ELEMS - 1) / SQ_ELEMS;
   if (workspace_bytes < (size_t)np * sizeof(float)) return CSSHIP_EWORKSPACE;
@@ -102,9 +107,9 @@ extern "C" int csship_adam_clip(float* params, const float* grads, float* exp_av
   CSSHIP_CHECK_LAUNCH();
   hipLaunchKernelGGL(norm_finish_kernel, dim3(1), dim3(1024), 0, s, part, (int)np, grad_norm);
   CSSHIP_CHECK_LAUNCH();
-  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  const float bc1 = step > 0 ? 1.f - powf(beta1, (float)step) : 1.f, bc2 = step > 0 ? 1.f - powf(beta2, (float)step) : 1.f;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, n,
-                     grad_norm, max_norm, lr, beta1, beta2, eps, bc1, bc2, weight_decay);
+                     grad_norm, max_norm, lr, beta1, beta2, eps, bc1, bc2, weight_decay, hyper_dev);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }

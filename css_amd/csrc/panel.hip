@@ -294,6 +294,222 @@ __global__ __launch_bounds__(NW * 64) void ffn_kernel(FfnArgs a) {
   stamp(a.stamps, 5);
 }
 
+// =============================================================================== fused FFN backward (dX side)
+// out = x + alpha * (relu(LN(x) W1^T + b1) W2^T + b2)  (ffn_kernel above).  Given dy = d(out), ONE kernel per row panel
+//   a  = LN(x)                                  -> Xs (bf16 panel) and global a_bf   (operand of dW1 = dh^T a)
+//   per hidden chunk c (three MFMA passes, weights streamed like the forward):
+//     h  = relu(a W1_c^T + b1_c)                -> global h_bf (operand of dW2 = dy^T h); its sign = the ReLU mask
+//     dh = alpha * (dy W2[:, c]) o [h > 0]      -> LDS hidden panel (bf16) and global dh_bf (operand of dW1, db1)
+//     da += dh W1_c
+//   dx = dy + LayerNorm-backward(da) in the staged row epilogue; dgamma / dbeta partials per workgroup.
+// Replaces, per FeedForward: LayerNorm + tiled GEMM (h recompute) + two tiled backward GEMMs + the LayerNorm-backward
+// kernel.  The weight-gradient GEMMs (reductions over the B*T rows) stay in csship_bgemm.
+struct FfnBwdArgs {
+  const float* x;
+  const float* dy;
+  const float *ln_g, *ln_b;
+  const bf16x8* w1;   // packed from W1  [FF, 256]  (as the forward)
+  const float* b1;
+  const bf16x8* w2t;  // packed from W2^T [FF, 256]
+  const bf16x8* w1t;  // packed from W1^T [256, FF]
+  unsigned short* a_bf;   // [M, 256]
+  unsigned short* h_bf;   // [M, FF]
+  unsigned short* dh_bf;  // [M, FF]
+  float* dx;              // [M, 256]
+  float* part;            // [nwg][2][256]  dgamma | dbeta partial sums
+  int M, FF;
+  float alpha;
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
+  static_assert(NW * 64 == 8 * BM, "row phases assume 8 lanes per panel row");
+  constexpr int NT = 16 / NW;
+  __shared__ __attribute__((aligned(16))) unsigned char XD[2 * PANEL_BYTES];  // a = LN(x) | alpha * dy; later 64 KB of sums
+  unsigned char* const Xs = XD;
+  unsigned char* const Ds = XD + PANEL_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char Graw[2 * PANEL_BYTES + 1024];  // 2 dh panels, later the Ys tile
+  static_assert(2 * PANEL_BYTES + 1024 >= YS_BYTES, "Ys tile must fit the dh panels");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15;
+  const int m0 = blockIdx.x * BM;
+  const int nchunk = a.FF / DM, ks2 = a.FF / 32;
+  const bf16x8* w1s = a.w1 + (size_t)(wave * NT) * KS * 64 + lane;
+  const bf16x8* w2ts = a.w2t + (size_t)(wave * NT) * KS * 64 + lane;
+  const bf16x8* w1ts = a.w1t + (size_t)(wave * NT) * ks2 * 64 + lane;
+  const int rot = blockIdx.x % nchunk;
+  bf16x8 wq[PD][NT];
+  prefetch_first<NT>(wq, w1s + (size_t)rot * 16 * KS * 64, KS, NT);
+
+  // ---- prologue: the two bf16 panels; LN(x) also goes to global for the weight-gradient GEMM
+  {
+    const int r = tid >> 3, part = tid & 7;
+    const int row = m0 + r, rowc = min(row, a.M - 1);
+    float4 v[8], d[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v[i] = *reinterpret_cast<const float4*>(a.x + (size_t)rowc * DM + (i * 8 + part) * 4);
+      d[i] = *reinterpret_cast<const float4*>(a.dy + (size_t)rowc * DM + (i * 8 + part) * 4);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    const float mean = sum8(s) * (1.f / DM);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+      ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float rstd = rsqrtf(sum8(ss) * (1.f / DM) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c4 = i * 8 + part;
+      const float4 gm = *reinterpret_cast<const float4*>(a.ln_g + c4 * 4);
+      const float4 bt = *reinterpret_cast<const float4*>(a.ln_b + c4 * 4);
+      const uint2 av = make_uint2(pack_bf2(v[i].x * rstd * gm.x + bt.x, v[i].y * rstd * gm.y + bt.y),
+                                  pack_bf2(v[i].z * rstd * gm.z + bt.z, v[i].w * rstd * gm.w + bt.w));
+      *reinterpret_cast<uint2*>(Xs + panel_off(r, c4 >> 1) + (c4 & 1) * 8) = av;
+      if (row < a.M) *reinterpret_cast<uint2*>(a.a_bf + (size_t)row * DM + c4 * 4) = av;
+      *reinterpret_cast<uint2*>(Ds + panel_off(r, c4 >> 1) + (c4 & 1) * 8) =
+          make_uint2(pack_bf2(a.alpha * d[i].x, a.alpha * d[i].y), pack_bf2(a.alpha * d[i].z, a.alpha * d[i].w));
+    }
+  }
+  __syncthreads();
+
+  f32x4 o[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) o[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int ci = 0; ci < nchunk; ++ci) {
+    const int c = (ci + rot) % nchunk;
+    const bf16x8* w1c = w1s + (size_t)c * 16 * KS * 64;
+    const bf16x8* w2tc = w2ts + (size_t)c * 16 * KS * 64;
+    const bf16x8* w1tc = w1ts + (size_t)c * KS * 64;
+    const bf16x8* w1n = w1s + (size_t)((c + 1) % nchunk) * 16 * KS * 64;
+    float4 bb[NT];
+    f32x4 h[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      bb[t] = *reinterpret_cast<const float4*>(a.b1 + c * DM + (wave * NT + t) * 16 + 4 * g);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) h[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // pass A: h = relu(a W1_c^T + b1_c); keep the mask, store h
+    mma_pass<NT>(h, Xs, n, g, NT, w1c, KS, w2tc, KS, NT, wq);
+    unsigned mask = 0u;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int fcol = c * DM + (wave * NT + t) * 16 + 4 * g;
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        const float v0 = fmaxf(h[t][rt][0] + bb[t].x, 0.f), v1 = fmaxf(h[t][rt][1] + bb[t].y, 0.f);
+        const float v2 = fmaxf(h[t][rt][2] + bb[t].z, 0.f), v3 = fmaxf(h[t][rt][3] + bb[t].w, 0.f);
+        mask |= ((v0 > 0.f ? 1u : 0u) | (v1 > 0.f ? 2u : 0u) | (v2 > 0.f ? 4u : 0u) | (v3 > 0.f ? 8u : 0u)) << ((t * 4 + rt) * 4);
+        const int row = m0 + rt * 16 + n;
+        if (row < a.M)
+          *reinterpret_cast<uint2*>(a.h_bf + (size_t)row * a.FF + fcol) = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
+        h[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    // pass B: dh = (alpha dy) W2[:, c] masked  -> LDS panel + global
+    mma_pass<NT>(h, Ds, n, g, NT, w2tc, KS, w1tc, ks2, NT, wq);
+    unsigned char* gs = Graw + (ci & 1) * PANEL_BYTES;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int hc = (wave * NT + t) * 16 + 4 * g;
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        const unsigned mb = mask >> ((t * 4 + rt) * 4);
+        const uint2 pk = make_uint2(pack_bf2((mb & 1u) ? h[t][rt][0] : 0.f, (mb & 2u) ? h[t][rt][1] : 0.f),
+                                    pack_bf2((mb & 4u) ? h[t][rt][2] : 0.f, (mb & 8u) ? h[t][rt][3] : 0.f));
+        *reinterpret_cast<uint2*>(gs + panel_off(rt * 16 + n, hc >> 3) + (hc & 7) * 2) = pk;
+        const int row = m0 + rt * 16 + n;
+        if (row < a.M) *reinterpret_cast<uint2*>(a.dh_bf + (size_t)row * a.FF + c * DM + hc) = pk;
+      }
+    }
+    __syncthreads();
+    // pass C: da += dh W1_c
+    mma_pass<NT>(o, gs, n, g, NT, w1tc, ks2, w1n, KS, NT, wq);
+  }
+
+  // ---- epilogue: da rows through the Ys tile; LayerNorm backward; gamma / beta partials
+  __syncthreads();  // every wave is done reading the dh panels
+  float* ys = reinterpret_cast<float*>(Graw);
+  {
+    float4 zero[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) zero[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    park_tiles<NT, false>(ys, o, NT, wave * NT * 16, g, n, zero);
+  }
+  __syncthreads();
+  const int r = tid >> 3, part = tid & 7;
+  const int row = m0 + r, rowc = min(row, a.M - 1);
+  const bool rvalid = row < a.M;
+  float4 v[8], da[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    v[i] = *reinterpret_cast<const float4*>(a.x + (size_t)rowc * DM + (i * 8 + part) * 4);
+    da[i] = *reinterpret_cast<const float4*>(ys + r * YS + (i * 8 + part) * 4);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float mean = sum8(s) * (1.f / DM);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+    ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+  }
+  const float rstd = rsqrtf(sum8(ss) * (1.f / DM) + 1e-5f);
+  float s1 = 0.f, s2 = 0.f;
+  float4 gg[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float4 gm = *reinterpret_cast<const float4*>(a.ln_g + (i * 8 + part) * 4);
+    v[i].x *= rstd; v[i].y *= rstd; v[i].z *= rstd; v[i].w *= rstd;  // xhat
+    if (!rvalid) da[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    gg[i] = make_float4(da[i].x * gm.x, da[i].y * gm.y, da[i].z * gm.z, da[i].w * gm.w);
+    s1 += (gg[i].x + gg[i].y) + (gg[i].z + gg[i].w);
+    s2 += (gg[i].x * v[i].x + gg[i].y * v[i].y) + (gg[i].z * v[i].z + gg[i].w * v[i].w);
+  }
+  s1 = sum8(s1) * (1.f / DM);
+  s2 = sum8(s2) * (1.f / DM);
+  __syncthreads();  // all da values are in registers: the Ys tile (and Xs / Ds) can be reused for the column sums
+  float* cg = reinterpret_cast<float*>(Graw);  // [64][260] da * xhat
+  float* cb = reinterpret_cast<float*>(XD);    // [64][256] da       (both panels: 64 KB)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int col = (i * 8 + part) * 4;
+    if (rvalid) {
+      const float4 d = *reinterpret_cast<const float4*>(a.dy + (size_t)row * DM + col);
+      float4 o4;
+      o4.x = d.x + rstd * (gg[i].x - s1 - v[i].x * s2);
+      o4.y = d.y + rstd * (gg[i].y - s1 - v[i].y * s2);
+      o4.z = d.z + rstd * (gg[i].z - s1 - v[i].z * s2);
+      o4.w = d.w + rstd * (gg[i].w - s1 - v[i].w * s2);
+      *reinterpret_cast<float4*>(a.dx + (size_t)row * DM + col) = o4;
+    }
+    *reinterpret_cast<float4*>(cg + r * YS + col) = make_float4(da[i].x * v[i].x, da[i].y * v[i].y, da[i].z * v[i].z, da[i].w * v[i].w);
+    *reinterpret_cast<float4*>(cb + r * DM + col) = da[i];
+  }
+  __syncthreads();
+  {
+    const int col = tid & 255, which = tid >> 8;  // 512 threads: 256 columns x {dgamma, dbeta}
+    float acc = 0.f;
+    if (which == 0) {
+#pragma unroll 8
+      for (int rr = 0; rr < BM; ++rr) acc += cg[rr * YS + col];
+    } else {
+#pragma unroll 8
+      for (int rr = 0; rr < BM; ++rr) acc += cb[rr * DM + col];
+    }
+    a.part[(size_t)blockIdx.x * 2 * DM + which * DM + col] = acc;
+  }
+}
+
 // =============================================================================== panel linear
 struct LinArgs {
   const void* a;
@@ -834,6 +1050,33 @@ extern "C" int csship_ffn_fused(const float* x, float* out, const float* ln_g, c
   else hipLaunchKernelGGL((ffn_kernel<NWAVES, false>), grid, block, 0, as_stream(stream), a);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
+}
+
+extern "C" size_t csship_ffn_bwd_workspace(int32_t M) { return (size_t)((M + BM - 1) / BM) * 2 * DM * sizeof(float); }
+
+extern "C" int csship_ffn_bwd(const float* x, const float* dy, const float* ln_g, const float* ln_b,
+                              const uint16_t* w1_packed, const float* b1, const uint16_t* w2t_packed,
+                              const uint16_t* w1t_packed, uint16_t* a_bf16, uint16_t* h_bf16, uint16_t* dh_bf16,
+                              float* dx, float* dgamma_dbeta, int32_t M, int32_t d_model, int32_t d_ffn, float alpha,
+                              void* workspace, size_t workspace_bytes, csship_stream_t stream) {
+  if (!x || !dy || !ln_g || !ln_b || !w1_packed || !b1 || !w2t_packed || !w1t_packed || !a_bf16 || !h_bf16 || !dh_bf16 ||
+      !dx || !dgamma_dbeta || !workspace)
+    return CSSHIP_ENULL;
+  if (M <= 0) return CSSHIP_EBADSHAPE;
+  if (d_model != DM || d_ffn <= 0 || (d_ffn % DM) != 0) return CSSHIP_EUNSUPPORTED;
+  if (!aligned16(x) || !aligned16(dy) || !aligned16(dx) || !aligned16(ln_g) || !aligned16(ln_b) || !aligned16(b1) ||
+      !aligned16(w1_packed) || !aligned16(w2t_packed) || !aligned16(w1t_packed) || !aligned8(a_bf16) || !aligned8(h_bf16) ||
+      !aligned8(dh_bf16))
+    return CSSHIP_EALIGN;
+  const int nwg = (M + BM - 1) / BM;
+  if (workspace_bytes < (size_t)nwg * 2 * DM * sizeof(float)) return CSSHIP_EWORKSPACE;
+  FfnBwdArgs a{x, dy, ln_g, ln_b, reinterpret_cast<const bf16x8*>(w1_packed), b1,
+               reinterpret_cast<const bf16x8*>(w2t_packed), reinterpret_cast<const bf16x8*>(w1t_packed), a_bf16, h_bf16,
+               dh_bf16, dx, reinterpret_cast<float*>(workspace), M, d_ffn, alpha};
+  hipLaunchKernelGGL((ffn_bwd_kernel<NWAVES>), dim3(nwg), dim3(NWAVES * 64), 0, as_stream(stream), a);
+  CSSHIP_CHECK_LAUNCH();
+  return launch_slab_reduce(reinterpret_cast<const float*>(workspace), nwg, 2 * DM, 2 * DM, 2 * DM, 1.f, nullptr, nullptr, 0,
+                            dgamma_dbeta, as_stream(stream));
 }
 
 extern "C" int csship_panel_linear(const void* a, int32_t prologue, const float* ln_g, const float* ln_b,

@@ -224,3 +224,24 @@ def lstm_bidir_bwd(gates, c, dy, whhT_packed):
     dg = torch.empty_like(gates)
     check(lib().csship_lstm_bidir_bwd(_ptr(gates), _ptr(c), _ptr(dy), _ptr(whhT_packed), _ptr(dg), B, T, H4 // 4, _stream()))
     return dg
+
+
+def ffn_bwd(x, dy, ln_g, ln_b, w1p, b1, w2tp, w1tp, d_ffn, alpha=0.5):
+    """Activation side of the FeedForward backward in one kernel (csship_ffn_bwd).
+    Returns (dx f32 [M,256], dgamma, dbeta, a bf16 [M,256], h bf16 [M,d_ffn], dh bf16 [M,d_ffn])."""
+    _need(x, torch.float32, "x"), _need(dy, torch.float32, "dy")
+    M, D = x.shape
+    if not (x.is_contiguous() and dy.is_contiguous()) or dy.shape != x.shape:
+        raise RuntimeError("css_amd: ffn_bwd expects dense [M, 256] x and dy")
+    dev = x.device
+    a = torch.empty((M, D), dtype=torch.bfloat16, device=dev)
+    h = torch.empty((M, d_ffn), dtype=torch.bfloat16, device=dev)
+    dh = torch.empty((M, d_ffn), dtype=torch.bfloat16, device=dev)
+    dx = torch.empty_like(x)
+    gb = torch.empty((2, D), dtype=torch.float32, device=dev)
+    nws = lib().csship_ffn_bwd_workspace(M)
+    ws = _workspace(nws, dev)
+    check(lib().csship_ffn_bwd(_ptr(x), _ptr(dy), _ptr(ln_g), _ptr(ln_b), _ptr(w1p), _ptr(b1), _ptr(w2tp), _ptr(w1tp),
+                               _ptr(a), _ptr(h), _ptr(dh), _ptr(dx), _ptr(gb), M, D, d_ffn, float(alpha), _ptr(ws), nws,
+                               _stream()))
+    return dx, gb[0], gb[1], a, h, dh

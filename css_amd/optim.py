@@ -33,6 +33,10 @@ class FusedAdam(torch.optim.Optimizer):
         self.grad_norm = torch.zeros((), dtype=torch.float32, device=dev)
         self._ws = torch.empty(max(lib().csship_adam_clip_workspace(n), 16), dtype=torch.uint8, device=dev)
         self._step = 0
+        # {lr, 1 - beta1^t, 1 - beta2^t} on the device: read by the kernel, so a captured step can be replayed
+        self._hyper = torch.zeros(3, dtype=torch.float32, device=dev)
+        self._hyper_host = torch.zeros(3, dtype=torch.float32).pin_memory()
+        self.capturable = False
         with torch.no_grad():
             for p, o in zip(params, offs):
                 seg = self.flat_param[o:o + p.numel()].view(p.shape)
@@ -51,13 +55,28 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             raise RuntimeError("css_amd.FusedAdam does not take a closure")
         g = self.param_groups[0]
-        self._step += 1
         mn = g["max_norm"] if max_norm is None else max_norm
+        # lr and the bias corrections (computed in double on the host, like torch.optim.Adam) are read from device
+        # memory.  Eager mode uploads them here; in capturable mode the caller does (advance_hyper() before every
+        # replay), so eager and graph-replayed training are bit-identical.
+        if not self.capturable:
+            self.advance_hyper()
+        hyper, step = self._hyper, 0
         check(lib().csship_adam_clip(_ptr(self.flat_param), _ptr(self.flat_grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
                                      self._n, float(mn), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
-                                     float(g["eps"]), self._step, float(g["weight_decay"]), _ptr(self.grad_norm),
+                                     float(g["eps"]), step, float(g["weight_decay"]), _ptr(hyper), _ptr(self.grad_norm),
                                      _ptr(self._ws), self._ws.numel(), _stream()))
         return self.grad_norm
+
+    def advance_hyper(self):
+        """capturable mode: count one step and upload {lr, bias corrections} for it (asynchronous pinned copy on the
+        current stream, ordered before the graph replay that follows)."""
+        g = self.param_groups[0]
+        self._step += 1
+        self._hyper_host[0] = float(g["lr"])
+        self._hyper_host[1] = 1.0 - float(g["betas"][0]) ** self._step
+        self._hyper_host[2] = 1.0 - float(g["betas"][1]) ** self._step
+        self._hyper.copy_(self._hyper_host, non_blocking=True)
 
     def state_dict(self):
         sd = super().state_dict()

@@ -1,0 +1,61 @@
+"""Whole training step as ONE HIP graph.
+
+A css_amd training step is ~2 300 kernel launches (forward operators, PIT, every gradient GEMM, optimiser) issued
+from Python; at 23 ms of GPU work the host cannot keep up.  ``GraphedTrainStep`` captures
+zero_grad -> objective(model, batch) -> backward -> [flat all-reduce] -> clip + Adam once and replays it per step:
+inputs are copied into static buffers, the learning rate / Adam bias corrections live in device memory
+(``FusedAdam.advance_hyper``), BatchNorm bookkeeping and the PIT permutation search are device-side already.
+Batches must keep one shape (the reference trains on fixed-length windows, separation.py:204-232).
+"""
+import torch
+
+from .. import parallel
+from ..optim import FusedAdam
+
+
+class GraphedTrainStep:
+    def __init__(self, model, objective, optim, example_batch, max_norm, device="cuda", warmup=2):
+        if not isinstance(optim, FusedAdam):
+            raise TypeError("GraphedTrainStep needs css_amd.optim.FusedAdam (static parameter / gradient buffers)")
+        if parallel.is_distributed():
+            raise NotImplementedError("graph capture of the RCCL all-reduce is not wired up; use train_one_epoch")
+        self.model, self.objective, self.optim, self.max_norm = model, objective, optim, max_norm
+        self.keys = [k for k in ("mix", "source1", "source2") if k in example_batch]
+        self.static = {k: example_batch[k].to(device).clone() for k in self.keys}
+        optim.capturable = True
+        # warm-up steps outside the capture (allocator pools, lazy initialisation) must not train: snapshot every
+        # piece of state they touch and put it back
+        snap = [t.clone() for t in (optim.flat_param, optim.exp_avg, optim.exp_avg_sq)]
+        bufs = [(b, b.clone()) for b in model.buffers()]
+        step0 = optim._step
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                optim.advance_hyper()
+                self._eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for t, s_ in zip((optim.flat_param, optim.exp_avg, optim.exp_avg_sq), snap):
+            t.copy_(s_)
+        for b, s_ in bufs:
+            b.copy_(s_)
+        optim._step = step0
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss, self.grad_norm = self._eager()
+
+    def _eager(self):
+        self.optim.zero_grad()
+        loss = self.objective(self.model, self.static, device=self.static[self.keys[0]].device)
+        loss.backward()
+        return loss.detach(), self.optim.step(max_norm=self.max_norm)
+
+    def __call__(self, batch):
+        """One optimiser step on ``batch``; returns (loss, grad_norm) as 0-dim device tensors of THIS step (they are
+        overwritten by the next call)."""
+        for k in self.keys:
+            self.static[k].copy_(batch[k], non_blocking=True)
+        self.optim.advance_hyper()
+        self.graph.replay()
+        return self.loss, self.grad_norm

@@ -349,6 +349,19 @@ size_t csship_colsum_workspace(int64_t M, int32_t N);
 int csship_colsum(const void* x, int32_t x_is_f32, int64_t M, int32_t N, int64_t ld, float alpha, float* out,
                   void* workspace, size_t workspace_bytes, csship_stream_t stream);
 
+/* ---- csship_ffn_bwd (css_amd/csrc/panel.hip): the activation side of the FeedForward backward as ONE row-panel kernel.
+ * For out = x + alpha * (relu(LN(x) W1^T + b1) W2^T + b2) and dy = d(out) it produces
+ *   a_bf16 = LN(x) [M, 256], h_bf16 = relu(.) [M, d_ffn], dh_bf16 = alpha * (dy W2) o [h > 0] [M, d_ffn]
+ *   (the operands of the weight-gradient GEMMs dW1 = dh^T a, db1 = colsum(dh), dW2 = alpha dy^T h, db2 = alpha colsum(dy)),
+ *   dx = dy + LayerNorm-backward(dh W1) [M, 256] and dgamma_dbeta f32 [2, 256].
+ * w1_packed as in csship_ffn_fused; w2t_packed / w1t_packed = fragment-packed W2^T [d_ffn, 256] / W1^T [256, d_ffn]. */
+size_t csship_ffn_bwd_workspace(int32_t M);
+int csship_ffn_bwd(const float* x, const float* dy, const float* ln_g, const float* ln_b,
+                   const uint16_t* w1_packed, const float* b1, const uint16_t* w2t_packed,
+                   const uint16_t* w1t_packed, uint16_t* a_bf16, uint16_t* h_bf16, uint16_t* dh_bf16,
+                   float* dx, float* dgamma_dbeta, int32_t M, int32_t d_model, int32_t d_ffn, float alpha,
+                   void* workspace, size_t workspace_bytes, csship_stream_t stream);
+
 /* ---- attention, training (css_amd/csrc/attn.hip).  csship_mha_relpos_train = csship_mha_relpos that also returns
  * lse[b, h, i] = log sum_j exp(score[i, j]) (f32 [B, H, T]).  csship_mha_relpos_probs recomputes the softmax for the
  * backward pass: p[b, h, i, j] = exp(score[i, j] - lse[b, h, i]) as bf16 [B, H, T, ld_p] (ld_p >= T, ld_p % 4 == 0;
@@ -423,12 +436,14 @@ int csship_lstm_bidir_bwd(const float* gates, const float* c, const float* dy, c
  * (iteration_types.py:17-64) on FLAT f32 buffers of n elements (parameters, gradients, first and second moments), in
  * three launches with no host round trip.  grad_norm (device f32) receives the total 2-norm before clipping; a
  * non-finite norm skips the update.  max_norm <= 0 disables clipping; step is the 1-based Adam step count;
- * weight_decay is torch.optim.Adam's L2 form. */
+ * weight_decay is torch.optim.Adam's L2 form.  hyper_dev (optional, device f32[3] = {lr, 1 - beta1^step,
+ * 1 - beta2^step}) overrides lr / step at execution time, so a captured HIP graph of the training step can be replayed
+ * while the schedule advances. */
 size_t csship_adam_clip_workspace(int64_t n);
 int csship_adam_clip(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                      float max_norm, float lr, float beta1, float beta2, float eps, int64_t step,
-                     float weight_decay, float* grad_norm, void* workspace, size_t workspace_bytes,
-                     csship_stream_t stream);
+                     float weight_decay, const float* hyper_dev, float* grad_norm, void* workspace,
+                     size_t workspace_bytes, csship_stream_t stream);
 
 #ifdef __cplusplus
 }

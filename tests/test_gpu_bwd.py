@@ -180,6 +180,13 @@ def test_ffn_and_head_backward(ob):
     for got, k in zip(grads, ("g", "b", "w1", "b1", "w2", "b2")):
         assert relerr(got, want[k]) < tol, k
     tol = 5e-2
+    # the fused row-panel kernel (csship_ffn_bwd) gives the same gradients as the composed route
+    w1p = ops.pack_frag(G["w1"])
+    w2tp, w1tp = ops.pack_frag(G["w2"].t().contiguous()), ops.pack_frag(G["w1"].t().contiguous())
+    dx2, grads2 = bw.ffn_bwd_fused(x.to(DEV), dy.to(DEV), G["g"], G["b"], G["b1"], w1p, w2tp, w1tp, FF, 0.5)
+    assert relerr(dx2, xd.grad + dy.double()) < 2e-3
+    for got, k in zip(grads2, ("g", "b", "w1", "b1", "w2", "b2")):
+        assert relerr(got, want[k]) < 2e-3, k
     # mask head
     N = 771
     w, b = rnd((N, D), 31, 0.06), rnd((N,), 32, 0.1)

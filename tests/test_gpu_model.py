@@ -325,3 +325,43 @@ def test_blstm_hip_backward_matches_fp32_autograd(hdim, layers, B, T):
             worst = (k, (n / d) ** 0.5)
     print(f"[parity] BLSTM hdim {hdim}: HIP backward vs fp32 autograd: global rel err {(num / den) ** 0.5:.3e}, worst {worst[0]} {worst[1]:.3e}")
     assert (num / den) ** 0.5 < 3e-2 and worst[1] < 0.15
+
+
+def test_graphed_train_step_matches_eager():
+    """GraphedTrainStep (whole step captured in one HIP graph, lr and Adam bias corrections read from device memory)
+    reproduces eager FusedAdam training bit for bit over 4 steps with a changing learning rate, and its constructor
+    leaves model / optimiser state untouched."""
+    from css_amd.objectives import OBJECTIVES
+    from css_amd.optim import FusedAdam
+    from css_amd.trainer import GraphedTrainStep
+
+    def batches(i):
+        return {"mix": rnd((2, 40, 257), 500 + i).abs().to(DEV), "source1": (rnd((2, 40, 257), 600 + i).abs() * 0.5).to(DEV),
+                "source2": (rnd((2, 40, 257), 700 + i).abs() * 0.5).to(DEV)}
+
+    lrs = [1e-3, 2e-3, 5e-4, 1e-3]
+    obj = OBJECTIVES["MSE"].build_objective({})
+    runs = []
+    for graphed in (False, True):
+        m, _ = build(1, 47)
+        m.train()
+        opt = FusedAdam(m.parameters(), lr=lrs[0], max_norm=5.0)
+        losses = []
+        if graphed:
+            p0 = opt.flat_param.clone()
+            stepper = GraphedTrainStep(m, obj, opt, batches(0), max_norm=5.0)
+            assert torch.equal(p0, opt.flat_param) and opt._step == 0
+        for i, lr in enumerate(lrs):
+            opt.param_groups[0]["lr"] = lr
+            if graphed:
+                loss, _ = stepper(batches(i))
+            else:
+                opt.zero_grad()
+                loss = obj(m, batches(i), device=DEV)
+                loss.backward()
+                opt.step(max_norm=5.0)
+            losses.append(float(loss))
+        runs.append((losses, opt.flat_param.clone(), m.conformer.encoders[0].conv.BN.running_mean.clone()))
+    print("[parity] eager losses", runs[0][0], "graphed", runs[1][0])
+    assert runs[0][0] == runs[1][0]
+    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])

@@ -14,6 +14,7 @@ from css_amd.utils import synthetic as syn  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--twin", action="store_true")
+ap.add_argument("--graph", action="store_true", help="capture the whole step in a HIP graph and replay it")
 ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam + clip_grad_norm_ instead of FusedAdam")
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--blocks", type=int, default=16)
@@ -51,6 +52,14 @@ def step():
 for _ in range(2):
     step()
 torch.cuda.synchronize()
+if a.graph:
+    from css_amd.trainer import GraphedTrainStep
+    stepper = GraphedTrainStep(m, obj, opt, batch, max_norm=5.0)
+
+    def step():  # noqa: F811
+        return stepper(batch)[0]
+    step()
+    torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(a.steps):
     loss = step()
