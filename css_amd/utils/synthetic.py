@@ -177,3 +177,15 @@ def synthetic_multichannel(sources, n_ch=7, max_delay=3, seed=0, sensor_noise=0.
         r = np.random.RandomState(7919 * seed + 3)
         out += torch.from_numpy((sensor_noise * r.standard_normal(out.shape)).astype(np.float32))
     return out
+
+
+def mvdr_inputs(D=7, F=257, T=40, seed=0):
+    """Complex multichannel spectrum [D,F,T] (complex64) with one coherent source per bin plus diffuse noise, and three
+    soft masks [3,F,T] - shared by tests/golden/make_golden_mvdr.py and the MVDR parity tests."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    mix = (rs.standard_normal((D, F, T)) + 1j * rs.standard_normal((D, F, T))).astype(np.complex64)
+    steer = np.exp(1j * rs.uniform(0, 2 * np.pi, (D, F, 1))).astype(np.complex64)
+    mix = mix * 0.3 + steer * (rs.standard_normal((1, F, T)) + 1j * rs.standard_normal((1, F, T))).astype(np.complex64)
+    masks = rs.uniform(0.05, 1.0, (3, F, T)).astype(np.float32)
+    return mix, masks

@@ -445,6 +445,34 @@ int csship_adam_clip(float* params, const float* grads, float* exp_avg, float* e
                      float weight_decay, const float* hyper_dev, float* grad_norm, void* workspace,
                      size_t workspace_bytes, csship_stream_t stream);
 
+/* ======================================================================================
+ * Mask-based MVDR beamformer (css_amd/csrc/mvdr.hip; css/executor/beamformer.py:126-183, arithmetic of asteroid's
+ * compute_scm + SoudenMVDRBeamformer, also stated in css/utils/mvdr_util.py:45-66).
+ * Spectra are re / im planes: x [B, D, T_x, F] (csship_stft's layout) of which the first T frames are used, masks
+ * [B, >=T, F] (row stride ld_mask, batch stride mask_batch_stride), results y [B, F, T] (csship_istft's layout).
+ * 2 <= D <= 8.
+ * ====================================================================================== */
+/* scm[b, f] = sum_t mask x x^H (interleaved complex f32 [B, F, D, D, 2]) and mask_sum[b, f]; normalize != 0 divides by
+ * mask_sum (asteroid), diag_load is added to the diagonal afterwards (mvdr_util.py:51). */
+int csship_mvdr_scm(const float* x_re, const float* x_im, const float* mask, int64_t ld_mask,
+                    int64_t mask_batch_stride, int32_t B, int32_t D, int32_t T, int32_t T_x, int32_t F,
+                    float diag_load, int32_t normalize, float* scm, float* mask_sum, csship_stream_t stream);
+/* Souden MVDR weights w[bin] = Z[:, ref_mic] / (trace(Z) + trace_eps), Z = (noise_scm [+ noise_scm2])^-1 target_scm,
+ * for n_bins = B*F bins (fp64 elimination with partial pivoting); w: interleaved complex f32 [n_bins, D, 2]. */
+int csship_mvdr_souden(const float* target_scm, const float* noise_scm, const float* noise_scm2, int64_t n_bins,
+                       int32_t D, int32_t ref_mic, float trace_eps, float* w, csship_stream_t stream);
+/* y = w^H x per bin; energies[b] = {sum |y|^2, sum |mask * x_0|^2} (mask may be NULL: second sum is 0). */
+size_t csship_mvdr_apply_workspace(int32_t B, int32_t T, int32_t F);
+int csship_mvdr_apply(const float* x_re, const float* x_im, const float* w, const float* mask, int64_t ld_mask,
+                      int64_t mask_batch_stride, int32_t B, int32_t D, int32_t T, int32_t T_x, int32_t F,
+                      float* y_re, float* y_im, float* energies, void* workspace, size_t workspace_bytes,
+                      csship_stream_t stream);
+/* In place on the two sources' outputs: energy rescale (beamformer.py:165-183) and the deduplication gain of
+ * beamformer.py:67-80 (15 dB power gap -> quieter source times clamp(|y_quiet| / max(|y_0|, |y_1|), 0.01)). */
+int csship_mvdr_finish(float* y0_re, float* y0_im, float* y1_re, float* y1_im, const float* energies0,
+                       const float* energies1, int32_t rescale, int32_t dedup, int32_t B, int64_t per_batch,
+                       csship_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,3 +87,66 @@ def test_synthetic_dataset_batches_and_validate():
     model = model.to(DEV)
     loss = validate(ds, model, OBJECTIVES["MSE"].build_objective({}), device=DEV, num_batches=3)
     assert loss.dim() == 0 and torch.isfinite(loss) and model.training
+
+
+def test_mvdr_kernels_vs_reference_numpy_twin(golden):
+    """SCM, Souden solve and w^H x on the GPU vs the outputs of css/utils/mvdr_util.py (tests/golden/mvdr.npz)."""
+    from css_amd import ops_mvdr as mv
+    g = golden("mvdr.npz")
+    mix, masks = syn.mvdr_inputs()
+    x = torch.from_numpy(mix).permute(0, 2, 1)[None].contiguous()        # [1, D, T, F]
+    xr, xi = x.real.contiguous().to(DEV), x.imag.contiguous().to(DEV)
+    mt = [torch.from_numpy(m).t().contiguous()[None].to(DEV) for m in masks]  # [1, T, F]
+    tgt, ms = mv.scm(xr, xi, mt[0], normalize=False, diag_load=1e-15)
+    itf, _ = mv.scm(xr, xi, mt[1], normalize=False, diag_load=1e-15)
+    noi, _ = mv.scm(xr, xi, mt[2], normalize=False, diag_load=1e-15)
+    ref_scm = torch.from_numpy(g["tgt_scm"])
+    assert float((tgt[0].cpu() - ref_scm).abs().max()) < 1e-4 * float(ref_scm.abs().max())
+    assert abs(float(ms.sum()) - float(g["mask_sum"])) < 1e-2
+    w = mv.souden(tgt, noi, noise_scm2=itf, trace_eps=0.0)
+    assert float((w[0].cpu() - torch.from_numpy(g["coef"])).abs().max()) < 5e-5
+    yr, yi, e = mv.apply(xr, xi, w)
+    res = torch.complex(yr, yi)[0].cpu()
+    ref = torch.from_numpy(g["res"])
+    assert float((res - ref).abs().max()) < 2e-4
+    assert abs(float(e[0, 0]) - float((ref.abs() ** 2).sum())) < 1e-3 * float((ref.abs() ** 2).sum())
+
+
+def test_beamformer_vs_oracle():
+    """css_amd.executor.beamformer.Beamformer (process_one_batch and a whole continuous_process session: 4 windows,
+    the reference's batch overlap, deduplication, iSTFT, overlap-add, peak normalisation) vs oracle/mvdr.py."""
+    from css_amd.executor.beamformer import Beamformer
+    from oracle import mvdr
+    cfg = dict(batch_size=2, type="SoudenMVDRBeamformer", hop_size=256, n_fft=512, eval_hop=0.8, proceed_margin=2,
+               eval_win=2.4, wta_thresh=0.0001)
+    sr = 16000
+    n_win = 4
+    T = int(0.8 * sr) * (n_win - 1) + int(2.4 * sr) + 256
+    rs = np.random.RandomState(5)
+    src = rs.standard_normal((2, T)).astype(np.float32) * 0.1
+    delays = rs.randint(0, 4, (2, 7))
+    X = np.zeros((7, T), np.float32)
+    for k in range(2):
+        for d in range(7):
+            X[d] += np.roll(src[k], delays[k, d]) * (1.0 if k == 0 else 0.6)
+    X += 0.01 * rs.standard_normal((7, T)).astype(np.float32)
+    n_frames = (n_win - 1) * 50 + 150
+    masks = [torch.from_numpy(rs.uniform(0.05, 1.0, (257, n_frames)).astype(np.float32)) for _ in range(3)]
+    Xt = torch.from_numpy(X)
+    bf = Beamformer(cfg, sr=sr, rescale=True)
+    with pytest.raises(ValueError):
+        Beamformer(dict(cfg, type="NoSuchBeamformer"))
+    # one batch
+    xb = Xt.unfold(-1, bf.eval_win + 256, bf.eval_hop).permute(1, 0, 2)[:2].contiguous()
+    sm = masks[0].unfold(1, 150, 50).permute(1, 0, 2)[:2].contiguous()
+    nm = masks[2].unfold(1, 150, 50).permute(1, 0, 2)[:2].contiguous()
+    got = bf.process_one_batch(xb, sm, nm).cpu()
+    ref = mvdr.process_one_batch(xb, sm, nm)
+    assert got.shape == ref.shape == (2, 257, 150)
+    assert float((got - ref).abs().max()) < 2e-3 * float(ref.abs().max())
+    # the whole session
+    w0, w1 = bf.continuous_process(Xt, masks)
+    r0, r1 = mvdr.continuous_process(Xt, masks, cfg, sr=sr)
+    assert w0.shape == r0.shape == (1, T)
+    for a, b in ((w0, r0), (w1, r1)):
+        assert float((a.cpu() - b).abs().max()) < 2e-3   # waveforms peak-normalised to 0.9

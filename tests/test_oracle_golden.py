@@ -201,3 +201,29 @@ def test_lr_trace():
     tr = json.load(open(os.path.join(GOLDEN, "trainer.json")))
     got = oracle.schedule.lr_trace(1e-3, 10, warmup=4, fixed=2, decay=0.1, min_lr=1e-9)
     assert np.allclose(got, tr["lr_trace"], rtol=1e-12, atol=0)
+
+
+def test_mvdr_oracle_matches_reference_numpy_twin(golden):
+    """oracle/mvdr.py (mask_scm, souden_coeffs, apply_bf) vs css/utils/mvdr_util.py outputs (tests/golden/mvdr.npz),
+    and the asteroid-style restatement (normalised SCMs, eps on the trace; parity unpinned) agrees with it."""
+    import numpy as np
+    from oracle import mvdr
+    g = golden("mvdr.npz")
+    mix, masks = syn.mvdr_inputs()
+    tgt, ms = mvdr.mask_scm(mix, masks[0])
+    itf, _ = mvdr.mask_scm(mix, masks[1])
+    noi, _ = mvdr.mask_scm(mix, masks[2])
+    coef = mvdr.souden_coeffs(noi + itf, tgt)
+    res = mvdr.apply_bf(mix, coef)
+    assert np.abs(tgt - g["tgt_scm"]).max() < 1e-4 * np.abs(g["tgt_scm"]).max()
+    assert abs(ms - float(g["mask_sum"])) < 1e-3
+    assert np.abs(coef - g["coef"]).max() < 2e-5 and np.abs(res - g["res"]).max() < 1e-4
+    # live-path formulation: scalar SCM normalisation cancels in w
+    S = torch.from_numpy(mix)[None].to(torch.complex128)
+    m = torch.from_numpy(masks).double()
+    t2 = mvdr.compute_scm(S, m[0:1])
+    n2 = mvdr.compute_scm(S, m[1:2] + m[2:3])   # same noise statistics as noi + itf up to the per-bin normaliser
+    n_un = torch.einsum("bmft,bnft->bfmn", S * (m[1:2] + m[2:3])[:, None], S.conj())
+    y = mvdr.souden_mvdr(S, t2, n_un / (m[1:2] + m[2:3]).sum(-1)[..., None, None], eps=0.0)[0].numpy()
+    assert np.abs(y - g["res"]).max() < 2e-4
+    assert np.isfinite(n2.real.numpy()).all()
