@@ -113,6 +113,8 @@ SIGNATURES = {
     "csship_mvdr_apply_workspace": (_sz, [_i32, _i32, _i32]),
     "csship_mvdr_apply": (_i32, [_p, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
     "csship_mvdr_finish": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i64, _p]),
+    "csship_doa_workspace": (_sz, [_i32, _i32, _i32, _i32, _i32]),
+    "csship_doa_likelihood": (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _p, _p, _p, _sz, _p]),
     "csship_conformer_workspace": (_sz, [C.POINTER(ConformerWeights), _i32, _i32]),
     "csship_conformer_forward": (_i32, [C.POINTER(ConformerWeights), _p, _i64, _i32, _i32, _p, _i64, _p, _p, _sz, _p]),
 }

@@ -6,21 +6,27 @@ Differences from the reference, all stated:
     ``separation_config["model"]``); the reference's ONNX path (third-party runtime, checkpoints not in the
     repo) is out of scope.  Any batch size is accepted (the ONNX restriction to 1 does not apply).
   * ``merge`` defaults to False when the key is missing (conf/config_1ch.yaml has none; the reference raises
-    KeyError).  The DOA-based ``angle_merge`` is out of scope and raises if requested.
+    KeyError).  With ``merge: True`` (conf/config_7ch.yaml) the DOA-based ``angle_merge`` of
+    separator.py:113-250 runs: the likelihood over 30 steering directions is a HIP kernel (csship_doa_likelihood),
+    the per-window decision is a handful of [B, 2, 30] tensor ops.  The reference always silences output 0
+    (``masked_magnitude[b]`` indexes the frequency axis); that is reproduced by default,
+    ``fix_merge_indexing=True`` silences the output with less masked energy instead.
   * With torch.distributed initialised, windows are sharded contiguously across ranks and gathered
     (long-recording inference): no collective on the per-window data path.
 """
+import ctypes as C
 import math
 
 import torch
 
 from .. import ops, parallel
+from .._lib import check, lib
 from .feature import FeatureExtractor
 
 
 class Separator:
     def __init__(self, separation_config, sr=16000, sess_options=None, device="cuda", backend="hip", lowcut=80,
-                 highcut=2000, model=None):
+                 highcut=2000, model=None, fix_merge_indexing=False):
         if backend != "hip":
             raise ValueError(f"Unknown backend: {backend}")
         self.separator = model if model is not None else separation_config.get("model")
@@ -37,8 +43,62 @@ class Separator:
         self.feature = FeatureExtractor(frame_len=self.frame_length, frame_hop=self.frame_shift, ipd_index=self.ipd)
         self.merge = separation_config.get("merge", False)
         self.merge_threshold = separation_config.get("merge_threshold", None)
+        self.fix_merge_indexing = fix_merge_indexing
         if self.merge:
-            raise NotImplementedError("DOA-based angle_merge (separator.py:113-250) is out of scope for css_amd")
+            sv, self.angles = self.steervec_7ch(nfreqs=257, nvecs=30, samplerate=sr, return_angles=True)
+            self.steervec = sv
+            self._sv_re = sv.real.contiguous().float().to(device)
+            self._sv_im = sv.imag.contiguous().float().to(device)
+            freq_step = (sr // 2) / (257 - 1)
+            self._lo = int(math.floor(lowcut / freq_step))
+            self._hi = int(math.ceil(highcut / freq_step))
+
+    @staticmethod
+    def steervec_7ch(nfreqs, *, nvecs, radius=0.0425, sndvelocity=340, samplerate=16000, return_angles=False,
+                     reference=0, inverse_shift=False):
+        """separator.py:113-163: plane-wave steering vectors of the 7-microphone circular array (constant table)."""
+        angles = torch.tensor([2 * math.pi * k / nvecs for k in range(nvecs)])
+        distances = radius * torch.stack((torch.zeros(nvecs), torch.cos(angles + math.pi / 6),
+                                          torch.cos(angles - math.pi / 6), torch.cos(angles - math.pi / 2),
+                                          torch.cos(angles - 5 * math.pi / 6), torch.cos(angles + 5 * math.pi / 6),
+                                          torch.cos(angles + math.pi / 2)), dim=1)
+        if reference != 0:
+            distances -= distances[:, reference, None]
+        deltas = distances / sndvelocity * samplerate
+        sign = -1j if inverse_shift else 1j
+        steervecs = torch.stack([torch.exp(sign * deltas * math.pi * f / (nfreqs - 1)) for f in range(nfreqs)])
+        steervecs = steervecs / math.sqrt(7)
+        return (steervecs, angles * 360 / (2 * math.pi)) if return_angles else steervecs
+
+    def doa_likelihood(self, re, im, mask, mask_binarize_thres=0.5, compression=0.5):
+        """separator.py:206-250 (softmax=False) on the GPU: re / im [B,7,F,T], mask [B,F,T,2] ->
+        (likelihood [B,2,30], masked energy [B,2])."""
+        B, D, F, T = re.shape
+        if D != 7:
+            raise RuntimeError("the DOA merge is defined for the 7-channel array (separator.py:113)")
+        re, im, mask = re.contiguous(), im.contiguous(), mask.contiguous()
+        like = torch.empty((B, 2, 30), dtype=torch.float32, device=re.device)
+        en = torch.empty((B, 2), dtype=torch.float32, device=re.device)
+        nws = lib().csship_doa_workspace(B, F, self._lo, self._hi, 30)
+        ws = torch.empty(nws, dtype=torch.uint8, device=re.device)
+        check(lib().csship_doa_likelihood(ops._ptr(re), ops._ptr(im), ops._ptr(mask), ops._ptr(self._sv_re),
+                                          ops._ptr(self._sv_im), B, F, T, 30, self._lo, self._hi, mask_binarize_thres,
+                                          compression, ops._ptr(like), ops._ptr(en), ops._ptr(ws), nws, ops._stream()))
+        return like, en
+
+    def angle_merge(self, re, im, mask, thresh=16, mask_binarize_thres=0.5, compression=0.5):
+        """separator.py:165-204: where the two outputs point at the same direction (<= thresh degrees apart) one of
+        them is silenced (mask = 1e-12)."""
+        like, en = self.doa_likelihood(re, im, mask, mask_binarize_thres, compression)
+        doa = self.angles.to(like.device)[torch.argmax(like, dim=-1)]                      # [B,2] degrees
+        diff = torch.minimum((doa[:, 0] - doa[:, 1]) % 360, (doa[:, 1] - doa[:, 0]) % 360)
+        close = diff <= thresh
+        kill = torch.argmin(en, dim=1) if self.fix_merge_indexing else torch.zeros_like(close, dtype=torch.long)
+        new_mask = mask.clone()
+        sel = torch.zeros((mask.shape[0], 2), dtype=torch.bool, device=mask.device)
+        sel[torch.arange(mask.shape[0], device=mask.device), kill] = close
+        new_mask.masked_fill_(sel[:, None, None, :], 1e-12)
+        return new_mask
 
     def separate(self, s):
         """s: waveform [D, n] -> (masks [W, 257, T, 3] clamped to <= 1, mags [W, 257, T])."""
@@ -72,4 +132,6 @@ class Separator:
         nb = self.feature.num_bins
         masks = m.reshape(B, T, -1, nb).permute(0, 3, 1, 2)[..., :3]  # (B, 257, T, 3): spk1, spk2, noise
         masks = torch.clamp(masks, max=1.0).contiguous()  # separator.py:104
+        if self.merge:  # separator.py:106-110
+            masks[..., :2] = self.angle_merge(re, im, masks[..., :2].contiguous(), thresh=self.merge_threshold)
         return masks, mag_specs

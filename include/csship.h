@@ -473,6 +473,16 @@ int csship_mvdr_finish(float* y0_re, float* y0_im, float* y1_re, float* y1_im, c
                        const float* energies1, int32_t rescale, int32_t dedup, int32_t B, int64_t per_batch,
                        csship_stream_t stream);
 
+/* ---- DOA likelihood of the 7-channel mask merge (css_amd/csrc/doa.hip; css/executor/separator.py:206-250 with
+ * softmax = False, as angle_merge calls it).  x re / im planes [B, 7, F, T]; mask f32 [B, F, T, 2] (binarised at
+ * binarize_thr); steering vectors re / im [F, n_angles, 7] (n_angles = 30, separator.py:52); band [lo, hi).
+ * likelihood: f32 [B, 2, n_angles]; masked_energy: f32 [B, 2] = sum_{f,t} binmask * |x_0| (separator.py:196-200). */
+size_t csship_doa_workspace(int32_t B, int32_t F, int32_t lo, int32_t hi, int32_t n_angles);
+int csship_doa_likelihood(const float* x_re, const float* x_im, const float* mask, const float* sv_re,
+                          const float* sv_im, int32_t B, int32_t F, int32_t T, int32_t n_angles, int32_t lo,
+                          int32_t hi, float binarize_thr, float compression, float* likelihood,
+                          float* masked_energy, void* workspace, size_t workspace_bytes, csship_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -150,3 +150,48 @@ def test_beamformer_vs_oracle():
     assert w0.shape == r0.shape == (1, T)
     for a, b in ((w0, r0), (w1, r1)):
         assert float((a.cpu() - b).abs().max()) < 2e-3   # waveforms peak-normalised to 0.9
+
+
+def test_doa_merge_vs_oracle():
+    """7-channel DOA merge (separator.py:113-250): steering vectors, likelihood kernel and the merge decision vs
+    oracle/doa.py (restated from the source text; parity unpinned).  Window 0: both masks select the same plane wave
+    (outputs point the same way -> one is silenced); window 1: two sources 120 degrees apart (nothing changes)."""
+    from css_amd.executor.separator import Separator
+    from oracle import doa
+
+    class _NoModel:
+        pass
+
+    conf = dict(batch_size=2, eval_win=2.4, eval_hop=0.8, frame_length=512, frame_shift=256,
+                ipd="1,0;2,0;3,0;4,0;5,0;6,0", merge=True, merge_threshold=16)
+    sep = Separator(conf, model=_NoModel())
+    sv, ang = doa.steervec_7ch(257, 30)
+    assert float((sep.steervec - sv).abs().max()) < 1e-6 and torch.equal(sep.angles, ang)
+    B, F, T = 2, 257, 40
+    rs = np.random.RandomState(3)
+    s = torch.from_numpy((rs.standard_normal((2, B, F, T)) + 1j * rs.standard_normal((2, B, F, T))).astype(np.complex64))
+    # plane waves built from the steering table itself (which look direction the likelihood peaks at is the
+    # reference's convention; only "same direction" vs "120 degrees apart" matters here)
+    dirs = [(4, 4), (3, 13)]
+    X = torch.zeros((B, 7, F, T), dtype=torch.complex64)
+    mask = torch.zeros((B, F, T, 2))
+    sel = torch.from_numpy(rs.uniform(0, 1, (B, F, T)) > 0.5)
+    for b in range(B):
+        for k in range(2):
+            X[b] += sv[:, dirs[b][k], :].conj().t()[:, :, None] * s[k, b][None] * (sel[b] if k == 0 else ~sel[b])[None]
+        mask[b, ..., 0] = sel[b].float() * 0.9 + 0.05
+        mask[b, ..., 1] = (~sel[b]).float() * 0.9 + 0.05
+    X += 0.05 * torch.from_numpy((rs.standard_normal(tuple(X.shape)) + 1j * rs.standard_normal(tuple(X.shape))).astype(np.complex64))
+    re, im = X.real.contiguous().to(DEV), X.imag.contiguous().to(DEV)
+    like, en = sep.doa_likelihood(re, im, mask.to(DEV))
+    for fix in (False, True):
+        ref_mask, ref_like = doa.angle_merge(X, mask, sv, ang, sep._lo, sep._hi, thresh=16, fix_indexing=fix)
+        if not fix:
+            assert float((like.cpu() - ref_like).abs().max()) < 2e-4 * float(ref_like.abs().max())
+            am = torch.argmax(like.cpu(), -1).tolist()
+            assert am == torch.argmax(ref_like, -1).tolist()
+            assert am[0][0] == am[0][1] and (am[1][1] - am[1][0]) % 30 == 10   # same direction / 120 degrees apart
+        sep.fix_merge_indexing = fix
+        got = sep.angle_merge(re, im, mask.to(DEV), thresh=16).cpu()
+        assert torch.equal(got, ref_mask)
+        assert float(got[0, ..., :].min()) == pytest.approx(1e-12) and torch.equal(got[1], mask[1])
