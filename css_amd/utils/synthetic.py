@@ -141,7 +141,7 @@ def synthetic_sources(batch, n_samples, n_src=2, seed=0, noise=0.0):
     starts at a delay drawn from U(0, n/2) (separation.py:176-190 semantics:
     offset mix, pad to mixture length).
     """
-    r = np.random.RandomState(1000003 * seed + 17)
+    r = np.random.RandomState((1000003 * seed + 17) % (2 ** 32))
     fir = np.array([0.25, 0.5, 0.25])
     src = np.zeros((n_src, batch, n_samples), dtype=np.float32)
     for k in range(n_src):
