@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fuse-conv", type=int, default=None, help="debug: csship_conformer_weights.fuse_conv override")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying the "
                     "step as one captured HIP graph")
     ap.add_argument("--blocks", type=int, default=16, help="debug only: anything but 16 is not the headline config")
@@ -71,6 +72,8 @@ def main():
     sd = syn.fill_state_dict(syn.conformer_shapes(num_blocks=args.blocks), 0)
     model.load_state_dict(sd)
     model = model.to(dev).eval()
+    if args.fuse_conv is not None:
+        model.fuse_conv = args.fuse_conv
 
     mix, src = syn.synthetic_sources(B, N_SAMPLES, seed=rank)
     audio = torch.stack([mix, src[0], src[1]], 0).to(dev)  # [3, B, n]

@@ -180,6 +180,10 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
         // optional (28.4 vs 27.2 us): x += out-proj(attn); g = glu(LN_conv(x)) in the same epilogue; conv back half from g
         TRY(csship_outproj_glu(ws.ao_bf, L.mha.wo, L.mha.bo, x, x, &L.conv, y, M, D, stream));
         TRY(csship_conv_from_glu(x, y, x, &L.conv, B, T, D, w->kernel_size, stream));
+      } else if (w->bn_mode == 0 && w->fuse_conv == 3) {
+        // one kernel: x2 = x + out-proj(attn) and the conv module on it (256 workgroups at T = 400)
+        TRY(csship_outproj_conv(ws.ao_bf, L.mha.wo, L.mha.bo, x, y, &L.conv, B, T, D, w->kernel_size, stream));
+        { float* t = x; x = y; y = t; }
       } else {
         TRY(csship_panel_linear(ws.ao_bf, CSSHIP_PRO_BF16, nullptr, nullptr, L.mha.wo, L.mha.bo, x, D, 1.f, x, D, M, D,
                                 D, CSSHIP_EPI_RESIDUAL, stream));

@@ -1021,6 +1021,212 @@ __global__ __launch_bounds__(NW * 64) void embed_kernel(EmbedArgs a) {
   }
 }
 
+// =============================================================================== out-proj + conv module, one kernel
+// x2 = x1 + attn_out Wo^T + bo (conformer.py:254,356) followed by the convolution module + residual
+// (conformer.py:289-303,357), eval-mode BatchNorm.  One workgroup = (batch b, 50 output frames): it projects the 82
+// frames of tile + halo (96-row bf16 panel, 6 row tiles per wave: the halo is recomputed, 1.6x of a 13 MFLOP GEMM),
+// finishes the rows through the staged tile (residual -> x2 rows of the own frames go to `out`; LayerNorm -> scalar
+// GLU written back IN PLACE, so the staging tile becomes the stencil's input), then two threads per channel run the
+// 33-tap depthwise convolution, BatchNorm, ReLU, affine and add onto x2 in `out`.  8 tiles x 32 chunks = 256
+// workgroups at T = 400: exactly one round of the chip, one launch per block instead of two, x2 never makes a round
+// trip through a separate buffer.  `out` must not alias x1 (neighbouring workgroups read each other's halo rows).
+constexpr int OC_TT = 50, OC_HALO = 16, OC_USED = OC_TT + 2 * OC_HALO, OC_RT = 6, OC_ROWS = 16 * OC_RT, OC_KS = 33;
+static_assert(OC_USED <= OC_ROWS, "tile + halo must fit the row tiles");
+
+struct OcArgs {
+  const unsigned short* ao;  // attention output bf16 [B*T, 256]
+  const bf16x8* wo;          // packed [16][8][64]
+  const float* bo;
+  const float* x1;           // residual stream in  [B*T, 256]
+  float* out;                // residual stream out [B*T, 256]
+  csship_conv_weights cw;
+  int B, T;
+  unsigned long long* stamps;
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void outproj_conv_kernel(OcArgs a) {
+  static_assert(NW == 8, "row phases: 8 lanes per row, 64 rows per pass; stencil: 2 threads per channel");
+  constexpr int NT = 16 / NW, NSTAGE = OC_ROWS * 32 / (NW * 64);
+  __shared__ __attribute__((aligned(16))) unsigned char Xs[OC_ROWS * 512];
+  __shared__ __attribute__((aligned(16))) float Ys[OC_ROWS * YS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15;
+  const int b = blockIdx.y, t0 = blockIdx.x * OC_TT;
+  const size_t rowb = (size_t)b * a.T;
+  const bf16x8* ws_ = a.wo + (size_t)(wave * NT) * KS * 64 + lane;
+  bf16x8 wq[PD][NT];
+  stamp(a.stamps, 0);
+  prefetch_first<NT>(wq, ws_, KS, NT);
+
+  // ---- attention-output rows of tile + halo -> bf16 panel (rows outside the utterance / beyond row 81: zero).
+  // Panel loads first, then the residual rows of the row phase are put in flight, then the panel is written: the
+  // barrier below waits for the panel data only, the residual rows land during the GEMM.
+  uint4 av[NSTAGE];
+#pragma unroll
+  for (int k = 0; k < NSTAGE; ++k) {
+    const int i = tid + k * NW * 64;
+    const int r = i >> 5, c = i & 31, t = t0 - OC_HALO + r;
+    av[k] = make_uint4(0, 0, 0, 0);
+    if (r < OC_USED && t >= 0 && t < a.T) av[k] = *reinterpret_cast<const uint4*>(a.ao + (rowb + t) * DM + c * 8);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  float4 xres[2][8];  // two passes of 64 rows, 8 lanes per row
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int r = pass * 64 + (tid >> 3), t = t0 - OC_HALO + r;
+    const bool ok = r < OC_USED && t >= 0 && t < a.T;
+    const float* xr = a.x1 + (rowb + (ok ? t : 0)) * DM;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      xres[pass][i] = ok ? *reinterpret_cast<const float4*>(xr + (i * 8 + (tid & 7)) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < NSTAGE; ++k) {
+    const int i = tid + k * NW * 64;
+    *reinterpret_cast<uint4*>(Xs + panel_off(i >> 5, i & 31)) = av[k];
+  }
+  __syncthreads();
+  stamp(a.stamps, 1);
+
+  // ---- out-proj: acc[t][rt] = Wo(tile)[16 x 256] . panel^T, weights streamed PD k-steps ahead
+  f32x4 acc[NT][OC_RT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int rt = 0; rt < OC_RT; ++rt) acc[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    bf16x8 xa[2][OC_RT];
+#pragma unroll
+    for (int rt = 0; rt < OC_RT; ++rt) xa[0][rt] = *reinterpret_cast<const bf16x8*>(Xs + panel_off(rt * 16 + n, g));
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 wc[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) wc[t] = wq[ks % PD][t];
+      if (ks + PD < KS) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) wq[ks % PD][t] = ws_[(size_t)(t * KS + ks + PD) * 64];
+      }
+      if (ks + 1 < KS) {
+#pragma unroll
+        for (int rt = 0; rt < OC_RT; ++rt)
+          xa[(ks + 1) & 1][rt] = *reinterpret_cast<const bf16x8*>(Xs + panel_off(rt * 16 + n, (ks + 1) * 4 + g));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int rt = 0; rt < OC_RT; ++rt)
+          acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[t], xa[ks & 1][rt], acc[t][rt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int col = (wave * NT + t) * 16 + 4 * g;
+    const float4 bb = *reinterpret_cast<const float4*>(a.bo + col);
+#pragma unroll
+    for (int rt = 0; rt < OC_RT; ++rt)
+      *reinterpret_cast<float4*>(Ys + (rt * 16 + n) * YS + col) =
+          make_float4(acc[t][rt][0] + bb.x, acc[t][rt][1] + bb.y, acc[t][rt][2] + bb.z, acc[t][rt][3] + bb.w);
+  }
+  __syncthreads();
+  stamp(a.stamps, 2);
+
+  // ---- rows: x2 = x1 + proj; own frames -> out; g = GLU(LN(x2)) back into the staging tile (zero outside the utterance)
+  {
+    const float w0 = a.cw.pw1_w[0], w1 = a.cw.pw1_w[1], b0 = a.cw.pw1_b[0], b1 = a.cw.pw1_b[1];
+    const int part = tid & 7;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int r = pass * 64 + (tid >> 3);
+      if (r >= OC_USED) continue;
+      const int t = t0 - OC_HALO + r;
+      float* yrow = Ys + r * YS;
+      if (t < 0 || t >= a.T) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(yrow + (i * 8 + part) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        continue;
+      }
+      const bool own = r >= OC_HALO && r < OC_HALO + OC_TT;
+      float4 v[8];
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float4 xv = xres[pass][i];
+        const float4 pv = *reinterpret_cast<const float4*>(yrow + (i * 8 + part) * 4);
+        v[i] = make_float4(xv.x + pv.x, xv.y + pv.y, xv.z + pv.z, xv.w + pv.w);
+        if (own) *reinterpret_cast<float4*>(a.out + (rowb + t) * DM + (i * 8 + part) * 4) = v[i];
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      }
+      const float mean = sum8(s) * (1.f / DM);
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+        ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+      }
+      const float rstd = rsqrtf(sum8(ss) * (1.f / DM) + 1e-5f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = (i * 8 + part) * 4;
+        const float4 gm = *reinterpret_cast<const float4*>(a.cw.ln_g + c);
+        const float4 bt = *reinterpret_cast<const float4*>(a.cw.ln_b + c);
+        float e[4] = {v[i].x * rstd * gm.x + bt.x, v[i].y * rstd * gm.y + bt.y, v[i].z * rstd * gm.z + bt.z,
+                      v[i].w * rstd * gm.w + bt.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e[q] = (w0 * e[q] + b0) * __builtin_amdgcn_rcpf(1.f + __expf(-(w1 * e[q] + b1)));
+        *reinterpret_cast<float4*>(yrow + c) = make_float4(e[0], e[1], e[2], e[3]);
+      }
+    }
+  }
+  __syncthreads();  // also orders this workgroup's x2 stores before they are read back below
+  stamp(a.stamps, 3);
+
+  // ---- depthwise conv + BatchNorm (running statistics) + ReLU + affine, added onto x2
+  {
+    const int c = tid & (DM - 1), half = tid >> 8;
+    constexpr int TH = OC_TT / 2, OB = 5;
+    float wk[OC_KS];
+#pragma unroll
+    for (int k = 0; k < OC_KS; ++k) wk[k] = a.cw.dw_w[k * DM + c];
+    const float cb = a.cw.dw_b[c];
+    const float scale = a.cw.bn_g[c] * rsqrtf(a.cw.bn_var[c] + 1e-5f);
+    const float shift = a.cw.bn_b[c] - a.cw.bn_mean[c] * scale;
+    const float pw2w = a.cw.pw2_w[0], pw2b = a.cw.pw2_b[0];
+    float x2v[TH];  // this thread's x2 values (written by the row phase of this workgroup): all loads in flight at once
+#pragma unroll
+    for (int j = 0; j < TH; ++j) {
+      const int t = min(t0 + half * TH + j, a.T - 1);
+      x2v[j] = a.out[(rowb + t) * DM + c];
+    }
+#pragma unroll
+    for (int blk = 0; blk < TH / OB; ++blk) {
+      const int tb = half * TH + blk * OB;  // output frame within the tile; its taps are staging rows tb .. tb + 32
+      float o[OB];
+#pragma unroll
+      for (int j = 0; j < OB; ++j) o[j] = cb;
+#pragma unroll
+      for (int u = 0; u < OB + OC_KS - 1; ++u) {
+        const float gv = Ys[(tb + u) * YS + c];
+#pragma unroll
+        for (int j = 0; j < OB; ++j) {
+          const int k = u - j;
+          if (k >= 0 && k < OC_KS) o[j] += wk[k] * gv;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < OB; ++j) {
+        const int t = t0 + tb + j;
+        if (t >= a.T) continue;
+        a.out[(rowb + t) * DM + c] = x2v[blk * OB + j] + fmaxf(o[j] * scale + shift, 0.f) * pw2w + pw2b;
+      }
+    }
+  }
+  stamp(a.stamps, 4);
+}
+
 constexpr int NWAVES = 8;
 
 template <int PRO, int EPI>
@@ -1048,6 +1254,25 @@ extern "C" int csship_ffn_fused(const float* x, float* out, const float* ln_g, c
   dim3 grid((M + BM - 1) / BM), block(NWAVES * 64);
   if (final_ln_g) hipLaunchKernelGGL((ffn_kernel<NWAVES, true>), grid, block, 0, as_stream(stream), a);
   else hipLaunchKernelGGL((ffn_kernel<NWAVES, false>), grid, block, 0, as_stream(stream), a);
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
+extern "C" int csship_outproj_conv(const uint16_t* attn_out, const uint16_t* wo_packed, const float* bo, const float* x,
+                                   float* out, const csship_conv_weights* conv, int32_t B, int32_t T, int32_t d_model,
+                                   int32_t kernel_size, csship_stream_t stream) {
+  if (!attn_out || !wo_packed || !bo || !x || !out || !conv) return CSSHIP_ENULL;
+  if (!conv->ln_g || !conv->ln_b || !conv->pw1_w || !conv->pw1_b || !conv->dw_w || !conv->dw_b || !conv->bn_g ||
+      !conv->bn_b || !conv->bn_mean || !conv->bn_var || !conv->pw2_w || !conv->pw2_b)
+    return CSSHIP_ENULL;
+  if (B <= 0 || T <= 0 || B > 65535) return CSSHIP_EBADSHAPE;
+  if (d_model != DM || kernel_size != OC_KS) return CSSHIP_EUNSUPPORTED;
+  if (x == out) return CSSHIP_EBADSHAPE;  // halo rows of neighbouring tiles are read from x
+  if (!aligned16(attn_out) || !aligned16(wo_packed) || !aligned16(bo) || !aligned16(x) || !aligned16(out) ||
+      !aligned16(conv->ln_g) || !aligned16(conv->ln_b))
+    return CSSHIP_EALIGN;
+  OcArgs a{attn_out, reinterpret_cast<const bf16x8*>(wo_packed), bo, x, out, *conv, B, T, g_csship_stamps};
+  hipLaunchKernelGGL((outproj_conv_kernel<NWAVES>), dim3((T + OC_TT - 1) / OC_TT, B), dim3(NWAVES * 64), 0, as_stream(stream), a);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }

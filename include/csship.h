@@ -297,8 +297,9 @@ typedef struct {
   int32_t bn_mode;         /* 0 eval, 1 batch statistics */
   int32_t generic;         /* 0: tuned d_model = 256 path, PACKED weights as documented per field; 1: any-width
                             * unfused path (d_model 256 or 512), ALL Linear weights ROW-MAJOR bf16 [N, K padded to 64] */
-  int32_t fuse_conv;       /* eval only: 0 = separate conv module (default, fastest at B=32 x T=400); 1 = conv fused into
-                            * csship_outproj_glu + csship_encoder_chain; 2 = csship_outproj_glu + csship_conv_from_glu */
+  int32_t fuse_conv;       /* eval only: 0 = default; 1 = conv fused into csship_outproj_glu + csship_encoder_chain;
+                            * 2 = csship_outproj_glu + csship_conv_from_glu; 3 = csship_outproj_conv (one kernel for
+                            * output projection + conv module); 4 = separate csship_panel_linear + csship_convmod */
   const uint16_t* embed_w; const float* embed_b; /* PACKED bf16 from [d_model, idim_pad], idim_pad = idim rounded up to 256 */
   const float *embed_ln_g, *embed_ln_b;
   const uint16_t* pe_k;    /* PACKED relative-position blocks (csship_mha_relpos) */
@@ -348,6 +349,14 @@ int csship_bgemm(const void* A, const void* B, void* C, const float* bias, const
 size_t csship_colsum_workspace(int64_t M, int32_t N);
 int csship_colsum(const void* x, int32_t x_is_f32, int64_t M, int32_t N, int64_t ld, float alpha, float* out,
                   void* workspace, size_t workspace_bytes, csship_stream_t stream);
+
+/* ---- csship_outproj_conv (css_amd/csrc/panel.hip): attention output projection + residual (conformer.py:254,356)
+ * AND the convolution module + residual (conformer.py:289-303,357, BatchNorm with running statistics) as one kernel:
+ * out = x2 + ConvModule(x2), x2 = x + attn_out Wo^T + bo.  attn_out bf16 [B*T, 256]; x, out f32 [B*T, 256], out != x;
+ * conv as for csship_convmod (bn_mean / bn_var required). */
+int csship_outproj_conv(const uint16_t* attn_out, const uint16_t* wo_packed, const float* bo, const float* x,
+                        float* out, const csship_conv_weights* conv, int32_t B, int32_t T, int32_t d_model,
+                        int32_t kernel_size, csship_stream_t stream);
 
 /* ---- csship_ffn_bwd (css_amd/csrc/panel.hip): the activation side of the FeedForward backward as ONE row-panel kernel.
  * For out = x + alpha * (relu(LN(x) W1^T + b1) W2^T + b2) and dy = d(out) it produces

@@ -134,10 +134,20 @@ def test_fused_conv_path_matches():
     f = rnd((3, 70, 257), 21).abs().to(DEV)
     ref = m.forward_masks(f).clone()
     o = torch.cat(oracle.conformer.forward(f.cpu(), sd, num_blocks=2)[1], 2)
-    for mode in (1, 2):  # 1: conv inside the chain kernel; 2: out-proj + GLU, then conv from g
+    # 1: conv inside the chain kernel; 2: out-proj + GLU, then conv from g; 3: out-proj + conv module in one kernel
+    # (50-frame tiles: T = 70 has a partial second tile); 4: separate out-proj and conv kernels
+    for mode in (1, 2, 3, 4):
         m.fuse_conv = mode
         got = m.forward_masks(f)
-        assert mask_mse(got, ref) < 1e-6 and mask_mse(got, o) < 1e-4
+        assert mask_mse(got, ref) < 1e-6 and mask_mse(got, o) < 1e-4, mode
+    m.fuse_conv = 0
+    # a length that is an exact multiple of the tile, and one frame more
+    for T in (100, 101):
+        f2 = rnd((2, T, 257), 22).abs().to(DEV)
+        m.fuse_conv = 4
+        r2 = m.forward_masks(f2).clone()
+        m.fuse_conv = 3
+        assert mask_mse(m.forward_masks(f2), r2) < 1e-6
     m.fuse_conv = 0
 
 
