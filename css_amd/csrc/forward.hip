@@ -145,7 +145,10 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
   TRY(csship_embed(f, ldf, ws.mean, ws.rinv, w->embed_w, w->embed_b, w->embed_ln_g, w->embed_ln_b, ws.x0, B, T, w->idim,
                    D, stream));
   float *x = ws.x0, *y = ws.x1;
-  if (w->bn_mode == 0 && w->fuse_conv == 1) {
+  // fuse_conv 0 = default: out-proj + conv module as one kernel in eval mode, separate kernels when BatchNorm needs
+  // batch statistics (a grid-wide reduction sits between the convolution and the ReLU then)
+  const int conv_mode = w->fuse_conv != 0 ? w->fuse_conv : (w->bn_mode == 0 ? 3 : 4);
+  if (w->bn_mode == 0 && conv_mode == 1) {
     // optional (measured slower at B=32 x T=400: 83 vs 75 us per block): 3 launches per block.  Row-local operators are chained per 64-row panel (csship_encoder_chain):
     //   [conv back half(l-1) -> FFN_out(l-1) + block LN] -> FFN_in(l) -> pre-LN + q/k/v projection(l)
     float* gbuf = y;  // glu(LN_conv(x)) rows handed from the output projection to the next chain
@@ -166,9 +169,8 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
       }
     }
   } else {
-    // default: 4 launches per block.  The conv module is a separate op (in training mode BatchNorm batch
-    // statistics need a grid-wide reduction between conv and ReLU anyway); FFN_out(l-1) + LN -> FFN_in(l) ->
-    // q/k/v projection(l) are chained per 64-row panel
+    // default: 3 launches per block: chain (FFN_out(l-1) + LN -> FFN_in(l) -> q/k/v projection(l), per 64-row
+    // panel), attention, out-proj + conv module
     for (int l = 0; l < w->n_layer; ++l) {
       const csship_layer_weights& L = w->layers[l];
       const csship_layer_weights* P = l > 0 ? &w->layers[l - 1] : nullptr;
@@ -176,11 +178,11 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
                                P ? P->ln_b : nullptr, &L.ffn_in, L.mha.ln_g, L.mha.ln_b, L.mha.wqkv, L.mha.bqkv,
                                ws.qkv_bf, M, D, FF, 3 * D, stream));
       TRY(csship_mha_relpos(ws.qkv_bf, w->pe_k, w->pe_q_min, w->pe_q_max, ws.ao_bf, B, T, w->n_head, stream));
-      if (w->bn_mode == 0 && w->fuse_conv == 2) {
+      if (w->bn_mode == 0 && conv_mode == 2) {
         // optional (28.4 vs 27.2 us): x += out-proj(attn); g = glu(LN_conv(x)) in the same epilogue; conv back half from g
         TRY(csship_outproj_glu(ws.ao_bf, L.mha.wo, L.mha.bo, x, x, &L.conv, y, M, D, stream));
         TRY(csship_conv_from_glu(x, y, x, &L.conv, B, T, D, w->kernel_size, stream));
-      } else if (w->bn_mode == 0 && w->fuse_conv == 3) {
+      } else if (w->bn_mode == 0 && conv_mode == 3) {
         // one kernel: x2 = x + out-proj(attn) and the conv module on it (256 workgroups at T = 400)
         TRY(csship_outproj_conv(ws.ao_bf, L.mha.wo, L.mha.bo, x, y, &L.conv, B, T, D, w->kernel_size, stream));
         { float* t = x; x = y; y = t; }

@@ -297,9 +297,10 @@ typedef struct {
   int32_t bn_mode;         /* 0 eval, 1 batch statistics */
   int32_t generic;         /* 0: tuned d_model = 256 path, PACKED weights as documented per field; 1: any-width
                             * unfused path (d_model 256 or 512), ALL Linear weights ROW-MAJOR bf16 [N, K padded to 64] */
-  int32_t fuse_conv;       /* eval only: 0 = default; 1 = conv fused into csship_outproj_glu + csship_encoder_chain;
-                            * 2 = csship_outproj_glu + csship_conv_from_glu; 3 = csship_outproj_conv (one kernel for
-                            * output projection + conv module); 4 = separate csship_panel_linear + csship_convmod */
+  int32_t fuse_conv;       /* 0 = default (3 in eval mode, 4 with batch statistics); eval only: 1 = conv fused into
+                            * csship_outproj_glu + csship_encoder_chain; 2 = csship_outproj_glu + csship_conv_from_glu;
+                            * 3 = csship_outproj_conv (output projection + conv module in one kernel);
+                            * 4 = separate csship_panel_linear + csship_convmod */
   const uint16_t* embed_w; const float* embed_b; /* PACKED bf16 from [d_model, idim_pad], idim_pad = idim rounded up to 256 */
   const float *embed_ln_g, *embed_ln_b;
   const uint16_t* pe_k;    /* PACKED relative-position blocks (csship_mha_relpos) */
