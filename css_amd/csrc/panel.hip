@@ -1131,6 +1131,14 @@ __global__ __launch_bounds__(NW * 64) void outproj_conv_kernel(OcArgs a) {
       *reinterpret_cast<float4*>(Ys + (rt * 16 + n) * YS + col) =
           make_float4(acc[t][rt][0] + bb.x, acc[t][rt][1] + bb.y, acc[t][rt][2] + bb.z, acc[t][rt][3] + bb.w);
   }
+  // stencil constants of this thread's channel: requested now, they arrive during the row phase
+  float wk[OC_KS];
+  {
+    const int c = tid & (DM - 1);
+#pragma unroll
+    for (int k = 0; k < OC_KS; ++k) wk[k] = a.cw.dw_w[k * DM + c];
+  }
+  __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
   stamp(a.stamps, 2);
 
@@ -1184,13 +1192,16 @@ __global__ __launch_bounds__(NW * 64) void outproj_conv_kernel(OcArgs a) {
   __syncthreads();  // also orders this workgroup's x2 stores before they are read back below
   stamp(a.stamps, 3);
 
-  // ---- depthwise conv + BatchNorm (running statistics) + ReLU + affine, added onto x2
+  // ---- depthwise conv + BatchNorm (running statistics) + ReLU + affine, added onto x2.
+  // Two outputs per packed FMA: o2[p] = {out[2p], out[2p+1]} += {w[m], w[m-1]} * g[u] with m = u - 2p; the thread's
+  // 57 staging values are read once into registers (no re-reads, no wait per tap).
   {
+    typedef float f2 __attribute__((ext_vector_type(2)));
     const int c = tid & (DM - 1), half = tid >> 8;
-    constexpr int TH = OC_TT / 2, OB = 5;
-    float wk[OC_KS];
+    constexpr int TH = OC_TT / 2, NP = (TH + 1) / 2, NG = TH + OC_KS - 1;
+    f2 wp[OC_KS + 1];  // wp[m] = {w[m], w[m-1]}, zero outside 0..32
 #pragma unroll
-    for (int k = 0; k < OC_KS; ++k) wk[k] = a.cw.dw_w[k * DM + c];
+    for (int m = 0; m <= OC_KS; ++m) wp[m] = f2{m < OC_KS ? wk[m] : 0.f, m > 0 ? wk[m - 1] : 0.f};
     const float cb = a.cw.dw_b[c];
     const float scale = a.cw.bn_g[c] * rsqrtf(a.cw.bn_var[c] + 1e-5f);
     const float shift = a.cw.bn_b[c] - a.cw.bn_mean[c] * scale;
@@ -1201,27 +1212,25 @@ __global__ __launch_bounds__(NW * 64) void outproj_conv_kernel(OcArgs a) {
       const int t = min(t0 + half * TH + j, a.T - 1);
       x2v[j] = a.out[(rowb + t) * DM + c];
     }
+    float gv[NG];
 #pragma unroll
-    for (int blk = 0; blk < TH / OB; ++blk) {
-      const int tb = half * TH + blk * OB;  // output frame within the tile; its taps are staging rows tb .. tb + 32
-      float o[OB];
+    for (int u = 0; u < NG; ++u) gv[u] = Ys[(half * TH + u) * YS + c];
+    f2 o2[NP];
 #pragma unroll
-      for (int j = 0; j < OB; ++j) o[j] = cb;
+    for (int p_ = 0; p_ < NP; ++p_) o2[p_] = f2{cb, cb};
 #pragma unroll
-      for (int u = 0; u < OB + OC_KS - 1; ++u) {
-        const float gv = Ys[(tb + u) * YS + c];
+    for (int u = 0; u < NG; ++u)
 #pragma unroll
-        for (int j = 0; j < OB; ++j) {
-          const int k = u - j;
-          if (k >= 0 && k < OC_KS) o[j] += wk[k] * gv;
-        }
+      for (int p_ = 0; p_ < NP; ++p_) {
+        const int m = u - 2 * p_;
+        if (m >= 0 && m <= OC_KS) o2[p_] = __builtin_elementwise_fma(wp[m], f2{gv[u], gv[u]}, o2[p_]);
       }
 #pragma unroll
-      for (int j = 0; j < OB; ++j) {
-        const int t = t0 + tb + j;
-        if (t >= a.T) continue;
-        a.out[(rowb + t) * DM + c] = x2v[blk * OB + j] + fmaxf(o[j] * scale + shift, 0.f) * pw2w + pw2b;
-      }
+    for (int j = 0; j < TH; ++j) {
+      const int t = t0 + half * TH + j;
+      if (t >= a.T) continue;
+      const float v = (j & 1) ? o2[j >> 1].y : o2[j >> 1].x;
+      a.out[(rowb + t) * DM + c] = x2v[j] + fmaxf(v * scale + shift, 0.f) * pw2w + pw2b;
     }
   }
   stamp(a.stamps, 4);
