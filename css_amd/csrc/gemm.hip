@@ -241,7 +241,8 @@ extern "C" int csship_gemm(const void* A, const uint16_t* W, const float* bias, 
     case CSSHIP_A_BF16 * 16 + (CSSHIP_EPI_RELU | CSSHIP_EPI_OUT_BF16):
       return launch<2, 2, CSSHIP_A_BF16, CSSHIP_EPI_RELU | CSSHIP_EPI_OUT_BF16>(a, s);
     case CSSHIP_A_BF16 * 16 + CSSHIP_EPI_RELU: return launch<2, 2, CSSHIP_A_BF16, CSSHIP_EPI_RELU>(a, s);
-    case CSSHIP_A_BF16 * 16 + CSSHIP_EPI_RESIDUAL: return launch<1, 4, CSSHIP_A_BF16, CSSHIP_EPI_RESIDUAL>(a, s);
+    case CSSHIP_A_BF16 * 16 + CSSHIP_EPI_RESIDUAL:  // no row-wide epilogue: the square tile does more MFMA work per byte staged
+      return launch<2, 2, CSSHIP_A_BF16, CSSHIP_EPI_RESIDUAL>(a, s);
     case CSSHIP_A_BF16 * 16 + (CSSHIP_EPI_RESIDUAL | CSSHIP_EPI_LAYERNORM):
       return launch<1, 4, CSSHIP_A_BF16, CSSHIP_EPI_RESIDUAL | CSSHIP_EPI_LAYERNORM>(a, s);
     // A fp32 (converted on load)

@@ -1,0 +1,28 @@
+"""Forward + PIT timing of the Conformer-large shape class (config 5: d_model 512, 8 heads, ffn 2048, 18 blocks,
+3 speakers + noise) through the any-width path.  Usage: python tools/bench_large.py [--blocks 18]"""
+import argparse, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from css_amd import ops
+from css_amd.models import MODELS
+from css_amd.utils import synthetic as syn
+
+ap = argparse.ArgumentParser(); ap.add_argument("--blocks", type=int, default=18); a = ap.parse_args()
+conf = dict(attention_dim=512, attention_heads=8, linear_units=2048, num_blocks=a.blocks, kernel_size=33, dropout_rate=0.1,
+            relative_pos_emb=True)
+m = MODELS["Conformer"](257, 257, 3, 1, conf)
+m.load_state_dict(syn.fill_state_dict(syn.conformer_shapes(num_spk=3, attention_dim=512, attention_heads=8, linear_units=2048,
+                                                           num_blocks=a.blocks), 0))
+m = m.cuda().eval()
+B, T = 32, 400
+f = torch.rand(B, T, 257, device="cuda")
+tg = [torch.rand(B, T, 257, device="cuda") * 0.5 for _ in range(3)]
+with torch.no_grad():
+    for _ in range(3):
+        masks = m.forward_masks(f); ops.pit_mse(masks, f, tg)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10):
+        masks = m.forward_masks(f); loss = ops.pit_mse(masks, f, tg)[0]
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+flop = B * T * 212.8e6 * a.blocks / 18
+print(f"Conformer-large {a.blocks} blocks, 32x400: {dt*1e3:.2f} ms/step = {B*T/dt/1e6:.3f} M frames/s, {flop/dt/1e12:.0f} TFLOP/s algorithmic, loss {float(loss):.4f}")
