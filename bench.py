@@ -92,7 +92,7 @@ def main():
 
     for _ in range(args.warmup):
         loss = step()
-    fence()
+    torch.cuda.synchronize()  # (the first collective - the barrier in fence() - comes after the capture below)
     # the step is a fixed sequence of ~70 kernel launches on one stream: capture it once, replay it per step
     # (same kernels, same inputs resident in HBM; only the host-side launch work disappears)
     graphed = False
@@ -105,7 +105,9 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread_local: other threads of this process (e.g. the RCCL watchdog when world > 1) may touch the
+            # runtime while this thread captures
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 static_loss = step()
             eager_step = step
 
@@ -118,7 +120,7 @@ def main():
         except Exception as e:  # noqa: BLE001  (capture unsupported: keep the eager launches)
             print(f"[bench] graph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
             step = eager_step if "eager_step" in dir() else step
-        fence()
+    fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()

@@ -42,7 +42,7 @@ class GraphedTrainStep:
             b.copy_(s_)
         optim._step = step0
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss, self.grad_norm = self._eager()
 
     def _eager(self):
