@@ -390,3 +390,31 @@ def test_forward_bitwise_reproducible():
         from css_amd import ops
         l0 = ops.pit_mse(a, f, tg)[0].clone()
         assert torch.equal(ops.pit_mse(a, f, tg)[0], l0)
+
+
+@pytest.mark.parametrize("B,T", [(1, 2), (1, 9), (2, 49), (2, 50), (1, 51), (5, 129)])
+def test_conformer_small_and_ragged_shapes(B, T):
+    """Edge shapes through the whole eval path (tiles of 50 / 64 frames, 64-row panels, 64-key tiles all partial) vs
+    the oracle, both conv modes."""
+    m, sd = build(1, 35)
+    f = rnd((B, T, 257), 90 + T).abs()
+    o = torch.cat(oracle.conformer.forward(f, sd, num_blocks=1)[1], 2)
+    for mode in (0, 4):
+        m.fuse_conv = mode
+        got = m.forward_masks(f.to(DEV))
+        assert bool(torch.isfinite(got).all())
+        assert mask_mse(got, o) < 1e-4, (mode, B, T)
+    m.fuse_conv = 0
+
+
+def test_stft_short_signals():
+    """fewer frames than one wave's run of 8, and frame counts that are not multiples of it"""
+    from css_amd import ops
+    for n_frames in (1, 2, 7, 8, 9, 33):
+        n = 512 + 256 * (n_frames - 1)
+        x = rnd((3, n), 95 + n_frames, 0.1)
+        got = ops.stft(x.to(DEV), ("mag", "re", "im"))
+        ref = oracle.feature.stft(x)
+        assert got["mag"].shape == (3, n_frames, 257)
+        for k, r in zip(("mag", "re", "im"), (ref[0], ref[2], ref[3])):
+            assert float((got[k].cpu() - r.transpose(1, 2)).abs().max()) < 2e-5 * max(1.0, float(r.abs().max()))
