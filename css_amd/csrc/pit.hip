@@ -88,6 +88,8 @@ __global__ __launch_bounds__(256) void pit_finalize_kernel(const float* __restri
                                                            double norm, float* __restrict__ loss,
                                                            int* __restrict__ perm_out, float* __restrict__ pair_sse,
                                                            float* __restrict__ per_sample) {
+  __shared__ double best_sum[4];
+  double acc_best = 0.0;  // sum of this thread's samples' minima (threads with part == 0 only)
   for (int b0 = 0; b0 < B; b0 += 32) {
   const int b = b0 + (threadIdx.x >> 3), part = threadIdx.x & 7;
   double Dm[K][K];
@@ -132,16 +134,18 @@ __global__ __launch_bounds__(256) void pit_finalize_kernel(const float* __restri
       for (int l = i + 1, r = K - 1; l < r; ++l, --r) { tmp = p[l]; p[l] = p[r]; p[r] = tmp; }
     }
     per_sample[b] = best;
+    acc_best += (double)best;
     if (perm_out)
       for (int i = 0; i < K; ++i) perm_out[(size_t)b * K + i] = best_p[i];
   }
   }
+  // batch mean: fixed-order tree (lanes, then waves) instead of one thread re-reading per_sample from memory
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) acc_best += __shfl_xor(acc_best, o);
+  if ((threadIdx.x & 63) == 0) best_sum[threadIdx.x >> 6] = acc_best;
   __syncthreads();
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    // single block launch: per_sample is complete after the barrier
-    double s = 0.0;
-    for (int i = 0; i < B; ++i) s += (double)per_sample[i];
-    *loss = (float)(s / (double)B);
+    *loss = (float)(((best_sum[0] + best_sum[1]) + (best_sum[2] + best_sum[3])) / (double)B);
   }
 }
 
