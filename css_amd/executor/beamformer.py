@@ -81,35 +81,49 @@ class Beamformer:
         return result_spec / mvdr_energy * masked_energy
 
     # ------------------------------------------------------------------ the session loop, beamformer.py:32-124
+    def _spans(self, first, count, total):
+        """Which samples of each beamformed window go where (beamformer.py:104-118): window k = first + i keeps
+        [0, margin) if it starts the session, [margin - hop, end) if its batch ends the session, else the hop-long
+        piece [margin - hop, margin); it lands at k*hop + the same offset.  Returns (source offset, length) per window;
+        the destination is k*hop + source offset.  `total` is the session length T; the reference tests the BATCH end
+        (hop * (first + count)) against it, shifted per window."""
+        pm, eh = self.proceed_margin, self.eval_hop
+        out = []
+        for i in range(count):
+            st, en = eh * (first + i), eh * (first + count) + eh * i
+            if st == 0:
+                out.append((0, pm))
+            elif en == total:
+                out.append((pm - eh, None))
+            else:
+                out.append((pm - eh, eh))
+        return out
+
     def continuous_process(self, X, masks):
         """X: D x T waveform; masks: (speech_mask1, speech_mask2, noise_mask), each F x frames.
         Returns two 1 x T waveforms, peak-normalised to 0.9."""
         X = X.cuda().float()
         D, T = X.shape
-        m0, m1, mn = (m.cuda().float() for m in masks)
-        Xw = X.unfold(-1, self.eval_win + 256, self.eval_hop).permute(1, 0, 2)
-        m0 = m0.unfold(1, self.mask_win, self.mask_hop).permute(1, 0, 2)
-        m1 = m1.unfold(1, self.mask_win, self.mask_hop).permute(1, 0, 2)
-        mn = mn.unfold(1, self.mask_win, self.mask_hop).permute(1, 0, 2)
-        n_batches = math.ceil(Xw.shape[0] / self.batch_size)
-        res = [torch.zeros(T, device=X.device), torch.zeros(T, device=X.device)]
-        pm, eh = self.proceed_margin, self.eval_hop
-        for i in range(n_batches):
-            bstart = i * self.batch_size
-            bend = min((i + 1) * self.batch_size, Xw.shape[0]) + 1   # the reference's overlap by one window
-            xb = Xw[bstart:bend].contiguous()
-            ys = self._pair(xb, m0[bstart:bend].contiguous(), m1[bstart:bend].contiguous(), mn[bstart:bend].contiguous())
-            wavs = [ops.istft(yr, yi)[:, : xb.shape[-1]] for yr, yi in ys]
-            st, en = eh * bstart, eh * bend
-            for b in range(wavs[0].shape[0]):
-                for r, w in zip(res, wavs):
-                    if st == 0:
-                        r[st: st + pm] += w[b, :pm]
-                    elif en == T:
-                        r[st + pm - eh: st + w.shape[1]] += w[b, pm - eh:]
-                    else:
-                        r[st + pm - eh: st + pm] += w[b, pm - eh: pm]
-                st += eh
-                en += eh
-        out = [r * 0.9 / torch.max(torch.abs(r)) for r in res]
-        return out[0].unsqueeze(0), out[1].unsqueeze(0)
+        windows = X.unfold(-1, self.eval_win + 256, self.eval_hop).permute(1, 0, 2)           # W x D x n
+        mwin = [m.cuda().float().unfold(1, self.mask_win, self.mask_hop).permute(1, 0, 2) for m in masks]  # W x F x frames
+        W = windows.shape[0]
+        res = torch.zeros((2, T), device=X.device)
+        for first in range(0, W, self.batch_size):
+            last = min(first + self.batch_size, W) + 1          # the reference processes one window of the next batch too
+            xb = windows[first:last].contiguous()
+            ys = self._pair(xb, *(m[first:last].contiguous() for m in mwin))
+            wavs = torch.stack([ops.istft(yr, yi)[:, : xb.shape[-1]] for yr, yi in ys])   # 2 x nb x samples
+            nb, ns = wavs.shape[1], wavs.shape[2]
+            # gather every window's kept piece in ONE index_add per batch (a window shared by two batches adds twice,
+            # exactly as the reference's overlapping loop does)
+            src, dst = [], []
+            for i, (off, length) in enumerate(self._spans(first, nb, T)):
+                length = ns - off if length is None else min(length, ns - off)
+                k = torch.arange(length, device=X.device)
+                src.append(i * ns + off + k)
+                dst.append(self.eval_hop * (first + i) + off + k)
+            src, dst = torch.cat(src), torch.cat(dst)
+            keep = dst < T
+            res.index_add_(1, dst[keep], wavs.reshape(2, nb * ns)[:, src[keep]])
+        res = res * (0.9 / res.abs().amax(dim=1, keepdim=True))
+        return res[0:1], res[1:2]
