@@ -101,6 +101,8 @@ SIGNATURES = {
     "csship_relu_bwd": (_i32, [_p, _i64, _p, _i64, _i64, _i32, _p, _i64, _p]),
     "csship_mvn_apply": (_i32, [_p, _i64, _i64, _i64, _i64, _f32, _p, _p, _p, _i64, _p]),
     "csship_relpos_softmax": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p]),
+    "csship_attn_rowdot": (_i32, [_p, _p, _i32, _i32, _i32, _p, _p]),
+    "csship_attn_softmax_bwd": (_i32, [_p, _p, _p, _i64, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "csship_relpos_softmax_bwd": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _i32, _p]),
     "csship_convmod_bwd_workspace": (_sz, [_i32, _i32, _i32]),
     "csship_convmod_bwd": (_i32, [_p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p]),

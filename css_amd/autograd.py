@@ -166,6 +166,8 @@ class ConformerTrain(torch.autograd.Function):
         put(model.linear.weight, dw), put(model.linear.bias, db)
         window = bw.relpos_window(S["pe_bf"], T, enc.pos_emb.maxlen)
         dwin = None
+        # skewed dS buffer shared by all layers: the band positions are the same every layer, the rest stays zero
+        skew_buf = torch.zeros((B, T, H, window[0].shape[0]), dtype=BF, device=masks.device)
         for lay, L in zip(reversed(list(enc.encoders)), reversed(S["layers"])):
             dx, dg, dbeta = ob.layernorm_bwd(L["x4"], dx, lay.layer_norm.weight.detach(), lay.layer_norm.bias.detach())
             put(lay.layer_norm.weight, dg), put(lay.layer_norm.bias, dbeta)
@@ -193,7 +195,7 @@ class ConformerTrain(torch.autograd.Function):
             a = lay.self_attn
             dx, g = bw.mha_bwd(x1, dx, qkv.view(B, T, 3 * D), ao, a.layer_norm.weight.detach(),
                                a.layer_norm.bias.detach(), wqkv_bf, wo_bf, S["pe_bf"], H, scale, window=window,
-                               probs=(S["pe_pack"], lse))
+                               probs=(S["pe_pack"], lse), skew_buf=skew_buf)
             dg, dbeta, dwqkv, dbqkv, dwo, dbo, dw_l = g
             dwin = dw_l if dwin is None else dwin.add_(dw_l)
             put(a.layer_norm.weight, dg), put(a.layer_norm.bias, dbeta)

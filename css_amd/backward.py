@@ -64,7 +64,7 @@ def relpos_window(pe_table_bf, T, maxlen):
     return win, idx
 
 
-def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000, window=None, probs=None):
+def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000, window=None, probs=None, ao=None, skew_buf=None):
     """Backward of o = softmax(q k^T + q pe[i-j]^T) v (conformer.py:229-253; q already carries 1/sqrt(d_k)).
 
     qkv: bf16 [B, T, 3*H*64]; dao: bf16 [B*T, H*64] (gradient of the head-concatenated output).
@@ -84,8 +84,13 @@ def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000, window=None, probs=
         rel = ob.bgemm(q, win[None, None])               # q pe_window^T    [B,H,T,W]
         p = ob.relpos_softmax(s, rel, T)                 # bf16 [B,H,T,Tp]
     do = dao.view(B, T, H, 64).permute(0, 2, 1, 3)
-    dp = ob.bgemm(do, v)                                 # dO v^T           [B,H,T,T]
-    ds, dsk = ob.relpos_softmax_bwd(p, dp, T, W)         # dS, and dS skewed onto the window axis [B,T,H,W]
+    if ao is not None:      # attention-shaped softmax backward: no [B,H,T,T] f32 dP buffer
+        d = ob.attn_rowdot(dao, ao, B, T, H)
+        dsk = torch.zeros((B, T, H, W), dtype=BF, device=qkv.device) if skew_buf is None else skew_buf
+        ds, dsk = ob.attn_softmax_bwd(qkv, dao, p, d, dsk, H)
+    else:                   # generic route
+        dp = ob.bgemm(do, v)                             # dO v^T           [B,H,T,T]
+        ds, dsk = ob.relpos_softmax_bwd(p, dp, T, W)     # dS, and dS skewed onto the window axis [B,T,H,W]
     dqkv = torch.empty_like(qkv)
     dq, dk, dv = (dqkv.view(B, T, 3, H, 64)[:, :, i].permute(0, 2, 1, 3) for i in range(3))
     ob.bgemm(p[..., :T], do, a_kmajor=True, b_kmajor=True, out=dv)      # dV = P^T dO
@@ -101,7 +106,8 @@ def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000, window=None, probs=
     return dqkv, dpe
 
 
-def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_scale=0.125, window=None, probs=None):
+def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_scale=0.125, window=None, probs=None,
+            skew_buf=None, fused_softmax_bwd=True):
     """out = x + attention(LN(x)) @ wo^T + bo  (conformer.py:213-254,356).
 
     wqkv_bf holds the q rows already multiplied by q_scale (as the forward uses them); the returned dwqkv / dbqkv are
@@ -111,7 +117,8 @@ def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_s
     D = x.shape[1]
     dao, dwo, dbo = linear_bwd(dy, ao, wo_bf, dx_bf16=True)
     B = qkv.shape[0]
-    dqkv, dpe = mha_core_bwd(qkv, dao, pe_table_bf, n_head, window=window, probs=probs)
+    dqkv, dpe = mha_core_bwd(qkv, dao, pe_table_bf, n_head, window=window, probs=probs,
+                             ao=ao if fused_softmax_bwd else None, skew_buf=skew_buf)
     dq2 = dqkv.view(-1, 3 * D)
     a, _ = ops.layernorm(x, ln_g, ln_b)
     dw = torch.empty((3 * D, D), dtype=torch.float32, device=x.device)

@@ -261,6 +261,99 @@ __global__ __launch_bounds__(256, 4) void mha_relpos_kernel(const unsigned short
   }
 }
 
+// ---- softmax backward of the attention, attention-shaped (backward pass; replaces a [B,H,T,T] f32 dP buffer):
+//   dS[b,h,i,j] = P[i,j] * (dO_i . v_j - D[b,h,i]),   D = rowsum(dO o O)
+// Same tiling as the forward: workgroup = (b, h, 64 queries), wave = 16 queries, 64-key tiles of V staged in LDS in
+// the K-tile image, dP^T = V dO^T by MFMA with the dO rows as the B operand (as q is in the forward).  dS goes out
+// twice: row-major bf16 [B,H,T,ldp] (operand of dK = dS^T q, dq = dS k) and skewed onto the relative-position axis,
+// ds_skew[b,i,h, i-j+T-1] (operand of the position-table gradients); entries of ds_skew outside the band are not
+// written: the caller zeroes that buffer once.
+__global__ __launch_bounds__(256, 4) void attn_ds_kernel(const unsigned short* __restrict__ qkv,
+                                                         const unsigned short* __restrict__ dout,
+                                                         const unsigned short* __restrict__ p, const float* __restrict__ dvec,
+                                                         unsigned short* __restrict__ ds, unsigned short* __restrict__ dsk,
+                                                         int B, int T, int H, int64_t ldp, int W) {
+  __shared__ __attribute__((aligned(16))) unsigned char sV[64 * 128];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, n = lane & 15;
+  const int i0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  const int D = H * 64, D3 = 3 * D;
+  const int i0w = i0 + 16 * w;
+  const size_t base_b = (size_t)b * T;
+  const int qi = min(i0w + n, T - 1);
+  const bool qvalid = i0w + n < T;
+  bf16x8 dof[2];
+  {
+    const unsigned short* drow = dout + (base_b + qi) * D + h * 64;
+    dof[0] = *reinterpret_cast<const bf16x8*>(drow + 8 * g);
+    dof[1] = *reinterpret_cast<const bf16x8*>(drow + 32 + 8 * g);
+  }
+  const float dval = dvec[((size_t)b * H + h) * T + qi];
+  const size_t prow = (((size_t)b * H + h) * T + qi) * ldp;
+  unsigned short* skrow = dsk + ((base_b + qi) * H + h) * (size_t)W + (qi + T - 1);  // + (-j)
+
+  const int srow0 = tid >> 3, srow1 = srow0 + 32, sc = tid & 7;
+  uint4 vreg0, vreg1;
+#define DS_LOAD_V(J0)                                                                                          \
+  {                                                                                                            \
+    vreg0 = *reinterpret_cast<const uint4*>(qkv + (base_b + min((J0) + srow0, T - 1)) * D3 + 2 * D + h * 64 + sc * 8); \
+    vreg1 = *reinterpret_cast<const uint4*>(qkv + (base_b + min((J0) + srow1, T - 1)) * D3 + 2 * D + h * 64 + sc * 8); \
+  }
+#define DS_STORE_V()                                                 \
+  {                                                                  \
+    *reinterpret_cast<uint4*>(sV + tile_off(srow0, sc)) = vreg0;     \
+    *reinterpret_cast<uint4*>(sV + tile_off(srow1, sc)) = vreg1;     \
+  }
+  DS_LOAD_V(0)
+  DS_STORE_V()
+  __syncthreads();
+  for (int j0 = 0; j0 < T; j0 += 64) {
+    const bool more = j0 + 64 < T;
+    if (more) DS_LOAD_V(j0 + 64)
+    // P of this lane's 4 x 4 keys (zero beyond T by construction of the probabilities buffer)
+    uint2 pv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int j = j0 + 16 * t + 4 * g;
+      pv[t] = (j + 3 < ldp) ? *reinterpret_cast<const uint2*>(p + prow + j) : make_uint2(0u, 0u);
+    }
+    f32x4 s[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(sV + tile_off(16 * t + n, ks * 4 + g));
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, dof[ks], s[t], 0, 0, 0);
+      }
+    if (qvalid) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int j = j0 + 16 * t + 4 * g;
+        if (j + 3 >= ldp) continue;
+        const float p0 = bf2f((unsigned short)(pv[t].x & 0xffff)), p1 = bf2f((unsigned short)(pv[t].x >> 16));
+        const float p2 = bf2f((unsigned short)(pv[t].y & 0xffff)), p3 = bf2f((unsigned short)(pv[t].y >> 16));
+        const unsigned short d0 = f2bf(p0 * (s[t][0] - dval)), d1 = f2bf(p1 * (s[t][1] - dval));
+        const unsigned short d2 = f2bf(p2 * (s[t][2] - dval)), d3 = f2bf(p3 * (s[t][3] - dval));
+        *reinterpret_cast<uint2*>(ds + prow + j) = make_uint2((unsigned)d0 | ((unsigned)d1 << 16), (unsigned)d2 | ((unsigned)d3 << 16));
+        if (j < T) skrow[-j] = d0;
+        if (j + 1 < T) skrow[-j - 1] = d1;
+        if (j + 2 < T) skrow[-j - 2] = d2;
+        if (j + 3 < T) skrow[-j - 3] = d3;
+      }
+    }
+    if (more) {
+      __syncthreads();
+      DS_STORE_V()
+      __syncthreads();
+    }
+  }
+#undef DS_LOAD_V
+#undef DS_STORE_V
+}
+
 }  // namespace
 
 extern "C" int csship_mha_relpos(const uint16_t* qkv, const uint16_t* pe_packed, int32_t q_min, int32_t q_max,
@@ -299,6 +392,19 @@ extern "C" int csship_mha_relpos_probs(const uint16_t* qkv, const uint16_t* pe_p
   hipLaunchKernelGGL(mha_relpos_kernel<true>, grid, dim3(256), 0, as_stream(stream), qkv,
                      reinterpret_cast<const bf16x8*>(pe_packed), q_min, q_max, p_bf16, B, T, H, nullptr,
                      const_cast<float*>(lse), ld_p);
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
+extern "C" int csship_attn_softmax_bwd(const uint16_t* qkv, const uint16_t* d_out, const uint16_t* p_bf16, int64_t ld_p,
+                                       const float* d, uint16_t* ds_bf16, uint16_t* ds_skew_bf16, int32_t W, int32_t B,
+                                       int32_t T, int32_t H, csship_stream_t stream) {
+  if (!qkv || !d_out || !p_bf16 || !d || !ds_bf16 || !ds_skew_bf16) return CSSHIP_ENULL;
+  if (B <= 0 || T <= 0 || H <= 0 || B > 65535 || H > 65535 || ld_p < T || W < 2 * T - 1) return CSSHIP_EBADSHAPE;
+  if (!aligned16(qkv) || !aligned16(d_out) || !aligned8(p_bf16) || !aligned8(ds_bf16) || (ld_p % 4) != 0) return CSSHIP_EALIGN;
+  dim3 grid((T + 63) / 64, H, B);
+  hipLaunchKernelGGL(attn_ds_kernel, grid, dim3(256), 0, as_stream(stream), qkv, d_out, p_bf16, d, ds_bf16, ds_skew_bf16, B, T,
+                     H, ld_p, W);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }

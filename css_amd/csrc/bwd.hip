@@ -211,6 +211,32 @@ __global__ __launch_bounds__(256) void relpos_softmax_bwd_kernel(const unsigned 
   }
 }
 
+// ---- D[b,h,i] = sum_d dO[b,i,h,d] * O[b,i,h,d]; 8 lanes per (b,i,h), 16-byte loads
+__global__ __launch_bounds__(256) void attn_rowdot_kernel(const unsigned short* __restrict__ dO,
+                                                          const unsigned short* __restrict__ O, int B, int T, int H,
+                                                          float* __restrict__ d) {
+  const int64_t idx = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);  // (b*T + i)*H + h
+  const int part = threadIdx.x & 7;
+  const int64_t n = (int64_t)B * T * H;
+  const int64_t c = min(idx, n - 1);
+  const uint4 a = *reinterpret_cast<const uint4*>(dO + c * 64 + part * 8);
+  const uint4 b = *reinterpret_cast<const uint4*>(O + c * 64 + part * 8);
+  const unsigned av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    s += bf2f((unsigned short)(av[q] & 0xffff)) * bf2f((unsigned short)(bv[q] & 0xffff)) +
+         bf2f((unsigned short)(av[q] >> 16)) * bf2f((unsigned short)(bv[q] >> 16));
+  s += __shfl_xor(s, 1);
+  s += __shfl_xor(s, 2);
+  s += __shfl_xor(s, 4);
+  if (part == 0 && idx < n) {
+    const int h = (int)(idx % H);
+    const int64_t bi = idx / H;
+    d[((bi / T) * H + h) * T + bi % T] = s;
+  }
+}
+
 // ---- weight shadows: f32 [R, K] (row stride lds) -> bf16 row-major [.., ld_rm] and/or MFMA fragment order, rows
 // scaled by `scale`; one thread per 8 consecutive k.  Fragment layout as in include/csship.h:
 // block(rt, ks)[16*g + m][j] = W[16*rt + m][32*ks + 8*g + j], rows beyond R are zero.
@@ -313,6 +339,18 @@ extern "C" int csship_relpos_softmax(const float* s_qk, int64_t ld_s, const floa
   const int64_t nrows = (int64_t)B * H * T;
   hipLaunchKernelGGL(relpos_softmax_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, as_stream(stream), s_qk,
                      ld_s, rel, ld_rel, nrows, T, p_bf16, ld_p);
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
+extern "C" int csship_attn_rowdot(const uint16_t* d_out, const uint16_t* out, int32_t B, int32_t T, int32_t H, float* d,
+                                  csship_stream_t stream) {
+  if (!d_out || !out || !d) return CSSHIP_ENULL;
+  if (B <= 0 || T <= 0 || H <= 0) return CSSHIP_EBADSHAPE;
+  if (!aligned16(d_out) || !aligned16(out)) return CSSHIP_EALIGN;
+  const int64_t n = (int64_t)B * T * H;
+  hipLaunchKernelGGL(attn_rowdot_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, as_stream(stream), d_out, out, B, T, H,
+                     d);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }

@@ -245,3 +245,23 @@ def ffn_bwd(x, dy, ln_g, ln_b, w1p, b1, w2tp, w1tp, d_ffn, alpha=0.5):
                                _ptr(a), _ptr(h), _ptr(dh), _ptr(dx), _ptr(gb), M, D, d_ffn, float(alpha), _ptr(ws), nws,
                                _stream()))
     return dx, gb[0], gb[1], a, h, dh
+
+
+def attn_rowdot(d_out, out, B, T, H):
+    """D[b,h,i] = sum_d dO[b,i,h,d] * O[b,i,h,d] for bf16 [B*T, H*64] operands -> f32 [B,H,T]."""
+    _need(d_out, torch.bfloat16, "d_out"), _need(out, torch.bfloat16, "out")
+    d = torch.empty((B, H, T), dtype=torch.float32, device=out.device)
+    check(lib().csship_attn_rowdot(_ptr(d_out.contiguous()), _ptr(out.contiguous()), B, T, H, _ptr(d), _stream()))
+    return d
+
+
+def attn_softmax_bwd(qkv, d_out, p, d, skew, n_head):
+    """dS = P o (dO v^T - D) -> (dS bf16 like p, skew) ; skew: bf16 [B,T,H,W], zero outside the band, filled in place."""
+    _need(qkv, torch.bfloat16, "qkv"), _need(p, torch.bfloat16, "p")
+    B, T, _ = qkv.shape
+    if not (qkv.is_contiguous() and d_out.is_contiguous() and p.is_contiguous() and d.is_contiguous() and skew.is_contiguous()):
+        raise RuntimeError("css_amd: attn_softmax_bwd expects dense operands")
+    ds = torch.empty_like(p)
+    check(lib().csship_attn_softmax_bwd(_ptr(qkv), _ptr(d_out), _ptr(p), p.shape[3], _ptr(d), _ptr(ds), _ptr(skew),
+                                        skew.shape[3], B, T, n_head, _stream()))
+    return ds, skew

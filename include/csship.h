@@ -382,6 +382,14 @@ int csship_mha_relpos_probs(const uint16_t* qkv, const uint16_t* pe_packed, int3
                             const float* lse, uint16_t* p_bf16, int64_t ld_p, int32_t B, int32_t T, int32_t H,
                             csship_stream_t stream);
 
+/* csship_attn_softmax_bwd: dS[b,h,i,j] = P[i,j] * (dO_i . v_j - d[b,h,i]) computed attention-shaped (V tiles in LDS,
+ * dO rows as MFMA operand), no [B,H,T,T] f32 intermediate.  qkv as in csship_mha_relpos; d_out bf16 [B*T, H*64];
+ * p_bf16 / ds_bf16: [B,H,T,ld_p]; d: f32 [B,H,T] (csship_attn_rowdot); ds_skew_bf16 [B,T,H,W] as in
+ * csship_relpos_softmax_bwd, but only the band entries are written (zero the buffer once). */
+int csship_attn_softmax_bwd(const uint16_t* qkv, const uint16_t* d_out, const uint16_t* p_bf16, int64_t ld_p,
+                            const float* d, uint16_t* ds_bf16, uint16_t* ds_skew_bf16, int32_t W, int32_t B,
+                            int32_t T, int32_t H, csship_stream_t stream);
+
 /* ---- row kernels of the backward pass (css_amd/csrc/bwd.hip)
  * csship_layernorm_bwd: y = LayerNorm(x) [then ReLU if relu != 0]; given dy returns dx (+ dx_add, may alias dx or dy)
  * and dgamma_dbeta = f32 [2, D] (dgamma row, dbeta row).  D <= 1024 (vector path for 256 / 512 / 1024); x, dy, dx
@@ -406,6 +414,9 @@ int csship_mvn_apply(const float* x, int64_t B, int64_t T, int64_t F, int64_t ld
  *   relative-position gradients (dq += dS_skew . pe_window, dpe_window = dS_skew^T . q) into plain GEMMs. */
 int csship_relpos_softmax(const float* s_qk, int64_t ld_s, const float* rel, int64_t ld_rel, int32_t B,
                           int32_t H, int32_t T, uint16_t* p_bf16, int64_t ld_p, csship_stream_t stream);
+/* D[b, h, i] = sum_d dO[b, i, h, d] * O[b, i, h, d]  (= rowsum(P o dP)); dO, O: bf16 [B*T, H*64]; out f32 [B, H, T]. */
+int csship_attn_rowdot(const uint16_t* d_out, const uint16_t* out, int32_t B, int32_t T, int32_t H, float* d,
+                       csship_stream_t stream);
 int csship_relpos_softmax_bwd(const uint16_t* p_bf16, int64_t ld_p, const float* dp, int64_t ld_dp,
                               int32_t B, int32_t H, int32_t T, uint16_t* ds_bf16, uint16_t* ds_skew_bf16,
                               int32_t W, csship_stream_t stream);
