@@ -105,7 +105,7 @@ SIGNATURES = {
     "csship_attn_softmax_bwd": (_i32, [_p, _p, _p, _i64, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "csship_relpos_softmax_bwd": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _i32, _p]),
     "csship_convmod_bwd_workspace": (_sz, [_i32, _i32, _i32]),
-    "csship_convmod_bwd": (_i32, [_p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
+    "csship_convmod_bwd": (_i32, [_p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _sz, _p]),
     "csship_pack_weight": (_i32, [_p, _i32, _i32, _i64, _f32, _p, _i64, _p, _i32, _p]),
     "csship_lstm_bidir_train": (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p]),
     "csship_lstm_bidir_bwd": (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p]),

@@ -8,7 +8,7 @@ Forward values ALWAYS come from the HIP kernels.  Backward:
     operator's input; hidden activations are recomputed in the backward;
   * masks -> parameters, BLSTM (``BlstmTrain``): back-propagation-through-time kernel for the recurrence, the same
     GEMM / LayerNorm backward kernels for the rest;
-  * other shapes (Conformer-large widths, eval-mode BatchNorm): STOP-GAP ``MasksWithTwinBackward`` - the gradient is obtained by
+  * anything else (BLSTM hidden sizes that are not a multiple of 32, ``force_twin_backward``): ``MasksWithTwinBackward`` - the gradient is obtained by
     re-evaluating a differentiable PyTorch-ROCm restatement of the model ("twin", GPU torch ops, fp32) and
     back-propagating grad_masks through it.  The twin never produces a forward result that is returned.
 """
@@ -62,8 +62,10 @@ class MasksWithTwinBackward(torch.autograd.Function):
 
 
 class ConformerTrain(torch.autograd.Function):
-    """masks = Conformer(f) in training mode (BatchNorm batch statistics, running statistics updated, no dropout)
-    with the explicit HIP backward.  d_model = 256, d_k = 64, kernel 33 (the tuned panel kernels)."""
+    """masks = Conformer(f) with the explicit HIP backward (no dropout).  model.training selects BatchNorm batch
+    statistics (running statistics updated) or, in eval mode, the frozen running statistics.  d_k = 64, kernel 33;
+    d_model = 256 runs the tuned row-panel kernels (fused FeedForward forward / backward, LN-prologue projections),
+    other widths (Conformer-large: 512) the same operators from the size-generic kernels."""
 
     @staticmethod
     def forward(ctx, model, f, *params):
@@ -72,8 +74,10 @@ class ConformerTrain(torch.autograd.Function):
         B, T, F = f.shape
         M = B * T
         f = f.contiguous()
+        wide = D != 256          # size-generic kernels
+        batch_bn = model.training
         mean, rinv = ops.mvn_stats(f)
-        S = {"f": f, "mean": mean, "rinv": rinv, "layers": []}
+        S = {"f": f, "mean": mean, "rinv": rinv, "layers": [], "wide": wide, "batch_bn": batch_bn}
         Kp = (F + 7) // 8 * 8
         we_bf, _ = ob.pack_weight(enc.embed[0].weight.detach(), want_row_major=True)
         fn = ob.mvn_apply(f, mean, rinv, Kp)
@@ -89,6 +93,13 @@ class ConformerTrain(torch.autograd.Function):
 
             def ffn(m, xin, tag):
                 w1, w2 = m.net[0].weight.detach(), m.net[3].weight.detach()
+                if wide:  # LayerNorm -> tiled GEMM (ReLU, bf16) -> tiled GEMM (+ residual)
+                    w1_bf, _ = ob.pack_weight(w1, want_row_major=True)
+                    w2_bf, _ = ob.pack_weight(w2, want_row_major=True)
+                    L[tag] = (xin, w1_bf, w2_bf)
+                    a_, _ = ops.layernorm(xin, m.layer_norm.weight.detach(), m.layer_norm.bias.detach())
+                    h_ = ops.gemm(a_, w1_bf, m.net[0].bias.detach(), relu=True, out_bf16=True)
+                    return ops.gemm(h_, w2_bf, m.net[3].bias.detach(), residual=xin, alpha=0.5)
                 _, w1p = ob.pack_weight(w1, want_frag=True)
                 _, w2p = ob.pack_weight(w2, want_frag=True)
                 # fragment-packed transposes for the fused backward kernel
@@ -102,42 +113,56 @@ class ConformerTrain(torch.autograd.Function):
             a = lay.self_attn
             scale = a.d_k ** -0.5
             wqkv_bf = torch.empty((3 * D, D), dtype=BF, device=f.device)
-            wqkv_p = torch.empty(3 * D * D, dtype=BF, device=f.device)
+            wqkv_p = None if wide else torch.empty(3 * D * D, dtype=BF, device=f.device)
             for i, lin in enumerate((a.linear_q, a.linear_k, a.linear_v)):
                 ob.pack_weight(lin.weight.detach(), scale=scale if i == 0 else 1.0, row_major=wqkv_bf, frag=wqkv_p,
                                row0=i * D)
             bqkv = torch.cat([a.linear_q.bias.detach() * scale, a.linear_k.bias.detach(), a.linear_v.bias.detach()], 0)
-            wo_bf, wo_p = ob.pack_weight(a.linear_out.weight.detach(), want_row_major=True, want_frag=True)
-            qkv = ops.panel_linear(x1, wqkv_p, bqkv, 3 * D,
-                                   ln=(a.layer_norm.weight.detach(), a.layer_norm.bias.detach()), out_bf16=True)
+            wo_bf, wo_p = ob.pack_weight(a.linear_out.weight.detach(), want_row_major=True, want_frag=not wide)
+            if wide:
+                a2, _ = ops.layernorm(x1, a.layer_norm.weight.detach(), a.layer_norm.bias.detach())
+                qkv = ops.gemm(a2, wqkv_bf, bqkv, out_bf16=True)
+            else:
+                qkv = ops.panel_linear(x1, wqkv_p, bqkv, 3 * D,
+                                       ln=(a.layer_norm.weight.detach(), a.layer_norm.bias.detach()), out_bf16=True)
             ao, lse = ops.mha_relpos_train(qkv.view(B, T, 3 * D), pe_pack, H)
             ao = ao.view(M, D)
-            x2 = ops.panel_linear(ao, wo_p, a.linear_out.bias.detach(), D, residual=x1)
+            if wide:
+                x2 = ops.gemm(ao, wo_bf, a.linear_out.bias.detach(), residual=x1, alpha=1.0)
+            else:
+                x2 = ops.panel_linear(ao, wo_p, a.linear_out.bias.detach(), D, residual=x1)
             L["mha"] = (x1, qkv, ao, wqkv_bf, wo_bf, scale, lse)
             c = lay.conv
             W = {"ln_g": c.layer_norm.weight.detach(), "ln_b": c.layer_norm.bias.detach(),
                  "pw1_w": c.pw_conv_1.weight.detach().view(2), "pw1_b": c.pw_conv_1.bias.detach(),
                  "dw_w": c.dw_conv_1d.weight.detach().view(D, K).t().contiguous(), "dw_b": c.dw_conv_1d.bias.detach(),
                  "bn_g": c.BN.weight.detach(), "bn_b": c.BN.bias.detach(),
+                 "bn_mean": c.BN.running_mean, "bn_var": c.BN.running_var,
                  "pw2_w": c.pw_conv_2.weight.detach().view(1), "pw2_b": c.pw_conv_2.bias.detach()}
-            x3, fws = ops.convmod(x2.view(B, T, D), W, K, batch_stats=True, return_workspace=True)
+            x3, fws = ops.convmod(x2.view(B, T, D), W, K, batch_stats=batch_bn, keep_activations=not batch_bn,
+                                  return_workspace=True)
             x3 = x3.view(M, D)
             L["conv"] = (x2, W, fws)
-            stats = fws.view(torch.float32)[-4 * D:]
-            with torch.no_grad():  # BatchNorm1d bookkeeping (momentum 0.1, unbiased running variance)
-                c.BN.running_mean.mul_(0.9).add_(stats[2 * D:3 * D], alpha=0.1)
-                c.BN.running_var.mul_(0.9).add_(stats[3 * D:], alpha=0.1 * M / max(M - 1, 1))
-                c.BN.num_batches_tracked += 1
+            if batch_bn:
+                stats = fws.view(torch.float32)[-4 * D:]
+                with torch.no_grad():  # BatchNorm1d bookkeeping (momentum 0.1, unbiased running variance)
+                    c.BN.running_mean.mul_(0.9).add_(stats[2 * D:3 * D], alpha=0.1)
+                    c.BN.running_var.mul_(0.9).add_(stats[3 * D:], alpha=0.1 * M / max(M - 1, 1))
+                    c.BN.num_batches_tracked += 1
             x4 = ffn(lay.feed_forward_out, x3, "ffn_out")
             _, x = ops.layernorm(x4, lay.layer_norm.weight.detach(), lay.layer_norm.bias.detach(), out_bf16=False,
                                  out_f32=True)
             L["x4"] = x4
             S["layers"].append(L)
         n_out = model.linear.out_features
-        wh_bf, wh_p = ob.pack_weight(model.linear.weight.detach(), want_row_major=True, want_frag=True)
+        wh_bf, wh_p = ob.pack_weight(model.linear.weight.detach(), want_row_major=True, want_frag=not wide)
         ld = (n_out + 3) // 4 * 4
         masks = torch.empty((M, ld), dtype=torch.float32, device=f.device)[:, :n_out]
-        ops.panel_linear(x, wh_p, model.linear.bias.detach(), n_out, relu=True, out=masks)
+        if wide:
+            ob.bgemm(x, wh_bf, bias=model.linear.bias.detach(), out=masks)
+            torch.relu_(masks)
+        else:
+            ops.panel_linear(x, wh_p, model.linear.bias.detach(), n_out, relu=True, out=masks)
         S.update(e=e, x_enc=x, masks=masks, wh_bf=wh_bf)
         ctx.model, ctx.S = model, S
         return masks.view(B, T, n_out)
@@ -173,9 +198,14 @@ class ConformerTrain(torch.autograd.Function):
             put(lay.layer_norm.weight, dg), put(lay.layer_norm.bias, dbeta)
 
             def ffn_b(m, tag, dy):
-                xin, w1p, w2tp, w1tp = L[tag]
-                dxo, g = bw.ffn_bwd_fused(xin, dy, m.layer_norm.weight.detach(), m.layer_norm.bias.detach(),
-                                          m.net[0].bias.detach(), w1p, w2tp, w1tp, enc.d_ffn, 0.5)
+                if S["wide"]:
+                    xin, w1_bf, w2_bf = L[tag]
+                    dxo, g = bw.ffn_bwd(xin, dy, m.layer_norm.weight.detach(), m.layer_norm.bias.detach(),
+                                        m.net[0].bias.detach(), w1_bf, w2_bf, 0.5)
+                else:
+                    xin, w1p, w2tp, w1tp = L[tag]
+                    dxo, g = bw.ffn_bwd_fused(xin, dy, m.layer_norm.weight.detach(), m.layer_norm.bias.detach(),
+                                              m.net[0].bias.detach(), w1p, w2tp, w1tp, enc.d_ffn, 0.5)
                 for p, gv in zip((m.layer_norm.weight, m.layer_norm.bias, m.net[0].weight, m.net[0].bias,
                                   m.net[3].weight, m.net[3].bias), g):
                     put(p, gv)
@@ -184,7 +214,8 @@ class ConformerTrain(torch.autograd.Function):
             dx = ffn_b(lay.feed_forward_out, "ffn_out", dx)
             x2, W, fws = L["conv"]
             c = lay.conv
-            dx3, g = ob.convmod_bwd(x2.view(B, T, D), dx.view(B, T, D), W, fws, enc.kernel_size)
+            dx3, g = ob.convmod_bwd(x2.view(B, T, D), dx.view(B, T, D), W, fws, enc.kernel_size,
+                                    bn_eval=not S["batch_bn"])
             dx = dx3.view(M, D)
             put(c.layer_norm.weight, g["ln_g"]), put(c.layer_norm.bias, g["ln_b"])
             put(c.pw_conv_1.weight, g["pw1_w"]), put(c.pw_conv_1.bias, g["pw1_b"])
@@ -314,8 +345,8 @@ class BlstmTrain(torch.autograd.Function):
 def masks_for_training(model, f):
     params = tuple(model.parameters())
     enc = getattr(model, "conformer", None)
-    if enc is not None and enc.d_model == 256 and enc.d_model // enc.n_head == 64 and enc.kernel_size == 33 \
-            and model.training and not getattr(model, "force_twin_backward", False):
+    if enc is not None and enc.d_model in (256, 512) and enc.d_model // enc.n_head == 64 and enc.kernel_size == 33 \
+            and enc.d_ffn % 64 == 0 and not getattr(model, "force_twin_backward", False):
         return ConformerTrain.apply(model, f, *params)
     if hasattr(model, "blstm") and not getattr(model, "force_twin_backward", False):
         H = model.blstm.hidden_dim // 2

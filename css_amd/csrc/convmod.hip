@@ -210,6 +210,20 @@ __global__ __launch_bounds__(1024) void bn_reduce_kernel(const float* __restrict
   }
 }
 
+// bn_mode 2: scale / shift / mean / var from the RUNNING statistics, in the layout bn_reduce_kernel produces, so the
+// backward (and bn_apply) read one format
+__global__ __launch_bounds__(256) void bn_from_running_kernel(const float* __restrict__ bn_g, const float* __restrict__ bn_b,
+                                                              const float* __restrict__ mean, const float* __restrict__ var,
+                                                              int D, float* __restrict__ scale_shift) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= D) return;
+  const float sc = bn_g[c] * rsqrtf(var[c] + 1e-5f);
+  scale_shift[c] = sc;
+  scale_shift[D + c] = bn_b[c] - mean[c] * sc;
+  scale_shift[2 * D + c] = mean[c];
+  scale_shift[3 * D + c] = var[c];
+}
+
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ z,
                                                        const float* __restrict__ scale_shift,
                                                        const float* __restrict__ pw2_w, const float* __restrict__ pw2_b,
@@ -248,8 +262,12 @@ int run(const ConvArgs& a0, int bn_mode, void* workspace, hipStream_t s) {
   float* scale_shift = a.partial + (size_t)nblk * 2 * D;
   hipLaunchKernelGGL((convmod_kernel<D, TT, 33, 1, false>), grid, dim3(2 * D), 0, s, a);
   CSSHIP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_reduce_kernel, dim3((D + 63) / 64), dim3(1024), 0, s, a.partial, nblk, D,
-                     (double)a.B * (double)a.T, a.w.bn_g, a.w.bn_b, scale_shift);
+  if (bn_mode == 2)
+    hipLaunchKernelGGL(bn_from_running_kernel, dim3((D + 255) / 256), dim3(256), 0, s, a.w.bn_g, a.w.bn_b, a.w.bn_mean,
+                       a.w.bn_var, D, scale_shift);
+  else
+    hipLaunchKernelGGL(bn_reduce_kernel, dim3((D + 63) / 64), dim3(1024), 0, s, a.partial, nblk, D,
+                       (double)a.B * (double)a.T, a.w.bn_g, a.w.bn_b, scale_shift);
   CSSHIP_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, a.x, a.zbuf, scale_shift,
                      a.w.pw2_w, a.w.pw2_b, a.y, n / 4, D);
@@ -438,7 +456,7 @@ BwdLayout bwd_layout(int B, int T, int D, int TT) {
 
 template <int D, int TT>
 int run_bwd(const float* x, const float* dy, const csship_conv_weights& w, int B, int T, const float* fwd_ws, float* dx,
-            float* grads, float* ws, hipStream_t s) {
+            float* grads, float* ws, int bn_eval, hipStream_t s) {
   const BwdLayout L = bwd_layout(B, T, D, TT);
   const int64_t M = (int64_t)B * T;
   const size_t n = (size_t)M * D;
@@ -456,8 +474,9 @@ int run_bwd(const float* x, const float* dy, const csship_conv_weights& w, int B
   int rc = launch_slab_reduce(part, L.nwg_rows, 2 * D + 2, 2 * D + 2, 2 * D + 2, 1.f, nullptr, nullptr, 0, gA, s);
   if (rc) return rc;
   // pass A'
+  // running statistics are constants of the graph: no mean / projection terms (1/n -> 0)
   hipLaunchKernelGGL(conv_bn_bwd_apply_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, dy, z, stats, gA,
-                     w.pw2_w, 1.f / (float)M, n / 4, D, dc);
+                     w.pw2_w, bn_eval ? 0.f : 1.f / (float)M, n / 4, D, dc);
   CSSHIP_CHECK_LAUNCH();
   // pass B1 / B2 on the forward's tile structure
   dim3 grid((T + TT - 1) / TT, B);
@@ -489,10 +508,10 @@ extern "C" int csship_convmod(const float* x, float* y, const csship_conv_weight
                               csship_stream_t stream) {
   if (!x || !y || !w) return CSSHIP_ENULL;
   if (!w->ln_g || !w->ln_b || !w->pw1_w || !w->pw1_b || !w->dw_w || !w->dw_b || !w->bn_g || !w->bn_b ||
-      !w->pw2_w || !w->pw2_b || (bn_mode == 0 && (!w->bn_mean || !w->bn_var)))
+      !w->pw2_w || !w->pw2_b || (bn_mode != 1 && (!w->bn_mean || !w->bn_var)))
     return CSSHIP_ENULL;
   if (B <= 0 || T <= 0 || B > 65535) return CSSHIP_EBADSHAPE;
-  if (kernel_size != 33 || (D != 256 && D != 512) || (bn_mode != 0 && bn_mode != 1)) return CSSHIP_EUNSUPPORTED;
+  if (kernel_size != 33 || (D != 256 && D != 512) || bn_mode < 0 || bn_mode > 2) return CSSHIP_EUNSUPPORTED;
   if (x == y) return CSSHIP_EBADSHAPE;  // neighbouring tiles read the halo rows: not in-place safe
   if (!aligned16(x) || !aligned16(y) || !aligned16(w->ln_g) || !aligned16(w->ln_b) || (workspace && !aligned16(workspace)))
     return CSSHIP_EALIGN;
@@ -519,7 +538,7 @@ extern "C" size_t csship_convmod_bwd_workspace(int32_t B, int32_t T, int32_t D) 
 
 extern "C" int csship_convmod_bwd(const float* x, const float* dy, const csship_conv_weights* w, int32_t B, int32_t T,
                                   int32_t D, int32_t kernel_size, const void* fwd_workspace, float* dx,
-                                  float* grads, void* workspace, size_t workspace_bytes,
+                                  float* grads, int32_t bn_eval, void* workspace, size_t workspace_bytes,
                                   csship_stream_t stream) {
   if (!x || !dy || !w || !fwd_workspace || !dx || !grads || !workspace) return CSSHIP_ENULL;
   if (!w->ln_g || !w->ln_b || !w->pw1_w || !w->pw1_b || !w->dw_w || !w->dw_b || !w->pw2_w) return CSSHIP_ENULL;
@@ -530,6 +549,6 @@ extern "C" int csship_convmod_bwd(const float* x, const float* dy, const csship_
   if (workspace_bytes < csship_convmod_bwd_workspace(B, T, D)) return CSSHIP_EWORKSPACE;
   const float* fw = reinterpret_cast<const float*>(fwd_workspace);
   float* ws = reinterpret_cast<float*>(workspace);
-  if (D == 256) return run_bwd<256, TT256>(x, dy, *w, B, T, fw, dx, grads, ws, as_stream(stream));
-  return run_bwd<512, TT512>(x, dy, *w, B, T, fw, dx, grads, ws, as_stream(stream));
+  if (D == 256) return run_bwd<256, TT256>(x, dy, *w, B, T, fw, dx, grads, ws, bn_eval, as_stream(stream));
+  return run_bwd<512, TT512>(x, dy, *w, B, T, fw, dx, grads, ws, bn_eval, as_stream(stream));
 }

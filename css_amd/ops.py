@@ -220,7 +220,7 @@ def conv_weights_struct(t):
     return cw
 
 
-def convmod(x, weights, kernel_size=33, batch_stats=False, return_workspace=False):
+def convmod(x, weights, kernel_size=33, batch_stats=False, return_workspace=False, keep_activations=False):
     """x f32 [B,T,D] -> x + ConvModule(x).  weights: dict for conv_weights_struct.
     return_workspace (batch_stats only): also return the workspace the backward needs (pre-BN activations; its last
     4*D floats are scale | shift | batch mean | biased batch variance)."""
@@ -230,9 +230,10 @@ def convmod(x, weights, kernel_size=33, batch_stats=False, return_workspace=Fals
     y = torch.empty_like(x)
     cw = conv_weights_struct(weights)
     ws = None
-    if batch_stats:
+    mode = 1 if batch_stats else (2 if keep_activations else 0)  # 2: running statistics, activations kept for the backward
+    if mode:
         ws = torch.empty(lib().csship_convmod_workspace(B, T, D), device=x.device, dtype=torch.uint8)
-    check(lib().csship_convmod(_ptr(x), _ptr(y), C.byref(cw), B, T, D, kernel_size, 1 if batch_stats else 0,
+    check(lib().csship_convmod(_ptr(x), _ptr(y), C.byref(cw), B, T, D, kernel_size, mode,
                                _ptr(ws), _stream()))
     return (y, ws) if return_workspace else y
 

@@ -168,8 +168,8 @@ def relpos_softmax_bwd(p, dp, T, W):
     return ds, dsk
 
 
-def convmod_bwd(x, dy, weights, fwd_ws, kernel_size=33):
-    """Backward of ops.convmod(x, weights, batch_stats=True).  x, dy f32 [B,T,D]; fwd_ws: that call's workspace.
+def convmod_bwd(x, dy, weights, fwd_ws, kernel_size=33, bn_eval=False):
+    """Backward of ops.convmod(x, weights, batch_stats=True) (or keep_activations=True with bn_eval=True).  x, dy f32 [B,T,D]; fwd_ws: that call's workspace.
     Returns dx and a dict of f32 gradients keyed like the weights dict (dw_w as [k, D])."""
     from .ops import conv_weights_struct
     _need(x, torch.float32, "x"), _need(dy, torch.float32, "dy")
@@ -181,7 +181,7 @@ def convmod_bwd(x, dy, weights, fwd_ws, kernel_size=33):
     nws = lib().csship_convmod_bwd_workspace(B, T, D)
     ws = _workspace(nws, x.device)
     check(lib().csship_convmod_bwd(_ptr(x), _ptr(dy), C.byref(cw), B, T, D, kernel_size, _ptr(fwd_ws), _ptr(dx),
-                                   _ptr(flat), _ptr(ws), nws, _stream()))
+                                   _ptr(flat), int(bn_eval), _ptr(ws), nws, _stream()))
     o = 2 * D + 4
     grads = {"bn_b": flat[:D], "bn_g": flat[D:2 * D], "pw2_w": flat[2 * D:2 * D + 1], "pw2_b": flat[2 * D + 1:2 * D + 2],
              "dw_w": flat[o:o + kernel_size * D].view(kernel_size, D), "dw_b": flat[o + 33 * D:o + 34 * D],

@@ -207,8 +207,9 @@ int csship_mha_relpos(const uint16_t* qkv, const uint16_t* pe_packed, int32_t q_
 /* ConvModule.forward + residual (css/models/conformer.py:289-303, 357):
  *   y = x + pw2( relu( BN( dwconv_k( glu( LN(x) ) ) ) ) ),  x,y: f32 [B, T, 256].
  * pw1_w/pw1_b: 2 floats each (Conv2d(1,2,1)), pw2_w/pw2_b: 1 float each (device).
- * bn_mode 0: running statistics (eval).  bn_mode 1: batch statistics (train forward);
- * needs workspace of csship_convmod_workspace() bytes and updates nothing. */
+ * bn_mode 0: running statistics (eval).  bn_mode 1: batch statistics (train forward); bn_mode 2: running statistics
+ * but through the same three passes as 1, keeping the pre-BatchNorm activations for csship_convmod_bwd (gradients with
+ * a frozen BatchNorm).  Modes 1 and 2 need a workspace of csship_convmod_workspace() bytes; nothing is updated. */
 typedef struct csship_conv_weights_s {
   const float *ln_g, *ln_b;
   const float *pw1_w, *pw1_b;
@@ -421,7 +422,8 @@ int csship_relpos_softmax_bwd(const uint16_t* p_bf16, int64_t ld_p, const float*
                               int32_t B, int32_t H, int32_t T, uint16_t* ds_bf16, uint16_t* ds_skew_bf16,
                               int32_t W, csship_stream_t stream);
 
-/* ---- csship_convmod_bwd (css_amd/csrc/convmod.hip): backward of csship_convmod run with bn_mode = 1.
+/* ---- csship_convmod_bwd (css_amd/csrc/convmod.hip): backward of csship_convmod run with bn_mode = 1 (batch
+ * statistics; bn_eval = 0) or bn_mode = 2 (running statistics, activations kept; bn_eval = 1).
  * fwd_workspace is that forward call's workspace, untouched since (it holds the pre-BatchNorm activations and the
  * batch statistics: after the call its last 4*D floats are [scale | shift | batch mean | biased batch variance]).
  * dx = dy + (gradient through the module).  The parameter gradients are written to ONE f32 buffer `grads` of
@@ -432,7 +434,8 @@ int csship_relpos_softmax_bwd(const uint16_t* p_bf16, int64_t ld_p, const float*
 size_t csship_convmod_bwd_workspace(int32_t B, int32_t T, int32_t D);
 int csship_convmod_bwd(const float* x, const float* dy, const csship_conv_weights* w, int32_t B, int32_t T,
                        int32_t D, int32_t kernel_size, const void* fwd_workspace, float* dx,
-                       float* grads, void* workspace, size_t workspace_bytes, csship_stream_t stream);
+                       float* grads, int32_t bn_eval, void* workspace, size_t workspace_bytes,
+                       csship_stream_t stream);
 
 /* Weight shadows for one Linear in ONE launch: f32 w[R, K] (row stride ld_w), every element times `scale`, written
  * as bf16 row-major rows dst_row0.. of a [.., ld_row_major] matrix (optional; the kmajor operand of csship_bgemm)
