@@ -79,9 +79,12 @@ def main():
     audio = torch.stack([mix, src[0], src[1]], 0).to(dev)  # [3, B, n]
 
     def step():
-        mags = ops.stft(audio, ("mag",))["mag"]  # [3,B,T,257]
-        masks = model.forward_masks(mags[0])
-        loss, perm, _, _ = ops.pit_mse(masks, mags[0], [mags[1], mags[2]])
+        # the metric is forward + PIT loss: inference mode (under autograd the model would run its training forward,
+        # which keeps every operator's input for the backward pass)
+        with torch.no_grad():
+            mags = ops.stft(audio, ("mag",))["mag"]  # [3,B,T,257]
+            masks = model.forward_masks(mags[0])
+            loss, perm, _, _ = ops.pit_mse(masks, mags[0], [mags[1], mags[2]])
         return loss
 
     def fence():
@@ -184,8 +187,9 @@ def main():
                         "frac": nfr * 2052 / sd_ / 8.0e12, "avg_launch_us": sd_ * 1e6,
                         "bytes_per_frame": 2052}
         # mask application + PIT-MSE (pit_sse + finalize launches), SURVEY 8(d): 6 168 B/frame minus the noise mask
-        mags_ = ops.stft(audio, ("mag",))["mag"]
-        masks_ = model.forward_masks(mags_[0])
+        with torch.no_grad():
+            mags_ = ops.stft(audio, ("mag",))["mag"]
+            masks_ = model.forward_masks(mags_[0])
         for _ in range(3):
             ops.pit_mse(masks_, mags_[0], [mags_[1], mags_[2]])
         e0.record(torch.cuda.current_stream())

@@ -85,8 +85,11 @@ class BLSTM(nn.Module):
         return P
 
     def forward_masks(self, f):
-        """HIP forward; under autograd the backward is the stop-gap of css_amd/autograd.py."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        """HIP forward.  In training mode under autograd the result carries a grad_fn (css_amd/autograd.py BlstmTrain:
+        the recurrence also stores gates and cell states for the BPTT kernel); in eval mode the plain inference path
+        runs unless ``self.eval_gradients`` is set."""
+        if (torch.is_grad_enabled() and (self.training or getattr(self, "eval_gradients", False))
+                and any(p.requires_grad for p in self.parameters())):
             from ..autograd import masks_for_training
             return masks_for_training(self, f)
         return self._forward_masks_hip(f)

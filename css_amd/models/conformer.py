@@ -224,9 +224,11 @@ class Conformer(nn.Module):
     def forward_masks(self, f, want_encoder_out=False):
         """f: f32 [N,T,idim] on the GPU -> ReLU masks f32 [N,T,num_bins*(num_spk+num_noise)].
 
-        Under autograd (grad enabled and trainable parameters) the result carries a grad_fn whose backward is
-        the stop-gap of css_amd/autograd.py; the values are the HIP kernels' either way."""
-        if (not want_encoder_out and torch.is_grad_enabled()
+        In training mode under autograd the result carries a grad_fn (css_amd/autograd.py ConformerTrain: operator by
+        operator forward that keeps what the explicit HIP backward needs).  In eval mode the inference path runs
+        (chained / fused kernels, nothing kept) and the result has no grad_fn; set ``self.eval_gradients = True`` to
+        differentiate through the model with its BatchNorm frozen at the running statistics."""
+        if (not want_encoder_out and torch.is_grad_enabled() and (self.training or getattr(self, "eval_gradients", False))
                 and any(p.requires_grad for p in self.parameters())):
             from ..autograd import masks_for_training
             return masks_for_training(self, f)

@@ -235,6 +235,8 @@ def test_conformer_gradients_flow_and_match_twin():
     f = rnd((2, 40, 257), 14).abs().to(DEV)
     tg = [(rnd((2, 40, 257), 60 + k).abs() * 0.5).to(DEV) for k in range(2)]
     obj = OBJECTIVES["MSE"].build_objective({})
+    assert not obj(m, {"mix": f, "source1": tg[0], "source2": tg[1]}, device=DEV).requires_grad  # eval: inference path
+    m.eval_gradients = True   # differentiate with BatchNorm frozen at its running statistics
     loss = obj(m, {"mix": f, "source1": tg[0], "source2": tg[1]}, device=DEV)
     assert loss.requires_grad
     loss.backward()
