@@ -62,7 +62,7 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
-    from css_amd import _lib, ops
+    from css_amd import ops
     from css_amd.models import MODELS
     from css_amd.utils import synthetic as syn
 

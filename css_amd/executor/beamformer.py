@@ -7,7 +7,6 @@ STFT (centre padding by reflection, then csship_stft), masked SCMs, a per-bin fp
 rescale energies, rescale + deduplication, iSTFT (csship_istft).  The overlap-add of the few-second output windows
 and the final peak normalisation are slice assignments on the GPU (plumbing).
 """
-import math
 
 import torch
 import torch.nn.functional as F_

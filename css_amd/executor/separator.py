@@ -14,7 +14,6 @@ Differences from the reference, all stated:
   * With torch.distributed initialised, windows are sharded contiguously across ranks and gathered
     (long-recording inference): no collective on the per-window data path.
 """
-import ctypes as C
 import math
 
 import torch
