@@ -19,6 +19,21 @@ from . import backward as bw, ops, ops_bwd as ob
 BF = torch.bfloat16
 
 
+def _deliver(model, G):
+    """Hand the parameter gradients G to autograd.  Parameters whose ``.grad`` already exists (FusedAdam presets them
+    as views of its flat gradient buffer) are accumulated in place by ONE multi-tensor add and get None back, instead
+    of one accumulate launch per parameter (~550 for Conformer-base); the rest go back through autograd as usual."""
+    params = list(model.parameters())
+    direct = [p for p in params if p.requires_grad and p in G and p.grad is not None
+              and p.grad.dtype == G[p].dtype and p.grad.is_contiguous()]
+    if direct:
+        with torch.no_grad():
+            torch._foreach_add_([p.grad for p in direct], [G[p].contiguous() for p in direct])
+        for p in direct:
+            del G[p]
+    return tuple(G.get(p) if p.requires_grad else None for p in params)
+
+
 class PitMse(torch.autograd.Function):
     """loss = mean_b min_perm MSE(mask_k * f_orig, target_{perm})  with the hand-written backward."""
 
@@ -242,7 +257,7 @@ class ConformerTrain(torch.autograd.Function):
                                            enc.embed[1].weight.detach(), enc.embed[1].bias.detach(), e=S["e"])
         put(enc.embed[0].weight, dwe), put(enc.embed[0].bias, dbe)
         put(enc.embed[1].weight, dg), put(enc.embed[1].bias, dbeta)
-        return (None, None) + tuple(G.get(p) if p.requires_grad else None for p in model.parameters())
+        return (None, None) + _deliver(model, G)
 
 
 class BlstmTrain(torch.autograd.Function):
@@ -339,7 +354,7 @@ class BlstmTrain(torch.autograd.Function):
                                            enc.embed[1].weight.detach(), enc.embed[1].bias.detach(), e=S["e"])
         put(enc.embed[0].weight, dwe), put(enc.embed[0].bias, dbe)
         put(enc.embed[1].weight, dg), put(enc.embed[1].bias, dbeta)
-        return (None, None) + tuple(G.get(p) if p.requires_grad else None for p in model.parameters())
+        return (None, None) + _deliver(model, G)
 
 
 def masks_for_training(model, f):
