@@ -11,14 +11,16 @@
 #pragma once
 #include "common.hpp"
 
-struct cplx {
-  float x, y;
-};
-DEV cplx cmul(cplx a, cplx b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+// complex numbers are 2-vectors so that the butterflies compile to packed FP32 (v_pk_add_f32 / v_pk_fma_f32 with
+// op_sel / neg modifiers): one instruction per complex add, two per complex multiply
+typedef float cplx __attribute__((ext_vector_type(2)));
+DEV cplx cmul(cplx a, cplx b) {  // a.xx * b + a.yy * (-b.y, b.x)
+  return __builtin_elementwise_fma(a.xx, b, a.yy * cplx{-b.y, b.x});
+}
 DEV cplx cis_pi(float t) {  // exp(i*pi*t)
-  cplx r;
-  sincospif(t, &r.y, &r.x);
-  return r;
+  float sn, cs;
+  sincospif(t, &sn, &cs);
+  return {cs, sn};
 }
 
 template <int CTRL>
@@ -68,26 +70,42 @@ DEV int fft_out_index(int l) { return ((l >> 4) & 3) | (l & 12) | ((l & 3) << 4)
 constexpr int FFT_SCRATCH = 4 * 68;  // cplx entries of per-wave LDS scratch
 
 DEV void radix4_dif(cplx (&u)[4]) {  // y_k = sum_n x_n (-i)^(n k)
-  const cplx a02 = {u[0].x + u[2].x, u[0].y + u[2].y}, s02 = {u[0].x - u[2].x, u[0].y - u[2].y};
-  const cplx a13 = {u[1].x + u[3].x, u[1].y + u[3].y}, s13 = {u[1].x - u[3].x, u[1].y - u[3].y};
-  u[0] = {a02.x + a13.x, a02.y + a13.y};
-  u[1] = {s02.x + s13.y, s02.y - s13.x};  // (x0-x2) - i(x1-x3)
-  u[2] = {a02.x - a13.x, a02.y - a13.y};
-  u[3] = {s02.x - s13.y, s02.y + s13.x};  // (x0-x2) + i(x1-x3)
+  const cplx a02 = u[0] + u[2], s02 = u[0] - u[2];
+  const cplx a13 = u[1] + u[3], s13 = u[1] - u[3];
+  const cplx r = {s13.y, -s13.x};  // -i (x1-x3)
+  u[0] = a02 + a13;
+  u[1] = s02 + r;
+  u[2] = a02 - a13;
+  u[3] = s02 - r;
 }
 
 // 2x2 block transposes between a register pair and one lane bit: a' = [a.low | b.low], b' = [a.high | b.high]
-DEV void swap32(float& a, float& b) {
+DEV void swap32f(float& a, float& b) {
   const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
   const unsigned r0 = r[0], r1 = r[1];  // extract first: bit_cast applied directly to r[1] reads element 0 (hipcc 7.2)
   a = __uint_as_float(r0);
   b = __uint_as_float(r1);
 }
-DEV void swap16(float& a, float& b) {
+DEV void swap16f(float& a, float& b) {
   const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
   const unsigned r0 = r[0], r1 = r[1];
   a = __uint_as_float(r0);
   b = __uint_as_float(r1);
+}
+
+DEV void swap32(cplx& a, cplx& b) {
+  float ax = a.x, ay = a.y, bx = b.x, by = b.y;
+  swap32f(ax, bx);
+  swap32f(ay, by);
+  a = {ax, ay};
+  b = {bx, by};
+}
+DEV void swap16(cplx& a, cplx& b) {
+  float ax = a.x, ay = a.y, bx = b.x, by = b.y;
+  swap16f(ax, bx);
+  swap16f(ay, by);
+  a = {ax, ay};
+  b = {bx, by};
 }
 
 DEV void fft_wave_sync() {
@@ -96,42 +114,62 @@ DEV void fft_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// z[q] = input point l + 64q; tw1[q] = W256^(l q); tws[0..2] = W64^((l & 15) k), tws[3..5] = W16^((l & 3) k), k = 1..3;
-// zs: this wave's LDS scratch (FFT_SCRATCH entries).  u may alias z.
-DEV void fft256_wave(const cplx (&z)[4], cplx (&u)[4], const cplx (&tw1)[4], const cplx (&tws)[6], cplx* zs, int l) {
+// u[c][q] = input point l + 64q of transform c (in place); tw1[q] = W256^(l q); tws[0..2] = W64^((l & 15) k),
+// tws[3..5] = W16^((l & 3) k), k = 1..3; zs: this wave's LDS scratch (NC * FFT_SCRATCH entries).  NC independent
+// transforms advance together: one wave-level sync per exchange serves all of them and the scheduler overlaps one
+// transform's LDS round trip with the other's butterflies (a lone dependent chain leaves the SIMD idle).
+template <int NC>
+DEV void fft256_wave_n(cplx (&u)[NC][4], const cplx (&tw1)[4], const cplx (&tws)[6], cplx* zs, int l) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) u[q] = z[q];
-  radix4_dif(u);  // over n3 -> k0
+  for (int c = 0; c < NC; ++c) {
+    radix4_dif(u[c]);  // over n3 -> k0
 #pragma unroll
-  for (int q = 1; q < 4; ++q) u[q] = cmul(u[q], tw1[q]);
-  // register k0 <-> lane digit n2
-  swap32(u[0].x, u[2].x); swap32(u[0].y, u[2].y); swap32(u[1].x, u[3].x); swap32(u[1].y, u[3].y);
-  swap16(u[0].x, u[1].x); swap16(u[0].y, u[1].y); swap16(u[2].x, u[3].x); swap16(u[2].y, u[3].y);
-  radix4_dif(u);  // over n2 -> k1
+    for (int q = 1; q < 4; ++q) u[c][q] = cmul(u[c][q], tw1[q]);
+    // register k0 <-> lane digit n2
+    swap32(u[c][0], u[c][2]); swap32(u[c][1], u[c][3]);
+    swap16(u[c][0], u[c][1]); swap16(u[c][2], u[c][3]);
+    radix4_dif(u[c]);  // over n2 -> k1
 #pragma unroll
-  for (int q = 1; q < 4; ++q) u[q] = cmul(u[q], tws[q - 1]);
-  // register k1 <-> lane digit n1
+    for (int q = 1; q < 4; ++q) u[c][q] = cmul(u[c][q], tws[q - 1]);
+    // register k1 <-> lane digit n1
 #pragma unroll
-  for (int r = 0; r < 4; ++r) zs[r * 68 + l] = u[r];
+    for (int r = 0; r < 4; ++r) zs[c * FFT_SCRATCH + r * 68 + l] = u[c][r];
+  }
   fft_wave_sync();
-  {
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
     const int base = ((l >> 2) & 3) * 68 + (l & ~12);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) u[j] = zs[base + 4 * j];
+    for (int j = 0; j < 4; ++j) u[c][j] = zs[c * FFT_SCRATCH + base + 4 * j];
   }
-  radix4_dif(u);  // over n1 -> k2
-#pragma unroll
-  for (int q = 1; q < 4; ++q) u[q] = cmul(u[q], tws[2 + q]);
   fft_wave_sync();
-  // register k2 <-> lane digit n0
 #pragma unroll
-  for (int r = 0; r < 4; ++r) zs[r * 65 + l] = u[r];
+  for (int c = 0; c < NC; ++c) {
+    radix4_dif(u[c]);  // over n1 -> k2
+#pragma unroll
+    for (int q = 1; q < 4; ++q) u[c][q] = cmul(u[c][q], tws[2 + q]);
+    // register k2 <-> lane digit n0
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zs[c * FFT_SCRATCH + r * 65 + l] = u[c][r];
+  }
   fft_wave_sync();
-  {
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
     const int base = (l & 3) * 65 + (l & ~3);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) u[j] = zs[base + j];
+    for (int j = 0; j < 4; ++j) u[c][j] = zs[c * FFT_SCRATCH + base + j];
   }
-  radix4_dif(u);  // over n0 -> k3
   fft_wave_sync();
+#pragma unroll
+  for (int c = 0; c < NC; ++c) radix4_dif(u[c]);  // over n0 -> k3
+}
+
+// single transform: u may alias z
+DEV void fft256_wave(const cplx (&z)[4], cplx (&u)[4], const cplx (&tw1)[4], const cplx (&tws)[6], cplx* zs, int l) {
+  cplx v[1][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[0][q] = z[q];
+  fft256_wave_n<1>(v, tw1, tws, zs, l);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) u[q] = v[0][q];
 }

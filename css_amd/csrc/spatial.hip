@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void istft_kernel(const float* __restrict__ re
       const int k = l + 64 * q, kc = 256 - k;  // kc in 1..256
       const cplx A = {sre[k][j], sim[k][j]}, Bc = {sre[kc][j], -sim[kc][j]};
       const cplx E = {0.5f * (A.x + Bc.x), 0.5f * (A.y + Bc.y)};
-      const cplx O = cmul({0.5f * (A.x - Bc.x), 0.5f * (A.y - Bc.y)}, twp[q]);
+      const cplx O = cmul(cplx{0.5f * (A.x - Bc.x), 0.5f * (A.y - Bc.y)}, twp[q]);
       // Z = E + i O ;  conj(Z) = (E.x - O.y, -(E.y + O.x))
       z[q] = {E.x - O.y, -(E.y + O.x)};
     }
