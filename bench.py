@@ -137,6 +137,34 @@ def main():
 
     # ---- roofline of the dominant kernel (the fused FeedForward, 32 launches per step), measured live with
     # HIP events recorded on the stream the kernel is launched on (torch's current stream)
+    def launch_time(fn, reps):
+        """Seconds per call of fn: `reps` calls recorded into one HIP graph, the replay timed with HIP events on the
+        stream it is launched on - the host's per-call work (allocations, ctypes) cannot leak into a 20 us kernel's
+        figure.  Falls back to timing the eager loop when capture is unavailable."""
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                for _ in range(reps):
+                    fn()
+            g.replay()
+            torch.cuda.synchronize()
+            e0.record(torch.cuda.current_stream())
+            g.replay()
+            e1.record(torch.cuda.current_stream())
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] roofline capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
+            torch.cuda.synchronize()
+            e0.record(torch.cuda.current_stream())
+            for _ in range(reps):
+                fn()
+            e1.record(torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+
     roof = None
     if rank == 0:
         M = B * T
@@ -150,16 +178,7 @@ def main():
         wq, bq = ops.pack_frag(torch.randn(768, 256, device=dev) / 16), torch.zeros(768, device=dev)
         out = torch.empty_like(x)
         run = lambda: ops.encoder_chain(x, 1024, ffn_a=fa, final_ln=(g1, b0), ffn_b=fb, qkv=((g1, b0), wq, bq, 768), out=out)  # noqa: E731
-        for _ in range(5):
-            run()
-        reps = 50
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(torch.cuda.current_stream())
-        for _ in range(reps):
-            run()
-        e1.record(torch.cuda.current_stream())
-        torch.cuda.synchronize()
-        dur = e0.elapsed_time(e1) * 1e-3 / reps
+        dur = launch_time(run, 50)
         # two FeedForwards (4*M*256*1024 each) + the q/k/v projection (2*M*256*768): SURVEY.md 8(d) per-layer figures
         flops = 2 * 4.0 * M * 256 * 1024 + 2.0 * M * 256 * 768
         traffic = None
@@ -174,14 +193,7 @@ def main():
                 "flops_per_launch": flops,
                 "whole_step_frac": (B * T * FLOP_PER_FRAME * args.blocks / 16) / (dt / args.steps) / PEAK_BF16}
         # HBM-bound front end for reference (north_star asks for the STFT roofline too)
-        for _ in range(3):
-            ops.stft(audio, ("mag",))
-        e0.record(torch.cuda.current_stream())
-        for _ in range(20):
-            ops.stft(audio, ("mag",))
-        e1.record(torch.cuda.current_stream())
-        torch.cuda.synchronize()
-        sd_ = e0.elapsed_time(e1) * 1e-3 / 20
+        sd_ = launch_time(lambda: ops.stft(audio, ("mag",)), 20)
         nfr = 3 * B * T
         roof["stft"] = {"bound": "hbm", "achieved": nfr * 2052 / sd_ / 1e9, "peak": 8000.0, "unit": "GB/s",
                         "frac": nfr * 2052 / sd_ / 8.0e12, "avg_launch_us": sd_ * 1e6,
@@ -190,14 +202,7 @@ def main():
         with torch.no_grad():
             mags_ = ops.stft(audio, ("mag",))["mag"]
             masks_ = model.forward_masks(mags_[0])
-        for _ in range(3):
-            ops.pit_mse(masks_, mags_[0], [mags_[1], mags_[2]])
-        e0.record(torch.cuda.current_stream())
-        for _ in range(20):
-            ops.pit_mse(masks_, mags_[0], [mags_[1], mags_[2]])
-        e1.record(torch.cuda.current_stream())
-        torch.cuda.synchronize()
-        pd_ = e0.elapsed_time(e1) * 1e-3 / 20
+        pd_ = launch_time(lambda: ops.pit_mse(masks_, mags_[0], [mags_[1], mags_[2]]), 20)
         pit_bytes = 5 * 257 * 4
         roof["pit"] = {"bound": "hbm", "achieved": B * T * pit_bytes / pd_ / 1e9, "peak": 8000.0, "unit": "GB/s",
                        "frac": B * T * pit_bytes / pd_ / 8.0e12, "avg_launch_us": pd_ * 1e6,

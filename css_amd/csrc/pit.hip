@@ -12,7 +12,15 @@
 
 namespace {
 
-constexpr int CHUNK = 2048;  // elements of one sample's T*F handled per workgroup
+#ifndef PIT_RPW
+#define PIT_RPW 2
+#endif
+#ifndef PIT_ROWS
+#define PIT_ROWS 16
+#endif
+constexpr int RPW = PIT_RPW;       // rows (frames) a wave has in flight
+constexpr int ROWS_WG = PIT_ROWS;  // rows per workgroup = one partial-sum chunk
+constexpr int ROWS_WAVE = ROWS_WG / 4;
 constexpr int MAXK = 4;
 
 struct PitArgs {
@@ -26,32 +34,86 @@ struct PitArgs {
 };
 
 template <int K>
+DEV void pit_finalize_body(const float* __restrict__ partial, int B, int nchunk, double norm, float* __restrict__ loss,
+                           int* __restrict__ perm_out, float* __restrict__ pair_sse, float* __restrict__ per_sample,
+                           double* best_sum);
+
+// 16-byte access that is only 4-byte aligned (rows are F = 257 floats).  The texture-address unit spends the same
+// ~16-20 cycles on a wave's load whatever its width, so one dwordx4 per four elements instead of four dword loads
+// is what takes this kernel off the instruction-rate limit of the memory pipeline.
+struct __attribute__((packed, aligned(4))) f4u {
+  float v[4];
+};
+DEV f4u load4(const float* p) { return *reinterpret_cast<const f4u*>(p); }
+
+// One wave takes RPW rows (frames) of one sample at a time: lane l covers bins 4l .. 4l+3 of each row with one
+// 16-byte load per operand (f_orig, K masks, K targets), the F mod 4 bins left at the end of the rows by one more
+// instruction with ROWS_WAVE * (F mod 4) lanes active.  All loads of a pass are issued before any arithmetic.
+template <int K>
 __global__ __launch_bounds__(256) void pit_sse_kernel(PitArgs a) {
   __shared__ float red[4][K * K];
-  const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-  const int TF = a.T * a.F;
+  const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int F = a.F, F4 = F & ~3, T = a.T;
+  const size_t TF = (size_t)T * F;
+  const int tw = chunk * ROWS_WG + w * ROWS_WAVE;
   float acc[K][K];
 #pragma unroll
   for (int k = 0; k < K; ++k)
 #pragma unroll
     for (int j = 0; j < K; ++j) acc[k][j] = 0.f;
-  const int e0 = chunk * CHUNK;
-  // (t, f) of this thread's first element by one division; afterwards e advances by 256 per step: f += 256 with
-  // at most F-sized wraps (no per-element division)
-  int t = (e0 + tid) / a.F, f = (e0 + tid) - t * a.F;
-  const int dt = 256 / a.F, df = 256 - dt * a.F;
-#pragma unroll 8
-  for (int i = 0; i < CHUNK / 256; ++i) {
-    const int e = e0 + i * 256 + tid;
-    if (e < TF) {
-      const size_t row = (size_t)b * a.T + t;
+  for (int t0 = tw; t0 < tw + ROWS_WAVE; t0 += RPW)
+  for (int f0 = 0; f0 < F4; f0 += 256) {
+    const int f = f0 + 4 * lane;
+    const bool fok = f < F4;
+    const int fc = fok ? f : 0;
+    f4u fo[RPW], mk[RPW][K], tg[RPW][K];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const int tc = min(t0 + r, T - 1);
+      const size_t row = (size_t)b * T + tc;
+      fo[r] = load4(a.f + row * a.ld_f + fc);
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        mk[r][k] = load4(a.masks + row * a.ld_mask + k * F + fc);
+        tg[r][k] = load4(a.tgt[k] + (size_t)b * TF + (size_t)tc * F + fc);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const bool ok = fok && t0 + r < T;
+      f4u y[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) y[k].v[c] = mk[r][k].v[c] * fo[r].v[c];
+        if (a.y_pred && ok) *reinterpret_cast<f4u*>(a.y_pred + ((size_t)b * K + k) * TF + (size_t)(t0 + r) * F + f) = y[k];
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          float s = 0.f;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float d = y[k].v[c] - tg[r][j].v[c];
+            s += d * d;
+          }
+          acc[k][j] += ok ? s : 0.f;
+        }
+    }
+  }
+  const int nt = F - F4;  // 0..3 bins at the end of every row
+  if (nt && lane < ROWS_WAVE * nt) {
+    const int r = lane / nt, f = F4 + lane - r * nt, t = tw + r;
+    if (t < T) {
+      const size_t row = (size_t)b * T + t;
       const float fo = a.f[row * a.ld_f + f];
       float y[K], tg[K];
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        y[k] = a.masks[row * a.ld_mask + k * a.F + f] * fo;
-        tg[k] = a.tgt[k][(size_t)b * TF + e];
-        if (a.y_pred) a.y_pred[((size_t)b * K + k) * TF + e] = y[k];
+        y[k] = a.masks[row * a.ld_mask + k * F + f] * fo;
+        tg[k] = a.tgt[k][(size_t)b * TF + (size_t)t * F + f];
+        if (a.y_pred) a.y_pred[((size_t)b * K + k) * TF + (size_t)t * F + f] = y[k];
       }
 #pragma unroll
       for (int k = 0; k < K; ++k)
@@ -61,14 +123,7 @@ __global__ __launch_bounds__(256) void pit_sse_kernel(PitArgs a) {
           acc[k][j] += d * d;
         }
     }
-    t += dt;
-    f += df;
-    if (f >= a.F) {
-      f -= a.F;
-      ++t;
-    }
   }
-  const int lane = tid & 63, w = tid >> 6;
 #pragma unroll
   for (int k = 0; k < K; ++k)
 #pragma unroll
@@ -84,21 +139,34 @@ __global__ __launch_bounds__(256) void pit_sse_kernel(PitArgs a) {
 // Eight lanes per sample reduce its partials (double, fixed order), one of them scans the K! permutations in
 // itertools.permutations order (first minimum wins, like torch.min), then thread 0 averages.  Single workgroup.
 template <int K>
-__global__ __launch_bounds__(256) void pit_finalize_kernel(const float* __restrict__ partial, int B, int nchunk,
-                                                           double norm, float* __restrict__ loss,
-                                                           int* __restrict__ perm_out, float* __restrict__ pair_sse,
-                                                           float* __restrict__ per_sample) {
-  __shared__ double best_sum[4];
+DEV void pit_finalize_body(const float* __restrict__ partial, int B, int nchunk, double norm, float* __restrict__ loss,
+                           int* __restrict__ perm_out, float* __restrict__ pair_sse, float* __restrict__ per_sample,
+                           double* best_sum) {
   double acc_best = 0.0;  // sum of this thread's samples' minima (threads with part == 0 only)
   for (int b0 = 0; b0 < B; b0 += 32) {
   const int b = b0 + (threadIdx.x >> 3), part = threadIdx.x & 7;
   double Dm[K][K];
   for (int k = 0; k < K; ++k)
     for (int j = 0; j < K; ++j) Dm[k][j] = 0.0;
+  // four chunks per lane are loaded before any is added; the additions keep the ascending-chunk order
   if (b < B)
-    for (int c = part; c < nchunk; c += 8)
-      for (int k = 0; k < K; ++k)
-        for (int j = 0; j < K; ++j) Dm[k][j] += (double)partial[((size_t)b * nchunk + c) * (K * K) + k * K + j];
+    for (int c0 = part; c0 < nchunk; c0 += 32) {
+      float v[4][K * K];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = min(c0 + 8 * u, nchunk - 1);
+#pragma unroll
+        for (int i = 0; i < K * K; ++i)
+          v[u][i] = partial[((size_t)b * nchunk + c) * (K * K) + i];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (c0 + 8 * u < nchunk)
+#pragma unroll
+          for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int j = 0; j < K; ++j) Dm[k][j] += (double)v[u][k * K + j];
+    }
   for (int k = 0; k < K; ++k)
     for (int j = 0; j < K; ++j) {
       double v = Dm[k][j];
@@ -144,9 +212,16 @@ __global__ __launch_bounds__(256) void pit_finalize_kernel(const float* __restri
   for (int o = 32; o >= 1; o >>= 1) acc_best += __shfl_xor(acc_best, o);
   if ((threadIdx.x & 63) == 0) best_sum[threadIdx.x >> 6] = acc_best;
   __syncthreads();
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    *loss = (float)(((best_sum[0] + best_sum[1]) + (best_sum[2] + best_sum[3])) / (double)B);
-  }
+  if (threadIdx.x == 0) *loss = (float)(((best_sum[0] + best_sum[1]) + (best_sum[2] + best_sum[3])) / (double)B);
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void pit_finalize_kernel(const float* __restrict__ partial, int B, int nchunk,
+                                                           double norm, float* __restrict__ loss,
+                                                           int* __restrict__ perm_out, float* __restrict__ pair_sse,
+                                                           float* __restrict__ per_sample) {
+  __shared__ double best_sum[4];
+  pit_finalize_body<K>(partial, B, nchunk, norm, loss, perm_out, pair_sse, per_sample, best_sum);
 }
 
 template <int K>
@@ -187,7 +262,7 @@ __global__ __launch_bounds__(256) void apply_masks_kernel(const float* __restric
 }  // namespace
 
 extern "C" size_t csship_pit_workspace(int32_t B, int32_t T, int32_t F, int32_t K) {
-  const size_t nchunk = ((size_t)T * F + CHUNK - 1) / CHUNK;
+  const size_t nchunk = ((size_t)T + ROWS_WG - 1) / ROWS_WG;
   return ((size_t)B * nchunk * K * K + (size_t)B) * sizeof(float);
 }
 
@@ -205,19 +280,19 @@ extern "C" int csship_pit_mse(const float* masks, int64_t ld_mask, const float* 
     if (!targets_host[k]) return CSSHIP_ENULL;
     a.tgt[k] = targets_host[k];
   }
-  a.nchunk = (int)(((size_t)T * F + CHUNK - 1) / CHUNK);
+  a.nchunk = (T + ROWS_WG - 1) / ROWS_WG;
   a.partial = reinterpret_cast<float*>(workspace);
   float* per_sample = a.partial + (size_t)B * a.nchunk * K * K;
+  const double norm = (double)K * T * F;
   hipStream_t s = as_stream(stream);
   dim3 grid(a.nchunk, B);
-  const double norm = (double)K * T * F;
   const int fb = 256;  // finalize: one block (32 samples per pass) so the batch mean can follow a block barrier
-#define PIT_CASE(KK)                                                                                        \
-  case KK:                                                                                                  \
-    hipLaunchKernelGGL(pit_sse_kernel<KK>, grid, dim3(256), 0, s, a);                                       \
-    CSSHIP_CHECK_LAUNCH();                                                                                  \
-    hipLaunchKernelGGL(pit_finalize_kernel<KK>, dim3(1), dim3(fb), 0, s, a.partial, B, a.nchunk, norm, loss, \
-                       perm, pair_sse, per_sample);                                                         \
+#define PIT_CASE(KK)                                                                                          \
+  case KK:                                                                                                    \
+    hipLaunchKernelGGL(pit_sse_kernel<KK>, grid, dim3(256), 0, s, a);                                         \
+    CSSHIP_CHECK_LAUNCH();                                                                                    \
+    hipLaunchKernelGGL(pit_finalize_kernel<KK>, dim3(1), dim3(fb), 0, s, a.partial, B, a.nchunk, norm, loss,   \
+                       perm, pair_sse, per_sample);                                                           \
     break;
   switch (K) {
     PIT_CASE(1) PIT_CASE(2) PIT_CASE(3) PIT_CASE(4)
