@@ -38,42 +38,65 @@ constexpr int STAGE = 256 * 128;  // A image (16 KB) + B image (16 KB)
 // A half-wave's transposing read touches k rows {8a..8a+3, 8a+8..8a+11}: 8 distinct keys -> conflict free.
 DEV int km_off(int k, int grp) { return k * 256 + ((grp ^ ((k & 3) | (((k >> 3) & 1) << 2))) << 5); }
 
+// Raw image of 8 consecutive operand elements as loaded: bf16 -> x (one 16-byte load), f32 -> x, y (two).  The
+// conversion to bf16 happens when the tile is written to LDS, AFTER the MFMAs of the current tile.
+struct Raw8 {
+  uint4 x, y;
+};
+
 template <bool F32>
-DEV uint4 load8(const void* base, int64_t off, int n_valid) {  // 8 consecutive elements -> 8 bf16
+DEV Raw8 load8(const void* base, int64_t off, int n_valid) {
+  Raw8 r;
+  r.y = make_uint4(0, 0, 0, 0);
   if constexpr (F32) {
     const float* p = reinterpret_cast<const float*>(base) + off;
     if (n_valid >= 8) {
-      const float4 x0 = *reinterpret_cast<const float4*>(p);
-      const float4 x1 = *reinterpret_cast<const float4*>(p + 4);
-      return make_uint4(pack_bf2(x0.x, x0.y), pack_bf2(x0.z, x0.w), pack_bf2(x1.x, x1.y), pack_bf2(x1.z, x1.w));
+      r.x = *reinterpret_cast<const uint4*>(p);
+      r.y = *reinterpret_cast<const uint4*>(p + 4);
+      return r;
     }
-    float v[8];
+    unsigned v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = e < n_valid ? p[e] : 0.f;
-    return make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+    for (int e = 0; e < 8; ++e) v[e] = e < n_valid ? __float_as_uint(p[e]) : 0u;
+    r.x = make_uint4(v[0], v[1], v[2], v[3]);
+    r.y = make_uint4(v[4], v[5], v[6], v[7]);
+    return r;
   } else {
     const unsigned short* p = reinterpret_cast<const unsigned short*>(base) + off;
-    if (n_valid >= 8) return *reinterpret_cast<const uint4*>(p);
+    if (n_valid >= 8) {
+      r.x = *reinterpret_cast<const uint4*>(p);
+      return r;
+    }
     unsigned short v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = e < n_valid ? p[e] : (unsigned short)0;
-    return make_uint4(v[0] | ((unsigned)v[1] << 16), v[2] | ((unsigned)v[3] << 16), v[4] | ((unsigned)v[5] << 16),
-                      v[6] | ((unsigned)v[7] << 16));
+    r.x = make_uint4(v[0] | ((unsigned)v[1] << 16), v[2] | ((unsigned)v[3] << 16), v[4] | ((unsigned)v[5] << 16),
+                     v[6] | ((unsigned)v[7] << 16));
+    return r;
   }
 }
 
-// one operand's 128 x 64 tile -> 4 x 16 bytes per thread.  rows: tile's first operand row, nrows: operand rows,
-// k0/kend: reduction range of this tile.
+DEV uint4 to_bf16(const Raw8& r, bool f32) {
+  if (!f32) return r.x;
+  return make_uint4(pack_bf2(__uint_as_float(r.x.x), __uint_as_float(r.x.y)), pack_bf2(__uint_as_float(r.x.z), __uint_as_float(r.x.w)),
+                    pack_bf2(__uint_as_float(r.y.x), __uint_as_float(r.y.y)), pack_bf2(__uint_as_float(r.y.z), __uint_as_float(r.y.w)));
+}
+
+// Generic loader (any shape): one operand's 128 x 64 tile -> 4 raw groups per thread.  rows: tile's first operand row,
+// nrows: operand rows, k0/kend: reduction range of this tile.  hipcc branches around every conditional load and
+// waits for it inside the branch, so this loader's loads go out one after the other - it only serves shapes whose
+// grouped dimension is not a multiple of 8.
 template <bool KM>
 DEV void load_operand(const void* base, bool f32, int64_t ld, int row0, int nrows, int k0, int kend, int tid,
-                      uint4 (&r)[4]) {
+                      Raw8 (&r)[4]) {
+  const Raw8 zero = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
   if constexpr (!KM) {
     const int srow = tid >> 3, k = k0 + (tid & 7) * 8;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = row0 + srow + 32 * i;
       const int nv = (row < nrows) ? kend - k : 0;
-      if (nv <= 0) r[i] = make_uint4(0, 0, 0, 0);
+      if (nv <= 0) r[i] = zero;
       else r[i] = f32 ? load8<true>(base, (int64_t)row * ld + k, nv) : load8<false>(base, (int64_t)row * ld + k, nv);
     }
   } else {
@@ -82,23 +105,59 @@ DEV void load_operand(const void* base, bool f32, int64_t ld, int row0, int nrow
     for (int i = 0; i < 4; ++i) {
       const int k = k0 + krow + 16 * i;
       const int nv = (k < kend) ? nrows - col : 0;
-      if (nv <= 0) r[i] = make_uint4(0, 0, 0, 0);
+      if (nv <= 0) r[i] = zero;
       else r[i] = f32 ? load8<true>(base, (int64_t)k * ld + col, nv) : load8<false>(base, (int64_t)k * ld + col, nv);
     }
   }
 }
 
+// Fast loader (whole 8-element groups, operand < 4 GB): buffer loads through a descriptor that covers exactly the
+// operand.  A group outside the tile's rows or reduction range gets an offset beyond the descriptor's range and the
+// hardware returns zeros: no branch, no select on the data, and the four (bf16) / eight (f32) loads of an operand go
+// out back to back.
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0xFFFFFF00u;
+
+template <bool KM, bool F32>
+DEV void load_operand_buf(__amdgpu_buffer_rsrc_t rs, unsigned ld, int row0, int nrows, int k0, int kend, int tid,
+                          Raw8 (&r)[4]) {
+  constexpr unsigned esz = F32 ? 4 : 2;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    unsigned off;
+    bool valid;
+    if constexpr (!KM) {
+      const int row = row0 + (tid >> 3) + 32 * i, k = k0 + (tid & 7) * 8;
+      valid = row < nrows && k + 8 <= kend;
+      off = (unsigned)row * ld + (unsigned)k;
+    } else {
+      const int k = k0 + (tid >> 4) + 16 * i, col = row0 + (tid & 15) * 8;
+      valid = k < kend && col + 8 <= nrows;
+      off = (unsigned)k * ld + (unsigned)col;
+    }
+    const unsigned vo = valid ? off * esz : OOB;
+    const v4u x = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0);
+    r[i].x = make_uint4(x.x, x.y, x.z, x.w);
+    if constexpr (F32) {
+      const v4u y = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 16, 0, 0);
+      r[i].y = make_uint4(y.x, y.y, y.z, y.w);
+    } else {
+      r[i].y = make_uint4(0, 0, 0, 0);
+    }
+  }
+}
+
 template <bool KM>
-DEV void store_operand(unsigned char* img, int tid, const uint4 (&r)[4]) {
+DEV void store_operand(unsigned char* img, int tid, const Raw8 (&r)[4], bool f32) {
   if constexpr (!KM) {
     const int srow = tid >> 3, sc = tid & 7;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(img + tile_off(srow + 32 * i, sc)) = r[i];
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(img + tile_off(srow + 32 * i, sc)) = to_bf16(r[i], f32);
   } else {
     const int krow = tid >> 4, ch = tid & 15;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<uint4*>(img + km_off(krow + 16 * i, ch >> 1) + (ch & 1) * 16) = r[i];
+      *reinterpret_cast<uint4*>(img + km_off(krow + 16 * i, ch >> 1) + (ch & 1) * 16) = to_bf16(r[i], f32);
   }
 }
 
@@ -117,22 +176,54 @@ DEV bf16x8 read_frag(const unsigned char* img, int r0, int ks, int lane) {
   }
 }
 
-template <bool A_KM, bool B_KM>
+// FAST: whole 8-element groups and operands below 4 GB -> descriptor loads with compile-time operand types.
+template <bool A_KM, bool B_KM, bool FAST, bool A_F32, bool B_F32>
 __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int lg = lane >> 4, ln = lane & 15;
-  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
-  const int z = blockIdx.z / g.splits, split = blockIdx.z % g.splits;
+  // XCD-aware tile order.  Workgroups go to the 8 XCDs round-robin by their linear id, and every XCD has its own L2:
+  // in the natural order the tiles that share operand rows (all output tiles of one K-split, or of one batch entry)
+  // land on 8 different XCDs and each pulls the same rows through its own L2 (166 MB of L2 fills for 39 MB of
+  // operands in the FeedForward dW product).  Here the workgroups of one XCD walk all tiles of one (batch, split)
+  // slice before the next, so the re-reads hit that XCD's L2.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  {
+    const unsigned tiles = gridDim.x * gridDim.y, nz = gridDim.z;
+    if ((nz & 7) == 0) {
+      const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      const unsigned xcd = lin & 7, j = lin >> 3;
+      const unsigned t = j % tiles;
+      bz = (j / tiles) * 8 + xcd;
+      bx = t % gridDim.x;
+      by = t / gridDim.x;
+    }
+  }
+  const int m0 = by * 128, n0 = bx * 128;
+  const int z = bz / g.splits, split = bz % g.splits;
   const int z1 = z / g.nb2, z2 = z % g.nb2;
   const int kbeg = split * g.k_per_split, kend = min(g.K, kbeg + g.k_per_split);
   const int nk = (kend - kbeg + BK - 1) / BK;
-  const bool af32 = g.a_f32 != 0, bf32 = g.b_f32 != 0;
+  const bool af32 = FAST ? A_F32 : g.a_f32 != 0, bf32 = FAST ? B_F32 : g.b_f32 != 0;
   const void* Ab = reinterpret_cast<const unsigned char*>(g.A) + (z1 * g.sA1 + z2 * g.sA2) * (af32 ? 4 : 2);
   const void* Bb = reinterpret_cast<const unsigned char*>(g.B) + (z1 * g.sB1 + z2 * g.sB2) * (bf32 ? 4 : 2);
 
-  uint4 ra[4], rb[4];
+  Raw8 ra[4], rb[4];
+  // descriptors over exactly this batch entry's operands (wave-uniform: built from kernel arguments and blockIdx)
+  const unsigned a_bytes = ((A_KM ? (unsigned)(g.K - 1) * (unsigned)g.lda + g.M : (unsigned)(g.M - 1) * (unsigned)g.lda + g.K)) * (A_F32 ? 4u : 2u);
+  const unsigned b_bytes = ((B_KM ? (unsigned)(g.K - 1) * (unsigned)g.ldb + g.N : (unsigned)(g.N - 1) * (unsigned)g.ldb + g.K)) * (B_F32 ? 4u : 2u);
+  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(Ab), 0, FAST ? a_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(Bb), 0, FAST ? b_bytes : 0, 0x00020000);
+  auto load_tile = [&](int k0) {
+    if constexpr (FAST) {
+      load_operand_buf<A_KM, A_F32>(rsa, (unsigned)g.lda, m0, g.M, k0, kend, tid, ra);
+      load_operand_buf<B_KM, B_F32>(rsb, (unsigned)g.ldb, n0, g.N, k0, kend, tid, rb);
+    } else {
+      load_operand<A_KM>(Ab, af32, g.lda, m0, g.M, k0, kend, tid, ra);
+      load_operand<B_KM>(Bb, bf32, g.ldb, n0, g.N, k0, kend, tid, rb);
+    }
+  };
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -140,17 +231,16 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (nk > 0) {
-    load_operand<A_KM>(Ab, af32, g.lda, m0, g.M, kbeg, kend, tid, ra);
-    load_operand<B_KM>(Bb, bf32, g.ldb, n0, g.N, kbeg, kend, tid, rb);
-    store_operand<A_KM>(smem, tid, ra);
-    store_operand<B_KM>(smem + 128 * 128, tid, rb);
+    load_tile(kbeg);
+    store_operand<A_KM>(smem, tid, ra, af32);
+    store_operand<B_KM>(smem + 128 * 128, tid, rb, bf32);
   }
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) {
-      load_operand<A_KM>(Ab, af32, g.lda, m0, g.M, kbeg + (kt + 1) * BK, kend, tid, ra);
-      load_operand<B_KM>(Bb, bf32, g.ldb, n0, g.N, kbeg + (kt + 1) * BK, kend, tid, rb);
+      load_tile(kbeg + (kt + 1) * BK);
     }
+    __builtin_amdgcn_sched_barrier(0);  // hipcc would sink the loads / hoist their conversion next to each other
     const unsigned char* as = smem + (kt & 1) * STAGE;
     const unsigned char* bs = as + 128 * 128;
 #pragma unroll
@@ -167,10 +257,11 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
     if (kt + 1 < nk) {
       unsigned char* nx = smem + ((kt + 1) & 1) * STAGE;
-      store_operand<A_KM>(nx, tid, ra);
-      store_operand<B_KM>(nx + 128 * 128, tid, rb);
+      store_operand<A_KM>(nx, tid, ra, af32);
+      store_operand<B_KM>(nx + 128 * 128, tid, rb, bf32);
     }
     __syncthreads();
   }
@@ -334,10 +425,24 @@ extern "C" int csship_bgemm(const void* A, const void* B, void* C, const float* 
   a.a_f32 = p->a_f32; a.b_f32 = p->b_f32; a.epi = p->epilogue; a.alpha = p->alpha;
   dim3 grid((p->N + 127) / 128, (p->M + 127) / 128, (unsigned)nz);
   hipStream_t s = as_stream(stream);
-  if (p->a_kmajor && p->b_kmajor) hipLaunchKernelGGL((bgemm_kernel<true, true>), grid, dim3(256), 0, s, a);
-  else if (p->a_kmajor) hipLaunchKernelGGL((bgemm_kernel<true, false>), grid, dim3(256), 0, s, a);
-  else if (p->b_kmajor) hipLaunchKernelGGL((bgemm_kernel<false, true>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((bgemm_kernel<false, false>), grid, dim3(256), 0, s, a);
+  // descriptor loads need whole 8-element groups and 32-bit byte offsets inside one batch entry
+  const int64_t a_elems = p->a_kmajor ? (int64_t)(p->K - 1) * p->lda + p->M : (int64_t)(p->M - 1) * p->lda + p->K;
+  const int64_t b_elems = p->b_kmajor ? (int64_t)(p->K - 1) * p->ldb + p->N : (int64_t)(p->N - 1) * p->ldb + p->K;
+  const bool fast = (((p->a_kmajor ? p->M : p->K) | (p->b_kmajor ? p->N : p->K)) & 7) == 0 &&
+                    a_elems * (p->a_f32 ? 4 : 2) < 0xFFFFFF00ll && b_elems * (p->b_f32 ? 4 : 2) < 0xFFFFFF00ll;
+#define BG_LAUNCH(AK, BK_)                                                                                      \
+  do {                                                                                                          \
+    if (!fast) hipLaunchKernelGGL((bgemm_kernel<AK, BK_, false, false, false>), grid, dim3(256), 0, s, a);      \
+    else if (p->a_f32 && p->b_f32) hipLaunchKernelGGL((bgemm_kernel<AK, BK_, true, true, true>), grid, dim3(256), 0, s, a);   \
+    else if (p->a_f32) hipLaunchKernelGGL((bgemm_kernel<AK, BK_, true, true, false>), grid, dim3(256), 0, s, a);              \
+    else if (p->b_f32) hipLaunchKernelGGL((bgemm_kernel<AK, BK_, true, false, true>), grid, dim3(256), 0, s, a);              \
+    else hipLaunchKernelGGL((bgemm_kernel<AK, BK_, true, false, false>), grid, dim3(256), 0, s, a);                           \
+  } while (0)
+  if (p->a_kmajor && p->b_kmajor) BG_LAUNCH(true, true);
+  else if (p->a_kmajor) BG_LAUNCH(true, false);
+  else if (p->b_kmajor) BG_LAUNCH(false, true);
+  else BG_LAUNCH(false, false);
+#undef BG_LAUNCH
   CSSHIP_CHECK_LAUNCH();
   if (splits > 1) {
     const int64_t n = (int64_t)p->M * p->N;
