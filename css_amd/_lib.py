@@ -53,6 +53,11 @@ class BgemmParams(C.Structure):
                 ("sX1", _i64), ("sX2", _i64), ("alpha", _f32)]
 
 
+class PackJob(C.Structure):  # csship_pack_job (64 bytes)
+    _fields_ = [("w", _p), ("row_major", _p), ("frag", _p), ("ld_w", _i64), ("ld_row_major", _i64),
+                ("R", _i32), ("K", _i32), ("dst_row0", _i32), ("Kp", _i32), ("scale", _f32), ("transposed", _i32)]
+
+
 A_BF16, A_F32, A_F32_MVN = 0, 1, 2
 BEPI_OUT_BF16, BEPI_MASK_POS, BEPI_ADD = 1, 2, 4
 EPI_RELU, EPI_RESIDUAL, EPI_LAYERNORM, EPI_OUT_BF16 = 1, 2, 4, 8
@@ -107,6 +112,7 @@ SIGNATURES = {
     "csship_convmod_bwd_workspace": (_sz, [_i32, _i32, _i32]),
     "csship_convmod_bwd": (_i32, [_p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _sz, _p]),
     "csship_pack_weight": (_i32, [_p, _i32, _i32, _i64, _f32, _p, _i64, _p, _i32, _p]),
+    "csship_pack_weights_multi": (_i32, [_p, _i32, _i64, _p]),
     "csship_lstm_bidir_train": (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p]),
     "csship_lstm_bidir_bwd": (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p]),
     "csship_adam_clip_workspace": (_sz, [_i64]),

@@ -76,6 +76,41 @@ class MasksWithTwinBackward(torch.autograd.Function):
         return (None, None) + full
 
 
+def _conformer_pack_plan(model, wide, device):
+    """bf16 shadows (row-major / MFMA fragment order / fragment-packed transposes) of every Linear weight of the model,
+    produced by ONE launch per step.  Built once per (model, kernel family, device); the destinations are rewritten in
+    place by every forward."""
+    ent = getattr(model, "_train_pack", None)
+    if ent is not None and ent["wide"] == wide and ent["device"] == device:
+        return ent
+    enc = model.conformer
+    D = enc.d_model
+    plan = ob.PackPlan(device)
+    ent = {"wide": wide, "device": device, "plan": plan, "layers": []}
+    ent["we_bf"] = plan.add(enc.embed[0].weight.detach(), want_row_major=True)[0]
+    ent["wh_bf"], ent["wh_p"] = plan.add(model.linear.weight.detach(), want_row_major=True, want_frag=not wide)
+    for lay in enc.encoders:
+        h = {}
+        for tag, m in (("ffn_in", lay.feed_forward_in), ("ffn_out", lay.feed_forward_out)):
+            w1, w2 = m.net[0].weight.detach(), m.net[3].weight.detach()
+            if wide:
+                h[tag] = (plan.add(w1, want_row_major=True)[0], plan.add(w2, want_row_major=True)[0])
+            else:  # fragment-packed weights and, for the fused backward kernel, their transposes
+                h[tag] = (plan.add(w1, want_frag=True)[1], plan.add(w2, want_frag=True)[1],
+                          plan.add(w2, transposed=True, want_frag=True)[1], plan.add(w1, transposed=True, want_frag=True)[1])
+        a = lay.self_attn
+        wqkv_bf = torch.empty((3 * D, D), dtype=BF, device=device)
+        wqkv_p = None if wide else torch.empty(3 * D * D, dtype=BF, device=device)
+        for i, lin in enumerate((a.linear_q, a.linear_k, a.linear_v)):
+            plan.add(lin.weight.detach(), scale=a.d_k ** -0.5 if i == 0 else 1.0, row_major=wqkv_bf, frag=wqkv_p,
+                     row0=i * D)
+        h["wqkv_bf"], h["wqkv_p"] = wqkv_bf, wqkv_p
+        h["wo_bf"], h["wo_p"] = plan.add(a.linear_out.weight.detach(), want_row_major=True, want_frag=not wide)
+        ent["layers"].append(h)
+    model._train_pack = ent
+    return ent
+
+
 class ConformerTrain(torch.autograd.Function):
     """masks = Conformer(f) with the explicit HIP backward (no dropout).  model.training selects BatchNorm batch
     statistics (running statistics updated) or, in eval mode, the frozen running statistics.  d_k = 64, kernel 33;
@@ -94,7 +129,9 @@ class ConformerTrain(torch.autograd.Function):
         mean, rinv = ops.mvn_stats(f)
         S = {"f": f, "mean": mean, "rinv": rinv, "layers": [], "wide": wide, "batch_bn": batch_bn}
         Kp = (F + 7) // 8 * 8
-        we_bf, _ = ob.pack_weight(enc.embed[0].weight.detach(), want_row_major=True)
+        pack = _conformer_pack_plan(model, wide, f.device)
+        pack["plan"].run()
+        we_bf = pack["we_bf"]
         fn = ob.mvn_apply(f, mean, rinv, Kp)
         e = ob.bgemm(fn, we_bf, bias=enc.embed[0].bias.detach())
         _, x = ops.layernorm_relu(e, enc.embed[1].weight.detach(), enc.embed[1].bias.detach())
@@ -103,23 +140,18 @@ class ConformerTrain(torch.autograd.Function):
         pe_pack = ops.pack_relpos(pe, enc.pos_emb.maxlen)
         S["pe_bf"] = pe.to(BF)
         S["pe_pack"] = pe_pack
-        for lay in enc.encoders:
+        bn_means, bn_vars, bn_cnt, bn_new_m, bn_new_v = [], [], [], [], []
+        for lay, wp in zip(enc.encoders, pack["layers"]):
             L = {}
 
             def ffn(m, xin, tag):
-                w1, w2 = m.net[0].weight.detach(), m.net[3].weight.detach()
                 if wide:  # LayerNorm -> tiled GEMM (ReLU, bf16) -> tiled GEMM (+ residual)
-                    w1_bf, _ = ob.pack_weight(w1, want_row_major=True)
-                    w2_bf, _ = ob.pack_weight(w2, want_row_major=True)
+                    w1_bf, w2_bf = wp[tag]
                     L[tag] = (xin, w1_bf, w2_bf)
                     a_, _ = ops.layernorm(xin, m.layer_norm.weight.detach(), m.layer_norm.bias.detach())
                     h_ = ops.gemm(a_, w1_bf, m.net[0].bias.detach(), relu=True, out_bf16=True)
                     return ops.gemm(h_, w2_bf, m.net[3].bias.detach(), residual=xin, alpha=0.5)
-                _, w1p = ob.pack_weight(w1, want_frag=True)
-                _, w2p = ob.pack_weight(w2, want_frag=True)
-                # fragment-packed transposes for the fused backward kernel
-                _, w1tp = ob.pack_weight(w1.t().contiguous(), want_frag=True)
-                _, w2tp = ob.pack_weight(w2.t().contiguous(), want_frag=True)
+                w1p, w2p, w2tp, w1tp = wp[tag]
                 L[tag] = (xin, w1p, w2tp, w1tp)
                 return ops.ffn_fused(xin, (m.layer_norm.weight.detach(), m.layer_norm.bias.detach()), w1p,
                                      m.net[0].bias.detach(), w2p, m.net[3].bias.detach(), FF, 0.5)
@@ -127,13 +159,8 @@ class ConformerTrain(torch.autograd.Function):
             x1 = ffn(lay.feed_forward_in, x, "ffn_in")
             a = lay.self_attn
             scale = a.d_k ** -0.5
-            wqkv_bf = torch.empty((3 * D, D), dtype=BF, device=f.device)
-            wqkv_p = None if wide else torch.empty(3 * D * D, dtype=BF, device=f.device)
-            for i, lin in enumerate((a.linear_q, a.linear_k, a.linear_v)):
-                ob.pack_weight(lin.weight.detach(), scale=scale if i == 0 else 1.0, row_major=wqkv_bf, frag=wqkv_p,
-                               row0=i * D)
+            wqkv_bf, wqkv_p, wo_bf, wo_p = wp["wqkv_bf"], wp["wqkv_p"], wp["wo_bf"], wp["wo_p"]
             bqkv = torch.cat([a.linear_q.bias.detach() * scale, a.linear_k.bias.detach(), a.linear_v.bias.detach()], 0)
-            wo_bf, wo_p = ob.pack_weight(a.linear_out.weight.detach(), want_row_major=True, want_frag=not wide)
             if wide:
                 a2, _ = ops.layernorm(x1, a.layer_norm.weight.detach(), a.layer_norm.bias.detach())
                 qkv = ops.gemm(a2, wqkv_bf, bqkv, out_bf16=True)
@@ -160,17 +187,21 @@ class ConformerTrain(torch.autograd.Function):
             L["conv"] = (x2, W, fws)
             if batch_bn:
                 stats = fws.view(torch.float32)[-4 * D:]
-                with torch.no_grad():  # BatchNorm1d bookkeeping (momentum 0.1, unbiased running variance)
-                    c.BN.running_mean.mul_(0.9).add_(stats[2 * D:3 * D], alpha=0.1)
-                    c.BN.running_var.mul_(0.9).add_(stats[3 * D:], alpha=0.1 * M / max(M - 1, 1))
-                    c.BN.num_batches_tracked += 1
+                bn_means.append(c.BN.running_mean), bn_vars.append(c.BN.running_var), bn_cnt.append(c.BN.num_batches_tracked)
+                bn_new_m.append(stats[2 * D:3 * D]), bn_new_v.append(stats[3 * D:])
             x4 = ffn(lay.feed_forward_out, x3, "ffn_out")
             _, x = ops.layernorm(x4, lay.layer_norm.weight.detach(), lay.layer_norm.bias.detach(), out_bf16=False,
                                  out_f32=True)
             L["x4"] = x4
             S["layers"].append(L)
+        if bn_means:  # BatchNorm1d bookkeeping for all blocks at once (momentum 0.1, unbiased running variance)
+            with torch.no_grad():
+                torch._foreach_mul_(bn_means + bn_vars, 0.9)
+                torch._foreach_add_(bn_means, bn_new_m, alpha=0.1)
+                torch._foreach_add_(bn_vars, bn_new_v, alpha=0.1 * M / max(M - 1, 1))
+                torch._foreach_add_(bn_cnt, 1)
         n_out = model.linear.out_features
-        wh_bf, wh_p = ob.pack_weight(model.linear.weight.detach(), want_row_major=True, want_frag=not wide)
+        wh_bf, wh_p = pack["wh_bf"], pack["wh_p"]
         ld = (n_out + 3) // 4 * 4
         masks = torch.empty((M, ld), dtype=torch.float32, device=f.device)[:, :n_out]
         if wide:

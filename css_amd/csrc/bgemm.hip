@@ -243,20 +243,23 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
     __builtin_amdgcn_sched_barrier(0);  // hipcc would sink the loads / hoist their conversion next to each other
     const unsigned char* as = smem + (kt & 1) * STAGE;
     const unsigned char* bs = as + 128 * 128;
+    // both k-steps' fragments are requested before the first MFMA: the second half's LDS reads run under the first
+    // half's MFMAs (with one wave per SIMD nothing else would overlap them)
+    bf16x8 af[2][4], bf[2][4];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[4], bf[4];
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        af[i] = read_frag<A_KM>(as, wm * 64 + i * 16, ks, lane);
-        bf[i] = read_frag<B_KM>(bs, wn * 64 + i * 16, ks, lane);
+        af[ks][i] = read_frag<A_KM>(as, wm * 64 + i * 16, ks, lane);
+        bf[ks][i] = read_frag<B_KM>(bs, wn * 64 + i * 16, ks, lane);
       }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     if (kt + 1 < nk) {
       unsigned char* nx = smem + ((kt + 1) & 1) * STAGE;

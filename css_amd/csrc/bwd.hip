@@ -260,6 +260,42 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
   }
 }
 
+// The same for a whole table of weights in ONE launch (blockIdx.y = job): a training step re-packs every Linear
+// weight of the model (12 per Conformer block) and a launch each costs more than the packing itself.  A job may read
+// its source transposed (logical W[r][k] = w[k * ld + r], e.g. the [K, R] view of a Linear weight whose transpose
+// the FeedForward backward kernel wants fragment-packed): consecutive threads then walk r, so the reads stay
+// coalesced and the 16-row fragment groups are written as contiguous 256-byte pieces.
+__global__ __launch_bounds__(256) void pack_multi_kernel(const csship_pack_job* __restrict__ jobs) {
+  const csship_pack_job j = jobs[blockIdx.y];
+  const int kc = j.Kp / 8;
+  const int Rp = (j.R + 15) / 16 * 16;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)Rp * kc) return;
+  int r, k;
+  if (j.transposed) {
+    r = (int)(i % Rp);
+    k = (int)(i / Rp) * 8;
+  } else {
+    r = (int)(i / kc);
+    k = (int)(i % kc) * 8;
+  }
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const bool ok = r < j.R && k + e < j.K;
+    const int64_t src = j.transposed ? (int64_t)(k + e) * j.ld_w + r : (int64_t)r * j.ld_w + k + e;
+    v[e] = ok ? j.w[src] * j.scale : 0.f;
+  }
+  const uint4 o = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+  if (j.row_major && r < j.R && k < j.ld_row_major)
+    *reinterpret_cast<uint4*>(j.row_major + (int64_t)(j.dst_row0 + r) * j.ld_row_major + k) = o;
+  if (j.frag) {
+    const int rr = j.dst_row0 + r;
+    const int64_t blk = (int64_t)(rr / 16) * (j.Kp / 32) + k / 32;
+    *reinterpret_cast<uint4*>(j.frag + (blk * 64 + ((k % 32) / 8) * 16 + (rr % 16)) * 8) = o;
+  }
+}
+
 }  // namespace
 
 extern "C" int csship_pack_weight(const float* w, int32_t R, int32_t K, int64_t ld_w, float scale,
@@ -273,6 +309,16 @@ extern "C" int csship_pack_weight(const float* w, int32_t R, int32_t K, int64_t 
   const int64_t n = (int64_t)((R + 15) / 16 * 16) * (Kp / 8);
   hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), w, R, K, ld_w,
                      scale, row_major_bf16, ld_row_major, frag_packed_bf16, dst_row0, Kp);
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
+extern "C" int csship_pack_weights_multi(const csship_pack_job* jobs_device, int32_t n_jobs, int64_t max_chunks,
+                                         csship_stream_t stream) {
+  if (!jobs_device) return CSSHIP_ENULL;
+  if (n_jobs <= 0 || n_jobs > 65535 || max_chunks <= 0) return CSSHIP_EBADSHAPE;
+  hipLaunchKernelGGL(pack_multi_kernel, dim3((unsigned)((max_chunks + 255) / 256), (unsigned)n_jobs), dim3(256), 0,
+                     as_stream(stream), jobs_device);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }

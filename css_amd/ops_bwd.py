@@ -206,6 +206,56 @@ def pack_weight(w, *, scale=1.0, row_major=None, frag=None, row0=0, want_row_maj
     return row_major, frag
 
 
+class PackPlan:
+    """All bf16 weight shadows of a model in ONE launch per step (csship_pack_weights_multi).
+
+    ``add`` registers a job and returns its destination tensors (allocated once, rewritten by every ``run``); the job
+    table is uploaded to the device the first time and again only if a source pointer moved."""
+
+    def __init__(self, device):
+        self.device = device
+        self.jobs = []      # (w, row_major, frag, scale, transposed, row0)
+        self.table = None
+        self.ptrs = None
+        self.max_chunks = 0
+
+    def add(self, w, *, scale=1.0, transposed=False, row_major=None, frag=None, row0=0, want_row_major=False,
+            want_frag=False):
+        """w: f32 [R, K] (transposed=False) or the [K, R] storage of the logical [R, K] weight (transposed=True)."""
+        _need(w, torch.float32, "w")
+        if w.dim() != 2 or w.stride(1) != 1:
+            raise RuntimeError("css_amd: PackPlan needs 2-d weights with contiguous rows")
+        R, K = (w.shape[1], w.shape[0]) if transposed else w.shape
+        if want_row_major and row_major is None:
+            row_major = torch.empty((R, (K + 7) // 8 * 8), dtype=torch.bfloat16, device=w.device)
+        if want_frag and frag is None:
+            frag = torch.empty(((R + 15) // 16 * 16) * ((K + 31) // 32 * 32), dtype=torch.bfloat16, device=w.device)
+        self.jobs.append((w, row_major, frag, float(scale), bool(transposed), int(row0)))
+        self.table = None
+        return row_major, frag
+
+    def _build(self):
+        arr = (_lib.PackJob * len(self.jobs))()
+        self.max_chunks = 0
+        for j, (w, rm, fr, scale, tr, row0) in zip(arr, self.jobs):
+            R, K = (w.shape[1], w.shape[0]) if tr else w.shape
+            Kp = (K + 31) // 32 * 32 if fr is not None else (K + 7) // 8 * 8
+            j.w, j.row_major, j.frag = w.data_ptr(), (rm.data_ptr() if rm is not None else None), (fr.data_ptr() if fr is not None else None)
+            j.ld_w, j.ld_row_major = w.stride(0), (rm.stride(0) if rm is not None else 0)
+            j.R, j.K, j.dst_row0, j.Kp, j.scale, j.transposed = R, K, row0, Kp, scale, int(tr)
+            self.max_chunks = max(self.max_chunks, ((R + 15) // 16 * 16) * (Kp // 8))
+        raw = bytes(arr)
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        self.ptrs = [w.data_ptr() for w, *_ in self.jobs]
+
+    def run(self):
+        if self.table is None or self.ptrs != [w.data_ptr() for w, *_ in self.jobs]:
+            if torch.cuda.is_current_stream_capturing() and self.table is not None:
+                raise RuntimeError("css_amd: a parameter moved while a HIP graph is being captured")
+            self._build()
+        check(lib().csship_pack_weights_multi(_ptr(self.table), len(self.jobs), self.max_chunks, _stream()))
+
+
 def lstm_bidir_train(gx, whh_packed, B, T, H):
     """BLSTM recurrence that also returns what the backward needs: (y [B,T,2H], gates [B,T,2,4H], c [B,T,2,H])."""
     _need(gx, torch.float32, "gx")

@@ -445,6 +445,23 @@ int csship_pack_weight(const float* w, int32_t R, int32_t K, int64_t ld_w, float
                        uint16_t* row_major_bf16, int64_t ld_row_major, uint16_t* frag_packed_bf16,
                        int32_t dst_row0, csship_stream_t stream);
 
+/* The same for a table of weights in one launch.  jobs_device: n_jobs records IN DEVICE MEMORY (the table is built
+ * once per model: parameter storage does not move between steps).  Per job: w f32, logical [R, K] with
+ * W[r][k] = w[r * ld_w + k] (transposed = 0) or w[k * ld_w + r] (transposed = 1); Kp = K rounded up to 32 when frag
+ * is given, else to 8; the other fields as in csship_pack_weight.  max_chunks = max over jobs of
+ * roundup(R, 16) * Kp / 8. */
+typedef struct csship_pack_job {
+  const float* w;
+  uint16_t* row_major;
+  uint16_t* frag;
+  int64_t ld_w, ld_row_major;
+  int32_t R, K, dst_row0, Kp;
+  float scale;
+  int32_t transposed;
+} csship_pack_job;
+int csship_pack_weights_multi(const csship_pack_job* jobs_device, int32_t n_jobs, int64_t max_chunks,
+                              csship_stream_t stream);
+
 /* ---- BLSTM recurrence, training (css_amd/csrc/lstm.hip).  csship_lstm_bidir_train = csship_lstm_bidir that also keeps
  * the activated gates (i, f, g, o; f32 [B, T, 2, 4H]) and the cell states (f32 [B, T, 2, H]).
  * csship_lstm_bidir_bwd: back-propagation through time.  dy: f32 [B, T, 2H]; whhT_packed: both directions'
