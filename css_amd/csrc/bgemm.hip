@@ -303,33 +303,40 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
 }
 
 // out[r, c] = alpha * sum_s slab[s][r, c] (+ bias[c]) (+ add[r, c]); fixed summation order.
-// Workgroup = 64 consecutive elements x 4 waves; wave w adds slabs w, w+4, ... with four loads in flight, then one
-// LDS reduction - short outputs with many slabs (LayerNorm / bias partials) no longer serialise on one thread.
+// Workgroup = 64 lanes x V consecutive elements x 4 waves; wave w adds slabs w, w+4, ... with four loads in flight,
+// then one LDS reduction - short outputs with many slabs (LayerNorm / bias partials) do not serialise on one thread,
+// long ones (V = 4: N and the slab size are multiples of 4) move 16 bytes per load instruction.
+template <int V>
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int S, int64_t n, int N,
                                                           int64_t ldc, float alpha, const float* __restrict__ bias,
                                                           const float* add, int64_t ldadd, float* out) {
-  __shared__ float red[4][64];
+  typedef float vec __attribute__((ext_vector_type(V)));
+  __shared__ vec red[4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const int64_t i = ((int64_t)blockIdx.x * 64 + lane) * V;
+  vec s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (i < n) {
     int k = w;
     for (; k + 12 < S; k += 16) {
-      s0 += slabs[(int64_t)k * n + i];
-      s1 += slabs[(int64_t)(k + 4) * n + i];
-      s2 += slabs[(int64_t)(k + 8) * n + i];
-      s3 += slabs[(int64_t)(k + 12) * n + i];
+      s0 += *reinterpret_cast<const vec*>(slabs + (int64_t)k * n + i);
+      s1 += *reinterpret_cast<const vec*>(slabs + (int64_t)(k + 4) * n + i);
+      s2 += *reinterpret_cast<const vec*>(slabs + (int64_t)(k + 8) * n + i);
+      s3 += *reinterpret_cast<const vec*>(slabs + (int64_t)(k + 12) * n + i);
     }
-    for (; k < S; k += 4) s0 += slabs[(int64_t)k * n + i];
+    for (; k < S; k += 4) s0 += *reinterpret_cast<const vec*>(slabs + (int64_t)k * n + i);
   }
   red[w][lane] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (w != 0 || i >= n) return;
   const int64_t r = i / N, c = i % N;
-  float v = alpha * ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
-  if (bias) v += bias[c];
-  if (add) v += add[r * ldadd + c];
-  out[r * ldc + c] = v;
+  const vec t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+#pragma unroll
+  for (int e = 0; e < V; ++e) {  // V = 4: the four elements share a row (N % 4 == 0)
+    float v = alpha * t[e];
+    if (bias) v += bias[c + e];
+    if (add) v += add[r * ldadd + c + e];
+    out[r * ldc + c + e] = v;
+  }
 }
 
 // ---- column sums of a [M, N] f32 / bf16 matrix (bias gradients): stage 1 = per-slice partials, stage 2 = slab_reduce
@@ -382,8 +389,12 @@ int pick_splits(const csship_bgemm_params* p) {
 
 int launch_slab_reduce(const float* slabs, int S, int64_t n, int N, int64_t ldc, float alpha, const float* bias,
                        const float* add, int64_t ldadd, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, slabs, S, n, N, ldc, alpha,
-                     bias, add, ldadd, out);
+  if ((N & 3) == 0 && (n & 3) == 0 && n >= 4096 && aligned16(slabs))
+    hipLaunchKernelGGL(slab_reduce_kernel<4>, dim3((unsigned)((n / 4 + 63) / 64)), dim3(256), 0, s, slabs, S, n, N, ldc,
+                       alpha, bias, add, ldadd, out);
+  else
+    hipLaunchKernelGGL(slab_reduce_kernel<1>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, slabs, S, n, N, ldc, alpha,
+                       bias, add, ldadd, out);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }
