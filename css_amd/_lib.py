@@ -75,6 +75,9 @@ SIGNATURES = {
     "csship_layernorm": (_i32, [_p, _i64, _i32, _p, _p, _p, _p, _p]),
     "csship_layernorm_relu": (_i32, [_p, _i64, _i32, _p, _p, _i32, _p, _p, _p]),
     "csship_lstm_bidir": (_i32, [_p, _p, _p, _i32, _i32, _i32, _p]),
+    "csship_lstm_dist_workspace": (_sz, [_i32, _i32]),
+    "csship_lstm_dist_workspace_error_offset": (_sz, [_i32, _i32]),
+    "csship_lstm_bidir_dist": (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _sz, _p]),
     "csship_gemm": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(GemmParams), _p]),
     "csship_ffn_fused": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _p]),
     "csship_panel_linear": (_i32, [_p, _i32, _p, _p, _p, _p, _p, _i64, _f32, _p, _i64, _i32, _i32, _i32, _i32, _p]),

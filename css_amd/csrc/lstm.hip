@@ -97,6 +97,132 @@ __global__ __launch_bounds__(512) void lstm_kernel(LstmArgs a) {
   }
 }
 
+// ---- the same recurrence spread over H/32 CUs per (16 batch rows, direction).
+// The kernel above is bound by one CU pulling all of W_hh (2 MB at H = 512) through its L1 every step (13 us per step,
+// 8.9 ms per layer at T = 400, 4 workgroups busy).  Here a workgroup of two waves owns 32 hidden units: each wave keeps
+// the W_hh rows of its 16 units (4 gates x H: 64 KB at H = 512) IN REGISTERS for the whole sequence, so a step is 4*H/32
+// MFMAs on register operands.  What a step needs from the other workgroups is h_{t-1} (16 rows x H bf16 = 16 KB):
+//   publish: every lane stores its 4 units of h_t write-through (sc1) into a double-buffered global panel, the waves
+//            drain their stores (vmcnt 0), barrier, one lane stores the workgroup's epoch flag (agent-scope atomic);
+//   consume: each wave polls the H/32 flags of its group (relaxed, bounded), then loads its MFMA B fragments of the
+//            panel with sc1 loads - every load of a handed-off byte is an sc1 load, so no acquire fence is needed.
+// Nothing depends on dispatch order or placement; all workgroups of a group must be resident together (64 workgroups of
+// 128 threads at B = 32, H = 512), and every spin is bounded: on a timeout the error word is set and the kernel exits.
+constexpr int FLAG_STRIDE = 16;            // 32-bit words between flags (one 64-byte line each)
+constexpr unsigned SPIN_LIMIT = 1u << 21;  // ~1 s
+
+struct LstmDistArgs {
+  const float* gx;      // [B, T, 2, 4H]
+  const bf16x8* whh;    // packed per direction: [2][4H/16][H/32][64]
+  float* out;           // [B, T, 2H]
+  float* gates_out;     // optional (training)
+  float* c_out;         // optional (training)
+  unsigned char* hx;    // [2 parity][2 dir][tiles][16][H] bf16
+  unsigned* flags;      // [2 dir][tiles][H/32] * FLAG_STRIDE, zero at launch
+  unsigned* err;        // zero at launch; 1 = a spin timed out
+  int B, T;
+};
+
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+
+template <int KSH>  // H = 32 * KSH
+__global__ __launch_bounds__(128) void lstm_dist_kernel(LstmDistArgs a) {
+  constexpr int H = 32 * KSH, NCU = H / 32;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, n = lane & 15;
+  const int cu = blockIdx.x, tile = blockIdx.y, dir = blockIdx.z, tiles = gridDim.y;
+  const int ut = cu * 2 + w, unit0 = 16 * ut;
+  const int b0 = tile * 16;
+  const int brow = min(b0 + n, a.B - 1);
+  const bool bvalid = b0 + n < a.B;
+
+  // this wave's rows of W_hh: gate q, k-step ks -> packed tile (q*(H/16) + ut, ks); resident for all T steps
+  bf16x8 wf[4][KSH];
+  {
+    const bf16x8* wbase = a.whh + (size_t)dir * (4 * H / 16) * KSH * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int ks = 0; ks < KSH; ++ks) wf[q][ks] = wbase[((size_t)(q * (H / 16) + ut) * KSH + ks) * 64];
+  }
+  float c[4] = {0.f, 0.f, 0.f, 0.f};
+  const unsigned group = (unsigned)(dir * tiles + tile) * 16u * H * 2u;  // byte offset of the group's panel
+  const unsigned parity_bytes = 2u * (unsigned)tiles * 16u * H * 2u;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.hx, 0, (int)(2u * parity_bytes), 0x00020000);
+  unsigned* fl = a.flags + (size_t)(dir * tiles + tile) * NCU * FLAG_STRIDE;
+
+  for (int step = 0; step < a.T; ++step) {
+    const int t = dir == 0 ? step : a.T - 1 - step;
+    const float* gxr = a.gx + (((size_t)brow * a.T + t) * 2 + dir) * 4 * H;
+    f32x4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(gxr + q * H + unit0 + 4 * g);
+      acc[q] = f32x4{v.x, v.y, v.z, v.w};
+    }
+    if (step > 0) {
+      // ---- wait for h_{t-1} of every workgroup of the group (epoch = step), bounded
+      bool ok = false;
+      for (unsigned spins = 0; spins < SPIN_LIMIT; ++spins) {
+        unsigned v = (unsigned)step;
+        if (lane < NCU) v = __hip_atomic_load(fl + lane * FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all(v >= (unsigned)step)) {
+          ok = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (!ok) {
+        if (lane == 0) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler ordering only: the loads below are sc1
+      const unsigned pbase = (unsigned)(step & 1) * parity_bytes + group + (unsigned)n * H * 2u + (unsigned)g * 16u;
+      bf16x8 hb[KSH];
+#pragma unroll
+      for (int ks = 0; ks < KSH; ++ks)
+        hb[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, pbase + (unsigned)ks * 64u, 0, 16));
+#pragma unroll
+      for (int ks = 0; ks < KSH; ++ks)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[q][ks], hb[ks], acc[q], 0, 0, 0);
+    }
+    float hv[4];
+    const int un = unit0 + 4 * g;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float ig = sigmoidf_fast(acc[0][r]), fg = sigmoidf_fast(acc[1][r]);
+      const float gg = tanhf_fast(acc[2][r]), og = sigmoidf_fast(acc[3][r]);
+      c[r] = fg * c[r] + ig * gg;
+      hv[r] = og * tanhf_fast(c[r]);
+      acc[0][r] = ig; acc[1][r] = fg; acc[2][r] = gg; acc[3][r] = og;
+    }
+    // ---- publish h_t (bf16) for the next step, then the results
+    if (step + 1 < a.T) {
+      const v2u_t hp = {pack_bf2(hv[0], hv[1]), pack_bf2(hv[2], hv[3])};
+      const unsigned off = (unsigned)((step + 1) & 1) * parity_bytes + group + (unsigned)n * H * 2u + (unsigned)un * 2u;
+      __builtin_amdgcn_raw_buffer_store_b64(hp, rs, off, 0, 16);  // sc1: write-through
+    }
+    const size_t srow = ((size_t)brow * a.T + t) * 2 + dir;
+    if (bvalid) {
+      *reinterpret_cast<float4*>(a.out + ((size_t)brow * a.T + t) * 2 * H + dir * H + un) =
+          make_float4(hv[0], hv[1], hv[2], hv[3]);
+      if (a.gates_out) {  // saved for the backward pass
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(a.gates_out + srow * 4 * H + q * H + un) =
+              make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
+        *reinterpret_cast<float4*>(a.c_out + srow * H + un) = make_float4(c[0], c[1], c[2], c[3]);
+      }
+    }
+    if (step + 1 < a.T) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: h_t is in memory
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(fl + cu * FLAG_STRIDE, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // ---- backward of the recurrence (BPTT).  Mirrors the forward: workgroup = (16 batch rows, direction), wave w owns
 // H/NW hidden units; per step (walking time against the forward order)
 //   dh^T[unit][batch] = dy_t + W_hh^T[unit rows][4H] . dgates_{next}^T      (MFMA, W_hh^T streamed, dgates panel in LDS)
@@ -221,6 +347,48 @@ extern "C" int csship_lstm_bidir_bwd(const float* gates, const float* c, const f
     default: return CSSHIP_EUNSUPPORTED;
   }
 #undef LSTM_BWD_CASE
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
+extern "C" size_t csship_lstm_dist_workspace(int32_t B, int32_t H) {
+  if (B <= 0 || (H != 256 && H != 512)) return 0;
+  const size_t tiles = (size_t)(B + 15) / 16, ncu = (size_t)H / 32;
+  const size_t sync_bytes = (2 * tiles * ncu * FLAG_STRIDE + 16) * sizeof(unsigned);  // flags + error word, 64-byte multiple
+  return sync_bytes + 2 * 2 * tiles * 16 * (size_t)H * 2;
+}
+
+extern "C" size_t csship_lstm_dist_workspace_error_offset(int32_t B, int32_t H) {
+  if (B <= 0 || (H != 256 && H != 512)) return 0;
+  return 2 * ((size_t)(B + 15) / 16) * ((size_t)H / 32) * FLAG_STRIDE * sizeof(unsigned);
+}
+
+extern "C" int csship_lstm_bidir_dist(const float* gx, const uint16_t* whh_packed, float* out, float* gates_out,
+                                      float* c_out, int32_t B, int32_t T, int32_t H, void* workspace,
+                                      size_t workspace_bytes, csship_stream_t stream) {
+  if (!gx || !whh_packed || !out || !workspace) return CSSHIP_ENULL;
+  if ((gates_out == nullptr) != (c_out == nullptr)) return CSSHIP_ENULL;
+  if (B <= 0 || T <= 0) return CSSHIP_EBADSHAPE;
+  if (H != 256 && H != 512) return CSSHIP_EUNSUPPORTED;
+  if (!aligned16(gx) || !aligned16(whh_packed) || !aligned16(out) || !aligned16(workspace) ||
+      (gates_out && (!aligned16(gates_out) || !aligned16(c_out))))
+    return CSSHIP_EALIGN;
+  const size_t need = csship_lstm_dist_workspace(B, H);
+  if (workspace_bytes < need) return CSSHIP_EWORKSPACE;
+  const int tiles = (B + 15) / 16, ncu = H / 32;
+  if (tiles > 65535 || 2 * (size_t)tiles * ncu > 2048) return CSSHIP_EBADSHAPE;  // all workgroups must be resident together
+  const size_t sync_bytes = (2 * (size_t)tiles * ncu * FLAG_STRIDE + 16) * sizeof(unsigned);
+  hipStream_t s = as_stream(stream);
+  if (hipMemsetAsync(workspace, 0, sync_bytes, s) != hipSuccess) return CSSHIP_ELAUNCH;  // flags + error word, every call
+  LstmDistArgs a{};
+  a.gx = gx; a.whh = reinterpret_cast<const bf16x8*>(whh_packed); a.out = out; a.gates_out = gates_out; a.c_out = c_out;
+  a.flags = reinterpret_cast<unsigned*>(workspace);
+  a.err = a.flags + 2 * (size_t)tiles * ncu * FLAG_STRIDE;
+  a.hx = reinterpret_cast<unsigned char*>(workspace) + sync_bytes;
+  a.B = B; a.T = T;
+  dim3 grid(ncu, tiles, 2);
+  if (H == 512) hipLaunchKernelGGL(lstm_dist_kernel<16>, grid, dim3(128), 0, s, a);
+  else hipLaunchKernelGGL(lstm_dist_kernel<8>, grid, dim3(128), 0, s, a);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }

@@ -141,8 +141,7 @@ class BLSTM(nn.Module):
                                           ops._ptr(enc.embed[1].bias.detach()), 1, None, ops._ptr(x), ops._stream()))
         for lay, lp in zip(enc.encoders, P["layers"]):
             gx = ops.gemm(x, lp["w_ih"], lp["b"], K=h)  # [M, 8H] = (dir, 4H): x W_ih^T + b_ih + b_hh
-            y = torch.empty(B, T, 2 * H, device=f.device, dtype=torch.float32)
-            check(lib().csship_lstm_bidir(ops._ptr(gx), ops._ptr(lp["whh"]), ops._ptr(y), B, T, H, ops._stream()))
+            y = ops.lstm_bidir(gx, lp["whh"], B, T, H)
             x = torch.empty(M, h, device=f.device, dtype=torch.float32)
             check(lib().csship_layernorm_relu(ops._ptr(y), M, h, ops._ptr(lay.layer_norm.weight.detach()),
                                               ops._ptr(lay.layer_norm.bias.detach()), 0, None, ops._ptr(x), ops._stream()))

@@ -5,6 +5,7 @@ kernel), allocates outputs with torch's caching allocator, and enqueues the kern
 current torch HIP stream.  CPU tensors are refused: there is no CPU implementation.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -249,6 +250,46 @@ def _targets_array(targets, B, T, F):
         keep.append(t)
         arr[i] = t.data_ptr()
     return arr, keep
+
+
+_LSTM_WS = {}  # (device index, stream, B, H) -> workspace of the distributed recurrence
+
+
+def lstm_dist_enabled(H):
+    return H in (256, 512) and os.environ.get("CSS_AMD_LSTM_DIST", "1") != "0"
+
+
+def lstm_bidir(gx, whh_packed, B, T, H, keep=False):
+    """BLSTM recurrence (both directions).  gx f32 [B*T, 8H] -> y f32 [B, T, 2H]; with keep=True also the activated
+    gates [B,T,2,4H] and cell states [B,T,2,H] for the backward pass.  H = 256 / 512 run the distributed kernel (W_hh
+    resident in registers across H/32 CUs per batch tile and direction), other sizes the single-CU kernel."""
+    _need(gx, torch.float32, "gx")
+    dev = gx.device
+    y = torch.empty((B, T, 2 * H), dtype=torch.float32, device=dev)
+    gates = torch.empty((B, T, 2, 4 * H), dtype=torch.float32, device=dev) if keep else None
+    c = torch.empty((B, T, 2, H), dtype=torch.float32, device=dev) if keep else None
+    if lstm_dist_enabled(H):
+        key = (dev.index, _stream() or 0, B, H)
+        ws = _LSTM_WS.get(key)
+        if ws is None:
+            ws = _LSTM_WS[key] = torch.empty(lib().csship_lstm_dist_workspace(B, H), dtype=torch.uint8, device=dev)
+        check(lib().csship_lstm_bidir_dist(_ptr(gx), _ptr(whh_packed), _ptr(y), _ptr(gates), _ptr(c), B, T, H, _ptr(ws),
+                                          ws.numel(), _stream()))
+    elif keep:
+        check(lib().csship_lstm_bidir_train(_ptr(gx), _ptr(whh_packed), _ptr(y), _ptr(gates), _ptr(c), B, T, H, _stream()))
+    else:
+        check(lib().csship_lstm_bidir(_ptr(gx), _ptr(whh_packed), _ptr(y), B, T, H, _stream()))
+    return (y, gates, c) if keep else y
+
+
+def lstm_dist_check():
+    """Synchronise and raise if any distributed-recurrence launch since the last check timed out on a hand-off."""
+    torch.cuda.synchronize()
+    for (idx, _, B, H), ws in _LSTM_WS.items():
+        off = lib().csship_lstm_dist_workspace_error_offset(B, H)
+        if int(ws[off:off + 4].view(torch.int32).item()) != 0:
+            raise RuntimeError("css_amd: BLSTM distributed recurrence timed out waiting for a workgroup "
+                               "(are other processes using this GPU?); set CSS_AMD_LSTM_DIST=0")
 
 
 def pit_mse(masks, f_orig, targets, want_y_pred=False, want_pairs=False):

@@ -258,13 +258,8 @@ class PackPlan:
 
 def lstm_bidir_train(gx, whh_packed, B, T, H):
     """BLSTM recurrence that also returns what the backward needs: (y [B,T,2H], gates [B,T,2,4H], c [B,T,2,H])."""
-    _need(gx, torch.float32, "gx")
-    dev = gx.device
-    y = torch.empty((B, T, 2 * H), dtype=torch.float32, device=dev)
-    gates = torch.empty((B, T, 2, 4 * H), dtype=torch.float32, device=dev)
-    c = torch.empty((B, T, 2, H), dtype=torch.float32, device=dev)
-    check(lib().csship_lstm_bidir_train(_ptr(gx), _ptr(whh_packed), _ptr(y), _ptr(gates), _ptr(c), B, T, H, _stream()))
-    return y, gates, c
+    from . import ops
+    return ops.lstm_bidir(gx, whh_packed, B, T, H, keep=True)
 
 
 def lstm_bidir_bwd(gates, c, dy, whhT_packed):

@@ -105,6 +105,20 @@ int csship_layernorm_relu(const float* x, int64_t M, int32_t D, const float* gam
 int csship_lstm_bidir(const float* gx, const uint16_t* whh_packed, float* out, int32_t B, int32_t T,
                       int32_t H, csship_stream_t stream);
 
+/* The same recurrence spread over H/32 CUs per (16 batch rows, direction): every wave keeps the W_hh rows of its 16
+ * hidden units in registers for the whole sequence and the workgroups exchange h_t once per step through a
+ * write-through global panel + epoch flags (agent-scope hand-off, bounded spins).  H = 256 or 512; identical results.
+ * gates_out / c_out: both NULL, or both given (training: activated gates f32 [B, T, 2, 4H], cell states f32
+ * [B, T, 2, H]).  workspace: csship_lstm_dist_workspace(B, H) bytes (0 = unsupported shape), 16-byte aligned; its
+ * head is zeroed by the call.  After the stream has drained, the 32-bit word at workspace +
+ * csship_lstm_dist_workspace_error_offset(B, H) is 0, or 1 if a wait timed out (the workgroups of a group were not
+ * resident together): the outputs are then invalid. */
+size_t csship_lstm_dist_workspace(int32_t B, int32_t H);
+size_t csship_lstm_dist_workspace_error_offset(int32_t B, int32_t H);
+int csship_lstm_bidir_dist(const float* gx, const uint16_t* whh_packed, float* out, float* gates_out, float* c_out,
+                           int32_t B, int32_t T, int32_t H, void* workspace, size_t workspace_bytes,
+                           csship_stream_t stream);
+
 /* C[M,N] = epilogue( A[M,K] @ W[N,K]^T + bias ).  bf16 MFMA, fp32 accumulate.
  * Replaces every torch.nn.Linear on the path (css/models/conformer.py:98,124,205-209,
  * 315-318).  W is bf16 [N, ldw] with ldw a multiple of 64 and >= K, zero padded. */

@@ -183,6 +183,30 @@ def test_blstm_golden(golden):
     assert mse < 1e-4 and mask_mse(y_pred, torch.from_numpy(g["y_pred"])) < 1e-4
 
 
+@pytest.mark.parametrize("H,B,T", [(256, 1, 7), (256, 20, 33), (512, 16, 50), (512, 32, 400), (512, 35, 21)])
+def test_lstm_distributed_recurrence_equals_single_cu_kernel(H, B, T):
+    """csship_lstm_bidir_dist (W_hh in registers across H/32 CUs, h exchanged per step through write-through global
+    panels + epoch flags) vs csship_lstm_bidir_train (one CU streams W_hh): same arithmetic order, so bitwise equal
+    outputs, gates and cell states; no hand-off timeout; repeated calls reuse the workspace."""
+    from css_amd import ops
+    from css_amd._lib import check, lib
+    g = torch.Generator().manual_seed(H + B + T)
+    gx = (torch.randn((B * T, 8 * H), generator=g) * 0.5).to(DEV)
+    whh = torch.cat([ops.pack_frag((torch.randn((4 * H, H), generator=g) / H ** 0.5).to(DEV)) for _ in range(2)]).contiguous()
+    y0 = torch.empty((B, T, 2 * H), device=DEV)
+    g0 = torch.empty((B, T, 2, 4 * H), device=DEV)
+    c0 = torch.empty((B, T, 2, H), device=DEV)
+    check(lib().csship_lstm_bidir_train(gx.data_ptr(), whh.data_ptr(), y0.data_ptr(), g0.data_ptr(), c0.data_ptr(), B, T, H, None))
+    assert ops.lstm_dist_enabled(H)
+    for it in range(3):
+        y1, g1, c1 = ops.lstm_bidir(gx, whh, B, T, H, keep=True)
+        ops.lstm_dist_check()
+        assert torch.equal(y1, y0) and torch.equal(g1, g0) and torch.equal(c1, c0), it
+    y2 = ops.lstm_bidir(gx, whh, B, T, H)
+    ops.lstm_dist_check()
+    assert torch.equal(y2, y0)
+
+
 def test_blstm_default_width_vs_oracle():
     """CLI-default width (hdim 1024 -> H = 512 per direction: streamed W_hh, 4 unit tiles per wave), 1 layer."""
     from css_amd.models import MODELS
