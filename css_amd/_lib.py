@@ -118,6 +118,7 @@ SIGNATURES = {
     "csship_pack_weights_multi": (_i32, [_p, _i32, _i64, _p]),
     "csship_lstm_bidir_train": (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p]),
     "csship_lstm_bidir_bwd": (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p]),
+    "csship_lstm_bidir_bwd_dist": (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _sz, _p]),
     "csship_adam_clip_workspace": (_sz, [_i64]),
     "csship_adam_clip": (_i32, [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _f32, _p, _p, _p, _sz, _p]),
     "csship_mvdr_scm": (_i32, [_p, _p, _p, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _p, _p, _p]),

@@ -351,11 +351,135 @@ extern "C" int csship_lstm_bidir_bwd(const float* gates, const float* c, const f
   return CSSHIP_OK;
 }
 
+namespace {
+
+// ---- BPTT spread the same way: a wave keeps the W_hh^T rows of its 16 units (16 x 4H bf16 = 64 KB at H = 512) in
+// registers; per step the group exchanges the pre-activation gate gradients of the previous step (16 rows x 4H bf16 =
+// 64 KB), fetched as MFMA B fragments 16 k-steps at a time, the next 16 in flight under the current MFMAs.
+struct LstmBwdDistArgs {
+  const float* gates;   // [B, T, 2, 4H] activated
+  const float* c;       // [B, T, 2, H]
+  const float* dy;      // [B, T, 2H]
+  const bf16x8* whhT;   // packed per direction from W_hh^T [H, 4H]: [2][H/16][4H/32][64]
+  float* dgates;        // [B, T, 2, 4H]
+  unsigned char* dx;    // exchange panels [2 parity][2 dir][tiles][16][4H] bf16
+  unsigned* flags;
+  unsigned* err;
+  int B, T;
+};
+
+template <int KSH>  // H = 32 * KSH
+__global__ __launch_bounds__(128) void lstm_bwd_dist_kernel(LstmBwdDistArgs a) {
+  constexpr int H = 32 * KSH, NCU = H / 32, KS4 = 4 * KSH, CH = 16;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, n = lane & 15;
+  const int cu = blockIdx.x, tile = blockIdx.y, dir = blockIdx.z, tiles = gridDim.y;
+  const int ut = cu * 2 + w, un = 16 * ut + 4 * g;
+  const int b0 = tile * 16;
+  const int brow = min(b0 + n, a.B - 1);
+  const bool bvalid = b0 + n < a.B;
+
+  bf16x8 wf[KS4];
+  {
+    const bf16x8* wbase = a.whhT + (size_t)dir * (H / 16) * KS4 * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < KS4; ++ks) wf[ks] = wbase[((size_t)ut * KS4 + ks) * 64];
+  }
+  float dc[4] = {0.f, 0.f, 0.f, 0.f};
+  const unsigned row_bytes = 4u * H * 2u;
+  const unsigned group = (unsigned)(dir * tiles + tile) * 16u * row_bytes;
+  const unsigned parity_bytes = 2u * (unsigned)tiles * 16u * row_bytes;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.dx, 0, (int)(2u * parity_bytes), 0x00020000);
+  unsigned* fl = a.flags + (size_t)(dir * tiles + tile) * NCU * FLAG_STRIDE;
+
+  for (int step = 0; step < a.T; ++step) {
+    const int t = dir == 0 ? a.T - 1 - step : step;            // against the forward order
+    const int tp = dir == 0 ? t - 1 : t + 1;                   // the forward pass's previous step
+    const bool has_prev = tp >= 0 && tp < a.T;
+    const size_t srow = ((size_t)brow * a.T + t) * 2 + dir;
+    const size_t prow = ((size_t)brow * a.T + (has_prev ? tp : t)) * 2 + dir;
+    const float4 dyv = *reinterpret_cast<const float4*>(a.dy + ((size_t)brow * a.T + t) * 2 * H + dir * H + un);
+    f32x4 acc = {dyv.x, dyv.y, dyv.z, dyv.w};
+    // this step's saved forward values (independent of the hand-off: requested before the wait)
+    float4 gq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gq[q] = *reinterpret_cast<const float4*>(a.gates + srow * 4 * H + q * H + un);
+    const float4 ct = *reinterpret_cast<const float4*>(a.c + srow * H + un);
+    float4 cp = *reinterpret_cast<const float4*>(a.c + prow * H + un);
+    if (!has_prev) cp = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (step > 0) {
+      bool ok = false;
+      for (unsigned spins = 0; spins < SPIN_LIMIT; ++spins) {
+        unsigned v = (unsigned)step;
+        if (lane < NCU) v = __hip_atomic_load(fl + lane * FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all(v >= (unsigned)step)) {
+          ok = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (!ok) {
+        if (lane == 0) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler ordering only: the loads below are sc1
+      const unsigned pbase = (unsigned)(step & 1) * parity_bytes + group + (unsigned)n * row_bytes + (unsigned)g * 16u;
+      bf16x8 db[2][CH];
+#pragma unroll
+      for (int i = 0; i < CH; ++i)
+        db[0][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, pbase + (unsigned)i * 64u, 0, 16));
+#pragma unroll
+      for (int ch = 0; ch < KS4 / CH; ++ch) {
+        if (ch + 1 < KS4 / CH) {
+#pragma unroll
+          for (int i = 0; i < CH; ++i)
+            db[(ch + 1) & 1][i] = __builtin_bit_cast(
+                bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, pbase + (unsigned)((ch + 1) * CH + i) * 64u, 0, 16));
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ch * CH + i], db[ch & 1][i], acc, 0, 0, 0);
+      }
+    }
+    const float iv[4] = {gq[0].x, gq[0].y, gq[0].z, gq[0].w}, fv[4] = {gq[1].x, gq[1].y, gq[1].z, gq[1].w};
+    const float gv[4] = {gq[2].x, gq[2].y, gq[2].z, gq[2].w}, ov[4] = {gq[3].x, gq[3].y, gq[3].z, gq[3].w};
+    const float cv[4] = {ct.x, ct.y, ct.z, ct.w}, pv[4] = {cp.x, cp.y, cp.z, cp.w};
+    float da[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float dh = acc[r];
+      const float tc = tanhf_fast(cv[r]);
+      const float dcc = dc[r] + dh * ov[r] * (1.f - tc * tc);
+      da[0][r] = dcc * gv[r] * iv[r] * (1.f - iv[r]);
+      da[1][r] = dcc * pv[r] * fv[r] * (1.f - fv[r]);
+      da[2][r] = dcc * iv[r] * (1.f - gv[r] * gv[r]);
+      da[3][r] = dh * tc * ov[r] * (1.f - ov[r]);
+      dc[r] = dcc * fv[r];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (step + 1 < a.T) {
+        const v2u_t dp = {pack_bf2(da[q][0], da[q][1]), pack_bf2(da[q][2], da[q][3])};
+        const unsigned off = (unsigned)((step + 1) & 1) * parity_bytes + group + (unsigned)n * row_bytes + (unsigned)(q * H + un) * 2u;
+        __builtin_amdgcn_raw_buffer_store_b64(dp, rs, off, 0, 16);  // sc1: write-through
+      }
+      if (bvalid)
+        *reinterpret_cast<float4*>(a.dgates + srow * 4 * H + q * H + un) = make_float4(da[q][0], da[q][1], da[q][2], da[q][3]);
+    }
+    if (step + 1 < a.T) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(fl + cu * FLAG_STRIDE, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+}  // namespace
+
 extern "C" size_t csship_lstm_dist_workspace(int32_t B, int32_t H) {
   if (B <= 0 || (H != 256 && H != 512)) return 0;
   const size_t tiles = (size_t)(B + 15) / 16, ncu = (size_t)H / 32;
   const size_t sync_bytes = (2 * tiles * ncu * FLAG_STRIDE + 16) * sizeof(unsigned);  // flags + error word, 64-byte multiple
-  return sync_bytes + 2 * 2 * tiles * 16 * (size_t)H * 2;
+  return sync_bytes + 2 * 2 * tiles * 16 * (size_t)(4 * H) * 2;  // sized for the backward's 4H-wide panels
 }
 
 extern "C" size_t csship_lstm_dist_workspace_error_offset(int32_t B, int32_t H) {
@@ -389,6 +513,34 @@ extern "C" int csship_lstm_bidir_dist(const float* gx, const uint16_t* whh_packe
   dim3 grid(ncu, tiles, 2);
   if (H == 512) hipLaunchKernelGGL(lstm_dist_kernel<16>, grid, dim3(128), 0, s, a);
   else hipLaunchKernelGGL(lstm_dist_kernel<8>, grid, dim3(128), 0, s, a);
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
+extern "C" int csship_lstm_bidir_bwd_dist(const float* gates, const float* c, const float* dy, const uint16_t* whhT_packed,
+                                          float* dgates, int32_t B, int32_t T, int32_t H, void* workspace,
+                                          size_t workspace_bytes, csship_stream_t stream) {
+  if (!gates || !c || !dy || !whhT_packed || !dgates || !workspace) return CSSHIP_ENULL;
+  if (B <= 0 || T <= 0) return CSSHIP_EBADSHAPE;
+  if (H != 256 && H != 512) return CSSHIP_EUNSUPPORTED;
+  if (!aligned16(gates) || !aligned16(c) || !aligned16(dy) || !aligned16(whhT_packed) || !aligned16(dgates) ||
+      !aligned16(workspace))
+    return CSSHIP_EALIGN;
+  if (workspace_bytes < csship_lstm_dist_workspace(B, H)) return CSSHIP_EWORKSPACE;
+  const int tiles = (B + 15) / 16, ncu = H / 32;
+  if (tiles > 65535 || 2 * (size_t)tiles * ncu > 2048) return CSSHIP_EBADSHAPE;
+  const size_t sync_bytes = (2 * (size_t)tiles * ncu * FLAG_STRIDE + 16) * sizeof(unsigned);
+  hipStream_t s = as_stream(stream);
+  if (hipMemsetAsync(workspace, 0, sync_bytes, s) != hipSuccess) return CSSHIP_ELAUNCH;
+  LstmBwdDistArgs a{};
+  a.gates = gates; a.c = c; a.dy = dy; a.whhT = reinterpret_cast<const bf16x8*>(whhT_packed); a.dgates = dgates;
+  a.flags = reinterpret_cast<unsigned*>(workspace);
+  a.err = a.flags + 2 * (size_t)tiles * ncu * FLAG_STRIDE;
+  a.dx = reinterpret_cast<unsigned char*>(workspace) + sync_bytes;
+  a.B = B; a.T = T;
+  dim3 grid(ncu, tiles, 2);
+  if (H == 512) hipLaunchKernelGGL(lstm_bwd_dist_kernel<16>, grid, dim3(128), 0, s, a);
+  else hipLaunchKernelGGL(lstm_bwd_dist_kernel<8>, grid, dim3(128), 0, s, a);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }

@@ -264,10 +264,20 @@ def lstm_bidir_train(gx, whh_packed, B, T, H):
 
 def lstm_bidir_bwd(gates, c, dy, whhT_packed):
     """Back-propagation through time: dy f32 [B,T,2H] -> dgates f32 [B,T,2,4H] (gradient wrt pre-activation gates)."""
+    from . import ops
     B, T, _, H4 = gates.shape
+    H = H4 // 4
     dy = dy.contiguous()
     dg = torch.empty_like(gates)
-    check(lib().csship_lstm_bidir_bwd(_ptr(gates), _ptr(c), _ptr(dy), _ptr(whhT_packed), _ptr(dg), B, T, H4 // 4, _stream()))
+    if ops.lstm_dist_enabled(H):
+        key = (gates.device.index, _stream() or 0, B, H)
+        ws = ops._LSTM_WS.get(key)
+        if ws is None:
+            ws = ops._LSTM_WS[key] = torch.empty(lib().csship_lstm_dist_workspace(B, H), dtype=torch.uint8, device=gates.device)
+        check(lib().csship_lstm_bidir_bwd_dist(_ptr(gates), _ptr(c), _ptr(dy), _ptr(whhT_packed), _ptr(dg), B, T, H,
+                                              _ptr(ws), ws.numel(), _stream()))
+    else:
+        check(lib().csship_lstm_bidir_bwd(_ptr(gates), _ptr(c), _ptr(dy), _ptr(whhT_packed), _ptr(dg), B, T, H, _stream()))
     return dg
 
 

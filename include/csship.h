@@ -486,6 +486,12 @@ int csship_lstm_bidir_train(const float* gx, const uint16_t* whh_packed, float* 
                             float* c_out, int32_t B, int32_t T, int32_t H, csship_stream_t stream);
 int csship_lstm_bidir_bwd(const float* gates, const float* c, const float* dy, const uint16_t* whhT_packed,
                           float* dgates, int32_t B, int32_t T, int32_t H, csship_stream_t stream);
+/* Back-propagation through time spread over H/32 CUs per (16 batch rows, direction) like csship_lstm_bidir_dist (W_hh^T
+ * rows in registers, the previous step's gate gradients exchanged per step); H = 256 or 512, identical results, same
+ * workspace contract. */
+int csship_lstm_bidir_bwd_dist(const float* gates, const float* c, const float* dy, const uint16_t* whhT_packed,
+                               float* dgates, int32_t B, int32_t T, int32_t H, void* workspace,
+                               size_t workspace_bytes, csship_stream_t stream);
 
 /* ---- csship_adam_clip (css_amd/csrc/optim.hip): clip_grad_norm_(max_norm) followed by one Adam step
  * (iteration_types.py:17-64) on FLAT f32 buffers of n elements (parameters, gradients, first and second moments), in

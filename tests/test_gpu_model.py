@@ -185,14 +185,17 @@ def test_blstm_golden(golden):
 
 @pytest.mark.parametrize("H,B,T", [(256, 1, 7), (256, 20, 33), (512, 16, 50), (512, 32, 400), (512, 35, 21)])
 def test_lstm_distributed_recurrence_equals_single_cu_kernel(H, B, T):
-    """csship_lstm_bidir_dist (W_hh in registers across H/32 CUs, h exchanged per step through write-through global
-    panels + epoch flags) vs csship_lstm_bidir_train (one CU streams W_hh): same arithmetic order, so bitwise equal
-    outputs, gates and cell states; no hand-off timeout; repeated calls reuse the workspace."""
+    """csship_lstm_bidir_dist / csship_lstm_bidir_bwd_dist (W_hh in registers across H/32 CUs, state exchanged per step
+    through write-through global panels + epoch flags) vs the single-CU kernels that stream W_hh: same arithmetic
+    order, so bitwise equal outputs, gates, cell states and gate gradients; no hand-off timeout; repeated calls reuse
+    the workspace."""
     from css_amd import ops
     from css_amd._lib import check, lib
     g = torch.Generator().manual_seed(H + B + T)
     gx = (torch.randn((B * T, 8 * H), generator=g) * 0.5).to(DEV)
-    whh = torch.cat([ops.pack_frag((torch.randn((4 * H, H), generator=g) / H ** 0.5).to(DEV)) for _ in range(2)]).contiguous()
+    w_raw = [(torch.randn((4 * H, H), generator=g) / H ** 0.5).to(DEV) for _ in range(2)]
+    whh = torch.cat([ops.pack_frag(w) for w in w_raw]).contiguous()
+    whhT = torch.cat([ops.pack_frag(w.t().contiguous()) for w in w_raw]).contiguous()
     y0 = torch.empty((B, T, 2 * H), device=DEV)
     g0 = torch.empty((B, T, 2, 4 * H), device=DEV)
     c0 = torch.empty((B, T, 2, H), device=DEV)
@@ -205,6 +208,15 @@ def test_lstm_distributed_recurrence_equals_single_cu_kernel(H, B, T):
     y2 = ops.lstm_bidir(gx, whh, B, T, H)
     ops.lstm_dist_check()
     assert torch.equal(y2, y0)
+    # back-propagation through time: distributed vs single-CU kernel on the saved gates / cell states
+    from css_amd import ops_bwd as ob
+    dy = (torch.randn((B, T, 2 * H), generator=g) * 0.1).to(DEV)
+    d0 = torch.empty_like(g0)
+    check(lib().csship_lstm_bidir_bwd(g0.data_ptr(), c0.data_ptr(), dy.data_ptr(), whhT.data_ptr(), d0.data_ptr(), B, T, H, None))
+    for it in range(2):
+        d1 = ob.lstm_bidir_bwd(g0, c0, dy, whhT)
+        ops.lstm_dist_check()
+        assert torch.equal(d1, d0), it
 
 
 def test_blstm_default_width_vs_oracle():
