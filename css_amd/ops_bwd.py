@@ -89,12 +89,15 @@ def bgemm(a, b, *, a_kmajor=False, b_kmajor=False, out=None, out_bf16=False, alp
     return out_ret
 
 
-def colsum(x, alpha=1.0):
+def colsum(x, alpha=1.0, out=None):
     """alpha * column sums of a [M, N] f32/bf16 matrix (row stride free) -> f32 [N]."""
     if x.dim() != 2 or x.stride(1) != 1 or not x.is_cuda:
         raise RuntimeError("css_amd: colsum expects a HIP [M, N] matrix with contiguous columns")
     M, N = x.shape
-    out = torch.empty(N, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=x.device)
+    elif out.dtype != torch.float32 or out.shape != (N,) or not out.is_contiguous():
+        raise RuntimeError("css_amd: colsum out must be a contiguous f32 [N] vector")
     nws = lib().csship_colsum_workspace(M, N)
     ws = _workspace(nws, x.device)
     check(lib().csship_colsum(_ptr(x), int(x.dtype == torch.float32), M, N, x.stride(0), float(alpha), _ptr(out),

@@ -35,7 +35,8 @@ class FusedAdam(torch.optim.Optimizer):
         self._step = 0
         # {lr, 1 - beta1^t, 1 - beta2^t} on the device: read by the kernel, so a captured step can be replayed
         self._hyper = torch.zeros(3, dtype=torch.float32, device=dev)
-        self._hyper_host = torch.zeros(3, dtype=torch.float32).pin_memory()
+        self._hyper_host = torch.zeros((16, 3), dtype=torch.float32).pin_memory()  # one staging slot per step in flight
+        self._hyper_events = [None] * 16
         self.capturable = False
         with torch.no_grad():
             for p, o in zip(params, offs):
@@ -73,10 +74,20 @@ class FusedAdam(torch.optim.Optimizer):
         current stream, ordered before the graph replay that follows)."""
         g = self.param_groups[0]
         self._step += 1
-        self._hyper_host[0] = float(g["lr"])
-        self._hyper_host[1] = 1.0 - float(g["betas"][0]) ** self._step
-        self._hyper_host[2] = 1.0 - float(g["betas"][1]) ** self._step
-        self._hyper.copy_(self._hyper_host, non_blocking=True)
+        # The copy is asynchronous and the host may be several steps ahead of the GPU: every step stages its values in
+        # its own pinned slot, reused only after the copy that read it has completed (a single staging buffer would be
+        # overwritten with a later step's values before an earlier copy ran).
+        slot = self._step % len(self._hyper_events)
+        if self._hyper_events[slot] is not None:
+            self._hyper_events[slot].synchronize()
+        stage = self._hyper_host[slot]
+        stage[0] = float(g["lr"])
+        stage[1] = 1.0 - float(g["betas"][0]) ** self._step
+        stage[2] = 1.0 - float(g["betas"][1]) ** self._step
+        self._hyper.copy_(stage, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._hyper_events[slot] = ev
 
     def state_dict(self):
         sd = super().state_dict()

@@ -415,6 +415,32 @@ def test_graphed_train_step_matches_eager():
     assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
 
 
+def test_training_does_not_depend_on_host_synchronisation():
+    """12 replayed steps with a different learning rate every step, queued without ever synchronising (the host runs
+    many steps ahead of the GPU), equal the same steps with a synchronise after each one, bit for bit: the per-step
+    hyper-parameters reach the device through per-step pinned staging slots."""
+    from css_amd.objectives import OBJECTIVES
+    from css_amd.optim import FusedAdam
+    from css_amd.trainer import GraphedTrainStep
+    obj = OBJECTIVES["MSE"].build_objective({})
+    batch = {"mix": rnd((16, 200, 257), 900).abs().to(DEV), "source1": (rnd((16, 200, 257), 901).abs() * 0.5).to(DEV),
+             "source2": (rnd((16, 200, 257), 902).abs() * 0.5).to(DEV)}
+    finals = []
+    for sync_each in (True, False):
+        m, _ = build(4, 48)
+        m.train()
+        opt = FusedAdam(m.parameters(), lr=1e-3, max_norm=5.0)
+        stepper = GraphedTrainStep(m, obj, opt, batch, max_norm=5.0)
+        for i in range(12):
+            opt.param_groups[0]["lr"] = 1e-3 * (1 + i % 5)
+            stepper(batch)
+            if sync_each:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        finals.append(opt.flat_param.clone())
+    assert torch.equal(finals[0], finals[1])
+
+
 def test_forward_bitwise_reproducible():
     """No atomics, fixed reduction orders, barriers where workgroups hand data to themselves: repeated forwards of
     the headline shape (and of a shape with partial tiles everywhere) are bit-identical."""

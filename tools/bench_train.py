@@ -61,8 +61,13 @@ if a.graph:
     step()
     torch.cuda.synchronize()
 t0 = time.perf_counter()
+trace = []
 for _ in range(a.steps):
     loss = step()
+    if os.environ.get("TRACE_LOSS"):
+        trace.append(float(loss))
+if trace:
+    print("losses", " ".join(f"{x:.9f}" for x in trace))
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
 print(f"train step ({'twin' if a.twin else 'hip'} backward, {a.blocks} blocks): {dt * 1e3:.1f} ms  "
