@@ -351,6 +351,29 @@ def test_pit_mse(ops, K):
     assert err(gm, m.grad) < 1e-9 + 1e-5 * float(m.grad.abs().max())
 
 
+@pytest.mark.parametrize("shape", [(1, 1, 5, 1), (3, 37, 257, 2), (7, 130, 64, 3), (2, 50, 771, 4), (5, 16, 3, 2),
+                                   (2, 33, 1030, 2)])
+def test_pit_mse_ragged_shapes(ops, shape):
+    """Row-wise 16-byte-load PIT kernel on shapes that exercise every path: F < 4 (tail lanes only), F % 4 = 0..3, F
+    beyond one 256-bin pass, frame counts that are not a multiple of the 16-row chunk, a single sample; y_pred rows
+    written by the unaligned 16-byte stores; padded mask rows."""
+    B, T, F, K = shape
+    ld = (K + 1) * F + 3
+    masks = torch.full((B, T, ld), float("nan"))
+    masks[..., :(K + 1) * F] = rnd((B, T, (K + 1) * F), 160).abs()
+    f = rnd((B, T, F), 161).abs()
+    tg = [rnd((B, T, F), 162 + k).abs() * 0.5 for k in range(K)]
+    md = masks.to(DEV)[..., :(K + 1) * F]
+    loss, perm, y_pred, pairs = ops.pit_mse(md, f.to(DEV), [t.to(DEV) for t in tg], True, True)
+    yp = torch.stack([masks[..., k * F:(k + 1) * F] * f for k in range(K)], 1)
+    assert torch.equal(y_pred.cpu(), yp)
+    ref_loss, ref_perm = oracle.pit.objective_multi(yp, torch.stack(tg, 1))
+    assert abs(float(loss) - float(ref_loss)) < 1e-6 * max(1.0, float(ref_loss))
+    assert [tuple(p) for p in perm.cpu().tolist()] == [tuple(p) for p in ref_perm]
+    for b in range(B):
+        assert err(pairs[b], oracle.pit.pairwise_sse(yp[b], torch.stack(tg, 1)[b])) < 1e-3 * float(pairs[b].max()) + 1e-6
+
+
 def test_pit_loss_api_golden(ops, golden):
     from css_amd.objectives import pit_loss
     g = golden("pit.npz")
