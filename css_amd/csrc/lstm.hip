@@ -128,7 +128,7 @@ typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
 
 template <int KSH>  // H = 32 * KSH
 __global__ __launch_bounds__(128) void lstm_dist_kernel(LstmDistArgs a) {
-  constexpr int H = 32 * KSH, NCU = H / 32;
+  constexpr int H = 32 * KSH;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, n = lane & 15;
   const int cu = blockIdx.x, tile = blockIdx.y, dir = blockIdx.z, tiles = gridDim.y;
   const int ut = cu * 2 + w, unit0 = 16 * ut;
@@ -146,27 +146,53 @@ __global__ __launch_bounds__(128) void lstm_dist_kernel(LstmDistArgs a) {
       for (int ks = 0; ks < KSH; ++ks) wf[q][ks] = wbase[((size_t)(q * (H / 16) + ut) * KSH + ks) * 64];
   }
   float c[4] = {0.f, 0.f, 0.f, 0.f};
-  const unsigned group = (unsigned)(dir * tiles + tile) * 16u * H * 2u;  // byte offset of the group's panel
-  const unsigned parity_bytes = 2u * (unsigned)tiles * 16u * H * 2u;
+  // The exchanged panel carries its own validity: every two bf16 values travel as an 8-byte granule {epoch, value}
+  // (epoch = step + 1, never 0; the panels are zeroed per launch), so the consumer polls the data itself - no flag,
+  // no store drain, no barrier: one fabric round trip per step instead of three.  Row stride 4*H bytes.
+  const unsigned row_bytes = 4u * H;
+  const unsigned group = (unsigned)(dir * tiles + tile) * 16u * row_bytes;
+  const unsigned parity_bytes = 2u * (unsigned)tiles * 16u * row_bytes;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.hx, 0, (int)(2u * parity_bytes), 0x00020000);
-  unsigned* fl = a.flags + (size_t)(dir * tiles + tile) * NCU * FLAG_STRIDE;
 
+  // the input projections of step s + 1 are requested during step s (they come from HBM: 2 us if asked for on demand)
+  float4 gxn[4];
+  {
+    const int t0 = dir == 0 ? 0 : a.T - 1;
+    const float* gxr = a.gx + (((size_t)brow * a.T + t0) * 2 + dir) * 4 * H + unit0 + 4 * g;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gxn[q] = *reinterpret_cast<const float4*>(gxr + q * H);
+  }
   for (int step = 0; step < a.T; ++step) {
     const int t = dir == 0 ? step : a.T - 1 - step;
-    const float* gxr = a.gx + (((size_t)brow * a.T + t) * 2 + dir) * 4 * H;
     f32x4 acc[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 v = *reinterpret_cast<const float4*>(gxr + q * H + unit0 + 4 * g);
-      acc[q] = f32x4{v.x, v.y, v.z, v.w};
+    for (int q = 0; q < 4; ++q) acc[q] = f32x4{gxn[q].x, gxn[q].y, gxn[q].z, gxn[q].w};
+    if (step + 1 < a.T) {
+      const int tn = dir == 0 ? step + 1 : a.T - 2 - step;
+      const float* gxr = a.gx + (((size_t)brow * a.T + tn) * 2 + dir) * 4 * H + unit0 + 4 * g;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gxn[q] = *reinterpret_cast<const float4*>(gxr + q * H);
     }
     if (step > 0) {
-      // ---- wait for h_{t-1} of every workgroup of the group (epoch = step), bounded
+      // ---- h_{t-1}: this lane's B fragments are 8 consecutive units of row n per k-step = 4 granules = 32 bytes;
+      // re-read (bounded) until every granule of the wave carries this step's epoch
+      const unsigned pbase = (unsigned)(step & 1) * parity_bytes + group + (unsigned)n * row_bytes + (unsigned)g * 32u;
+      bf16x8 hb[KSH];
       bool ok = false;
       for (unsigned spins = 0; spins < SPIN_LIMIT; ++spins) {
-        unsigned v = (unsigned)step;
-        if (lane < NCU) v = __hip_atomic_load(fl + lane * FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__all(v >= (unsigned)step)) {
+        bool mine = true;
+#pragma unroll
+        for (int ks = 0; ks < KSH; ++ks) {
+          const v4u_t lo = __builtin_amdgcn_raw_buffer_load_b128(rs, pbase + (unsigned)ks * 128u, 0, 16);
+          const v4u_t hi = __builtin_amdgcn_raw_buffer_load_b128(rs, pbase + (unsigned)ks * 128u + 16u, 0, 16);
+          mine = mine && lo.x == (unsigned)step && lo.z == (unsigned)step && hi.x == (unsigned)step && hi.z == (unsigned)step;
+          const v4u_t fr = {lo.y, lo.w, hi.y, hi.w};
+          hb[ks] = __builtin_bit_cast(bf16x8, fr);
+        }
+#ifdef LSTM_NOEXCH
+        mine = true;
+#endif
+        if (__all(mine)) {
           ok = true;
           break;
         }
@@ -176,12 +202,6 @@ __global__ __launch_bounds__(128) void lstm_dist_kernel(LstmDistArgs a) {
         if (lane == 0) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler ordering only: the loads below are sc1
-      const unsigned pbase = (unsigned)(step & 1) * parity_bytes + group + (unsigned)n * H * 2u + (unsigned)g * 16u;
-      bf16x8 hb[KSH];
-#pragma unroll
-      for (int ks = 0; ks < KSH; ++ks)
-        hb[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, pbase + (unsigned)ks * 64u, 0, 16));
 #pragma unroll
       for (int ks = 0; ks < KSH; ++ks)
 #pragma unroll
@@ -197,11 +217,12 @@ __global__ __launch_bounds__(128) void lstm_dist_kernel(LstmDistArgs a) {
       hv[r] = og * tanhf_fast(c[r]);
       acc[0][r] = ig; acc[1][r] = fg; acc[2][r] = gg; acc[3][r] = og;
     }
-    // ---- publish h_t (bf16) for the next step, then the results
+    // ---- publish h_t: two granules {epoch = step + 1, 2 x bf16}, one 16-byte write-through store
     if (step + 1 < a.T) {
-      const v2u_t hp = {pack_bf2(hv[0], hv[1]), pack_bf2(hv[2], hv[3])};
-      const unsigned off = (unsigned)((step + 1) & 1) * parity_bytes + group + (unsigned)n * H * 2u + (unsigned)un * 2u;
-      __builtin_amdgcn_raw_buffer_store_b64(hp, rs, off, 0, 16);  // sc1: write-through
+      const unsigned ep = (unsigned)(step + 1);
+      const v4u_t hp = {ep, pack_bf2(hv[0], hv[1]), ep, pack_bf2(hv[2], hv[3])};
+      const unsigned off = (unsigned)((step + 1) & 1) * parity_bytes + group + (unsigned)n * row_bytes + (unsigned)un * 4u;
+      __builtin_amdgcn_raw_buffer_store_b128(hp, rs, off, 0, 16);  // sc1: write-through
     }
     const size_t srow = ((size_t)brow * a.T + t) * 2 + dir;
     if (bvalid) {
@@ -214,11 +235,6 @@ __global__ __launch_bounds__(128) void lstm_dist_kernel(LstmDistArgs a) {
               make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
         *reinterpret_cast<float4*>(a.c_out + srow * H + un) = make_float4(c[0], c[1], c[2], c[3]);
       }
-    }
-    if (step + 1 < a.T) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: h_t is in memory
-      __syncthreads();
-      if (tid == 0) __hip_atomic_store(fl + cu * FLAG_STRIDE, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -503,7 +519,10 @@ extern "C" int csship_lstm_bidir_dist(const float* gx, const uint16_t* whh_packe
   if (tiles > 65535 || 2 * (size_t)tiles * ncu > 2048) return CSSHIP_EBADSHAPE;  // all workgroups must be resident together
   const size_t sync_bytes = (2 * (size_t)tiles * ncu * FLAG_STRIDE + 16) * sizeof(unsigned);
   hipStream_t s = as_stream(stream);
-  if (hipMemsetAsync(workspace, 0, sync_bytes, s) != hipSuccess) return CSSHIP_ELAUNCH;  // flags + error word, every call
+  // error word + this call's tagged panels (2 parities x 2 directions x tiles x 16 rows x 4H bytes): epoch tags
+  // of an earlier call must not be mistaken for this one's
+  const size_t panel_bytes = 2 * 2 * (size_t)tiles * 16 * (size_t)(4 * H);
+  if (hipMemsetAsync(workspace, 0, sync_bytes + panel_bytes, s) != hipSuccess) return CSSHIP_ELAUNCH;
   LstmDistArgs a{};
   a.gx = gx; a.whh = reinterpret_cast<const bf16x8*>(whh_packed); a.out = out; a.gates_out = gates_out; a.c_out = c_out;
   a.flags = reinterpret_cast<unsigned*>(workspace);
