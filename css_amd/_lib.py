@@ -71,6 +71,8 @@ SIGNATURES = {
     "csship_mvn_stats": (_i32, [_p, _i64, _i64, _i64, _i64, _f32, _f32, _p, _p, _p]),
     "csship_transpose_norm": (_i32, [_p, _i64, _i64, _i64, _i64, _f32, _p, _p, _p, _i64, _i64, _p]),
     "csship_ipd": (_i32, [_p, _p, _i64, _i64, _i64, C.POINTER(_i32), C.POINTER(_i32), _i32, _p, _i64, _i64, _p, _p]),
+    "csship_ipd_tf_workspace": (_sz, [_i64, _i32]),
+    "csship_ipd_tf": (_i32, [_p, _p, _i64, _i64, _i64, C.POINTER(_i32), C.POINTER(_i32), _i32, _p, _i64, _i64, _p, _sz, _p]),
     "csship_istft": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p]),
     "csship_layernorm": (_i32, [_p, _i64, _i32, _p, _p, _p, _p, _p]),
     "csship_layernorm_relu": (_i32, [_p, _i64, _i32, _p, _p, _i32, _p, _p, _p]),

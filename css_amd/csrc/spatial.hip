@@ -95,6 +95,107 @@ __global__ __launch_bounds__(256) void ipd_out_kernel(const float* __restrict__ 
   }
 }
 
+// ---- frame-major IPD (what the models consume: out[b, t, f_off + p*257 + f]).  One wave = one frame at a time: lane l
+// takes bins 4l .. 4l+3 with ONE 16-byte load per channel and component (rows are 257 floats: 4-byte aligned), bin 256
+// of the frame by lane 0.  Pass 1 leaves per-(batch, pair, time slice) partial sums, pass 2 adds them in a fixed order
+// (bit-reproducible).
+constexpr int IPD_TS = 8;  // time slices of pass 1
+
+struct __attribute__((packed, aligned(4))) f4u {
+  float v[4];
+};
+DEV f4u ld4(const float* p) { return *reinterpret_cast<const f4u*>(p); }
+
+// pass 1: partial[b][p][slice][2][260] = sum over the slice's frames of cos / sin(phase_l - phase_r)
+__global__ __launch_bounds__(256) void ipd_mean_tf_kernel(const float* __restrict__ re, const float* __restrict__ im, int C,
+                                                          int T, Pairs pr, float* __restrict__ partial) {
+  __shared__ float red[4][2][260];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int sl = blockIdx.x, p = blockIdx.y, b = blockIdx.z, P = gridDim.y;
+  const int per = (T + IPD_TS - 1) / IPD_TS, t_beg = sl * per, t_end = min(T, t_beg + per);
+  const size_t cl = ((size_t)b * C + pr.l[p]) * T, cr = ((size_t)b * C + pr.r[p]) * T;
+  float ac[4] = {0.f, 0.f, 0.f, 0.f}, as[4] = {0.f, 0.f, 0.f, 0.f}, tc = 0.f, ts = 0.f;
+  for (int t = t_beg + w; t < t_end; t += 4) {
+    const size_t ol = (cl + t) * NBIN + 4 * lane, orr = (cr + t) * NBIN + 4 * lane;
+    const f4u rl = ld4(re + ol), il = ld4(im + ol), rr = ld4(re + orr), ir = ld4(im + orr);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float yr, yi;
+      phase_diff(rl.v[e], il.v[e], rr.v[e], ir.v[e], yr, yi);
+      ac[e] += yr;
+      as[e] += yi;
+    }
+    if (lane == 0) {  // bin 256
+      const size_t ql = (cl + t) * NBIN + 256, qr = (cr + t) * NBIN + 256;
+      float yr, yi;
+      phase_diff(re[ql], im[ql], re[qr], im[qr], yr, yi);
+      tc += yr;
+      ts += yi;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[w][0][4 * lane + e] = ac[e];
+    red[w][1][4 * lane + e] = as[e];
+  }
+  if (lane == 0) {
+    red[w][0][256] = tc;
+    red[w][1][256] = ts;
+  }
+  __syncthreads();
+  float* dst = partial + (((size_t)b * P + p) * IPD_TS + sl) * 2 * 260;
+  for (int i = threadIdx.x; i < 2 * NBIN; i += 256) {
+    const int row = i / NBIN, f = i - row * NBIN;
+    dst[row * 260 + f] = (red[0][row][f] + red[1][row][f]) + (red[2][row][f] + red[3][row][f]);
+  }
+}
+
+// pass 2: out[b, t, f_off + p*257 + f] = atan2(sin - mean sin, cos - mean cos); workgroup = (frames, pair, batch)
+__global__ __launch_bounds__(256) void ipd_out_tf_kernel(const float* __restrict__ re, const float* __restrict__ im, int C,
+                                                         int T, Pairs pr, const float* __restrict__ partial,
+                                                         float* __restrict__ out, int64_t ld_out, int64_t f_off,
+                                                         int frames_per_wg) {
+  __shared__ float mean[2][260];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int p = blockIdx.y, b = blockIdx.z, P = gridDim.y, t0 = blockIdx.x * frames_per_wg;
+  const float inv_t = 1.f / (float)T;
+  for (int i = threadIdx.x; i < 2 * NBIN; i += 256) {
+    const int row = i / NBIN, f = i - row * NBIN;
+    float s = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < IPD_TS; ++sl) s += partial[(((size_t)b * P + p) * IPD_TS + sl) * 2 * 260 + row * 260 + f];
+    mean[row][f] = s * inv_t;
+  }
+  __syncthreads();
+  const size_t cl = ((size_t)b * C + pr.l[p]) * T, cr = ((size_t)b * C + pr.r[p]) * T;
+  float mc[4], ms[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    mc[e] = mean[0][4 * lane + e];
+    ms[e] = mean[1][4 * lane + e];
+  }
+  const float mc256 = mean[0][256], ms256 = mean[1][256];
+  for (int t = t0 + w; t < min(T, t0 + frames_per_wg); t += 4) {
+    const size_t ol = (cl + t) * NBIN + 4 * lane, orr = (cr + t) * NBIN + 4 * lane;
+    const f4u rl = ld4(re + ol), il = ld4(im + ol), rr = ld4(re + orr), ir = ld4(im + orr);
+    float* orow = out + ((size_t)b * T + t) * ld_out + f_off + (size_t)p * NBIN;
+    f4u o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float yr, yi;
+      phase_diff(rl.v[e], il.v[e], rr.v[e], ir.v[e], yr, yi);
+      o.v[e] = atan2f(yi - ms[e], yr - mc[e]);
+    }
+    *reinterpret_cast<f4u*>(orow + 4 * lane) = o;
+    if (lane == 0) {
+      const size_t ql = (cl + t) * NBIN + 256, qr = (cr + t) * NBIN + 256;
+      float yr, yi;
+      phase_diff(re[ql], im[ql], re[qr], im[qr], yr, yi);
+      orow[256] = atan2f(yi - ms256, yr - mc256);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ iSTFT
 // One wave per frame: 512-point inverse real FFT as conj(FFT256(conj(Z)))/256 with
 //   Z[k] = Xe[k] + i Xo[k],  Xe = (X[k] + conj X[256-k])/2,  Xo = (X[k] - conj X[256-k])/2 * e^{+2 pi i k/512},
@@ -186,6 +287,35 @@ extern "C" int csship_ipd(const float* re, const float* im, int64_t B, int64_t C
   CSSHIP_CHECK_LAUNCH();
   hipLaunchKernelGGL(ipd_out_kernel, dim3((NBIN + 31) / 32, (unsigned)((T + 31) / 32), (unsigned)(B * n_pairs)),
                      dim3(256), 0, s, re, im, (int)C, (int)T, pr, n_pairs, workspace, out, out_batch_stride, f_off);
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
+extern "C" size_t csship_ipd_tf_workspace(int64_t B, int32_t n_pairs) {
+  return (size_t)B * (size_t)n_pairs * IPD_TS * 2 * 260 * sizeof(float);
+}
+
+extern "C" int csship_ipd_tf(const float* re, const float* im, int64_t B, int64_t C, int64_t T, const int32_t* pairs_l,
+                             const int32_t* pairs_r, int32_t n_pairs, float* out, int64_t ld_out, int64_t f_off,
+                             float* workspace, size_t workspace_bytes, csship_stream_t stream) {
+  if (!re || !im || !pairs_l || !pairs_r || !out || !workspace) return CSSHIP_ENULL;
+  if (B <= 0 || C <= 0 || T <= 0 || n_pairs <= 0 || B > 65535) return CSSHIP_EBADSHAPE;
+  if (n_pairs > 16) return CSSHIP_EUNSUPPORTED;
+  if (ld_out < f_off + (int64_t)n_pairs * NBIN) return CSSHIP_EBADSHAPE;
+  if (workspace_bytes < csship_ipd_tf_workspace(B, n_pairs)) return CSSHIP_EWORKSPACE;
+  Pairs pr{};
+  for (int i = 0; i < n_pairs; ++i) {
+    if (pairs_l[i] < 0 || pairs_l[i] >= C || pairs_r[i] < 0 || pairs_r[i] >= C) return CSSHIP_EBADSHAPE;
+    pr.l[i] = pairs_l[i];
+    pr.r[i] = pairs_r[i];
+  }
+  hipStream_t s = as_stream(stream);
+  const int fpw = 32;  // frames per workgroup in pass 2
+  hipLaunchKernelGGL(ipd_mean_tf_kernel, dim3(IPD_TS, n_pairs, (unsigned)B), dim3(256), 0, s, re, im, (int)C, (int)T, pr,
+                     workspace);
+  CSSHIP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(ipd_out_tf_kernel, dim3((unsigned)((T + fpw - 1) / fpw), n_pairs, (unsigned)B), dim3(256), 0, s, re,
+                     im, (int)C, (int)T, pr, workspace, out, ld_out, f_off, fpw);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }

@@ -51,6 +51,31 @@ class FeatureExtractor(torch.nn.Module):
             self.index_r = [p[1] for p in pairs]
             self.feature_dim = self.num_bins * (1 + len(pairs))
 
+    def forward_tf(self, x, want_spectra=True):
+        """Frame-major features, the layout the mask estimators consume (no transposes anywhere):
+        (mag [B,T,257] of channel 0, f [B,T,257*(1+P)], re, im [B,(C,)T,257] or None).  Same values as ``forward``."""
+        multi = x.dim() == 3
+        if multi and (self.ipd_index or want_spectra):
+            o = ops.stft(x, ("re", "im"))                      # all channels: the spectra feed IPD / MVDR / DOA
+            re_tf, im_tf = o["re"], o["im"]
+            mag0 = ops.stft(x[:, 0], ("mag",))["mag"]          # only channel 0's magnitude is a feature
+        else:
+            x0 = x[:, 0] if multi else x
+            want = ("mag", "re", "im") if want_spectra else ("mag",)
+            o = ops.stft(x0, want)
+            mag0, re_tf, im_tf = o["mag"], o.get("re"), o.get("im")
+        B, T, F = mag0.shape
+        mean, rinv = ops.mvn_stats(mag0, clamp_min=EPSILON)   # [B, F] each
+        f = torch.empty(B, T, self.feature_dim, device=x.device, dtype=torch.float32)
+        fm = f[:, :, :F]
+        torch.clamp(mag0, min=EPSILON, out=fm)
+        fm.sub_(mean.view(B, 1, F)).mul_(rinv.view(B, 1, F))
+        if self.ipd_index:
+            if not multi:
+                raise RuntimeError("IPD features need a multi-channel signal")
+            ops.ipd_tf(re_tf, im_tf, self.index_l, self.index_r, out=f, f_off=F)
+        return mag0, f, re_tf, im_tf
+
     def forward(self, x):
         o = ops.stft(x, ("mag", "re", "im"))
         mag_tf, re_tf, im_tf = o["mag"], o["re"], o["im"]

@@ -125,12 +125,18 @@ class Separator:
         """s: [B, D, n] (may be a strided view) -> (masks [B,257,T,3], mag [B,257,T])."""
         if s.shape[1] == 1 and self.ipd is None:
             s = s[:, 0]
-        mag_specs, f, re, im = self.feature.forward(s)
-        B, Fd, T = f.shape
-        m = self.separator.forward_masks(f.transpose(1, 2).contiguous())  # [B, T, 3*257]
+        # frame-major features: what the mask estimator consumes (the reference's [B, F, T] tensors are produced only
+        # where this method hands them on)
+        mag_tf, f, re_tf, im_tf = self.feature.forward_tf(s, want_spectra=bool(self.merge))
+        B, T, Fd = f.shape
+        m = self.separator.forward_masks(f)  # [B, T, 3*257]
+        mag_specs = ops.transpose_norm(mag_tf)  # [B, 257, T]
         nb = self.feature.num_bins
         masks = m.reshape(B, T, -1, nb).permute(0, 3, 1, 2)[..., :3]  # (B, 257, T, 3): spk1, spk2, noise
         masks = torch.clamp(masks, max=1.0).contiguous()  # separator.py:104
         if self.merge:  # separator.py:106-110
+            lead = re_tf.shape[:-2]
+            re = ops.transpose_norm(re_tf.reshape(-1, T, re_tf.shape[-1])).reshape(*lead, re_tf.shape[-1], T)
+            im = ops.transpose_norm(im_tf.reshape(-1, T, im_tf.shape[-1])).reshape(*lead, im_tf.shape[-1], T)
             masks[..., :2] = self.angle_merge(re, im, masks[..., :2].contiguous(), thresh=self.merge_threshold)
         return masks, mag_specs

@@ -354,6 +354,25 @@ def ipd(re_tf, im_tf, index_l, index_r, out, f_off):
     return out
 
 
+def ipd_tf(re_tf, im_tf, index_l, index_r, out, f_off):
+    """IPD features from TF-layout spectra [B,C,T,257] into the frame-major out[b, t, f_off + p*257 + f]."""
+    _need(re_tf, torch.float32, "re")
+    _need(im_tf, torch.float32, "im")
+    B, Cn, T, F = re_tf.shape
+    P = len(index_l)
+    assert F == 257 and re_tf.is_contiguous() and im_tf.is_contiguous()
+    assert all(0 <= i < Cn for i in list(index_l) + list(index_r))
+    assert out.dim() == 3 and out.shape[:2] == (B, T) and out.stride(2) == 1 and out.stride(0) == T * out.stride(1)
+    assert out.shape[2] >= f_off + P * F
+    li = (C.c_int32 * P)(*index_l)
+    ri = (C.c_int32 * P)(*index_r)
+    nws = lib().csship_ipd_tf_workspace(B, P)
+    ws = torch.empty(nws, device=re_tf.device, dtype=torch.uint8)
+    check(lib().csship_ipd_tf(_ptr(re_tf), _ptr(im_tf), B, Cn, T, li, ri, P, _ptr(out), out.stride(1), f_off, _ptr(ws), nws,
+                              _stream()))
+    return out
+
+
 def pack_frag(w):
     """[R, K] float -> bf16 in MFMA fragment order (include/csship.h, "row-panel kernels").
 

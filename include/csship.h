@@ -79,6 +79,14 @@ int csship_ipd(const float* re, const float* im, int64_t B, int64_t C, int64_t T
                const int32_t* pairs_l, const int32_t* pairs_r, int32_t n_pairs,
                float* out, int64_t out_batch_stride, int64_t f_off, float* workspace,
                csship_stream_t stream);
+/* The same features frame-major, the layout the mask estimators consume: out[b, t, f_off + p*257 + f] with ld_out
+ * floats between frames (>= f_off + n_pairs*257) - no transposed write, 16-byte row loads.
+ * workspace: csship_ipd_tf_workspace(B, n_pairs) bytes. */
+size_t csship_ipd_tf_workspace(int64_t B, int32_t n_pairs);
+int csship_ipd_tf(const float* re, const float* im, int64_t B, int64_t C, int64_t T,
+                  const int32_t* pairs_l, const int32_t* pairs_r, int32_t n_pairs,
+                  float* out, int64_t ld_out, int64_t f_off, float* workspace, size_t workspace_bytes,
+                  csship_stream_t stream);
 
 /* Inverse of the centre-padded Hann STFT: torch.istft(center=True) as used at
  * css/executor/beamformer.py:83-102.  re/im: [S, 257, T] (the reference's layout);

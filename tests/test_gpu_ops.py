@@ -328,6 +328,30 @@ def test_convmod_golden(ops, golden):
     assert err(ops.convmod(x.to(DEV), dw, 33, batch_stats=True) - x.to(DEV), torch.from_numpy(g["conv_trainbn"])) < 2e-4
 
 
+def test_feature_extractor_frame_major_equals_reference_layout(ops):
+    """FeatureExtractor.forward_tf (frame-major STFT -> MVN -> 16-byte-row IPD kernels, no transposes) returns the
+    same features as forward (the reference's [B, F, T] layout, itself checked against the goldens): magnitudes and
+    spectra bitwise, normalised magnitude to 1 ulp-level, IPD to 2e-6 rad (different summation order of the time
+    means); single-channel input without IPD as well; odd frame counts."""
+    from css_amd.executor.feature import FeatureExtractor
+    for n, B in ((512 + 256 * 36, 3), (512 + 256 * 149, 2)):
+        x = (rnd((B, 7, n), 170) * 0.1).to(DEV)
+        fe = FeatureExtractor(ipd_index="1,0;2,0;3,0;4,0;5,0;6,0")
+        mag, f, re, im = fe.forward(x)
+        mag_tf, f_tf, re_tf, im_tf = fe.forward_tf(x)
+        assert torch.equal(mag_tf.transpose(1, 2), mag) and torch.equal(re_tf.transpose(2, 3), re) and torch.equal(im_tf.transpose(2, 3), im)
+        ft = f_tf.transpose(1, 2)
+        assert err(ft[:, :257], f[:, :257]) < 1e-5 * float(f[:, :257].abs().max())
+        d = (ft[:, 257:] - f[:, 257:]).abs()
+        d = torch.minimum(d, (2 * np.pi - d).abs())  # +-pi wrap
+        assert float(d.max()) < 2e-5, float(d.max())
+        fe1 = FeatureExtractor()
+        mag1, f1, _, _ = fe1.forward(x[:, 0])
+        mag1_tf, f1_tf, re1, _ = fe1.forward_tf(x[:, 0], want_spectra=False)
+        assert re1 is None and torch.equal(mag1_tf.transpose(1, 2), mag1)
+        assert err(f1_tf.transpose(1, 2), f1) < 1e-5 * float(f1.abs().max())
+
+
 # ----------------------------------------------------------------------------- PIT
 @pytest.mark.parametrize("K", [2, 3])
 def test_pit_mse(ops, K):
