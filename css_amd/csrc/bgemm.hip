@@ -303,33 +303,45 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
 }
 
 // out[r, c] = alpha * sum_s slab[s][r, c] (+ bias[c]) (+ add[r, c]); fixed summation order.
-// Workgroup = 64 lanes x V consecutive elements x 4 waves; wave w adds slabs w, w+4, ... with four loads in flight,
+// Workgroup = 64 lanes x V consecutive elements x NW waves; wave w adds slabs w, w+NW, ... with eight loads in flight,
 // then one LDS reduction - short outputs with many slabs (LayerNorm / bias partials) do not serialise on one thread,
 // long ones (V = 4: N and the slab size are multiples of 4) move 16 bytes per load instruction.
-template <int V>
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int S, int64_t n, int N,
-                                                          int64_t ldc, float alpha, const float* __restrict__ bias,
-                                                          const float* add, int64_t ldadd, float* out) {
+template <int V, int NW, int U>
+__global__ __launch_bounds__(64 * NW) void slab_reduce_kernel(const float* __restrict__ slabs, int S, int64_t n, int N,
+                                                              int64_t ldc, float alpha, const float* __restrict__ bias,
+                                                              const float* add, int64_t ldadd, float* out) {
   typedef float vec __attribute__((ext_vector_type(V)));
-  __shared__ vec red[4][64];
+  __shared__ vec red[NW][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t i = ((int64_t)blockIdx.x * 64 + lane) * V;
-  vec s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  vec s[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) s[u] = 0.f;
   if (i < n) {
     int k = w;
-    for (; k + 12 < S; k += 16) {
-      s0 += *reinterpret_cast<const vec*>(slabs + (int64_t)k * n + i);
-      s1 += *reinterpret_cast<const vec*>(slabs + (int64_t)(k + 4) * n + i);
-      s2 += *reinterpret_cast<const vec*>(slabs + (int64_t)(k + 8) * n + i);
-      s3 += *reinterpret_cast<const vec*>(slabs + (int64_t)(k + 12) * n + i);
+    for (; k + (U - 1) * NW < S; k += U * NW) {  // U independent loads in flight per lane
+#pragma unroll
+      for (int u = 0; u < U; ++u) s[u] += *reinterpret_cast<const vec*>(slabs + (int64_t)(k + u * NW) * n + i);
     }
-    for (; k < S; k += 4) s0 += *reinterpret_cast<const vec*>(slabs + (int64_t)k * n + i);
+    if (k < S) {  // last, partial round: no branch around the loads (out-of-range slabs re-read the last one, masked)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int kk = k + u * NW;
+        const vec v = *reinterpret_cast<const vec*>(slabs + (int64_t)min(kk, S - 1) * n + i);
+        s[u] += kk < S ? v : (vec)0.f;
+      }
+    }
   }
-  red[w][lane] = (s0 + s1) + (s2 + s3);
+  vec tot = s[0];
+#pragma unroll
+  for (int u = 1; u < U; ++u) tot += s[u];
+  red[w][lane] = tot;
   __syncthreads();
   if (w != 0 || i >= n) return;
   const int64_t r = i / N, c = i % N;
-  const vec t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  vec t = red[0][lane];
+#pragma unroll
+  for (int j = 1; j < NW; ++j) t += red[j][lane];
 #pragma unroll
   for (int e = 0; e < V; ++e) {  // V = 4: the four elements share a row (N % 4 == 0)
     float v = alpha * t[e];
@@ -389,12 +401,17 @@ int pick_splits(const csship_bgemm_params* p) {
 
 int launch_slab_reduce(const float* slabs, int S, int64_t n, int N, int64_t ldc, float alpha, const float* bias,
                        const float* add, int64_t ldadd, float* out, hipStream_t s) {
+  // long outputs: 16-byte loads, 4 waves per 256 elements; short outputs with many slabs (bias / LayerNorm partials): 16
+  // waves share the slabs of 64 elements
   if ((N & 3) == 0 && (n & 3) == 0 && n >= 4096 && aligned16(slabs))
-    hipLaunchKernelGGL(slab_reduce_kernel<4>, dim3((unsigned)((n / 4 + 63) / 64)), dim3(256), 0, s, slabs, S, n, N, ldc,
+    hipLaunchKernelGGL((slab_reduce_kernel<4, 4, 4>), dim3((unsigned)((n / 4 + 63) / 64)), dim3(256), 0, s, slabs, S, n, N, ldc,
+                       alpha, bias, add, ldadd, out);
+  else if (S >= 32)
+    hipLaunchKernelGGL((slab_reduce_kernel<1, 16, 8>), dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, s, slabs, S, n, N, ldc,
                        alpha, bias, add, ldadd, out);
   else
-    hipLaunchKernelGGL(slab_reduce_kernel<1>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, slabs, S, n, N, ldc, alpha,
-                       bias, add, ldadd, out);
+    hipLaunchKernelGGL((slab_reduce_kernel<1, 4, 4>), dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, slabs, S, n, N, ldc,
+                       alpha, bias, add, ldadd, out);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }

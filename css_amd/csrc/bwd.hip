@@ -323,8 +323,12 @@ extern "C" int csship_pack_weights_multi(const csship_pack_job* jobs_device, int
   return CSSHIP_OK;
 }
 
+// rows per workgroup of the LayerNorm backward: a row is a serial chain of four wave reductions, so the kernel wants
+// many waves in flight (16 rows = 4 per wave: 3 waves per SIMD at 12 800 rows), not long row loops
+static constexpr int LNB_ROWS = 16;
+
 extern "C" size_t csship_layernorm_bwd_workspace(int64_t M, int32_t D) {
-  return (size_t)((M + 63) / 64) * 2 * D * sizeof(float);
+  return (size_t)((M + LNB_ROWS - 1) / LNB_ROWS) * 2 * D * sizeof(float);
 }
 
 extern "C" int csship_layernorm_bwd(const float* x, const float* dy, const float* gamma, const float* beta,
@@ -338,19 +342,19 @@ extern "C" int csship_layernorm_bwd(const float* x, const float* dy, const float
   if (fast && (!aligned16(x) || !aligned16(dy) || !aligned16(dx) || !aligned16(gamma) || !aligned16(beta) ||
                (dx_add && !aligned16(dx_add))))
     return CSSHIP_EALIGN;
-  const int nwg = (int)((M + 63) / 64);
+  const int nwg = (int)((M + LNB_ROWS - 1) / LNB_ROWS);
   if (workspace_bytes < (size_t)nwg * 2 * D * sizeof(float)) return CSSHIP_EWORKSPACE;
   hipStream_t s = as_stream(stream);
   float* part = reinterpret_cast<float*>(workspace);
   if (!fast)
     hipLaunchKernelGGL(ln_bwd_any_kernel, dim3(nwg), dim3(256), (size_t)8 * D * sizeof(float), s, x, dy, gamma, beta, dx_add,
-                       relu, M, D, 64, dx, part);
+                       relu, M, D, LNB_ROWS, dx, part);
   else if (D == 256)
-    hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(nwg), dim3(256), 0, s, x, dy, gamma, beta, dx_add, relu, M, 64, dx, part);
+    hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(nwg), dim3(256), 0, s, x, dy, gamma, beta, dx_add, relu, M, LNB_ROWS, dx, part);
   else if (D == 512)
-    hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(nwg), dim3(256), 0, s, x, dy, gamma, beta, dx_add, relu, M, 64, dx, part);
+    hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(nwg), dim3(256), 0, s, x, dy, gamma, beta, dx_add, relu, M, LNB_ROWS, dx, part);
   else
-    hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nwg), dim3(256), 0, s, x, dy, gamma, beta, dx_add, relu, M, 64, dx, part);
+    hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nwg), dim3(256), 0, s, x, dy, gamma, beta, dx_add, relu, M, LNB_ROWS, dx, part);
   CSSHIP_CHECK_LAUNCH();
   return launch_slab_reduce(part, nwg, 2 * (int64_t)D, 2 * D, 2 * (int64_t)D, 1.f, nullptr, nullptr, 0, dgamma_dbeta, s);
 }
