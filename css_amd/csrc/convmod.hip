@@ -186,11 +186,23 @@ __global__ __launch_bounds__(1024) void bn_reduce_kernel(const float* __restrict
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
   double s = 0.0, q = 0.0;
-  if (c < D)
-    for (int i = w; i < nblk; i += 16) {
-      s += (double)partial[((size_t)i * 2 + 0) * D + c];
-      q += (double)partial[((size_t)i * 2 + 1) * D + c];
+  if (c < D) {
+    // four partials per lane in flight (a dependent chain of nblk/16 loads took 19 us); out-of-range ones re-read the
+    // last partial and are masked, so no load sits behind a branch
+    double sa[4] = {0.0, 0.0, 0.0, 0.0}, qa[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = w; i < nblk; i += 64) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ii = i + 16 * u;
+        const size_t o = (size_t)min(ii, nblk - 1) * 2 * D + c;
+        const float a = partial[o], b = partial[o + D];
+        sa[u] += ii < nblk ? (double)a : 0.0;
+        qa[u] += ii < nblk ? (double)b : 0.0;
+      }
     }
+    s = (sa[0] + sa[1]) + (sa[2] + sa[3]);
+    q = (qa[0] + qa[1]) + (qa[2] + qa[3]);
+  }
   red[0][w][lane] = s;
   red[1][w][lane] = q;
   __syncthreads();
@@ -439,6 +451,10 @@ __global__ __launch_bounds__(256) void glu_ln_bwd_kernel(const float* __restrict
     part[(int64_t)blockIdx.x * (2 * D + 4) + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
 
+// rows per workgroup of the row-wise backward passes: short row loops, many waves in flight (these passes are chains of
+// loads and wave reductions, not bandwidth: 64 rows per workgroup left less than one wave per SIMD at 12 800 rows)
+constexpr int BWD_ROWS = 16;
+
 struct BwdLayout {  // carve of the backward workspace (floats)
   size_t dc, dg, part, sums, total;
   int nwg_rows, nblk;
@@ -446,7 +462,7 @@ struct BwdLayout {  // carve of the backward workspace (floats)
 BwdLayout bwd_layout(int B, int T, int D, int TT) {
   BwdLayout L{};
   const size_t n = (size_t)B * T * D;
-  L.nwg_rows = (int)(((size_t)B * T + 63) / 64);
+  L.nwg_rows = (int)(((size_t)B * T + BWD_ROWS - 1) / BWD_ROWS);
   L.nblk = ((T + TT - 1) / TT) * B * 2;
   const size_t p = (size_t)L.nwg_rows * (2 * D + 4) > (size_t)L.nblk * 34 * D ? (size_t)L.nwg_rows * (2 * D + 4)
                                                                              : (size_t)L.nblk * 34 * D;
@@ -469,7 +485,7 @@ int run_bwd(const float* x, const float* dy, const csship_conv_weights& w, int B
   float* gB = grads + 2 * D + 4;
   float* gC = gB + 34 * D;
   // pass A
-  hipLaunchKernelGGL((conv_bn_bwd_stats_kernel<D>), dim3(L.nwg_rows), dim3(D), 0, s, dy, z, stats, w.pw2_w, M, 64, part);
+  hipLaunchKernelGGL((conv_bn_bwd_stats_kernel<D>), dim3(L.nwg_rows), dim3(D), 0, s, dy, z, stats, w.pw2_w, M, BWD_ROWS, part);
   CSSHIP_CHECK_LAUNCH();
   int rc = launch_slab_reduce(part, L.nwg_rows, 2 * D + 2, 2 * D + 2, 2 * D + 2, 1.f, nullptr, nullptr, 0, gA, s);
   if (rc) return rc;
@@ -490,7 +506,7 @@ int run_bwd(const float* x, const float* dy, const csship_conv_weights& w, int B
   if (rc) return rc;
   // pass C
   hipLaunchKernelGGL((glu_ln_bwd_kernel<D / 256>), dim3(L.nwg_rows), dim3(256), 0, s, x, dg, dy, w.ln_g, w.ln_b, w.pw1_w,
-                     w.pw1_b, M, 64, dx, part);
+                     w.pw1_b, M, BWD_ROWS, dx, part);
   CSSHIP_CHECK_LAUNCH();
   return launch_slab_reduce(part, L.nwg_rows, 2 * D + 4, 2 * D + 4, 2 * D + 4, 1.f, nullptr, nullptr, 0, gC, s);
 }
