@@ -27,28 +27,23 @@ struct GemmArgs {
 
 constexpr int BK = 64;
 
-template <int WAVES_M, int WAVES_N, int AMODE, int EPI>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-  constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
-  constexpr int A_CH = BM / 32, B_CH = BN / 32;  // 16-byte chunks per thread per tile
-  constexpr int STAGE = (BM + BN) * 128;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int lg = lane >> 4, ln = lane & 15;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int nk = (g.K + BK - 1) / BK;
-  const int srow = tid >> 3, sc = tid & 7;  // staging row (0..31) and chunk (0..7)
-
-  uint4 ra[A_CH], rb[B_CH];
-
-  auto load_tiles = [&](int kt) {
+template <int WAVES_M, int WAVES_N, int AMODE, bool KFULL>
+DEV void gemm_load_tiles(const GemmArgs& g, int kt, int m0, int n0, int srow, int sc,
+                         uint4 (&ra)[WAVES_M * 2], uint4 (&rb)[WAVES_N * 2],
+                         uint4 (&ra2)[WAVES_M * 2]) {
+  constexpr int A_CH = WAVES_M * 2, B_CH = WAVES_N * 2;
+  constexpr bool RAW_F32 = KFULL && AMODE == CSSHIP_A_F32;
     const int k = kt * BK + sc * 8;
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
       const int row = min(m0 + srow + 32 * i, g.M - 1);
-      if constexpr (AMODE == CSSHIP_A_BF16) {
+      if constexpr (KFULL && AMODE == CSSHIP_A_BF16) {
+        ra[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(g.A) + (size_t)row * g.lda + k);
+      } else if constexpr (RAW_F32) {
+        const float* p = reinterpret_cast<const float*>(g.A) + (size_t)row * g.lda + k;
+        ra[i] = *reinterpret_cast<const uint4*>(p);
+        ra2[i] = *reinterpret_cast<const uint4*>(p + 4);
+      } else if constexpr (AMODE == CSSHIP_A_BF16) {
         const unsigned short* p = reinterpret_cast<const unsigned short*>(g.A) + (size_t)row * g.lda + k;
         ra[i] = (k < g.K) ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
       } else if constexpr (AMODE == CSSHIP_A_F32) {
@@ -77,27 +72,64 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       const int row = min(n0 + srow + 32 * i, g.N - 1);
       rb[i] = *reinterpret_cast<const uint4*>(g.W + (size_t)row * g.ldw + k);  // ldw padded to nk*64
     }
-  };
-  auto store_tiles = [&](int stage) {
+}
+
+template <int WAVES_M, int WAVES_N, int AMODE, bool KFULL>
+DEV void gemm_store_tiles(unsigned char* smem, int stage, int srow, int sc, uint4 (&ra)[WAVES_M * 2], const uint4 (&rb)[WAVES_N * 2],
+                          const uint4 (&ra2)[WAVES_M * 2]) {
+  constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
+  constexpr int A_CH = WAVES_M * 2, B_CH = WAVES_N * 2;
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr bool RAW_F32 = KFULL && AMODE == CSSHIP_A_F32;
     unsigned char* as = smem + stage * STAGE;
     unsigned char* bs = as + BM * 128;
+    if constexpr (RAW_F32) {
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i)
+        ra[i] = make_uint4(pack_bf2(__uint_as_float(ra[i].x), __uint_as_float(ra[i].y)),
+                           pack_bf2(__uint_as_float(ra[i].z), __uint_as_float(ra[i].w)),
+                           pack_bf2(__uint_as_float(ra2[i].x), __uint_as_float(ra2[i].y)),
+                           pack_bf2(__uint_as_float(ra2[i].z), __uint_as_float(ra2[i].w)));
+    }
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) *reinterpret_cast<uint4*>(as + tile_off(srow + 32 * i, sc)) = ra[i];
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) *reinterpret_cast<uint4*>(bs + tile_off(srow + 32 * i, sc)) = rb[i];
-  };
+}
 
+// KFULL: K is a multiple of the 64-deep tile (every large Linear on the path) - the tile loads are straight-line code and
+// f32 activations stay raw in registers until the tile is written to LDS, after the MFMAs.  hipcc waits for a conditional
+// load inside its branch, which made the generic loader's eight loads go out one memory round trip after the other.
+template <int WAVES_M, int WAVES_N, int AMODE, int EPI, bool KFULL>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
+  constexpr int A_CH = BM / 32, B_CH = BN / 32;  // 16-byte chunks per thread per tile
+  constexpr int STAGE = (BM + BN) * 128;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int lg = lane >> 4, ln = lane & 15;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int nk = (g.K + BK - 1) / BK;
+  const int srow = tid >> 3, sc = tid & 7;  // staging row (0..31) and chunk (0..7)
+
+  uint4 ra[A_CH], rb[B_CH], ra2[A_CH];  // ra2: second half of raw f32 groups (KFULL f32 activations only)
+
+  // (tile loads / LDS stores are free functions on the register arrays: arrays captured by a lambda are demoted to
+  // scratch memory by hipcc, which turned the prefetch into load -> wait -> scratch store)
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  load_tiles(0);
-  store_tiles(0);
+  gemm_load_tiles<WAVES_M, WAVES_N, AMODE, KFULL>(g, 0, m0, n0, srow, sc, ra, rb, ra2);
+  gemm_store_tiles<WAVES_M, WAVES_N, AMODE, KFULL>(smem, 0, srow, sc, ra, rb, ra2);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load_tiles(kt + 1);
+    if (kt + 1 < nk) gemm_load_tiles<WAVES_M, WAVES_N, AMODE, KFULL>(g, kt + 1, m0, n0, srow, sc, ra, rb, ra2);
+    if constexpr (KFULL) __builtin_amdgcn_sched_barrier(0);  // loads stay up here, conversion + LDS stores below the MFMAs
     const unsigned char* as = smem + (kt & 1) * STAGE;
     const unsigned char* bs = as + BM * 128;
 #pragma unroll
@@ -114,7 +146,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) store_tiles((kt + 1) & 1);
+    if constexpr (KFULL) __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < nk) gemm_store_tiles<WAVES_M, WAVES_N, AMODE, KFULL>(smem, (kt + 1) & 1, srow, sc, ra, rb, ra2);
     __syncthreads();
   }
 
@@ -208,7 +241,12 @@ template <int WAVES_M, int WAVES_N, int AMODE, int EPI>
 int launch(const GemmArgs& a, hipStream_t s) {
   constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
   dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM);
-  hipLaunchKernelGGL((gemm_kernel<WAVES_M, WAVES_N, AMODE, EPI>), grid, dim3(256), 0, s, a);
+  // (only for f32 activations: with bf16 activations hipcc parks the staged registers in scratch memory for the
+  // straight-line form and the kernel gets slower, 129 vs 112 us at 12800 x 2048 x 512)
+  if (AMODE == CSSHIP_A_F32 && (a.K % BK) == 0)
+    hipLaunchKernelGGL((gemm_kernel<WAVES_M, WAVES_N, AMODE, EPI, AMODE == CSSHIP_A_F32>), grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((gemm_kernel<WAVES_M, WAVES_N, AMODE, EPI, false>), grid, dim3(256), 0, s, a);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }
