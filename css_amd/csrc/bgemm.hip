@@ -288,12 +288,13 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
           reinterpret_cast<float*>(g.C)[coff + (int64_t)row * g.N + col] = v;
           continue;
         }
-        v = g.alpha * v + bias;
+        v = (g.epi & CSSHIP_BEPI_SCALE_BIAS) ? g.alpha * (v + bias) : g.alpha * v + bias;
         const int64_t xo = z1 * g.sX1 + z2 * g.sX2;
         if (g.epi & CSSHIP_BEPI_MASK_POS) {
           if (!(bf2f(reinterpret_cast<const unsigned short*>(g.aux)[xo + (int64_t)row * g.ldaux + col]) > 0.f)) v = 0.f;
         }
         if (g.epi & CSSHIP_BEPI_ADD) v += reinterpret_cast<const float*>(g.aux)[xo + (int64_t)row * g.ldaux + col];
+        if (g.epi & CSSHIP_BEPI_RELU) v = fmaxf(v, 0.f);
         if (g.epi & CSSHIP_BEPI_OUT_BF16)
           reinterpret_cast<unsigned short*>(g.C)[coff + (int64_t)row * g.ldc + col] = f2bf(v);
         else

@@ -354,7 +354,9 @@ int csship_conformer_forward(const csship_conformer_weights* w, const float* f, 
 enum {
   CSSHIP_BEPI_OUT_BF16 = 1, /* C is bf16 (else f32) */
   CSSHIP_BEPI_MASK_POS = 2, /* v = aux_bf16[row, col] > 0 ? v : 0   (ReLU backward) */
-  CSSHIP_BEPI_ADD = 4       /* v += aux_f32[row, col]               (gradient accumulation; aux may alias C) */
+  CSSHIP_BEPI_ADD = 4,      /* v += aux_f32[row, col]               (gradient accumulation / residual; aux may alias C) */
+  CSSHIP_BEPI_SCALE_BIAS = 8, /* v = alpha * (acc + bias) instead of alpha * acc + bias (forward Linear with a scaled residual branch) */
+  CSSHIP_BEPI_RELU = 16     /* v = max(v, 0), applied last */
 };
 typedef struct {
   int32_t M, N, K;
