@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);  // C^T tile
     __builtin_amdgcn_sched_barrier(0);
     if (kt + 1 < nk) {
       unsigned char* nx = smem + ((kt + 1) & 1) * STAGE;
@@ -269,37 +269,85 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
     __syncthreads();
   }
 
-  // ---- epilogue.  acc[i][j][r]: row = m0 + wm*64 + i*16 + lg*4 + r, col = n0 + wn*64 + j*16 + ln
+  // ---- epilogue.  The MFMAs compute the transposed tile (B fragment as the A operand), so acc[i][j][r] is
+  //   row = m0 + wm*64 + i*16 + ln,  col = n0 + wn*64 + j*16 + lg*4 + r :
+  // a lane owns FOUR CONSECUTIVE COLUMNS of one row per (i, j) and stores them as one 16-byte (f32) / 8-byte (bf16)
+  // piece.  With one element per store the epilogue of a K = 512 product cost as much as its main loop (1 300 VALU
+  // instructions of address arithmetic and 64 store instructions per lane against 256 MFMAs).
   const int64_t coff = z1 * g.sC1 + z2 * g.sC2 + (int64_t)split * g.slab;
+  const int64_t xo = z1 * g.sX1 + z2 * g.sX2;
   const bool to_slab = g.splits > 1;
+  const bool obf = (g.epi & CSSHIP_BEPI_OUT_BF16) != 0;
+  // whole 4-column groups and 16- / 8-byte aligned rows (checked once per launch: wave-uniform)
+  const bool vec = (g.N & 3) == 0 &&
+                   (to_slab || ((g.ldc & 3) == 0 && (coff & 3) == 0 && ((uintptr_t)g.C & 15) == 0 &&
+                                (!g.bias || ((uintptr_t)g.bias & 15) == 0) &&
+                                (!(g.epi & (CSSHIP_BEPI_MASK_POS | CSSHIP_BEPI_ADD)) ||
+                                 ((g.ldaux & 3) == 0 && (xo & 3) == 0 && ((uintptr_t)g.aux & 15) == 0))));
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int col = n0 + wn * 64 + j * 16 + ln;
-    if (col >= g.N) continue;
-    const float bias = (!to_slab && g.bias) ? g.bias[col] : 0.f;
+  for (int i = 0; i < 4; ++i) {
+    const int row = m0 + wm * 64 + i * 16 + ln;
+    if (row >= g.M) continue;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      const int col = n0 + wn * 64 + j * 16 + lg * 4;
+      if (col >= g.N) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (to_slab) {
+        float* dst = reinterpret_cast<float*>(g.C) + coff + (int64_t)row * g.N + col;
+        if (vec) {
+          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm * 64 + i * 16 + lg * 4 + r;
-        if (row >= g.M) continue;
-        float v = acc[i][j][r];
-        if (to_slab) {
-          reinterpret_cast<float*>(g.C)[coff + (int64_t)row * g.N + col] = v;
-          continue;
+          for (int r = 0; r < 4; ++r)
+            if (col + r < g.N) dst[r] = v[r];
         }
-        v = (g.epi & CSSHIP_BEPI_SCALE_BIAS) ? g.alpha * (v + bias) : g.alpha * v + bias;
-        const int64_t xo = z1 * g.sX1 + z2 * g.sX2;
-        if (g.epi & CSSHIP_BEPI_MASK_POS) {
-          if (!(bf2f(reinterpret_cast<const unsigned short*>(g.aux)[xo + (int64_t)row * g.ldaux + col]) > 0.f)) v = 0.f;
-        }
-        if (g.epi & CSSHIP_BEPI_ADD) v += reinterpret_cast<const float*>(g.aux)[xo + (int64_t)row * g.ldaux + col];
-        if (g.epi & CSSHIP_BEPI_RELU) v = fmaxf(v, 0.f);
-        if (g.epi & CSSHIP_BEPI_OUT_BF16)
-          reinterpret_cast<unsigned short*>(g.C)[coff + (int64_t)row * g.ldc + col] = f2bf(v);
-        else
-          reinterpret_cast<float*>(g.C)[coff + (int64_t)row * g.ldc + col] = v;
+        continue;
       }
+      const int64_t co = coff + (int64_t)row * g.ldc + col, ao = xo + (int64_t)row * g.ldaux + col;
+      if (vec) {
+        float b[4] = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias) {
+          const float4 bv = *reinterpret_cast<const float4*>(g.bias + col);
+          b[0] = bv.x; b[1] = bv.y; b[2] = bv.z; b[3] = bv.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (g.epi & CSSHIP_BEPI_SCALE_BIAS) ? g.alpha * (v[r] + b[r]) : g.alpha * v[r] + b[r];
+        if (g.epi & CSSHIP_BEPI_MASK_POS) {
+          const uint2 m = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(g.aux) + ao);
+          if (!(__uint_as_float(m.x << 16) > 0.f)) v[0] = 0.f;
+          if (!(__uint_as_float(m.x & 0xffff0000u) > 0.f)) v[1] = 0.f;
+          if (!(__uint_as_float(m.y << 16) > 0.f)) v[2] = 0.f;
+          if (!(__uint_as_float(m.y & 0xffff0000u) > 0.f)) v[3] = 0.f;
+        }
+        if (g.epi & CSSHIP_BEPI_ADD) {
+          const float4 a4 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.aux) + ao);
+          v[0] += a4.x; v[1] += a4.y; v[2] += a4.z; v[3] += a4.w;
+        }
+        if (g.epi & CSSHIP_BEPI_RELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (obf)
+          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(g.C) + co) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        else
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + co) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (col + r >= g.N) continue;
+          const float bias = g.bias ? g.bias[col + r] : 0.f;
+          float x = (g.epi & CSSHIP_BEPI_SCALE_BIAS) ? g.alpha * (v[r] + bias) : g.alpha * v[r] + bias;
+          if (g.epi & CSSHIP_BEPI_MASK_POS) {
+            if (!(bf2f(reinterpret_cast<const unsigned short*>(g.aux)[ao + r]) > 0.f)) x = 0.f;
+          }
+          if (g.epi & CSSHIP_BEPI_ADD) x += reinterpret_cast<const float*>(g.aux)[ao + r];
+          if (g.epi & CSSHIP_BEPI_RELU) x = fmaxf(x, 0.f);
+          if (obf) reinterpret_cast<unsigned short*>(g.C)[co + r] = f2bf(x);
+          else reinterpret_cast<float*>(g.C)[co + r] = x;
+        }
+      }
+    }
   }
 }
 
