@@ -59,7 +59,7 @@ class PackJob(C.Structure):  # csship_pack_job (64 bytes)
 
 
 A_BF16, A_F32, A_F32_MVN = 0, 1, 2
-BEPI_OUT_BF16, BEPI_MASK_POS, BEPI_ADD = 1, 2, 4
+BEPI_OUT_BF16, BEPI_MASK_POS, BEPI_ADD, BEPI_SCALE_BIAS, BEPI_RELU = 1, 2, 4, 8, 16
 EPI_RELU, EPI_RESIDUAL, EPI_LAYERNORM, EPI_OUT_BF16 = 1, 2, 4, 8
 PRO_LN, PRO_BF16, PRO_F32 = 0, 1, 2
 

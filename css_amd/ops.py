@@ -151,6 +151,17 @@ def gemm(a, w_bf16, bias=None, *, K=None, relu=False, residual=None, alpha=1.0, 
           (_lib.EPI_LAYERNORM if ln is not None else 0) | (_lib.EPI_OUT_BF16 if out_bf16 else 0)
     if out is None:
         out = torch.empty(M, N, device=a.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    if mvn is None and ln is None and K % 8 == 0 and a.stride(0) % 8 == 0 and K * max(M, N) * 4 < 2 ** 31:
+        # the batched-GEMM kernel (back-to-back descriptor loads, vector epilogue) is 1.1-2x faster than the classic tiled
+        # kernel wherever its loader applies; same arithmetic (bf16 operands, f32 accumulation in the same order)
+        q = _lib.BgemmParams(M=M, N=N, K=K, lda=a.stride(0), ldb=ldw, ldc=out.stride(0),
+                             ldaux=residual.stride(0) if residual is not None else 0, a_kmajor=0, b_kmajor=0,
+                             a_f32=int(a.dtype == torch.float32), b_f32=0,
+                             epilogue=(_lib.BEPI_OUT_BF16 if out_bf16 else 0) | (_lib.BEPI_RELU if relu else 0) |
+                             ((_lib.BEPI_ADD | _lib.BEPI_SCALE_BIAS) if residual is not None else 0),
+                             batch1=1, batch2=1, splits=1, alpha=float(alpha) if residual is not None else 1.0)
+        check(lib().csship_bgemm(_ptr(a), _ptr(w_bf16), _ptr(out), _ptr(bias), _ptr(residual), C.byref(q), None, 0, _stream()))
+        return out
     p = _lib.GemmParams(M=M, N=N, K=K, lda=a.stride(0), ldw=ldw, ldc=out.stride(0),
                         ldr=residual.stride(0) if residual is not None else N, a_mode=mode, epilogue=epi,
                         rows_per_batch=rows_per_batch, alpha=alpha)
