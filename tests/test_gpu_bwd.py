@@ -350,3 +350,33 @@ def test_attention_probs_recompute(ob):
         # lse against float64
         sc = s.double().cpu() + torch.stack([rel.double().cpu()[:, :, i, i + T - 1 - torch.arange(T)] for i in range(T)], 2)
         assert float((lse.double().cpu() - torch.logsumexp(sc, -1)).abs().max()) < 2e-3
+
+
+def test_pack_weights_multi_matches_single_and_host_layout():
+    """csship_pack_weights_multi (one launch for a table of weights, optionally reading the source transposed) vs
+    csship_pack_weight per weight and vs the host-side fragment layout (ops.pack_frag): bitwise equal, including
+    shared destinations written at row offsets and ragged shapes (R % 16 != 0, K % 32 != 0)."""
+    from css_amd import ops, ops_bwd as ob
+    g = torch.Generator().manual_seed(5)
+    ws = [torch.randn(s, generator=g).to(DEV) for s in ((256, 1024), (1024, 256), (771, 256), (40, 72), (256, 257))]
+    plan = ob.PackPlan(torch.device(DEV, torch.cuda.current_device()))
+    outs = []
+    for i, w in enumerate(ws):  # row-major and fragment shadows as separate jobs (their K paddings differ when K % 32 != 0)
+        outs.append((plan.add(w, scale=0.5 if i == 1 else 1.0, want_row_major=True)[0],
+                     plan.add(w, scale=0.5 if i == 1 else 1.0, want_frag=True)[1]))
+    tr = plan.add(ws[0], transposed=True, want_frag=True)[1]           # logical [1024, 256] = ws[0]^T
+    shared_rm = torch.zeros((768, 256), dtype=torch.bfloat16, device=DEV)
+    shared_fr = torch.zeros(768 * 256, dtype=torch.bfloat16, device=DEV)
+    qkv = [torch.randn((256, 256), generator=g).to(DEV) for _ in range(3)]
+    for i, w in enumerate(qkv):
+        plan.add(w, scale=0.125 if i == 0 else 1.0, row_major=shared_rm, frag=shared_fr, row0=256 * i)
+    plan.run()
+    plan.run()  # the table is reused
+    for i, (w, (rm, fr)) in enumerate(zip(ws, outs)):
+        rm1, _ = ob.pack_weight(w, scale=0.5 if i == 1 else 1.0, want_row_major=True)
+        _, fr1 = ob.pack_weight(w, scale=0.5 if i == 1 else 1.0, want_frag=True)
+        assert torch.equal(rm, rm1) and torch.equal(fr, fr1), i
+    assert torch.equal(tr, ob.pack_weight(ws[0].t().contiguous(), want_frag=True)[1])
+    assert torch.equal(tr, ops.pack_frag(ws[0].t().contiguous()))
+    cat = torch.cat([qkv[0] * 0.125, qkv[1], qkv[2]], 0)
+    assert torch.equal(shared_rm, cat.to(torch.bfloat16)) and torch.equal(shared_fr, ops.pack_frag(cat))
