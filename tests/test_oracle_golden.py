@@ -227,3 +227,40 @@ def test_mvdr_oracle_matches_reference_numpy_twin(golden):
     y = mvdr.souden_mvdr(S, t2, n_un / (m[1:2] + m[2:3]).sum(-1)[..., None, None], eps=0.0)[0].numpy()
     assert np.abs(y - g["res"]).max() < 2e-4
     assert np.isfinite(n2.real.numpy()).all()
+
+
+# ------------------------------------------------------------------ properties of the oracle (hypothesis, small sizes)
+def test_oracle_properties_pit_permutation_and_stft_linearity():
+    """The checker itself obeys the domain's invariants: PIT loss is invariant under a joint relabelling of the estimates
+    (the returned permutation maps through it) and under a relabelling of the targets; the STFT is linear."""
+    import itertools
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=15, deadline=None)
+    @given(seed=st.integers(0, 10_000), K=st.integers(2, 3), T=st.integers(1, 9), F=st.integers(1, 7))
+    def pit(seed, K, T, F):
+        r = np.random.RandomState(seed)
+        est = torch.from_numpy(r.standard_normal((K, T, F)).astype(np.float32))
+        tgt = torch.from_numpy(r.standard_normal((K, T, F)).astype(np.float32))
+        l0, p0 = oracle.pit.pit_mse(est, tgt, return_permutation=True)
+        for sigma in itertools.permutations(range(K)):
+            ls, ps = oracle.pit.pit_mse(est[list(sigma)], tgt, return_permutation=True)
+            assert abs(float(ls) - float(l0)) <= 1e-6 * max(1.0, abs(float(l0)))
+            # est'[i] = est[sigma[i]]; est'[ps[i]] matched to tgt[i]  =>  est[sigma[ps[i]]] matched to tgt[i]
+            assert abs(float(((est[[sigma[j] for j in ps]] - tgt) ** 2).mean()) - float(l0)) <= 1e-6 * max(1.0, abs(float(l0)))
+            lt, _ = oracle.pit.pit_mse(est, tgt[list(sigma)], return_permutation=True)
+            assert abs(float(lt) - float(l0)) <= 1e-6 * max(1.0, abs(float(l0)))
+
+    @settings(max_examples=8, deadline=None)
+    @given(seed=st.integers(0, 10_000), frames=st.integers(1, 5), a=st.floats(-2, 2), b=st.floats(-2, 2))
+    def lin(seed, frames, a, b):
+        r = np.random.RandomState(seed)
+        n = 512 + 256 * (frames - 1)
+        x = torch.from_numpy(r.standard_normal((2, n)).astype(np.float32))
+        y = torch.from_numpy(r.standard_normal((2, n)).astype(np.float32))
+        sx, sy, sz = (oracle.feature.stft(v) for v in (x, y, a * x + b * y))
+        for i in (2, 3):  # re, im
+            assert float((sz[i] - (a * sx[i] + b * sy[i])).abs().max()) < 1e-3
+
+    pit()
+    lin()
