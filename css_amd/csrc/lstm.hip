@@ -386,7 +386,7 @@ struct LstmBwdDistArgs {
 
 template <int KSH>  // H = 32 * KSH
 __global__ __launch_bounds__(128) void lstm_bwd_dist_kernel(LstmBwdDistArgs a) {
-  constexpr int H = 32 * KSH, NCU = H / 32, KS4 = 4 * KSH, CH = 16;
+  constexpr int H = 32 * KSH, NCU = H / 32, KS4 = 4 * KSH;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, n = lane & 15;
   const int cu = blockIdx.x, tile = blockIdx.y, dir = blockIdx.z, tiles = gridDim.y;
   const int ut = cu * 2 + w, un = 16 * ut + 4 * g;
@@ -394,11 +394,14 @@ __global__ __launch_bounds__(128) void lstm_bwd_dist_kernel(LstmBwdDistArgs a) {
   const int brow = min(b0 + n, a.B - 1);
   const bool bvalid = b0 + n < a.B;
 
-  bf16x8 wf[KS4];
+  // W_hh^T fragments live in LDS (each lane re-reads only what it wrote, so no barrier): the registers
+  // they would take hold the whole incoming panel instead, so a step costs one memory round trip.
+  extern __shared__ bf16x8 wlds[];
+  bf16x8* wf = wlds + (size_t)w * KS4 * 64 + lane;
   {
     const bf16x8* wbase = a.whhT + (size_t)dir * (H / 16) * KS4 * 64 + lane;
-#pragma unroll
-    for (int ks = 0; ks < KS4; ++ks) wf[ks] = wbase[((size_t)ut * KS4 + ks) * 64];
+#pragma unroll 8
+    for (int ks = 0; ks < KS4; ++ks) wf[ks * 64] = wbase[((size_t)ut * KS4 + ks) * 64];
   }
   float dc[4] = {0.f, 0.f, 0.f, 0.f};
   const unsigned row_bytes = 4u * H * 2u;
@@ -439,22 +442,13 @@ __global__ __launch_bounds__(128) void lstm_bwd_dist_kernel(LstmBwdDistArgs a) {
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler ordering only: the loads below are sc1
       const unsigned pbase = (unsigned)(step & 1) * parity_bytes + group + (unsigned)n * row_bytes + (unsigned)g * 16u;
-      bf16x8 db[2][CH];
+      bf16x8 db[KS4];
 #pragma unroll
-      for (int i = 0; i < CH; ++i)
-        db[0][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, pbase + (unsigned)i * 64u, 0, 16));
+      for (int i = 0; i < KS4; ++i)
+        db[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, pbase + (unsigned)i * 64u, 0, 16));
+      __builtin_amdgcn_sched_barrier(0);  // every load in flight before the first MFMA waits
 #pragma unroll
-      for (int ch = 0; ch < KS4 / CH; ++ch) {
-        if (ch + 1 < KS4 / CH) {
-#pragma unroll
-          for (int i = 0; i < CH; ++i)
-            db[(ch + 1) & 1][i] = __builtin_bit_cast(
-                bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, pbase + (unsigned)((ch + 1) * CH + i) * 64u, 0, 16));
-        }
-#pragma unroll
-        for (int i = 0; i < CH; ++i)
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ch * CH + i], db[ch & 1][i], acc, 0, 0, 0);
-      }
+      for (int i = 0; i < KS4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i * 64], db[i], acc, 0, 0, 0);
     }
     const float iv[4] = {gq[0].x, gq[0].y, gq[0].z, gq[0].w}, fv[4] = {gq[1].x, gq[1].y, gq[1].z, gq[1].w};
     const float gv[4] = {gq[2].x, gq[2].y, gq[2].z, gq[2].w}, ov[4] = {gq[3].x, gq[3].y, gq[3].z, gq[3].w};
@@ -471,20 +465,22 @@ __global__ __launch_bounds__(128) void lstm_bwd_dist_kernel(LstmBwdDistArgs a) {
       da[3][r] = dh * tc * ov[r] * (1.f - ov[r]);
       dc[r] = dcc * fv[r];
     }
+    if (step + 1 < a.T) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (step + 1 < a.T) {
+      for (int q = 0; q < 4; ++q) {
         const v2u_t dp = {pack_bf2(da[q][0], da[q][1]), pack_bf2(da[q][2], da[q][3])};
         const unsigned off = (unsigned)((step + 1) & 1) * parity_bytes + group + (unsigned)n * row_bytes + (unsigned)(q * H + un) * 2u;
         __builtin_amdgcn_raw_buffer_store_b64(dp, rs, off, 0, 16);  // sc1: write-through
       }
-      if (bvalid)
-        *reinterpret_cast<float4*>(a.dgates + srow * 4 * H + q * H + un) = make_float4(da[q][0], da[q][1], da[q][2], da[q][3]);
-    }
-    if (step + 1 < a.T) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) __hip_atomic_store(fl + cu * FLAG_STRIDE, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // the kernel's own output goes out after the hand-off, off the other workgroups' critical path
+    if (bvalid) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(a.dgates + srow * 4 * H + q * H + un) = make_float4(da[q][0], da[q][1], da[q][2], da[q][3]);
     }
   }
 }
@@ -558,8 +554,15 @@ extern "C" int csship_lstm_bidir_bwd_dist(const float* gates, const float* c, co
   a.dx = reinterpret_cast<unsigned char*>(workspace) + sync_bytes;
   a.B = B; a.T = T;
   dim3 grid(ncu, tiles, 2);
-  if (H == 512) hipLaunchKernelGGL(lstm_bwd_dist_kernel<16>, grid, dim3(128), 0, s, a);
-  else hipLaunchKernelGGL(lstm_bwd_dist_kernel<8>, grid, dim3(128), 0, s, a);
+  const size_t lds = (size_t)2 * (H / 8) * 64 * 16;  // both waves' W_hh^T fragments
+  if (H == 512) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_dist_kernel<16>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (attr != hipSuccess) return CSSHIP_ELAUNCH;
+    hipLaunchKernelGGL(lstm_bwd_dist_kernel<16>, grid, dim3(128), lds, s, a);
+  } else {
+    hipLaunchKernelGGL(lstm_bwd_dist_kernel<8>, grid, dim3(128), lds, s, a);
+  }
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }
