@@ -176,11 +176,24 @@ DEV bf16x8 read_frag(const unsigned char* img, int r0, int ks, int lane) {
   }
 }
 
+// -DBG_STAMPS: per-workgroup cycle stamps of the main loop's phases (tools/bgemm_stamps.py); not part of the product build
+#ifdef BG_STAMPS
+__device__ unsigned* g_bg_stamps = nullptr;
+#define STAMP(i) do { if (tid == 0) stamps[(i)] = (unsigned)__builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
 // FAST: whole 8-element groups and operands below 4 GB -> descriptor loads with compile-time operand types.
 template <bool A_KM, bool B_KM, bool FAST, bool A_F32, bool B_F32>
 __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef BG_STAMPS
+  __shared__ unsigned stamps[96];
+  if (tid < 96) stamps[tid] = 0;
+  __syncthreads();
+  STAMP(0);
+#endif
   const int wm = wave >> 1, wn = wave & 1;
   const int lg = lane >> 4, ln = lane & 15;
   // XCD-aware tile order.  Workgroups go to the 8 XCDs round-robin by their linear id, and every XCD has its own L2:
@@ -236,11 +249,13 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
     store_operand<B_KM>(smem + 128 * 128, tid, rb, bf32);
   }
   __syncthreads();
+  STAMP(1);
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) {
       load_tile(kbeg + (kt + 1) * BK);
     }
     __builtin_amdgcn_sched_barrier(0);  // hipcc would sink the loads / hoist their conversion next to each other
+    if (kt < 12) STAMP(2 + kt * 5);  // loads requested
     const unsigned char* as = smem + (kt & 1) * STAGE;
     const unsigned char* bs = as + 128 * 128;
     // both k-steps' fragments are requested before the first MFMA: the second half's LDS reads run under the first
@@ -253,6 +268,10 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
         af[ks][i] = read_frag<A_KM>(as, wm * 64 + i * 16, ks, lane);
         bf[ks][i] = read_frag<B_KM>(bs, wn * 64 + i * 16, ks, lane);
       }
+#ifdef BG_STAMPS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (kt < 12) STAMP(3 + kt * 5);  // fragments read
+#endif
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -261,13 +280,17 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);  // C^T tile
     __builtin_amdgcn_sched_barrier(0);
+    if (kt < 12) STAMP(4 + kt * 5);  // MFMAs issued
     if (kt + 1 < nk) {
       unsigned char* nx = smem + ((kt + 1) & 1) * STAGE;
       store_operand<A_KM>(nx, tid, ra, af32);
       store_operand<B_KM>(nx + 128 * 128, tid, rb, bf32);
     }
+    if (kt < 12) STAMP(5 + kt * 5);  // next tile in LDS
     __syncthreads();
+    if (kt < 12) STAMP(6 + kt * 5);
   }
+  STAMP(62);
 
   // ---- epilogue.  The MFMAs compute the transposed tile (B fragment as the A operand), so acc[i][j][r] is
   //   row = m0 + wm*64 + i*16 + ln,  col = n0 + wn*64 + j*16 + lg*4 + r :
@@ -349,6 +372,15 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
       }
     }
   }
+#ifdef BG_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP(63);  // result stores drained
+  __syncthreads();
+  if (g_bg_stamps && tid < 96) {
+    const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    g_bg_stamps[lin * 96 + tid] = stamps[tid];
+  }
+#endif
 }
 
 // out[r, c] = alpha * sum_s slab[s][r, c] (+ bias[c]) (+ add[r, c]); fixed summation order.
@@ -464,6 +496,12 @@ int launch_slab_reduce(const float* slabs, int S, int64_t n, int N, int64_t ldc,
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }
+
+#ifdef BG_STAMPS
+extern "C" int csship_debug_bgemm_stamps(unsigned* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_bg_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" size_t csship_bgemm_workspace(const csship_bgemm_params* p) {
   if (!p) return 0;
