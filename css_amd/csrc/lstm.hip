@@ -120,17 +120,20 @@ struct LstmDistArgs {
   unsigned char* hx;    // [2 parity][2 dir][tiles][16][H] bf16
   unsigned* flags;      // [2 dir][tiles][H/32] * FLAG_STRIDE, zero at launch
   unsigned* err;        // zero at launch; 1 = a spin timed out
-  int B, T;
+  int B, T, tiles, allow_l2;
 };
 
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
 
-template <int KSH>  // H = 32 * KSH
-__global__ __launch_bounds__(128) void lstm_dist_kernel(LstmDistArgs a) {
+// AUX: cache-coherence bits of the hand-off STORE.  The loads are always sc1 (miss the CU's L1, served by the XCD's L2
+// or, for lines it does not hold, by memory).  16 = sc1 store: written through to memory, visible on every XCD.
+// 0 = plain store: stays in the producer's L2, which only the CUs of the same XCD read - a third of the round trip
+// (tools/micro/pingpong.hip: 0.34 us against 0.95 us), valid only when the whole group runs on one XCD.
+template <int KSH, int AUX>  // H = 32 * KSH
+DEV void lstm_dist_body(const LstmDistArgs& a, const int cu, const int tile, const int dir, const int tiles) {
   constexpr int H = 32 * KSH;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, n = lane & 15;
-  const int cu = blockIdx.x, tile = blockIdx.y, dir = blockIdx.z, tiles = gridDim.y;
   const int ut = cu * 2 + w, unit0 = 16 * ut;
   const int b0 = tile * 16;
   const int brow = min(b0 + n, a.B - 1);
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(128) void lstm_dist_kernel(LstmDistArgs a) {
       const unsigned ep = (unsigned)(step + 1);
       const v4u_t hp = {ep, pack_bf2(hv[0], hv[1]), ep, pack_bf2(hv[2], hv[3])};
       const unsigned off = (unsigned)((step + 1) & 1) * parity_bytes + group + (unsigned)n * row_bytes + (unsigned)un * 4u;
-      __builtin_amdgcn_raw_buffer_store_b128(hp, rs, off, 0, 16);  // sc1: write-through
+      __builtin_amdgcn_raw_buffer_store_b128(hp, rs, off, 0, AUX);  // sc1: write-through
     }
     const size_t srow = ((size_t)brow * a.T + t) * 2 + dir;
     if (bvalid) {
@@ -237,6 +240,40 @@ __global__ __launch_bounds__(128) void lstm_dist_kernel(LstmDistArgs a) {
       }
     }
   }
+}
+
+// Placement.  Workgroups are dealt to the 8 XCDs round-robin by linear id, and an XCD's CUs share one L2: a group
+// (one direction x 16 batch rows, H/32 workgroups) whose members all sit on ONE XCD can hand its state over through
+// that L2 (sc0 loads, ~4x shorter round trip) instead of through memory.  The 1-D grid is laid out so that group g
+// owns the ids = g (mod 8); nothing relies on it: every workgroup publishes the XCC_ID it actually runs on, the
+// group compares (bounded wait), and only a group that is provably co-located takes the L2 path - all members see
+// the same ids, so they all take the same path.
+DEV int lstm_group_colocated(unsigned* place, int slot, int n, unsigned* err) {
+  const int lane = threadIdx.x & 63;
+  const unsigned mine = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) + 1u;  // HW_REG_XCC_ID[3:0] + 1
+  if (threadIdx.x == 0) __hip_atomic_store(place + slot * FLAG_STRIDE + 1, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (unsigned spins = 0; spins < SPIN_LIMIT; ++spins) {
+    unsigned v = mine;
+    if (lane < n) v = __hip_atomic_load(place + lane * FLAG_STRIDE + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__all(v != 0u)) return __all(v == mine) ? 1 : 0;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return -1;
+}
+
+template <int KSH>
+__global__ __launch_bounds__(128) void lstm_dist_kernel(LstmDistArgs a) {
+  constexpr int NCU = KSH;  // H / 32
+  const int tiles = a.tiles, groups = 2 * tiles;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int g = xcd + 8 * (slot / NCU), cu = slot % NCU;
+  if (g >= groups) return;
+  const int dir = g / tiles, tile = g % tiles;
+  const int same = a.allow_l2 ? lstm_group_colocated(a.flags + (size_t)g * NCU * FLAG_STRIDE, cu, NCU, a.err) : 0;
+  if (same < 0) return;
+  if (same) lstm_dist_body<KSH, 0>(a, cu, tile, dir, tiles);
+  else lstm_dist_body<KSH, 16>(a, cu, tile, dir, tiles);
 }
 
 // ---- backward of the recurrence (BPTT).  Mirrors the forward: workgroup = (16 batch rows, direction), wave w owns
@@ -381,14 +418,13 @@ struct LstmBwdDistArgs {
   unsigned char* dx;    // exchange panels [2 parity][2 dir][tiles][16][4H] bf16
   unsigned* flags;
   unsigned* err;
-  int B, T;
+  int B, T, tiles, allow_l2;
 };
 
-template <int KSH>  // H = 32 * KSH
-__global__ __launch_bounds__(128) void lstm_bwd_dist_kernel(LstmBwdDistArgs a) {
+template <int KSH, int AUX>  // AUX as in lstm_dist_body: 16 = through memory, 0 = through the XCD's L2 (co-located group)
+DEV void lstm_bwd_dist_body(const LstmBwdDistArgs& a, const int cu, const int tile, const int dir, const int tiles) {
   constexpr int H = 32 * KSH, NCU = H / 32, KS4 = 4 * KSH;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, n = lane & 15;
-  const int cu = blockIdx.x, tile = blockIdx.y, dir = blockIdx.z, tiles = gridDim.y;
   const int ut = cu * 2 + w, un = 16 * ut + 4 * g;
   const int b0 = tile * 16;
   const int brow = min(b0 + n, a.B - 1);
@@ -470,11 +506,14 @@ __global__ __launch_bounds__(128) void lstm_bwd_dist_kernel(LstmBwdDistArgs a) {
       for (int q = 0; q < 4; ++q) {
         const v2u_t dp = {pack_bf2(da[q][0], da[q][1]), pack_bf2(da[q][2], da[q][3])};
         const unsigned off = (unsigned)((step + 1) & 1) * parity_bytes + group + (unsigned)n * row_bytes + (unsigned)(q * H + un) * 2u;
-        __builtin_amdgcn_raw_buffer_store_b64(dp, rs, off, 0, 16);  // sc1: write-through
+        __builtin_amdgcn_raw_buffer_store_b64(dp, rs, off, 0, AUX);  // sc1: write-through
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0) __hip_atomic_store(fl + cu * FLAG_STRIDE, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) {
+        if constexpr (AUX == 16) __hip_atomic_store(fl + cu * FLAG_STRIDE, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_store(fl + cu * FLAG_STRIDE, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
     }
     // the kernel's own output goes out after the hand-off, off the other workgroups' critical path
     if (bvalid) {
@@ -483,6 +522,20 @@ __global__ __launch_bounds__(128) void lstm_bwd_dist_kernel(LstmBwdDistArgs a) {
         *reinterpret_cast<float4*>(a.dgates + srow * 4 * H + q * H + un) = make_float4(da[q][0], da[q][1], da[q][2], da[q][3]);
     }
   }
+}
+
+template <int KSH>
+__global__ __launch_bounds__(128) void lstm_bwd_dist_kernel(LstmBwdDistArgs a) {
+  constexpr int NCU = KSH;  // H / 32
+  const int tiles = a.tiles, groups = 2 * tiles;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int g = xcd + 8 * (slot / NCU), cu = slot % NCU;
+  if (g >= groups) return;
+  const int dir = g / tiles, tile = g % tiles;
+  const int same = a.allow_l2 ? lstm_group_colocated(a.flags + (size_t)g * NCU * FLAG_STRIDE, cu, NCU, a.err) : 0;
+  if (same < 0) return;
+  if (same) lstm_bwd_dist_body<KSH, 0>(a, cu, tile, dir, tiles);
+  else lstm_bwd_dist_body<KSH, 16>(a, cu, tile, dir, tiles);
 }
 
 }  // namespace
@@ -524,8 +577,10 @@ extern "C" int csship_lstm_bidir_dist(const float* gx, const uint16_t* whh_packe
   a.flags = reinterpret_cast<unsigned*>(workspace);
   a.err = a.flags + 2 * (size_t)tiles * ncu * FLAG_STRIDE;
   a.hx = reinterpret_cast<unsigned char*>(workspace) + sync_bytes;
-  a.B = B; a.T = T;
-  dim3 grid(ncu, tiles, 2);
+  a.B = B; a.T = T; a.tiles = tiles;
+  static const bool l2_off = [] { const char* e = getenv("CSSHIP_LSTM_L2"); return e && e[0] == '0'; }();
+  a.allow_l2 = l2_off ? 0 : 1;
+  dim3 grid(8 * ncu * ((2 * tiles + 7) / 8));  // group g = ids congruent to g mod 8 (see lstm_group_colocated)
   if (H == 512) hipLaunchKernelGGL(lstm_dist_kernel<16>, grid, dim3(128), 0, s, a);
   else hipLaunchKernelGGL(lstm_dist_kernel<8>, grid, dim3(128), 0, s, a);
   CSSHIP_CHECK_LAUNCH();
@@ -552,8 +607,10 @@ extern "C" int csship_lstm_bidir_bwd_dist(const float* gates, const float* c, co
   a.flags = reinterpret_cast<unsigned*>(workspace);
   a.err = a.flags + 2 * (size_t)tiles * ncu * FLAG_STRIDE;
   a.dx = reinterpret_cast<unsigned char*>(workspace) + sync_bytes;
-  a.B = B; a.T = T;
-  dim3 grid(ncu, tiles, 2);
+  a.B = B; a.T = T; a.tiles = tiles;
+  static const bool l2_off = [] { const char* e = getenv("CSSHIP_LSTM_L2"); return e && e[0] == '0'; }();
+  a.allow_l2 = l2_off ? 0 : 1;
+  dim3 grid(8 * ncu * ((2 * tiles + 7) / 8));  // group g = ids congruent to g mod 8 (see lstm_group_colocated)
   const size_t lds = (size_t)2 * (H / 8) * 64 * 16;  // both waves' W_hh^T fragments
   if (H == 512) {
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_dist_kernel<16>),

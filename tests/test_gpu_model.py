@@ -183,7 +183,8 @@ def test_blstm_golden(golden):
     assert mse < 1e-4 and mask_mse(y_pred, torch.from_numpy(g["y_pred"])) < 1e-4
 
 
-@pytest.mark.parametrize("H,B,T", [(256, 1, 7), (256, 20, 33), (512, 16, 50), (512, 32, 400), (512, 35, 21)])
+@pytest.mark.parametrize("H,B,T", [(256, 1, 7), (256, 20, 33), (512, 16, 50), (512, 32, 400), (512, 35, 21), (512, 70, 9),
+                                   (256, 130, 5)])
 def test_lstm_distributed_recurrence_equals_single_cu_kernel(H, B, T):
     """csship_lstm_bidir_dist / csship_lstm_bidir_bwd_dist (W_hh in registers across H/32 CUs, state exchanged per step
     through write-through global panels + epoch flags) vs the single-CU kernels that stream W_hh: same arithmetic
