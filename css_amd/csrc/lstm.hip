@@ -121,6 +121,7 @@ struct LstmDistArgs {
   unsigned* flags;      // [2 dir][tiles][H/32] * FLAG_STRIDE, zero at launch
   unsigned* err;        // zero at launch; 1 = a spin timed out
   int B, T, tiles, allow_l2;
+  unsigned* stamps;     // -DLSTM_STAMPS only
 };
 
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
@@ -149,6 +150,7 @@ DEV void lstm_dist_body(const LstmDistArgs& a, const int cu, const int tile, con
       for (int ks = 0; ks < KSH; ++ks) wf[q][ks] = wbase[((size_t)(q * (H / 16) + ut) * KSH + ks) * 64];
   }
   float c[4] = {0.f, 0.f, 0.f, 0.f};
+  __shared__ bf16x8 xch[2 * KSH * 64];  // the step's h_{t-1} fragments, shared by the two waves (2 parities)
   // The exchanged panel carries its own validity: every two bf16 values travel as an 8-byte granule {epoch, value}
   // (epoch = step + 1, never 0; the panels are zeroed per launch), so the consumer polls the data itself - no flag,
   // no store drain, no barrier: one fabric round trip per step instead of three.  Row stride 4*H bytes.
@@ -165,8 +167,15 @@ DEV void lstm_dist_body(const LstmDistArgs& a, const int cu, const int tile, con
 #pragma unroll
     for (int q = 0; q < 4; ++q) gxn[q] = *reinterpret_cast<const float4*>(gxr + q * H);
   }
+#ifdef LSTM_STAMPS
+  __shared__ unsigned stamps[2][32][6];
+#define LSTAMP(i, v) do { if (lane == 0 && step >= 100 && step < 132) stamps[w][step - 100][(i)] = (v); } while (0)
+#else
+#define LSTAMP(i, v) do {} while (0)
+#endif
   for (int step = 0; step < a.T; ++step) {
     const int t = dir == 0 ? step : a.T - 1 - step;
+    LSTAMP(0, (unsigned)__builtin_readcyclecounter());
     f32x4 acc[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = f32x4{gxn[q].x, gxn[q].y, gxn[q].z, gxn[q].w};
@@ -179,37 +188,53 @@ DEV void lstm_dist_body(const LstmDistArgs& a, const int cu, const int tile, con
     if (step > 0) {
       // ---- h_{t-1}: this lane's B fragments are 8 consecutive units of row n per k-step = 4 granules = 32 bytes;
       // re-read (bounded) until every granule of the wave carries this step's epoch
-      const unsigned pbase = (unsigned)(step & 1) * parity_bytes + group + (unsigned)n * row_bytes + (unsigned)g * 32u;
-      bf16x8 hb[KSH];
+      // fragment order: piece (k-step, half) of all 64 lanes is 1 KB contiguous - one load instruction = 8 whole lines
+      const unsigned pbase = (unsigned)(step & 1) * parity_bytes + group + (unsigned)lane * 16u;
+      // The two waves need the same panel: each fetches half of its k-steps (the sc1 loads are the step's longest
+      // phase: ~2 us for 32 KB per wave), the halves meet in LDS (double-buffered by step parity, one bare barrier).
+      constexpr int KH = KSH / 2;
+      bf16x8 hh[KH];
       bool ok = false;
+      LSTAMP(1, (unsigned)__builtin_readcyclecounter());
+      const unsigned hbase = pbase + (unsigned)(w * KH) * 2048u;
       for (unsigned spins = 0; spins < SPIN_LIMIT; ++spins) {
         bool mine = true;
 #pragma unroll
-        for (int ks = 0; ks < KSH; ++ks) {
-          const v4u_t lo = __builtin_amdgcn_raw_buffer_load_b128(rs, pbase + (unsigned)ks * 128u, 0, 16);
-          const v4u_t hi = __builtin_amdgcn_raw_buffer_load_b128(rs, pbase + (unsigned)ks * 128u + 16u, 0, 16);
+        for (int ks = 0; ks < KH; ++ks) {
+          const v4u_t lo = __builtin_amdgcn_raw_buffer_load_b128(rs, hbase + (unsigned)ks * 2048u, 0, 16);
+          const v4u_t hi = __builtin_amdgcn_raw_buffer_load_b128(rs, hbase + (unsigned)ks * 2048u + 1024u, 0, 16);
           mine = mine && lo.x == (unsigned)step && lo.z == (unsigned)step && hi.x == (unsigned)step && hi.z == (unsigned)step;
           const v4u_t fr = {lo.y, lo.w, hi.y, hi.w};
-          hb[ks] = __builtin_bit_cast(bf16x8, fr);
+          hh[ks] = __builtin_bit_cast(bf16x8, fr);
         }
 #ifdef LSTM_NOEXCH
         mine = true;
 #endif
         if (__all(mine)) {
           ok = true;
+          LSTAMP(5, spins);
           break;
         }
         __builtin_amdgcn_s_sleep(1);
       }
       if (!ok) {
         if (lane == 0) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
+        return;  // (a wave that has ended no longer counts at the other wave's barrier)
       }
+      bf16x8* xs = xch + (size_t)(step & 1) * KSH * 64 + lane;
+#pragma unroll
+      for (int ks = 0; ks < KH; ++ks) xs[(w * KH + ks) * 64] = hh[ks];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // bare: __syncthreads() would also wait for the output stores and the gx prefetch
+      bf16x8 hb[KSH];
+#pragma unroll
+      for (int ks = 0; ks < KSH; ++ks) hb[ks] = xs[ks * 64];
 #pragma unroll
       for (int ks = 0; ks < KSH; ++ks)
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[q][ks], hb[ks], acc[q], 0, 0, 0);
     }
+    LSTAMP(2, (unsigned)__builtin_readcyclecounter());
     float hv[4];
     const int un = unit0 + 4 * g;
 #pragma unroll
@@ -224,9 +249,13 @@ DEV void lstm_dist_body(const LstmDistArgs& a, const int cu, const int tile, con
     if (step + 1 < a.T) {
       const unsigned ep = (unsigned)(step + 1);
       const v4u_t hp = {ep, pack_bf2(hv[0], hv[1]), ep, pack_bf2(hv[2], hv[3])};
-      const unsigned off = (unsigned)((step + 1) & 1) * parity_bytes + group + (unsigned)n * row_bytes + (unsigned)un * 4u;
+      // units un..un+3 of row n = half (un % 8) / 4 of the consumer lane (g = (un % 32) / 8, n)'s fragment of k-step un / 32
+      const unsigned piece = (unsigned)(un >> 5) * 2u + (unsigned)((un >> 2) & 1);
+      const unsigned off = (unsigned)((step + 1) & 1) * parity_bytes + group + piece * 1024u +
+                           ((unsigned)((un & 31) >> 3) * 16u + (unsigned)n) * 16u;
       __builtin_amdgcn_raw_buffer_store_b128(hp, rs, off, 0, AUX);  // sc1: write-through
     }
+    LSTAMP(3, (unsigned)__builtin_readcyclecounter());
     const size_t srow = ((size_t)brow * a.T + t) * 2 + dir;
     if (bvalid) {
       *reinterpret_cast<float4*>(a.out + ((size_t)brow * a.T + t) * 2 * H + dir * H + un) =
@@ -239,7 +268,14 @@ DEV void lstm_dist_body(const LstmDistArgs& a, const int cu, const int tile, con
         *reinterpret_cast<float4*>(a.c_out + srow * H + un) = make_float4(c[0], c[1], c[2], c[3]);
       }
     }
+    LSTAMP(4, (unsigned)__builtin_readcyclecounter());
   }
+#ifdef LSTM_STAMPS
+  if (a.stamps && lane < 32) {
+    unsigned* o = a.stamps + (((size_t)(dir * tiles + tile) * (H / 32) + cu) * 2 + w) * 32 * 6 + lane * 6;
+    for (int i = 0; i < 6; ++i) o[i] = stamps[w][lane][i];
+  }
+#endif
 }
 
 // Placement.  Workgroups are dealt to the 8 XCDs round-robin by linear id, and an XCD's CUs share one L2: a group
@@ -540,6 +576,11 @@ __global__ __launch_bounds__(128) void lstm_bwd_dist_kernel(LstmBwdDistArgs a) {
 
 }  // namespace
 
+#ifdef LSTM_STAMPS
+static unsigned* g_lstm_stamps = nullptr;
+extern "C" void csship_debug_lstm_stamps(unsigned* buf) { g_lstm_stamps = buf; }
+#endif
+
 extern "C" size_t csship_lstm_dist_workspace(int32_t B, int32_t H) {
   if (B <= 0 || (H != 256 && H != 512)) return 0;
   const size_t tiles = (size_t)(B + 15) / 16, ncu = (size_t)H / 32;
@@ -580,6 +621,9 @@ extern "C" int csship_lstm_bidir_dist(const float* gx, const uint16_t* whh_packe
   a.B = B; a.T = T; a.tiles = tiles;
   static const bool l2_off = [] { const char* e = getenv("CSSHIP_LSTM_L2"); return e && e[0] == '0'; }();
   a.allow_l2 = l2_off ? 0 : 1;
+#ifdef LSTM_STAMPS
+  a.stamps = g_lstm_stamps;
+#endif
   dim3 grid(8 * ncu * ((2 * tiles + 7) / 8));  // group g = ids congruent to g mod 8 (see lstm_group_colocated)
   if (H == 512) hipLaunchKernelGGL(lstm_dist_kernel<16>, grid, dim3(128), 0, s, a);
   else hipLaunchKernelGGL(lstm_dist_kernel<8>, grid, dim3(128), 0, s, a);
