@@ -513,11 +513,12 @@ DEV void lstm_bwd_dist_body(const LstmBwdDistArgs& a, const int cu, const int ti
         return;
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler ordering only: the loads below are sc1
-      const unsigned pbase = (unsigned)(step & 1) * parity_bytes + group + (unsigned)n * row_bytes + (unsigned)g * 16u;
+      // fragment order: the 64 lanes' fragments of one k-step are 1 KB contiguous (one load instruction = 8 whole lines)
+      const unsigned pbase = (unsigned)(step & 1) * parity_bytes + group + (unsigned)lane * 16u;
       bf16x8 db[KS4];
 #pragma unroll
       for (int i = 0; i < KS4; ++i)
-        db[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, pbase + (unsigned)i * 64u, 0, 16));
+        db[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, pbase + (unsigned)i * 1024u, 0, 16));
       __builtin_amdgcn_sched_barrier(0);  // every load in flight before the first MFMA waits
 #pragma unroll
       for (int i = 0; i < KS4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i * 64], db[i], acc, 0, 0, 0);
@@ -541,7 +542,10 @@ DEV void lstm_bwd_dist_body(const LstmBwdDistArgs& a, const int cu, const int ti
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const v2u_t dp = {pack_bf2(da[q][0], da[q][1]), pack_bf2(da[q][2], da[q][3])};
-        const unsigned off = (unsigned)((step + 1) & 1) * parity_bytes + group + (unsigned)n * row_bytes + (unsigned)(q * H + un) * 2u;
+        // reduction index k = q*H + un .. +3 of row n: half (k % 8) / 4 of consumer lane (g = (k % 32) / 8, n), k-step k / 32
+        const unsigned k = (unsigned)(q * H + un);
+        const unsigned off = (unsigned)((step + 1) & 1) * parity_bytes + group + (k >> 5) * 1024u +
+                             (((k & 31u) >> 3) * 16u + (unsigned)n) * 16u + ((k >> 2) & 1u) * 8u;
         __builtin_amdgcn_raw_buffer_store_b64(dp, rs, off, 0, AUX);  // sc1: write-through
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
