@@ -459,9 +459,11 @@ struct LstmBwdDistArgs {
 
 template <int KSH, int AUX>  // AUX as in lstm_dist_body: 16 = through memory, 0 = through the XCD's L2 (co-located group)
 DEV void lstm_bwd_dist_body(const LstmBwdDistArgs& a, const int cu, const int tile, const int dir, const int tiles) {
-  constexpr int H = 32 * KSH, NCU = H / 32, KS4 = 4 * KSH;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, n = lane & 15;
-  const int ut = cu * 2 + w, un = 16 * ut + 4 * g;
+  // one wave per workgroup, H/16 workgroups per group: a CU fetches the panel once (two waves of a workgroup would
+  // each fetch all of it), and the hand-off needs no barrier
+  constexpr int H = 32 * KSH, NCU = H / 16, KS4 = 4 * KSH;
+  const int lane = threadIdx.x, g = lane >> 4, n = lane & 15;
+  const int ut = cu, un = 16 * ut + 4 * g;
   const int b0 = tile * 16;
   const int brow = min(b0 + n, a.B - 1);
   const bool bvalid = b0 + n < a.B;
@@ -469,7 +471,7 @@ DEV void lstm_bwd_dist_body(const LstmBwdDistArgs& a, const int cu, const int ti
   // W_hh^T fragments live in LDS (each lane re-reads only what it wrote, so no barrier): the registers
   // they would take hold the whole incoming panel instead, so a step costs one memory round trip.
   extern __shared__ bf16x8 wlds[];
-  bf16x8* wf = wlds + (size_t)w * KS4 * 64 + lane;
+  bf16x8* wf = wlds + lane;
   {
     const bf16x8* wbase = a.whhT + (size_t)dir * (H / 16) * KS4 * 64 + lane;
 #pragma unroll 8
@@ -549,8 +551,7 @@ DEV void lstm_bwd_dist_body(const LstmBwdDistArgs& a, const int cu, const int ti
         __builtin_amdgcn_raw_buffer_store_b64(dp, rs, off, 0, AUX);  // sc1: write-through
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) {
+      if (lane == 0) {
         if constexpr (AUX == 16) __hip_atomic_store(fl + cu * FLAG_STRIDE, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else __hip_atomic_store(fl + cu * FLAG_STRIDE, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
@@ -565,8 +566,8 @@ DEV void lstm_bwd_dist_body(const LstmBwdDistArgs& a, const int cu, const int ti
 }
 
 template <int KSH>
-__global__ __launch_bounds__(128) void lstm_bwd_dist_kernel(LstmBwdDistArgs a) {
-  constexpr int NCU = KSH;  // H / 32
+__global__ __launch_bounds__(64) void lstm_bwd_dist_kernel(LstmBwdDistArgs a) {
+  constexpr int NCU = 2 * KSH;  // H / 16
   const int tiles = a.tiles, groups = 2 * tiles;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int g = xcd + 8 * (slot / NCU), cu = slot % NCU;
@@ -587,14 +588,14 @@ extern "C" void csship_debug_lstm_stamps(unsigned* buf) { g_lstm_stamps = buf; }
 
 extern "C" size_t csship_lstm_dist_workspace(int32_t B, int32_t H) {
   if (B <= 0 || (H != 256 && H != 512)) return 0;
-  const size_t tiles = (size_t)(B + 15) / 16, ncu = (size_t)H / 32;
+  const size_t tiles = (size_t)(B + 15) / 16, ncu = (size_t)H / 16;  // the backward runs H/16 workgroups per group
   const size_t sync_bytes = (2 * tiles * ncu * FLAG_STRIDE + 16) * sizeof(unsigned);  // flags + error word, 64-byte multiple
   return sync_bytes + 2 * 2 * tiles * 16 * (size_t)(4 * H) * 2;  // sized for the backward's 4H-wide panels
 }
 
 extern "C" size_t csship_lstm_dist_workspace_error_offset(int32_t B, int32_t H) {
   if (B <= 0 || (H != 256 && H != 512)) return 0;
-  return 2 * ((size_t)(B + 15) / 16) * ((size_t)H / 32) * FLAG_STRIDE * sizeof(unsigned);
+  return 2 * ((size_t)(B + 15) / 16) * ((size_t)H / 16) * FLAG_STRIDE * sizeof(unsigned);
 }
 
 extern "C" int csship_lstm_bidir_dist(const float* gx, const uint16_t* whh_packed, float* out, float* gates_out,
@@ -609,9 +610,9 @@ extern "C" int csship_lstm_bidir_dist(const float* gx, const uint16_t* whh_packe
     return CSSHIP_EALIGN;
   const size_t need = csship_lstm_dist_workspace(B, H);
   if (workspace_bytes < need) return CSSHIP_EWORKSPACE;
-  const int tiles = (B + 15) / 16, ncu = H / 32;
+  const int tiles = (B + 15) / 16, ncu = H / 32, nslot = H / 16;  // sync region: sized for the backward's H/16 workgroups
   if (tiles > 65535 || 2 * (size_t)tiles * ncu > 2048) return CSSHIP_EBADSHAPE;  // all workgroups must be resident together
-  const size_t sync_bytes = (2 * (size_t)tiles * ncu * FLAG_STRIDE + 16) * sizeof(unsigned);
+  const size_t sync_bytes = (2 * (size_t)tiles * nslot * FLAG_STRIDE + 16) * sizeof(unsigned);
   hipStream_t s = as_stream(stream);
   // error word + this call's tagged panels (2 parities x 2 directions x tiles x 16 rows x 4H bytes): epoch tags
   // of an earlier call must not be mistaken for this one's
@@ -620,7 +621,7 @@ extern "C" int csship_lstm_bidir_dist(const float* gx, const uint16_t* whh_packe
   LstmDistArgs a{};
   a.gx = gx; a.whh = reinterpret_cast<const bf16x8*>(whh_packed); a.out = out; a.gates_out = gates_out; a.c_out = c_out;
   a.flags = reinterpret_cast<unsigned*>(workspace);
-  a.err = a.flags + 2 * (size_t)tiles * ncu * FLAG_STRIDE;
+  a.err = a.flags + 2 * (size_t)tiles * nslot * FLAG_STRIDE;
   a.hx = reinterpret_cast<unsigned char*>(workspace) + sync_bytes;
   a.B = B; a.T = T; a.tiles = tiles;
   static const bool l2_off = [] { const char* e = getenv("CSSHIP_LSTM_L2"); return e && e[0] == '0'; }();
@@ -645,8 +646,8 @@ extern "C" int csship_lstm_bidir_bwd_dist(const float* gates, const float* c, co
       !aligned16(workspace))
     return CSSHIP_EALIGN;
   if (workspace_bytes < csship_lstm_dist_workspace(B, H)) return CSSHIP_EWORKSPACE;
-  const int tiles = (B + 15) / 16, ncu = H / 32;
-  if (tiles > 65535 || 2 * (size_t)tiles * ncu > 2048) return CSSHIP_EBADSHAPE;
+  const int tiles = (B + 15) / 16, ncu = H / 16;  // one-wave workgroups of 16 hidden units
+  if (tiles > 65535 || 2 * (size_t)tiles * ncu > 4096) return CSSHIP_EBADSHAPE;
   const size_t sync_bytes = (2 * (size_t)tiles * ncu * FLAG_STRIDE + 16) * sizeof(unsigned);
   hipStream_t s = as_stream(stream);
   if (hipMemsetAsync(workspace, 0, sync_bytes, s) != hipSuccess) return CSSHIP_ELAUNCH;
@@ -659,15 +660,9 @@ extern "C" int csship_lstm_bidir_bwd_dist(const float* gates, const float* c, co
   static const bool l2_off = [] { const char* e = getenv("CSSHIP_LSTM_L2"); return e && e[0] == '0'; }();
   a.allow_l2 = l2_off ? 0 : 1;
   dim3 grid(8 * ncu * ((2 * tiles + 7) / 8));  // group g = ids congruent to g mod 8 (see lstm_group_colocated)
-  const size_t lds = (size_t)2 * (H / 8) * 64 * 16;  // both waves' W_hh^T fragments
-  if (H == 512) {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_dist_kernel<16>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    if (attr != hipSuccess) return CSSHIP_ELAUNCH;
-    hipLaunchKernelGGL(lstm_bwd_dist_kernel<16>, grid, dim3(128), lds, s, a);
-  } else {
-    hipLaunchKernelGGL(lstm_bwd_dist_kernel<8>, grid, dim3(128), lds, s, a);
-  }
+  const size_t lds = (size_t)(H / 8) * 64 * 16;  // the wave's W_hh^T fragments (64 KB at H = 512)
+  if (H == 512) hipLaunchKernelGGL(lstm_bwd_dist_kernel<16>, grid, dim3(64), lds, s, a);
+  else hipLaunchKernelGGL(lstm_bwd_dist_kernel<8>, grid, dim3(64), lds, s, a);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }
