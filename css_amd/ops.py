@@ -266,8 +266,16 @@ def _targets_array(targets, B, T, F):
 _LSTM_WS = {}  # (device index, stream, B, H) -> workspace of the distributed recurrence
 
 
-def lstm_dist_enabled(H):
-    return H in (256, 512) and os.environ.get("CSS_AMD_LSTM_DIST", "1") != "0"
+def lstm_dist_enabled(H, B=1, backward=False):
+    """The distributed recurrence needs all its workgroups resident at once (256 CUs): the forward runs H/32 two-wave
+    workgroups per (16 batch rows, direction), two to a CU; the backward H/16 one-wave workgroups holding W_hh^T in
+    LDS (64 KB at H = 512: two to a CU; 32 KB at H = 256: four).  Larger batches take the single-CU kernels."""
+    if H not in (256, 512) or os.environ.get("CSS_AMD_LSTM_DIST", "1") == "0":
+        return False
+    groups = 2 * ((B + 15) // 16)
+    if backward:
+        return groups * (H // 16) <= 256 * (2 if H == 512 else 4)
+    return groups * (H // 32) <= 512
 
 
 def lstm_bidir(gx, whh_packed, B, T, H, keep=False):
@@ -279,7 +287,7 @@ def lstm_bidir(gx, whh_packed, B, T, H, keep=False):
     y = torch.empty((B, T, 2 * H), dtype=torch.float32, device=dev)
     gates = torch.empty((B, T, 2, 4 * H), dtype=torch.float32, device=dev) if keep else None
     c = torch.empty((B, T, 2, H), dtype=torch.float32, device=dev) if keep else None
-    if lstm_dist_enabled(H):
+    if lstm_dist_enabled(H, B):
         key = (dev.index, _stream() or 0, B, H)
         ws = _LSTM_WS.get(key)
         if ws is None:

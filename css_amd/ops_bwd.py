@@ -272,7 +272,7 @@ def lstm_bidir_bwd(gates, c, dy, whhT_packed):
     H = H4 // 4
     dy = dy.contiguous()
     dg = torch.empty_like(gates)
-    if ops.lstm_dist_enabled(H):
+    if ops.lstm_dist_enabled(H, B, backward=True):
         key = (gates.device.index, _stream() or 0, B, H)
         ws = ops._LSTM_WS.get(key)
         if ws is None:

@@ -201,7 +201,7 @@ def test_lstm_distributed_recurrence_equals_single_cu_kernel(H, B, T):
     g0 = torch.empty((B, T, 2, 4 * H), device=DEV)
     c0 = torch.empty((B, T, 2, H), device=DEV)
     check(lib().csship_lstm_bidir_train(gx.data_ptr(), whh.data_ptr(), y0.data_ptr(), g0.data_ptr(), c0.data_ptr(), B, T, H, None))
-    assert ops.lstm_dist_enabled(H)
+    assert ops.lstm_dist_enabled(H, B) and ops.lstm_dist_enabled(H, B, backward=True)
     for it in range(3):
         y1, g1, c1 = ops.lstm_bidir(gx, whh, B, T, H, keep=True)
         ops.lstm_dist_check()
