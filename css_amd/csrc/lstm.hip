@@ -108,6 +108,7 @@ __global__ __launch_bounds__(512) void lstm_kernel(LstmArgs a) {
 //            panel with sc1 loads - every load of a handed-off byte is an sc1 load, so no acquire fence is needed.
 // Nothing depends on dispatch order or placement; all workgroups of a group must be resident together (64 workgroups of
 // 128 threads at B = 32, H = 512), and every spin is bounded: on a timeout the error word is set and the kernel exits.
+constexpr int LSTM_NW = 2;                 // waves per forward workgroup, 16 hidden units each (4 measured: 2.71 vs 2.66 us per step)
 constexpr int FLAG_STRIDE = 16;            // 32-bit words between flags (one 64-byte line each)
 constexpr unsigned SPIN_LIMIT = 1u << 21;  // ~1 s
 
@@ -135,7 +136,7 @@ template <int KSH, int AUX>  // H = 32 * KSH
 DEV void lstm_dist_body(const LstmDistArgs& a, const int cu, const int tile, const int dir, const int tiles) {
   constexpr int H = 32 * KSH;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, n = lane & 15;
-  const int ut = cu * 2 + w, unit0 = 16 * ut;
+  const int ut = cu * LSTM_NW + w, unit0 = 16 * ut;
   const int b0 = tile * 16;
   const int brow = min(b0 + n, a.B - 1);
   const bool bvalid = b0 + n < a.B;
@@ -168,7 +169,7 @@ DEV void lstm_dist_body(const LstmDistArgs& a, const int cu, const int tile, con
     for (int q = 0; q < 4; ++q) gxn[q] = *reinterpret_cast<const float4*>(gxr + q * H);
   }
 #ifdef LSTM_STAMPS
-  __shared__ unsigned stamps[2][32][6];
+  __shared__ unsigned stamps[LSTM_NW][32][6];
 #define LSTAMP(i, v) do { if (lane == 0 && step >= 100 && step < 132) stamps[w][step - 100][(i)] = (v); } while (0)
 #else
 #define LSTAMP(i, v) do {} while (0)
@@ -192,7 +193,7 @@ DEV void lstm_dist_body(const LstmDistArgs& a, const int cu, const int tile, con
       const unsigned pbase = (unsigned)(step & 1) * parity_bytes + group + (unsigned)lane * 16u;
       // The two waves need the same panel: each fetches half of its k-steps (the sc1 loads are the step's longest
       // phase: ~2 us for 32 KB per wave), the halves meet in LDS (double-buffered by step parity, one bare barrier).
-      constexpr int KH = KSH / 2;
+      constexpr int KH = KSH / LSTM_NW;
       bf16x8 hh[KH];
       bool ok = false;
       LSTAMP(1, (unsigned)__builtin_readcyclecounter());
@@ -272,7 +273,7 @@ DEV void lstm_dist_body(const LstmDistArgs& a, const int cu, const int tile, con
   }
 #ifdef LSTM_STAMPS
   if (a.stamps && lane < 32) {
-    unsigned* o = a.stamps + (((size_t)(dir * tiles + tile) * (H / 32) + cu) * 2 + w) * 32 * 6 + lane * 6;
+    unsigned* o = a.stamps + (((size_t)(dir * tiles + tile) * (H / (16 * LSTM_NW)) + cu) * LSTM_NW + w) * 32 * 6 + lane * 6;
     for (int i = 0; i < 6; ++i) o[i] = stamps[w][lane][i];
   }
 #endif
@@ -299,8 +300,8 @@ DEV int lstm_group_colocated(unsigned* place, int slot, int n, unsigned* err) {
 }
 
 template <int KSH>
-__global__ __launch_bounds__(128) void lstm_dist_kernel(LstmDistArgs a) {
-  constexpr int NCU = KSH;  // H / 32
+__global__ __launch_bounds__(64 * LSTM_NW) void lstm_dist_kernel(LstmDistArgs a) {
+  constexpr int NCU = 2 * KSH / LSTM_NW;  // H / (16 * LSTM_NW)
   const int tiles = a.tiles, groups = 2 * tiles;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int g = xcd + 8 * (slot / NCU), cu = slot % NCU;
@@ -610,7 +611,7 @@ extern "C" int csship_lstm_bidir_dist(const float* gx, const uint16_t* whh_packe
     return CSSHIP_EALIGN;
   const size_t need = csship_lstm_dist_workspace(B, H);
   if (workspace_bytes < need) return CSSHIP_EWORKSPACE;
-  const int tiles = (B + 15) / 16, ncu = H / 32, nslot = H / 16;  // sync region: sized for the backward's H/16 workgroups
+  const int tiles = (B + 15) / 16, ncu = H / (16 * LSTM_NW), nslot = H / 16;  // sync region: sized for the backward's H/16 workgroups
   if (tiles > 65535 || 2 * (size_t)tiles * ncu > 2048) return CSSHIP_EBADSHAPE;  // all workgroups must be resident together
   const size_t sync_bytes = (2 * (size_t)tiles * nslot * FLAG_STRIDE + 16) * sizeof(unsigned);
   hipStream_t s = as_stream(stream);
@@ -630,8 +631,8 @@ extern "C" int csship_lstm_bidir_dist(const float* gx, const uint16_t* whh_packe
   a.stamps = g_lstm_stamps;
 #endif
   dim3 grid(8 * ncu * ((2 * tiles + 7) / 8));  // group g = ids congruent to g mod 8 (see lstm_group_colocated)
-  if (H == 512) hipLaunchKernelGGL(lstm_dist_kernel<16>, grid, dim3(128), 0, s, a);
-  else hipLaunchKernelGGL(lstm_dist_kernel<8>, grid, dim3(128), 0, s, a);
+  if (H == 512) hipLaunchKernelGGL(lstm_dist_kernel<16>, grid, dim3(64 * LSTM_NW), 0, s, a);
+  else hipLaunchKernelGGL(lstm_dist_kernel<8>, grid, dim3(64 * LSTM_NW), 0, s, a);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }
