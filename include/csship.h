@@ -115,7 +115,11 @@ int csship_lstm_bidir(const float* gx, const uint16_t* whh_packed, float* out, i
 
 /* The same recurrence spread over H/32 CUs per (16 batch rows, direction): every wave keeps the W_hh rows of its 16
  * hidden units in registers for the whole sequence and the workgroups exchange h_t once per step through a
- * write-through global panel + epoch flags (agent-scope hand-off, bounded spins).  H = 256 or 512; identical results.
+ * global panel of epoch-tagged values (bounded spins).  A group whose workgroups all run on one XCD (checked per
+ * launch from the hardware's XCC_ID) hands over through that XCD's L2, any other placement through memory with
+ * write-through stores; the environment variable CSSHIP_LSTM_L2=0 forces the latter.  All workgroups of a group must
+ * be resident together: 2 * ceil(B/16) * H/32 workgroups of 128 threads here, 2 * ceil(B/16) * H/16 workgroups of 64
+ * threads (64 KB of LDS at H = 512) in csship_lstm_bidir_bwd_dist.  H = 256 or 512; identical results.
  * gates_out / c_out: both NULL, or both given (training: activated gates f32 [B, T, 2, 4H], cell states f32
  * [B, T, 2, H]).  workspace: csship_lstm_dist_workspace(B, H) bytes (0 = unsupported shape), 16-byte aligned; its
  * head is zeroed by the call.  After the stream has drained, the 32-bit word at workspace +
@@ -496,9 +500,9 @@ int csship_lstm_bidir_train(const float* gx, const uint16_t* whh_packed, float* 
                             float* c_out, int32_t B, int32_t T, int32_t H, csship_stream_t stream);
 int csship_lstm_bidir_bwd(const float* gates, const float* c, const float* dy, const uint16_t* whhT_packed,
                           float* dgates, int32_t B, int32_t T, int32_t H, csship_stream_t stream);
-/* Back-propagation through time spread over H/32 CUs per (16 batch rows, direction) like csship_lstm_bidir_dist (W_hh^T
- * rows in registers, the previous step's gate gradients exchanged per step); H = 256 or 512, identical results, same
- * workspace contract. */
+/* Back-propagation through time spread over H/16 one-wave workgroups per (16 batch rows, direction) like
+ * csship_lstm_bidir_dist (W_hh^T rows in LDS, the previous step's gate gradients exchanged per step behind epoch
+ * flags); H = 256 or 512, identical results, same workspace and placement contract. */
 int csship_lstm_bidir_bwd_dist(const float* gates, const float* c, const float* dy, const uint16_t* whhT_packed,
                                float* dgates, int32_t B, int32_t T, int32_t H, void* workspace,
                                size_t workspace_bytes, csship_stream_t stream);
