@@ -8,9 +8,9 @@ Forward values ALWAYS come from the HIP kernels.  Backward:
     operator's input; hidden activations are recomputed in the backward;
   * masks -> parameters, BLSTM (``BlstmTrain``): back-propagation-through-time kernel for the recurrence, the same
     GEMM / LayerNorm backward kernels for the rest;
-  * anything else (BLSTM hidden sizes that are not a multiple of 32, ``force_twin_backward``): ``MasksWithTwinBackward`` - the gradient is obtained by
-    re-evaluating a differentiable PyTorch-ROCm restatement of the model ("twin", GPU torch ops, fp32) and
-    back-propagating grad_masks through it.  The twin never produces a forward result that is returned.
+  * anything else (Conformer widths other than 256 / 512, BLSTM hidden sizes the BPTT kernel does not tile) raises
+    NotImplementedError: there is no torch-op arithmetic path in this package (the fp32 autograd references the tests
+    compare against live in oracle/ and tests/).
 """
 import torch
 
@@ -50,30 +50,6 @@ class PitMse(torch.autograd.Function):
         masks, f_orig, perm, *targets = ctx.saved_tensors
         g = ops.pit_mse_bwd(masks, f_orig, targets, perm, ctx.n_masks, 1.0)
         return (g * grad_loss,) + (None,) * (2 + len(targets))
-
-
-class MasksWithTwinBackward(torch.autograd.Function):
-    """masks = model.forward_masks(f) on the HIP path; d masks / d params through the model's torch twin."""
-
-    @staticmethod
-    def forward(ctx, model, f, *params):
-        ctx.model = model
-        ctx.save_for_backward(f)
-        ctx.n_params = len(params)
-        return model._forward_masks_hip(f)
-
-    @staticmethod
-    def backward(ctx, grad_masks):
-        (f,) = ctx.saved_tensors
-        model = ctx.model
-        params = [p for p in model.parameters()]
-        with torch.enable_grad():
-            out = model._twin_forward_masks(f.detach())
-            need = [p for p in params if p.requires_grad]
-            grads = torch.autograd.grad(out, need, grad_masks.contiguous(), allow_unused=True)
-        it = iter(grads)
-        full = tuple(next(it) if p.requires_grad else None for p in params)
-        return (None, None) + full
 
 
 def _conformer_pack_plan(model, wide, device):
@@ -391,11 +367,16 @@ class BlstmTrain(torch.autograd.Function):
 def masks_for_training(model, f):
     params = tuple(model.parameters())
     enc = getattr(model, "conformer", None)
-    if enc is not None and enc.d_model in (256, 512) and enc.d_model // enc.n_head == 64 and enc.kernel_size == 33 \
-            and enc.d_ffn % 64 == 0 and not getattr(model, "force_twin_backward", False):
-        return ConformerTrain.apply(model, f, *params)
-    if hasattr(model, "blstm") and not getattr(model, "force_twin_backward", False):
+    if enc is not None:
+        if enc.d_model in (256, 512) and enc.d_model // enc.n_head == 64 and enc.kernel_size == 33 and enc.d_ffn % 64 == 0:
+            return ConformerTrain.apply(model, f, *params)
+        raise NotImplementedError("css_amd: the Conformer backward kernels cover d_model 256 / 512 with 64-wide heads, "
+                                  "kernel 33 and d_ffn % 64 == 0; got "
+                                  f"d_model {enc.d_model}, {enc.n_head} heads, kernel {enc.kernel_size}, d_ffn {enc.d_ffn}")
+    if hasattr(model, "blstm"):
         H = model.blstm.hidden_dim // 2
         if H % 16 == 0 and (H <= 128 or H % 128 == 0) and H <= 512 and model.blstm.hidden_dim <= 1024:
             return BlstmTrain.apply(model, f, *params)
-    return MasksWithTwinBackward.apply(model, f, *params)
+        raise NotImplementedError("css_amd: the BLSTM back-propagation-through-time kernel covers hidden_dim = 32k up to "
+                                  f"256 and 512, 768, 1024; got {model.blstm.hidden_dim}")
+    raise NotImplementedError(f"css_amd: no backward for {type(model).__name__}")

@@ -24,6 +24,7 @@
 //   * online softmax over key tiles; key padding mask is always None on this path
 //     (conformer.py:97), only the T tail of the last tile is masked.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -261,6 +262,442 @@ __global__ __launch_bounds__(256, 4) void mha_relpos_kernel(const unsigned short
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Forward attention, second generation (the inference / training forward; mha_relpos_kernel above stays for the
+// backward's recomputation of the probabilities).
+//
+// What changed against mha_relpos_kernel, and why (rocprof / PMC of round 1: 29.9 us per launch at 32 x 4 x 400,
+// MFMA pipe 21 % busy, 4.0x the algorithmic traffic, two workgroup barriers per 64-key tile; ablation builds of this
+// kernel, tools/attn_ablate.sh: the position band alone cost 8 of 25 us while its 12 fragment loads per wave and tile
+// came straight from global memory - the CU's texture-address path takes ~18 cycles per wave-wide load):
+//   * a workgroup is NW = 8 (4) waves and every wave owns a PAIR of 16-query blocks (32 queries): a workgroup covers up
+//     to 256 queries of one (b, h), so each K/V tile is fetched by ceil(T/256) workgroups instead of ceil(T/64), and the
+//     K and V^T fragments a wave reads from LDS feed two MFMAs each;
+//   * the position blocks live in an LDS RING shared by the workgroup: at key tile j0 its waves need the 2 NW + 4
+//     consecutive blocks (i0 - j0)/16 - 4 .. + 2 NW - 1, the next tile the same window moved down by four, so every
+//     tile only FOUR new blocks (8 KB) enter the ring - one 1-KB fragment per wave - instead of 12 KB per wave;
+//   * K/V tiles are double buffered in LDS: tile j+1 (and the ring's four new blocks) travel global -> registers during
+//     tile j's work and are written at the end of the iteration: ONE workgroup barrier per key tile;
+//   * the band's rel-shift is done by the STORE: every band value is written straight to the place in the wave's
+//     scratch where its consumer's 16-byte accumulator load takes it from (a per-lane, per-register base that is fixed
+//     for the whole kernel + an immediate per band tile), and the band of tile j+1 is computed during tile j's
+//     exponentials (it depends on nothing but q and the ring);
+//   * row sums come from one extra MFMA per k-step against a fragment of ones (the matrix pipe has slack, the vector
+//     pipe does not), so the normaliser is the sum of the SAME bf16-rounded probabilities that multiply V; the cross
+//     lane part of the row maximum uses v_permlane16/32_swap instead of two ds_bpermute round trips;
+//   * workgroups of one (b, h) get ids that are equal mod 8 (the dispatcher deals ids round-robin over the XCDs), so
+//     the second fetch of that head's K/V hits the same L2.  Speed only: nothing depends on the placement.
+// Measured at 32 x 4 x 400 (graph replay, tools/bench_kernels.py attn): 24.2 us against 30.1 us.  What bounds it now
+// (PMC + per-wave phase stamps, tools/attn_stamps.py, profiles/r02_attn_*): instruction ISSUE.  A wave issues for 39 %
+// of its cycles (VALU incl. MFMA 57 %, scalar 23 %, LDS 17 % of that), the two waves of a SIMD are served strictly
+// oldest first (waves 0-3 pass the exp + band phase in 1 775 cycles per tile, waves 4-7 in 3 035 and the older half
+// waits for them at the barrier; s_setprio on the younger half just swaps the roles, running them half a tile out
+// of phase changes nothing), so the SIMD's issue port is ~90 % busy.  The next step is fewer, fatter instructions:
+// 32x32x16 MFMAs (half the matrix instructions, 12 + 16 LDS instructions for the rel-shift instead of 48), see DESIGN.md.
+#ifndef A2_ABL
+#define A2_ABL 0  // diagnostic builds only (tools/attn_ablate.sh): bit 0 no band, 1 no softmax, 2 no P.V, 3 no staging, 4 no S
+#endif
+#ifdef A2_STAMPS  // diagnostic build: per-wave cycle sums of the loop's phases -> stamps[(wg * NW + wave) * 8 + phase]
+#define A2_T(i)                                                                                          \
+  {                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    unsigned long long t_;                                                                               \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    acc_[i] += t_ - tl_;                                                                                 \
+    tl_ = t_;                                                                                            \
+  }
+#else
+#define A2_T(i)
+#endif
+constexpr int A2_KV = 64 * 128;   // one K (or V) tile in LDS
+constexpr int A2_PQ = 6 * 256;    // band scratch floats per wave: 1 KB pad | 4 key blocks x [16 queries][16 keys] | 1 KB pad
+
+DEV float vmax(float a, float b) {  // bare v_max_f32 (fmaxf adds a canonicalising v_max per MFMA-produced operand)
+  float d;
+  asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+DEV float vmax3(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+DEV float xmax16(float x) {  // max over the four 16-lane rows of the wave (same column n), in all lanes
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  const unsigned a0 = r[0], a1 = r[1];
+  const float y = vmax(__uint_as_float(a0), __uint_as_float(a1));
+  auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+  const unsigned b0 = q[0], b1 = q[1];
+  return vmax(__uint_as_float(b0), __uint_as_float(b1));
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mha_fwd_kernel(const unsigned short* __restrict__ qkv,
+                                                            const bf16x8* __restrict__ pe_packed, int q_min, int q_max,
+                                                            unsigned short* __restrict__ out, float* __restrict__ lse,
+                                                            int BH, int T, int H, int G, int ppw,
+                                                            unsigned long long* stamps) {
+  constexpr int CH = 512 / (NW * 64);  // 16-byte chunks of a K (and of a V) tile staged per thread
+  constexpr int R = 2 * NW + 8;        // ring slots (position blocks of 2 x 1 KB): 2 NW + 4 live + 4 arriving
+  constexpr int NF = 8 / NW;           // new fragments staged per wave and tile
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * A2_KV + R * 2048 + NW * A2_PQ * 4];
+  unsigned char* const sK = smem;                   // [2][64 x 128 B]
+  unsigned char* const sV = smem + 2 * A2_KV;       // [2][64 x 128 B]
+  unsigned char* const sR = smem + 4 * A2_KV;       // [R][2 k-steps][64 lanes x 16 B]
+  float* const sP = reinterpret_cast<float*>(smem + 4 * A2_KV + R * 2048);
+  (void)sP;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, n = lane & 15;
+  int bh, gi;
+  {
+    const int id = blockIdx.x;
+    if ((BH & 7) == 0) {  // ids equal mod 8 share an XCD: give them to one (b, h)
+      const int per = 8 * G, blk = id / per, r = id - blk * per;
+      bh = blk * 8 + (r & 7);
+      gi = r >> 3;
+    } else {
+      bh = id / G;
+      gi = id - bh * G;
+    }
+  }
+  const int b = bh / H, h = bh - b * H;
+  const int D = H * 64, D3 = 3 * D;
+  const size_t base_b = (size_t)b * T;
+  const int P = (T + 31) >> 5;
+  const int pair = gi * ppw + w;
+  const bool owner = (w < ppw) && (pair < P);                   // wave-uniform; the others repeat a neighbour's work
+  const int i0g = 32 * gi * ppw;                                // first query of the workgroup
+  const int i0w = 32 * min(gi * ppw + min(w, ppw - 1), P - 1);  // and only help with staging and barriers
+
+  bf16x8 qf[2][2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int qi = min(i0w + 16 * qb + n, T - 1);
+    const unsigned short* qrow = qkv + (base_b + qi) * D3 + h * 64;
+    qf[qb][0] = *reinterpret_cast<const bf16x8*>(qrow + 8 * g);
+    qf[qb][1] = *reinterpret_cast<const bf16x8*>(qrow + 32 + 8 * g);
+  }
+
+  // K/V staging: chunk idx = tid + c * NW*64 -> (row = idx >> 3, 16-byte chunk = idx & 7)
+  const int sc = tid & 7;
+  uint4 kreg0, kreg1, vreg0, vreg1;  // named registers: small arrays written under `if (more)` are demoted to scratch
+  kreg1 = vreg1 = make_uint4(0u, 0u, 0u, 0u);
+#define A2_LOAD_KV(J0)                                                                                     \
+  {                                                                                                        \
+    const unsigned short* s_ = qkv + (base_b + min((J0) + (tid >> 3), T - 1)) * D3 + D + h * 64 + sc * 8;  \
+    kreg0 = *reinterpret_cast<const uint4*>(s_);                                                           \
+    vreg0 = *reinterpret_cast<const uint4*>(s_ + D);                                                       \
+    if constexpr (CH > 1) {                                                                                \
+      s_ = qkv + (base_b + min((J0) + (tid >> 3) + NW * 8, T - 1)) * D3 + D + h * 64 + sc * 8;             \
+      kreg1 = *reinterpret_cast<const uint4*>(s_);                                                         \
+      vreg1 = *reinterpret_cast<const uint4*>(s_ + D);                                                     \
+    }                                                                                                      \
+  }
+#define A2_STORE_KV(BUF)                                                                                   \
+  {                                                                                                        \
+    *reinterpret_cast<uint4*>(sK + (BUF) * A2_KV + tile_off(tid >> 3, sc)) = kreg0;                        \
+    *reinterpret_cast<uint4*>(sV + (BUF) * A2_KV + v_off(tid >> 3, sc)) = vreg0;                           \
+    if constexpr (CH > 1) {                                                                                \
+      *reinterpret_cast<uint4*>(sK + (BUF) * A2_KV + tile_off((tid >> 3) + NW * 8, sc)) = kreg1;           \
+      *reinterpret_cast<uint4*>(sV + (BUF) * A2_KV + v_off((tid >> 3) + NW * 8, sc)) = vreg1;              \
+    }                                                                                                      \
+  }
+  // ---- the position-block ring.  Block q (16 reversed rows of pe_k, clamp baked in; csship.h) sits in slot q mod R
+  // as two lane-linear 1-KB fragments.  At key tile j0 the workgroup reads blocks qlo .. qlo + 2 NW + 3,
+  // qlo = (i0g - j0)/16 - 4; blocks qlo - 4 .. qlo - 1 are the next tile's newcomers.
+  const bf16x8* pe_lane = pe_packed + lane;
+  auto ring_slot = [](int q) { const int m = q % R; return m < 0 ? m + R : m; };
+  auto pe_src = [&](int q, int ks) {
+    const int qi_ = min(max(q, q_min), q_max) - q_min;
+    return pe_lane + (size_t)(qi_ * 2 + ks) * 64;
+  };
+  bf16x8 nf0, nf1;  // staged newcomers (NW = 8: one fragment per wave; NW = 4: one block = two fragments)
+  nf1 = bf16x8{};
+#define A2_LOAD_RING(J0) /* the four blocks below tile J0's window... i.e. tile J0's own lowest four */    \
+  {                                                                                                        \
+    const int qn_ = (i0g - (J0)) / 16 - 4;                                                                 \
+    if constexpr (NF == 1) nf0 = *pe_src(qn_ + (w >> 1), w & 1);                                           \
+    else { nf0 = *pe_src(qn_ + w, 0); nf1 = *pe_src(qn_ + w, 1); }                                         \
+  }
+#define A2_STORE_RING(J0)                                                                                  \
+  {                                                                                                        \
+    const int qn_ = (i0g - (J0)) / 16 - 4;                                                                 \
+    if constexpr (NF == 1)                                                                                 \
+      *reinterpret_cast<bf16x8*>(sR + (ring_slot(qn_ + (w >> 1)) * 2 + (w & 1)) * 1024 + lane * 16) = nf0; \
+    else {                                                                                                 \
+      *reinterpret_cast<bf16x8*>(sR + (ring_slot(qn_ + w) * 2) * 1024 + lane * 16) = nf0;                  \
+      *reinterpret_cast<bf16x8*>(sR + (ring_slot(qn_ + w) * 2 + 1) * 1024 + lane * 16) = nf1;              \
+    }                                                                                                      \
+  }
+
+  f32x4 o[2][4], lsum[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[qb][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    lsum[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  float m_run[2] = {-1e30f, -1e30f};
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+  // Band scratch of this wave, laid out for the CONSUMER: query n's 64 values of a key tile as [key block tc][n][16],
+  // so lane (g, n) reads its accumulator registers of key block tc with one 16-byte load at tc*256 + 16 n + 4 g.
+  // The producer (band tile t, lane (g, n), register r) holds relative offset c = 16 t + 4 g + r, which is key
+  // k = c - (15 - n) of the tile: it stores to (k >> 4) * 256 + 16 n + (k & 15) = base_r + 256 t with a per-lane,
+  // per-register base that is fixed for the whole kernel.  Of the five band tiles exactly one of t = 0 / t = 4 falls
+  // outside the 64 keys for every (lane, r): those stores land in a 1-KB pad below / above the four key blocks.
+  float* const Pw = sP + w * A2_PQ + 256;
+  float* pwr[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int k0 = 4 * g + r + n - 15;  // key (may be negative) of band tile 0's value
+    pwr[r] = Pw + 16 * n + (k0 >= 0 ? k0 : k0 + 16 - 256);
+  }
+  const float* const prd = Pw + 16 * n + 4 * g;
+  const int q4 = n >> 2, p4 = n & 3;
+
+  // band of key tile J0 for both query blocks -> scratch -> s (the S^T accumulators' initial value).  One query block
+  // after the other through the SAME scratch: LDS operations of one wave execute in order, so the skew reads see the
+  // stores before them and the second block's stores cannot overtake the first block's reads.
+#define A2_BAND()                                                                                                        \
+  {                                                                                                                      \
+    /* block u = 0..5 of the pair sits in slot rs0 - u (mod R); query block qb uses u = t + 1 - qb */                    \
+    bf16x8 pf[6][2];                                                                                                     \
+    _Pragma("unroll") for (int u = 0; u < 6; ++u) {                                                                      \
+      const int sl_ = rs0 - u + ((rs0 - u) < 0 ? R : 0);                                                                 \
+      const unsigned char* fr = sR + sl_ * 2048 + lane * 16;                                                             \
+      pf[u][0] = *reinterpret_cast<const bf16x8*>(fr);                                                                   \
+      pf[u][1] = *reinterpret_cast<const bf16x8*>(fr + 1024);                                                            \
+    }                                                                                                                    \
+    rs0 = rs0 - 4 + (rs0 < 4 ? R : 0); /* the next tile's window sits four blocks lower */                               \
+    f32x4 pb[2][5];                                                                                                      \
+    _Pragma("unroll") for (int qb = 0; qb < 2; ++qb) {                                                                   \
+      _Pragma("unroll") for (int t = 0; t < 5; ++t) pb[qb][t] = f32x4{0.f, 0.f, 0.f, 0.f};                               \
+      _Pragma("unroll") for (int t = 0; t < 5; ++t)                                                                      \
+        pb[qb][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[t + 1 - qb][0], qf[qb][0], pb[qb][t], 0, 0, 0);           \
+      _Pragma("unroll") for (int t = 0; t < 5; ++t)                                                                      \
+        pb[qb][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[t + 1 - qb][1], qf[qb][1], pb[qb][t], 0, 0, 0);           \
+    }                                                                                                                    \
+    _Pragma("unroll") for (int qb = 0; qb < 2; ++qb) {                                                                   \
+      /* the skew is done by the STORE: each band value goes straight to the place its consumer's 16-byte read takes */ \
+      _Pragma("unroll") for (int t = 0; t < 5; ++t)                                                                      \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) pwr[r][256 * t] = pb[qb][t][r];                                    \
+      _Pragma("unroll") for (int t = 0; t < 4; ++t) s[qb][t] = *reinterpret_cast<const f32x4*>(prd + 256 * t);           \
+    }                                                                                                                    \
+  }
+#define A2_BAND_WAIT() {}
+
+  stamp(stamps, 0);
+  A2_LOAD_KV(0)
+  {  // the whole ring: the windows of key tiles 0 and 64 (the band runs one tile ahead), 2 R fragments, NW at a time
+    const int qlo = i0g / 16 - 8;
+#pragma unroll
+    for (int f0 = 0; f0 < 2 * R; f0 += NW) {
+      const int f = f0 + w;
+      *reinterpret_cast<bf16x8*>(sR + (ring_slot(qlo + (f >> 1)) * 2 + (f & 1)) * 1024 + lane * 16) = *pe_src(qlo + (f >> 1), f & 1);
+    }
+  }
+  A2_STORE_KV(0)
+  __syncthreads();
+  stamp(stamps, 1);
+
+  // Software pipeline: the band of tile j+1 depends on nothing but q and the ring, so it is computed DURING tile j's
+  // softmax (matrix work beside vector work) and parked in s as the next S^T's initial value while P.V runs.
+  if ((A2_ABL & 32) && w >= NW / 2) return;  // diagnostic (with bit 3): one wave per SIMD
+#ifdef A2_DELAY
+  if (w >= NW / 2) __builtin_amdgcn_s_sleep(A2_DELAY);  // diagnostic (with bit 3): the younger half runs out of phase
+#endif
+  f32x4 s[2][4];
+  int rs0 = ring_slot(i0w / 16 + 1);  // slot of the pair's highest block at the tile the NEXT A2_BAND works on
+  A2_BAND()
+  int cur = 0;
+#ifdef A2_STAMPS
+  unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_)::"memory");
+#endif
+  for (int j0 = 0; j0 < T; j0 += 64, cur ^= 1) {
+    const bool more = j0 + 64 < T;
+    if (more && !(A2_ABL & 8)) {  // in flight during this tile's work; written to LDS at the end of the iteration
+      A2_LOAD_KV(j0 + 64)
+      if (j0 + 128 < T) A2_LOAD_RING(j0 + 128)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- S^T += K Q^T
+    const unsigned char* const kt = sK + cur * A2_KV;
+    const unsigned char* const vt = sV + cur * A2_KV;
+    A2_BAND_WAIT()
+#pragma unroll
+    for (int ks = 0; ks < ((A2_ABL & 16) ? 0 : 2); ++ks) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(kt + tile_off(16 * t + n, ks * 4 + g));
+        s[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[0][ks], s[0][t], 0, 0, 0);
+        s[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[1][ks], s[1][t], 0, 0, 0);
+      }
+    }
+    if (!more) {  // only the last key tile has a tail
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (j0 + 16 * t + 4 * g + r >= T) s[qb][t][r] = -1e30f;
+      asm volatile("" ::: "memory");
+    }
+    A2_T(0)
+
+    // ---- online softmax, part 1: running maxima and (rarely) the rescale of what has been accumulated
+    float mscaled[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      float mx = vmax3(s[qb][0][0], s[qb][0][1], s[qb][0][2]);
+      mx = vmax3(mx, s[qb][0][3], s[qb][1][0]);
+      mx = vmax3(mx, s[qb][1][1], s[qb][1][2]);
+      mx = vmax3(mx, s[qb][1][3], s[qb][2][0]);
+      mx = vmax3(mx, s[qb][2][1], s[qb][2][2]);
+      mx = vmax3(mx, s[qb][2][3], s[qb][3][0]);
+      mx = vmax3(mx, s[qb][3][1], s[qb][3][2]);
+      mx = vmax(mx, s[qb][3][3]);
+      mx = xmax16(mx);
+      const float m_new = vmax(m_run[qb], mx);
+      mscaled[qb] = m_new * LOG2E;
+      if (__any(m_new != m_run[qb])) {  // rescale only when some query's running maximum moved
+        const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * LOG2E);
+        lsum[qb] *= alpha;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[qb][i] *= alpha;
+        m_run[qb] = m_new;
+      }
+    }
+    A2_T(1)
+    // ---- part 2: P = exp2(S log2e - m log2e) as bf16 MFMA operands ...
+    bf16x8 pbf[2][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      if (!(A2_ABL & 2)) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[qb][t][r] = __builtin_amdgcn_exp2f(s[qb][t][r] * LOG2E - mscaled[qb]);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          pbf[qb][ks][e] = (__bf16)s[qb][2 * ks][e];
+          pbf[qb][ks][4 + e] = (__bf16)s[qb][2 * ks + 1][e];
+        }
+    }
+    // ---- ... beside the NEXT tile's position band (same basic block: the scheduler interleaves the two streams)
+    // (no branch: after the last tile it works on ring slots nobody needs and its result is dropped)
+    if (!(A2_ABL & 1)) A2_BAND()
+    else {
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s[qb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    A2_T(2)
+    // ---- O^T += V^T P^T.  k index of the MFMA <-> key j = 32ks + 16*(e>>2) + 4g + (e&3); V^T fragments feed both blocks;
+    // the row sums are one more MFMA per k-step: sum_j 1 . P^T[j, i] (every row of the result holds it)
+    if (A2_ABL & 4) {
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) asm volatile("" ::"v"(pbf[qb][ks]));
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int r0 = 32 * ks + 4 * g + q4, r1 = r0 + 16;
+        lsum[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pbf[0][ks], lsum[0], 0, 0, 0);
+        lsum[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pbf[1][ks], lsum[1], 0, 0, 0);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const unsigned char* a0 = vt + v_off(r0, 2 * dt + (p4 >> 1)) + (p4 & 1) * 8;
+          const unsigned char* a1 = vt + v_off(r1, 2 * dt + (p4 >> 1)) + (p4 & 1) * 8;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a1));
+          const bf16x8 av = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+          o[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pbf[0][ks], o[0][dt], 0, 0, 0);
+          o[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pbf[1][ks], o[1][dt], 0, 0, 0);
+        }
+      }
+    }
+
+    A2_T(3)
+    if (more && !(A2_ABL & 8)) {
+      A2_STORE_KV(cur ^ 1)   // last read during the previous iteration: everyone has passed that iteration's barrier
+      // the ring's newcomers are tile j0 + 128's lowest four blocks: their slots held blocks above tile j0 + 64's
+      // window, last read for tile j0's band one iteration ago
+      if (j0 + 128 < T) A2_STORE_RING(j0 + 128)
+      A2_T(4)
+      __syncthreads();
+      A2_T(5)
+    }
+  }
+#ifdef A2_STAMPS
+  if (stamps != nullptr && lane == 0)
+    for (int i = 0; i < 8; ++i) stamps[((size_t)blockIdx.x * NW + w) * 8 + i] = acc_[i];
+#endif
+#undef A2_BAND
+#undef A2_LOAD_KV
+#undef A2_STORE_KV
+#undef A2_LOAD_RING
+#undef A2_STORE_RING
+
+  stamp(stamps, 2);
+  if (!owner) return;
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const float l = lsum[qb][0];
+    const float inv = 1.f / l;
+    const int qi = i0w + 16 * qb + n;
+    if (lse != nullptr && qi < T && g == 0) lse[((size_t)b * H + h) * T + qi] = m_run[qb] + __logf(l);
+    if (qi < T) {
+      unsigned short* orow = out + (base_b + qi) * D + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        uint2 v;
+        v.x = pack_bf2(o[qb][dt][0] * inv, o[qb][dt][1] * inv);
+        v.y = pack_bf2(o[qb][dt][2] * inv, o[qb][dt][3] * inv);
+        *reinterpret_cast<uint2*>(orow + 16 * dt + 4 * g) = v;
+      }
+    }
+  }
+}
+
+// Host side of mha_fwd_kernel: pairs of 16-query blocks, dealt to workgroups of 8 (or 4) waves.
+static int launch_mha_fwd(const uint16_t* qkv, const uint16_t* pe_packed, int q_min, int q_max, uint16_t* out, float* lse,
+                          int B, int T, int H, unsigned long long* stamps, hipStream_t s) {
+  const int P = (T + 31) / 32, BH = B * H;
+  // 8 waves unless 4-wave workgroups are needed to give every CU one (short utterances, small batches)
+  const int G8 = (P + 7) / 8, G4 = (P + 3) / 4;
+  const bool four = (BH * G8 <= 128) && (G4 > G8);  // (a 4-wave workgroup's 84 KB of LDS leaves one workgroup per CU)
+  const int G = four ? G4 : G8, ppw = (P + G - 1) / G;
+  const long long nwg = (long long)BH * G;
+  if (nwg > 0x7fffffffLL) return CSSHIP_EBADSHAPE;
+  if (four)
+    hipLaunchKernelGGL(mha_fwd_kernel<4>, dim3((unsigned)nwg), dim3(256), 0, s, qkv, reinterpret_cast<const bf16x8*>(pe_packed),
+                       q_min, q_max, out, lse, BH, T, H, G, ppw, stamps);
+  else
+    hipLaunchKernelGGL(mha_fwd_kernel<8>, dim3((unsigned)nwg), dim3(512), 0, s, qkv, reinterpret_cast<const bf16x8*>(pe_packed),
+                       q_min, q_max, out, lse, BH, T, H, G, ppw, stamps);
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
+static bool attn_v1() {  // diagnostic switch: CSSHIP_ATTN_V1=1 runs the first-generation forward kernel (A/B timing)
+  static const bool v = [] { const char* e = getenv("CSSHIP_ATTN_V1"); return e && e[0] == '1'; }();
+  return v;
+}
+
 // ---- softmax backward of the attention, attention-shaped (backward pass; replaces a [B,H,T,T] f32 dP buffer):
 //   dS[b,h,i,j] = P[i,j] * (dO_i . v_j - D[b,h,i]),   D = rowsum(dO o O)
 // Same tiling as the forward: workgroup = (b, h, 64 queries), wave = 16 queries, 64-key tiles of V staged in LDS in
@@ -361,6 +798,7 @@ extern "C" int csship_mha_relpos(const uint16_t* qkv, const uint16_t* pe_packed,
   if (!qkv || !pe_packed || !out) return CSSHIP_ENULL;
   if (B <= 0 || T <= 0 || H <= 0 || q_max < q_min || B > 65535 || H > 65535) return CSSHIP_EBADSHAPE;
   if (!aligned16(qkv) || !aligned16(pe_packed) || !aligned8(out)) return CSSHIP_EALIGN;
+  if (!attn_v1()) return launch_mha_fwd(qkv, pe_packed, q_min, q_max, out, nullptr, B, T, H, g_csship_stamps, as_stream(stream));
   dim3 grid((T + 63) / 64, H, B);
   hipLaunchKernelGGL(mha_relpos_kernel<false>, grid, dim3(256), 0, as_stream(stream), qkv,
                      reinterpret_cast<const bf16x8*>(pe_packed), q_min, q_max, out, B, T, H, g_csship_stamps, nullptr,
@@ -375,6 +813,7 @@ extern "C" int csship_mha_relpos_train(const uint16_t* qkv, const uint16_t* pe_p
   if (!qkv || !pe_packed || !out || !lse) return CSSHIP_ENULL;
   if (B <= 0 || T <= 0 || H <= 0 || q_max < q_min || B > 65535 || H > 65535) return CSSHIP_EBADSHAPE;
   if (!aligned16(qkv) || !aligned16(pe_packed) || !aligned8(out)) return CSSHIP_EALIGN;
+  if (!attn_v1()) return launch_mha_fwd(qkv, pe_packed, q_min, q_max, out, lse, B, T, H, nullptr, as_stream(stream));
   dim3 grid((T + 63) / 64, H, B);
   hipLaunchKernelGGL(mha_relpos_kernel<false>, grid, dim3(256), 0, as_stream(stream), qkv,
                      reinterpret_cast<const bf16x8*>(pe_packed), q_min, q_max, out, B, T, H, nullptr, lse, (int64_t)0);

@@ -120,8 +120,10 @@ struct LstmDistArgs {
   float* c_out;         // optional (training)
   unsigned char* hx;    // [2 parity][2 dir][tiles][16][H] bf16
   unsigned* flags;      // [2 dir][tiles][H/32] * FLAG_STRIDE, zero at launch
-  unsigned* err;        // zero at launch; 1 = a spin timed out
+  unsigned* err;        // STICKY: outside the per-launch memset, only ever set (1 = a spin timed out); read and cleared
+                        // by the host at its own synchronisation points (css_amd.ops.lstm_dist_check)
   int B, T, tiles, allow_l2;
+  unsigned tag0;        // per-launch salt << 16: a granule left by an earlier launch can never carry this launch's tag
   unsigned* stamps;     // -DLSTM_STAMPS only
 };
 
@@ -153,7 +155,8 @@ DEV void lstm_dist_body(const LstmDistArgs& a, const int cu, const int tile, con
   float c[4] = {0.f, 0.f, 0.f, 0.f};
   __shared__ bf16x8 xch[2 * KSH * 64];  // the step's h_{t-1} fragments, shared by the two waves (2 parities)
   // The exchanged panel carries its own validity: every two bf16 values travel as an 8-byte granule {epoch, value}
-  // (epoch = step + 1, never 0; the panels are zeroed per launch), so the consumer polls the data itself - no flag,
+  // (epoch = tag0 + step + 1, never 0; tag0 = a per-launch salt in the high half, and the panels are zeroed per launch
+  // as well), so the consumer polls the data itself - no flag,
   // no store drain, no barrier: one fabric round trip per step instead of three.  Row stride 4*H bytes.
   const unsigned row_bytes = 4u * H;
   const unsigned group = (unsigned)(dir * tiles + tile) * 16u * row_bytes;
@@ -204,7 +207,8 @@ DEV void lstm_dist_body(const LstmDistArgs& a, const int cu, const int tile, con
         for (int ks = 0; ks < KH; ++ks) {
           const v4u_t lo = __builtin_amdgcn_raw_buffer_load_b128(rs, hbase + (unsigned)ks * 2048u, 0, 16);
           const v4u_t hi = __builtin_amdgcn_raw_buffer_load_b128(rs, hbase + (unsigned)ks * 2048u + 1024u, 0, 16);
-          mine = mine && lo.x == (unsigned)step && lo.z == (unsigned)step && hi.x == (unsigned)step && hi.z == (unsigned)step;
+          const unsigned want = a.tag0 + (unsigned)step;
+          mine = mine && lo.x == want && lo.z == want && hi.x == want && hi.z == want;
           const v4u_t fr = {lo.y, lo.w, hi.y, hi.w};
           hh[ks] = __builtin_bit_cast(bf16x8, fr);
         }
@@ -248,7 +252,7 @@ DEV void lstm_dist_body(const LstmDistArgs& a, const int cu, const int tile, con
     }
     // ---- publish h_t: two granules {epoch = step + 1, 2 x bf16}, one 16-byte write-through store
     if (step + 1 < a.T) {
-      const unsigned ep = (unsigned)(step + 1);
+      const unsigned ep = a.tag0 + (unsigned)(step + 1);
       const v4u_t hp = {ep, pack_bf2(hv[0], hv[1]), ep, pack_bf2(hv[2], hv[3])};
       // units un..un+3 of row n = half (un % 8) / 4 of the consumer lane (g = (un % 32) / 8, n)'s fragment of k-step un / 32
       const unsigned piece = (unsigned)(un >> 5) * 2u + (unsigned)((un >> 2) & 1);
@@ -454,8 +458,9 @@ struct LstmBwdDistArgs {
   float* dgates;        // [B, T, 2, 4H]
   unsigned char* dx;    // exchange panels [2 parity][2 dir][tiles][16][4H] bf16
   unsigned* flags;
-  unsigned* err;
+  unsigned* err;        // sticky, as in LstmDistArgs
   int B, T, tiles, allow_l2;
+  unsigned tag0;        // per-launch salt << 16 added to the epoch flags
 };
 
 template <int KSH, int AUX>  // AUX as in lstm_dist_body: 16 = through memory, 0 = through the XCD's L2 (co-located group)
@@ -503,9 +508,10 @@ DEV void lstm_bwd_dist_body(const LstmBwdDistArgs& a, const int cu, const int ti
     if (step > 0) {
       bool ok = false;
       for (unsigned spins = 0; spins < SPIN_LIMIT; ++spins) {
-        unsigned v = (unsigned)step;
+        const unsigned want = a.tag0 + (unsigned)step;  // flags are zero at launch and only grow: tag0 + 1 .. tag0 + T
+        unsigned v = want;
         if (lane < NCU) v = __hip_atomic_load(fl + lane * FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__all(v >= (unsigned)step)) {
+        if (__all(v >= want && v - a.tag0 <= (unsigned)a.T)) {
           ok = true;
           break;
         }
@@ -553,8 +559,8 @@ DEV void lstm_bwd_dist_body(const LstmBwdDistArgs& a, const int cu, const int ti
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) {
-        if constexpr (AUX == 16) __hip_atomic_store(fl + cu * FLAG_STRIDE, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else __hip_atomic_store(fl + cu * FLAG_STRIDE, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if constexpr (AUX == 16) __hip_atomic_store(fl + cu * FLAG_STRIDE, a.tag0 + (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_store(fl + cu * FLAG_STRIDE, a.tag0 + (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
     // the kernel's own output goes out after the hand-off, off the other workgroups' critical path
@@ -591,12 +597,21 @@ extern "C" size_t csship_lstm_dist_workspace(int32_t B, int32_t H) {
   if (B <= 0 || (H != 256 && H != 512)) return 0;
   const size_t tiles = (size_t)(B + 15) / 16, ncu = (size_t)H / 16;  // the backward runs H/16 workgroups per group
   const size_t sync_bytes = (2 * tiles * ncu * FLAG_STRIDE + 16) * sizeof(unsigned);  // flags + error word, 64-byte multiple
-  return sync_bytes + 2 * 2 * tiles * 16 * (size_t)(4 * H) * 2;  // sized for the backward's 4H-wide panels
+  return sync_bytes + 2 * 2 * tiles * 16 * (size_t)(4 * H) * 2 + 64;  // the backward's 4H-wide panels + the sticky error line
 }
 
+// The error word is STICKY: it lives in the last 64 bytes of the workspace, which no launch ever clears (the caller
+// zeroes the workspace once when it allocates it).  A timed-out hand-off in any launch sets it; the host reads and
+// clears it at its own synchronisation points.
 extern "C" size_t csship_lstm_dist_workspace_error_offset(int32_t B, int32_t H) {
-  if (B <= 0 || (H != 256 && H != 512)) return 0;
-  return 2 * ((size_t)(B + 15) / 16) * ((size_t)H / 16) * FLAG_STRIDE * sizeof(unsigned);
+  const size_t n = csship_lstm_dist_workspace(B, H);
+  return n ? n - 64 : 0;
+}
+
+static unsigned lstm_launch_tag() {  // 1 .. 0x7fff in the high half; eager launches never repeat a recent tag
+  static unsigned counter = 0;
+  counter = counter % 0x7fffu + 1u;
+  return counter << 16;
 }
 
 extern "C" int csship_lstm_bidir_dist(const float* gx, const uint16_t* whh_packed, float* out, float* gates_out,
@@ -604,7 +619,7 @@ extern "C" int csship_lstm_bidir_dist(const float* gx, const uint16_t* whh_packe
                                       size_t workspace_bytes, csship_stream_t stream) {
   if (!gx || !whh_packed || !out || !workspace) return CSSHIP_ENULL;
   if ((gates_out == nullptr) != (c_out == nullptr)) return CSSHIP_ENULL;
-  if (B <= 0 || T <= 0) return CSSHIP_EBADSHAPE;
+  if (B <= 0 || T <= 0 || T > 65534) return CSSHIP_EBADSHAPE;
   if (H != 256 && H != 512) return CSSHIP_EUNSUPPORTED;
   if (!aligned16(gx) || !aligned16(whh_packed) || !aligned16(out) || !aligned16(workspace) ||
       (gates_out && (!aligned16(gates_out) || !aligned16(c_out))))
@@ -622,9 +637,10 @@ extern "C" int csship_lstm_bidir_dist(const float* gx, const uint16_t* whh_packe
   LstmDistArgs a{};
   a.gx = gx; a.whh = reinterpret_cast<const bf16x8*>(whh_packed); a.out = out; a.gates_out = gates_out; a.c_out = c_out;
   a.flags = reinterpret_cast<unsigned*>(workspace);
-  a.err = a.flags + 2 * (size_t)tiles * nslot * FLAG_STRIDE;
+  a.err = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(workspace) + csship_lstm_dist_workspace_error_offset(B, H));
   a.hx = reinterpret_cast<unsigned char*>(workspace) + sync_bytes;
   a.B = B; a.T = T; a.tiles = tiles;
+  a.tag0 = lstm_launch_tag();
   static const bool l2_off = [] { const char* e = getenv("CSSHIP_LSTM_L2"); return e && e[0] == '0'; }();
   a.allow_l2 = l2_off ? 0 : 1;
 #ifdef LSTM_STAMPS
@@ -641,7 +657,7 @@ extern "C" int csship_lstm_bidir_bwd_dist(const float* gates, const float* c, co
                                           float* dgates, int32_t B, int32_t T, int32_t H, void* workspace,
                                           size_t workspace_bytes, csship_stream_t stream) {
   if (!gates || !c || !dy || !whhT_packed || !dgates || !workspace) return CSSHIP_ENULL;
-  if (B <= 0 || T <= 0) return CSSHIP_EBADSHAPE;
+  if (B <= 0 || T <= 0 || T > 65534) return CSSHIP_EBADSHAPE;
   if (H != 256 && H != 512) return CSSHIP_EUNSUPPORTED;
   if (!aligned16(gates) || !aligned16(c) || !aligned16(dy) || !aligned16(whhT_packed) || !aligned16(dgates) ||
       !aligned16(workspace))
@@ -655,9 +671,10 @@ extern "C" int csship_lstm_bidir_bwd_dist(const float* gates, const float* c, co
   LstmBwdDistArgs a{};
   a.gates = gates; a.c = c; a.dy = dy; a.whhT = reinterpret_cast<const bf16x8*>(whhT_packed); a.dgates = dgates;
   a.flags = reinterpret_cast<unsigned*>(workspace);
-  a.err = a.flags + 2 * (size_t)tiles * ncu * FLAG_STRIDE;
+  a.err = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(workspace) + csship_lstm_dist_workspace_error_offset(B, H));
   a.dx = reinterpret_cast<unsigned char*>(workspace) + sync_bytes;
   a.B = B; a.T = T; a.tiles = tiles;
+  a.tag0 = lstm_launch_tag();
   static const bool l2_off = [] { const char* e = getenv("CSSHIP_LSTM_L2"); return e && e[0] == '0'; }();
   a.allow_l2 = l2_off ? 0 : 1;
   dim3 grid(8 * ncu * ((2 * tiles + 7) / 8));  // group g = ids congruent to g mod 8 (see lstm_group_colocated)

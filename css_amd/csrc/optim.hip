@@ -3,7 +3,10 @@
 // for the norm).  Two launches, no host round trip: the clip coefficient is read from device memory.
 //   1. sqnorm: per-workgroup partial sums of g^2 (fixed order) -> one-workgroup reduce -> norm
 //   2. adam:   c = min(1, max_norm / (norm + 1e-6)); g' = c g; m, v moments; p -= lr (m/bc1) / (sqrt(v/bc2) + eps)
-//      (skipped entirely when the norm is not finite, like the reference's isnan guard around optimizer.step()).
+//      The update is skipped entirely when the norm is not finite.  DEVIATION from the reference, which has no such
+//      guard around optimizer.step() (it only refuses to SAVE a checkpoint after a NaN epoch loss, train.py:313): a
+//      non-finite gradient there poisons the parameters, here it costs one step (the host-side step counter and
+//      the bias corrections still advance).
 #include "common.hpp"
 
 namespace {

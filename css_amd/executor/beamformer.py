@@ -80,16 +80,19 @@ class Beamformer:
         return result_spec / mvdr_energy * masked_energy
 
     # ------------------------------------------------------------------ the session loop, beamformer.py:32-124
-    def _spans(self, first, count, total):
+    def _spans(self, first, count, total, batch_end=None):
         """Which samples of each beamformed window go where (beamformer.py:104-118): window k = first + i keeps
         [0, margin) if it starts the session, [margin - hop, end) if its batch ends the session, else the hop-long
         piece [margin - hop, margin); it lands at k*hop + the same offset.  Returns (source offset, length) per window;
         the destination is k*hop + source offset.  `total` is the session length T; the reference tests the BATCH end
-        (hop * (first + count)) against it, shifted per window."""
+        against it, shifted per window: en = hop * batch_end + hop * i with batch_end = min(first + batch_size, W) + 1
+        (beamformer.py:57,104-105) - on the last, truncated batch that is one window MORE than the slice holds."""
         pm, eh = self.proceed_margin, self.eval_hop
+        if batch_end is None:
+            batch_end = first + count
         out = []
         for i in range(count):
-            st, en = eh * (first + i), eh * (first + count) + eh * i
+            st, en = eh * (first + i), eh * batch_end + eh * i
             if st == 0:
                 out.append((0, pm))
             elif en == total:
@@ -116,7 +119,7 @@ class Beamformer:
             # gather every window's kept piece in ONE index_add per batch (a window shared by two batches adds twice,
             # exactly as the reference's overlapping loop does)
             src, dst = [], []
-            for i, (off, length) in enumerate(self._spans(first, nb, T)):
+            for i, (off, length) in enumerate(self._spans(first, nb, T, batch_end=last)):
                 length = ns - off if length is None else min(length, ns - off)
                 k = torch.arange(length, device=X.device)
                 src.append(i * ns + off + k)

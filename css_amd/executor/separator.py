@@ -119,6 +119,7 @@ class Separator:
         if world > 1:
             masks = parallel.gather_windows(masks, W, rank, world)
             mags = parallel.gather_windows(mags, W, rank, world)
+        ops.lstm_dist_check()  # BLSTM separators: a timed-out recurrence hand-off must not pass as masks
         return masks, mags
 
     def separate_one_batch(self, s):

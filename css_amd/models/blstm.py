@@ -57,7 +57,8 @@ class BLSTM(nn.Module):
         self._packed, self._packed_key = None, None
 
     def _pack(self):
-        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        from .. import param_generation  # FusedAdam rewrites parameter storage without touching data_ptr / _version
+        key = (param_generation(),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
         if self._packed is not None and key == self._packed_key:
             return self._packed
         enc = self.blstm
@@ -93,36 +94,6 @@ class BLSTM(nn.Module):
             from ..autograd import masks_for_training
             return masks_for_training(self, f)
         return self._forward_masks_hip(f)
-
-    def _twin_forward_masks(self, f):
-        """Differentiable PyTorch-ROCm restatement of blstm.py:68-88 (dropout off), used ONLY to back-propagate."""
-        import torch.nn.functional as F
-        enc = self.blstm
-        eps = torch.finfo(torch.float32).eps
-        x = (f - f.mean(-2, keepdim=True)) / (f.std(-2, keepdim=True) + eps)
-        x = F.relu(enc.embed[1](enc.embed[0](x)))
-        def direction(xin, w_ih, w_hh, b_ih, b_hh, reverse):
-            # explicit recurrence (gate order i,f,g,o): plain tensor ops, no MIOpen RNN kernel search
-            Bn, Tn, _ = xin.shape
-            Hh = w_hh.shape[1]
-            gx = F.linear(xin, w_ih, b_ih + b_hh)
-            h = xin.new_zeros(Bn, Hh)
-            c = xin.new_zeros(Bn, Hh)
-            outs = [None] * Tn
-            for t in (range(Tn - 1, -1, -1) if reverse else range(Tn)):
-                i, f_, g_, o = (gx[:, t] + F.linear(h, w_hh)).chunk(4, 1)
-                c = torch.sigmoid(f_) * c + torch.sigmoid(i) * torch.tanh(g_)
-                h = torch.sigmoid(o) * torch.tanh(c)
-                outs[t] = h
-            return torch.stack(outs, 1)
-
-        for lay in enc.encoders:
-            l = lay.lstm
-            y = torch.cat([direction(x, l.weight_ih_l0, l.weight_hh_l0, l.bias_ih_l0, l.bias_hh_l0, False),
-                           direction(x, l.weight_ih_l0_reverse, l.weight_hh_l0_reverse, l.bias_ih_l0_reverse,
-                                     l.bias_hh_l0_reverse, True)], -1)
-            x = lay.layer_norm(y)
-        return F.relu(self.linear(x))
 
     def _forward_masks_hip(self, f):
         ops._need(f, torch.float32, "f")

@@ -7,9 +7,8 @@ hot path.  ``forward`` hands raw device pointers to ``csship_conformer_forward``
 (css_amd/csrc/forward.hip), which enqueues the hand-written HIP kernels.
 
 Deviations from the reference, all deliberate and documented in DESIGN.md:
-  * dropout is not applied (the forward equals the reference with dropout_rate = 0; eval
-    mode is bit-for-bit the same function);
-  * ``self.training`` selects BatchNorm batch statistics, running statistics are not updated;
+  * ``self.training`` selects BatchNorm batch statistics (running statistics updated by the
+    training forward, css_amd/autograd.py);
   * for ``idim != num_bins`` (7-channel IPD features) the reference's ``m * f_orig`` raises a
     shape error (conformer.py:103); here the masks multiply the first ``num_bins`` feature
     columns (the magnitude part);
@@ -145,7 +144,10 @@ class Conformer(nn.Module):
 
     # ------------------------------------------------------------------ weight packing
     def _pack_key(self):
-        return (self.training, getattr(self, "fuse_conv", False), getattr(self, "force_generic", False)) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        # param_generation(): FusedAdam rewrites parameter storage without touching data_ptr / _version
+        from .. import param_generation
+        return (self.training, getattr(self, "fuse_conv", False), getattr(self, "force_generic", False),
+                param_generation()) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def _pack(self):
         """bf16 shadow copies of the GEMM weights + the pointer table csship_conformer_forward reads."""
@@ -233,59 +235,6 @@ class Conformer(nn.Module):
             from ..autograd import masks_for_training
             return masks_for_training(self, f)
         return self._forward_masks_hip(f, want_encoder_out)
-
-    # ------------------------------------------------------------------ backward stop-gap (see css_amd/autograd.py)
-    def _twin_forward_masks(self, f):
-        """Differentiable fp32 PyTorch-ROCm restatement of conformer.py:83-104 (dropout off), used ONLY to
-        back-propagate; BatchNorm follows self.training and updates its running statistics like the reference."""
-        import math
-        import torch.nn.functional as F
-        enc = self.conformer
-        eps = torch.finfo(torch.float32).eps
-        x = (f - f.mean(-2, keepdim=True)) / (f.std(-2, keepdim=True) + eps)
-        x = F.relu(enc.embed[1](enc.embed[0](x)))
-        B, T, D = x.shape
-        H = enc.n_head
-        dk = D // H
-        idx = torch.arange(T, device=x.device)
-        rel = (idx[:, None] - idx[None, :]).clamp(-enc.pos_emb.maxlen, enc.pos_emb.maxlen - 1) + enc.pos_emb.maxlen
-        pos_k = enc.pos_emb.pe_k(rel)  # [T,T,dk]
-        for lay in enc.encoders:
-            def ffn(m, h):
-                return m.net[3](F.relu(m.net[0](m.layer_norm(h))))
-            x = x + 0.5 * ffn(lay.feed_forward_in, x)
-            a = lay.self_attn
-            h = a.layer_norm(x)
-            q = a.linear_q(h).view(B, T, H, dk).transpose(1, 2)
-            k = a.linear_k(h).view(B, T, H, dk).transpose(1, 2)
-            v = a.linear_v(h).view(B, T, H, dk).transpose(1, 2)
-            sc = (torch.matmul(q, k.transpose(-1, -2)) + torch.einsum("bhid,ijd->bhij", q, pos_k)) / math.sqrt(dk)
-            ctxv = torch.matmul(torch.softmax(sc, -1), v).transpose(1, 2).reshape(B, T, D)
-            x = x + a.linear_out(ctxv)
-            c = lay.conv
-            h = c.layer_norm(x)
-            w1, b1 = c.pw_conv_1.weight.view(2), c.pw_conv_1.bias
-            g = (w1[0] * h + b1[0]) * torch.sigmoid(w1[1] * h + b1[1])            # [B,T,D]
-            # depthwise conv as unfold + contraction, BatchNorm written out: plain tensor ops only (no MIOpen
-            # kernel search on the first call)
-            ksz = c.kernel_size
-            gp = F.pad(g, (0, 0, ksz // 2, ksz // 2)).unfold(1, ksz, 1)             # [B,T,D,k]
-            y = (gp * c.dw_conv_1d.weight.view(1, 1, D, ksz)).sum(-1) + c.dw_conv_1d.bias
-            if self.training:
-                mu, var = y.mean((0, 1)), y.var((0, 1), unbiased=False)
-                with torch.no_grad():
-                    nel = y.shape[0] * y.shape[1]
-                    c.BN.running_mean.mul_(0.9).add_(0.1 * mu)
-                    c.BN.running_var.mul_(0.9).add_(0.1 * var * nel / max(nel - 1, 1))
-                    c.BN.num_batches_tracked += 1
-            else:
-                mu, var = c.BN.running_mean, c.BN.running_var
-            y = (y - mu) * torch.rsqrt(var + c.BN.eps) * c.BN.weight + c.BN.bias
-            y = F.relu(y) * c.pw_conv_2.weight.view(()) + c.pw_conv_2.bias.view(())
-            x = x + y
-            x = x + 0.5 * ffn(lay.feed_forward_out, x)
-            x = lay.layer_norm(x)
-        return F.relu(self.linear(x))
 
     def _forward_masks_hip(self, f, want_encoder_out=False):
         ops._need(f, torch.float32, "f")

@@ -291,7 +291,7 @@ def lstm_bidir(gx, whh_packed, B, T, H, keep=False):
         key = (dev.index, _stream() or 0, B, H)
         ws = _LSTM_WS.get(key)
         if ws is None:
-            ws = _LSTM_WS[key] = torch.empty(lib().csship_lstm_dist_workspace(B, H), dtype=torch.uint8, device=dev)
+            ws = _LSTM_WS[key] = torch.zeros(lib().csship_lstm_dist_workspace(B, H), dtype=torch.uint8, device=dev)
         check(lib().csship_lstm_bidir_dist(_ptr(gx), _ptr(whh_packed), _ptr(y), _ptr(gates), _ptr(c), B, T, H, _ptr(ws),
                                           ws.numel(), _stream()))
     elif keep:
@@ -302,13 +302,26 @@ def lstm_bidir(gx, whh_packed, B, T, H, keep=False):
 
 
 def lstm_dist_check():
-    """Synchronise and raise if any distributed-recurrence launch since the last check timed out on a hand-off."""
+    """Synchronise and raise if any distributed-recurrence launch since the last check timed out on a hand-off.
+
+    The error word is sticky (the last 64 bytes of the workspace, never cleared by a launch): a timeout in ANY layer /
+    step since the previous check is seen here.  Called where the host synchronises anyway: the ``loss.item()`` of
+    ``train_one_epoch`` / ``validate`` and the end of ``Separator.separate``.  A no-op when the distributed kernels
+    were never used."""
+    if not _LSTM_WS:
+        return
     torch.cuda.synchronize()
+    bad = False
     for (idx, _, B, H), ws in _LSTM_WS.items():
         off = lib().csship_lstm_dist_workspace_error_offset(B, H)
-        if int(ws[off:off + 4].view(torch.int32).item()) != 0:
-            raise RuntimeError("css_amd: BLSTM distributed recurrence timed out waiting for a workgroup "
-                               "(are other processes using this GPU?); set CSS_AMD_LSTM_DIST=0")
+        word = ws[off:off + 4].view(torch.int32)
+        if int(word.item()) != 0:
+            word.zero_()
+            bad = True
+    if bad:
+        raise RuntimeError("css_amd: BLSTM distributed recurrence timed out waiting for a workgroup: outputs and "
+                           "gradients since the last check are invalid (are other processes using this GPU?); "
+                           "set CSS_AMD_LSTM_DIST=0 to use the single-CU recurrence")
 
 
 def pit_mse(masks, f_orig, targets, want_y_pred=False, want_pairs=False):

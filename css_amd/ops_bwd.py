@@ -276,7 +276,7 @@ def lstm_bidir_bwd(gates, c, dy, whhT_packed):
         key = (gates.device.index, _stream() or 0, B, H)
         ws = ops._LSTM_WS.get(key)
         if ws is None:
-            ws = ops._LSTM_WS[key] = torch.empty(lib().csship_lstm_dist_workspace(B, H), dtype=torch.uint8, device=gates.device)
+            ws = ops._LSTM_WS[key] = torch.zeros(lib().csship_lstm_dist_workspace(B, H), dtype=torch.uint8, device=gates.device)
         check(lib().csship_lstm_bidir_bwd_dist(_ptr(gates), _ptr(c), _ptr(dy), _ptr(whhT_packed), _ptr(dg), B, T, H,
                                               _ptr(ws), ws.numel(), _stream()))
     else:

@@ -8,6 +8,7 @@ drops into ``train_one_epoch`` in place of ``torch.optim.Adam`` + ``clip_grad_no
 """
 import torch
 
+from . import bump_param_generation
 from ._lib import check, lib
 from .ops import _ptr, _stream
 
@@ -19,6 +20,9 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError("FusedAdam got an empty parameter list")
         if any((not p.is_cuda) or p.dtype != torch.float32 for p in params):
             raise RuntimeError("css_amd.FusedAdam needs float32 parameters on the GPU (no CPU path exists)")
+        if any(isinstance(p, dict) for p in params):
+            raise ValueError("css_amd.FusedAdam takes ONE parameter group (a flat list of tensors): the fused step "
+                             "applies one lr / betas / weight_decay to the whole flat buffer")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_norm=max_norm))
         dev = params[0].device
         offs, n = [], 0
@@ -26,6 +30,7 @@ class FusedAdam(torch.optim.Optimizer):
             offs.append(n)
             n += (p.numel() + 3) // 4 * 4  # 16-byte aligned segments
         self._n = n
+        self._offs = offs
         self.flat_param = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -63,6 +68,7 @@ class FusedAdam(torch.optim.Optimizer):
         if not self.capturable:
             self.advance_hyper()
         hyper, step = self._hyper, 0
+        bump_param_generation()  # the kernel below rewrites the parameter storage: weight-shadow caches are stale
         check(lib().csship_adam_clip(_ptr(self.flat_param), _ptr(self.flat_grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
                                      self._n, float(mn), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
                                      float(g["eps"]), step, float(g["weight_decay"]), _ptr(hyper), _ptr(self.grad_norm),
@@ -74,6 +80,7 @@ class FusedAdam(torch.optim.Optimizer):
         current stream, ordered before the graph replay that follows)."""
         g = self.param_groups[0]
         self._step += 1
+        bump_param_generation()  # capturable mode: the replayed graph rewrites the parameter storage after this call
         # The copy is asynchronous and the host may be several steps ahead of the GPU: every step stages its values in
         # its own pinned slot, reused only after the copy that read it has completed (a single staging buffer would be
         # overwritten with a later step's values before an earlier copy ran).
@@ -89,15 +96,49 @@ class FusedAdam(torch.optim.Optimizer):
         ev.record()
         self._hyper_events[slot] = ev
 
+    def add_param_group(self, group):
+        if getattr(self, "param_groups", None):
+            raise ValueError("css_amd.FusedAdam supports a single parameter group")
+        super().add_param_group(group)
+
     def state_dict(self):
+        """torch.optim.Adam's format (per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq``, as views of the flat
+        moment buffers), so that the reference's train.py resume and combine_models.py read the moments, plus the
+        flat buffers themselves under ``fused``."""
         sd = super().state_dict()
+        params = self.param_groups[0]["params"]
+        step = torch.tensor(float(self._step))
+        sd["state"] = {i: {"step": step.clone(), "exp_avg": self.exp_avg[o:o + p.numel()].view(p.shape),
+                           "exp_avg_sq": self.exp_avg_sq[o:o + p.numel()].view(p.shape)}
+                       for i, (p, o) in enumerate(zip(params, self._offs))}
         sd["fused"] = {"step": self._step, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq}
         return sd
 
     def load_state_dict(self, sd):
-        fused = sd.get("fused")
-        super().load_state_dict({k: v for k, v in sd.items() if k != "fused"})
+        """Accepts this class's own checkpoints and torch.optim.Adam's (the reference's ``optimizer`` entry,
+        train.py:209-225): the per-parameter moments are scattered into the flat buffers."""
+        fused, state = sd.get("fused"), sd.get("state") or {}
+        if len(sd.get("param_groups", [])) != 1:
+            raise ValueError("css_amd.FusedAdam supports a single parameter group")
+        super().load_state_dict({"state": {}, "param_groups": sd["param_groups"]})
         if fused is not None:
             self._step = int(fused["step"])
             self.exp_avg.copy_(fused["exp_avg"])
             self.exp_avg_sq.copy_(fused["exp_avg_sq"])
+        elif state:
+            params = self.param_groups[0]["params"]
+            ids = sd["param_groups"][0]["params"]
+            steps = set()
+            with torch.no_grad():
+                for p, o, pid in zip(params, self._offs, ids):
+                    st = state.get(pid, state.get(str(pid)))
+                    if st is None:
+                        continue
+                    self.exp_avg[o:o + p.numel()].view(p.shape).copy_(st["exp_avg"])
+                    self.exp_avg_sq[o:o + p.numel()].view(p.shape).copy_(st["exp_avg_sq"])
+                    steps.add(int(float(st["step"])))
+            if len(steps) > 1:
+                raise ValueError(f"css_amd.FusedAdam: per-parameter step counts differ ({sorted(steps)}); one shared "
+                                 "step is required")
+            self._step = steps.pop() if steps else 0
+        bump_param_generation()

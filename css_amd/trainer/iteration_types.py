@@ -13,7 +13,7 @@ import logging
 
 import torch
 
-from .. import parallel
+from .. import ops, parallel
 
 
 def train_one_epoch(args, generator, model, objective, optim, lr_sched, device="cpu"):
@@ -26,6 +26,7 @@ def train_one_epoch(args, generator, model, objective, optim, lr_sched, device="
         if not loss.requires_grad:
             raise RuntimeError("css_amd: loss has no grad_fn (model parameters frozen or grad disabled)")
         loss_val = loss.data.item()
+        ops.lstm_dist_check()  # the item() above synchronised: a timed-out BLSTM hand-off invalidates this loss
         log += f"Loss: {loss_val:0.5f} "
         total_loss += loss_val
         loss.backward()
@@ -38,6 +39,7 @@ def train_one_epoch(args, generator, model, objective, optim, lr_sched, device="
             grad_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), args.grad_thresh)
             optim.step()
         log += f"Grad_norm: {grad_norm.data.item():0.5f}"
+        ops.lstm_dist_check()  # ... and the backward's hand-offs before the update is logged as good
         logging.info(log)
         optim.zero_grad()
         lr_sched.step(1.0)
@@ -54,6 +56,7 @@ def validate(generator, model, objective, device="cpu", num_batches=100):
             b = next(generator)
             avg_loss = avg_loss + objective(model, b, device=device)
         avg_loss = avg_loss / num_batches
+    ops.lstm_dist_check()
     if was_training:
         model.train()
     return avg_loss
