@@ -18,11 +18,11 @@ class FusedAdam(torch.optim.Optimizer):
         params = [p for p in params]
         if not params:
             raise ValueError("FusedAdam got an empty parameter list")
-        if any((not p.is_cuda) or p.dtype != torch.float32 for p in params):
-            raise RuntimeError("css_amd.FusedAdam needs float32 parameters on the GPU (no CPU path exists)")
         if any(isinstance(p, dict) for p in params):
             raise ValueError("css_amd.FusedAdam takes ONE parameter group (a flat list of tensors): the fused step "
                              "applies one lr / betas / weight_decay to the whole flat buffer")
+        if any((not p.is_cuda) or p.dtype != torch.float32 for p in params):
+            raise RuntimeError("css_amd.FusedAdam needs float32 parameters on the GPU (no CPU path exists)")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_norm=max_norm))
         dev = params[0].device
         offs, n = [], 0

@@ -1,0 +1,54 @@
+"""Reference gradients for the GPU gradient tests: torch.autograd (CPU, fp32) through the ORACLE's restatement of the
+reference model (oracle/conformer.py, oracle/blstm.py) and of the PIT-MSE objective (oracle/pit.py).  Test
+infrastructure only - nothing under css_amd/ imports this."""
+import torch
+
+import oracle
+
+
+def oracle_masks(model, f, training_bn):
+    """(masks [N,T,(K+1)*F] as one tensor with grad, leaf state dict) of the oracle forward for `model`'s weights."""
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    f = f.detach().cpu()
+    if hasattr(model, "conformer"):
+        enc = model.conformer
+        _, masks = oracle.conformer.forward(f, sd, num_spk=model.num_spk, num_noise=model.num_noise, n_head=enc.n_head,
+                                            kernel_size=enc.kernel_size, num_blocks=len(enc.encoders),
+                                            training_bn=training_bn)
+    else:
+        _, masks = oracle.blstm.forward(f, sd, num_layers=len(model.blstm.encoders), num_spk=model.num_spk,
+                                        num_noise=model.num_noise)
+    return torch.cat(masks, -1), sd
+
+
+def pit_loss_with_perm(masks, f, targets, perm, nbins=257):
+    """mean_b MSE(mask_{perm[b][i]} * f, target_i): the objective's value at the permutation the GPU chose."""
+    B = f.shape[0]
+    tot = 0
+    for b in range(B):
+        est = torch.stack([masks[b, :, perm[b][i] * nbins:(perm[b][i] + 1) * nbins] * f[b] for i in range(len(targets))])
+        tot = tot + ((est - torch.stack([t[b] for t in targets])) ** 2).mean()
+    return tot / B
+
+
+def oracle_param_grads(model, loss_of_masks, f, training_bn):
+    """{parameter name: gradient} of loss_of_masks(masks) by autograd through the oracle."""
+    masks, sd = oracle_masks(model, f, training_bn)
+    loss_of_masks(masks).backward()
+    return {k: sd[k].grad for k, _ in model.named_parameters()}
+
+
+def compare(grads, ref):
+    """(global relative L2 error, (worst parameter, its relative error)) of {name: grad} against the reference."""
+    num = den = 0.0
+    worst = ("", 0.0)
+    for k, g in grads.items():
+        r = ref[k]
+        n, d = float(((g.detach().cpu() - r) ** 2).sum()), float((r ** 2).sum())
+        num, den = num + n, den + d
+        if d > 1e-16 and (n / d) ** 0.5 > worst[1]:
+            worst = (k, (n / d) ** 0.5)
+    return (num / den) ** 0.5, worst

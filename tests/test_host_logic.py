@@ -195,3 +195,31 @@ def test_checkpoint_roundtrip_and_combine(tmp_path):
     c = MODELS["Conformer"](257, 257, 2, 1, conf)
     assert ck.load_checkpoint(out, c) == 2
     assert torch.equal(c.state_dict()[k], avg[k])
+
+
+def test_beamformer_spans_follow_the_reference_batch_end():
+    """beamformer.py:57,104-118: the per-window test `en == T` uses en = hop * (min(first + batch, W) + 1) + hop * i, one
+    window more than the last (truncated) batch holds.  Session length chosen so that the tail branch fires."""
+    import types
+    from css_amd.executor.beamformer import Beamformer
+    hop, margin, bs = 100, 160, 4
+    self = types.SimpleNamespace(proceed_margin=margin, eval_hop=hop)
+    W = 6                                    # windows; batches [0..4], [4..6) (+1 beyond the end)
+    for first in (0, 4):
+        bend = min(first + bs, W) + 1
+        count = min(bend, W) - first
+        for T in (hop * (bend + 1), hop * (bend + 7)):   # T = hop * (bend + i) for i = 1 (a window of the batch) / never
+            got = Beamformer._spans(self, first, count, T, batch_end=bend)
+            st, en, want = hop * first, hop * bend, []
+            for _ in range(count):           # the reference's loop, literally
+                if st == 0:
+                    want.append((0, margin))
+                elif en == T:
+                    want.append((margin - hop, None))
+                else:
+                    want.append((margin - hop, hop))
+                st += hop
+                en += hop
+            assert got == want, (first, T)
+    # the old computation (batch end = first + count) differs exactly on the truncated batch
+    assert Beamformer._spans(self, 4, 2, hop * 8) != Beamformer._spans(self, 4, 2, hop * 8, batch_end=7)

@@ -1,5 +1,5 @@
 """Training-step timing at the headline shape (Conformer-base, 32 x 400 frames): HIP forward + PIT + explicit HIP
-backward (+ Adam), and the torch-autograd stop-gap for comparison.  Usage: python tools/bench_train.py [--twin]"""
+backward (+ Adam).  Usage: python tools/bench_train.py [--graph]"""
 import argparse
 import os
 import sys
@@ -13,7 +13,6 @@ from css_amd.objectives import OBJECTIVES  # noqa: E402
 from css_amd.utils import synthetic as syn  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--twin", action="store_true")
 ap.add_argument("--graph", action="store_true", help="capture the whole step in a HIP graph and replay it")
 ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam + clip_grad_norm_ instead of FusedAdam")
 ap.add_argument("--steps", type=int, default=5)
@@ -25,7 +24,6 @@ conf = dict(attention_dim=256, attention_heads=4, linear_units=1024, num_blocks=
 m = MODELS["Conformer"](257, 257, 2, 1, conf)
 m.load_state_dict(syn.fill_state_dict(syn.conformer_shapes(num_blocks=a.blocks), 0))
 m = m.to(dev).train()
-m.force_twin_backward = a.twin
 obj = OBJECTIVES["MSE"].build_objective({})
 if a.torch_adam:
     opt = torch.optim.Adam(m.parameters(), lr=1e-4)
@@ -70,5 +68,5 @@ if trace:
     print("losses", " ".join(f"{x:.9f}" for x in trace))
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
-print(f"train step ({'twin' if a.twin else 'hip'} backward, {a.blocks} blocks): {dt * 1e3:.1f} ms  "
+print(f"train step (hip backward, {a.blocks} blocks): {dt * 1e3:.1f} ms  "
       f"= {12800 / dt / 1e6:.3f} M frames/s   loss {float(loss):.5f}   peak mem {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB")
