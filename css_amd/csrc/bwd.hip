@@ -227,9 +227,7 @@ __global__ __launch_bounds__(256) void attn_rowdot_kernel(const unsigned short* 
   for (int q = 0; q < 4; ++q)
     s += bf2f((unsigned short)(av[q] & 0xffff)) * bf2f((unsigned short)(bv[q] & 0xffff)) +
          bf2f((unsigned short)(av[q] >> 16)) * bf2f((unsigned short)(bv[q] >> 16));
-  s += __shfl_xor(s, 1);
-  s += __shfl_xor(s, 2);
-  s += __shfl_xor(s, 4);
+  s = sum8(s);
   if (part == 0 && idx < n) {
     const int h = (int)(idx % H);
     const int64_t bi = idx / H;

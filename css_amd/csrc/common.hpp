@@ -14,17 +14,65 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 DEV unsigned short f2bf(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
 DEV float bf2f(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }
-DEV unsigned pack_bf2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+// two f32 -> packed bf16 pair (round to nearest even): ONE v_cvt_pk_bf16_f32 (two scalar casts + shift/or took 3-4)
+DEV unsigned pack_bf2(float lo, float hi) {
+  const bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, v);
+}
+// max(x, 0) on a packed bf16 pair: as signed 16-bit integers every negative bf16 (sign bit set, -0 included) is < 0
+DEV unsigned relu_bf2(unsigned p) {
+  const s16x2 z = {0, 0};
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), z));
+}
 
-DEV float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+// Cross-lane reductions without the LDS crossbar: __shfl_xor compiles to ds_bpermute_b32 (an LDS round trip of
+// ~120 cycles per step in a dependent chain); DPP quad permutes / mirrors and v_permlane16/32_swap are plain VALU.
+// All lanes of an already-reduced group hold the same value, so a mirror (lane i <-> 7-i, 15-i) pairs the same
+// partial sums as xor 4 / xor 8 would: the results are bit-identical to the xor-butterfly they replace.
+template <int CTRL>
+DEV float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+DEV float sum8(float v) {  // over aligned groups of 8 lanes, result in all of them
+  v += dpp_mov<DPP_XOR1>(v);
+  v += dpp_mov<DPP_XOR2>(v);
+  v += dpp_mov<DPP_HALF_MIRROR>(v);
   return v;
 }
-DEV float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+DEV float max8(float v) {
+  v = fmaxf(v, dpp_mov<DPP_XOR1>(v));
+  v = fmaxf(v, dpp_mov<DPP_XOR2>(v));
+  v = fmaxf(v, dpp_mov<DPP_HALF_MIRROR>(v));
   return v;
+}
+DEV float rows_sum4(float x) {  // sum over the four 16-lane rows of the wave (same column), in all lanes
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  const unsigned a0 = r[0], a1 = r[1];
+  const float y = __uint_as_float(a0) + __uint_as_float(a1);
+  auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+  const unsigned b0 = q[0], b1 = q[1];
+  return __uint_as_float(b0) + __uint_as_float(b1);
+}
+DEV float rows_max4(float x) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  const unsigned a0 = r[0], a1 = r[1];
+  const float y = fmaxf(__uint_as_float(a0), __uint_as_float(a1));
+  auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+  const unsigned b0 = q[0], b1 = q[1];
+  return fmaxf(__uint_as_float(b0), __uint_as_float(b1));
+}
+DEV float wave_sum(float v) {
+  v = sum8(v);
+  v += dpp_mov<DPP_MIRROR>(v);
+  return rows_sum4(v);
+}
+DEV float wave_max(float v) {
+  v = max8(v);
+  v = fmaxf(v, dpp_mov<DPP_MIRROR>(v));
+  return rows_max4(v);
 }
 
 // LDS tile of bf16 rows of 64 elements (128 B, eight 16-byte chunks).  Chunk c of row r

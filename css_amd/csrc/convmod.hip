@@ -60,8 +60,9 @@ __global__ __launch_bounds__(2 * D) void convmod_kernel(ConvArgs a) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-#pragma unroll
-    for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o);
+    static_assert(LPR == 8 || LPR == 16, "row reductions are written for 8 or 16 lanes per row");
+    s = sum8(s);
+    if constexpr (LPR == 16) s += dpp_mov<DPP_MIRROR>(s);
     const float mean = s * (1.f / D);
     float ss = 0.f;
 #pragma unroll
@@ -69,8 +70,8 @@ __global__ __launch_bounds__(2 * D) void convmod_kernel(ConvArgs a) {
       v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
       ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
     }
-#pragma unroll
-    for (int o = 1; o < LPR; o <<= 1) ss += __shfl_xor(ss, o);
+    ss = sum8(ss);
+    if constexpr (LPR == 16) ss += dpp_mov<DPP_MIRROR>(ss);
     const float rstd = rsqrtf(ss * (1.f / D) + 1e-5f);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {

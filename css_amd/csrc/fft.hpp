@@ -23,10 +23,7 @@ DEV cplx cis_pi(float t) {  // exp(i*pi*t)
   return {cs, sn};
 }
 
-template <int CTRL>
-DEV float dpp_mov(float x) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
-}
+// dpp_mov<CTRL>: common.hpp
 
 template <int H>
 DEV float lane_xor(float x, int lane) {

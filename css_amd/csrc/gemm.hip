@@ -191,10 +191,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             const float d = pass == 0 ? acc[i][j][r] : acc[i][j][r] - mean[i][r];
             s += pass == 0 ? d : d * d;
           }
-          s += __shfl_xor(s, 1);
-          s += __shfl_xor(s, 2);
-          s += __shfl_xor(s, 4);
-          s += __shfl_xor(s, 8);
+          s = sum8(s);
+          s += dpp_mov<DPP_MIRROR>(s);
           if (ln == 0) red[wn * 64 + i * 16 + lg * 4 + r] = s;
         }
       __syncthreads();

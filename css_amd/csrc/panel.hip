@@ -29,6 +29,23 @@ constexpr int PANEL_BYTES = BM * DM * 2;
 DEV int panel_off(int row, int chunk) { return row * 512 + ((chunk ^ (row & 15)) << 4); }
 
 constexpr int PD = 4;  // weight prefetch distance in k-steps (ring of PD fragment sets per wave)
+#ifdef P_STAMPS  // diagnostic build: wave 0 of every workgroup stores s_memtime at phase boundaries -> g_csship_stamps[wg*32 + i]
+#define P_T(i)                                                                                                  \
+  {                                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
+    if (g_stamps_dev != nullptr && threadIdx.x == 0) {                                                          \
+      unsigned long long t_;                                                                                    \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                \
+      g_stamps_dev[(size_t)blockIdx.x * 32 + (i)] = t_;                                                         \
+    }                                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
+  }
+#else
+#define P_T(i)
+#endif
+#ifndef P_ABL
+#define P_ABL 0  // diagnostic builds only: bit 0 no weight loads in the k-loop, bit 1 no MFMAs, bit 2 no LDS operand reads
+#endif
 
 // acc[t][rt] += W(tile0+t)[16 x 256] . panel^T[256 x 16 rows of tile rt]
 //   w: this lane's pointer at block (tile0, k-step 0); block (t, ks) is at w[(t*tstride + ks)*64].
@@ -49,7 +66,8 @@ DEV void mma_pass(f32x4 (&acc)[NT][4], const unsigned char* panel, int n, int g,
     bf16x8 wc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) wc[t] = wq[ks % PD][t];
-    if (ks + PD < KS) {
+    if (P_ABL & 1) {
+    } else if (ks + PD < KS) {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
         if (t < nt) wq[ks % PD][t] = w[(size_t)(t * tstride + ks + PD) * 64];
@@ -58,7 +76,7 @@ DEV void mma_pass(f32x4 (&acc)[NT][4], const unsigned char* panel, int n, int g,
       for (int t = 0; t < NT; ++t)
         if (t < nnt) wq[ks % PD][t] = wn[(size_t)(t * nstride + ks + PD - KS) * 64];
     }
-    if (ks + 1 < KS) {
+    if (ks + 1 < KS && !(P_ABL & 4)) {
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt)
         xa[(ks + 1) & 1][rt] = *reinterpret_cast<const bf16x8*>(panel + panel_off(rt * 16 + n, (ks + 1) * 4 + g));
@@ -67,9 +85,15 @@ DEV void mma_pass(f32x4 (&acc)[NT][4], const unsigned char* panel, int n, int g,
 #pragma unroll
     for (int t = 0; t < NT; ++t)
       if (t < nt) {
+        if (P_ABL & 2) {
+          asm volatile("" ::"v"(wc[t]));
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) asm volatile("" ::"v"(xa[ks & 1][rt]));
+          continue;
+        }
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
-          acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[t], xa[ks & 1][rt], acc[t][rt], 0, 0, 0);
+          acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[t], xa[(P_ABL & 4) ? 0 : (ks & 1)][rt], acc[t][rt], 0, 0, 0);
       }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -88,12 +112,6 @@ DEV void prefetch_first(bf16x8 (&wq)[PD][NT], const bf16x8* w, int tstride, int 
 // ---- panel prologues.  Thread (row = tid>>3, part = tid&7) owns 32 elements of one row: float4 pieces
 // (i*8 + part), i = 0..7, so the 8 lanes of a row read one full 128-byte line per load instruction and
 // the LayerNorm statistics need only 3 shuffle steps (xor 1, 2, 4).  Requires NW*64 == 8*BM threads.
-DEV float sum8(float v) {
-  v += __shfl_xor(v, 1);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 4);
-  return v;
-}
 template <bool LN>
 DEV void load_panel_rows(unsigned char* panel, const float* x, int m0, int M, const float* gam, const float* bet,
                          int tid) {
@@ -218,25 +236,23 @@ __global__ __launch_bounds__(NW * 64) void ffn_kernel(FfnArgs a) {
   for (int ci = 0; ci < nchunk; ++ci) {
     const int c = (ci + rot) % nchunk;
     f32x4 h[NT][4];
-    float4 bb[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      bb[t] = *reinterpret_cast<const float4*>(a.b1 + c * DM + (wave * NT + t) * 16 + 4 * g);  // ahead of the MFMA loop
+    for (int t = 0; t < NT; ++t) {  // the bias is the accumulators' initial value
+      const float4 bb = *reinterpret_cast<const float4*>(a.b1 + c * DM + (wave * NT + t) * 16 + 4 * g);
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) h[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int rt = 0; rt < 4; ++rt) h[t][rt] = f32x4{bb.x, bb.y, bb.z, bb.w};
     }
     const bf16x8* w1c = w1s + (size_t)c * 16 * KS * 64;
     const bf16x8* w2c = w2s + (size_t)c * KS * 64;
     mma_pass<NT>(h, Xs, n, g, NT, w1c, KS, w2c, ks2, NT, wq);
-    // hidden = relu(h + b1) -> bf16 -> Hs[c&1][row][wave's 16*NT columns]
+    // hidden = relu(h) -> bf16 -> Hs[c&1][row][wave's 16*NT columns]; ReLU on the packed pairs
     unsigned char* hs = (ci & 1) ? Hs1 : Hs0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int hc = (wave * NT + t) * 16 + 4 * g;  // column within the chunk
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
-        const uint2 pk = make_uint2(pack_bf2(fmaxf(h[t][rt][0] + bb[t].x, 0.f), fmaxf(h[t][rt][1] + bb[t].y, 0.f)),
-                                    pack_bf2(fmaxf(h[t][rt][2] + bb[t].z, 0.f), fmaxf(h[t][rt][3] + bb[t].w, 0.f)));
+        const uint2 pk = make_uint2(relu_bf2(pack_bf2(h[t][rt][0], h[t][rt][1])), relu_bf2(pack_bf2(h[t][rt][2], h[t][rt][3])));
         *reinterpret_cast<uint2*>(hs + panel_off(rt * 16 + n, hc >> 3) + (hc & 7) * 2) = pk;
       }
     }
@@ -696,6 +712,7 @@ struct ChainArgs {
   unsigned short* qkv;
   int M, FF, NQKV;
   float alpha;
+  unsigned long long* stamps;  // -DP_STAMPS diagnostic builds only
 };
 
 // LayerNorm of the register rows -> bf16 activation panel in LDS
@@ -725,7 +742,8 @@ DEV void rows_to_panel(unsigned char* panel, const float4 (&v)[8], const float* 
 // one FeedForward on the register rows: v <- v + alpha * FFN(LN(v))  [-> LayerNorm(fin)]
 template <int NW, bool FINAL_LN>
 DEV void ffn_stage(float4 (&v)[8], unsigned char* Xs, unsigned char* Hraw, const FfnW& f, const float* fin_g,
-                   const float* fin_b, int FF, float alpha, int tid, int rot) {
+                   const float* fin_b, int FF, float alpha, int tid, int rot, unsigned long long* g_stamps_dev = nullptr,
+                   int st0 = 0) {
   constexpr int NT = 16 / NW;
   const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15, r = tid >> 3, part = tid & 7;
   const int nchunk = FF / DM, ks2 = FF / 32;
@@ -737,6 +755,7 @@ DEV void ffn_stage(float4 (&v)[8], unsigned char* Xs, unsigned char* Hraw, const
   prefetch_first<NT>(wq, w1s + (size_t)(rot % nchunk) * 16 * KS * 64, KS, NT);
   rows_to_panel(Xs, v, f.ln_g, f.ln_b, r, part);
   __syncthreads();  // also: every wave has left the previous stage's Ys reads
+  P_T(st0 + 0)
   f32x4 o[NT][4];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -745,38 +764,63 @@ DEV void ffn_stage(float4 (&v)[8], unsigned char* Xs, unsigned char* Hraw, const
   for (int ci = 0; ci < nchunk; ++ci) {
     const int c = (ci + rot) % nchunk;
     f32x4 h[NT][4];
-    float4 bb[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      bb[t] = *reinterpret_cast<const float4*>(f.b1 + c * DM + (wave * NT + t) * 16 + 4 * g);
+    for (int t = 0; t < NT; ++t) {  // the bias is the accumulators' initial value
+      const float4 bb = *reinterpret_cast<const float4*>(f.b1 + c * DM + (wave * NT + t) * 16 + 4 * g);
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) h[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int rt = 0; rt < 4; ++rt) h[t][rt] = f32x4{bb.x, bb.y, bb.z, bb.w};
     }
     const bf16x8* w1c = w1s + (size_t)c * 16 * KS * 64;
     const bf16x8* w2c = w2s + (size_t)c * KS * 64;
+#ifdef P_STAMPS
+    unsigned long long tq0_ = 0, tq1_ = 0, tq2_ = 0, tq3_ = 0, tq4_ = 0;
+    if (st0 == 1) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tq0_)::"memory"); __builtin_amdgcn_sched_barrier(0); }
+#endif
     mma_pass<NT>(h, Xs, n, g, NT, w1c, KS, w2c, ks2, NT, wq);
+#ifdef P_STAMPS
+    if (st0 == 1) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tq1_)::"memory"); __builtin_amdgcn_sched_barrier(0); }
+#endif
     unsigned char* hs = (ci & 1) ? Hs1 : Hs0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int hc = (wave * NT + t) * 16 + 4 * g;
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-        const uint2 pk = make_uint2(pack_bf2(fmaxf(h[t][rt][0] + bb[t].x, 0.f), fmaxf(h[t][rt][1] + bb[t].y, 0.f)),
-                                    pack_bf2(fmaxf(h[t][rt][2] + bb[t].z, 0.f), fmaxf(h[t][rt][3] + bb[t].w, 0.f)));
+      for (int rt = 0; rt < 4; ++rt) {  // ReLU on the packed pairs: 2 conversions + 2 integer max per 4 values
+        const uint2 pk = make_uint2(relu_bf2(pack_bf2(h[t][rt][0], h[t][rt][1])), relu_bf2(pack_bf2(h[t][rt][2], h[t][rt][3])));
         *reinterpret_cast<uint2*>(hs + panel_off(rt * 16 + n, hc >> 3) + (hc & 7) * 2) = pk;
       }
     }
+#ifdef P_STAMPS
+    if (st0 == 1) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tq2_)::"memory"); __builtin_amdgcn_sched_barrier(0); }
+#endif
     __syncthreads();
+#ifdef P_STAMPS
+    if (st0 == 1) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tq3_)::"memory"); __builtin_amdgcn_sched_barrier(0); }
+#endif
     const bf16x8* w1n = w1s + (size_t)((c + 1) % nchunk) * 16 * KS * 64;
     mma_pass<NT>(o, hs, n, g, NT, w2c, ks2, w1n, KS, NT, wq);
+#ifdef P_STAMPS
+    if (st0 == 1 && g_stamps_dev != nullptr && (threadIdx.x & 63) == 0) {
+      __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tq4_)::"memory"); __builtin_amdgcn_sched_barrier(0);
+      unsigned long long* q_ = g_stamps_dev + (size_t)blockIdx.x * 32 + 12;
+      // wave 0 and wave 7 only: slots 12..15 (wave 0), 16..19 (wave 7): W1 pass, hidden epilogue, barrier wait, W2 pass
+      const int wv_ = threadIdx.x >> 6;
+      if (wv_ == 0 || wv_ == 7) {
+        unsigned long long* d_ = q_ + (wv_ == 7 ? 4 : 0);
+        d_[0] += tq1_ - tq0_; d_[1] += tq2_ - tq1_; d_[2] += tq3_ - tq2_; d_[3] += tq4_ - tq3_;
+      }
+    }
+#endif
   }
   float4 b2v[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) b2v[t] = *reinterpret_cast<const float4*>(f.b2 + (wave * NT + t) * 16 + 4 * g);
+  P_T(st0 + 1)
   __syncthreads();  // every wave is done reading the hidden panels
   float* ys = reinterpret_cast<float*>(Hraw);
   park_tiles<NT, false>(ys, o, NT, wave * NT * 16, g, n, b2v);
   __syncthreads();
+  P_T(st0 + 2)
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const float4 y = *reinterpret_cast<const float4*>(ys + r * YS + (i * 8 + part) * 4);
@@ -891,8 +935,14 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(ChainArgs a) {
     }
     __syncthreads();  // ys is overwritten by the first FFN stage's hidden panel
   }
-  if constexpr (HAS_A) ffn_stage<NW, true>(v, Xs, Hraw, a.fa, a.fin_g, a.fin_b, a.FF, a.alpha, tid, blockIdx.x);
-  if constexpr (HAS_B) ffn_stage<NW, false>(v, Xs, Hraw, a.fb, nullptr, nullptr, a.FF, a.alpha, tid, blockIdx.x + 2);
+#ifdef P_STAMPS
+  unsigned long long* const g_stamps_dev = a.stamps;
+#endif
+  P_T(0)
+  if constexpr (HAS_A) ffn_stage<NW, true>(v, Xs, Hraw, a.fa, a.fin_g, a.fin_b, a.FF, a.alpha, tid, blockIdx.x, a.stamps, 1);
+  P_T(4)
+  if constexpr (HAS_B) ffn_stage<NW, false>(v, Xs, Hraw, a.fb, nullptr, nullptr, a.FF, a.alpha, tid, blockIdx.x + 2, a.stamps, 5);
+  P_T(8)
   if (row < a.M) {  // the residual stream the attention output projection adds to
 #pragma unroll
     for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(a.xout + (size_t)row * DM + (i * 8 + part) * 4) = v[i];
@@ -904,38 +954,39 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(ChainArgs a) {
     prefetch_first<NT>(wq, wbase + (size_t)(wave * NT) * KS * 64, KS, max(0, min(NT, ntiles - wave * NT)));
     rows_to_panel(Xs, v, a.qln_g, a.qln_b, r, part);
     __syncthreads();
-    float* Ys = reinterpret_cast<float*>(Hraw);
+    P_T(9)
+    // The projection is written straight from the transposed accumulators (bias = their initial value): a lane owns
+    // one token row per row tile and 4 consecutive features per tile = one 8-byte bf16 store.  No fp32 staging tile
+    // and no barrier in this loop (phase stamps: the park / barrier / row read-back / barrier of the staged form cost
+    // 4 300 cycles per 256-column pass against 2 048 cycles of MFMA).
     for (int p = 0; p < npass; ++p) {
       const int tile0 = p * 16 + wave * NT;
       const int nt = max(0, min(NT, ntiles - tile0));
       const int nnt = max(0, min(NT, ntiles - (tile0 + 16)));
-      float4 bb[NT];
       f32x4 acc[NT][4];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        bb[t] = load_bias4(a.bqkv, (tile0 + t) * 16 + 4 * g, a.NQKV);
+        const float4 bb = load_bias4(a.bqkv, (tile0 + t) * 16 + 4 * g, a.NQKV);
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) acc[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int rt = 0; rt < 4; ++rt) acc[t][rt] = f32x4{bb.x, bb.y, bb.z, bb.w};
       }
       const bf16x8* wc = wbase + (size_t)tile0 * KS * 64;
       mma_pass<NT>(acc, Xs, n, g, nt, wc, KS, wc + (size_t)16 * KS * 64, KS, nnt, wq);
-      park_tiles<NT, false>(Ys, acc, nt, wave * NT * 16, g, n, bb);
-      __syncthreads();
-      const int f0 = p * 256, ncols = min(256, a.NQKV - f0);  // NQKV % 8 == 0 (checked on the host)
-      if (row < a.M) {
-        unsigned short* o = a.qkv + (size_t)row * a.NQKV + f0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int c = (i * 8 + part) * 8;
-          if (c + 7 < ncols) {
-            const float4 y0 = *reinterpret_cast<const float4*>(Ys + r * YS + c);
-            const float4 y1 = *reinterpret_cast<const float4*>(Ys + r * YS + c + 4);
-            *reinterpret_cast<uint4*>(o + c) = make_uint4(pack_bf2(y0.x, y0.y), pack_bf2(y0.z, y0.w), pack_bf2(y1.x, y1.y), pack_bf2(y1.z, y1.w));
+      for (int t = 0; t < NT; ++t) {
+        const int f = (tile0 + t) * 16 + 4 * g;
+        if (t < nt && f + 3 < a.NQKV) {  // NQKV % 8 == 0 (checked on the host)
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) {
+            const int orow = m0 + rt * 16 + n;
+            if (orow < a.M)
+              *reinterpret_cast<uint2*>(a.qkv + (size_t)orow * a.NQKV + f) =
+                  make_uint2(pack_bf2(acc[t][rt][0], acc[t][rt][1]), pack_bf2(acc[t][rt][2], acc[t][rt][3]));
           }
         }
       }
-      if (p + 1 < npass) __syncthreads();
     }
+    P_T(10)
   }
 }
 
@@ -1358,6 +1409,7 @@ extern "C" int csship_encoder_chain(const float* x, float* x_out, const float* c
   if (CV && (!conv_w || T <= 0 || !aligned16(conv_g) || conv_g == x_out)) return CSSHIP_EBADSHAPE;
   ChainArgs a{};
   a.x = x; a.xout = x_out; a.M = M; a.FF = d_ffn; a.NQKV = n_qkv; a.alpha = 0.5f; a.g = conv_g; a.T = T;
+  a.stamps = g_csship_stamps;
   if (CV) a.cv = ConvW{conv_w->dw_w, conv_w->dw_b, conv_w->bn_g, conv_w->bn_b, conv_w->bn_mean, conv_w->bn_var,
                        conv_w->pw2_w, conv_w->pw2_b};
   auto conv = [](const csship_ffn_weights* w) {

@@ -90,6 +90,24 @@ def bench_attn():
         print(f"mha_relpos B={b_} T={t_}  {us:8.1f} us  {fl / us / 1e6:8.1f} TFLOP/s (algorithmic)")
 
 
+def bench_chain():
+    """The dominant kernel of the step: FFN_out + block LayerNorm -> FFN_in -> LayerNorm + q/k/v (conformer.py:322-326,355-360,222-225)."""
+    x = torch.randn(M, D, device=DEV)
+    g1, b0 = torch.ones(D, device=DEV), torch.zeros(D, device=DEV)
+
+    def ffn_w():
+        return ((g1, b0), ops.pack_frag(torch.randn(1024, D, device=DEV) / 16), torch.zeros(1024, device=DEV),
+                ops.pack_frag(torch.randn(D, 1024, device=DEV) / 32), torch.zeros(D, device=DEV))
+    fa, fb = ffn_w(), ffn_w()
+    wq, bq = ops.pack_frag(torch.randn(768, D, device=DEV) / 16), torch.zeros(768, device=DEV)
+    out = torch.empty_like(x)
+    us = timeit(lambda: ops.encoder_chain(x, 1024, ffn_a=fa, final_ln=(g1, b0), ffn_b=fb, qkv=((g1, b0), wq, bq, 768), out=out))
+    fl = 2 * 4.0 * M * D * 1024 + 2.0 * M * D * 768
+    print(f"encoder_chain (FFN+LN, FFN, LN+QKV)  {us:8.1f} us  {fl / us / 1e6:8.1f} TFLOP/s = {fl / us / 1e6 / 2500:.3f} of 2.5 PF")
+    us = timeit(lambda: ops.encoder_chain(x, 1024, ffn_a=fa, final_ln=(g1, b0), out=out))
+    print(f"encoder_chain (FFN+LN only)          {us:8.1f} us  {4.0 * M * D * 1024 / us / 1e6:8.1f} TFLOP/s")
+
+
 def bench_conv():
     full = syn.conformer_shapes(num_blocks=1)
     pre = "conformer.encoders.0.conv."
@@ -129,7 +147,7 @@ def bench_ln():
     print(f"layernorm  {us:8.1f} us  {M * D * 6 / us / 1e3:8.1f} GB/s")
 
 
-ALL = {"ffn": bench_ffn, "linear": bench_linear, "attn": bench_attn, "conv": bench_conv, "stft": bench_stft,
+ALL = {"chain": bench_chain, "ffn": bench_ffn, "linear": bench_linear, "attn": bench_attn, "conv": bench_conv, "stft": bench_stft,
        "pit": bench_pit, "ln": bench_ln}
 
 if __name__ == "__main__":
