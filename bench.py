@@ -1,33 +1,41 @@
 #!/usr/bin/env python3
-"""Headline benchmark: STFT-frames/sec (fwd + PIT), Conformer-1ch, batch = 32 x 400-frame chunks.
+"""Headline benchmark: STFT-frames/sec (fwd + PIT), Conformer-1ch, batch = 32 x 400-frame chunks (BASELINE.json configs[1]).
 
-One "step" = one pass of the hot path over one synthetic batch that is already resident in
-HBM:  raw audio (mix, source1, source2: 3 x [32, 102 656] f32)
+One "step" = one pass of the hot path over one synthetic batch that is already resident in HBM:
+    raw audio (mix, source1, source2: 3 x [32, 102 656] f32)
       -> STFT magnitudes (csship_stft)                     [feature.py:45-82]
       -> Conformer-base forward to the ReLU masks          [conformer.py:83-104]
       -> fused mask-apply + PIT-MSE loss                   [conformer.py:103, mse.py:22-37]
-Frames counted per step = B*T = 12 800 mixture frames per GPU (the two target spectrograms
-are work, not frames).  N > 1: one process per GPU (torchrun), every rank runs its own batch
-(weak scaling), no collective on the data path; barrier + synchronize on both
-sides of the timed region, max over ranks.
+Frames counted per step = B*T = 12 800 mixture frames per GPU (the two target spectrograms are work, not frames).
+
+--mode train times the training step instead: the same forward in TRAIN mode (batch-statistics BatchNorm), PIT-MSE,
+the explicit HIP backward, the gradient all-reduce over RCCL (N > 1) and the fused clip + Adam update
+(css_amd.trainer.GraphedTrainStep).  Same frame count per step.
+
+Multi-GPU: one process per GPU over torch.distributed (backend "nccl" = RCCL over xGMI).  Either the launcher starts
+the ranks (torchrun: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or, when WORLD_SIZE is not set and
+--gpus N > 1, this script starts N rank processes itself (plain subprocesses, before anything touches a GPU).  Every
+rank runs its own batch (weak scaling); the fwd+PIT path has no collective on the data path, the train
+mode has the gradient all-reduce.  Barrier + synchronize on both sides of the timed region, max over ranks; rank 0
+prints ONE JSON line with n_gpus = the world size the collective library reports and every rank's ms/step.
 
 Extra objects on the JSON line (task section 4):
-  roofline     dominant kernel = the encoder chain (chain_kernel: FFN_out+LN -> FFN_in -> LN+QKV,
-               15 launches per step, MFMA bound); achieved = algorithmic flops (2 x 4*M*256*1024 +
-               2*M*256*768) / average launch duration measured with HIP events on the launch
-               stream; peak = 2.5 PFLOP/s dense bf16; traffic = HBM bytes per launch from the
-               rocprofv3 PMC pass committed under profiles/ (null if absent).
-               roofline.stft carries the HBM-bound front end the same way (2 052 B/frame).
-  cpu_baseline the oracle (fp32 CPU restatement, kind "port") timed on this box's host cores on
-               ONE full batch (rank 0, N = 1 only).
+  roofline     measured INSIDE the step: one un-captured step is run with the library's launch timeline on (HIP event
+               pairs directly around every kernel launch, on the launch stream); dominant kernel = the encoder chain
+               (chain_kernel<8,0,1,1,1>: FFN_out+LN -> FFN_in -> LN+QKV, 15 launches per step, MFMA bound):
+               achieved = algorithmic flops (2 x 4*M*256*1024 + 2*M*256*768) / average launch duration; peak = 2.5
+               PFLOP/s dense bf16; traffic = HBM bytes per launch from the rocprofv3 PMC passes under profiles/.
+               roofline.attention / .outproj_conv (MFMA), .stft / .pit (HBM, 2 052 and 5 140 B/frame) the same way.
+  cpu_baseline the oracle (fp32 CPU restatement, kind "port") timed on this box's host cores on ONE full batch
+               (rank 0, N = 1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -35,34 +43,77 @@ sys.path.insert(0, ROOT)
 B, T, NBIN = 32, 400, 257
 N_SAMPLES = 512 + 256 * (T - 1)  # 102 656
 PEAK_BF16 = 2.5e15
+PEAK_HBM = 8.0e12
 FLOP_PER_FRAME = 52.57e6  # Conformer-base forward @ T=400
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", choices=("fwd", "train"), default="fwd",
+                    help="fwd: the headline metric (features + forward + PIT); train: + backward, all-reduce, Adam")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="gloo: rehearsal without RCCL")
+    ap.add_argument("--same-device", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses cuda:0 (implies --backend gloo)")
+    ap.add_argument("--buckets", type=int, default=4, help="train mode: all-reduce chunks in flight")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fuse-conv", type=int, default=None, help="debug: csship_conformer_weights.fuse_conv override")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying the "
                     "step as one captured HIP graph")
     ap.add_argument("--blocks", type=int, default=16, help="debug only: anything but 16 is not the headline config")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def spawn_ranks(n):
+    """Start n rank processes of this script (fresh interpreters: nothing here has touched a GPU) and wait."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r))))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
+
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s): reporting the launcher's world size",
+              file=sys.stderr)
+    backend = "gloo" if args.same_device else args.backend
+    dev_index = 0 if args.same_device else local_rank
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if not args.same_device and torch.cuda.device_count() < world:
+            raise SystemExit(f"[bench] {world} ranks need {world} GPUs, this node shows {torch.cuda.device_count()} "
+                             "(--same-device rehearses the rank logic on one GPU over gloo)")
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", dev_index)
 
-    from css_amd import ops
+    from css_amd import _lib, ops
     from css_amd.models import MODELS
     from css_amd.utils import synthetic as syn
 
@@ -71,21 +122,12 @@ def main():
     model = MODELS["Conformer"](257, 257, 2, 1, conf)
     sd = syn.fill_state_dict(syn.conformer_shapes(num_blocks=args.blocks), 0)
     model.load_state_dict(sd)
-    model = model.to(dev).eval()
+    model = model.to(dev)
     if args.fuse_conv is not None:
         model.fuse_conv = args.fuse_conv
 
     mix, src = syn.synthetic_sources(B, N_SAMPLES, seed=rank)
     audio = torch.stack([mix, src[0], src[1]], 0).to(dev)  # [3, B, n]
-
-    def step():
-        # the metric is forward + PIT loss: inference mode (under autograd the model would run its training forward,
-        # which keeps every operator's input for the backward pass)
-        with torch.no_grad():
-            mags = ops.stft(audio, ("mag",))["mag"]  # [3,B,T,257]
-            masks = model.forward_masks(mags[0])
-            loss, perm, _, _ = ops.pit_mse(masks, mags[0], [mags[1], mags[2]])
-        return loss
 
     def fence():
         torch.cuda.synchronize()
@@ -93,120 +135,178 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        loss = step()
-    torch.cuda.synchronize()  # (the first collective - the barrier in fence() - comes after the capture below)
-    # the step is a fixed sequence of ~70 kernel launches on one stream: capture it once, replay it per step
-    # (same kernels, same inputs resident in HBM; only the host-side launch work disappears)
     graphed = False
-    if not args.no_graph:
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                step()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            # thread_local: other threads of this process (e.g. the RCCL watchdog when world > 1) may touch the
-            # runtime while this thread captures
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                static_loss = step()
-            eager_step = step
+    if args.mode == "fwd":
+        model.eval()
 
-            def step():  # noqa: F811
-                graph.replay()
-                return static_loss
-            for _ in range(2):
-                step()
+        def step():
+            # the metric is forward + PIT loss: inference mode (under autograd the model would run its training
+            # forward, which keeps every operator's input for the backward pass)
+            with torch.no_grad():
+                mags = ops.stft(audio, ("mag",))["mag"]  # [3,B,T,257]
+                masks = model.forward_masks(mags[0])
+                loss, perm, _, _ = ops.pit_mse(masks, mags[0], [mags[1], mags[2]])
+            return loss
+        eager_step = step
+        for _ in range(args.warmup):
+            loss = step()
+        torch.cuda.synchronize()  # (the first collective - the barrier in fence() - comes after the capture below)
+        # the step is a fixed sequence of ~55 kernel launches on one stream: capture it once, replay it per step
+        # (same kernels, same inputs resident in HBM; only the host-side launch work disappears)
+        if not args.no_graph:
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    step()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                # thread_local: other threads of this process (e.g. the RCCL watchdog when world > 1) may touch the
+                # runtime while this thread captures
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    static_loss = step()
+
+                def step():  # noqa: F811
+                    graph.replay()
+                    return static_loss
+                for _ in range(2):
+                    step()
+                graphed = True
+            except Exception as e:  # noqa: BLE001  (capture unsupported: keep the eager launches)
+                print(f"[bench] graph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
+                step = eager_step
+    else:
+        from css_amd.objectives import OBJECTIVES
+        from css_amd.optim import FusedAdam
+        from css_amd.trainer import GraphedTrainStep
+        model.train()
+        objective = OBJECTIVES["MSE"].build_objective({})
+        optim = FusedAdam(model.parameters(), lr=1e-4, max_norm=5.0)
+
+        def features():
+            with torch.no_grad():
+                mags = ops.stft(audio, ("mag",))["mag"]
+            return {"mix": mags[0], "source1": mags[1], "source2": mags[2]}
+        if args.no_graph:
+            from css_amd import parallel
+
+            def step():
+                optim.zero_grad()
+                loss = objective(model, features(), device=dev)
+                loss.backward()
+                parallel.allreduce_flat(optim.flat_grad, buckets=args.buckets)
+                optim.step(max_norm=5.0)
+                return loss.detach()
+        else:
+            stepper = GraphedTrainStep(model, objective, optim, features(), max_norm=5.0, device=dev,
+                                       buckets=args.buckets)
             graphed = True
-        except Exception as e:  # noqa: BLE001  (capture unsupported: keep the eager launches)
-            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
-            step = eager_step if "eager_step" in dir() else step
+
+            def step():
+                return stepper(features())[0]
+        for _ in range(args.warmup):
+            loss = step()
+
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
     dt = time.perf_counter() - t0
+    per_rank_ms = [dt / args.steps * 1e3]
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        per_rank_ms = [float(g.item()) / args.steps * 1e3 for g in gathered]
+        dt = max(float(g.item()) for g in gathered)
     loss_val = float(loss)
 
-    # ---- roofline of the dominant kernel (the fused FeedForward, 32 launches per step), measured live with
-    # HIP events recorded on the stream the kernel is launched on (torch's current stream)
-    def launch_time(fn, reps):
-        """Seconds per call of fn: `reps` calls recorded into one HIP graph, the replay timed with HIP events on the
-        stream it is launched on - the host's per-call work (allocations, ctypes) cannot leak into a 20 us kernel's
-        figure.  Falls back to timing the eager loop when capture is unavailable."""
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for _ in range(3):
-            fn()
-        torch.cuda.synchronize()
-        try:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                for _ in range(reps):
-                    fn()
-            g.replay()
-            torch.cuda.synchronize()
-            e0.record(torch.cuda.current_stream())
-            g.replay()
-            e1.record(torch.cuda.current_stream())
-        except Exception as e:  # noqa: BLE001
-            print(f"[bench] roofline capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
-            torch.cuda.synchronize()
-            e0.record(torch.cuda.current_stream())
-            for _ in range(reps):
-                fn()
-            e1.record(torch.cuda.current_stream())
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) * 1e-3 / reps
-
+    # ---- rooflines from INSIDE the step: one un-captured eval step with the library's launch timeline on
     roof = None
     if rank == 0:
-        M = B * T
-        x = torch.randn(M, 256, device=dev)
-        g1, b0 = torch.ones(256, device=dev), torch.zeros(256, device=dev)
+        import ctypes as C
+        lib = C.CDLL(_lib.LIB_PATH)
+        lib.csship_debug_timeline.argtypes = [C.c_int]
+        lib.csship_debug_timeline_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        was_training = model.training
+        model.eval()
+        REPS = 3
 
-        def ffn_w():
-            return ((g1, b0), ops.pack_frag(torch.randn(1024, 256, device=dev) / 16), torch.zeros(1024, device=dev),
-                    ops.pack_frag(torch.randn(256, 1024, device=dev) / 32), torch.zeros(256, device=dev))
-        fa, fb = ffn_w(), ffn_w()
-        wq, bq = ops.pack_frag(torch.randn(768, 256, device=dev) / 16), torch.zeros(768, device=dev)
-        out = torch.empty_like(x)
-        run = lambda: ops.encoder_chain(x, 1024, ffn_a=fa, final_ln=(g1, b0), ffn_b=fb, qkv=((g1, b0), wq, bq, 768), out=out)  # noqa: E731
-        dur = launch_time(run, 50)
+        def probe():
+            with torch.no_grad():
+                mags = ops.stft(audio, ("mag",))["mag"]
+                masks = model.forward_masks(mags[0])
+                ops.pit_mse(masks, mags[0], [mags[1], mags[2]])
+        probe()
+        torch.cuda.synchronize()
+        # two un-timed steps are queued first and the timeline is switched on while the GPU is still working on them:
+        # every timed launch then runs back to back behind earlier work, as in the replayed graph (a launch on an idle
+        # GPU reads twice as long: cold caches, clock ramp)
+        probe()
+        probe()
+        lib.csship_debug_timeline(1)
+        for _ in range(REPS):
+            probe()
+        torch.cuda.synchronize()
+        tl = {}
+        for tag, name in enumerate(("chain", "chain_edge", "attention", "outproj_conv", "embed", "head", "stft", "pit_sse",
+                                    "pit_finalize", "mvn")):
+            ms, n = C.c_double(0), C.c_int(0)
+            lib.csship_debug_timeline_read(tag, C.byref(ms), C.byref(n))
+            tl[name] = (ms.value * 1e-3 / max(n.value, 1), n.value // REPS)  # (seconds per launch, launches per step)
+        lib.csship_debug_timeline(0)
+        if was_training:
+            model.train()
+        M = B * T
+        traffic = {}
+        for tp in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tp)
+            if os.path.exists(tpath):
+                for name, rec in json.load(open(tpath)).items():
+                    traffic.setdefault(name, rec["hbm_bytes_per_launch"])
+
+        def traffic_of(prefix):
+            for name, v in traffic.items():
+                if name.startswith(prefix):
+                    return v
+            return None
+        dur, nl = tl["chain"]
         # two FeedForwards (4*M*256*1024 each) + the q/k/v projection (2*M*256*768): SURVEY.md 8(d) per-layer figures
         flops = 2 * 4.0 * M * 256 * 1024 + 2.0 * M * 256 * 768
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath):
-            for name, rec in json.load(open(tpath)).items():
-                if name.startswith("chain_kernel<8, false, true, true, true>"):
-                    traffic = rec["hbm_bytes_per_launch"]
-        roof = {"bound": "mfma", "kernel": "chain_kernel<8,0,1,1,1> (FFN_out+LN -> FFN_in -> LN+QKV, M=12800; 15 launches/step)",
-                "achieved": flops / dur / 1e12, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                "frac": flops / dur / PEAK_BF16, "traffic": traffic, "avg_launch_us": dur * 1e6,
-                "flops_per_launch": flops,
-                "whole_step_frac": (B * T * FLOP_PER_FRAME * args.blocks / 16) / (dt / args.steps) / PEAK_BF16}
-        # HBM-bound front end for reference (north_star asks for the STFT roofline too)
-        sd_ = launch_time(lambda: ops.stft(audio, ("mag",)), 20)
+        step_flops = B * T * FLOP_PER_FRAME * args.blocks / 16
+        roof = {"bound": "mfma",
+                "kernel": f"chain_kernel<8,0,1,1,1> (FFN_out+LN -> FFN_in -> LN+QKV, M=12800; {nl} launches/step)",
+                "achieved": flops / dur / 1e12 if dur else None, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                "frac": flops / dur / PEAK_BF16 if dur else None, "traffic": traffic_of("chain_kernel<8, false, true, true, true>"),
+                "avg_launch_us": dur * 1e6, "flops_per_launch": flops, "timing": "HIP events around the in-step launches",
+                "whole_step_frac": (step_flops * (3.0 if args.mode == "train" else 1.0)) / (dt / args.steps) / PEAK_BF16}
+        ad, an = tl["attention"]
+        aflops = B * 4 * (2.0 * T * T * 64 * 3)  # QK^T + Q.PE^T + P.V over the full T x T, SURVEY 8(d)
+        roof["attention"] = {"bound": "mfma", "kernel": f"mha_fwd_kernel<8> ({an} launches/step)",
+                             "achieved": aflops / ad / 1e12 if ad else None, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                             "frac": aflops / ad / PEAK_BF16 if ad else None, "avg_launch_us": ad * 1e6,
+                             "traffic": traffic_of("mha_fwd_kernel")}
+        od, on = tl["outproj_conv"]
+        oflops = 2.0 * M * 256 * 256 + 2.0 * M * 256 * 33  # output projection + depthwise taps (halo excluded)
+        roof["outproj_conv"] = {"bound": "mixed", "kernel": f"outproj_conv_kernel ({on} launches/step)",
+                                "achieved": oflops / od / 1e12 if od else None, "unit": "TFLOP/s", "avg_launch_us": od * 1e6,
+                                "hbm_algorithmic_GBps": (M * 256 * (2 + 4 + 4)) / od / 1e9 if od else None,
+                                "traffic": traffic_of("outproj_conv_kernel")}
+        sdur, _ = tl["stft"]
         nfr = 3 * B * T
-        roof["stft"] = {"bound": "hbm", "achieved": nfr * 2052 / sd_ / 1e9, "peak": 8000.0, "unit": "GB/s",
-                        "frac": nfr * 2052 / sd_ / 8.0e12, "avg_launch_us": sd_ * 1e6,
-                        "bytes_per_frame": 2052}
+        roof["stft"] = {"bound": "hbm", "achieved": nfr * 2052 / sdur / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                        "frac": nfr * 2052 / sdur / PEAK_HBM, "avg_launch_us": sdur * 1e6, "bytes_per_frame": 2052,
+                        "traffic": traffic_of("stft_kernel")}
         # mask application + PIT-MSE (pit_sse + finalize launches), SURVEY 8(d): 6 168 B/frame minus the noise mask
-        with torch.no_grad():
-            mags_ = ops.stft(audio, ("mag",))["mag"]
-            masks_ = model.forward_masks(mags_[0])
-        pd_ = launch_time(lambda: ops.pit_mse(masks_, mags_[0], [mags_[1], mags_[2]]), 20)
+        pdur = tl["pit_sse"][0] + tl["pit_finalize"][0]
         pit_bytes = 5 * 257 * 4
-        roof["pit"] = {"bound": "hbm", "achieved": B * T * pit_bytes / pd_ / 1e9, "peak": 8000.0, "unit": "GB/s",
-                       "frac": B * T * pit_bytes / pd_ / 8.0e12, "avg_launch_us": pd_ * 1e6,
-                       "bytes_per_frame": pit_bytes}
+        roof["pit"] = {"bound": "hbm", "achieved": B * T * pit_bytes / pdur / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                       "frac": B * T * pit_bytes / pdur / PEAK_HBM, "avg_launch_us": pdur * 1e6,
+                       "sse_us": tl["pit_sse"][0] * 1e6, "finalize_us": tl["pit_finalize"][0] * 1e6,
+                       "bytes_per_frame": pit_bytes, "traffic": traffic_of("pit_sse_kernel")}
+        roof["step_kernel_us"] = {k: round(v[0] * v[1] * 1e6, 1) for k, v in tl.items()}
 
     # ---- CPU baseline: the oracle on one full batch, host cores of this box
     cpu = None
@@ -225,24 +325,34 @@ def main():
             closs = oracle.pit.mse_objective(y_pred, mags[1], mags[2])
             cdt = time.perf_counter() - c0
         cpu = {"value": B * T / cdt, "unit": "frames/s", "cores": cores, "kind": "port",
-               "sample": f"1 step of the full workload (B={B} x T={T} frames, fp32, torch {torch.__version__} CPU ops)",
-               "loss": float(closs), "gpu_loss": loss_val}
+               "sample": f"1 forward+PIT step of the full workload (B={B} x T={T} frames, fp32, torch {torch.__version__} CPU ops)",
+               "loss": float(closs), "gpu_loss": loss_val if args.mode == "fwd" else None}
 
     if rank == 0:
         frames = world * B * T * args.steps
+        mode_txt = ("eval forward (running-stat BN, no dropout)" if args.mode == "fwd" else
+                    "training step: train-mode forward (batch-stat BN) + PIT + backward + gradient all-reduce + clip/Adam")
+        metric = "STFT-frames/sec (fwd+PIT) Conformer-1ch" if args.mode == "fwd" else \
+            "STFT-frames/sec (training step: fwd+PIT+bwd+all-reduce+Adam) Conformer-1ch"
         line = {
-            "metric": "STFT-frames/sec (fwd+PIT) Conformer-1ch", "value": frames / dt, "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
-            "data": "synthetic",
+            "metric": metric, "value": frames / dt, "unit": "frames/s",
+            "n_gpus": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "Conformer-base 1ch 2-spk fwd+PIT, batch=32x400-frame chunks (configs[1])",
                        "global_batch": world * B, "frames_per_chunk": T, "num_blocks": args.blocks,
-                       "mode": "eval forward (running-stat BN, no dropout)", "parallelism": f"dp{world}",
-                       "launch": "hip-graph replay" if graphed else "eager"},
+                       "mode": mode_txt, "parallelism": f"dp{world}",
+                       "launch": "hip-graph replay" if graphed else "eager",
+                       "collective_backend": (backend if world > 1 else None),
+                       "ranks_launched_by": ("launcher" if "TORCHELASTIC_RUN_ID" in os.environ or "GROUP_RANK" in os.environ
+                                             else ("bench.py --gpus" if world > 1 else None))},
+            "per_rank_ms_per_step": per_rank_ms,
             "roofline": roof, "cpu_baseline": cpu, "loss": loss_val,
         }
         print(json.dumps(line))
+        sys.stdout.flush()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -34,6 +34,23 @@ def _deliver(model, G):
     return tuple(G.get(p) if p.requires_grad else None for p in params)
 
 
+def _deliver_group(model, module, G):
+    """Gradients of ``module``'s parameters are final while the backward pass is still running: add them into their
+    preset ``.grad`` views now and tell the trainer's bucket hook (css_amd.parallel.OverlappedGradReducer starts the
+    all-reduce of that stretch of the flat gradient buffer while the remaining layers are back-propagated)."""
+    hook = getattr(model, "_grad_bucket_hook", None)
+    if hook is None:
+        return
+    ps = [p for p in module.parameters() if p.requires_grad and p in G and p.grad is not None
+          and p.grad.dtype == G[p].dtype and p.grad.is_contiguous()]
+    if ps:
+        with torch.no_grad():
+            torch._foreach_add_([p.grad for p in ps], [G[p].contiguous() for p in ps])
+        for p in ps:
+            del G[p]
+    hook(module)
+
+
 class PitMse(torch.autograd.Function):
     """loss = mean_b min_perm MSE(mask_k * f_orig, target_{perm})  with the hand-written backward."""
 
@@ -211,6 +228,7 @@ class ConformerTrain(torch.autograd.Function):
             dm = buf
         dx, dw, db = bw.head_bwd(dm, masks, S["x_enc"], S["wh_bf"])
         put(model.linear.weight, dw), put(model.linear.bias, db)
+        _deliver_group(model, model.linear, G)
         window = bw.relpos_window(S["pe_bf"], T, enc.pos_emb.maxlen)
         dwin = None
         # skewed dS buffer shared by all layers: the band positions are the same every layer, the rest stays zero
@@ -257,6 +275,7 @@ class ConformerTrain(torch.autograd.Function):
             put(a.linear_out.weight, dwo), put(a.linear_out.bias, dbo)
             dx = ffn_b(lay.feed_forward_in, "ffn_in", dx)
             L.clear()
+            _deliver_group(model, lay, G)
         dpe = torch.zeros_like(enc.pos_emb.pe_k.weight)
         dpe.index_add_(0, window[1], dwin[:2 * T - 1])
         put(enc.pos_emb.pe_k.weight, dpe)

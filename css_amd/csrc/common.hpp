@@ -103,3 +103,35 @@ DEV void stamp(unsigned long long* st, int slot) {
     st[wg * 8 + slot] = __builtin_amdgcn_s_memrealtime();
   }
 }
+
+// Optional per-launch timeline (diagnostic / bench.py's in-step roofline; off in normal operation): when switched on
+// with csship_debug_timeline(1), instrumented entry points bracket their launches with a pair of HIP events on the
+// launch stream, tagged with a kernel family; csship_debug_timeline_read() sums the elapsed times per tag.  The events
+// sit directly around the launch in submission order, so host-side gaps between calls are not inside the bracket.
+// Not usable while a HIP graph is being captured (events are recorded eagerly): bench.py runs an un-captured step.
+enum {
+  CSSHIP_TL_CHAIN = 0,      /* chain_kernel<8,0,1,1,1>: FFN_out + LN -> FFN_in -> LN + q/k/v (interior blocks) */
+  CSSHIP_TL_CHAIN_EDGE = 1, /* first / last chain launches (one FeedForward only) */
+  CSSHIP_TL_ATTN = 2,
+  CSSHIP_TL_OUTPROJ_CONV = 3,
+  CSSHIP_TL_EMBED = 4,
+  CSSHIP_TL_HEAD = 5,
+  CSSHIP_TL_STFT = 6,
+  CSSHIP_TL_PIT_SSE = 7,
+  CSSHIP_TL_PIT_FINALIZE = 8,
+  CSSHIP_TL_MVN = 9,
+  CSSHIP_TL_OTHER = 10,
+  CSSHIP_TL_NTAGS = 11
+};
+extern bool g_csship_timeline_on;
+void csship_timeline_push(int tag, hipStream_t s, bool stop);
+struct TimelineScope {
+  int tag;
+  hipStream_t s;
+  TimelineScope(int tag_, hipStream_t s_) : tag(tag_), s(s_) {
+    if (g_csship_timeline_on) csship_timeline_push(tag, s, false);
+  }
+  ~TimelineScope() {
+    if (g_csship_timeline_on) csship_timeline_push(tag, s, true);
+  }
+};

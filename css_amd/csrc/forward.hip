@@ -4,6 +4,8 @@
 // ctypes call per forward instead of ~180, and the launch is hipGraph-capturable.
 #include "common.hpp"
 
+#include <vector>
+
 namespace {
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -110,6 +112,46 @@ int forward_generic(const csship_conformer_weights* w, const float* f, int64_t l
 }  // namespace
 
 unsigned long long* g_csship_stamps = nullptr;
+
+// ---- per-launch timeline (see common.hpp)
+bool g_csship_timeline_on = false;
+namespace {
+struct TlRec { int tag; hipEvent_t e0, e1; bool closed; };
+std::vector<TlRec> g_tl;
+}  // namespace
+void csship_timeline_push(int tag, hipStream_t s, bool stop) {
+  if (!stop) {
+    TlRec r{tag, nullptr, nullptr, false};
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+    (void)hipEventRecord(r.e0, s);
+    g_tl.push_back(r);
+  } else {
+    for (size_t i = g_tl.size(); i-- > 0;)
+      if (g_tl[i].tag == tag && !g_tl[i].closed) {
+        (void)hipEventRecord(g_tl[i].e1, s);
+        g_tl[i].closed = true;
+        break;
+      }
+  }
+}
+// Diagnostic only (not part of include/csship.h's product surface): enable = 1 starts a fresh timeline, 0 stops it.
+extern "C" void csship_debug_timeline(int enable) {
+  for (auto& r : g_tl) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  g_tl.clear();
+  g_csship_timeline_on = enable != 0;
+}
+// After the caller has synchronised the stream: total milliseconds and number of launches recorded under `tag`.
+extern "C" int csship_debug_timeline_read(int tag, double* total_ms, int* count) {
+  double t = 0.0; int n = 0;
+  for (auto& r : g_tl)
+    if (r.tag == tag && r.closed) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { t += ms; ++n; }
+    }
+  if (total_ms) *total_ms = t;
+  if (count) *count = n;
+  return CSSHIP_OK;
+}
 // Diagnostic only (not part of include/csship.h): device buffer of [n_workgroups][8] u64 that instrumented
 // kernels fill with s_memrealtime phase stamps; pass NULL to switch stamping off.
 extern "C" void csship_debug_stamps(void* device_buffer) {
@@ -154,9 +196,15 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
   const int M = B * T, D = w->d_model, FF = w->d_ffn;
 
   // input MVN over time (conformer.py:95) folded into the embed GEMM's A load
-  TRY(csship_mvn_stats(f, B, T, w->idim, ldf, -INFINITY, 1.1920928955078125e-07f, ws.mean, ws.rinv, stream));
-  TRY(csship_embed(f, ldf, ws.mean, ws.rinv, w->embed_w, w->embed_b, w->embed_ln_g, w->embed_ln_b, ws.x0, B, T, w->idim,
-                   D, stream));
+  {
+    TimelineScope tl(CSSHIP_TL_MVN, as_stream(stream));
+    TRY(csship_mvn_stats(f, B, T, w->idim, ldf, -INFINITY, 1.1920928955078125e-07f, ws.mean, ws.rinv, stream));
+  }
+  {
+    TimelineScope tl(CSSHIP_TL_EMBED, as_stream(stream));
+    TRY(csship_embed(f, ldf, ws.mean, ws.rinv, w->embed_w, w->embed_b, w->embed_ln_g, w->embed_ln_b, ws.x0, B, T, w->idim,
+                     D, stream));
+  }
   float *x = ws.x0, *y = ws.x1;
   // fuse_conv 0 = default: out-proj + conv module as one kernel in eval mode, separate kernels when BatchNorm needs
   // batch statistics (a grid-wide reduction sits between the convolution and the ReLU then)
@@ -187,16 +235,23 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
     for (int l = 0; l < w->n_layer; ++l) {
       const csship_layer_weights& L = w->layers[l];
       const csship_layer_weights* P = l > 0 ? &w->layers[l - 1] : nullptr;
-      TRY(csship_encoder_chain(x, x, nullptr, nullptr, T, P ? &P->ffn_out : nullptr, P ? P->ln_g : nullptr,
-                               P ? P->ln_b : nullptr, &L.ffn_in, L.mha.ln_g, L.mha.ln_b, L.mha.wqkv, L.mha.bqkv,
-                               ws.qkv_bf, M, D, FF, 3 * D, stream));
-      TRY(csship_mha_relpos(ws.qkv_bf, w->pe_k, w->pe_q_min, w->pe_q_max, ws.ao_bf, B, T, w->n_head, stream));
+      {
+        TimelineScope tl(P ? CSSHIP_TL_CHAIN : CSSHIP_TL_CHAIN_EDGE, as_stream(stream));
+        TRY(csship_encoder_chain(x, x, nullptr, nullptr, T, P ? &P->ffn_out : nullptr, P ? P->ln_g : nullptr,
+                                 P ? P->ln_b : nullptr, &L.ffn_in, L.mha.ln_g, L.mha.ln_b, L.mha.wqkv, L.mha.bqkv,
+                                 ws.qkv_bf, M, D, FF, 3 * D, stream));
+      }
+      {
+        TimelineScope tl(CSSHIP_TL_ATTN, as_stream(stream));
+        TRY(csship_mha_relpos(ws.qkv_bf, w->pe_k, w->pe_q_min, w->pe_q_max, ws.ao_bf, B, T, w->n_head, stream));
+      }
       if (w->bn_mode == 0 && conv_mode == 2) {
         // optional (28.4 vs 27.2 us): x += out-proj(attn); g = glu(LN_conv(x)) in the same epilogue; conv back half from g
         TRY(csship_outproj_glu(ws.ao_bf, L.mha.wo, L.mha.bo, x, x, &L.conv, y, M, D, stream));
         TRY(csship_conv_from_glu(x, y, x, &L.conv, B, T, D, w->kernel_size, stream));
       } else if (w->bn_mode == 0 && conv_mode == 3) {
         // one kernel: x2 = x + out-proj(attn) and the conv module on it (256 workgroups at T = 400)
+        TimelineScope tl(CSSHIP_TL_OUTPROJ_CONV, as_stream(stream));
         TRY(csship_outproj_conv(ws.ao_bf, L.mha.wo, L.mha.bo, x, y, &L.conv, B, T, D, w->kernel_size, stream));
         { float* t = x; x = y; y = t; }
       } else {
@@ -207,6 +262,7 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
       }
     }
     const csship_layer_weights& L = w->layers[w->n_layer - 1];
+    TimelineScope tl(CSSHIP_TL_CHAIN_EDGE, as_stream(stream));
     TRY(csship_encoder_chain(x, x, nullptr, nullptr, T, &L.ffn_out, L.ln_g, L.ln_b, nullptr, nullptr, nullptr, nullptr,
                              nullptr, nullptr, M, D, FF, 0, stream));
   }
@@ -216,6 +272,7 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
       return CSSHIP_ELAUNCH;
   }
   // mask head: ReLU(Linear(d_model -> num_bins*(K+1)))         (conformer.py:98-100)
+  TimelineScope tl(CSSHIP_TL_HEAD, as_stream(stream));
   TRY(csship_panel_linear(x, CSSHIP_PRO_F32, nullptr, nullptr, w->head_w, w->head_b, nullptr, 0, 0.f, masks,
                           ld_masks, M, w->n_out, D, CSSHIP_EPI_RELU, stream));
   return CSSHIP_OK;

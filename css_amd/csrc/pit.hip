@@ -289,10 +289,16 @@ extern "C" int csship_pit_mse(const float* masks, int64_t ld_mask, const float* 
   const int fb = 256;  // finalize: one block (32 samples per pass) so the batch mean can follow a block barrier
 #define PIT_CASE(KK)                                                                                          \
   case KK:                                                                                                    \
-    hipLaunchKernelGGL(pit_sse_kernel<KK>, grid, dim3(256), 0, s, a);                                         \
+    {                                                                                                         \
+      TimelineScope tl(CSSHIP_TL_PIT_SSE, s);                                                                 \
+      hipLaunchKernelGGL(pit_sse_kernel<KK>, grid, dim3(256), 0, s, a);                                       \
+    }                                                                                                         \
     CSSHIP_CHECK_LAUNCH();                                                                                    \
-    hipLaunchKernelGGL(pit_finalize_kernel<KK>, dim3(1), dim3(fb), 0, s, a.partial, B, a.nchunk, norm, loss,   \
-                       perm, pair_sse, per_sample);                                                           \
+    {                                                                                                         \
+      TimelineScope tl(CSSHIP_TL_PIT_FINALIZE, s);                                                            \
+      hipLaunchKernelGGL(pit_finalize_kernel<KK>, dim3(1), dim3(fb), 0, s, a.partial, B, a.nchunk, norm, loss, \
+                         perm, pair_sse, per_sample);                                                         \
+    }                                                                                                         \
     break;
   switch (K) {
     PIT_CASE(1) PIT_CASE(2) PIT_CASE(3) PIT_CASE(4)

@@ -219,6 +219,7 @@ extern "C" int csship_stft(const float* audio, int64_t n0, int64_t stride0, int6
   }
   const int64_t runs = (T + fw - 1) / fw;
   dim3 grid((unsigned)((runs + 3) / 4), (unsigned)S);
+  TimelineScope tl(CSSHIP_TL_STFT, as_stream(stream));
   if (mag && !re && !im && !pha)
     hipLaunchKernelGGL(stft_kernel<true>, grid, dim3(256), 0, as_stream(stream), audio, n1, stride0, stride1, n_samples,
                        (int)T, fw, mag, re, im, pha);

@@ -2,7 +2,12 @@
 
 A css_amd training step is ~2 300 kernel launches (forward operators, PIT, every gradient GEMM, optimiser) issued
 from Python; at 23 ms of GPU work the host cannot keep up.  ``GraphedTrainStep`` captures
-zero_grad -> objective(model, batch) -> backward -> [flat all-reduce] -> clip + Adam once and replays it per step:
+zero_grad -> objective(model, batch) -> backward -> clip + Adam once and replays it per step.  In a multi-GPU job
+(torch.distributed initialised, one process per GPU) the step is TWO graphs with the gradient all-reduce between them:
+graph 1 = zero_grad, forward, PIT, backward; then ``parallel.allreduce_flat`` on FusedAdam's flat gradient buffer
+(RCCL over xGMI, ``buckets`` asynchronous chunks in flight; issued eagerly - no collective is captured, so nothing
+depends on the runtime's support for capturing RCCL); graph 2 = clip + Adam.  Replaces the reference's per-epoch
+checkpoint averaging (scripts/python/combine_models.py:55-82).  Common to both forms:
 inputs are copied into static buffers, the learning rate / Adam bias corrections live in device memory
 (``FusedAdam.advance_hyper``), BatchNorm bookkeeping and the PIT permutation search are device-side already.
 Batches must keep one shape (the reference trains on fixed-length windows, separation.py:204-232).
@@ -14,11 +19,11 @@ from ..optim import FusedAdam
 
 
 class GraphedTrainStep:
-    def __init__(self, model, objective, optim, example_batch, max_norm, device="cuda", warmup=2):
+    def __init__(self, model, objective, optim, example_batch, max_norm, device="cuda", warmup=2, buckets=4):
         if not isinstance(optim, FusedAdam):
             raise TypeError("GraphedTrainStep needs css_amd.optim.FusedAdam (static parameter / gradient buffers)")
-        if parallel.is_distributed():
-            raise NotImplementedError("graph capture of the RCCL all-reduce is not wired up; use train_one_epoch")
+        self.distributed = parallel.is_distributed()
+        self.buckets = buckets
         self.model, self.objective, self.optim, self.max_norm = model, objective, optim, max_norm
         self.keys = [k for k in ("mix", "source1", "source2") if k in example_batch]
         self.static = {k: example_batch[k].to(device).clone() for k in self.keys}
@@ -41,15 +46,29 @@ class GraphedTrainStep:
         for b, s_ in bufs:
             b.copy_(s_)
         optim._step = step0
+        # thread_local: other threads of this process (the RCCL watchdog) may touch the runtime during the capture
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self.loss, self.grad_norm = self._eager()
+        if not self.distributed:
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.loss, self.grad_norm = self._eager()
+        else:
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.loss = self._forward_backward()
+            self.graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool(), capture_error_mode="thread_local"):
+                self.grad_norm = self.optim.step(max_norm=self.max_norm)
 
-    def _eager(self):
+    def _forward_backward(self):
         self.optim.zero_grad()
         loss = self.objective(self.model, self.static, device=self.static[self.keys[0]].device)
         loss.backward()
-        return loss.detach(), self.optim.step(max_norm=self.max_norm)
+        return loss.detach()
+
+    def _eager(self):
+        loss = self._forward_backward()
+        if self.distributed:
+            parallel.allreduce_flat(self.optim.flat_grad, average=True, buckets=self.buckets)
+        return loss, self.optim.step(max_norm=self.max_norm)
 
     def __call__(self, batch):
         """One optimiser step on ``batch``; returns (loss, grad_norm) as 0-dim device tensors of THIS step (they are
@@ -58,4 +77,7 @@ class GraphedTrainStep:
             self.static[k].copy_(batch[k], non_blocking=True)
         self.optim.advance_hyper()
         self.graph.replay()
+        if self.distributed:
+            parallel.allreduce_flat(self.optim.flat_grad, average=True, buckets=self.buckets)
+            self.graph_opt.replay()
         return self.loss, self.grad_norm

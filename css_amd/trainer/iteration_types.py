@@ -5,8 +5,9 @@ reference's step order (forward, backward, clip, step, zero_grad, scheduler).  F
 PIT backward are HIP kernels; the Conformer (d_model 256) backward is explicit HIP kernels too, other models use
 the torch-autograd stop-gap of css_amd/autograd.py
 (PyTorch-ROCm restatement used only to back-propagate) until the backward kernels exist.
-In a multi-GPU job (torch.distributed initialised) gradients are summed across ranks with one
-flat-bucket all-reduce over RCCL before clipping (css_amd/parallel.py), replacing the
+In a multi-GPU job (torch.distributed initialised) gradients are averaged across ranks over RCCL
+before clipping (css_amd/parallel.py: with FusedAdam, buckets of ~4 encoder blocks of the flat
+gradient buffer are all-reduced while the remaining blocks are back-propagated), replacing the
 reference's per-epoch checkpoint averaging (scripts/python/combine_models.py:55-82).
 """
 import logging
@@ -18,6 +19,9 @@ from .. import ops, parallel
 
 def train_one_epoch(args, generator, model, objective, optim, lr_sched, device="cpu"):
     total_loss = 0.0
+    reducer = None
+    if hasattr(optim, "flat_grad") and parallel.is_distributed():
+        reducer = parallel.OverlappedGradReducer(model, optim, blocks_per_bucket=getattr(args, "blocks_per_bucket", 4))
     for i in range(1, args.batches_per_epoch + 1):
         b = next(generator)
         log = (f"Iter: {i} of {args.batches_per_epoch} LR:{lr_sched.curr_lr:0.5e} bsize: {b['mix'].size(0)} "
@@ -29,10 +33,13 @@ def train_one_epoch(args, generator, model, objective, optim, lr_sched, device="
         ops.lstm_dist_check()  # the item() above synchronised: a timed-out BLSTM hand-off invalidates this loss
         log += f"Loss: {loss_val:0.5f} "
         total_loss += loss_val
+        if reducer is not None:
+            reducer.begin()   # finished blocks are all-reduced while the rest of the backward pass runs
         loss.backward()
         del b
         if hasattr(optim, "flat_grad"):  # css_amd.optim.FusedAdam: the flat gradient buffer is the all-reduce bucket
-            parallel.allreduce_flat(optim.flat_grad)
+            if reducer is not None:
+                reducer.finish()
             grad_norm = optim.step(max_norm=args.grad_thresh)  # clip + Adam in one pass, norm stays on the device
         else:
             parallel.allreduce_gradients(model.parameters())
