@@ -53,6 +53,13 @@ class BgemmParams(C.Structure):
                 ("sX1", _i64), ("sX2", _i64), ("alpha", _f32)]
 
 
+class DropoutCfg(C.Structure):  # csship_dropout_cfg
+    _fields_ = [("seed", _p), ("stream", C.c_uint32), ("p", _f32)]
+
+
+_dc = C.POINTER(DropoutCfg)
+
+
 class PackJob(C.Structure):  # csship_pack_job (64 bytes)
     _fields_ = [("w", _p), ("row_major", _p), ("frag", _p), ("ld_w", _i64), ("ld_row_major", _i64),
                 ("R", _i32), ("K", _i32), ("dst_row0", _i32), ("Kp", _i32), ("scale", _f32), ("transposed", _i32)]
@@ -130,6 +137,18 @@ SIGNATURES = {
     "csship_mvdr_finish": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i64, _p]),
     "csship_doa_workspace": (_sz, [_i32, _i32, _i32, _i32, _i32]),
     "csship_doa_likelihood": (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _p, _p, _p, _sz, _p]),
+    "csship_dropout_apply": (_i32, [_p, _i64, _p, _i64, _i64, _i32, _dc, _p]),
+    "csship_dropout_add": (_i32, [_p, _p, _p, _f32, _i64, _i32, _dc, _p]),
+    "csship_dropout_mask": (_i32, [_p, _i64, _dc, _p]),
+    "csship_ffn_fused_drop": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _dc, _dc, _p]),
+    "csship_ffn_bwd_drop": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _dc, _dc, _p,
+                                    _p, _sz, _p]),
+    "csship_mha_relpos_train_drop": (_i32, [_p, _p, _i32, _i32, _p, _p, _i32, _i32, _i32, _dc, _p]),
+    "csship_mha_relpos_probs_drop": (_i32, [_p, _p, _i32, _i32, _p, _p, _p, _i64, _i32, _i32, _i32, _dc, _p]),
+    "csship_attn_softmax_bwd_drop": (_i32, [_p, _p, _p, _i64, _p, _p, _p, _i32, _i32, _i32, _i32, _dc, _p]),
+    "csship_convmod_drop": (_i32, [_p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _i32, _p, _dc, _p]),
+    "csship_convmod_bwd_drop": (_i32, [_p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _dc, _p,
+                                        _sz, _p]),
     "csship_conformer_workspace": (_sz, [C.POINTER(ConformerWeights), _i32, _i32]),
     "csship_conformer_forward": (_i32, [C.POINTER(ConformerWeights), _p, _i64, _i32, _i32, _p, _i64, _p, _p, _sz, _p]),
 }

@@ -15,6 +15,7 @@ Forward values ALWAYS come from the HIP kernels.  Backward:
 import torch
 
 from . import backward as bw, ops, ops_bwd as ob
+from .dropout import DropState, model_drop_state
 
 BF = torch.bfloat16
 
@@ -105,8 +106,9 @@ def _conformer_pack_plan(model, wide, device):
 
 
 class ConformerTrain(torch.autograd.Function):
-    """masks = Conformer(f) with the explicit HIP backward (no dropout).  model.training selects BatchNorm batch
-    statistics (running statistics updated) or, in eval mode, the frozen running statistics.  d_k = 64, kernel 33;
+    """masks = Conformer(f) with the explicit HIP backward.  model.training selects BatchNorm batch statistics (running
+    statistics updated) and the reference's dropouts (css_amd/dropout.py) or, in eval mode, the frozen running
+    statistics and no dropout.  d_k = 64, kernel 33;
     d_model = 256 runs the tuned row-panel kernels (fused FeedForward forward / backward, LN-prologue projections),
     other widths (Conformer-large: 512) the same operators from the size-generic kernels."""
 
@@ -120,7 +122,12 @@ class ConformerTrain(torch.autograd.Function):
         wide = D != 256          # size-generic kernels
         batch_bn = model.training
         mean, rinv = ops.mvn_stats(f)
-        S = {"f": f, "mean": mean, "rinv": rinv, "layers": [], "wide": wide, "batch_bn": batch_bn}
+        # dropout (training only): the step's seed is snapshotted so that the backward regenerates the same masks even if
+        # another forward runs in between
+        ds = model_drop_state(model, getattr(enc, "dropout_rate", 0.0))
+        if ds.active:
+            ds = DropState(ds.seed.clone(), ds.p, ds.offset)
+        S = {"f": f, "mean": mean, "rinv": rinv, "layers": [], "wide": wide, "batch_bn": batch_bn, "drop": ds}
         Kp = (F + 7) // 8 * 8
         pack = _conformer_pack_plan(model, wide, f.device)
         pack["plan"].run()
@@ -128,26 +135,32 @@ class ConformerTrain(torch.autograd.Function):
         fn = ob.mvn_apply(f, mean, rinv, Kp)
         e = ob.bgemm(fn, we_bf, bias=enc.embed[0].bias.detach())
         _, x = ops.layernorm_relu(e, enc.embed[1].weight.detach(), enc.embed[1].bias.detach())
+        if ds.active:  # conformer.py:127 drops before the ReLU; relu(drop(v)) == drop(relu(v)) (the scale is positive)
+            ops.dropout_apply(x, ds.cfg("embed"))
         S["we_bf"] = we_bf
         pe = enc.pos_emb.pe_k.weight.detach()
         pe_pack = ops.pack_relpos(pe, enc.pos_emb.maxlen)
         S["pe_bf"] = pe.to(BF)
         S["pe_pack"] = pe_pack
         bn_means, bn_vars, bn_cnt, bn_new_m, bn_new_v = [], [], [], [], []
-        for lay, wp in zip(enc.encoders, pack["layers"]):
+        for li, (lay, wp) in enumerate(zip(enc.encoders, pack["layers"])):
             L = {}
 
             def ffn(m, xin, tag):
+                dh, do = ds.cfg(f"{li}.{tag}.hidden"), ds.cfg(f"{li}.{tag}.out")
                 if wide:  # LayerNorm -> tiled GEMM (ReLU, bf16) -> tiled GEMM (+ residual)
                     w1_bf, w2_bf = wp[tag]
                     L[tag] = (xin, w1_bf, w2_bf)
                     a_, _ = ops.layernorm(xin, m.layer_norm.weight.detach(), m.layer_norm.bias.detach())
-                    h_ = ops.gemm(a_, w1_bf, m.net[0].bias.detach(), relu=True, out_bf16=True)
-                    return ops.gemm(h_, w2_bf, m.net[3].bias.detach(), residual=xin, alpha=0.5)
+                    if not ds.active:
+                        h_ = ops.gemm(a_, w1_bf, m.net[0].bias.detach(), relu=True, out_bf16=True)
+                        return ops.gemm(h_, w2_bf, m.net[3].bias.detach(), residual=xin, alpha=0.5)
+                    h_ = ops.dropout_apply(ops.gemm(a_, w1_bf, m.net[0].bias.detach(), relu=True), dh)   # f32 hidden
+                    return ops.dropout_add(xin, ops.gemm(h_, w2_bf, m.net[3].bias.detach()), do, alpha=0.5)
                 w1p, w2p, w2tp, w1tp = wp[tag]
                 L[tag] = (xin, w1p, w2tp, w1tp)
                 return ops.ffn_fused(xin, (m.layer_norm.weight.detach(), m.layer_norm.bias.detach()), w1p,
-                                     m.net[0].bias.detach(), w2p, m.net[3].bias.detach(), FF, 0.5)
+                                     m.net[0].bias.detach(), w2p, m.net[3].bias.detach(), FF, 0.5, drop_hidden=dh, drop_out=do)
 
             x1 = ffn(lay.feed_forward_in, x, "ffn_in")
             a = lay.self_attn
@@ -160,9 +173,13 @@ class ConformerTrain(torch.autograd.Function):
             else:
                 qkv = ops.panel_linear(x1, wqkv_p, bqkv, 3 * D,
                                        ln=(a.layer_norm.weight.detach(), a.layer_norm.bias.detach()), out_bf16=True)
-            ao, lse = ops.mha_relpos_train(qkv.view(B, T, 3 * D), pe_pack, H)
+            ao, lse = ops.mha_relpos_train(qkv.view(B, T, 3 * D), pe_pack, H, drop=ds.cfg(f"{li}.attn.p"))
             ao = ao.view(M, D)
-            if wide:
+            if ds.active:   # x2 = x1 + D(ao wo^T + bo): the projection without its fused residual, then one add pass
+                y2 = ops.gemm(ao, wo_bf, a.linear_out.bias.detach()) if wide else \
+                    ops.panel_linear(ao, wo_p, a.linear_out.bias.detach(), D)
+                x2 = ops.dropout_add(x1, y2, ds.cfg(f"{li}.attn.out"))
+            elif wide:
                 x2 = ops.gemm(ao, wo_bf, a.linear_out.bias.detach(), residual=x1, alpha=1.0)
             else:
                 x2 = ops.panel_linear(ao, wo_p, a.linear_out.bias.detach(), D, residual=x1)
@@ -175,7 +192,7 @@ class ConformerTrain(torch.autograd.Function):
                  "bn_mean": c.BN.running_mean, "bn_var": c.BN.running_var,
                  "pw2_w": c.pw_conv_2.weight.detach().view(1), "pw2_b": c.pw_conv_2.bias.detach()}
             x3, fws = ops.convmod(x2.view(B, T, D), W, K, batch_stats=batch_bn, keep_activations=not batch_bn,
-                                  return_workspace=True)
+                                  return_workspace=True, drop=ds.cfg(f"{li}.conv.out"))
             x3 = x3.view(M, D)
             L["conv"] = (x2, W, fws)
             if batch_bn:
@@ -233,19 +250,23 @@ class ConformerTrain(torch.autograd.Function):
         dwin = None
         # skewed dS buffer shared by all layers: the band positions are the same every layer, the rest stays zero
         skew_buf = torch.zeros((B, T, H, window[0].shape[0]), dtype=BF, device=masks.device)
-        for lay, L in zip(reversed(list(enc.encoders)), reversed(S["layers"])):
+        ds = S["drop"]
+        nlay = len(enc.encoders)
+        for li, lay, L in zip(range(nlay - 1, -1, -1), reversed(list(enc.encoders)), reversed(S["layers"])):
             dx, dg, dbeta = ob.layernorm_bwd(L["x4"], dx, lay.layer_norm.weight.detach(), lay.layer_norm.bias.detach())
             put(lay.layer_norm.weight, dg), put(lay.layer_norm.bias, dbeta)
 
             def ffn_b(m, tag, dy):
+                dh, do = ds.cfg(f"{li}.{tag}.hidden"), ds.cfg(f"{li}.{tag}.out")
                 if S["wide"]:
                     xin, w1_bf, w2_bf = L[tag]
                     dxo, g = bw.ffn_bwd(xin, dy, m.layer_norm.weight.detach(), m.layer_norm.bias.detach(),
-                                        m.net[0].bias.detach(), w1_bf, w2_bf, 0.5)
+                                        m.net[0].bias.detach(), w1_bf, w2_bf, 0.5, drop_hidden=dh, drop_out=do)
                 else:
                     xin, w1p, w2tp, w1tp = L[tag]
                     dxo, g = bw.ffn_bwd_fused(xin, dy, m.layer_norm.weight.detach(), m.layer_norm.bias.detach(),
-                                              m.net[0].bias.detach(), w1p, w2tp, w1tp, enc.d_ffn, 0.5)
+                                              m.net[0].bias.detach(), w1p, w2tp, w1tp, enc.d_ffn, 0.5,
+                                              drop_hidden=dh, drop_out=do)
                 for p, gv in zip((m.layer_norm.weight, m.layer_norm.bias, m.net[0].weight, m.net[0].bias,
                                   m.net[3].weight, m.net[3].bias), g):
                     put(p, gv)
@@ -255,7 +276,7 @@ class ConformerTrain(torch.autograd.Function):
             x2, W, fws = L["conv"]
             c = lay.conv
             dx3, g = ob.convmod_bwd(x2.view(B, T, D), dx.view(B, T, D), W, fws, enc.kernel_size,
-                                    bn_eval=not S["batch_bn"])
+                                    bn_eval=not S["batch_bn"], drop=ds.cfg(f"{li}.conv.out"))
             dx = dx3.view(M, D)
             put(c.layer_norm.weight, g["ln_g"]), put(c.layer_norm.bias, g["ln_b"])
             put(c.pw_conv_1.weight, g["pw1_w"]), put(c.pw_conv_1.bias, g["pw1_b"])
@@ -266,7 +287,8 @@ class ConformerTrain(torch.autograd.Function):
             a = lay.self_attn
             dx, g = bw.mha_bwd(x1, dx, qkv.view(B, T, 3 * D), ao, a.layer_norm.weight.detach(),
                                a.layer_norm.bias.detach(), wqkv_bf, wo_bf, S["pe_bf"], H, scale, window=window,
-                               probs=(S["pe_pack"], lse), skew_buf=skew_buf)
+                               probs=(S["pe_pack"], lse), skew_buf=skew_buf, drop_p=ds.cfg(f"{li}.attn.p"),
+                               drop_out=ds.cfg(f"{li}.attn.out"))
             dg, dbeta, dwqkv, dbqkv, dwo, dbo, dw_l = g
             dwin = dw_l if dwin is None else dwin.add_(dw_l)
             put(a.layer_norm.weight, dg), put(a.layer_norm.bias, dbeta)
@@ -279,6 +301,8 @@ class ConformerTrain(torch.autograd.Function):
         dpe = torch.zeros_like(enc.pos_emb.pe_k.weight)
         dpe.index_add_(0, window[1], dwin[:2 * T - 1])
         put(enc.pos_emb.pe_k.weight, dpe)
+        if ds.active:
+            ops.dropout_apply(dx, ds.cfg("embed"))
         dwe, dbe, dg, dbeta = bw.embed_bwd(S["f"], dx, S["mean"], S["rinv"], S["we_bf"], enc.embed[0].bias.detach(),
                                            enc.embed[1].weight.detach(), enc.embed[1].bias.detach(), e=S["e"])
         put(enc.embed[0].weight, dwe), put(enc.embed[0].bias, dbe)
@@ -304,9 +328,13 @@ class BlstmTrain(torch.autograd.Function):
         fn = ob.mvn_apply(f, mean, rinv, Kp)
         e = ob.bgemm(fn, we_bf, bias=enc.embed[0].bias.detach())
         _, x = ops.layernorm_relu(e, enc.embed[1].weight.detach(), enc.embed[1].bias.detach())
-        S = {"f": f, "mean": mean, "rinv": rinv, "we_bf": we_bf, "e": e, "layers": []}
+        ds = model_drop_state(model, getattr(enc, "dropout_rate", 0.0))   # blstm.py:147 (embedding) and :158 (every layer)
+        if ds.active:
+            ds = DropState(ds.seed.clone(), ds.p, ds.offset)
+            ops.dropout_apply(x, ds.cfg("embed"))
+        S = {"f": f, "mean": mean, "rinv": rinv, "we_bf": we_bf, "e": e, "layers": [], "drop": ds}
         Hp = (H + 31) // 32 * 32
-        for lay in enc.encoders:
+        for li, lay in enumerate(enc.encoders):
             l = lay.lstm
             w_ih_bf = torch.empty((8 * H, h), dtype=BF, device=f.device)
             whh_p = torch.empty(2 * 4 * H * Hp, dtype=BF, device=f.device)
@@ -323,6 +351,8 @@ class BlstmTrain(torch.autograd.Function):
             S["layers"].append({"x": x, "y": y, "gates": gates, "c": c, "w_ih_bf": w_ih_bf, "whhT_p": whhT_p})
             _, x = ops.layernorm_relu(y.view(M, h), lay.layer_norm.weight.detach(), lay.layer_norm.bias.detach(),
                                       relu=False)
+            if ds.active:
+                ops.dropout_apply(x, ds.cfg(f"{li}.blstm.layer"))
         n_out = model.linear.out_features
         wh_bf, _ = ob.pack_weight(model.linear.weight.detach(), want_row_major=True)
         ld = (n_out + 3) // 4 * 4
@@ -355,8 +385,12 @@ class BlstmTrain(torch.autograd.Function):
             dm = buf
         dx, dw, db = bw.head_bwd(dm, masks, S["x_last"], S["wh_bf"])
         put(model.linear.weight, dw), put(model.linear.bias, db)
-        for lay, L in zip(reversed(list(enc.encoders)), reversed(S["layers"])):
+        ds = S["drop"]
+        nlay = len(enc.encoders)
+        for li, lay, L in zip(range(nlay - 1, -1, -1), reversed(list(enc.encoders)), reversed(S["layers"])):
             y = L["y"]
+            if ds.active:
+                dx = ops.dropout_apply(dx.contiguous(), ds.cfg(f"{li}.blstm.layer"))
             dy, dg, dbeta = ob.layernorm_bwd(y.view(M, h), dx, lay.layer_norm.weight.detach(), lay.layer_norm.bias.detach())
             put(lay.layer_norm.weight, dg), put(lay.layer_norm.bias, dbeta)
             dgates = ob.lstm_bidir_bwd(L["gates"], L["c"], dy.view(B, T, h), L["whhT_p"])
@@ -376,6 +410,8 @@ class BlstmTrain(torch.autograd.Function):
                 put(getattr(l, "bias_ih_l0" + sfx), dbias[d * 4 * H:(d + 1) * 4 * H])
                 put(getattr(l, "bias_hh_l0" + sfx), dbias[d * 4 * H:(d + 1) * 4 * H])
             L.clear()
+        if ds.active:
+            dx = ops.dropout_apply(dx.contiguous(), ds.cfg("embed"))
         dwe, dbe, dg, dbeta = bw.embed_bwd(S["f"], dx, S["mean"], S["rinv"], S["we_bf"], enc.embed[0].bias.detach(),
                                            enc.embed[1].weight.detach(), enc.embed[1].bias.detach(), e=S["e"])
         put(enc.embed[0].weight, dwe), put(enc.embed[0].bias, dbe)

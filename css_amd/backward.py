@@ -26,13 +26,24 @@ def head_bwd(dmasks, masks, x, w_bf):
     return linear_bwd(dz, x, w_bf)
 
 
-def ffn_bwd(x, dy, ln_g, ln_b, b1, w1_bf, w2_bf, alpha=0.5):
+def ffn_bwd(x, dy, ln_g, ln_b, b1, w1_bf, w2_bf, alpha=0.5, drop_hidden=None, drop_out=None):
     """out = x + alpha * (relu(LN(x) @ w1^T + b1) @ w2^T + b2)  (conformer.py:322-326 with the half-step residual).
 
     x, dy: f32 [M, 256].  Returns dx and the parameter gradients (ln_g, ln_b, w1, b1, w2, b2).
     The hidden activations are recomputed (LN + first Linear), not stored by the forward.
     """
     a, _ = ops.layernorm(x, ln_g, ln_b)
+    if drop_hidden is not None:   # training with dropout: h is the dropped hidden activation; its positive entries are
+        # the survivors of ReLU AND dropout, each carrying 1 / (1 - p); the output branch gradient is dy o mask / (1 - p)
+        h = ops.dropout_apply(ops.gemm(a, w1_bf, b1, relu=True), drop_hidden).to(BF)
+        dyb = ops.dropout_apply(dy, drop_out, out=torch.empty_like(dy))
+        sc = 65536.0 / (65536 - int(drop_hidden.contents.p * 65536.0 + 0.5))
+        dw2 = ob.bgemm(dyb, h, a_kmajor=True, b_kmajor=True, alpha=alpha)
+        db2 = ob.colsum(dyb, alpha)
+        dh = ob.bgemm(dyb, w2_bf, b_kmajor=True, alpha=alpha * sc, mask_pos=h, out_bf16=True)
+        da, dw1, db1 = linear_bwd(dh, a, w1_bf)
+        dx, dg, dbeta = ob.layernorm_bwd(x, da, ln_g, ln_b, dx_add=dy)
+        return dx, (dg, dbeta, dw1, db1, dw2, db2)
     h = ops.gemm(a, w1_bf, b1, relu=True, out_bf16=True)
     dw2 = ob.bgemm(dy, h, a_kmajor=True, b_kmajor=True, alpha=alpha)
     db2 = ob.colsum(dy, alpha)
@@ -42,13 +53,17 @@ def ffn_bwd(x, dy, ln_g, ln_b, b1, w1_bf, w2_bf, alpha=0.5):
     return dx, (dg, dbeta, dw1, db1, dw2, db2)
 
 
-def ffn_bwd_fused(x, dy, ln_g, ln_b, b1, w1p, w2tp, w1tp, d_ffn, alpha=0.5):
+def ffn_bwd_fused(x, dy, ln_g, ln_b, b1, w1p, w2tp, w1tp, d_ffn, alpha=0.5, drop_hidden=None, drop_out=None):
     """ffn_bwd with the activation side in ONE row-panel kernel (d_model = 256): LN + hidden recompute, masked dh,
     da and the LayerNorm backward never leave the CU; the four weight / bias gradients are GEMMs / column sums over
     the B*T rows.  w1p / w2tp / w1tp: fragment-packed W1, W2^T, W1^T."""
-    dx, dg, dbeta, a, h, dh = ob.ffn_bwd(x, dy, ln_g, ln_b, w1p, b1, w2tp, w1tp, d_ffn, alpha)
-    dw2 = ob.bgemm(dy, h, a_kmajor=True, b_kmajor=True, alpha=alpha)
-    db2 = ob.colsum(dy, alpha)
+    dx, dg, dbeta, a, h, dh, dyd = ob.ffn_bwd(x, dy, ln_g, ln_b, w1p, b1, w2tp, w1tp, d_ffn, alpha, drop_hidden, drop_out)
+    if dyd is not None:   # output dropout: the second Linear saw h (dropped) and its gradient is alpha * dy o mask / (1 - p)
+        dw2 = ob.bgemm(dyd, h, a_kmajor=True, b_kmajor=True)
+        db2 = ob.colsum(dyd)
+    else:
+        dw2 = ob.bgemm(dy, h, a_kmajor=True, b_kmajor=True, alpha=alpha)
+        db2 = ob.colsum(dy, alpha)
     dw1 = ob.bgemm(dh, a, a_kmajor=True, b_kmajor=True)
     db1 = ob.colsum(dh)
     return dx, (dg, dbeta, dw1, db1, dw2, db2)
@@ -64,7 +79,8 @@ def relpos_window(pe_table_bf, T, maxlen):
     return win, idx
 
 
-def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000, window=None, probs=None, ao=None, skew_buf=None):
+def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000, window=None, probs=None, ao=None, skew_buf=None,
+                 drop_p=None):
     """Backward of o = softmax(q k^T + q pe[i-j]^T) v (conformer.py:229-253; q already carries 1/sqrt(d_k)).
 
     qkv: bf16 [B, T, 3*H*64]; dao: bf16 [B*T, H*64] (gradient of the head-concatenated output).
@@ -77,8 +93,12 @@ def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000, window=None, probs=
     q, k, v = (g[:, :, i].permute(0, 2, 1, 3) for i in range(3))  # [B,H,T,64] strided views
     win, idx = relpos_window(pe_table_bf, T, maxlen) if window is None else window
     W = win.shape[0]
+    p_v = None              # operand of dV: the dropped probabilities when the forward dropped them (conformer.py:249)
     if probs is not None:   # (pe_pack, lse) from the training forward: one attention-shaped kernel recomputes P
-        p = ops.mha_relpos_probs(qkv, probs[0], probs[1], H)
+        if drop_p is not None:
+            p, p_v = ops.mha_relpos_probs(qkv, probs[0], probs[1], H, drop=drop_p)
+        else:
+            p = ops.mha_relpos_probs(qkv, probs[0], probs[1], H)
     else:                   # generic route: materialise the scores and the window products, then a row softmax
         s = ob.bgemm(q, k)                               # q k^T            [B,H,T,T]
         rel = ob.bgemm(q, win[None, None])               # q pe_window^T    [B,H,T,W]
@@ -87,13 +107,13 @@ def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000, window=None, probs=
     if ao is not None:      # attention-shaped softmax backward: no [B,H,T,T] f32 dP buffer
         d = ob.attn_rowdot(dao, ao, B, T, H)
         dsk = torch.zeros((B, T, H, W), dtype=BF, device=qkv.device) if skew_buf is None else skew_buf
-        ds, dsk = ob.attn_softmax_bwd(qkv, dao, p, d, dsk, H)
+        ds, dsk = ob.attn_softmax_bwd(qkv, dao, p, d, dsk, H, drop=drop_p)
     else:                   # generic route
         dp = ob.bgemm(do, v)                             # dO v^T           [B,H,T,T]
         ds, dsk = ob.relpos_softmax_bwd(p, dp, T, W)     # dS, and dS skewed onto the window axis [B,T,H,W]
     dqkv = torch.empty_like(qkv)
     dq, dk, dv = (dqkv.view(B, T, 3, H, 64)[:, :, i].permute(0, 2, 1, 3) for i in range(3))
-    ob.bgemm(p[..., :T], do, a_kmajor=True, b_kmajor=True, out=dv)      # dV = P^T dO
+    ob.bgemm((p if p_v is None else p_v)[..., :T], do, a_kmajor=True, b_kmajor=True, out=dv)      # dV = P^T dO
     ob.bgemm(ds[..., :T], q, a_kmajor=True, b_kmajor=True, out=dk)      # dK = dS^T q
     dq1 = ob.bgemm(ds[..., :T], k, b_kmajor=True)                       # dS k
     ob.bgemm(dsk.permute(0, 2, 1, 3), win[None, None], b_kmajor=True, add=dq1, out=dq)   # + dS_skew pe_window
@@ -107,7 +127,7 @@ def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000, window=None, probs=
 
 
 def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_scale=0.125, window=None, probs=None,
-            skew_buf=None, fused_softmax_bwd=True):
+            skew_buf=None, fused_softmax_bwd=True, drop_p=None, drop_out=None):
     """out = x + attention(LN(x)) @ wo^T + bo  (conformer.py:213-254,356).
 
     wqkv_bf holds the q rows already multiplied by q_scale (as the forward uses them); the returned dwqkv / dbqkv are
@@ -115,10 +135,14 @@ def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_s
     ``window`` (from relpos_window) the last one is the gradient of the window rows instead of the whole table.
     """
     D = x.shape[1]
-    dao, dwo, dbo = linear_bwd(dy, ao, wo_bf, dx_bf16=True)
+    # training: out = x + D_out(ao wo^T + bo) (conformer.py:254): the branch gradient is dy o mask / (1 - p)
+    dyb = dy if drop_out is None else ops.dropout_apply(dy, drop_out, out=torch.empty_like(dy))
+    dao, dwo, dbo = linear_bwd(dyb, ao, wo_bf, dx_bf16=True)
     B = qkv.shape[0]
+    if drop_p is not None and (probs is None or not fused_softmax_bwd):
+        raise NotImplementedError("css_amd: dropout of the attention probabilities needs the attention-shaped backward")
     dqkv, dpe = mha_core_bwd(qkv, dao, pe_table_bf, n_head, window=window, probs=probs,
-                             ao=ao if fused_softmax_bwd else None, skew_buf=skew_buf)
+                             ao=ao if fused_softmax_bwd else None, skew_buf=skew_buf, drop_p=drop_p)
     dq2 = dqkv.view(-1, 3 * D)
     a, _ = ops.layernorm(x, ln_g, ln_b)
     dw = torch.empty((3 * D, D), dtype=torch.float32, device=x.device)

@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256, 4) void mha_relpos_kernel(const unsigned short
                                                          const bf16x8* __restrict__ pe_packed, int q_min, int q_max,
                                                          unsigned short* __restrict__ out, int B, int T, int H,
                                                             unsigned long long* stamps, float* __restrict__ lse,
-                                                            int64_t ldp) {
+                                                            int64_t ldp, unsigned short* __restrict__ pdrop = nullptr,
+                                                            csship_dropout_cfg dcfg = csship_dropout_cfg{nullptr, 0u, 0.f}) {
   __shared__ __attribute__((aligned(16))) unsigned char sK[64 * 128];
   __shared__ __attribute__((aligned(16))) unsigned char sV[64 * 128];
   __shared__ __attribute__((aligned(16))) float sP[4 * 16 * PS];
@@ -173,14 +174,25 @@ __global__ __launch_bounds__(256, 4) void mha_relpos_kernel(const unsigned short
     if constexpr (PROBS) {  // P = exp(score - lse), 4 consecutive keys per store; the T tail is exactly 0
       const int qi_ = i0w + n;
       if (qi_ < T) {
-        unsigned short* prow = out + (((size_t)b * H + h) * T + qi_) * ldp + j0 + 4 * g;
+        const size_t poff = (((size_t)b * H + h) * T + qi_) * ldp + j0 + 4 * g;
+        unsigned short* prow = out + poff;
+        const Drop dp = drop_make(dcfg.seed, dcfg.stream, dcfg.p);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
           if (j0 + 16 * t + 4 * g + 3 < ldp) {
+            const float p0 = __builtin_amdgcn_exp2f(s[t][0] * LOG2E - lse2), p1 = __builtin_amdgcn_exp2f(s[t][1] * LOG2E - lse2);
+            const float p2 = __builtin_amdgcn_exp2f(s[t][2] * LOG2E - lse2), p3 = __builtin_amdgcn_exp2f(s[t][3] * LOG2E - lse2);
             uint2 v;
-            v.x = pack_bf2(__builtin_amdgcn_exp2f(s[t][0] * LOG2E - lse2), __builtin_amdgcn_exp2f(s[t][1] * LOG2E - lse2));
-            v.y = pack_bf2(__builtin_amdgcn_exp2f(s[t][2] * LOG2E - lse2), __builtin_amdgcn_exp2f(s[t][3] * LOG2E - lse2));
+            v.x = pack_bf2(p0, p1);
+            v.y = pack_bf2(p2, p3);
             *reinterpret_cast<uint2*>(prow + 16 * t) = v;
+            if (pdrop != nullptr) {  // training with dropout: the masked, rescaled probabilities (operand of dV = P~^T dO)
+              const float4 pd = drop_apply4(dp, (unsigned)(poff + 16 * t), make_float4(p0, p1, p2, p3));
+              uint2 vd;
+              vd.x = pack_bf2(pd.x, pd.y);
+              vd.y = pack_bf2(pd.z, pd.w);
+              *reinterpret_cast<uint2*>(pdrop + poff + 16 * t) = vd;
+            }
           }
       }
     } else {
@@ -332,12 +344,16 @@ DEV float xmax16(float x) {  // max over the four 16-lane rows of the wave (same
   return vmax(__uint_as_float(b0), __uint_as_float(b1));
 }
 
-template <int NW>
+// DROP (training): dropout of the attention probabilities (conformer.py:249).  The mask multiplies the NORMALISED
+// probabilities, so the row sums keep the undropped values and only the P.V operands are masked; the 1 / (1 - p) goes on
+// the output.  Element index of P[b, h, i, j]: ((b*H + h)*T + i) * pad8(T) + j (the layout of the backward's probability
+// buffer).
+template <int NW, bool DROP>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mha_fwd_kernel(const unsigned short* __restrict__ qkv,
                                                             const bf16x8* __restrict__ pe_packed, int q_min, int q_max,
                                                             unsigned short* __restrict__ out, float* __restrict__ lse,
                                                             int BH, int T, int H, int G, int ppw,
-                                                            unsigned long long* stamps) {
+                                                            unsigned long long* stamps, csship_dropout_cfg dcfg) {
   constexpr int CH = 512 / (NW * 64);  // 16-byte chunks of a K (and of a V) tile staged per thread
   constexpr int R = 2 * NW + 8;        // ring slots (position blocks of 2 x 1 KB): 2 NW + 4 live + 4 arriving
   constexpr int NF = 8 / NW;           // new fragments staged per wave and tile
@@ -439,6 +455,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mha_fwd_kernel(const
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[qb][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     lsum[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  Drop dp{0u, 0u, 1.f};
+  unsigned ebase[2] = {0u, 0u};  // element index of P[b, h, this lane's query of block qb, 4g]
+  if constexpr (DROP) {
+    dp = drop_make(dcfg.seed, dcfg.stream, dcfg.p);
+    const unsigned Tp = (unsigned)((T + 7) / 8 * 8);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+      ebase[qb] = ((unsigned)bh * (unsigned)T + (unsigned)min(i0w + 16 * qb + n, T - 1)) * Tp + 4u * (unsigned)g;
   }
   float m_run[2] = {-1e30f, -1e30f};
   bf16x8 ones;
@@ -578,6 +603,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mha_fwd_kernel(const
     A2_T(1)
     // ---- part 2: P = exp2(S log2e - m log2e) as bf16 MFMA operands ...
     bf16x8 pbf[2][2];
+    bf16x8 pbd[2][2];  // DROP: the masked probabilities (operands of P.V); pbf keeps the full ones for the row sums
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       if (!(A2_ABL & 2)) {
@@ -593,6 +619,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mha_fwd_kernel(const
           pbf[qb][ks][e] = (__bf16)s[qb][2 * ks][e];
           pbf[qb][ks][4 + e] = (__bf16)s[qb][2 * ks + 1][e];
         }
+      if constexpr (DROP) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const unsigned k = dp.thresh ? drop_keep4(dp, ebase[qb] + (unsigned)(j0 + 16 * t)) : 15u;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pbd[qb][t >> 1][(t & 1) * 4 + r] = (k >> r) & 1u ? pbf[qb][t >> 1][(t & 1) * 4 + r] : (__bf16)0.f;
+        }
+      }
     }
     // ---- ... beside the NEXT tile's position band (same basic block: the scheduler interleaves the two streams)
     // (no branch: after the last tile it works on ring slots nobody needs and its result is dropped)
@@ -625,8 +659,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mha_fwd_kernel(const
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a1));
           const bf16x8 av = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-          o[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pbf[0][ks], o[0][dt], 0, 0, 0);
-          o[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pbf[1][ks], o[1][dt], 0, 0, 0);
+          o[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, DROP ? pbd[0][ks] : pbf[0][ks], o[0][dt], 0, 0, 0);
+          o[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, DROP ? pbd[1][ks] : pbf[1][ks], o[1][dt], 0, 0, 0);
         }
       }
     }
@@ -657,7 +691,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mha_fwd_kernel(const
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     const float l = lsum[qb][0];
-    const float inv = 1.f / l;
+    const float inv = dp.scale / l;  // (dropout: survivors carry 1 / (1 - p))
     const int qi = i0w + 16 * qb + n;
     if (lse != nullptr && qi < T && g == 0) lse[((size_t)b * H + h) * T + qi] = m_run[qb] + __logf(l);
     if (qi < T) {
@@ -675,7 +709,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mha_fwd_kernel(const
 
 // Host side of mha_fwd_kernel: pairs of 16-query blocks, dealt to workgroups of 8 (or 4) waves.
 static int launch_mha_fwd(const uint16_t* qkv, const uint16_t* pe_packed, int q_min, int q_max, uint16_t* out, float* lse,
-                          int B, int T, int H, unsigned long long* stamps, hipStream_t s) {
+                          int B, int T, int H, unsigned long long* stamps, hipStream_t s,
+                          const csship_dropout_cfg* drop = nullptr) {
   const int P = (T + 31) / 32, BH = B * H;
   // 8 waves unless 4-wave workgroups are needed to give every CU one (short utterances, small batches)
   const int G8 = (P + 7) / 8, G4 = (P + 3) / 4;
@@ -683,12 +718,18 @@ static int launch_mha_fwd(const uint16_t* qkv, const uint16_t* pe_packed, int q_
   const int G = four ? G4 : G8, ppw = (P + G - 1) / G;
   const long long nwg = (long long)BH * G;
   if (nwg > 0x7fffffffLL) return CSSHIP_EBADSHAPE;
-  if (four)
-    hipLaunchKernelGGL(mha_fwd_kernel<4>, dim3((unsigned)nwg), dim3(256), 0, s, qkv, reinterpret_cast<const bf16x8*>(pe_packed),
-                       q_min, q_max, out, lse, BH, T, H, G, ppw, stamps);
+  const bool dropping = drop != nullptr && drop->seed != nullptr && drop->p > 0.f;
+  if (dropping && (int64_t)BH * T * ((T + 7) / 8 * 8) > 0xffffffffLL) return CSSHIP_EBADSHAPE;  // 32-bit element indices
+  const csship_dropout_cfg dc = dropping ? *drop : csship_dropout_cfg{nullptr, 0u, 0.f};
+  const bf16x8* pe = reinterpret_cast<const bf16x8*>(pe_packed);
+  if (four && dropping)
+    hipLaunchKernelGGL((mha_fwd_kernel<4, true>), dim3((unsigned)nwg), dim3(256), 0, s, qkv, pe, q_min, q_max, out, lse, BH, T, H, G, ppw, stamps, dc);
+  else if (four)
+    hipLaunchKernelGGL((mha_fwd_kernel<4, false>), dim3((unsigned)nwg), dim3(256), 0, s, qkv, pe, q_min, q_max, out, lse, BH, T, H, G, ppw, stamps, dc);
+  else if (dropping)
+    hipLaunchKernelGGL((mha_fwd_kernel<8, true>), dim3((unsigned)nwg), dim3(512), 0, s, qkv, pe, q_min, q_max, out, lse, BH, T, H, G, ppw, stamps, dc);
   else
-    hipLaunchKernelGGL(mha_fwd_kernel<8>, dim3((unsigned)nwg), dim3(512), 0, s, qkv, reinterpret_cast<const bf16x8*>(pe_packed),
-                       q_min, q_max, out, lse, BH, T, H, G, ppw, stamps);
+    hipLaunchKernelGGL((mha_fwd_kernel<8, false>), dim3((unsigned)nwg), dim3(512), 0, s, qkv, pe, q_min, q_max, out, lse, BH, T, H, G, ppw, stamps, dc);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }
@@ -709,8 +750,9 @@ __global__ __launch_bounds__(256, 4) void attn_ds_kernel(const unsigned short* _
                                                          const unsigned short* __restrict__ dout,
                                                          const unsigned short* __restrict__ p, const float* __restrict__ dvec,
                                                          unsigned short* __restrict__ ds, unsigned short* __restrict__ dsk,
-                                                         int B, int T, int H, int64_t ldp, int W) {
+                                                         int B, int T, int H, int64_t ldp, int W, csship_dropout_cfg dcfg) {
   __shared__ __attribute__((aligned(16))) unsigned char sV[64 * 128];
+  const Drop dp = drop_make(dcfg.seed, dcfg.stream, dcfg.p);  // dropout of the probabilities: dP = mask / (1 - p) o (dO v^T)
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, n = lane & 15;
@@ -772,8 +814,9 @@ __global__ __launch_bounds__(256, 4) void attn_ds_kernel(const unsigned short* _
         if (j + 3 >= ldp) continue;
         const float p0 = bf2f((unsigned short)(pv[t].x & 0xffff)), p1 = bf2f((unsigned short)(pv[t].x >> 16));
         const float p2 = bf2f((unsigned short)(pv[t].y & 0xffff)), p3 = bf2f((unsigned short)(pv[t].y >> 16));
-        const unsigned short d0 = f2bf(p0 * (s[t][0] - dval)), d1 = f2bf(p1 * (s[t][1] - dval));
-        const unsigned short d2 = f2bf(p2 * (s[t][2] - dval)), d3 = f2bf(p3 * (s[t][3] - dval));
+        const float4 dpv = drop_apply4(dp, (unsigned)(prow + j), make_float4(s[t][0], s[t][1], s[t][2], s[t][3]));
+        const unsigned short d0 = f2bf(p0 * (dpv.x - dval)), d1 = f2bf(p1 * (dpv.y - dval));
+        const unsigned short d2 = f2bf(p2 * (dpv.z - dval)), d3 = f2bf(p3 * (dpv.w - dval));
         *reinterpret_cast<uint2*>(ds + prow + j) = make_uint2((unsigned)d0 | ((unsigned)d1 << 16), (unsigned)d2 | ((unsigned)d3 << 16));
         if (j < T) skrow[-j] = d0;
         if (j + 1 < T) skrow[-j - 1] = d1;
@@ -810,10 +853,17 @@ extern "C" int csship_mha_relpos(const uint16_t* qkv, const uint16_t* pe_packed,
 extern "C" int csship_mha_relpos_train(const uint16_t* qkv, const uint16_t* pe_packed, int32_t q_min, int32_t q_max,
                                        uint16_t* out, float* lse, int32_t B, int32_t T, int32_t H,
                                        csship_stream_t stream) {
+  return csship_mha_relpos_train_drop(qkv, pe_packed, q_min, q_max, out, lse, B, T, H, nullptr, stream);
+}
+
+extern "C" int csship_mha_relpos_train_drop(const uint16_t* qkv, const uint16_t* pe_packed, int32_t q_min, int32_t q_max,
+                                            uint16_t* out, float* lse, int32_t B, int32_t T, int32_t H,
+                                            const csship_dropout_cfg* drop, csship_stream_t stream) {
   if (!qkv || !pe_packed || !out || !lse) return CSSHIP_ENULL;
   if (B <= 0 || T <= 0 || H <= 0 || q_max < q_min || B > 65535 || H > 65535) return CSSHIP_EBADSHAPE;
   if (!aligned16(qkv) || !aligned16(pe_packed) || !aligned8(out)) return CSSHIP_EALIGN;
-  if (!attn_v1()) return launch_mha_fwd(qkv, pe_packed, q_min, q_max, out, lse, B, T, H, nullptr, as_stream(stream));
+  if (!attn_v1() || (drop && drop->seed && drop->p > 0.f))
+    return launch_mha_fwd(qkv, pe_packed, q_min, q_max, out, lse, B, T, H, nullptr, as_stream(stream), drop);
   dim3 grid((T + 63) / 64, H, B);
   hipLaunchKernelGGL(mha_relpos_kernel<false>, grid, dim3(256), 0, as_stream(stream), qkv,
                      reinterpret_cast<const bf16x8*>(pe_packed), q_min, q_max, out, B, T, H, nullptr, lse, (int64_t)0);
@@ -824,13 +874,24 @@ extern "C" int csship_mha_relpos_train(const uint16_t* qkv, const uint16_t* pe_p
 extern "C" int csship_mha_relpos_probs(const uint16_t* qkv, const uint16_t* pe_packed, int32_t q_min, int32_t q_max,
                                        const float* lse, uint16_t* p_bf16, int64_t ld_p, int32_t B, int32_t T, int32_t H,
                                        csship_stream_t stream) {
+  return csship_mha_relpos_probs_drop(qkv, pe_packed, q_min, q_max, lse, p_bf16, nullptr, ld_p, B, T, H, nullptr, stream);
+}
+
+extern "C" int csship_mha_relpos_probs_drop(const uint16_t* qkv, const uint16_t* pe_packed, int32_t q_min, int32_t q_max,
+                                            const float* lse, uint16_t* p_bf16, uint16_t* p_dropped_bf16, int64_t ld_p,
+                                            int32_t B, int32_t T, int32_t H, const csship_dropout_cfg* drop,
+                                            csship_stream_t stream) {
   if (!qkv || !pe_packed || !lse || !p_bf16) return CSSHIP_ENULL;
+  const bool dropping = drop && drop->seed && drop->p > 0.f;
+  if (dropping && (!p_dropped_bf16 || ld_p != (T + 7) / 8 * 8 || (int64_t)B * H * T * ld_p > 0xffffffffLL)) return CSSHIP_EBADSHAPE;
+  if (p_dropped_bf16 && !aligned8(p_dropped_bf16)) return CSSHIP_EALIGN;
   if (B <= 0 || T <= 0 || H <= 0 || q_max < q_min || B > 65535 || H > 65535 || ld_p < T) return CSSHIP_EBADSHAPE;
   if (!aligned16(qkv) || !aligned16(pe_packed) || !aligned8(p_bf16) || (ld_p % 4) != 0) return CSSHIP_EALIGN;
   dim3 grid((T + 63) / 64, H, B);
   hipLaunchKernelGGL(mha_relpos_kernel<true>, grid, dim3(256), 0, as_stream(stream), qkv,
                      reinterpret_cast<const bf16x8*>(pe_packed), q_min, q_max, p_bf16, B, T, H, nullptr,
-                     const_cast<float*>(lse), ld_p);
+                     const_cast<float*>(lse), ld_p, dropping ? p_dropped_bf16 : nullptr,
+                     dropping ? *drop : csship_dropout_cfg{nullptr, 0u, 0.f});
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }
@@ -838,12 +899,20 @@ extern "C" int csship_mha_relpos_probs(const uint16_t* qkv, const uint16_t* pe_p
 extern "C" int csship_attn_softmax_bwd(const uint16_t* qkv, const uint16_t* d_out, const uint16_t* p_bf16, int64_t ld_p,
                                        const float* d, uint16_t* ds_bf16, uint16_t* ds_skew_bf16, int32_t W, int32_t B,
                                        int32_t T, int32_t H, csship_stream_t stream) {
+  return csship_attn_softmax_bwd_drop(qkv, d_out, p_bf16, ld_p, d, ds_bf16, ds_skew_bf16, W, B, T, H, nullptr, stream);
+}
+
+extern "C" int csship_attn_softmax_bwd_drop(const uint16_t* qkv, const uint16_t* d_out, const uint16_t* p_bf16, int64_t ld_p,
+                                            const float* d, uint16_t* ds_bf16, uint16_t* ds_skew_bf16, int32_t W, int32_t B,
+                                            int32_t T, int32_t H, const csship_dropout_cfg* drop, csship_stream_t stream) {
+  const bool dropping = drop && drop->seed && drop->p > 0.f;
+  if (dropping && (ld_p != (T + 7) / 8 * 8 || (int64_t)B * H * T * ld_p > 0xffffffffLL)) return CSSHIP_EBADSHAPE;
   if (!qkv || !d_out || !p_bf16 || !d || !ds_bf16 || !ds_skew_bf16) return CSSHIP_ENULL;
   if (B <= 0 || T <= 0 || H <= 0 || B > 65535 || H > 65535 || ld_p < T || W < 2 * T - 1) return CSSHIP_EBADSHAPE;
   if (!aligned16(qkv) || !aligned16(d_out) || !aligned8(p_bf16) || !aligned8(ds_bf16) || (ld_p % 4) != 0) return CSSHIP_EALIGN;
   dim3 grid((T + 63) / 64, H, B);
   hipLaunchKernelGGL(attn_ds_kernel, grid, dim3(256), 0, as_stream(stream), qkv, d_out, p_bf16, d, ds_bf16, ds_skew_bf16, B, T,
-                     H, ld_p, W);
+                     H, ld_p, W, dropping ? *drop : csship_dropout_cfg{nullptr, 0u, 0.f});
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }

@@ -104,6 +104,50 @@ DEV void stamp(unsigned long long* st, int slot) {
   }
 }
 
+// ---- dropout (training mode only; css/models/conformer.py:127,249,254,302,317,319, css/models/blstm.py:147,158).
+// Counter-based: element e (row-major index in its tensor) of dropout site `stream` is kept iff the 16-bit field
+// (e & 1) of hash32(key + (e >> 1)) is >= thresh, key = hash32(seed ^ stream * 0x9E3779B9), thresh = round(p * 65536).
+// Forward and backward regenerate the same mask from (seed, stream, e); nothing is stored.  The seed lives in DEVICE
+// memory so that a captured training step can be replayed with a fresh mask (the host bumps it before each replay).
+// oracle/dropout.py is the numpy statement of the same function (the oracle applies identical masks in the tests).
+DEV unsigned hash32(unsigned x) {  // "lowbias32" avalanche mixer
+  x ^= x >> 16;
+  x *= 0x7feb352dU;
+  x ^= x >> 15;
+  x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
+struct Drop {  // device-side view of csship_dropout_cfg; thresh == 0 means "no dropout"
+  unsigned key, thresh;
+  float scale;
+};
+DEV Drop drop_make(const unsigned* seed, unsigned stream, float p) {
+  Drop d{0u, 0u, 1.f};
+  if (seed != nullptr && p > 0.f) {
+    d.key = hash32(*seed ^ (stream * 0x9E3779B9u));
+    d.thresh = (unsigned)(p * 65536.f + 0.5f);
+    d.scale = 65536.f / (float)(65536u - d.thresh);  // 1 / (1 - p_effective)
+  }
+  return d;
+}
+// keep-bits of elements e0 .. e0+3 (e0 even): bit j set = element e0 + j survives
+DEV unsigned drop_keep4(const Drop& d, unsigned e0) {
+  const unsigned h0 = hash32(d.key + (e0 >> 1)), h1 = hash32(d.key + (e0 >> 1) + 1u);
+  return ((h0 & 0xffffu) >= d.thresh ? 1u : 0u) | ((h0 >> 16) >= d.thresh ? 2u : 0u) |
+         ((h1 & 0xffffu) >= d.thresh ? 4u : 0u) | ((h1 >> 16) >= d.thresh ? 8u : 0u);
+}
+DEV bool drop_keep1(const Drop& d, unsigned e) {
+  const unsigned h = hash32(d.key + (e >> 1));
+  return ((e & 1u) ? (h >> 16) : (h & 0xffffu)) >= d.thresh;
+}
+DEV float4 drop_apply4(const Drop& d, unsigned e0, float4 v) {  // v * keep / (1 - p)
+  if (d.thresh == 0u) return v;
+  const unsigned k = drop_keep4(d, e0);
+  return make_float4((k & 1u) ? v.x * d.scale : 0.f, (k & 2u) ? v.y * d.scale : 0.f, (k & 4u) ? v.z * d.scale : 0.f,
+                     (k & 8u) ? v.w * d.scale : 0.f);
+}
+
 // Optional per-launch timeline (diagnostic / bench.py's in-step roofline; off in normal operation): when switched on
 // with csship_debug_timeline(1), instrumented entry points bracket their launches with a pair of HIP events on the
 // launch stream, tagged with a kernel family; csship_debug_timeline_read() sums the elapsed times per tag.  The events

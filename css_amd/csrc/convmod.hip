@@ -240,25 +240,25 @@ __global__ __launch_bounds__(256) void bn_from_running_kernel(const float* __res
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ z,
                                                        const float* __restrict__ scale_shift,
                                                        const float* __restrict__ pw2_w, const float* __restrict__ pw2_b,
-                                                       float* __restrict__ y, size_t n4, int D) {
+                                                       float* __restrict__ y, size_t n4, int D, csship_dropout_cfg dcfg) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
+  const Drop dp = drop_make(dcfg.seed, dcfg.stream, dcfg.p);  // training: the module's final dropout (conformer.py:302)
   const int c = (int)((i * 4) % D);
   const float4 xv = reinterpret_cast<const float4*>(x)[i];
   const float4 zv = reinterpret_cast<const float4*>(z)[i];
   const float4 sc = *reinterpret_cast<const float4*>(scale_shift + c);
   const float4 sh = *reinterpret_cast<const float4*>(scale_shift + D + c);
   const float pw = pw2_w[0], pb = pw2_b[0];
-  float4 o;
-  o.x = xv.x + fmaxf(zv.x * sc.x + sh.x, 0.f) * pw + pb;
-  o.y = xv.y + fmaxf(zv.y * sc.y + sh.y, 0.f) * pw + pb;
-  o.z = xv.z + fmaxf(zv.z * sc.z + sh.z, 0.f) * pw + pb;
-  o.w = xv.w + fmaxf(zv.w * sc.w + sh.w, 0.f) * pw + pb;
-  reinterpret_cast<float4*>(y)[i] = o;
+  const float4 br = drop_apply4(dp, (unsigned)(i * 4),
+                                make_float4(fmaxf(zv.x * sc.x + sh.x, 0.f) * pw + pb, fmaxf(zv.y * sc.y + sh.y, 0.f) * pw + pb,
+                                            fmaxf(zv.z * sc.z + sh.z, 0.f) * pw + pb, fmaxf(zv.w * sc.w + sh.w, 0.f) * pw + pb));
+  reinterpret_cast<float4*>(y)[i] = make_float4(xv.x + br.x, xv.y + br.y, xv.z + br.z, xv.w + br.w);
 }
 
 template <int D, int TT>
-int run(const ConvArgs& a0, int bn_mode, void* workspace, hipStream_t s) {
+int run(const ConvArgs& a0, int bn_mode, void* workspace, hipStream_t s,
+        csship_dropout_cfg dcfg = csship_dropout_cfg{nullptr, 0u, 0.f}) {
   ConvArgs a = a0;
   dim3 grid((a.T + TT - 1) / TT, a.B);
   if (bn_mode == 0) {
@@ -283,7 +283,7 @@ int run(const ConvArgs& a0, int bn_mode, void* workspace, hipStream_t s) {
                        (double)a.B * (double)a.T, a.w.bn_g, a.w.bn_b, scale_shift);
   CSSHIP_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, a.x, a.zbuf, scale_shift,
-                     a.w.pw2_w, a.w.pw2_b, a.y, n / 4, D);
+                     a.w.pw2_w, a.w.pw2_b, a.y, n / 4, D, dcfg);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }
@@ -303,15 +303,19 @@ template <int D>
 __global__ __launch_bounds__(D) void conv_bn_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ z,
                                                               const float* __restrict__ stats,
                                                               const float* __restrict__ pw2_w, int64_t M,
-                                                              int rows_per_wg, float* __restrict__ part) {
+                                                              int rows_per_wg, float* __restrict__ part,
+                                                              csship_dropout_cfg dcfg) {
   __shared__ float red[2][D / 64];
   const int c = threadIdx.x;
+  const Drop dp = drop_make(dcfg.seed, dcfg.stream, dcfg.p);  // the forward's output dropout: d(branch) = dy o mask / (1 - p)
   const float sc = stats[c], sh = stats[D + c], mu = stats[2 * D + c], rstd = rsqrtf(stats[3 * D + c] + 1e-5f);
   const float w3 = pw2_w[0];
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg, r1 = min(M, r0 + rows_per_wg);
   float s1 = 0.f, s2 = 0.f, dw3 = 0.f, db3 = 0.f;
   for (int64_t r = r0; r < r1; ++r) {
-    const float d = dy[r * D + c], zz = z[r * D + c];
+    float d = dy[r * D + c];
+    const float zz = z[r * D + c];
+    if (dp.thresh != 0u) d = drop_keep1(dp, (unsigned)(r * D + c)) ? d * dp.scale : 0.f;
     const float zh = zz * sc + sh;
     const float dzh = zh > 0.f ? d * w3 : 0.f;
     s1 += dzh;
@@ -338,11 +342,12 @@ __global__ __launch_bounds__(256) void conv_bn_bwd_apply_kernel(const float* __r
                                                                 const float* __restrict__ stats,
                                                                 const float* __restrict__ sums,
                                                                 const float* __restrict__ pw2_w, float inv_n, size_t n4,
-                                                                int D, float* __restrict__ dc) {
+                                                                int D, float* __restrict__ dc, csship_dropout_cfg dcfg) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
   const int c = (int)((i * 4) % D);
-  const float4 d = reinterpret_cast<const float4*>(dy)[i];
+  const Drop dp = drop_make(dcfg.seed, dcfg.stream, dcfg.p);
+  const float4 d = drop_apply4(dp, (unsigned)(i * 4), reinterpret_cast<const float4*>(dy)[i]);
   const float4 zz = reinterpret_cast<const float4*>(z)[i];
   const float w3 = pw2_w[0];
   const float dv[4] = {d.x, d.y, d.z, d.w}, zv[4] = {zz.x, zz.y, zz.z, zz.w};
@@ -473,7 +478,7 @@ BwdLayout bwd_layout(int B, int T, int D, int TT) {
 
 template <int D, int TT>
 int run_bwd(const float* x, const float* dy, const csship_conv_weights& w, int B, int T, const float* fwd_ws, float* dx,
-            float* grads, float* ws, int bn_eval, hipStream_t s) {
+            float* grads, float* ws, int bn_eval, hipStream_t s, csship_dropout_cfg dcfg) {
   const BwdLayout L = bwd_layout(B, T, D, TT);
   const int64_t M = (int64_t)B * T;
   const size_t n = (size_t)M * D;
@@ -486,14 +491,14 @@ int run_bwd(const float* x, const float* dy, const csship_conv_weights& w, int B
   float* gB = grads + 2 * D + 4;
   float* gC = gB + 34 * D;
   // pass A
-  hipLaunchKernelGGL((conv_bn_bwd_stats_kernel<D>), dim3(L.nwg_rows), dim3(D), 0, s, dy, z, stats, w.pw2_w, M, BWD_ROWS, part);
+  hipLaunchKernelGGL((conv_bn_bwd_stats_kernel<D>), dim3(L.nwg_rows), dim3(D), 0, s, dy, z, stats, w.pw2_w, M, BWD_ROWS, part, dcfg);
   CSSHIP_CHECK_LAUNCH();
   int rc = launch_slab_reduce(part, L.nwg_rows, 2 * D + 2, 2 * D + 2, 2 * D + 2, 1.f, nullptr, nullptr, 0, gA, s);
   if (rc) return rc;
   // pass A'
   // running statistics are constants of the graph: no mean / projection terms (1/n -> 0)
   hipLaunchKernelGGL(conv_bn_bwd_apply_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, dy, z, stats, gA,
-                     w.pw2_w, bn_eval ? 0.f : 1.f / (float)M, n / 4, D, dc);
+                     w.pw2_w, bn_eval ? 0.f : 1.f / (float)M, n / 4, D, dc, dcfg);
   CSSHIP_CHECK_LAUNCH();
   // pass B1 / B2 on the forward's tile structure
   dim3 grid((T + TT - 1) / TT, B);
@@ -523,7 +528,16 @@ extern "C" size_t csship_convmod_workspace(int32_t B, int32_t T, int32_t D) {
 extern "C" int csship_convmod(const float* x, float* y, const csship_conv_weights* w, int32_t B, int32_t T,
                               int32_t D, int32_t kernel_size, int32_t bn_mode, void* workspace,
                               csship_stream_t stream) {
+  return csship_convmod_drop(x, y, w, B, T, D, kernel_size, bn_mode, workspace, nullptr, stream);
+}
+
+extern "C" int csship_convmod_drop(const float* x, float* y, const csship_conv_weights* w, int32_t B, int32_t T,
+                                   int32_t D, int32_t kernel_size, int32_t bn_mode, void* workspace,
+                                   const csship_dropout_cfg* drop, csship_stream_t stream) {
   if (!x || !y || !w) return CSSHIP_ENULL;
+  const bool dropping = drop && drop->seed && drop->p > 0.f;
+  if (dropping && (bn_mode == 0 || (int64_t)B * T * D > 0xffffffffLL)) return CSSHIP_EBADSHAPE;  // training forward only
+  const csship_dropout_cfg dc = dropping ? *drop : csship_dropout_cfg{nullptr, 0u, 0.f};
   if (!w->ln_g || !w->ln_b || !w->pw1_w || !w->pw1_b || !w->dw_w || !w->dw_b || !w->bn_g || !w->bn_b ||
       !w->pw2_w || !w->pw2_b || (bn_mode != 1 && (!w->bn_mean || !w->bn_var)))
     return CSSHIP_ENULL;
@@ -533,8 +547,8 @@ extern "C" int csship_convmod(const float* x, float* y, const csship_conv_weight
   if (!aligned16(x) || !aligned16(y) || !aligned16(w->ln_g) || !aligned16(w->ln_b) || (workspace && !aligned16(workspace)))
     return CSSHIP_EALIGN;
   ConvArgs a{x, y, *w, nullptr, nullptr, nullptr, nullptr, B, T, g_csship_stamps};
-  if (D == 256) return run<256, TT256>(a, bn_mode, workspace, as_stream(stream));
-  return run<512, TT512>(a, bn_mode, workspace, as_stream(stream));
+  if (D == 256) return run<256, TT256>(a, bn_mode, workspace, as_stream(stream), dc);
+  return run<512, TT512>(a, bn_mode, workspace, as_stream(stream), dc);
 }
 
 extern "C" int csship_conv_from_glu(const float* x, const float* g, float* y, const csship_conv_weights* w, int32_t B,
@@ -557,6 +571,17 @@ extern "C" int csship_convmod_bwd(const float* x, const float* dy, const csship_
                                   int32_t D, int32_t kernel_size, const void* fwd_workspace, float* dx,
                                   float* grads, int32_t bn_eval, void* workspace, size_t workspace_bytes,
                                   csship_stream_t stream) {
+  return csship_convmod_bwd_drop(x, dy, w, B, T, D, kernel_size, fwd_workspace, dx, grads, bn_eval, nullptr, workspace,
+                                 workspace_bytes, stream);
+}
+
+extern "C" int csship_convmod_bwd_drop(const float* x, const float* dy, const csship_conv_weights* w, int32_t B, int32_t T,
+                                       int32_t D, int32_t kernel_size, const void* fwd_workspace, float* dx,
+                                       float* grads, int32_t bn_eval, const csship_dropout_cfg* drop, void* workspace,
+                                       size_t workspace_bytes, csship_stream_t stream) {
+  const bool dropping = drop && drop->seed && drop->p > 0.f;
+  if (dropping && (int64_t)B * T * D > 0xffffffffLL) return CSSHIP_EBADSHAPE;
+  const csship_dropout_cfg dc = dropping ? *drop : csship_dropout_cfg{nullptr, 0u, 0.f};
   if (!x || !dy || !w || !fwd_workspace || !dx || !grads || !workspace) return CSSHIP_ENULL;
   if (!w->ln_g || !w->ln_b || !w->pw1_w || !w->pw1_b || !w->dw_w || !w->dw_b || !w->pw2_w) return CSSHIP_ENULL;
   if (B <= 0 || T <= 0 || B > 65535) return CSSHIP_EBADSHAPE;
@@ -566,6 +591,6 @@ extern "C" int csship_convmod_bwd(const float* x, const float* dy, const csship_
   if (workspace_bytes < csship_convmod_bwd_workspace(B, T, D)) return CSSHIP_EWORKSPACE;
   const float* fw = reinterpret_cast<const float*>(fwd_workspace);
   float* ws = reinterpret_cast<float*>(workspace);
-  if (D == 256) return run_bwd<256, TT256>(x, dy, *w, B, T, fw, dx, grads, ws, bn_eval, as_stream(stream));
-  return run_bwd<512, TT512>(x, dy, *w, B, T, fw, dx, grads, ws, bn_eval, as_stream(stream));
+  if (D == 256) return run_bwd<256, TT256>(x, dy, *w, B, T, fw, dx, grads, ws, bn_eval, as_stream(stream), dc);
+  return run_bwd<512, TT512>(x, dy, *w, B, T, fw, dx, grads, ws, bn_eval, as_stream(stream), dc);
 }

@@ -198,6 +198,7 @@ struct FfnArgs {
   int M, FF;
   float alpha;
   unsigned long long* stamps;
+  csship_dropout_cfg drop_h, drop_o;  // training: dropout of the hidden activation [M, FF] and of the output [M, 256]
 };
 
 template <int NW, bool FINAL_LN>
@@ -211,6 +212,8 @@ __global__ __launch_bounds__(NW * 64) void ffn_kernel(FfnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15;
   const int m0 = blockIdx.x * BM;
   const int nchunk = a.FF / DM, ks2 = a.FF / 32;
+  const Drop dh = drop_make(a.drop_h.seed, a.drop_h.stream, a.drop_h.p);
+  const Drop dout = drop_make(a.drop_o.seed, a.drop_o.stream, a.drop_o.p);
 
   // weight streams of this wave: W1 chunk c -> hidden tiles c*16 + wave*NT + t (tile stride KS blocks);
   // W2 chunk c -> output tiles wave*NT + t, k-steps 8c.. (tile stride FF/32 blocks)
@@ -252,7 +255,14 @@ __global__ __launch_bounds__(NW * 64) void ffn_kernel(FfnArgs a) {
       const int hc = (wave * NT + t) * 16 + 4 * g;  // column within the chunk
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
-        const uint2 pk = make_uint2(relu_bf2(pack_bf2(h[t][rt][0], h[t][rt][1])), relu_bf2(pack_bf2(h[t][rt][2], h[t][rt][3])));
+        uint2 pk;
+        if (dh.thresh != 0u) {  // training: relu, then the hidden activation's dropout (conformer.py:317), element (row, c*256 + hc)
+          const float4 v = drop_apply4(dh, (unsigned)((m0 + rt * 16 + n) * a.FF + c * DM + hc),
+                                       make_float4(fmaxf(h[t][rt][0], 0.f), fmaxf(h[t][rt][1], 0.f), fmaxf(h[t][rt][2], 0.f), fmaxf(h[t][rt][3], 0.f)));
+          pk = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+        } else {
+          pk = make_uint2(relu_bf2(pack_bf2(h[t][rt][0], h[t][rt][1])), relu_bf2(pack_bf2(h[t][rt][2], h[t][rt][3])));
+        }
         *reinterpret_cast<uint2*>(hs + panel_off(rt * 16 + n, hc >> 3) + (hc & 7) * 2) = pk;
       }
     }
@@ -279,7 +289,9 @@ __global__ __launch_bounds__(NW * 64) void ffn_kernel(FfnArgs a) {
   float4 v[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const float4 y = *reinterpret_cast<const float4*>(ys + r * YS + (i * 8 + part) * 4);
+    // (training: the output's dropout, conformer.py:319, element (row, column) of [M, 256])
+    const float4 y = drop_apply4(dout, (unsigned)((m0 + r) * DM + (i * 8 + part) * 4),
+                                 *reinterpret_cast<const float4*>(ys + r * YS + (i * 8 + part) * 4));
     v[i] = make_float4(xr[i].x + a.alpha * y.x, xr[i].y + a.alpha * y.y, xr[i].z + a.alpha * y.z, xr[i].w + a.alpha * y.w);
   }
   if constexpr (FINAL_LN) {
@@ -335,6 +347,8 @@ struct FfnBwdArgs {
   float* part;            // [nwg][2][256]  dgamma | dbeta partial sums
   int M, FF;
   float alpha;
+  csship_dropout_cfg drop_h, drop_o;  // the forward's dropout sites (hidden [M, FF], output [M, 256])
+  unsigned short* dyd_bf;             // optional [M, 256]: alpha * dy o output-dropout mask / (1 - p): operand of dW2 / db2
 };
 
 template <int NW>
@@ -353,6 +367,8 @@ __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
   const bf16x8* w2ts = a.w2t + (size_t)(wave * NT) * KS * 64 + lane;
   const bf16x8* w1ts = a.w1t + (size_t)(wave * NT) * ks2 * 64 + lane;
   const int rot = blockIdx.x % nchunk;
+  const Drop dh = drop_make(a.drop_h.seed, a.drop_h.stream, a.drop_h.p);
+  const Drop dout = drop_make(a.drop_o.seed, a.drop_o.stream, a.drop_o.p);
   bf16x8 wq[PD][NT];
   prefetch_first<NT>(wq, w1s + (size_t)rot * 16 * KS * 64, KS, NT);
 
@@ -386,8 +402,12 @@ __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
                                   pack_bf2(v[i].z * rstd * gm.z + bt.z, v[i].w * rstd * gm.w + bt.w));
       *reinterpret_cast<uint2*>(Xs + panel_off(r, c4 >> 1) + (c4 & 1) * 8) = av;
       if (row < a.M) *reinterpret_cast<uint2*>(a.a_bf + (size_t)row * DM + c4 * 4) = av;
-      *reinterpret_cast<uint2*>(Ds + panel_off(r, c4 >> 1) + (c4 & 1) * 8) =
-          make_uint2(pack_bf2(a.alpha * d[i].x, a.alpha * d[i].y), pack_bf2(a.alpha * d[i].z, a.alpha * d[i].w));
+      // gradient of the FeedForward's (dropped) output: alpha * dy o mask / (1 - p)
+      const float4 dd = drop_apply4(dout, (unsigned)((m0 + r) * DM + c4 * 4),
+                                    make_float4(a.alpha * d[i].x, a.alpha * d[i].y, a.alpha * d[i].z, a.alpha * d[i].w));
+      const uint2 dv = make_uint2(pack_bf2(dd.x, dd.y), pack_bf2(dd.z, dd.w));
+      *reinterpret_cast<uint2*>(Ds + panel_off(r, c4 >> 1) + (c4 & 1) * 8) = dv;
+      if (a.dyd_bf != nullptr && row < a.M) *reinterpret_cast<uint2*>(a.dyd_bf + (size_t)row * DM + c4 * 4) = dv;
     }
   }
   __syncthreads();
@@ -404,15 +424,14 @@ __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
     const bf16x8* w2tc = w2ts + (size_t)c * 16 * KS * 64;
     const bf16x8* w1tc = w1ts + (size_t)c * KS * 64;
     const bf16x8* w1n = w1s + (size_t)((c + 1) % nchunk) * 16 * KS * 64;
-    float4 bb[NT];
     f32x4 h[NT][4];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      bb[t] = *reinterpret_cast<const float4*>(a.b1 + c * DM + (wave * NT + t) * 16 + 4 * g);
+    for (int t = 0; t < NT; ++t) {  // the bias is the accumulators' initial value, as in the forward
+      const float4 bb = *reinterpret_cast<const float4*>(a.b1 + c * DM + (wave * NT + t) * 16 + 4 * g);
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) h[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int rt = 0; rt < 4; ++rt) h[t][rt] = f32x4{bb.x, bb.y, bb.z, bb.w};
     }
-    // pass A: h = relu(a W1_c^T + b1_c); keep the mask, store h
+    // pass A: h = dropout(relu(a W1_c^T + b1_c)); keep the (ReLU and dropout) mask, store h
     mma_pass<NT>(h, Xs, n, g, NT, w1c, KS, w2tc, KS, NT, wq);
     unsigned mask = 0u;
 #pragma unroll
@@ -420,10 +439,11 @@ __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
       const int fcol = c * DM + (wave * NT + t) * 16 + 4 * g;
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
-        const float v0 = fmaxf(h[t][rt][0] + bb[t].x, 0.f), v1 = fmaxf(h[t][rt][1] + bb[t].y, 0.f);
-        const float v2 = fmaxf(h[t][rt][2] + bb[t].z, 0.f), v3 = fmaxf(h[t][rt][3] + bb[t].w, 0.f);
-        mask |= ((v0 > 0.f ? 1u : 0u) | (v1 > 0.f ? 2u : 0u) | (v2 > 0.f ? 4u : 0u) | (v3 > 0.f ? 8u : 0u)) << ((t * 4 + rt) * 4);
         const int row = m0 + rt * 16 + n;
+        const float4 hv = drop_apply4(dh, (unsigned)(row * a.FF + fcol),
+                                      make_float4(fmaxf(h[t][rt][0], 0.f), fmaxf(h[t][rt][1], 0.f), fmaxf(h[t][rt][2], 0.f), fmaxf(h[t][rt][3], 0.f)));
+        const float v0 = hv.x, v1 = hv.y, v2 = hv.z, v3 = hv.w;
+        mask |= ((v0 > 0.f ? 1u : 0u) | (v1 > 0.f ? 2u : 0u) | (v2 > 0.f ? 4u : 0u) | (v3 > 0.f ? 8u : 0u)) << ((t * 4 + rt) * 4);
         if (row < a.M)
           *reinterpret_cast<uint2*>(a.h_bf + (size_t)row * a.FF + fcol) = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
         h[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -437,9 +457,10 @@ __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
       const int hc = (wave * NT + t) * 16 + 4 * g;
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
-        const unsigned mb = mask >> ((t * 4 + rt) * 4);
-        const uint2 pk = make_uint2(pack_bf2((mb & 1u) ? h[t][rt][0] : 0.f, (mb & 2u) ? h[t][rt][1] : 0.f),
-                                    pack_bf2((mb & 4u) ? h[t][rt][2] : 0.f, (mb & 8u) ? h[t][rt][3] : 0.f));
+        const unsigned mb = mask >> ((t * 4 + rt) * 4);  // survivors of ReLU AND dropout; they carry the 1 / (1 - p)
+        const float hs_ = dh.scale;
+        const uint2 pk = make_uint2(pack_bf2((mb & 1u) ? h[t][rt][0] * hs_ : 0.f, (mb & 2u) ? h[t][rt][1] * hs_ : 0.f),
+                                    pack_bf2((mb & 4u) ? h[t][rt][2] * hs_ : 0.f, (mb & 8u) ? h[t][rt][3] * hs_ : 0.f));
         *reinterpret_cast<uint2*>(gs + panel_off(rt * 16 + n, hc >> 3) + (hc & 7) * 2) = pk;
         const int row = m0 + rt * 16 + n;
         if (row < a.M) *reinterpret_cast<uint2*>(a.dh_bf + (size_t)row * a.FF + c * DM + hc) = pk;
@@ -1298,10 +1319,11 @@ int launch_linear(const LinArgs& a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int csship_ffn_fused(const float* x, float* out, const float* ln_g, const float* ln_b,
-                                const uint16_t* w1_packed, const float* b1, const uint16_t* w2_packed,
-                                const float* b2, const float* final_ln_g, const float* final_ln_b, int32_t M,
-                                int32_t d_model, int32_t d_ffn, float alpha, csship_stream_t stream) {
+extern "C" int csship_ffn_fused_drop(const float* x, float* out, const float* ln_g, const float* ln_b,
+                                     const uint16_t* w1_packed, const float* b1, const uint16_t* w2_packed,
+                                     const float* b2, const float* final_ln_g, const float* final_ln_b, int32_t M,
+                                     int32_t d_model, int32_t d_ffn, float alpha, const csship_dropout_cfg* drop_hidden,
+                                     const csship_dropout_cfg* drop_out, csship_stream_t stream) {
   if (!x || !out || !ln_g || !ln_b || !w1_packed || !b1 || !w2_packed || !b2) return CSSHIP_ENULL;
   if ((final_ln_g == nullptr) != (final_ln_b == nullptr)) return CSSHIP_ENULL;
   if (M <= 0) return CSSHIP_EBADSHAPE;
@@ -1309,13 +1331,24 @@ extern "C" int csship_ffn_fused(const float* x, float* out, const float* ln_g, c
   if (!aligned16(x) || !aligned16(out) || !aligned16(w1_packed) || !aligned16(w2_packed) || !aligned16(ln_g) ||
       !aligned16(ln_b) || !aligned16(b1) || !aligned16(b2) || (final_ln_g && (!aligned16(final_ln_g) || !aligned16(final_ln_b))))
     return CSSHIP_EALIGN;
+  if ((int64_t)((M + BM - 1) / BM * BM) * d_ffn > 0xffffffffLL) return CSSHIP_EBADSHAPE;  // 32-bit dropout element indices
+  const csship_dropout_cfg none{nullptr, 0u, 0.f};
   FfnArgs a{x, out, ln_g, ln_b, reinterpret_cast<const bf16x8*>(w1_packed), b1,
-            reinterpret_cast<const bf16x8*>(w2_packed), b2, final_ln_g, final_ln_b, M, d_ffn, alpha, g_csship_stamps};
+            reinterpret_cast<const bf16x8*>(w2_packed), b2, final_ln_g, final_ln_b, M, d_ffn, alpha, g_csship_stamps,
+            drop_hidden ? *drop_hidden : none, drop_out ? *drop_out : none};
   dim3 grid((M + BM - 1) / BM), block(NWAVES * 64);
   if (final_ln_g) hipLaunchKernelGGL((ffn_kernel<NWAVES, true>), grid, block, 0, as_stream(stream), a);
   else hipLaunchKernelGGL((ffn_kernel<NWAVES, false>), grid, block, 0, as_stream(stream), a);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
+}
+
+extern "C" int csship_ffn_fused(const float* x, float* out, const float* ln_g, const float* ln_b,
+                                const uint16_t* w1_packed, const float* b1, const uint16_t* w2_packed,
+                                const float* b2, const float* final_ln_g, const float* final_ln_b, int32_t M,
+                                int32_t d_model, int32_t d_ffn, float alpha, csship_stream_t stream) {
+  return csship_ffn_fused_drop(x, out, ln_g, ln_b, w1_packed, b1, w2_packed, b2, final_ln_g, final_ln_b, M, d_model, d_ffn,
+                               alpha, nullptr, nullptr, stream);
 }
 
 extern "C" int csship_outproj_conv(const uint16_t* attn_out, const uint16_t* wo_packed, const float* bo, const float* x,
@@ -1339,11 +1372,12 @@ extern "C" int csship_outproj_conv(const uint16_t* attn_out, const uint16_t* wo_
 
 extern "C" size_t csship_ffn_bwd_workspace(int32_t M) { return (size_t)((M + BM - 1) / BM) * 2 * DM * sizeof(float); }
 
-extern "C" int csship_ffn_bwd(const float* x, const float* dy, const float* ln_g, const float* ln_b,
-                              const uint16_t* w1_packed, const float* b1, const uint16_t* w2t_packed,
-                              const uint16_t* w1t_packed, uint16_t* a_bf16, uint16_t* h_bf16, uint16_t* dh_bf16,
-                              float* dx, float* dgamma_dbeta, int32_t M, int32_t d_model, int32_t d_ffn, float alpha,
-                              void* workspace, size_t workspace_bytes, csship_stream_t stream) {
+extern "C" int csship_ffn_bwd_drop(const float* x, const float* dy, const float* ln_g, const float* ln_b,
+                                   const uint16_t* w1_packed, const float* b1, const uint16_t* w2t_packed,
+                                   const uint16_t* w1t_packed, uint16_t* a_bf16, uint16_t* h_bf16, uint16_t* dh_bf16,
+                                   float* dx, float* dgamma_dbeta, int32_t M, int32_t d_model, int32_t d_ffn, float alpha,
+                                   const csship_dropout_cfg* drop_hidden, const csship_dropout_cfg* drop_out,
+                                   uint16_t* dyd_bf16, void* workspace, size_t workspace_bytes, csship_stream_t stream) {
   if (!x || !dy || !ln_g || !ln_b || !w1_packed || !b1 || !w2t_packed || !w1t_packed || !a_bf16 || !h_bf16 || !dh_bf16 ||
       !dx || !dgamma_dbeta || !workspace)
     return CSSHIP_ENULL;
@@ -1355,13 +1389,27 @@ extern "C" int csship_ffn_bwd(const float* x, const float* dy, const float* ln_g
     return CSSHIP_EALIGN;
   const int nwg = (M + BM - 1) / BM;
   if (workspace_bytes < (size_t)nwg * 2 * DM * sizeof(float)) return CSSHIP_EWORKSPACE;
+  if ((int64_t)nwg * BM * d_ffn > 0xffffffffLL) return CSSHIP_EBADSHAPE;  // 32-bit dropout element indices
+  if (dyd_bf16 && !aligned8(dyd_bf16)) return CSSHIP_EALIGN;
+  const csship_dropout_cfg none{nullptr, 0u, 0.f};
   FfnBwdArgs a{x, dy, ln_g, ln_b, reinterpret_cast<const bf16x8*>(w1_packed), b1,
                reinterpret_cast<const bf16x8*>(w2t_packed), reinterpret_cast<const bf16x8*>(w1t_packed), a_bf16, h_bf16,
-               dh_bf16, dx, reinterpret_cast<float*>(workspace), M, d_ffn, alpha};
+               dh_bf16, dx, reinterpret_cast<float*>(workspace), M, d_ffn, alpha,
+               drop_hidden ? *drop_hidden : none, drop_out ? *drop_out : none, dyd_bf16};
   hipLaunchKernelGGL((ffn_bwd_kernel<NWAVES>), dim3(nwg), dim3(NWAVES * 64), 0, as_stream(stream), a);
   CSSHIP_CHECK_LAUNCH();
   return launch_slab_reduce(reinterpret_cast<const float*>(workspace), nwg, 2 * DM, 2 * DM, 2 * DM, 1.f, nullptr, nullptr, 0,
                             dgamma_dbeta, as_stream(stream));
+}
+
+extern "C" int csship_ffn_bwd(const float* x, const float* dy, const float* ln_g, const float* ln_b,
+                              const uint16_t* w1_packed, const float* b1, const uint16_t* w2t_packed,
+                              const uint16_t* w1t_packed, uint16_t* a_bf16, uint16_t* h_bf16, uint16_t* dh_bf16,
+                              float* dx, float* dgamma_dbeta, int32_t M, int32_t d_model, int32_t d_ffn, float alpha,
+                              void* workspace, size_t workspace_bytes, csship_stream_t stream) {
+  return csship_ffn_bwd_drop(x, dy, ln_g, ln_b, w1_packed, b1, w2t_packed, w1t_packed, a_bf16, h_bf16, dh_bf16, dx,
+                             dgamma_dbeta, M, d_model, d_ffn, alpha, nullptr, nullptr, nullptr, workspace, workspace_bytes,
+                             stream);
 }
 
 extern "C" int csship_panel_linear(const void* a, int32_t prologue, const float* ln_g, const float* ln_b,

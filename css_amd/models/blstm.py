@@ -28,6 +28,7 @@ class BLSTMEncoder(nn.Module):  # blstm.py:96-120
         super().__init__()
         self.embed = nn.Sequential(nn.Linear(idim, hidden_dim), nn.LayerNorm(hidden_dim), nn.Dropout(dropout_rate), nn.ReLU())
         self.encoders = nn.Sequential(*[_BLSTMLayer(hidden_dim, dropout_rate) for _ in range(num_layers)])
+        self.dropout_rate = float(dropout_rate)  # applied by the training forward (css_amd/dropout.py)
         self.idim, self.hidden_dim = idim, hidden_dim
 
 
@@ -55,6 +56,7 @@ class BLSTM(nn.Module):
         self.num_bins, self.num_spk, self.num_noise = num_bins, num_spk, num_noise
         self.linear = nn.Linear(blstm_conf["hidden_dim"], num_bins * (num_spk + num_noise))
         self._packed, self._packed_key = None, None
+        self.register_buffer("_drop_seed", torch.zeros(1, dtype=torch.int32), persistent=False)  # see Conformer
 
     def _pack(self):
         from .. import param_generation  # FusedAdam rewrites parameter storage without touching data_ptr / _version

@@ -102,6 +102,7 @@ class ConformerEncoder(nn.Module):  # conformer.py:110-150
             for _ in range(num_blocks)])
         self.idim, self.d_model, self.n_head = idim, attention_dim, attention_heads
         self.d_ffn, self.kernel_size = linear_units, kernel_size
+        self.dropout_rate = float(dropout_rate)  # applied by the training forward (css_amd/dropout.py)
 
 
 class Conformer(nn.Module):
@@ -141,6 +142,9 @@ class Conformer(nn.Module):
         self._packed = None
         self._packed_key = None
         self._workspace = None
+        # dropout seed of the training forward: ONE device word, bumped on the device by every training forward (not a
+        # parameter, not in the state_dict: the keys stay the reference's)
+        self.register_buffer("_drop_seed", torch.zeros(1, dtype=torch.int32), persistent=False)
 
     # ------------------------------------------------------------------ weight packing
     def _pack_key(self):

@@ -197,30 +197,33 @@ def mha_relpos(qkv, pe_pack, n_head):
     return out
 
 
-def mha_relpos_train(qkv, pe_pack, n_head):
-    """mha_relpos that also returns the per-row log-sum-exp f32 [B,H,T] (saved for the backward)."""
+def mha_relpos_train(qkv, pe_pack, n_head, drop=None):
+    """mha_relpos that also returns the per-row log-sum-exp f32 [B,H,T] (saved for the backward).  drop: dropout cfg of
+    the attention probabilities (training)."""
     _need(qkv, torch.bfloat16, "qkv")
     packed, q_min, q_max = pe_pack
     B, T, D3 = qkv.shape
     assert qkv.is_contiguous() and D3 == 3 * n_head * 64
     out = torch.empty(B, T, n_head * 64, device=qkv.device, dtype=torch.bfloat16)
     lse = torch.empty(B, n_head, T, device=qkv.device, dtype=torch.float32)
-    check(lib().csship_mha_relpos_train(_ptr(qkv), _ptr(packed), q_min, q_max, _ptr(out), _ptr(lse), B, T, n_head,
-                                        _stream()))
+    check(lib().csship_mha_relpos_train_drop(_ptr(qkv), _ptr(packed), q_min, q_max, _ptr(out), _ptr(lse), B, T, n_head,
+                                             drop, _stream()))
     return out, lse
 
 
-def mha_relpos_probs(qkv, pe_pack, lse, n_head):
-    """softmax probabilities bf16 [B,H,T,pad8(T)] recomputed from q, k, the packed position table and lse."""
+def mha_relpos_probs(qkv, pe_pack, lse, n_head, drop=None):
+    """softmax probabilities bf16 [B,H,T,pad8(T)] recomputed from q, k, the packed position table and lse.  With a
+    dropout cfg returns (p, p_dropped): p_dropped = p o mask / (1 - p_drop), the operand of dV."""
     _need(qkv, torch.bfloat16, "qkv"), _need(lse, torch.float32, "lse")
     packed, q_min, q_max = pe_pack
     B, T, D3 = qkv.shape
     assert qkv.is_contiguous() and lse.is_contiguous() and D3 == 3 * n_head * 64
     ldp = (T + 7) // 8 * 8
     p = torch.empty(B, n_head, T, ldp, device=qkv.device, dtype=torch.bfloat16)
-    check(lib().csship_mha_relpos_probs(_ptr(qkv), _ptr(packed), q_min, q_max, _ptr(lse), _ptr(p), ldp, B, T, n_head,
-                                        _stream()))
-    return p
+    pd = torch.zeros_like(p) if drop is not None else None
+    check(lib().csship_mha_relpos_probs_drop(_ptr(qkv), _ptr(packed), q_min, q_max, _ptr(lse), _ptr(p), _ptr(pd), ldp, B,
+                                             T, n_head, drop, _stream()))
+    return p if drop is None else (p, pd)
 
 
 def conv_weights_struct(t):
@@ -232,7 +235,7 @@ def conv_weights_struct(t):
     return cw
 
 
-def convmod(x, weights, kernel_size=33, batch_stats=False, return_workspace=False, keep_activations=False):
+def convmod(x, weights, kernel_size=33, batch_stats=False, return_workspace=False, keep_activations=False, drop=None):
     """x f32 [B,T,D] -> x + ConvModule(x).  weights: dict for conv_weights_struct.
     return_workspace (batch_stats only): also return the workspace the backward needs (pre-BN activations; its last
     4*D floats are scale | shift | batch mean | biased batch variance)."""
@@ -245,8 +248,8 @@ def convmod(x, weights, kernel_size=33, batch_stats=False, return_workspace=Fals
     mode = 1 if batch_stats else (2 if keep_activations else 0)  # 2: running statistics, activations kept for the backward
     if mode:
         ws = torch.empty(lib().csship_convmod_workspace(B, T, D), device=x.device, dtype=torch.uint8)
-    check(lib().csship_convmod(_ptr(x), _ptr(y), C.byref(cw), B, T, D, kernel_size, mode,
-                               _ptr(ws), _stream()))
+    check(lib().csship_convmod_drop(_ptr(x), _ptr(y), C.byref(cw), B, T, D, kernel_size, mode,
+                                    _ptr(ws), drop, _stream()))
     return (y, ws) if return_workspace else y
 
 
@@ -419,17 +422,47 @@ def pack_frag(w):
     return wp.contiguous().to(torch.bfloat16).view(-1)
 
 
-def ffn_fused(x, ln, w1p, b1, w2p, b2, d_ffn, alpha=0.5, final_ln=None, out=None):
-    """out = x + alpha * FFN(LN(x)) [-> LN]; x f32 [M,256]; w1p/w2p from pack_frag."""
+def ffn_fused(x, ln, w1p, b1, w2p, b2, d_ffn, alpha=0.5, final_ln=None, out=None, drop_hidden=None, drop_out=None):
+    """out = x + alpha * FFN(LN(x)) [-> LN]; x f32 [M,256]; w1p/w2p from pack_frag.  drop_hidden / drop_out: dropout cfg
+    pointers (css_amd.dropout.DropState.cfg) of the training forward, None = no dropout."""
     _need(x, torch.float32, "x")
     assert x.dim() == 2 and x.is_contiguous()
     M, D = x.shape
     if out is None:
         out = torch.empty_like(x)
-    check(lib().csship_ffn_fused(_ptr(x), _ptr(out), _ptr(ln[0]), _ptr(ln[1]), _ptr(w1p), _ptr(b1), _ptr(w2p),
-                                 _ptr(b2), _ptr(final_ln[0]) if final_ln else None,
-                                 _ptr(final_ln[1]) if final_ln else None, M, D, d_ffn, alpha, _stream()))
+    check(lib().csship_ffn_fused_drop(_ptr(x), _ptr(out), _ptr(ln[0]), _ptr(ln[1]), _ptr(w1p), _ptr(b1), _ptr(w2p),
+                                      _ptr(b2), _ptr(final_ln[0]) if final_ln else None,
+                                      _ptr(final_ln[1]) if final_ln else None, M, D, d_ffn, alpha, drop_hidden, drop_out,
+                                      _stream()))
     return out
+
+
+def dropout_apply(x, cfg, out=None):
+    """y = x o mask / (1 - p) on an f32 [rows, cols] tensor (row stride free, cols % 4 == 0); in place by default."""
+    _need(x, torch.float32, "x")
+    x2 = x.view(-1, x.shape[-1]) if x.is_contiguous() else x
+    assert x2.dim() == 2 and x2.stride(1) == 1
+    y = x2 if out is None else out.view(-1, out.shape[-1])
+    check(lib().csship_dropout_apply(_ptr(x2), x2.stride(0), _ptr(y), y.stride(0), x2.shape[0], x2.shape[1], cfg, _stream()))
+    return x if out is None else out
+
+
+def dropout_add(x, y, cfg, alpha=1.0, out=None):
+    """out = x + alpha * dropout(y), dense f32 [rows, cols]."""
+    _need(x, torch.float32, "x"), _need(y, torch.float32, "y")
+    assert x.is_contiguous() and y.is_contiguous() and x.shape == y.shape
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().csship_dropout_add(_ptr(x), _ptr(y), _ptr(out), float(alpha), x.numel() // x.shape[-1], x.shape[-1], cfg,
+                                   _stream()))
+    return out
+
+
+def dropout_mask(n, cfg, device="cuda"):
+    """The keep mask itself (uint8 [n]) - tests compare it with oracle.dropout.keep_mask."""
+    keep = torch.empty(n, dtype=torch.uint8, device=device)
+    check(lib().csship_dropout_mask(_ptr(keep), n, cfg, _stream()))
+    return keep
 
 
 def panel_linear(a, wp, bias, N, *, ln=None, relu=False, residual=None, alpha=1.0, out_bf16=False, out=None):

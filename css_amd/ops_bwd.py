@@ -171,7 +171,7 @@ def relpos_softmax_bwd(p, dp, T, W):
     return ds, dsk
 
 
-def convmod_bwd(x, dy, weights, fwd_ws, kernel_size=33, bn_eval=False):
+def convmod_bwd(x, dy, weights, fwd_ws, kernel_size=33, bn_eval=False, drop=None):
     """Backward of ops.convmod(x, weights, batch_stats=True) (or keep_activations=True with bn_eval=True).  x, dy f32 [B,T,D]; fwd_ws: that call's workspace.
     Returns dx and a dict of f32 gradients keyed like the weights dict (dw_w as [k, D])."""
     from .ops import conv_weights_struct
@@ -183,8 +183,8 @@ def convmod_bwd(x, dy, weights, fwd_ws, kernel_size=33, bn_eval=False):
     dx = torch.empty_like(x)
     nws = lib().csship_convmod_bwd_workspace(B, T, D)
     ws = _workspace(nws, x.device)
-    check(lib().csship_convmod_bwd(_ptr(x), _ptr(dy), C.byref(cw), B, T, D, kernel_size, _ptr(fwd_ws), _ptr(dx),
-                                   _ptr(flat), int(bn_eval), _ptr(ws), nws, _stream()))
+    check(lib().csship_convmod_bwd_drop(_ptr(x), _ptr(dy), C.byref(cw), B, T, D, kernel_size, _ptr(fwd_ws), _ptr(dx),
+                                        _ptr(flat), int(bn_eval), drop, _ptr(ws), nws, _stream()))
     o = 2 * D + 4
     grads = {"bn_b": flat[:D], "bn_g": flat[D:2 * D], "pw2_w": flat[2 * D:2 * D + 1], "pw2_b": flat[2 * D + 1:2 * D + 2],
              "dw_w": flat[o:o + kernel_size * D].view(kernel_size, D), "dw_b": flat[o + 33 * D:o + 34 * D],
@@ -284,9 +284,10 @@ def lstm_bidir_bwd(gates, c, dy, whhT_packed):
     return dg
 
 
-def ffn_bwd(x, dy, ln_g, ln_b, w1p, b1, w2tp, w1tp, d_ffn, alpha=0.5):
+def ffn_bwd(x, dy, ln_g, ln_b, w1p, b1, w2tp, w1tp, d_ffn, alpha=0.5, drop_hidden=None, drop_out=None):
     """Activation side of the FeedForward backward in one kernel (csship_ffn_bwd).
-    Returns (dx f32 [M,256], dgamma, dbeta, a bf16 [M,256], h bf16 [M,d_ffn], dh bf16 [M,d_ffn])."""
+    Returns (dx f32 [M,256], dgamma, dbeta, a bf16 [M,256], h bf16 [M,d_ffn], dh bf16 [M,d_ffn], dyd): with dropout
+    cfgs h is the DROPPED hidden activation and dyd (bf16 [M,256]) = alpha * dy o output mask / (1 - p), else None."""
     _need(x, torch.float32, "x"), _need(dy, torch.float32, "dy")
     M, D = x.shape
     if not (x.is_contiguous() and dy.is_contiguous()) or dy.shape != x.shape:
@@ -299,10 +300,11 @@ def ffn_bwd(x, dy, ln_g, ln_b, w1p, b1, w2tp, w1tp, d_ffn, alpha=0.5):
     gb = torch.empty((2, D), dtype=torch.float32, device=dev)
     nws = lib().csship_ffn_bwd_workspace(M)
     ws = _workspace(nws, dev)
-    check(lib().csship_ffn_bwd(_ptr(x), _ptr(dy), _ptr(ln_g), _ptr(ln_b), _ptr(w1p), _ptr(b1), _ptr(w2tp), _ptr(w1tp),
-                               _ptr(a), _ptr(h), _ptr(dh), _ptr(dx), _ptr(gb), M, D, d_ffn, float(alpha), _ptr(ws), nws,
-                               _stream()))
-    return dx, gb[0], gb[1], a, h, dh
+    dyd = torch.empty((M, D), dtype=torch.bfloat16, device=dev) if drop_out is not None else None
+    check(lib().csship_ffn_bwd_drop(_ptr(x), _ptr(dy), _ptr(ln_g), _ptr(ln_b), _ptr(w1p), _ptr(b1), _ptr(w2tp), _ptr(w1tp),
+                                    _ptr(a), _ptr(h), _ptr(dh), _ptr(dx), _ptr(gb), M, D, d_ffn, float(alpha), drop_hidden,
+                                    drop_out, _ptr(dyd), _ptr(ws), nws, _stream()))
+    return dx, gb[0], gb[1], a, h, dh, dyd
 
 
 def attn_rowdot(d_out, out, B, T, H):
@@ -313,13 +315,13 @@ def attn_rowdot(d_out, out, B, T, H):
     return d
 
 
-def attn_softmax_bwd(qkv, d_out, p, d, skew, n_head):
+def attn_softmax_bwd(qkv, d_out, p, d, skew, n_head, drop=None):
     """dS = P o (dO v^T - D) -> (dS bf16 like p, skew) ; skew: bf16 [B,T,H,W], zero outside the band, filled in place."""
     _need(qkv, torch.bfloat16, "qkv"), _need(p, torch.bfloat16, "p")
     B, T, _ = qkv.shape
     if not (qkv.is_contiguous() and d_out.is_contiguous() and p.is_contiguous() and d.is_contiguous() and skew.is_contiguous()):
         raise RuntimeError("css_amd: attn_softmax_bwd expects dense operands")
     ds = torch.empty_like(p)
-    check(lib().csship_attn_softmax_bwd(_ptr(qkv), _ptr(d_out), _ptr(p), p.shape[3], _ptr(d), _ptr(ds), _ptr(skew),
-                                        skew.shape[3], B, T, n_head, _stream()))
+    check(lib().csship_attn_softmax_bwd_drop(_ptr(qkv), _ptr(d_out), _ptr(p), p.shape[3], _ptr(d), _ptr(ds), _ptr(skew),
+                                             skew.shape[3], B, T, n_head, drop, _stream()))
     return ds, skew

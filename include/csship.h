@@ -41,6 +41,30 @@ enum {
 int csship_version(void);
 const char* csship_strerror(int rc);
 
+/* ------------------------------------------------------------------ dropout (training mode)
+ * The reference applies nn.Dropout(p) at: the embedding (css/models/conformer.py:127, css/models/blstm.py:147), the
+ * attention probabilities and the attention output (conformer.py:249,254), the end of the ConvModule (:302), both
+ * FeedForward linears (:317,319) and every BLSTM layer (blstm.py:158).  Here a mask is a pure function of
+ * (seed, stream, element index): element e (row-major index in the dropped tensor) survives iff the 16-bit field
+ * (e & 1) of hash32(hash32(seed ^ stream*0x9E3779B9) + (e >> 1)) is >= round(p*65536); survivors are scaled by
+ * 65536 / (65536 - round(p*65536)).  hash32 is the "lowbias32" mixer (css_amd/csrc/common.hpp; oracle/dropout.py is
+ * its numpy twin).  `seed` points to ONE uint32 in DEVICE memory (read by the kernels, so a captured step can be
+ * replayed with new masks); a NULL cfg pointer, a NULL seed or p <= 0 mean "no dropout".  Forward and backward
+ * kernels take the same cfg and regenerate the same mask. */
+typedef struct csship_dropout_cfg_s {
+  const uint32_t* seed; /* device */
+  uint32_t stream;      /* dropout site id (the host gives every site of every layer its own) */
+  float p;
+} csship_dropout_cfg;
+/* y[r, c] = x[r, c] * keep(r*cols + c) / (1 - p), f32 [rows, cols] with row strides ldx / ldy (y may alias x). */
+int csship_dropout_apply(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int32_t cols,
+                         const csship_dropout_cfg* cfg, csship_stream_t stream);
+/* out = x + alpha * dropout(y): the residual add behind a dropped branch (f32 [rows, cols], dense). */
+int csship_dropout_add(const float* x, const float* y, float* out, float alpha, int64_t rows, int32_t cols,
+                       const csship_dropout_cfg* cfg, csship_stream_t stream);
+/* keep[e] = 1 / 0 (uint8 [n]): the mask itself, for tests and for callers that want to inspect it. */
+int csship_dropout_mask(uint8_t* keep, int64_t n, const csship_dropout_cfg* cfg, csship_stream_t stream);
+
 /* ------------------------------------------------------------------ features
  * Replaces STFT.forward (css/executor/feature.py:45-82): 512-point Hann-windowed
  * real DFT of every frame, hop 256, no centre padding, T = (n_samples-512)/256+1.
@@ -171,6 +195,16 @@ int csship_ffn_fused(const float* x, float* out, const float* ln_g, const float*
                      int32_t M, int32_t d_model, int32_t d_ffn, float alpha,
                      csship_stream_t stream);
 
+/* Training form of csship_ffn_fused with the reference's two dropouts (conformer.py:317,319):
+ *   out = x + alpha * D_out( D_hid( relu(LN(x) W1^T + b1) ) W2^T + b2 )  [-> LayerNorm];
+ * D_hid indexes the hidden activation as [M, d_ffn] row-major, D_out the output as [M, 256].  NULL = no dropout. */
+int csship_ffn_fused_drop(const float* x, float* out, const float* ln_g, const float* ln_b,
+                          const uint16_t* w1_packed, const float* b1, const uint16_t* w2_packed,
+                          const float* b2, const float* final_ln_g, const float* final_ln_b,
+                          int32_t M, int32_t d_model, int32_t d_ffn, float alpha,
+                          const csship_dropout_cfg* drop_hidden, const csship_dropout_cfg* drop_out,
+                          csship_stream_t stream);
+
 /* csship_panel_linear: out[M, N] = epi( pro(a)[M, 256] @ W[N, 256]^T + bias ).
  * prologue: LayerNorm of f32 rows (pre-LN of MultiHeadedAttention, conformer.py:222),
  * bf16 rows as they are, or f32 rows rounded to bf16.  epilogue: OR of CSSHIP_EPI_RELU,
@@ -247,6 +281,12 @@ size_t csship_convmod_workspace(int32_t B, int32_t T, int32_t D);
 int csship_convmod(const float* x, float* y, const csship_conv_weights* w, int32_t B, int32_t T,
                    int32_t D, int32_t kernel_size, int32_t bn_mode, void* workspace,
                    csship_stream_t stream);
+
+/* Training form with the module's final dropout (conformer.py:302): y = x + D(pw2(relu(BN(...)))), bn_mode 1 or 2;
+ * D indexes the branch as [B*T, D] row-major. */
+int csship_convmod_drop(const float* x, float* y, const csship_conv_weights* w, int32_t B, int32_t T,
+                        int32_t D, int32_t kernel_size, int32_t bn_mode, void* workspace,
+                        const csship_dropout_cfg* drop, csship_stream_t stream);
 
 /* Back half of the conv module from a precomputed g = glu(LayerNorm_conv(x)) (csship_outproj_glu):
  *   y = x + pw2( relu( BN_eval( dwconv_k(g) ) ) ).  x, g, y: f32 [B, T, D]; y may alias x (x is read
@@ -401,6 +441,16 @@ int csship_ffn_bwd(const float* x, const float* dy, const float* ln_g, const flo
                    float* dx, float* dgamma_dbeta, int32_t M, int32_t d_model, int32_t d_ffn, float alpha,
                    void* workspace, size_t workspace_bytes, csship_stream_t stream);
 
+/* Backward of csship_ffn_fused_drop (same cfgs): h_bf16 is the DROPPED hidden activation, dh_bf16 carries both masks,
+ * and dyd_bf16 (optional, bf16 [M, 256]) = alpha * dy o output mask / (1 - p): with dropout the weight-gradient GEMMs
+ * are dW2 = dyd^T h, db2 = colsum(dyd). */
+int csship_ffn_bwd_drop(const float* x, const float* dy, const float* ln_g, const float* ln_b,
+                        const uint16_t* w1_packed, const float* b1, const uint16_t* w2t_packed,
+                        const uint16_t* w1t_packed, uint16_t* a_bf16, uint16_t* h_bf16, uint16_t* dh_bf16,
+                        float* dx, float* dgamma_dbeta, int32_t M, int32_t d_model, int32_t d_ffn, float alpha,
+                        const csship_dropout_cfg* drop_hidden, const csship_dropout_cfg* drop_out, uint16_t* dyd_bf16,
+                        void* workspace, size_t workspace_bytes, csship_stream_t stream);
+
 /* ---- attention, training (css_amd/csrc/attn.hip).  csship_mha_relpos_train = csship_mha_relpos that also returns
  * lse[b, h, i] = log sum_j exp(score[i, j]) (f32 [B, H, T]).  csship_mha_relpos_probs recomputes the softmax for the
  * backward pass: p[b, h, i, j] = exp(score[i, j] - lse[b, h, i]) as bf16 [B, H, T, ld_p] (ld_p >= T, ld_p % 4 == 0;
@@ -410,6 +460,20 @@ int csship_mha_relpos_train(const uint16_t* qkv, const uint16_t* pe_packed, int3
 int csship_mha_relpos_probs(const uint16_t* qkv, const uint16_t* pe_packed, int32_t q_min, int32_t q_max,
                             const float* lse, uint16_t* p_bf16, int64_t ld_p, int32_t B, int32_t T, int32_t H,
                             csship_stream_t stream);
+
+/* Training forms with dropout of the attention probabilities (conformer.py:249): out = (mask / (1 - p) o softmax(.)) v.
+ * Element index of P[b, h, i, j] for the mask: ((b*H + h)*T + i) * pad8(T) + j.  csship_mha_relpos_probs_drop also
+ * writes the masked, rescaled probabilities (operand of dV); with dropout ld_p must be pad8(T). */
+int csship_mha_relpos_train_drop(const uint16_t* qkv, const uint16_t* pe_packed, int32_t q_min, int32_t q_max,
+                                 uint16_t* out, float* lse, int32_t B, int32_t T, int32_t H,
+                                 const csship_dropout_cfg* drop, csship_stream_t stream);
+int csship_mha_relpos_probs_drop(const uint16_t* qkv, const uint16_t* pe_packed, int32_t q_min, int32_t q_max,
+                                 const float* lse, uint16_t* p_bf16, uint16_t* p_dropped_bf16, int64_t ld_p,
+                                 int32_t B, int32_t T, int32_t H, const csship_dropout_cfg* drop, csship_stream_t stream);
+/* dS = P o (mask / (1 - p) o (dO v^T) - D) */
+int csship_attn_softmax_bwd_drop(const uint16_t* qkv, const uint16_t* d_out, const uint16_t* p_bf16, int64_t ld_p,
+                                 const float* d, uint16_t* ds_bf16, uint16_t* ds_skew_bf16, int32_t W, int32_t B,
+                                 int32_t T, int32_t H, const csship_dropout_cfg* drop, csship_stream_t stream);
 
 /* csship_attn_softmax_bwd: dS[b,h,i,j] = P[i,j] * (dO_i . v_j - d[b,h,i]) computed attention-shaped (V tiles in LDS,
  * dO rows as MFMA operand), no [B,H,T,T] f32 intermediate.  qkv as in csship_mha_relpos; d_out bf16 [B*T, H*64];
@@ -464,6 +528,11 @@ int csship_convmod_bwd(const float* x, const float* dy, const csship_conv_weight
                        int32_t D, int32_t kernel_size, const void* fwd_workspace, float* dx,
                        float* grads, int32_t bn_eval, void* workspace, size_t workspace_bytes,
                        csship_stream_t stream);
+/* ... of csship_convmod_drop (same cfg): the branch gradient is dy o mask / (1 - p), the residual path dy. */
+int csship_convmod_bwd_drop(const float* x, const float* dy, const csship_conv_weights* w, int32_t B, int32_t T,
+                            int32_t D, int32_t kernel_size, const void* fwd_workspace, float* dx,
+                            float* grads, int32_t bn_eval, const csship_dropout_cfg* drop, void* workspace,
+                            size_t workspace_bytes, csship_stream_t stream);
 
 /* Weight shadows for one Linear in ONE launch: f32 w[R, K] (row stride ld_w), every element times `scale`, written
  * as bf16 row-major rows dst_row0.. of a [.., ld_row_major] matrix (optional; the kmajor operand of csship_bgemm)

@@ -27,32 +27,37 @@ def lstm_direction(x, w_ih, w_hh, b_ih, b_hh, reverse=False):
     return out
 
 
-def blstm_layer(x, sd, p):
-    """BLSTMLayer.forward, blstm.py:149-160 (eval: dropout = identity)."""
+def _no_drop(x, site):
+    return x
+
+
+def blstm_layer(x, sd, p, drop=_no_drop, layer=0):
+    """BLSTMLayer.forward, blstm.py:149-160; drop(x, site): the layer's dropout (:158) with the build's masks."""
     fw = lstm_direction(x, sd[p + ".lstm.weight_ih_l0"], sd[p + ".lstm.weight_hh_l0"],
                         sd[p + ".lstm.bias_ih_l0"], sd[p + ".lstm.bias_hh_l0"])
     bw = lstm_direction(x, sd[p + ".lstm.weight_ih_l0_reverse"], sd[p + ".lstm.weight_hh_l0_reverse"],
                         sd[p + ".lstm.bias_ih_l0_reverse"], sd[p + ".lstm.bias_hh_l0_reverse"],
                         reverse=True)
     y = torch.cat([fw, bw], dim=-1)
-    return F.layer_norm(y, (y.shape[-1],), sd[p + ".layer_norm.weight"], sd[p + ".layer_norm.bias"], LN_EPS)
+    return drop(F.layer_norm(y, (y.shape[-1],), sd[p + ".layer_norm.weight"], sd[p + ".layer_norm.bias"], LN_EPS),
+                f"{layer}.blstm.layer")
 
 
-def encoder(x, sd, num_layers, p="blstm"):
-    """BLSTMEncoder.forward, blstm.py:122-128."""
+def encoder(x, sd, num_layers, p="blstm", drop=_no_drop):
+    """BLSTMEncoder.forward, blstm.py:122-128 (embed: Linear, LayerNorm, Dropout, ReLU, :143-148)."""
     x = F.linear(x, sd[p + ".embed.0.weight"], sd[p + ".embed.0.bias"])
-    x = torch.relu(F.layer_norm(x, (x.shape[-1],), sd[p + ".embed.1.weight"], sd[p + ".embed.1.bias"], LN_EPS))
+    x = torch.relu(drop(F.layer_norm(x, (x.shape[-1],), sd[p + ".embed.1.weight"], sd[p + ".embed.1.bias"], LN_EPS), "embed"))
     for l in range(num_layers):
-        x = blstm_layer(x, sd, f"{p}.encoders.{l}")
+        x = blstm_layer(x, sd, f"{p}.encoders.{l}", drop, l)
     return x
 
 
-def forward(f, sd, num_layers, num_spk=2, num_noise=1):
+def forward(f, sd, num_layers, num_spk=2, num_noise=1, drop=_no_drop):
     """BLSTM.forward, blstm.py:68-88 -> (y_pred, masks)."""
     if f.dim() == 4:
         f = f.squeeze(0)
     f_orig = f
-    h = encoder(mvn_time(f), sd, num_layers)
+    h = encoder(mvn_time(f), sd, num_layers, drop=drop)
     m = torch.relu(F.linear(h, sd["linear.weight"], sd["linear.bias"]))
     masks = torch.chunk(m, num_spk + num_noise, dim=-1)
     y_pred = torch.stack([mk * f_orig for mk in masks[:-1]], dim=1)

@@ -34,15 +34,21 @@ def rel_pos_table(pe_k, T, maxlen=1000):
     return pe_k[rel]  # [T,T,d_k]
 
 
-def feed_forward(x, sd, p):
-    """FeedForward.forward, conformer.py:322-326 (eval: dropout = identity)."""
+def _no_drop(x, site):
+    return x
+
+
+def feed_forward(x, sd, p, drop=_no_drop, site=""):
+    """FeedForward.forward, conformer.py:322-326.  drop(x, site) applies the two nn.Dropout layers (:317,319) with the
+    build's masks (oracle/dropout.py); the default is eval mode (identity)."""
     h = _ln(x, sd, p + ".layer_norm")
-    h = torch.relu(_lin(h, sd, p + ".net.0"))
-    return _lin(h, sd, p + ".net.3")
+    h = drop(torch.relu(_lin(h, sd, p + ".net.0")), site + ".hidden")
+    return drop(_lin(h, sd, p + ".net.3"), site + ".out")
 
 
-def attention(x, sd, p, n_head, pos_k):
-    """MultiHeadedAttention.forward, conformer.py:213-254 (mask=None, eval)."""
+def attention(x, sd, p, n_head, pos_k, drop=_no_drop, site=""):
+    """MultiHeadedAttention.forward, conformer.py:213-254 (mask=None).  drop: the dropouts of the probabilities (:249,
+    indexed as [B, H, T, pad8(T)] like the build's probability buffer) and of the output (:254)."""
     B, T, D = x.shape
     dk = D // n_head
     h = _ln(x, sd, p + ".layer_norm")
@@ -54,11 +60,14 @@ def attention(x, sd, p, n_head, pos_k):
         # B_[b,h,i,j] = q[b,h,i,:] . pos_k[i,j,:]   (conformer.py:230-233)
         scores = scores + torch.einsum("bhid,ijd->bhij", q, pos_k)
     att = torch.softmax(scores / math.sqrt(dk), dim=-1)
+    if drop is not _no_drop:
+        Tp = (T + 7) // 8 * 8
+        att = drop(F.pad(att, (0, Tp - T)), site + ".p")[..., :T]
     ctx = torch.matmul(att, v).transpose(1, 2).reshape(B, T, D)
-    return _lin(ctx, sd, p + ".linear_out")
+    return drop(_lin(ctx, sd, p + ".linear_out"), site + ".out")
 
 
-def conv_module(x, sd, p, kernel_size, training_bn=False):
+def conv_module(x, sd, p, kernel_size, training_bn=False, drop=_no_drop, site=""):
     """ConvModule.forward, conformer.py:289-303 (non-causal).
 
     The two "pointwise convs" are Conv2d(1,2,1) / Conv2d(1,1,1): scalar gains.
@@ -82,40 +91,40 @@ def conv_module(x, sd, p, kernel_size, training_bn=False):
     y = (y - mu) / torch.sqrt(var + LN_EPS)
     y = y * sd[p + ".BN.weight"].view(1, D, 1) + sd[p + ".BN.bias"].view(1, D, 1)
     y = torch.relu(y).transpose(1, 2)
-    return y * sd[p + ".pw_conv_2.weight"].reshape(()) + sd[p + ".pw_conv_2.bias"].reshape(())
+    return drop(y * sd[p + ".pw_conv_2.weight"].reshape(()) + sd[p + ".pw_conv_2.bias"].reshape(()), site + ".out")  # :302
 
 
-def encoder_layer(x, sd, p, n_head, kernel_size, pos_k, training_bn=False):
+def encoder_layer(x, sd, p, n_head, kernel_size, pos_k, training_bn=False, drop=_no_drop, layer=0):
     """EncoderLayer.forward, conformer.py:348-362."""
-    x = x + 0.5 * feed_forward(x, sd, p + ".feed_forward_in")
-    x = x + attention(x, sd, p + ".self_attn", n_head, pos_k)
-    x = x + conv_module(x, sd, p + ".conv", kernel_size, training_bn)
-    x = x + 0.5 * feed_forward(x, sd, p + ".feed_forward_out")
+    x = x + 0.5 * feed_forward(x, sd, p + ".feed_forward_in", drop, f"{layer}.ffn_in")
+    x = x + attention(x, sd, p + ".self_attn", n_head, pos_k, drop, f"{layer}.attn")
+    x = x + conv_module(x, sd, p + ".conv", kernel_size, training_bn, drop, f"{layer}.conv")
+    x = x + 0.5 * feed_forward(x, sd, p + ".feed_forward_out", drop, f"{layer}.ffn_out")
     return _ln(x, sd, p + ".layer_norm")
 
 
-def embed(x, sd, p="conformer.embed"):
-    """conformer.py:124-129: Linear + LayerNorm + (Dropout) + ReLU."""
-    return torch.relu(_ln(_lin(x, sd, p + ".0"), sd, p + ".1"))
+def embed(x, sd, p="conformer.embed", drop=_no_drop):
+    """conformer.py:124-129: Linear + LayerNorm + Dropout + ReLU."""
+    return torch.relu(drop(_ln(_lin(x, sd, p + ".0"), sd, p + ".1"), "embed"))
 
 
 def encoder(x, sd, n_head=4, kernel_size=33, num_blocks=16, relative_pos_emb=True,
-            training_bn=False, p="conformer"):
+            training_bn=False, p="conformer", drop=_no_drop):
     """ConformerEncoder.forward, conformer.py:152-165."""
-    x = embed(x, sd, p + ".embed")
+    x = embed(x, sd, p + ".embed", drop)
     pos_k = rel_pos_table(sd[p + ".pos_emb.pe_k.weight"], x.shape[1]) if relative_pos_emb else None
     for l in range(num_blocks):
-        x = encoder_layer(x, sd, f"{p}.encoders.{l}", n_head, kernel_size, pos_k, training_bn)
+        x = encoder_layer(x, sd, f"{p}.encoders.{l}", n_head, kernel_size, pos_k, training_bn, drop, l)
     return x
 
 
 def forward(f, sd, num_spk=2, num_noise=1, n_head=4, kernel_size=33, num_blocks=16,
-            relative_pos_emb=True, training_bn=False):
+            relative_pos_emb=True, training_bn=False, drop=_no_drop):
     """Conformer.forward, conformer.py:83-104 -> (y_pred [N,K,T,F], masks (K+1)x[N,T,F])."""
     if f.dim() == 4:
         f = f.squeeze(0)
     f_orig = f
-    h = encoder(mvn_time(f), sd, n_head, kernel_size, num_blocks, relative_pos_emb, training_bn)
+    h = encoder(mvn_time(f), sd, n_head, kernel_size, num_blocks, relative_pos_emb, training_bn, drop=drop)
     m = torch.relu(_lin(h, sd, "linear"))
     masks = torch.chunk(m, num_spk + num_noise, dim=2)
     y_pred = torch.stack([mk * f_orig for mk in masks[:-1]], dim=1)

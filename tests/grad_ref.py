@@ -6,7 +6,17 @@ import torch
 import oracle
 
 
-def oracle_masks(model, f, training_bn):
+def drop_of(model):
+    """The oracle-side drop(x, site) that applies exactly the masks of the model's LAST training forward (the device
+    seed after its bump), or the identity when the model does not drop (eval mode / dropout_rate 0)."""
+    from css_amd.dropout import stream_of
+    enc = getattr(model, "conformer", None) or model.blstm
+    if not model.training or enc.dropout_rate <= 0.0:
+        return None
+    return oracle.dropout.Masks(int(model._drop_seed.item()), enc.dropout_rate, stream_of)
+
+
+def oracle_masks(model, f, training_bn, drop=None):
     """(masks [N,T,(K+1)*F] as one tensor with grad, leaf state dict) of the oracle forward for `model`'s weights."""
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     for v in sd.values():
@@ -17,10 +27,10 @@ def oracle_masks(model, f, training_bn):
         enc = model.conformer
         _, masks = oracle.conformer.forward(f, sd, num_spk=model.num_spk, num_noise=model.num_noise, n_head=enc.n_head,
                                             kernel_size=enc.kernel_size, num_blocks=len(enc.encoders),
-                                            training_bn=training_bn)
+                                            training_bn=training_bn, **({"drop": drop} if drop is not None else {}))
     else:
         _, masks = oracle.blstm.forward(f, sd, num_layers=len(model.blstm.encoders), num_spk=model.num_spk,
-                                        num_noise=model.num_noise)
+                                        num_noise=model.num_noise, **({"drop": drop} if drop is not None else {}))
     return torch.cat(masks, -1), sd
 
 
@@ -35,8 +45,9 @@ def pit_loss_with_perm(masks, f, targets, perm, nbins=257):
 
 
 def oracle_param_grads(model, loss_of_masks, f, training_bn):
-    """{parameter name: gradient} of loss_of_masks(masks) by autograd through the oracle."""
-    masks, sd = oracle_masks(model, f, training_bn)
+    """{parameter name: gradient} of loss_of_masks(masks) by autograd through the oracle (with the dropout masks of the
+    model's last training forward, if it dropped)."""
+    masks, sd = oracle_masks(model, f, training_bn, drop_of(model))
     loss_of_masks(masks).backward()
     return {k: sd[k].grad for k, _ in model.named_parameters()}
 

@@ -264,3 +264,37 @@ def test_oracle_properties_pit_permutation_and_stft_linearity():
 
     pit()
     lin()
+
+
+def test_oracle_training_forward_with_dropout_matches_reference(golden):
+    """Train-mode forwards (batch-statistics BatchNorm + dropout) of the oracle vs the reference run with its nn.Dropout
+    layers applying the build's counter-based masks (tests/golden/make_golden_dropout.py): pins WHERE and on WHAT the
+    dropout acts (embed before the ReLU, hidden / output of both FeedForwards, attention probabilities and output,
+    ConvModule output; BLSTM: embed and every layer)."""
+    from css_amd.dropout import stream_of
+    g = golden("dropout.npz")
+    drop = oracle.dropout.Masks(int(g["seed"]), float(g["p"]), stream_of)
+    sd = syn.fill_state_dict(syn.conformer_shapes(num_blocks=2), 61)
+    f = rnd((3, 44, 257), 62).abs()
+    _, masks = oracle.conformer.forward(f, sd, num_blocks=2, training_bn=True, drop=drop)
+    ref = torch.from_numpy(g["conformer_masks"])
+    assert float((torch.stack(masks) - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max()))
+    # and dropout matters: the eval-style forward differs visibly
+    _, masks0 = oracle.conformer.forward(f, sd, num_blocks=2, training_bn=True)
+    assert float((torch.stack(masks0) - ref).abs().max()) > 1e-2
+    sdb = syn.fill_state_dict(syn.blstm_shapes(hidden_dim=64, num_layers=2), 63)
+    fb = rnd((2, 30, 257), 64).abs()
+    _, bm = oracle.blstm.forward(fb, sdb, num_layers=2, drop=drop)
+    refb = torch.from_numpy(g["blstm_masks"])
+    assert float((torch.stack(bm) - refb).abs().max()) < 2e-4 * max(1.0, float(refb.abs().max()))
+
+
+def test_dropout_mask_statistics():
+    """keep rate of the counter-based mask = 1 - round(p * 65536) / 65536; different sites / seeds are uncorrelated."""
+    k1 = oracle.dropout.keep_mask(7, 17, 200000, 0.1)
+    k2 = oracle.dropout.keep_mask(7, 18, 200000, 0.1)
+    k3 = oracle.dropout.keep_mask(8, 17, 200000, 0.1)
+    assert abs(k1.mean() - (1 - 6554 / 65536)) < 3e-3
+    for a, b in ((k1, k2), (k1, k3)):
+        assert abs(np.corrcoef(a, b)[0, 1]) < 1e-2
+    assert oracle.dropout.keep_mask(7, 17, 100, 0.0).all()
