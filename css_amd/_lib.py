@@ -75,6 +75,9 @@ SIGNATURES = {
     "csship_version": (_i32, []),
     "csship_strerror": (C.c_char_p, [_i32]),
     "csship_stft": (_i32, [_p, _i64, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _p]),
+    "csship_stft_logpower": (_i32, [_p, _i64, _i64, _i64, _i64, _i64, _f32, _p, _p]),
+    "csship_mix_workspace": (_sz, [_i32]),
+    "csship_mix_batch": (_i32, [_p, _i64, _i32, _p, _i64, _i32, _p, _i32, _i32, _p, _p, _p, _i64, _p, _sz, _p]),
     "csship_mvn_stats": (_i32, [_p, _i64, _i64, _i64, _i64, _f32, _f32, _p, _p, _p]),
     "csship_transpose_norm": (_i32, [_p, _i64, _i64, _i64, _i64, _f32, _p, _p, _p, _i64, _i64, _p]),
     "csship_ipd": (_i32, [_p, _p, _i64, _i64, _i64, C.POINTER(_i32), C.POINTER(_i32), _i32, _p, _i64, _i64, _p, _p]),

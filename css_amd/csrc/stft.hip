@@ -43,11 +43,14 @@ constexpr int NBIN = 257;
 #endif
 constexpr int NC = STFT_NC;  // frames in flight per wave (independent chains)
 
-template <bool MAG_ONLY>
+// LOGPOW (with MAG_ONLY): the `mag` output holds log(max(|X|^2, eps)) instead of |X| - the log-power feature variant
+// (north_star "log-power / IPD features"; SURVEY 8c: the build-defined stand-in for Lhotse's unpinned training
+// features), as an epilogue flag of the same kernel.
+template <bool MAG_ONLY, bool LOGPOW = false>
 __global__ __launch_bounds__(256, STFT_MINW) void stft_kernel(const float* __restrict__ audio, int64_t n1, int64_t stride0,
                                                    int64_t stride1, int64_t n_samples, int T, int fw,
                                                    float* __restrict__ mag, float* __restrict__ re,
-                                                   float* __restrict__ im, float* __restrict__ pha) {
+                                                   float* __restrict__ im, float* __restrict__ pha, float eps = 0.f) {
   __shared__ __attribute__((aligned(16))) cplx sz[4][NC * FFT_SCRATCH];
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
   const int64_t s = blockIdx.y;
@@ -131,7 +134,9 @@ __global__ __launch_bounds__(256, STFT_MINW) void stft_kernel(const float* __res
         const cplx A = zc[k + (k >> 4)], Bv = zc[kc + (kc >> 4)];
         const cplx Bc = {Bv.x, -Bv.y};
         const cplx X = cmul(A - Bc, twp[q]) + (A + Bc);
-        if constexpr (MAG_ONLY) {
+        if constexpr (MAG_ONLY && LOGPOW) {
+          mag[orow + k] = __logf(fmaxf(X.x * X.x + X.y * X.y, eps));
+        } else if constexpr (MAG_ONLY) {
           mag[orow + k] = __builtin_amdgcn_sqrtf(X.x * X.x + X.y * X.y);  // v_sqrt_f32, 1 ulp
         } else {
           if (mag) mag[orow + k] = __builtin_amdgcn_sqrtf(X.x * X.x + X.y * X.y);
@@ -143,7 +148,8 @@ __global__ __launch_bounds__(256, STFT_MINW) void stft_kernel(const float* __res
       if (l == 0) {  // Nyquist bin k = 256: X = Re Z[0] - Im Z[0] of the unscaled Z (ours carries the 1/2)
         const cplx A = zc[0];
         const float xr = 2.f * (A.x - A.y);
-        if (MAG_ONLY || mag) mag[orow + 256] = fabsf(xr);
+        if constexpr (MAG_ONLY && LOGPOW) mag[orow + 256] = __logf(fmaxf(xr * xr, eps));
+        else if (MAG_ONLY || mag) mag[orow + 256] = fabsf(xr);
         if constexpr (!MAG_ONLY) {
           if (re) re[orow + 256] = xr;
           if (im) im[orow + 256] = 0.f;
@@ -185,9 +191,23 @@ extern "C" int csship_debug_stft_stamps(void* dst) {
 }
 #endif
 
+static int stft_launch(const float* audio, int64_t n0, int64_t stride0, int64_t n1, int64_t stride1, int64_t n_samples,
+                       float* mag, float* re, float* im, float* pha, bool logpow, float eps, csship_stream_t stream);
+
 extern "C" int csship_stft(const float* audio, int64_t n0, int64_t stride0, int64_t n1, int64_t stride1,
                            int64_t n_samples, float* mag, float* re, float* im, float* pha,
                            csship_stream_t stream) {
+  return stft_launch(audio, n0, stride0, n1, stride1, n_samples, mag, re, im, pha, false, 0.f, stream);
+}
+
+extern "C" int csship_stft_logpower(const float* audio, int64_t n0, int64_t stride0, int64_t n1, int64_t stride1,
+                                    int64_t n_samples, float eps, float* logpow, csship_stream_t stream) {
+  if (!(eps > 0.f)) return CSSHIP_EBADSHAPE;
+  return stft_launch(audio, n0, stride0, n1, stride1, n_samples, logpow, nullptr, nullptr, nullptr, true, eps, stream);
+}
+
+static int stft_launch(const float* audio, int64_t n0, int64_t stride0, int64_t n1, int64_t stride1, int64_t n_samples,
+                       float* mag, float* re, float* im, float* pha, bool logpow, float eps, csship_stream_t stream) {
   if (!audio || (!mag && !re && !im && !pha)) return CSSHIP_ENULL;
   if (n0 <= 0 || n1 <= 0 || n_samples < 512) return CSSHIP_EBADSHAPE;
   if (!aligned16(audio) || (stride0 % 4) != 0 || (stride1 % 4) != 0) return CSSHIP_EALIGN;
@@ -220,7 +240,10 @@ extern "C" int csship_stft(const float* audio, int64_t n0, int64_t stride0, int6
   const int64_t runs = (T + fw - 1) / fw;
   dim3 grid((unsigned)((runs + 3) / 4), (unsigned)S);
   TimelineScope tl(CSSHIP_TL_STFT, as_stream(stream));
-  if (mag && !re && !im && !pha)
+  if (logpow)
+    hipLaunchKernelGGL((stft_kernel<true, true>), grid, dim3(256), 0, as_stream(stream), audio, n1, stride0, stride1,
+                       n_samples, (int)T, fw, mag, re, im, pha, eps);
+  else if (mag && !re && !im && !pha)
     hipLaunchKernelGGL(stft_kernel<true>, grid, dim3(256), 0, as_stream(stream), audio, n1, stride0, stride1, n_samples,
                        (int)T, fw, mag, re, im, pha);
   else

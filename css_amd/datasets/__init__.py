@@ -2,4 +2,5 @@
 (third-party, unpinned, out of scope); the synthetic counterpart produces the same batch dict on the GPU."""
 from . import synthetic
 
-DATASETS = {"SyntheticSeparation": synthetic.SyntheticSeparationDataset}
+DATASETS = {"SyntheticSeparation": synthetic.SyntheticSeparationDataset,      # a fixed pool of pre-mixed batches
+            "OnDeviceMixture": synthetic.OnDeviceMixtureDataset}              # per-step random mixing on the GPU (N2)

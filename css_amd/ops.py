@@ -38,8 +38,9 @@ def num_frames(n_samples):
     return (n_samples - FRAME_LEN) // FRAME_HOP + 1
 
 
-def stft(x, want=("mag",)):
-    """x: [B,n] or [B,D,n] f32 (last dim contiguous) -> dict of [B,(D,)T,257] tensors (TF layout)."""
+def stft(x, want=("mag",), logpow_eps=1e-10):
+    """x: [B,n] or [B,D,n] f32 (last dim contiguous) -> dict of [B,(D,)T,257] tensors (TF layout).  want: any of
+    "mag", "re", "im", "pha", "logpow" (= log(max(|X|^2, logpow_eps)))."""
     _need(x, torch.float32, "x")
     if x.dim() not in (2, 3):
         raise RuntimeError(f"STFT expect 2D/3D tensor, but got {x.dim()}D signal")  # feature.py:54-59
@@ -66,9 +67,43 @@ def stft(x, want=("mag",)):
     T = num_frames(n)
     shape = tuple(x.shape[:-1]) + (T, NBIN)
     out = {k: torch.empty(shape, device=x.device, dtype=torch.float32) for k in want}
+    if "logpow" in out:  # log(max(|X|^2, eps)): an epilogue flag of the STFT kernel (training features)
+        check(lib().csship_stft_logpower(_ptr(x), n0, s0, n1, s1, n, float(logpow_eps), _ptr(out["logpow"]), _stream()))
+        if len(out) == 1:
+            return out
     check(lib().csship_stft(_ptr(x), n0, s0, n1, s1, n, _ptr(out.get("mag")), _ptr(out.get("re")),
                             _ptr(out.get("im")), _ptr(out.get("pha")), _stream()))
     return out
+
+
+MIX_FIELDS = ("u1", "u2", "w0", "delay", "len1", "len2", "rir_on", "d1", "d2", "noise_on", "nu", "n0", "h0", "h1", "h2", "snr_db")
+
+
+def mix_params(records):
+    """list of dicts keyed by MIX_FIELDS -> host uint8 tensor [B, 64] in csship_mix_batch's record layout."""
+    import numpy as np
+    a = np.zeros((len(records), 16), dtype=np.int32)
+    for i, r in enumerate(records):
+        a[i, :12] = [int(r[k]) for k in MIX_FIELDS[:12]]
+        a[i, 12:] = np.array([r[k] for k in MIX_FIELDS[12:]], dtype=np.float32).view(np.int32)
+    return torch.from_numpy(a)
+
+
+def mix_batch(pool, params_dev, n, noise_pool=None):
+    """On-device mixtures: pool f32 [U, L], params_dev int32 [B, 16] (mix_params(...) on the device), window length n
+    -> (mix, source1, source2) f32 [B, n].  separation.py:163-267 semantics; see include/csship.h."""
+    _need(pool, torch.float32, "pool")
+    assert pool.is_contiguous() and params_dev.is_cuda and params_dev.dtype == torch.int32 and params_dev.is_contiguous()
+    B = params_dev.shape[0]
+    ld = (n + 3) // 4 * 4
+    out = torch.empty((3, B, ld), dtype=torch.float32, device=pool.device)
+    nws = lib().csship_mix_workspace(B)
+    ws = torch.empty(nws, dtype=torch.uint8, device=pool.device)
+    npool = noise_pool.contiguous() if noise_pool is not None else None
+    check(lib().csship_mix_batch(_ptr(pool), pool.shape[1], pool.shape[0], _ptr(npool), npool.shape[1] if npool is not None else 0,
+                                 npool.shape[0] if npool is not None else 0, _ptr(params_dev), B, n, _ptr(out[0]), _ptr(out[1]),
+                                 _ptr(out[2]), ld, _ptr(ws), nws, _stream()))
+    return out[0, :, :n], out[1, :, :n], out[2, :, :n]
 
 
 def mvn_stats(x, clamp_min=NEG_INF, eps=F32_EPS):

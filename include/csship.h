@@ -76,6 +76,28 @@ int csship_stft(const float* audio, int64_t n0, int64_t stride0, int64_t n1, int
                 int64_t n_samples, float* mag, float* re, float* im, float* pha,
                 csship_stream_t stream);
 
+/* Log-power variant of the same transform: logpow[s, t, k] = log(max(|X[s, t, k]|^2, eps)) (natural log), the
+ * build-defined stand-in for the reference's training-time features (Lhotse Spectrogram: third-party, unpinned;
+ * SURVEY.md 8c).  Same addressing and output layout as csship_stft; eps > 0. */
+int csship_stft_logpower(const float* audio, int64_t n0, int64_t stride0, int64_t n1, int64_t stride1,
+                         int64_t n_samples, float eps, float* logpow, csship_stream_t stream);
+
+/* ------------------------------------------------------------------ on-device training mixtures
+ * One call builds a batch of B windows of n samples the way css/datasets/separation.py:163-267 builds them (two
+ * utterances, the second delayed and both zero padded to the mixture length, summed, cut into windows; augmentations on
+ * the mixture only: a sparse 3-tap impulse response and additive noise at a drawn SNR - stand-ins for Lhotse's
+ * ReverbWithImpulseResponse / CutMix, which are third-party and unpinned).  pool: f32 [n_utt, pool_len] device-resident
+ * utterances; noise_pool: f32 [n_noise, noise_len] or NULL.  params: DEVICE array of B records of 16 x 4 bytes
+ *   int32 u1, u2, w0, delay, len1, len2, rir_on, d1, d2, noise_on, nu, n0;  float h0, h1, h2, snr_db
+ * (window start w0 on the mixture's time line; source k valid for 0 <= t < len_k of its own time line; impulse
+ * response y[t] = h0 m[t] + h1 m[t - d1] + h2 m[t - d2]; noise segment noise_pool[nu][n0 .. n0 + n), gain such that
+ * 10 log10(E_mix / E_noise) = snr_db over the window).  Outputs: f32 [B, ld] rows (ld >= n, ld % 4 == 0).
+ * The host draws the parameters; every sample is touched on the device only. */
+size_t csship_mix_workspace(int32_t B);
+int csship_mix_batch(const float* pool, int64_t pool_len, int32_t n_utt, const float* noise_pool, int64_t noise_len,
+                     int32_t n_noise, const void* params, int32_t B, int32_t n, float* mix, float* source1,
+                     float* source2, int64_t ld, void* workspace, size_t workspace_bytes, csship_stream_t stream);
+
 /* Per-(batch, column) mean and 1/(unbiased std + eps) over the time axis of x[B,T,F]
  * (row stride ldx >= F).  Replaces the statistics of css/models/conformer.py:95,
  * css/models/blstm.py:80 and css/executor/feature.py:169-171 (clamp_min applies

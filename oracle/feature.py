@@ -84,6 +84,13 @@ def feature_extractor(x, frame_len=512, frame_hop=256, round_pow_of_two=True, ip
     return mag, f, re, im
 
 
+def log_power(x, eps=1e-10, frame_len=512, frame_hop=256):
+    """Build-defined log-power features log(max(|X|^2, eps)) on the reference's STFT (feature.py:45-82); the reference's
+    own training features come from Lhotse (third-party, unpinned: SURVEY.md 8c).  -> [B,(D,)257,T]."""
+    _, _, re, im = stft(x, frame_len, frame_hop)
+    return torch.log(torch.clamp(re * re + im * im, min=eps))
+
+
 def istft_center(re, im, n_fft=512, hop=256, length=None):
     """torch.istft(center=True, hann, onesided) as used at beamformer.py:83-102.
 

@@ -225,3 +225,35 @@ def test_inference_pipeline_end_to_end():
     # the mask estimator is not bit-identical across batch compositions (~2e-6 mask MSE) and the MVDR
     # solve amplifies that on this random-weight model: a loose consistency bound, not a parity claim
     assert float((w0 - v0).abs().max()) < 5e-2 and float((w1 - v1).abs().max()) < 5e-2
+
+
+def test_on_device_mixer_and_logpower_vs_oracle():
+    """csship_mix_batch (per-chunk delay / pad / sum, 3-tap impulse response, noise at a drawn SNR) and the log-power
+    STFT epilogue vs the oracle's numpy restatement on the SAME drawn parameters; the dataset yields the reference's batch
+    dict, draws new mixtures every step, and trains end to end."""
+    from css_amd import ops
+    from css_amd.datasets import DATASETS
+    ds = DATASETS["OnDeviceMixture"](batch_size=6, frames=60, seed=5, features="logpow", max_utt_frames=200)
+    b = next(ds)
+    assert set(b) == {"mix", "source1", "source2", "lens", "ovl"} and b["mix"].shape == (6, 60, 257) and 0 < b["ovl"] <= 1
+    recs = ds.last_params
+    assert any(r["rir_on"] for r in recs) or any(r["noise_on"] for r in recs)
+    pool, noise = ds.pool.cpu().numpy(), ds.noise.cpu().numpy()
+    params = ops.mix_params(recs).to(DEV)
+    mix, s1, s2 = ops.mix_batch(ds.pool, params, ds.n, noise_pool=ds.noise)
+    for i, r in enumerate(recs):
+        om, o1, o2 = oracle.mixer.mix_chunk(pool, r, ds.n, noise)
+        assert np.array_equal(s1[i].cpu().numpy(), o1) and np.array_equal(s2[i].cpu().numpy(), o2)
+        scale = max(1e-6, float(np.abs(om).max()))
+        assert float(np.abs(mix[i].cpu().numpy() - om).max()) < 2e-5 * scale, (i, r)
+    ref = oracle.feature.log_power(mix.cpu(), eps=1e-10).transpose(1, 2)
+    # log of a power: relative error of the power (2e-5 of the frame's peak power) in absolute log units
+    got = b["mix"].cpu()
+    pw = torch.exp(ref)
+    ok = (got - ref).abs() < 1e-3 + 2e-4 * pw.amax(-1, keepdim=True) / pw
+    assert bool(ok.all())
+    b2 = next(ds)
+    assert not torch.equal(b2["mix"], b["mix"])      # a new draw every step
+    mag = ops.stft(mix, ("mag",))["mag"]
+    lp = ops.stft(mix, ("logpow",), logpow_eps=1e-10)["logpow"]
+    assert torch.allclose(lp, torch.log(torch.clamp(mag * mag, min=1e-10)), rtol=0, atol=2e-3)
