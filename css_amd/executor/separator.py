@@ -3,8 +3,11 @@ mask model running on the HIP path instead of an ONNX session.
 
 Differences from the reference, all stated:
   * ``backend="hip"``: the mask estimator is a css_amd model (``model=`` argument or
-    ``separation_config["model"]``); the reference's ONNX path (third-party runtime, checkpoints not in the
-    repo) is out of scope.  Any batch size is accepted (the ONNX restriction to 1 does not apply).
+    ``separation_config["model"]``).  Any batch size is accepted (the ONNX restriction to 1 does not apply).
+  * ``backend="onnx"``: the reference's session protocol, line by line (separator.py:94-103: features reshaped to
+    ``(1, F, B*T)``, ``session.run``, three mask arrays stacked and reshaped to ``(B, F', T, 3)``), with a
+    ``css_amd.utils.model_util.HipSession`` as the session (onnxruntime and the .onnx checkpoints are third-party
+    artefacts outside the repository).  ``batch_size`` must be 1 as in the reference (:21-24).
   * ``merge`` defaults to False when the key is missing (conf/config_1ch.yaml has none; the reference raises
     KeyError).  With ``merge: True`` (conf/config_7ch.yaml) the DOA-based ``angle_merge`` of
     separator.py:113-250 runs: the likelihood over 30 steering directions is a HIP kernel (csship_doa_likelihood),
@@ -26,11 +29,16 @@ from .feature import FeatureExtractor
 class Separator:
     def __init__(self, separation_config, sr=16000, sess_options=None, device="cuda", backend="hip", lowcut=80,
                  highcut=2000, model=None, fix_merge_indexing=False):
-        if backend != "hip":
+        if backend not in ("hip", "onnx"):
             raise ValueError(f"Unknown backend: {backend}")
+        self.backend = backend
         self.separator = model if model is not None else separation_config.get("model")
         if self.separator is None:
-            raise ValueError("backend='hip' needs a css_amd model (model=... or separation_config['model'])")
+            raise ValueError("the separator needs a css_amd model (model=... or separation_config['model'])")
+        if backend == "onnx":
+            assert separation_config["batch_size"] == 1, "ONNX models only support batch size 1"  # separator.py:21-24
+            from ..utils.model_util import get_onnx_model
+            self.session, _ = get_onnx_model(separation_config.get("model_path"), sess_options, device, model=self.separator)
         self.batch_size = separation_config["batch_size"]
         self.device = device
         self.eval_win = int(separation_config["eval_win"] * sr)
@@ -122,8 +130,28 @@ class Separator:
         ops.lstm_dist_check()  # BLSTM separators: a timed-out recurrence hand-off must not pass as masks
         return masks, mags
 
+    def _separate_one_batch_session(self, s):
+        """separator.py:86-111 through the session interface (the (1, F, B*T) layout of the ONNX models)."""
+        import numpy as np
+        from ..utils.model_util import to_numpy
+        if s.shape[1] == 1 and self.ipd is None:
+            s = s[:, 0]
+        mag_specs, f, re, im = self.feature.forward(s.contiguous())
+        B, F, T = f.shape
+        f = f.reshape(1, F, B * T)
+        ort_inputs = {self.session.get_inputs()[0].name: to_numpy(f)}
+        this_res = self.session.run(None, ort_inputs)
+        masks = torch.Tensor(np.stack((this_res[0], this_res[1], this_res[2]), axis=0))
+        masks = masks.reshape(3, B, -1, T).permute(1, 2, 3, 0).to(self.device)
+        masks = torch.clamp(masks, max=1.0)
+        if self.merge:
+            masks[..., :2] = self.angle_merge(re, im, masks[..., :2].contiguous(), thresh=self.merge_threshold)
+        return masks.contiguous(), mag_specs
+
     def separate_one_batch(self, s):
         """s: [B, D, n] (may be a strided view) -> (masks [B,257,T,3], mag [B,257,T])."""
+        if self.backend == "onnx":
+            return self._separate_one_batch_session(s)
         if s.shape[1] == 1 and self.ipd is None:
             s = s[:, 0]
         # frame-major features: what the mask estimator consumes (the reference's [B, F, T] tensors are produced only

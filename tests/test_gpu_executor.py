@@ -257,3 +257,30 @@ def test_on_device_mixer_and_logpower_vs_oracle():
     mag = ops.stft(mix, ("mag",))["mag"]
     lp = ops.stft(mix, ("logpow",), logpow_eps=1e-10)["logpow"]
     assert torch.allclose(lp, torch.log(torch.clamp(mag * mag, min=1e-10)), rtol=0, atol=2e-3)
+
+
+def test_onnx_layout_session_adapter_matches_hip_backend():
+    """separator.py:94-103 drives its mask model through an onnxruntime session with a (1, F, B*T) input and three
+    mask outputs; HipSession gives a css_amd model that interface.  Same masks as the native backend, window by window
+    (batch size 1, the reference's restriction), and the raw session protocol (names, shapes, dtypes)."""
+    from css_amd.executor import Separator
+    from css_amd.models import MODELS
+    from css_amd.utils.model_util import HipSession
+    conf = dict(attention_dim=256, attention_heads=4, linear_units=1024, num_blocks=1, kernel_size=33,
+                dropout_rate=0.1, relative_pos_emb=True)
+    model = MODELS["Conformer"](257, 257, 2, 1, conf)
+    model.load_state_dict(syn.fill_state_dict(syn.conformer_shapes(num_blocks=1), 5))
+    model = model.to(DEV).eval()
+    cfg = {"batch_size": 1, "eval_win": 2.4, "eval_hop": 0.8, "frame_length": 512, "frame_shift": 256}
+    rec, _ = syn.synthetic_sources(1, 12800 * 2 + 38656, seed=9)   # 3 windows
+    with torch.no_grad():
+        m_hip, g_hip = Separator(cfg, 16000, device=DEV, backend="hip", model=model).separate(rec)
+        m_onx, g_onx = Separator(cfg, 16000, device=DEV, backend="onnx", model=model).separate(rec)
+    assert m_onx.shape == m_hip.shape == (3, 257, 150, 3) and torch.equal(g_hip, g_onx)
+    assert float((m_onx - m_hip).abs().max()) < 1e-5
+    sess = HipSession(model)
+    x = np.random.RandomState(0).rand(1, 257, 150).astype(np.float32)
+    out = sess.run(None, {sess.get_inputs()[0].name: x})
+    assert len(out) == 3 and all(o.shape == (1, 257, 150) and o.dtype == np.float32 for o in out)
+    with pytest.raises(AssertionError):
+        Separator(dict(cfg, batch_size=2), 16000, device=DEV, backend="onnx", model=model)
