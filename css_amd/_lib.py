@@ -150,6 +150,13 @@ SIGNATURES = {
     "csship_mha_relpos_probs_drop": (_i32, [_p, _p, _i32, _i32, _p, _p, _p, _i64, _i32, _i32, _i32, _dc, _p]),
     "csship_attn_softmax_bwd_drop": (_i32, [_p, _p, _p, _i64, _p, _p, _p, _i32, _i32, _i32, _i32, _dc, _p]),
     "csship_convmod_drop": (_i32, [_p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _i32, _p, _dc, _p]),
+    "csship_convmod_sums_offset": (_sz, [_i32, _i32, _i32]),
+    "csship_convmod_stats": (_i32, [_p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _p, _p]),
+    "csship_convmod_finish": (_i32, [_p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, C.c_double, _p, _dc, _p]),
+    "csship_convmod_bwd_sums_offset": (_sz, [_i32, _i32, _i32]),
+    "csship_convmod_bwd_stats": (_i32, [_p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _p, _p, _p, _dc, _p, _sz, _p]),
+    "csship_convmod_bwd_finish": (_i32, [_p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _p, _p, _p, C.c_double, _dc,
+                                         _p, _sz, _p]),
     "csship_convmod_bwd_drop": (_i32, [_p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _dc, _p,
                                         _sz, _p]),
     "csship_conformer_workspace": (_sz, [C.POINTER(ConformerWeights), _i32, _i32]),

@@ -121,13 +121,18 @@ class ConformerTrain(torch.autograd.Function):
         f = f.contiguous()
         wide = D != 256          # size-generic kernels
         batch_bn = model.training
+        from .parallel import is_distributed
+        sync_bn = bool(batch_bn and getattr(model, "sync_batchnorm", False) and is_distributed())
+        if sync_bn and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("SyncBatchNorm all-reduces inside the step: use the eager step, not GraphedTrainStep")
+        M_bn = f.shape[0] * f.shape[1] * (torch.distributed.get_world_size() if sync_bn else 1)
         mean, rinv = ops.mvn_stats(f)
         # dropout (training only): the step's seed is snapshotted so that the backward regenerates the same masks even if
         # another forward runs in between
         ds = model_drop_state(model, getattr(enc, "dropout_rate", 0.0))
         if ds.active:
             ds = DropState(ds.seed.clone(), ds.p, ds.offset)
-        S = {"f": f, "mean": mean, "rinv": rinv, "layers": [], "wide": wide, "batch_bn": batch_bn, "drop": ds}
+        S = {"f": f, "mean": mean, "rinv": rinv, "layers": [], "wide": wide, "batch_bn": batch_bn, "drop": ds, "sync_bn": sync_bn}
         Kp = (F + 7) // 8 * 8
         pack = _conformer_pack_plan(model, wide, f.device)
         pack["plan"].run()
@@ -192,7 +197,7 @@ class ConformerTrain(torch.autograd.Function):
                  "bn_mean": c.BN.running_mean, "bn_var": c.BN.running_var,
                  "pw2_w": c.pw_conv_2.weight.detach().view(1), "pw2_b": c.pw_conv_2.bias.detach()}
             x3, fws = ops.convmod(x2.view(B, T, D), W, K, batch_stats=batch_bn, keep_activations=not batch_bn,
-                                  return_workspace=True, drop=ds.cfg(f"{li}.conv.out"))
+                                  return_workspace=True, drop=ds.cfg(f"{li}.conv.out"), sync=sync_bn)
             x3 = x3.view(M, D)
             L["conv"] = (x2, W, fws)
             if batch_bn:
@@ -208,7 +213,7 @@ class ConformerTrain(torch.autograd.Function):
             with torch.no_grad():
                 torch._foreach_mul_(bn_means + bn_vars, 0.9)
                 torch._foreach_add_(bn_means, bn_new_m, alpha=0.1)
-                torch._foreach_add_(bn_vars, bn_new_v, alpha=0.1 * M / max(M - 1, 1))
+                torch._foreach_add_(bn_vars, bn_new_v, alpha=0.1 * M_bn / max(M_bn - 1, 1))
                 torch._foreach_add_(bn_cnt, 1)
         n_out = model.linear.out_features
         wh_bf, wh_p = pack["wh_bf"], pack["wh_p"]
@@ -276,7 +281,7 @@ class ConformerTrain(torch.autograd.Function):
             x2, W, fws = L["conv"]
             c = lay.conv
             dx3, g = ob.convmod_bwd(x2.view(B, T, D), dx.view(B, T, D), W, fws, enc.kernel_size,
-                                    bn_eval=not S["batch_bn"], drop=ds.cfg(f"{li}.conv.out"))
+                                    bn_eval=not S["batch_bn"], drop=ds.cfg(f"{li}.conv.out"), sync=S["sync_bn"])
             dx = dx3.view(M, D)
             put(c.layer_norm.weight, g["ln_g"]), put(c.layer_norm.bias, g["ln_b"])
             put(c.pw_conv_1.weight, g["pw1_w"]), put(c.pw_conv_1.bias, g["pw1_b"])

@@ -223,6 +223,43 @@ __global__ __launch_bounds__(1024) void bn_reduce_kernel(const float* __restrict
   }
 }
 
+// SyncBN split of bn_reduce_kernel: (1) partials -> per-channel sums (f64: sum z | sum z^2 over this rank's rows), which the
+// caller all-reduces across ranks; (2) global sums + global row count -> scale / shift / mean / var
+__global__ __launch_bounds__(1024) void bn_sums_kernel(const float* __restrict__ partial, int nblk, int D,
+                                                       double* __restrict__ sums) {
+  __shared__ double red[2][16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  double s = 0.0, q = 0.0;
+  if (c < D)
+    for (int i = w; i < nblk; i += 16) {
+      s += (double)partial[(size_t)i * 2 * D + c];
+      q += (double)partial[(size_t)i * 2 * D + D + c];
+    }
+  red[0][w][lane] = s;
+  red[1][w][lane] = q;
+  __syncthreads();
+  if (w == 0 && c < D) {
+    s = q = 0.0;
+    for (int i = 0; i < 16; ++i) { s += red[0][i][lane]; q += red[1][i][lane]; }
+    sums[c] = s;
+    sums[D + c] = q;
+  }
+}
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ sums, double count, int D,
+                                                          const float* __restrict__ bn_g, const float* __restrict__ bn_b,
+                                                          float* __restrict__ scale_shift) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= D) return;
+  const double mu = sums[c] / count;
+  const double var = fmax(sums[D + c] / count - mu * mu, 0.0);
+  const float sc = bn_g[c] * (float)(1.0 / sqrt(var + 1e-5));
+  scale_shift[c] = sc;
+  scale_shift[D + c] = bn_b[c] - (float)mu * sc;
+  scale_shift[2 * D + c] = (float)mu;
+  scale_shift[3 * D + c] = (float)var;
+}
+
 // bn_mode 2: scale / shift / mean / var from the RUNNING statistics, in the layout bn_reduce_kernel produces, so the
 // backward (and bn_apply) read one format
 __global__ __launch_bounds__(256) void bn_from_running_kernel(const float* __restrict__ bn_g, const float* __restrict__ bn_b,
@@ -256,9 +293,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   reinterpret_cast<float4*>(y)[i] = make_float4(xv.x + br.x, xv.y + br.y, xv.z + br.z, xv.w + br.w);
 }
 
+// phase 0: the whole module; SyncBN (bn_mode 1 only): phase 1 = convolution + this rank's channel sums (f64 [2D] behind the
+// scale/shift block of the workspace), phase 2 = statistics from the (all-reduced) sums and `total_rows`, then apply
 template <int D, int TT>
 int run(const ConvArgs& a0, int bn_mode, void* workspace, hipStream_t s,
-        csship_dropout_cfg dcfg = csship_dropout_cfg{nullptr, 0u, 0.f}) {
+        csship_dropout_cfg dcfg = csship_dropout_cfg{nullptr, 0u, 0.f}, int phase = 0, double total_rows = 0.0) {
   ConvArgs a = a0;
   dim3 grid((a.T + TT - 1) / TT, a.B);
   if (bn_mode == 0) {
@@ -272,10 +311,21 @@ int run(const ConvArgs& a0, int bn_mode, void* workspace, hipStream_t s,
   const int nblk = grid.x * grid.y * 2;  // two half-tiles per workgroup
   a.zbuf = reinterpret_cast<float*>(workspace);
   a.partial = a.zbuf + n;
-  float* scale_shift = a.partial + (size_t)nblk * 2 * D;
-  hipLaunchKernelGGL((convmod_kernel<D, TT, 33, 1, false>), grid, dim3(2 * D), 0, s, a);
-  CSSHIP_CHECK_LAUNCH();
-  if (bn_mode == 2)
+  double* sums = reinterpret_cast<double*>(a.partial + (size_t)nblk * 2 * D);  // f64 [2D] (SyncBN); statistics stay LAST
+  float* scale_shift = a.partial + (size_t)nblk * 2 * D + 4 * D;
+  if (phase != 2) {
+    hipLaunchKernelGGL((convmod_kernel<D, TT, 33, 1, false>), grid, dim3(2 * D), 0, s, a);
+    CSSHIP_CHECK_LAUNCH();
+  }
+  if (phase == 1) {
+    hipLaunchKernelGGL(bn_sums_kernel, dim3((D + 63) / 64), dim3(1024), 0, s, a.partial, nblk, D, sums);
+    CSSHIP_CHECK_LAUNCH();
+    return CSSHIP_OK;
+  }
+  if (phase == 2)
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((D + 255) / 256), dim3(256), 0, s, sums, total_rows, D, a.w.bn_g, a.w.bn_b,
+                       scale_shift);
+  else if (bn_mode == 2)
     hipLaunchKernelGGL(bn_from_running_kernel, dim3((D + 255) / 256), dim3(256), 0, s, a.w.bn_g, a.w.bn_b, a.w.bn_mean,
                        a.w.bn_var, D, scale_shift);
   else
@@ -472,33 +522,45 @@ BwdLayout bwd_layout(int B, int T, int D, int TT) {
   L.nblk = ((T + TT - 1) / TT) * B * 2;
   const size_t p = (size_t)L.nwg_rows * (2 * D + 4) > (size_t)L.nblk * 34 * D ? (size_t)L.nwg_rows * (2 * D + 4)
                                                                              : (size_t)L.nblk * 34 * D;
-  L.dc = 0; L.dg = n; L.part = 2 * n; L.sums = 2 * n + p; L.total = L.sums;
+  L.dc = 0; L.dg = n; L.part = 2 * n; L.sums = 2 * n + p; L.total = L.sums + 2 * (size_t)D;  // sums: S1 | S2 for the apply pass
   return L;
 }
 
 template <int D, int TT>
+// phase 0: everything; SyncBN: phase 1 = pass A (+ this rank's S1 | S2 copied to the workspace's sums block, which the
+// caller all-reduces), phase 2 = the rest with those sums and the GLOBAL row count
 int run_bwd(const float* x, const float* dy, const csship_conv_weights& w, int B, int T, const float* fwd_ws, float* dx,
-            float* grads, float* ws, int bn_eval, hipStream_t s, csship_dropout_cfg dcfg) {
+            float* grads, float* ws, int bn_eval, hipStream_t s, csship_dropout_cfg dcfg, int phase = 0,
+            double total_rows = 0.0) {
   const BwdLayout L = bwd_layout(B, T, D, TT);
   const int64_t M = (int64_t)B * T;
   const size_t n = (size_t)M * D;
   const float* z = fwd_ws;
   const int fwd_nblk = ((T + TT - 1) / TT) * B * 2;
-  const float* stats = fwd_ws + n + (size_t)fwd_nblk * 2 * D;
+  const float* stats = fwd_ws + n + (size_t)fwd_nblk * 2 * D + 4 * D;
   float *dc = ws + L.dc, *dg = ws + L.dg, *part = ws + L.part;
   // grads layout (CSSHIP_CONV_GRADS_*): [bn_b D | bn_g D | pw2_w 1 | pw2_b 1 | pad 2][dw_w 33*D | dw_b D][ln_g D | ln_b D | pw1_w 2 | pw1_b 2]
   float* gA = grads;
   float* gB = grads + 2 * D + 4;
   float* gC = gB + 34 * D;
-  // pass A
-  hipLaunchKernelGGL((conv_bn_bwd_stats_kernel<D>), dim3(L.nwg_rows), dim3(D), 0, s, dy, z, stats, w.pw2_w, M, BWD_ROWS, part, dcfg);
-  CSSHIP_CHECK_LAUNCH();
-  int rc = launch_slab_reduce(part, L.nwg_rows, 2 * D + 2, 2 * D + 2, 2 * D + 2, 1.f, nullptr, nullptr, 0, gA, s);
-  if (rc) return rc;
+  float* sums = ws + L.sums;
+  int rc = 0;
+  if (phase != 2) {
+    // pass A
+    hipLaunchKernelGGL((conv_bn_bwd_stats_kernel<D>), dim3(L.nwg_rows), dim3(D), 0, s, dy, z, stats, w.pw2_w, M, BWD_ROWS, part, dcfg);
+    CSSHIP_CHECK_LAUNCH();
+    rc = launch_slab_reduce(part, L.nwg_rows, 2 * D + 2, 2 * D + 2, 2 * D + 2, 1.f, nullptr, nullptr, 0, gA, s);
+    if (rc) return rc;
+    if (phase == 1) {
+      if (hipMemcpyAsync(sums, gA, 2 * (size_t)D * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return CSSHIP_ELAUNCH;
+      return CSSHIP_OK;
+    }
+  }
   // pass A'
   // running statistics are constants of the graph: no mean / projection terms (1/n -> 0)
-  hipLaunchKernelGGL(conv_bn_bwd_apply_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, dy, z, stats, gA,
-                     w.pw2_w, bn_eval ? 0.f : 1.f / (float)M, n / 4, D, dc, dcfg);
+  hipLaunchKernelGGL(conv_bn_bwd_apply_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, dy, z, stats,
+                     phase == 2 ? sums : gA, w.pw2_w, bn_eval ? 0.f : 1.f / (float)(phase == 2 ? total_rows : (double)M), n / 4,
+                     D, dc, dcfg);
   CSSHIP_CHECK_LAUNCH();
   // pass B1 / B2 on the forward's tile structure
   dim3 grid((T + TT - 1) / TT, B);
@@ -522,7 +584,13 @@ int run_bwd(const float* x, const float* dy, const csship_conv_weights& w, int B
 extern "C" size_t csship_convmod_workspace(int32_t B, int32_t T, int32_t D) {
   const int TT = D == 256 ? TT256 : TT512;
   const size_t nblk = (size_t)((T + TT - 1) / TT) * B * 2;
-  return ((size_t)B * T * D + nblk * 2 * D + 4 * (size_t)D) * sizeof(float);
+  return ((size_t)B * T * D + nblk * 2 * D + 4 * (size_t)D + 4 * (size_t)D) * sizeof(float);  // f64 [2D] sums (SyncBN), then stats
+}
+
+extern "C" size_t csship_convmod_sums_offset(int32_t B, int32_t T, int32_t D) {
+  const int TT = D == 256 ? TT256 : TT512;
+  const size_t nblk = (size_t)((T + TT - 1) / TT) * B * 2;
+  return ((size_t)B * T * D + nblk * 2 * D) * sizeof(float);
 }
 
 extern "C" int csship_convmod(const float* x, float* y, const csship_conv_weights* w, int32_t B, int32_t T,
@@ -551,6 +619,36 @@ extern "C" int csship_convmod_drop(const float* x, float* y, const csship_conv_w
   return run<512, TT512>(a, bn_mode, workspace, as_stream(stream), dc);
 }
 
+extern "C" int csship_convmod_stats(const float* x, const csship_conv_weights* w, int32_t B, int32_t T, int32_t D,
+                                    int32_t kernel_size, void* workspace, csship_stream_t stream) {
+  if (!x || !w || !workspace) return CSSHIP_ENULL;
+  if (!w->ln_g || !w->ln_b || !w->pw1_w || !w->pw1_b || !w->dw_w || !w->dw_b) return CSSHIP_ENULL;
+  if (B <= 0 || T <= 0 || B > 65535) return CSSHIP_EBADSHAPE;
+  if (kernel_size != 33 || (D != 256 && D != 512)) return CSSHIP_EUNSUPPORTED;
+  if (!aligned16(x) || !aligned16(workspace)) return CSSHIP_EALIGN;
+  ConvArgs a{x, nullptr, *w, nullptr, nullptr, nullptr, nullptr, B, T, nullptr};
+  const csship_dropout_cfg none{nullptr, 0u, 0.f};
+  if (D == 256) return run<256, TT256>(a, 1, workspace, as_stream(stream), none, 1);
+  return run<512, TT512>(a, 1, workspace, as_stream(stream), none, 1);
+}
+
+extern "C" int csship_convmod_finish(const float* x, float* y, const csship_conv_weights* w, int32_t B, int32_t T, int32_t D,
+                                     double total_rows, void* workspace, const csship_dropout_cfg* drop,
+                                     csship_stream_t stream) {
+  if (!x || !y || !w || !workspace) return CSSHIP_ENULL;
+  if (!w->bn_g || !w->bn_b || !w->pw2_w || !w->pw2_b) return CSSHIP_ENULL;
+  if (B <= 0 || T <= 0 || B > 65535 || !(total_rows >= (double)B * T)) return CSSHIP_EBADSHAPE;
+  if (D != 256 && D != 512) return CSSHIP_EUNSUPPORTED;
+  if (x == y) return CSSHIP_EBADSHAPE;
+  if (!aligned16(x) || !aligned16(y) || !aligned16(workspace)) return CSSHIP_EALIGN;
+  const bool dropping = drop && drop->seed && drop->p > 0.f;
+  if (dropping && (int64_t)B * T * D > 0xffffffffLL) return CSSHIP_EBADSHAPE;
+  ConvArgs a{x, y, *w, nullptr, nullptr, nullptr, nullptr, B, T, nullptr};
+  const csship_dropout_cfg dc = dropping ? *drop : csship_dropout_cfg{nullptr, 0u, 0.f};
+  if (D == 256) return run<256, TT256>(a, 1, workspace, as_stream(stream), dc, 2, total_rows);
+  return run<512, TT512>(a, 1, workspace, as_stream(stream), dc, 2, total_rows);
+}
+
 extern "C" int csship_conv_from_glu(const float* x, const float* g, float* y, const csship_conv_weights* w, int32_t B,
                                     int32_t T, int32_t D, int32_t kernel_size, csship_stream_t stream) {
   if (!x || !g || !y || !w) return CSSHIP_ENULL;
@@ -575,10 +673,44 @@ extern "C" int csship_convmod_bwd(const float* x, const float* dy, const csship_
                                  workspace_bytes, stream);
 }
 
+static int convmod_bwd_impl(const float* x, const float* dy, const csship_conv_weights* w, int32_t B, int32_t T, int32_t D,
+                            int32_t kernel_size, const void* fwd_workspace, float* dx, float* grads, int32_t bn_eval,
+                            const csship_dropout_cfg* drop, void* workspace, size_t workspace_bytes, csship_stream_t stream,
+                            int phase, double total_rows);
+
 extern "C" int csship_convmod_bwd_drop(const float* x, const float* dy, const csship_conv_weights* w, int32_t B, int32_t T,
                                        int32_t D, int32_t kernel_size, const void* fwd_workspace, float* dx,
                                        float* grads, int32_t bn_eval, const csship_dropout_cfg* drop, void* workspace,
                                        size_t workspace_bytes, csship_stream_t stream) {
+  return convmod_bwd_impl(x, dy, w, B, T, D, kernel_size, fwd_workspace, dx, grads, bn_eval, drop, workspace, workspace_bytes,
+                          stream, 0, 0.0);
+}
+
+extern "C" size_t csship_convmod_bwd_sums_offset(int32_t B, int32_t T, int32_t D) {
+  return bwd_layout(B, T, D, D == 256 ? TT256 : TT512).sums * sizeof(float);
+}
+
+extern "C" int csship_convmod_bwd_stats(const float* x, const float* dy, const csship_conv_weights* w, int32_t B, int32_t T,
+                                        int32_t D, int32_t kernel_size, const void* fwd_workspace, float* dx, float* grads,
+                                        const csship_dropout_cfg* drop, void* workspace, size_t workspace_bytes,
+                                        csship_stream_t stream) {
+  return convmod_bwd_impl(x, dy, w, B, T, D, kernel_size, fwd_workspace, dx, grads, 0, drop, workspace, workspace_bytes, stream,
+                          1, 0.0);
+}
+
+extern "C" int csship_convmod_bwd_finish(const float* x, const float* dy, const csship_conv_weights* w, int32_t B, int32_t T,
+                                         int32_t D, int32_t kernel_size, const void* fwd_workspace, float* dx, float* grads,
+                                         double total_rows, const csship_dropout_cfg* drop, void* workspace,
+                                         size_t workspace_bytes, csship_stream_t stream) {
+  if (!(total_rows >= (double)B * T)) return CSSHIP_EBADSHAPE;
+  return convmod_bwd_impl(x, dy, w, B, T, D, kernel_size, fwd_workspace, dx, grads, 0, drop, workspace, workspace_bytes, stream,
+                          2, total_rows);
+}
+
+static int convmod_bwd_impl(const float* x, const float* dy, const csship_conv_weights* w, int32_t B, int32_t T, int32_t D,
+                            int32_t kernel_size, const void* fwd_workspace, float* dx, float* grads, int32_t bn_eval,
+                            const csship_dropout_cfg* drop, void* workspace, size_t workspace_bytes, csship_stream_t stream,
+                            int phase, double total_rows) {
   const bool dropping = drop && drop->seed && drop->p > 0.f;
   if (dropping && (int64_t)B * T * D > 0xffffffffLL) return CSSHIP_EBADSHAPE;
   const csship_dropout_cfg dc = dropping ? *drop : csship_dropout_cfg{nullptr, 0u, 0.f};
@@ -591,6 +723,6 @@ extern "C" int csship_convmod_bwd_drop(const float* x, const float* dy, const cs
   if (workspace_bytes < csship_convmod_bwd_workspace(B, T, D)) return CSSHIP_EWORKSPACE;
   const float* fw = reinterpret_cast<const float*>(fwd_workspace);
   float* ws = reinterpret_cast<float*>(workspace);
-  if (D == 256) return run_bwd<256, TT256>(x, dy, *w, B, T, fw, dx, grads, ws, bn_eval, as_stream(stream), dc);
-  return run_bwd<512, TT512>(x, dy, *w, B, T, fw, dx, grads, ws, bn_eval, as_stream(stream), dc);
+  if (D == 256) return run_bwd<256, TT256>(x, dy, *w, B, T, fw, dx, grads, ws, bn_eval, as_stream(stream), dc, phase, total_rows);
+  return run_bwd<512, TT512>(x, dy, *w, B, T, fw, dx, grads, ws, bn_eval, as_stream(stream), dc, phase, total_rows);
 }

@@ -270,10 +270,13 @@ def conv_weights_struct(t):
     return cw
 
 
-def convmod(x, weights, kernel_size=33, batch_stats=False, return_workspace=False, keep_activations=False, drop=None):
+def convmod(x, weights, kernel_size=33, batch_stats=False, return_workspace=False, keep_activations=False, drop=None,
+            sync=False):
     """x f32 [B,T,D] -> x + ConvModule(x).  weights: dict for conv_weights_struct.
     return_workspace (batch_stats only): also return the workspace the backward needs (pre-BN activations; its last
-    4*D floats are scale | shift | batch mean | biased batch variance)."""
+    4*D floats are scale | shift | batch mean | biased batch variance).
+    sync (batch_stats only; SyncBatchNorm, train.py:70): the statistics are those of all ranks' rows - two launches
+    with an all-reduce of the per-channel f64 sums in between; every rank must hold the same B*T."""
     _need(x, torch.float32, "x")
     x = x.contiguous()
     B, T, D = x.shape
@@ -283,6 +286,15 @@ def convmod(x, weights, kernel_size=33, batch_stats=False, return_workspace=Fals
     mode = 1 if batch_stats else (2 if keep_activations else 0)  # 2: running statistics, activations kept for the backward
     if mode:
         ws = torch.empty(lib().csship_convmod_workspace(B, T, D), device=x.device, dtype=torch.uint8)
+    if sync and batch_stats:
+        from .parallel import allreduce_sum_
+        import torch.distributed as dist
+        check(lib().csship_convmod_stats(_ptr(x), C.byref(cw), B, T, D, kernel_size, _ptr(ws), _stream()))
+        off = lib().csship_convmod_sums_offset(B, T, D)
+        allreduce_sum_(ws[off:off + 16 * D].view(torch.float64))
+        check(lib().csship_convmod_finish(_ptr(x), _ptr(y), C.byref(cw), B, T, D, float(B * T * dist.get_world_size()),
+                                          _ptr(ws), drop, _stream()))
+        return (y, ws) if return_workspace else y
     check(lib().csship_convmod_drop(_ptr(x), _ptr(y), C.byref(cw), B, T, D, kernel_size, mode,
                                     _ptr(ws), drop, _stream()))
     return (y, ws) if return_workspace else y

@@ -171,7 +171,7 @@ def relpos_softmax_bwd(p, dp, T, W):
     return ds, dsk
 
 
-def convmod_bwd(x, dy, weights, fwd_ws, kernel_size=33, bn_eval=False, drop=None):
+def convmod_bwd(x, dy, weights, fwd_ws, kernel_size=33, bn_eval=False, drop=None, sync=False):
     """Backward of ops.convmod(x, weights, batch_stats=True) (or keep_activations=True with bn_eval=True).  x, dy f32 [B,T,D]; fwd_ws: that call's workspace.
     Returns dx and a dict of f32 gradients keyed like the weights dict (dw_w as [k, D])."""
     from .ops import conv_weights_struct
@@ -183,8 +183,17 @@ def convmod_bwd(x, dy, weights, fwd_ws, kernel_size=33, bn_eval=False, drop=None
     dx = torch.empty_like(x)
     nws = lib().csship_convmod_bwd_workspace(B, T, D)
     ws = _workspace(nws, x.device)
-    check(lib().csship_convmod_bwd_drop(_ptr(x), _ptr(dy), C.byref(cw), B, T, D, kernel_size, _ptr(fwd_ws), _ptr(dx),
-                                        _ptr(flat), int(bn_eval), drop, _ptr(ws), nws, _stream()))
+    if sync and not bn_eval:  # SyncBatchNorm: the two channel sums of the BN input gradient are over all ranks' rows
+        from .parallel import allreduce_sum_
+        import torch.distributed as dist
+        args = (_ptr(x), _ptr(dy), C.byref(cw), B, T, D, kernel_size, _ptr(fwd_ws), _ptr(dx), _ptr(flat))
+        check(lib().csship_convmod_bwd_stats(*args, drop, _ptr(ws), nws, _stream()))
+        off = lib().csship_convmod_bwd_sums_offset(B, T, D)
+        allreduce_sum_(ws[off:off + 8 * D].view(torch.float32))
+        check(lib().csship_convmod_bwd_finish(*args, float(B * T * dist.get_world_size()), drop, _ptr(ws), nws, _stream()))
+    else:
+        check(lib().csship_convmod_bwd_drop(_ptr(x), _ptr(dy), C.byref(cw), B, T, D, kernel_size, _ptr(fwd_ws), _ptr(dx),
+                                            _ptr(flat), int(bn_eval), drop, _ptr(ws), nws, _stream()))
     o = 2 * D + 4
     grads = {"bn_b": flat[:D], "bn_g": flat[D:2 * D], "pw2_w": flat[2 * D:2 * D + 1], "pw2_b": flat[2 * D + 1:2 * D + 2],
              "dw_w": flat[o:o + kernel_size * D].view(kernel_size, D), "dw_b": flat[o + 33 * D:o + 34 * D],

@@ -110,6 +110,28 @@ def allreduce_flat(flat, average=True, buckets=1, async_handles=None):
         flat /= world
 
 
+def allreduce_sum_(t):
+    """In-place SUM all-reduce of a small tensor inside a step (SyncBatchNorm statistics)."""
+    if not is_distributed():
+        return t
+    if t.is_cuda and dist.get_backend() == "gloo":  # rehearsal backend: staged through host memory
+        host = t.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def convert_sync_batchnorm(model):
+    """css_amd's form of nn.SyncBatchNorm.convert_sync_batchnorm (reference train.py:70): the BatchNorm modules stay
+    what they are (parameter containers); the training forward / backward of the conv module all-reduce the batch
+    statistics across ranks (ops.convmod(sync=True)).  Needs the eager step: collectives are not captured into the
+    GraphedTrainStep graphs."""
+    model.sync_batchnorm = True
+    return model
+
+
 def allreduce_segment(flat, lo, hi, handles, average=True):
     """Asynchronous all-reduce of flat[lo:hi] (a bucket whose gradients are final while the backward pass is still
     producing the rest).  Averaging for backends without AVG happens in ``wait_all``."""

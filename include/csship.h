@@ -310,6 +310,18 @@ int csship_convmod_drop(const float* x, float* y, const csship_conv_weights* w, 
                         int32_t D, int32_t kernel_size, int32_t bn_mode, void* workspace,
                         const csship_dropout_cfg* drop, csship_stream_t stream);
 
+/* SyncBatchNorm (train.py:70 convert_sync_batchnorm) as two calls with the caller's all-reduce in between:
+ *   csship_convmod_stats  : LayerNorm .. depthwise conv, pre-BN activations kept; this rank's per-channel sums land as
+ *                           f64 [2D] = (sum z | sum z^2) at byte csship_convmod_sums_offset() of the workspace;
+ *   (caller: all-reduce SUM of those 2D doubles over the ranks; total_rows = sum of B*T over the ranks)
+ *   csship_convmod_finish : statistics from the reduced sums, then BN + ReLU + pw2 + dropout + residual as above.
+ * After finish the workspace's last 4*D floats are [scale | shift | mean | biased var] of the GLOBAL batch. */
+size_t csship_convmod_sums_offset(int32_t B, int32_t T, int32_t D);
+int csship_convmod_stats(const float* x, const csship_conv_weights* w, int32_t B, int32_t T, int32_t D,
+                         int32_t kernel_size, void* workspace, csship_stream_t stream);
+int csship_convmod_finish(const float* x, float* y, const csship_conv_weights* w, int32_t B, int32_t T, int32_t D,
+                          double total_rows, void* workspace, const csship_dropout_cfg* drop, csship_stream_t stream);
+
 /* Back half of the conv module from a precomputed g = glu(LayerNorm_conv(x)) (csship_outproj_glu):
  *   y = x + pw2( relu( BN_eval( dwconv_k(g) ) ) ).  x, g, y: f32 [B, T, D]; y may alias x (x is read
  * row-locally) but not g (neighbouring tiles read halo rows of g). */
@@ -555,6 +567,20 @@ int csship_convmod_bwd_drop(const float* x, const float* dy, const csship_conv_w
                             int32_t D, int32_t kernel_size, const void* fwd_workspace, float* dx,
                             float* grads, int32_t bn_eval, const csship_dropout_cfg* drop, void* workspace,
                             size_t workspace_bytes, csship_stream_t stream);
+
+/* SyncBatchNorm backward, split like the forward: _stats leaves this rank's S1 = sum dy_bn and S2 = sum dy_bn * zhat
+ * (f32 [2D]) at byte csship_convmod_bwd_sums_offset() of `workspace`; the caller all-reduces them (SUM); _finish uses
+ * them with 1 / total_rows in the BatchNorm input gradient.  bn_g / bn_b gradients in `grads` are this rank's share
+ * (the usual gradient all-reduce completes them).  Same workspace for both calls. */
+size_t csship_convmod_bwd_sums_offset(int32_t B, int32_t T, int32_t D);
+int csship_convmod_bwd_stats(const float* x, const float* dy, const csship_conv_weights* w, int32_t B, int32_t T,
+                             int32_t D, int32_t kernel_size, const void* fwd_workspace, float* dx, float* grads,
+                             const csship_dropout_cfg* drop, void* workspace, size_t workspace_bytes,
+                             csship_stream_t stream);
+int csship_convmod_bwd_finish(const float* x, const float* dy, const csship_conv_weights* w, int32_t B, int32_t T,
+                              int32_t D, int32_t kernel_size, const void* fwd_workspace, float* dx, float* grads,
+                              double total_rows, const csship_dropout_cfg* drop, void* workspace,
+                              size_t workspace_bytes, csship_stream_t stream);
 
 /* Weight shadows for one Linear in ONE launch: f32 w[R, K] (row stride ld_w), every element times `scale`, written
  * as bf16 row-major rows dst_row0.. of a [.., ld_row_major] matrix (optional; the kmajor operand of csship_bgemm)

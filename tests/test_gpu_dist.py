@@ -75,6 +75,64 @@ gathered = [torch.zeros_like(p_g.cpu()) for _ in range(ws)]
 dist.all_gather(gathered, p_g.cpu())
 ok = ok and all(torch.equal(gathered[0], g) for g in gathered)
 print(f"rank {rank}: graphed == eager {torch.equal(p_e, p_g)}, ranks identical {all(torch.equal(gathered[0], g) for g in gathered)}", flush=True)
+# (3) SyncBatchNorm: train mode (batch statistics), dropout off; two ranks x 2 windows with the statistics all-reduced
+# == one process on the 4 concatenated windows: loss, averaged gradient and running statistics
+def build_nodrop():
+    mm = build(); mm.conformer.dropout_rate = 0.0
+    return mm.train()
+m = parallel.convert_sync_batchnorm(build_nodrop())
+opt = FusedAdam(m.parameters(), lr=1e-3, max_norm=0.0)
+opt.zero_grad(); l_sync = obj(m, batch(5, rank), device=DEV); l_sync.backward(); parallel.allreduce_flat(opt.flat_grad)
+l_mean = parallel.allreduce_sum_(l_sync.detach().clone().reshape(1)) / ws
+ref = build_nodrop()
+opt_r = FusedAdam(ref.parameters(), lr=1e-3, max_norm=0.0)
+opt_r.zero_grad()
+shards = [batch(5, r) for r in range(ws)]
+big = {k: torch.cat([sh[k] for sh in shards]) for k in ("mix", "source1", "source2")}; big["ovl"] = 0.5
+l_big = obj(ref, big, device=DEV); l_big.backward()
+err = float((opt.flat_grad - opt_r.flat_grad).norm() / opt_r.flat_grad.norm())
+bn, bn_r = m.conformer.encoders[0].conv.BN, ref.conformer.encoders[0].conv.BN
+err_rm = float((bn.running_mean - bn_r.running_mean).abs().max()); err_rv = float((bn.running_var - bn_r.running_var).abs().max() / bn_r.running_var.abs().max())
+# and WITHOUT the switch the per-rank statistics give a different gradient (the test has power)
+m2 = build_nodrop(); o2 = FusedAdam(m2.parameters(), lr=1e-3, max_norm=0.0)
+o2.zero_grad(); obj(m2, batch(5, rank), device=DEV).backward(); parallel.allreduce_flat(o2.flat_grad)
+err_nosync = float((o2.flat_grad - opt_r.flat_grad).norm() / opt_r.flat_grad.norm())
+# the operator itself (f32 throughout): shards with sync == the concatenated batch without
+from css_amd import ops, ops_bwd as ob
+Dm = 256
+Wc = {"ln_g": 1 + 0.1 * rnd((Dm,), 1), "ln_b": 0.1 * rnd((Dm,), 2), "pw1_w": rnd((2,), 3), "pw1_b": 0.1 * rnd((2,), 4),
+      "dw_w": 0.2 * rnd((33, Dm), 5), "dw_b": 0.1 * rnd((Dm,), 6), "bn_g": 1 + 0.1 * rnd((Dm,), 7), "bn_b": 0.1 * rnd((Dm,), 8),
+      "bn_mean": torch.zeros(Dm), "bn_var": torch.ones(Dm), "pw2_w": rnd((1,), 9), "pw2_b": 0.1 * rnd((1,), 10)}
+Wc = {k: v.to(DEV) for k, v in Wc.items()}
+xs = [rnd((3, 50, Dm), 40 + r).to(DEV) for r in range(ws)]; dys = [rnd((3, 50, Dm), 50 + r).to(DEV) for r in range(ws)]
+y_s, fws_s = ops.convmod(xs[rank], Wc, 33, batch_stats=True, return_workspace=True, sync=True)
+dx_s, g_s = ob.convmod_bwd(xs[rank], dys[rank], Wc, fws_s, 33, sync=True)
+y_b, fws_b = ops.convmod(torch.cat(xs), Wc, 33, batch_stats=True, return_workspace=True)
+dx_b, g_b = ob.convmod_bwd(torch.cat(xs), torch.cat(dys), Wc, fws_b, 33)
+lo = 3 * rank
+e_y = float((y_s - y_b[lo:lo + 3]).abs().max()); e_dx = float((dx_s - dx_b[lo:lo + 3]).abs().max() / dx_b.abs().max())
+e_g, e_k = 0.0, {}
+for k in g_b:
+    gs = parallel.allreduce_sum_(g_s[k].clone())
+    # d dw_b is zero in exact arithmetic (BatchNorm removes the channel mean): measured against d dw_w's scale
+    e_k[k] = float((gs - g_b[k]).abs().max() / ((g_b["dw_w"] if k == "dw_b" else g_b[k]).abs().max() + 1e-20))
+    e_g = max(e_g, e_k[k])
+op_ok = e_y < 1e-4 and e_dx < 1e-4 and e_g < 1e-4
+ok = ok and op_ok
+print(f"rank {rank}: SyncBN conv module vs concatenated: y {e_y:.1e} dx {e_dx:.1e} grads {e_g:.1e} " + " ".join(f"{k}:{v:.0e}" for k, v in e_k.items()), flush=True)
+# noise floor of "2 x 2 windows vs 4 windows" with nothing to synchronise (frozen BatchNorm): launch shapes differ with M
+# (tiles, split-K of the weight gradients), so bf16 roundings fall differently
+fz = build().eval(); fz.eval_gradients = True; fz.conformer.dropout_rate = 0.0
+of = FusedAdam(fz.parameters(), lr=1e-3, max_norm=0.0)
+of.zero_grad(); obj(fz, big, device=DEV).backward(); g_big = of.flat_grad.clone()
+of.zero_grad()
+for sh in shards:
+    (obj(fz, sh, device=DEV) / ws).backward()
+err_floor = float((of.flat_grad - g_big).norm() / g_big.norm())
+good = err < 8 * err_floor and abs(float(l_mean) - float(l_big)) < 1e-4 * abs(float(l_big)) and err_rm < 1e-5 and err_rv < 1e-4 and err_nosync > 5 * err
+ok = ok and good
+print(f"rank {rank}: SyncBN gradient vs concatenated batch: rel err {err:.2e} (unsynced {err_nosync:.2e}, frozen-BN floor {err_floor:.2e}), loss {float(l_mean):.6f} vs {float(l_big):.6f}, "
+      f"running mean/var err {err_rm:.1e}/{err_rv:.1e}", flush=True)
 dist.barrier()
 dist.destroy_process_group()
 sys.exit(0 if ok else 3)
