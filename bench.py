@@ -260,12 +260,17 @@ def main():
         if was_training:
             model.train()
         M = B * T
-        traffic = {}
+        traffic, mfma_busy = {}, {}
         for tp in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tp)
             if os.path.exists(tpath):
                 for name, rec in json.load(open(tpath)).items():
                     traffic.setdefault(name, rec["hbm_bytes_per_launch"])
+                    if rec.get("mfma_busy_frac") is not None:
+                        mfma_busy.setdefault(name, rec["mfma_busy_frac"])
+
+        def busy_of(prefix):  # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch duration x 2.4 GHz), committed PMC pass
+            return next((v for name, v in mfma_busy.items() if name.startswith(prefix)), None)
 
         def traffic_of(prefix):
             for name, v in traffic.items():
@@ -280,6 +285,7 @@ def main():
                 "kernel": f"chain_kernel<8,0,1,1,1> (FFN_out+LN -> FFN_in -> LN+QKV, M=12800; {nl} launches/step)",
                 "achieved": flops / dur / 1e12 if dur else None, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                 "frac": flops / dur / PEAK_BF16 if dur else None, "traffic": traffic_of("chain_kernel<8, false, true, true, true>"),
+                "mfma_busy_pmc": busy_of("chain_kernel<8, false, true, true, true>"),
                 "avg_launch_us": dur * 1e6, "flops_per_launch": flops, "timing": "HIP events around the in-step launches",
                 "whole_step_frac": (step_flops * (3.0 if args.mode == "train" else 1.0)) / (dt / args.steps) / PEAK_BF16}
         ad, an = tl["attention"]
@@ -287,7 +293,7 @@ def main():
         roof["attention"] = {"bound": "mfma", "kernel": f"mha_fwd_kernel<8> ({an} launches/step)",
                              "achieved": aflops / ad / 1e12 if ad else None, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                              "frac": aflops / ad / PEAK_BF16 if ad else None, "avg_launch_us": ad * 1e6,
-                             "traffic": traffic_of("mha_fwd_kernel")}
+                             "traffic": traffic_of("mha_fwd_kernel"), "mfma_busy_pmc": busy_of("mha_fwd_kernel")}
         od, on = tl["outproj_conv"]
         oflops = 2.0 * M * 256 * 256 + 2.0 * M * 256 * 33  # output projection + depthwise taps (halo excluded)
         roof["outproj_conv"] = {"bound": "mixed", "kernel": f"outproj_conv_kernel ({on} launches/step)",
