@@ -44,7 +44,8 @@ constexpr int PD = 4;  // weight prefetch distance in k-steps (ring of PD fragme
 #define P_T(i)
 #endif
 #ifndef P_ABL
-#define P_ABL 0  // diagnostic builds only: bit 0 no weight loads in the k-loop, bit 1 no MFMAs, bit 2 no LDS operand reads
+#define P_ABL 0  // diagnostic builds only: bit 0 no weight loads in the k-loop, bit 1 no MFMAs, bit 2 no LDS operand reads,
+                 // bit 3 no qkv stores, bit 4 no x stores, bit 5 no hidden-bias loads (chain kernel)
 #endif
 
 // acc[t][rt] += W(tile0+t)[16 x 256] . panel^T[256 x 16 rows of tile rt]
@@ -787,7 +788,8 @@ DEV void ffn_stage(float4 (&v)[8], unsigned char* Xs, unsigned char* Hraw, const
     f32x4 h[NT][4];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {  // the bias is the accumulators' initial value
-      const float4 bb = *reinterpret_cast<const float4*>(f.b1 + c * DM + (wave * NT + t) * 16 + 4 * g);
+      const float4 bb = (P_ABL & 32) ? make_float4(0.f, 0.f, 0.f, 0.f)
+                                     : *reinterpret_cast<const float4*>(f.b1 + c * DM + (wave * NT + t) * 16 + 4 * g);
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) h[t][rt] = f32x4{bb.x, bb.y, bb.z, bb.w};
     }
@@ -964,7 +966,7 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(ChainArgs a) {
   P_T(4)
   if constexpr (HAS_B) ffn_stage<NW, false>(v, Xs, Hraw, a.fb, nullptr, nullptr, a.FF, a.alpha, tid, blockIdx.x + 2, a.stamps, 5);
   P_T(8)
-  if (row < a.M) {  // the residual stream the attention output projection adds to
+  if (row < a.M && !(P_ABL & 16)) {  // the residual stream the attention output projection adds to
 #pragma unroll
     for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(a.xout + (size_t)row * DM + (i * 8 + part) * 4) = v[i];
   }
@@ -1000,7 +1002,7 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(ChainArgs a) {
 #pragma unroll
           for (int rt = 0; rt < 4; ++rt) {
             const int orow = m0 + rt * 16 + n;
-            if (orow < a.M)
+            if (orow < a.M && (!(P_ABL & 8) || acc[t][rt][0] == 123.456f))
               *reinterpret_cast<uint2*>(a.qkv + (size_t)orow * a.NQKV + f) =
                   make_uint2(pack_bf2(acc[t][rt][0], acc[t][rt][1]), pack_bf2(acc[t][rt][2], acc[t][rt][3]));
           }
@@ -1008,6 +1010,297 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(ChainArgs a) {
       }
     }
     P_T(10)
+  }
+}
+
+// =============================================================================== chain, second form
+// NOT the default (csship_encoder_chain runs it with CSSHIP_CHAIN=8 or 4): it is 8 % slower than the first form, and
+// is kept as the measured counter-example to "the row phases and barriers are what is slow" - tools/chain2_stamps.py.
+// What the stamps of both forms say instead: a 256-wide pass over a 64-row panel needs 128 KB of weight fragments
+// through the CU's L1 (64 B/clk -> 2 048 cycles), 8 waves x 4 KB of LDS operand reads per k-step (128 B/clk -> 2 048
+// cycles per pass) and 2 048 cycles of MFMA on each SIMD: all three at their peak at once, so the passes run at
+// ~3 000 cycles whatever is done around them.  The accumulator-layout LayerNorm of this form costs MORE VALU than the
+// row form (4 row reductions per lane instead of 1), and with 4 waves (half the LDS operand traffic) a single wave per
+// SIMD cannot cover its own load latencies.
+//
+// Same operator chain, re-laid out after the phase stamps of the first form (tools/chain_stamps.py: of 93 600 cycles per
+// workgroup 39 000 are MFMA; 23 000 sat in the row phases - park the accumulators in LDS, barrier, read rows back, LayerNorm,
+// write the panel - and 18 000 in the hidden epilogues + barriers between the W1 and W2 passes):
+//   * the residual rows never leave the ACCUMULATOR layout (lane = one token row per row tile, 4 consecutive features of each
+//     of the wave's 2 feature tiles): the FFN output is added in registers, and LayerNorm needs only the per-row (mean, M2) of
+//     the wave's 32 features (in-lane sums + 2 permlane swaps), an 8-byte-per-row exchange between the 8 waves through LDS
+//     and Chan's combination - no fp32 staging tile, no row read-back;
+//   * the W1 pass of chunk c+1 runs BEFORE the barrier that publishes the hidden panel of chunk c (three hidden panels in
+//     rotation), so that barrier finds the stores long retired and every wave arriving together.  Weight streams therefore
+//     run W1(c0) W1(c1) W2(c0) W1(c2) W2(c1) ... through the same prefetch ring.
+constexpr int C2_STAT_BYTES = 8 * BM * 8;  // [<= 8 waves][64 rows] (mean, M2)
+
+DEV uint2 relu_pack4(const f32x4& h) { return make_uint2(relu_bf2(pack_bf2(h[0], h[1])), relu_bf2(pack_bf2(h[2], h[3]))); }
+
+// hidden epilogue: ReLU + bf16 pack of a wave's accumulators -> operand panel of the W2 pass
+template <int NT>
+DEV void store_hidden(unsigned char* hs, const f32x4 (&h)[NT][4], int hcol0, int n) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int hc = hcol0 + t * 16;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+      *reinterpret_cast<uint2*>(hs + panel_off(rt * 16 + n, hc >> 3) + (hc & 7) * 2) = relu_pack4(h[t][rt]);
+  }
+}
+
+#ifdef P_STAMPS
+#define P_T2(i) if (sbase >= 0) { P_T(sbase + (i)) }
+#else
+#define P_T2(i)
+#endif
+// per-row LayerNorm statistics of rows held in accumulator layout; contains ONE workgroup barrier
+template <int NT>
+DEV void acc_row_stats(const f32x4 (&v)[NT][4], float2* stat, int wave, int g, int n, float (&mean)[4], float (&rstd)[4],
+                       unsigned long long* g_stamps_dev = nullptr, int sbase = -1) {
+  P_T2(0)
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) s += (v[t][rt][0] + v[t][rt][1]) + (v[t][rt][2] + v[t][rt][3]);
+    const float m = rows_sum4(s) * (1.f / (16 * NT));
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float d0 = v[t][rt][0] - m, d1 = v[t][rt][1] - m, d2 = v[t][rt][2] - m, d3 = v[t][rt][3] - m;
+      q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    q = rows_sum4(q);
+    if (g == 0) stat[wave * BM + rt * 16 + n] = make_float2(m, q);
+  }
+  P_T2(1)
+  __syncthreads();
+  P_T2(2)
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    constexpr int NW = 16 / NT;
+    float2 e[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) e[w] = stat[w * BM + rt * 16 + n];
+    float mu = 0.f, m2 = 0.f, dev = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { mu += e[w].x; m2 += e[w].y; }
+    mu *= 1.f / NW;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) dev += (e[w].x - mu) * (e[w].x - mu);
+    mean[rt] = mu;
+    rstd[rt] = rsqrtf((m2 + (16.f * NT) * dev) * (1.f / DM) + 1e-5f);
+  }
+  P_T2(3)
+}
+
+// LayerNorm of the accumulator-layout rows; PANEL: bf16 operand panel in LDS, else in place
+template <bool PANEL, int NT>
+DEV void acc_layernorm(f32x4 (&v)[NT][4], unsigned char* panel, float2* stat, const float4 (&gm)[NT], const float4 (&bt)[NT],
+                       int wave, int g, int n, unsigned long long* g_stamps_dev = nullptr, int sbase = -1) {
+  float mean[4], rstd[4];
+  acc_row_stats<NT>(v, stat, wave, g, n, mean, rstd, g_stamps_dev, sbase);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int col = (wave * NT + t) * 16 + 4 * g;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const float y0 = (v[t][rt][0] - mean[rt]) * rstd[rt] * gm[t].x + bt[t].x;
+      const float y1 = (v[t][rt][1] - mean[rt]) * rstd[rt] * gm[t].y + bt[t].y;
+      const float y2 = (v[t][rt][2] - mean[rt]) * rstd[rt] * gm[t].z + bt[t].z;
+      const float y3 = (v[t][rt][3] - mean[rt]) * rstd[rt] * gm[t].w + bt[t].w;
+      if constexpr (PANEL)
+        *reinterpret_cast<uint2*>(panel + panel_off(rt * 16 + n, col >> 3) + (col & 7) * 2) =
+            make_uint2(pack_bf2(y0, y1), pack_bf2(y2, y3));
+      else
+        v[t][rt] = f32x4{y0, y1, y2, y3};
+    }
+  }
+  P_T2(4)
+}
+
+template <int NT, bool FINAL_LN>
+DEV void ffn2_stage(f32x4 (&v)[NT][4], unsigned char* Xs, unsigned char* Hs, float2* stat0, float2* stat1, const FfnW& f,
+                    const float* fin_g, const float* fin_b, int FF, float alpha, int tid, int rot,
+                    unsigned long long* g_stamps_dev = nullptr, int st0 = 0) {
+  const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15;
+  const int nchunk = FF / DM, ks2 = FF / 32;
+  const int fcol = wave * NT * 16 + 4 * g;  // this lane's first feature (tile t adds 16)
+  const bf16x8* w1s = f.w1 + (size_t)(wave * NT) * KS * 64 + lane;
+  const bf16x8* w2s = f.w2 + (size_t)(wave * NT) * ks2 * 64 + lane;
+  int c = rot % nchunk;
+  bf16x8 wq[PD][NT];
+  prefetch_first<NT>(wq, w1s + (size_t)c * 16 * KS * 64, KS, NT);
+  float4 gm[NT], bt[NT], bias[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    gm[t] = *reinterpret_cast<const float4*>(f.ln_g + fcol + t * 16);
+    bt[t] = *reinterpret_cast<const float4*>(f.ln_b + fcol + t * 16);
+    bias[t] = *reinterpret_cast<const float4*>(f.b1 + c * DM + fcol + t * 16);
+  }
+  acc_layernorm<true, NT>(v, Xs, stat0, gm, bt, wave, g, n, g_stamps_dev, st0 == 4 ? 10 : -1);  // its barrier: every wave is past the previous stage's passes
+  __syncthreads();
+  P_T(st0 + 0)
+  f32x4 o[NT][4], h[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      o[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      h[t][rt] = f32x4{bias[t].x, bias[t].y, bias[t].z, bias[t].w};  // the bias is the accumulators' initial value
+    }
+  {
+    const int c1 = (c + 1) % nchunk;
+    const bf16x8* nxt = nchunk > 1 ? w1s + (size_t)c1 * 16 * KS * 64 : w2s + (size_t)c * KS * 64;
+    if (nchunk > 1) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bias[t] = *reinterpret_cast<const float4*>(f.b1 + c1 * DM + fcol + t * 16);
+    }
+    mma_pass<NT>(h, Xs, n, g, NT, w1s + (size_t)c * 16 * KS * 64, KS, nxt, nchunk > 1 ? KS : ks2, NT, wq);
+    store_hidden<NT>(Hs, h, fcol, n);
+  }
+#ifdef P_STAMPS
+  unsigned long long tq_[5] = {0, 0, 0, 0, 0};
+#define P_Q(i) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tq_[i])::"memory"); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define P_Q(i)
+#endif
+  int slot = 0;  // hidden panel of chunk ci (three in rotation)
+  for (int ci = 0; ci < nchunk; ++ci) {
+    const int c1 = (c + 1) % nchunk, c2 = (c + 2) % nchunk;
+    const int slot1 = slot == 2 ? 0 : slot + 1;
+    const bf16x8* w2c = w2s + (size_t)c * KS * 64;
+    if (ci + 1 < nchunk) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) h[t][rt] = f32x4{bias[t].x, bias[t].y, bias[t].z, bias[t].w};
+      if (ci + 2 < nchunk) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bias[t] = *reinterpret_cast<const float4*>(f.b1 + c2 * DM + fcol + t * 16);
+      }
+      P_Q(0)
+      mma_pass<NT>(h, Xs, n, g, NT, w1s + (size_t)c1 * 16 * KS * 64, KS, w2c, ks2, NT, wq);
+      P_Q(1)
+      // panel slot1 was last read by the W2 pass of chunk ci-2: every wave finished that before the barrier of ci-1
+      store_hidden<NT>(Hs + slot1 * PANEL_BYTES, h, fcol, n);
+    }
+    P_Q(2)
+    __syncthreads();
+    P_Q(3)
+    const bf16x8* nxt = w2c;
+    int nstride = ks2, nnt = 0;
+    if (ci + 2 < nchunk) { nxt = w1s + (size_t)c2 * 16 * KS * 64; nstride = KS; nnt = NT; }
+    else if (ci + 1 < nchunk) { nxt = w2s + (size_t)c1 * KS * 64; nnt = NT; }
+    mma_pass<NT>(o, Hs + slot * PANEL_BYTES, n, g, NT, w2c, ks2, nxt, nstride, nnt, wq);
+    P_Q(4)
+#ifdef P_STAMPS
+    if (st0 == 1 && ci == 1 && g_stamps_dev != nullptr && (threadIdx.x & 63) == 0 && (wave == 0 || wave == 7)) {
+      unsigned long long* d_ = g_stamps_dev + (size_t)blockIdx.x * 32 + 16 + (wave == 7 ? 5 : 0);
+      for (int i_ = 0; i_ < 5; ++i_) d_[i_] = tq_[i_];
+    }
+#endif
+    c = c1;
+    slot = slot1;
+  }
+  P_T(st0 + 1)
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const float4 b2 = *reinterpret_cast<const float4*>(f.b2 + fcol + t * 16);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      v[t][rt][0] += alpha * (o[t][rt][0] + b2.x); v[t][rt][1] += alpha * (o[t][rt][1] + b2.y);
+      v[t][rt][2] += alpha * (o[t][rt][2] + b2.z); v[t][rt][3] += alpha * (o[t][rt][3] + b2.w);
+    }
+  }
+  if constexpr (FINAL_LN) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      gm[t] = *reinterpret_cast<const float4*>(fin_g + fcol + t * 16);
+      bt[t] = *reinterpret_cast<const float4*>(fin_b + fcol + t * 16);
+    }
+    acc_layernorm<false, NT>(v, nullptr, stat1, gm, bt, wave, g, n);
+  }
+  P_T(st0 + 2)
+}
+
+template <int NW, bool HAS_A, bool HAS_B, bool HAS_C>
+__global__ __launch_bounds__(NW * 64) void chain2_kernel(ChainArgs a) {
+  constexpr int NT = 16 / NW;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * PANEL_BYTES + 2 * C2_STAT_BYTES];
+  unsigned char* const Xs = smem;
+  unsigned char* const Hs = smem + PANEL_BYTES;
+  float2* const stat0 = reinterpret_cast<float2*>(smem + 4 * PANEL_BYTES);
+  float2* const stat1 = stat0 + 8 * BM;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15;
+  const int m0 = blockIdx.x * BM, fcol = wave * NT * 16 + 4 * g;
+  f32x4 v[NT][4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    const float* xr = a.x + (size_t)min(m0 + rt * 16 + n, a.M - 1) * DM + fcol;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) v[t][rt] = *reinterpret_cast<const f32x4*>(xr + t * 16);
+  }
+#ifdef P_STAMPS
+  unsigned long long* const g_stamps_dev = a.stamps;
+#endif
+  P_T(0)
+  if constexpr (HAS_A)
+    ffn2_stage<NT, true>(v, Xs, Hs, stat0, stat1, a.fa, a.fin_g, a.fin_b, a.FF, a.alpha, tid, blockIdx.x, a.stamps, 1);
+  if constexpr (HAS_B)
+    ffn2_stage<NT, false>(v, Xs, Hs, stat0, stat1, a.fb, nullptr, nullptr, a.FF, a.alpha, tid, blockIdx.x + 2, a.stamps, 4);
+  if constexpr (HAS_C) {
+    const int ntiles = (a.NQKV + 15) / 16, npass = (ntiles + 15) / 16;
+    bf16x8 wq[PD][NT];
+    const bf16x8* wbase = a.wqkv + lane;
+    prefetch_first<NT>(wq, wbase + (size_t)(wave * NT) * KS * 64, KS, max(0, min(NT, ntiles - wave * NT)));
+    float4 gm[NT], bt[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      gm[t] = *reinterpret_cast<const float4*>(a.qln_g + fcol + t * 16);
+      bt[t] = *reinterpret_cast<const float4*>(a.qln_b + fcol + t * 16);
+    }
+    acc_layernorm<true, NT>(v, Xs, stat0, gm, bt, wave, g, n);
+    __syncthreads();
+    P_T(7)
+    for (int p = 0; p < npass; ++p) {
+      const int tile0 = p * 16 + wave * NT;
+      const int nt = max(0, min(NT, ntiles - tile0));
+      const int nnt = max(0, min(NT, ntiles - (tile0 + 16)));
+      f32x4 acc[NT][4];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float4 bb = load_bias4(a.bqkv, (tile0 + t) * 16 + 4 * g, a.NQKV);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[t][rt] = f32x4{bb.x, bb.y, bb.z, bb.w};
+      }
+      const bf16x8* wc = wbase + (size_t)tile0 * KS * 64;
+      mma_pass<NT>(acc, Xs, n, g, nt, wc, KS, wc + (size_t)16 * KS * 64, KS, nnt, wq);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int f = (tile0 + t) * 16 + 4 * g;
+        if (t < nt && f + 3 < a.NQKV) {  // NQKV % 8 == 0 (checked on the host)
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) {
+            const int orow = m0 + rt * 16 + n;
+            if (orow < a.M)
+              *reinterpret_cast<uint2*>(a.qkv + (size_t)orow * a.NQKV + f) =
+                  make_uint2(pack_bf2(acc[t][rt][0], acc[t][rt][1]), pack_bf2(acc[t][rt][2], acc[t][rt][3]));
+          }
+        }
+      }
+    }
+    P_T(8)
+  }
+  // the residual stream the attention output projection adds to (last: nothing in this kernel waits behind these stores)
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    const int orow = m0 + rt * 16 + n;
+    if (orow < a.M) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(a.xout + (size_t)orow * DM + fcol + t * 16) = v[t][rt];
+    }
   }
 }
 
@@ -1468,6 +1761,20 @@ extern "C" int csship_encoder_chain(const float* x, float* x_out, const float* c
   if (Cq) { a.qln_g = qkv_ln_g; a.qln_b = qkv_ln_b; a.wqkv = reinterpret_cast<const bf16x8*>(wqkv_packed); a.bqkv = bqkv; a.qkv = qkv_out; }
   dim3 grid((M + BM - 1) / BM), block(NWAVES * 64);
   hipStream_t s = as_stream(stream);
+  // CSSHIP_CHAIN=8 / 4 run the second form of the kernel (8 or 4 waves) for A/B timing; measured at M = 12 800:
+  // first form 50.1 us, second form 54.0 us (8 waves), 61.4 us (4 waves) - see the note above chain2_kernel
+  static const int form = [] { const char* e = getenv("CSSHIP_CHAIN"); return e ? atoi(e) : 1; }();
+  if (form != 1 && !CV && (A || Bs)) {
+#define C2_LAUNCH(W)                                                                                            \
+  if (A && Bs && Cq) hipLaunchKernelGGL((chain2_kernel<W, true, true, true>), grid, dim3(W * 64), 0, s, a);      \
+  else if (!A && Bs && Cq) hipLaunchKernelGGL((chain2_kernel<W, false, true, true>), grid, dim3(W * 64), 0, s, a); \
+  else if (A && !Bs && !Cq) hipLaunchKernelGGL((chain2_kernel<W, true, false, false>), grid, dim3(W * 64), 0, s, a); \
+  else return CSSHIP_EUNSUPPORTED;
+    if (form == 8) { C2_LAUNCH(8) } else { C2_LAUNCH(4) }
+#undef C2_LAUNCH
+    CSSHIP_CHECK_LAUNCH();
+    return CSSHIP_OK;
+  }
   if (!CV && A && Bs && Cq) hipLaunchKernelGGL((chain_kernel<NWAVES, false, true, true, true>), grid, block, 0, s, a);
   else if (!CV && !A && Bs && Cq) hipLaunchKernelGGL((chain_kernel<NWAVES, false, false, true, true>), grid, block, 0, s, a);
   else if (!CV && A && !Bs && !Cq) hipLaunchKernelGGL((chain_kernel<NWAVES, false, true, false, false>), grid, block, 0, s, a);

@@ -266,9 +266,22 @@ def test_encoder_chain(ops):
     r1 = ops.ffn_fused(d(x), fa[0], fa[1], fa[2], fa[3], fa[4], 1024, 0.5, final_ln=fin)
     r2 = ops.ffn_fused(r1, fb[0], fb[1], fb[2], fb[3], fb[4], 1024, 0.5)
     rq = ops.panel_linear(r2, wq, bq, 768, ln=qln, out_bf16=True)
-    assert err(xo, r2) < 1e-3        # same arithmetic; hidden-chunk rotation differs between the kernels
+    # the two paths round differently (hidden-chunk rotation, LayerNorm statistics combined across waves): they agree to
+    # bf16-operand noise, and against a float64 evaluation of the same chain the fused kernel is no further off
+    assert err(xo, r2) < 5e-3
     assert err(qkv.float(), rq.float()) < 6e-2  # bf16 outputs of O(4) values: one ulp = 3e-2
     assert float(((qkv.float() - rq.float()) ** 2).mean()) < 1e-5
+
+    def ffn64(v, seed, fin_ln=None):
+        g, b = (1 + 0.1 * rnd((256,), seed)).double(), (0.1 * rnd((256,), seed + 1)).double()
+        w1, b1 = bf(rnd((1024, 256), seed + 2, 1 / 16)).double(), rnd((1024,), seed + 3, 0.1).double()
+        w2, b2 = bf(rnd((256, 1024), seed + 4, 1 / 32)).double(), rnd((256,), seed + 5, 0.1).double()
+        a = torch.nn.functional.layer_norm(v, (256,), g, b)
+        v = v + 0.5 * (torch.relu(a @ w1.t() + b1) @ w2.t() + b2)
+        return torch.nn.functional.layer_norm(v, (256,), fin_ln[0].double().cpu(), fin_ln[1].double().cpu()) if fin_ln else v
+    x64 = ffn64(ffn64(x.double(), 120, fin), 130)
+    e_fused, e_sep = err(xo, x64), err(r2, x64)
+    assert e_fused < 1.5 * e_sep + 1e-3, (e_fused, e_sep)
 
 
 # ----------------------------------------------------------------------------- attention
