@@ -152,6 +152,25 @@ model.zero_grad(); torch.nn.functional.mse_loss(model(data[lo:hi]), tgt[lo:hi]).
 flat = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
 parallel.allreduce_flat(flat, average=True)
 ok = ok and torch.allclose(flat, torch.cat([r.reshape(-1) for r in ref]), atol=1e-6)
+# bucketed (chunks issued back to back), asynchronous (handles waited for later) and per-segment forms; SyncBN-style sum
+want = torch.cat([r.reshape(-1) for r in ref])
+def fresh():
+    model.zero_grad(); torch.nn.functional.mse_loss(model(data[lo:hi]), tgt[lo:hi]).backward()
+    return torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+f3 = fresh(); parallel.allreduce_flat(f3, average=True, buckets=3)
+ok = ok and torch.allclose(f3, want, atol=1e-6)
+fa, hs = fresh(), []
+parallel.allreduce_flat(fa, average=True, buckets=2, async_handles=hs)
+ok = ok and len(hs) == 2
+parallel.wait_all(hs, fa, average=True)
+ok = ok and torch.allclose(fa, want, atol=1e-6)
+fs, hs = fresh(), []
+mid = fs.numel() // 2 // 4 * 4
+parallel.allreduce_segment(fs, mid, fs.numel(), hs); parallel.allreduce_segment(fs, 0, mid, hs)   # last block first
+parallel.wait_all(hs, fs, average=True)
+ok = ok and torch.allclose(fs, want, atol=1e-6)
+t = torch.full((5,), float(rank + 1), dtype=torch.float64)
+ok = ok and torch.equal(parallel.allreduce_sum_(t), torch.full((5,), 3.0, dtype=torch.float64))
 # window gather
 local = torch.arange(lo, hi, dtype=torch.float32)[:, None].repeat(1, 3)
 full = parallel.gather_windows(local, 8, rank, ws)

@@ -25,4 +25,9 @@ with torch.no_grad():
         masks = m.forward_masks(f); loss = ops.pit_mse(masks, f, tg)[0]
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
 flop = B * T * 212.8e6 * a.blocks / 18
+import json
+print(json.dumps({"metric": "STFT-frames/sec (fwd+PIT) Conformer-large", "value": B * T / dt, "unit": "frames/s", "ms_per_step": dt * 1e3,
+                  "dtype": "bf16", "config": {"workload": f"config 5: d_model 512, 8 heads, ffn 2048, {a.blocks} blocks, 3 spk + noise, 32x400",
+                  "fp8": "bf16 by measured necessity: MXFP8 operands give mask MSE 3.1e-3 (FFN only) .. 1.4e-2 (all Linears) against the "
+                         "1e-4 budget on this configuration (tools/mxfp8_budget.py --large, profiles/r02_mxfp8_budget_large.txt)"}}))
 print(f"Conformer-large {a.blocks} blocks, 32x400: {dt*1e3:.2f} ms/step = {B*T/dt/1e6:.3f} M frames/s, {flop/dt/1e12:.0f} TFLOP/s algorithmic, loss {float(loss):.4f}")
