@@ -400,8 +400,7 @@ class BlstmTrain(torch.autograd.Function):
             put(lay.layer_norm.weight, dg), put(lay.layer_norm.bias, dbeta)
             dgates = ob.lstm_bidir_bwd(L["gates"], L["c"], dy.view(B, T, h), L["whhT_p"])
             dg2 = dgates.view(M, 8 * H)
-            dwih = ob.bgemm(dg2, L["x"], a_kmajor=True, b_kmajor=True)       # [8H, h]
-            dbias = ob.colsum(dg2)
+            dwih, dbias = ob.linear_wgrad(dg2, L["x"])                        # [8H, h], [8H]
             dx = ob.bgemm(dg2, L["w_ih_bf"], b_kmajor=True)                   # [M, h]
             yp = torch.zeros_like(y)                                          # h_{t-1} of each direction
             yp[:, 1:, :H] = y[:, :-1, :H]

@@ -14,8 +14,7 @@ BF = torch.bfloat16
 
 def linear_bwd(dy, x, w_bf, *, need_dx=True, dx_bf16=False, alpha=1.0):
     """y = x @ w^T + b.  dy: [M, N] f32/bf16, x: [M, K] f32/bf16, w_bf: bf16 [N, K] -> (dx, dw, db)."""
-    dw = ob.bgemm(dy, x, a_kmajor=True, b_kmajor=True, alpha=alpha)
-    db = ob.colsum(dy, alpha)
+    dw, db = ob.linear_wgrad(dy, x, alpha)
     dx = ob.bgemm(dy, w_bf, b_kmajor=True, alpha=alpha, out_bf16=dx_bf16) if need_dx else None
     return dx, dw, db
 
@@ -38,15 +37,13 @@ def ffn_bwd(x, dy, ln_g, ln_b, b1, w1_bf, w2_bf, alpha=0.5, drop_hidden=None, dr
         h = ops.dropout_apply(ops.gemm(a, w1_bf, b1, relu=True), drop_hidden).to(BF)
         dyb = ops.dropout_apply(dy, drop_out, out=torch.empty_like(dy))
         sc = 65536.0 / (65536 - int(drop_hidden.contents.p * 65536.0 + 0.5))
-        dw2 = ob.bgemm(dyb, h, a_kmajor=True, b_kmajor=True, alpha=alpha)
-        db2 = ob.colsum(dyb, alpha)
+        dw2, db2 = ob.linear_wgrad(dyb, h, alpha)
         dh = ob.bgemm(dyb, w2_bf, b_kmajor=True, alpha=alpha * sc, mask_pos=h, out_bf16=True)
         da, dw1, db1 = linear_bwd(dh, a, w1_bf)
         dx, dg, dbeta = ob.layernorm_bwd(x, da, ln_g, ln_b, dx_add=dy)
         return dx, (dg, dbeta, dw1, db1, dw2, db2)
     h = ops.gemm(a, w1_bf, b1, relu=True, out_bf16=True)
-    dw2 = ob.bgemm(dy, h, a_kmajor=True, b_kmajor=True, alpha=alpha)
-    db2 = ob.colsum(dy, alpha)
+    dw2, db2 = ob.linear_wgrad(dy, h, alpha)
     dh = ob.bgemm(dy, w2_bf, b_kmajor=True, alpha=alpha, mask_pos=h, out_bf16=True)
     da, dw1, db1 = linear_bwd(dh, a, w1_bf)
     dx, dg, dbeta = ob.layernorm_bwd(x, da, ln_g, ln_b, dx_add=dy)
@@ -59,13 +56,10 @@ def ffn_bwd_fused(x, dy, ln_g, ln_b, b1, w1p, w2tp, w1tp, d_ffn, alpha=0.5, drop
     the B*T rows.  w1p / w2tp / w1tp: fragment-packed W1, W2^T, W1^T."""
     dx, dg, dbeta, a, h, dh, dyd = ob.ffn_bwd(x, dy, ln_g, ln_b, w1p, b1, w2tp, w1tp, d_ffn, alpha, drop_hidden, drop_out)
     if dyd is not None:   # output dropout: the second Linear saw h (dropped) and its gradient is alpha * dy o mask / (1 - p)
-        dw2 = ob.bgemm(dyd, h, a_kmajor=True, b_kmajor=True)
-        db2 = ob.colsum(dyd)
+        dw2, db2 = ob.linear_wgrad(dyd, h)
     else:
-        dw2 = ob.bgemm(dy, h, a_kmajor=True, b_kmajor=True, alpha=alpha)
-        db2 = ob.colsum(dy, alpha)
-    dw1 = ob.bgemm(dh, a, a_kmajor=True, b_kmajor=True)
-    db1 = ob.colsum(dh)
+        dw2, db2 = ob.linear_wgrad(dy, h, alpha)
+    dw1, db1 = ob.linear_wgrad(dh, a)
     return dx, (dg, dbeta, dw1, db1, dw2, db2)
 
 
@@ -147,10 +141,8 @@ def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_s
     a, _ = ops.layernorm(x, ln_g, ln_b)
     dw = torch.empty((3 * D, D), dtype=torch.float32, device=x.device)
     db = torch.empty(3 * D, dtype=torch.float32, device=x.device)
-    ob.bgemm(dq2[:, :D], a, a_kmajor=True, b_kmajor=True, alpha=q_scale, out=dw[:D])
-    ob.bgemm(dq2[:, D:], a, a_kmajor=True, b_kmajor=True, out=dw[D:])
-    db[:D] = ob.colsum(dq2[:, :D], q_scale)
-    db[D:] = ob.colsum(dq2[:, D:])
+    ob.linear_wgrad(dq2[:, :D], a, q_scale, dw_out=dw[:D], db_out=db[:D])
+    ob.linear_wgrad(dq2[:, D:], a, 1.0, dw_out=dw[D:], db_out=db[D:])
     da = ob.bgemm(dq2, wqkv_bf, b_kmajor=True)
     dx, dg, dbeta = ob.layernorm_bwd(x, da, ln_g, ln_b, dx_add=dy)
     return dx, (dg, dbeta, dw, db, dwo, dbo, dpe)
@@ -164,5 +156,5 @@ def embed_bwd(f, dy, mean, rinv, w_bf_pad, bias, ln_g, ln_b, e=None):
     if e is None:
         e = ob.bgemm(fn, w_bf_pad, bias=bias)                            # pre-LN activations, recomputed
     de, dg, dbeta = ob.layernorm_bwd(e, dy, ln_g, ln_b, relu=True)
-    dw = ob.bgemm(de, fn, a_kmajor=True, b_kmajor=True)[:, :F]
-    return dw, ob.colsum(de), dg, dbeta
+    dw, db = ob.linear_wgrad(de, fn)
+    return dw[:, :F], db, dg, dbeta

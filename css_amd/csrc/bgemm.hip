@@ -29,6 +29,9 @@ struct BgemmArgs {
   int64_t sA1, sA2, sB1, sB2, sC1, sC2, sX1, sX2, slab;
   int a_f32, b_f32, epi;
   float alpha;
+  // COLSUM kernels (weight gradients): column sums of the kmajor A operand (= the bias gradient of the same Linear)
+  float* cs_out;   // [M], alpha applied (splits == 1)
+  float* cs_slab;  // [splits][M] partial sums (splits > 1), reduced with the C slabs
 };
 
 constexpr int BK = 64;
@@ -184,7 +187,9 @@ __device__ unsigned* g_bg_stamps = nullptr;
 #define STAMP(i) do {} while (0)
 #endif
 // FAST: whole 8-element groups and operands below 4 GB -> descriptor loads with compile-time operand types.
-template <bool A_KM, bool B_KM, bool FAST, bool A_F32, bool B_F32>
+// COLSUM: the workgroups of the first tile column also sum the A operand over the reduction index with one more MFMA
+// per A fragment against a fragment of ones (D[n][m] = sum_k 1 * A[k][m]: every row of the result is the column sum).
+template <bool A_KM, bool B_KM, bool FAST, bool A_F32, bool B_F32, bool COLSUM = false>
 __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -242,6 +247,13 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 cs[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) cs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_cs = COLSUM && bx == 0 && wn == 0;  // wave-uniform
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
   if (nk > 0) {
     load_tile(kbeg);
@@ -279,6 +291,14 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);  // C^T tile
+    if constexpr (COLSUM) {
+      if (do_cs) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[ks][i], cs[i], 0, 0, 0);
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
     if (kt < 12) STAMP(4 + kt * 5);  // MFMAs issued
     if (kt + 1 < nk) {
@@ -297,6 +317,18 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
   // a lane owns FOUR CONSECUTIVE COLUMNS of one row per (i, j) and stores them as one 16-byte (f32) / 8-byte (bf16)
   // piece.  With one element per store the epilogue of a K = 512 product cost as much as its main loop (1 300 VALU
   // instructions of address arithmetic and 64 store instructions per lane against 256 MFMAs).
+  if constexpr (COLSUM) {
+    if (do_cs && lg == 0) {  // rows 0..3 of the 16 x 16 result are all the column sum: lane ln of the first row group stores it
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + ln;
+        if (m < g.M) {
+          if (g.splits > 1) g.cs_slab[(int64_t)split * g.M + m] = cs[i][0];
+          else g.cs_out[m] = g.alpha * cs[i][0];
+        }
+      }
+    }
+  }
   const int64_t coff = z1 * g.sC1 + z2 * g.sC2 + (int64_t)split * g.slab;
   const int64_t xo = z1 * g.sX1 + z2 * g.sX2;
   const bool to_slab = g.splits > 1;
@@ -390,11 +422,18 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
 template <int V, int NW, int U>
 __global__ __launch_bounds__(64 * NW) void slab_reduce_kernel(const float* __restrict__ slabs, int S, int64_t n, int N,
                                                               int64_t ldc, float alpha, const float* __restrict__ bias,
-                                                              const float* add, int64_t ldadd, float* out) {
+                                                              const float* add, int64_t ldadd, float* out, int nb_main,
+                                                              const float* __restrict__ slabs2, int64_t n2,
+                                                              float* __restrict__ out2) {
   typedef float vec __attribute__((ext_vector_type(V)));
   __shared__ vec red[NW][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t i = ((int64_t)blockIdx.x * 64 + lane) * V;
+  int bid = blockIdx.x;
+  if (bid >= nb_main) {  // second, short output reduced by the same launch (the bias gradient next to its weight gradient)
+    bid -= nb_main;
+    slabs = slabs2; n = n2; N = (int)n2; ldc = n2; bias = nullptr; add = nullptr; out = out2;
+  }
+  const int64_t i = ((int64_t)bid * 64 + lane) * V;
   vec s[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) s[u] = 0.f;
@@ -480,21 +519,32 @@ int pick_splits(const csship_bgemm_params* p) {
 
 }  // namespace
 
-int launch_slab_reduce(const float* slabs, int S, int64_t n, int N, int64_t ldc, float alpha, const float* bias,
-                       const float* add, int64_t ldadd, float* out, hipStream_t s) {
+// slabs2 / n2 / out2 (optional): a second output of n2 elements with the same S and alpha, reduced by the same launch
+static int launch_slab_reduce2(const float* slabs, int S, int64_t n, int N, int64_t ldc, float alpha, const float* bias,
+                               const float* add, int64_t ldadd, float* out, const float* slabs2, int64_t n2, float* out2,
+                               hipStream_t s) {
   // long outputs: 16-byte loads, 4 waves per 256 elements; short outputs with many slabs (bias / LayerNorm partials): 16
   // waves share the slabs of 64 elements
-  if ((N & 3) == 0 && (n & 3) == 0 && n >= 4096 && aligned16(slabs))
-    hipLaunchKernelGGL((slab_reduce_kernel<4, 4, 4>), dim3((unsigned)((n / 4 + 63) / 64)), dim3(256), 0, s, slabs, S, n, N, ldc,
-                       alpha, bias, add, ldadd, out);
-  else if (S >= 32)
-    hipLaunchKernelGGL((slab_reduce_kernel<1, 16, 8>), dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, s, slabs, S, n, N, ldc,
-                       alpha, bias, add, ldadd, out);
-  else
-    hipLaunchKernelGGL((slab_reduce_kernel<1, 4, 4>), dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, slabs, S, n, N, ldc,
-                       alpha, bias, add, ldadd, out);
+  if ((N & 3) == 0 && (n & 3) == 0 && n >= 4096 && aligned16(slabs) && (n2 & 3) == 0 && aligned16(slabs2)) {
+    const unsigned nb = (unsigned)((n / 4 + 63) / 64), nb2 = (unsigned)((n2 / 4 + 63) / 64);
+    hipLaunchKernelGGL((slab_reduce_kernel<4, 4, 4>), dim3(nb + nb2), dim3(256), 0, s, slabs, S, n, N, ldc, alpha, bias, add,
+                       ldadd, out, (int)nb, slabs2, n2, out2);
+  } else {
+    const unsigned nb = (unsigned)((n + 63) / 64), nb2 = (unsigned)((n2 + 63) / 64);
+    if (S >= 32)
+      hipLaunchKernelGGL((slab_reduce_kernel<1, 16, 8>), dim3(nb + nb2), dim3(1024), 0, s, slabs, S, n, N, ldc, alpha, bias,
+                         add, ldadd, out, (int)nb, slabs2, n2, out2);
+    else
+      hipLaunchKernelGGL((slab_reduce_kernel<1, 4, 4>), dim3(nb + nb2), dim3(256), 0, s, slabs, S, n, N, ldc, alpha, bias, add,
+                         ldadd, out, (int)nb, slabs2, n2, out2);
+  }
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
+}
+
+int launch_slab_reduce(const float* slabs, int S, int64_t n, int N, int64_t ldc, float alpha, const float* bias,
+                       const float* add, int64_t ldadd, float* out, hipStream_t s) {
+  return launch_slab_reduce2(slabs, S, n, N, ldc, alpha, bias, add, ldadd, out, nullptr, 0, nullptr, s);
 }
 
 #ifdef BG_STAMPS
@@ -509,9 +559,38 @@ extern "C" size_t csship_bgemm_workspace(const csship_bgemm_params* p) {
   return s > 1 ? (size_t)s * p->M * p->N * sizeof(float) : 0;
 }
 
+static int bgemm_impl(const void* A, const void* B, void* C, const float* bias, const void* aux,
+                      const csship_bgemm_params* p, void* workspace, size_t workspace_bytes, csship_stream_t stream,
+                      float* colsum_out);
+
 extern "C" int csship_bgemm(const void* A, const void* B, void* C, const float* bias, const void* aux,
                             const csship_bgemm_params* p, void* workspace, size_t workspace_bytes,
                             csship_stream_t stream) {
+  return bgemm_impl(A, B, C, bias, aux, p, workspace, workspace_bytes, stream, nullptr);
+}
+
+static bool wgrad_shape_ok(const csship_bgemm_params* p) {
+  return p->a_kmajor && p->b_kmajor && p->batch1 == 1 && p->batch2 == 1 && (p->epilogue & ~CSSHIP_BEPI_ADD) == 0 &&
+         ((p->M | p->N) & 7) == 0;
+}
+
+extern "C" size_t csship_bgemm_wgrad_workspace(const csship_bgemm_params* p) {
+  if (!p) return 0;
+  const int s = pick_splits(p);
+  return s > 1 ? (size_t)s * ((size_t)p->M * p->N + p->M) * sizeof(float) : 0;
+}
+
+extern "C" int csship_bgemm_wgrad(const void* dY, const void* X, float* dW, float* db, const void* aux,
+                                  const csship_bgemm_params* p, void* workspace, size_t workspace_bytes,
+                                  csship_stream_t stream) {
+  if (!db || !p) return CSSHIP_ENULL;
+  if (!wgrad_shape_ok(p)) return CSSHIP_EUNSUPPORTED;
+  return bgemm_impl(dY, X, dW, nullptr, aux, p, workspace, workspace_bytes, stream, db);
+}
+
+static int bgemm_impl(const void* A, const void* B, void* C, const float* bias, const void* aux,
+                      const csship_bgemm_params* p, void* workspace, size_t workspace_bytes, csship_stream_t stream,
+                      float* colsum_out) {
   if (!A || !B || !C || !p) return CSSHIP_ENULL;
   if (p->M <= 0 || p->N <= 0 || p->K <= 0 || p->batch1 <= 0 || p->batch2 <= 0) return CSSHIP_EBADSHAPE;
   if ((p->epilogue & (CSSHIP_BEPI_MASK_POS | CSSHIP_BEPI_ADD)) && !aux) return CSSHIP_ENULL;
@@ -528,7 +607,8 @@ extern "C" int csship_bgemm(const void* A, const void* B, void* C, const float* 
   if (nz > 65535) return CSSHIP_EBADSHAPE;
   if (splits > 1) {
     if (p->batch1 * p->batch2 != 1 || (p->epilogue & ~CSSHIP_BEPI_ADD) != 0) return CSSHIP_EUNSUPPORTED;
-    if (!workspace || workspace_bytes < (size_t)splits * p->M * p->N * sizeof(float)) return CSSHIP_EWORKSPACE;
+    if (!workspace || workspace_bytes < (size_t)splits * ((size_t)p->M * p->N + (colsum_out ? p->M : 0)) * sizeof(float))
+      return CSSHIP_EWORKSPACE;
   }
   BgemmArgs a{};
   a.A = A; a.B = B; a.bias = bias; a.aux = aux;
@@ -541,6 +621,8 @@ extern "C" int csship_bgemm(const void* A, const void* B, void* C, const float* 
   a.sA1 = p->sA1; a.sA2 = p->sA2; a.sB1 = p->sB1; a.sB2 = p->sB2; a.sC1 = p->sC1; a.sC2 = p->sC2; a.sX1 = p->sX1; a.sX2 = p->sX2;
   a.slab = (int64_t)p->M * p->N;
   a.a_f32 = p->a_f32; a.b_f32 = p->b_f32; a.epi = p->epilogue; a.alpha = p->alpha;
+  a.cs_out = colsum_out;
+  a.cs_slab = splits > 1 ? reinterpret_cast<float*>(workspace) + (size_t)splits * p->M * p->N : nullptr;
   dim3 grid((p->N + 127) / 128, (p->M + 127) / 128, (unsigned)nz);
   hipStream_t s = as_stream(stream);
   // descriptor loads need whole 8-element groups and 32-bit byte offsets inside one batch entry
@@ -556,7 +638,13 @@ extern "C" int csship_bgemm(const void* A, const void* B, void* C, const float* 
     else if (p->b_f32) hipLaunchKernelGGL((bgemm_kernel<AK, BK_, true, false, true>), grid, dim3(256), 0, s, a);              \
     else hipLaunchKernelGGL((bgemm_kernel<AK, BK_, true, false, false>), grid, dim3(256), 0, s, a);                           \
   } while (0)
-  if (p->a_kmajor && p->b_kmajor) BG_LAUNCH(true, true);
+  if (colsum_out) {
+    if (!fast) return CSSHIP_EUNSUPPORTED;
+    if (p->a_f32 && p->b_f32) hipLaunchKernelGGL((bgemm_kernel<true, true, true, true, true, true>), grid, dim3(256), 0, s, a);
+    else if (p->a_f32) hipLaunchKernelGGL((bgemm_kernel<true, true, true, true, false, true>), grid, dim3(256), 0, s, a);
+    else if (p->b_f32) hipLaunchKernelGGL((bgemm_kernel<true, true, true, false, true, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((bgemm_kernel<true, true, true, false, false, true>), grid, dim3(256), 0, s, a);
+  } else if (p->a_kmajor && p->b_kmajor) BG_LAUNCH(true, true);
   else if (p->a_kmajor) BG_LAUNCH(true, false);
   else if (p->b_kmajor) BG_LAUNCH(false, true);
   else BG_LAUNCH(false, false);
@@ -564,9 +652,10 @@ extern "C" int csship_bgemm(const void* A, const void* B, void* C, const float* 
   CSSHIP_CHECK_LAUNCH();
   if (splits > 1) {
     const int64_t n = (int64_t)p->M * p->N;
-    return launch_slab_reduce(reinterpret_cast<const float*>(workspace), splits, n, p->N, p->ldc, p->alpha, bias,
-                              (p->epilogue & CSSHIP_BEPI_ADD) ? reinterpret_cast<const float*>(aux) : nullptr,
-                              p->ldaux, reinterpret_cast<float*>(C), s);
+    return launch_slab_reduce2(reinterpret_cast<const float*>(workspace), splits, n, p->N, p->ldc, p->alpha, bias,
+                               (p->epilogue & CSSHIP_BEPI_ADD) ? reinterpret_cast<const float*>(aux) : nullptr,
+                               p->ldaux, reinterpret_cast<float*>(C), colsum_out ? a.cs_slab : nullptr,
+                               colsum_out ? (int64_t)p->M : 0, colsum_out, s);
   }
   return CSSHIP_OK;
 }

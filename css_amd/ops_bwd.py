@@ -4,6 +4,7 @@ Same rules as ``ops.py``: HIP tensors only, shapes validated on the host, output
 allocator, launches on the current stream.  The reference obtains these gradients from torch.autograd.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -87,6 +88,35 @@ def bgemm(a, b, *, a_kmajor=False, b_kmajor=False, out=None, out_bf16=False, alp
     ws = _workspace(nws, a.device) if nws else None
     check(lib().csship_bgemm(_ptr(a4), _ptr(b4), _ptr(out), _ptr(bias), _ptr(aux), C.byref(p), _ptr(ws), nws, _stream()))
     return out_ret
+
+
+_SPLIT_WGRAD = os.environ.get("CSS_AMD_SPLIT_WGRAD", "0") == "1"  # A/B timing: the product and the column sums as two calls
+
+
+def linear_wgrad(dy, x, alpha=1.0, dw_out=None, db_out=None):
+    """(dW, db) of y = x W^T + b from dy [rows, M] and x [rows, N] (f32 or bf16, rows contiguous): dW = alpha * dy^T x
+    f32 [M, N], db = alpha * column sums of dy f32 [M] - ONE pass over dy (csship_bgemm_wgrad) when the widths are
+    multiples of 8, else the product and the column sums as two calls."""
+    if dy.dim() != 2 or x.dim() != 2 or dy.shape[0] != x.shape[0]:
+        raise RuntimeError("css_amd: linear_wgrad expects dy [rows, M] and x [rows, N]")
+    K, M = dy.shape
+    N = x.shape[1]
+    if (M | N) & 7 or dy.stride(1) != 1 or x.stride(1) != 1 or dy.stride(0) % 8 or x.stride(0) % 8 or _SPLIT_WGRAD:
+        dw = bgemm(dy, x, a_kmajor=True, b_kmajor=True, alpha=alpha, out=dw_out)
+        return dw, colsum(dy, alpha, out=db_out)
+    dw = torch.empty((M, N), dtype=torch.float32, device=dy.device) if dw_out is None else dw_out
+    db = torch.empty(M, dtype=torch.float32, device=dy.device) if db_out is None else db_out
+    if dw.dtype != torch.float32 or dw.shape != (M, N) or dw.stride(1) != 1 or db.dtype != torch.float32 or \
+            db.shape != (M,) or not db.is_contiguous():
+        raise RuntimeError("css_amd: linear_wgrad outputs must be f32 [M, N] (contiguous columns) and contiguous f32 [M]")
+    p = _lib.BgemmParams(M=M, N=N, K=K, lda=dy.stride(0), ldb=x.stride(0), ldc=dw.stride(0), ldaux=0, a_kmajor=1,
+                         b_kmajor=1, a_f32=int(dy.dtype == torch.float32), b_f32=int(x.dtype == torch.float32), epilogue=0,
+                         batch1=1, batch2=1, splits=0, sA1=0, sA2=0, sB1=0, sB2=0, sC1=0, sC2=0, sX1=0, sX2=0,
+                         alpha=float(alpha))
+    nws = lib().csship_bgemm_wgrad_workspace(C.byref(p))
+    ws = _workspace(nws, dy.device) if nws else None
+    check(lib().csship_bgemm_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), None, C.byref(p), _ptr(ws), nws, _stream()))
+    return dw, db
 
 
 def colsum(x, alpha=1.0, out=None):

@@ -448,6 +448,15 @@ typedef struct {
 size_t csship_bgemm_workspace(const csship_bgemm_params* p);
 int csship_bgemm(const void* A, const void* B, void* C, const float* bias, const void* aux,
                  const csship_bgemm_params* p, void* workspace, size_t workspace_bytes, csship_stream_t stream);
+/* Weight AND bias gradient of a Linear y = x W^T + b in one pass over dY (torch.autograd's two products in the
+ * reference): dW[M, N] = alpha * dY^T . X (+ aux with CSSHIP_BEPI_ADD) and db[M] = alpha * column sums of dY, where
+ * dY is [K, M] and X is [K, N] (both kmajor: p->a_kmajor = p->b_kmajor = 1, no batch, f32 output, M and N multiples of
+ * 8; anything else: CSSHIP_EUNSUPPORTED).  The column sums are one more MFMA per dY fragment against ones in the
+ * workgroups of the first tile column; with a split reduction they are reduced by the same launch as the slabs
+ * (fixed order).  db sums the bf16-ROUNDED dY the product uses.  Workspace: csship_bgemm_wgrad_workspace(). */
+size_t csship_bgemm_wgrad_workspace(const csship_bgemm_params* p);
+int csship_bgemm_wgrad(const void* dY, const void* X, float* dW, float* db, const void* aux,
+                       const csship_bgemm_params* p, void* workspace, size_t workspace_bytes, csship_stream_t stream);
 
 /* out[c] = alpha * sum_r x[r, c] for x f32 or bf16 [M, N] (row stride ld): the bias gradient of a Linear. */
 size_t csship_colsum_workspace(int64_t M, int32_t N);

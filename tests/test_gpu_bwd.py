@@ -114,6 +114,28 @@ def test_bgemm_batched_strided_views(ob):
     assert relerr(r, qf @ bf(pe.float().cpu()).double().T) < 2e-5
 
 
+@pytest.mark.parametrize("K,M,N,dy_f32,x_f32", [(12800, 256, 1024, True, False), (12800, 1024, 256, False, False),
+                                                 (12800, 512, 256, True, True), (700, 264, 256, True, False),
+                                                 (3000, 768, 264, False, True)])
+def test_linear_wgrad_fused_bias_gradient(ob, K, M, N, dy_f32, x_f32):
+    """dW = dy^T x and db = column sums of dy from ONE pass over dy (csship_bgemm_wgrad; split and unsplit reductions,
+    both operand types) == the product and the column sums as separate calls; db sums the bf16-rounded dy."""
+    dy = rnd((K, M), 71).to(DEV) if dy_f32 else rnd((K, M), 71).to(DEV).to(torch.bfloat16)
+    x = rnd((K, N), 72).to(DEV) if x_f32 else rnd((K, N), 72).to(DEV).to(torch.bfloat16)
+    dw, db = ob.linear_wgrad(dy, x, 0.5)
+    dw_ref = ob.bgemm(dy, x, a_kmajor=True, b_kmajor=True, alpha=0.5)
+    assert torch.equal(dw, dw_ref)                       # the same kernel arithmetic, the same slab order
+    db64 = 0.5 * dy.to(torch.bfloat16).double().sum(0)
+    assert float((db.double() - db64).abs().max()) < 2e-5 * float(dy.float().abs().sum(0).max())
+    # strided views: rows of a wider buffer, outputs into slices
+    wide = rnd((K, M + 2 * N + 16), 73).to(DEV)
+    dwo, dbo = torch.zeros(M + 8, N, device=DEV), torch.zeros(M + 8, device=DEV)
+    ob.linear_wgrad(wide[:, 8:8 + M], x, 1.0, dw_out=dwo[8:], db_out=dbo[8:])
+    assert torch.equal(dwo[8:], ob.bgemm(wide[:, 8:8 + M], x, a_kmajor=True, b_kmajor=True)) and float(dwo[:8].abs().max()) == 0
+    want = wide[:, 8:8 + M].to(torch.bfloat16).double().sum(0)
+    assert float((dbo[8:].double() - want).abs().max()) < 2e-5 * float(wide[:, 8:8 + M].abs().sum(0).max())
+
+
 def test_colsum(ob):
     for M, N, dt in ((12800, 771, torch.float32), (1000, 1024, torch.bfloat16), (7, 3, torch.float32)):
         ld = (N + 7) // 8 * 8
