@@ -141,8 +141,7 @@ def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_s
     a, _ = ops.layernorm(x, ln_g, ln_b)
     dw = torch.empty((3 * D, D), dtype=torch.float32, device=x.device)
     db = torch.empty(3 * D, dtype=torch.float32, device=x.device)
-    ob.linear_wgrad(dq2[:, :D], a, q_scale, dw_out=dw[:D], db_out=db[:D])
-    ob.linear_wgrad(dq2[:, D:], a, 1.0, dw_out=dw[D:], db_out=db[D:])
+    ob.linear_wgrad(dq2, a, 1.0, dw_out=dw, db_out=db, head=(D, q_scale))   # q rows carry the projection's 1/sqrt(d_k)
     da = ob.bgemm(dq2, wqkv_bf, b_kmajor=True)
     dx, dg, dbeta = ob.layernorm_bwd(x, da, ln_g, ln_b, dx_add=dy)
     return dx, (dg, dbeta, dw, db, dwo, dbo, dpe)

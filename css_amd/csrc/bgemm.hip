@@ -32,6 +32,8 @@ struct BgemmArgs {
   // COLSUM kernels (weight gradients): column sums of the kmajor A operand (= the bias gradient of the same Linear)
   float* cs_out;   // [M], alpha applied (splits == 1)
   float* cs_slab;  // [splits][M] partial sums (splits > 1), reduced with the C slabs
+  float alpha_head;  // COLSUM kernels: output rows < head_rows take this factor instead of alpha (fused q | k | v weight
+  int head_rows;     // gradient: the q rows carry the 1/sqrt(d_k) of the pre-scaled projection)
 };
 
 constexpr int BK = 64;
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
         const int m = m0 + wm * 64 + i * 16 + ln;
         if (m < g.M) {
           if (g.splits > 1) g.cs_slab[(int64_t)split * g.M + m] = cs[i][0];
-          else g.cs_out[m] = g.alpha * cs[i][0];
+          else g.cs_out[m] = (m < g.head_rows ? g.alpha_head : g.alpha) * cs[i][0];
         }
       }
     }
@@ -366,8 +368,9 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
           const float4 bv = *reinterpret_cast<const float4*>(g.bias + col);
           b[0] = bv.x; b[1] = bv.y; b[2] = bv.z; b[3] = bv.w;
         }
+        const float al = (COLSUM && row < g.head_rows) ? g.alpha_head : g.alpha;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (g.epi & CSSHIP_BEPI_SCALE_BIAS) ? g.alpha * (v[r] + b[r]) : g.alpha * v[r] + b[r];
+        for (int r = 0; r < 4; ++r) v[r] = (g.epi & CSSHIP_BEPI_SCALE_BIAS) ? al * (v[r] + b[r]) : al * v[r] + b[r];
         if (g.epi & CSSHIP_BEPI_MASK_POS) {
           const uint2 m = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(g.aux) + ao);
           if (!(__uint_as_float(m.x << 16) > 0.f)) v[0] = 0.f;
@@ -392,7 +395,8 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
         for (int r = 0; r < 4; ++r) {
           if (col + r >= g.N) continue;
           const float bias = g.bias ? g.bias[col + r] : 0.f;
-          float x = (g.epi & CSSHIP_BEPI_SCALE_BIAS) ? g.alpha * (v[r] + bias) : g.alpha * v[r] + bias;
+          const float al = (COLSUM && row < g.head_rows) ? g.alpha_head : g.alpha;
+          float x = (g.epi & CSSHIP_BEPI_SCALE_BIAS) ? al * (v[r] + bias) : al * v[r] + bias;
           if (g.epi & CSSHIP_BEPI_MASK_POS) {
             if (!(bf2f(reinterpret_cast<const unsigned short*>(g.aux)[ao + r]) > 0.f)) x = 0.f;
           }
@@ -424,13 +428,15 @@ __global__ __launch_bounds__(64 * NW) void slab_reduce_kernel(const float* __res
                                                               int64_t ldc, float alpha, const float* __restrict__ bias,
                                                               const float* add, int64_t ldadd, float* out, int nb_main,
                                                               const float* __restrict__ slabs2, int64_t n2,
-                                                              float* __restrict__ out2) {
+                                                              float* __restrict__ out2, float alpha_head, int head_rows) {
   typedef float vec __attribute__((ext_vector_type(V)));
   __shared__ vec red[NW][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   int bid = blockIdx.x;
+  bool tail = false;
   if (bid >= nb_main) {  // second, short output reduced by the same launch (the bias gradient next to its weight gradient)
     bid -= nb_main;
+    tail = true;
     slabs = slabs2; n = n2; N = (int)n2; ldc = n2; bias = nullptr; add = nullptr; out = out2;
   }
   const int64_t i = ((int64_t)bid * 64 + lane) * V;
@@ -464,7 +470,8 @@ __global__ __launch_bounds__(64 * NW) void slab_reduce_kernel(const float* __res
   for (int j = 1; j < NW; ++j) t += red[j][lane];
 #pragma unroll
   for (int e = 0; e < V; ++e) {  // V = 4: the four elements share a row (N % 4 == 0)
-    float v = alpha * t[e];
+    // head_rows: the first rows of the main output (first elements of the tail vector) take alpha_head
+    float v = ((tail ? c + e : r) < head_rows ? alpha_head : alpha) * t[e];
     if (bias) v += bias[c + e];
     if (add) v += add[r * ldadd + c + e];
     out[r * ldc + c + e] = v;
@@ -522,21 +529,21 @@ int pick_splits(const csship_bgemm_params* p) {
 // slabs2 / n2 / out2 (optional): a second output of n2 elements with the same S and alpha, reduced by the same launch
 static int launch_slab_reduce2(const float* slabs, int S, int64_t n, int N, int64_t ldc, float alpha, const float* bias,
                                const float* add, int64_t ldadd, float* out, const float* slabs2, int64_t n2, float* out2,
-                               hipStream_t s) {
+                               hipStream_t s, float alpha_head = 0.f, int head_rows = 0) {
   // long outputs: 16-byte loads, 4 waves per 256 elements; short outputs with many slabs (bias / LayerNorm partials): 16
   // waves share the slabs of 64 elements
   if ((N & 3) == 0 && (n & 3) == 0 && n >= 4096 && aligned16(slabs) && (n2 & 3) == 0 && aligned16(slabs2)) {
     const unsigned nb = (unsigned)((n / 4 + 63) / 64), nb2 = (unsigned)((n2 / 4 + 63) / 64);
     hipLaunchKernelGGL((slab_reduce_kernel<4, 4, 4>), dim3(nb + nb2), dim3(256), 0, s, slabs, S, n, N, ldc, alpha, bias, add,
-                       ldadd, out, (int)nb, slabs2, n2, out2);
+                       ldadd, out, (int)nb, slabs2, n2, out2, alpha_head, head_rows);
   } else {
     const unsigned nb = (unsigned)((n + 63) / 64), nb2 = (unsigned)((n2 + 63) / 64);
     if (S >= 32)
       hipLaunchKernelGGL((slab_reduce_kernel<1, 16, 8>), dim3(nb + nb2), dim3(1024), 0, s, slabs, S, n, N, ldc, alpha, bias,
-                         add, ldadd, out, (int)nb, slabs2, n2, out2);
+                         add, ldadd, out, (int)nb, slabs2, n2, out2, alpha_head, head_rows);
     else
       hipLaunchKernelGGL((slab_reduce_kernel<1, 4, 4>), dim3(nb + nb2), dim3(256), 0, s, slabs, S, n, N, ldc, alpha, bias, add,
-                         ldadd, out, (int)nb, slabs2, n2, out2);
+                         ldadd, out, (int)nb, slabs2, n2, out2, alpha_head, head_rows);
   }
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
@@ -561,7 +568,7 @@ extern "C" size_t csship_bgemm_workspace(const csship_bgemm_params* p) {
 
 static int bgemm_impl(const void* A, const void* B, void* C, const float* bias, const void* aux,
                       const csship_bgemm_params* p, void* workspace, size_t workspace_bytes, csship_stream_t stream,
-                      float* colsum_out);
+                      float* colsum_out, float alpha_head = 0.f, int head_rows = 0);
 
 extern "C" int csship_bgemm(const void* A, const void* B, void* C, const float* bias, const void* aux,
                             const csship_bgemm_params* p, void* workspace, size_t workspace_bytes,
@@ -581,16 +588,16 @@ extern "C" size_t csship_bgemm_wgrad_workspace(const csship_bgemm_params* p) {
 }
 
 extern "C" int csship_bgemm_wgrad(const void* dY, const void* X, float* dW, float* db, const void* aux,
-                                  const csship_bgemm_params* p, void* workspace, size_t workspace_bytes,
-                                  csship_stream_t stream) {
+                                  const csship_bgemm_params* p, float alpha_head, int32_t head_rows, void* workspace,
+                                  size_t workspace_bytes, csship_stream_t stream) {
   if (!db || !p) return CSSHIP_ENULL;
-  if (!wgrad_shape_ok(p)) return CSSHIP_EUNSUPPORTED;
-  return bgemm_impl(dY, X, dW, nullptr, aux, p, workspace, workspace_bytes, stream, db);
+  if (!wgrad_shape_ok(p) || head_rows < 0 || head_rows > p->M) return CSSHIP_EUNSUPPORTED;
+  return bgemm_impl(dY, X, dW, nullptr, aux, p, workspace, workspace_bytes, stream, db, alpha_head, head_rows);
 }
 
 static int bgemm_impl(const void* A, const void* B, void* C, const float* bias, const void* aux,
                       const csship_bgemm_params* p, void* workspace, size_t workspace_bytes, csship_stream_t stream,
-                      float* colsum_out) {
+                      float* colsum_out, float alpha_head, int head_rows) {
   if (!A || !B || !C || !p) return CSSHIP_ENULL;
   if (p->M <= 0 || p->N <= 0 || p->K <= 0 || p->batch1 <= 0 || p->batch2 <= 0) return CSSHIP_EBADSHAPE;
   if ((p->epilogue & (CSSHIP_BEPI_MASK_POS | CSSHIP_BEPI_ADD)) && !aux) return CSSHIP_ENULL;
@@ -622,6 +629,7 @@ static int bgemm_impl(const void* A, const void* B, void* C, const float* bias, 
   a.slab = (int64_t)p->M * p->N;
   a.a_f32 = p->a_f32; a.b_f32 = p->b_f32; a.epi = p->epilogue; a.alpha = p->alpha;
   a.cs_out = colsum_out;
+  a.alpha_head = alpha_head; a.head_rows = head_rows;
   a.cs_slab = splits > 1 ? reinterpret_cast<float*>(workspace) + (size_t)splits * p->M * p->N : nullptr;
   dim3 grid((p->N + 127) / 128, (p->M + 127) / 128, (unsigned)nz);
   hipStream_t s = as_stream(stream);
@@ -655,7 +663,7 @@ static int bgemm_impl(const void* A, const void* B, void* C, const float* bias, 
     return launch_slab_reduce2(reinterpret_cast<const float*>(workspace), splits, n, p->N, p->ldc, p->alpha, bias,
                                (p->epilogue & CSSHIP_BEPI_ADD) ? reinterpret_cast<const float*>(aux) : nullptr,
                                p->ldaux, reinterpret_cast<float*>(C), colsum_out ? a.cs_slab : nullptr,
-                               colsum_out ? (int64_t)p->M : 0, colsum_out, s);
+                               colsum_out ? (int64_t)p->M : 0, colsum_out, s, alpha_head, head_rows);
   }
   return CSSHIP_OK;
 }

@@ -93,17 +93,22 @@ def bgemm(a, b, *, a_kmajor=False, b_kmajor=False, out=None, out_bf16=False, alp
 _SPLIT_WGRAD = os.environ.get("CSS_AMD_SPLIT_WGRAD", "0") == "1"  # A/B timing: the product and the column sums as two calls
 
 
-def linear_wgrad(dy, x, alpha=1.0, dw_out=None, db_out=None):
+def linear_wgrad(dy, x, alpha=1.0, dw_out=None, db_out=None, head=None):
     """(dW, db) of y = x W^T + b from dy [rows, M] and x [rows, N] (f32 or bf16, rows contiguous): dW = alpha * dy^T x
     f32 [M, N], db = alpha * column sums of dy f32 [M] - ONE pass over dy (csship_bgemm_wgrad) when the widths are
-    multiples of 8, else the product and the column sums as two calls."""
+    multiples of 8, else the product and the column sums as two calls.  head = (rows, alpha_head): the first ``rows``
+    output rows take alpha_head instead of alpha."""
     if dy.dim() != 2 or x.dim() != 2 or dy.shape[0] != x.shape[0]:
         raise RuntimeError("css_amd: linear_wgrad expects dy [rows, M] and x [rows, N]")
     K, M = dy.shape
     N = x.shape[1]
     if (M | N) & 7 or dy.stride(1) != 1 or x.stride(1) != 1 or dy.stride(0) % 8 or x.stride(0) % 8 or _SPLIT_WGRAD:
         dw = bgemm(dy, x, a_kmajor=True, b_kmajor=True, alpha=alpha, out=dw_out)
-        return dw, colsum(dy, alpha, out=db_out)
+        db = colsum(dy, alpha, out=db_out)
+        if head is not None and alpha != 0:
+            dw[:head[0]] *= head[1] / alpha
+            db[:head[0]] *= head[1] / alpha
+        return dw, db
     dw = torch.empty((M, N), dtype=torch.float32, device=dy.device) if dw_out is None else dw_out
     db = torch.empty(M, dtype=torch.float32, device=dy.device) if db_out is None else db_out
     if dw.dtype != torch.float32 or dw.shape != (M, N) or dw.stride(1) != 1 or db.dtype != torch.float32 or \
@@ -115,7 +120,8 @@ def linear_wgrad(dy, x, alpha=1.0, dw_out=None, db_out=None):
                          alpha=float(alpha))
     nws = lib().csship_bgemm_wgrad_workspace(C.byref(p))
     ws = _workspace(nws, dy.device) if nws else None
-    check(lib().csship_bgemm_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), None, C.byref(p), _ptr(ws), nws, _stream()))
+    check(lib().csship_bgemm_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), None, C.byref(p),
+                                   float(head[1]) if head else 0.0, int(head[0]) if head else 0, _ptr(ws), nws, _stream()))
     return dw, db
 
 

@@ -453,10 +453,13 @@ int csship_bgemm(const void* A, const void* B, void* C, const float* bias, const
  * dY is [K, M] and X is [K, N] (both kmajor: p->a_kmajor = p->b_kmajor = 1, no batch, f32 output, M and N multiples of
  * 8; anything else: CSSHIP_EUNSUPPORTED).  The column sums are one more MFMA per dY fragment against ones in the
  * workgroups of the first tile column; with a split reduction they are reduced by the same launch as the slabs
- * (fixed order).  db sums the bf16-ROUNDED dY the product uses.  Workspace: csship_bgemm_wgrad_workspace(). */
+ * (fixed order).  db sums the bf16-ROUNDED dY the product uses.  head_rows > 0: rows [0, head_rows) of dW and db take
+ * alpha_head instead of p->alpha (the fused q | k | v projection: q rows carry 1/sqrt(d_k)).
+ * Workspace: csship_bgemm_wgrad_workspace(). */
 size_t csship_bgemm_wgrad_workspace(const csship_bgemm_params* p);
 int csship_bgemm_wgrad(const void* dY, const void* X, float* dW, float* db, const void* aux,
-                       const csship_bgemm_params* p, void* workspace, size_t workspace_bytes, csship_stream_t stream);
+                       const csship_bgemm_params* p, float alpha_head, int32_t head_rows, void* workspace,
+                       size_t workspace_bytes, csship_stream_t stream);
 
 /* out[c] = alpha * sum_r x[r, c] for x f32 or bf16 [M, N] (row stride ld): the bias gradient of a Linear. */
 size_t csship_colsum_workspace(int64_t M, int32_t N);

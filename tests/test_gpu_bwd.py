@@ -127,6 +127,10 @@ def test_linear_wgrad_fused_bias_gradient(ob, K, M, N, dy_f32, x_f32):
     assert torch.equal(dw, dw_ref)                       # the same kernel arithmetic, the same slab order
     db64 = 0.5 * dy.to(torch.bfloat16).double().sum(0)
     assert float((db.double() - db64).abs().max()) < 2e-5 * float(dy.float().abs().sum(0).max())
+    # a head of output rows with its own factor (fused q | k | v projection)
+    dwh, dbh = ob.linear_wgrad(dy, x, 0.5, head=(64, 0.25))
+    assert torch.equal(dwh[64:], dw[64:]) and torch.equal(dbh[64:], db[64:])
+    assert torch.allclose(dwh[:64], dw[:64] * 0.5, rtol=1e-6, atol=0) and torch.allclose(dbh[:64], db[:64] * 0.5, rtol=1e-6, atol=0)
     # strided views: rows of a wider buffer, outputs into slices
     wide = rnd((K, M + 2 * N + 16), 73).to(DEV)
     dwo, dbo = torch.zeros(M + 8, N, device=DEV), torch.zeros(M + 8, device=DEV)
