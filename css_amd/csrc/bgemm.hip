@@ -123,20 +123,25 @@ DEV void load_operand(const void* base, bool f32, int64_t ld, int row0, int nrow
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 constexpr unsigned OOB = 0xFFFFFF00u;
 
-template <bool KM, bool F32>
+// ROWS = operand rows of the tile (128, or 64 for the narrow B tile): ROWS / 32 groups per thread
+template <bool KM, bool F32, int ROWS = 128>
 DEV void load_operand_buf(__amdgpu_buffer_rsrc_t rs, unsigned ld, int row0, int nrows, int k0, int kend, int tid,
                           Raw8 (&r)[4]) {
   constexpr unsigned esz = F32 ? 4 : 2;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < ROWS / 32; ++i) {
     unsigned off;
     bool valid;
     if constexpr (!KM) {
       const int row = row0 + (tid >> 3) + 32 * i, k = k0 + (tid & 7) * 8;
       valid = row < nrows && k + 8 <= kend;
       off = (unsigned)row * ld + (unsigned)k;
-    } else {
+    } else if constexpr (ROWS == 128) {
       const int k = k0 + (tid >> 4) + 16 * i, col = row0 + (tid & 15) * 8;
+      valid = k < kend && col + 8 <= nrows;
+      off = (unsigned)k * ld + (unsigned)col;
+    } else {
+      const int k = k0 + (tid >> 3) + 32 * i, col = row0 + (tid & 7) * 8;
       valid = k < kend && col + 8 <= nrows;
       off = (unsigned)k * ld + (unsigned)col;
     }
@@ -152,17 +157,22 @@ DEV void load_operand_buf(__amdgpu_buffer_rsrc_t rs, unsigned ld, int row0, int 
   }
 }
 
-template <bool KM>
+template <bool KM, int ROWS = 128>
 DEV void store_operand(unsigned char* img, int tid, const Raw8 (&r)[4], bool f32) {
   if constexpr (!KM) {
     const int srow = tid >> 3, sc = tid & 7;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(img + tile_off(srow + 32 * i, sc)) = to_bf16(r[i], f32);
-  } else {
+    for (int i = 0; i < ROWS / 32; ++i) *reinterpret_cast<uint4*>(img + tile_off(srow + 32 * i, sc)) = to_bf16(r[i], f32);
+  } else if constexpr (ROWS == 128) {
     const int krow = tid >> 4, ch = tid & 15;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       *reinterpret_cast<uint4*>(img + km_off(krow + 16 * i, ch >> 1) + (ch & 1) * 16) = to_bf16(r[i], f32);
+  } else {  // 64 operand rows: half of every 256-byte k row is used (same swizzle, same transposing reads)
+    const int krow = tid >> 3, ch = tid & 7;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      *reinterpret_cast<uint4*>(img + km_off(krow + 32 * i, ch >> 1) + (ch & 1) * 16) = to_bf16(r[i], f32);
   }
 }
 
@@ -191,8 +201,12 @@ __device__ unsigned* g_bg_stamps = nullptr;
 // FAST: whole 8-element groups and operands below 4 GB -> descriptor loads with compile-time operand types.
 // COLSUM: the workgroups of the first tile column also sum the A operand over the reduction index with one more MFMA
 // per A fragment against a fragment of ones (D[n][m] = sum_k 1 * A[k][m]: every row of the result is the column sum).
-template <bool A_KM, bool B_KM, bool FAST, bool A_F32, bool B_F32, bool COLSUM = false>
+// TN: output columns per tile.  64 (FAST kernels only): products whose N is 64 (the per-head attention gradients) or
+// whose 128-wide tiling leaves less than two workgroups per CU - a wave then owns 64 x 32 of the tile.
+template <bool A_KM, bool B_KM, bool FAST, bool A_F32, bool B_F32, bool COLSUM = false, int TN = 128>
 __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
+  static_assert(TN == 128 || (TN == 64 && FAST), "narrow tiles use the descriptor loaders");
+  constexpr int NJ = TN / 32, WN = TN / 2;  // 16-column fragments per wave, columns per wave
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef BG_STAMPS
@@ -220,7 +234,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
       by = t / gridDim.x;
     }
   }
-  const int m0 = by * 128, n0 = bx * 128;
+  const int m0 = by * 128, n0 = bx * TN;
   const int z = bz / g.splits, split = bz % g.splits;
   const int z1 = z / g.nb2, z2 = z % g.nb2;
   const int kbeg = split * g.k_per_split, kend = min(g.K, kbeg + g.k_per_split);
@@ -238,17 +252,17 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
   auto load_tile = [&](int k0) {
     if constexpr (FAST) {
       load_operand_buf<A_KM, A_F32>(rsa, (unsigned)g.lda, m0, g.M, k0, kend, tid, ra);
-      load_operand_buf<B_KM, B_F32>(rsb, (unsigned)g.ldb, n0, g.N, k0, kend, tid, rb);
+      load_operand_buf<B_KM, B_F32, TN>(rsb, (unsigned)g.ldb, n0, g.N, k0, kend, tid, rb);
     } else {
       load_operand<A_KM>(Ab, af32, g.lda, m0, g.M, k0, kend, tid, ra);
       load_operand<B_KM>(Bb, bf32, g.ldb, n0, g.N, k0, kend, tid, rb);
     }
   };
-  f32x4 acc[4][4];
+  f32x4 acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 cs[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) cs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -260,7 +274,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
   if (nk > 0) {
     load_tile(kbeg);
     store_operand<A_KM>(smem, tid, ra, af32);
-    store_operand<B_KM>(smem + 128 * 128, tid, rb, bf32);
+    store_operand<B_KM, TN>(smem + 128 * 128, tid, rb, bf32);
   }
   __syncthreads();
   STAMP(1);
@@ -274,14 +288,14 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
     const unsigned char* bs = as + 128 * 128;
     // both k-steps' fragments are requested before the first MFMA: the second half's LDS reads run under the first
     // half's MFMAs (with one wave per SIMD nothing else would overlap them)
-    bf16x8 af[2][4], bf[2][4];
+    bf16x8 af[2][4], bf[2][NJ];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        af[ks][i] = read_frag<A_KM>(as, wm * 64 + i * 16, ks, lane);
-        bf[ks][i] = read_frag<B_KM>(bs, wn * 64 + i * 16, ks, lane);
-      }
+      for (int i = 0; i < 4; ++i) af[ks][i] = read_frag<A_KM>(as, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bf[ks][j] = read_frag<B_KM>(bs, wn * WN + j * 16, ks, lane);
+    }
 #ifdef BG_STAMPS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (kt < 12) STAMP(3 + kt * 5);  // fragments read
@@ -291,7 +305,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);  // C^T tile
     if constexpr (COLSUM) {
       if (do_cs) {
@@ -306,7 +320,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
     if (kt + 1 < nk) {
       unsigned char* nx = smem + ((kt + 1) & 1) * STAGE;
       store_operand<A_KM>(nx, tid, ra, af32);
-      store_operand<B_KM>(nx + 128 * 128, tid, rb, bf32);
+      store_operand<B_KM, TN>(nx + 128 * 128, tid, rb, bf32);
     }
     if (kt < 12) STAMP(5 + kt * 5);  // next tile in LDS
     __syncthreads();
@@ -346,8 +360,8 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
     const int row = m0 + wm * 64 + i * 16 + ln;
     if (row >= g.M) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = n0 + wn * 64 + j * 16 + lg * 4;
+    for (int j = 0; j < NJ; ++j) {
+      const int col = n0 + wn * WN + j * 16 + lg * 4;
       if (col >= g.N) continue;
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
       if (to_slab) {
@@ -514,9 +528,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x,
   if (w == 0 && c < N) part[(int64_t)blockIdx.y * N + c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
 
+// narrow (128 x 64) tiles: N of 64 or less (no half-empty B tile), needs the descriptor loaders
+bool narrow_tile(const csship_bgemm_params* p) {
+  static const bool off = getenv("CSSHIP_BGEMM_WIDE") != nullptr;  // A/B timing
+  static const int maxn = [] { const char* e = getenv("CSSHIP_BGEMM_NARROW_MAXN"); return e ? atoi(e) : 64; }();
+  return !off && p->N <= maxn && (((p->a_kmajor ? p->M : p->K) | (p->b_kmajor ? p->N : p->K)) & 7) == 0;
+}
+
 int pick_splits(const csship_bgemm_params* p) {
   if (p->splits > 0) return p->splits;
-  const int64_t tiles = (int64_t)((p->M + 127) / 128) * ((p->N + 127) / 128) * p->batch1 * p->batch2;
+  const int tn = narrow_tile(p) ? 64 : 128;
+  const int64_t tiles = (int64_t)((p->M + 127) / 128) * ((p->N + tn - 1) / tn) * p->batch1 * p->batch2;
   const int kt = (p->K + BK - 1) / BK;
   if (tiles >= 128 || kt < 8 || p->batch1 * p->batch2 != 1 || (p->epilogue & ~CSSHIP_BEPI_ADD) != 0) return 1;
   int s = (int)((384 + tiles - 1) / tiles);
@@ -631,7 +653,8 @@ static int bgemm_impl(const void* A, const void* B, void* C, const float* bias, 
   a.cs_out = colsum_out;
   a.alpha_head = alpha_head; a.head_rows = head_rows;
   a.cs_slab = splits > 1 ? reinterpret_cast<float*>(workspace) + (size_t)splits * p->M * p->N : nullptr;
-  dim3 grid((p->N + 127) / 128, (p->M + 127) / 128, (unsigned)nz);
+  const bool narrow = narrow_tile(p) && !colsum_out;
+  dim3 grid(narrow ? (p->N + 63) / 64 : (p->N + 127) / 128, (p->M + 127) / 128, (unsigned)nz);
   hipStream_t s = as_stream(stream);
   // descriptor loads need whole 8-element groups and 32-bit byte offsets inside one batch entry
   const int64_t a_elems = p->a_kmajor ? (int64_t)(p->K - 1) * p->lda + p->M : (int64_t)(p->M - 1) * p->lda + p->K;
@@ -640,6 +663,12 @@ static int bgemm_impl(const void* A, const void* B, void* C, const float* bias, 
                     a_elems * (p->a_f32 ? 4 : 2) < 0xFFFFFF00ll && b_elems * (p->b_f32 ? 4 : 2) < 0xFFFFFF00ll;
 #define BG_LAUNCH(AK, BK_)                                                                                      \
   do {                                                                                                          \
+    if (fast && narrow) {                                                                                       \
+      if (p->a_f32 && p->b_f32) hipLaunchKernelGGL((bgemm_kernel<AK, BK_, true, true, true, false, 64>), grid, dim3(256), 0, s, a);   \
+      else if (p->a_f32) hipLaunchKernelGGL((bgemm_kernel<AK, BK_, true, true, false, false, 64>), grid, dim3(256), 0, s, a);         \
+      else if (p->b_f32) hipLaunchKernelGGL((bgemm_kernel<AK, BK_, true, false, true, false, 64>), grid, dim3(256), 0, s, a);         \
+      else hipLaunchKernelGGL((bgemm_kernel<AK, BK_, true, false, false, false, 64>), grid, dim3(256), 0, s, a);                      \
+    } else                                                                                                      \
     if (!fast) hipLaunchKernelGGL((bgemm_kernel<AK, BK_, false, false, false>), grid, dim3(256), 0, s, a);      \
     else if (p->a_f32 && p->b_f32) hipLaunchKernelGGL((bgemm_kernel<AK, BK_, true, true, true>), grid, dim3(256), 0, s, a);   \
     else if (p->a_f32) hipLaunchKernelGGL((bgemm_kernel<AK, BK_, true, true, false>), grid, dim3(256), 0, s, a);              \

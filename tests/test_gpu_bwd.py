@@ -38,7 +38,8 @@ def ob():
 
 
 @pytest.mark.parametrize("a_km,b_km", [(False, False), (False, True), (True, False), (True, True)])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 72, 100), (257, 771, 1300), (64, 256, 12800)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 72, 100), (257, 771, 1300), (64, 256, 12800),
+                                   (400, 64, 400), (264, 48, 1000), (800, 64, 25600), (130, 40, 72)])  # N <= 64: narrow tiles
 def test_bgemm_layouts(ob, a_km, b_km, M, N, K):
     """all four operand layouts, ragged sizes, f32 and bf16 inputs, automatic split of long reductions"""
     def pad8(n):
