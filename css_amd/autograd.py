@@ -143,8 +143,8 @@ class ConformerTrain(torch.autograd.Function):
         if ds.active:  # conformer.py:127 drops before the ReLU; relu(drop(v)) == drop(relu(v)) (the scale is positive)
             ops.dropout_apply(x, ds.cfg("embed"))
         S["we_bf"] = we_bf
-        pe = enc.pos_emb.pe_k.weight.detach()
-        pe_pack = ops.pack_relpos(pe, enc.pos_emb.maxlen)
+        pe = model.position_table()
+        pe_pack = ops.pack_relpos(pe, 1000)
         S["pe_bf"] = pe.to(BF)
         S["pe_pack"] = pe_pack
         bn_means, bn_vars, bn_cnt, bn_new_m, bn_new_v = [], [], [], [], []
@@ -251,7 +251,7 @@ class ConformerTrain(torch.autograd.Function):
         dx, dw, db = bw.head_bwd(dm, masks, S["x_enc"], S["wh_bf"])
         put(model.linear.weight, dw), put(model.linear.bias, db)
         _deliver_group(model, model.linear, G)
-        window = bw.relpos_window(S["pe_bf"], T, enc.pos_emb.maxlen)
+        window = bw.relpos_window(S["pe_bf"], T, 1000)
         dwin = None
         # skewed dS buffer shared by all layers: the band positions are the same every layer, the rest stays zero
         skew_buf = torch.zeros((B, T, H, window[0].shape[0]), dtype=BF, device=masks.device)
@@ -303,9 +303,10 @@ class ConformerTrain(torch.autograd.Function):
             dx = ffn_b(lay.feed_forward_in, "ffn_in", dx)
             L.clear()
             _deliver_group(model, lay, G)
-        dpe = torch.zeros_like(enc.pos_emb.pe_k.weight)
-        dpe.index_add_(0, window[1], dwin[:2 * T - 1])
-        put(enc.pos_emb.pe_k.weight, dpe)
+        if enc.pos_emb is not None:
+            dpe = torch.zeros_like(enc.pos_emb.pe_k.weight)
+            dpe.index_add_(0, window[1], dwin[:2 * T - 1])
+            put(enc.pos_emb.pe_k.weight, dpe)
         if ds.active:
             ops.dropout_apply(dx, ds.cfg("embed"))
         dwe, dbe, dg, dbeta = bw.embed_bwd(S["f"], dx, S["mean"], S["rinv"], S["we_bf"], enc.embed[0].bias.detach(),

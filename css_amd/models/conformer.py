@@ -92,11 +92,12 @@ class ConformerEncoder(nn.Module):  # conformer.py:110-150
         super().__init__()
         if causal:
             raise NotImplementedError("causal ConvModule is never used by the reference path")
-        if not relative_pos_emb:
-            raise NotImplementedError("css_amd builds the relative-position attention only (reference default)")
         self.embed = nn.Sequential(nn.Linear(idim, attention_dim), nn.LayerNorm(attention_dim),
                                    nn.Dropout(dropout_rate), nn.ReLU())
-        self.pos_emb = _RelPos(attention_dim // attention_heads, 1000)
+        # conformer.py:131-137.  Without relative positions the kernels run against an all-zero position table: the band
+        # term q . pe is then exactly 0.0 and the scores are q . k / sqrt(d_k), conformer.py:236 (no extra kernel family
+        # for an option no recipe of the reference selects)
+        self.pos_emb = _RelPos(attention_dim // attention_heads, 1000) if relative_pos_emb else None
         self.encoders = nn.Sequential(*[
             _EncoderLayer(attention_dim, attention_heads, linear_units, kernel_size, dropout_rate)
             for _ in range(num_blocks)])
@@ -212,7 +213,7 @@ class Conformer(nn.Module):
         w.d_model, w.n_head, w.d_ffn = enc.d_model, enc.n_head, enc.d_ffn
         w.n_layer, w.kernel_size = len(enc.encoders), enc.kernel_size
         w.n_out = self.linear.out_features
-        pe_packed, w.pe_q_min, w.pe_q_max = ops.pack_relpos(enc.pos_emb.pe_k.weight, enc.pos_emb.maxlen)
+        pe_packed, w.pe_q_min, w.pe_q_max = ops.pack_relpos(self.position_table(), 1000)
         w.bn_mode = 1 if self.training else 0
         w.fuse_conv = int(getattr(self, "fuse_conv", 0))
         ew = torch.zeros(enc.d_model, w.idim_pad, device=dev)
@@ -225,6 +226,13 @@ class Conformer(nn.Module):
         self._packed = (w, layers, keep)
         self._packed_key = key
         return self._packed
+
+    def position_table(self):
+        """pe_k [2 * maxlen, d_k] (conformer.py:179-185), or zeros when the model has no relative positions."""
+        enc = self.conformer
+        if enc.pos_emb is not None:
+            return enc.pos_emb.pe_k.weight.detach()
+        return torch.zeros(2000, enc.d_model // enc.n_head, device=self.linear.weight.device)
 
     # ------------------------------------------------------------------ forward
     def forward_masks(self, f, want_encoder_out=False):

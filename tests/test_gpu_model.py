@@ -339,6 +339,40 @@ def test_conformer_hip_backward_matches_oracle_autograd():
     del ref_state
 
 
+def test_conformer_without_relative_positions():
+    """`relative_pos_emb=False` (conformer.py:131-137, 236: scores = q . k / sqrt(d_k)): no pe_k parameter, eval forward
+    and train-mode gradients vs the oracle run the same way."""
+    from css_amd.models import MODELS
+    from css_amd.objectives import OBJECTIVES
+    import grad_ref
+    conf = dict(attention_dim=256, attention_heads=4, linear_units=1024, num_blocks=2, kernel_size=33, dropout_rate=0.1,
+                relative_pos_emb=False)
+    m = MODELS["Conformer"](257, 257, 2, 1, conf)
+    sd = syn.fill_state_dict(syn.conformer_shapes(num_blocks=2, relative_pos_emb=False), 47)
+    assert not any("pe_k" in k for k in m.state_dict()) and set(m.state_dict()) == set(sd)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    f = rnd((2, 90, 257), 15).abs()
+    want = torch.cat(oracle.conformer.forward(f, sd, num_blocks=2, relative_pos_emb=False)[1], -1)
+    with_pos = torch.cat(oracle.conformer.forward(f, dict(sd, **{"conformer.pos_emb.pe_k.weight": 0.3 * rnd((2000, 64), 5)}),
+                                                  num_blocks=2)[1], -1)
+    got = m.forward_masks(f.to(DEV))
+    print(f"[parity] no relative positions: mask MSE {mask_mse(got, want):.3e} (vs the relative model {mask_mse(with_pos, want):.3e})")
+    assert mask_mse(got, want) < 1e-4 and mask_mse(with_pos, want) > 10 * mask_mse(got, want)
+    m.train()
+    tg = [(rnd((2, 90, 257), 60 + k).abs() * 0.5).to(DEV) for k in range(2)]
+    obj = OBJECTIVES["MSE"].build_objective({})
+    loss = obj(m, {"mix": f.to(DEV), "source1": tg[0], "source2": tg[1]}, device=DEV)
+    loss.backward()
+    grads = {k: p.grad.clone() for k, p in m.named_parameters()}
+    perm = obj.last_permutation.cpu().tolist()
+    tc = [t.cpu() for t in tg]
+    ref = grad_ref.oracle_param_grads(m, lambda mk: grad_ref.pit_loss_with_perm(mk, f, tc, perm), f.to(DEV), training_bn=True)
+    err, worst = grad_ref.compare(grads, ref)
+    print(f"[parity] no relative positions: gradients vs oracle autograd {err:.3e}, worst {worst[0]} {worst[1]:.3e}")
+    assert err < 6e-2
+
+
 def test_unsupported_widths_raise_instead_of_falling_back():
     """There is no torch-op arithmetic path in the package: a training forward the backward kernels do not cover raises."""
     from css_amd.models import MODELS
