@@ -148,6 +148,14 @@ class ConformerTrain(torch.autograd.Function):
         S["pe_bf"] = pe.to(BF)
         S["pe_pack"] = pe_pack
         bn_means, bn_vars, bn_cnt, bn_new_m, bn_new_v = [], [], [], [], []
+        # small per-block operands for ALL blocks in a handful of launches (was 3 tiny launches per block): the fused
+        # q | k | v bias with the q part pre-scaled, and the depthwise taps as [k][D] (lanes read consecutive channels)
+        lays = list(enc.encoders)
+        qs = lays[0].self_attn.d_k ** -0.5
+        bqkv_all = torch.cat([torch.stack([l_.self_attn.linear_q.bias.detach() for l_ in lays]) * qs,
+                              torch.stack([l_.self_attn.linear_k.bias.detach() for l_ in lays]),
+                              torch.stack([l_.self_attn.linear_v.bias.detach() for l_ in lays])], 1)
+        dww_all = torch.stack([l_.conv.dw_conv_1d.weight.detach().view(D, K) for l_ in lays]).transpose(1, 2).contiguous()
         for li, (lay, wp) in enumerate(zip(enc.encoders, pack["layers"])):
             L = {}
 
@@ -171,7 +179,7 @@ class ConformerTrain(torch.autograd.Function):
             a = lay.self_attn
             scale = a.d_k ** -0.5
             wqkv_bf, wqkv_p, wo_bf, wo_p = wp["wqkv_bf"], wp["wqkv_p"], wp["wo_bf"], wp["wo_p"]
-            bqkv = torch.cat([a.linear_q.bias.detach() * scale, a.linear_k.bias.detach(), a.linear_v.bias.detach()], 0)
+            bqkv = bqkv_all[li]
             if wide:
                 a2, _ = ops.layernorm(x1, a.layer_norm.weight.detach(), a.layer_norm.bias.detach())
                 qkv = ops.gemm(a2, wqkv_bf, bqkv, out_bf16=True)
@@ -192,7 +200,7 @@ class ConformerTrain(torch.autograd.Function):
             c = lay.conv
             W = {"ln_g": c.layer_norm.weight.detach(), "ln_b": c.layer_norm.bias.detach(),
                  "pw1_w": c.pw_conv_1.weight.detach().view(2), "pw1_b": c.pw_conv_1.bias.detach(),
-                 "dw_w": c.dw_conv_1d.weight.detach().view(D, K).t().contiguous(), "dw_b": c.dw_conv_1d.bias.detach(),
+                 "dw_w": dww_all[li], "dw_b": c.dw_conv_1d.bias.detach(),
                  "bn_g": c.BN.weight.detach(), "bn_b": c.BN.bias.detach(),
                  "bn_mean": c.BN.running_mean, "bn_var": c.BN.running_var,
                  "pw2_w": c.pw_conv_2.weight.detach().view(1), "pw2_b": c.pw_conv_2.bias.detach()}
@@ -293,9 +301,8 @@ class ConformerTrain(torch.autograd.Function):
             dx, g = bw.mha_bwd(x1, dx, qkv.view(B, T, 3 * D), ao, a.layer_norm.weight.detach(),
                                a.layer_norm.bias.detach(), wqkv_bf, wo_bf, S["pe_bf"], H, scale, window=window,
                                probs=(S["pe_pack"], lse), skew_buf=skew_buf, drop_p=ds.cfg(f"{li}.attn.p"),
-                               drop_out=ds.cfg(f"{li}.attn.out"))
-            dg, dbeta, dwqkv, dbqkv, dwo, dbo, dw_l = g
-            dwin = dw_l if dwin is None else dwin.add_(dw_l)
+                               drop_out=ds.cfg(f"{li}.attn.out"), dwin_acc=dwin)
+            dg, dbeta, dwqkv, dbqkv, dwo, dbo, dwin = g   # dwin: the window gradient summed over the blocks so far
             put(a.layer_norm.weight, dg), put(a.layer_norm.bias, dbeta)
             for i, lin in enumerate((a.linear_q, a.linear_k, a.linear_v)):
                 put(lin.weight, dwqkv[i * D:(i + 1) * D]), put(lin.bias, dbqkv[i * D:(i + 1) * D])

@@ -73,7 +73,7 @@ def relpos_window(pe_table_bf, T, maxlen):
     return win, idx
 
 
-def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000, window=None, probs=None, ao=None, skew_buf=None,
+def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000, window=None, probs=None, ao=None, skew_buf=None, dwin_acc=None,
                  drop_p=None):
     """Backward of o = softmax(q k^T + q pe[i-j]^T) v (conformer.py:229-253; q already carries 1/sqrt(d_k)).
 
@@ -112,7 +112,8 @@ def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000, window=None, probs=
     dq1 = ob.bgemm(ds[..., :T], k, b_kmajor=True)                       # dS k
     ob.bgemm(dsk.permute(0, 2, 1, 3), win[None, None], b_kmajor=True, add=dq1, out=dq)   # + dS_skew pe_window
     q_rows = g[:, :, 0].reshape(B * T * H, 64)                          # rows ordered (b, t, h) like dsk
-    dwin = ob.bgemm(dsk.view(B * T * H, W), q_rows, a_kmajor=True, b_kmajor=True)        # [W, 64]
+    # [W, 64]; dwin_acc (the sum over the blocks already back-propagated) is added by the product's epilogue, in place
+    dwin = ob.bgemm(dsk.view(B * T * H, W), q_rows, a_kmajor=True, b_kmajor=True, add=dwin_acc, out=dwin_acc)
     if window is not None:
         return dqkv, dwin  # the caller accumulates window gradients over the layers and scatters once
     dpe = torch.zeros((2 * maxlen, 64), dtype=torch.float32, device=qkv.device)
@@ -121,7 +122,7 @@ def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000, window=None, probs=
 
 
 def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_scale=0.125, window=None, probs=None,
-            skew_buf=None, fused_softmax_bwd=True, drop_p=None, drop_out=None):
+            skew_buf=None, fused_softmax_bwd=True, drop_p=None, drop_out=None, dwin_acc=None):
     """out = x + attention(LN(x)) @ wo^T + bo  (conformer.py:213-254,356).
 
     wqkv_bf holds the q rows already multiplied by q_scale (as the forward uses them); the returned dwqkv / dbqkv are
@@ -135,7 +136,7 @@ def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_s
     B = qkv.shape[0]
     if drop_p is not None and (probs is None or not fused_softmax_bwd):
         raise NotImplementedError("css_amd: dropout of the attention probabilities needs the attention-shaped backward")
-    dqkv, dpe = mha_core_bwd(qkv, dao, pe_table_bf, n_head, window=window, probs=probs,
+    dqkv, dpe = mha_core_bwd(qkv, dao, pe_table_bf, n_head, window=window, probs=probs, dwin_acc=dwin_acc,
                              ao=ao if fused_softmax_bwd else None, skew_buf=skew_buf, drop_p=drop_p)
     dq2 = dqkv.view(-1, 3 * D)
     a, _ = ops.layernorm(x, ln_g, ln_b)

@@ -255,7 +255,7 @@ def mha_relpos_probs(qkv, pe_pack, lse, n_head, drop=None):
     assert qkv.is_contiguous() and lse.is_contiguous() and D3 == 3 * n_head * 64
     ldp = (T + 7) // 8 * 8
     p = torch.empty(B, n_head, T, ldp, device=qkv.device, dtype=torch.bfloat16)
-    pd = torch.zeros_like(p) if drop is not None else None
+    pd = torch.empty_like(p) if drop is not None else None  # the kernel writes every element p has
     check(lib().csship_mha_relpos_probs_drop(_ptr(qkv), _ptr(packed), q_min, q_max, _ptr(lse), _ptr(p), _ptr(pd), ldp, B,
                                              T, n_head, drop, _stream()))
     return p if drop is None else (p, pd)
