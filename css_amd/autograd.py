@@ -105,6 +105,22 @@ def _conformer_pack_plan(model, wide, device):
     return ent
 
 
+def bn_counters(model):
+    """ONE int64 tensor behind the `num_batches_tracked` buffers of all conv modules (the buffers become views of it, same
+    state_dict keys and values): the per-step increment is one launch instead of one per BatchNorm (torch's foreach ops
+    have no multi-tensor path for int64).  Rebuilt when the module was moved or its buffers were replaced."""
+    bns = [lay.conv.BN for lay in model.conformer.encoders]
+    flat = getattr(model, "_bn_cnt_flat", None)
+    if flat is None or flat.device != bns[0].num_batches_tracked.device or \
+            any(b.num_batches_tracked._base is not flat for b in bns):
+        with torch.no_grad():
+            flat = torch.stack([b.num_batches_tracked for b in bns])
+        for i, b in enumerate(bns):
+            b._buffers["num_batches_tracked"] = flat[i]
+        model._bn_cnt_flat = flat
+    return flat
+
+
 class ConformerTrain(torch.autograd.Function):
     """masks = Conformer(f) with the explicit HIP backward.  model.training selects BatchNorm batch statistics (running
     statistics updated) and the reference's dropouts (css_amd/dropout.py) or, in eval mode, the frozen running
@@ -147,7 +163,7 @@ class ConformerTrain(torch.autograd.Function):
         pe_pack = ops.pack_relpos(pe, 1000)
         S["pe_bf"] = pe.to(BF)
         S["pe_pack"] = pe_pack
-        bn_means, bn_vars, bn_cnt, bn_new_m, bn_new_v = [], [], [], [], []
+        bn_means, bn_vars, bn_new_m, bn_new_v = [], [], [], []
         # small per-block operands for ALL blocks in a handful of launches (was 3 tiny launches per block): the fused
         # q | k | v bias with the q part pre-scaled, and the depthwise taps as [k][D] (lanes read consecutive channels)
         lays = list(enc.encoders)
@@ -210,7 +226,7 @@ class ConformerTrain(torch.autograd.Function):
             L["conv"] = (x2, W, fws)
             if batch_bn:
                 stats = fws.view(torch.float32)[-4 * D:]
-                bn_means.append(c.BN.running_mean), bn_vars.append(c.BN.running_var), bn_cnt.append(c.BN.num_batches_tracked)
+                bn_means.append(c.BN.running_mean), bn_vars.append(c.BN.running_var)
                 bn_new_m.append(stats[2 * D:3 * D]), bn_new_v.append(stats[3 * D:])
             x4 = ffn(lay.feed_forward_out, x3, "ffn_out")
             _, x = ops.layernorm(x4, lay.layer_norm.weight.detach(), lay.layer_norm.bias.detach(), out_bf16=False,
@@ -222,7 +238,7 @@ class ConformerTrain(torch.autograd.Function):
                 torch._foreach_mul_(bn_means + bn_vars, 0.9)
                 torch._foreach_add_(bn_means, bn_new_m, alpha=0.1)
                 torch._foreach_add_(bn_vars, bn_new_v, alpha=0.1 * M_bn / max(M_bn - 1, 1))
-                torch._foreach_add_(bn_cnt, 1)
+                bn_counters(model).add_(1)
         n_out = model.linear.out_features
         wh_bf, wh_p = pack["wh_bf"], pack["wh_p"]
         ld = (n_out + 3) // 4 * 4

@@ -30,6 +30,9 @@ class GraphedTrainStep:
         optim.capturable = True
         # warm-up steps outside the capture (allocator pools, lazy initialisation) must not train: snapshot every
         # piece of state they touch and put it back
+        if hasattr(model, "conformer"):   # buffers that the training forward re-homes must be in place before the snapshot
+            from ..autograd import bn_counters
+            bn_counters(model)
         snap = [t.clone() for t in (optim.flat_param, optim.exp_avg, optim.exp_avg_sq)]
         bufs = [(b, b.clone()) for b in model.buffers()]
         step0 = optim._step

@@ -322,11 +322,17 @@ def test_conformer_hip_backward_matches_oracle_autograd():
     tg = [(rnd((B, T, 257), 60 + k).abs() * 0.5).to(DEV) for k in range(2)]
     obj = OBJECTIVES["MSE"].build_objective({})
     rm0 = m.conformer.encoders[0].conv.BN.running_mean.clone()
+    cnt0 = [int(l.conv.BN.num_batches_tracked) for l in m.conformer.encoders]
     ref_state = {k: v.clone() for k, v in m.state_dict().items()}  # the oracle must see the PRE-step running statistics
     loss = obj(m, {"mix": f, "source1": tg[0], "source2": tg[1]}, device=DEV)
     assert isinstance(loss.grad_fn, torch.autograd.graph.Node) and loss.requires_grad
     loss.backward()
     assert not torch.equal(rm0, m.conformer.encoders[0].conv.BN.running_mean)   # BatchNorm bookkeeping happened
+    assert [int(l.conv.BN.num_batches_tracked) for l in m.conformer.encoders] == [c + 1 for c in cnt0]
+    sdn = m.state_dict()   # the counters are views of one tensor now: keys, dtypes and values as before
+    assert all(sdn[f"conformer.encoders.{i}.conv.BN.num_batches_tracked"].dtype == torch.int64 and
+               int(sdn[f"conformer.encoders.{i}.conv.BN.num_batches_tracked"]) == cnt0[i] + 1 for i in range(2))
+    m.load_state_dict({k: v.clone() for k, v in sdn.items()})
     grads = {k: p.grad.clone() for k, p in m.named_parameters()}
     assert all(g is not None and torch.isfinite(g).all() for g in grads.values())
     perm = obj.last_permutation.cpu().tolist()
