@@ -122,7 +122,8 @@ def test_config3_seven_channel_full_size():
 
 def test_config4_long_recording_747_windows():
     """configs[3]: one 600 s recording -> 747 sliding windows (2.4 s / 0.8 s hop) -> Separator (batches of 64) ->
-    Stitcher.  Window-batch independence (a second pass with batch 13, whose batches are ragged), windows 0-5 and the
+    Stitcher.  Window-batch independence (the default pass takes 256 windows per launch sequence whatever the
+    configured batch size; a second pass 13 at a time, whose batches are ragged), windows 0-5 and the
     last window vs the oracle, stitched length and the 1e-4 winner-take-all floor of stitcher.py:71-84."""
     from css_amd.executor import Separator, Stitcher
     m, sd = _conformer(2, 84)
@@ -136,7 +137,7 @@ def test_config4_long_recording_747_windows():
     with torch.no_grad():
         masks, mags = Separator(cfg, sr, device=DEV, backend="hip", model=m).separate(rec)
         cfg2 = dict(cfg, batch_size=13)
-        masks_b, mags_b = Separator(cfg2, sr, device=DEV, backend="hip", model=m).separate(rec)
+        masks_b, mags_b = Separator(cfg2, sr, device=DEV, backend="hip", model=m, device_batch=13).separate(rec)
     assert masks.shape == (747, 257, 150, 3) and mags.shape == (747, 257, 150)
     assert torch.equal(mags, mags_b) and float(((masks - masks_b) ** 2).mean()) < 1e-5
     assert bool(torch.isfinite(masks).all()) and float(masks.max()) <= 1.0

@@ -274,7 +274,7 @@ def test_onnx_layout_session_adapter_matches_hip_backend():
     cfg = {"batch_size": 1, "eval_win": 2.4, "eval_hop": 0.8, "frame_length": 512, "frame_shift": 256}
     rec, _ = syn.synthetic_sources(1, 12800 * 2 + 38656, seed=9)   # 3 windows
     with torch.no_grad():
-        m_hip, g_hip = Separator(cfg, 16000, device=DEV, backend="hip", model=model).separate(rec)
+        m_hip, g_hip = Separator(cfg, 16000, device=DEV, backend="hip", model=model, device_batch=1).separate(rec)
         m_onx, g_onx = Separator(cfg, 16000, device=DEV, backend="onnx", model=model).separate(rec)
     assert m_onx.shape == m_hip.shape == (3, 257, 150, 3) and torch.equal(g_hip, g_onx)
     assert float((m_onx - m_hip).abs().max()) < 1e-5
