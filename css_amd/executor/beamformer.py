@@ -8,6 +8,7 @@ rescale energies, rescale + deduplication, iSTFT (csship_istft).  The overlap-ad
 and the final peak normalisation are slice assignments on the GPU (plumbing).
 """
 
+import numpy as np
 import torch
 import torch.nn.functional as F_
 
@@ -27,6 +28,7 @@ class Beamformer:
         self.eval_hop = int(beamforming_config["eval_hop"] * sr)
         self.proceed_margin = int(beamforming_config["proceed_margin"] * sr)
         self.batch_size = beamforming_config["batch_size"]
+        self.use_graph, self._graph = True, None   # full batches replay one captured launch sequence (_batch_waveforms)
         self.sr = sr
         self.mask_hop = int(self.eval_hop / self.hop_length)
         self.mask_win = int(self.eval_win / self.hop_length)
@@ -101,6 +103,39 @@ class Beamformer:
                 out.append((pm - eh, eh))
         return out
 
+    def _batch_waveforms(self, windows, mwin, first, last):
+        """Beamformed waveforms of windows first..last-1 (both speakers), 2 x nb x samples.  Every full batch has the same
+        shapes, so its ~14 launches (STFT, three SCMs, two solves, two applications, rescale / dedup, two iSTFTs) are
+        captured once into a HIP graph and replayed from static input buffers: the stage is launch-bound (a batch is
+        33 windows), a 10-minute session spends 21 ms in it eagerly."""
+        nb = min(last, windows.shape[0]) - first   # `last` may point one past the final window
+        key = (nb, tuple(windows.shape[1:]), tuple(mwin[0].shape[1:]), windows.device)
+        full = nb == self.batch_size + 1
+        st = self._graph if full and self._graph is not None and self._graph["key"] == key else None
+        if full and st is None and self.use_graph and not torch.cuda.is_current_stream_capturing():
+            xs = windows[first:last].contiguous()
+            ms = [m[first:last].contiguous() for m in mwin]
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                      # warm-up outside the capture (allocator pools)
+                self._eager_waveforms(xs, ms)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self._eager_waveforms(xs, ms)
+            st = self._graph = {"key": key, "graph": g, "x": xs, "m": ms, "out": out}
+        if st is None:
+            return self._eager_waveforms(windows[first:last].contiguous(), [m[first:last].contiguous() for m in mwin])
+        st["x"].copy_(windows[first:last])
+        for dst, m in zip(st["m"], mwin):
+            dst.copy_(m[first:last])
+        st["graph"].replay()
+        return st["out"]
+
+    def _eager_waveforms(self, xb, ms):
+        ys = self._pair(xb, *ms)
+        return torch.stack([ops.istft(yr, yi)[:, : xb.shape[-1]] for yr, yi in ys])
+
     def continuous_process(self, X, masks):
         """X: D x T waveform; masks: (speech_mask1, speech_mask2, noise_mask), each F x frames.
         Returns two 1 x T waveforms, peak-normalised to 0.9."""
@@ -112,20 +147,27 @@ class Beamformer:
         res = torch.zeros((2, T), device=X.device)
         for first in range(0, W, self.batch_size):
             last = min(first + self.batch_size, W) + 1          # the reference processes one window of the next batch too
-            xb = windows[first:last].contiguous()
-            ys = self._pair(xb, *(m[first:last].contiguous() for m in mwin))
-            wavs = torch.stack([ops.istft(yr, yi)[:, : xb.shape[-1]] for yr, yi in ys])   # 2 x nb x samples
+            wavs = self._batch_waveforms(windows, mwin, first, last)                     # 2 x nb x samples
             nb, ns = wavs.shape[1], wavs.shape[2]
             # gather every window's kept piece in ONE index_add per batch (a window shared by two batches adds twice,
             # exactly as the reference's overlapping loop does)
+            # index arithmetic on the host (no per-window launches, no mask-select sync), one transfer per batch
             src, dst = [], []
             for i, (off, length) in enumerate(self._spans(first, nb, T, batch_end=last)):
                 length = ns - off if length is None else min(length, ns - off)
-                k = torch.arange(length, device=X.device)
+                d0 = self.eval_hop * (first + i) + off
+                length = min(length, T - d0)            # samples past the end of the recording are dropped
+                if length <= 0:
+                    continue
+                k = np.arange(length, dtype=np.int64)
                 src.append(i * ns + off + k)
-                dst.append(self.eval_hop * (first + i) + off + k)
-            src, dst = torch.cat(src), torch.cat(dst)
-            keep = dst < T
-            res.index_add_(1, dst[keep], wavs.reshape(2, nb * ns)[:, src[keep]])
-        res = res * (0.9 / res.abs().amax(dim=1, keepdim=True))
+                dst.append(d0 + k)
+            if not src:
+                continue
+            src = torch.from_numpy(np.concatenate(src)).to(X.device, non_blocking=True)
+            dst = torch.from_numpy(np.concatenate(dst)).to(X.device, non_blocking=True)
+            res.index_add_(1, dst, wavs.reshape(2, nb * ns)[:, src])
+        # peak per output: two full reductions (a dim-1 amax over 2 x T runs as two single-block scans: 1.6 ms at T = 9.6 M)
+        peak = torch.stack([res[0].abs().max(), res[1].abs().max()])[:, None]
+        res = res * (0.9 / peak)
         return res[0:1], res[1:2]

@@ -216,9 +216,12 @@ def test_inference_pipeline_end_to_end():
     mixed = mod.session(6.0).to(DEV)
     cfg = mod.config()
     with torch.no_grad():
-        (w0, w1), n_win = mod.run(mixed, model, cfg)
+        (w0, w1), n_win = mod.run(mixed, mod.executors(model, cfg))
         cfg["separation"]["batch_size"] = 1          # the reference's ONNX restriction: one window per call
-        (v0, v1), _ = mod.run(mixed, model, cfg)
+        ex1 = mod.executors(model, cfg)
+        ex1[0].device_batch = 1                      # ... really one window per launch sequence
+        ex1[2].use_graph = False                     # and the beamformer launch by launch
+        (v0, v1), _ = mod.run(mixed, ex1)
     assert n_win == 5 and w0.shape == w1.shape == (1, mixed.shape[1])
     assert bool(torch.isfinite(w0).all()) and bool(torch.isfinite(w1).all())
     assert abs(float(w0.abs().max()) - 0.9) < 1e-5 and abs(float(w1.abs().max()) - 0.9) < 1e-5

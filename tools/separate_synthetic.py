@@ -41,11 +41,13 @@ def session(seconds, sr=16000, seed=0):
     return syn.synthetic_multichannel(src, n_ch=7, seed=seed)[0]           # [7, T]
 
 
-def run(mixed, model, cfg):
-    sr = cfg["sampling_rate"]
-    separator = Separator(cfg["separation"], sr=sr, model=model)
-    stitcher = Stitcher(cfg["stitching"])
-    beamformer = Beamformer(cfg["beamforming"])
+def executors(model, cfg):
+    return (Separator(cfg["separation"], sr=cfg["sampling_rate"], model=model), Stitcher(cfg["stitching"]),
+            Beamformer(cfg["beamforming"]))
+
+
+def run(mixed, ex):
+    separator, stitcher, beamformer = ex
     window_masks, mag_specs = separator.separate(mixed)
     perm = stitcher.get_stitch(mag_specs, window_masks)
     stitched = stitcher.get_connect(perm, window_masks)
@@ -64,10 +66,11 @@ if __name__ == "__main__":
     model = model.cuda().eval()
     mixed = session(a.seconds).cuda()
     with torch.no_grad():
-        run(mixed, model, config())  # warm-up
+        ex = executors(model, config())   # built once per process, like the reference's script (separate_libricss.py:55-63)
+        run(mixed, ex)  # warm-up (the beamformer captures its per-batch launch sequence here)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        (w0, w1), n_win = run(mixed, model, config())
+        (w0, w1), n_win = run(mixed, ex)
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(f"{mixed.shape[1] / 16000:.1f} s of 7-channel audio, {n_win} windows -> 2 x {w0.shape[1]} samples in {dt * 1e3:.1f} ms "
