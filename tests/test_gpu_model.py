@@ -284,6 +284,38 @@ def test_train_one_epoch_matches_reference_trace():
     assert np.allclose(losses, tr["train_losses"], rtol=5e-3)
 
 
+def test_train_one_epoch_replays_a_graph_with_fused_adam():
+    """train_one_epoch with css_amd.optim.FusedAdam captures the step once per batch shape and replays it: same losses and
+    parameters, bit for bit, as the same loop launched kernel by kernel (args.graph = False), with the warm-up learning-rate
+    schedule changing the rate every step and dropout on (the seed advances inside the graph)."""
+    import types
+    from css_amd.objectives import OBJECTIVES
+    from css_amd.optim import FusedAdam
+    from css_amd.trainer import LRScheduler, train_one_epoch
+
+    def gen():
+        i = 0
+        while True:
+            yield {"mix": rnd((2, 40, 257), 200 + i).abs().to(DEV), "source1": (rnd((2, 40, 257), 300 + i).abs() * 0.5).to(DEV),
+                   "source2": (rnd((2, 40, 257), 400 + i).abs() * 0.5).to(DEV), "ovl": 0.5}
+            i += 1
+
+    def run(graph):
+        m, _ = build(2, 61)
+        m.train()
+        opt = FusedAdam(m.parameters(), lr=1e-3, max_norm=5.0)
+        sch = LRScheduler(opt, types.SimpleNamespace(warmup=3, decay=0.0, fixed=0, min_lr=1e-9))
+        targs = types.SimpleNamespace(gpu=True, fp16=False, batches_per_epoch=2, grad_thresh=5.0, graph=graph)
+        g = gen()
+        obj = OBJECTIVES["MSE"].build_objective({})
+        losses = [train_one_epoch(targs, g, m, obj, opt, sch, DEV) for _ in range(3)]
+        return losses, opt.flat_param.clone(), len(getattr(opt, "_graphed_steps", {}))
+    l_e, p_e, n_e = run(False)
+    l_g, p_g, n_g = run(True)
+    assert n_e == 0 and n_g == 1
+    assert l_e == l_g and torch.equal(p_e, p_g)
+
+
 def test_conformer_gradients_flow_and_match_oracle_autograd():
     """Gradient check of the training path on a 1-block Conformer with BatchNorm frozen (model.eval() +
     eval_gradients): loss.backward() fills every parameter's grad, and the gradients agree with torch.autograd through
