@@ -1341,12 +1341,25 @@ __global__ __launch_bounds__(NW * 64) void embed_kernel(EmbedArgs a) {
     for (int rt = 0; rt < 4; ++rt) acc[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int kc = 0; kc < nkc; ++kc) {
     if (kc > 0) __syncthreads();  // the previous chunk's panel has been consumed
+    // rows of f are only 4-byte aligned (idim = 257, 1799): ONE 16-byte load per operand and four columns (unaligned
+    // dwordx4 is fine, and the memory pipeline takes the same ~18 cycles per wave-wide load whatever its width); column
+    // groups that lie wholly beyond idim (all of the last chunk but its first columns) are zero without any load
+    struct __attribute__((packed, aligned(4))) f4u { float v[4]; };
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int c4 = i * 8 + part, k = kc * DM + c4 * 4;
-      float e[4];
+      float e[4] = {0.f, 0.f, 0.f, 0.f};
+      if (kc * DM + i * 32 < a.idim) {  // wave-uniform
+        if (k + 3 < a.idim) {
+          const f4u fv = *reinterpret_cast<const f4u*>(fr + k), mv = *reinterpret_cast<const f4u*>(a.mean + sb + k),
+                    rv = *reinterpret_cast<const f4u*>(a.rinv + sb + k);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) e[q] = (k + q < a.idim) ? (fr[k + q] - a.mean[sb + k + q]) * a.rinv[sb + k + q] : 0.f;
+          for (int q = 0; q < 4; ++q) e[q] = (fv.v[q] - mv.v[q]) * rv.v[q];
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) e[q] = (k + q < a.idim) ? (fr[k + q] - a.mean[sb + k + q]) * a.rinv[sb + k + q] : 0.f;
+        }
+      }
       *reinterpret_cast<uint2*>(Xs + panel_off(r, c4 >> 1) + (c4 & 1) * 8) = make_uint2(pack_bf2(e[0], e[1]), pack_bf2(e[2], e[3]));
     }
     __syncthreads();
