@@ -136,6 +136,46 @@ __global__ __launch_bounds__(256) void pit_sse_kernel(PitArgs a) {
     a.partial[((size_t)b * a.nchunk + chunk) * (K * K) + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
+// double-precision lane reductions on the data-parallel primitives (a double __shfl_xor is two ds_bpermute round trips of
+// ~120 cycles in a dependent chain; this tiny kernel is nothing but such chains)
+template <int CTRL>
+DEV double dpp_mov_d(double v) {
+  const unsigned long long u = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, true);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
+  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+DEV double sum8_d(double v) {  // over aligned groups of 8 lanes, result in all of them
+  v += dpp_mov_d<DPP_XOR1>(v);
+  v += dpp_mov_d<DPP_XOR2>(v);
+  v += dpp_mov_d<DPP_HALF_MIRROR>(v);
+  return v;
+}
+DEV double swap_sum_d(double v, bool row32) {  // v + the value of the lane 16 (or 32) away
+  const unsigned long long u = __double_as_longlong(v);
+  unsigned p[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const unsigned x = (unsigned)(u >> (32 * h));
+    if (row32) {
+      auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+      const unsigned a0 = r[0], a1 = r[1];
+      p[h] = a0 ^ a1 ^ x;   // {a0, a1} = {own word, partner's word} in a lane-dependent order: xor with x leaves the partner's
+    } else {
+      auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+      const unsigned a0 = r[0], a1 = r[1];
+      p[h] = a0 ^ a1 ^ x;
+    }
+  }
+  return v + __longlong_as_double(((unsigned long long)p[1] << 32) | p[0]);
+}
+DEV double wave_sum_d(double v) {
+  v = sum8_d(v);
+  v += dpp_mov_d<DPP_MIRROR>(v);
+  v = swap_sum_d(v, false);
+  return swap_sum_d(v, true);
+}
+
 // Eight lanes per sample reduce its partials (double, fixed order), one of them scans the K! permutations in
 // itertools.permutations order (first minimum wins, like torch.min), then thread 0 averages.  Single workgroup.
 template <int K>
@@ -169,11 +209,7 @@ DEV void pit_finalize_body(const float* __restrict__ partial, int B, int nchunk,
     }
   for (int k = 0; k < K; ++k)
     for (int j = 0; j < K; ++j) {
-      double v = Dm[k][j];
-      v += __shfl_xor(v, 1);
-      v += __shfl_xor(v, 2);
-      v += __shfl_xor(v, 4);
-      Dm[k][j] = v;
+      Dm[k][j] = sum8_d(Dm[k][j]);
     }
   if (b < B && part == 0) {
     if (pair_sse)
@@ -208,8 +244,7 @@ DEV void pit_finalize_body(const float* __restrict__ partial, int B, int nchunk,
   }
   }
   // batch mean: fixed-order tree (lanes, then waves) instead of one thread re-reading per_sample from memory
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) acc_best += __shfl_xor(acc_best, o);
+  acc_best = wave_sum_d(acc_best);
   if ((threadIdx.x & 63) == 0) best_sum[threadIdx.x >> 6] = acc_best;
   __syncthreads();
   if (threadIdx.x == 0) *loss = (float)(((best_sum[0] + best_sum[1]) + (best_sum[2] + best_sum[3])) / (double)B);
