@@ -5,280 +5,40 @@
 //     score[i,j] = q_i.k_j + q_i.pe[clamp(i-j,-maxlen,maxlen-1)+maxlen]      (q pre-scaled)
 //     out[i]     = softmax_j(score[i,:]) @ v
 //
-// One 256-thread workgroup = 4 waves per (b, h, 64 queries); wave w owns 16 queries.
+// mha_fwd_kernel below (8 or 4 waves per workgroup, a pair of 16-query blocks per wave):
 //   * everything is computed TRANSPOSED so the softmax'd tile is already the MFMA B
 //     operand of the P.V product (no LDS round trip for P):
-//         S^T[j,i]  = K_tile[j,:]  . Q[i,:]      4 x (16 keys x 16 queries) per 64-key tile
+//         S^T[j,i]  = K_tile[j,:]  . Q[i,:]      4 x (16 keys x 16 queries) per 64-key tile and query block
 //         Pb^T[c,i] = PE_band[c,:] . Q[i,:]      5 x (16 rel. offsets x 16 queries)
 //         O^T[d,i] += V^T[d,j] P^T[j,i]          V^T fragments come from ds_read_b64_tr_b16
 //   * the position term only depends on i-j: for a 16-query x 64-key block the 79 distinct
 //     offsets form a band c = 15 - a + jl (a = query in block, jl = key in tile).  Because
 //     query blocks and key tiles start at multiples of 16, every band tile is one ALIGNED,
 //     REVERSED block of 16 consecutive pe rows; the host packs those blocks in MFMA fragment
-//     order with the clamp baked in (css_amd.ops.pack_relpos), so the band operand is a
-//     coalesced 1 KB global->VGPR load per fragment: no LDS staging, no per-element clamp.
-//     The band product is skew-read from a per-wave fp32 scratch (the "rel-shift" without a
-//     T x T x d_k table);
-//   * K/V tiles are register-prefetched one tile ahead (issue-early / write-late), V is kept
-//     in a 32-byte-group XOR swizzle that makes the transposed reads conflict free;
+//     order with the clamp baked in (css_amd.ops.pack_relpos): no per-element clamp, no
+//     T x T x d_k table.  The band product reaches the score accumulators through a per-wave
+//     fp32 scratch whose STORES do the rel-shift;
+//   * V is kept in a 32-byte-group XOR swizzle that makes the transposed reads conflict free;
 //   * online softmax over key tiles; key padding mask is always None on this path
 //     (conformer.py:97), only the T tail of the last tile is masked.
+// The first-generation kernel of round 1 (4 waves per (b, h, 64 queries), band fragments straight from global memory,
+// 29.9 us at 32 x 4 x 400 against 24.7) was removed once the backward's probability recompute moved here too (PROBS).
 #include "common.hpp"
 #include <stdlib.h>
 
 namespace {
 
-constexpr int PS = 84;  // per-wave band scratch row stride (floats): 336 B rows -> 8 consecutive rows hit 8 distinct 16-B slots
 constexpr float LOG2E = 1.4426950408889634f;
 
 DEV int v_off(int row, int chunk) {  // 16-byte chunk of a 128-byte V row; 32-byte groups XOR (row>>1)&3
   return row * 128 + ((((chunk >> 1) ^ ((row >> 1) & 3)) << 1) | (chunk & 1)) * 16;
 }
 
-// PROBS = false: the attention itself (optionally also the per-row log-sum-exp, for the backward pass).
-// PROBS = true: no P.V; the normalised probabilities P[b,h,i,j] = exp(score - lse[b,h,i]) are written out as bf16
-// [B,H,T,ldp] - the backward's recomputation of the softmax, with the same band machinery and no [T,T] f32 buffers.
-template <bool PROBS>
-__global__ __launch_bounds__(256, 4) void mha_relpos_kernel(const unsigned short* __restrict__ qkv,
-                                                         const bf16x8* __restrict__ pe_packed, int q_min, int q_max,
-                                                         unsigned short* __restrict__ out, int B, int T, int H,
-                                                            unsigned long long* stamps, float* __restrict__ lse,
-                                                            int64_t ldp, unsigned short* __restrict__ pdrop = nullptr,
-                                                            csship_dropout_cfg dcfg = csship_dropout_cfg{nullptr, 0u, 0.f}) {
-  __shared__ __attribute__((aligned(16))) unsigned char sK[64 * 128];
-  __shared__ __attribute__((aligned(16))) unsigned char sV[64 * 128];
-  __shared__ __attribute__((aligned(16))) float sP[4 * 16 * PS];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps block indices / addresses scalar
-  const int g = lane >> 4, n = lane & 15;
-  const int i0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
-  const int D = H * 64, D3 = 3 * D;
-  const int i0w = i0 + 16 * w;
-  const size_t base_b = (size_t)b * T;
-
-  // Q fragments (MFMA B operand): lane (g,n) holds Q[i0w+n][ks*32 + 8g .. +7]
-  bf16x8 qf[2];
-  {
-    const int qi = min(i0w + n, T - 1);
-    const unsigned short* qrow = qkv + (base_b + qi) * D3 + h * 64;
-    qf[0] = *reinterpret_cast<const bf16x8*>(qrow + 8 * g);
-    qf[1] = *reinterpret_cast<const bf16x8*>(qrow + 32 + 8 * g);
-  }
-
-  // K/V staging: thread owns chunks (row = idx>>3, c = idx&7), idx = tid and tid + 256.  Named registers
-  // (not arrays captured by a lambda: those are demoted to scratch memory and serialise the prefetch).
-  // Per-lane base pointers are formed once; a key tile only adds a uniform offset (tail tile: clamped rows).
-  const int srow0 = tid >> 3, srow1 = srow0 + 32, sc = tid & 7;
-  const unsigned short* kv0 = qkv + (base_b + srow0) * D3 + h * 64 + sc * 8 + D;
-  const unsigned short* kv1 = qkv + (base_b + srow1) * D3 + h * 64 + sc * 8 + D;
-  uint4 kreg0, kreg1, vreg0, vreg1;
-#define ATTN_LOAD_KV(J0)                                                                                  \
-  {                                                                                                       \
-    const unsigned short *s0_, *s1_;                                                                      \
-    if ((J0) + 64 <= T) { /* uniform: whole tile inside the utterance */                                  \
-      s0_ = kv0 + (size_t)(J0) * D3;                                                                      \
-      s1_ = kv1 + (size_t)(J0) * D3;                                                                      \
-    } else {                                                                                              \
-      s0_ = qkv + (base_b + min((J0) + srow0, T - 1)) * D3 + h * 64 + sc * 8 + D;                         \
-      s1_ = qkv + (base_b + min((J0) + srow1, T - 1)) * D3 + h * 64 + sc * 8 + D;                         \
-    }                                                                                                     \
-    kreg0 = *reinterpret_cast<const uint4*>(s0_);                                                         \
-    kreg1 = *reinterpret_cast<const uint4*>(s1_);                                                         \
-    if constexpr (!PROBS) {                                                                               \
-      vreg0 = *reinterpret_cast<const uint4*>(s0_ + D);                                                   \
-      vreg1 = *reinterpret_cast<const uint4*>(s1_ + D);                                                   \
-    }                                                                                                     \
-  }
-#define ATTN_STORE_KV()                                                       \
-  {                                                                           \
-    *reinterpret_cast<uint4*>(sK + tile_off(srow0, sc)) = kreg0;              \
-    *reinterpret_cast<uint4*>(sK + tile_off(srow1, sc)) = kreg1;              \
-    if constexpr (!PROBS) {                                                   \
-      *reinterpret_cast<uint4*>(sV + v_off(srow0, sc)) = vreg0;               \
-      *reinterpret_cast<uint4*>(sV + v_off(srow1, sc)) = vreg1;               \
-    }                                                                         \
-  }
-  // band fragments of key tile j0: band tile t covers rel = 16*q + 15 - m, q = (i0w - j0)/16 - t (scalar)
-  bf16x8 pf0[5], pf1[5];
-  const bf16x8* pe_lane = pe_packed + lane;
-#define ATTN_LOAD_PE(PF, KSI, J0)                                                 \
-  {                                                                               \
-    const int qb_ = (i0w - (J0)) / 16; /* exact: both are multiples of 16 */      \
-    _Pragma("unroll") for (int t = 0; t < 5; ++t) {                               \
-      const int qi_ = min(max(qb_ - t, q_min), q_max) - q_min;                    \
-      PF[t] = pe_lane[(size_t)(qi_ * 2 + (KSI)) * 64];                            \
-    }                                                                             \
-  }
-
-  f32x4 o[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run = -1e30f, l_run = 0.f;
-  float lse2 = 0.f;  // PROBS: this lane's query log-sum-exp in log2 units
-  if constexpr (PROBS) lse2 = lse[((size_t)b * H + h) * T + min(i0w + n, T - 1)] * LOG2E;
-  float* Pw = sP + w * 16 * PS;
-  const float* Pr = Pw + n * PS + 15 - n + 4 * g;  // this lane's skewed read base: + 16t + r
-  const int q4 = n >> 2, p4 = n & 3;
-
-  stamp(stamps, 0);
-  ATTN_LOAD_KV(0)
-  ATTN_LOAD_PE(pf0, 0, 0)
-  ATTN_STORE_KV()
-  __syncthreads();
-
-  stamp(stamps, 1);
-  for (int j0 = 0; j0 < T; j0 += 64) {
-    const bool more = j0 + 64 < T;
-    ATTN_LOAD_PE(pf1, 1, j0)  // second half of this tile's band operands: lands during the first band MFMAs
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- position band Pb^T = PE_band Q^T  -> per-wave scratch Pw[query n][c], c = 16t + 4g + r
-    f32x4 pb[5];
-#pragma unroll
-    for (int t = 0; t < 5; ++t) pb[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < 5; ++t) pb[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf0[t], qf[0], pb[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < 5; ++t) pb[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf1[t], qf[1], pb[t], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (more) ATTN_LOAD_KV(j0 + 64)  // next K/V tile: in flight during S, softmax and P.V; written to LDS after them
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < 5; ++t) *reinterpret_cast<f32x4*>(Pw + n * PS + 16 * t + 4 * g) = pb[t];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    // ---- S^T = bias (skew-read of the band, as the accumulator's initial value) + K Q^T
-    f32x4 s[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) s[t] = f32x4{Pr[16 * t], Pr[16 * t + 1], Pr[16 * t + 2], Pr[16 * t + 3]};
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(sK + tile_off(16 * t + n, ks * 4 + g));
-        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], s[t], 0, 0, 0);
-      }
-    }
-    if (!more) {  // only the last key tile has a tail: real branch (uniform), no selects on the main path
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (j0 + 16 * t + 4 * g + r >= T) s[t][r] = -1e30f;
-      asm volatile("" ::: "memory");
-    }
-
-    if constexpr (PROBS) {  // P = exp(score - lse), 4 consecutive keys per store; the T tail is exactly 0
-      const int qi_ = i0w + n;
-      if (qi_ < T) {
-        const size_t poff = (((size_t)b * H + h) * T + qi_) * ldp + j0 + 4 * g;
-        unsigned short* prow = out + poff;
-        const Drop dp = drop_make(dcfg.seed, dcfg.stream, dcfg.p);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          if (j0 + 16 * t + 4 * g + 3 < ldp) {
-            const float p0 = __builtin_amdgcn_exp2f(s[t][0] * LOG2E - lse2), p1 = __builtin_amdgcn_exp2f(s[t][1] * LOG2E - lse2);
-            const float p2 = __builtin_amdgcn_exp2f(s[t][2] * LOG2E - lse2), p3 = __builtin_amdgcn_exp2f(s[t][3] * LOG2E - lse2);
-            uint2 v;
-            v.x = pack_bf2(p0, p1);
-            v.y = pack_bf2(p2, p3);
-            *reinterpret_cast<uint2*>(prow + 16 * t) = v;
-            if (pdrop != nullptr) {  // training with dropout: the masked, rescaled probabilities (operand of dV = P~^T dO)
-              const float4 pd = drop_apply4(dp, (unsigned)(poff + 16 * t), make_float4(p0, p1, p2, p3));
-              uint2 vd;
-              vd.x = pack_bf2(pd.x, pd.y);
-              vd.y = pack_bf2(pd.z, pd.w);
-              *reinterpret_cast<uint2*>(pdrop + poff + 16 * t) = vd;
-            }
-          }
-      }
-    } else {
-    // ---- online softmax (query i = lane&15; keys spread over regs and g)
-    float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
-#pragma unroll
-    for (int t = 1; t < 4; ++t) mx = fmaxf(mx, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
-    const float mscaled = m_new * LOG2E;
-    float psum = 0.f;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = __builtin_amdgcn_exp2f(s[t][r] * LOG2E - mscaled);
-        s[t][r] = p;
-        psum += p;
-      }
-    if (__any(m_new != m_run)) {  // rescale only when some query's running maximum moved
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
-      l_run *= alpha;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] *= alpha;
-      m_run = m_new;
-    }
-    l_run += psum;
-
-    // ---- O^T += V^T P^T.  k index of the MFMA <-> key j = 32ks + 16*(e>>2) + 4g + (e&3)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 pbf;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        pbf[e] = (__bf16)s[2 * ks][e];
-        pbf[4 + e] = (__bf16)s[2 * ks + 1][e];
-      }
-      const int r0 = 32 * ks + 4 * g + q4, r1 = r0 + 16;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        // 4 bf16 (8 B) at column 16dt + 4p4 of rows r0 / r1: chunk 2dt + (p4>>1), half-chunk p4&1
-        const unsigned char* a0 = sV + v_off(r0, 2 * dt + (p4 >> 1)) + (p4 & 1) * 8;
-        const unsigned char* a1 = sV + v_off(r1, 2 * dt + (p4 >> 1)) + (p4 & 1) * 8;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a1));
-        const s16x8 av = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), pbf, o[dt], 0, 0, 0);
-      }
-    }
-    }  // !PROBS
-
-    if (more) {
-      ATTN_LOAD_PE(pf0, 0, j0 + 64)  // first half of the next tile's band operands; lands during the barriers
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();  // everyone is done reading this tile's K/V
-      ATTN_STORE_KV()
-      __syncthreads();
-    }
-  }
-
-  stamp(stamps, 2);
-  if constexpr (PROBS) return;
-  float l = l_run;
-  l += __shfl_xor(l, 16);
-  l += __shfl_xor(l, 32);
-  const float inv = 1.f / l;
-  const int qi = i0w + n;
-  if (lse != nullptr && qi < T && g == 0) lse[((size_t)b * H + h) * T + qi] = m_run + __logf(l);
-  if (qi < T) {
-    unsigned short* orow = out + (base_b + qi) * D + h * 64;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      uint2 v;
-      v.x = pack_bf2(o[dt][0] * inv, o[dt][1] * inv);
-      v.y = pack_bf2(o[dt][2] * inv, o[dt][3] * inv);
-      *reinterpret_cast<uint2*>(orow + 16 * dt + 4 * g) = v;
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// Forward attention, second generation (the inference / training forward; mha_relpos_kernel above stays for the
-// backward's recomputation of the probabilities).
+// Forward attention, second generation (inference / training forward, and with PROBS the backward's recomputation of the
+// probabilities).
 //
-// What changed against mha_relpos_kernel, and why (rocprof / PMC of round 1: 29.9 us per launch at 32 x 4 x 400,
+// What changed against round 1's mha_relpos_kernel, and why (rocprof / PMC of round 1: 29.9 us per launch at 32 x 4 x 400,
 // MFMA pipe 21 % busy, 4.0x the algorithmic traffic, two workgroup barriers per 64-key tile; ablation builds of this
 // kernel, tools/attn_ablate.sh: the position band alone cost 8 of 25 us while its 12 fragment loads per wave and tile
 // came straight from global memory - the CU's texture-address path takes ~18 cycles per wave-wide load):
@@ -348,12 +108,16 @@ DEV float xmax16(float x) {  // max over the four 16-lane rows of the wave (same
 // probabilities, so the row sums keep the undropped values and only the P.V operands are masked; the 1 / (1 - p) goes on
 // the output.  Element index of P[b, h, i, j]: ((b*H + h)*T + i) * pad8(T) + j (the layout of the backward's probability
 // buffer).
-template <int NW, bool DROP>
+// PROBS (backward pass): the probabilities themselves, P = exp(score - lse) from the training forward's log-sum-exp, as
+// bf16 rows of `out` = [B, H, T, ldp] (and with DROP the masked, rescaled copy `pdrop`, the operand of dV) - no online
+// softmax, no P.V; same staging, band pipeline and tiling.
+template <int NW, bool DROP, bool PROBS = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mha_fwd_kernel(const unsigned short* __restrict__ qkv,
                                                             const bf16x8* __restrict__ pe_packed, int q_min, int q_max,
                                                             unsigned short* __restrict__ out, float* __restrict__ lse,
                                                             int BH, int T, int H, int G, int ppw,
-                                                            unsigned long long* stamps, csship_dropout_cfg dcfg) {
+                                                            unsigned long long* stamps, csship_dropout_cfg dcfg,
+                                                            unsigned short* __restrict__ pdrop = nullptr, int ldp = 0) {
   constexpr int CH = 512 / (NW * 64);  // 16-byte chunks of a K (and of a V) tile staged per thread
   constexpr int R = 2 * NW + 8;        // ring slots (position blocks of 2 x 1 KB): 2 NW + 4 live + 4 arriving
   constexpr int NF = 8 / NW;           // new fragments staged per wave and tile
@@ -466,6 +230,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mha_fwd_kernel(const
       ebase[qb] = ((unsigned)bh * (unsigned)T + (unsigned)min(i0w + 16 * qb + n, T - 1)) * Tp + 4u * (unsigned)g;
   }
   float m_run[2] = {-1e30f, -1e30f};
+  float lse2[2] = {0.f, 0.f};  // PROBS: log-sum-exp of this lane's two queries, in log2 units
+  if constexpr (PROBS) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) lse2[qb] = lse[(size_t)bh * T + min(i0w + 16 * qb + n, T - 1)] * LOG2E;
+  }
   bf16x8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
@@ -577,6 +346,36 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mha_fwd_kernel(const
     }
     A2_T(0)
 
+    if constexpr (PROBS) {
+      // P = exp2(S log2e - lse log2e); a lane holds 4 consecutive keys of one query per key block: one 8-byte store each.
+      // Keys in [T, ldp) come out as exact zeros (their scores were set to -1e30 above), columns >= ldp are not written.
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        const int qi = i0w + 16 * qb + n;
+        const size_t poff = (((size_t)bh) * T + min(qi, T - 1)) * (size_t)ldp + j0 + 4 * g;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float pv[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(s[qb][t][r] * LOG2E - lse2[qb]);
+          if (owner && qi < T && j0 + 16 * t + 4 * g + 3 < ldp) {
+            *reinterpret_cast<uint2*>(out + poff + 16 * t) = make_uint2(pack_bf2(pv[0], pv[1]), pack_bf2(pv[2], pv[3]));
+            if constexpr (DROP) {
+              const float4 pd = drop_apply4(dp, (unsigned)(poff + 16 * t), make_float4(pv[0], pv[1], pv[2], pv[3]));
+              *reinterpret_cast<uint2*>(pdrop + poff + 16 * t) = make_uint2(pack_bf2(pd.x, pd.y), pack_bf2(pd.z, pd.w));
+            }
+          }
+        }
+      }
+      if (!(A2_ABL & 1)) A2_BAND()
+      if (more) {
+        A2_STORE_KV(cur ^ 1)
+        if (j0 + 128 < T) A2_STORE_RING(j0 + 128)
+        __syncthreads();
+      }
+      continue;
+    }
+
     // ---- online softmax, part 1: running maxima and (rarely) the rescale of what has been accumulated
     float mscaled[2];
 #pragma unroll
@@ -687,7 +486,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mha_fwd_kernel(const
 #undef A2_STORE_RING
 
   stamp(stamps, 2);
-  if (!owner) return;
+  if (!owner || PROBS) return;
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     const float l = lsum[qb][0];
@@ -734,9 +533,30 @@ static int launch_mha_fwd(const uint16_t* qkv, const uint16_t* pe_packed, int q_
   return CSSHIP_OK;
 }
 
-static bool attn_v1() {  // diagnostic switch: CSSHIP_ATTN_V1=1 runs the first-generation forward kernel (A/B timing)
-  static const bool v = [] { const char* e = getenv("CSSHIP_ATTN_V1"); return e && e[0] == '1'; }();
-  return v;
+// the probabilities of the backward pass through the same kernel (PROBS)
+static int launch_mha_probs(const uint16_t* qkv, const uint16_t* pe_packed, int q_min, int q_max, const float* lse,
+                            uint16_t* p, uint16_t* pdrop, int64_t ldp, int B, int T, int H, hipStream_t s,
+                            const csship_dropout_cfg* drop) {
+  const int P = (T + 31) / 32, BH = B * H;
+  const int G8 = (P + 7) / 8, G4 = (P + 3) / 4;
+  const bool four = (BH * G8 <= 128) && (G4 > G8);
+  const int G = four ? G4 : G8, ppw = (P + G - 1) / G;
+  const long long nwg = (long long)BH * G;
+  if (nwg > 0x7fffffffLL || ldp > 0x7fffffffLL) return CSSHIP_EBADSHAPE;
+  const bool dropping = drop != nullptr && drop->seed != nullptr && drop->p > 0.f && pdrop != nullptr;
+  if ((int64_t)BH * T * ldp > 0xffffffffLL && dropping) return CSSHIP_EBADSHAPE;  // 32-bit element indices of the mask
+  const csship_dropout_cfg dc = dropping ? *drop : csship_dropout_cfg{nullptr, 0u, 0.f};
+  const bf16x8* pe = reinterpret_cast<const bf16x8*>(pe_packed);
+  float* lse_ = const_cast<float*>(lse);
+#define A2_PROBS(NWV, DR) hipLaunchKernelGGL((mha_fwd_kernel<NWV, DR, true>), dim3((unsigned)nwg), dim3(NWV * 64), 0, s, qkv, pe, \
+                                             q_min, q_max, p, lse_, BH, T, H, G, ppw, nullptr, dc, pdrop, (int)ldp)
+  if (four && dropping) A2_PROBS(4, true);
+  else if (four) A2_PROBS(4, false);
+  else if (dropping) A2_PROBS(8, true);
+  else A2_PROBS(8, false);
+#undef A2_PROBS
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
 }
 
 // ---- softmax backward of the attention, attention-shaped (backward pass; replaces a [B,H,T,T] f32 dP buffer):
@@ -841,13 +661,7 @@ extern "C" int csship_mha_relpos(const uint16_t* qkv, const uint16_t* pe_packed,
   if (!qkv || !pe_packed || !out) return CSSHIP_ENULL;
   if (B <= 0 || T <= 0 || H <= 0 || q_max < q_min || B > 65535 || H > 65535) return CSSHIP_EBADSHAPE;
   if (!aligned16(qkv) || !aligned16(pe_packed) || !aligned8(out)) return CSSHIP_EALIGN;
-  if (!attn_v1()) return launch_mha_fwd(qkv, pe_packed, q_min, q_max, out, nullptr, B, T, H, g_csship_stamps, as_stream(stream));
-  dim3 grid((T + 63) / 64, H, B);
-  hipLaunchKernelGGL(mha_relpos_kernel<false>, grid, dim3(256), 0, as_stream(stream), qkv,
-                     reinterpret_cast<const bf16x8*>(pe_packed), q_min, q_max, out, B, T, H, g_csship_stamps, nullptr,
-                     (int64_t)0);
-  CSSHIP_CHECK_LAUNCH();
-  return CSSHIP_OK;
+  return launch_mha_fwd(qkv, pe_packed, q_min, q_max, out, nullptr, B, T, H, g_csship_stamps, as_stream(stream));
 }
 
 extern "C" int csship_mha_relpos_train(const uint16_t* qkv, const uint16_t* pe_packed, int32_t q_min, int32_t q_max,
@@ -862,13 +676,7 @@ extern "C" int csship_mha_relpos_train_drop(const uint16_t* qkv, const uint16_t*
   if (!qkv || !pe_packed || !out || !lse) return CSSHIP_ENULL;
   if (B <= 0 || T <= 0 || H <= 0 || q_max < q_min || B > 65535 || H > 65535) return CSSHIP_EBADSHAPE;
   if (!aligned16(qkv) || !aligned16(pe_packed) || !aligned8(out)) return CSSHIP_EALIGN;
-  if (!attn_v1() || (drop && drop->seed && drop->p > 0.f))
-    return launch_mha_fwd(qkv, pe_packed, q_min, q_max, out, lse, B, T, H, nullptr, as_stream(stream), drop);
-  dim3 grid((T + 63) / 64, H, B);
-  hipLaunchKernelGGL(mha_relpos_kernel<false>, grid, dim3(256), 0, as_stream(stream), qkv,
-                     reinterpret_cast<const bf16x8*>(pe_packed), q_min, q_max, out, B, T, H, nullptr, lse, (int64_t)0);
-  CSSHIP_CHECK_LAUNCH();
-  return CSSHIP_OK;
+  return launch_mha_fwd(qkv, pe_packed, q_min, q_max, out, lse, B, T, H, nullptr, as_stream(stream), drop);
 }
 
 extern "C" int csship_mha_relpos_probs(const uint16_t* qkv, const uint16_t* pe_packed, int32_t q_min, int32_t q_max,
@@ -887,13 +695,8 @@ extern "C" int csship_mha_relpos_probs_drop(const uint16_t* qkv, const uint16_t*
   if (p_dropped_bf16 && !aligned8(p_dropped_bf16)) return CSSHIP_EALIGN;
   if (B <= 0 || T <= 0 || H <= 0 || q_max < q_min || B > 65535 || H > 65535 || ld_p < T) return CSSHIP_EBADSHAPE;
   if (!aligned16(qkv) || !aligned16(pe_packed) || !aligned8(p_bf16) || (ld_p % 4) != 0) return CSSHIP_EALIGN;
-  dim3 grid((T + 63) / 64, H, B);
-  hipLaunchKernelGGL(mha_relpos_kernel<true>, grid, dim3(256), 0, as_stream(stream), qkv,
-                     reinterpret_cast<const bf16x8*>(pe_packed), q_min, q_max, p_bf16, B, T, H, nullptr,
-                     const_cast<float*>(lse), ld_p, dropping ? p_dropped_bf16 : nullptr,
-                     dropping ? *drop : csship_dropout_cfg{nullptr, 0u, 0.f});
-  CSSHIP_CHECK_LAUNCH();
-  return CSSHIP_OK;
+  return launch_mha_probs(qkv, pe_packed, q_min, q_max, lse, p_bf16, dropping ? p_dropped_bf16 : nullptr, ld_p, B, T, H,
+                          as_stream(stream), drop);
 }
 
 extern "C" int csship_attn_softmax_bwd(const uint16_t* qkv, const uint16_t* d_out, const uint16_t* p_bf16, int64_t ld_p,
