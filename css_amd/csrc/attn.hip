@@ -638,10 +638,18 @@ __global__ __launch_bounds__(256, 4) void attn_ds_kernel(const unsigned short* _
         const unsigned short d0 = f2bf(p0 * (dpv.x - dval)), d1 = f2bf(p1 * (dpv.y - dval));
         const unsigned short d2 = f2bf(p2 * (dpv.z - dval)), d3 = f2bf(p3 * (dpv.w - dval));
         *reinterpret_cast<uint2*>(ds + prow + j) = make_uint2((unsigned)d0 | ((unsigned)d1 << 16), (unsigned)d2 | ((unsigned)d3 << 16));
-        if (j < T) skrow[-j] = d0;
-        if (j + 1 < T) skrow[-j - 1] = d1;
-        if (j + 2 < T) skrow[-j - 2] = d2;
-        if (j + 3 < T) skrow[-j - 3] = d3;
+        // skewed copy: keys j .. j+3 are positions r .. r-3 of the query's row, i.e. ONE 8-byte piece (d3 d2 d1 d0) that is
+        // only 2-byte aligned (its start is i + T - 4 - j): an unaligned global_store_dwordx2 instead of four 2-byte stores
+        if (j + 3 < T) {
+          struct __attribute__((packed, aligned(2))) h4u { unsigned short v[4]; };
+          h4u sk;
+          sk.v[0] = d3; sk.v[1] = d2; sk.v[2] = d1; sk.v[3] = d0;
+          *reinterpret_cast<h4u*>(skrow - j - 3) = sk;
+        } else {
+          if (j < T) skrow[-j] = d0;
+          if (j + 1 < T) skrow[-j - 1] = d1;
+          if (j + 2 < T) skrow[-j - 2] = d2;
+        }
       }
     }
     if (more) {

@@ -90,6 +90,25 @@ def bench_attn():
         print(f"mha_relpos B={b_} T={t_}  {us:8.1f} us  {fl / us / 1e6:8.1f} TFLOP/s (algorithmic)")
 
 
+def bench_attn_bwd():
+    """the two attention-shaped kernels of the backward pass: probability recompute and softmax backward + skewed copy"""
+    from css_amd import ops_bwd as ob
+    H, B_, T_ = 4, 32, 400
+    pe = ops.pack_relpos(0.3 * torch.randn(2000, 64, device=DEV))
+    qkv = torch.randn(B_, T_, 3 * H * 64, device=DEV)
+    qkv[..., :256] *= 0.125
+    qkv = qkv.to(torch.bfloat16)
+    ao, lse = ops.mha_relpos_train(qkv, pe, H)
+    us = timeit(lambda: ops.mha_relpos_probs(qkv, pe, lse, H))
+    print(f"mha_relpos_probs B={B_} T={T_}  {us:8.1f} us")
+    p = ops.mha_relpos_probs(qkv, pe, lse, H)
+    dao = torch.randn(B_, T_, H * 64, device=DEV).to(torch.bfloat16)
+    d = ob.attn_rowdot(dao, ao, B_, T_, H)
+    skew = torch.zeros(B_, T_, H, 800, device=DEV, dtype=torch.bfloat16)
+    us = timeit(lambda: ob.attn_softmax_bwd(qkv, dao, p, d, skew, H))
+    print(f"attn_softmax_bwd (dS + skewed copy) B={B_} T={T_}  {us:8.1f} us")
+
+
 def bench_chain():
     """The dominant kernel of the step: FFN_out + block LayerNorm -> FFN_in -> LayerNorm + q/k/v (conformer.py:322-326,355-360,222-225)."""
     x = torch.randn(M, D, device=DEV)
@@ -147,7 +166,7 @@ def bench_ln():
     print(f"layernorm  {us:8.1f} us  {M * D * 6 / us / 1e3:8.1f} GB/s")
 
 
-ALL = {"chain": bench_chain, "ffn": bench_ffn, "linear": bench_linear, "attn": bench_attn, "conv": bench_conv, "stft": bench_stft,
+ALL = {"chain": bench_chain, "ffn": bench_ffn, "linear": bench_linear, "attn": bench_attn, "attn_bwd": bench_attn_bwd, "conv": bench_conv, "stft": bench_stft,
        "pit": bench_pit, "ln": bench_ln}
 
 if __name__ == "__main__":
