@@ -120,10 +120,13 @@ class Beamformer:
             with torch.cuda.stream(side):                      # warm-up outside the capture (allocator pools)
                 self._eager_waveforms(xs, ms)
             torch.cuda.current_stream().wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out = self._eager_waveforms(xs, ms)
-            st = self._graph = {"key": key, "graph": g, "x": xs, "m": ms, "out": out}
+            try:   # thread_local: other threads of the process (an RCCL watchdog) may touch the runtime meanwhile
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    out = self._eager_waveforms(xs, ms)
+                st = self._graph = {"key": key, "graph": g, "x": xs, "m": ms, "out": out}
+            except RuntimeError:   # not capturable in this process: launch by launch from now on
+                self.use_graph = False
         if st is None:
             return self._eager_waveforms(windows[first:last].contiguous(), [m[first:last].contiguous() for m in mwin])
         st["x"].copy_(windows[first:last])
