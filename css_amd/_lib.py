@@ -136,6 +136,7 @@ SIGNATURES = {
     "csship_adam_clip_workspace": (_sz, [_i64]),
     "csship_adam_clip": (_i32, [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _f32, _p, _p, _p, _sz, _p]),
     "csship_mvdr_scm": (_i32, [_p, _p, _p, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _p, _p, _p]),
+    "csship_mvdr_scm_multi": (_i32, [_p, _p, _p, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _p, _p, _p]),
     "csship_mvdr_souden": (_i32, [_p, _p, _p, _i64, _i32, _i32, _f32, _p, _p]),
     "csship_mvdr_apply_workspace": (_sz, [_i32, _i32, _i32]),
     "csship_mvdr_apply": (_i32, [_p, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p]),

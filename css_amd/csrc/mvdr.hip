@@ -12,11 +12,21 @@
 
 namespace {
 
+// up to four masks over the same spectra in one launch (blockIdx.z picks the mask and its outputs): the beamformer
+// needs the noise and the two speech covariances of every batch, and one mask's grid is 5 x B workgroups
+struct ScmSet {
+  const float* mask[4];
+  float* scm[4];
+  float* msum[4];
+};
+
 template <int D>
-__global__ __launch_bounds__(256) void scm_kernel(const float* __restrict__ xr, const float* __restrict__ xi,
-                                                  const float* __restrict__ mask, int64_t ldm, int64_t mask_bs, int T,
-                                                  int Tx, int F, float diag, int normalize, float* __restrict__ scm,
-                                                  float* __restrict__ msum) {
+__global__ __launch_bounds__(256) void scm_kernel(const float* __restrict__ xr, const float* __restrict__ xi, ScmSet set,
+                                                  int64_t ldm, int64_t mask_bs, int T, int Tx, int F, float diag,
+                                                  int normalize) {
+  const float* __restrict__ mask = set.mask[blockIdx.z];
+  float* __restrict__ scm = set.scm[blockIdx.z];
+  float* __restrict__ msum = set.msum[blockIdx.z];
   constexpr int NTRI = D * (D + 1) / 2;
   __shared__ float red[4][2 * NTRI + 1][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -303,10 +313,29 @@ extern "C" int csship_mvdr_scm(const float* x_re, const float* x_im, const float
                                float diag_load, int32_t normalize, float* scm, float* mask_sum, csship_stream_t stream) {
   if (!x_re || !x_im || !mask || !scm || !mask_sum) return CSSHIP_ENULL;
   if (B <= 0 || T <= 0 || T_x < T || F <= 0 || ld_mask < F || B > 65535) return CSSHIP_EBADSHAPE;
-  dim3 grid((F + 63) / 64, B);
+  const float* masks[1] = {mask};
+  float* scms[1] = {scm};
+  float* sums[1] = {mask_sum};
+  return csship_mvdr_scm_multi(x_re, x_im, masks, 1, ld_mask, mask_batch_stride, B, D, T, T_x, F, diag_load, normalize, scms, sums,
+                               stream);
+}
+
+extern "C" int csship_mvdr_scm_multi(const float* x_re, const float* x_im, const float* const* masks, int32_t n_masks,
+                                     int64_t ld_mask, int64_t mask_batch_stride, int32_t B, int32_t D, int32_t T, int32_t T_x,
+                                     int32_t F, float diag_load, int32_t normalize, float* const* scms, float* const* mask_sums,
+                                     csship_stream_t stream) {
+  if (!x_re || !x_im || !masks || !scms || !mask_sums) return CSSHIP_ENULL;
+  if (n_masks < 1 || n_masks > 4) return CSSHIP_EUNSUPPORTED;
+  if (B <= 0 || T <= 0 || T_x < T || F <= 0 || ld_mask < F || B > 65535) return CSSHIP_EBADSHAPE;
+  ScmSet set{};
+  for (int i = 0; i < n_masks; ++i) {
+    if (!masks[i] || !scms[i] || !mask_sums[i]) return CSSHIP_ENULL;
+    set.mask[i] = masks[i]; set.scm[i] = scms[i]; set.msum[i] = mask_sums[i];
+  }
+  dim3 grid((F + 63) / 64, B, n_masks);
   hipStream_t s = as_stream(stream);
-  MVDR_DISPATCH_D(D, hipLaunchKernelGGL((scm_kernel<DD>), grid, dim3(256), 0, s, x_re, x_im, mask, ld_mask, mask_batch_stride, T, T_x, F,
-                                        diag_load, normalize, scm, mask_sum))
+  MVDR_DISPATCH_D(D, hipLaunchKernelGGL((scm_kernel<DD>), grid, dim3(256), 0, s, x_re, x_im, set, ld_mask, mask_batch_stride, T, T_x,
+                                        F, diag_load, normalize))
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }

@@ -48,10 +48,9 @@ class Beamformer:
         xr, xi = self._stft(x)
         L = min(xr.shape[2], m0.shape[-1])
         mt = [m.transpose(1, 2).contiguous() for m in (m0, m1, mn)]  # [B,Tm,F]
-        noise, _ = mv.scm(xr, xi, mt[2], T=L)
+        (tgt0, _), (tgt1, _), (noise, _) = mv.scm_multi(xr, xi, mt, T=L)   # three covariances, one launch
         ys, es = [], []
-        for k in range(2):
-            tgt, _ = mv.scm(xr, xi, mt[k], T=L)
+        for k, tgt in enumerate((tgt0, tgt1)):
             w = mv.souden(tgt, noise, trace_eps=1e-8)
             yr, yi, e = mv.apply(xr, xi, w, mask=mt[k], T=L)
             ys.append((yr, yi))

@@ -1,4 +1,6 @@
 """Torch-tensor front door to the MVDR kernels of libcsship.so (css_amd/csrc/mvdr.hip)."""
+import ctypes as C
+
 import torch
 
 from ._lib import check, lib
@@ -28,6 +30,25 @@ def scm(x_re, x_im, mask, T=None, normalize=True, diag_load=0.0):
     check(lib().csship_mvdr_scm(_ptr(x_re), _ptr(x_im), _ptr(mask), mask.stride(1), mask.stride(0), B, D, T, Tx, F,
                                 float(diag_load), int(normalize), _ptr(out), _ptr(msum), _stream()))
     return torch.view_as_complex(out), msum
+
+
+def scm_multi(x_re, x_im, masks, T=None, normalize=True, diag_load=0.0):
+    """scm() for up to four masks of equal shape and strides over the same spectra, ONE launch: list of (scm, mask_sum)."""
+    B, D, Tx, F = _xcheck(x_re, x_im)
+    T = Tx if T is None else T
+    n = len(masks)
+    if not 1 <= n <= 4:
+        raise RuntimeError("css_amd: scm_multi takes 1..4 masks")
+    for m in masks:
+        _mcheck(m, B, T, F)
+        if m.stride() != masks[0].stride():
+            raise RuntimeError("css_amd: scm_multi needs masks with equal strides")
+    outs = [torch.empty((B, F, D, D, 2), dtype=torch.float32, device=x_re.device) for _ in range(n)]
+    sums = [torch.empty((B, F), dtype=torch.float32, device=x_re.device) for _ in range(n)]
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])  # noqa: E731
+    check(lib().csship_mvdr_scm_multi(_ptr(x_re), _ptr(x_im), arr(masks), n, masks[0].stride(1), masks[0].stride(0), B, D, T, Tx,
+                                      F, float(diag_load), int(normalize), arr(outs), arr(sums), _stream()))
+    return [(torch.view_as_complex(o), s_) for o, s_ in zip(outs, sums)]
 
 
 def souden(target_scm, noise_scm, noise_scm2=None, ref_mic=0, trace_eps=1e-8):

@@ -661,6 +661,11 @@ int csship_adam_clip(float* params, const float* grads, float* exp_avg, float* e
 int csship_mvdr_scm(const float* x_re, const float* x_im, const float* mask, int64_t ld_mask,
                     int64_t mask_batch_stride, int32_t B, int32_t D, int32_t T, int32_t T_x, int32_t F,
                     float diag_load, int32_t normalize, float* scm, float* mask_sum, csship_stream_t stream);
+/* The same for n_masks <= 4 masks over the same spectra in ONE launch (HOST arrays of device pointers; equal strides):
+ * the noise and the two speech covariances of a beamformer batch (beamformer.py:151-159). */
+int csship_mvdr_scm_multi(const float* x_re, const float* x_im, const float* const* masks, int32_t n_masks, int64_t ld_mask,
+                          int64_t mask_batch_stride, int32_t B, int32_t D, int32_t T, int32_t T_x, int32_t F, float diag_load,
+                          int32_t normalize, float* const* scms, float* const* mask_sums, csship_stream_t stream);
 /* Souden MVDR weights w[bin] = Z[:, ref_mic] / (trace(Z) + trace_eps), Z = (noise_scm [+ noise_scm2])^-1 target_scm,
  * for n_bins = B*F bins (fp64 elimination with partial pivoting); w: interleaved complex f32 [n_bins, D, 2]. */
 int csship_mvdr_souden(const float* target_scm, const float* noise_scm, const float* noise_scm2, int64_t n_bins,

@@ -100,6 +100,8 @@ def test_mvdr_kernels_vs_reference_numpy_twin(golden):
     tgt, ms = mv.scm(xr, xi, mt[0], normalize=False, diag_load=1e-15)
     itf, _ = mv.scm(xr, xi, mt[1], normalize=False, diag_load=1e-15)
     noi, _ = mv.scm(xr, xi, mt[2], normalize=False, diag_load=1e-15)
+    multi = mv.scm_multi(xr, xi, mt, normalize=False, diag_load=1e-15)   # the three covariances from ONE launch: bitwise
+    assert all(torch.equal(a_, b_) for (a_, _), b_ in zip(multi, (tgt, itf, noi))) and torch.equal(multi[0][1], ms)
     ref_scm = torch.from_numpy(g["tgt_scm"])
     assert float((tgt[0].cpu() - ref_scm).abs().max()) < 1e-4 * float(ref_scm.abs().max())
     assert abs(float(ms.sum()) - float(g["mask_sum"])) < 1e-2
