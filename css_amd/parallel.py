@@ -213,14 +213,25 @@ class OverlappedGradReducer:
 
 
 def average_parameters(models_state_dicts):
-    """combine_models.py:55-82 equivalent: elementwise mean of state dicts (scalar buffers keep dtype)."""
+    """combine_models.py:55-82, statement by statement (pinned by tests/golden/combine.npz, which is the output of the
+    reference script itself on three job checkpoints):
+      * tensors with at least one dimension: zeroed (:57-59), then ``add_(p, alpha=1/n)`` job by job in the tensor's
+        own dtype (:73-76) - the f32 summation order of the reference;
+      * 0-dim tensors (BatchNorm ``num_batches_tracked``): NOT accumulated - every job REPLACES the entry with
+        ``(p * fraction).type(dtype)`` (:77-78), so the result is the LAST job's counter times 1/n, truncated
+        (three jobs at 500, 500, 501 steps -> 167).  Reproduced as is: the counter only feeds BatchNorm's
+        cumulative-average mode (momentum=None), which the reference models do not use."""
     n = len(models_state_dicts)
+    fraction = 1.0 / n
     out = {}
     for k, v in models_state_dicts[0].items():
-        acc = torch.zeros_like(v, dtype=torch.float64)
+        if v.dim() == 0:
+            out[k] = (models_state_dicts[-1][k] * fraction).type(v.dtype)
+            continue
+        acc = torch.zeros_like(v)
         for sd in models_state_dicts:
-            acc += sd[k].double() / n
-        out[k] = acc.to(v.dtype)
+            acc.add_(sd[k].to(acc.device), alpha=fraction)
+        out[k] = acc
     return out
 
 

@@ -189,3 +189,39 @@ def mvdr_inputs(D=7, F=257, T=40, seed=0):
     mix = mix * 0.3 + steer * (rs.standard_normal((1, F, T)) + 1j * rs.standard_normal((1, F, T))).astype(np.complex64)
     masks = rs.uniform(0.05, 1.0, (3, F, T)).astype(np.float32)
     return mix, masks
+
+
+def doa_inputs(sv, B=2, F=257, T=40, seed=3, dirs=((4, 4), (3, 13))):
+    """7-channel spectra X [B,7,F,T] complex64 built from plane waves of the steering table `sv` [F,A,7] and two
+    complementary soft masks [B,F,T,2] - shared by tests/golden/make_golden_separator.py and the DOA-merge tests.
+    Window 0: both masks select the same direction (one output gets silenced); window 1: two directions 120 degrees
+    apart (nothing changes)."""
+    rs = np.random.RandomState(seed)
+    s = torch.from_numpy((rs.standard_normal((2, B, F, T)) + 1j * rs.standard_normal((2, B, F, T))).astype(np.complex64))
+    X = torch.zeros((B, 7, F, T), dtype=torch.complex64)
+    mask = torch.zeros((B, F, T, 2))
+    sel = torch.from_numpy(rs.uniform(0, 1, (B, F, T)) > 0.5)
+    for b in range(B):
+        for k in range(2):
+            X[b] += sv[:, dirs[b][k], :].conj().t()[:, :, None] * s[k, b][None] * (sel[b] if k == 0 else ~sel[b])[None]
+        mask[b, ..., 0] = sel[b].float() * 0.9 + 0.05
+        mask[b, ..., 1] = (~sel[b]).float() * 0.9 + 0.05
+    X += 0.05 * torch.from_numpy((rs.standard_normal(tuple(X.shape)) + 1j * rs.standard_normal(tuple(X.shape))).astype(np.complex64))
+    return X, mask
+
+
+class FakeMaskSession:
+    """Stand-in for the onnxruntime session of separator.py:94-103 with a closed-form "model": three mask arrays of
+    shape (1, 257, L) computed from the first 257 rows of the (1, F, L) input, some of them above 1 so that the clamp
+    of separator.py:104 is exercised.  Shared by tests/golden/make_golden_separator.py (plugged into the REFERENCE
+    Separator) and the tests (plugged into css_amd's)."""
+
+    class _In:
+        name = "input"
+
+    def get_inputs(self):
+        return [self._In()]
+
+    def run(self, output_names, feed):
+        f = np.asarray(feed["input"], dtype=np.float32)[0, :257, :]
+        return [(np.abs(np.sin(f * (k + 1) + 0.3 * k)) * 1.3).astype(np.float32)[None] for k in range(3)]

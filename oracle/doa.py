@@ -1,11 +1,14 @@
 """CPU restatement of the DOA-based mask merge of css/executor/separator.py:113-250 (TEST INFRASTRUCTURE ONLY).
 
-PARITY UNPINNED: css.executor.separator cannot be imported here (its module top imports onnxruntime through
-css/utils/model_util.py:1, which is not installed) and the reference has no fixtures for it, so these functions are
-restated from the source text, line by line, including SURVEY quirk 6: ``masked_magnitude[b]`` (separator.py:200)
-indexes the FREQUENCY axis with the batch index, the sum then collapses to a scalar and ``argmin`` of a scalar is 0 -
-the reference always silences output 0 when two directions coincide.  ``fix_indexing=True`` gives the evidently
-intended behaviour (silence the output with less masked energy).
+Pinned: css.executor.separator imports onnxruntime at its top (css/utils/model_util.py:1), which is not installed;
+with a stub module of that name registered in sys.modules the reference's own Separator imports and runs in the
+build container (tests/golden/make_golden_separator.py).  tests/golden/separator.npz holds ITS steering table,
+``doa_likelihood`` (softmax off and on) and ``angle_merge`` outputs on css_amd.utils.synthetic.doa_inputs, and
+tests/test_oracle_golden.py checks the functions below against them.  SURVEY quirk 6 is part of what is pinned:
+``masked_magnitude[b]`` (separator.py:200) indexes the FREQUENCY axis with the batch index, the sum collapses to a
+scalar and ``argmin`` of a scalar is 0 - the reference always silences output 0 when two directions coincide.
+``fix_indexing=True`` gives the evidently intended behaviour (silence the output with less masked energy); that
+variant has no reference counterpart and is build-defined.
 """
 import math
 

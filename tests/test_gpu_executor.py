@@ -156,7 +156,7 @@ def test_beamformer_vs_oracle():
 
 def test_doa_merge_vs_oracle():
     """7-channel DOA merge (separator.py:113-250): steering vectors, likelihood kernel and the merge decision vs
-    oracle/doa.py (restated from the source text; parity unpinned).  Window 0: both masks select the same plane wave
+    oracle/doa.py (pinned by tests/golden/separator.npz, see test_doa_merge_vs_reference_golden).  Window 0: both masks select the same plane wave
     (outputs point the same way -> one is silenced); window 1: two sources 120 degrees apart (nothing changes)."""
     from css_amd.executor.separator import Separator
     from oracle import doa
@@ -169,21 +169,7 @@ def test_doa_merge_vs_oracle():
     sep = Separator(conf, model=_NoModel())
     sv, ang = doa.steervec_7ch(257, 30)
     assert float((sep.steervec - sv).abs().max()) < 1e-6 and torch.equal(sep.angles, ang)
-    B, F, T = 2, 257, 40
-    rs = np.random.RandomState(3)
-    s = torch.from_numpy((rs.standard_normal((2, B, F, T)) + 1j * rs.standard_normal((2, B, F, T))).astype(np.complex64))
-    # plane waves built from the steering table itself (which look direction the likelihood peaks at is the
-    # reference's convention; only "same direction" vs "120 degrees apart" matters here)
-    dirs = [(4, 4), (3, 13)]
-    X = torch.zeros((B, 7, F, T), dtype=torch.complex64)
-    mask = torch.zeros((B, F, T, 2))
-    sel = torch.from_numpy(rs.uniform(0, 1, (B, F, T)) > 0.5)
-    for b in range(B):
-        for k in range(2):
-            X[b] += sv[:, dirs[b][k], :].conj().t()[:, :, None] * s[k, b][None] * (sel[b] if k == 0 else ~sel[b])[None]
-        mask[b, ..., 0] = sel[b].float() * 0.9 + 0.05
-        mask[b, ..., 1] = (~sel[b]).float() * 0.9 + 0.05
-    X += 0.05 * torch.from_numpy((rs.standard_normal(tuple(X.shape)) + 1j * rs.standard_normal(tuple(X.shape))).astype(np.complex64))
+    X, mask = syn.doa_inputs(sv)
     re, im = X.real.contiguous().to(DEV), X.imag.contiguous().to(DEV)
     like, en = sep.doa_likelihood(re, im, mask.to(DEV))
     for fix in (False, True):
@@ -289,3 +275,56 @@ def test_onnx_layout_session_adapter_matches_hip_backend():
     assert len(out) == 3 and all(o.shape == (1, 257, 150) and o.dtype == np.float32 for o in out)
     with pytest.raises(AssertionError):
         Separator(dict(cfg, batch_size=2), 16000, device=DEV, backend="onnx", model=model)
+
+
+class _NoModel:
+    def to(self, device):
+        return self
+
+    def eval(self):
+        return self
+
+
+def test_doa_merge_vs_reference_golden(golden):
+    """The HIP DOA likelihood + merge decision vs the outputs of the REFERENCE's Separator.doa_likelihood / angle_merge
+    (tests/golden/separator.npz, made by running separator.py:113-250 with a stub onnxruntime module)."""
+    from css_amd.executor.separator import Separator
+    g = golden("separator.npz")
+    conf = dict(batch_size=2, eval_win=2.4, eval_hop=0.8, frame_length=512, frame_shift=256,
+                ipd="1,0;2,0;3,0;4,0;5,0;6,0", merge=True, merge_threshold=16)
+    sep = Separator(conf, model=_NoModel())
+    ref_sv = torch.complex(torch.from_numpy(g["steervec_re"]), torch.from_numpy(g["steervec_im"]))
+    assert float((sep.steervec - ref_sv).abs().max()) < 1e-6 and torch.equal(sep.angles, torch.from_numpy(g["angles"]))
+    assert [sep._lo, sep._hi] == g["lo_hi"].tolist()
+    X, mask = syn.doa_inputs(ref_sv)
+    re, im = X.real.contiguous().to(DEV), X.imag.contiguous().to(DEV)
+    like, _ = sep.doa_likelihood(re, im, mask.to(DEV))
+    ref_like = torch.from_numpy(g["like"])
+    assert float((like.cpu() - ref_like).abs().max()) < 2e-4 * float(ref_like.abs().max())
+    assert torch.argmax(like.cpu(), -1).tolist() == torch.argmax(ref_like, -1).tolist()
+    got = sep.angle_merge(re, im, mask.to(DEV), thresh=16).cpu()
+    assert torch.equal(got, torch.from_numpy(g["merged"]))
+
+
+def test_separator_session_protocol_vs_reference_golden(golden):
+    """Separator(backend="onnx").separate - unfold windows, HIP features, the (1, F, B*T) session layout, reshape,
+    clamp, DOA merge (separator.py:63-111) - vs the reference's own separate() on the same recordings with the same
+    closed-form session (synthetic.FakeMaskSession) in place of the ONNX model."""
+    from css_amd.executor import Separator
+    g = golden("separator.npz")
+    n = 12800 * 2 + 38656 + 777
+    mix, src = syn.synthetic_sources(1, n, seed=5)
+    rec7 = syn.synthetic_multichannel(src, n_ch=7, seed=5)[0]
+    cfg7 = dict(batch_size=1, eval_win=2.4, eval_hop=0.8, frame_length=512, frame_shift=256,
+                ipd="1,0;2,0;3,0;4,0;5,0;6,0", merge=True, merge_threshold=16)
+    cfg1 = dict(batch_size=1, eval_win=2.4, eval_hop=0.8, frame_length=512, frame_shift=256, merge=False)
+    for cfg, rec, km, kg in ((cfg7, rec7, "sep7_masks", "sep7_mags"), (cfg1, mix, "sep1_masks", "sep1_mags")):
+        sep = Separator(cfg, 16000, device=DEV, backend="onnx", model=_NoModel())
+        sep.session = syn.FakeMaskSession()
+        masks, mags = sep.separate(rec)
+        rm, rg = torch.from_numpy(g[km]), torch.from_numpy(g[kg])
+        assert masks.shape == rm.shape and mags.shape == rg.shape
+        assert float((mags.cpu() - rg).abs().max()) < 2e-5 * float(rg.max())
+        d = (masks.cpu() - rm).abs()
+        # top bins: the synthetic sources' shaping filter has its zero there, see tests/test_oracle_golden.py
+        assert float(d[:, :250].max()) < 3e-3 and float(d.max()) < 8e-2 and float(masks.max()) <= 1.0

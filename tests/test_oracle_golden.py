@@ -298,3 +298,73 @@ def test_dropout_mask_statistics():
     for a, b in ((k1, k2), (k1, k3)):
         assert abs(np.corrcoef(a, b)[0, 1]) < 1e-2
     assert oracle.dropout.keep_mask(7, 17, 100, 0.0).all()
+
+
+def test_doa_merge_golden(golden):
+    """oracle/doa.py vs the reference's own Separator.steervec_7ch / doa_likelihood / angle_merge
+    (tests/golden/make_golden_separator.py: separator.py:113-250 run with a stub onnxruntime module)."""
+    g = golden("separator.npz")
+    sv, ang = oracle.doa.steervec_7ch(257, 30)
+    ref_sv = torch.complex(torch.from_numpy(g["steervec_re"]), torch.from_numpy(g["steervec_im"]))
+    assert float((sv - ref_sv).abs().max()) < 1e-6 and torch.equal(ang, torch.from_numpy(g["angles"]))
+    lo, hi = (int(v) for v in g["lo_hi"])
+    assert (lo, hi) == (2, 64)   # 80 Hz / 31.25 Hz floor, 2000 Hz / 31.25 Hz ceil (separator.py:59-61)
+    X, mask = syn.doa_inputs(ref_sv)
+    like = oracle.doa.doa_likelihood(X, sv, (mask > 0.5).float(), compression=0.5, lowcut=lo, highcut=hi, softmax=False)
+    close(like, g["like"], 0.0, 1e-5)
+    sm = oracle.doa.doa_likelihood(X, sv, mask, compression=1 / 3, lowcut=lo, highcut=hi, softmax=True)
+    close(sm, g["like_softmax"], 1e-6, 1e-4)
+    merged, _ = oracle.doa.angle_merge(X, mask, sv, ang, lo, hi, thresh=16)
+    assert torch.equal(merged, torch.from_numpy(g["merged"]))
+    # quirk 6 is in the golden: window 0 (same direction) has OUTPUT 0 silenced, window 1 is untouched
+    assert float(merged[0, ..., 0].max()) == pytest.approx(1e-12) and torch.equal(merged[1], mask[1])
+
+
+def test_separator_windowing_golden(golden):
+    """oracle/separator.py vs the reference's Separator.separate (separator.py:63-111) on a 7-channel recording with the
+    DOA merge and a 1-channel one, the ONNX session replaced on both sides by synthetic.FakeMaskSession."""
+    g = golden("separator.npz")
+    n = 12800 * 2 + 38656 + 777
+    mix, src = syn.synthetic_sources(1, n, seed=5)
+    rec7 = syn.synthetic_multichannel(src, n_ch=7, seed=5)[0]
+    m7, g7 = oracle.separator.separate(rec7, syn.FakeMaskSession(), ipd="1,0;2,0;3,0;4,0;5,0;6,0", merge=True)
+    assert m7.shape == (3, 257, 150, 3) and float(m7.max()) <= 1.0
+    close(g7, g["sep7_mags"], 2e-5 * float(np.abs(g["sep7_mags"]).max()))
+    # sin(k * f) of the MVN'd feature: 1e-4 feature noise times k <= 3 - except in the top bins, where the synthetic
+    # sources' 3-tap shaping filter has its zero (|X| ~ 3e-4 of the peak): there the 2e-5 absolute difference between
+    # an FFT and the reference's DFT matrix is several per cent of the bin's own standard deviation
+    close(m7[:, :250], g["sep7_masks"][:, :250], 2e-3)
+    close(m7, g["sep7_masks"], 6e-2)
+    m1, g1 = oracle.separator.separate(mix, syn.FakeMaskSession())
+    close(g1, g["sep1_mags"], 2e-5 * float(np.abs(g["sep1_mags"]).max()))
+    close(m1[:, :250], g["sep1_masks"][:, :250], 2e-3)
+    close(m1, g["sep1_masks"], 6e-2)
+
+
+def test_combine_models_golden(golden, tmp_path):
+    """css_amd.utils.checkpoint.combine_models vs the output of the reference's scripts/python/combine_models.py on three
+    job checkpoints (tests/golden/combine.npz): f32 accumulation order of :73-76 and the 0-dim buffer rule of :77-78
+    (last job's counter x 1/n, truncated: 500, 500, 501 -> 167)."""
+    from css_amd.models import MODELS
+    from css_amd.utils import checkpoint as ck
+    g = golden("combine.npz")
+    conf = dict(attention_dim=64, attention_heads=1, linear_units=64, num_blocks=1, kernel_size=33, dropout_rate=0.1,
+                relative_pos_emb=True)
+    paths = []
+    for j, seed in enumerate(g["seeds"]):
+        torch.manual_seed(int(seed))
+        m = MODELS["Conformer"](257, 257, 2, 1, conf)   # same parameter creation order as the reference class
+        sd = m.state_dict()
+        for k in sd:
+            if sd[k].dim() == 0:
+                sd[k].fill_(int(g["tracked"][j]))
+        p = str(tmp_path / f"1.{j + 1}.mdl")
+        torch.save({"model": sd, "objective": {}, "optimizer": None, "lr_sched": None, "epoch": 1}, p)
+        paths.append(p)
+    res = torch.load(ck.combine_models(str(tmp_path / "1.mdl"), paths))["model"]
+    i = 0
+    while f"key{i}" in g:
+        k, ref = str(g[f"key{i}"]), torch.from_numpy(np.asarray(g[f"val{i}"]))
+        assert res[k].dtype == ref.dtype and torch.equal(res[k], ref), k
+        i += 1
+    assert i >= 2 and int(res["conformer.encoders.0.conv.BN.num_batches_tracked"]) == 167
