@@ -121,6 +121,8 @@ class FusedAdam(torch.optim.Optimizer):
         if len(sd.get("param_groups", [])) != 1:
             raise ValueError("css_amd.FusedAdam supports a single parameter group")
         super().load_state_dict({"state": {}, "param_groups": sd["param_groups"]})
+        for k, v in self.defaults.items():   # a torch.optim.Adam checkpoint has no FusedAdam-only keys (max_norm)
+            self.param_groups[0].setdefault(k, v)
         if fused is not None:
             self._step = int(fused["step"])
             self.exp_avg.copy_(fused["exp_avg"])

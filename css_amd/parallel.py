@@ -58,16 +58,28 @@ _BUCKETS = {}
 
 def allreduce_gradients(params, average=True):
     """Sum (or average) .grad of all params across ranks.  No-op on 1 rank.  The first call re-homes the gradients as
-    views of one flat buffer (GradBucket), every call is then ONE collective on that buffer - no cat / copy-back passes
-    over the gradients (86 MB for Conformer-base)."""
+    views of one flat buffer (GradBucket); every later call is ONE collective on that buffer.  An optimiser whose
+    ``zero_grad()`` drops the gradients (torch's default ``set_to_none=True``) makes autograd allocate fresh tensors
+    every step: those are copied INTO the existing flat buffer and re-pointed at it (one copy per step, no 86 MB
+    reallocation) - call ``zero_grad(set_to_none=False)`` to avoid even that."""
     if not is_distributed():
         return
     params = [p for p in params if p.requires_grad]
     key = tuple(id(p) for p in params)
     b = _BUCKETS.get(key)
-    if b is None or any(p.grad is None or p.grad.data_ptr() != b.flat[o:].data_ptr()
-                        for p, o in zip(b.params, _offsets(b.params))):
-        b = _BUCKETS[key] = GradBucket(params)  # (re)build: gradients created by autograd are copied in once
+    if b is None:
+        for k in [k for k, v in _BUCKETS.items() if any(q.grad is None and q not in params for q in v.params)]:
+            del _BUCKETS[k]   # buckets of models that are gone
+        b = _BUCKETS[key] = GradBucket(params)
+    else:
+        with torch.no_grad():
+            for p, o in zip(b.params, _offsets(b.params)):
+                view = b.flat[o:o + p.numel()].view(p.shape)
+                if p.grad is None:
+                    view.zero_()
+                elif p.grad.data_ptr() != view.data_ptr():
+                    view.copy_(p.grad)
+                p.grad = view
     b.allreduce(average=average)
 
 
@@ -166,20 +178,24 @@ class OverlappedGradReducer:
     what is left (embedding, position table) and waits for everything.  One process per GPU; xGMI is point to point,
     so a handful of ~20 MB messages in flight suits it better than one 86 MB message or hundreds of small ones."""
 
-    def __init__(self, model, optim, blocks_per_bucket=4, average=True):
+    def __init__(self, model, optim, blocks_per_bucket=4, average=True, emit=None):
         self.model, self.optim, self.every, self.average = model, optim, max(1, int(blocks_per_bucket)), average
         self.span = {}  # id(parameter) -> (lo, hi) in the flat buffer
         for p, o in zip(optim.param_groups[0]["params"], optim._offs):
             self.span[id(p)] = (o, o + (p.numel() + 3) // 4 * 4)
         self.handles, self.pending, self.low = [], [], optim.flat_grad.numel()
+        # emit(lo, hi): what happens when a stretch is final.  Default: start its all-reduce.  bucket_plan() records
+        # the stretches instead, the graphed step closes one captured sub-graph per stretch (trainer/graphed.py).
+        self.emit = emit if emit is not None else \
+            (lambda lo, hi: allreduce_segment(self.optim.flat_grad, lo, hi, self.handles, self.average))
 
     def _span_of(self, module):
         spans = [self.span[id(p)] for p in module.parameters() if id(p) in self.span]
         return (min(lo for lo, _ in spans), max(hi for _, hi in spans)) if spans else None
 
-    def begin(self):
+    def begin(self, force=False):
         self.handles, self.pending, self.low = [], [], self.optim.flat_grad.numel()
-        self.model._grad_bucket_hook = self._on_module if is_distributed() else None
+        self.model._grad_bucket_hook = self._on_module if (force or is_distributed()) else None
 
     def _flush(self):
         if not self.pending:
@@ -188,7 +204,7 @@ class OverlappedGradReducer:
         self.pending = []
         hi = min(hi, self.low)          # never send a stretch twice
         if lo < hi:
-            allreduce_segment(self.optim.flat_grad, lo, hi, self.handles, self.average)
+            self.emit(lo, hi)
             self.low = lo
 
     def _on_module(self, module):
@@ -200,16 +216,51 @@ class OverlappedGradReducer:
         if not is_block or len(self.pending) >= self.every:
             self._flush()
 
+    def flush_rest(self):
+        """The stretches no module has reported (embedding, position table: the front of the buffer)."""
+        self.model._grad_bucket_hook = None
+        self._flush()
+        if self.low > 0:
+            self.emit(0, self.low)
+            self.low = 0
+
     def finish(self):
         """All-reduce whatever has not been sent (the front of the buffer) and wait for every bucket."""
         self.model._grad_bucket_hook = None
         if not is_distributed():
             return
-        self._flush()
-        if self.low > 0:
-            allreduce_segment(self.optim.flat_grad, 0, self.low, self.handles, self.average)
-            self.low = 0
+        self.flush_rest()
         wait_all(self.handles, self.optim.flat_grad, self.average)
+
+
+def bucket_plan(model, optim, blocks_per_bucket=4):
+    """The all-reduce schedule of one training step: the (lo, hi) stretches of FusedAdam's flat gradient buffer in the
+    order the explicit backward finishes them (mask head, encoder blocks L-1 .. 0 in groups of ``blocks_per_bucket``,
+    then the front of the buffer).  It is a function of the model and the optimiser layout ONLY, and both forms of the
+    step - eager (OverlappedGradReducer) and captured (GraphedTrainStep) - issue exactly these collectives in this
+    order, so ranks may take different forms in the same step (a rank that meets a new batch shape runs eager while
+    the others replay a graph) without their collectives pairing up wrongly."""
+    plan = []
+    r = OverlappedGradReducer(model, optim, blocks_per_bucket, emit=lambda lo, hi: plan.append((lo, hi)))
+    r.begin(force=True)
+    enc = getattr(model, "conformer", None)
+    if enc is not None and hasattr(enc, "encoders"):   # the Conformer backward reports head and blocks (autograd.py)
+        r._on_module(model.linear)
+        for lay in reversed(list(enc.encoders)):
+            r._on_module(lay)
+    r.flush_rest()                                      # (other models: one stretch, the whole buffer)
+    return plan
+
+
+def allreduce_plan(flat, plan, average=True, async_handles=None):
+    """Issue the stretches of ``bucket_plan`` back to back (asynchronous on RCCL) and wait, unless ``async_handles``."""
+    if not is_distributed():
+        return
+    handles = [] if async_handles is None else async_handles
+    for lo, hi in plan:
+        allreduce_segment(flat, lo, hi, handles, average)
+    if async_handles is None:
+        wait_all(handles, flat, average)
 
 
 def average_parameters(models_state_dicts):

@@ -4,13 +4,16 @@ A css_amd training step is ~2 300 kernel launches (forward operators, PIT, every
 from Python; at 23 ms of GPU work the host cannot keep up.  ``GraphedTrainStep`` captures
 zero_grad -> objective(model, batch) -> backward -> clip + Adam once and replays it per step.  In a multi-GPU job
 (torch.distributed initialised, one process per GPU) the step is TWO graphs with the gradient all-reduce between them:
-graph 1 = zero_grad, forward, PIT, backward; then ``parallel.allreduce_flat`` on FusedAdam's flat gradient buffer
-(RCCL over xGMI, ``buckets`` asynchronous chunks in flight; issued eagerly - no collective is captured, so nothing
-depends on the runtime's support for capturing RCCL); graph 2 = clip + Adam.  Replaces the reference's per-epoch
+graph 1 = zero_grad, forward, PIT, backward; then the stretches of ``parallel.bucket_plan`` on FusedAdam's flat
+gradient buffer (RCCL over xGMI, asynchronous, all in flight; issued eagerly - no collective is captured, so nothing
+depends on the runtime's support for capturing RCCL); graph 2 = clip + Adam.  The schedule of collectives is the one
+the eager step issues (same stretches, same order), so a rank that runs a step eagerly - a batch shape it has not
+captured - stays paired with ranks that replay.  The warm-up steps before the capture issue NO collective.  Replaces the reference's per-epoch
 checkpoint averaging (scripts/python/combine_models.py:55-82).  Common to both forms:
 inputs are copied into static buffers, the learning rate / Adam bias corrections live in device memory
 (``FusedAdam.advance_hyper``), BatchNorm bookkeeping and the PIT permutation search are device-side already.
-Batches must keep one shape (the reference trains on fixed-length windows, separation.py:204-232).
+One captured step serves ONE batch shape; the reference draws the window length per batch (separation.py:94-95,175:
+2 to 5 s), so train_one_epoch keeps a small LRU of captured shapes and runs shapes it has seen only once eagerly.
 """
 import torch
 
@@ -19,11 +22,13 @@ from ..optim import FusedAdam
 
 
 class GraphedTrainStep:
-    def __init__(self, model, objective, optim, example_batch, max_norm, device="cuda", warmup=2, buckets=4):
+    def __init__(self, model, objective, optim, example_batch, max_norm, device="cuda", warmup=2, buckets=4,
+                 blocks_per_bucket=4):
         if not isinstance(optim, FusedAdam):
             raise TypeError("GraphedTrainStep needs css_amd.optim.FusedAdam (static parameter / gradient buffers)")
         self.distributed = parallel.is_distributed()
-        self.buckets = buckets
+        self.buckets = buckets   # (kept for callers; the collective schedule is bucket_plan's)
+        self.plan = parallel.bucket_plan(model, optim, blocks_per_bucket) if self.distributed else []
         self.model, self.objective, self.optim, self.max_norm = model, objective, optim, max_norm
         self.keys = [k for k in ("mix", "source1", "source2") if k in example_batch]
         self.static = {k: example_batch[k].to(device).clone() for k in self.keys}
@@ -50,7 +55,7 @@ class GraphedTrainStep:
             with torch.cuda.stream(side):
                 for _ in range(warmup):
                     optim.advance_hyper()
-                    self._eager()
+                    self._eager(collective=False)   # ranks capture at different times: no collective in here
         except Exception:   # a step that cannot run: leave model and optimiser as they were, eager-capable
             restore()
             optim.capturable = False
@@ -80,11 +85,17 @@ class GraphedTrainStep:
         loss.backward()
         return loss.detach()
 
-    def _eager(self):
+    def _eager(self, collective=True):
         loss = self._forward_backward()
-        if self.distributed:
-            parallel.allreduce_flat(self.optim.flat_grad, average=True, buckets=self.buckets)
+        if self.distributed and collective:
+            parallel.allreduce_plan(self.optim.flat_grad, self.plan)
         return loss, self.optim.step(max_norm=self.max_norm)
+
+    def release(self):
+        """Drop the captured graphs and their private memory pool (LRU eviction in train_one_epoch)."""
+        self.graph = None
+        self.graph_opt = None
+        self.static = {}
 
     def __call__(self, batch):
         """One optimiser step on ``batch``; returns (loss, grad_norm) as 0-dim device tensors of THIS step (they are
@@ -94,6 +105,6 @@ class GraphedTrainStep:
         self.optim.advance_hyper()
         self.graph.replay()
         if self.distributed:
-            parallel.allreduce_flat(self.optim.flat_grad, average=True, buckets=self.buckets)
+            parallel.allreduce_plan(self.optim.flat_grad, self.plan)
             self.graph_opt.replay()
         return self.loss, self.grad_norm

@@ -2,8 +2,8 @@
 
 ``validate`` (forward only) runs entirely on the HIP path.  ``train_one_epoch`` keeps the
 reference's step order (forward, backward, clip, step, zero_grad, scheduler) and its per-iteration log line; forward,
-PIT and the whole backward are HIP kernels (css_amd/autograd.py).  With ``css_amd.optim.FusedAdam`` and batches of one
-shape the step is replayed as a captured HIP graph (``GraphedTrainStep``: 14.2 ms against 19.8 ms launch by launch for
+PIT and the whole backward are HIP kernels (css_amd/autograd.py).  With ``css_amd.optim.FusedAdam`` a batch
+shape that repeats is replayed as a captured HIP graph (``GraphedTrainStep``: 14.2 ms against 19.8 ms launch by launch for
 Conformer-base at 32 x 400; ``args.graph = False`` switches it off), bit-identical to the eager step.
 In a multi-GPU job (torch.distributed initialised) gradients are averaged across ranks over RCCL
 before clipping (css_amd/parallel.py: with FusedAdam, buckets of ~4 encoder blocks of the flat
@@ -11,6 +11,7 @@ gradient buffer are all-reduced while the remaining blocks are back-propagated),
 reference's per-epoch checkpoint averaging (scripts/python/combine_models.py:55-82).
 """
 import logging
+from collections import OrderedDict
 
 import torch
 
@@ -18,21 +19,40 @@ from .. import ops, parallel
 
 
 def _graphed_step(args, model, objective, optim, b, device):
-    """The captured step for this batch shape, or None (no FusedAdam, switched off, SyncBatchNorm, capture failed)."""
+    """The captured step for this batch shape, or None: no FusedAdam, switched off, SyncBatchNorm, capture failed - or a
+    shape met for the first time.  The reference draws the window length per batch (separation.py:94-95,175), so the
+    shape changes from batch to batch: a shape is captured the SECOND time it is met (``args.graph_after``), at most
+    ``args.graph_cache`` (default 4) captured steps are kept, least recently used first out (each owns a private
+    memory pool holding a whole step's activations), everything else runs the eager step.  Ranks of a distributed job
+    decide independently: both forms issue the same collectives (parallel.bucket_plan)."""
     if not hasattr(optim, "flat_grad") or not getattr(args, "graph", True) or str(device) == "cpu" or \
             getattr(model, "sync_batchnorm", False) or not model.training:
         return None
-    cache = optim.__dict__.setdefault("_graphed_steps", {})
+    state = optim.__dict__.setdefault("_graphed_steps", {"cache": OrderedDict(), "seen": {}})
+    cache, seen = state["cache"], state["seen"]
     key = (id(model), id(objective), float(args.grad_thresh)) + tuple((k, tuple(b[k].shape)) for k in ("mix", "source1", "source2") if k in b)
-    if key not in cache:
-        from .graphed import GraphedTrainStep
-        try:
-            cache[key] = GraphedTrainStep(model, objective, optim, b, max_norm=args.grad_thresh, device=device,
-                                          buckets=getattr(args, "buckets", 4))
-        except (RuntimeError, TypeError, NotImplementedError) as e:   # e.g. a model whose step syncs with the host
-            logging.warning("css_amd: training step not captured (%s); launching it kernel by kernel", e)
-            cache[key] = None
-    return cache[key]
+    if key in cache:
+        cache.move_to_end(key)
+        return cache[key]
+    seen[key] = seen.get(key, 0) + 1
+    if len(seen) > 4096:   # bounded bookkeeping
+        seen.clear()
+    if seen[key] < int(getattr(args, "graph_after", 2)):
+        return None
+    from .graphed import GraphedTrainStep
+    try:
+        step = GraphedTrainStep(model, objective, optim, b, max_norm=args.grad_thresh, device=device,
+                                buckets=getattr(args, "buckets", 4), blocks_per_bucket=getattr(args, "blocks_per_bucket", 4))
+    except (RuntimeError, TypeError, NotImplementedError) as e:   # e.g. a model whose step syncs with the host
+        logging.warning("css_amd: training step not captured (%s); launching it kernel by kernel", e)
+        step = None
+    cache[key] = step
+    while len(cache) > max(1, int(getattr(args, "graph_cache", 4))):
+        old_key, old = cache.popitem(last=False)
+        seen.pop(old_key, None)   # an evicted shape starts over: it must repeat again before it is re-captured
+        if old is not None:
+            old.release()
+    return step
 
 
 def train_one_epoch(args, generator, model, objective, optim, lr_sched, device="cpu"):

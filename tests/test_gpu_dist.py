@@ -66,7 +66,7 @@ def run(graphed):
     else:
         for i in range(1, 4):
             oo.zero_grad(); l = obj(mm, batch(i, rank), device=DEV); l.backward()
-            parallel.allreduce_flat(oo.flat_grad, buckets=3); oo.step(max_norm=5.0); losses.append(float(l))
+            parallel.allreduce_plan(oo.flat_grad, parallel.bucket_plan(mm, oo, 4)); oo.step(max_norm=5.0); losses.append(float(l))
     return oo.flat_param.clone(), losses
 p_e, l_e = run(False)
 p_g, l_g = run(True)

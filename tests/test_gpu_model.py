@@ -285,7 +285,8 @@ def test_train_one_epoch_matches_reference_trace():
 
 
 def test_train_one_epoch_replays_a_graph_with_fused_adam():
-    """train_one_epoch with css_amd.optim.FusedAdam captures the step once per batch shape and replays it: same losses and
+    """train_one_epoch with css_amd.optim.FusedAdam captures the step the second time a batch shape is met (the first
+    occurrence runs eagerly; at most args.graph_cache captured shapes are kept) and replays it: same losses and
     parameters, bit for bit, as the same loop launched kernel by kernel (args.graph = False), with the warm-up learning-rate
     schedule changing the rate every step and dropout on (the seed advances inside the graph)."""
     import types
@@ -309,11 +310,35 @@ def test_train_one_epoch_replays_a_graph_with_fused_adam():
         g = gen()
         obj = OBJECTIVES["MSE"].build_objective({})
         losses = [train_one_epoch(targs, g, m, obj, opt, sch, DEV) for _ in range(3)]
-        return losses, opt.flat_param.clone(), len(getattr(opt, "_graphed_steps", {}))
+        return losses, opt.flat_param.clone(), len(getattr(opt, "_graphed_steps", {"cache": {}})["cache"])
     l_e, p_e, n_e = run(False)
     l_g, p_g, n_g = run(True)
     assert n_e == 0 and n_g == 1
     assert l_e == l_g and torch.equal(p_e, p_g)
+
+
+def test_graphed_step_cache_is_bounded_and_first_sight_runs_eager():
+    """The reference draws the window length per batch (separation.py:94-95,175): shapes seen once run the eager step,
+    a repeated shape is captured, and the cache evicts the least recently used captured step beyond args.graph_cache."""
+    import types
+    from css_amd.objectives import OBJECTIVES
+    from css_amd.optim import FusedAdam
+    from css_amd.trainer import LRScheduler, train_one_epoch
+    m, _ = build(1, 61)
+    m.train()
+    opt = FusedAdam(m.parameters(), lr=1e-3, max_norm=5.0)
+    sch = LRScheduler(opt, types.SimpleNamespace(warmup=3, decay=0.0, fixed=0, min_lr=1e-9))
+    frames = [24, 24, 32, 32, 40, 40, 24, 56]   # 24, 32, 40 captured in turn (cache of 2: 24 evicted, re-seen -> eager count restarts)
+
+    def gen():
+        for i, t in enumerate(frames):
+            yield {"mix": rnd((2, t, 257), 200 + i).abs().to(DEV), "source1": (rnd((2, t, 257), 300 + i).abs() * 0.5).to(DEV),
+                   "source2": (rnd((2, t, 257), 400 + i).abs() * 0.5).to(DEV), "ovl": 0.5}
+    targs = types.SimpleNamespace(gpu=True, fp16=False, batches_per_epoch=len(frames), grad_thresh=5.0, graph=True, graph_cache=2)
+    loss = train_one_epoch(targs, gen(), m, OBJECTIVES["MSE"].build_objective({}), opt, sch, DEV)
+    st = opt._graphed_steps
+    assert np.isfinite(loss) and len(st["cache"]) == 2
+    assert [k[3][1][1] for k in st["cache"]] == [32, 40]   # key = (model, objective, clip, ("mix", shape), ...)
 
 
 def test_conformer_gradients_flow_and_match_oracle_autograd():

@@ -243,3 +243,28 @@ def test_beamformer_spans_follow_the_reference_batch_end():
             assert got == want, (first, T)
     # the old computation (batch end = first + count) differs exactly on the truncated batch
     assert Beamformer._spans(self, 4, 2, hop * 8) != Beamformer._spans(self, 4, 2, hop * 8, batch_end=7)
+
+
+def test_bucket_plan_partitions_the_flat_buffer_in_backward_order():
+    """parallel.bucket_plan: the collective schedule both step forms issue - a partition of the flat gradient buffer,
+    mask head first (the END of the buffer), encoder blocks in groups from the last to the first, the front last."""
+    import types
+    from css_amd import parallel
+    from css_amd.models import MODELS
+    conf = dict(attention_dim=64, attention_heads=1, linear_units=64, num_blocks=5, kernel_size=33, dropout_rate=0.1,
+                relative_pos_emb=True)
+    m = MODELS["Conformer"](257, 257, 2, 1, conf)
+    params = [p for p in m.parameters()]
+    offs, n = [], 0
+    for p in params:
+        offs.append(n)
+        n += (p.numel() + 3) // 4 * 4
+    opt = types.SimpleNamespace(param_groups=[{"params": params}], _offs=offs, flat_grad=torch.zeros(n))
+    for every, nseg in ((1, 7), (2, 5), (4, 4)):   # head + ceil(5 / every) block groups + the front
+        plan = parallel.bucket_plan(m, opt, every)
+        assert len(plan) == nseg, (every, plan)
+        assert plan[0][1] == n and plan[-1][0] == 0
+        assert all(plan[i][0] == plan[i + 1][1] for i in range(len(plan) - 1))   # contiguous, descending: a partition
+        head_lo = min(offs[i] for i, p in enumerate(params) if any(p is q for q in m.linear.parameters()))
+        assert plan[0] == (head_lo, n)
+    assert getattr(m, "_grad_bucket_hook", None) is None   # planning leaves no hook behind
