@@ -26,8 +26,13 @@ Extra objects on the JSON line (task section 4):
                achieved = algorithmic flops (2 x 4*M*256*1024 + 2*M*256*768) / average launch duration; peak = 2.5
                PFLOP/s dense bf16; traffic = HBM bytes per launch from the rocprofv3 PMC passes under profiles/.
                roofline.attention / .outproj_conv (MFMA), .stft / .pit (HBM, 2 052 and 5 140 B/frame) the same way.
-  cpu_baseline the oracle (fp32 CPU restatement, kind "port") timed on this box's host cores on ONE full batch
-               (rank 0, N = 1 only).
+  cpu_baseline the oracle (fp32 CPU restatement, kind "port") timed on this box's host cores (rank 0, N = 1 only),
+               BASELINE.md section 3: 1 warm-up + 3 timed passes of the full batch on all (<= 16) cores, and a second
+               leg on ONE thread over a bounded sample (4 of the 32 chunks); CPU model string reported.
+  train_step   (default fwd mode) the TRAINING step of the same workload measured in the same run: train-mode forward
+               (dropout, batch-statistics BatchNorm), PIT, explicit backward, gradient all-reduce (N > 1), clip + Adam,
+               replayed as captured HIP graph(s); ms/step, frames/s, fraction of the bf16 MFMA peak at 3 x the forward
+               FLOPs, and with N > 1 the collective backend, world size and bytes all-reduced per step.
 """
 import argparse
 import json
@@ -59,6 +64,7 @@ def parse_args():
                     help="rehearsal on a one-GPU box: every rank uses cuda:0 (implies --backend gloo)")
     ap.add_argument("--buckets", type=int, default=4, help="train mode: all-reduce chunks in flight")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-step", action="store_true", help="fwd mode: skip the extra training-step measurement")
     ap.add_argument("--fuse-conv", type=int, default=None, help="debug: csship_conformer_weights.fuse_conv override")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying the "
                     "step as one captured HIP graph")
@@ -208,20 +214,64 @@ def main():
         for _ in range(args.warmup):
             loss = step()
 
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    dt = time.perf_counter() - t0
-    per_rank_ms = [dt / args.steps * 1e3]
-    if world > 1:
-        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        gathered = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(gathered, t)
-        per_rank_ms = [float(g.item()) / args.steps * 1e3 for g in gathered]
-        dt = max(float(g.item()) for g in gathered)
+    def timed(fn, n):
+        """n calls of fn between barrier + synchronize fences; (max-over-ranks seconds, per-rank ms/step, last result)"""
+        fence()
+        t0 = time.perf_counter()
+        out = None
+        for _ in range(n):
+            out = fn()
+        fence()
+        d = time.perf_counter() - t0
+        per_rank = [d / n * 1e3]
+        if world > 1:
+            t = torch.tensor([d], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            gathered = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(gathered, t)
+            per_rank = [float(g.item()) / n * 1e3 for g in gathered]
+            d = max(float(g.item()) for g in gathered)
+        return d, per_rank, out
+
+    dt, per_rank_ms, loss = timed(step, args.steps)
     loss_val = float(loss)
+
+    # ---- fwd mode: the TRAINING step of the same workload, same run (SURVEY 8d asks for train-mode throughput;
+    # configs[1]/[2] are training configurations).  With N > 1 this is the path that communicates.
+    train_rec = None
+    if args.mode == "fwd" and not args.no_train_step:
+        try:
+            from css_amd.objectives import OBJECTIVES
+            from css_amd.optim import FusedAdam
+            from css_amd.trainer import GraphedTrainStep
+            tmodel = MODELS["Conformer"](257, 257, 2, 1, conf)
+            tmodel.load_state_dict(sd)
+            tmodel = tmodel.to(dev).train()
+            tobj = OBJECTIVES["MSE"].build_objective({})
+            toptim = FusedAdam(tmodel.parameters(), lr=1e-4, max_norm=5.0)
+
+            def tfeatures():
+                with torch.no_grad():
+                    mags = ops.stft(audio, ("mag",))["mag"]
+                return {"mix": mags[0], "source1": mags[1], "source2": mags[2]}
+            tstep = GraphedTrainStep(tmodel, tobj, toptim, tfeatures(), max_norm=5.0, device=dev, buckets=args.buckets)
+            for _ in range(2):
+                tstep(tfeatures())
+            tsteps = max(5, args.steps // 2)
+            tdt, tper_rank, tout = timed(lambda: tstep(tfeatures())[0], tsteps)
+            tms = tdt / tsteps * 1e3
+            train_rec = {"metric": "STFT-frames/sec (training step: fwd+PIT+bwd+all-reduce+clip/Adam) Conformer-1ch",
+                         "ms_per_step": tms, "value": world * B * T / (tdt / tsteps), "unit": "frames/s", "steps": tsteps,
+                         "whole_step_frac": 3.0 * B * T * FLOP_PER_FRAME * args.blocks / 16 / (tdt / tsteps) / PEAK_BF16,
+                         "mode": "train-mode forward (dropout 0.1, batch-statistics BatchNorm) + PIT + explicit backward + "
+                                 "gradient all-reduce (N > 1) + fused clip/Adam; captured HIP graph replay",
+                         "loss": float(tout), "per_rank_ms_per_step": tper_rank,
+                         "collective_backend": (backend if world > 1 else None),
+                         "world_size": dist.get_world_size() if world > 1 else 1,
+                         "allreduce_bytes_per_step": int(toptim.flat_grad.numel() * 4) if world > 1 else 0,
+                         "allreduce_schedule": ([hi - lo for lo, hi in tstep.plan] if world > 1 else None)}
+            del tstep, toptim, tmodel
+        except Exception as e:  # noqa: BLE001  (the headline line must not die with the extra leg)
+            train_rec = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- rooflines from INSIDE the step: one un-captured eval step with the library's launch timeline on
     roof = None
@@ -260,14 +310,29 @@ def main():
         if was_training:
             model.train()
         M = B * T
-        traffic, mfma_busy = {}, {}
-        for tp in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        # HBM traffic / MFMA-busy come from a committed rocprofv3 PMC pass of THIS command (tools/profile_round.sh), not
+        # from this run: the record names the profile and is dropped when the kernel sources changed since it was taken
+        traffic, mfma_busy, pmc_src = {}, {}, None
+        import hashlib
+        hsh = hashlib.sha1()
+        for fn in sorted(os.listdir(os.path.join(ROOT, "css_amd", "csrc"))):
+            if fn.endswith((".hip", ".hpp")):
+                hsh.update(open(os.path.join(ROOT, "css_amd", "csrc", fn), "rb").read())
+        csrc_sha = hsh.hexdigest()[:16]
+        for tp in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tp)
             if os.path.exists(tpath):
-                for name, rec in json.load(open(tpath)).items():
-                    traffic.setdefault(name, rec["hbm_bytes_per_launch"])
-                    if rec.get("mfma_busy_frac") is not None:
-                        mfma_busy.setdefault(name, rec["mfma_busy_frac"])
+                rec_all = json.load(open(tpath))
+                meta = rec_all.pop("_meta", {})
+                pmc_src = {"file": "profiles/" + tp, "csrc_sha_at_profile": meta.get("csrc_sha"), "csrc_sha_now": csrc_sha,
+                           "current": meta.get("csrc_sha") == csrc_sha}
+                if pmc_src["current"]:
+                    for name, rec in rec_all.items():
+                        if "hbm_bytes_per_launch" in rec:
+                            traffic.setdefault(name, rec["hbm_bytes_per_launch"])
+                        if rec.get("mfma_busy_frac") is not None:
+                            mfma_busy.setdefault(name, rec["mfma_busy_frac"])
+                break
 
         def busy_of(prefix):  # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch duration x 2.4 GHz), committed PMC pass
             return next((v for name, v in mfma_busy.items() if name.startswith(prefix)), None)
@@ -287,6 +352,7 @@ def main():
                 "frac": flops / dur / PEAK_BF16 if dur else None, "traffic": traffic_of("chain_kernel<8, false, true, true, true>"),
                 "mfma_busy_pmc": busy_of("chain_kernel<8, false, true, true, true>"),
                 "avg_launch_us": dur * 1e6, "flops_per_launch": flops, "timing": "HIP events around the in-step launches",
+                "pmc_source": pmc_src,
                 "whole_step_frac": (step_flops * (3.0 if args.mode == "train" else 1.0)) / (dt / args.steps) / PEAK_BF16}
         ad, an = tl["attention"]
         aflops = B * 4 * (2.0 * T * T * 64 * 3)  # QK^T + Q.PE^T + P.V over the full T x T, SURVEY 8(d)
@@ -323,16 +389,39 @@ def main():
         except AttributeError:
             cores = os.cpu_count() or 1
         cores = max(1, min(cores, int(os.environ.get("CSS_CPU_THREADS", "16"))))  # the GPU box shares its host cores
+        cpu_model = "unknown"
+        try:
+            with open("/proc/cpuinfo") as fh:
+                cpu_model = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), "unknown")
+        except OSError:
+            pass
+
+        def cpu_pass(nb):
+            """features -> Conformer forward -> PIT-MSE of the first nb chunks through the oracle; seconds"""
+            with torch.no_grad():
+                c0 = time.perf_counter()
+                mags = [oracle.feature.stft(x[:nb])[0].transpose(1, 2).contiguous() for x in (mix, src[0], src[1])]
+                y_pred, _ = oracle.conformer.forward(mags[0], sd, num_blocks=args.blocks)
+                closs = oracle.pit.mse_objective(y_pred, mags[1], mags[2])
+                return time.perf_counter() - c0, float(closs)
+        # BASELINE.md section 3: >= 1 warm-up + >= 3 timed iterations, all cores and one thread
         torch.set_num_threads(cores)
-        with torch.no_grad():
-            c0 = time.perf_counter()
-            mags = [oracle.feature.stft(x)[0].transpose(1, 2).contiguous() for x in (mix, src[0], src[1])]
-            y_pred, _ = oracle.conformer.forward(mags[0], sd, num_blocks=args.blocks)
-            closs = oracle.pit.mse_objective(y_pred, mags[1], mags[2])
-            cdt = time.perf_counter() - c0
+        cpu_pass(B)
+        runs = [cpu_pass(B) for _ in range(3)]
+        cdt = sorted(r[0] for r in runs)[1]   # median of 3
+        nb1 = 4                                # one thread: a bounded sample (4 of the 32 chunks)
+        torch.set_num_threads(1)
+        cpu_pass(nb1)
+        runs1 = sorted(cpu_pass(nb1)[0] for _ in range(3))
+        torch.set_num_threads(cores)
         cpu = {"value": B * T / cdt, "unit": "frames/s", "cores": cores, "kind": "port",
-               "sample": f"1 forward+PIT step of the full workload (B={B} x T={T} frames, fp32, torch {torch.__version__} CPU ops)",
-               "loss": float(closs), "gpu_loss": loss_val if args.mode == "fwd" else None}
+               "sample": f"forward+PIT of the full batch (B={B} x T={T} frames, fp32, torch {torch.__version__} CPU ops): "
+                         f"1 warm-up + 3 timed passes, median",
+               "seconds_per_pass": [round(r[0], 3) for r in runs], "cpu_model": cpu_model, "host_cpu_count": os.cpu_count(),
+               "single_thread": {"value": nb1 * T / runs1[1], "unit": "frames/s", "cores": 1,
+                                 "sample": f"{nb1} of the {B} chunks x T={T} frames: 1 warm-up + 3 timed passes, median",
+                                 "seconds_per_pass": [round(r, 3) for r in runs1]},
+               "loss": runs[-1][1], "gpu_loss": loss_val if args.mode == "fwd" else None}
 
     if rank == 0:
         frames = world * B * T * args.steps
@@ -353,7 +442,7 @@ def main():
                        "ranks_launched_by": ("launcher" if "TORCHELASTIC_RUN_ID" in os.environ or "GROUP_RANK" in os.environ
                                              else ("bench.py --gpus" if world > 1 else None))},
             "per_rank_ms_per_step": per_rank_ms,
-            "roofline": roof, "cpu_baseline": cpu, "loss": loss_val,
+            "roofline": roof, "cpu_baseline": cpu, "train_step": train_rec, "loss": loss_val,
         }
         print(json.dumps(line))
         sys.stdout.flush()

@@ -692,6 +692,17 @@ int csship_doa_likelihood(const float* x_re, const float* x_im, const float* mas
                           int32_t hi, float binarize_thr, float compression, float* likelihood,
                           float* masked_energy, void* workspace, size_t workspace_bytes, csship_stream_t stream);
 
+/* ---- diagnostics (css_amd/csrc/forward.hip; not on the product path: bench.py's in-step roofline and the stamp tools).
+ * csship_debug_timeline(1) starts a fresh per-launch timeline: instrumented entry points then bracket each kernel launch
+ * with a HIP event pair on the launch stream (not usable during graph capture); (0) stops it and frees the events.
+ * csship_debug_timeline_read: after the caller synchronised the stream, total milliseconds and number of launches
+ * recorded under `tag` (CSSHIP_TL_* in css_amd/csrc/common.hpp: 0 chain, 1 chain edge, 2 attention, 3 out-proj+conv,
+ * 4 embed, 5 head, 6 stft, 7 pit sse, 8 pit finalize, 9 mvn, 10 other).
+ * csship_debug_stamps: device buffer that -D*_STAMPS diagnostic builds fill with s_memtime phase stamps; NULL = off. */
+void csship_debug_timeline(int enable);
+int csship_debug_timeline_read(int tag, double* total_ms, int* count);
+void csship_debug_stamps(void* device_buffer);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,11 @@ def test_abi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(h, name), f"{name} declared in csship.h but not exported"
     assert declared == set(_lib.SIGNATURES), "ctypes signature table and header disagree"
+    # ... and nothing else: every csship_* symbol the library exports with C linkage is declared in the header
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if " T " in ln and ln.split()[-1].startswith("csship_")}
+    assert exported == declared, f"exported but not declared: {sorted(exported - declared)}; declared only: {sorted(declared - exported)}"
     lib = _lib.lib()
     assert lib.csship_version() >= 100
     assert b"NULL" in lib.csship_strerror(-5)

@@ -7,7 +7,7 @@
 set -u
 tag=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train-step"
 for mode in fwd train; do
   rm -rf gpurun_out/prof_$mode
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$mode -- $B --mode $mode > gpurun_out/${tag}_bench_$mode.log 2>&1
@@ -21,7 +21,7 @@ i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY"; do
   i=$((i + 1))
   rm -rf gpurun_out/pmc_$i
-  timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmc_$i -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_$i.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmc_$i -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train-step > gpurun_out/pmc_$i.log 2>&1
   rc=$?; echo "pmc [$set] rc=$rc"
   [ $rc -eq 124 ] || [ $rc -eq 137 ] && exit 1
 done
@@ -57,7 +57,14 @@ for k, v in vals.items():
         e["valu_active_frac_of_wave_cycles"] = round(m.get("SQ_ACTIVE_INST_VALU", 0.0) / m["SQ_WAVE_CYCLES"], 4)
         e["lds_active_frac_of_wave_cycles"] = round(m.get("SQ_ACTIVE_INST_LDS", 0.0) / m["SQ_WAVE_CYCLES"], 4) if "SQ_ACTIVE_INST_LDS" in m else None
     out[short] = e
+import hashlib, os
+hsh = hashlib.sha1()
+for fn in sorted(os.listdir("css_amd/csrc")):
+    if fn.endswith((".hip", ".hpp")):
+        hsh.update(open(os.path.join("css_amd/csrc", fn), "rb").read())
+out["_meta"] = {"csrc_sha": hsh.hexdigest()[:16], "command": "python bench.py --steps 3 --warmup 1 --no-cpu-baseline",
+                "note": "bench.py quotes traffic / mfma_busy from this file only while csrc_sha matches the tree"}
 json.dump(out, open("gpurun_out/${tag}_pmc.json", "w"), indent=1)
-for k, e in sorted(out.items(), key=lambda kv: -kv[1].get("hbm_bytes_per_launch", 0)):
+for k, e in sorted(((k, e) for k, e in out.items() if k != "_meta"), key=lambda kv: -kv[1].get("hbm_bytes_per_launch", 0)):
     print(f"{k[:56]:56s} n={e['launches']:4d} hbm {e.get('hbm_bytes_per_launch', 0) / 1e6:8.2f} MB  mfma_busy {e.get('mfma_busy_frac')}")
 PY
