@@ -69,6 +69,8 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying the "
                     "step as one captured HIP graph")
     ap.add_argument("--blocks", type=int, default=16, help="debug only: anything but 16 is not the headline config")
+    ap.add_argument("--no-ln-fold", action="store_true", help="debug A/B: keep the LayerNorm affines out of the weights and "
+                    "the q/k/v rows in natural order (the round-2 form of the chain kernel's inputs)")
     return ap.parse_args()
 
 
@@ -131,6 +133,8 @@ def main():
     model = model.to(dev)
     if args.fuse_conv is not None:
         model.fuse_conv = args.fuse_conv
+    if args.no_ln_fold:
+        model.no_ln_fold = True
 
     mix, src = syn.synthetic_sources(B, N_SAMPLES, seed=rank)
     audio = torch.stack([mix, src[0], src[1]], 0).to(dev)  # [3, B, n]

@@ -42,7 +42,7 @@ class ConformerWeights(C.Structure):
                 ("n_layer", _i32), ("kernel_size", _i32), ("n_out", _i32), ("pe_q_min", _i32), ("pe_q_max", _i32),
                 ("bn_mode", _i32), ("generic", _i32), ("fuse_conv", _i32),
                 ("embed_w", _p), ("embed_b", _p), ("embed_ln_g", _p), ("embed_ln_b", _p), ("pe_k", _p),
-                ("layers", C.POINTER(LayerWeights)), ("head_w", _p), ("head_b", _p)]
+                ("layers", C.POINTER(LayerWeights)), ("head_w", _p), ("head_b", _p), ("chain_flags", _i32)]
 
 
 class BgemmParams(C.Structure):
@@ -69,6 +69,7 @@ A_BF16, A_F32, A_F32_MVN = 0, 1, 2
 BEPI_OUT_BF16, BEPI_MASK_POS, BEPI_ADD, BEPI_SCALE_BIAS, BEPI_RELU = 1, 2, 4, 8, 16
 EPI_RELU, EPI_RESIDUAL, EPI_LAYERNORM, EPI_OUT_BF16 = 1, 2, 4, 8
 PRO_LN, PRO_BF16, PRO_F32 = 0, 1, 2
+CHAIN_QKV_IL8 = 1
 
 # name -> (restype, argtypes); mirrors include/csship.h one to one
 SIGNATURES = {
@@ -96,7 +97,7 @@ SIGNATURES = {
     "csship_embed": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "csship_outproj_glu": (_i32, [_p, _p, _p, _p, _p, C.POINTER(ConvWeights), _p, _i32, _i32, _p]),
     "csship_encoder_chain": (_i32, [_p, _p, _p, C.POINTER(ConvWeights), _i32, C.POINTER(FfnWeights), _p, _p,
-                                     C.POINTER(FfnWeights), _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
+                                     C.POINTER(FfnWeights), _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "csship_mha_relpos": (_i32, [_p, _p, _i32, _i32, _p, _i32, _i32, _i32, _p]),
     "csship_outproj_conv": (_i32, [_p, _p, _p, _p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _p]),
     "csship_ffn_bwd_workspace": (_sz, [_i32]),

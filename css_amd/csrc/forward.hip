@@ -215,7 +215,7 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
     float* gbuf = y;  // glu(LN_conv(x)) rows handed from the output projection to the next chain
     TRY(csship_encoder_chain(x, x, nullptr, nullptr, T, nullptr, nullptr, nullptr, &w->layers[0].ffn_in,
                              w->layers[0].mha.ln_g, w->layers[0].mha.ln_b, w->layers[0].mha.wqkv,
-                             w->layers[0].mha.bqkv, ws.qkv_bf, M, D, FF, 3 * D, stream));
+                             w->layers[0].mha.bqkv, ws.qkv_bf, M, D, FF, 3 * D, w->chain_flags, stream));
     for (int l = 0; l < w->n_layer; ++l) {
       const csship_layer_weights& L = w->layers[l];
       TRY(csship_mha_relpos(ws.qkv_bf, w->pe_k, w->pe_q_min, w->pe_q_max, ws.ao_bf, B, T, w->n_head, stream));
@@ -223,10 +223,10 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
       if (l + 1 < w->n_layer) {
         const csship_layer_weights& N = w->layers[l + 1];
         TRY(csship_encoder_chain(x, x, gbuf, &L.conv, T, &L.ffn_out, L.ln_g, L.ln_b, &N.ffn_in, N.mha.ln_g, N.mha.ln_b,
-                                 N.mha.wqkv, N.mha.bqkv, ws.qkv_bf, M, D, FF, 3 * D, stream));
+                                 N.mha.wqkv, N.mha.bqkv, ws.qkv_bf, M, D, FF, 3 * D, w->chain_flags, stream));
       } else {
         TRY(csship_encoder_chain(x, x, gbuf, &L.conv, T, &L.ffn_out, L.ln_g, L.ln_b, nullptr, nullptr, nullptr, nullptr,
-                                 nullptr, nullptr, M, D, FF, 0, stream));
+                                 nullptr, nullptr, M, D, FF, 0, 0, stream));
       }
     }
   } else {
@@ -239,7 +239,7 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
         TimelineScope tl(P ? CSSHIP_TL_CHAIN : CSSHIP_TL_CHAIN_EDGE, as_stream(stream));
         TRY(csship_encoder_chain(x, x, nullptr, nullptr, T, P ? &P->ffn_out : nullptr, P ? P->ln_g : nullptr,
                                  P ? P->ln_b : nullptr, &L.ffn_in, L.mha.ln_g, L.mha.ln_b, L.mha.wqkv, L.mha.bqkv,
-                                 ws.qkv_bf, M, D, FF, 3 * D, stream));
+                                 ws.qkv_bf, M, D, FF, 3 * D, w->chain_flags, stream));
       }
       {
         TimelineScope tl(CSSHIP_TL_ATTN, as_stream(stream));
@@ -264,7 +264,7 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
     const csship_layer_weights& L = w->layers[w->n_layer - 1];
     TimelineScope tl(CSSHIP_TL_CHAIN_EDGE, as_stream(stream));
     TRY(csship_encoder_chain(x, x, nullptr, nullptr, T, &L.ffn_out, L.ln_g, L.ln_b, nullptr, nullptr, nullptr, nullptr,
-                             nullptr, nullptr, M, D, FF, 0, stream));
+                             nullptr, nullptr, M, D, FF, 0, 0, stream));
   }
   if (enc_out) {
     if (hipMemcpyAsync(enc_out, x, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream)) !=

@@ -735,9 +735,13 @@ struct ChainArgs {
   int M, FF, NQKV;
   float alpha;
   unsigned long long* stamps;  // -DP_STAMPS diagnostic builds only
+  int qkv_il8;                 // wqkv / bqkv in the 8-feature interleaved row order (CSSHIP_CHAIN_QKV_IL8)
 };
 
-// LayerNorm of the register rows -> bf16 activation panel in LDS
+// LayerNorm of the register rows -> bf16 activation panel in LDS.  gam == nullptr: no affine - the caller folded gamma
+// into the columns of the Linear that consumes the panel and W.beta into its bias (css_amd/models/conformer.py _pack):
+// 16 float4 loads per thread = 128 KB per workgroup less through the texture path, and no wait behind the weight
+// prefetch that was issued just before (loads return in order: phase stamps, 4 300 cycles per prologue with them)
 DEV void rows_to_panel(unsigned char* panel, const float4 (&v)[8], const float* gam, const float* bet, int r, int part) {
   float s = 0.f;
 #pragma unroll
@@ -750,6 +754,15 @@ DEV void rows_to_panel(unsigned char* panel, const float4 (&v)[8], const float* 
     ss += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
   }
   const float rstd = rsqrtf(sum8(ss) * (1.f / DM) + 1e-5f);
+  if (gam == nullptr) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c4 = i * 8 + part;
+      *reinterpret_cast<uint2*>(panel + panel_off(r, c4 >> 1) + (c4 & 1) * 8) =
+          make_uint2(pack_bf2((v[i].x - mean) * rstd, (v[i].y - mean) * rstd), pack_bf2((v[i].z - mean) * rstd, (v[i].w - mean) * rstd));
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int c4 = i * 8 + part;
@@ -783,6 +796,9 @@ DEV void ffn_stage(float4 (&v)[8], unsigned char* Xs, unsigned char* Hraw, const
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) o[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float4 b2v[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) b2v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int ci = 0; ci < nchunk; ++ci) {
     const int c = (ci + rot) % nchunk;
     f32x4 h[NT][4];
@@ -821,7 +837,13 @@ DEV void ffn_stage(float4 (&v)[8], unsigned char* Xs, unsigned char* Hraw, const
     if (st0 == 1) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tq3_)::"memory"); __builtin_amdgcn_sched_barrier(0); }
 #endif
     const bf16x8* w1n = w1s + (size_t)((c + 1) % nchunk) * 16 * KS * 64;
-    mma_pass<NT>(o, hs, n, g, NT, w2c, ks2, w1n, KS, NT, wq);
+    // last chunk: nothing follows in this stream (the next stage primes its own), and the output bias is fetched
+    // now, ahead of the pass, instead of behind 8 KB per wave of prefetches nobody uses
+    if (ci + 1 == nchunk) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) b2v[t] = *reinterpret_cast<const float4*>(f.b2 + (wave * NT + t) * 16 + 4 * g);
+    }
+    mma_pass<NT>(o, hs, n, g, NT, w2c, ks2, w1n, KS, ci + 1 < nchunk ? NT : 0, wq);
 #ifdef P_STAMPS
     if (st0 == 1 && g_stamps_dev != nullptr && (threadIdx.x & 63) == 0) {
       __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tq4_)::"memory"); __builtin_amdgcn_sched_barrier(0);
@@ -835,9 +857,6 @@ DEV void ffn_stage(float4 (&v)[8], unsigned char* Xs, unsigned char* Hraw, const
     }
 #endif
   }
-  float4 b2v[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) b2v[t] = *reinterpret_cast<const float4*>(f.b2 + (wave * NT + t) * 16 + 4 * g);
   P_T(st0 + 1)
   __syncthreads();  // every wave is done reading the hidden panels
   float* ys = reinterpret_cast<float*>(Hraw);
@@ -995,6 +1014,23 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(ChainArgs a) {
       }
       const bf16x8* wc = wbase + (size_t)tile0 * KS * 64;
       mma_pass<NT>(acc, Xs, n, g, nt, wc, KS, wc + (size_t)16 * KS * 64, KS, nnt, wq);
+      if (NT == 2 && a.qkv_il8) {
+        // CSSHIP_CHAIN_QKV_IL8 weights: rows of the wave's two tiles interleaved so that a lane's 2 x 4 results are
+        // EIGHT CONSECUTIVE features of its token row: one 16-byte store per row tile instead of two 8-byte ones
+        // (half the store instructions; every instruction writes 64 contiguous bytes of 16 rows)
+        const int f = (p * 16 + wave * NT) * 16 + 8 * g;
+        if (nt == NT && f + 7 < a.NQKV) {
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) {
+            const int orow = m0 + rt * 16 + n;
+            if (orow < a.M && (!(P_ABL & 8) || acc[0][rt][0] == 123.456f))
+              *reinterpret_cast<uint4*>(a.qkv + (size_t)orow * a.NQKV + f) =
+                  make_uint4(pack_bf2(acc[0][rt][0], acc[0][rt][1]), pack_bf2(acc[0][rt][2], acc[0][rt][3]),
+                             pack_bf2(acc[NT - 1][rt][0], acc[NT - 1][rt][1]), pack_bf2(acc[NT - 1][rt][2], acc[NT - 1][rt][3]));
+          }
+        }
+        continue;
+      }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int f = (tile0 + t) * 16 + 4 * g;
@@ -1751,19 +1787,21 @@ extern "C" int csship_encoder_chain(const float* x, float* x_out, const float* c
                                     const float* final_ln_b, const csship_ffn_weights* ffn_b, const float* qkv_ln_g,
                                     const float* qkv_ln_b, const uint16_t* wqkv_packed, const float* bqkv,
                                     uint16_t* qkv_out, int32_t M, int32_t d_model, int32_t d_ffn, int32_t n_qkv,
-                                    csship_stream_t stream) {
+                                    int32_t flags, csship_stream_t stream) {
   if (!x || !x_out) return CSSHIP_ENULL;
   if (M <= 0) return CSSHIP_EBADSHAPE;
   if (d_model != DM || d_ffn <= 0 || (d_ffn % DM) != 0) return CSSHIP_EUNSUPPORTED;
   const bool A = ffn_a != nullptr, Bs = ffn_b != nullptr, Cq = wqkv_packed != nullptr;
   if (A && (!final_ln_g || !final_ln_b)) return CSSHIP_ENULL;
-  if (Cq && (!qkv_ln_g || !qkv_ln_b || !qkv_out || n_qkv <= 0 || (n_qkv % 8) != 0)) return CSSHIP_EBADSHAPE;
+  if (Cq && (((qkv_ln_g == nullptr) != (qkv_ln_b == nullptr)) || !qkv_out || n_qkv <= 0 || (n_qkv % 8) != 0)) return CSSHIP_EBADSHAPE;
+  if ((flags & CSSHIP_CHAIN_QKV_IL8) && (!Cq || (n_qkv % 32) != 0)) return CSSHIP_EBADSHAPE;
   if (!aligned16(x) || !aligned16(x_out) || (Cq && (!aligned16(wqkv_packed) || !aligned16(qkv_out)))) return CSSHIP_EALIGN;
   const bool CV = conv_g != nullptr;
   if (CV && (!conv_w || T <= 0 || !aligned16(conv_g) || conv_g == x_out)) return CSSHIP_EBADSHAPE;
   ChainArgs a{};
   a.x = x; a.xout = x_out; a.M = M; a.FF = d_ffn; a.NQKV = n_qkv; a.alpha = 0.5f; a.g = conv_g; a.T = T;
   a.stamps = g_csship_stamps;
+  a.qkv_il8 = (flags & CSSHIP_CHAIN_QKV_IL8) ? 1 : 0;
   if (CV) a.cv = ConvW{conv_w->dw_w, conv_w->dw_b, conv_w->bn_g, conv_w->bn_b, conv_w->bn_mean, conv_w->bn_var,
                        conv_w->pw2_w, conv_w->pw2_b};
   auto conv = [](const csship_ffn_weights* w) {
@@ -1778,6 +1816,7 @@ extern "C" int csship_encoder_chain(const float* x, float* x_out, const float* c
   // first form 50.1 us, second form 54.0 us (8 waves), 61.4 us (4 waves) - see the note above chain2_kernel
   static const int form = [] { const char* e = getenv("CSSHIP_CHAIN"); return e ? atoi(e) : 1; }();
   if (form != 1 && !CV && (A || Bs)) {
+    if ((A && !ffn_a->ln_g) || (Bs && !ffn_b->ln_g) || (Cq && !qkv_ln_g) || a.qkv_il8) return CSSHIP_EUNSUPPORTED;  // second form: plain weights only
 #define C2_LAUNCH(W)                                                                                            \
   if (A && Bs && Cq) hipLaunchKernelGGL((chain2_kernel<W, true, true, true>), grid, dim3(W * 64), 0, s, a);      \
   else if (!A && Bs && Cq) hipLaunchKernelGGL((chain2_kernel<W, false, true, true>), grid, dim3(W * 64), 0, s, a); \

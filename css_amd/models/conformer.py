@@ -152,6 +152,7 @@ class Conformer(nn.Module):
         # param_generation(): FusedAdam rewrites parameter storage without touching data_ptr / _version
         from .. import param_generation
         return (self.training, getattr(self, "fuse_conv", False), getattr(self, "force_generic", False),
+                getattr(self, "no_ln_fold", False),
                 param_generation()) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def _pack(self):
@@ -177,10 +178,20 @@ class Conformer(nn.Module):
                 raise TypeError("css_amd.Conformer expects contiguous float32 parameters")
             return t.data_ptr()
 
+        # tuned d_model = 256 path: the FeedForward / attention LayerNorms' affine parts are folded into the Linear behind
+        # them (ops.fold_layernorm; the chain kernel's prologues then read no LayerNorm parameters), and the q | k | v
+        # rows are packed in the 8-feature interleave that lets the chain kernel store 16 bytes per lane
+        fold = not generic and not bool(getattr(self, "no_ln_fold", False))
+
         def ffn(m):
             w = _lib.FfnWeights()
-            w.ln_g, w.ln_b = f32(m.layer_norm.weight), f32(m.layer_norm.bias)
-            w.w1, w.b1 = own(packw(m.net[0].weight)), f32(m.net[0].bias)
+            if fold:
+                w1, b1 = ops.fold_layernorm(m.net[0].weight, m.net[0].bias, m.layer_norm.weight, m.layer_norm.bias)
+                w.ln_g, w.ln_b = None, None
+                w.w1, w.b1 = own(packw(w1)), own(b1.contiguous())
+            else:
+                w.ln_g, w.ln_b = f32(m.layer_norm.weight), f32(m.layer_norm.bias)
+                w.w1, w.b1 = own(packw(m.net[0].weight)), f32(m.net[0].bias)
             w.w2, w.b2 = own(packw(m.net[3].weight)), f32(m.net[3].bias)
             return w
 
@@ -194,8 +205,14 @@ class Conformer(nn.Module):
                               a.linear_v.weight.detach()], 0)
             bqkv = torch.cat([a.linear_q.bias.detach() * scale, a.linear_k.bias.detach(),
                               a.linear_v.bias.detach()], 0).float().contiguous()
-            L.mha.ln_g, L.mha.ln_b = f32(a.layer_norm.weight), f32(a.layer_norm.bias)
-            L.mha.wqkv, L.mha.bqkv = own(packw(wqkv)), own(bqkv)
+            if fold:
+                wqkv, bqkv = ops.fold_layernorm(wqkv, bqkv, a.layer_norm.weight, a.layer_norm.bias)
+                order = ops.il8_row_order(wqkv.shape[0], wqkv.device)
+                L.mha.ln_g, L.mha.ln_b = None, None
+                L.mha.wqkv, L.mha.bqkv = own(packw(wqkv[order])), own(bqkv[order].contiguous())
+            else:
+                L.mha.ln_g, L.mha.ln_b = f32(a.layer_norm.weight), f32(a.layer_norm.bias)
+                L.mha.wqkv, L.mha.bqkv = own(packw(wqkv)), own(bqkv)
             L.mha.wo, L.mha.bo = own(packw(a.linear_out.weight)), f32(a.linear_out.bias)
             c = lay.conv
             L.conv.ln_g, L.conv.ln_b = f32(c.layer_norm.weight), f32(c.layer_norm.bias)
@@ -216,6 +233,7 @@ class Conformer(nn.Module):
         pe_packed, w.pe_q_min, w.pe_q_max = ops.pack_relpos(self.position_table(), 1000)
         w.bn_mode = 1 if self.training else 0
         w.fuse_conv = int(getattr(self, "fuse_conv", 0))
+        w.chain_flags = _lib.CHAIN_QKV_IL8 if fold else 0
         ew = torch.zeros(enc.d_model, w.idim_pad, device=dev)
         ew[:, :enc.idim] = enc.embed[0].weight.detach().float()
         w.embed_w, w.embed_b = own(packw(ew)), f32(enc.embed[0].bias)

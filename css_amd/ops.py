@@ -469,6 +469,28 @@ def pack_frag(w):
     return wp.contiguous().to(torch.bfloat16).view(-1)
 
 
+def il8_row_order(R, device=None):
+    """Row order of the 8-feature interleaved packing (CSSHIP_CHAIN_QKV_IL8, include/csship.h): packed row 16*tile + m
+    holds feature 32*(tile//2) + 8*(m//4) + 4*(tile%2) + m%4, so that the chain kernel's lane (g, token row) - which
+    owns rows 4g..4g+3 of its wave's two tiles - ends up with the 8 consecutive features 32*wave + 8g .. + 7."""
+    assert R % 32 == 0
+    r = torch.arange(R, device=device)
+    tile, m = r // 16, r % 16
+    return 32 * (tile // 2) + 8 * (m // 4) + 4 * (tile % 2) + m % 4
+
+
+def pack_frag_il8(w):
+    """pack_frag of the rows of ``w`` [R, K] in il8_row_order (R % 32 == 0); the bias goes through the same order."""
+    return pack_frag(w.detach().float()[il8_row_order(w.shape[0], w.device)])
+
+
+def fold_layernorm(w, b, gamma, beta):
+    """Linear(LayerNorm(x)) with the LayerNorm's affine part folded into the Linear (f32):
+    (xhat * gamma + beta) W^T + b = xhat (W diag(gamma))^T + (b + W beta) -> (W', b')."""
+    w, b = w.detach().float(), b.detach().float()
+    return w * gamma.detach().float()[None, :], b + w @ beta.detach().float()
+
+
 def ffn_fused(x, ln, w1p, b1, w2p, b2, d_ffn, alpha=0.5, final_ln=None, out=None, drop_hidden=None, drop_out=None):
     """out = x + alpha * FFN(LN(x)) [-> LN]; x f32 [M,256]; w1p/w2p from pack_frag.  drop_hidden / drop_out: dropout cfg
     pointers (css_amd.dropout.DropState.cfg) of the training forward, None = no dropout."""
@@ -548,13 +570,15 @@ def istft(re, im, length=None):
 
 def _ffn_struct(ln, w1p, b1, w2p, b2):
     w = _lib.FfnWeights()
-    w.ln_g, w.ln_b, w.w1, w.b1, w.w2, w.b2 = (t.data_ptr() for t in (ln[0], ln[1], w1p, b1, w2p, b2))
+    w.ln_g, w.ln_b = (ln[0].data_ptr(), ln[1].data_ptr()) if ln is not None else (None, None)
+    w.w1, w.b1, w.w2, w.b2 = (t.data_ptr() for t in (w1p, b1, w2p, b2))
     return w
 
 
-def encoder_chain(x, d_ffn, ffn_a=None, final_ln=None, ffn_b=None, qkv=None, out=None):
-    """csship_encoder_chain on x f32 [M,256].  ffn_a / ffn_b: (ln=(g,b), w1p, b1, w2p, b2) with packed weights;
-    final_ln: (g, b) applied after ffn_a; qkv: (ln=(g,b), wqkv_packed, bqkv, n_qkv).  Returns (x_out, qkv_bf16|None)."""
+def encoder_chain(x, d_ffn, ffn_a=None, final_ln=None, ffn_b=None, qkv=None, out=None, flags=0):
+    """csship_encoder_chain on x f32 [M,256].  ffn_a / ffn_b: (ln=(g,b) or None, w1p, b1, w2p, b2) with packed weights
+    (ln None: the affine part is folded into w1p / b1, fold_layernorm); final_ln: (g, b) applied after ffn_a; qkv:
+    (ln=(g,b) or None, wqkv_packed, bqkv, n_qkv); flags: _lib.CHAIN_QKV_IL8.  Returns (x_out, qkv_bf16|None)."""
     _need(x, torch.float32, "x")
     assert x.dim() == 2 and x.is_contiguous() and x.shape[1] == 256
     M = x.shape[0]
@@ -569,6 +593,7 @@ def encoder_chain(x, d_ffn, ffn_a=None, final_ln=None, ffn_b=None, qkv=None, out
     check(lib().csship_encoder_chain(
         _ptr(x), _ptr(out), None, None, 1, C.byref(fa) if fa is not None else None,
         _ptr(final_ln[0]) if final_ln else None, _ptr(final_ln[1]) if final_ln else None,
-        C.byref(fb) if fb is not None else None, _ptr(qkv[0][0]) if qkv else None, _ptr(qkv[0][1]) if qkv else None,
-        _ptr(qkv[1]) if qkv else None, _ptr(qkv[2]) if qkv else None, _ptr(q_out), M, 256, d_ffn, n_qkv, _stream()))
+        C.byref(fb) if fb is not None else None, _ptr(qkv[0][0]) if qkv and qkv[0] else None,
+        _ptr(qkv[0][1]) if qkv and qkv[0] else None,
+        _ptr(qkv[1]) if qkv else None, _ptr(qkv[2]) if qkv else None, _ptr(q_out), M, 256, d_ffn, n_qkv, int(flags), _stream()))
     return out, q_out

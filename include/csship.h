@@ -254,7 +254,15 @@ int csship_outproj_glu(const uint16_t* attn_out, const uint16_t* wo_packed, cons
  *   [ffn_b != NULL]  x = x + 0.5 FFN_b(x)                         FFN_in of block l   (conformer.py:355)
  *   x_out <- x
  *   [wqkv != NULL]   qkv_out = bf16( LayerNorm_qkv(x) @ Wqkv^T + bqkv )   (conformer.py:222-225)
- * Supported combinations: (a,b,qkv), (b,qkv), (a), (conv,a,b,qkv), (conv,a). */
+ * Supported combinations: (a,b,qkv), (b,qkv), (a), (conv,a,b,qkv), (conv,a).
+ * A LayerNorm whose gamma AND beta pointers are NULL (ffn->ln_g / ln_b, qkv_ln_g / qkv_ln_b; never the block-final
+ * one) is applied WITHOUT its affine part: the caller folded it into the Linear behind it, W' = W diag(gamma),
+ * b' = b + W beta (css_amd.ops.fold_layernorm) - the kernel then reads no LayerNorm parameters in its prologues.
+ * flags: CSSHIP_CHAIN_QKV_IL8 = wqkv_packed / bqkv rows are in the 8-feature interleaved order of
+ * css_amd.ops.pack_frag_il8 (packed row 16*tile + m holds feature 32*(tile/2) + 8*(m/4) + 4*(tile%2) + m%4), with which
+ * a lane's results are 8 consecutive features of a token row and qkv_out is written with 16-byte stores
+ * (n_qkv % 32 == 0); qkv_out itself is in natural feature order either way. */
+#define CSSHIP_CHAIN_QKV_IL8 1
 struct csship_ffn_weights_s;
 int csship_encoder_chain(const float* x, float* x_out, const float* conv_g,
                          const struct csship_conv_weights_s* conv_w, int32_t T,
@@ -262,7 +270,7 @@ int csship_encoder_chain(const float* x, float* x_out, const float* conv_g,
                          const float* final_ln_b, const struct csship_ffn_weights_s* ffn_b,
                          const float* qkv_ln_g, const float* qkv_ln_b, const uint16_t* wqkv_packed,
                          const float* bqkv, uint16_t* qkv_out, int32_t M, int32_t d_model, int32_t d_ffn,
-                         int32_t n_qkv, csship_stream_t stream);
+                         int32_t n_qkv, int32_t flags, csship_stream_t stream);
 
 /* csship_embed: x0 = ReLU(LayerNorm(Linear(MVN_time(f))))  (css/models/conformer.py:95, 124-129) as one
  * row-panel kernel; f f32 [B, T, idim] (row stride ldf, any idim); mvn_mean / mvn_rinv from
@@ -407,6 +415,9 @@ typedef struct {
   const uint16_t* pe_k;    /* PACKED relative-position blocks (csship_mha_relpos) */
   const csship_layer_weights* layers; /* HOST array [n_layer] */
   const uint16_t* head_w; const float* head_b; /* PACKED bf16 from [n_out, d_model] */
+  int32_t chain_flags;     /* generic == 0: flags handed to csship_encoder_chain (CSSHIP_CHAIN_QKV_IL8: every layer's
+                            * mha.wqkv / bqkv in the interleaved row order).  FeedForward / attention LayerNorms with NULL
+                            * gamma and beta are folded into w1 / wqkv (see csship_encoder_chain) */
 } csship_conformer_weights;
 size_t csship_conformer_workspace(const csship_conformer_weights* w, int32_t B, int32_t T);
 /* f: f32 [B, T, idim] (row stride ldf); masks: f32 [B, T, n_out] with row stride ld_masks >= n_out

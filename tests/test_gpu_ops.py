@@ -272,6 +272,20 @@ def test_encoder_chain(ops):
     assert err(qkv.float(), rq.float()) < 6e-2  # bf16 outputs of O(4) values: one ulp = 3e-2
     assert float(((qkv.float() - rq.float()) ** 2).mean()) < 1e-5
 
+    # the form the model runs: LayerNorm affines folded into W1 / Wqkv (the prologues read no parameters) and the
+    # q | k | v rows in the 8-feature interleave (16-byte stores); same function up to bf16 rounding points
+    from css_amd import _lib
+
+    def folded(f, seed):
+        w1, b1 = ops.fold_layernorm(d(rnd((1024, 256), seed + 2, 1 / 16)), f[2], f[0][0], f[0][1])
+        return (None, ops.pack_frag(w1), b1.contiguous(), f[3], f[4])
+    wqf, bqf = ops.fold_layernorm(d(rnd((768, 256), 144, 1 / 16)), bq, qln[0], qln[1])
+    order = ops.il8_row_order(768, DEV)
+    xo2, qkv2 = ops.encoder_chain(d(x), 1024, ffn_a=folded(fa, 120), final_ln=fin, ffn_b=folded(fb, 130),
+                                  qkv=(None, ops.pack_frag(wqf[order]), bqf[order].contiguous(), 768), flags=_lib.CHAIN_QKV_IL8)
+    assert err(xo2, xo) < 1.5e-2   # max abs on O(1) values: two chains of bf16 products with different rounding points
+    assert float(((qkv2.float() - qkv.float()) ** 2).mean()) < 4e-5 and err(qkv2.float(), qkv.float()) < 6e-2
+
     def ffn64(v, seed, fin_ln=None):
         g, b = (1 + 0.1 * rnd((256,), seed)).double(), (0.1 * rnd((256,), seed + 1)).double()
         w1, b1 = bf(rnd((1024, 256), seed + 2, 1 / 16)).double(), rnd((1024,), seed + 3, 0.1).double()
@@ -282,6 +296,13 @@ def test_encoder_chain(ops):
     x64 = ffn64(ffn64(x.double(), 120, fin), 130)
     e_fused, e_sep = err(xo, x64), err(r2, x64)
     assert e_fused < 1.5 * e_sep + 1e-3, (e_fused, e_sep)
+    assert err(xo2, x64) < 1.5 * e_sep + 1e-3
+    # q | k | v against float64 on the float64 residual stream: the folded / interleaved form is as close as the plain one
+    q64 = torch.nn.functional.layer_norm(x64, (256,), qln[0].double().cpu(), qln[1].double().cpu()) @ \
+        bf(rnd((768, 256), 144, 1 / 16)).double().t() + rnd((768,), 145, 0.1).double()
+    mse_plain = float(((qkv.float().cpu().double() - q64) ** 2).mean())
+    mse_fold = float(((qkv2.float().cpu().double() - q64) ** 2).mean())
+    assert mse_fold < 1.5 * mse_plain + 1e-6, (mse_fold, mse_plain)
 
 
 # ----------------------------------------------------------------------------- attention

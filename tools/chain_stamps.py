@@ -15,7 +15,10 @@ def ffn_w():
 fa, fb = ffn_w(), ffn_w()
 wq, bq = ops.pack_frag(torch.randn(768, D, device="cuda") / 16), torch.zeros(768, device="cuda")
 out = torch.empty_like(x)
-run = lambda: ops.encoder_chain(x, 1024, ffn_a=fa, final_ln=(g1, b0), ffn_b=fb, qkv=((g1, b0), wq, bq, 768), out=out)
+FOLD = "--fold" in sys.argv
+if FOLD:
+    fa, fb = (None,) + fa[1:], (None,) + fb[1:]
+run = lambda: ops.encoder_chain(x, 1024, ffn_a=fa, final_ln=(g1, b0), ffn_b=fb, qkv=((None if FOLD else (g1, b0)), wq, bq, 768), out=out, flags=1 if FOLD else 0)
 buf = torch.zeros(256, 32, device="cuda", dtype=torch.int64)
 for _ in range(3): run()
 torch.cuda.synchronize()
