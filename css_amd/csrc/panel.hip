@@ -1462,8 +1462,15 @@ template <int NW>
 __global__ __launch_bounds__(NW * 64) void outproj_conv_kernel(OcArgs a) {
   static_assert(NW == 8, "row phases: 8 lanes per row, 64 rows per pass; stencil: 2 threads per channel");
   constexpr int NT = 16 / NW, NSTAGE = OC_ROWS * 32 / (NW * 64);
-  __shared__ __attribute__((aligned(16))) unsigned char Xs[OC_ROWS * 512];
+  // Xs: the bf16 operand panel of the projection (96 rows x 512 B), and once the GEMM is done the f32 tile of the
+  // workgroup's OWN x2 rows (50 x 1 KB): x2 stays on the CU from the row phase to the final store (it used to be
+  // written to `out`, read back by the stencil and written again: the kernel is bound by the rate at which the CU's
+  // texture-address unit takes wave memory instructions, ~170 per wave then, ~80 now)
+  constexpr int XS_BYTES = OC_TT * DM * 4 > OC_ROWS * 512 ? OC_TT * DM * 4 : OC_ROWS * 512;
+  __shared__ __attribute__((aligned(16))) unsigned char Xs[XS_BYTES];
   __shared__ __attribute__((aligned(16))) float Ys[OC_ROWS * YS];
+  __shared__ __attribute__((aligned(16))) float Ps[2 * DM];  // conv-module LayerNorm gamma | beta, staged once
+  float* const X2 = reinterpret_cast<float*>(Xs);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15;
   const int b = blockIdx.y, t0 = blockIdx.x * OC_TT;
   const size_t rowb = (size_t)b * a.T;
@@ -1471,6 +1478,8 @@ __global__ __launch_bounds__(NW * 64) void outproj_conv_kernel(OcArgs a) {
   bf16x8 wq[PD][NT];
   stamp(a.stamps, 0);
   prefetch_first<NT>(wq, ws_, KS, NT);
+  if (tid < 2 * DM / 4)
+    *reinterpret_cast<float4*>(Ps + tid * 4) = *reinterpret_cast<const float4*>((tid < DM / 4 ? a.cw.ln_g : a.cw.ln_b - DM) + tid * 4);
 
   // ---- attention-output rows of tile + halo -> bf16 panel (rows outside the utterance / beyond row 81: zero).
   // Panel loads first, then the residual rows of the row phase are put in flight, then the panel is written: the
@@ -1579,7 +1588,7 @@ __global__ __launch_bounds__(NW * 64) void outproj_conv_kernel(OcArgs a) {
         const float4 xv = xres[pass][i];
         const float4 pv = *reinterpret_cast<const float4*>(yrow + (i * 8 + part) * 4);
         v[i] = make_float4(xv.x + pv.x, xv.y + pv.y, xv.z + pv.z, xv.w + pv.w);
-        if (own) *reinterpret_cast<float4*>(a.out + (rowb + t) * DM + (i * 8 + part) * 4) = v[i];
+        if (own) *reinterpret_cast<float4*>(X2 + (r - OC_HALO) * DM + (i * 8 + part) * 4) = v[i];
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
       }
       const float mean = sum8(s) * (1.f / DM);
@@ -1593,8 +1602,8 @@ __global__ __launch_bounds__(NW * 64) void outproj_conv_kernel(OcArgs a) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int c = (i * 8 + part) * 4;
-        const float4 gm = *reinterpret_cast<const float4*>(a.cw.ln_g + c);
-        const float4 bt = *reinterpret_cast<const float4*>(a.cw.ln_b + c);
+        const float4 gm = *reinterpret_cast<const float4*>(Ps + c);
+        const float4 bt = *reinterpret_cast<const float4*>(Ps + DM + c);
         float e[4] = {v[i].x * rstd * gm.x + bt.x, v[i].y * rstd * gm.y + bt.y, v[i].z * rstd * gm.z + bt.z,
                       v[i].w * rstd * gm.w + bt.w};
 #pragma unroll
@@ -1603,7 +1612,7 @@ __global__ __launch_bounds__(NW * 64) void outproj_conv_kernel(OcArgs a) {
       }
     }
   }
-  __syncthreads();  // also orders this workgroup's x2 stores before they are read back below
+  __syncthreads();
   stamp(a.stamps, 3);
 
   // ---- depthwise conv + BatchNorm (running statistics) + ReLU + affine, added onto x2.
@@ -1620,12 +1629,6 @@ __global__ __launch_bounds__(NW * 64) void outproj_conv_kernel(OcArgs a) {
     const float scale = a.cw.bn_g[c] * rsqrtf(a.cw.bn_var[c] + 1e-5f);
     const float shift = a.cw.bn_b[c] - a.cw.bn_mean[c] * scale;
     const float pw2w = a.cw.pw2_w[0], pw2b = a.cw.pw2_b[0];
-    float x2v[TH];  // this thread's x2 values (written by the row phase of this workgroup): all loads in flight at once
-#pragma unroll
-    for (int j = 0; j < TH; ++j) {
-      const int t = min(t0 + half * TH + j, a.T - 1);
-      x2v[j] = a.out[(rowb + t) * DM + c];
-    }
     float gv[NG];
 #pragma unroll
     for (int u = 0; u < NG; ++u) gv[u] = Ys[(half * TH + u) * YS + c];
@@ -1639,13 +1642,18 @@ __global__ __launch_bounds__(NW * 64) void outproj_conv_kernel(OcArgs a) {
         const int m = u - 2 * p_;
         if (m >= 0 && m <= OC_KS) o2[p_] = __builtin_elementwise_fma(wp[m], f2{gv[u], gv[u]}, o2[p_]);
       }
+    // the branch is added onto the x2 tile in place (this thread is the only one that touches these elements) ...
 #pragma unroll
     for (int j = 0; j < TH; ++j) {
-      const int t = t0 + half * TH + j;
-      if (t >= a.T) continue;
       const float v = (j & 1) ? o2[j >> 1].y : o2[j >> 1].x;
-      a.out[(rowb + t) * DM + c] = x2v[j] + fmaxf(v * scale + shift, 0.f) * pw2w + pw2b;
+      X2[(half * TH + j) * DM + c] += fmaxf(v * scale + shift, 0.f) * pw2w + pw2b;
     }
+  }
+  __syncthreads();
+  // ... and the finished rows leave as whole 16-byte pieces, 64 lanes = one row (rows beyond the utterance: not stored)
+  for (int i = tid; i < OC_TT * (DM / 4); i += NW * 64) {
+    const int r = i / (DM / 4), c4 = i % (DM / 4), t = t0 + r;
+    if (t < a.T) *reinterpret_cast<float4*>(a.out + (rowb + t) * DM + c4 * 4) = *reinterpret_cast<const float4*>(X2 + r * DM + c4 * 4);
   }
   stamp(a.stamps, 4);
 }

@@ -491,6 +491,50 @@ def fold_layernorm(w, b, gamma, beta):
     return w * gamma.detach().float()[None, :], b + w @ beta.detach().float()
 
 
+def pack_mx(w):
+    """W [R, K] f32 -> (e4m3 bytes, e8m0 scale dwords) in the operand layout of csship_ffn_mx (include/csship.h):
+    OCP MXFP8 along K (32 consecutive elements per block, shared exponent floor(log2(max|block|)) - 8, round to nearest
+    even, saturating at +-448).  R % 16 == 0, K % 256 == 0.
+      bytes  uint8 [R/16][K/128][2][64][16]: lane 16*g + m <- W8[16*tile + m][128*ks + 64*half + 16*g + (0..15)]
+      scales int32 [R/16][K/256][64]: byte q of lane 16*b + m <- scale of block 4*(2*kp + q) + b of row 16*tile + m"""
+    R, K = w.shape
+    assert R % 16 == 0 and K % 256 == 0
+    x = w.detach().float().reshape(R, K // 32, 32)
+    amax = x.abs().amax(-1).clamp_min(2.0 ** -126)
+    e = torch.floor(torch.log2(amax)) - 8.0                                   # shared exponent per block
+    q = (x / torch.exp2(e)[..., None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8).reshape(R, K)
+    sb = (e + 127.0).clamp(0, 254).to(torch.int32)                            # e8m0 byte [R, K/32]
+    qb = q.view(R // 16, 16, K // 128, 2, 4, 16).permute(0, 2, 3, 4, 1, 5)    # [tile, ks, half, g, m, 16]
+    sc = sb.view(R // 16, 16, K // 256, 2, 4).permute(0, 2, 4, 1, 3)          # [tile, kp, b, m, q]
+    dw = sc[..., 0] | (sc[..., 1] << 8) | (127 << 16) | (127 << 24)
+    return qb.contiguous().view(-1), dw.contiguous().to(torch.int32).view(-1)
+
+
+def ffn_wide(x, ln, w1p, b1, w2p, b2, d_ffn, alpha=0.5, final_ln=None, out=None):
+    """csship_ffn_wide: out = x + alpha * FFN(LN(x)) [-> LN] for x f32 [M, 256 | 512]; w1p / w2p from pack_frag."""
+    _need(x, torch.float32, "x")
+    assert x.dim() == 2 and x.is_contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().csship_ffn_wide(_ptr(x), _ptr(out), _ptr(ln[0]), _ptr(ln[1]), _ptr(w1p), _ptr(b1), _ptr(w2p), _ptr(b2),
+                                _ptr(final_ln[0]) if final_ln else None, _ptr(final_ln[1]) if final_ln else None,
+                                x.shape[0], x.shape[1], d_ffn, float(alpha), _stream()))
+    return out
+
+
+def ffn_mx(x, ln, w1mx, b1, w2mx, b2, d_ffn, alpha=0.5, final_ln=None, out=None):
+    """csship_ffn_mx: the fused FeedForward with MXFP8 operands; w1mx / w2mx = pack_mx(W) tuples (bytes, scales)."""
+    _need(x, torch.float32, "x")
+    assert x.dim() == 2 and x.is_contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().csship_ffn_mx(_ptr(x), _ptr(out), _ptr(ln[0]), _ptr(ln[1]), _ptr(w1mx[0]), _ptr(w1mx[1]), _ptr(b1),
+                              _ptr(w2mx[0]), _ptr(w2mx[1]), _ptr(b2), _ptr(final_ln[0]) if final_ln else None,
+                              _ptr(final_ln[1]) if final_ln else None, x.shape[0], x.shape[1], d_ffn, float(alpha),
+                              _stream()))
+    return out
+
+
 def ffn_fused(x, ln, w1p, b1, w2p, b2, d_ffn, alpha=0.5, final_ln=None, out=None, drop_hidden=None, drop_out=None):
     """out = x + alpha * FFN(LN(x)) [-> LN]; x f32 [M,256]; w1p/w2p from pack_frag.  drop_hidden / drop_out: dropout cfg
     pointers (css_amd.dropout.DropState.cfg) of the training forward, None = no dropout."""

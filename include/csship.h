@@ -217,6 +217,29 @@ int csship_ffn_fused(const float* x, float* out, const float* ln_g, const float*
                      int32_t M, int32_t d_model, int32_t d_ffn, float alpha,
                      csship_stream_t stream);
 
+/* csship_ffn_wide: the same fused FeedForward for d_model 256 OR 512 (css_amd/csrc/ffnw.hip; Conformer-large of
+ * BASELINE.json configs[4]: d_model 512, d_ffn 2048): w1_packed from [d_ffn, d_model], w2_packed from [d_model, d_ffn],
+ * both in the fragment order above; x / out f32 [M, d_model] (out may alias x); d_ffn % 256 == 0. */
+int csship_ffn_wide(const float* x, float* out, const float* ln_g, const float* ln_b, const uint16_t* w1_packed,
+                    const float* b1, const uint16_t* w2_packed, const float* b2, const float* final_ln_g,
+                    const float* final_ln_b, int32_t M, int32_t d_model, int32_t d_ffn, float alpha,
+                    csship_stream_t stream);
+
+/* csship_ffn_mx: the fused FeedForward with BLOCK-SCALED FP8 operands (OCP MXFP8: e4m3 elements, one e8m0 power-of-two
+ * scale per 32 consecutive elements of the reduction dimension; v_mfma_scale_f32_16x16x128_f8f6f4) in both products:
+ * LayerNorm output and ReLU'd hidden activation are quantised in the kernel (scale 2^(floor(log2(max|block|)) - 8),
+ * round to nearest even, saturating at +-448), weights arrive quantised and packed (css_amd.ops.pack_mx):
+ *   w_mx     e4m3 bytes [R/16 tiles][K/128 k-steps][2 halves][64 lanes][16]: lane 16*g + m holds
+ *            W[16*tile + m][128*ks + 64*half + 16*g + (0..15)]   (the operand layout of the instruction, see ffnw.hip)
+ *   w_scales uint32 [R/16][K/256][64 lanes]: byte q (q = 0, 1) of lane 16*b + m = e8m0 scale of the 32-block
+ *            4*(2*kp + q) + b of row 16*tile + m; bytes 2, 3 = 127.
+ * Accumulation, biases, residual and LayerNorms are f32.  d_model 256 or 512, d_ffn % 256 == 0.  OPT-IN numerics: not
+ * within the 1e-4 mask budget on arbitrary weights; parity is stated against oracle/mxfp8.py. */
+int csship_ffn_mx(const float* x, float* out, const float* ln_g, const float* ln_b, const uint8_t* w1_mx,
+                  const uint32_t* w1_scales, const float* b1, const uint8_t* w2_mx, const uint32_t* w2_scales,
+                  const float* b2, const float* final_ln_g, const float* final_ln_b, int32_t M, int32_t d_model,
+                  int32_t d_ffn, float alpha, csship_stream_t stream);
+
 /* Training form of csship_ffn_fused with the reference's two dropouts (conformer.py:317,319):
  *   out = x + alpha * D_out( D_hid( relu(LN(x) W1^T + b1) ) W2^T + b2 )  [-> LayerNorm];
  * D_hid indexes the hidden activation as [M, d_ffn] row-major, D_out the output as [M, 256].  NULL = no dropout. */

@@ -298,8 +298,9 @@ def test_encoder_chain(ops):
     assert e_fused < 1.5 * e_sep + 1e-3, (e_fused, e_sep)
     assert err(xo2, x64) < 1.5 * e_sep + 1e-3
     # q | k | v against float64 on the float64 residual stream: the folded / interleaved form is as close as the plain one
+    # (UNROUNDED projection weights: both forms round their own weight matrix to bf16 - W or W diag(gamma))
     q64 = torch.nn.functional.layer_norm(x64, (256,), qln[0].double().cpu(), qln[1].double().cpu()) @ \
-        bf(rnd((768, 256), 144, 1 / 16)).double().t() + rnd((768,), 145, 0.1).double()
+        rnd((768, 256), 144, 1 / 16).double().t() + rnd((768,), 145, 0.1).double()
     mse_plain = float(((qkv.float().cpu().double() - q64) ** 2).mean())
     mse_fold = float(((qkv2.float().cpu().double() - q64) ** 2).mean())
     assert mse_fold < 1.5 * mse_plain + 1e-6, (mse_fold, mse_plain)
@@ -445,3 +446,56 @@ def test_pit_loss_api_golden(ops, golden):
         assert abs(float(l2) - float(g[f"loss_rot_k{K}"])) < 1e-7 and list(p2) == list(g[f"perm_rot_k{K}"])
     with pytest.raises(AssertionError):
         pit_loss(est.to(DEV), tgt[:, :10].to(DEV), axis=0)
+
+
+# ----------------------------------------------------------------------------- wide / MXFP8 FeedForward (ffnw.hip)
+def _ffn_params(D, FF, seed):
+    g, b = 1 + 0.1 * rnd((D,), seed), 0.1 * rnd((D,), seed + 1)
+    w1, b1 = rnd((FF, D), seed + 2, D ** -0.5), rnd((FF,), seed + 3, 0.1)
+    w2, b2 = rnd((D, FF), seed + 4, FF ** -0.5), rnd((D,), seed + 5, 0.1)
+    return g, b, w1, b1, w2, b2
+
+
+def _ffn_ref64(x, g, b, w1, b1, w2, b2, fin=None, qx=lambda t: t, qw=lambda t: t):
+    """x + 0.5 * FFN(LN(x)) [-> LN] in float64 with operand roundings qx (activations) / qw (weights)."""
+    D = x.shape[1]
+    a = torch.nn.functional.layer_norm(x.double(), (D,), g.double(), b.double())
+    h = torch.relu(qx(a.float()).double() @ qw(w1).double().t() + b1.double())
+    y = x.double() + 0.5 * (qx(h.float()).double() @ qw(w2).double().t() + b2.double())
+    return torch.nn.functional.layer_norm(y, (D,), fin[0].double(), fin[1].double()) if fin else y
+
+
+@pytest.mark.parametrize("D,FF,M", [(256, 1024, 300), (512, 2048, 200), (512, 1024, 64)])
+def test_ffn_wide_bf16(ops, D, FF, M):
+    """csship_ffn_wide (d_model 256 / 512) vs float64 on the same bf16-rounded operands, with and without the final LN."""
+    g, b, w1, b1, w2, b2 = _ffn_params(D, FF, 500 + D)
+    x = rnd((M, D), 510 + D) * 1.5
+    fin = (1 + 0.1 * rnd((D,), 520), 0.1 * rnd((D,), 521))
+    d = lambda t: t.to(DEV)  # noqa: E731
+    for f in (None, fin):
+        out = ops.ffn_wide(d(x), (d(g), d(b)), ops.pack_frag(d(w1)), d(b1), ops.pack_frag(d(w2)), d(b2), FF, 0.5,
+                           final_ln=(d(f[0]), d(f[1])) if f else None)
+        ref = _ffn_ref64(x, g, b, w1, b1, w2, b2, f, qx=bf, qw=bf)
+        assert err(out, ref) < 3e-3, (D, FF, f is not None)
+
+
+@pytest.mark.parametrize("D,FF,M", [(256, 1024, 300), (512, 2048, 200), (512, 1024, 64)])
+def test_ffn_mx(ops, D, FF, M):
+    """csship_ffn_mx vs float64 on MXFP8-quantised operands (oracle/mxfp8.py: the OCP MX rule restated) - tight; and
+    the format's own price vs the unquantised float64 FeedForward - loose, reported."""
+    g, b, w1, b1, w2, b2 = _ffn_params(D, FF, 600 + D)
+    x = rnd((M, D), 610 + D) * 1.5
+    fin = (1 + 0.1 * rnd((D,), 620), 0.1 * rnd((D,), 621))
+    d = lambda t: t.to(DEV)  # noqa: E731
+    q = oracle.mxfp8.quantize
+    w1p, w2p = ops.pack_mx(d(w1)), ops.pack_mx(d(w2))
+    for f in (None, fin):
+        out = ops.ffn_mx(d(x), (d(g), d(b)), w1p, d(b1), w2p, d(b2), FF, 0.5, final_ln=(d(f[0]), d(f[1])) if f else None)
+        ref_q = _ffn_ref64(x, g, b, w1, b1, w2, b2, f, qx=q, qw=q)
+        ref = _ffn_ref64(x, g, b, w1, b1, w2, b2, f)
+        e_q, e_fmt = err(out, ref_q), err(out, ref)
+        # a LayerNorm output that differs in the last f32 bit can land on the other side of an e4m3 rounding boundary
+        # (1 fp8 ulp = 6 % of one element): the bound is on the mean, the max is reported by the assert message
+        mse_q = float(((out.cpu().double() - ref_q) ** 2).mean())
+        assert mse_q < 2e-6 and e_q < 3e-2, (D, FF, e_q, mse_q)
+        assert e_fmt < 0.3, (D, FF, e_fmt)
