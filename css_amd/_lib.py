@@ -25,7 +25,7 @@ class ConvWeights(C.Structure):
 
 
 class FfnWeights(C.Structure):
-    _fields_ = [(n, _p) for n in ("ln_g", "ln_b", "w1", "b1", "w2", "b2")]
+    _fields_ = [(n, _p) for n in ("ln_g", "ln_b", "w1", "b1", "w2", "b2", "w1_scale", "w2_scale")]
 
 
 class MhaWeights(C.Structure):
@@ -42,7 +42,8 @@ class ConformerWeights(C.Structure):
                 ("n_layer", _i32), ("kernel_size", _i32), ("n_out", _i32), ("pe_q_min", _i32), ("pe_q_max", _i32),
                 ("bn_mode", _i32), ("generic", _i32), ("fuse_conv", _i32),
                 ("embed_w", _p), ("embed_b", _p), ("embed_ln_g", _p), ("embed_ln_b", _p), ("pe_k", _p),
-                ("layers", C.POINTER(LayerWeights)), ("head_w", _p), ("head_b", _p), ("chain_flags", _i32)]
+                ("layers", C.POINTER(LayerWeights)), ("head_w", _p), ("head_b", _p), ("ffn_mode", _i32),
+                ("chain_flags", _i32)]
 
 
 class BgemmParams(C.Structure):

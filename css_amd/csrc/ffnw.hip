@@ -253,18 +253,31 @@ DEV i32x8 frag8(const i32x4& lo, const i32x4& hi) { return __builtin_shufflevect
 // Weight streams are addressed as (wave-uniform pointer, kept in SGPRs) + (this lane's byte offset, ONE VGPR): with
 // per-lane 64-bit pointers hipcc keeps a VGPR pair per (tile, k-step) it prefetches - ~100 registers of addresses at
 // d_model 512, which is what pushed the kernel into scratch.
+// Loads go through a buffer descriptor: address = descriptor base + (wave-uniform byte offset: an SGPR) + (lane * 16:
+// one VGPR) - the addressing form cannot degrade into per-lane 64-bit pointers.
+typedef __attribute__((ext_vector_type(4))) unsigned v4u_t;
 struct WStream {
-  const unsigned char* base;  // wave-uniform
-  unsigned lane_off;          // lane * 16
+  __amdgpu_buffer_rsrc_t rs;
+  unsigned base;      // wave-uniform byte offset of (tile 0, k-step 0, half 0) of this stream
+  unsigned lane_off;  // lane * 16
 };
-DEV i32x8 load_frag(const WStream& w, size_t piece) {  // two 16-byte pieces 64 lanes apart -> one 8-register operand
-  const unsigned char* p = w.base + piece * 1024;
-  return frag8(*reinterpret_cast<const i32x4*>(p + w.lane_off), *reinterpret_cast<const i32x4*>(p + 1024 + w.lane_off));
+DEV i32x8 load_frag(const WStream& w, unsigned piece) {  // two 16-byte pieces 1 KB apart -> one 8-register operand
+  const unsigned so = w.base + piece * 1024u;
+  const v4u_t lo = __builtin_amdgcn_raw_buffer_load_b128(w.rs, w.lane_off, so, 0);
+  const v4u_t hi = __builtin_amdgcn_raw_buffer_load_b128(w.rs, w.lane_off, so + 1024u, 0);
+  return frag8(__builtin_bit_cast(i32x4, lo), __builtin_bit_cast(i32x4, hi));
 }
+// fp8 panels: rows of ROWB bytes PADDED by 32 (no XOR swizzle).  Row r, 16-byte piece c sits in bank slot
+// (2 r + c) mod 16: for every lane group of a ds_read_b128 ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... = eight
+// rows at lane group g and eight at g + 1) the 16 slots are distinct, i.e. conflict free - and, unlike the swizzle,
+// the address of (k-step, half) is the row's base + a compile-time constant: ONE address register per row tile instead
+// of one per (row tile, k-step, half), ~80 registers at d_model 512.
+template <int ROWB>
+DEV int poff8(int row, int byte) { return row * (ROWB + 32) + byte; }
 template <int ROWB>
 DEV i32x8 lds_frag(const unsigned char* panel8, int row, int ks, int g) {
-  return frag8(*reinterpret_cast<const i32x4*>(panel8 + poff<ROWB>(row, ks * 8 + g)),
-               *reinterpret_cast<const i32x4*>(panel8 + poff<ROWB>(row, ks * 8 + 4 + g)));
+  const unsigned char* p = panel8 + poff8<ROWB>(row, 16 * g);
+  return frag8(*reinterpret_cast<const i32x4*>(p + ks * 128), *reinterpret_cast<const i32x4*>(p + ks * 128 + 64));
 }
 template <int OW, int OX>
 DEV f32x4 mx_mfma(const i32x8& w, const i32x8& x, const f32x4& c, unsigned ws, unsigned xs) {
@@ -280,7 +293,7 @@ DEV f32x4 mx_mfma_ks(const i32x8& w, const i32x8& x, const f32x4& c, unsigned ws
 }
 
 // One pass: acc[t][rt] += W(tile t)[16 x 128*KSTEPS] . panel8^T, both operands block-scaled.
-//   panel8: e4m3 rows of ROWB bytes (16-byte pieces XOR-swizzled by row & 15); xsc: dword (row, g) = the scale bytes of
+//   panel8: e4m3 rows of ROWB (+ 32 padding) bytes, see poff8; xsc: dword (row, g) = the scale bytes of
 //   blocks g, 4 + g, 8 + g, 12 + g of the row (byte = k-step).
 //   w: this lane's pointer at (tile 0, k-step 0, half 0); tile t / k-step ks / half hf at w[(t * tstride + ks * 2 + hf) * 64].
 //   wsc[t][kp]: scale dwords of the pass (loaded by the caller a pass ahead).
@@ -308,10 +321,10 @@ struct PassMx {
     __builtin_amdgcn_sched_barrier(0);
     if (STEP + PDM < KSTEPS) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) wq[STEP % PDM][t] = load_frag(w, (size_t)t * tstride + (STEP + PDM) * 2);
+      for (int t = 0; t < NT; ++t) wq[STEP % PDM][t] = load_frag(w, (unsigned)(t * tstride + (STEP + PDM) * 2));
     } else if (has_next) {
 #pragma unroll
-      for (int t = 0; t < NTN; ++t) wq[STEP % PDM][t] = load_frag(wn, (size_t)t * nstride + (STEP + PDM - KSTEPS) * 2);
+      for (int t = 0; t < NTN; ++t) wq[STEP % PDM][t] = load_frag(wn, (unsigned)(t * nstride + (STEP + PDM - KSTEPS) * 2));
     }
     if (XB == 1 && STEP + 1 < KSTEPS) {
 #pragma unroll
@@ -340,24 +353,29 @@ __global__ __launch_bounds__(512) void ffnmx_kernel(FfnMxArgs a) {
   // NH: the W2 pass runs as NH sub-passes of 2 output tiles per wave (d_model 512: the wave's 4 output tiles = 64
   // accumulator registers, and a 4-tile weight ring next to them does not fit 256 registers; the hidden operands are
   // read from LDS once per sub-pass instead)
-  constexpr int KS1 = D / 128, KP1 = (KS1 + 1) / 2, NH = D / 256, NTO = 2 * NH, XROWB = D, HROWB = 256, HBYTES = BM * HROWB;
-  constexpr int NTM = 2, XB = D == 256 ? 2 : 1;
+  constexpr int KS1 = D / 128, KP1 = (KS1 + 1) / 2, NH = D / 256, NTO = 2 * NH, XROWB = D, HROWB = 256;
+  constexpr int XBYTES = BM * (XROWB + 32), HBYTES = BM * (HROWB + 32);
+  constexpr int NTM = 2, XB = 2;
   constexpr int SC_BYTES = BM * 16;  // [64 rows][4 g] dwords
-  constexpr int PANELS = BM * XROWB + SC_BYTES + 2 * (HBYTES + SC_BYTES), YSB = BM * (D + 4) * 4;
+  constexpr int PANELS = XBYTES + SC_BYTES + 2 * (HBYTES + SC_BYTES), YSB = BM * (D + 4) * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem[PANELS > YSB ? PANELS : YSB];
   unsigned char* const X8 = smem;
-  unsigned* const xsc = reinterpret_cast<unsigned*>(smem + BM * XROWB);
-  unsigned char* const H8 = smem + BM * XROWB + SC_BYTES;           // buffer b at H8 + b * (HBYTES + SC_BYTES): panel | scales
+  unsigned* const xsc = reinterpret_cast<unsigned*>(smem + XBYTES);
+  unsigned char* const H8 = smem + XBYTES + SC_BYTES;               // buffer b at H8 + b * (HBYTES + SC_BYTES): panel | scales
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, n = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: everything derived from it stays scalar
   const int m0 = blockIdx.x * BM, nchunk = a.FF / 256, ks2 = a.FF / 128, kp2 = a.FF / 256, rot = blockIdx.x % nchunk;
   const unsigned lane16 = (unsigned)lane * 16u, lane4 = (unsigned)lane * 4u;
   // byte offsets (uniform): W1 tile = KS1 * 2 pieces of 1 KB, chunk c = 16 tiles; W2 tile = ks2 * 2 pieces, chunk c = k-steps 2c, 2c + 1
-  const unsigned char* const w1b = reinterpret_cast<const unsigned char*>(a.w1) + (size_t)(wave * 2) * KS1 * 2 * 1024;
-  const unsigned char* const w2b = reinterpret_cast<const unsigned char*>(a.w2) + (size_t)(wave * NTO) * ks2 * 2 * 1024;
-  const unsigned char* const w1sb = reinterpret_cast<const unsigned char*>(a.w1s) + (size_t)(wave * 2) * KP1 * 256;
-  const unsigned char* const w2sb = reinterpret_cast<const unsigned char*>(a.w2s) + (size_t)(wave * NTO) * kp2 * 256;
-  auto sc_load = [&](const unsigned char* b, size_t dword_row) { return *reinterpret_cast<const unsigned*>(b + dword_row * 256 + lane4); };
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.w1), 0, a.FF * D, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.w2), 0, a.FF * D, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rss1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(a.w1s), 0, a.FF / 16 * KP1 * 256, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rss2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(a.w2s), 0, D / 16 * kp2 * 256, 0x00020000);
+  const unsigned w1b = (unsigned)(wave * 2) * KS1 * 2 * 1024u, w2b = (unsigned)(wave * NTO) * ks2 * 2 * 1024u;
+  const unsigned w1sb = (unsigned)(wave * 2) * KP1 * 256u, w2sb = (unsigned)(wave * NTO) * kp2 * 256u;
+  auto sc_load = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned b, unsigned dword_row) {
+    return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, lane4, b + dword_row * 256u, 0);
+  };
   i32x8 wq[PDM][NTM];
   unsigned wsc1[NTM][2], wsc2[NH][NTM][2];
 #pragma unroll
@@ -367,15 +385,15 @@ __global__ __launch_bounds__(512) void ffnmx_kernel(FfnMxArgs a) {
     for (int hf = 0; hf < NH; ++hf) wsc2[hf][t][0] = wsc2[hf][t][1] = 0x7f7f7f7fu;
   }
   {
-    const WStream w1c{w1b + (size_t)rot * 16 * KS1 * 2 * 1024, lane16};
+    const WStream w1c{rs1, w1b + (unsigned)rot * 16 * KS1 * 2 * 1024u, lane16};
 #pragma unroll
     for (int k = 0; k < PDM; ++k)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) wq[k][t] = load_frag(w1c, (size_t)t * KS1 * 2 + k * 2);
+      for (int t = 0; t < 2; ++t) wq[k][t] = load_frag(w1c, (unsigned)(t * KS1 * 2 + k * 2));
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int kp = 0; kp < KP1; ++kp) wsc1[t][kp] = sc_load(w1sb, (size_t)(rot * 16 + t) * KP1 + kp);
+      for (int kp = 0; kp < KP1; ++kp) wsc1[t][kp] = sc_load(rss1, w1sb, (unsigned)((rot * 16 + t) * KP1 + kp));
     __builtin_amdgcn_sched_barrier(0);
   }
   {  // LayerNorm -> e4m3 operand panel + block scales.  Block i of row r = the i-th piece of its 8 lanes.
@@ -388,7 +406,7 @@ __global__ __launch_bounds__(512) void ffnmx_kernel(FfnMxArgs a) {
       const float am = max8(fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))));
       const unsigned sb = mx_scale_byte(am);
       const int c4 = i * 8 + part;  // 4-byte piece index in the row
-      *reinterpret_cast<unsigned*>(X8 + poff<XROWB>(r, c4 >> 2) + (c4 & 3) * 4) = mx_pack4(v[i].x, v[i].y, v[i].z, v[i].w, mx_inv_scale(sb));
+      *reinterpret_cast<unsigned*>(X8 + poff8<XROWB>(r, c4 * 4)) = mx_pack4(v[i].x, v[i].y, v[i].z, v[i].w, mx_inv_scale(sb));
       if ((i & 7) == part)  // block i: k-step i / 4, lane group i % 4
         reinterpret_cast<unsigned char*>(xsc)[(r * 4 + (i & 3)) * 4 + (i >> 2)] = (unsigned char)sb;
     }
@@ -410,13 +428,13 @@ __global__ __launch_bounds__(512) void ffnmx_kernel(FfnMxArgs a) {
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) h[t][rt] = f32x4{bb.x, bb.y, bb.z, bb.w};
     }
-    const WStream w1c{w1b + (size_t)c * 16 * KS1 * 2 * 1024, lane16};
-    const WStream w2c{w2b + (size_t)c * 2 * 2 * 1024, lane16};
+    const WStream w1c{rs1, w1b + (unsigned)c * 16 * KS1 * 2 * 1024u, lane16};
+    const WStream w2c{rs2, w2b + (unsigned)c * 2 * 2 * 1024u, lane16};
     // scale dwords of this chunk's W2 sub-passes: requested now, used after the W1 pass
 #pragma unroll
     for (int hf = 0; hf < NH; ++hf)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) wsc2[hf][t][0] = sc_load(w2sb, (size_t)(hf * 2 + t) * kp2 + c);
+      for (int t = 0; t < 2; ++t) wsc2[hf][t][0] = sc_load(rss2, w2sb, (unsigned)((hf * 2 + t) * kp2 + c));
     pass_mx<2, 2, KS1, XROWB, NTM, XB>(h, X8, xsc, n, g, w1c, KS1 * 2, w2c, ks2 * 2, true, wsc1, wq);
     // hidden = relu(h) as one MX block per (row, wave): the wave's 32 features ARE block `wave` of this 256-chunk
     unsigned char* hb = H8 + (ci & 1) * (HBYTES + SC_BYTES);
@@ -433,21 +451,21 @@ __global__ __launch_bounds__(512) void ffnmx_kernel(FfnMxArgs a) {
       const float inv = mx_inv_scale(sb);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
-        *reinterpret_cast<unsigned*>(hb + poff<HROWB>(rt * 16 + n, wave * 2 + t) + 4 * g) = mx_pack4(h[t][rt][0], h[t][rt][1], h[t][rt][2], h[t][rt][3], inv);
+        *reinterpret_cast<unsigned*>(hb + poff8<HROWB>(rt * 16 + n, (wave * 2 + t) * 16 + 4 * g)) = mx_pack4(h[t][rt][0], h[t][rt][1], h[t][rt][2], h[t][rt][3], inv);
       if (g == 0) hsc[((rt * 16 + n) * 4 + (wave & 3)) * 4 + (wave >> 2)] = (unsigned char)sb;  // block wave: k-step wave / 4, group wave % 4
     }
     // scale dwords of the next chunk's W1 pass
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int kp = 0; kp < KP1; ++kp) wsc1[t][kp] = sc_load(w1sb, (size_t)(cn * 16 + t) * KP1 + kp);
+      for (int kp = 0; kp < KP1; ++kp) wsc1[t][kp] = sc_load(rss1, w1sb, (unsigned)((cn * 16 + t) * KP1 + kp));
     __syncthreads();
-    const WStream w1n{w1b + (size_t)cn * 16 * KS1 * 2 * 1024, lane16};
+    const WStream w1n{rs1, w1b + (unsigned)cn * 16 * KS1 * 2 * 1024u, lane16};
 #pragma unroll
     for (int hf = 0; hf < NH; ++hf) {
-      const WStream wcur{w2c.base + (size_t)(hf * 2) * ks2 * 2 * 1024, lane16};
+      const WStream wcur{rs2, w2c.base + (unsigned)(hf * 2) * ks2 * 2 * 1024u, lane16};
       const bool last = hf + 1 == NH;
-      const WStream wnext{last ? w1n.base : wcur.base + (size_t)2 * ks2 * 2 * 1024, lane16};
+      const WStream wnext{last ? rs1 : rs2, last ? w1n.base : wcur.base + 2u * ks2 * 2 * 1024u, lane16};
       pass_mx<2, 2, 2, HROWB, NTM, XB>(o[hf], hb, reinterpret_cast<const unsigned*>(hsc), n, g, wcur, ks2 * 2, wnext,
                                        last ? KS1 * 2 : ks2 * 2, !last || ci + 1 < nchunk, wsc2[hf], wq);
     }

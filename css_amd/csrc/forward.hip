@@ -84,21 +84,29 @@ int forward_generic(const csship_conformer_weights* w, const float* f, int64_t l
     TRY(csship_layernorm_relu(ws.x1, M, D, w->embed_ln_g, w->embed_ln_b, 1, nullptr, ws.x0, stream));
   }
   float *x = ws.x0, *y = ws.x1;
+  // one FeedForward: x <- x + 0.5 FFN(LN(x)) in place, or (fin) out <- LayerNorm_fin(x + 0.5 FFN(LN(x)))
+  auto feed_forward = [&](const csship_ffn_weights& f, float* xin, float* out, const float* fin_g, const float* fin_b) -> int {
+    if (w->ffn_mode == 2)
+      return csship_ffn_mx(xin, out, f.ln_g, f.ln_b, reinterpret_cast<const uint8_t*>(f.w1), f.w1_scale, f.b1,
+                           reinterpret_cast<const uint8_t*>(f.w2), f.w2_scale, f.b2, fin_g, fin_b, M, D, FF, 0.5f, stream);
+    if (w->ffn_mode == 1)
+      return csship_ffn_wide(xin, out, f.ln_g, f.ln_b, f.w1, f.b1, f.w2, f.b2, fin_g, fin_b, M, D, FF, 0.5f, stream);
+    TRY(csship_layernorm(xin, M, D, f.ln_g, f.ln_b, ws.a_bf, nullptr, stream));
+    TRY(tiled_linear(ws.a_bf, CSSHIP_A_BF16, f.w1, f.b1, nullptr, ws.h_bf, M, FF, D, D, CSSHIP_EPI_RELU | BF, 0.f, stream));
+    TRY(tiled_linear(ws.h_bf, CSSHIP_A_BF16, f.w2, f.b2, xin, xin, M, D, FF, FF, CSSHIP_EPI_RESIDUAL, 0.5f, stream));
+    if (fin_g) return csship_layernorm(xin, M, D, fin_g, fin_b, nullptr, out, stream);
+    return CSSHIP_OK;
+  };
   for (int l = 0; l < w->n_layer; ++l) {
     const csship_layer_weights& L = w->layers[l];
-    TRY(csship_layernorm(x, M, D, L.ffn_in.ln_g, L.ffn_in.ln_b, ws.a_bf, nullptr, stream));
-    TRY(tiled_linear(ws.a_bf, CSSHIP_A_BF16, L.ffn_in.w1, L.ffn_in.b1, nullptr, ws.h_bf, M, FF, D, D, CSSHIP_EPI_RELU | BF, 0.f, stream));
-    TRY(tiled_linear(ws.h_bf, CSSHIP_A_BF16, L.ffn_in.w2, L.ffn_in.b2, x, x, M, D, FF, FF, CSSHIP_EPI_RESIDUAL, 0.5f, stream));
+    TRY(feed_forward(L.ffn_in, x, x, nullptr, nullptr));
     TRY(csship_layernorm(x, M, D, L.mha.ln_g, L.mha.ln_b, ws.a_bf, nullptr, stream));
     TRY(tiled_linear(ws.a_bf, CSSHIP_A_BF16, L.mha.wqkv, L.mha.bqkv, nullptr, ws.qkv_bf, M, 3 * D, D, D, BF, 0.f, stream));
     TRY(csship_mha_relpos(ws.qkv_bf, w->pe_k, w->pe_q_min, w->pe_q_max, ws.ao_bf, B, T, w->n_head, stream));
     TRY(tiled_linear(ws.ao_bf, CSSHIP_A_BF16, L.mha.wo, L.mha.bo, x, x, M, D, D, D, CSSHIP_EPI_RESIDUAL, 1.f, stream));
     TRY(csship_convmod(x, y, &L.conv, B, T, D, w->kernel_size, w->bn_mode, ws.conv_ws, stream));
     { float* t = x; x = y; y = t; }
-    TRY(csship_layernorm(x, M, D, L.ffn_out.ln_g, L.ffn_out.ln_b, ws.a_bf, nullptr, stream));
-    TRY(tiled_linear(ws.a_bf, CSSHIP_A_BF16, L.ffn_out.w1, L.ffn_out.b1, nullptr, ws.h_bf, M, FF, D, D, CSSHIP_EPI_RELU | BF, 0.f, stream));
-    TRY(tiled_linear(ws.h_bf, CSSHIP_A_BF16, L.ffn_out.w2, L.ffn_out.b2, x, x, M, D, FF, FF, CSSHIP_EPI_RESIDUAL, 0.5f, stream));
-    TRY(csship_layernorm(x, M, D, L.ln_g, L.ln_b, nullptr, y, stream));
+    TRY(feed_forward(L.ffn_out, x, y, L.ln_g, L.ln_b));   // FFN_out + the block-final LayerNorm (conformer.py:358-360)
     { float* t = x; x = y; y = t; }
   }
   if (enc_out && hipMemcpyAsync(enc_out, x, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream)) != hipSuccess)
@@ -186,6 +194,7 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
   if (w->d_model / w->n_head != 64 || w->kernel_size != 33 || w->idim_pad < w->idim) return CSSHIP_EUNSUPPORTED;
   if (w->generic) {
     if ((w->d_model != 256 && w->d_model != 512) || (w->d_ffn % 64) != 0 || (w->idim_pad % 64) != 0) return CSSHIP_EUNSUPPORTED;
+    if (w->ffn_mode < 0 || w->ffn_mode > 2 || (w->ffn_mode != 0 && (w->d_ffn % 256) != 0)) return CSSHIP_EUNSUPPORTED;
   } else if (w->d_model != 256 || (w->d_ffn % 256) != 0 || (w->idim_pad % 256) != 0) {
     return CSSHIP_EUNSUPPORTED;
   }

@@ -120,6 +120,8 @@ class Conformer(nn.Module):
         parser.add_argument("--conformer-kernel-size", type=int, default=33)
         parser.add_argument("--conformer-dropout-rate", type=float, default=0.1)
         parser.add_argument("--conformer-relative-pos-emb", type=_str2bool, default=True)
+        # css_amd only (not a reference flag): inference with block-scaled fp8 FeedForward operands, see ``fp8_ffn``
+        parser.add_argument("--conformer-fp8-ffn", type=_str2bool, default=False)
 
     @classmethod
     def build_model(cls, conf):  # conformer.py:44-61
@@ -132,8 +134,10 @@ class Conformer(nn.Module):
             "dropout_rate": float(conf["conformer_dropout_rate"]),
             "relative_pos_emb": _str2bool(conf["conformer_relative_pos_emb"]),
         }
-        return cls(in_features=conf["idim"], num_bins=conf["num_bins"], num_spk=conf["num_spk"],
-                   num_noise=conf["num_noise"], conformer_conf=conformer_conf)
+        model = cls(in_features=conf["idim"], num_bins=conf["num_bins"], num_spk=conf["num_spk"],
+                    num_noise=conf["num_noise"], conformer_conf=conformer_conf)
+        model.fp8_ffn = _str2bool(conf.get("conformer_fp8_ffn", False))
+        return model
 
     def __init__(self, in_features=257, num_bins=257, num_spk=2, num_noise=1, conformer_conf=DEFAULT_CONFORMER_CONF):
         super().__init__()
@@ -143,6 +147,12 @@ class Conformer(nn.Module):
         self._packed = None
         self._packed_key = None
         self._workspace = None
+        # OPT-IN (BASELINE.json configs[4], "fp8 MFMA ... FFN"): the inference forward runs every FeedForward with OCP
+        # MXFP8 operands - e4m3 elements, one power-of-two scale per 32 consecutive reduction elements, weights AND
+        # activations - on v_mfma_scale_f32_16x16x128_f8f6f4 (csship_ffn_mx).  NOT the parity path: on seeded random
+        # weights it costs ~2.6e-3 mask MSE against the fp32 reference (budget 1e-4); on a trained checkpoint ~5e-5
+        # (DESIGN.md).  What it computes is pinned tightly by oracle/mxfp8.py.  Training ignores the switch.
+        self.fp8_ffn = False
         # dropout seed of the training forward: ONE device word, bumped on the device by every training forward (not a
         # parameter, not in the state_dict: the keys stay the reference's)
         self.register_buffer("_drop_seed", torch.zeros(1, dtype=torch.int32), persistent=False)
@@ -152,7 +162,7 @@ class Conformer(nn.Module):
         # param_generation(): FusedAdam rewrites parameter storage without touching data_ptr / _version
         from .. import param_generation
         return (self.training, getattr(self, "fuse_conv", False), getattr(self, "force_generic", False),
-                getattr(self, "no_ln_fold", False),
+                getattr(self, "no_ln_fold", False), bool(self.fp8_ffn), getattr(self, "unfused_ffn", False),
                 param_generation()) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def _pack(self):
@@ -165,7 +175,7 @@ class Conformer(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError("css_amd.Conformer runs on an MI355X only; move the module to 'cuda' (no CPU path)")
         keep = []  # tensors owned by the pack (bf16 shadows, fused biases)
-        generic = enc.d_model != 256 or bool(getattr(self, "force_generic", False))
+        generic = enc.d_model != 256 or bool(getattr(self, "force_generic", False)) or bool(self.fp8_ffn)
         packw = ops.pad_weight_bf16 if generic else ops.pack_frag  # row-major (any width) vs MFMA fragment order
 
         def own(t):
@@ -183,6 +193,14 @@ class Conformer(nn.Module):
         # rows are packed in the 8-feature interleave that lets the chain kernel store 16 bytes per lane
         fold = not generic and not bool(getattr(self, "no_ln_fold", False))
 
+        # any-width path: the FeedForward runs as ONE kernel when the widths allow it (csship_ffn_wide, bf16, weights in
+        # fragment order), or - opt-in, self.fp8_ffn - with block-scaled fp8 operands (csship_ffn_mx, ops.pack_mx)
+        ffn_mode = 0
+        if generic and enc.d_model in (256, 512) and enc.d_ffn % 256 == 0 and not getattr(self, "unfused_ffn", False):
+            ffn_mode = 2 if self.fp8_ffn else 1
+        elif self.fp8_ffn:
+            raise RuntimeError("css_amd.Conformer: fp8_ffn needs d_model 256 or 512 and linear_units % 256 == 0")
+
         def ffn(m):
             w = _lib.FfnWeights()
             if fold:
@@ -191,8 +209,16 @@ class Conformer(nn.Module):
                 w.w1, w.b1 = own(packw(w1)), own(b1.contiguous())
             else:
                 w.ln_g, w.ln_b = f32(m.layer_norm.weight), f32(m.layer_norm.bias)
-                w.w1, w.b1 = own(packw(m.net[0].weight)), f32(m.net[0].bias)
-            w.w2, w.b2 = own(packw(m.net[3].weight)), f32(m.net[3].bias)
+                if ffn_mode == 2:
+                    q1, s1 = ops.pack_mx(m.net[0].weight)
+                    w.w1, w.w1_scale, w.b1 = own(q1), own(s1), f32(m.net[0].bias)
+                else:
+                    w.w1, w.b1 = own((ops.pack_frag if ffn_mode == 1 else packw)(m.net[0].weight)), f32(m.net[0].bias)
+            if ffn_mode == 2:
+                q2, s2 = ops.pack_mx(m.net[3].weight)
+                w.w2, w.w2_scale, w.b2 = own(q2), own(s2), f32(m.net[3].bias)
+            else:
+                w.w2, w.b2 = own((ops.pack_frag if ffn_mode == 1 else packw)(m.net[3].weight)), f32(m.net[3].bias)
             return w
 
         layers = (_lib.LayerWeights * len(enc.encoders))()
@@ -234,6 +260,7 @@ class Conformer(nn.Module):
         w.bn_mode = 1 if self.training else 0
         w.fuse_conv = int(getattr(self, "fuse_conv", 0))
         w.chain_flags = _lib.CHAIN_QKV_IL8 if fold else 0
+        w.ffn_mode = ffn_mode
         ew = torch.zeros(enc.d_model, w.idim_pad, device=dev)
         ew[:, :enc.idim] = enc.embed[0].weight.detach().float()
         w.embed_w, w.embed_b = own(packw(ew)), f32(enc.embed[0].bias)

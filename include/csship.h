@@ -408,6 +408,8 @@ typedef struct csship_ffn_weights_s {
   const float *ln_g, *ln_b;
   const uint16_t* w1; const float* b1; /* PACKED bf16 from [d_ffn, d_model]; f32 [d_ffn] */
   const uint16_t* w2; const float* b2; /* PACKED bf16 from [d_model, d_ffn]; f32 [d_model] */
+  const uint32_t *w1_scale, *w2_scale; /* csship_conformer_weights.ffn_mode == 2 only: w1 / w2 are the e4m3 bytes of
+                                        * css_amd.ops.pack_mx and these its e8m0 scale dwords (csship_ffn_mx); else NULL */
 } csship_ffn_weights;
 typedef struct {
   const float *ln_g, *ln_b;
@@ -438,6 +440,9 @@ typedef struct {
   const uint16_t* pe_k;    /* PACKED relative-position blocks (csship_mha_relpos) */
   const csship_layer_weights* layers; /* HOST array [n_layer] */
   const uint16_t* head_w; const float* head_b; /* PACKED bf16 from [n_out, d_model] */
+  int32_t ffn_mode;        /* generic == 1 only: 0 = FeedForward unfused (LayerNorm + two tiled Linears, row-major weights);
+                            * 1 = csship_ffn_wide (FeedForward weights in FRAGMENT order, d_model 256 / 512, d_ffn % 256 == 0);
+                            * 2 = csship_ffn_mx (opt-in block-scaled fp8: w1 / w2 / w*_scale from css_amd.ops.pack_mx) */
   int32_t chain_flags;     /* generic == 0: flags handed to csship_encoder_chain (CSSHIP_CHAIN_QKV_IL8: every layer's
                             * mha.wqkv / bqkv in the interleaved row order).  FeedForward / attention LayerNorms with NULL
                             * gamma and beta are folded into w1 / wqkv (see csship_encoder_chain) */
