@@ -4,8 +4,9 @@
 One "step" = one pass of the hot path over one synthetic batch that is already resident in HBM:
     raw audio (mix, source1, source2: 3 x [32, 102 656] f32)
       -> STFT magnitudes (csship_stft)                     [feature.py:45-82]
-      -> Conformer-base forward to the ReLU masks          [conformer.py:83-104]
-      -> fused mask-apply + PIT-MSE loss                   [conformer.py:103, mse.py:22-37]
+      -> Conformer-base encoder forward                    [conformer.py:83-97]
+      -> mask head + mask application + PIT-MSE loss, one kernel, masks never written
+                                                           [conformer.py:98-103, mse.py:22-37]
 Frames counted per step = B*T = 12 800 mixture frames per GPU (the two target spectrograms are work, not frames).
 
 --mode train times the training step instead: the same forward in TRAIN mode (batch-statistics BatchNorm), PIT-MSE,
@@ -25,7 +26,7 @@ Extra objects on the JSON line (task section 4):
                (chain_kernel<8,0,1,1,1>: FFN_out+LN -> FFN_in -> LN+QKV, 15 launches per step, MFMA bound):
                achieved = algorithmic flops (2 x 4*M*256*1024 + 2*M*256*768) / average launch duration; peak = 2.5
                PFLOP/s dense bf16; traffic = HBM bytes per launch from the rocprofv3 PMC passes under profiles/.
-               roofline.attention / .outproj_conv (MFMA), .stft / .pit (HBM, 2 052 and 5 140 B/frame) the same way.
+               roofline.attention / .outproj_conv (MFMA), .stft / .pit (HBM, 2 052 and 4 108 B/frame) the same way.
   cpu_baseline the oracle (fp32 CPU restatement, kind "port") timed on this box's host cores (rank 0, N = 1 only),
                BASELINE.md section 3: 1 warm-up + 3 timed passes of the full batch on all (<= 16) cores, and a second
                leg on ONE thread over a bounded sample (4 of the 32 chunks); CPU model string reported.
@@ -154,8 +155,7 @@ def main():
             # forward, which keeps every operator's input for the backward pass)
             with torch.no_grad():
                 mags = ops.stft(audio, ("mag",))["mag"]  # [3,B,T,257]
-                masks = model.forward_masks(mags[0])
-                loss, perm, _, _ = ops.pit_mse(masks, mags[0], [mags[1], mags[2]])
+                loss, perm, _ = model.forward_loss(mags[0], [mags[1], mags[2]])
             return loss
         eager_step = step
         for _ in range(args.warmup):
@@ -291,8 +291,7 @@ def main():
         def probe():
             with torch.no_grad():
                 mags = ops.stft(audio, ("mag",))["mag"]
-                masks = model.forward_masks(mags[0])
-                ops.pit_mse(masks, mags[0], [mags[1], mags[2]])
+                model.forward_loss(mags[0], [mags[1], mags[2]])
         probe()
         torch.cuda.synchronize()
         # two un-timed steps are queued first and the timeline is switched on while the GPU is still working on them:
@@ -375,13 +374,26 @@ def main():
         roof["stft"] = {"bound": "hbm", "achieved": nfr * 2052 / sdur / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
                         "frac": nfr * 2052 / sdur / PEAK_HBM, "avg_launch_us": sdur * 1e6, "bytes_per_frame": 2052,
                         "traffic": traffic_of("stft_kernel")}
-        # mask application + PIT-MSE (pit_sse + finalize launches), SURVEY 8(d): 6 168 B/frame minus the noise mask
-        pdur = tl["pit_sse"][0] + tl["pit_finalize"][0]
-        pit_bytes = 5 * 257 * 4
-        roof["pit"] = {"bound": "hbm", "achieved": B * T * pit_bytes / pdur / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
-                       "frac": B * T * pit_bytes / pdur / PEAK_HBM, "avg_launch_us": pdur * 1e6,
-                       "sse_us": tl["pit_sse"][0] * 1e6, "finalize_us": tl["pit_finalize"][0] * 1e6,
-                       "bytes_per_frame": pit_bytes, "traffic": traffic_of("pit_sse_kernel")}
+        # mask head + mask application + PIT-MSE.  Fused (csship_head_pit, the default loss-only path): the masks are never
+        # written; algorithmic bytes per frame = the encoder row (256 f32) + f_orig and the two targets (3 x 257 f32) =
+        # 4 108 B (+ 0.26 MB of head weights per launch), timed as the fused kernel + the finalize launch.  Unfused
+        # (pit_sse + finalize on materialised masks): SURVEY 8(d)'s 6 168 B/frame minus the unused noise mask.
+        fused_pit = tl["pit_sse"][1] == 0
+        if fused_pit:
+            pdur = tl["head"][0] + tl["pit_finalize"][0]
+            pit_bytes = 256 * 4 + 3 * 257 * 4
+            roof["pit"] = {"bound": "hbm", "kernel": "head_pit_kernel (mask head + mask application + pairwise SSE) + finalize",
+                           "achieved": B * T * pit_bytes / pdur / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                           "frac": B * T * pit_bytes / pdur / PEAK_HBM, "avg_launch_us": pdur * 1e6,
+                           "head_pit_us": tl["head"][0] * 1e6, "finalize_us": tl["pit_finalize"][0] * 1e6,
+                           "bytes_per_frame": pit_bytes, "traffic": traffic_of("head_pit_kernel")}
+        else:
+            pdur = tl["pit_sse"][0] + tl["pit_finalize"][0]
+            pit_bytes = 5 * 257 * 4
+            roof["pit"] = {"bound": "hbm", "achieved": B * T * pit_bytes / pdur / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                           "frac": B * T * pit_bytes / pdur / PEAK_HBM, "avg_launch_us": pdur * 1e6,
+                           "sse_us": tl["pit_sse"][0] * 1e6, "finalize_us": tl["pit_finalize"][0] * 1e6,
+                           "bytes_per_frame": pit_bytes, "traffic": traffic_of("pit_sse_kernel")}
         roof["step_kernel_us"] = {k: round(v[0] * v[1] * 1e6, 1) for k, v in tl.items()}
 
     # ---- CPU baseline: the oracle on one full batch, host cores of this box

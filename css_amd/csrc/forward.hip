@@ -111,6 +111,7 @@ int forward_generic(const csship_conformer_weights* w, const float* f, int64_t l
   }
   if (enc_out && hipMemcpyAsync(enc_out, x, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream)) != hipSuccess)
     return CSSHIP_ELAUNCH;
+  if (!masks) return CSSHIP_OK;
   csship_gemm_params p{};
   p.M = M; p.N = w->n_out; p.K = D; p.lda = D; p.ldw = (D + 63) / 64 * 64; p.ldc = (int)ld_masks; p.ldr = (int)ld_masks;
   p.a_mode = CSSHIP_A_F32; p.epilogue = CSSHIP_EPI_RELU; p.rows_per_batch = 1;
@@ -189,8 +190,8 @@ extern "C" size_t csship_conformer_workspace(const csship_conformer_weights* w, 
 extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const float* f, int64_t ldf, int32_t B,
                                         int32_t T, float* masks, int64_t ld_masks, float* enc_out, void* workspace,
                                         size_t workspace_bytes, csship_stream_t stream) {
-  if (!w || !f || !masks || !workspace || !w->layers) return CSSHIP_ENULL;
-  if (B <= 0 || T <= 0 || ldf < w->idim || ld_masks < w->n_out) return CSSHIP_EBADSHAPE;
+  if (!w || !f || (!masks && !enc_out) || !workspace || !w->layers) return CSSHIP_ENULL;
+  if (B <= 0 || T <= 0 || ldf < w->idim || (masks && ld_masks < w->n_out)) return CSSHIP_EBADSHAPE;
   if (w->d_model / w->n_head != 64 || w->kernel_size != 33 || w->idim_pad < w->idim) return CSSHIP_EUNSUPPORTED;
   if (w->generic) {
     if ((w->d_model != 256 && w->d_model != 512) || (w->d_ffn % 64) != 0 || (w->idim_pad % 64) != 0) return CSSHIP_EUNSUPPORTED;
@@ -272,14 +273,18 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
     }
     const csship_layer_weights& L = w->layers[w->n_layer - 1];
     TimelineScope tl(CSSHIP_TL_CHAIN_EDGE, as_stream(stream));
-    TRY(csship_encoder_chain(x, x, nullptr, nullptr, T, &L.ffn_out, L.ln_g, L.ln_b, nullptr, nullptr, nullptr, nullptr,
+    // the last FeedForward + block LayerNorm writes the encoder output where the caller wants it (no copy afterwards)
+    float* const xo = enc_out ? enc_out : x;
+    TRY(csship_encoder_chain(x, xo, nullptr, nullptr, T, &L.ffn_out, L.ln_g, L.ln_b, nullptr, nullptr, nullptr, nullptr,
                              nullptr, nullptr, M, D, FF, 0, 0, stream));
+    x = xo;
   }
-  if (enc_out) {
+  if (enc_out && x != enc_out) {
     if (hipMemcpyAsync(enc_out, x, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream)) !=
         hipSuccess)
       return CSSHIP_ELAUNCH;
   }
+  if (!masks) return CSSHIP_OK;  // the caller continues from enc_out (csship_head_pit: head + mask application + PIT-MSE)
   // mask head: ReLU(Linear(d_model -> num_bins*(K+1)))         (conformer.py:98-100)
   TimelineScope tl(CSSHIP_TL_HEAD, as_stream(stream));
   TRY(csship_panel_linear(x, CSSHIP_PRO_F32, nullptr, nullptr, w->head_w, w->head_b, nullptr, 0, 0.f, masks,

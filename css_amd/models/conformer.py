@@ -147,6 +147,7 @@ class Conformer(nn.Module):
         self._packed = None
         self._packed_key = None
         self._workspace = None
+        self._head_pit, self._head_pit_key = None, None
         # OPT-IN (BASELINE.json configs[4], "fp8 MFMA ... FFN"): the inference forward runs every FeedForward with OCP
         # MXFP8 operands - e4m3 elements, one power-of-two scale per 32 consecutive reduction elements, weights AND
         # activations - on v_mfma_scale_f32_16x16x128_f8f6f4 (csship_ffn_mx).  NOT the parity path: on seeded random
@@ -311,6 +312,39 @@ class Conformer(nn.Module):
             C.byref(w), ops._ptr(f), f.stride(1), B, T, ops._ptr(masks), masks.stride(1), ops._ptr(enc_out),
             ops._ptr(self._workspace), self._workspace.numel(), ops._stream()))
         return (masks, enc_out) if want_encoder_out else masks
+
+    def forward_loss(self, f, targets, want_pairs=False):
+        """Loss-only inference path (validation, the fwd+PIT benchmark): features -> encoder -> mask head -> mask
+        application -> PIT-MSE with the mask tensors never written (csship_head_pit).  f f32 [N,T,idim]; targets: K x
+        [N,T,num_bins].  Returns (loss 0-dim, perm int32 [N,K], pair_sse or None) - the same values as
+        ``ops.pit_mse(self.forward_masks(f), f, targets)`` up to f32 summation order.  Shapes the fused kernel is not
+        built for (K != 2, num_bins != 257, d_model != 256, T < 64, the any-width path) take exactly that route."""
+        K = len(targets)
+        T = f.shape[1]
+        fused = (K == 2 == self.num_spk and self.num_bins == 257 and self.conformer.d_model == 256 and T >= 64
+                 and not getattr(self, "no_head_pit", False))
+        if not fused:
+            loss, perm, _, pairs = ops.pit_mse(self.forward_masks(f), f, targets, want_pairs=want_pairs)
+            return loss, perm, pairs
+        ops._need(f, torch.float32, "f")
+        if f.stride(2) != 1 or f.stride(0) != T * f.stride(1):
+            f = f.contiguous()
+        w, _layers, keep = self._pack()
+        if w.generic:
+            loss, perm, _, pairs = ops.pit_mse(self.forward_masks(f), f, targets, want_pairs=want_pairs)
+            return loss, perm, pairs
+        B = f.shape[0]
+        need = _lib.lib().csship_conformer_workspace(C.byref(w), B, T)
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != f.device:
+            self._workspace = torch.empty(need, device=f.device, dtype=torch.uint8)
+        enc_out = torch.empty(B, T, w.d_model, device=f.device, dtype=torch.float32)
+        _lib.check(_lib.lib().csship_conformer_forward(
+            C.byref(w), ops._ptr(f), f.stride(1), B, T, None, 0, ops._ptr(enc_out), ops._ptr(self._workspace),
+            self._workspace.numel(), ops._stream()))
+        if self._head_pit_key != self._packed_key:
+            self._head_pit = ops.pack_head_pit(self.linear.weight, self.linear.bias, K, self.num_bins)
+            self._head_pit_key = self._packed_key
+        return ops.head_pit(enc_out, self._head_pit[0], self._head_pit[1], f, targets, want_pairs=want_pairs)
 
     def forward(self, f):
         """f: N x T x F (or 1 x N x T x F) -> (y_pred [N,K,T,F], masks tuple of K+1 x [N,T,F])."""

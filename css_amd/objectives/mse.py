@@ -34,11 +34,17 @@ class MeanSquaredError(torch.nn.Module):
         if hasattr(model, "forward_masks"):  # css_amd model: fused mask-apply + PIT
             if xs.ndim == 4:
                 xs = xs.squeeze(0)
-            masks = model.forward_masks(xs)
             B, T, _ = xs.shape
             F = model.num_bins
             assert model.num_spk == 2, "MeanSquaredError hard-codes two sources (mse.py:27-28)"
             assert tuple(y1.shape) == (B, T, F), f"{(B, 2, T, F)} != {tuple(torch.stack((y1, y2), 1).shape)}"
+            wants_grad = torch.is_grad_enabled() and (model.training or getattr(model, "eval_gradients", False)) and \
+                any(p.requires_grad for p in model.parameters())
+            if not wants_grad and hasattr(model, "forward_loss"):   # loss only: head + mask application + PIT in one kernel
+                loss, perm, _ = model.forward_loss(xs, [y1, y2])
+                self.last_permutation = perm
+                return loss
+            masks = model.forward_masks(xs)
             if masks.requires_grad:  # training: hand-written PIT backward w.r.t. the masks
                 from ..autograd import PitMse
                 loss, perm = PitMse.apply(masks, xs, model.num_spk + model.num_noise, y1, y2)

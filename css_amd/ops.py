@@ -397,6 +397,38 @@ def pit_mse(masks, f_orig, targets, want_y_pred=False, want_pairs=False):
     return loss, perm, y_pred, pairs
 
 
+def pack_head_pit(w, b, K, F):
+    """Head rows for csship_head_pit: the first K*F rows of the mask head ([n_out, 256] weight, [n_out] bias) reordered as
+    (speaker 0 bins 0..255 | speaker 1 bins 0..255 | ... | one 16-row tile: bin 256 of speaker 0 .. K-1, zero padded),
+    fragment-packed; returns (w_packed bf16, bias_perm f32)."""
+    assert F == 257 and w.shape[1] == 256 and w.shape[0] >= K * F
+    idx = torch.cat([torch.arange(k * F, k * F + 256) for k in range(K)] + [torch.tensor([k * F + 256 for k in range(K)])]).to(w.device)
+    wp = torch.zeros(K * 256 + 16, 256, device=w.device, dtype=torch.float32)
+    bp = torch.zeros(K * 256 + 16, device=w.device, dtype=torch.float32)
+    wp[:idx.numel()] = w.detach().float()[idx]
+    bp[:idx.numel()] = b.detach().float()[idx]
+    return pack_frag(wp), bp.contiguous()
+
+
+def head_pit(x_enc, w_packed, bias_perm, f_orig, targets, want_pairs=False):
+    """csship_head_pit: x_enc f32 [B,T,256] -> (loss 0-dim, perm int32 [B,K], pair_sse or None); masks never materialised."""
+    _need(x_enc, torch.float32, "x_enc")
+    _need(f_orig, torch.float32, "f_orig")
+    K = len(targets)
+    B, T, F = targets[0].shape
+    assert x_enc.is_contiguous() and f_orig.stride(2) == 1 and f_orig.stride(0) == T * f_orig.stride(1)
+    arr, keep = _targets_array(targets, B, T, F)
+    dev = x_enc.device
+    loss = torch.empty((), device=dev, dtype=torch.float32)
+    perm = torch.empty(B, K, device=dev, dtype=torch.int32)
+    pairs = torch.empty(B, K, K, device=dev, dtype=torch.float32) if want_pairs else None
+    nws = lib().csship_head_pit_workspace(B, T)
+    ws = torch.empty(nws, device=dev, dtype=torch.uint8)
+    check(lib().csship_head_pit(_ptr(x_enc), _ptr(w_packed), _ptr(bias_perm), _ptr(f_orig), f_orig.stride(1), arr, B, T, F, K,
+                                x_enc.shape[2], _ptr(loss), _ptr(perm), _ptr(pairs), _ptr(ws), nws, _stream()))
+    return loss, perm, pairs
+
+
 def pit_mse_bwd(masks, f_orig, targets, perm, n_masks, grad_loss=1.0):
     K = len(targets)
     B, T, F = targets[0].shape

@@ -450,10 +450,26 @@ typedef struct {
 size_t csship_conformer_workspace(const csship_conformer_weights* w, int32_t B, int32_t T);
 /* f: f32 [B, T, idim] (row stride ldf); masks: f32 [B, T, n_out] with row stride ld_masks >= n_out
  * (a multiple of 4 enables vector stores); enc_out (optional): f32 [B, T, d_model] encoder output
- * before the head. */
+ * before the head.  masks == NULL (with enc_out): the mask head is skipped - csship_head_pit continues from enc_out. */
 int csship_conformer_forward(const csship_conformer_weights* w, const float* f, int64_t ldf,
                              int32_t B, int32_t T, float* masks, int64_t ld_masks, float* enc_out,
                              void* workspace, size_t workspace_bytes, csship_stream_t stream);
+
+/* csship_head_pit (css_amd/csrc/headpit.hip): mask head + mask application + PIT-MSE as one kernel for the loss-only
+ * path - ReLU(Linear(x_enc)) (conformer.py:98-101), y_k = m_k * f_orig (:103), the K x K pairwise squared errors and the
+ * minimum over permutations / batch mean (pit.py:53-57, mse.py:31-37), without ever writing the mask tensors (the
+ * noise mask, which does not enter the loss, is not computed).  x_enc: f32 [B*T, d_model] (csship_conformer_forward
+ * with masks == NULL writes it to enc_out); w_perm_packed / bias_perm: the first K*F head rows in the order of
+ * css_amd.ops.pack_head_pit (bins 0..255 of speaker 0, of speaker 1, then one tile with bin 256 of every speaker),
+ * fragment-packed; f_orig f32 [B, T, >= F] (row stride ld_f); targets: K dense f32 [B, T, F].  loss: 0-dim f32; perm
+ * int32 [B, K] (optional); pair_sse f32 [B, K, K] (optional).  Built for K == 2, F == 257, d_model == 256, T >= 64:
+ * anything else returns CSSHIP_EUNSUPPORTED (callers then run csship_conformer_forward + csship_pit_mse).
+ * Bit-reproducible (fixed-order partial sums, no atomics). */
+size_t csship_head_pit_workspace(int32_t B, int32_t T);
+int csship_head_pit(const float* x_enc, const uint16_t* w_perm_packed, const float* bias_perm, const float* f_orig,
+                    int64_t ld_f, const float* const* targets_host, int32_t B, int32_t T, int32_t F, int32_t K,
+                    int32_t d_model, float* loss, int32_t* perm, float* pair_sse, void* workspace,
+                    size_t workspace_bytes, csship_stream_t stream);
 
 /* ======================================================================================
  * Backward pass ("_bwd twins").  The reference gets these from torch.autograd over the ops of

@@ -673,3 +673,43 @@ def test_fused_adam_state_dict_is_torch_adam_compatible():
     assert opt2._step == 2 and torch.equal(opt2.exp_avg, opt.exp_avg) and torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq)
     with pytest.raises(ValueError):
         FusedAdam([{"params": list(m2.parameters())[:2]}, {"params": list(m2.parameters())[2:]}])
+
+
+@pytest.mark.parametrize("B,T", [(3, 100), (2, 64), (5, 77), (1, 400)])
+def test_forward_loss_fused_head_pit_matches_unfused(B, T):
+    """model.forward_loss (csship_head_pit: mask head + mask application + PIT-MSE, masks never written) ==
+    ops.pit_mse(model.forward_masks(f), f, targets): pair matrix, permutations and loss; panels that straddle two
+    samples (T not a multiple of 64), a ragged last panel, swapped targets.  T < 64 takes the unfused route."""
+    from css_amd import ops
+    m, sd = build(1, 91)
+    f = rnd((B, T, 257), 92).abs().to(DEV)
+    tg = [(rnd((B, T, 257), 93 + k).abs() * 0.5).to(DEV) for k in range(2)]
+    with torch.no_grad():
+        masks = m.forward_masks(f)
+        l0, p0, _, d0 = ops.pit_mse(masks, f, tg, want_pairs=True)
+        # make half of the samples prefer the swapped assignment
+        est = ops.apply_masks(masks, f, 2, 257)                      # [B,2,T,257]
+        tg2 = [torch.where((torch.arange(B, device=DEV) % 2 == 0)[:, None, None], est[:, 1], est[:, 0]) * 0.9 + 0.01,
+               torch.where((torch.arange(B, device=DEV) % 2 == 0)[:, None, None], est[:, 0], est[:, 1]) * 0.9 + 0.01]
+        l1, p1, d1 = m.forward_loss(f, tg, want_pairs=True)
+        l2, p2, _, d2 = ops.pit_mse(masks, f, tg2, want_pairs=True)
+        l3, p3, d3 = m.forward_loss(f, tg2, want_pairs=True)
+    assert torch.equal(p0, p1) and torch.equal(p2, p3)
+    assert p3[:, 0].tolist() == [1 if b % 2 == 0 else 0 for b in range(B)]
+    for a_, b_ in ((d0, d1), (d2, d3)):
+        assert float((a_ - b_).abs().max()) < 2e-5 * float(a_.abs().max())
+    assert abs(float(l0) - float(l1)) < 1e-5 * abs(float(l0)) and abs(float(l2) - float(l3)) < 1e-5 * abs(float(l2)) + 1e-9
+    with torch.no_grad():
+        l4, p4, _ = m.forward_loss(f, tg)
+    assert torch.equal(l4, l1) and torch.equal(p4, p1)                # bit-reproducible (no atomics)
+
+
+def test_forward_loss_short_windows_take_the_unfused_route():
+    from css_amd import ops
+    m, sd = build(1, 91)
+    f = rnd((2, 40, 257), 95).abs().to(DEV)
+    tg = [(rnd((2, 40, 257), 96 + k).abs() * 0.5).to(DEV) for k in range(2)]
+    with torch.no_grad():
+        l0 = ops.pit_mse(m.forward_masks(f), f, tg)[0]
+        l1 = m.forward_loss(f, tg)[0]
+    assert torch.equal(l0, l1)
