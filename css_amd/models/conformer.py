@@ -313,25 +313,37 @@ class Conformer(nn.Module):
             ops._ptr(self._workspace), self._workspace.numel(), ops._stream()))
         return (masks, enc_out) if want_encoder_out else masks
 
-    def forward_loss(self, f, targets, want_pairs=False):
+    def forward_loss(self, f, targets, want_pairs=False, before_head=None):
         """Loss-only inference path (validation, the fwd+PIT benchmark): features -> encoder -> mask head -> mask
         application -> PIT-MSE with the mask tensors never written (csship_head_pit).  f f32 [N,T,idim]; targets: K x
         [N,T,num_bins].  Returns (loss 0-dim, perm int32 [N,K], pair_sse or None) - the same values as
         ``ops.pit_mse(self.forward_masks(f), f, targets)`` up to f32 summation order.  Shapes the fused kernel is not
-        built for (K != 2, num_bins != 257, d_model != 256, T < 64, the any-width path) take exactly that route."""
-        K = len(targets)
+        built for (K != 2, num_bins != 257, d_model != 256, T < 64, the any-width path) take exactly that route.
+        ``targets`` may be a callable returning the list and ``before_head`` a callable run right before the loss kernel
+        (a caller that computes the target spectrograms on a second stream while the encoder runs joins the streams
+        there)."""
+        def resolve():
+            if before_head is not None:
+                before_head()
+            return targets() if callable(targets) else targets
+        if callable(targets):
+            K = self.num_spk
+        else:
+            K = len(targets)
         T = f.shape[1]
         fused = (K == 2 == self.num_spk and self.num_bins == 257 and self.conformer.d_model == 256 and T >= 64
                  and not getattr(self, "no_head_pit", False))
         if not fused:
-            loss, perm, _, pairs = ops.pit_mse(self.forward_masks(f), f, targets, want_pairs=want_pairs)
+            masks = self.forward_masks(f)
+            loss, perm, _, pairs = ops.pit_mse(masks, f, resolve(), want_pairs=want_pairs)
             return loss, perm, pairs
         ops._need(f, torch.float32, "f")
         if f.stride(2) != 1 or f.stride(0) != T * f.stride(1):
             f = f.contiguous()
         w, _layers, keep = self._pack()
         if w.generic:
-            loss, perm, _, pairs = ops.pit_mse(self.forward_masks(f), f, targets, want_pairs=want_pairs)
+            masks = self.forward_masks(f)
+            loss, perm, _, pairs = ops.pit_mse(masks, f, resolve(), want_pairs=want_pairs)
             return loss, perm, pairs
         B = f.shape[0]
         need = _lib.lib().csship_conformer_workspace(C.byref(w), B, T)
@@ -344,7 +356,7 @@ class Conformer(nn.Module):
         if self._head_pit_key != self._packed_key:
             self._head_pit = ops.pack_head_pit(self.linear.weight, self.linear.bias, K, self.num_bins)
             self._head_pit_key = self._packed_key
-        return ops.head_pit(enc_out, self._head_pit[0], self._head_pit[1], f, targets, want_pairs=want_pairs)
+        return ops.head_pit(enc_out, self._head_pit[0], self._head_pit[1], f, resolve(), want_pairs=want_pairs)
 
     def forward(self, f):
         """f: N x T x F (or 1 x N x T x F) -> (y_pred [N,K,T,F], masks tuple of K+1 x [N,T,F])."""
