@@ -19,4 +19,4 @@ under css_amd/ imports it: the product path fails loudly when the HIP
 library is missing instead of falling back to this code.
 """
 
-from . import feature, conformer, blstm, pit, stitcher, schedule, dropout, mixer, doa, separator, mxfp8  # noqa: F401
+from . import feature, conformer, blstm, pit, stitcher, schedule, dropout, mixer, doa, separator, mxfp8, emulate  # noqa: F401

@@ -22,6 +22,11 @@ def _lin(x, sd, p):
     return F.linear(x, sd[p + ".weight"], sd[p + ".bias"])
 
 
+# every matrix product of the attention goes through this name, so that oracle/emulate.py can evaluate the SAME graph
+# with the operand roundings of the HIP path (bf16 operands, f32 accumulation) - plain torch.matmul otherwise
+_mm = torch.matmul
+
+
 def mvn_time(f):
     """conformer.py:95 / blstm.py:80: MVN over the time axis (-2), unbiased std, +eps."""
     return (f - f.mean(-2, keepdim=True)) / (f.std(-2, keepdim=True) + EPS)
@@ -55,15 +60,17 @@ def attention(x, sd, p, n_head, pos_k, drop=_no_drop, site=""):
     q = _lin(h, sd, p + ".linear_q").view(B, T, n_head, dk).transpose(1, 2)  # [B,H,T,dk]
     k = _lin(h, sd, p + ".linear_k").view(B, T, n_head, dk).transpose(1, 2)
     v = _lin(h, sd, p + ".linear_v").view(B, T, n_head, dk).transpose(1, 2)
-    scores = torch.matmul(q, k.transpose(-1, -2))
+    scores = _mm(q, k.transpose(-1, -2))
     if pos_k is not None:
-        # B_[b,h,i,j] = q[b,h,i,:] . pos_k[i,j,:]   (conformer.py:230-233)
-        scores = scores + torch.einsum("bhid,ijd->bhij", q, pos_k)
+        # B_[b,h,i,j] = q[b,h,i,:] . pos_k[i,j,:], as the reference forms it (conformer.py:230-233): one batched product
+        # per query position, (T, B*h, d_k) x (T, d_k, T)
+        qt = q.permute(2, 0, 1, 3).reshape(T, B * n_head, dk)
+        scores = scores + _mm(qt, pos_k.transpose(1, 2)).reshape(T, B, n_head, T).permute(1, 2, 0, 3)
     att = torch.softmax(scores / math.sqrt(dk), dim=-1)
     if drop is not _no_drop:
         Tp = (T + 7) // 8 * 8
         att = drop(F.pad(att, (0, Tp - T)), site + ".p")[..., :T]
-    ctx = torch.matmul(att, v).transpose(1, 2).reshape(B, T, D)
+    ctx = _mm(att, v).transpose(1, 2).reshape(B, T, D)
     return drop(_lin(ctx, sd, p + ".linear_out"), site + ".out")
 
 

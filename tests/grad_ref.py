@@ -44,12 +44,25 @@ def pit_loss_with_perm(masks, f, targets, perm, nbins=257):
     return tot / B
 
 
-def oracle_param_grads(model, loss_of_masks, f, training_bn):
+def oracle_param_grads(model, loss_of_masks, f, training_bn, emulate_bf16=False):
     """{parameter name: gradient} of loss_of_masks(masks) by autograd through the oracle (with the dropout masks of the
-    model's last training forward, if it dropped)."""
-    masks, sd = oracle_masks(model, f, training_bn, drop_of(model))
-    loss_of_masks(masks).backward()
+    model's last training forward, if it dropped).  emulate_bf16: every Linear / attention product with bf16 operands
+    in forward and backward (oracle/emulate.py) - the arithmetic of the HIP path up to summation order."""
+    import contextlib
+    with (oracle.emulate.bf16_operands() if emulate_bf16 else contextlib.nullcontext()):
+        masks, sd = oracle_masks(model, f, training_bn, drop_of(model))
+        loss_of_masks(masks).backward()
     return {k: sd[k].grad for k, _ in model.named_parameters()}
+
+
+def per_parameter(grads, ref):
+    """[(name, relative L2 error, |ref|)] sorted by error, largest first"""
+    rows = []
+    for k, g in grads.items():
+        r = ref[k]
+        d = float((r ** 2).sum()) ** 0.5
+        rows.append((k, float(((g.detach().cpu() - r) ** 2).sum()) ** 0.5 / max(d, 1e-30), d))
+    return sorted(rows, key=lambda t: -t[1])
 
 
 def compare(grads, ref):
@@ -63,3 +76,20 @@ def compare(grads, ref):
         if d > 1e-16 and (n / d) ** 0.5 > worst[1]:
             worst = (k, (n / d) ** 0.5)
     return (num / den) ** 0.5, worst
+
+
+def check_against_emulation(grads, ref16, global_tol, param_tol):
+    """HIP gradients vs the oracle with bf16 operands in forward and backward (oracle/emulate.py): global relative L2
+    error and the worst parameter among those whose reference gradient is not numerically zero (>= 1e-4 of the largest
+    parameter-gradient norm: the key bias - softmax is shift invariant - and a bias in front of a batch-statistics
+    BatchNorm have mathematically zero gradients, there both sides hold rounding noise).  Returns (global, worst)."""
+    rows = per_parameter(grads, ref16)
+    big = max(d for _, _, d in rows)
+    live = [(k, e) for k, e, d in rows if d >= 1e-4 * big]
+    num = sum(float(((grads[k].detach().cpu() - ref16[k]) ** 2).sum()) for k in grads)
+    den = sum(float((ref16[k] ** 2).sum()) for k in grads)
+    glob = (num / den) ** 0.5
+    worst = max(live, key=lambda t: t[1])
+    assert glob < global_tol, f"global relative gradient error vs the bf16-operand oracle {glob:.3e} >= {global_tol}"
+    assert worst[1] < param_tol, f"{worst[0]}: relative gradient error vs the bf16-operand oracle {worst[1]:.3e} >= {param_tol}"
+    return glob, worst
