@@ -3,12 +3,16 @@
 A css_amd training step is ~2 300 kernel launches (forward operators, PIT, every gradient GEMM, optimiser) issued
 from Python; at 23 ms of GPU work the host cannot keep up.  ``GraphedTrainStep`` captures
 zero_grad -> objective(model, batch) -> backward -> clip + Adam once and replays it per step.  In a multi-GPU job
-(torch.distributed initialised, one process per GPU) the step is TWO graphs with the gradient all-reduce between them:
-graph 1 = zero_grad, forward, PIT, backward; then the stretches of ``parallel.bucket_plan`` on FusedAdam's flat
-gradient buffer (RCCL over xGMI, asynchronous, all in flight; issued eagerly - no collective is captured, so nothing
-depends on the runtime's support for capturing RCCL); graph 2 = clip + Adam.  The schedule of collectives is the one
-the eager step issues (same stretches, same order), so a rank that runs a step eagerly - a batch shape it has not
-captured - stays paired with ranks that replay.  The warm-up steps before the capture issue NO collective.  Replaces the reference's per-epoch
+(torch.distributed initialised, one process per GPU) the forward + backward is captured as a CHAIN OF SUB-GRAPHS cut
+where a stretch of FusedAdam's flat gradient buffer becomes final (the mask head, then every ``blocks_per_bucket``
+encoder blocks: the backward's ``_grad_bucket_hook`` ends one capture and begins the next), and the replay issues that
+stretch's all-reduce (RCCL over xGMI, asynchronous, on RCCL's own stream behind an event) BETWEEN two sub-graph
+replays: the all-reduce of blocks 15..12 travels while blocks 11..8 are back-propagated, as in the eager step's
+OverlappedGradReducer.  No collective is captured, so nothing depends on the runtime's support for
+capturing RCCL; the last graph is clip + Adam, replayed after every handle has been waited for.  The schedule of
+collectives is ``parallel.bucket_plan`` - the one the eager step issues (same stretches, same order) - so a rank that
+runs a step eagerly (a batch shape it has not captured) stays paired with ranks that replay.  The warm-up steps before
+the capture issue NO collective.  Replaces the reference's per-epoch
 checkpoint averaging (scripts/python/combine_models.py:55-82).  Common to both forms:
 inputs are copied into static buffers, the learning rate / Adam bias corrections live in device memory
 (``FusedAdam.advance_hyper``), BatchNorm bookkeeping and the PIT permutation search are device-side already.
@@ -62,22 +66,57 @@ class GraphedTrainStep:
             raise
         torch.cuda.current_stream().wait_stream(side)
         restore()
-        # thread_local: other threads of this process (the RCCL watchdog) may touch the runtime during the capture
         self.graph = torch.cuda.CUDAGraph()
         try:
             if not self.distributed:
+                # thread_local: other threads of this process may touch the runtime during the capture
                 with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                     self.loss, self.grad_norm = self._eager()
             else:
-                with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                    self.loss = self._forward_backward()
+                self._capture_distributed(blocks_per_bucket)
                 self.graph_opt = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph_opt, pool=self.graph.pool(), capture_error_mode="thread_local"):
+                with torch.cuda.graph(self.graph_opt, pool=self.graphs[0].pool(), capture_error_mode="thread_local"):
                     self.grad_norm = self.optim.step(max_norm=self.max_norm)
         except Exception:   # the capture does not execute anything, but a failed one must not leave the optimiser capturable
             restore()
             optim.capturable = False
             raise
+
+    def _capture_distributed(self, blocks_per_bucket):
+        """zero_grad + forward + PIT + backward as sub-graphs cut at the bucket boundaries of parallel.bucket_plan.  The
+        cut happens inside the backward pass (autograd's device thread), so the captures run in "relaxed" mode: a capture
+        may be ended by another thread than the one that began it."""
+        import gc
+        self.graphs, self.cuts = [torch.cuda.CUDAGraph()], []
+        cutting = [True]
+
+        def on_final(lo, hi):
+            self.cuts.append((lo, hi))
+            if cutting[0]:   # stretches reported while the backward is still running end a sub-graph
+                self.graphs[-1].capture_end()
+                g = torch.cuda.CUDAGraph()
+                g.capture_begin(pool=self.graphs[0].pool(), capture_error_mode="relaxed")
+                self.graphs.append(g)
+        reducer = parallel.OverlappedGradReducer(self.model, self.optim, blocks_per_bucket, emit=on_final)
+        torch.cuda.synchronize()
+        gc.collect()
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            self.graphs[0].capture_begin(capture_error_mode="relaxed")
+            try:
+                reducer.begin(force=True)
+                self.loss = self._forward_backward()
+                cutting[0] = False
+                reducer.flush_rest()      # the front of the buffer (embedding, position table): after the last kernel
+            finally:
+                self.model._grad_bucket_hook = None
+                self.graphs[-1].capture_end()
+        torch.cuda.current_stream().wait_stream(stream)
+        self.n_cut = len(self.graphs) - 1     # all-reduces issued between sub-graph replays; the rest after the last one
+        if self.cuts != self.plan:
+            raise RuntimeError(f"css_amd: captured bucket boundaries {self.cuts} differ from parallel.bucket_plan {self.plan}")
+        self.graph = self.graphs[0]
 
     def _forward_backward(self):
         self.optim.zero_grad()
@@ -95,6 +134,7 @@ class GraphedTrainStep:
         """Drop the captured graphs and their private memory pool (LRU eviction in train_one_epoch)."""
         self.graph = None
         self.graph_opt = None
+        self.graphs = []
         self.static = {}
 
     def __call__(self, batch):
@@ -103,8 +143,16 @@ class GraphedTrainStep:
         for k in self.keys:
             self.static[k].copy_(batch[k], non_blocking=True)
         self.optim.advance_hyper()
-        self.graph.replay()
-        if self.distributed:
-            parallel.allreduce_plan(self.optim.flat_grad, self.plan)
-            self.graph_opt.replay()
+        if not self.distributed:
+            self.graph.replay()
+            return self.loss, self.grad_norm
+        handles = []
+        for i, g in enumerate(self.graphs):
+            g.replay()
+            if i < self.n_cut:   # this sub-graph finished a stretch: its all-reduce travels beside the next sub-graph
+                parallel.allreduce_segment(self.optim.flat_grad, *self.cuts[i], handles)
+        for lo, hi in self.cuts[self.n_cut:]:
+            parallel.allreduce_segment(self.optim.flat_grad, lo, hi, handles)
+        parallel.wait_all(handles, self.optim.flat_grad)
+        self.graph_opt.replay()
         return self.loss, self.grad_norm
