@@ -4,6 +4,7 @@
 // ctypes call per forward instead of ~180, and the launch is hipGraph-capturable.
 #include "common.hpp"
 
+#include <stdlib.h>
 #include <vector>
 
 namespace {
@@ -187,6 +188,39 @@ extern "C" size_t csship_conformer_workspace(const csship_conformer_weights* w, 
   return carve(w, B, T, nullptr).total;
 }
 
+// Diagnostic only (CSSHIP_DEBUG_NODEP=N, eager launches, results are WRONG): the encoder's launches are dealt
+// round-robin to N internal streams that only fork from / join the caller's stream, i.e. the dependencies between
+// consecutive launches are cut.  What the step then takes is the ceiling of any scheme that overlaps one launch's ramp /
+// tail with its neighbours (persistent kernels, cross-launch prefetch): DESIGN.md, "launch boundaries".
+namespace {
+struct NoDep {
+  int n = 0, k = 0;
+  hipStream_t s[8];
+  hipEvent_t fork, join[8];
+  hipStream_t base = nullptr;
+  bool init() {
+    static const int want = [] { const char* e = getenv("CSSHIP_DEBUG_NODEP"); return e ? atoi(e) : 0; }();
+    if (want <= 0) return false;
+    if (n == 0) {
+      n = want > 8 ? 8 : want;
+      for (int i = 0; i < n; ++i) { (void)hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking); (void)hipEventCreateWithFlags(&join[i], hipEventDisableTiming); }
+      (void)hipEventCreateWithFlags(&fork, hipEventDisableTiming);
+    }
+    return true;
+  }
+  void begin(hipStream_t b) {
+    base = b; k = 0;
+    (void)hipEventRecord(fork, b);
+    for (int i = 0; i < n; ++i) (void)hipStreamWaitEvent(s[i], fork, 0);
+  }
+  csship_stream_t next() { return reinterpret_cast<csship_stream_t>(s[k++ % n]); }
+  void end() {
+    for (int i = 0; i < n; ++i) { (void)hipEventRecord(join[i], s[i]); (void)hipStreamWaitEvent(base, join[i], 0); }
+  }
+};
+NoDep g_nodep;
+}  // namespace
+
 extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const float* f, int64_t ldf, int32_t B,
                                         int32_t T, float* masks, int64_t ld_masks, float* enc_out, void* workspace,
                                         size_t workspace_bytes, csship_stream_t stream) {
@@ -242,16 +276,21 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
   } else {
     // default: 3 launches per block: chain (FFN_out(l-1) + LN -> FFN_in(l) -> q/k/v projection(l), per 64-row
     // panel), attention, out-proj + conv module
+    const bool nodep = g_nodep.init();
+    const csship_stream_t stream0 = stream;
+    if (nodep) g_nodep.begin(as_stream(stream0));
     for (int l = 0; l < w->n_layer; ++l) {
       const csship_layer_weights& L = w->layers[l];
       const csship_layer_weights* P = l > 0 ? &w->layers[l - 1] : nullptr;
       {
+        if (nodep) stream = g_nodep.next();
         TimelineScope tl(P ? CSSHIP_TL_CHAIN : CSSHIP_TL_CHAIN_EDGE, as_stream(stream));
         TRY(csship_encoder_chain(x, x, nullptr, nullptr, T, P ? &P->ffn_out : nullptr, P ? P->ln_g : nullptr,
                                  P ? P->ln_b : nullptr, &L.ffn_in, L.mha.ln_g, L.mha.ln_b, L.mha.wqkv, L.mha.bqkv,
                                  ws.qkv_bf, M, D, FF, 3 * D, w->chain_flags, stream));
       }
       {
+        if (nodep) stream = g_nodep.next();
         TimelineScope tl(CSSHIP_TL_ATTN, as_stream(stream));
         TRY(csship_mha_relpos(ws.qkv_bf, w->pe_k, w->pe_q_min, w->pe_q_max, ws.ao_bf, B, T, w->n_head, stream));
       }
@@ -261,6 +300,7 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
         TRY(csship_conv_from_glu(x, y, x, &L.conv, B, T, D, w->kernel_size, stream));
       } else if (w->bn_mode == 0 && conv_mode == 3) {
         // one kernel: x2 = x + out-proj(attn) and the conv module on it (256 workgroups at T = 400)
+        if (nodep) stream = g_nodep.next();
         TimelineScope tl(CSSHIP_TL_OUTPROJ_CONV, as_stream(stream));
         TRY(csship_outproj_conv(ws.ao_bf, L.mha.wo, L.mha.bo, x, y, &L.conv, B, T, D, w->kernel_size, stream));
         { float* t = x; x = y; y = t; }
@@ -271,6 +311,7 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
         { float* t = x; x = y; y = t; }
       }
     }
+    if (nodep) { g_nodep.end(); stream = stream0; }
     const csship_layer_weights& L = w->layers[w->n_layer - 1];
     TimelineScope tl(CSSHIP_TL_CHAIN_EDGE, as_stream(stream));
     // the last FeedForward + block LayerNorm writes the encoder output where the caller wants it (no copy afterwards)
