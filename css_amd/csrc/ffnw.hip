@@ -318,6 +318,12 @@ struct PassMx {
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt)
         acc[t][rt] = mx_mfma_ks<STEP>(wq[STEP % PDM][t], xa[STEP % XB][rt], acc[t][rt], wsc[t][STEP >> 1], xs[rt]);
+    // hipcc otherwise interchanges the unrolled nest (all k-steps of row tile 0, then of row tile 1, ...), which makes
+    // every k-step's weights and fragments live at once (at d_model 512: ~140 registers spilled per chunk).  An empty
+    // asm that "touches" all accumulators of the step ties the independent chains together: k-step major order.
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      asm volatile("" : "+v"(acc[t][0]), "+v"(acc[t][1]), "+v"(acc[t][2]), "+v"(acc[t][3]));
     __builtin_amdgcn_sched_barrier(0);
     if (STEP + PDM < KSTEPS) {
 #pragma unroll
@@ -357,11 +363,17 @@ __global__ __launch_bounds__(512) void ffnmx_kernel(FfnMxArgs a) {
   constexpr int XBYTES = BM * (XROWB + 32), HBYTES = BM * (HROWB + 32);
   constexpr int NTM = 2, XB = 2;
   constexpr int SC_BYTES = BM * 16;  // [64 rows][4 g] dwords
-  constexpr int PANELS = XBYTES + SC_BYTES + 2 * (HBYTES + SC_BYTES), YSB = BM * (D + 4) * 4;
+  // d_model 512: the wave's second pair of output tiles (32 accumulator registers) LIVES IN LDS between its W2
+  // sub-passes - [wave][tile][row tile][lane] 16-byte pieces, 64 KB - so that 64 + 32 + 32 + 64 registers of
+  // accumulators, weight ring and operand fragments never have to coexist (hipcc spilled ~140 registers per chunk to
+  // scratch otherwise: 109 us against 65 us for the bf16 kernel)
+  constexpr int OPARK = NH > 1 ? 8 * 2 * 4 * 64 * 16 : 0;
+  constexpr int PANELS = XBYTES + SC_BYTES + 2 * (HBYTES + SC_BYTES) + OPARK, YSB = BM * (D + 4) * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem[PANELS > YSB ? PANELS : YSB];
   unsigned char* const X8 = smem;
   unsigned* const xsc = reinterpret_cast<unsigned*>(smem + XBYTES);
   unsigned char* const H8 = smem + XBYTES + SC_BYTES;               // buffer b at H8 + b * (HBYTES + SC_BYTES): panel | scales
+  f32x4* const opark = reinterpret_cast<f32x4*>(smem + XBYTES + SC_BYTES + 2 * (HBYTES + SC_BYTES));
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, n = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: everything derived from it stays scalar
   const int m0 = blockIdx.x * BM, nchunk = a.FF / 256, ks2 = a.FF / 128, kp2 = a.FF / 256, rot = blockIdx.x % nchunk;
@@ -412,13 +424,14 @@ __global__ __launch_bounds__(512) void ffnmx_kernel(FfnMxArgs a) {
     }
   }
   __syncthreads();
-  f32x4 o[NH][2][4];
+  f32x4 o[2][4];   // output tiles 0, 1 of the wave; tiles 2, 3 (d_model 512) are parked in LDS
 #pragma unroll
-  for (int hf = 0; hf < NH; ++hf)
+  for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) o[hf][t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int rt = 0; rt < 4; ++rt) {
+      o[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (NH > 1) opark[((wave * 2 + t) * 4 + rt) * 64 + lane] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   for (int ci = 0; ci < nchunk; ++ci) {
     const int c = (ci + rot) % nchunk, cn = (c + 1) % nchunk;
     f32x4 h[2][4];
@@ -466,13 +479,34 @@ __global__ __launch_bounds__(512) void ffnmx_kernel(FfnMxArgs a) {
       const WStream wcur{rs2, w2c.base + (unsigned)(hf * 2) * ks2 * 2 * 1024u, lane16};
       const bool last = hf + 1 == NH;
       const WStream wnext{last ? rs1 : rs2, last ? w1n.base : wcur.base + 2u * ks2 * 2 * 1024u, lane16};
-      pass_mx<2, 2, 2, HROWB, NTM, XB>(o[hf], hb, reinterpret_cast<const unsigned*>(hsc), n, g, wcur, ks2 * 2, wnext,
-                                       last ? KS1 * 2 : ks2 * 2, !last || ci + 1 < nchunk, wsc2[hf], wq);
+      if (hf == 0) {
+        pass_mx<2, 2, 2, HROWB, NTM, XB>(o, hb, reinterpret_cast<const unsigned*>(hsc), n, g, wcur, ks2 * 2, wnext,
+                                         last ? KS1 * 2 : ks2 * 2, !last || ci + 1 < nchunk, wsc2[hf], wq);
+      } else {
+        f32x4 ob[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) ob[t][rt] = opark[((wave * 2 + t) * 4 + rt) * 64 + lane];
+        pass_mx<2, 2, 2, HROWB, NTM, XB>(ob, hb, reinterpret_cast<const unsigned*>(hsc), n, g, wcur, ks2 * 2, wnext,
+                                         last ? KS1 * 2 : ks2 * 2, !last || ci + 1 < nchunk, wsc2[hf], wq);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) opark[((wave * 2 + t) * 4 + rt) * 64 + lane] = ob[t][rt];
+      }
     }
   }
   float4 b2v[NTO];
 #pragma unroll
   for (int t = 0; t < NTO; ++t) b2v[t] = *reinterpret_cast<const float4*>(a.b2 + (wave * NTO + t) * 16 + 4 * g);
+  f32x4 ob[2][4];   // the parked tiles come back into registers before their LDS region becomes part of the staging tile
+  if constexpr (NH > 1) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) ob[t][rt] = opark[((wave * 2 + t) * 4 + rt) * 64 + lane];
+  }
   __syncthreads();
   float* ys = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -482,8 +516,9 @@ __global__ __launch_bounds__(512) void ffnmx_kernel(FfnMxArgs a) {
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
         const float4 bb = b2v[hf * 2 + t];
+        const f32x4 ov = hf == 0 ? o[t][rt] : ob[t][rt];
         *reinterpret_cast<float4*>(ys + (rt * 16 + n) * (D + 4) + (wave * NTO + hf * 2 + t) * 16 + 4 * g) =
-            make_float4(o[hf][t][rt][0] + bb.x, o[hf][t][rt][1] + bb.y, o[hf][t][rt][2] + bb.z, o[hf][t][rt][3] + bb.w);
+            make_float4(ov[0] + bb.x, ov[1] + bb.y, ov[2] + bb.z, ov[3] + bb.w);
       }
   __syncthreads();
   finish_rows<D, FINAL_LN>(ys, a.x, a.out, a.fin_g, a.fin_b, m0, a.M, a.alpha, tid);

@@ -520,7 +520,7 @@ def fold_layernorm(w, b, gamma, beta):
     """Linear(LayerNorm(x)) with the LayerNorm's affine part folded into the Linear (f32):
     (xhat * gamma + beta) W^T + b = xhat (W diag(gamma))^T + (b + W beta) -> (W', b')."""
     w, b = w.detach().float(), b.detach().float()
-    return w * gamma.detach().float()[None, :], b + w @ beta.detach().float()
+    return w * gamma.detach().float()[None, :], b + (w * beta.detach().float()[None, :]).sum(1)   # (no BLAS call: pack time only)
 
 
 def pack_mx(w):
