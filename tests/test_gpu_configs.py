@@ -252,3 +252,21 @@ def test_fp8_ffn_base_width_and_wide_bf16_path():
     assert float(((wide - unfused) ** 2).mean()) < 2e-5
     e_emul, e_fp32 = float(((fp8 - o_emul) ** 2).mean()), float(((fp8 - o_fp32) ** 2).mean())
     assert e_emul < 3e-4 and e_emul < 0.3 * e_fp32, (e_emul, e_fp32)
+
+
+def test_fp8_ffn_meets_the_mask_budget_on_a_trained_checkpoint():
+    """The second parity statement of the opt-in fp8 path: on a briefly TRAINED Conformer-base (the deterministic recipe of
+    tools/fp8_trained_parity.py: 300 optimiser steps of css_amd training from the seeded initialisation) the HIP model
+    with fp8_ffn = True stays within the 1e-4 mask-MSE budget against the fp32 oracle (the CPU emulation of round 2
+    predicted 4.9e-5), while on the untrained seeded weights it does not (2.6e-3): trained weights have the block
+    structure block-scaled fp8 is made for."""
+    sys_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools")
+    import sys
+    sys.path.insert(0, sys_path)
+    import fp8_trained_parity as tp
+    r = tp.run(300, verbose=False)
+    print(f"[parity] fp8_ffn after 300 training steps: vs fp32 oracle {r['fp8_vs_fp32']:.3e} (bf16 path {r['bf16_vs_fp32']:.3e}, "
+          f"emulating oracle {r['emulation_vs_fp32']:.3e})")
+    assert r["bf16_vs_fp32"] < 2e-5
+    assert r["fp8_vs_fp32"] < 1e-4            # measured 2.0e-5 (profiles/r03_fp8_trained_parity.txt)
+    assert r["fp8_vs_emulation"] < 1e-5       # and tight against the oracle with the same operand formats: 4.4e-6
