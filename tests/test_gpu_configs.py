@@ -260,9 +260,9 @@ def test_fp8_ffn_meets_the_mask_budget_on_a_trained_checkpoint():
     with fp8_ffn = True stays within the 1e-4 mask-MSE budget against the fp32 oracle (the CPU emulation of round 2
     predicted 4.9e-5), while on the untrained seeded weights it does not (2.6e-3): trained weights have the block
     structure block-scaled fp8 is made for."""
-    sys_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools")
+    import os
     import sys
-    sys.path.insert(0, sys_path)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
     import fp8_trained_parity as tp
     r = tp.run(300, verbose=False)
     print(f"[parity] fp8_ffn after 300 training steps: vs fp32 oracle {r['fp8_vs_fp32']:.3e} (bf16 path {r['bf16_vs_fp32']:.3e}, "
