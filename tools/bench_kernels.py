@@ -123,6 +123,10 @@ def bench_chain():
     us = timeit(lambda: ops.encoder_chain(x, 1024, ffn_a=fa, final_ln=(g1, b0), ffn_b=fb, qkv=((g1, b0), wq, bq, 768), out=out))
     fl = 2 * 4.0 * M * D * 1024 + 2.0 * M * D * 768
     print(f"encoder_chain (FFN+LN, FFN, LN+QKV)  {us:8.1f} us  {fl / us / 1e6:8.1f} TFLOP/s = {fl / us / 1e6 / 2500:.3f} of 2.5 PF")
+    # the form the model runs: LayerNorm affines folded into the weights, q | k | v rows interleaved (16-byte stores)
+    fa2, fb2 = (None,) + fa[1:], (None,) + fb[1:]
+    us = timeit(lambda: ops.encoder_chain(x, 1024, ffn_a=fa2, final_ln=(g1, b0), ffn_b=fb2, qkv=(None, wq, bq, 768), out=out, flags=1))
+    print(f"encoder_chain, folded LN + IL8       {us:8.1f} us  {fl / us / 1e6:8.1f} TFLOP/s = {fl / us / 1e6 / 2500:.3f} of 2.5 PF")
     us = timeit(lambda: ops.encoder_chain(x, 1024, ffn_a=fa, final_ln=(g1, b0), out=out))
     print(f"encoder_chain (FFN+LN only)          {us:8.1f} us  {4.0 * M * D * 1024 / us / 1e6:8.1f} TFLOP/s")
 
