@@ -43,7 +43,7 @@ class ConformerWeights(C.Structure):
                 ("bn_mode", _i32), ("generic", _i32), ("fuse_conv", _i32),
                 ("embed_w", _p), ("embed_b", _p), ("embed_ln_g", _p), ("embed_ln_b", _p), ("pe_k", _p),
                 ("layers", C.POINTER(LayerWeights)), ("head_w", _p), ("head_b", _p), ("ffn_mode", _i32),
-                ("chain_flags", _i32)]
+                ("lin_mode", _i32), ("chain_flags", _i32)]
 
 
 class BgemmParams(C.Structure):
@@ -167,6 +167,8 @@ SIGNATURES = {
     "csship_conformer_workspace": (_sz, [C.POINTER(ConformerWeights), _i32, _i32]),
     "csship_conformer_forward": (_i32, [C.POINTER(ConformerWeights), _p, _i64, _i32, _i32, _p, _i64, _p, _p, _sz, _p]),
     "csship_ffn_wide": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _p]),
+    "csship_ln_linear_wide": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p]),
+    "csship_linear_res_wide": (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _p]),
     "csship_ffn_mx": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _p]),
     "csship_head_pit_workspace": (_sz, [_i32, _i32]),
     "csship_head_pit": (_i32, [_p, _p, _p, _p, _i64, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p]),

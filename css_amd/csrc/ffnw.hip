@@ -214,6 +214,99 @@ __global__ __launch_bounds__(512) void ffnw_kernel(FfnwArgs a) {
   finish_rows<D, FINAL_LN>(ys, a.x, a.out, a.fin_g, a.fin_b, m0, a.M, a.alpha, tid);
 }
 
+// ================================================================================================ wide row-panel Linears
+// The two Linears of the attention stage at any width as row-panel kernels (the any-width path ran them as LayerNorm +
+// tiled GEMM: at d_model 512 the q | k | v projection is a 12 800 x 512 x 1 536 product whose tiles are 16 k-steps
+// deep - prologue / epilogue bound):
+//   lnlin_kernel   out_bf16[M, N] = bf16( LayerNorm(x) W^T + b )      conformer.py:222-225, N = 3 d_model, rows of W in
+//                  the 8-feature interleave of ops.pack_frag_il8 (a lane's 2 x 4 results = 8 consecutive features:
+//                  one 16-byte store per row tile)
+//   linres_kernel  out[M, D] = res + a_bf16 W^T + b                    conformer.py:254, 356 (attention output projection)
+// Same pass structure as the FeedForward above (NT = 2 tiles per wave and 256-feature pass, weights streamed in
+// fragment order PDW k-steps ahead, continuing across passes).
+struct LinwArgs {
+  const void* a;        // f32 [M, D] (lnlin) or bf16 [M, D] (linres)
+  const float *ln_g, *ln_b;
+  const bf16x8* w;      // fragment order [N/16][D/32][64]
+  const float* bias;
+  const float* res;     // linres: f32 [M, N]
+  void* out;
+  int M, N;
+};
+
+template <int D, bool LN_IN>
+__global__ __launch_bounds__(512) void linw_kernel(LinwArgs a) {
+  constexpr int KSN = D / 32, XROWB = 2 * D, PDW = 4;
+  __shared__ __attribute__((aligned(16))) unsigned char Xs[BM * XROWB];
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, n = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.x * BM, npass = a.N / 256;
+  const bf16x8* ws = a.w + (size_t)(wave * 2) * KSN * 64 + lane;  // + pass p: 16 tiles
+  bf16x8 wq[PDW][2];
+#pragma unroll
+  for (int k = 0; k < PDW; ++k)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) wq[k][t] = ws[(size_t)(t * KSN + k) * 64];
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (LN_IN) {
+    const int r = tid >> 3, part = tid & 7;
+    float4 v[D / 32];
+    load_rows<D>(v, reinterpret_cast<const float*>(a.a), min(m0 + r, a.M - 1), part);
+    layernorm_rows<D>(v, a.ln_g, a.ln_b, part);
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i) {
+      const int c4 = i * 8 + part;
+      *reinterpret_cast<uint2*>(Xs + poff<XROWB>(r, c4 >> 1) + (c4 & 1) * 8) = make_uint2(pack_bf2(v[i].x, v[i].y), pack_bf2(v[i].z, v[i].w));
+    }
+  } else {
+    const unsigned short* ab = reinterpret_cast<const unsigned short*>(a.a);
+    for (int i = tid; i < BM * (D / 8); i += 512) {
+      const int r = i / (D / 8), c = i % (D / 8);
+      *reinterpret_cast<uint4*>(Xs + poff<XROWB>(r, c)) = *reinterpret_cast<const uint4*>(ab + (size_t)min(m0 + r, a.M - 1) * D + c * 8);
+    }
+  }
+  __syncthreads();
+  for (int p = 0; p < npass; ++p) {
+    const int tile0 = p * 16 + wave * 2;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {  // the bias is the accumulators' initial value
+      const float4 bb = *reinterpret_cast<const float4*>(a.bias + (tile0 + t) * 16 + 4 * g);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) acc[t][rt] = f32x4{bb.x, bb.y, bb.z, bb.w};
+    }
+    const bf16x8* wc = ws + (size_t)p * 16 * KSN * 64;
+    pass_bf16<2, 2, KSN, XROWB, PDW, 2>(acc, Xs, n, g, wc, KSN, wc + (size_t)16 * KSN * 64, KSN, p + 1 < npass, wq);
+    if constexpr (LN_IN) {  // interleaved rows: 8 consecutive features per lane, one 16-byte bf16 store per row tile
+      unsigned short* o = reinterpret_cast<unsigned short*>(a.out);
+      const int f = tile0 * 16 + 8 * g;
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        const int row = m0 + rt * 16 + n;
+        if (row < a.M)
+          *reinterpret_cast<uint4*>(o + (size_t)row * a.N + f) =
+              make_uint4(pack_bf2(acc[0][rt][0], acc[0][rt][1]), pack_bf2(acc[0][rt][2], acc[0][rt][3]),
+                         pack_bf2(acc[1][rt][0], acc[1][rt][1]), pack_bf2(acc[1][rt][2], acc[1][rt][3]));
+      }
+    } else {  // natural rows: 4 consecutive features per lane and tile, f32 residual add
+      float* o = reinterpret_cast<float*>(a.out);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int f = (tile0 + t) * 16 + 4 * g;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+          const int row = m0 + rt * 16 + n;
+          if (row < a.M) {
+            const float4 r4 = *reinterpret_cast<const float4*>(a.res + (size_t)row * a.N + f);
+            *reinterpret_cast<float4*>(o + (size_t)row * a.N + f) =
+                make_float4(r4.x + acc[t][rt][0], r4.y + acc[t][rt][1], r4.z + acc[t][rt][2], r4.w + acc[t][rt][3]);
+          }
+        }
+      }
+    }
+  }
+}
+
 // ================================================================================================ MXFP8
 struct FfnMxArgs {
   const float* x;
@@ -547,6 +640,35 @@ extern "C" int csship_ffn_wide(const float* x, float* out, const float* ln_g, co
     if (final_ln_g) hipLaunchKernelGGL((ffnw_kernel<512, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((ffnw_kernel<512, false>), grid, block, 0, s, a);
   }
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
+extern "C" int csship_ln_linear_wide(const float* x, const float* ln_g, const float* ln_b, const uint16_t* w_il8_packed,
+                                     const float* bias_il8, uint16_t* out_bf16, int32_t M, int32_t d_model, int32_t N,
+                                     csship_stream_t stream) {
+  if (!x || !ln_g || !ln_b || !w_il8_packed || !bias_il8 || !out_bf16) return CSSHIP_ENULL;
+  if (M <= 0 || N <= 0 || (N % 256) != 0) return CSSHIP_EBADSHAPE;
+  if (d_model != 256 && d_model != 512) return CSSHIP_EUNSUPPORTED;
+  if (!aligned16(x) || !aligned16(w_il8_packed) || !aligned16(bias_il8) || !aligned16(out_bf16)) return CSSHIP_EALIGN;
+  LinwArgs a{x, ln_g, ln_b, reinterpret_cast<const bf16x8*>(w_il8_packed), bias_il8, nullptr, out_bf16, M, N};
+  dim3 grid((M + BM - 1) / BM), block(512);
+  if (d_model == 256) hipLaunchKernelGGL((linw_kernel<256, true>), grid, block, 0, as_stream(stream), a);
+  else hipLaunchKernelGGL((linw_kernel<512, true>), grid, block, 0, as_stream(stream), a);
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
+extern "C" int csship_linear_res_wide(const uint16_t* a_bf16, const uint16_t* w_packed, const float* bias, const float* res,
+                                      float* out, int32_t M, int32_t d_model, csship_stream_t stream) {
+  if (!a_bf16 || !w_packed || !bias || !res || !out) return CSSHIP_ENULL;
+  if (M <= 0) return CSSHIP_EBADSHAPE;
+  if (d_model != 256 && d_model != 512) return CSSHIP_EUNSUPPORTED;
+  if (!aligned16(a_bf16) || !aligned16(w_packed) || !aligned16(bias) || !aligned16(res) || !aligned16(out)) return CSSHIP_EALIGN;
+  LinwArgs a{a_bf16, nullptr, nullptr, reinterpret_cast<const bf16x8*>(w_packed), bias, res, out, M, d_model};
+  dim3 grid((M + BM - 1) / BM), block(512);
+  if (d_model == 256) hipLaunchKernelGGL((linw_kernel<256, false>), grid, block, 0, as_stream(stream), a);
+  else hipLaunchKernelGGL((linw_kernel<512, false>), grid, block, 0, as_stream(stream), a);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }

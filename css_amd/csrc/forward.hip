@@ -101,10 +101,18 @@ int forward_generic(const csship_conformer_weights* w, const float* f, int64_t l
   for (int l = 0; l < w->n_layer; ++l) {
     const csship_layer_weights& L = w->layers[l];
     TRY(feed_forward(L.ffn_in, x, x, nullptr, nullptr));
-    TRY(csship_layernorm(x, M, D, L.mha.ln_g, L.mha.ln_b, ws.a_bf, nullptr, stream));
-    TRY(tiled_linear(ws.a_bf, CSSHIP_A_BF16, L.mha.wqkv, L.mha.bqkv, nullptr, ws.qkv_bf, M, 3 * D, D, D, BF, 0.f, stream));
+    if (w->lin_mode == 1) {
+      TRY(csship_ln_linear_wide(x, L.mha.ln_g, L.mha.ln_b, L.mha.wqkv, L.mha.bqkv, ws.qkv_bf, M, D, 3 * D, stream));
+    } else {
+      TRY(csship_layernorm(x, M, D, L.mha.ln_g, L.mha.ln_b, ws.a_bf, nullptr, stream));
+      TRY(tiled_linear(ws.a_bf, CSSHIP_A_BF16, L.mha.wqkv, L.mha.bqkv, nullptr, ws.qkv_bf, M, 3 * D, D, D, BF, 0.f, stream));
+    }
     TRY(csship_mha_relpos(ws.qkv_bf, w->pe_k, w->pe_q_min, w->pe_q_max, ws.ao_bf, B, T, w->n_head, stream));
-    TRY(tiled_linear(ws.ao_bf, CSSHIP_A_BF16, L.mha.wo, L.mha.bo, x, x, M, D, D, D, CSSHIP_EPI_RESIDUAL, 1.f, stream));
+    if (w->lin_mode == 1) {
+      TRY(csship_linear_res_wide(ws.ao_bf, L.mha.wo, L.mha.bo, x, x, M, D, stream));
+    } else {
+      TRY(tiled_linear(ws.ao_bf, CSSHIP_A_BF16, L.mha.wo, L.mha.bo, x, x, M, D, D, D, CSSHIP_EPI_RESIDUAL, 1.f, stream));
+    }
     TRY(csship_convmod(x, y, &L.conv, B, T, D, w->kernel_size, w->bn_mode, ws.conv_ws, stream));
     { float* t = x; x = y; y = t; }
     TRY(feed_forward(L.ffn_out, x, y, L.ln_g, L.ln_b));   // FFN_out + the block-final LayerNorm (conformer.py:358-360)
@@ -230,6 +238,7 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
   if (w->generic) {
     if ((w->d_model != 256 && w->d_model != 512) || (w->d_ffn % 64) != 0 || (w->idim_pad % 64) != 0) return CSSHIP_EUNSUPPORTED;
     if (w->ffn_mode < 0 || w->ffn_mode > 2 || (w->ffn_mode != 0 && (w->d_ffn % 256) != 0)) return CSSHIP_EUNSUPPORTED;
+    if (w->lin_mode < 0 || w->lin_mode > 1) return CSSHIP_EUNSUPPORTED;
   } else if (w->d_model != 256 || (w->d_ffn % 256) != 0 || (w->idim_pad % 256) != 0) {
     return CSSHIP_EUNSUPPORTED;
   }

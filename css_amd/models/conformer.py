@@ -202,6 +202,8 @@ class Conformer(nn.Module):
         elif self.fp8_ffn:
             raise RuntimeError("css_amd.Conformer: fp8_ffn needs d_model 256 or 512 and linear_units % 256 == 0")
 
+        lin_mode = 1 if (generic and enc.d_model in (256, 512) and not getattr(self, "unfused_ffn", False)) else 0
+
         def ffn(m):
             w = _lib.FfnWeights()
             if fold:
@@ -237,10 +239,14 @@ class Conformer(nn.Module):
                 order = ops.il8_row_order(wqkv.shape[0], wqkv.device)
                 L.mha.ln_g, L.mha.ln_b = None, None
                 L.mha.wqkv, L.mha.bqkv = own(packw(wqkv[order])), own(bqkv[order].contiguous())
+            elif lin_mode == 1:   # any-width path, row-panel Linears: q | k | v rows in the IL8 fragment order
+                order = ops.il8_row_order(wqkv.shape[0], wqkv.device)
+                L.mha.ln_g, L.mha.ln_b = f32(a.layer_norm.weight), f32(a.layer_norm.bias)
+                L.mha.wqkv, L.mha.bqkv = own(ops.pack_frag(wqkv[order])), own(bqkv[order].contiguous())
             else:
                 L.mha.ln_g, L.mha.ln_b = f32(a.layer_norm.weight), f32(a.layer_norm.bias)
                 L.mha.wqkv, L.mha.bqkv = own(packw(wqkv)), own(bqkv)
-            L.mha.wo, L.mha.bo = own(packw(a.linear_out.weight)), f32(a.linear_out.bias)
+            L.mha.wo, L.mha.bo = own((ops.pack_frag if lin_mode == 1 else packw)(a.linear_out.weight)), f32(a.linear_out.bias)
             c = lay.conv
             L.conv.ln_g, L.conv.ln_b = f32(c.layer_norm.weight), f32(c.layer_norm.bias)
             L.conv.pw1_w, L.conv.pw1_b = f32(c.pw_conv_1.weight), f32(c.pw_conv_1.bias)
@@ -262,6 +268,7 @@ class Conformer(nn.Module):
         w.fuse_conv = int(getattr(self, "fuse_conv", 0))
         w.chain_flags = _lib.CHAIN_QKV_IL8 if fold else 0
         w.ffn_mode = ffn_mode
+        w.lin_mode = lin_mode
         ew = torch.zeros(enc.d_model, w.idim_pad, device=dev)
         ew[:, :enc.idim] = enc.embed[0].weight.detach().float()
         w.embed_w, w.embed_b = own(packw(ew)), f32(enc.embed[0].bias)

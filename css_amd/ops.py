@@ -554,6 +554,28 @@ def ffn_wide(x, ln, w1p, b1, w2p, b2, d_ffn, alpha=0.5, final_ln=None, out=None)
     return out
 
 
+def ln_linear_wide(x, ln, w, b):
+    """csship_ln_linear_wide: bf16(LayerNorm(x) W^T + b) for x f32 [M, 256 | 512], W f32 [N, D] (N % 256 == 0); packs W / b in
+    the IL8 order itself (callers on a hot path keep the packed form)."""
+    _need(x, torch.float32, "x")
+    N, D = w.shape
+    order = il8_row_order(N, w.device)
+    wp, bp = pack_frag(w.detach().float()[order]), b.detach().float()[order].contiguous()
+    out = torch.empty((x.shape[0], N), dtype=torch.bfloat16, device=x.device)
+    check(lib().csship_ln_linear_wide(_ptr(x), _ptr(ln[0]), _ptr(ln[1]), _ptr(wp), _ptr(bp), _ptr(out), x.shape[0], D, N, _stream()))
+    return out
+
+
+def linear_res_wide(a_bf16, w, b, res):
+    """csship_linear_res_wide: res + a W^T + b for a bf16 [M, D], W f32 [D, D], res f32 [M, D]."""
+    _need(a_bf16, torch.bfloat16, "a")
+    _need(res, torch.float32, "res")
+    out = torch.empty_like(res)
+    check(lib().csship_linear_res_wide(_ptr(a_bf16), _ptr(pack_frag(w)), _ptr(b), _ptr(res), _ptr(out), a_bf16.shape[0],
+                                       w.shape[0], _stream()))
+    return out
+
+
 def ffn_mx(x, ln, w1mx, b1, w2mx, b2, d_ffn, alpha=0.5, final_ln=None, out=None):
     """csship_ffn_mx: the fused FeedForward with MXFP8 operands; w1mx / w2mx = pack_mx(W) tuples (bytes, scales)."""
     _need(x, torch.float32, "x")

@@ -225,6 +225,17 @@ int csship_ffn_wide(const float* x, float* out, const float* ln_g, const float* 
                     const float* final_ln_b, int32_t M, int32_t d_model, int32_t d_ffn, float alpha,
                     csship_stream_t stream);
 
+/* The two Linears of the attention stage at d_model 256 OR 512 as row-panel kernels (css_amd/csrc/ffnw.hip):
+ * csship_ln_linear_wide: out_bf16[M, N] = bf16(LayerNorm(x) W^T + b)  (conformer.py:222-225; N % 256 == 0; w / bias rows
+ *   in the 8-feature interleave of css_amd.ops.pack_frag_il8 / il8_row_order - out itself is in natural feature order);
+ * csship_linear_res_wide: out[M, d_model] = res + a_bf16 W^T + b  (conformer.py:254, 356; w from css_amd.ops.pack_frag;
+ *   out may alias res). */
+int csship_ln_linear_wide(const float* x, const float* ln_g, const float* ln_b, const uint16_t* w_il8_packed,
+                          const float* bias_il8, uint16_t* out_bf16, int32_t M, int32_t d_model, int32_t N,
+                          csship_stream_t stream);
+int csship_linear_res_wide(const uint16_t* a_bf16, const uint16_t* w_packed, const float* bias, const float* res,
+                           float* out, int32_t M, int32_t d_model, csship_stream_t stream);
+
 /* csship_ffn_mx: the fused FeedForward with BLOCK-SCALED FP8 operands (OCP MXFP8: e4m3 elements, one e8m0 power-of-two
  * scale per 32 consecutive elements of the reduction dimension; v_mfma_scale_f32_16x16x128_f8f6f4) in both products:
  * LayerNorm output and ReLU'd hidden activation are quantised in the kernel (scale 2^(floor(log2(max|block|)) - 8),
@@ -443,6 +454,9 @@ typedef struct {
   int32_t ffn_mode;        /* generic == 1 only: 0 = FeedForward unfused (LayerNorm + two tiled Linears, row-major weights);
                             * 1 = csship_ffn_wide (FeedForward weights in FRAGMENT order, d_model 256 / 512, d_ffn % 256 == 0);
                             * 2 = csship_ffn_mx (opt-in block-scaled fp8: w1 / w2 / w*_scale from css_amd.ops.pack_mx) */
+  int32_t lin_mode;        /* generic == 1 only: 0 = q/k/v and output projections as LayerNorm + tiled Linear (row-major
+                            * weights); 1 = csship_ln_linear_wide / csship_linear_res_wide (mha.wqkv / bqkv in the IL8
+                            * fragment order, mha.wo in fragment order; d_model 256 / 512) */
   int32_t chain_flags;     /* generic == 0: flags handed to csship_encoder_chain (CSSHIP_CHAIN_QKV_IL8: every layer's
                             * mha.wqkv / bqkv in the interleaved row order).  FeedForward / attention LayerNorms with NULL
                             * gamma and beta are folded into w1 / wqkv (see csship_encoder_chain) */

@@ -499,3 +499,23 @@ def test_ffn_mx(ops, D, FF, M):
         mse_q = float(((out.cpu().double() - ref_q) ** 2).mean())
         assert mse_q < 2e-6 and e_q < 3e-2, (D, FF, e_q, mse_q)
         assert e_fmt < 0.3, (D, FF, e_fmt)
+
+
+@pytest.mark.parametrize("D,M", [(256, 300), (512, 200)])
+def test_wide_row_panel_linears(ops, D, M):
+    """csship_ln_linear_wide (LayerNorm + q|k|v projection, interleaved rows, bf16 out) and csship_linear_res_wide
+    (output projection + residual) vs float64 on the same bf16-rounded operands."""
+    d = lambda t: t.to(DEV)  # noqa: E731
+    x = rnd((M, D), 700 + D) * 1.5
+    g, b = 1 + 0.1 * rnd((D,), 701), 0.1 * rnd((D,), 702)
+    wq, bq = rnd((3 * D, D), 703, D ** -0.5), rnd((3 * D,), 704, 0.1)
+    out = ops.ln_linear_wide(d(x), (d(g), d(b)), d(wq), d(bq))
+    a64 = torch.nn.functional.layer_norm(x.double(), (D,), g.double(), b.double())
+    ref = bf(a64.float()).double() @ bf(wq).double().t() + bq.double()
+    assert out.shape == (M, 3 * D) and err(out.float(), ref) < 3e-2                      # bf16 output of O(2) values
+    assert float(((out.float().cpu().double() - ref) ** 2).mean()) < 3e-5
+    a = bf(rnd((M, D), 705))
+    wo, bo, res = rnd((D, D), 706, D ** -0.5), rnd((D,), 707, 0.1), rnd((M, D), 708)
+    out2 = ops.linear_res_wide(d(a).to(torch.bfloat16), d(wo), d(bo), d(res))
+    ref2 = res.double() + a.double() @ bf(wo).double().t() + bo.double()
+    assert err(out2, ref2) < 2e-4
