@@ -531,7 +531,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x,
 // narrow (128 x 64) tiles: N of 64 or less (no half-empty B tile), needs the descriptor loaders
 bool narrow_tile(const csship_bgemm_params* p) {
   static const bool off = getenv("CSSHIP_BGEMM_WIDE") != nullptr;  // A/B timing
-  static const int maxn = [] { const char* e = getenv("CSSHIP_BGEMM_NARROW_MAXN"); return e ? atoi(e) : 64; }();
+  static const int maxn = [] { const char* e = getenv("CSSHIP_BGEMM_NARROW_MAXN"); return e ? atoi(e) : 256; }();  // 256: the 1024 x 256 FeedForward weight gradient takes 32 narrow tiles x 12 slabs instead of 16 x 24 (half the slab traffic): training step 13.76 -> 13.56 ms
   return !off && p->N <= maxn && (((p->a_kmajor ? p->M : p->K) | (p->b_kmajor ? p->N : p->K)) & 7) == 0;
 }
 
@@ -541,7 +541,8 @@ int pick_splits(const csship_bgemm_params* p) {
   const int64_t tiles = (int64_t)((p->M + 127) / 128) * ((p->N + tn - 1) / tn) * p->batch1 * p->batch2;
   const int kt = (p->K + BK - 1) / BK;
   if (tiles >= 128 || kt < 8 || p->batch1 * p->batch2 != 1 || (p->epilogue & ~CSSHIP_BEPI_ADD) != 0) return 1;
-  int s = (int)((384 + tiles - 1) / tiles);
+  static const int target = [] { const char* e = getenv("CSSHIP_BGEMM_TARGET_WGS"); return e ? atoi(e) : 384; }();  // A/B timing
+  int s = (int)((target + tiles - 1) / tiles);
   if (s > kt / 2) s = kt / 2;
   return s < 1 ? 1 : s;
 }
@@ -556,7 +557,7 @@ static int launch_slab_reduce2(const float* slabs, int S, int64_t n, int N, int6
   // waves share the slabs of 64 elements
   if ((N & 3) == 0 && (n & 3) == 0 && n >= 4096 && aligned16(slabs) && (n2 & 3) == 0 && aligned16(slabs2)) {
     const unsigned nb = (unsigned)((n / 4 + 63) / 64), nb2 = (unsigned)((n2 / 4 + 63) / 64);
-    hipLaunchKernelGGL((slab_reduce_kernel<4, 4, 4>), dim3(nb + nb2), dim3(256), 0, s, slabs, S, n, N, ldc, alpha, bias, add,
+    hipLaunchKernelGGL((slab_reduce_kernel<4, 4, 8>), dim3(nb + nb2), dim3(256), 0, s, slabs, S, n, N, ldc, alpha, bias, add,
                        ldadd, out, (int)nb, slabs2, n2, out2, alpha_head, head_rows);
   } else {
     const unsigned nb = (unsigned)((n + 63) / 64), nb2 = (unsigned)((n2 + 63) / 64);
