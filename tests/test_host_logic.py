@@ -175,6 +175,21 @@ mid = fs.numel() // 2 // 4 * 4
 parallel.allreduce_segment(fs, mid, fs.numel(), hs); parallel.allreduce_segment(fs, 0, mid, hs)   # last block first
 parallel.wait_all(hs, fs, average=True)
 ok = ok and torch.allclose(fs, want, atol=1e-6)
+# the collective schedule both step forms issue (parallel.bucket_plan -> allreduce_plan): a plan of stretches in backward
+# order, here rank 0 issues it in one go and rank 1 stretch by stretch with work in between (an eager rank next to a
+# replaying one): same result, ranks stay paired
+fp = fresh()
+n = fp.numel()
+plan = [(n - n // 3 // 4 * 4, n), (n // 4 // 4 * 4, n - n // 3 // 4 * 4), (0, n // 4 // 4 * 4)]
+if rank == 0:
+    parallel.allreduce_plan(fp, plan)
+else:
+    hs = []
+    for lo_, hi_ in plan:
+        parallel.allreduce_segment(fp, lo_, hi_, hs)
+        _ = torch.randn(64, 64) @ torch.randn(64, 64)
+    parallel.wait_all(hs, fp, average=True)
+ok = ok and torch.allclose(fp, want, atol=1e-6)
 t = torch.full((5,), float(rank + 1), dtype=torch.float64)
 ok = ok and torch.equal(parallel.allreduce_sum_(t), torch.full((5,), 3.0, dtype=torch.float64))
 # window gather
