@@ -264,8 +264,22 @@ class ConformerTrain(torch.autograd.Function):
 
         def put(p, g):
             g = g.reshape(p.shape)
-            G[p] = G[p] + g if p in G else g
+            if p in G:
+                red.flush()   # the sum reads both gradients
+                G[p] = G[p] + g
+            else:
+                G[p] = g
 
+        # the reductions behind the parameter gradients of a block run as ONE launch at its end (ops_bwd.deferred_reductions)
+        with ob.deferred_reductions() as red:
+            return ConformerTrain._backward(ctx, grad_masks, model, S, G, put, red)
+
+    @staticmethod
+    def _backward(ctx, grad_masks, model, S, G, put, red):
+        enc = model.conformer
+        D, H = enc.d_model, enc.n_head
+        B, T, F = S["f"].shape
+        M = B * T
         masks = S["masks"]
         dm = grad_masks.reshape(M, -1)
         if dm.stride(1) != 1 or dm.stride(0) % 4:
@@ -274,6 +288,7 @@ class ConformerTrain(torch.autograd.Function):
             dm = buf
         dx, dw, db = bw.head_bwd(dm, masks, S["x_enc"], S["wh_bf"])
         put(model.linear.weight, dw), put(model.linear.bias, db)
+        red.flush()
         _deliver_group(model, model.linear, G)
         window = bw.relpos_window(S["pe_bf"], T, 1000)
         dwin = None
@@ -325,6 +340,7 @@ class ConformerTrain(torch.autograd.Function):
             put(a.linear_out.weight, dwo), put(a.linear_out.bias, dbo)
             dx = ffn_b(lay.feed_forward_in, "ffn_in", dx)
             L.clear()
+            red.flush()
             _deliver_group(model, lay, G)
         if enc.pos_emb is not None:
             dpe = torch.zeros_like(enc.pos_emb.pe_k.weight)
@@ -336,6 +352,7 @@ class ConformerTrain(torch.autograd.Function):
                                            enc.embed[1].weight.detach(), enc.embed[1].bias.detach(), e=S["e"])
         put(enc.embed[0].weight, dwe), put(enc.embed[0].bias, dbe)
         put(enc.embed[1].weight, dg), put(enc.embed[1].bias, dbeta)
+        red.flush()
         return (None, None) + _deliver(model, G)
 
 

@@ -13,6 +13,10 @@
 // buffering.  Long reductions (dW: K = B*T = 12 800) are split over blockIdx.z into fp32 slabs that a
 // second kernel sums in a fixed order (deterministic, no atomics).  fp32 operands are rounded to bf16
 // on load.  Batches use a two-level index z = z1 * nb2 + z2 (batch, head).
+#include <algorithm>
+#include <type_traits>
+#include <vector>
+
 #include "common.hpp"
 
 namespace {
@@ -191,6 +195,41 @@ DEV bf16x8 read_frag(const unsigned char* img, int r0, int ks, int lane) {
   }
 }
 
+// The same k-major fragment read as inline assembly, for the LDS-DMA loop: behind the builtin hipcc waits vmcnt(0)
+// before every LDS read that follows a buffer_load ... lds (it cannot tell the stages apart), which would serialise
+// the loop again.  The caller counts lgkmcnt itself (FRAG_WAIT).  OFF = byte offset of the k-step inside the tile.
+template <int OFF>
+DEV bf16x8 read_frag_km_asm(unsigned lds_addr) {
+  s16x4 lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(lds_addr), "n"(OFF));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(lds_addr), "n"(OFF + 1024));
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+#define FRAG_WAIT(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]))
+
+// one k-step of the LDS-DMA loop: fragments of both operands (OFF = the k-step's byte offset in the tile) ...
+template <int OFF>
+DEV void gl_read_step(bf16x8 (&a)[4], bf16x8 (&b)[4], unsigned st, const unsigned (&fa)[4], const unsigned (&fb)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i] = read_frag_km_asm<OFF>(st + fa[i]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b[j] = read_frag_km_asm<128 * 128 + OFF>(st + fb[j]);
+}
+// ... and its MFMAs, accumulating in place (transposed product, as the compiler-scheduled loop).  hipcc does not see
+// an MFMA inside an asm statement, so the wait states it would insert are ours: an MFMA reading a register a VALU
+// instruction wrote needs 2 - the fragments come from LDS (s_waitcnt), the accumulators are zeroed long before
+// (s_nop after the zeroing), the vector of ones is a constant the compiler may re-create anywhere (s_nop in place).
+#define GL_MFMA(c, x, y) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(x), "v"(y))
+template <bool CS>
+DEV void gl_mfma_step(f32x4 (&acc)[4][4], f32x4 (&cs)[4], const bf16x8& ones, const bf16x8 (&a)[4], const bf16x8 (&b)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) GL_MFMA(acc[i][j], b[j], a[i]);
+    if constexpr (CS) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(cs[i]) : "v"(ones), "v"(a[i]));
+  }
+}
+
 // -DBG_STAMPS: per-workgroup cycle stamps of the main loop's phases (tools/bgemm_stamps.py); not part of the product build
 #ifdef BG_STAMPS
 __device__ unsigned* g_bg_stamps = nullptr;
@@ -203,12 +242,24 @@ __device__ unsigned* g_bg_stamps = nullptr;
 // per A fragment against a fragment of ones (D[n][m] = sum_k 1 * A[k][m]: every row of the result is the column sum).
 // TN: output columns per tile.  64 (FAST kernels only): products whose N is 64 (the per-head attention gradients) or
 // whose 128-wide tiling leaves less than two workgroups per CU - a wave then owns 64 x 32 of the tile.
-template <bool A_KM, bool B_KM, bool FAST, bool A_F32, bool B_F32, bool COLSUM = false, int TN = 128>
+// GL (both operands bf16 and reduction-strided, whole tiles: the weight-gradient products): the tiles travel global ->
+// LDS by LDS-DMA (buffer_load ... lds, 16 bytes per lane, no register hop) into GL_STAGES stages, GL_STAGES - 1 tiles
+// ahead of the MFMAs, behind counted vmcnt waits and a bare s_barrier - the register-staged loop above it is phase-serial with
+// one wave per SIMD (request loads 580 cycles, fragments 380, MFMAs 620, wait + LDS store 364, barrier 144 per
+// 64-deep tile).  The LDS image is lane-linear per wave instruction, so the bank swizzle of km_off is applied to
+// the SOURCE address (XOR is its own inverse).
+constexpr int GL_STAGES = 4;  // 128 KB of the CU's 160 KB: one workgroup per CU, 96 KB of operands in flight
+#define GL_WAIT_TILE_(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define GL_WAIT_TILE() GL_WAIT_TILE_(16)
+static_assert(8 * (GL_STAGES - 2) == 16, "GL_WAIT_TILE: 8 LDS-DMA instructions per wave and tile, GL_STAGES - 2 newer tiles in flight");
+template <bool A_KM, bool B_KM, bool FAST, bool A_F32, bool B_F32, bool COLSUM = false, int TN = 128, bool GL = false>
 __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
   static_assert(TN == 128 || (TN == 64 && FAST), "narrow tiles use the descriptor loaders");
+  static_assert(!GL || (A_KM && B_KM && FAST && !A_F32 && !B_F32 && TN == 128), "LDS-DMA path: bf16 k-major operands, 128 x 128 tiles");
   constexpr int NJ = TN / 32, WN = TN / 2;  // 16-column fragments per wave, columns per wave
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(GL ? GL_STAGES : 2) * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = GL ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
 #ifdef BG_STAMPS
   __shared__ unsigned stamps[96];
   if (tid < 96) stamps[tid] = 0;
@@ -271,6 +322,100 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
+  if constexpr (GL) {
+    // one tile = 2 x 16 wave instructions of 1 KB (4 k rows of 256 B); wave w issues instructions 4w .. 4w + 3 of each
+    // operand: lane l lands at row 4q + (l >> 4), 16-byte piece l & 15 of the image, and fetches the piece the swizzle
+    // wants there
+    // M, N are whole tiles and the split's reduction range whole 64-deep tiles here (host), so a tile is either all
+    // there or all beyond the range: per-lane byte offsets inside a tile once, the tile's offset (or OOB) per issue
+    unsigned ga[4], gb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = wave * 4 + j;
+      const int kl = q * 4 + (lane >> 4), cp = lane & 15;
+      const int grp = (cp >> 1) ^ ((kl & 3) | (((kl >> 3) & 1) << 2));
+      const int e0 = (2 * grp + (cp & 1)) * 8;
+      ga[j] = ((unsigned)kl * (unsigned)g.lda + (unsigned)(m0 + e0)) * 2u;
+      gb[j] = ((unsigned)kl * (unsigned)g.ldb + (unsigned)(n0 + e0)) * 2u;
+    }
+    auto glds_tile = [&](int k0, unsigned so) {
+      const bool valid = k0 < kend;
+      const unsigned ka = (unsigned)k0 * (unsigned)g.lda * 2u, kb = (unsigned)k0 * (unsigned)g.ldb * 2u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int q = wave * 4 + j;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (__attribute__((address_space(3))) void*)(smem + so + q * 1024), 16, (int)(valid ? ga[j] + ka : OOB), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (__attribute__((address_space(3))) void*)(smem + so + 128 * 128 + q * 1024), 16, (int)(valid ? gb[j] + kb : OOB), 0, 0, 0);
+      }
+    };
+    // per-lane part of the fragment addresses (read_frag<true>): k = 8 (lane >> 4) + ((lane & 15) >> 2) within the
+    // k-step, 8 bytes per lane & 3; km_off's swizzle key depends on k & 3 and bit 3 of k only, so the k-step (a
+    // multiple of 32) and the stage add linearly and ride in the instruction's offset field
+    const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    unsigned fa[4], fb[4];
+    {
+      const int kf = 8 * (lane >> 4) + ((lane & 15) >> 2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = km_off(kf, wm * 4 + i) + (lane & 3) * 8;
+        fb[i] = km_off(kf, wn * 4 + i) + (lane & 3) * 8;
+      }
+    }
+    // The loop in inline assembly statements, which hipcc keeps in source order.  Left to the compiler, the second
+    // k-step's MFMAs get destination tuples shifted against their sources and 48 accumulators travel through register
+    // copies per tile; and the LDS reads would wait for vmcnt(0) (read_frag_km_asm).  Schedule per tile, one barrier:
+    //   wait my part of tile kt | barrier | read k-step 0 of tile kt | MFMAs of k-step 1 of tile kt - 1 (they hide the
+    //   barrier and the LDS latency) | issue tile kt + 2 | read k-step 1 | MFMAs of k-step 0 | fragments landed
+    // The body exists twice, with and without the column-sum MFMAs (a wave-uniform branch inside would sit between asm
+    // statements).  Every iteration issues a tile - beyond the reduction range the offsets are outside the descriptor:
+    // zeros, no memory traffic - so the vmcnt count is the same everywhere.
+    auto main_loop = [&](auto with_cs) {
+      constexpr bool CS = decltype(with_cs)::value;
+      bf16x8 a0[4], b0[4], a1[4], b1[4];
+      auto read_step0 = [&](unsigned st) { gl_read_step<0>(a0, b0, st, fa, fb); };
+      auto read_step1 = [&](unsigned st) { gl_read_step<32 * 256>(a1, b1, st, fa, fb); };
+      auto mfma_step = [&](bf16x8 (&a)[4], bf16x8 (&b)[4]) { gl_mfma_step<CS>(acc, cs, ones, a, b); };
+#pragma unroll
+      for (int t = 0; t < GL_STAGES - 1; ++t) glds_tile(kbeg + t * BK, t * STAGE);
+      // tile kt lives in stage kt % GL_STAGES; tiles kt + 1 .. kt + GL_STAGES - 2 may still be in flight when tile kt is
+      // needed (8 instructions per wave each), and tile kt + GL_STAGES - 1 goes into the stage tile kt - 1 was read from
+      unsigned cur = 0, prev = (GL_STAGES - 1) * STAGE;
+      GL_WAIT_TILE();
+      __builtin_amdgcn_s_barrier();
+      read_step0(smem_lds);
+      glds_tile(kbeg + (GL_STAGES - 1) * BK, prev);
+      FRAG_WAIT(0, a0);
+      FRAG_WAIT(0, b0);
+      read_step1(smem_lds);
+      asm volatile("s_nop 4");  // accumulators zeroed by VALU moves
+      mfma_step(a0, b0);
+      FRAG_WAIT(0, a1);
+      FRAG_WAIT(0, b1);
+      for (int kt = 1; kt < nk; ++kt) {
+        prev = cur;
+        cur = (cur == (GL_STAGES - 1) * STAGE) ? 0 : cur + STAGE;
+        GL_WAIT_TILE();                // my part of tile kt has landed
+        __builtin_amdgcn_s_barrier();  // all of tile kt is in LDS, and every wave is done reading tile kt - 1
+        read_step0(smem_lds + cur);
+        mfma_step(a1, b1);             // k-step 1 of tile kt - 1
+        glds_tile(kbeg + (kt + GL_STAGES - 1) * BK, prev);
+        FRAG_WAIT(0, a0);
+        FRAG_WAIT(0, b0);
+        read_step1(smem_lds + cur);
+        mfma_step(a0, b0);
+        FRAG_WAIT(0, a1);
+        FRAG_WAIT(0, b1);
+      }
+      mfma_step(a1, b1);
+      // the zero tiles behind the last one; and the MFMA results are read by ordinary instructions next, which
+      // the compiler cannot know to delay
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    };
+    if (nk > 0) {
+      if (COLSUM && do_cs) main_loop(std::true_type{});
+      else main_loop(std::false_type{});
+    }
+  } else {
   if (nk > 0) {
     load_tile(kbeg);
     store_operand<A_KM>(smem, tid, ra, af32);
@@ -326,6 +471,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
     __syncthreads();
     if (kt < 12) STAMP(6 + kt * 5);
   }
+  }  // !GL
   STAMP(62);
 
   // ---- epilogue.  The MFMAs compute the transposed tile (B fragment as the A operand), so acc[i][j][r] is
@@ -437,22 +583,15 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
 // Workgroup = 64 lanes x V consecutive elements x NW waves; wave w adds slabs w, w+NW, ... with eight loads in flight,
 // then one LDS reduction - short outputs with many slabs (LayerNorm / bias partials) do not serialise on one thread,
 // long ones (V = 4: N and the slab size are multiples of 4) move 16 bytes per load instruction.
+// one virtual workgroup of 64 * NW threads (thread index tix) reducing 64 * V elements; red: its NW x 64 vectors of LDS.
+// tail: the short second output of a weight-gradient product (head_rows counts its elements, not rows).
 template <int V, int NW, int U>
-__global__ __launch_bounds__(64 * NW) void slab_reduce_kernel(const float* __restrict__ slabs, int S, int64_t n, int N,
-                                                              int64_t ldc, float alpha, const float* __restrict__ bias,
-                                                              const float* add, int64_t ldadd, float* out, int nb_main,
-                                                              const float* __restrict__ slabs2, int64_t n2,
-                                                              float* __restrict__ out2, float alpha_head, int head_rows) {
+DEV void slab_reduce_body(const float* __restrict__ slabs, int S, int64_t n, int N, int64_t ldc, float alpha,
+                          const float* __restrict__ bias, const float* add, int64_t ldadd, float* out, float alpha_head,
+                          int head_rows, bool tail, int bid, int tix, float (*red_)[64][V]) {
   typedef float vec __attribute__((ext_vector_type(V)));
-  __shared__ vec red[NW][64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  int bid = blockIdx.x;
-  bool tail = false;
-  if (bid >= nb_main) {  // second, short output reduced by the same launch (the bias gradient next to its weight gradient)
-    bid -= nb_main;
-    tail = true;
-    slabs = slabs2; n = n2; N = (int)n2; ldc = n2; bias = nullptr; add = nullptr; out = out2;
-  }
+  vec(*red)[64] = reinterpret_cast<vec(*)[64]>(red_);
+  const int lane = tix & 63, w = tix >> 6;
   const int64_t i = ((int64_t)bid * 64 + lane) * V;
   vec s[U];
 #pragma unroll
@@ -489,6 +628,67 @@ __global__ __launch_bounds__(64 * NW) void slab_reduce_kernel(const float* __res
     if (bias) v += bias[c + e];
     if (add) v += add[r * ldadd + c + e];
     out[r * ldc + c + e] = v;
+  }
+}
+
+template <int V, int NW, int U>
+__global__ __launch_bounds__(64 * NW) void slab_reduce_kernel(const float* __restrict__ slabs, int S, int64_t n, int N,
+                                                              int64_t ldc, float alpha, const float* __restrict__ bias,
+                                                              const float* add, int64_t ldadd, float* out, int nb_main,
+                                                              const float* __restrict__ slabs2, int64_t n2,
+                                                              float* __restrict__ out2, float alpha_head, int head_rows) {
+  __shared__ __attribute__((aligned(16))) float red[NW][64][V];
+  int bid = blockIdx.x;
+  bool tail = false;
+  if (bid >= nb_main) {  // second, short output reduced by the same launch (the bias gradient next to its weight gradient)
+    bid -= nb_main;
+    tail = true;
+    slabs = slabs2; n = n2; N = (int)n2; ldc = n2; bias = nullptr; add = nullptr; out = out2;
+  }
+  slab_reduce_body<V, NW, U>(slabs, S, n, N, ldc, alpha, bias, add, ldadd, out, alpha_head, head_rows, tail, bid,
+                             (int)threadIdx.x, red);
+}
+
+// ---- deferred reductions: up to RB_MAX queued jobs in ONE launch of 1024-thread workgroups.  Every job keeps the
+// summation structure (V, NW, U) its own launch would use, so the results are the same bit for bit: a 16-wave job takes a
+// whole workgroup per virtual workgroup, a 4-wave job four virtual workgroups per workgroup.
+constexpr int RB_MAX = 36;
+struct ReduceJob {
+  const float* slabs;
+  const float* bias;
+  const float* add;
+  float* out;
+  int64_t n, ldc, ldadd;
+  int S, N, head_rows, kind;  // kind: 0 = <4,4,8>, 1 = <1,16,8>, 2 = <1,4,4>; | 4 = tail output
+  float alpha, alpha_head;
+  int nvb, pad_;              // virtual workgroups
+};
+struct ReduceBatch {
+  ReduceJob job[RB_MAX];
+  int first[RB_MAX + 1];  // first workgroup of every job
+  int njobs;
+};
+
+__global__ __launch_bounds__(1024) void slab_reduce_batch_kernel(ReduceBatch b) {
+  __shared__ __attribute__((aligned(16))) float red[4][4][64][4];
+  int j = 0;
+  while (j + 1 < b.njobs && (int)blockIdx.x >= b.first[j + 1]) ++j;  // wave-uniform
+  const ReduceJob& q = b.job[j];
+  const int wg = blockIdx.x - b.first[j], t = threadIdx.x;
+  const int kind = q.kind & 3;
+  const bool tail = (q.kind & 4) != 0;
+  if (kind == 1) {
+    slab_reduce_body<1, 16, 8>(q.slabs, q.S, q.n, q.N, q.ldc, q.alpha, q.bias, q.add, q.ldadd, q.out, q.alpha_head,
+                               q.head_rows, tail, wg, t, reinterpret_cast<float(*)[64][1]>(&red[0][0][0][0]));
+  } else {
+    // virtual workgroups beyond the job's last one find i >= n and only take part in the barrier
+    const int sub = t >> 8, vb = wg * 4 + sub;
+    if (kind == 0)
+      slab_reduce_body<4, 4, 8>(q.slabs, q.S, q.n, q.N, q.ldc, q.alpha, q.bias, q.add, q.ldadd, q.out, q.alpha_head,
+                                q.head_rows, tail, vb, t & 255, reinterpret_cast<float(*)[64][4]>(&red[sub][0][0][0]));
+    else
+      slab_reduce_body<1, 4, 4>(q.slabs, q.S, q.n, q.N, q.ldc, q.alpha, q.bias, q.add, q.ldadd, q.out, q.alpha_head,
+                                q.head_rows, tail, vb, t & 255, reinterpret_cast<float(*)[64][1]>(&red[sub][0][0][0]));
   }
 }
 
@@ -535,8 +735,24 @@ bool narrow_tile(const csship_bgemm_params* p) {
   return !off && p->N <= maxn && (((p->a_kmajor ? p->M : p->K) | (p->b_kmajor ? p->N : p->K)) & 7) == 0;
 }
 
-int pick_splits(const csship_bgemm_params* p) {
+// the LDS-DMA loop (bgemm_kernel<..., GL>): weight-gradient products of bf16 operands in whole tiles
+bool glds_path(const csship_bgemm_params* p, bool colsum) {
+  static const bool off = getenv("CSSHIP_BGEMM_NOGLDS") != nullptr;  // A/B timing
+  return !off && colsum && p->a_kmajor && p->b_kmajor && !p->a_f32 && !p->b_f32 && (p->M % 128) == 0 && (p->N % 128) == 0 &&
+         (p->K % BK) == 0 && p->batch1 == 1 && p->batch2 == 1;
+}
+
+int pick_splits(const csship_bgemm_params* p, bool colsum = false) {
   if (p->splits > 0) return p->splits;
+  if (glds_path(p, colsum)) {
+    // one workgroup per CU (128 KB of LDS): as many slabs as fill the 256 CUs once, in eights for the XCD-aware order
+    // (measured, 12 800 rows: 256 x 1024 -> 16 slabs 21 us against 30 us with 24; tools/wgrad_sweep.py)
+    const int tiles = (p->M / 128) * (p->N / 128), kt = p->K / BK;
+    int s = 256 / tiles;
+    if (s >= 8) s &= ~7;
+    if (s > kt / 2) s = kt / 2;
+    return s < 1 ? 1 : s;
+  }
   const int tn = narrow_tile(p) ? 64 : 128;
   const int64_t tiles = (int64_t)((p->M + 127) / 128) * ((p->N + tn - 1) / tn) * p->batch1 * p->batch2;
   const int kt = (p->K + BK - 1) / BK;
@@ -550,12 +766,41 @@ int pick_splits(const csship_bgemm_params* p) {
 }  // namespace
 
 // slabs2 / n2 / out2 (optional): a second output of n2 elements with the same S and alpha, reduced by the same launch
+// the host thread's queue of deferred reductions (csship_reduce_defer / csship_reduce_flush)
+struct DeferQueue {
+  bool on = false;
+  std::vector<ReduceJob> jobs;
+};
+static thread_local DeferQueue t_defer;
+
+static void queue_job(const float* slabs, int S, int64_t n, int N, int64_t ldc, float alpha, const float* bias,
+                      const float* add, int64_t ldadd, float* out, float alpha_head, int head_rows, int kind) {
+  ReduceJob j{};
+  j.slabs = slabs; j.bias = bias; j.add = add; j.out = out; j.n = n; j.ldc = ldc; j.ldadd = ldadd; j.S = S; j.N = N;
+  j.head_rows = head_rows; j.kind = kind; j.alpha = alpha; j.alpha_head = alpha_head;
+  const int v = (kind & 3) == 0 ? 4 : 1;
+  j.nvb = (int)((n / v + 63) / 64);
+  t_defer.jobs.push_back(j);
+}
+
 static int launch_slab_reduce2(const float* slabs, int S, int64_t n, int N, int64_t ldc, float alpha, const float* bias,
                                const float* add, int64_t ldadd, float* out, const float* slabs2, int64_t n2, float* out2,
-                               hipStream_t s, float alpha_head = 0.f, int head_rows = 0) {
+                               hipStream_t s, float alpha_head = 0.f, int head_rows = 0, bool deferrable = false) {
   // long outputs: 16-byte loads, 4 waves per 256 elements; short outputs with many slabs (bias / LayerNorm partials): 16
   // waves share the slabs of 64 elements
-  if ((N & 3) == 0 && (n & 3) == 0 && n >= 4096 && aligned16(slabs) && (n2 & 3) == 0 && aligned16(slabs2)) {
+  const bool wide = (N & 3) == 0 && (n & 3) == 0 && n >= 4096 && aligned16(slabs) && (n2 & 3) == 0 && aligned16(slabs2);
+  // only SMALL slab sets are ever marked deferrable (LayerNorm / FeedForward bias partials).  A weight gradient's 16 MB of
+  // slabs are summed right behind the product, out of the 256 MB MALL, and its scratch is rewritten by the next
+  // product without reaching HBM; queued for the end of the block they came back from HBM: 112 us per block for 125 MB
+  // against 14 launches x 5.7 us (measured).  The size test keeps that true whatever a caller marks.
+  static const int64_t defer_max = (int64_t)4 << 20;
+  if (deferrable && t_defer.on && (int64_t)S * (n + n2) * 4 <= defer_max) {  // the same kernel shape as the launch below would pick, later
+    const int kind = wide ? 0 : (S >= 32 ? 1 : 2);
+    queue_job(slabs, S, n, N, ldc, alpha, bias, add, ldadd, out, alpha_head, head_rows, kind);
+    if (n2 > 0) queue_job(slabs2, S, n2, (int)n2, n2, alpha, nullptr, nullptr, 0, out2, alpha_head, head_rows, kind | 4);
+    return CSSHIP_OK;
+  }
+  if (wide) {
     const unsigned nb = (unsigned)((n / 4 + 63) / 64), nb2 = (unsigned)((n2 / 4 + 63) / 64);
     hipLaunchKernelGGL((slab_reduce_kernel<4, 4, 8>), dim3(nb + nb2), dim3(256), 0, s, slabs, S, n, N, ldc, alpha, bias, add,
                        ldadd, out, (int)nb, slabs2, n2, out2, alpha_head, head_rows);
@@ -573,8 +818,42 @@ static int launch_slab_reduce2(const float* slabs, int S, int64_t n, int N, int6
 }
 
 int launch_slab_reduce(const float* slabs, int S, int64_t n, int N, int64_t ldc, float alpha, const float* bias,
-                       const float* add, int64_t ldadd, float* out, hipStream_t s) {
-  return launch_slab_reduce2(slabs, S, n, N, ldc, alpha, bias, add, ldadd, out, nullptr, 0, nullptr, s);
+                       const float* add, int64_t ldadd, float* out, hipStream_t s, bool deferrable) {
+  return launch_slab_reduce2(slabs, S, n, N, ldc, alpha, bias, add, ldadd, out, nullptr, 0, nullptr, s, 0.f, 0, deferrable);
+}
+
+extern "C" int csship_reduce_defer(int32_t on) {
+  const int was = t_defer.on ? 1 : 0;
+  t_defer.on = on != 0;
+  if (!on) t_defer.jobs.clear();  // leaving the mode without a flush (error paths) drops what was queued
+  return was;
+}
+
+extern "C" int csship_reduce_pending(void) { return (int)t_defer.jobs.size(); }
+
+extern "C" int csship_reduce_flush(csship_stream_t stream) {
+  hipStream_t s = as_stream(stream);
+  std::vector<ReduceJob>& q = t_defer.jobs;
+  for (size_t at = 0; at < q.size(); at += RB_MAX) {
+    ReduceBatch b{};
+    b.njobs = (int)std::min<size_t>(RB_MAX, q.size() - at);
+    int wgs = 0;
+    for (int j = 0; j < b.njobs; ++j) {
+      b.job[j] = q[at + j];
+      b.first[j] = wgs;
+      wgs += (b.job[j].kind & 3) == 1 ? b.job[j].nvb : (b.job[j].nvb + 3) / 4;
+    }
+    b.first[b.njobs] = wgs;
+    if (wgs > 0) {
+      hipLaunchKernelGGL(slab_reduce_batch_kernel, dim3((unsigned)wgs), dim3(1024), 0, s, b);
+      if (hipGetLastError() != hipSuccess) {
+        q.clear();
+        return CSSHIP_ELAUNCH;
+      }
+    }
+  }
+  q.clear();
+  return CSSHIP_OK;
 }
 
 #ifdef BG_STAMPS
@@ -606,7 +885,7 @@ static bool wgrad_shape_ok(const csship_bgemm_params* p) {
 
 extern "C" size_t csship_bgemm_wgrad_workspace(const csship_bgemm_params* p) {
   if (!p) return 0;
-  const int s = pick_splits(p);
+  const int s = pick_splits(p, true);
   return s > 1 ? (size_t)s * ((size_t)p->M * p->N + p->M) * sizeof(float) : 0;
 }
 
@@ -632,7 +911,7 @@ static int bgemm_impl(const void* A, const void* B, void* C, const float* bias, 
     return CSSHIP_EALIGN;
   if (p->lda < (p->a_kmajor ? p->M : p->K) || p->ldb < (p->b_kmajor ? p->N : p->K) || p->ldc < p->N)
     return CSSHIP_EBADSHAPE;
-  const int splits = pick_splits(p);
+  const int splits = pick_splits(p, colsum_out != nullptr);
   const int64_t nz = (int64_t)p->batch1 * p->batch2 * splits;
   if (nz > 65535) return CSSHIP_EBADSHAPE;
   if (splits > 1) {
@@ -678,9 +957,11 @@ static int bgemm_impl(const void* A, const void* B, void* C, const float* bias, 
   } while (0)
   if (colsum_out) {
     if (!fast) return CSSHIP_EUNSUPPORTED;
+    const bool gl = glds_path(p, true);
     if (p->a_f32 && p->b_f32) hipLaunchKernelGGL((bgemm_kernel<true, true, true, true, true, true>), grid, dim3(256), 0, s, a);
     else if (p->a_f32) hipLaunchKernelGGL((bgemm_kernel<true, true, true, true, false, true>), grid, dim3(256), 0, s, a);
     else if (p->b_f32) hipLaunchKernelGGL((bgemm_kernel<true, true, true, false, true, true>), grid, dim3(256), 0, s, a);
+    else if (gl) hipLaunchKernelGGL((bgemm_kernel<true, true, true, false, false, true, 128, true>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((bgemm_kernel<true, true, true, false, false, true>), grid, dim3(256), 0, s, a);
   } else if (p->a_kmajor && p->b_kmajor) BG_LAUNCH(true, true);
   else if (p->a_kmajor) BG_LAUNCH(true, false);

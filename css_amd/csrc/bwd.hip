@@ -354,7 +354,7 @@ extern "C" int csship_layernorm_bwd(const float* x, const float* dy, const float
   else
     hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nwg), dim3(256), 0, s, x, dy, gamma, beta, dx_add, relu, M, LNB_ROWS, dx, part);
   CSSHIP_CHECK_LAUNCH();
-  return launch_slab_reduce(part, nwg, 2 * (int64_t)D, 2 * D, 2 * (int64_t)D, 1.f, nullptr, nullptr, 0, dgamma_dbeta, s);
+  return launch_slab_reduce(part, nwg, 2 * (int64_t)D, 2 * D, 2 * (int64_t)D, 1.f, nullptr, nullptr, 0, dgamma_dbeta, s, true);
 }
 
 extern "C" int csship_relu_bwd(const float* dy, int64_t ld_dy, const float* y, int64_t ld_y, int64_t M, int32_t N,

@@ -91,8 +91,11 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 static inline bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
 
 // out[r, c] = alpha * sum_s slabs[s][r*N + c] (+ bias[c]) (+ add[r*ldadd + c]), fixed order (bgemm.hip)
+// deferrable: the output is a parameter gradient nobody reads before the caller's csship_reduce_flush() - between
+// csship_reduce_defer(1) and that flush such reductions are queued (per host thread) and run as ONE launch; the slabs
+// must stay untouched until then.
 int launch_slab_reduce(const float* slabs, int S, int64_t n, int N, int64_t ldc, float alpha, const float* bias,
-                       const float* add, int64_t ldadd, float* out, hipStream_t s);
+                       const float* add, int64_t ldadd, float* out, hipStream_t s, bool deferrable = false);
 
 // Optional in-kernel phase stamps (diagnostic only; nullptr in normal operation): thread 0 of every
 // workgroup stores s_memrealtime (100 MHz) at up to 8 phase boundaries.  Set by csship_debug_stamps().

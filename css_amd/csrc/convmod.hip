@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) void glu_ln_bwd_kernel(const float* __restrict
 constexpr int BWD_ROWS = 16;
 
 struct BwdLayout {  // carve of the backward workspace (floats)
-  size_t dc, dg, part, sums, total;
+  size_t dc, dg, part, part_c, sums, total;
   int nwg_rows, nblk;
 };
 BwdLayout bwd_layout(int B, int T, int D, int TT) {
@@ -522,7 +522,9 @@ BwdLayout bwd_layout(int B, int T, int D, int TT) {
   L.nblk = ((T + TT - 1) / TT) * B * 2;
   const size_t p = (size_t)L.nwg_rows * (2 * D + 4) > (size_t)L.nblk * 34 * D ? (size_t)L.nwg_rows * (2 * D + 4)
                                                                              : (size_t)L.nblk * 34 * D;
-  L.dc = 0; L.dg = n; L.part = 2 * n; L.sums = 2 * n + p; L.total = L.sums + 2 * (size_t)D;  // sums: S1 | S2 for the apply pass
+  // part: the partials of pass A, then of pass B; part_c: pass C's own; sums: S1 | S2 for the apply pass
+  const size_t pc = ((size_t)L.nwg_rows * (2 * D + 4) + 3) / 4 * 4;
+  L.dc = 0; L.dg = n; L.part = 2 * n; L.part_c = 2 * n + (p + 3) / 4 * 4; L.sums = L.part_c + pc; L.total = L.sums + 2 * (size_t)D;
   return L;
 }
 
@@ -538,7 +540,7 @@ int run_bwd(const float* x, const float* dy, const csship_conv_weights& w, int B
   const float* z = fwd_ws;
   const int fwd_nblk = ((T + TT - 1) / TT) * B * 2;
   const float* stats = fwd_ws + n + (size_t)fwd_nblk * 2 * D + 4 * D;
-  float *dc = ws + L.dc, *dg = ws + L.dg, *part = ws + L.part;
+  float *dc = ws + L.dc, *dg = ws + L.dg, *part = ws + L.part, *part_c = ws + L.part_c;
   // grads layout (CSSHIP_CONV_GRADS_*): [bn_b D | bn_g D | pw2_w 1 | pw2_b 1 | pad 2][dw_w 33*D | dw_b D][ln_g D | ln_b D | pw1_w 2 | pw1_b 2]
   float* gA = grads;
   float* gB = grads + 2 * D + 4;
@@ -574,9 +576,9 @@ int run_bwd(const float* x, const float* dy, const csship_conv_weights& w, int B
   if (rc) return rc;
   // pass C
   hipLaunchKernelGGL((glu_ln_bwd_kernel<D / 256>), dim3(L.nwg_rows), dim3(256), 0, s, x, dg, dy, w.ln_g, w.ln_b, w.pw1_w,
-                     w.pw1_b, M, BWD_ROWS, dx, part);
+                     w.pw1_b, M, BWD_ROWS, dx, part_c);
   CSSHIP_CHECK_LAUNCH();
-  return launch_slab_reduce(part, L.nwg_rows, 2 * D + 4, 2 * D + 4, 2 * D + 4, 1.f, nullptr, nullptr, 0, gC, s);
+  return launch_slab_reduce(part_c, L.nwg_rows, 2 * D + 4, 2 * D + 4, 2 * D + 4, 1.f, nullptr, nullptr, 0, gC, s);
 }
 
 }  // namespace

@@ -1749,7 +1749,7 @@ extern "C" int csship_ffn_bwd_drop(const float* x, const float* dy, const float*
   hipLaunchKernelGGL((ffn_bwd_kernel<NWAVES>), dim3(nwg), dim3(NWAVES * 64), 0, as_stream(stream), a);
   CSSHIP_CHECK_LAUNCH();
   return launch_slab_reduce(reinterpret_cast<const float*>(workspace), nwg, 2 * DM, 2 * DM, 2 * DM, 1.f, nullptr, nullptr, 0,
-                            dgamma_dbeta, as_stream(stream));
+                            dgamma_dbeta, as_stream(stream), true);
 }
 
 extern "C" int csship_ffn_bwd(const float* x, const float* dy, const float* ln_g, const float* ln_b,

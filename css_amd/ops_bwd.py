@@ -15,8 +15,50 @@ from .ops import _need, _ptr, _stream
 _ws_cache = {}
 
 
-def _workspace(nbytes, dev):
-    """Scratch reused across calls on one stream (kernels on a stream run in order)."""
+_deferred_ws = []   # workspaces of the calls whose reductions are queued (csship_reduce_defer): alive until the flush
+_defer = {"on": False}
+_NO_DEFER = bool(os.environ.get("CSSHIP_NO_DEFER"))
+
+
+class deferred_reductions:
+    """``with deferred_reductions() as d: ... d.flush() ...``: inside, the slab reductions that produce PARAMETER gradients
+    out of SMALL slab sets (layernorm_bwd, ffn_bwd_fused: dgamma / dbeta partials) are queued and run as one launch per
+    ``flush()`` (include/csship.h, csship_reduce_defer).  Those calls get their own workspace, kept until the flush.  Nobody may read those gradients before the flush; the
+    exit flushes what is left (or drops it when an exception is travelling)."""
+
+    def __enter__(self):
+        if _NO_DEFER:   # A/B timing: every reduction as its own launch
+            self.was = 1
+            return self
+        self.was = lib().csship_reduce_defer(1)
+        _defer["on"] = True
+        return self
+
+    def flush(self):
+        if lib().csship_reduce_pending():
+            check(lib().csship_reduce_flush(_stream()))
+        _deferred_ws.clear()
+
+    def __exit__(self, et, ev, tb):
+        try:
+            if et is None:
+                self.flush()
+        finally:
+            if not self.was:
+                lib().csship_reduce_defer(0)
+                _defer["on"] = False
+                _deferred_ws.clear()
+        return False
+
+
+def _workspace(nbytes, dev, own=False):
+    """Scratch reused across calls on one stream (kernels on a stream run in order).  own: the call's reduction is one
+    of the deferrable ones - while reductions are deferred it gets a workspace of its own (the slabs live in it until
+    the flush)."""
+    if own and _defer["on"]:
+        t = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+        _deferred_ws.append(t)
+        return t
     key = (dev, torch.cuda.current_stream().cuda_stream)
     t = _ws_cache.get(key)
     if t is None or t.numel() < nbytes:
@@ -150,7 +192,7 @@ def layernorm_bwd(x, dy, gamma, beta, dx_add=None, relu=False, out=None):
     dx = torch.empty_like(x) if out is None else out
     gb = torch.empty((2, D), dtype=torch.float32, device=x.device)
     nws = lib().csship_layernorm_bwd_workspace(M, D)
-    ws = _workspace(nws, x.device)
+    ws = _workspace(nws, x.device, own=True)
     check(lib().csship_layernorm_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(beta), _ptr(dx_add), int(relu), M, D, _ptr(dx),
                                      _ptr(gb), _ptr(ws), nws, _stream()))
     return dx, gb[0], gb[1]
@@ -344,7 +386,7 @@ def ffn_bwd(x, dy, ln_g, ln_b, w1p, b1, w2tp, w1tp, d_ffn, alpha=0.5, drop_hidde
     dx = torch.empty_like(x)
     gb = torch.empty((2, D), dtype=torch.float32, device=dev)
     nws = lib().csship_ffn_bwd_workspace(M)
-    ws = _workspace(nws, dev)
+    ws = _workspace(nws, dev, own=True)
     dyd = torch.empty((M, D), dtype=torch.bfloat16, device=dev) if drop_out is not None else None
     check(lib().csship_ffn_bwd_drop(_ptr(x), _ptr(dy), _ptr(ln_g), _ptr(ln_b), _ptr(w1p), _ptr(b1), _ptr(w2tp), _ptr(w1tp),
                                     _ptr(a), _ptr(h), _ptr(dh), _ptr(dx), _ptr(gb), M, D, d_ffn, float(alpha), drop_hidden,

@@ -530,6 +530,19 @@ int csship_bgemm_wgrad(const void* dY, const void* X, float* dW, float* db, cons
                        const csship_bgemm_params* p, float alpha_head, int32_t head_rows, void* workspace,
                        size_t workspace_bytes, csship_stream_t stream);
 
+/* Deferred reductions of parameter gradients.  The backward kernels leave per-workgroup partial sums ("slabs") in their
+ * workspaces and sum them in a second, tiny launch at the ~5 us floor of a launch.  Between csship_reduce_defer(1) and
+ * csship_reduce_flush() the calling host thread's SMALL reductions whose outputs are parameter gradients (the dgamma /
+ * dbeta of csship_layernorm_bwd and csship_ffn_bwd_fused; at most 4 MB of slabs) are queued instead and run as ONE
+ * launch by the flush, with the summation order their own launches would have used (identical results).  Contract while
+ * deferring: every such call gets its OWN workspace, left untouched until the flush, and nobody reads those gradients
+ * before it.  The large reductions (weight-gradient products) always run at once: right behind their producer the slabs
+ * are still in the last-level cache.  csship_reduce_defer returns the previous mode; switching the mode off drops
+ * anything still queued (error paths).  csship_reduce_pending: queued jobs. */
+int csship_reduce_defer(int32_t on);
+int csship_reduce_pending(void);
+int csship_reduce_flush(csship_stream_t stream);
+
 /* out[c] = alpha * sum_r x[r, c] for x f32 or bf16 [M, N] (row stride ld): the bias gradient of a Linear. */
 size_t csship_colsum_workspace(int64_t M, int32_t N);
 int csship_colsum(const void* x, int32_t x_is_f32, int64_t M, int32_t N, int64_t ld, float alpha, float* out,

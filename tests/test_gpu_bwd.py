@@ -125,7 +125,10 @@ def test_linear_wgrad_fused_bias_gradient(ob, K, M, N, dy_f32, x_f32):
     x = rnd((K, N), 72).to(DEV) if x_f32 else rnd((K, N), 72).to(DEV).to(torch.bfloat16)
     dw, db = ob.linear_wgrad(dy, x, 0.5)
     dw_ref = ob.bgemm(dy, x, a_kmajor=True, b_kmajor=True, alpha=0.5)
-    assert torch.equal(dw, dw_ref)                       # the same kernel arithmetic, the same slab order
+    if dy_f32 or x_f32 or (M % 128) or (N % 128):
+        assert torch.equal(dw, dw_ref)                   # the same kernel arithmetic, the same slab order
+    else:  # bf16 operands in whole tiles take the LDS-DMA loop with its own slab count: same products, another summation order
+        assert relerr(dw, dw_ref.double().cpu()) < 1e-6
     db64 = 0.5 * dy.to(torch.bfloat16).double().sum(0)
     assert float((db.double() - db64).abs().max()) < 2e-5 * float(dy.float().abs().sum(0).max())
     # a head of output rows with its own factor (fused q | k | v projection)
@@ -407,3 +410,38 @@ def test_pack_weights_multi_matches_single_and_host_layout():
     assert torch.equal(tr, ops.pack_frag(ws[0].t().contiguous()))
     cat = torch.cat([qkv[0] * 0.125, qkv[1], qkv[2]], 0)
     assert torch.equal(shared_rm, cat.to(torch.bfloat16)) and torch.equal(shared_fr, ops.pack_frag(cat))
+
+
+def test_deferred_reductions_match_immediate(ob):
+    """csship_reduce_defer / csship_reduce_flush: the queued slab reductions (LayerNorm backward, fused FeedForward
+    backward: dgamma | dbeta partials) give bit for bit what their own launches give, several jobs in one flush; the
+    large ones (weight-gradient products) are never queued."""
+    K = 12800
+    xs = [rnd((K, 256), 5 + i).to(DEV) for i in range(3)]
+    dys = [rnd((K, 256), 15 + i).to(DEV) for i in range(3)]
+    g, b = rnd((256,), 7).to(DEV) + 1.0, rnd((256,), 8).to(DEV)
+    dyb, xb = rnd((K, 256), 80).to(DEV).to(torch.bfloat16), rnd((K, 1024), 90).to(DEV).to(torch.bfloat16)
+    want_ln = [ob.layernorm_bwd(x, dy, g, b) for x, dy in zip(xs, dys)]
+    want_w = ob.linear_wgrad(dyb, xb, 0.5)
+    with ob.deferred_reductions() as red:
+        got_ln = [ob.layernorm_bwd(x, dy, g, b) for x, dy in zip(xs, dys)]
+        assert _lib_pending() == 3
+        got_w = ob.linear_wgrad(dyb, xb, 0.5)
+        assert _lib_pending() == 3                       # 16 MB of slabs: reduced at once
+        assert torch.equal(got_w[0], want_w[0]) and torch.equal(got_w[1], want_w[1])
+        red.flush()
+        assert _lib_pending() == 0
+        for got, want in zip(got_ln, want_ln):
+            for a_, b_ in zip(got, want):
+                assert torch.equal(a_, b_)
+        again = ob.layernorm_bwd(xs[0], dys[0], g, b)   # left to the exit's flush
+    assert _lib_pending() == 0
+    for a_, b_ in zip(again, want_ln[0]):
+        assert torch.equal(a_, b_)
+    out = ob.layernorm_bwd(xs[1], dys[1], g, b)         # outside the scope: immediate again
+    assert _lib_pending() == 0 and torch.equal(out[1], want_ln[1][1])
+
+
+def _lib_pending():
+    from css_amd._lib import lib
+    return lib().csship_reduce_pending()

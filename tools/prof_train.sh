@@ -1,16 +1,21 @@
 #!/bin/bash
-# rocprofv3 kernel stats of the graphed Conformer training step (on the GPU box): per-step totals of the top kernels
+# kernel stats of the training step, twice on one box: default build and with the env given as $1 (e.g. CSSHIP_BGEMM_NOGLDS=1)
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-rm -rf gpurun_out/prof_train
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_train -- python tools/bench_train.py --graph > gpurun_out/pt.log 2>&1
-tail -1 gpurun_out/pt.log
-python - <<PY
-import csv, glob
-f = sorted(glob.glob("gpurun_out/prof_train/*/*kernel_stats.csv"))[-1]
-rows = list(csv.DictReader(open(f)))
+for leg in B A; do
+  rm -rf gpurun_out/pt_$leg
+  if [ $leg = A ] && [ -n "${1:-}" ]; then export "$1"; fi
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pt_$leg -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --mode train > gpurun_out/pt_$leg.log 2>&1
+  rc=$?; echo "leg $leg rc=$rc"
+  [ $rc -eq 124 ] || [ $rc -eq 137 ] && exit 1
+  f=$(ls gpurun_out/pt_$leg/*/*kernel_stats.csv | tail -1)
+  cp "$f" gpurun_out/pt_${leg}_kernel_stats.csv
+  python - "$f" <<PY
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-print("total ms/step", round(tot / 10 / 1e6, 2))
-for r in rows[:${1:-24}]:
+print("total ms", tot / 1e6)
+for r in rows[:22]:
     n = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
-    print(f"{float(r['TotalDurationNs'])/10/1e3:8.0f} us {int(r['Calls'])//10:4d} x {float(r['AverageNs'])/1e3:6.1f}  {n[:90]}")
+    print("%-110s %6d %9.1f us %5.1f%%" % (n[:110], int(r["Calls"]), float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
 PY
+done
