@@ -5,6 +5,8 @@ backward built from: the batched MFMA GEMM (csship_bgemm: dX = dY.W, dW = dY^T.X
 ReLU / softmax backward row kernels, and column sums for the biases.  Nothing in this file computes on the CPU and
 nothing falls back to torch arithmetic beyond gathers / scatters of parameter-sized tensors.
 """
+import os
+
 import torch
 
 from . import ops, ops_bwd as ob
@@ -63,6 +65,9 @@ def ffn_bwd_fused(x, dy, ln_g, ln_b, b1, w1p, w2tp, w1tp, d_ffn, alpha=0.5, drop
     return dx, (dg, dbeta, dw1, db1, dw2, db2)
 
 
+_SPLIT_ATTN_BWD = bool(os.environ.get("CSSHIP_ATTN_BWD_SPLIT"))   # A/B timing: probabilities / softmax backward / dS k as separate launches
+
+
 def relpos_window(pe_table_bf, T, maxlen):
     """rows of the relative-position table seen by a length-T sequence: window[r] = pe[clamp(r - (T-1)) + maxlen]
     (conformer.py:157-159,179-185), zero padded to a multiple of 8 rows.  Returns (window bf16 [W, d_k], index)."""
@@ -88,6 +93,13 @@ def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000, window=None, probs=
     win, idx = relpos_window(pe_table_bf, T, maxlen) if window is None else window
     W = win.shape[0]
     p_v = None              # operand of dV: the dropped probabilities when the forward dropped them (conformer.py:249)
+    do = dao.view(B, T, H, 64).permute(0, 2, 1, 3)
+    if probs is not None and ao is not None and not _SPLIT_ATTN_BWD:
+        # one pass over the scores: probabilities, softmax backward (row-major and skewed dS) and dS k
+        d = ob.attn_rowdot(dao, ao, B, T, H)
+        dsk = torch.zeros((B, T, H, W), dtype=BF, device=qkv.device) if skew_buf is None else skew_buf
+        p_v, ds, dsk, dq1 = ob.mha_bwd_core(qkv, probs[0], probs[1], dao, d, dsk, H, drop=drop_p)
+        return _mha_core_products(qkv, g, q, k, do, p_v, ds, dsk, dq1, win, idx, window, dwin_acc, maxlen)
     if probs is not None:   # (pe_pack, lse) from the training forward: one attention-shaped kernel recomputes P
         if drop_p is not None:
             p, p_v = ops.mha_relpos_probs(qkv, probs[0], probs[1], H, drop=drop_p)
@@ -97,7 +109,6 @@ def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000, window=None, probs=
         s = ob.bgemm(q, k)                               # q k^T            [B,H,T,T]
         rel = ob.bgemm(q, win[None, None])               # q pe_window^T    [B,H,T,W]
         p = ob.relpos_softmax(s, rel, T)                 # bf16 [B,H,T,Tp]
-    do = dao.view(B, T, H, 64).permute(0, 2, 1, 3)
     if ao is not None:      # attention-shaped softmax backward: no [B,H,T,T] f32 dP buffer
         d = ob.attn_rowdot(dao, ao, B, T, H)
         dsk = torch.zeros((B, T, H, W), dtype=BF, device=qkv.device) if skew_buf is None else skew_buf
@@ -105,11 +116,18 @@ def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000, window=None, probs=
     else:                   # generic route
         dp = ob.bgemm(do, v)                             # dO v^T           [B,H,T,T]
         ds, dsk = ob.relpos_softmax_bwd(p, dp, T, W)     # dS, and dS skewed onto the window axis [B,T,H,W]
+    dq1 = ob.bgemm(ds[..., :T], k, b_kmajor=True)                       # dS k
+    return _mha_core_products(qkv, g, q, k, do, p if p_v is None else p_v, ds, dsk, dq1, win, idx, window, dwin_acc, maxlen)
+
+
+def _mha_core_products(qkv, g, q, k, do, p_v, ds, dsk, dq1, win, idx, window, dwin_acc, maxlen):
+    """the batched GEMMs behind dS: dV = p_v^T dO, dK = dS^T q, dq = dS_skew pe_window + dq1, d(pe_window) = dS_skew^T q"""
+    B, T, _ = qkv.shape
+    H, W = g.shape[3], win.shape[0]
     dqkv = torch.empty_like(qkv)
     dq, dk, dv = (dqkv.view(B, T, 3, H, 64)[:, :, i].permute(0, 2, 1, 3) for i in range(3))
-    ob.bgemm((p if p_v is None else p_v)[..., :T], do, a_kmajor=True, b_kmajor=True, out=dv)      # dV = P^T dO
+    ob.bgemm(p_v[..., :T], do, a_kmajor=True, b_kmajor=True, out=dv)    # dV = P^T dO
     ob.bgemm(ds[..., :T], q, a_kmajor=True, b_kmajor=True, out=dk)      # dK = dS^T q
-    dq1 = ob.bgemm(ds[..., :T], k, b_kmajor=True)                       # dS k
     ob.bgemm(dsk.permute(0, 2, 1, 3), win[None, None], b_kmajor=True, add=dq1, out=dq)   # + dS_skew pe_window
     q_rows = g[:, :, 0].reshape(B * T * H, 64)                          # rows ordered (b, t, h) like dsk
     # [W, 64]; dwin_acc (the sum over the blocks already back-propagated) is added by the product's epilogue, in place

@@ -83,7 +83,13 @@ DEV int v_off(int row, int chunk) {  // 16-byte chunk of a 128-byte V row; 32-by
 #define A2_T(i)
 #endif
 constexpr int A2_KV = 64 * 128;   // one K (or V) tile in LDS
-constexpr int A2_PQ = 6 * 256;    // band scratch floats per wave: 1 KB pad | 4 key blocks x [16 queries][16 keys] | 1 KB pad
+// band scratch floats per wave: pad | 4 key blocks x [16 queries][A2_PS] | pad.  A query's 16 keys of a block sit in a row
+// of A2_PS = 20 floats: with 16 (64-byte rows) the skew's 40 single-float stores per tile hit every bank of their 32-lane
+// group twice (address = 17 n + 4 g + const: n and n + 4, g and g - 1 collide) - 0.76 conflict cycles per active LDS
+// cycle for the whole kernel (r03 PMC); 20 makes the stores conflict free and leaves the eight 16-byte loads two-way.
+constexpr int A2_PS = 20;
+constexpr int A2_PB = 16 * A2_PS;  // one key block of the scratch
+constexpr int A2_PQ = 6 * A2_PB;
 
 DEV float vmax(float a, float b) {  // bare v_max_f32 (fmaxf adds a canonicalising v_max per MFMA-produced operand)
   float d;
@@ -111,13 +117,29 @@ DEV float xmax16(float x) {  // max over the four 16-lane rows of the wave (same
 // PROBS (backward pass): the probabilities themselves, P = exp(score - lse) from the training forward's log-sum-exp, as
 // bf16 rows of `out` = [B, H, T, ldp] (and with DROP the masked, rescaled copy `pdrop`, the operand of dV) - no online
 // softmax, no P.V; same staging, band pipeline and tiling.
-template <int NW, bool DROP, bool PROBS = false>
+// BWD (with PROBS): the softmax backward and the first input gradient in the same pass, while the probabilities are in
+// registers - dP^T = V dO^T (the V tile is already staged), dS = P o (mask / (1 - p) o dP - D), dS out row-major and skewed
+// (as attn_ds_kernel, which read P back from memory), and dq1^T += K^T dS^T exactly as O^T += V^T P^T in the forward (K^T
+// fragments by transposing reads of the staged K tile).  Of the probabilities only the operand of dV is written (the
+// dropped ones with DROP).  One launch for four (probabilities, attn_rowdot's consumer attn_ds, dS k).
+struct MhaBwdArgs {
+  const unsigned short* dout;  // bf16 [B*T, H*64]
+  const float* dvec;           // f32 [B, H, T]: rowsum(dO o O)
+  unsigned short* ds;          // bf16 [B, H, T, ldp]
+  unsigned short* dsk;         // bf16 [B, T, H, W], zero outside the band (caller)
+  float* dq1;                  // f32 [B, H, T, 64] = dS k
+  int W;
+};
+
+template <int NW, bool DROP, bool PROBS = false, bool BWD = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mha_fwd_kernel(const unsigned short* __restrict__ qkv,
                                                             const bf16x8* __restrict__ pe_packed, int q_min, int q_max,
                                                             unsigned short* __restrict__ out, float* __restrict__ lse,
                                                             int BH, int T, int H, int G, int ppw,
                                                             unsigned long long* stamps, csship_dropout_cfg dcfg,
-                                                            unsigned short* __restrict__ pdrop = nullptr, int ldp = 0) {
+                                                            unsigned short* __restrict__ pdrop = nullptr, int ldp = 0,
+                                                            MhaBwdArgs bw = MhaBwdArgs{}) {
+  static_assert(!BWD || PROBS, "the backward pass recomputes the probabilities");
   constexpr int CH = 512 / (NW * 64);  // 16-byte chunks of a K (and of a V) tile staged per thread
   constexpr int R = 2 * NW + 8;        // ring slots (position blocks of 2 x 1 KB): 2 NW + 4 live + 4 arriving
   constexpr int NF = 8 / NW;           // new fragments staged per wave and tile
@@ -159,6 +181,22 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mha_fwd_kernel(const
     const unsigned short* qrow = qkv + (base_b + qi) * D3 + h * 64;
     qf[qb][0] = *reinterpret_cast<const bf16x8*>(qrow + 8 * g);
     qf[qb][1] = *reinterpret_cast<const bf16x8*>(qrow + 32 + 8 * g);
+  }
+
+  bf16x8 dof[2][2];   // BWD: dO rows of the two query blocks (B operand, like q), D of this lane's two queries
+  float dval[2] = {0.f, 0.f};
+  f32x4 dq[2][4];
+  if constexpr (BWD) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int qi = min(i0w + 16 * qb + n, T - 1);
+      const unsigned short* drow = bw.dout + (base_b + qi) * D + h * 64;
+      dof[qb][0] = *reinterpret_cast<const bf16x8*>(drow + 8 * g);
+      dof[qb][1] = *reinterpret_cast<const bf16x8*>(drow + 32 + 8 * g);
+      dval[qb] = bw.dvec[(size_t)bh * T + qi];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dq[qb][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   }
 
   // K/V staging: chunk idx = tid + c * NW*64 -> (row = idx >> 3, 16-byte chunk = idx & 7)
@@ -239,19 +277,19 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mha_fwd_kernel(const
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
   // Band scratch of this wave, laid out for the CONSUMER: query n's 64 values of a key tile as [key block tc][n][16],
-  // so lane (g, n) reads its accumulator registers of key block tc with one 16-byte load at tc*256 + 16 n + 4 g.
+  // so lane (g, n) reads its accumulator registers of key block tc with one 16-byte load at tc*A2_PB + A2_PS n + 4 g.
   // The producer (band tile t, lane (g, n), register r) holds relative offset c = 16 t + 4 g + r, which is key
-  // k = c - (15 - n) of the tile: it stores to (k >> 4) * 256 + 16 n + (k & 15) = base_r + 256 t with a per-lane,
+  // k = c - (15 - n) of the tile: it stores to (k >> 4) * A2_PB + A2_PS n + (k & 15) = base_r + A2_PB t with a per-lane,
   // per-register base that is fixed for the whole kernel.  Of the five band tiles exactly one of t = 0 / t = 4 falls
-  // outside the 64 keys for every (lane, r): those stores land in a 1-KB pad below / above the four key blocks.
-  float* const Pw = sP + w * A2_PQ + 256;
+  // outside the 64 keys for every (lane, r): those stores land in a pad block below / above the four key blocks.
+  float* const Pw = sP + w * A2_PQ + A2_PB;
   float* pwr[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int k0 = 4 * g + r + n - 15;  // key (may be negative) of band tile 0's value
-    pwr[r] = Pw + 16 * n + (k0 >= 0 ? k0 : k0 + 16 - 256);
+    pwr[r] = Pw + A2_PS * n + (k0 >= 0 ? k0 : k0 + 16 - A2_PB);
   }
-  const float* const prd = Pw + 16 * n + 4 * g;
+  const float* const prd = Pw + A2_PS * n + 4 * g;
   const int q4 = n >> 2, p4 = n & 3;
 
   // band of key tile J0 for both query blocks -> scratch -> s (the S^T accumulators' initial value).  One query block
@@ -279,8 +317,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mha_fwd_kernel(const
     _Pragma("unroll") for (int qb = 0; qb < 2; ++qb) {                                                                   \
       /* the skew is done by the STORE: each band value goes straight to the place its consumer's 16-byte read takes */ \
       _Pragma("unroll") for (int t = 0; t < 5; ++t)                                                                      \
-        _Pragma("unroll") for (int r = 0; r < 4; ++r) pwr[r][256 * t] = pb[qb][t][r];                                    \
-      _Pragma("unroll") for (int t = 0; t < 4; ++t) s[qb][t] = *reinterpret_cast<const f32x4*>(prd + 256 * t);           \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) pwr[r][A2_PB * t] = pb[qb][t][r];                                    \
+      _Pragma("unroll") for (int t = 0; t < 4; ++t) s[qb][t] = *reinterpret_cast<const f32x4*>(prd + A2_PB * t);          \
     }                                                                                                                    \
   }
 #define A2_BAND_WAIT() {}
@@ -349,6 +387,22 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mha_fwd_kernel(const
     if constexpr (PROBS) {
       // P = exp2(S log2e - lse log2e); a lane holds 4 consecutive keys of one query per key block: one 8-byte store each.
       // Keys in [T, ldp) come out as exact zeros (their scores were set to -1e30 above), columns >= ldp are not written.
+      f32x4 dpt[2][4];      // BWD: dP^T = V dO^T of the tile
+      bf16x8 dsb[2][2] = {};  // and dS^T as the B operand of dq1^T += K^T dS^T
+      if constexpr (BWD) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) dpt[qb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(vt + v_off(16 * t + n, ks * 4 + g));
+            dpt[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, dof[0][ks], dpt[0][t], 0, 0, 0);
+            dpt[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, dof[1][ks], dpt[1][t], 0, 0, 0);
+          }
+      }
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
         const int qi = i0w + 16 * qb + n;
@@ -358,12 +412,67 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mha_fwd_kernel(const
           float pv[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(s[qb][t][r] * LOG2E - lse2[qb]);
-          if (owner && qi < T && j0 + 16 * t + 4 * g + 3 < ldp) {
-            *reinterpret_cast<uint2*>(out + poff + 16 * t) = make_uint2(pack_bf2(pv[0], pv[1]), pack_bf2(pv[2], pv[3]));
-            if constexpr (DROP) {
-              const float4 pd = drop_apply4(dp, (unsigned)(poff + 16 * t), make_float4(pv[0], pv[1], pv[2], pv[3]));
-              *reinterpret_cast<uint2*>(pdrop + poff + 16 * t) = make_uint2(pack_bf2(pd.x, pd.y), pack_bf2(pd.z, pd.w));
+          const bool st = owner && qi < T && j0 + 16 * t + 4 * g + 3 < ldp;
+          if constexpr (!BWD) {
+            if (st) {
+              *reinterpret_cast<uint2*>(out + poff + 16 * t) = make_uint2(pack_bf2(pv[0], pv[1]), pack_bf2(pv[2], pv[3]));
+              if constexpr (DROP) {
+                const float4 pd = drop_apply4(dp, (unsigned)(poff + 16 * t), make_float4(pv[0], pv[1], pv[2], pv[3]));
+                *reinterpret_cast<uint2*>(pdrop + poff + 16 * t) = make_uint2(pack_bf2(pd.x, pd.y), pack_bf2(pd.z, pd.w));
+              }
             }
+          } else {
+            float4 dpv = make_float4(dpt[qb][t][0], dpt[qb][t][1], dpt[qb][t][2], dpt[qb][t][3]);
+            float4 pd = make_float4(pv[0], pv[1], pv[2], pv[3]);
+            if constexpr (DROP) {  // one mask for both: dP = mask / (1 - p) o (dO v^T), operand of dV = mask / (1 - p) o P
+              const unsigned e0 = (unsigned)(poff + 16 * t);
+              dpv = drop_apply4(dp, e0, dpv);
+              pd = drop_apply4(dp, e0, pd);
+            }
+            const unsigned short d0 = f2bf(pv[0] * (dpv.x - dval[qb])), d1 = f2bf(pv[1] * (dpv.y - dval[qb]));
+            const unsigned short d2 = f2bf(pv[2] * (dpv.z - dval[qb])), d3 = f2bf(pv[3] * (dpv.w - dval[qb]));
+            const uint2 dpk = make_uint2((unsigned)d0 | ((unsigned)d1 << 16), (unsigned)d2 | ((unsigned)d3 << 16));
+            {  // key j = 32 ks + 16 (e >> 2) + 4 g + (e & 3) <-> k index e of k-step ks = t >> 1 (as pbf in the forward)
+              typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+              u32x4 v = __builtin_bit_cast(u32x4, dsb[qb][t >> 1]);
+              v[(t & 1) * 2] = dpk.x;
+              v[(t & 1) * 2 + 1] = dpk.y;
+              dsb[qb][t >> 1] = __builtin_bit_cast(bf16x8, v);
+            }
+            if (st) {
+              *reinterpret_cast<uint2*>((DROP ? pdrop : out) + poff + 16 * t) = make_uint2(pack_bf2(pd.x, pd.y), pack_bf2(pd.z, pd.w));
+              *reinterpret_cast<uint2*>(bw.ds + poff + 16 * t) = dpk;
+              // skewed copy: keys j .. j+3 are positions r .. r-3 of the query's row of ds_skew, ONE 8-byte piece
+              // (d3 d2 d1 d0) that is only 2-byte aligned (attn_ds_kernel)
+              const int j = j0 + 16 * t + 4 * g;
+              unsigned short* skrow = bw.dsk + ((base_b + qi) * H + h) * (size_t)bw.W + (qi + T - 1);
+              if (j + 3 < T) {
+                struct __attribute__((packed, aligned(2))) h4u { unsigned short v[4]; };
+                h4u sk;
+                sk.v[0] = d3; sk.v[1] = d2; sk.v[2] = d1; sk.v[3] = d0;
+                *reinterpret_cast<h4u*>(skrow - j - 3) = sk;
+              } else {
+                if (j < T) skrow[-j] = d0;
+                if (j + 1 < T) skrow[-j - 1] = d1;
+                if (j + 2 < T) skrow[-j - 2] = d2;
+              }
+            }
+          }
+        }
+      }
+      if constexpr (BWD) {  // dq1^T += K^T dS^T: K^T fragments feed both query blocks (the forward's P.V with K for V)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int r0 = 32 * ks + 4 * g + q4, r1 = r0 + 16;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            const unsigned char* a0 = kt + tile_off(r0, 2 * dt + (p4 >> 1)) + (p4 & 1) * 8;
+            const unsigned char* a1 = kt + tile_off(r1, 2 * dt + (p4 >> 1)) + (p4 & 1) * 8;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a1));
+            const bf16x8 av = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            dq[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, dsb[0][ks], dq[0][dt], 0, 0, 0);
+            dq[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, dsb[1][ks], dq[1][dt], 0, 0, 0);
           }
         }
       }
@@ -486,6 +595,19 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mha_fwd_kernel(const
 #undef A2_STORE_RING
 
   stamp(stamps, 2);
+  if constexpr (BWD) {
+    if (owner) {
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        const int qi = i0w + 16 * qb + n;
+        if (qi < T) {
+          float* row = bw.dq1 + ((size_t)bh * T + qi) * 64 + 4 * g;  // dq1^T rows d = 16 dt + 4 g + r of column i = n
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(row + 16 * dt) = dq[qb][dt];
+        }
+      }
+    }
+  }
   if (!owner || PROBS) return;
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
@@ -555,6 +677,31 @@ static int launch_mha_probs(const uint16_t* qkv, const uint16_t* pe_packed, int 
   else if (dropping) A2_PROBS(8, true);
   else A2_PROBS(8, false);
 #undef A2_PROBS
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
+// probabilities + softmax backward + dS k in one pass (BWD)
+static int launch_mha_bwd(const uint16_t* qkv, const uint16_t* pe_packed, int q_min, int q_max, const float* lse,
+                          const MhaBwdArgs& bw, uint16_t* p_v, int64_t ldp, int B, int T, int H, hipStream_t s,
+                          const csship_dropout_cfg* drop) {
+  const int P = (T + 31) / 32, BH = B * H;
+  const int G8 = (P + 7) / 8, G4 = (P + 3) / 4;
+  const bool four = (BH * G8 <= 128) && (G4 > G8);
+  const int G = four ? G4 : G8, ppw = (P + G - 1) / G;
+  const long long nwg = (long long)BH * G;
+  if (nwg > 0x7fffffffLL || ldp > 0x7fffffffLL) return CSSHIP_EBADSHAPE;
+  const bool dropping = drop != nullptr && drop->seed != nullptr && drop->p > 0.f;
+  if ((int64_t)BH * T * ldp > 0xffffffffLL && dropping) return CSSHIP_EBADSHAPE;  // 32-bit element indices of the mask
+  const csship_dropout_cfg dc = dropping ? *drop : csship_dropout_cfg{nullptr, 0u, 0.f};
+  const bf16x8* pe = reinterpret_cast<const bf16x8*>(pe_packed);
+  float* lse_ = const_cast<float*>(lse);
+#define A2_BWD(NWV, DR) hipLaunchKernelGGL((mha_fwd_kernel<NWV, DR, true, true>), dim3((unsigned)nwg), dim3(NWV * 64), 0, s, qkv, pe,                                            q_min, q_max, p_v, lse_, BH, T, H, G, ppw, nullptr, dc, p_v, (int)ldp, bw)
+  if (four && dropping) A2_BWD(4, true);
+  else if (four) A2_BWD(4, false);
+  else if (dropping) A2_BWD(8, true);
+  else A2_BWD(8, false);
+#undef A2_BWD
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }
@@ -705,6 +852,22 @@ extern "C" int csship_mha_relpos_probs_drop(const uint16_t* qkv, const uint16_t*
   if (!aligned16(qkv) || !aligned16(pe_packed) || !aligned8(p_bf16) || (ld_p % 4) != 0) return CSSHIP_EALIGN;
   return launch_mha_probs(qkv, pe_packed, q_min, q_max, lse, p_bf16, dropping ? p_dropped_bf16 : nullptr, ld_p, B, T, H,
                           as_stream(stream), drop);
+}
+
+extern "C" int csship_mha_relpos_bwd_core(const uint16_t* qkv, const uint16_t* pe_packed, int32_t q_min, int32_t q_max,
+                                          const float* lse, const uint16_t* d_out, const float* d, uint16_t* p_v_bf16,
+                                          uint16_t* ds_bf16, uint16_t* ds_skew_bf16, float* dq1, int64_t ld_p, int32_t W,
+                                          int32_t B, int32_t T, int32_t H, const csship_dropout_cfg* drop,
+                                          csship_stream_t stream) {
+  if (!qkv || !pe_packed || !lse || !d_out || !d || !p_v_bf16 || !ds_bf16 || !ds_skew_bf16 || !dq1) return CSSHIP_ENULL;
+  if (B <= 0 || T <= 0 || H <= 0 || q_max < q_min || B > 65535 || H > 65535 || ld_p < T || (ld_p & 3) || W < 2 * T - 1)
+    return CSSHIP_EBADSHAPE;
+  if (drop && drop->seed && drop->p > 0.f && ld_p != (T + 7) / 8 * 8) return CSSHIP_EBADSHAPE;
+  if (!aligned16(qkv) || !aligned16(pe_packed) || !aligned16(d_out) || !aligned8(p_v_bf16) || !aligned8(ds_bf16) ||
+      !aligned16(dq1))
+    return CSSHIP_EALIGN;
+  const MhaBwdArgs bw{d_out, d, ds_bf16, ds_skew_bf16, dq1, W};
+  return launch_mha_bwd(qkv, pe_packed, q_min, q_max, lse, bw, p_v_bf16, ld_p, B, T, H, as_stream(stream), drop);
 }
 
 extern "C" int csship_attn_softmax_bwd(const uint16_t* qkv, const uint16_t* d_out, const uint16_t* p_bf16, int64_t ld_p,

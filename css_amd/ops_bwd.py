@@ -402,6 +402,26 @@ def attn_rowdot(d_out, out, B, T, H):
     return d
 
 
+def mha_bwd_core(qkv, pe_pack, lse, d_out, d, skew, n_head, drop=None):
+    """Probabilities, softmax backward and dS k in one pass (csship_mha_relpos_bwd_core) -> (p_v, dS, skew, dq1):
+    p_v bf16 [B,H,T,pad8(T)] the operand of dV (the dropped probabilities with a dropout cfg), dS bf16 alike, skew
+    bf16 [B,T,H,W] filled in place inside the band, dq1 f32 [B,H,T,64] = dS k."""
+    _need(qkv, torch.bfloat16, "qkv"), _need(lse, torch.float32, "lse"), _need(d_out, torch.bfloat16, "d_out")
+    _need(d, torch.float32, "d"), _need(skew, torch.bfloat16, "skew")
+    packed, q_min, q_max = pe_pack
+    B, T, D3 = qkv.shape
+    if not (qkv.is_contiguous() and d_out.is_contiguous() and lse.is_contiguous() and d.is_contiguous() and skew.is_contiguous()) \
+            or D3 != 3 * n_head * 64 or skew.shape[:3] != (B, T, n_head):
+        raise RuntimeError("css_amd: mha_bwd_core expects dense qkv [B,T,3*H*64], d_out [B*T,H*64], skew [B,T,H,W]")
+    ldp = (T + 7) // 8 * 8
+    p_v = torch.empty(B, n_head, T, ldp, device=qkv.device, dtype=torch.bfloat16)
+    ds = torch.empty_like(p_v)
+    dq1 = torch.empty(B, n_head, T, 64, device=qkv.device, dtype=torch.float32)
+    check(lib().csship_mha_relpos_bwd_core(_ptr(qkv), _ptr(packed), q_min, q_max, _ptr(lse), _ptr(d_out), _ptr(d), _ptr(p_v),
+                                           _ptr(ds), _ptr(skew), _ptr(dq1), ldp, skew.shape[3], B, T, n_head, drop, _stream()))
+    return p_v, ds, skew, dq1
+
+
 def attn_softmax_bwd(qkv, d_out, p, d, skew, n_head, drop=None):
     """dS = P o (dO v^T - D) -> (dS bf16 like p, skew) ; skew: bf16 [B,T,H,W], zero outside the band, filled in place."""
     _need(qkv, torch.bfloat16, "qkv"), _need(p, torch.bfloat16, "p")

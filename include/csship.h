@@ -603,6 +603,19 @@ int csship_attn_softmax_bwd_drop(const uint16_t* qkv, const uint16_t* d_out, con
                                  const float* d, uint16_t* ds_bf16, uint16_t* ds_skew_bf16, int32_t W, int32_t B,
                                  int32_t T, int32_t H, const csship_dropout_cfg* drop, csship_stream_t stream);
 
+/* csship_mha_relpos_bwd_core: csship_mha_relpos_probs(_drop) + csship_attn_softmax_bwd(_drop) + the product dS k in ONE
+ * pass over the scores (the probabilities never make a round trip through memory on their way to dS):
+ *   p_v_bf16  [B,H,T,ld_p] = the operand of dV = p_v^T dO (the probabilities; with dropout mask / (1 - p) o P),
+ *   ds_bf16   [B,H,T,ld_p] = dS = P o (mask / (1 - p) o (dO v^T) - d),  ds_skew_bf16 [B,T,H,W] its skewed copy
+ *   (csship_relpos_softmax_bwd; zero outside the band: the caller zeroes the buffer once),
+ *   dq1       f32 [B,H,T,64] = dS k (the key part of the query gradient).
+ * d_out bf16 [B*T, H*64]; d f32 [B,H,T] (csship_attn_rowdot); lse from csship_mha_relpos_train(_drop); drop may be NULL;
+ * with dropout ld_p must be pad8(T) (the mask's element index, as in the forward). */
+int csship_mha_relpos_bwd_core(const uint16_t* qkv, const uint16_t* pe_packed, int32_t q_min, int32_t q_max,
+                               const float* lse, const uint16_t* d_out, const float* d, uint16_t* p_v_bf16,
+                               uint16_t* ds_bf16, uint16_t* ds_skew_bf16, float* dq1, int64_t ld_p, int32_t W,
+                               int32_t B, int32_t T, int32_t H, const csship_dropout_cfg* drop, csship_stream_t stream);
+
 /* csship_attn_softmax_bwd: dS[b,h,i,j] = P[i,j] * (dO_i . v_j - d[b,h,i]) computed attention-shaped (V tiles in LDS,
  * dO rows as MFMA operand), no [B,H,T,T] f32 intermediate.  qkv as in csship_mha_relpos; d_out bf16 [B*T, H*64];
  * p_bf16 / ds_bf16: [B,H,T,ld_p]; d: f32 [B,H,T] (csship_attn_rowdot); ds_skew_bf16 [B,T,H,W] as in

@@ -445,3 +445,43 @@ def test_deferred_reductions_match_immediate(ob):
 def _lib_pending():
     from css_amd._lib import lib
     return lib().csship_reduce_pending()
+
+
+@pytest.mark.parametrize("B,T,H,p_drop", [(2, 400, 4, 0.0), (2, 400, 4, 0.1), (3, 77, 2, 0.0), (1, 150, 4, 0.1), (32, 400, 4, 0.1)])
+def test_attention_backward_core_one_pass(ob, B, T, H, p_drop):
+    """csship_mha_relpos_bwd_core (probabilities + softmax backward + dS k in one pass) against the three launches it
+    replaces: the dV operand bit for bit; dS within a bf16 rounding of P (the fused pass multiplies by the unrounded
+    probability); the skewed copy is exactly the fused dS moved onto the window axis; dq1 = (fused dS) k."""
+    from css_amd import ops
+    from css_amd.dropout import DropState
+    D = H * 64
+    qkv = rnd((B, T, 3 * D), 60, 0.5).to(DEV).to(torch.bfloat16)
+    pe = rnd((2000, 64), 61, 0.3).to(DEV)
+    pe_pack = ops.pack_relpos(pe, 1000)
+    dao = rnd((B * T, D), 62, 0.2).to(DEV).to(torch.bfloat16)
+    cfg = None
+    if p_drop > 0:
+        ds_ = DropState(torch.tensor([1234], dtype=torch.int32, device=DEV), p_drop, 0)
+        cfg = ds_.cfg("0.attn.p")
+    ao, lse = ops.mha_relpos_train(qkv, pe_pack, H, drop=cfg)
+    d = ob.attn_rowdot(dao, ao.view(B * T, D), B, T, H)
+    W = (2 * T - 1 + 7) // 8 * 8
+    if cfg is not None:
+        p, p_v0 = ops.mha_relpos_probs(qkv, pe_pack, lse, H, drop=cfg)
+    else:
+        p = p_v0 = ops.mha_relpos_probs(qkv, pe_pack, lse, H)
+    ds0, sk0 = ob.attn_softmax_bwd(qkv, dao, p, d, torch.zeros((B, T, H, W), dtype=torch.bfloat16, device=DEV), H, drop=cfg)
+    p_v, ds, sk, dq1 = ob.mha_bwd_core(qkv, pe_pack, lse, dao, d, torch.zeros((B, T, H, W), dtype=torch.bfloat16, device=DEV), H, drop=cfg)
+    assert torch.equal(p_v, p_v0)
+    a, b_ = ds.float(), ds0.float()
+    assert float((a - b_).abs().max()) <= 2.0 ** -7 * float(b_.abs().max()) and froerr(a, b_.cpu()) < 4e-3
+    # the skew: ds_skew[b, i, h, i - j + T - 1] = dS[b, h, i, j]
+    i = torch.arange(T, device=DEV)
+    r = (i[:, None] - i[None, :] + T - 1)                                # [i, j]
+    want = torch.zeros_like(sk)
+    want[:, i[:, None].expand(T, T), :, r] = ds[..., :T].permute(2, 3, 0, 1)     # [i, j, B, H]
+    assert torch.equal(sk, want)
+    g = qkv.view(B, T, 3, H, 64)
+    k = g[:, :, 1].permute(0, 2, 1, 3)
+    ref = ds[..., :T].float().cpu().double() @ k.float().cpu().double()
+    assert relerr(dq1, ref) < 2e-5
