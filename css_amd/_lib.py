@@ -157,7 +157,7 @@ SIGNATURES = {
     "csship_mha_relpos_train_drop": (_i32, [_p, _p, _i32, _i32, _p, _p, _i32, _i32, _i32, _dc, _p]),
     "csship_mha_relpos_probs_drop": (_i32, [_p, _p, _i32, _i32, _p, _p, _p, _i64, _i32, _i32, _i32, _dc, _p]),
     "csship_attn_softmax_bwd_drop": (_i32, [_p, _p, _p, _i64, _p, _p, _p, _i32, _i32, _i32, _i32, _dc, _p]),
-    "csship_mha_relpos_bwd_core": (_i32, [_p, _p, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _dc, _p]),
+    "csship_mha_relpos_bwd_core": (_i32, [_p, _p, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _dc, _p]),
     "csship_convmod_drop": (_i32, [_p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _i32, _p, _dc, _p]),
     "csship_convmod_sums_offset": (_sz, [_i32, _i32, _i32]),
     "csship_convmod_stats": (_i32, [_p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _p, _p]),

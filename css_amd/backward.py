@@ -96,10 +96,10 @@ def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000, window=None, probs=
     do = dao.view(B, T, H, 64).permute(0, 2, 1, 3)
     if probs is not None and ao is not None and not _SPLIT_ATTN_BWD:
         # one pass over the scores: probabilities, softmax backward (row-major and skewed dS) and dS k
-        d = ob.attn_rowdot(dao, ao, B, T, H)
         dsk = torch.zeros((B, T, H, W), dtype=BF, device=qkv.device) if skew_buf is None else skew_buf
-        p_v, ds, dsk, dq1 = ob.mha_bwd_core(qkv, probs[0], probs[1], dao, d, dsk, H, drop=drop_p)
-        return _mha_core_products(qkv, g, q, k, do, p_v, ds, dsk, dq1, win, idx, window, dwin_acc, maxlen)
+        p_v, ds, dsk, dq1, q_rows = ob.mha_bwd_core(qkv, probs[0], probs[1], dao, None, dsk, H, drop=drop_p,
+                                                    out=ao.reshape(B * T, H * 64), want_q_rows=True)
+        return _mha_core_products(qkv, g, q, k, do, p_v, ds, dsk, dq1, win, idx, window, dwin_acc, maxlen, q_rows)
     if probs is not None:   # (pe_pack, lse) from the training forward: one attention-shaped kernel recomputes P
         if drop_p is not None:
             p, p_v = ops.mha_relpos_probs(qkv, probs[0], probs[1], H, drop=drop_p)
@@ -120,7 +120,7 @@ def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000, window=None, probs=
     return _mha_core_products(qkv, g, q, k, do, p if p_v is None else p_v, ds, dsk, dq1, win, idx, window, dwin_acc, maxlen)
 
 
-def _mha_core_products(qkv, g, q, k, do, p_v, ds, dsk, dq1, win, idx, window, dwin_acc, maxlen):
+def _mha_core_products(qkv, g, q, k, do, p_v, ds, dsk, dq1, win, idx, window, dwin_acc, maxlen, q_rows=None):
     """the batched GEMMs behind dS: dV = p_v^T dO, dK = dS^T q, dq = dS_skew pe_window + dq1, d(pe_window) = dS_skew^T q"""
     B, T, _ = qkv.shape
     H, W = g.shape[3], win.shape[0]
@@ -129,7 +129,8 @@ def _mha_core_products(qkv, g, q, k, do, p_v, ds, dsk, dq1, win, idx, window, dw
     ob.bgemm(p_v[..., :T], do, a_kmajor=True, b_kmajor=True, out=dv)    # dV = P^T dO
     ob.bgemm(ds[..., :T], q, a_kmajor=True, b_kmajor=True, out=dk)      # dK = dS^T q
     ob.bgemm(dsk.permute(0, 2, 1, 3), win[None, None], b_kmajor=True, add=dq1, out=dq)   # + dS_skew pe_window
-    q_rows = g[:, :, 0].reshape(B * T * H, 64)                          # rows ordered (b, t, h) like dsk
+    if q_rows is None:
+        q_rows = g[:, :, 0].reshape(B * T * H, 64)                      # rows ordered (b, t, h) like dsk
     # [W, 64]; dwin_acc (the sum over the blocks already back-propagated) is added by the product's epilogue, in place
     dwin = ob.bgemm(dsk.view(B * T * H, W), q_rows, a_kmajor=True, b_kmajor=True, add=dwin_acc, out=dwin_acc)
     if window is not None:

@@ -129,6 +129,8 @@ struct MhaBwdArgs {
   unsigned short* dsk;         // bf16 [B, T, H, W], zero outside the band (caller)
   float* dq1;                  // f32 [B, H, T, 64] = dS k
   int W;
+  const unsigned short* ao;    // bf16 [B*T, H*64]: the forward's output; non-null: D is computed here (dvec unused)
+  unsigned short* q_rows;      // optional bf16 [B*T*H, 64]: the q rows in ds_skew's row order (operand of d(pe_window))
 };
 
 template <int NW, bool DROP, bool PROBS = false, bool BWD = false>
@@ -193,7 +195,23 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mha_fwd_kernel(const
       const unsigned short* drow = bw.dout + (base_b + qi) * D + h * 64;
       dof[qb][0] = *reinterpret_cast<const bf16x8*>(drow + 8 * g);
       dof[qb][1] = *reinterpret_cast<const bf16x8*>(drow + 32 + 8 * g);
-      dval[qb] = bw.dvec[(size_t)bh * T + qi];
+      if (bw.ao != nullptr) {  // D = dO . O over the 64 features of the head: 16 per lane, then the four lanes of the query
+        const unsigned short* orow = bw.ao + (base_b + qi) * D + h * 64;
+        const bf16x8 o0 = *reinterpret_cast<const bf16x8*>(orow + 8 * g), o1 = *reinterpret_cast<const bf16x8*>(orow + 32 + 8 * g);
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += (float)dof[qb][0][e] * (float)o0[e] + (float)dof[qb][1][e] * (float)o1[e];
+        acc += __shfl_xor(acc, 16);
+        acc += __shfl_xor(acc, 32);
+        dval[qb] = acc;
+      } else {
+        dval[qb] = bw.dvec[(size_t)bh * T + qi];
+      }
+      if (bw.q_rows != nullptr && owner && i0w + 16 * qb + n < T) {
+        unsigned short* qr = bw.q_rows + ((base_b + qi) * H + h) * 64;
+        *reinterpret_cast<bf16x8*>(qr + 8 * g) = qf[qb][0];
+        *reinterpret_cast<bf16x8*>(qr + 32 + 8 * g) = qf[qb][1];
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) dq[qb][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -855,18 +873,19 @@ extern "C" int csship_mha_relpos_probs_drop(const uint16_t* qkv, const uint16_t*
 }
 
 extern "C" int csship_mha_relpos_bwd_core(const uint16_t* qkv, const uint16_t* pe_packed, int32_t q_min, int32_t q_max,
-                                          const float* lse, const uint16_t* d_out, const float* d, uint16_t* p_v_bf16,
-                                          uint16_t* ds_bf16, uint16_t* ds_skew_bf16, float* dq1, int64_t ld_p, int32_t W,
-                                          int32_t B, int32_t T, int32_t H, const csship_dropout_cfg* drop,
-                                          csship_stream_t stream) {
-  if (!qkv || !pe_packed || !lse || !d_out || !d || !p_v_bf16 || !ds_bf16 || !ds_skew_bf16 || !dq1) return CSSHIP_ENULL;
+                                          const float* lse, const uint16_t* d_out, const float* d, const uint16_t* out,
+                                          uint16_t* p_v_bf16, uint16_t* ds_bf16, uint16_t* ds_skew_bf16, float* dq1,
+                                          uint16_t* q_rows, int64_t ld_p, int32_t W, int32_t B, int32_t T, int32_t H,
+                                          const csship_dropout_cfg* drop, csship_stream_t stream) {
+  if (!qkv || !pe_packed || !lse || !d_out || (!d && !out) || !p_v_bf16 || !ds_bf16 || !ds_skew_bf16 || !dq1) return CSSHIP_ENULL;
   if (B <= 0 || T <= 0 || H <= 0 || q_max < q_min || B > 65535 || H > 65535 || ld_p < T || (ld_p & 3) || W < 2 * T - 1)
     return CSSHIP_EBADSHAPE;
   if (drop && drop->seed && drop->p > 0.f && ld_p != (T + 7) / 8 * 8) return CSSHIP_EBADSHAPE;
   if (!aligned16(qkv) || !aligned16(pe_packed) || !aligned16(d_out) || !aligned8(p_v_bf16) || !aligned8(ds_bf16) ||
       !aligned16(dq1))
     return CSSHIP_EALIGN;
-  const MhaBwdArgs bw{d_out, d, ds_bf16, ds_skew_bf16, dq1, W};
+  if ((out && !aligned16(out)) || (q_rows && !aligned16(q_rows))) return CSSHIP_EALIGN;
+  const MhaBwdArgs bw{d_out, d, ds_bf16, ds_skew_bf16, dq1, W, out, q_rows};
   return launch_mha_bwd(qkv, pe_packed, q_min, q_max, lse, bw, p_v_bf16, ld_p, B, T, H, as_stream(stream), drop);
 }
 

@@ -402,24 +402,35 @@ def attn_rowdot(d_out, out, B, T, H):
     return d
 
 
-def mha_bwd_core(qkv, pe_pack, lse, d_out, d, skew, n_head, drop=None):
-    """Probabilities, softmax backward and dS k in one pass (csship_mha_relpos_bwd_core) -> (p_v, dS, skew, dq1):
+def mha_bwd_core(qkv, pe_pack, lse, d_out, d, skew, n_head, drop=None, out=None, want_q_rows=False):
+    """Probabilities, softmax backward and dS k in one pass (csship_mha_relpos_bwd_core) -> (p_v, dS, skew, dq1[, q_rows]):
     p_v bf16 [B,H,T,pad8(T)] the operand of dV (the dropped probabilities with a dropout cfg), dS bf16 alike, skew
-    bf16 [B,T,H,W] filled in place inside the band, dq1 f32 [B,H,T,64] = dS k."""
+    bf16 [B,T,H,W] filled in place inside the band, dq1 f32 [B,H,T,64] = dS k.  d = rowsum(dO o O) f32 [B,H,T]
+    (attn_rowdot), or None with ``out`` = the forward's output bf16 [B*T, H*64]: the pass computes it.  want_q_rows:
+    also the q rows as bf16 [B*T*H, 64] in skew's row order."""
     _need(qkv, torch.bfloat16, "qkv"), _need(lse, torch.float32, "lse"), _need(d_out, torch.bfloat16, "d_out")
-    _need(d, torch.float32, "d"), _need(skew, torch.bfloat16, "skew")
+    _need(skew, torch.bfloat16, "skew")
+    if d is not None:
+        _need(d, torch.float32, "d")
+    elif out is None:
+        raise RuntimeError("css_amd: mha_bwd_core needs d or the forward's output")
+    else:
+        _need(out, torch.bfloat16, "out")
     packed, q_min, q_max = pe_pack
     B, T, D3 = qkv.shape
-    if not (qkv.is_contiguous() and d_out.is_contiguous() and lse.is_contiguous() and d.is_contiguous() and skew.is_contiguous()) \
+    if not (qkv.is_contiguous() and d_out.is_contiguous() and lse.is_contiguous() and skew.is_contiguous()) \
+            or (d is not None and not d.is_contiguous()) or (out is not None and not out.is_contiguous()) \
             or D3 != 3 * n_head * 64 or skew.shape[:3] != (B, T, n_head):
         raise RuntimeError("css_amd: mha_bwd_core expects dense qkv [B,T,3*H*64], d_out [B*T,H*64], skew [B,T,H,W]")
     ldp = (T + 7) // 8 * 8
     p_v = torch.empty(B, n_head, T, ldp, device=qkv.device, dtype=torch.bfloat16)
     ds = torch.empty_like(p_v)
     dq1 = torch.empty(B, n_head, T, 64, device=qkv.device, dtype=torch.float32)
-    check(lib().csship_mha_relpos_bwd_core(_ptr(qkv), _ptr(packed), q_min, q_max, _ptr(lse), _ptr(d_out), _ptr(d), _ptr(p_v),
-                                           _ptr(ds), _ptr(skew), _ptr(dq1), ldp, skew.shape[3], B, T, n_head, drop, _stream()))
-    return p_v, ds, skew, dq1
+    q_rows = torch.empty(B * T * n_head, 64, device=qkv.device, dtype=torch.bfloat16) if want_q_rows else None
+    check(lib().csship_mha_relpos_bwd_core(_ptr(qkv), _ptr(packed), q_min, q_max, _ptr(lse), _ptr(d_out), _ptr(d),
+                                           _ptr(out) if d is None else None, _ptr(p_v), _ptr(ds), _ptr(skew), _ptr(dq1),
+                                           _ptr(q_rows), ldp, skew.shape[3], B, T, n_head, drop, _stream()))
+    return (p_v, ds, skew, dq1, q_rows) if want_q_rows else (p_v, ds, skew, dq1)
 
 
 def attn_softmax_bwd(qkv, d_out, p, d, skew, n_head, drop=None):

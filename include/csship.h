@@ -609,12 +609,16 @@ int csship_attn_softmax_bwd_drop(const uint16_t* qkv, const uint16_t* d_out, con
  *   ds_bf16   [B,H,T,ld_p] = dS = P o (mask / (1 - p) o (dO v^T) - d),  ds_skew_bf16 [B,T,H,W] its skewed copy
  *   (csship_relpos_softmax_bwd; zero outside the band: the caller zeroes the buffer once),
  *   dq1       f32 [B,H,T,64] = dS k (the key part of the query gradient).
- * d_out bf16 [B*T, H*64]; d f32 [B,H,T] (csship_attn_rowdot); lse from csship_mha_relpos_train(_drop); drop may be NULL;
- * with dropout ld_p must be pad8(T) (the mask's element index, as in the forward). */
+ * d_out bf16 [B*T, H*64]; d f32 [B,H,T] = rowsum(dO o O) (csship_attn_rowdot) - or NULL with out = the forward's
+ * output bf16 [B*T, H*64], from which the pass computes it itself; q_rows (optional) bf16 [B*T*H, 64] receives the q
+ * rows in ds_skew's row order (b, t, h), the second operand of d(pe_window) = ds_skew^T q; lse from
+ * csship_mha_relpos_train(_drop); drop may be NULL; with dropout ld_p must be pad8(T) (the mask's element index, as in
+ * the forward). */
 int csship_mha_relpos_bwd_core(const uint16_t* qkv, const uint16_t* pe_packed, int32_t q_min, int32_t q_max,
-                               const float* lse, const uint16_t* d_out, const float* d, uint16_t* p_v_bf16,
-                               uint16_t* ds_bf16, uint16_t* ds_skew_bf16, float* dq1, int64_t ld_p, int32_t W,
-                               int32_t B, int32_t T, int32_t H, const csship_dropout_cfg* drop, csship_stream_t stream);
+                               const float* lse, const uint16_t* d_out, const float* d, const uint16_t* out,
+                               uint16_t* p_v_bf16, uint16_t* ds_bf16, uint16_t* ds_skew_bf16, float* dq1, uint16_t* q_rows,
+                               int64_t ld_p, int32_t W, int32_t B, int32_t T, int32_t H, const csship_dropout_cfg* drop,
+                               csship_stream_t stream);
 
 /* csship_attn_softmax_bwd: dS[b,h,i,j] = P[i,j] * (dO_i . v_j - d[b,h,i]) computed attention-shaped (V tiles in LDS,
  * dO rows as MFMA operand), no [B,H,T,T] f32 intermediate.  qkv as in csship_mha_relpos; d_out bf16 [B*T, H*64];

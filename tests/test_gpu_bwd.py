@@ -473,6 +473,12 @@ def test_attention_backward_core_one_pass(ob, B, T, H, p_drop):
     ds0, sk0 = ob.attn_softmax_bwd(qkv, dao, p, d, torch.zeros((B, T, H, W), dtype=torch.bfloat16, device=DEV), H, drop=cfg)
     p_v, ds, sk, dq1 = ob.mha_bwd_core(qkv, pe_pack, lse, dao, d, torch.zeros((B, T, H, W), dtype=torch.bfloat16, device=DEV), H, drop=cfg)
     assert torch.equal(p_v, p_v0)
+    # D computed by the pass itself from the forward's output, and the q rows in the skewed buffer's row order
+    p_v2, ds2, _, dq2, q_rows = ob.mha_bwd_core(qkv, pe_pack, lse, dao, None, torch.zeros((B, T, H, W), dtype=torch.bfloat16, device=DEV),
+                                                H, drop=cfg, out=ao.view(B * T, D), want_q_rows=True)
+    assert torch.equal(p_v2, p_v) and torch.equal(q_rows, qkv.view(B, T, 3, H, 64)[:, :, 0].reshape(B * T * H, 64))
+    assert float((ds2.float() - ds.float()).abs().max()) <= 2.0 ** -7 * float(ds.float().abs().max()) and froerr(ds2.float(), ds.float().cpu()) < 2e-3
+    assert relerr(dq2, dq1.double().cpu()) < 5e-3
     a, b_ = ds.float(), ds0.float()
     assert float((a - b_).abs().max()) <= 2.0 ** -7 * float(b_.abs().max()) and froerr(a, b_.cpu()) < 4e-3
     # the skew: ds_skew[b, i, h, i - j + T - 1] = dS[b, h, i, j]
