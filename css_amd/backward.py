@@ -65,6 +65,7 @@ def ffn_bwd_fused(x, dy, ln_g, ln_b, b1, w1p, w2tp, w1tp, d_ffn, alpha=0.5, drop
     return dx, (dg, dbeta, dw1, db1, dw2, db2)
 
 
+_NO_LN_Y = bool(os.environ.get("CSSHIP_NO_LN_Y"))   # A/B timing: LayerNorm(x) for the q/k/v weight gradient by its own launch
 _SPLIT_ATTN_BWD = bool(os.environ.get("CSSHIP_ATTN_BWD_SPLIT"))   # A/B timing: probabilities / softmax backward / dS k as separate launches
 
 
@@ -158,12 +159,16 @@ def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_s
     dqkv, dpe = mha_core_bwd(qkv, dao, pe_table_bf, n_head, window=window, probs=probs, dwin_acc=dwin_acc,
                              ao=ao if fused_softmax_bwd else None, skew_buf=skew_buf, drop_p=drop_p)
     dq2 = dqkv.view(-1, 3 * D)
-    a, _ = ops.layernorm(x, ln_g, ln_b)
     dw = torch.empty((3 * D, D), dtype=torch.float32, device=x.device)
     db = torch.empty(3 * D, dtype=torch.float32, device=x.device)
-    ob.linear_wgrad(dq2, a, 1.0, dw_out=dw, db_out=db, head=(D, q_scale))   # q rows carry the projection's 1/sqrt(d_k)
     da = ob.bgemm(dq2, wqkv_bf, b_kmajor=True)
-    dx, dg, dbeta = ob.layernorm_bwd(x, da, ln_g, ln_b, dx_add=dy)
+    # the LayerNorm backward recomputes the normalised rows: it also hands back a = LayerNorm(x), the projection's input
+    if D in (256, 512, 1024) and not _NO_LN_Y:
+        dx, dg, dbeta, a = ob.layernorm_bwd(x, da, ln_g, ln_b, dx_add=dy, want_y=True)
+    else:
+        dx, dg, dbeta = ob.layernorm_bwd(x, da, ln_g, ln_b, dx_add=dy)
+        a, _ = ops.layernorm(x, ln_g, ln_b)
+    ob.linear_wgrad(dq2, a, 1.0, dw_out=dw, db_out=db, head=(D, q_scale))   # q rows carry the projection's 1/sqrt(d_k)
     return dx, (dg, dbeta, dw, db, dwo, dbo, dpe)
 
 

@@ -12,7 +12,8 @@ template <int VPL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      const float* dx_add, int relu, int64_t M, int rows_per_wg,
-                                                     float* dx, float* __restrict__ part) {
+                                                     float* dx, float* __restrict__ part,
+                                                     unsigned short* __restrict__ ybf = nullptr) {
   constexpr int D = 256 * VPL;
   __shared__ float red[4][2 * D];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -45,6 +46,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       v[i].x *= rstd; v[i].y *= rstd; v[i].z *= rstd; v[i].w *= rstd;  // xhat
+      if (ybf != nullptr)  // the LayerNorm's output itself, bf16: the second operand of the weight gradient behind it
+        *reinterpret_cast<uint2*>(ybf + row * D + (i * 64 + lane) * 4) =
+            make_uint2(pack_bf2(v[i].x * gm[i].x + bt[i].x, v[i].y * gm[i].y + bt[i].y),
+                       pack_bf2(v[i].z * gm[i].z + bt[i].z, v[i].w * gm[i].w + bt[i].w));
       if (relu) {
         if (!(v[i].x * gm[i].x + bt[i].x > 0.f)) d[i].x = 0.f;
         if (!(v[i].y * gm[i].y + bt[i].y > 0.f)) d[i].y = 0.f;
@@ -333,7 +338,16 @@ extern "C" int csship_layernorm_bwd(const float* x, const float* dy, const float
                                     const float* dx_add, int32_t relu, int64_t M, int32_t D, float* dx,
                                     float* dgamma_dbeta, void* workspace, size_t workspace_bytes,
                                     csship_stream_t stream) {
+  return csship_layernorm_bwd_y(x, dy, gamma, beta, dx_add, relu, M, D, dx, dgamma_dbeta, nullptr, workspace, workspace_bytes,
+                                stream);
+}
+
+extern "C" int csship_layernorm_bwd_y(const float* x, const float* dy, const float* gamma, const float* beta,
+                                      const float* dx_add, int32_t relu, int64_t M, int32_t D, float* dx,
+                                      float* dgamma_dbeta, uint16_t* y_bf16, void* workspace, size_t workspace_bytes,
+                                      csship_stream_t stream) {
   if (!x || !dy || !gamma || !beta || !dx || !dgamma_dbeta || !workspace) return CSSHIP_ENULL;
+  if (y_bf16 && (!(D == 256 || D == 512 || D == 1024) || !aligned8(y_bf16))) return CSSHIP_EUNSUPPORTED;
   if (M <= 0) return CSSHIP_EBADSHAPE;
   if (D <= 0 || D > 1024) return CSSHIP_EUNSUPPORTED;
   const bool fast = D == 256 || D == 512 || D == 1024;
@@ -348,11 +362,11 @@ extern "C" int csship_layernorm_bwd(const float* x, const float* dy, const float
     hipLaunchKernelGGL(ln_bwd_any_kernel, dim3(nwg), dim3(256), (size_t)8 * D * sizeof(float), s, x, dy, gamma, beta, dx_add,
                        relu, M, D, LNB_ROWS, dx, part);
   else if (D == 256)
-    hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(nwg), dim3(256), 0, s, x, dy, gamma, beta, dx_add, relu, M, LNB_ROWS, dx, part);
+    hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(nwg), dim3(256), 0, s, x, dy, gamma, beta, dx_add, relu, M, LNB_ROWS, dx, part, y_bf16);
   else if (D == 512)
-    hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(nwg), dim3(256), 0, s, x, dy, gamma, beta, dx_add, relu, M, LNB_ROWS, dx, part);
+    hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(nwg), dim3(256), 0, s, x, dy, gamma, beta, dx_add, relu, M, LNB_ROWS, dx, part, y_bf16);
   else
-    hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nwg), dim3(256), 0, s, x, dy, gamma, beta, dx_add, relu, M, LNB_ROWS, dx, part);
+    hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nwg), dim3(256), 0, s, x, dy, gamma, beta, dx_add, relu, M, LNB_ROWS, dx, part, y_bf16);
   CSSHIP_CHECK_LAUNCH();
   return launch_slab_reduce(part, nwg, 2 * (int64_t)D, 2 * D, 2 * (int64_t)D, 1.f, nullptr, nullptr, 0, dgamma_dbeta, s, true);
 }

@@ -183,8 +183,9 @@ def colsum(x, alpha=1.0, out=None):
     return out
 
 
-def layernorm_bwd(x, dy, gamma, beta, dx_add=None, relu=False, out=None):
-    """Backward of y = LayerNorm(x) [-> ReLU]: returns (dx (+ dx_add), dgamma, dbeta).  x, dy: f32 [M, D] dense."""
+def layernorm_bwd(x, dy, gamma, beta, dx_add=None, relu=False, out=None, want_y=False):
+    """Backward of y = LayerNorm(x) [-> ReLU]: returns (dx (+ dx_add), dgamma, dbeta).  x, dy: f32 [M, D] dense.
+    want_y: also LayerNorm(x) as bf16 [M, D] (the pass recomputes the normalised rows anyway)."""
     _need(x, torch.float32, "x"), _need(dy, torch.float32, "dy")
     M, D = x.shape
     if not (x.is_contiguous() and dy.is_contiguous()) or dy.shape != x.shape:
@@ -193,9 +194,10 @@ def layernorm_bwd(x, dy, gamma, beta, dx_add=None, relu=False, out=None):
     gb = torch.empty((2, D), dtype=torch.float32, device=x.device)
     nws = lib().csship_layernorm_bwd_workspace(M, D)
     ws = _workspace(nws, x.device, own=True)
-    check(lib().csship_layernorm_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(beta), _ptr(dx_add), int(relu), M, D, _ptr(dx),
-                                     _ptr(gb), _ptr(ws), nws, _stream()))
-    return dx, gb[0], gb[1]
+    y = torch.empty((M, D), dtype=torch.bfloat16, device=x.device) if want_y else None
+    check(lib().csship_layernorm_bwd_y(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(beta), _ptr(dx_add), int(relu), M, D, _ptr(dx),
+                                       _ptr(gb), _ptr(y), _ptr(ws), nws, _stream()))
+    return (dx, gb[0], gb[1], y) if want_y else (dx, gb[0], gb[1])
 
 
 def relu_bwd(dy, y, out=None):

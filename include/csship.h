@@ -636,6 +636,13 @@ size_t csship_layernorm_bwd_workspace(int64_t M, int32_t D);
 int csship_layernorm_bwd(const float* x, const float* dy, const float* gamma, const float* beta,
                          const float* dx_add, int32_t relu, int64_t M, int32_t D, float* dx,
                          float* dgamma_dbeta, void* workspace, size_t workspace_bytes, csship_stream_t stream);
+/* csship_layernorm_bwd_y: the same, and y_bf16 (optional, bf16 [M, D], D = 256 / 512 / 1024) receives LayerNorm(x) itself
+ * (before the ReLU): the backward of "LayerNorm -> Linear" needs it as the second operand of the Linear's weight
+ * gradient, and this pass has just recomputed the normalised rows. */
+int csship_layernorm_bwd_y(const float* x, const float* dy, const float* gamma, const float* beta,
+                           const float* dx_add, int32_t relu, int64_t M, int32_t D, float* dx,
+                           float* dgamma_dbeta, uint16_t* y_bf16, void* workspace, size_t workspace_bytes,
+                           csship_stream_t stream);
 /* out = dy where y > 0, else 0 (mask head ReLU, conformer.py:99); 2-D with row strides; out may alias dy. */
 int csship_relu_bwd(const float* dy, int64_t ld_dy, const float* y, int64_t ld_y, int64_t M, int32_t N,
                     float* out, int64_t ld_out, csship_stream_t stream);

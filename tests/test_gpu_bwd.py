@@ -168,6 +168,12 @@ def test_layernorm_bwd_and_relu_bwd(ob):
                                       dx_add=add.to(DEV), relu=relu)
         assert relerr(dx, xr.grad + add.double()) < 2e-5
         assert relerr(dg, gr.grad) < 2e-5 and relerr(db, br.grad) < 2e-5
+        # the pass also hands back LayerNorm(x) (before the ReLU) as bf16: same dx / dgamma / dbeta, y within a bf16 rounding
+        dx2, dg2, db2, yb = ob.layernorm_bwd(x.float().to(DEV), dy.float().to(DEV), g.float().to(DEV), b.float().to(DEV),
+                                             dx_add=add.to(DEV), relu=relu, want_y=True)
+        assert torch.equal(dx2, dx) and torch.equal(dg2, dg) and torch.equal(db2, db)
+        yref = torch.nn.functional.layer_norm(x, (D,), g, b, 1e-5)
+        assert float((yb.double().cpu() - yref).abs().max()) <= 2.0 ** -8 * float(yref.abs().max()) + 1e-6
     y = rnd((50, 771), 16)
     dyy = rnd((50, 772), 17).to(DEV)[:, :771]
     got = ob.relu_bwd(dyy, y.to(DEV))
