@@ -12,12 +12,15 @@ Forward values ALWAYS come from the HIP kernels.  Backward:
     NotImplementedError: there is no torch-op arithmetic path in this package (the fp32 autograd references the tests
     compare against live in oracle/ and tests/).
 """
+import os
+
 import torch
 
 from . import backward as bw, ops, ops_bwd as ob
 from .dropout import DropState, model_drop_state
 
 BF = torch.bfloat16
+_NO_DROP_EPI = bool(os.environ.get("CSSHIP_NO_DROP_EPI"))   # A/B timing: output-projection dropout as its own pass
 
 
 def _deliver(model, G):
@@ -204,7 +207,9 @@ class ConformerTrain(torch.autograd.Function):
                                        ln=(a.layer_norm.weight.detach(), a.layer_norm.bias.detach()), out_bf16=True)
             ao, lse = ops.mha_relpos_train(qkv.view(B, T, 3 * D), pe_pack, H, drop=ds.cfg(f"{li}.attn.p"))
             ao = ao.view(M, D)
-            if ds.active:   # x2 = x1 + D(ao wo^T + bo): the projection without its fused residual, then one add pass
+            if ds.active and not wide and not _NO_DROP_EPI:   # x2 = x1 + D(ao wo^T + bo): the mask in the projection's epilogue
+                x2 = ops.panel_linear(ao, wo_p, a.linear_out.bias.detach(), D, residual=x1, drop=ds.cfg(f"{li}.attn.out"))
+            elif ds.active:   # the projection without its fused residual, then one add pass
                 y2 = ops.gemm(ao, wo_bf, a.linear_out.bias.detach()) if wide else \
                     ops.panel_linear(ao, wo_p, a.linear_out.bias.detach(), D)
                 x2 = ops.dropout_add(x1, y2, ds.cfg(f"{li}.attn.out"))

@@ -564,6 +564,11 @@ struct LinArgs {
   //   g = glu(LayerNorm_conv(out_row))   (css/models/conformer.py:291-293)
   const float *cln_g, *cln_b, *pw1_w, *pw1_b;
   float* g_out;
+  // optional dropout of the projection's output in front of the residual add (training: x + D(a W^T + b),
+  // conformer.py:254), f32 output rows of N columns; element index row * N + column as csship_dropout_add
+  const unsigned* dseed;
+  unsigned dstream;
+  float dp;
 };
 
 template <int NW, int PRO, int EPI>
@@ -592,6 +597,8 @@ __global__ __launch_bounds__(NW * 64) void panel_linear_kernel(LinArgs a) {
   const int r = tid >> 3, part = tid & 7;
   const int row = m0 + r;
   const bool vec_ok = OBF ? ((a.ldo & 7) == 0) : ((a.ldo & 3) == 0);
+  Drop dd{0u, 0u, 1.f};
+  if constexpr (RES && !OBF) dd = drop_make(a.dseed, a.dstream, a.dp);
 
   for (int p = 0; p < npass; ++p) {
     const int tile0 = p * 16 + wave * NT;
@@ -647,6 +654,7 @@ __global__ __launch_bounds__(NW * 64) void panel_linear_kernel(LinArgs a) {
               float4 y = *reinterpret_cast<const float4*>(Ys + r * YS + c);
               if constexpr (RES) {
                 const float4 x0 = *reinterpret_cast<const float4*>(a.res + (size_t)row * a.ldr + f0 + c);
+                y = drop_apply4(dd, (unsigned)((size_t)row * a.N + f0 + c), y);
                 y = make_float4(x0.x + a.alpha * y.x, x0.y + a.alpha * y.y, x0.z + a.alpha * y.z, x0.w + a.alpha * y.w);
               }
               *reinterpret_cast<float4*>(o + c) = y;
@@ -1766,7 +1774,19 @@ extern "C" int csship_panel_linear(const void* a, int32_t prologue, const float*
                                    const uint16_t* w_packed, const float* bias, const float* residual, int64_t ldr,
                                    float alpha, void* out, int64_t ldo, int32_t M, int32_t N, int32_t d_model,
                                    int32_t epilogue, csship_stream_t stream) {
+  return csship_panel_linear_drop(a, prologue, ln_g, ln_b, w_packed, bias, residual, ldr, alpha, out, ldo, M, N, d_model,
+                                  epilogue, nullptr, stream);
+}
+
+extern "C" int csship_panel_linear_drop(const void* a, int32_t prologue, const float* ln_g, const float* ln_b,
+                                        const uint16_t* w_packed, const float* bias, const float* residual, int64_t ldr,
+                                        float alpha, void* out, int64_t ldo, int32_t M, int32_t N, int32_t d_model,
+                                        int32_t epilogue, const csship_dropout_cfg* drop, csship_stream_t stream) {
   if (!a || !w_packed || !out) return CSSHIP_ENULL;
+  const bool dropping = drop != nullptr && drop->seed != nullptr && drop->p > 0.f;
+  // the mask lives in the vector form of the f32 residual epilogue: whole 4-column groups, 16-byte aligned output rows
+  if (dropping && (epilogue != CSSHIP_EPI_RESIDUAL || (N & 3) != 0 || (ldo & 3) != 0 || (int64_t)M * N > 0xffffffffLL))
+    return CSSHIP_EUNSUPPORTED;
   if (M <= 0 || N <= 0 || ldo < N) return CSSHIP_EBADSHAPE;
   if (d_model != DM) return CSSHIP_EUNSUPPORTED;
   if (!aligned16(a) || !aligned16(w_packed) || !aligned16(out)) return CSSHIP_EALIGN;
@@ -1774,7 +1794,8 @@ extern "C" int csship_panel_linear(const void* a, int32_t prologue, const float*
   if ((epilogue & CSSHIP_EPI_RESIDUAL) && (!residual || !aligned16(residual) || (ldr & 3) != 0 || ldr < N || (N & 3) != 0))
     return CSSHIP_EALIGN;
   LinArgs la{a, ln_g, ln_b, reinterpret_cast<const bf16x8*>(w_packed), bias, residual, out, M, N, ldo, ldr, alpha,
-             g_csship_stamps, nullptr, nullptr, nullptr, nullptr, nullptr};
+             g_csship_stamps, nullptr, nullptr, nullptr, nullptr, nullptr,
+             dropping ? drop->seed : nullptr, dropping ? drop->stream : 0u, dropping ? drop->p : 0.f};
   hipStream_t s = as_stream(stream);
   const int key = prologue * 16 + epilogue;
   switch (key) {

@@ -632,8 +632,9 @@ def dropout_mask(n, cfg, device="cuda"):
     return keep
 
 
-def panel_linear(a, wp, bias, N, *, ln=None, relu=False, residual=None, alpha=1.0, out_bf16=False, out=None):
-    """out[M,N] = epi(pro(a)[M,256] @ W^T + bias); a: f32 (LN if ln given, else rounded) or bf16 [M,256]."""
+def panel_linear(a, wp, bias, N, *, ln=None, relu=False, residual=None, alpha=1.0, out_bf16=False, out=None, drop=None):
+    """out[M,N] = epi(pro(a)[M,256] @ W^T + bias); a: f32 (LN if ln given, else rounded) or bf16 [M,256].
+    drop (with residual, f32 output): out = residual + alpha * dropout(a W^T + bias), masks as dropout_add's."""
     assert a.dim() == 2 and a.is_contiguous() and a.shape[1] == 256
     M = a.shape[0]
     if a.dtype == torch.bfloat16:
@@ -645,10 +646,10 @@ def panel_linear(a, wp, bias, N, *, ln=None, relu=False, residual=None, alpha=1.
           (_lib.EPI_OUT_BF16 if out_bf16 else 0)
     if out is None:
         out = torch.empty(M, N, device=a.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
-    check(lib().csship_panel_linear(_ptr(a), pro, _ptr(ln[0]) if ln else None, _ptr(ln[1]) if ln else None,
-                                    _ptr(wp), _ptr(bias), _ptr(residual),
-                                    residual.stride(0) if residual is not None else 0, alpha, _ptr(out),
-                                    out.stride(0), M, N, 256, epi, _stream()))
+    check(lib().csship_panel_linear_drop(_ptr(a), pro, _ptr(ln[0]) if ln else None, _ptr(ln[1]) if ln else None,
+                                         _ptr(wp), _ptr(bias), _ptr(residual),
+                                         residual.stride(0) if residual is not None else 0, alpha, _ptr(out),
+                                         out.stride(0), M, N, 256, epi, drop, _stream()))
     return out
 
 

@@ -270,6 +270,13 @@ int csship_panel_linear(const void* a, int32_t prologue, const float* ln_g, cons
                         const uint16_t* w_packed, const float* bias, const float* residual,
                         int64_t ldr, float alpha, void* out, int64_t ldo, int32_t M, int32_t N,
                         int32_t d_model, int32_t epilogue, csship_stream_t stream);
+/* The same with dropout of the projection's output in front of the residual add (training: x + D(a W^T + b),
+ * conformer.py:254): out = residual + alpha * mask / (1 - p) o (a W^T + b), element index row * N + column as
+ * csship_dropout_add.  With a dropout cfg: epilogue == CSSHIP_EPI_RESIDUAL, N % 4 == 0, ldo % 4 == 0.  NULL = none. */
+int csship_panel_linear_drop(const void* a, int32_t prologue, const float* ln_g, const float* ln_b,
+                             const uint16_t* w_packed, const float* bias, const float* residual,
+                             int64_t ldr, float alpha, void* out, int64_t ldo, int32_t M, int32_t N,
+                             int32_t d_model, int32_t epilogue, const csship_dropout_cfg* drop, csship_stream_t stream);
 
 /* csship_outproj_glu: attention output projection + residual, and the front half of the conv module on the
  * fresh row:  x_out = x + attn_out @ Wo^T + bo  (conformer.py:254,356);  g_out = glu(LayerNorm_conv(x_out))

@@ -519,3 +519,24 @@ def test_wide_row_panel_linears(ops, D, M):
     out2 = ops.linear_res_wide(d(a).to(torch.bfloat16), d(wo), d(bo), d(res))
     ref2 = res.double() + a.double() @ bf(wo).double().t() + bo.double()
     assert err(out2, ref2) < 2e-4
+
+
+@pytest.mark.gpu
+def test_panel_linear_dropout_epilogue():
+    """csship_panel_linear_drop: x + D(a W^T + b) with the mask applied in the projection's epilogue == the projection
+    followed by csship_dropout_add (same element indices, same arithmetic order: bit for bit)."""
+    from css_amd import ops
+    from css_amd.dropout import DropState
+    torch.manual_seed(3)
+    M, D = 12800, 256
+    a = torch.randn(M, D, device="cuda").to(torch.bfloat16)
+    w = torch.randn(D, D, device="cuda") * 0.05
+    b = torch.randn(D, device="cuda") * 0.1
+    x = torch.randn(M, D, device="cuda")
+    wp = ops.pack_frag(w)
+    cfg = DropState(torch.tensor([77], dtype=torch.int32, device="cuda"), 0.1, 0).cfg("3.attn.out")
+    want = ops.dropout_add(x, ops.panel_linear(a, wp, b, D), cfg)
+    got = ops.panel_linear(a, wp, b, D, residual=x, drop=cfg)
+    assert torch.equal(got, want)
+    assert float((got == x).float().mean()) > 0.05          # about one element in ten is dropped
+    assert torch.equal(ops.panel_linear(a, wp, b, D, residual=x), x + ops.panel_linear(a, wp, b, D))
