@@ -154,6 +154,7 @@ SIGNATURES = {
     "csship_dropout_add": (_i32, [_p, _p, _p, _f32, _i64, _i32, _dc, _p]),
     "csship_dropout_mask": (_i32, [_p, _i64, _dc, _p]),
     "csship_ffn_fused_drop": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _dc, _dc, _p]),
+    "csship_ffn_fused_train": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _dc, _dc, _p]),
     "csship_ffn_bwd_drop": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _dc, _dc, _p,
                                     _p, _sz, _p]),
     "csship_mha_relpos_train_drop": (_i32, [_p, _p, _i32, _i32, _p, _p, _i32, _i32, _i32, _dc, _p]),

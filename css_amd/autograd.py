@@ -20,6 +20,7 @@ from . import backward as bw, ops, ops_bwd as ob
 from .dropout import DropState, model_drop_state
 
 BF = torch.bfloat16
+_NO_FFN_LN = bool(os.environ.get("CSSHIP_NO_FFN_LN"))       # A/B timing: the block's final LayerNorm as its own launch
 _NO_DROP_EPI = bool(os.environ.get("CSSHIP_NO_DROP_EPI"))   # A/B timing: output-projection dropout as its own pass
 
 
@@ -178,7 +179,7 @@ class ConformerTrain(torch.autograd.Function):
         for li, (lay, wp) in enumerate(zip(enc.encoders, pack["layers"])):
             L = {}
 
-            def ffn(m, xin, tag):
+            def ffn(m, xin, tag, final_ln=None):
                 dh, do = ds.cfg(f"{li}.{tag}.hidden"), ds.cfg(f"{li}.{tag}.out")
                 if wide:  # LayerNorm -> tiled GEMM (ReLU, bf16) -> tiled GEMM (+ residual)
                     w1_bf, w2_bf = wp[tag]
@@ -192,7 +193,8 @@ class ConformerTrain(torch.autograd.Function):
                 w1p, w2p, w2tp, w1tp = wp[tag]
                 L[tag] = (xin, w1p, w2tp, w1tp)
                 return ops.ffn_fused(xin, (m.layer_norm.weight.detach(), m.layer_norm.bias.detach()), w1p,
-                                     m.net[0].bias.detach(), w2p, m.net[3].bias.detach(), FF, 0.5, drop_hidden=dh, drop_out=do)
+                                     m.net[0].bias.detach(), w2p, m.net[3].bias.detach(), FF, 0.5, drop_hidden=dh, drop_out=do,
+                                     final_ln=final_ln, want_pre_ln=final_ln is not None)
 
             x1 = ffn(lay.feed_forward_in, x, "ffn_in")
             a = lay.self_attn
@@ -233,9 +235,13 @@ class ConformerTrain(torch.autograd.Function):
                 stats = fws.view(torch.float32)[-4 * D:]
                 bn_means.append(c.BN.running_mean), bn_vars.append(c.BN.running_var)
                 bn_new_m.append(stats[2 * D:3 * D]), bn_new_v.append(stats[3 * D:])
-            x4 = ffn(lay.feed_forward_out, x3, "ffn_out")
-            _, x = ops.layernorm(x4, lay.layer_norm.weight.detach(), lay.layer_norm.bias.detach(), out_bf16=False,
-                                 out_f32=True)
+            if wide or _NO_FFN_LN:
+                x4 = ffn(lay.feed_forward_out, x3, "ffn_out")
+                _, x = ops.layernorm(x4, lay.layer_norm.weight.detach(), lay.layer_norm.bias.detach(), out_bf16=False,
+                                     out_f32=True)
+            else:   # the block's LayerNorm in the FeedForward's row epilogue; the backward needs the rows in front of it too
+                x4, x = ffn(lay.feed_forward_out, x3, "ffn_out",
+                            final_ln=(lay.layer_norm.weight.detach(), lay.layer_norm.bias.detach()))
             L["x4"] = x4
             S["layers"].append(L)
         if bn_means:  # BatchNorm1d bookkeeping for all blocks at once (momentum 0.1, unbiased running variance)

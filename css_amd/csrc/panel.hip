@@ -200,6 +200,7 @@ struct FfnArgs {
   float alpha;
   unsigned long long* stamps;
   csship_dropout_cfg drop_h, drop_o;  // training: dropout of the hidden activation [M, FF] and of the output [M, 256]
+  float* pre_out;  // optional, with the final LayerNorm: the rows in front of it (the backward's saved input)
 };
 
 template <int NW, bool FINAL_LN>
@@ -296,6 +297,10 @@ __global__ __launch_bounds__(NW * 64) void ffn_kernel(FfnArgs a) {
     v[i] = make_float4(xr[i].x + a.alpha * y.x, xr[i].y + a.alpha * y.y, xr[i].z + a.alpha * y.z, xr[i].w + a.alpha * y.w);
   }
   if constexpr (FINAL_LN) {
+    if (a.pre_out != nullptr && row < a.M) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(a.pre_out + (size_t)row * DM + (i * 8 + part) * 4) = v[i];
+    }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
@@ -1682,7 +1687,17 @@ extern "C" int csship_ffn_fused_drop(const float* x, float* out, const float* ln
                                      const float* b2, const float* final_ln_g, const float* final_ln_b, int32_t M,
                                      int32_t d_model, int32_t d_ffn, float alpha, const csship_dropout_cfg* drop_hidden,
                                      const csship_dropout_cfg* drop_out, csship_stream_t stream) {
+  return csship_ffn_fused_train(x, out, nullptr, ln_g, ln_b, w1_packed, b1, w2_packed, b2, final_ln_g, final_ln_b, M, d_model,
+                                d_ffn, alpha, drop_hidden, drop_out, stream);
+}
+
+extern "C" int csship_ffn_fused_train(const float* x, float* out, float* pre_ln_out, const float* ln_g, const float* ln_b,
+                                      const uint16_t* w1_packed, const float* b1, const uint16_t* w2_packed,
+                                      const float* b2, const float* final_ln_g, const float* final_ln_b, int32_t M,
+                                      int32_t d_model, int32_t d_ffn, float alpha, const csship_dropout_cfg* drop_hidden,
+                                      const csship_dropout_cfg* drop_out, csship_stream_t stream) {
   if (!x || !out || !ln_g || !ln_b || !w1_packed || !b1 || !w2_packed || !b2) return CSSHIP_ENULL;
+  if (pre_ln_out && (!final_ln_g || !aligned16(pre_ln_out) || pre_ln_out == out)) return CSSHIP_EBADSHAPE;
   if ((final_ln_g == nullptr) != (final_ln_b == nullptr)) return CSSHIP_ENULL;
   if (M <= 0) return CSSHIP_EBADSHAPE;
   if (d_model != DM || d_ffn <= 0 || (d_ffn % DM) != 0) return CSSHIP_EUNSUPPORTED;
@@ -1693,7 +1708,7 @@ extern "C" int csship_ffn_fused_drop(const float* x, float* out, const float* ln
   const csship_dropout_cfg none{nullptr, 0u, 0.f};
   FfnArgs a{x, out, ln_g, ln_b, reinterpret_cast<const bf16x8*>(w1_packed), b1,
             reinterpret_cast<const bf16x8*>(w2_packed), b2, final_ln_g, final_ln_b, M, d_ffn, alpha, g_csship_stamps,
-            drop_hidden ? *drop_hidden : none, drop_out ? *drop_out : none};
+            drop_hidden ? *drop_hidden : none, drop_out ? *drop_out : none, pre_ln_out};
   dim3 grid((M + BM - 1) / BM), block(NWAVES * 64);
   if (final_ln_g) hipLaunchKernelGGL((ffn_kernel<NWAVES, true>), grid, block, 0, as_stream(stream), a);
   else hipLaunchKernelGGL((ffn_kernel<NWAVES, false>), grid, block, 0, as_stream(stream), a);

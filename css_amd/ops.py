@@ -589,19 +589,22 @@ def ffn_mx(x, ln, w1mx, b1, w2mx, b2, d_ffn, alpha=0.5, final_ln=None, out=None)
     return out
 
 
-def ffn_fused(x, ln, w1p, b1, w2p, b2, d_ffn, alpha=0.5, final_ln=None, out=None, drop_hidden=None, drop_out=None):
+def ffn_fused(x, ln, w1p, b1, w2p, b2, d_ffn, alpha=0.5, final_ln=None, out=None, drop_hidden=None, drop_out=None,
+              want_pre_ln=False):
     """out = x + alpha * FFN(LN(x)) [-> LN]; x f32 [M,256]; w1p/w2p from pack_frag.  drop_hidden / drop_out: dropout cfg
-    pointers (css_amd.dropout.DropState.cfg) of the training forward, None = no dropout."""
+    pointers (css_amd.dropout.DropState.cfg) of the training forward, None = no dropout.  want_pre_ln (with final_ln):
+    returns (rows in front of the final LayerNorm, out) - the training forward keeps both."""
     _need(x, torch.float32, "x")
     assert x.dim() == 2 and x.is_contiguous()
     M, D = x.shape
     if out is None:
         out = torch.empty_like(x)
-    check(lib().csship_ffn_fused_drop(_ptr(x), _ptr(out), _ptr(ln[0]), _ptr(ln[1]), _ptr(w1p), _ptr(b1), _ptr(w2p),
-                                      _ptr(b2), _ptr(final_ln[0]) if final_ln else None,
-                                      _ptr(final_ln[1]) if final_ln else None, M, D, d_ffn, alpha, drop_hidden, drop_out,
-                                      _stream()))
-    return out
+    pre = torch.empty_like(x) if want_pre_ln else None
+    check(lib().csship_ffn_fused_train(_ptr(x), _ptr(out), _ptr(pre), _ptr(ln[0]), _ptr(ln[1]), _ptr(w1p), _ptr(b1), _ptr(w2p),
+                                       _ptr(b2), _ptr(final_ln[0]) if final_ln else None,
+                                       _ptr(final_ln[1]) if final_ln else None, M, D, d_ffn, alpha, drop_hidden, drop_out,
+                                       _stream()))
+    return (pre, out) if want_pre_ln else out
 
 
 def dropout_apply(x, cfg, out=None):

@@ -260,6 +260,15 @@ int csship_ffn_fused_drop(const float* x, float* out, const float* ln_g, const f
                           int32_t M, int32_t d_model, int32_t d_ffn, float alpha,
                           const csship_dropout_cfg* drop_hidden, const csship_dropout_cfg* drop_out,
                           csship_stream_t stream);
+/* The same; with the final LayerNorm, pre_ln_out (optional, f32 [M, 256], != out) also receives the rows in front of it:
+ * the block's last FeedForward and the block's LayerNorm (conformer.py:360-361) as one launch in the training forward,
+ * whose backward needs both. */
+int csship_ffn_fused_train(const float* x, float* out, float* pre_ln_out, const float* ln_g, const float* ln_b,
+                           const uint16_t* w1_packed, const float* b1, const uint16_t* w2_packed,
+                           const float* b2, const float* final_ln_g, const float* final_ln_b,
+                           int32_t M, int32_t d_model, int32_t d_ffn, float alpha,
+                           const csship_dropout_cfg* drop_hidden, const csship_dropout_cfg* drop_out,
+                           csship_stream_t stream);
 
 /* csship_panel_linear: out[M, N] = epi( pro(a)[M, 256] @ W[N, 256]^T + bias ).
  * prologue: LayerNorm of f32 rows (pre-LN of MultiHeadedAttention, conformer.py:222),

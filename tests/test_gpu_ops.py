@@ -540,3 +540,24 @@ def test_panel_linear_dropout_epilogue():
     assert torch.equal(got, want)
     assert float((got == x).float().mean()) > 0.05          # about one element in ten is dropped
     assert torch.equal(ops.panel_linear(a, wp, b, D, residual=x), x + ops.panel_linear(a, wp, b, D))
+
+
+@pytest.mark.gpu
+def test_ffn_fused_final_layernorm_keeps_the_rows_in_front_of_it():
+    """csship_ffn_fused_train: FeedForward + residual + final LayerNorm in one launch, handing back the rows in front of
+    the LayerNorm as well == the FeedForward launch followed by the LayerNorm launch."""
+    from css_amd import ops
+    torch.manual_seed(5)
+    M, D, FF = 3000, 256, 1024
+    x = torch.randn(M, D, device="cuda")
+    ln = (1 + 0.1 * torch.randn(D, device="cuda"), 0.1 * torch.randn(D, device="cuda"))
+    fin = (1 + 0.1 * torch.randn(D, device="cuda"), 0.1 * torch.randn(D, device="cuda"))
+    w1, w2 = torch.randn(FF, D, device="cuda") * 0.05, torch.randn(D, FF, device="cuda") * 0.03
+    b1, b2 = torch.randn(FF, device="cuda") * 0.1, torch.randn(D, device="cuda") * 0.1
+    w1p, w2p = ops.pack_frag(w1), ops.pack_frag(w2)
+    want_pre = ops.ffn_fused(x, ln, w1p, b1, w2p, b2, FF, 0.5)
+    pre, out = ops.ffn_fused(x, ln, w1p, b1, w2p, b2, FF, 0.5, final_ln=fin, want_pre_ln=True)
+    assert torch.equal(pre, want_pre)
+    assert torch.equal(out, ops.ffn_fused(x, ln, w1p, b1, w2p, b2, FF, 0.5, final_ln=fin))
+    ref = torch.nn.functional.layer_norm(pre.double().cpu(), (D,), fin[0].double().cpu(), fin[1].double().cpu(), 1e-5)
+    assert float((out.double().cpu() - ref).abs().max()) < 1e-4
