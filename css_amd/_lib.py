@@ -169,6 +169,8 @@ SIGNATURES = {
     "csship_convmod_bwd_stats": (_i32, [_p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _p, _p, _p, _dc, _p, _sz, _p]),
     "csship_convmod_bwd_finish": (_i32, [_p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _p, _p, _p, C.c_double, _dc,
                                          _p, _sz, _p]),
+    "csship_convmod_bwd_next": (_i32, [_p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _dc, _dc, _p, _p,
+                                _sz, _p]),
     "csship_convmod_bwd_drop": (_i32, [_p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _dc, _p,
                                         _sz, _p]),
     "csship_conformer_workspace": (_sz, [C.POINTER(ConformerWeights), _i32, _i32]),

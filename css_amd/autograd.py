@@ -21,6 +21,7 @@ from .dropout import DropState, model_drop_state
 
 BF = torch.bfloat16
 _NO_FFN_LN = bool(os.environ.get("CSSHIP_NO_FFN_LN"))       # A/B timing: the block's final LayerNorm as its own launch
+_NO_CONV_NEXT = bool(os.environ.get("CSSHIP_NO_CONV_NEXT"))  # A/B timing: dropout(dx) for the output projection's backward as its own pass
 _NO_DROP_EPI = bool(os.environ.get("CSSHIP_NO_DROP_EPI"))   # A/B timing: output-projection dropout as its own pass
 
 
@@ -330,8 +331,14 @@ class ConformerTrain(torch.autograd.Function):
             dx = ffn_b(lay.feed_forward_out, "ffn_out", dx)
             x2, W, fws = L["conv"]
             c = lay.conv
-            dx3, g = ob.convmod_bwd(x2.view(B, T, D), dx.view(B, T, D), W, fws, enc.kernel_size,
-                                    bn_eval=not S["batch_bn"], drop=ds.cfg(f"{li}.conv.out"), sync=S["sync_bn"])
+            dyb = None
+            if S["sync_bn"] or _NO_CONV_NEXT:
+                dx3, g = ob.convmod_bwd(x2.view(B, T, D), dx.view(B, T, D), W, fws, enc.kernel_size,
+                                        bn_eval=not S["batch_bn"], drop=ds.cfg(f"{li}.conv.out"), sync=S["sync_bn"])
+            else:   # also the gradient through the attention output's dropout, as the bf16 operand of the two products behind it
+                dx3, g, dyb = ob.convmod_bwd(x2.view(B, T, D), dx.view(B, T, D), W, fws, enc.kernel_size,
+                                             bn_eval=not S["batch_bn"], drop=ds.cfg(f"{li}.conv.out"), want_next=True,
+                                             next_drop=ds.cfg(f"{li}.attn.out"))
             dx = dx3.view(M, D)
             put(c.layer_norm.weight, g["ln_g"]), put(c.layer_norm.bias, g["ln_b"])
             put(c.pw_conv_1.weight, g["pw1_w"]), put(c.pw_conv_1.bias, g["pw1_b"])
@@ -343,7 +350,7 @@ class ConformerTrain(torch.autograd.Function):
             dx, g = bw.mha_bwd(x1, dx, qkv.view(B, T, 3 * D), ao, a.layer_norm.weight.detach(),
                                a.layer_norm.bias.detach(), wqkv_bf, wo_bf, S["pe_bf"], H, scale, window=window,
                                probs=(S["pe_pack"], lse), skew_buf=skew_buf, drop_p=ds.cfg(f"{li}.attn.p"),
-                               drop_out=ds.cfg(f"{li}.attn.out"), dwin_acc=dwin)
+                               drop_out=ds.cfg(f"{li}.attn.out"), dwin_acc=dwin, dyb_bf16=dyb)
             dg, dbeta, dwqkv, dbqkv, dwo, dbo, dwin = g   # dwin: the window gradient summed over the blocks so far
             put(a.layer_norm.weight, dg), put(a.layer_norm.bias, dbeta)
             for i, lin in enumerate((a.linear_q, a.linear_k, a.linear_v)):

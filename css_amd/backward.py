@@ -142,7 +142,7 @@ def _mha_core_products(qkv, g, q, k, do, p_v, ds, dsk, dq1, win, idx, window, dw
 
 
 def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_scale=0.125, window=None, probs=None,
-            skew_buf=None, fused_softmax_bwd=True, drop_p=None, drop_out=None, dwin_acc=None):
+            skew_buf=None, fused_softmax_bwd=True, drop_p=None, drop_out=None, dwin_acc=None, dyb_bf16=None):
     """out = x + attention(LN(x)) @ wo^T + bo  (conformer.py:213-254,356).
 
     wqkv_bf holds the q rows already multiplied by q_scale (as the forward uses them); the returned dwqkv / dbqkv are
@@ -151,7 +151,11 @@ def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_s
     """
     D = x.shape[1]
     # training: out = x + D_out(ao wo^T + bo) (conformer.py:254): the branch gradient is dy o mask / (1 - p)
-    dyb = dy if drop_out is None else ops.dropout_apply(dy, drop_out, out=torch.empty_like(dy))
+    # dyb_bf16: that product already formed (and rounded to bf16, as the GEMMs round it) by the operator in front
+    if dyb_bf16 is not None:
+        dyb = dyb_bf16
+    else:
+        dyb = dy if drop_out is None else ops.dropout_apply(dy, drop_out, out=torch.empty_like(dy))
     dao, dwo, dbo = linear_bwd(dyb, ao, wo_bf, dx_bf16=True)
     B = qkv.shape[0]
     if drop_p is not None and (probs is None or not fused_softmax_bwd):

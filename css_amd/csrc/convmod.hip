@@ -413,6 +413,16 @@ __global__ __launch_bounds__(256) void conv_bn_bwd_apply_kernel(const float* __r
   reinterpret_cast<float4*>(dc)[i] = make_float4(o[0], o[1], o[2], o[3]);
 }
 
+// optional second form of the module's input gradient for the operator behind it in the backward pass (the attention
+// output projection: its weight and input gradients multiply with the DROPPED gradient, as bf16 MFMA operands):
+// out = bf16(mask / (1 - p) o dx), element index as csship_dropout_apply on the dense [B*T, D] rows; p = 0: plain bf16(dx)
+struct NextOut {
+  const unsigned* seed;
+  unsigned stream;
+  float p;
+  unsigned short* out;
+};
+
 // pass C: one wave per row.  a = LN(x); g = (w0 a + b0) * sigmoid(w1 a + b1); given dg: da, then LayerNorm backward,
 // dx = dy + ...; partials [nwg][2D + 4]: d ln_g | d ln_b | d w0, d w1, d b0, d b1
 template <int VPL>
@@ -420,9 +430,11 @@ __global__ __launch_bounds__(256) void glu_ln_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ dy, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const float* __restrict__ pw1_w,
                                                          const float* __restrict__ pw1_b, int64_t M, int rows_per_wg,
-                                                         float* __restrict__ dx, float* __restrict__ part) {
+                                                         float* __restrict__ dx, float* __restrict__ part,
+                                                         NextOut nx = NextOut{}) {
   constexpr int D = 256 * VPL;
   __shared__ float red[4][2 * D + 4];
+  const Drop ndrop = drop_make(nx.seed, nx.stream, nx.p);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float w0 = pw1_w[0], w1 = pw1_w[1], b0 = pw1_b[0], b1 = pw1_b[1];
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg, r1 = min(M, r0 + rows_per_wg);
@@ -491,6 +503,10 @@ __global__ __launch_bounds__(256) void glu_ln_bwd_kernel(const float* __restrict
       r.z = a.z + rstd * (d[i][2] - s1 - v[i][2] * s2);
       r.w = a.w + rstd * (d[i][3] - s1 - v[i][3] * s2);
       *reinterpret_cast<float4*>(dx + o) = r;
+      if (nx.out != nullptr) {  // what the NEXT backward operator multiplies with: mask / (1 - p) o dx, bf16
+        const float4 rd = drop_apply4(ndrop, (unsigned)o, r);
+        *reinterpret_cast<uint2*>(nx.out + o) = make_uint2(pack_bf2(rd.x, rd.y), pack_bf2(rd.z, rd.w));
+      }
     }
   }
 #pragma unroll
@@ -533,7 +549,7 @@ template <int D, int TT>
 // caller all-reduces), phase 2 = the rest with those sums and the GLOBAL row count
 int run_bwd(const float* x, const float* dy, const csship_conv_weights& w, int B, int T, const float* fwd_ws, float* dx,
             float* grads, float* ws, int bn_eval, hipStream_t s, csship_dropout_cfg dcfg, int phase = 0,
-            double total_rows = 0.0) {
+            double total_rows = 0.0, NextOut nx = NextOut{}) {
   const BwdLayout L = bwd_layout(B, T, D, TT);
   const int64_t M = (int64_t)B * T;
   const size_t n = (size_t)M * D;
@@ -576,7 +592,7 @@ int run_bwd(const float* x, const float* dy, const csship_conv_weights& w, int B
   if (rc) return rc;
   // pass C
   hipLaunchKernelGGL((glu_ln_bwd_kernel<D / 256>), dim3(L.nwg_rows), dim3(256), 0, s, x, dg, dy, w.ln_g, w.ln_b, w.pw1_w,
-                     w.pw1_b, M, BWD_ROWS, dx, part_c);
+                     w.pw1_b, M, BWD_ROWS, dx, part_c, nx);
   CSSHIP_CHECK_LAUNCH();
   return launch_slab_reduce(part_c, L.nwg_rows, 2 * D + 4, 2 * D + 4, 2 * D + 4, 1.f, nullptr, nullptr, 0, gC, s);
 }
@@ -678,7 +694,18 @@ extern "C" int csship_convmod_bwd(const float* x, const float* dy, const csship_
 static int convmod_bwd_impl(const float* x, const float* dy, const csship_conv_weights* w, int32_t B, int32_t T, int32_t D,
                             int32_t kernel_size, const void* fwd_workspace, float* dx, float* grads, int32_t bn_eval,
                             const csship_dropout_cfg* drop, void* workspace, size_t workspace_bytes, csship_stream_t stream,
-                            int phase, double total_rows);
+                            int phase, double total_rows, const csship_dropout_cfg* next_drop = nullptr,
+                            uint16_t* dx_next_bf16 = nullptr);
+
+extern "C" int csship_convmod_bwd_next(const float* x, const float* dy, const csship_conv_weights* w, int32_t B, int32_t T,
+                                       int32_t D, int32_t kernel_size, const void* fwd_workspace, float* dx,
+                                       float* grads, int32_t bn_eval, const csship_dropout_cfg* drop,
+                                       const csship_dropout_cfg* next_drop, uint16_t* dx_next_bf16, void* workspace,
+                                       size_t workspace_bytes, csship_stream_t stream) {
+  if (!dx_next_bf16 || !aligned8(dx_next_bf16)) return dx_next_bf16 ? CSSHIP_EALIGN : CSSHIP_ENULL;
+  return convmod_bwd_impl(x, dy, w, B, T, D, kernel_size, fwd_workspace, dx, grads, bn_eval, drop, workspace, workspace_bytes,
+                          stream, 0, 0.0, next_drop, dx_next_bf16);
+}
 
 extern "C" int csship_convmod_bwd_drop(const float* x, const float* dy, const csship_conv_weights* w, int32_t B, int32_t T,
                                        int32_t D, int32_t kernel_size, const void* fwd_workspace, float* dx,
@@ -712,7 +739,11 @@ extern "C" int csship_convmod_bwd_finish(const float* x, const float* dy, const 
 static int convmod_bwd_impl(const float* x, const float* dy, const csship_conv_weights* w, int32_t B, int32_t T, int32_t D,
                             int32_t kernel_size, const void* fwd_workspace, float* dx, float* grads, int32_t bn_eval,
                             const csship_dropout_cfg* drop, void* workspace, size_t workspace_bytes, csship_stream_t stream,
-                            int phase, double total_rows) {
+                            int phase, double total_rows, const csship_dropout_cfg* next_drop, uint16_t* dx_next_bf16) {
+  const bool ndropping = next_drop && next_drop->seed && next_drop->p > 0.f;
+  if (dx_next_bf16 && (int64_t)B * T * D > 0xffffffffLL) return CSSHIP_EBADSHAPE;
+  const NextOut nx{ndropping ? next_drop->seed : nullptr, ndropping ? next_drop->stream : 0u, ndropping ? next_drop->p : 0.f,
+                   dx_next_bf16};
   const bool dropping = drop && drop->seed && drop->p > 0.f;
   if (dropping && (int64_t)B * T * D > 0xffffffffLL) return CSSHIP_EBADSHAPE;
   const csship_dropout_cfg dc = dropping ? *drop : csship_dropout_cfg{nullptr, 0u, 0.f};
@@ -725,6 +756,6 @@ static int convmod_bwd_impl(const float* x, const float* dy, const csship_conv_w
   if (workspace_bytes < csship_convmod_bwd_workspace(B, T, D)) return CSSHIP_EWORKSPACE;
   const float* fw = reinterpret_cast<const float*>(fwd_workspace);
   float* ws = reinterpret_cast<float*>(workspace);
-  if (D == 256) return run_bwd<256, TT256>(x, dy, *w, B, T, fw, dx, grads, ws, bn_eval, as_stream(stream), dc, phase, total_rows);
-  return run_bwd<512, TT512>(x, dy, *w, B, T, fw, dx, grads, ws, bn_eval, as_stream(stream), dc, phase, total_rows);
+  if (D == 256) return run_bwd<256, TT256>(x, dy, *w, B, T, fw, dx, grads, ws, bn_eval, as_stream(stream), dc, phase, total_rows, nx);
+  return run_bwd<512, TT512>(x, dy, *w, B, T, fw, dx, grads, ws, bn_eval, as_stream(stream), dc, phase, total_rows, nx);
 }

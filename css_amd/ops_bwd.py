@@ -251,9 +251,11 @@ def relpos_softmax_bwd(p, dp, T, W):
     return ds, dsk
 
 
-def convmod_bwd(x, dy, weights, fwd_ws, kernel_size=33, bn_eval=False, drop=None, sync=False):
+def convmod_bwd(x, dy, weights, fwd_ws, kernel_size=33, bn_eval=False, drop=None, sync=False, want_next=False, next_drop=None):
     """Backward of ops.convmod(x, weights, batch_stats=True) (or keep_activations=True with bn_eval=True).  x, dy f32 [B,T,D]; fwd_ws: that call's workspace.
-    Returns dx and a dict of f32 gradients keyed like the weights dict (dw_w as [k, D])."""
+    Returns dx and a dict of f32 gradients keyed like the weights dict (dw_w as [k, D]).  want_next (not with sync): a
+    third result bf16 [B*T, D] = dropout(dx) under ``next_drop`` (None: bf16(dx)), the operand of the next operator of the
+    backward pass (csship_convmod_bwd_next)."""
     from .ops import conv_weights_struct
     _need(x, torch.float32, "x"), _need(dy, torch.float32, "dy")
     x, dy = x.contiguous(), dy.contiguous()
@@ -271,6 +273,10 @@ def convmod_bwd(x, dy, weights, fwd_ws, kernel_size=33, bn_eval=False, drop=None
         off = lib().csship_convmod_bwd_sums_offset(B, T, D)
         allreduce_sum_(ws[off:off + 8 * D].view(torch.float32))
         check(lib().csship_convmod_bwd_finish(*args, float(B * T * dist.get_world_size()), drop, _ptr(ws), nws, _stream()))
+    elif want_next:
+        nxt = torch.empty((B * T, D), dtype=torch.bfloat16, device=x.device)
+        check(lib().csship_convmod_bwd_next(_ptr(x), _ptr(dy), C.byref(cw), B, T, D, kernel_size, _ptr(fwd_ws), _ptr(dx),
+                                            _ptr(flat), int(bn_eval), drop, next_drop, _ptr(nxt), _ptr(ws), nws, _stream()))
     else:
         check(lib().csship_convmod_bwd_drop(_ptr(x), _ptr(dy), C.byref(cw), B, T, D, kernel_size, _ptr(fwd_ws), _ptr(dx),
                                             _ptr(flat), int(bn_eval), drop, _ptr(ws), nws, _stream()))
@@ -279,6 +285,10 @@ def convmod_bwd(x, dy, weights, fwd_ws, kernel_size=33, bn_eval=False, drop=None
              "dw_w": flat[o:o + kernel_size * D].view(kernel_size, D), "dw_b": flat[o + 33 * D:o + 34 * D],
              "ln_g": flat[o + 34 * D:o + 35 * D], "ln_b": flat[o + 35 * D:o + 36 * D],
              "pw1_w": flat[o + 36 * D:o + 36 * D + 2], "pw1_b": flat[o + 36 * D + 2:o + 36 * D + 4]}
+    if want_next:
+        if sync and not bn_eval:
+            raise RuntimeError("css_amd: convmod_bwd(want_next=True) is not built for SyncBatchNorm")
+        return dx, grads, nxt
     return dx, grads
 
 

@@ -702,6 +702,17 @@ int csship_convmod_bwd_drop(const float* x, const float* dy, const csship_conv_w
                             float* grads, int32_t bn_eval, const csship_dropout_cfg* drop, void* workspace,
                             size_t workspace_bytes, csship_stream_t stream);
 
+/* csship_convmod_bwd_drop that also writes dx_next_bf16 = bf16(mask_next / (1 - p_next) o dx) (bf16 [B*T, D]; next_drop
+ * NULL: bf16(dx)): the operand the NEXT operator of the backward pass multiplies with - in the Conformer block the
+ * attention output projection, whose weight and input gradients take the gradient through ITS output dropout
+ * (conformer.py:254) as bf16 MFMA operands.  Saves that operator a dropout pass over dx and the fp32 -> bf16 rounding in
+ * its two products (same rounding, same results). */
+int csship_convmod_bwd_next(const float* x, const float* dy, const csship_conv_weights* w, int32_t B, int32_t T,
+                            int32_t D, int32_t kernel_size, const void* fwd_workspace, float* dx,
+                            float* grads, int32_t bn_eval, const csship_dropout_cfg* drop,
+                            const csship_dropout_cfg* next_drop, uint16_t* dx_next_bf16, void* workspace,
+                            size_t workspace_bytes, csship_stream_t stream);
+
 /* SyncBatchNorm backward, split like the forward: _stats leaves this rank's S1 = sum dy_bn and S2 = sum dy_bn * zhat
  * (f32 [2D]) at byte csship_convmod_bwd_sums_offset() of `workspace`; the caller all-reduces them (SUM); _finish uses
  * them with 1 / total_rows in the BatchNorm input gradient.  bn_g / bn_b gradients in `grads` are this rank's share

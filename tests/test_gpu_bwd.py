@@ -497,3 +497,25 @@ def test_attention_backward_core_one_pass(ob, B, T, H, p_drop):
     k = g[:, :, 1].permute(0, 2, 1, 3)
     ref = ds[..., :T].float().cpu().double() @ k.float().cpu().double()
     assert relerr(dq1, ref) < 2e-5
+
+
+def test_convmod_backward_next_operand(ob):
+    """csship_convmod_bwd_next: the third result is bf16(dropout(dx)) under the next operator's cfg (what
+    csship_dropout_apply + the GEMM's rounding give), dx and the parameter gradients unchanged."""
+    from css_amd import ops
+    from css_amd.dropout import DropState
+    B, T, D, K = 4, 130, 256, 33
+    x = rnd((B, T, D), 30).to(DEV)
+    dy = rnd((B, T, D), 31).to(DEV)
+    W = {"ln_g": 1 + 0.1 * rnd((D,), 32), "ln_b": 0.1 * rnd((D,), 33), "pw1_w": rnd((2,), 34), "pw1_b": rnd((2,), 35),
+         "dw_w": rnd((K, D), 36, 0.2), "dw_b": 0.1 * rnd((D,), 37), "bn_g": 1 + 0.1 * rnd((D,), 38), "bn_b": 0.1 * rnd((D,), 39),
+         "bn_mean": torch.zeros(D), "bn_var": torch.ones(D), "pw2_w": rnd((1,), 40) + 1.0, "pw2_b": rnd((1,), 41)}
+    W = {k: v.to(DEV).contiguous() for k, v in W.items()}
+    _, fws = ops.convmod(x, W, K, batch_stats=True, return_workspace=True)
+    st = DropState(torch.tensor([99], dtype=torch.int32, device=DEV), 0.1, 0)
+    dx0, g0 = ob.convmod_bwd(x, dy, W, fws, K)
+    for cfg in (None, st.cfg("2.attn.out")):
+        dx, g, nxt = ob.convmod_bwd(x, dy, W, fws, K, want_next=True, next_drop=cfg)
+        assert torch.equal(dx, dx0) and all(torch.equal(g[k], g0[k]) for k in g0)
+        want = dx0.view(B * T, D) if cfg is None else ops.dropout_apply(dx0.view(B * T, D), cfg, out=torch.empty(B * T, D, device=DEV))
+        assert torch.equal(nxt, want.to(torch.bfloat16))
