@@ -24,8 +24,18 @@ class ConvWeights(C.Structure):
                                   "bn_mean", "bn_var", "pw2_w", "pw2_b")]
 
 
+class DropoutCfg(C.Structure):  # csship_dropout_cfg
+    _fields_ = [("seed", _p), ("stream", C.c_uint32), ("p", _f32)]
+
+
 class FfnWeights(C.Structure):
     _fields_ = [(n, _p) for n in ("ln_g", "ln_b", "w1", "b1", "w2", "b2", "w1_scale", "w2_scale")]
+
+
+class ChainTrain(C.Structure):  # csship_chain_train
+    _fields_ = [("drop_a_hidden", C.POINTER(DropoutCfg)), ("drop_a_out", C.POINTER(DropoutCfg)),
+                ("drop_b_hidden", C.POINTER(DropoutCfg)), ("drop_b_out", C.POINTER(DropoutCfg)),
+                ("pre_ln_out", _p), ("ln_out", _p)]
 
 
 class MhaWeights(C.Structure):
@@ -52,10 +62,6 @@ class BgemmParams(C.Structure):
                 ("batch1", _i32), ("batch2", _i32), ("splits", _i32),
                 ("sA1", _i64), ("sA2", _i64), ("sB1", _i64), ("sB2", _i64), ("sC1", _i64), ("sC2", _i64),
                 ("sX1", _i64), ("sX2", _i64), ("alpha", _f32)]
-
-
-class DropoutCfg(C.Structure):  # csship_dropout_cfg
-    _fields_ = [("seed", _p), ("stream", C.c_uint32), ("p", _f32)]
 
 
 _dc = C.POINTER(DropoutCfg)
@@ -98,6 +104,8 @@ SIGNATURES = {
     "csship_panel_linear_drop": (_i32, [_p, _i32, _p, _p, _p, _p, _p, _i64, _f32, _p, _i64, _i32, _i32, _i32, _i32, _dc, _p]),
     "csship_embed": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "csship_outproj_glu": (_i32, [_p, _p, _p, _p, _p, C.POINTER(ConvWeights), _p, _i32, _i32, _p]),
+    "csship_encoder_chain_train": (_i32, [_p, _p, C.POINTER(FfnWeights), _p, _p, C.POINTER(FfnWeights), _p, _p, _p, _p, _p,
+                                   _i32, _i32, _i32, _i32, C.POINTER(ChainTrain), _p]),
     "csship_encoder_chain": (_i32, [_p, _p, _p, C.POINTER(ConvWeights), _i32, C.POINTER(FfnWeights), _p, _p,
                                      C.POINTER(FfnWeights), _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "csship_mha_relpos": (_i32, [_p, _p, _i32, _i32, _p, _i32, _i32, _i32, _p]),

@@ -20,6 +20,7 @@ from . import backward as bw, ops, ops_bwd as ob
 from .dropout import DropState, model_drop_state
 
 BF = torch.bfloat16
+_NO_TRAIN_CHAIN = bool(os.environ.get("CSSHIP_NO_TRAIN_CHAIN"))   # A/B timing: the training forward operator by operator
 _NO_FFN_LN = bool(os.environ.get("CSSHIP_NO_FFN_LN"))       # A/B timing: the block's final LayerNorm as its own launch
 _NO_CONV_NEXT = bool(os.environ.get("CSSHIP_NO_CONV_NEXT"))  # A/B timing: dropout(dx) for the output projection's backward as its own pass
 _NO_DROP_EPI = bool(os.environ.get("CSSHIP_NO_DROP_EPI"))   # A/B timing: output-projection dropout as its own pass
@@ -177,6 +178,22 @@ class ConformerTrain(torch.autograd.Function):
                               torch.stack([l_.self_attn.linear_k.bias.detach() for l_ in lays]),
                               torch.stack([l_.self_attn.linear_v.bias.detach() for l_ in lays])], 1)
         dww_all = torch.stack([l_.conv.dw_conv_1d.weight.detach().view(D, K) for l_ in lays]).transpose(1, 2).contiguous()
+        chained = not wide and not _NO_TRAIN_CHAIN
+        carried = None
+
+        def chain_ffn(i, tag):
+            m = getattr(lays[i], "feed_forward_in" if tag == "ffn_in" else "feed_forward_out")
+            w1p, w2p = pack["layers"][i][tag][0], pack["layers"][i][tag][1]
+            return ((m.layer_norm.weight.detach(), m.layer_norm.bias.detach()), w1p, m.net[0].bias.detach(), w2p,
+                    m.net[3].bias.detach())
+
+        def chain_qkv(i):
+            a_ = lays[i].self_attn
+            return ((a_.layer_norm.weight.detach(), a_.layer_norm.bias.detach()), pack["layers"][i]["wqkv_p"], bqkv_all[i], 3 * D)
+
+        def chain_drops(i, tag):
+            return (ds.cfg(f"{i}.{tag}.hidden"), ds.cfg(f"{i}.{tag}.out"))
+
         for li, (lay, wp) in enumerate(zip(enc.encoders, pack["layers"])):
             L = {}
 
@@ -197,17 +214,25 @@ class ConformerTrain(torch.autograd.Function):
                                      m.net[0].bias.detach(), w2p, m.net[3].bias.detach(), FF, 0.5, drop_hidden=dh, drop_out=do,
                                      final_ln=final_ln, want_pre_ln=final_ln is not None)
 
-            x1 = ffn(lay.feed_forward_in, x, "ffn_in")
             a = lay.self_attn
             scale = a.d_k ** -0.5
             wqkv_bf, wqkv_p, wo_bf, wo_p = wp["wqkv_bf"], wp["wqkv_p"], wp["wo_bf"], wp["wo_p"]
             bqkv = bqkv_all[li]
-            if wide:
-                a2, _ = ops.layernorm(x1, a.layer_norm.weight.detach(), a.layer_norm.bias.detach())
-                qkv = ops.gemm(a2, wqkv_bf, bqkv, out_bf16=True)
+            if chained and li == 0:   # first FeedForward + LayerNorm + q | k | v of the first block: one launch
+                x1, qkv, _, _ = ops.encoder_chain_train(x, FF, chain_ffn(li, "ffn_in"), chain_qkv(li),
+                                                        drops=(None, None) + chain_drops(li, "ffn_in"))
+                L["ffn_in"] = (x,) + tuple(wp["ffn_in"][i] for i in (0, 2, 3))
+            elif chained:             # came out of the chained launch at the end of the previous block
+                x1, qkv = carried
+                L["ffn_in"] = (x,) + tuple(wp["ffn_in"][i] for i in (0, 2, 3))
             else:
-                qkv = ops.panel_linear(x1, wqkv_p, bqkv, 3 * D,
-                                       ln=(a.layer_norm.weight.detach(), a.layer_norm.bias.detach()), out_bf16=True)
+                x1 = ffn(lay.feed_forward_in, x, "ffn_in")
+                if wide:
+                    a2, _ = ops.layernorm(x1, a.layer_norm.weight.detach(), a.layer_norm.bias.detach())
+                    qkv = ops.gemm(a2, wqkv_bf, bqkv, out_bf16=True)
+                else:
+                    qkv = ops.panel_linear(x1, wqkv_p, bqkv, 3 * D,
+                                           ln=(a.layer_norm.weight.detach(), a.layer_norm.bias.detach()), out_bf16=True)
             ao, lse = ops.mha_relpos_train(qkv.view(B, T, 3 * D), pe_pack, H, drop=ds.cfg(f"{li}.attn.p"))
             ao = ao.view(M, D)
             if ds.active and not wide and not _NO_DROP_EPI:   # x2 = x1 + D(ao wo^T + bo): the mask in the projection's epilogue
@@ -236,7 +261,16 @@ class ConformerTrain(torch.autograd.Function):
                 stats = fws.view(torch.float32)[-4 * D:]
                 bn_means.append(c.BN.running_mean), bn_vars.append(c.BN.running_var)
                 bn_new_m.append(stats[2 * D:3 * D]), bn_new_v.append(stats[3 * D:])
-            if wide or _NO_FFN_LN:
+            if chained and li + 1 < len(lays):
+                # this block's last FeedForward + its LayerNorm, the next block's first FeedForward and its LayerNorm +
+                # q | k | v as ONE launch (the inference forward's chain kernel with the dropouts and the saved rows)
+                x1n, qkvn, x4, x = ops.encoder_chain_train(
+                    x3, FF, chain_ffn(li + 1, "ffn_in"), chain_qkv(li + 1), ffn_a=chain_ffn(li, "ffn_out"),
+                    final_ln=(lay.layer_norm.weight.detach(), lay.layer_norm.bias.detach()),
+                    drops=chain_drops(li, "ffn_out") + chain_drops(li + 1, "ffn_in"))
+                carried = (x1n, qkvn)
+                L["ffn_out"] = (x3,) + tuple(wp["ffn_out"][i] for i in (0, 2, 3))
+            elif wide or _NO_FFN_LN:
                 x4 = ffn(lay.feed_forward_out, x3, "ffn_out")
                 _, x = ops.layernorm(x4, lay.layer_norm.weight.detach(), lay.layer_norm.bias.detach(), out_bf16=False,
                                      out_f32=True)

@@ -749,6 +749,12 @@ struct ChainArgs {
   float alpha;
   unsigned long long* stamps;  // -DP_STAMPS diagnostic builds only
   int qkv_il8;                 // wqkv / bqkv in the 8-feature interleaved row order (CSSHIP_CHAIN_QKV_IL8)
+  // TRAIN (csship_encoder_chain_train): the reference's dropouts of both FeedForwards (hidden [M, FF] and output
+  // [M, 256], element indices as csship_ffn_fused_drop) and the rows the backward pass keeps: in front of stage A's
+  // final LayerNorm (pre_ln_out) and behind it (ln_out = stage B's input)
+  csship_dropout_cfg da_h, da_o, db_h, db_o;
+  float* pre_ln_out;
+  float* ln_out;
 };
 
 // LayerNorm of the register rows -> bf16 activation panel in LDS.  gam == nullptr: no affine - the caller folded gamma
@@ -788,10 +794,16 @@ DEV void rows_to_panel(unsigned char* panel, const float4 (&v)[8], const float* 
 }
 
 // one FeedForward on the register rows: v <- v + alpha * FFN(LN(v))  [-> LayerNorm(fin)]
-template <int NW, bool FINAL_LN>
+struct StageTrain {  // what a training stage needs beyond the inference one
+  Drop dh, dout;
+  int m0, M;
+  float* pre_ln_out;
+};
+
+template <int NW, bool FINAL_LN, bool TRAIN = false>
 DEV void ffn_stage(float4 (&v)[8], unsigned char* Xs, unsigned char* Hraw, const FfnW& f, const float* fin_g,
                    const float* fin_b, int FF, float alpha, int tid, int rot, unsigned long long* g_stamps_dev = nullptr,
-                   int st0 = 0) {
+                   int st0 = 0, const StageTrain& tr = StageTrain{}) {
   constexpr int NT = 16 / NW;
   const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15, r = tid >> 3, part = tid & 7;
   const int nchunk = FF / DM, ks2 = FF / 32;
@@ -838,7 +850,14 @@ DEV void ffn_stage(float4 (&v)[8], unsigned char* Xs, unsigned char* Hraw, const
       const int hc = (wave * NT + t) * 16 + 4 * g;
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {  // ReLU on the packed pairs: 2 conversions + 2 integer max per 4 values
-        const uint2 pk = make_uint2(relu_bf2(pack_bf2(h[t][rt][0], h[t][rt][1])), relu_bf2(pack_bf2(h[t][rt][2], h[t][rt][3])));
+        uint2 pk;
+        if (TRAIN && tr.dh.thresh != 0u) {  // relu, then the hidden activation's dropout (conformer.py:317), element (row, c*256 + hc)
+          const float4 hv = drop_apply4(tr.dh, (unsigned)((tr.m0 + rt * 16 + n) * FF + c * DM + hc),
+                                        make_float4(fmaxf(h[t][rt][0], 0.f), fmaxf(h[t][rt][1], 0.f), fmaxf(h[t][rt][2], 0.f), fmaxf(h[t][rt][3], 0.f)));
+          pk = make_uint2(pack_bf2(hv.x, hv.y), pack_bf2(hv.z, hv.w));
+        } else {
+          pk = make_uint2(relu_bf2(pack_bf2(h[t][rt][0], h[t][rt][1])), relu_bf2(pack_bf2(h[t][rt][2], h[t][rt][3])));
+        }
         *reinterpret_cast<uint2*>(hs + panel_off(rt * 16 + n, hc >> 3) + (hc & 7) * 2) = pk;
       }
     }
@@ -878,10 +897,17 @@ DEV void ffn_stage(float4 (&v)[8], unsigned char* Xs, unsigned char* Hraw, const
   P_T(st0 + 2)
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const float4 y = *reinterpret_cast<const float4*>(ys + r * YS + (i * 8 + part) * 4);
+    float4 y = *reinterpret_cast<const float4*>(ys + r * YS + (i * 8 + part) * 4);
+    if constexpr (TRAIN) y = drop_apply4(tr.dout, (unsigned)((tr.m0 + r) * DM + (i * 8 + part) * 4), y);  // conformer.py:319
     v[i] = make_float4(v[i].x + alpha * y.x, v[i].y + alpha * y.y, v[i].z + alpha * y.z, v[i].w + alpha * y.w);
   }
   if constexpr (FINAL_LN) {
+    if constexpr (TRAIN) {
+      if (tr.pre_ln_out != nullptr && tr.m0 + r < tr.M) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(tr.pre_ln_out + (size_t)(tr.m0 + r) * DM + (i * 8 + part) * 4) = v[i];
+      }
+    }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
@@ -903,8 +929,9 @@ DEV void ffn_stage(float4 (&v)[8], unsigned char* Xs, unsigned char* Hraw, const
   }
 }
 
-template <int NW, bool HAS_CONV, bool HAS_A, bool HAS_B, bool HAS_C>
+template <int NW, bool HAS_CONV, bool HAS_A, bool HAS_B, bool HAS_C, bool TRAIN = false>
 __global__ __launch_bounds__(NW * 64) void chain_kernel(ChainArgs a) {
+  static_assert(!TRAIN || !HAS_CONV, "the training forward runs the conv module with batch statistics, on its own");
   static_assert(NW * 64 == 8 * BM, "row phases assume 8 lanes per panel row");
   constexpr int NT = 16 / NW;
   __shared__ __attribute__((aligned(16))) unsigned char smem[PANEL_BYTES + YS_BYTES];
@@ -994,9 +1021,24 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(ChainArgs a) {
   unsigned long long* const g_stamps_dev = a.stamps;
 #endif
   P_T(0)
+  if constexpr (TRAIN) {
+    if constexpr (HAS_A) {
+      const StageTrain ta{drop_make(a.da_h.seed, a.da_h.stream, a.da_h.p), drop_make(a.da_o.seed, a.da_o.stream, a.da_o.p), m0, a.M, a.pre_ln_out};
+      ffn_stage<NW, true, true>(v, Xs, Hraw, a.fa, a.fin_g, a.fin_b, a.FF, a.alpha, tid, blockIdx.x, a.stamps, 1, ta);
+      if (a.ln_out != nullptr && row < a.M) {  // the next block's input: the backward of its first FeedForward needs it
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(a.ln_out + (size_t)row * DM + (i * 8 + part) * 4) = v[i];
+      }
+    }
+    if constexpr (HAS_B) {
+      const StageTrain tb{drop_make(a.db_h.seed, a.db_h.stream, a.db_h.p), drop_make(a.db_o.seed, a.db_o.stream, a.db_o.p), m0, a.M, nullptr};
+      ffn_stage<NW, false, true>(v, Xs, Hraw, a.fb, nullptr, nullptr, a.FF, a.alpha, tid, blockIdx.x + 2, a.stamps, 5, tb);
+    }
+  } else {
   if constexpr (HAS_A) ffn_stage<NW, true>(v, Xs, Hraw, a.fa, a.fin_g, a.fin_b, a.FF, a.alpha, tid, blockIdx.x, a.stamps, 1);
   P_T(4)
   if constexpr (HAS_B) ffn_stage<NW, false>(v, Xs, Hraw, a.fb, nullptr, nullptr, a.FF, a.alpha, tid, blockIdx.x + 2, a.stamps, 5);
+  }
   P_T(8)
   if (row < a.M && !(P_ABL & 16)) {  // the residual stream the attention output projection adds to
 #pragma unroll
@@ -1826,12 +1868,41 @@ extern "C" int csship_panel_linear_drop(const void* a, int32_t prologue, const f
 }
 
 
+static int encoder_chain_impl(const float* x, float* x_out, const float* conv_g, const csship_conv_weights* conv_w,
+                              int32_t T, const csship_ffn_weights* ffn_a, const float* final_ln_g,
+                              const float* final_ln_b, const csship_ffn_weights* ffn_b, const float* qkv_ln_g,
+                              const float* qkv_ln_b, const uint16_t* wqkv_packed, const float* bqkv,
+                              uint16_t* qkv_out, int32_t M, int32_t d_model, int32_t d_ffn, int32_t n_qkv,
+                              int32_t flags, csship_stream_t stream, const csship_chain_train* train);
+
 extern "C" int csship_encoder_chain(const float* x, float* x_out, const float* conv_g, const csship_conv_weights* conv_w,
                                     int32_t T, const csship_ffn_weights* ffn_a, const float* final_ln_g,
                                     const float* final_ln_b, const csship_ffn_weights* ffn_b, const float* qkv_ln_g,
                                     const float* qkv_ln_b, const uint16_t* wqkv_packed, const float* bqkv,
                                     uint16_t* qkv_out, int32_t M, int32_t d_model, int32_t d_ffn, int32_t n_qkv,
                                     int32_t flags, csship_stream_t stream) {
+  return encoder_chain_impl(x, x_out, conv_g, conv_w, T, ffn_a, final_ln_g, final_ln_b, ffn_b, qkv_ln_g, qkv_ln_b, wqkv_packed,
+                            bqkv, qkv_out, M, d_model, d_ffn, n_qkv, flags, stream, nullptr);
+}
+
+extern "C" int csship_encoder_chain_train(const float* x, float* x_out, const csship_ffn_weights* ffn_a,
+                                          const float* final_ln_g, const float* final_ln_b, const csship_ffn_weights* ffn_b,
+                                          const float* qkv_ln_g, const float* qkv_ln_b, const uint16_t* wqkv_packed,
+                                          const float* bqkv, uint16_t* qkv_out, int32_t M, int32_t d_model, int32_t d_ffn,
+                                          int32_t n_qkv, const csship_chain_train* train, csship_stream_t stream) {
+  if (!train) return CSSHIP_ENULL;
+  if ((int64_t)((M + BM - 1) / BM * BM) * d_ffn > 0xffffffffLL) return CSSHIP_EBADSHAPE;  // 32-bit dropout element indices
+  if ((train->pre_ln_out && !aligned16(train->pre_ln_out)) || (train->ln_out && !aligned16(train->ln_out))) return CSSHIP_EALIGN;
+  return encoder_chain_impl(x, x_out, nullptr, nullptr, 0, ffn_a, final_ln_g, final_ln_b, ffn_b, qkv_ln_g, qkv_ln_b, wqkv_packed,
+                            bqkv, qkv_out, M, d_model, d_ffn, n_qkv, 0, stream, train);
+}
+
+static int encoder_chain_impl(const float* x, float* x_out, const float* conv_g, const csship_conv_weights* conv_w,
+                              int32_t T, const csship_ffn_weights* ffn_a, const float* final_ln_g,
+                              const float* final_ln_b, const csship_ffn_weights* ffn_b, const float* qkv_ln_g,
+                              const float* qkv_ln_b, const uint16_t* wqkv_packed, const float* bqkv,
+                              uint16_t* qkv_out, int32_t M, int32_t d_model, int32_t d_ffn, int32_t n_qkv,
+                              int32_t flags, csship_stream_t stream, const csship_chain_train* train) {
   if (!x || !x_out) return CSSHIP_ENULL;
   if (M <= 0) return CSSHIP_EBADSHAPE;
   if (d_model != DM || d_ffn <= 0 || (d_ffn % DM) != 0) return CSSHIP_EUNSUPPORTED;
@@ -1856,6 +1927,19 @@ extern "C" int csship_encoder_chain(const float* x, float* x_out, const float* c
   if (Cq) { a.qln_g = qkv_ln_g; a.qln_b = qkv_ln_b; a.wqkv = reinterpret_cast<const bf16x8*>(wqkv_packed); a.bqkv = bqkv; a.qkv = qkv_out; }
   dim3 grid((M + BM - 1) / BM), block(NWAVES * 64);
   hipStream_t s = as_stream(stream);
+  if (train != nullptr) {
+    const csship_dropout_cfg none{nullptr, 0u, 0.f};
+    auto cfg = [&](const csship_dropout_cfg* c) { return (c && c->seed && c->p > 0.f) ? *c : none; };
+    a.da_h = cfg(train->drop_a_hidden); a.da_o = cfg(train->drop_a_out);
+    a.db_h = cfg(train->drop_b_hidden); a.db_o = cfg(train->drop_b_out);
+    a.pre_ln_out = train->pre_ln_out; a.ln_out = train->ln_out;
+    if ((A && !ffn_a->ln_g) || (Bs && !ffn_b->ln_g)) return CSSHIP_EUNSUPPORTED;  // folded LayerNorms belong to the inference packing
+    if (A && Bs && Cq) hipLaunchKernelGGL((chain_kernel<NWAVES, false, true, true, true, true>), grid, block, 0, s, a);
+    else if (!A && Bs && Cq) hipLaunchKernelGGL((chain_kernel<NWAVES, false, false, true, true, true>), grid, block, 0, s, a);
+    else return CSSHIP_EUNSUPPORTED;
+    CSSHIP_CHECK_LAUNCH();
+    return CSSHIP_OK;
+  }
   // CSSHIP_CHAIN=8 / 4 run the second form of the kernel (8 or 4 waves) for A/B timing; measured at M = 12 800:
   // first form 50.1 us, second form 54.0 us (8 waves), 61.4 us (4 waves) - see the note above chain2_kernel
   static const int form = [] { const char* e = getenv("CSSHIP_CHAIN"); return e ? atoi(e) : 1; }();

@@ -677,6 +677,31 @@ def _ffn_struct(ln, w1p, b1, w2p, b2):
     return w
 
 
+def encoder_chain_train(x, d_ffn, ffn_b, qkv, ffn_a=None, final_ln=None, drops=(None, None, None, None)):
+    """csship_encoder_chain_train on x f32 [M,256] (the training forward through the chain kernel).  ffn_a / ffn_b:
+    (ln=(g,b), w1p, b1, w2p, b2); final_ln: (g, b) behind ffn_a; qkv: (ln=(g,b), wqkv_packed, bqkv, n_qkv); drops: dropout
+    cfg pointers (a.hidden, a.out, b.hidden, b.out).  Returns (x_out, qkv_bf16, pre_ln_rows, ln_rows) - the last two
+    None without ffn_a."""
+    _need(x, torch.float32, "x")
+    assert x.dim() == 2 and x.is_contiguous() and x.shape[1] == 256
+    M = x.shape[0]
+    out = torch.empty_like(x)
+    fa = _ffn_struct(*ffn_a) if ffn_a is not None else None
+    fb = _ffn_struct(*ffn_b)
+    pre = torch.empty_like(x) if ffn_a is not None else None
+    lnr = torch.empty_like(x) if ffn_a is not None else None
+    n_qkv = qkv[3]
+    q_out = torch.empty(M, n_qkv, device=x.device, dtype=torch.bfloat16)
+    tr = _lib.ChainTrain()
+    tr.drop_a_hidden, tr.drop_a_out, tr.drop_b_hidden, tr.drop_b_out = (d if d is not None else None for d in drops)
+    tr.pre_ln_out, tr.ln_out = (pre.data_ptr() if pre is not None else None), (lnr.data_ptr() if lnr is not None else None)
+    check(lib().csship_encoder_chain_train(
+        _ptr(x), _ptr(out), C.byref(fa) if fa is not None else None,
+        _ptr(final_ln[0]) if final_ln else None, _ptr(final_ln[1]) if final_ln else None, C.byref(fb),
+        _ptr(qkv[0][0]), _ptr(qkv[0][1]), _ptr(qkv[1]), _ptr(qkv[2]), _ptr(q_out), M, 256, d_ffn, n_qkv, C.byref(tr), _stream()))
+    return out, q_out, pre, lnr
+
+
 def encoder_chain(x, d_ffn, ffn_a=None, final_ln=None, ffn_b=None, qkv=None, out=None, flags=0):
     """csship_encoder_chain on x f32 [M,256].  ffn_a / ffn_b: (ln=(g,b) or None, w1p, b1, w2p, b2) with packed weights
     (ln None: the affine part is folded into w1p / b1, fold_layernorm); final_ln: (g, b) applied after ffn_a; qkv:

@@ -322,6 +322,22 @@ int csship_encoder_chain(const float* x, float* x_out, const float* conv_g,
                          const float* bqkv, uint16_t* qkv_out, int32_t M, int32_t d_model, int32_t d_ffn,
                          int32_t n_qkv, int32_t flags, csship_stream_t stream);
 
+/* The training forward through the same kernel: stage A = the previous block's last FeedForward + residual + that block's
+ * final LayerNorm, stage B = this block's first FeedForward + residual, stage C = LayerNorm + q | k | v, with the
+ * reference's dropouts (element indices as csship_ffn_fused_drop) and the rows the backward pass keeps.  ffn_a may be
+ * NULL (first block: stages B + C only); ffn_b and wqkv_packed are required; the LayerNorm parameters must be given
+ * (no folded weights), wqkv_packed / bqkv in plain row order.  x_out = the rows behind stage B. */
+typedef struct {
+  const csship_dropout_cfg *drop_a_hidden, *drop_a_out, *drop_b_hidden, *drop_b_out;  /* NULL = no dropout */
+  float* pre_ln_out;  /* optional, with ffn_a: rows in front of the final LayerNorm (f32 [M, 256]) */
+  float* ln_out;      /* optional, with ffn_a: rows behind it = stage B's input */
+} csship_chain_train;
+int csship_encoder_chain_train(const float* x, float* x_out, const struct csship_ffn_weights_s* ffn_a,
+                               const float* final_ln_g, const float* final_ln_b, const struct csship_ffn_weights_s* ffn_b,
+                               const float* qkv_ln_g, const float* qkv_ln_b, const uint16_t* wqkv_packed,
+                               const float* bqkv, uint16_t* qkv_out, int32_t M, int32_t d_model, int32_t d_ffn,
+                               int32_t n_qkv, const csship_chain_train* train, csship_stream_t stream);
+
 /* csship_embed: x0 = ReLU(LayerNorm(Linear(MVN_time(f))))  (css/models/conformer.py:95, 124-129) as one
  * row-panel kernel; f f32 [B, T, idim] (row stride ldf, any idim); mvn_mean / mvn_rinv from
  * csship_mvn_stats; w_packed = fragment-packed [256, Kp] with Kp = idim rounded up to 256 (zero padded);
