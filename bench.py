@@ -369,8 +369,8 @@ def main():
         roof = {"bound": "mfma",
                 "kernel": f"chain_kernel<8,0,1,1,1> (FFN_out+LN -> FFN_in -> LN+QKV, M=12800; {nl} launches/step)",
                 "achieved": flops / dur / 1e12 if dur else None, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                "frac": flops / dur / PEAK_BF16 if dur else None, "traffic": traffic_of("chain_kernel<8, false, true, true, true>"),
-                "mfma_busy_pmc": busy_of("chain_kernel<8, false, true, true, true>"),
+                "frac": flops / dur / PEAK_BF16 if dur else None, "traffic": traffic_of("chain_kernel<8, false, true, true, true, false>"),
+                "mfma_busy_pmc": busy_of("chain_kernel<8, false, true, true, true, false>"),
                 "avg_launch_us": dur * 1e6, "flops_per_launch": flops, "timing": "HIP events around the in-step launches",
                 "pmc_source": pmc_src,
                 "whole_step_frac": (step_flops * (3.0 if args.mode == "train" else 1.0)) / (dt / args.steps) / PEAK_BF16}
