@@ -56,6 +56,23 @@ def bench_ffn():
             print(f"ffn_fused d_ffn={ff:5d} final_ln={int(fin)}  {us:8.1f} us  {4.0 * M * D * ff / us / 1e6:8.1f} TFLOP/s")
 
 
+def bench_ffn_bwd():
+    """the fused FeedForward backward (activation side) alone, with and without the reference's dropouts"""
+    from css_amd import ops_bwd as ob
+    from css_amd.dropout import DropState
+    x, dy = torch.randn(M, D, device=DEV), torch.randn(M, D, device=DEV)
+    g, b = torch.ones(D, device=DEV), torch.zeros(D, device=DEV)
+    ff = 1024
+    w1, w2 = torch.randn(ff, D, device=DEV) / 16, torch.randn(D, ff, device=DEV) / 32
+    w1p, w2tp, w1tp = ops.pack_frag(w1), ops.pack_frag(w2.t().contiguous()), ops.pack_frag(w1.t().contiguous())
+    b1 = torch.zeros(ff, device=DEV)
+    st = DropState(torch.tensor([5], dtype=torch.int32, device=DEV), 0.1, 0)
+    for drop in (False, True):
+        dh_, do_ = (st.cfg("0.ffn_in.hidden"), st.cfg("0.ffn_in.out")) if drop else (None, None)
+        us = timeit(lambda: ob.ffn_bwd(x, dy, g, b, w1p, b1, w2tp, w1tp, ff, 0.5, drop_hidden=dh_, drop_out=do_))
+        print(f"ffn_bwd d_ffn={ff} dropout={int(drop)}  {us:8.1f} us  {6.0 * M * D * ff / us / 1e6:8.1f} TFLOP/s")
+
+
 def bench_linear():
     x = torch.randn(M, D, device=DEV)
     xb = x.to(torch.bfloat16)
@@ -170,7 +187,7 @@ def bench_ln():
     print(f"layernorm  {us:8.1f} us  {M * D * 6 / us / 1e3:8.1f} GB/s")
 
 
-ALL = {"chain": bench_chain, "ffn": bench_ffn, "linear": bench_linear, "attn": bench_attn, "attn_bwd": bench_attn_bwd, "conv": bench_conv, "stft": bench_stft,
+ALL = {"chain": bench_chain, "ffn": bench_ffn, "ffn_bwd": bench_ffn_bwd, "linear": bench_linear, "attn": bench_attn, "attn_bwd": bench_attn_bwd, "conv": bench_conv, "stft": bench_stft,
        "pit": bench_pit, "ln": bench_ln}
 
 if __name__ == "__main__":
