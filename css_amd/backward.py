@@ -65,6 +65,7 @@ def ffn_bwd_fused(x, dy, ln_g, ln_b, b1, w1p, w2tp, w1tp, d_ffn, alpha=0.5, drop
     return dx, (dg, dbeta, dw1, db1, dw2, db2)
 
 
+_NO_BAND = bool(os.environ.get("CSSHIP_NO_BAND"))   # A/B timing: the skewed-dS product over the whole window axis
 _NO_LN_Y = bool(os.environ.get("CSSHIP_NO_LN_Y"))   # A/B timing: LayerNorm(x) for the q/k/v weight gradient by its own launch
 _SPLIT_ATTN_BWD = bool(os.environ.get("CSSHIP_ATTN_BWD_SPLIT"))   # A/B timing: probabilities / softmax backward / dS k as separate launches
 
@@ -129,7 +130,8 @@ def _mha_core_products(qkv, g, q, k, do, p_v, ds, dsk, dq1, win, idx, window, dw
     dq, dk, dv = (dqkv.view(B, T, 3, H, 64)[:, :, i].permute(0, 2, 1, 3) for i in range(3))
     ob.bgemm(p_v[..., :T], do, a_kmajor=True, b_kmajor=True, out=dv)    # dV = P^T dO
     ob.bgemm(ds[..., :T], q, a_kmajor=True, b_kmajor=True, out=dk)      # dK = dS^T q
-    ob.bgemm(dsk.permute(0, 2, 1, 3), win[None, None], b_kmajor=True, add=dq1, out=dq)   # + dS_skew pe_window
+    # + dS_skew pe_window; row i of dS_skew is zero outside columns i .. i + T - 1: the product skips those reduction tiles
+    ob.bgemm(dsk.permute(0, 2, 1, 3), win[None, None], b_kmajor=True, add=dq1, out=dq, band=0 if _NO_BAND else T - 1)
     if q_rows is None:
         q_rows = g[:, :, 0].reshape(B * T * H, 64)                      # rows ordered (b, t, h) like dsk
     # [W, 64]; dwin_acc (the sum over the blocks already back-propagated) is added by the product's epilogue, in place

@@ -34,6 +34,7 @@ struct BgemmArgs {
   int a_f32, b_f32, epi;
   float alpha;
   // COLSUM kernels (weight gradients): column sums of the kmajor A operand (= the bias gradient of the same Linear)
+  int band;        // > 0: A[m, k] = 0 unless m <= k <= m + band (csship_bgemm_params.band)
   float* cs_out;   // [M], alpha applied (splits == 1)
   float* cs_slab;  // [splits][M] partial sums (splits > 1), reduced with the C slabs
   float alpha_head;  // COLSUM kernels: output rows < head_rows take this factor instead of alpha (fused q | k | v weight
@@ -288,8 +289,12 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
   const int m0 = by * 128, n0 = bx * TN;
   const int z = bz / g.splits, split = bz % g.splits;
   const int z1 = z / g.nb2, z2 = z % g.nb2;
-  const int kbeg = split * g.k_per_split, kend = min(g.K, kbeg + g.k_per_split);
-  const int nk = (kend - kbeg + BK - 1) / BK;
+  int kbeg = split * g.k_per_split, kend = min(g.K, kbeg + g.k_per_split);
+  if (g.band > 0) {  // banded A: only the reduction tiles that meet rows m0 .. m0 + 127
+    kbeg = max(kbeg, (m0 / BK) * BK);
+    kend = min(kend, (m0 + 128 + g.band + BK - 1) / BK * BK);
+  }
+  const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
   const bool af32 = FAST ? A_F32 : g.a_f32 != 0, bf32 = FAST ? B_F32 : g.b_f32 != 0;
   const void* Ab = reinterpret_cast<const unsigned char*>(g.A) + (z1 * g.sA1 + z2 * g.sA2) * (af32 ? 4 : 2);
   const void* Bb = reinterpret_cast<const unsigned char*>(g.B) + (z1 * g.sB1 + z2 * g.sB2) * (bf32 ? 4 : 2);
@@ -931,6 +936,7 @@ static int bgemm_impl(const void* A, const void* B, void* C, const float* bias, 
   a.slab = (int64_t)p->M * p->N;
   a.a_f32 = p->a_f32; a.b_f32 = p->b_f32; a.epi = p->epilogue; a.alpha = p->alpha;
   a.cs_out = colsum_out;
+  a.band = (p->band > 0 && !p->a_kmajor && splits == 1) ? p->band : 0;
   a.alpha_head = alpha_head; a.head_rows = head_rows;
   a.cs_slab = splits > 1 ? reinterpret_cast<float*>(workspace) + (size_t)splits * p->M * p->N : nullptr;
   const bool narrow = narrow_tile(p) && !colsum_out;

@@ -545,6 +545,10 @@ typedef struct {
   int32_t batch1, batch2, splits;
   int64_t sA1, sA2, sB1, sB2, sC1, sC2, sX1, sX2; /* sX*: aux */
   float alpha;
+  int32_t band;             /* > 0: A[m, k] is ZERO unless m <= k <= m + band (row-major A only): output tiles skip the
+                             * 64-deep reduction tiles outside their rows' band.  Same results (the skipped products
+                             * are exact zeros); the skewed dS of the relative-position attention (band = T - 1 of
+                             * W = 2T - 1 columns) reads a third less.  0 = dense. */
 } csship_bgemm_params;
 size_t csship_bgemm_workspace(const csship_bgemm_params* p);
 int csship_bgemm(const void* A, const void* B, void* C, const float* bias, const void* aux,

@@ -519,3 +519,24 @@ def test_convmod_backward_next_operand(ob):
         assert torch.equal(dx, dx0) and all(torch.equal(g[k], g0[k]) for k in g0)
         want = dx0.view(B * T, D) if cfg is None else ops.dropout_apply(dx0.view(B * T, D), cfg, out=torch.empty(B * T, D, device=DEV))
         assert torch.equal(nxt, want.to(torch.bfloat16))
+
+
+def test_bgemm_band_hint_skips_only_zero_tiles(ob):
+    """csship_bgemm_params.band: a row-major A that is zero outside m <= k <= m + band gives the same product bit for bit
+    with the hint (batched, strided, f32 addend, bf16 output - the skewed-dS product of the attention backward)."""
+    Bz, H, T = 3, 2, 400
+    W = (2 * T - 1 + 7) // 8 * 8
+    dsk = torch.zeros(Bz, T, H, W, dtype=torch.bfloat16, device=DEV)
+    i = torch.arange(T, device=DEV)
+    vals = rnd((Bz, T, H, T), 200).to(DEV).to(torch.bfloat16)
+    for b in range(Bz):
+        for h in range(H):
+            dsk[b, i[:, None].expand(T, T), h, i[:, None] + torch.arange(T, device=DEV)[None, :]] = vals[b, :, h]
+    win = rnd((W, 64), 201).to(DEV).to(torch.bfloat16)
+    add = rnd((Bz, H, T, 64), 202).to(DEV)
+    a = dsk.permute(0, 2, 1, 3)
+    want = ob.bgemm(a, win[None, None], b_kmajor=True, add=add, out_bf16=True)
+    got = ob.bgemm(a, win[None, None], b_kmajor=True, add=add, out_bf16=True, band=T - 1)
+    assert torch.equal(got, want)
+    ref = a.float().cpu().double() @ win.float().cpu().double() + add.cpu().double()
+    assert relerr(got.float(), ref) < 1e-2
