@@ -61,7 +61,7 @@ class BgemmParams(C.Structure):
                 ("a_kmajor", _i32), ("b_kmajor", _i32), ("a_f32", _i32), ("b_f32", _i32), ("epilogue", _i32),
                 ("batch1", _i32), ("batch2", _i32), ("splits", _i32),
                 ("sA1", _i64), ("sA2", _i64), ("sB1", _i64), ("sB2", _i64), ("sC1", _i64), ("sC2", _i64),
-                ("sX1", _i64), ("sX2", _i64), ("alpha", _f32), ("band", _i32)]
+                ("sX1", _i64), ("sX2", _i64), ("alpha", _f32), ("band", _i32), ("band_stride", _i32)]
 
 
 _dc = C.POINTER(DropoutCfg)

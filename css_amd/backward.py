@@ -135,7 +135,10 @@ def _mha_core_products(qkv, g, q, k, do, p_v, ds, dsk, dq1, win, idx, window, dw
     if q_rows is None:
         q_rows = g[:, :, 0].reshape(B * T * H, 64)                      # rows ordered (b, t, h) like dsk
     # [W, 64]; dwin_acc (the sum over the blocks already back-propagated) is added by the product's epilogue, in place
-    dwin = ob.bgemm(dsk.view(B * T * H, W), q_rows, a_kmajor=True, b_kmajor=True, add=dwin_acc, out=dwin_acc)
+    # (rows (b, t, h) of dS_skew are zero outside columns t .. t + T - 1: one K-slab per batch entry, banded)
+    banded = not _NO_BAND and (T * H) % 64 == 0 and B > 1
+    dwin = ob.bgemm(dsk.view(B * T * H, W), q_rows, a_kmajor=True, b_kmajor=True, add=dwin_acc, out=dwin_acc,
+                    **({"band": T - 1, "band_stride": H, "splits": B} if banded else {}))
     if window is not None:
         return dqkv, dwin  # the caller accumulates window gradients over the layers and scatters once
     dpe = torch.zeros((2 * maxlen, 64), dtype=torch.float32, device=qkv.device)

@@ -34,7 +34,8 @@ struct BgemmArgs {
   int a_f32, b_f32, epi;
   float alpha;
   // COLSUM kernels (weight gradients): column sums of the kmajor A operand (= the bias gradient of the same Linear)
-  int band;        // > 0: A[m, k] = 0 unless m <= k <= m + band (csship_bgemm_params.band)
+  int band;        // > 0: banded A (csship_bgemm_params.band / band_stride)
+  int band_stride;
   float* cs_out;   // [M], alpha applied (splits == 1)
   float* cs_slab;  // [splits][M] partial sums (splits > 1), reduced with the C slabs
   float alpha_head;  // COLSUM kernels: output rows < head_rows take this factor instead of alpha (fused q | k | v weight
@@ -291,8 +292,15 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
   const int z1 = z / g.nb2, z2 = z % g.nb2;
   int kbeg = split * g.k_per_split, kend = min(g.K, kbeg + g.k_per_split);
   if (g.band > 0) {  // banded A: only the reduction tiles that meet rows m0 .. m0 + 127
-    kbeg = max(kbeg, (m0 / BK) * BK);
-    kend = min(kend, (m0 + 128 + g.band + BK - 1) / BK * BK);
+    if constexpr (!A_KM) {
+      kbeg = max(kbeg, (m0 / BK) * BK);
+      kend = min(kend, (m0 + 128 + g.band + BK - 1) / BK * BK);
+    } else {  // k = split * period + t * stride + h, nonzero for t in [m - band, m]
+      const int lo = max(0, m0 - g.band) * g.band_stride, hi = (m0 + 128) * g.band_stride;
+      const int base = split * g.k_per_split;
+      kend = min(kend, base + (hi + BK - 1) / BK * BK);
+      kbeg = min(kend, base + lo / BK * BK);
+    }
   }
   const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
   const bool af32 = FAST ? A_F32 : g.a_f32 != 0, bf32 = FAST ? B_F32 : g.b_f32 != 0;
@@ -936,7 +944,14 @@ static int bgemm_impl(const void* A, const void* B, void* C, const float* bias, 
   a.slab = (int64_t)p->M * p->N;
   a.a_f32 = p->a_f32; a.b_f32 = p->b_f32; a.epi = p->epilogue; a.alpha = p->alpha;
   a.cs_out = colsum_out;
-  a.band = (p->band > 0 && !p->a_kmajor && splits == 1) ? p->band : 0;
+  a.band = 0;
+  a.band_stride = 0;
+  if (p->band > 0 && !p->a_kmajor && splits == 1) a.band = p->band;
+  // kmajor form: one K-slab per period (the caller gave splits = K / period), whole 64-deep tiles
+  if (p->band > 0 && p->a_kmajor && p->band_stride > 0 && p->splits == splits && splits > 1 && p->K % (splits * BK) == 0) {
+    a.band = p->band;
+    a.band_stride = p->band_stride;
+  }
   a.alpha_head = alpha_head; a.head_rows = head_rows;
   a.cs_slab = splits > 1 ? reinterpret_cast<float*>(workspace) + (size_t)splits * p->M * p->N : nullptr;
   const bool narrow = narrow_tile(p) && !colsum_out;

@@ -82,9 +82,11 @@ def _as4(t, name):
 
 
 def bgemm(a, b, *, a_kmajor=False, b_kmajor=False, out=None, out_bf16=False, alpha=1.0, bias=None, mask_pos=None,
-          add=None, splits=0, band=0):
+          add=None, splits=0, band=0, band_stride=0):
     """C = alpha * opA(a) @ opB(b)^T-style product, batched over leading dims.
-    band > 0 (row-major a): a[m, k] is known to be zero unless m <= k <= m + band - reduction tiles outside are skipped.
+    band > 0: a is banded and reduction tiles outside an output tile's band are skipped (csship_bgemm_params.band):
+    row-major a zero unless m <= k <= m + band; kmajor a with band_stride and splits: rows k = z * (K / splits) +
+    t * band_stride + h, zero unless t <= m <= t + band.
 
     a: [.., M, K] (or [.., K, M] when a_kmajor); b: [.., N, K] (or [.., K, N] when b_kmajor); result [.., M, N].
     mask_pos: bf16 [.., M, N], zeroes the result where it is <= 0; add: f32 [.., M, N] added to the result.
@@ -126,7 +128,7 @@ def bgemm(a, b, *, a_kmajor=False, b_kmajor=False, out=None, out_bf16=False, alp
                          sA1=bstr(a4)[0], sA2=bstr(a4)[1], sB1=bstr(b4)[0], sB2=bstr(b4)[1],
                          sC1=bstr(out)[0], sC2=bstr(out)[1],
                          sX1=bstr(aux)[0] if aux is not None else 0, sX2=bstr(aux)[1] if aux is not None else 0,
-                         alpha=float(alpha), band=int(band) if not a_kmajor else 0)
+                         alpha=float(alpha), band=int(band), band_stride=int(band_stride) if a_kmajor else 0)
     nws = lib().csship_bgemm_workspace(C.byref(p))
     ws = _workspace(nws, a.device) if nws else None
     check(lib().csship_bgemm(_ptr(a4), _ptr(b4), _ptr(out), _ptr(bias), _ptr(aux), C.byref(p), _ptr(ws), nws, _stream()))

@@ -545,10 +545,15 @@ typedef struct {
   int32_t batch1, batch2, splits;
   int64_t sA1, sA2, sB1, sB2, sC1, sC2, sX1, sX2; /* sX*: aux */
   float alpha;
-  int32_t band;             /* > 0: A[m, k] is ZERO unless m <= k <= m + band (row-major A only): output tiles skip the
-                             * 64-deep reduction tiles outside their rows' band.  Same results (the skipped products
-                             * are exact zeros); the skewed dS of the relative-position attention (band = T - 1 of
-                             * W = 2T - 1 columns) reads a third less.  0 = dense. */
+  int32_t band;             /* > 0: A is banded and output tiles skip the 64-deep reduction tiles outside their rows'
+                             * band - same results (the skipped products are exact zeros).  Row-major A: A[m, k] = 0
+                             * unless m <= k <= m + band (the skewed dS of the relative-position attention as the left
+                             * operand: band = T - 1 of W = 2T - 1 columns, a third less to read).  kmajor A with
+                             * band_stride > 0: the reduction index is k = z * period + t * band_stride + h with
+                             * period = K / splits (splits given, K % (splits * 64) == 0), and A[k, m] = 0 unless
+                             * t <= m <= t + band (the same matrix as the left operand of d(pe_window) = dS_skew^T q,
+                             * rows (b, t, h): band_stride = H, splits = B).  0 = dense. */
+  int32_t band_stride;
 } csship_bgemm_params;
 size_t csship_bgemm_workspace(const csship_bgemm_params* p);
 int csship_bgemm(const void* A, const void* B, void* C, const float* bias, const void* aux,

@@ -540,3 +540,11 @@ def test_bgemm_band_hint_skips_only_zero_tiles(ob):
     assert torch.equal(got, want)
     ref = a.float().cpu().double() @ win.float().cpu().double() + add.cpu().double()
     assert relerr(got.float(), ref) < 1e-2
+    # the same matrix as the reduction-strided left operand of d(pe_window) = dS_skew^T q: rows (b, t, h), one K-slab per b
+    q_rows = rnd((Bz * T * H, 64), 203).to(DEV).to(torch.bfloat16)
+    acc = rnd((W, 64), 204).to(DEV)
+    a2 = dsk.view(Bz * T * H, W)
+    want2 = ob.bgemm(a2, q_rows, a_kmajor=True, b_kmajor=True, add=acc, splits=Bz)
+    got2 = ob.bgemm(a2, q_rows, a_kmajor=True, b_kmajor=True, add=acc, splits=Bz, band=T - 1, band_stride=H)
+    assert torch.equal(got2, want2)
+    assert relerr(got2, a2.float().cpu().double().T @ q_rows.float().cpu().double() + acc.cpu().double()) < 1e-4
