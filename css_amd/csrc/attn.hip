@@ -369,238 +369,19 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mha_fwd_kernel(const
   unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_)::"memory");
 #endif
-  for (int j0 = 0; j0 < T; j0 += 64, cur ^= 1) {
-    const bool more = j0 + 64 < T;
-    if (more && !(A2_ABL & 8)) {  // in flight during this tile's work; written to LDS at the end of the iteration
-      A2_LOAD_KV(j0 + 64)
-      if (j0 + 128 < T) A2_LOAD_RING(j0 + 128)
-    }
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- S^T += K Q^T
-    const unsigned char* const kt = sK + cur * A2_KV;
-    const unsigned char* const vt = sV + cur * A2_KV;
-    A2_BAND_WAIT()
-#pragma unroll
-    for (int ks = 0; ks < ((A2_ABL & 16) ? 0 : 2); ++ks) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(kt + tile_off(16 * t + n, ks * 4 + g));
-        s[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[0][ks], s[0][t], 0, 0, 0);
-        s[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[1][ks], s[1][t], 0, 0, 0);
-      }
-    }
-    if (!more) {  // only the last key tile has a tail
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (j0 + 16 * t + 4 * g + r >= T) s[qb][t][r] = -1e30f;
-      asm volatile("" ::: "memory");
-    }
-    A2_T(0)
-
-    if constexpr (PROBS) {
-      // P = exp2(S log2e - lse log2e); a lane holds 4 consecutive keys of one query per key block: one 8-byte store each.
-      // Keys in [T, ldp) come out as exact zeros (their scores were set to -1e30 above), columns >= ldp are not written.
-      f32x4 dpt[2][4];      // BWD: dP^T = V dO^T of the tile
-      bf16x8 dsb[2][2] = {};  // and dS^T as the B operand of dq1^T += K^T dS^T
-      if constexpr (BWD) {
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) dpt[qb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(vt + v_off(16 * t + n, ks * 4 + g));
-            dpt[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, dof[0][ks], dpt[0][t], 0, 0, 0);
-            dpt[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, dof[1][ks], dpt[1][t], 0, 0, 0);
-          }
-      }
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
-        const int qi = i0w + 16 * qb + n;
-        const size_t poff = (((size_t)bh) * T + min(qi, T - 1)) * (size_t)ldp + j0 + 4 * g;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          float pv[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(s[qb][t][r] * LOG2E - lse2[qb]);
-          const bool st = owner && qi < T && j0 + 16 * t + 4 * g + 3 < ldp;
-          if constexpr (!BWD) {
-            if (st) {
-              *reinterpret_cast<uint2*>(out + poff + 16 * t) = make_uint2(pack_bf2(pv[0], pv[1]), pack_bf2(pv[2], pv[3]));
-              if constexpr (DROP) {
-                const float4 pd = drop_apply4(dp, (unsigned)(poff + 16 * t), make_float4(pv[0], pv[1], pv[2], pv[3]));
-                *reinterpret_cast<uint2*>(pdrop + poff + 16 * t) = make_uint2(pack_bf2(pd.x, pd.y), pack_bf2(pd.z, pd.w));
-              }
-            }
-          } else {
-            float4 dpv = make_float4(dpt[qb][t][0], dpt[qb][t][1], dpt[qb][t][2], dpt[qb][t][3]);
-            float4 pd = make_float4(pv[0], pv[1], pv[2], pv[3]);
-            if constexpr (DROP) {  // one mask for both: dP = mask / (1 - p) o (dO v^T), operand of dV = mask / (1 - p) o P
-              const unsigned e0 = (unsigned)(poff + 16 * t);
-              dpv = drop_apply4(dp, e0, dpv);
-              pd = drop_apply4(dp, e0, pd);
-            }
-            const unsigned short d0 = f2bf(pv[0] * (dpv.x - dval[qb])), d1 = f2bf(pv[1] * (dpv.y - dval[qb]));
-            const unsigned short d2 = f2bf(pv[2] * (dpv.z - dval[qb])), d3 = f2bf(pv[3] * (dpv.w - dval[qb]));
-            const uint2 dpk = make_uint2((unsigned)d0 | ((unsigned)d1 << 16), (unsigned)d2 | ((unsigned)d3 << 16));
-            {  // key j = 32 ks + 16 (e >> 2) + 4 g + (e & 3) <-> k index e of k-step ks = t >> 1 (as pbf in the forward)
-              typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-              u32x4 v = __builtin_bit_cast(u32x4, dsb[qb][t >> 1]);
-              v[(t & 1) * 2] = dpk.x;
-              v[(t & 1) * 2 + 1] = dpk.y;
-              dsb[qb][t >> 1] = __builtin_bit_cast(bf16x8, v);
-            }
-            if (st) {
-              *reinterpret_cast<uint2*>((DROP ? pdrop : out) + poff + 16 * t) = make_uint2(pack_bf2(pd.x, pd.y), pack_bf2(pd.z, pd.w));
-              *reinterpret_cast<uint2*>(bw.ds + poff + 16 * t) = dpk;
-              // skewed copy: keys j .. j+3 are positions r .. r-3 of the query's row of ds_skew, ONE 8-byte piece
-              // (d3 d2 d1 d0) that is only 2-byte aligned (attn_ds_kernel)
-              const int j = j0 + 16 * t + 4 * g;
-              unsigned short* skrow = bw.dsk + ((base_b + qi) * H + h) * (size_t)bw.W + (qi + T - 1);
-              if (j + 3 < T) {
-                struct __attribute__((packed, aligned(2))) h4u { unsigned short v[4]; };
-                h4u sk;
-                sk.v[0] = d3; sk.v[1] = d2; sk.v[2] = d1; sk.v[3] = d0;
-                *reinterpret_cast<h4u*>(skrow - j - 3) = sk;
-              } else {
-                if (j < T) skrow[-j] = d0;
-                if (j + 1 < T) skrow[-j - 1] = d1;
-                if (j + 2 < T) skrow[-j - 2] = d2;
-              }
-            }
-          }
-        }
-      }
-      if constexpr (BWD) {  // dq1^T += K^T dS^T: K^T fragments feed both query blocks (the forward's P.V with K for V)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const int r0 = 32 * ks + 4 * g + q4, r1 = r0 + 16;
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt) {
-            const unsigned char* a0 = kt + tile_off(r0, 2 * dt + (p4 >> 1)) + (p4 & 1) * 8;
-            const unsigned char* a1 = kt + tile_off(r1, 2 * dt + (p4 >> 1)) + (p4 & 1) * 8;
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a1));
-            const bf16x8 av = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-            dq[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, dsb[0][ks], dq[0][dt], 0, 0, 0);
-            dq[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, dsb[1][ks], dq[1][dt], 0, 0, 0);
-          }
-        }
-      }
-      if (!(A2_ABL & 1)) A2_BAND()
-      if (more) {
-        A2_STORE_KV(cur ^ 1)
-        if (j0 + 128 < T) A2_STORE_RING(j0 + 128)
-        __syncthreads();
-      }
-      continue;
-    }
-
-    // ---- online softmax, part 1: running maxima and (rarely) the rescale of what has been accumulated
-    float mscaled[2];
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      float mx = vmax3(s[qb][0][0], s[qb][0][1], s[qb][0][2]);
-      mx = vmax3(mx, s[qb][0][3], s[qb][1][0]);
-      mx = vmax3(mx, s[qb][1][1], s[qb][1][2]);
-      mx = vmax3(mx, s[qb][1][3], s[qb][2][0]);
-      mx = vmax3(mx, s[qb][2][1], s[qb][2][2]);
-      mx = vmax3(mx, s[qb][2][3], s[qb][3][0]);
-      mx = vmax3(mx, s[qb][3][1], s[qb][3][2]);
-      mx = vmax(mx, s[qb][3][3]);
-      mx = xmax16(mx);
-      const float m_new = vmax(m_run[qb], mx);
-      mscaled[qb] = m_new * LOG2E;
-      if (__any(m_new != m_run[qb])) {  // rescale only when some query's running maximum moved
-        const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * LOG2E);
-        lsum[qb] *= alpha;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[qb][i] *= alpha;
-        m_run[qb] = m_new;
-      }
-    }
-    A2_T(1)
-    // ---- part 2: P = exp2(S log2e - m log2e) as bf16 MFMA operands ...
-    bf16x8 pbf[2][2];
-    bf16x8 pbd[2][2];  // DROP: the masked probabilities (operands of P.V); pbf keeps the full ones for the row sums
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      if (!(A2_ABL & 2)) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) s[qb][t][r] = __builtin_amdgcn_exp2f(s[qb][t][r] * LOG2E - mscaled[qb]);
-      }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          pbf[qb][ks][e] = (__bf16)s[qb][2 * ks][e];
-          pbf[qb][ks][4 + e] = (__bf16)s[qb][2 * ks + 1][e];
-        }
-      if constexpr (DROP) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const unsigned k = dp.thresh ? drop_keep4(dp, ebase[qb] + (unsigned)(j0 + 16 * t)) : 15u;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) pbd[qb][t >> 1][(t & 1) * 4 + r] = (k >> r) & 1u ? pbf[qb][t >> 1][(t & 1) * 4 + r] : (__bf16)0.f;
-        }
-      }
-    }
-    // ---- ... beside the NEXT tile's position band (same basic block: the scheduler interleaves the two streams)
-    // (no branch: after the last tile it works on ring slots nobody needs and its result is dropped)
-    if (!(A2_ABL & 1)) A2_BAND()
-    else {
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) s[qb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-
-    A2_T(2)
-    // ---- O^T += V^T P^T.  k index of the MFMA <-> key j = 32ks + 16*(e>>2) + 4g + (e&3); V^T fragments feed both blocks;
-    // the row sums are one more MFMA per k-step: sum_j 1 . P^T[j, i] (every row of the result holds it)
-    if (A2_ABL & 4) {
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) asm volatile("" ::"v"(pbf[qb][ks]));
-    } else {
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int r0 = 32 * ks + 4 * g + q4, r1 = r0 + 16;
-        lsum[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pbf[0][ks], lsum[0], 0, 0, 0);
-        lsum[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pbf[1][ks], lsum[1], 0, 0, 0);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const unsigned char* a0 = vt + v_off(r0, 2 * dt + (p4 >> 1)) + (p4 & 1) * 8;
-          const unsigned char* a1 = vt + v_off(r1, 2 * dt + (p4 >> 1)) + (p4 & 1) * 8;
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a1));
-          const bf16x8 av = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-          o[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, DROP ? pbd[0][ks] : pbf[0][ks], o[0][dt], 0, 0, 0);
-          o[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, DROP ? pbd[1][ks] : pbf[1][ks], o[1][dt], 0, 0, 0);
-        }
-      }
-    }
-
-    A2_T(3)
-    if (more && !(A2_ABL & 8)) {
-      A2_STORE_KV(cur ^ 1)   // last read during the previous iteration: everyone has passed that iteration's barrier
-      // the ring's newcomers are tile j0 + 128's lowest four blocks: their slots held blocks above tile j0 + 64's
-      // window, last read for tile j0's band one iteration ago
-      if (j0 + 128 < T) A2_STORE_RING(j0 + 128)
-      A2_T(4)
-      __syncthreads();
-      A2_T(5)
-    }
+  // the tiles that have a successor, then the last one on its own copy of the body: at T = 400 it holds 16 keys of 64,
+  // and three quarters of its S products, exponentials and P.V k-steps, and the band of a tile that does not exist,
+  // were a seventh of the loop spent on zeros
+  for (int j0 = 0; j0 + 64 < T; j0 += 64, cur ^= 1) {
+#define A2_LAST 0
+#include "attn_tile.inc"
+#undef A2_LAST
+  }
+  {
+    const int j0 = ((T - 1) / 64) * 64;
+#define A2_LAST 1
+#include "attn_tile.inc"
+#undef A2_LAST
   }
 #ifdef A2_STAMPS
   if (stamps != nullptr && lane == 0)
