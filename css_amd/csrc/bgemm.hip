@@ -224,6 +224,7 @@ DEV void gl_read_step(bf16x8 (&a)[4], bf16x8 (&b)[4], unsigned st, const unsigne
 #define GL_MFMA(c, x, y) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(x), "v"(y))
 template <bool CS>
 DEV void gl_mfma_step(f32x4 (&acc)[4][4], f32x4 (&cs)[4], const bf16x8& ones, const bf16x8 (&a)[4], const bf16x8 (&b)[4]) {
+  asm volatile("s_nop 1");  // should hipcc ever copy a fragment (VALU) between its wait and these MFMAs: 2 wait states
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
