@@ -561,3 +561,27 @@ def test_ffn_fused_final_layernorm_keeps_the_rows_in_front_of_it():
     assert torch.equal(out, ops.ffn_fused(x, ln, w1p, b1, w2p, b2, FF, 0.5, final_ln=fin))
     ref = torch.nn.functional.layer_norm(pre.double().cpu(), (D,), fin[0].double().cpu(), fin[1].double().cpu(), 1e-5)
     assert float((out.double().cpu() - ref).abs().max()) < 1e-4
+
+
+@pytest.mark.gpu
+def test_attention_training_forward_is_reproducible_at_full_size():
+    """Two launches of csship_mha_relpos_train_drop on the same operands at 32 x 4 x 400 (all 256 CUs busy) give the same
+    bits - and so do the probabilities / one-pass backward.  A running maximum read from MFMA accumulators still in the
+    pipe (inline-assembly v_max3 without wait states) is the same softmax with other roundings, only on a full chip."""
+    from css_amd import ops, ops_bwd as ob
+    from css_amd.dropout import DropState
+    B, T, H = 32, 400, 4
+    D = H * 64
+    torch.manual_seed(11)
+    qkv = (torch.randn(B, T, 3 * D, device="cuda") * 0.5).to(torch.bfloat16)
+    pack = ops.pack_relpos(torch.randn(2000, 64, device="cuda") * 0.3, 1000)
+    dao = (torch.randn(B * T, D, device="cuda") * 0.2).to(torch.bfloat16)
+    for cfg in (None, DropState(torch.tensor([5], dtype=torch.int32, device="cuda"), 0.1, 0).cfg("0.attn.p")):
+        runs = [ops.mha_relpos_train(qkv, pack, H, drop=cfg) for _ in range(4)]
+        assert all(torch.equal(runs[0][0], r[0]) and torch.equal(runs[0][1], r[1]) for r in runs[1:])
+        ao, lse = runs[0]
+        W = (2 * T - 1 + 7) // 8 * 8
+        outs = [ob.mha_bwd_core(qkv, pack, lse, dao, None, torch.zeros(B, T, H, W, dtype=torch.bfloat16, device="cuda"), H,
+                                drop=cfg, out=ao.view(B * T, D)) for _ in range(3)]
+        assert all(all(torch.equal(a, b) for a, b in zip(outs[0], o)) for o in outs[1:])
+    assert all(torch.equal(ops.mha_relpos(qkv, pack, H), ops.mha_relpos(qkv, pack, H)) for _ in range(3))
