@@ -50,7 +50,9 @@ B, T, NBIN = 32, 400, 257
 N_SAMPLES = 512 + 256 * (T - 1)  # 102 656
 PEAK_BF16 = 2.5e15
 PEAK_HBM = 8.0e12
+LOSS_BUDGET = 1e-3   # PIT loss relative error, bf16 operands vs the fp32 oracle
 FLOP_PER_FRAME = 52.57e6  # Conformer-base forward @ T=400
+FLOP_PER_FRAME_7CH = 53.36e6  # same table, idim 1799
 
 
 def parse_args():
@@ -256,43 +258,99 @@ def main():
     dt, per_rank_ms, loss = timed(step, args.steps)
     loss_val = float(loss)
 
-    # ---- fwd mode: the TRAINING step of the same workload, same run (SURVEY 8d asks for train-mode throughput;
-    # configs[1]/[2] are training configurations).  With N > 1 this is the path that communicates.
-    train_rec = None
-    if args.mode == "fwd" and not args.no_train_step:
+    # ---- fwd mode: the TRAINING legs of the same workload, same run (SURVEY 8d asks for train-mode throughput;
+    # configs[1]/[2] are training configurations).  With N > 1 the training steps are the path that communicates.
+    train_rec = train7_rec = train_fwd_rec = None
+
+    def all_ranks_ok(ok):
+        """A leg that failed on ONE rank must not leave the others waiting in a collective: every rank learns
+        whether all ranks built the leg before any of them enters its timed region."""
+        if world == 1:
+            return ok
+        flag = torch.tensor([1.0 if ok else 0.0], device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item() > 0.5)
+
+    def train_leg(idim, features_fn, flop_per_frame, what, forward_only=False):
+        """One training-mode leg on its own model instance: GraphedTrainStep (forward, PIT, backward, all-reduce, clip +
+        Adam) or, forward_only, the train-mode forward + PIT alone (dropout, batch-statistics BatchNorm, everything the
+        backward needs kept - what iteration_types.py:34-50 runs before loss.backward()), captured and replayed."""
+        from css_amd.objectives import OBJECTIVES
+        from css_amd.optim import FusedAdam
+        from css_amd.trainer import GraphedTrainStep
+        err, run, tstep, toptim = None, None, None, None
         try:
-            from css_amd.objectives import OBJECTIVES
-            from css_amd.optim import FusedAdam
-            from css_amd.trainer import GraphedTrainStep
-            tmodel = MODELS["Conformer"](257, 257, 2, 1, conf)
-            tmodel.load_state_dict(sd)
+            tmodel = MODELS["Conformer"](idim, 257, 2, 1, conf)
+            tmodel.load_state_dict(sd if idim == 257 else syn.fill_state_dict(syn.conformer_shapes(idim=idim, num_blocks=args.blocks), 0))
             tmodel = tmodel.to(dev).train()
             tobj = OBJECTIVES["MSE"].build_objective({})
-            toptim = FusedAdam(tmodel.parameters(), lr=1e-4, max_norm=5.0)
+            if forward_only:
+                static = features_fn()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        tobj(tmodel, static, device=dev)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    static_loss = tobj(tmodel, static, device=dev).detach()
 
-            def tfeatures():
-                with torch.no_grad():
-                    mags = ops.stft(audio, ("mag",))["mag"]
-                return {"mix": mags[0], "source1": mags[1], "source2": mags[2]}
-            tstep = GraphedTrainStep(tmodel, tobj, toptim, tfeatures(), max_norm=5.0, device=dev, buckets=args.buckets)
-            for _ in range(2):
-                tstep(tfeatures())
-            tsteps = max(5, args.steps // 2)
-            tdt, tper_rank, tout = timed(lambda: tstep(tfeatures())[0], tsteps)
-            tms = tdt / tsteps * 1e3
-            train_rec = {"metric": "STFT-frames/sec (training step: fwd+PIT+bwd+all-reduce+clip/Adam) Conformer-1ch",
-                         "ms_per_step": tms, "value": world * B * T / (tdt / tsteps), "unit": "frames/s", "steps": tsteps,
-                         "whole_step_frac": 3.0 * B * T * FLOP_PER_FRAME * args.blocks / 16 / (tdt / tsteps) / PEAK_BF16,
-                         "mode": "train-mode forward (dropout 0.1, batch-statistics BatchNorm) + PIT + explicit backward + "
-                                 "gradient all-reduce (N > 1) + fused clip/Adam; captured HIP graph replay",
-                         "loss": float(tout), "per_rank_ms_per_step": tper_rank,
-                         "collective_backend": (backend if world > 1 else None),
-                         "world_size": dist.get_world_size() if world > 1 else 1,
-                         "allreduce_bytes_per_step": int(toptim.flat_grad.numel() * 4) if world > 1 else 0,
-                         "allreduce_schedule": ([hi - lo for lo, hi in tstep.plan] if world > 1 else None)}
-            del tstep, toptim, tmodel
-        except Exception as e:  # noqa: BLE001  (the headline line must not die with the extra leg)
-            train_rec = {"error": f"{type(e).__name__}: {e}"}
+                def run():
+                    feats = features_fn()
+                    for k in static:
+                        static[k].copy_(feats[k], non_blocking=True)
+                    g.replay()
+                    return static_loss
+            else:
+                toptim = FusedAdam(tmodel.parameters(), lr=1e-4, max_norm=5.0)
+                tstep = GraphedTrainStep(tmodel, tobj, toptim, features_fn(), max_norm=5.0, device=dev, buckets=args.buckets)
+
+                def run():
+                    return tstep(features_fn())[0]
+        except Exception as e:  # noqa: BLE001  (the headline line must not die with an extra leg)
+            err = f"{type(e).__name__}: {e}"
+        if not all_ranks_ok(err is None):
+            return {"error": err or "the leg failed on another rank"}
+        for _ in range(2):
+            run()
+        tsteps = max(5, args.steps // 2)
+        tdt, tper_rank, tout = timed(run, tsteps)
+        rec = {"metric": what, "ms_per_step": tdt / tsteps * 1e3, "value": world * B * T / (tdt / tsteps), "unit": "frames/s",
+               "steps": tsteps, "idim": idim, "loss": float(tout), "per_rank_ms_per_step": tper_rank,
+               "whole_step_frac": (1.0 if forward_only else 3.0) * B * T * flop_per_frame * args.blocks / 16 / (tdt / tsteps) / PEAK_BF16}
+        if not forward_only:
+            rec.update({"collective_backend": (backend if world > 1 else None),
+                        "world_size": dist.get_world_size() if world > 1 else 1,
+                        "allreduce_bytes_per_step": int(toptim.flat_grad.numel() * 4) if world > 1 else 0,
+                        "allreduce_schedule": ([hi - lo for lo, hi in tstep.plan] if world > 1 else None)})
+        return rec
+
+    if args.mode == "fwd" and not args.no_train_step:
+        def tfeatures():
+            with torch.no_grad():
+                mags = ops.stft(audio, ("mag",))["mag"]
+            return {"mix": mags[0], "source1": mags[1], "source2": mags[2]}
+        train_fwd_rec = train_leg(257, tfeatures, FLOP_PER_FRAME, "STFT-frames/sec (TRAIN-mode fwd+PIT: dropout 0.1, batch-statistics "
+                                  "BatchNorm, activations kept for the backward; no backward) Conformer-1ch", forward_only=True)
+        train_rec = train_leg(257, tfeatures, FLOP_PER_FRAME, "STFT-frames/sec (training step: fwd+PIT+bwd+all-reduce+clip/Adam) Conformer-1ch")
+        if train_rec and "error" not in train_rec:
+            train_rec["mode"] = ("train-mode forward (dropout 0.1, batch-statistics BatchNorm) + PIT + explicit backward + "
+                                 "gradient all-reduce (N > 1) + fused clip/Adam; captured HIP graph replay")
+        # configs[2]: the 7-channel training step (IPD features [32, 400, 1799] from raw 7-channel audio, idim 1799)
+        from css_amd.executor.feature import FeatureExtractor
+        x7 = syn.synthetic_multichannel(src, n_ch=7, seed=rank).to(dev)          # [B, 7, n]
+        fe7 = FeatureExtractor(512, 256, True, "1,0;2,0;3,0;4,0;5,0;6,0")
+
+        def tfeatures7():
+            with torch.no_grad():
+                _, f7, _, _ = fe7.forward_tf(x7, want_spectra=False)
+                tg = ops.stft(audio[1:3], ("mag",))["mag"]
+            return {"mix": f7, "source1": tg[0], "source2": tg[1]}
+        train7_rec = train_leg(257 * 7, tfeatures7, FLOP_PER_FRAME_7CH, "STFT-frames/sec (training step, 7-channel IPD features "
+                               "idim 1799: features+fwd+PIT+bwd+all-reduce+clip/Adam) Conformer-7ch (configs[2])")
+        del x7
 
     # ---- rooflines from INSIDE the step: one un-captured eval step with the library's launch timeline on
     roof = None
@@ -316,16 +374,23 @@ def main():
         # GPU reads twice as long: cold caches, clock ramp)
         probe()
         probe()
+        lib.csship_debug_timeline_calibrate.argtypes = [C.c_void_p, C.c_int]
         lib.csship_debug_timeline(1)
         for _ in range(REPS):
             probe()
+            # empty brackets queued between two steps: what a bracket itself adds to the launch it times
+            lib.csship_debug_timeline_calibrate(C.c_void_p(torch.cuda.current_stream().cuda_stream), 8)
         torch.cuda.synchronize()
+        ems, en = C.c_double(0), C.c_int(0)
+        lib.csship_debug_timeline_read(11, C.byref(ems), C.byref(en))
+        bracket = ems.value * 1e-3 / max(en.value, 1)     # seconds per empty bracket
         tl = {}
         for tag, name in enumerate(("chain", "chain_edge", "attention", "outproj_conv", "embed", "head", "stft", "pit_sse",
                                     "pit_finalize", "mvn")):
             ms, n = C.c_double(0), C.c_int(0)
             lib.csship_debug_timeline_read(tag, C.byref(ms), C.byref(n))
-            tl[name] = (ms.value * 1e-3 / max(n.value, 1), n.value // REPS)  # (seconds per launch, launches per step)
+            # (seconds per launch with the bracket's own cost taken off, launches per step)
+            tl[name] = (max(ms.value * 1e-3 / max(n.value, 1) - bracket, 0.0) if n.value else 0.0, n.value // REPS)
         lib.csship_debug_timeline(0)
         if was_training:
             model.train()
@@ -336,10 +401,10 @@ def main():
         import hashlib
         hsh = hashlib.sha1()
         for fn in sorted(os.listdir(os.path.join(ROOT, "css_amd", "csrc"))):
-            if fn.endswith((".hip", ".hpp")):
+            if fn.endswith((".hip", ".hpp", ".inc")) and fn != "fft_tables.inc":   # (the generated table is not a source)
                 hsh.update(open(os.path.join(ROOT, "css_amd", "csrc", fn), "rb").read())
         csrc_sha = hsh.hexdigest()[:16]
-        for tp in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        for tp in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tp)
             if os.path.exists(tpath):
                 rec_all = json.load(open(tpath))
@@ -371,7 +436,9 @@ def main():
                 "achieved": flops / dur / 1e12 if dur else None, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                 "frac": flops / dur / PEAK_BF16 if dur else None, "traffic": traffic_of("chain_kernel<8, false, true, true, true, false>"),
                 "mfma_busy_pmc": busy_of("chain_kernel<8, false, true, true, true, false>"),
-                "avg_launch_us": dur * 1e6, "flops_per_launch": flops, "timing": "HIP events around the in-step launches",
+                "avg_launch_us": dur * 1e6, "flops_per_launch": flops,
+                "timing": "HIP event pair around every in-step launch, minus the measured cost of an empty pair",
+                "bracket_overhead_us": bracket * 1e6,
                 "pmc_source": pmc_src,
                 "whole_step_frac": (step_flops * (3.0 if args.mode == "train" else 1.0)) / (dt / args.steps) / PEAK_BF16}
         ad, an = tl["attention"]
@@ -412,6 +479,7 @@ def main():
                            "sse_us": tl["pit_sse"][0] * 1e6, "finalize_us": tl["pit_finalize"][0] * 1e6,
                            "bytes_per_frame": pit_bytes, "traffic": traffic_of("pit_sse_kernel")}
         roof["step_kernel_us"] = {k: round(v[0] * v[1] * 1e6, 1) for k, v in tl.items()}
+        roof["step_kernel_us_sum"] = round(sum(roof["step_kernel_us"].values()), 1)
 
     # ---- CPU baseline: the oracle on one full batch, host cores of this box
     cpu = None
@@ -446,8 +514,20 @@ def main():
         torch.set_num_threads(1)
         cpu_pass(nb1)
         runs1 = sorted(cpu_pass(nb1)[0] for _ in range(3))
+        # BASELINE.md section 3 says os.cpu_count(): the box's whole host (shared with other tenants, so the leg above on a
+        # <= 16-thread share stays the headline baseline); 1 warm-up + 2 timed passes, the faster one
+        allc = None
+        n_all = os.cpu_count() or cores
+        if n_all > cores and not os.environ.get("CSS_CPU_NO_ALLCORES"):
+            torch.set_num_threads(n_all)
+            cpu_pass(B)
+            runs_all = [cpu_pass(B)[0] for _ in range(2)]
+            allc = {"value": B * T / min(runs_all), "unit": "frames/s", "cores": n_all,
+                    "sample": f"forward+PIT of the full batch on torch.set_num_threads({n_all}) = os.cpu_count(): 1 warm-up + 2 "
+                              "timed passes, the faster one (a host shared with other jobs)",
+                    "seconds_per_pass": [round(r, 3) for r in runs_all]}
         torch.set_num_threads(cores)
-        cpu = {"value": B * T / cdt, "unit": "frames/s", "cores": cores, "kind": "port",
+        cpu = {"value": B * T / cdt, "unit": "frames/s", "cores": cores, "kind": "port", "all_cores": allc,
                "sample": f"forward+PIT of the full batch (B={B} x T={T} frames, fp32, torch {torch.__version__} CPU ops): "
                          f"1 warm-up + 3 timed passes, median",
                "seconds_per_pass": [round(r[0], 3) for r in runs], "cpu_model": cpu_model, "host_cpu_count": os.cpu_count(),
@@ -456,6 +536,12 @@ def main():
                                  "seconds_per_pass": [round(r, 3) for r in runs1]},
                "loss": runs[-1][1], "gpu_loss": loss_val if args.mode == "fwd" else None}
 
+    parity = None
+    if cpu is not None and cpu.get("gpu_loss") is not None:
+        rel = abs(cpu["gpu_loss"] - cpu["loss"]) / abs(cpu["loss"])
+        parity = {"gpu_loss": cpu["gpu_loss"], "cpu_loss": cpu["loss"], "rel_err": rel, "budget": LOSS_BUDGET,
+                  "margin": 1.0 - rel / LOSS_BUDGET, "ok": bool(rel < LOSS_BUDGET),
+                  "what": "PIT-MSE loss of the timed batch: HIP path (bf16 operands) vs the fp32 oracle, SURVEY 8d budget"}
     if rank == 0:
         frames = world * B * T * args.steps
         mode_txt = ("eval forward (running-stat BN, no dropout)" if args.mode == "fwd" else
@@ -477,10 +563,15 @@ def main():
                        "ranks_launched_by": ("launcher" if "TORCHELASTIC_RUN_ID" in os.environ or "GROUP_RANK" in os.environ
                                              else ("bench.py --gpus" if world > 1 else None))},
             "per_rank_ms_per_step": per_rank_ms,
-            "roofline": roof, "cpu_baseline": cpu, "train_step": train_rec, "loss": loss_val,
+            "roofline": roof, "cpu_baseline": cpu, "train_fwd_pit": train_fwd_rec, "train_step": train_rec,
+            "train_step_7ch": train7_rec, "loss": loss_val, "loss_parity": parity,
         }
         print(json.dumps(line))
         sys.stdout.flush()
+        if parity is not None and not parity["ok"]:
+            print(f"[bench] PARITY FAILURE: loss {parity['gpu_loss']:.6f} vs oracle {parity['cpu_loss']:.6f}: relative error "
+                  f"{parity['rel_err']:.2e} >= {LOSS_BUDGET:.0e}", file=sys.stderr)
+            sys.exit(3)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -168,7 +168,8 @@ enum {
   CSSHIP_TL_PIT_FINALIZE = 8,
   CSSHIP_TL_MVN = 9,
   CSSHIP_TL_OTHER = 10,
-  CSSHIP_TL_NTAGS = 11
+  CSSHIP_TL_EMPTY = 11,     /* csship_debug_timeline_calibrate: event pairs with nothing between them */
+  CSSHIP_TL_NTAGS = 12
 };
 extern bool g_csship_timeline_on;
 void csship_timeline_push(int tag, hipStream_t s, bool stop);

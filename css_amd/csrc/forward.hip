@@ -158,6 +158,15 @@ extern "C" void csship_debug_timeline(int enable) {
   g_tl.clear();
   g_csship_timeline_on = enable != 0;
 }
+// `pairs` empty brackets on `stream` (tag CSSHIP_TL_EMPTY): what a bracket itself adds to the launch it times.
+extern "C" void csship_debug_timeline_calibrate(csship_stream_t stream_, int pairs) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (!g_csship_timeline_on) return;
+  for (int i = 0; i < pairs; ++i) {
+    csship_timeline_push(CSSHIP_TL_EMPTY, stream, false);
+    csship_timeline_push(CSSHIP_TL_EMPTY, stream, true);
+  }
+}
 // After the caller has synchronised the stream: total milliseconds and number of launches recorded under `tag`.
 extern "C" int csship_debug_timeline_read(int tag, double* total_ms, int* count) {
   double t = 0.0; int n = 0;

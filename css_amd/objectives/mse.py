@@ -11,6 +11,15 @@ import torch
 from .. import ops
 
 
+def model_device(model, device):
+    """``device`` unless it is the reference's default "cpu" and the model's parameters are on a GPU."""
+    if str(device) == "cpu":
+        p = next(iter(model.parameters()), None)
+        if p is not None and p.is_cuda:
+            return p.device
+    return device
+
+
 class MeanSquaredError(torch.nn.Module):
     @staticmethod
     def add_args(parser):
@@ -28,7 +37,11 @@ class MeanSquaredError(torch.nn.Module):
         super().__init__()
         self.last_permutation = None
 
-    def forward(self, model, sample, device="cuda"):
+    def forward(self, model, sample, device="cpu"):
+        """Same signature and default as mse.py:22.  There is no CPU path here: the reference's default ``"cpu"`` can only
+        mean "where the model is", so with a model that lives on a GPU the batch follows the model (a caller that relies
+        on the default, as train_one_epoch's own default does, gets the reference's behaviour, not a device mismatch)."""
+        device = model_device(model, device)
         xs = sample["mix"].to(device)
         y1, y2 = sample["source1"].to(device), sample["source2"].to(device)
         if hasattr(model, "forward_masks"):  # css_amd model: fused mask-apply + PIT

@@ -42,7 +42,6 @@ class FusedAdam(torch.optim.Optimizer):
         self._hyper = torch.zeros(3, dtype=torch.float32, device=dev)
         self._hyper_host = torch.zeros((16, 3), dtype=torch.float32).pin_memory()  # one staging slot per step in flight
         self._hyper_events = [None] * 16
-        self.capturable = False
         with torch.no_grad():
             for p, o in zip(params, offs):
                 seg = self.flat_param[o:o + p.numel()].view(p.shape)
@@ -63,9 +62,11 @@ class FusedAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         mn = g["max_norm"] if max_norm is None else max_norm
         # lr and the bias corrections (computed in double on the host, like torch.optim.Adam) are read from device
-        # memory.  Eager mode uploads them here; in capturable mode the caller does (advance_hyper() before every
-        # replay), so eager and graph-replayed training are bit-identical.
-        if not self.capturable:
+        # memory.  A step launched kernel by kernel uploads them here; a step that is being CAPTURED does not (the
+        # host code runs once, the graph many times): GraphedTrainStep calls advance_hyper() before every replay, so
+        # eager and replayed steps are bit-identical and may be mixed freely (the decision is per call, not a mode of
+        # the optimiser: train_one_epoch runs shapes it has not captured eagerly between replays).
+        if not torch.cuda.is_current_stream_capturing():
             self.advance_hyper()
         hyper, step = self._hyper, 0
         bump_param_generation()  # the kernel below rewrites the parameter storage: weight-shadow caches are stale
@@ -76,11 +77,11 @@ class FusedAdam(torch.optim.Optimizer):
         return self.grad_norm
 
     def advance_hyper(self):
-        """capturable mode: count one step and upload {lr, bias corrections} for it (asynchronous pinned copy on the
-        current stream, ordered before the graph replay that follows)."""
+        """Count one step and upload {lr, bias corrections} for it (asynchronous pinned copy on the current stream,
+        ordered before the kernel launch or graph replay that follows).  step() calls it unless it is being captured."""
         g = self.param_groups[0]
         self._step += 1
-        bump_param_generation()  # capturable mode: the replayed graph rewrites the parameter storage after this call
+        bump_param_generation()  # replayed steps: the graph rewrites the parameter storage after this call
         # The copy is asynchronous and the host may be several steps ahead of the GPU: every step stages its values in
         # its own pinned slot, reused only after the copy that read it has completed (a single staging buffer would be
         # overwritten with a later step's values before an earlier copy ran).

@@ -68,7 +68,8 @@ def allreduce_gradients(params, average=True):
     key = tuple(id(p) for p in params)
     b = _BUCKETS.get(key)
     if b is None:
-        for k in [k for k, v in _BUCKETS.items() if any(q.grad is None and q not in params for q in v.params)]:
+        mine = set(key)   # identities: `q in params` would compare tensors element-wise
+        for k in [k for k, v in _BUCKETS.items() if any(q.grad is None and id(q) not in mine for q in v.params)]:
             del _BUCKETS[k]   # buckets of models that are gone
         b = _BUCKETS[key] = GradBucket(params)
     else:

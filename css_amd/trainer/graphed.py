@@ -36,7 +36,6 @@ class GraphedTrainStep:
         self.model, self.objective, self.optim, self.max_norm = model, objective, optim, max_norm
         self.keys = [k for k in ("mix", "source1", "source2") if k in example_batch]
         self.static = {k: example_batch[k].to(device).clone() for k in self.keys}
-        optim.capturable = True
         # warm-up steps outside the capture (allocator pools, lazy initialisation) must not train: snapshot every
         # piece of state they touch and put it back
         if hasattr(model, "conformer"):   # buffers that the training forward re-homes must be in place before the snapshot
@@ -58,11 +57,9 @@ class GraphedTrainStep:
         try:
             with torch.cuda.stream(side):
                 for _ in range(warmup):
-                    optim.advance_hyper()
                     self._eager(collective=False)   # ranks capture at different times: no collective in here
         except Exception:   # a step that cannot run: leave model and optimiser as they were, eager-capable
             restore()
-            optim.capturable = False
             raise
         torch.cuda.current_stream().wait_stream(side)
         restore()
@@ -77,9 +74,8 @@ class GraphedTrainStep:
                 self.graph_opt = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph_opt, pool=self.graphs[0].pool(), capture_error_mode="thread_local"):
                     self.grad_norm = self.optim.step(max_norm=self.max_norm)
-        except Exception:   # the capture does not execute anything, but a failed one must not leave the optimiser capturable
+        except Exception:   # the capture does not execute anything; put back what the warm-up touched
             restore()
-            optim.capturable = False
             raise
 
     def _capture_distributed(self, blocks_per_bucket):

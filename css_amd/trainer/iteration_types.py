@@ -16,6 +16,7 @@ from collections import OrderedDict
 import torch
 
 from .. import ops, parallel
+from ..objectives.mse import model_device
 
 
 def _graphed_step(args, model, objective, optim, b, device):
@@ -56,6 +57,7 @@ def _graphed_step(args, model, objective, optim, b, device):
 
 
 def train_one_epoch(args, generator, model, objective, optim, lr_sched, device="cpu"):
+    device = model_device(model, device)   # the reference's default "cpu" = "where the model is" (objectives/mse.py)
     total_loss = 0.0
     reducer = None
     for i in range(1, args.batches_per_epoch + 1):
@@ -73,6 +75,10 @@ def train_one_epoch(args, generator, model, objective, optim, lr_sched, device="
             continue
         if reducer is None and hasattr(optim, "flat_grad") and parallel.is_distributed():
             reducer = parallel.OverlappedGradReducer(model, optim, blocks_per_bucket=getattr(args, "blocks_per_bucket", 4))
+        if hasattr(optim, "flat_grad"):
+            # a replayed step leaves its (averaged) gradients in the flat buffer and the explicit backward ACCUMULATES
+            # into the .grad views: an eager step that follows a replay starts from a zeroed buffer, like the replay does
+            optim.zero_grad()
         loss = objective(model, b, device=device)
         if not loss.requires_grad:
             raise RuntimeError("css_amd: loss has no grad_fn (model parameters frozen or grad disabled)")
@@ -102,6 +108,7 @@ def train_one_epoch(args, generator, model, objective, optim, lr_sched, device="
 
 def validate(generator, model, objective, device="cpu", num_batches=100):
     """100 dev batches, mean loss (iteration_types.py:67-77); the mean stays a tensor like the reference's."""
+    device = model_device(model, device)
     was_training = model.training
     model.eval()
     with torch.no_grad():

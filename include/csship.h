@@ -856,9 +856,13 @@ int csship_doa_likelihood(const float* x_re, const float* x_im, const float* mas
  * csship_debug_timeline_read: after the caller synchronised the stream, total milliseconds and number of launches
  * recorded under `tag` (CSSHIP_TL_* in css_amd/csrc/common.hpp: 0 chain, 1 chain edge, 2 attention, 3 out-proj+conv,
  * 4 embed, 5 head, 6 stft, 7 pit sse, 8 pit finalize, 9 mvn, 10 other).
+ * csship_debug_timeline_calibrate: records `pairs` EMPTY event pairs (nothing launched between the two records) on
+ * `stream` under tag 11: their mean elapsed time is what a bracket adds to every launch it times (two timestamp packets
+ * the launch is serialised behind); bench.py subtracts it, so that the per-launch times add up to no more than the step.
  * csship_debug_stamps: device buffer that -D*_STAMPS diagnostic builds fill with s_memtime phase stamps; NULL = off. */
 void csship_debug_timeline(int enable);
 int csship_debug_timeline_read(int tag, double* total_ms, int* count);
+void csship_debug_timeline_calibrate(csship_stream_t stream, int pairs);
 void csship_debug_stamps(void* device_buffer);
 
 #ifdef __cplusplus

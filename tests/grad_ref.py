@@ -23,7 +23,15 @@ def oracle_masks(model, f, training_bn, drop=None):
         if v.is_floating_point():
             v.requires_grad_(True)
     f = f.detach().cpu()
-    if hasattr(model, "conformer"):
+    if hasattr(model, "conformer") and model.conformer.idim != model.num_bins:
+        # 7-channel IPD features: the reference's own forward raises at `mask * f_orig` (conformer.py:103, widths differ),
+        # so the oracle is evaluated up to the masks - conformer.py:95-101: MVN over time, encoder, Linear, ReLU, chunk
+        enc = model.conformer
+        h = oracle.conformer.encoder(oracle.conformer.mvn_time(f), sd, n_head=enc.n_head, kernel_size=enc.kernel_size,
+                                     num_blocks=len(enc.encoders), relative_pos_emb=enc.pos_emb is not None,
+                                     training_bn=training_bn, **({"drop": drop} if drop is not None else {}))
+        masks = (torch.relu(torch.nn.functional.linear(h, sd["linear.weight"], sd["linear.bias"])),)
+    elif hasattr(model, "conformer"):
         enc = model.conformer
         _, masks = oracle.conformer.forward(f, sd, num_spk=model.num_spk, num_noise=model.num_noise, n_head=enc.n_head,
                                             kernel_size=enc.kernel_size, num_blocks=len(enc.encoders),
@@ -39,7 +47,7 @@ def pit_loss_with_perm(masks, f, targets, perm, nbins=257):
     B = f.shape[0]
     tot = 0
     for b in range(B):
-        est = torch.stack([masks[b, :, perm[b][i] * nbins:(perm[b][i] + 1) * nbins] * f[b] for i in range(len(targets))])
+        est = torch.stack([masks[b, :, perm[b][i] * nbins:(perm[b][i] + 1) * nbins] * f[b][:, :nbins] for i in range(len(targets))])
         tot = tot + ((est - torch.stack([t[b] for t in targets])) ** 2).mean()
     return tot / B
 

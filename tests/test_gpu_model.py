@@ -341,6 +341,42 @@ def test_graphed_step_cache_is_bounded_and_first_sight_runs_eager():
     assert [k[3][1][1] for k in st["cache"]] == [32, 40]   # key = (model, objective, clip, ("mix", shape), ...)
 
 
+def test_mixed_eager_and_replayed_steps_equal_the_eager_loop():
+    """Shapes alternate the way the reference's random 2-5 s windows do (separation.py:94-95,175): a shape seen for the
+    first time runs eagerly BETWEEN replays of captured shapes, and an evicted shape runs eagerly again.  Every eager
+    step after a replay must (a) advance the step count / upload lr and the Adam bias corrections itself and (b) start
+    from a zeroed gradient buffer (the replay leaves its gradients in it and the explicit backward accumulates): losses,
+    parameters, Adam moments and the step count equal the graph=False loop bit for bit, with the warm-up schedule
+    changing the rate every step and dropout on (both high findings)."""
+    import types
+    from css_amd.objectives import OBJECTIVES
+    from css_amd.optim import FusedAdam
+    from css_amd.trainer import LRScheduler, train_one_epoch
+    frames = [24, 24, 32, 24, 32, 32, 40, 24, 40, 40, 24]
+
+    def gen():
+        for i, t in enumerate(frames):
+            yield {"mix": rnd((2, t, 257), 200 + i).abs().to(DEV), "source1": (rnd((2, t, 257), 300 + i).abs() * 0.5).to(DEV),
+                   "source2": (rnd((2, t, 257), 400 + i).abs() * 0.5).to(DEV), "ovl": 0.5}
+
+    def run(graph):
+        m, _ = build(1, 61)
+        m.train()
+        opt = FusedAdam(m.parameters(), lr=1e-3, max_norm=5.0)
+        sch = LRScheduler(opt, types.SimpleNamespace(warmup=5, decay=1e-2, fixed=0, min_lr=1e-9))
+        targs = types.SimpleNamespace(gpu=True, fp16=False, batches_per_epoch=1, grad_thresh=5.0, graph=graph, graph_cache=2)
+        g, obj = gen(), OBJECTIVES["MSE"].build_objective({})
+        losses = [train_one_epoch(targs, g, m, obj, opt, sch, DEV) for _ in frames]
+        replayed = sum(v is not None for v in getattr(opt, "_graphed_steps", {"cache": {}})["cache"].values())
+        return losses, opt.flat_param.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt._step, replayed
+    l_e, p_e, m_e, v_e, s_e, n_e = run(False)
+    l_g, p_g, m_g, v_g, s_g, n_g = run(True)
+    assert n_e == 0 and n_g == 2            # something WAS replayed in the second run
+    assert s_e == s_g == len(frames)        # every step, eager or replayed, counted once
+    assert l_e == l_g, (l_e, l_g)
+    assert torch.equal(p_e, p_g) and torch.equal(m_e, m_g) and torch.equal(v_e, v_g)
+
+
 def test_conformer_gradients_flow_and_match_oracle_autograd():
     """Gradient check of the training path on a 1-block Conformer with BatchNorm frozen (model.eval() +
     eval_gradients): loss.backward() fills every parameter's grad, and the gradients agree with torch.autograd through

@@ -60,9 +60,9 @@ for k, v in vals.items():
 import hashlib, os
 hsh = hashlib.sha1()
 for fn in sorted(os.listdir("css_amd/csrc")):
-    if fn.endswith((".hip", ".hpp")):
+    if fn.endswith((".hip", ".hpp", ".inc")) and fn != "fft_tables.inc":
         hsh.update(open(os.path.join("css_amd/csrc", fn), "rb").read())
-out["_meta"] = {"csrc_sha": hsh.hexdigest()[:16], "command": "python bench.py --steps 3 --warmup 1 --no-cpu-baseline",
+out["_meta"] = {"csrc_sha": hsh.hexdigest()[:16], "command": "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train-step",
                 "note": "bench.py quotes traffic / mfma_busy from this file only while csrc_sha matches the tree"}
 json.dump(out, open("gpurun_out/${tag}_pmc.json", "w"), indent=1)
 for k, e in sorted(((k, e) for k, e in out.items() if k != "_meta"), key=lambda kv: -kv[1].get("hbm_bytes_per_launch", 0)):
