@@ -79,6 +79,15 @@ def parse_args():
     return ap.parse_args()
 
 
+_T0 = time.time()
+
+
+def progress(msg):
+    """a line on stderr per phase: a long silent run is taken to be hung on the GPU box"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench] t={time.time() - _T0:6.1f}s {msg}", file=sys.stderr, flush=True)
+
+
 def spawn_ranks(n):
     """Start n rank processes of this script (fresh interpreters: nothing here has touched a GPU) and wait."""
     with socket.socket() as s:
@@ -255,8 +264,10 @@ def main():
             d = max(float(g.item()) for g in gathered)
         return d, per_rank, out
 
+    progress(f"warm-up done ({'graph replay' if graphed else 'eager'}); timing {args.steps} steps")
     dt, per_rank_ms, loss = timed(step, args.steps)
     loss_val = float(loss)
+    progress(f"headline: {dt / args.steps * 1e3:.4f} ms/step")
 
     # ---- fwd mode: the TRAINING legs of the same workload, same run (SURVEY 8d asks for train-mode throughput;
     # configs[1]/[2] are training configurations).  With N > 1 the training steps are the path that communicates.
@@ -332,8 +343,10 @@ def main():
             with torch.no_grad():
                 mags = ops.stft(audio, ("mag",))["mag"]
             return {"mix": mags[0], "source1": mags[1], "source2": mags[2]}
+        progress("leg: train-mode forward + PIT")
         train_fwd_rec = train_leg(257, tfeatures, FLOP_PER_FRAME, "STFT-frames/sec (TRAIN-mode fwd+PIT: dropout 0.1, batch-statistics "
                                   "BatchNorm, activations kept for the backward; no backward) Conformer-1ch", forward_only=True)
+        progress(f"leg: training step ({train_fwd_rec.get('ms_per_step', train_fwd_rec)} ms train fwd+PIT)")
         train_rec = train_leg(257, tfeatures, FLOP_PER_FRAME, "STFT-frames/sec (training step: fwd+PIT+bwd+all-reduce+clip/Adam) Conformer-1ch")
         if train_rec and "error" not in train_rec:
             train_rec["mode"] = ("train-mode forward (dropout 0.1, batch-statistics BatchNorm) + PIT + explicit backward + "
@@ -348,10 +361,12 @@ def main():
                 _, f7, _, _ = fe7.forward_tf(x7, want_spectra=False)
                 tg = ops.stft(audio[1:3], ("mag",))["mag"]
             return {"mix": f7, "source1": tg[0], "source2": tg[1]}
+        progress(f"leg: 7-channel training step ({train_rec.get('ms_per_step', train_rec)} ms 1ch)")
         train7_rec = train_leg(257 * 7, tfeatures7, FLOP_PER_FRAME_7CH, "STFT-frames/sec (training step, 7-channel IPD features "
                                "idim 1799: features+fwd+PIT+bwd+all-reduce+clip/Adam) Conformer-7ch (configs[2])")
         del x7
 
+    progress("in-step launch timeline")
     # ---- rooflines from INSIDE the step: one un-captured eval step with the library's launch timeline on
     roof = None
     if rank == 0:
@@ -507,8 +522,10 @@ def main():
                 return time.perf_counter() - c0, float(closs)
         # >= 1 warm-up + >= 3 timed iterations, all cores and one thread
         torch.set_num_threads(cores)
+        progress(f"cpu baseline: oracle on {cores} threads")
         cpu_pass(B)
         runs = [cpu_pass(B) for _ in range(3)]
+        progress(f"cpu baseline: {runs[0][0]:.2f} s per pass; one thread, 4 chunks")
         cdt = sorted(r[0] for r in runs)[1]   # median of 3
         nb1 = 4                                # one thread: a bounded sample (4 of the 32 chunks)
         torch.set_num_threads(1)
@@ -519,9 +536,14 @@ def main():
         allc = None
         n_all = os.cpu_count() or cores
         if n_all > cores and not os.environ.get("CSS_CPU_NO_ALLCORES"):
+            progress(f"cpu baseline: all {n_all} host threads")
             torch.set_num_threads(n_all)
-            cpu_pass(B)
-            runs_all = [cpu_pass(B)[0] for _ in range(2)]
+            warm = cpu_pass(B)[0]
+            progress(f"cpu baseline: all-cores warm-up pass {warm:.2f} s")
+            runs_all = []
+            for _ in range(2):
+                runs_all.append(cpu_pass(B)[0])
+                progress(f"cpu baseline: all-cores pass {runs_all[-1]:.2f} s")
             allc = {"value": B * T / min(runs_all), "unit": "frames/s", "cores": n_all,
                     "sample": f"forward+PIT of the full batch on torch.set_num_threads({n_all}) = os.cpu_count(): 1 warm-up + 2 "
                               "timed passes, the faster one (a host shared with other jobs)",

@@ -152,12 +152,21 @@ def test_config3_seven_channel_training_gradients_vs_oracle():
     tc = [x.cpu() for x in tg]
     of = lambda mk: grad_ref.pit_loss_with_perm(mk, f.cpu(), tc, perm)   # noqa: E731
     ref = grad_ref.oracle_param_grads(m, of, f, training_bn=True)
-    err, worst = grad_ref.compare(grads, ref)
-    e_emb = grad_ref.compare({"conformer.embed.0.weight": grads["conformer.embed.0.weight"]}, ref)[0]
-    print(f"[parity] config 3 training, 7ch idim 1799 (2 blocks): gradients vs oracle autograd {err:.3e}, worst {worst[0]} "
-          f"{worst[1]:.3e}; embedding weight [256, 1799] {e_emb:.3e}")
-    assert err < 3e-2 and worst[1] < 0.15 and e_emb < 3e-2
     ref16 = grad_ref.oracle_param_grads(m, of, f, training_bn=True, emulate_bf16=True)
+    err, worst = grad_ref.compare(grads, ref)
+    floor, floor_worst = grad_ref.compare({k: v for k, v in ref16.items()}, ref)   # what bf16 operands alone cost
+    emb = "conformer.embed.0.weight"
+    e_emb = grad_ref.compare({emb: grads[emb]}, ref)[0]
+    e_emb16 = grad_ref.compare({emb: grads[emb]}, ref16)[0]
+    f_emb = grad_ref.compare({emb: ref16[emb]}, ref)[0]
+    print(f"[parity] config 3 training, 7ch idim 1799 (2 blocks): gradients vs fp32 oracle autograd {err:.3e} (worst {worst[0]} "
+          f"{worst[1]:.3e}); the bf16-operand oracle itself vs fp32 {floor:.3e} (worst {floor_worst[0]} {floor_worst[1]:.3e}); "
+          f"embedding weight [256, 1799]: {e_emb:.3e} vs fp32, {e_emb16:.3e} vs bf16-operand oracle (which is {f_emb:.3e} from fp32)")
+    for k, e, d in grad_ref.per_parameter(grads, ref16)[:6]:
+        print(f"    vs bf16-operand oracle: {k:55s} rel {e:.3e}  |ref| {d:.3e}")
+    # the HIP path is no farther from the fp32 graph than its own arithmetic (bf16 operands, f32 accumulation) evaluated on
+    # the CPU is, and tight against that evaluation (same bounds as the 1-channel test)
+    assert err < max(3e-2, 1.5 * floor) and e_emb < max(3e-2, 1.5 * f_emb)
     g16, w16 = grad_ref.check_against_emulation(grads, ref16, global_tol=2.5e-2, param_tol=0.12)
     print(f"[parity] ... vs the bf16-operand oracle: global {g16:.3e}, worst live parameter {w16[0]} {w16[1]:.3e}")
 
