@@ -77,6 +77,7 @@ BEPI_OUT_BF16, BEPI_MASK_POS, BEPI_ADD, BEPI_SCALE_BIAS, BEPI_RELU = 1, 2, 4, 8,
 EPI_RELU, EPI_RESIDUAL, EPI_LAYERNORM, EPI_OUT_BF16 = 1, 2, 4, 8
 PRO_LN, PRO_BF16, PRO_F32 = 0, 1, 2
 CHAIN_QKV_IL8 = 1
+CHAIN_W2_CHUNKED = 2
 
 # name -> (restype, argtypes); mirrors include/csship.h one to one
 SIGNATURES = {

@@ -17,9 +17,12 @@ DEV float bf2f(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) short s16x2;
 // two f32 -> packed bf16 pair (round to nearest even): ONE v_cvt_pk_bf16_f32 (two scalar casts + shift/or took 3-4)
+typedef __attribute__((ext_vector_type(2))) float f32x2_cvt;
 DEV unsigned pack_bf2(float lo, float hi) {
-  const bf16x2 v = {(__bf16)lo, (__bf16)hi};
-  return __builtin_bit_cast(unsigned, v);
+  // ONE vector fptrunc: two scalar casts + a build_vector are fused into v_cvt_pk_bf16_f32 only some of the time (values
+  // coming out of MFMA accumulators were converted one by one against a zero and merged with v_perm_b32: 3 instructions)
+  const f32x2_cvt f = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
 }
 // max(x, 0) on a packed bf16 pair: as signed 16-bit integers every negative bf16 (sign bit set, -0 included) is < 0
 DEV unsigned relu_bf2(unsigned p) {

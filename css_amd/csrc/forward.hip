@@ -288,7 +288,7 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
                                  N.mha.wqkv, N.mha.bqkv, ws.qkv_bf, M, D, FF, 3 * D, w->chain_flags, stream));
       } else {
         TRY(csship_encoder_chain(x, x, gbuf, &L.conv, T, &L.ffn_out, L.ln_g, L.ln_b, nullptr, nullptr, nullptr, nullptr,
-                                 nullptr, nullptr, M, D, FF, 0, 0, stream));
+                                 nullptr, nullptr, M, D, FF, 0, w->chain_flags & CSSHIP_CHAIN_W2_CHUNKED, stream));
       }
     }
   } else {
@@ -335,7 +335,7 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
     // the last FeedForward + block LayerNorm writes the encoder output where the caller wants it (no copy afterwards)
     float* const xo = enc_out ? enc_out : x;
     TRY(csship_encoder_chain(x, xo, nullptr, nullptr, T, &L.ffn_out, L.ln_g, L.ln_b, nullptr, nullptr, nullptr, nullptr,
-                             nullptr, nullptr, M, D, FF, 0, 0, stream));
+                             nullptr, nullptr, M, D, FF, 0, w->chain_flags & CSSHIP_CHAIN_W2_CHUNKED, stream));
     x = xo;
   }
   if (enc_out && x != enc_out) {

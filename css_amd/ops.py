@@ -501,6 +501,14 @@ def pack_frag(w):
     return wp.contiguous().to(torch.bfloat16).view(-1)
 
 
+def pack_frag_chunked(w, chunk=256):
+    """[R, K] -> the K / chunk column blocks of w, each in pack_frag's order, one after the other
+    (CSSHIP_CHAIN_W2_CHUNKED, include/csship.h): a pass of the chain kernel over one hidden chunk reads one contiguous run."""
+    R, K = w.shape
+    assert K % chunk == 0
+    return torch.cat([pack_frag(w[:, c:c + chunk]) for c in range(0, K, chunk)])
+
+
 def il8_row_order(R, device=None):
     """Row order of the 8-feature interleaved packing (CSSHIP_CHAIN_QKV_IL8, include/csship.h): packed row 16*tile + m
     holds feature 32*(tile//2) + 8*(m//4) + 4*(tile%2) + m%4, so that the chain kernel's lane (g, token row) - which

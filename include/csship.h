@@ -311,8 +311,13 @@ int csship_outproj_glu(const uint16_t* attn_out, const uint16_t* wo_packed, cons
  * flags: CSSHIP_CHAIN_QKV_IL8 = wqkv_packed / bqkv rows are in the 8-feature interleaved order of
  * css_amd.ops.pack_frag_il8 (packed row 16*tile + m holds feature 32*(tile/2) + 8*(m/4) + 4*(tile%2) + m%4), with which
  * a lane's results are 8 consecutive features of a token row and qkv_out is written with 16-byte stores
- * (n_qkv % 32 == 0); qkv_out itself is in natural feature order either way. */
+ * (n_qkv % 32 == 0); qkv_out itself is in natural feature order either way.
+ * CSSHIP_CHAIN_W2_CHUNKED = both FeedForwards' w2 are packed chunk by chunk (css_amd.ops.pack_frag_chunked): the
+ * [256, d_ffn] matrix cut into d_ffn / 256 column blocks, each in the fragment order above, one after the other - block
+ * (chunk c, tile t, k-step ks) at ((c * 16 + t) * 8 + ks) * 64 lanes.  A pass over one hidden chunk then reads one
+ * contiguous 128 KB run. */
 #define CSSHIP_CHAIN_QKV_IL8 1
+#define CSSHIP_CHAIN_W2_CHUNKED 2
 struct csship_ffn_weights_s;
 int csship_encoder_chain(const float* x, float* x_out, const float* conv_g,
                          const struct csship_conv_weights_s* conv_w, int32_t T,

@@ -56,3 +56,33 @@ def ffn_emulation(other="bf16"):
         yield
     finally:
         _conformer._lin = orig
+
+
+@contextlib.contextmanager
+def attention_emulation(scores=True, pv=True, other="bf16"):
+    """Inside the block oracle.conformer evaluates the attention's matrix products (conformer.py:229-253) on MXFP8 operands,
+    quantised along the REDUCTION dimension of each product in blocks of 32 (what a block-scaled MFMA would consume):
+    ``scores``: q k^T and q pe^T (reduction over d_k = 64: two blocks per row of q / k / pe); ``pv``: P v (reduction over the
+    keys: P in blocks of 32 consecutive keys of a query row, v in blocks of 32 consecutive keys of a feature column).
+    Products that are not selected, and every Linear, use ``other`` operands ("bf16" = the HIP path, "fp32" = exact).
+    Used by tools/fp8_attn_budget.py to price "fp8 MFMA attention" (BASELINE.json configs[4]) before building a kernel."""
+    orig_lin, orig_mm = _conformer._lin, _conformer._mm
+    rnd = _bf16 if other == "bf16" else (lambda t: t)
+
+    def mm(a, b):
+        is_pv = a.shape[-1] != 64 or (b.shape[-2] != 64)      # P [.., T, T] x v [.., T, 64]; the score products reduce over d_k = 64
+        if a.shape[-1] == 64 and b.shape[-2] == 64:
+            is_pv = False
+        if (is_pv and pv) or (not is_pv and scores):
+            return torch.matmul(quantize(a), quantize(b.transpose(-1, -2)).transpose(-1, -2))
+        return torch.matmul(rnd(a), rnd(b))
+
+    def lin(x, sd, p):
+        return F.linear(rnd(x), rnd(sd[p + ".weight"]), sd[p + ".bias"])
+    _conformer._mm = mm
+    if other == "bf16":
+        _conformer._lin = lin
+    try:
+        yield
+    finally:
+        _conformer._lin, _conformer._mm = orig_lin, orig_mm
