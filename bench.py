@@ -74,6 +74,7 @@ def parse_args():
     ap.add_argument("--blocks", type=int, default=16, help="debug only: anything but 16 is not the headline config")
     ap.add_argument("--overlap-stft", action="store_true", help="debug A/B (measured SLOWER, 1.46 vs 1.43 ms): the two target "
                     "spectrograms on a second stream beside the encoder, joined before the loss kernel")
+    ap.add_argument("--no-q-log2e", action="store_true", help="debug A/B: attention with the explicit exponent scaling")
     ap.add_argument("--no-ln-fold", action="store_true", help="debug A/B: keep the LayerNorm affines out of the weights and "
                     "the q/k/v rows in natural order (the round-2 form of the chain kernel's inputs)")
     return ap.parse_args()
@@ -171,6 +172,8 @@ def main():
         model.fuse_conv = args.fuse_conv
     if args.no_ln_fold:
         model.no_ln_fold = True
+    if args.no_q_log2e:
+        model.no_q_log2e = True
 
     mix, src = syn.synthetic_sources(B, N_SAMPLES, seed=rank)
     audio = torch.stack([mix, src[0], src[1]], 0).to(dev)  # [3, B, n]
@@ -195,15 +198,15 @@ def main():
             # the 14 us it takes off the critical path), kept as the experiment it was.
             with torch.no_grad():
                 if not args.overlap_stft:
-                    mags = ops.stft(audio, ("mag",))["mag"]  # [3,B,T,257]
+                    mags = ops.stft(audio, ("mag",), pad_rows=True)["mag"]  # [3,B,T,257]
                     loss, perm, _ = model.forward_loss(mags[0], [mags[1], mags[2]])
                     return loss
                 main = torch.cuda.current_stream()
                 side_stream.wait_stream(main)
                 box = {}
                 with torch.cuda.stream(side_stream):
-                    box["t"] = ops.stft(audio[1:3], ("mag",))["mag"]   # [2,B,T,257]
-                mix_mag = ops.stft(audio[0], ("mag",))["mag"]           # [B,T,257]
+                    box["t"] = ops.stft(audio[1:3], ("mag",), pad_rows=True)["mag"]   # [2,B,T,257]
+                mix_mag = ops.stft(audio[0], ("mag",), pad_rows=True)["mag"]           # [B,T,257]
                 loss, perm, _ = model.forward_loss(mix_mag, lambda: [box["t"][0], box["t"][1]],
                                                    before_head=lambda: main.wait_stream(side_stream))
             return loss
@@ -246,7 +249,7 @@ def main():
 
         def features():
             with torch.no_grad():
-                mags = ops.stft(audio, ("mag",))["mag"]
+                mags = ops.stft(audio, ("mag",), pad_rows=True)["mag"]
             return {"mix": mags[0], "source1": mags[1], "source2": mags[2]}
         if args.no_graph:
             from css_amd import parallel
@@ -363,7 +366,7 @@ def main():
     if args.mode == "fwd" and not args.no_train_step:
         def tfeatures():
             with torch.no_grad():
-                mags = ops.stft(audio, ("mag",))["mag"]
+                mags = ops.stft(audio, ("mag",), pad_rows=True)["mag"]
             return {"mix": mags[0], "source1": mags[1], "source2": mags[2]}
         progress("leg: train-mode forward + PIT")
         train_fwd_rec = train_leg(257, tfeatures, FLOP_PER_FRAME, "STFT-frames/sec (TRAIN-mode fwd+PIT: dropout 0.1, batch-statistics "
@@ -381,7 +384,7 @@ def main():
         def tfeatures7():
             with torch.no_grad():
                 _, f7, _, _ = fe7.forward_tf(x7, want_spectra=False)
-                tg = ops.stft(audio[1:3], ("mag",))["mag"]
+                tg = ops.stft(audio[1:3], ("mag",), pad_rows=True)["mag"]
             return {"mix": f7, "source1": tg[0], "source2": tg[1]}
         progress(f"leg: 7-channel training step ({train_rec.get('ms_per_step', train_rec)} ms 1ch)")
         train7_rec = train_leg(257 * 7, tfeatures7, FLOP_PER_FRAME_7CH, "STFT-frames/sec (training step, 7-channel IPD features "
@@ -404,7 +407,7 @@ def main():
 
         def probe():
             with torch.no_grad():
-                mags = ops.stft(audio, ("mag",))["mag"]
+                mags = ops.stft(audio, ("mag",), pad_rows=True)["mag"]
                 if calib[0]:   # empty brackets queued in the MIDDLE of a step (the stream is busy on both sides of them)
                     lib.csship_debug_timeline_calibrate(C.c_void_p(torch.cuda.current_stream().cuda_stream), 4)
                 model.forward_loss(mags[0], [mags[1], mags[2]])

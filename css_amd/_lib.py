@@ -77,13 +77,15 @@ BEPI_OUT_BF16, BEPI_MASK_POS, BEPI_ADD, BEPI_SCALE_BIAS, BEPI_RELU = 1, 2, 4, 8,
 EPI_RELU, EPI_RESIDUAL, EPI_LAYERNORM, EPI_OUT_BF16 = 1, 2, 4, 8
 PRO_LN, PRO_BF16, PRO_F32 = 0, 1, 2
 CHAIN_QKV_IL8 = 1
-CHAIN_W2_CHUNKED = 2
+FWD_Q_LOG2E = 4
+MHA_Q_LOG2E = 1
 
 # name -> (restype, argtypes); mirrors include/csship.h one to one
 SIGNATURES = {
     "csship_version": (_i32, []),
     "csship_strerror": (C.c_char_p, [_i32]),
     "csship_stft": (_i32, [_p, _i64, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _p]),
+    "csship_stft_ld": (_i32, [_p, _i64, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _p]),
     "csship_stft_logpower": (_i32, [_p, _i64, _i64, _i64, _i64, _i64, _f32, _p, _p]),
     "csship_mix_workspace": (_sz, [_i32]),
     "csship_mix_batch": (_i32, [_p, _i64, _i32, _p, _i64, _i32, _p, _i32, _i32, _p, _p, _p, _i64, _p, _sz, _p]),
@@ -110,6 +112,7 @@ SIGNATURES = {
     "csship_encoder_chain": (_i32, [_p, _p, _p, C.POINTER(ConvWeights), _i32, C.POINTER(FfnWeights), _p, _p,
                                      C.POINTER(FfnWeights), _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "csship_mha_relpos": (_i32, [_p, _p, _i32, _i32, _p, _i32, _i32, _i32, _p]),
+    "csship_mha_relpos_ex": (_i32, [_p, _p, _i32, _i32, _p, _i32, _i32, _i32, _i32, _p]),
     "csship_outproj_conv": (_i32, [_p, _p, _p, _p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _p]),
     "csship_ffn_bwd_workspace": (_sz, [_i32]),
     "csship_ffn_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _p, _sz, _p]),
@@ -189,7 +192,7 @@ SIGNATURES = {
     "csship_linear_res_wide": (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _p]),
     "csship_ffn_mx": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _p]),
     "csship_head_pit_workspace": (_sz, [_i32, _i32]),
-    "csship_head_pit": (_i32, [_p, _p, _p, _p, _i64, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
+    "csship_head_pit": (_i32, [_p, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
     "csship_debug_timeline": (None, [_i32]),
     "csship_debug_timeline_read": (_i32, [_i32, C.POINTER(C.c_double), C.POINTER(_i32)]),
     "csship_debug_timeline_calibrate": (None, [_p, _i32]),

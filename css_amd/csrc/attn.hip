@@ -133,7 +133,14 @@ struct MhaBwdArgs {
   unsigned short* q_rows;      // optional bf16 [B*T*H, 64]: the q rows in ds_skew's row order (operand of d(pe_window))
 };
 
-template <int NW, bool DROP, bool PROBS = false, bool BWD = false>
+// LOG2Q (inference only: no DROP, no PROBS, no lse): q arrives pre-scaled by log2(e) / sqrt(d_k) (the caller folded the
+// factor into the q rows of the projection), so scores and position band come out of the MFMAs in log2 units, and the
+// band accumulators start at MINUS the running reference (m_run, in log2 units) instead of zero - the band of tile j+1 is
+// computed after tile j's maximum is known.  The exponent argument is then the accumulator itself: the 32 fused
+// multiply-adds per lane and tile are gone, and so is the cross-lane maximum unless some lane's scores exceed the
+// reference (then, in a wave-uniform branch, the classic step: the reference moves up, what has been accumulated is
+// rescaled and the tile's scores are brought onto the new reference).  Tile 0 establishes the reference explicitly.
+template <int NW, bool DROP, bool PROBS = false, bool BWD = false, bool LOG2Q = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mha_fwd_kernel(const unsigned short* __restrict__ qkv,
                                                             const bf16x8* __restrict__ pe_packed, int q_min, int q_max,
                                                             unsigned short* __restrict__ out, float* __restrict__ lse,
@@ -142,6 +149,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mha_fwd_kernel(const
                                                             unsigned short* __restrict__ pdrop = nullptr, int ldp = 0,
                                                             MhaBwdArgs bw = MhaBwdArgs{}) {
   static_assert(!BWD || PROBS, "the backward pass recomputes the probabilities");
+  static_assert(!LOG2Q || (!DROP && !PROBS), "LOG2Q is the inference form");
   constexpr int CH = 512 / (NW * 64);  // 16-byte chunks of a K (and of a V) tile staged per thread
   constexpr int R = 2 * NW + 8;        // ring slots (position blocks of 2 x 1 KB): 2 NW + 4 live + 4 arriving
   constexpr int NF = 8 / NW;           // new fragments staged per wave and tile
@@ -285,7 +293,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mha_fwd_kernel(const
     for (int qb = 0; qb < 2; ++qb)
       ebase[qb] = ((unsigned)bh * (unsigned)T + (unsigned)min(i0w + 16 * qb + n, T - 1)) * Tp + 4u * (unsigned)g;
   }
-  float m_run[2] = {-1e30f, -1e30f};
+  float m_run[2] = {LOG2Q ? 0.f : -1e30f, LOG2Q ? 0.f : -1e30f};
   float lse2[2] = {0.f, 0.f};  // PROBS: log-sum-exp of this lane's two queries, in log2 units
   if constexpr (PROBS) {
 #pragma unroll
@@ -326,7 +334,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mha_fwd_kernel(const
     rs0 = rs0 - 4 + (rs0 < 4 ? R : 0); /* the next tile's window sits four blocks lower */                               \
     f32x4 pb[2][5];                                                                                                      \
     _Pragma("unroll") for (int qb = 0; qb < 2; ++qb) {                                                                   \
-      _Pragma("unroll") for (int t = 0; t < 5; ++t) pb[qb][t] = f32x4{0.f, 0.f, 0.f, 0.f};                               \
+      const float bi_ = LOG2Q ? -m_run[qb] : 0.f;                                                                        \
+      _Pragma("unroll") for (int t = 0; t < 5; ++t) pb[qb][t] = f32x4{bi_, bi_, bi_, bi_};                               \
       _Pragma("unroll") for (int t = 0; t < 5; ++t)                                                                      \
         pb[qb][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[t + 1 - qb][0], qf[qb][0], pb[qb][t], 0, 0, 0);           \
       _Pragma("unroll") for (int t = 0; t < 5; ++t)                                                                      \
@@ -430,7 +439,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mha_fwd_kernel(const
 // Host side of mha_fwd_kernel: pairs of 16-query blocks, dealt to workgroups of 8 (or 4) waves.
 static int launch_mha_fwd(const uint16_t* qkv, const uint16_t* pe_packed, int q_min, int q_max, uint16_t* out, float* lse,
                           int B, int T, int H, unsigned long long* stamps, hipStream_t s,
-                          const csship_dropout_cfg* drop = nullptr) {
+                          const csship_dropout_cfg* drop = nullptr, bool log2q = false) {
   const int P = (T + 31) / 32, BH = B * H;
   // 8 waves unless 4-wave workgroups are needed to give every CU one (short utterances, small batches)
   const int G8 = (P + 7) / 8, G4 = (P + 3) / 4;
@@ -442,7 +451,12 @@ static int launch_mha_fwd(const uint16_t* qkv, const uint16_t* pe_packed, int q_
   if (dropping && (int64_t)BH * T * ((T + 7) / 8 * 8) > 0xffffffffLL) return CSSHIP_EBADSHAPE;  // 32-bit element indices
   const csship_dropout_cfg dc = dropping ? *drop : csship_dropout_cfg{nullptr, 0u, 0.f};
   const bf16x8* pe = reinterpret_cast<const bf16x8*>(pe_packed);
-  if (four && dropping)
+  if (log2q && (dropping || lse != nullptr)) return CSSHIP_EUNSUPPORTED;  // the log2-domain form is the inference form
+  if (log2q && four)
+    hipLaunchKernelGGL((mha_fwd_kernel<4, false, false, false, true>), dim3((unsigned)nwg), dim3(256), 0, s, qkv, pe, q_min, q_max, out, lse, BH, T, H, G, ppw, stamps, dc);
+  else if (log2q)
+    hipLaunchKernelGGL((mha_fwd_kernel<8, false, false, false, true>), dim3((unsigned)nwg), dim3(512), 0, s, qkv, pe, q_min, q_max, out, lse, BH, T, H, G, ppw, stamps, dc);
+  else if (four && dropping)
     hipLaunchKernelGGL((mha_fwd_kernel<4, true>), dim3((unsigned)nwg), dim3(256), 0, s, qkv, pe, q_min, q_max, out, lse, BH, T, H, G, ppw, stamps, dc);
   else if (four)
     hipLaunchKernelGGL((mha_fwd_kernel<4, false>), dim3((unsigned)nwg), dim3(256), 0, s, qkv, pe, q_min, q_max, out, lse, BH, T, H, G, ppw, stamps, dc);
@@ -612,10 +626,17 @@ __global__ __launch_bounds__(256, 4) void attn_ds_kernel(const unsigned short* _
 
 extern "C" int csship_mha_relpos(const uint16_t* qkv, const uint16_t* pe_packed, int32_t q_min, int32_t q_max,
                                  uint16_t* out, int32_t B, int32_t T, int32_t H, csship_stream_t stream) {
+  return csship_mha_relpos_ex(qkv, pe_packed, q_min, q_max, out, B, T, H, 0, stream);
+}
+
+extern "C" int csship_mha_relpos_ex(const uint16_t* qkv, const uint16_t* pe_packed, int32_t q_min, int32_t q_max,
+                                    uint16_t* out, int32_t B, int32_t T, int32_t H, int32_t flags, csship_stream_t stream) {
   if (!qkv || !pe_packed || !out) return CSSHIP_ENULL;
   if (B <= 0 || T <= 0 || H <= 0 || q_max < q_min || B > 65535 || H > 65535) return CSSHIP_EBADSHAPE;
+  if (flags & ~CSSHIP_MHA_Q_LOG2E) return CSSHIP_EUNSUPPORTED;
   if (!aligned16(qkv) || !aligned16(pe_packed) || !aligned8(out)) return CSSHIP_EALIGN;
-  return launch_mha_fwd(qkv, pe_packed, q_min, q_max, out, nullptr, B, T, H, g_csship_stamps, as_stream(stream));
+  return launch_mha_fwd(qkv, pe_packed, q_min, q_max, out, nullptr, B, T, H, g_csship_stamps, as_stream(stream), nullptr,
+                        (flags & CSSHIP_MHA_Q_LOG2E) != 0);
 }
 
 extern "C" int csship_mha_relpos_train(const uint16_t* qkv, const uint16_t* pe_packed, int32_t q_min, int32_t q_max,

@@ -107,7 +107,8 @@ int forward_generic(const csship_conformer_weights* w, const float* f, int64_t l
       TRY(csship_layernorm(x, M, D, L.mha.ln_g, L.mha.ln_b, ws.a_bf, nullptr, stream));
       TRY(tiled_linear(ws.a_bf, CSSHIP_A_BF16, L.mha.wqkv, L.mha.bqkv, nullptr, ws.qkv_bf, M, 3 * D, D, D, BF, 0.f, stream));
     }
-    TRY(csship_mha_relpos(ws.qkv_bf, w->pe_k, w->pe_q_min, w->pe_q_max, ws.ao_bf, B, T, w->n_head, stream));
+    TRY(csship_mha_relpos_ex(ws.qkv_bf, w->pe_k, w->pe_q_min, w->pe_q_max, ws.ao_bf, B, T, w->n_head,
+                                   (w->chain_flags & CSSHIP_FWD_Q_LOG2E) ? CSSHIP_MHA_Q_LOG2E : 0, stream));
     if (w->lin_mode == 1) {
       TRY(csship_linear_res_wide(ws.ao_bf, L.mha.wo, L.mha.bo, x, x, M, D, stream));
     } else {
@@ -277,18 +278,19 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
     float* gbuf = y;  // glu(LN_conv(x)) rows handed from the output projection to the next chain
     TRY(csship_encoder_chain(x, x, nullptr, nullptr, T, nullptr, nullptr, nullptr, &w->layers[0].ffn_in,
                              w->layers[0].mha.ln_g, w->layers[0].mha.ln_b, w->layers[0].mha.wqkv,
-                             w->layers[0].mha.bqkv, ws.qkv_bf, M, D, FF, 3 * D, w->chain_flags, stream));
+                             w->layers[0].mha.bqkv, ws.qkv_bf, M, D, FF, 3 * D, w->chain_flags & ~CSSHIP_FWD_Q_LOG2E, stream));
     for (int l = 0; l < w->n_layer; ++l) {
       const csship_layer_weights& L = w->layers[l];
-      TRY(csship_mha_relpos(ws.qkv_bf, w->pe_k, w->pe_q_min, w->pe_q_max, ws.ao_bf, B, T, w->n_head, stream));
+      TRY(csship_mha_relpos_ex(ws.qkv_bf, w->pe_k, w->pe_q_min, w->pe_q_max, ws.ao_bf, B, T, w->n_head,
+                                   (w->chain_flags & CSSHIP_FWD_Q_LOG2E) ? CSSHIP_MHA_Q_LOG2E : 0, stream));
       TRY(csship_outproj_glu(ws.ao_bf, L.mha.wo, L.mha.bo, x, x, &L.conv, gbuf, M, D, stream));
       if (l + 1 < w->n_layer) {
         const csship_layer_weights& N = w->layers[l + 1];
         TRY(csship_encoder_chain(x, x, gbuf, &L.conv, T, &L.ffn_out, L.ln_g, L.ln_b, &N.ffn_in, N.mha.ln_g, N.mha.ln_b,
-                                 N.mha.wqkv, N.mha.bqkv, ws.qkv_bf, M, D, FF, 3 * D, w->chain_flags, stream));
+                                 N.mha.wqkv, N.mha.bqkv, ws.qkv_bf, M, D, FF, 3 * D, w->chain_flags & ~CSSHIP_FWD_Q_LOG2E, stream));
       } else {
         TRY(csship_encoder_chain(x, x, gbuf, &L.conv, T, &L.ffn_out, L.ln_g, L.ln_b, nullptr, nullptr, nullptr, nullptr,
-                                 nullptr, nullptr, M, D, FF, 0, w->chain_flags & CSSHIP_CHAIN_W2_CHUNKED, stream));
+                                 nullptr, nullptr, M, D, FF, 0, 0, stream));
       }
     }
   } else {
@@ -305,12 +307,13 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
         TimelineScope tl(P ? CSSHIP_TL_CHAIN : CSSHIP_TL_CHAIN_EDGE, as_stream(stream));
         TRY(csship_encoder_chain(x, x, nullptr, nullptr, T, P ? &P->ffn_out : nullptr, P ? P->ln_g : nullptr,
                                  P ? P->ln_b : nullptr, &L.ffn_in, L.mha.ln_g, L.mha.ln_b, L.mha.wqkv, L.mha.bqkv,
-                                 ws.qkv_bf, M, D, FF, 3 * D, w->chain_flags, stream));
+                                 ws.qkv_bf, M, D, FF, 3 * D, w->chain_flags & ~CSSHIP_FWD_Q_LOG2E, stream));
       }
       {
         if (nodep) stream = g_nodep.next();
         TimelineScope tl(CSSHIP_TL_ATTN, as_stream(stream));
-        TRY(csship_mha_relpos(ws.qkv_bf, w->pe_k, w->pe_q_min, w->pe_q_max, ws.ao_bf, B, T, w->n_head, stream));
+        TRY(csship_mha_relpos_ex(ws.qkv_bf, w->pe_k, w->pe_q_min, w->pe_q_max, ws.ao_bf, B, T, w->n_head,
+                                   (w->chain_flags & CSSHIP_FWD_Q_LOG2E) ? CSSHIP_MHA_Q_LOG2E : 0, stream));
       }
       if (w->bn_mode == 0 && conv_mode == 2) {
         // optional (28.4 vs 27.2 us): x += out-proj(attn); g = glu(LN_conv(x)) in the same epilogue; conv back half from g
@@ -335,7 +338,7 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
     // the last FeedForward + block LayerNorm writes the encoder output where the caller wants it (no copy afterwards)
     float* const xo = enc_out ? enc_out : x;
     TRY(csship_encoder_chain(x, xo, nullptr, nullptr, T, &L.ffn_out, L.ln_g, L.ln_b, nullptr, nullptr, nullptr, nullptr,
-                             nullptr, nullptr, M, D, FF, 0, w->chain_flags & CSSHIP_CHAIN_W2_CHUNKED, stream));
+                             nullptr, nullptr, M, D, FF, 0, 0, stream));
     x = xo;
   }
   if (enc_out && x != enc_out) {

@@ -32,9 +32,9 @@ struct HeadPitArgs {
   const bf16x8* w;       // permuted head rows in fragment order: (K * 16 + 1) tiles x 8 k-steps x 64 lanes
   const float* bias;     // permuted the same way, (K * 16 + 1) * 16 floats
   const float* f;        // f_orig f32 [M, ldf]
-  const float* tgt[KSPK];  // targets f32 [M, 257] dense
+  const float* tgt[KSPK];  // targets f32 [M, ldt]
   float* partial;        // [n_workgroups][2 slots][K * K]
-  int64_t ldf;
+  int64_t ldf, ldt;
   int M, T;
 };
 
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(512) void head_pit_kernel(HeadPitArgs a) {
       const int bin = (wave * NT + t) * 16 + 4 * g;
       fo[t][rt] = load4(a.f + (size_t)rc * a.ldf + bin);
 #pragma unroll
-      for (int j = 0; j < K; ++j) tg[j][t][rt] = load4(a.tgt[j] + (size_t)rc * NF + bin);
+      for (int j = 0; j < K; ++j) tg[j][t][rt] = load4(a.tgt[j] + (size_t)rc * a.ldt + bin);
     }
   }
   // bare barrier behind lgkmcnt(0) only: __syncthreads() would also wait for the 24 loads above (vmcnt(0)) and put
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(512) void head_pit_kernel(HeadPitArgs a) {
           const float fv = a.f[(size_t)row * a.ldf + 256];
           float tv[K];
 #pragma unroll
-          for (int j = 0; j < K; ++j) tv[j] = a.tgt[j][(size_t)row * NF + 256];
+          for (int j = 0; j < K; ++j) tv[j] = a.tgt[j][(size_t)row * a.ldt + 256];
 #pragma unroll
           for (int k = 0; k < K; ++k) {
             const float y = fmaxf(acc[rt][k], 0.f) * fv;
@@ -266,16 +266,16 @@ extern "C" size_t csship_head_pit_workspace(int32_t B, int32_t T) {
 }
 
 extern "C" int csship_head_pit(const float* x_enc, const uint16_t* w_perm_packed, const float* bias_perm, const float* f_orig,
-                               int64_t ld_f, const float* const* targets_host, int32_t B, int32_t T, int32_t F, int32_t K,
+                               int64_t ld_f, const float* const* targets_host, int64_t ld_t, int32_t B, int32_t T, int32_t F, int32_t K,
                                int32_t d_model, float* loss, int32_t* perm, float* pair_sse, void* workspace,
                                size_t workspace_bytes, csship_stream_t stream) {
   if (!x_enc || !w_perm_packed || !bias_perm || !f_orig || !targets_host || !loss || !workspace) return CSSHIP_ENULL;
-  if (B <= 0 || T <= 0 || B > 1024 || (int64_t)B * T > 0x7fffffff / 1024 || ld_f < F) return CSSHIP_EBADSHAPE;
+  if (B <= 0 || T <= 0 || B > 1024 || (int64_t)B * T > 0x7fffffff / 1024 || ld_f < F || ld_t < F) return CSSHIP_EBADSHAPE;
   if (K != KSPK || F != NF || d_model != DM || T < BM) return CSSHIP_EUNSUPPORTED;
   if (!aligned16(x_enc) || !aligned16(w_perm_packed) || !aligned16(bias_perm)) return CSSHIP_EALIGN;
   if (workspace_bytes < csship_head_pit_workspace(B, T)) return CSSHIP_EWORKSPACE;
   HeadPitArgs a{};
-  a.x = x_enc; a.w = reinterpret_cast<const bf16x8*>(w_perm_packed); a.bias = bias_perm; a.f = f_orig; a.ldf = ld_f;
+  a.x = x_enc; a.w = reinterpret_cast<const bf16x8*>(w_perm_packed); a.bias = bias_perm; a.f = f_orig; a.ldf = ld_f; a.ldt = ld_t;
   for (int k = 0; k < K; ++k) {
     if (!targets_host[k]) return CSSHIP_ENULL;
     a.tgt[k] = targets_host[k];

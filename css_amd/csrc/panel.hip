@@ -749,7 +749,6 @@ struct ChainArgs {
   float alpha;
   unsigned long long* stamps;  // -DP_STAMPS diagnostic builds only
   int qkv_il8;                 // wqkv / bqkv in the 8-feature interleaved row order (CSSHIP_CHAIN_QKV_IL8)
-  int w2_chunked;              // both FeedForwards' W2 packed chunk by chunk (CSSHIP_CHAIN_W2_CHUNKED)
   // TRAIN (csship_encoder_chain_train): the reference's dropouts of both FeedForwards (hidden [M, FF] and output
   // [M, 256], element indices as csship_ffn_fused_drop) and the rows the backward pass keeps: in front of stage A's
   // final LayerNorm (pre_ln_out) and behind it (ln_out = stage B's input)
@@ -804,19 +803,14 @@ struct StageTrain {  // what a training stage needs beyond the inference one
 template <int NW, bool FINAL_LN, bool TRAIN = false>
 DEV void ffn_stage(float4 (&v)[8], unsigned char* Xs, unsigned char* Hraw, const FfnW& f, const float* fin_g,
                    const float* fin_b, int FF, float alpha, int tid, int rot, unsigned long long* g_stamps_dev = nullptr,
-                   int st0 = 0, const StageTrain& tr = StageTrain{}, int w2_chunked = 0) {
+                   int st0 = 0, const StageTrain& tr = StageTrain{}) {
   constexpr int NT = 16 / NW;
   const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15, r = tid >> 3, part = tid & 7;
   const int nchunk = FF / DM, ks2 = FF / 32;
   unsigned char* const Hs0 = Hraw;
   unsigned char* const Hs1 = Hraw + PANEL_BYTES;
   const bf16x8* w1s = f.w1 + (size_t)(wave * NT) * KS * 64 + lane;
-  // W2 fragments: block (tile t, k-step ks) at (t * ks2 + ks) * 64 (csship.h), or - CSSHIP_CHAIN_W2_CHUNKED - the four
-  // 256-deep chunks packed one after the other, block (chunk c, t, ks) at ((c * 16 + t) * KS + ks) * 64: what the eight
-  // waves of a pass fetch at the same time is then ONE contiguous 128 KB run (like W1) instead of sixteen 8 KB runs 32 KB apart
-  const int w2ts = w2_chunked ? KS : ks2;
-  const bf16x8* w2s = f.w2 + (size_t)(wave * NT) * w2ts * 64 + lane;
-  const size_t w2cs = w2_chunked ? (size_t)16 * KS * 64 : (size_t)KS * 64;
+  const bf16x8* w2s = f.w2 + (size_t)(wave * NT) * ks2 * 64 + lane;
   bf16x8 wq[PD][NT];
   prefetch_first<NT>(wq, w1s + (size_t)(rot % nchunk) * 16 * KS * 64, KS, NT);
   rows_to_panel(Xs, v, f.ln_g, f.ln_b, r, part);
@@ -841,12 +835,12 @@ DEV void ffn_stage(float4 (&v)[8], unsigned char* Xs, unsigned char* Hraw, const
       for (int rt = 0; rt < 4; ++rt) h[t][rt] = f32x4{bb.x, bb.y, bb.z, bb.w};
     }
     const bf16x8* w1c = w1s + (size_t)c * 16 * KS * 64;
-    const bf16x8* w2c = w2s + (size_t)c * w2cs;
+    const bf16x8* w2c = w2s + (size_t)c * KS * 64;
 #ifdef P_STAMPS
     unsigned long long tq0_ = 0, tq1_ = 0, tq2_ = 0, tq3_ = 0, tq4_ = 0;
     if (st0 == 1) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tq0_)::"memory"); __builtin_amdgcn_sched_barrier(0); }
 #endif
-    mma_pass<NT>(h, Xs, n, g, NT, w1c, KS, w2c, w2ts, NT, wq);
+    mma_pass<NT>(h, Xs, n, g, NT, w1c, KS, w2c, ks2, NT, wq);
 #ifdef P_STAMPS
     if (st0 == 1) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tq1_)::"memory"); __builtin_amdgcn_sched_barrier(0); }
 #endif
@@ -881,7 +875,7 @@ DEV void ffn_stage(float4 (&v)[8], unsigned char* Xs, unsigned char* Hraw, const
 #pragma unroll
       for (int t = 0; t < NT; ++t) b2v[t] = *reinterpret_cast<const float4*>(f.b2 + (wave * NT + t) * 16 + 4 * g);
     }
-    mma_pass<NT>(o, hs, n, g, NT, w2c, w2ts, w1n, KS, ci + 1 < nchunk ? NT : 0, wq);
+    mma_pass<NT>(o, hs, n, g, NT, w2c, ks2, w1n, KS, ci + 1 < nchunk ? NT : 0, wq);
 #ifdef P_STAMPS
     if (st0 == 1 && g_stamps_dev != nullptr && (threadIdx.x & 63) == 0) {
       __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tq4_)::"memory"); __builtin_amdgcn_sched_barrier(0);
@@ -1030,7 +1024,7 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(ChainArgs a) {
   if constexpr (TRAIN) {
     if constexpr (HAS_A) {
       const StageTrain ta{drop_make(a.da_h.seed, a.da_h.stream, a.da_h.p), drop_make(a.da_o.seed, a.da_o.stream, a.da_o.p), m0, a.M, a.pre_ln_out};
-      ffn_stage<NW, true, true>(v, Xs, Hraw, a.fa, a.fin_g, a.fin_b, a.FF, a.alpha, tid, blockIdx.x, a.stamps, 1, ta, a.w2_chunked);
+      ffn_stage<NW, true, true>(v, Xs, Hraw, a.fa, a.fin_g, a.fin_b, a.FF, a.alpha, tid, blockIdx.x, a.stamps, 1, ta);
       if (a.ln_out != nullptr && row < a.M) {  // the next block's input: the backward of its first FeedForward needs it
 #pragma unroll
         for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(a.ln_out + (size_t)row * DM + (i * 8 + part) * 4) = v[i];
@@ -1038,12 +1032,12 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(ChainArgs a) {
     }
     if constexpr (HAS_B) {
       const StageTrain tb{drop_make(a.db_h.seed, a.db_h.stream, a.db_h.p), drop_make(a.db_o.seed, a.db_o.stream, a.db_o.p), m0, a.M, nullptr};
-      ffn_stage<NW, false, true>(v, Xs, Hraw, a.fb, nullptr, nullptr, a.FF, a.alpha, tid, blockIdx.x + 2, a.stamps, 5, tb, a.w2_chunked);
+      ffn_stage<NW, false, true>(v, Xs, Hraw, a.fb, nullptr, nullptr, a.FF, a.alpha, tid, blockIdx.x + 2, a.stamps, 5, tb);
     }
   } else {
-  if constexpr (HAS_A) ffn_stage<NW, true>(v, Xs, Hraw, a.fa, a.fin_g, a.fin_b, a.FF, a.alpha, tid, blockIdx.x, a.stamps, 1, StageTrain{}, a.w2_chunked);
+  if constexpr (HAS_A) ffn_stage<NW, true>(v, Xs, Hraw, a.fa, a.fin_g, a.fin_b, a.FF, a.alpha, tid, blockIdx.x, a.stamps, 1);
   P_T(4)
-  if constexpr (HAS_B) ffn_stage<NW, false>(v, Xs, Hraw, a.fb, nullptr, nullptr, a.FF, a.alpha, tid, blockIdx.x + 2, a.stamps, 5, StageTrain{}, a.w2_chunked);
+  if constexpr (HAS_B) ffn_stage<NW, false>(v, Xs, Hraw, a.fb, nullptr, nullptr, a.FF, a.alpha, tid, blockIdx.x + 2, a.stamps, 5);
   }
   P_T(8)
   if (row < a.M && !(P_ABL & 16)) {  // the residual stream the attention output projection adds to
@@ -1923,7 +1917,6 @@ static int encoder_chain_impl(const float* x, float* x_out, const float* conv_g,
   a.x = x; a.xout = x_out; a.M = M; a.FF = d_ffn; a.NQKV = n_qkv; a.alpha = 0.5f; a.g = conv_g; a.T = T;
   a.stamps = g_csship_stamps;
   a.qkv_il8 = (flags & CSSHIP_CHAIN_QKV_IL8) ? 1 : 0;
-  a.w2_chunked = (flags & CSSHIP_CHAIN_W2_CHUNKED) ? 1 : 0;
   if (CV) a.cv = ConvW{conv_w->dw_w, conv_w->dw_b, conv_w->bn_g, conv_w->bn_b, conv_w->bn_mean, conv_w->bn_var,
                        conv_w->pw2_w, conv_w->pw2_b};
   auto conv = [](const csship_ffn_weights* w) {
@@ -1951,7 +1944,7 @@ static int encoder_chain_impl(const float* x, float* x_out, const float* conv_g,
   // first form 50.1 us, second form 54.0 us (8 waves), 61.4 us (4 waves) - see the note above chain2_kernel
   static const int form = [] { const char* e = getenv("CSSHIP_CHAIN"); return e ? atoi(e) : 1; }();
   if (form != 1 && !CV && (A || Bs)) {
-    if ((A && !ffn_a->ln_g) || (Bs && !ffn_b->ln_g) || (Cq && !qkv_ln_g) || a.qkv_il8 || a.w2_chunked) return CSSHIP_EUNSUPPORTED;  // second form: plain weights only
+    if ((A && !ffn_a->ln_g) || (Bs && !ffn_b->ln_g) || (Cq && !qkv_ln_g) || a.qkv_il8) return CSSHIP_EUNSUPPORTED;  // second form: plain weights only
 #define C2_LAUNCH(W)                                                                                            \
   if (A && Bs && Cq) hipLaunchKernelGGL((chain2_kernel<W, true, true, true>), grid, dim3(W * 64), 0, s, a);      \
   else if (!A && Bs && Cq) hipLaunchKernelGGL((chain2_kernel<W, false, true, true>), grid, dim3(W * 64), 0, s, a); \

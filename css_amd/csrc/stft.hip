@@ -50,7 +50,7 @@ template <bool MAG_ONLY, bool LOGPOW = false>
 __global__ __launch_bounds__(256, STFT_MINW) void stft_kernel(const float* __restrict__ audio, int64_t n1, int64_t stride0,
                                                    int64_t stride1, int64_t n_samples, int T, int fw,
                                                    float* __restrict__ mag, float* __restrict__ re,
-                                                   float* __restrict__ im, float* __restrict__ pha, float eps = 0.f) {
+                                                   float* __restrict__ im, float* __restrict__ pha, int64_t ld, float eps = 0.f) {
   __shared__ __attribute__((aligned(16))) cplx sz[4][NC * FFT_SCRATCH];
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
   const int64_t s = blockIdx.y;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256, STFT_MINW) void stft_kernel(const float* __res
     for (int c = 0; c < NC; ++c) {
       if (c == 1 && fi >= nB) continue;  // wave-uniform
       const int t = tw0 + (c == 0 ? 0 : nA) + fi;
-      const size_t orow = ((size_t)s * T + t) * NBIN;
+      const size_t orow = ((size_t)s * T + t) * (size_t)ld;
       const cplx* zc = zs + c * FFT_SCRATCH;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -192,12 +192,20 @@ extern "C" int csship_debug_stft_stamps(void* dst) {
 #endif
 
 static int stft_launch(const float* audio, int64_t n0, int64_t stride0, int64_t n1, int64_t stride1, int64_t n_samples,
-                       float* mag, float* re, float* im, float* pha, bool logpow, float eps, csship_stream_t stream);
+                       float* mag, float* re, float* im, float* pha, bool logpow, float eps, csship_stream_t stream,
+                       int64_t ld = NBIN);
 
 extern "C" int csship_stft(const float* audio, int64_t n0, int64_t stride0, int64_t n1, int64_t stride1,
                            int64_t n_samples, float* mag, float* re, float* im, float* pha,
                            csship_stream_t stream) {
   return stft_launch(audio, n0, stride0, n1, stride1, n_samples, mag, re, im, pha, false, 0.f, stream);
+}
+
+extern "C" int csship_stft_ld(const float* audio, int64_t n0, int64_t stride0, int64_t n1, int64_t stride1,
+                              int64_t n_samples, float* mag, float* re, float* im, float* pha, int64_t ld_out,
+                              csship_stream_t stream) {
+  if (ld_out < NBIN) return CSSHIP_EBADSHAPE;
+  return stft_launch(audio, n0, stride0, n1, stride1, n_samples, mag, re, im, pha, false, 0.f, stream, ld_out);
 }
 
 extern "C" int csship_stft_logpower(const float* audio, int64_t n0, int64_t stride0, int64_t n1, int64_t stride1,
@@ -207,7 +215,8 @@ extern "C" int csship_stft_logpower(const float* audio, int64_t n0, int64_t stri
 }
 
 static int stft_launch(const float* audio, int64_t n0, int64_t stride0, int64_t n1, int64_t stride1, int64_t n_samples,
-                       float* mag, float* re, float* im, float* pha, bool logpow, float eps, csship_stream_t stream) {
+                       float* mag, float* re, float* im, float* pha, bool logpow, float eps, csship_stream_t stream,
+                       int64_t ld) {
   if (!audio || (!mag && !re && !im && !pha)) return CSSHIP_ENULL;
   if (n0 <= 0 || n1 <= 0 || n_samples < 512) return CSSHIP_EBADSHAPE;
   if (!aligned16(audio) || (stride0 % 4) != 0 || (stride1 % 4) != 0) return CSSHIP_EALIGN;
@@ -242,13 +251,13 @@ static int stft_launch(const float* audio, int64_t n0, int64_t stride0, int64_t 
   TimelineScope tl(CSSHIP_TL_STFT, as_stream(stream));
   if (logpow)
     hipLaunchKernelGGL((stft_kernel<true, true>), grid, dim3(256), 0, as_stream(stream), audio, n1, stride0, stride1,
-                       n_samples, (int)T, fw, mag, re, im, pha, eps);
+                       n_samples, (int)T, fw, mag, re, im, pha, ld, eps);
   else if (mag && !re && !im && !pha)
     hipLaunchKernelGGL(stft_kernel<true>, grid, dim3(256), 0, as_stream(stream), audio, n1, stride0, stride1, n_samples,
-                       (int)T, fw, mag, re, im, pha);
+                       (int)T, fw, mag, re, im, pha, ld);
   else
     hipLaunchKernelGGL(stft_kernel<false>, grid, dim3(256), 0, as_stream(stream), audio, n1, stride0, stride1,
-                       n_samples, (int)T, fw, mag, re, im, pha);
+                       n_samples, (int)T, fw, mag, re, im, pha, ld);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }

@@ -163,7 +163,8 @@ class Conformer(nn.Module):
         # param_generation(): FusedAdam rewrites parameter storage without touching data_ptr / _version
         from .. import param_generation
         return (self.training, getattr(self, "fuse_conv", False), getattr(self, "force_generic", False),
-                getattr(self, "no_ln_fold", False), getattr(self, "no_w2_chunked", False), bool(self.fp8_ffn),
+                getattr(self, "no_ln_fold", False), getattr(self, "no_q_log2e", False),
+                bool(self.fp8_ffn),
                 getattr(self, "unfused_ffn", False),
                 param_generation()) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
@@ -194,8 +195,9 @@ class Conformer(nn.Module):
         # them (ops.fold_layernorm; the chain kernel's prologues then read no LayerNorm parameters), and the q | k | v
         # rows are packed in the 8-feature interleave that lets the chain kernel store 16 bytes per lane
         fold = not generic and not bool(getattr(self, "no_ln_fold", False))
-        # ... and W2 of every FeedForward chunk by chunk (ops.pack_frag_chunked, CSSHIP_CHAIN_W2_CHUNKED)
-        w2_chunked = fold and not bool(getattr(self, "no_w2_chunked", False)) and enc.d_ffn % 256 == 0
+        # ... and the q rows carry log2(e) as well as 1 / sqrt(d_k): the attention kernel's exponentials then take the
+        # scores as the matrix products deliver them (CSSHIP_MHA_Q_LOG2E)
+        q_log2e = fold and not bool(getattr(self, "no_q_log2e", False))
 
         # any-width path: the FeedForward runs as ONE kernel when the widths allow it (csship_ffn_wide, bf16, weights in
         # fragment order), or - opt-in, self.fp8_ffn - with block-scaled fp8 operands (csship_ffn_mx, ops.pack_mx)
@@ -223,8 +225,6 @@ class Conformer(nn.Module):
             if ffn_mode == 2:
                 q2, s2 = ops.pack_mx(m.net[3].weight)
                 w.w2, w.w2_scale, w.b2 = own(q2), own(s2), f32(m.net[3].bias)
-            elif w2_chunked:
-                w.w2, w.b2 = own(ops.pack_frag_chunked(m.net[3].weight)), f32(m.net[3].bias)
             else:
                 w.w2, w.b2 = own((ops.pack_frag if ffn_mode == 1 else packw)(m.net[3].weight)), f32(m.net[3].bias)
             return w
@@ -235,6 +235,8 @@ class Conformer(nn.Module):
             L.ffn_in, L.ffn_out = ffn(lay.feed_forward_in), ffn(lay.feed_forward_out)
             a = lay.self_attn
             scale = a.d_k ** -0.5  # exact power of two for d_k = 64: folds /sqrt(d_k) (conformer.py:234) into q
+            if q_log2e:
+                scale *= 1.4426950408889634
             wqkv = torch.cat([a.linear_q.weight.detach() * scale, a.linear_k.weight.detach(),
                               a.linear_v.weight.detach()], 0)
             bqkv = torch.cat([a.linear_q.bias.detach() * scale, a.linear_k.bias.detach(),
@@ -271,7 +273,7 @@ class Conformer(nn.Module):
         pe_packed, w.pe_q_min, w.pe_q_max = ops.pack_relpos(self.position_table(), 1000)
         w.bn_mode = 1 if self.training else 0
         w.fuse_conv = int(getattr(self, "fuse_conv", 0))
-        w.chain_flags = (_lib.CHAIN_QKV_IL8 if fold else 0) | (_lib.CHAIN_W2_CHUNKED if w2_chunked else 0)
+        w.chain_flags = (_lib.CHAIN_QKV_IL8 if fold else 0) | (_lib.FWD_Q_LOG2E if q_log2e else 0)
         w.ffn_mode = ffn_mode
         w.lin_mode = lin_mode
         ew = torch.zeros(enc.d_model, w.idim_pad, device=dev)

@@ -38,9 +38,11 @@ def num_frames(n_samples):
     return (n_samples - FRAME_LEN) // FRAME_HOP + 1
 
 
-def stft(x, want=("mag",), logpow_eps=1e-10):
+def stft(x, want=("mag",), logpow_eps=1e-10, pad_rows=False):
     """x: [B,n] or [B,D,n] f32 (last dim contiguous) -> dict of [B,(D,)T,257] tensors (TF layout).  want: any of
-    "mag", "re", "im", "pha", "logpow" (= log(max(|X|^2, logpow_eps)))."""
+    "mag", "re", "im", "pha", "logpow" (= log(max(|X|^2, logpow_eps))).  pad_rows: the outputs are [..., :257] views of
+    [..., 260] buffers - 16-byte aligned rows for the consumers that take a row stride (mvn_stats, the models'
+    forward / forward_loss, head_pit's targets); anything that needs dense rows gets them from .contiguous()."""
     _need(x, torch.float32, "x")
     if x.dim() not in (2, 3):
         raise RuntimeError(f"STFT expect 2D/3D tensor, but got {x.dim()}D signal")  # feature.py:54-59
@@ -65,8 +67,14 @@ def stft(x, want=("mag",), logpow_eps=1e-10):
             s0 = x.stride(0)
             s1 = x.stride(1) if x.dim() == 3 else 0
     T = num_frames(n)
-    shape = tuple(x.shape[:-1]) + (T, NBIN)
+    pad_rows = bool(pad_rows) and "logpow" not in want
+    ld = (NBIN + 3) // 4 * 4 if pad_rows else NBIN
+    shape = tuple(x.shape[:-1]) + (T, ld)
     out = {k: torch.empty(shape, device=x.device, dtype=torch.float32) for k in want}
+    if pad_rows:
+        check(lib().csship_stft_ld(_ptr(x), n0, s0, n1, s1, n, _ptr(out.get("mag")), _ptr(out.get("re")),
+                                   _ptr(out.get("im")), _ptr(out.get("pha")), ld, _stream()))
+        return {k: v[..., :NBIN] for k, v in out.items()}
     if "logpow" in out:  # log(max(|X|^2, eps)): an epilogue flag of the STFT kernel (training features)
         check(lib().csship_stft_logpower(_ptr(x), n0, s0, n1, s1, n, float(logpow_eps), _ptr(out["logpow"]), _stream()))
         if len(out) == 1:
@@ -219,8 +227,9 @@ def pack_relpos(pe_k, maxlen=1000):
     return blk.contiguous().to(torch.bfloat16).view(-1), int(q_min), int(q_max)
 
 
-def mha_relpos(qkv, pe_pack, n_head):
-    """qkv bf16 [B,T,3*H*64] (q pre-scaled), pe_pack = pack_relpos(pe_k) -> bf16 [B,T,H*64]."""
+def mha_relpos(qkv, pe_pack, n_head, q_log2e=False):
+    """qkv bf16 [B,T,3*H*64] (q pre-scaled by 1/sqrt(d_k); q_log2e: by log2(e)/sqrt(d_k), the inference forward's
+    log2-domain form), pe_pack = pack_relpos(pe_k) -> bf16 [B,T,H*64]."""
     _need(qkv, torch.bfloat16, "qkv")
     packed, q_min, q_max = pe_pack
     _need(packed, torch.bfloat16, "pe_packed")
@@ -228,7 +237,8 @@ def mha_relpos(qkv, pe_pack, n_head):
     assert qkv.is_contiguous() and packed.is_contiguous()
     assert D3 == 3 * n_head * 64 and packed.numel() == (q_max - q_min + 1) * 2 * 512
     out = torch.empty(B, T, n_head * 64, device=qkv.device, dtype=torch.bfloat16)
-    check(lib().csship_mha_relpos(_ptr(qkv), _ptr(packed), q_min, q_max, _ptr(out), B, T, n_head, _stream()))
+    check(lib().csship_mha_relpos_ex(_ptr(qkv), _ptr(packed), q_min, q_max, _ptr(out), B, T, n_head,
+                                     1 if q_log2e else 0, _stream()))
     return out
 
 
@@ -300,17 +310,25 @@ def convmod(x, weights, kernel_size=33, batch_stats=False, return_workspace=Fals
     return (y, ws) if return_workspace else y
 
 
-def _targets_array(targets, B, T, F):
+def _targets_array(targets, B, T, F, strided=False):
+    """HOST array of the targets' device pointers (+ the tensors kept alive).  strided: rows may be padded (stft's
+    pad_rows) as long as every target has the same row stride; returns (arr, keep, row stride) then."""
     arr = (C.c_void_p * len(targets))()
     keep = []
+    ld = None
     for i, t in enumerate(targets):
         _need(t, torch.float32, f"target{i}")
         if tuple(t.shape) != (B, T, F):
             raise AssertionError(f"{tuple(t.shape)} != {(B, T, F)}")  # mse.py:29 / pit.py:46
-        t = t.contiguous()
+        ok = strided and t.stride(2) == 1 and t.stride(0) == T * t.stride(1) and (ld is None or t.stride(1) == ld)
+        if not ok:
+            t = t.contiguous()
+            if strided and ld is not None and ld != F:   # mixed strides: everything dense
+                return _targets_array([u.contiguous() for u in targets], B, T, F, strided=True)
+        ld = t.stride(1) if strided else F
         keep.append(t)
         arr[i] = t.data_ptr()
-    return arr, keep
+    return (arr, keep, ld) if strided else (arr, keep)
 
 
 _LSTM_WS = {}  # (device index, stream, B, H) -> workspace of the distributed recurrence
@@ -417,14 +435,14 @@ def head_pit(x_enc, w_packed, bias_perm, f_orig, targets, want_pairs=False):
     K = len(targets)
     B, T, F = targets[0].shape
     assert x_enc.is_contiguous() and f_orig.stride(2) == 1 and f_orig.stride(0) == T * f_orig.stride(1)
-    arr, keep = _targets_array(targets, B, T, F)
+    arr, keep, ldt = _targets_array(targets, B, T, F, strided=True)
     dev = x_enc.device
     loss = torch.empty((), device=dev, dtype=torch.float32)
     perm = torch.empty(B, K, device=dev, dtype=torch.int32)
     pairs = torch.empty(B, K, K, device=dev, dtype=torch.float32) if want_pairs else None
     nws = lib().csship_head_pit_workspace(B, T)
     ws = torch.empty(nws, device=dev, dtype=torch.uint8)
-    check(lib().csship_head_pit(_ptr(x_enc), _ptr(w_packed), _ptr(bias_perm), _ptr(f_orig), f_orig.stride(1), arr, B, T, F, K,
+    check(lib().csship_head_pit(_ptr(x_enc), _ptr(w_packed), _ptr(bias_perm), _ptr(f_orig), f_orig.stride(1), arr, ldt, B, T, F, K,
                                 x_enc.shape[2], _ptr(loss), _ptr(perm), _ptr(pairs), _ptr(ws), nws, _stream()))
     return loss, perm, pairs
 
@@ -499,14 +517,6 @@ def pack_frag(w):
     wp[:R] = w.detach().float()
     wp = wp.view(Rp // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4)  # [rt, ks, g, m, j]
     return wp.contiguous().to(torch.bfloat16).view(-1)
-
-
-def pack_frag_chunked(w, chunk=256):
-    """[R, K] -> the K / chunk column blocks of w, each in pack_frag's order, one after the other
-    (CSSHIP_CHAIN_W2_CHUNKED, include/csship.h): a pass of the chain kernel over one hidden chunk reads one contiguous run."""
-    R, K = w.shape
-    assert K % chunk == 0
-    return torch.cat([pack_frag(w[:, c:c + chunk]) for c in range(0, K, chunk)])
 
 
 def il8_row_order(R, device=None):

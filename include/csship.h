@@ -75,6 +75,12 @@ int csship_dropout_mask(uint8_t* keep, int64_t n, const csship_dropout_cfg* cfg,
 int csship_stft(const float* audio, int64_t n0, int64_t stride0, int64_t n1, int64_t stride1,
                 int64_t n_samples, float* mag, float* re, float* im, float* pha,
                 csship_stream_t stream);
+/* The same with ld_out >= 257 floats between the frames of every output ([S, T, ld_out] storage, 257 valid columns):
+ * ld_out = 260 gives 16-byte aligned rows to the consumers that read 16-byte pieces of a row (csship_head_pit,
+ * csship_mvn_stats, csship_embed); the pad columns are not written. */
+int csship_stft_ld(const float* audio, int64_t n0, int64_t stride0, int64_t n1, int64_t stride1,
+                   int64_t n_samples, float* mag, float* re, float* im, float* pha, int64_t ld_out,
+                   csship_stream_t stream);
 
 /* Log-power variant of the same transform: logpow[s, t, k] = log(max(|X[s, t, k]|^2, eps)) (natural log), the
  * build-defined stand-in for the reference's training-time features (Lhotse Spectrogram: third-party, unpinned;
@@ -311,13 +317,11 @@ int csship_outproj_glu(const uint16_t* attn_out, const uint16_t* wo_packed, cons
  * flags: CSSHIP_CHAIN_QKV_IL8 = wqkv_packed / bqkv rows are in the 8-feature interleaved order of
  * css_amd.ops.pack_frag_il8 (packed row 16*tile + m holds feature 32*(tile/2) + 8*(m/4) + 4*(tile%2) + m%4), with which
  * a lane's results are 8 consecutive features of a token row and qkv_out is written with 16-byte stores
- * (n_qkv % 32 == 0); qkv_out itself is in natural feature order either way.
- * CSSHIP_CHAIN_W2_CHUNKED = both FeedForwards' w2 are packed chunk by chunk (css_amd.ops.pack_frag_chunked): the
- * [256, d_ffn] matrix cut into d_ffn / 256 column blocks, each in the fragment order above, one after the other - block
- * (chunk c, tile t, k-step ks) at ((c * 16 + t) * 8 + ks) * 64 lanes.  A pass over one hidden chunk then reads one
- * contiguous 128 KB run. */
+ * (n_qkv % 32 == 0); qkv_out itself is in natural feature order either way. */
 #define CSSHIP_CHAIN_QKV_IL8 1
-#define CSSHIP_CHAIN_W2_CHUNKED 2
+/* (csship_conformer_weights.chain_flags only, ignored by csship_encoder_chain) the q rows of every layer's wqkv / bqkv
+ * carry log2(e) / sqrt(d_k): csship_conformer_forward runs the attention with CSSHIP_MHA_Q_LOG2E */
+#define CSSHIP_FWD_Q_LOG2E 4
 struct csship_ffn_weights_s;
 int csship_encoder_chain(const float* x, float* x_out, const float* conv_g,
                          const struct csship_conv_weights_s* conv_w, int32_t T,
@@ -364,6 +368,13 @@ int csship_embed(const float* f, int64_t ldf, const float* mvn_mean, const float
  * clamp and block q_max entirely above it (css_amd.ops.pack_relpos builds it). */
 int csship_mha_relpos(const uint16_t* qkv, const uint16_t* pe_packed, int32_t q_min, int32_t q_max,
                       uint16_t* out, int32_t B, int32_t T, int32_t H, csship_stream_t stream);
+/* The same with flags.  CSSHIP_MHA_Q_LOG2E: q carries log2(e) / sqrt(d_k) instead of 1 / sqrt(d_k) (the caller folded
+ * the factor into the q rows of the projection, as css_amd.models.Conformer does for the inference forward): scores come
+ * out of the matrix products in log2 units and relative to the running maximum, the exponentials take them as they are
+ * (same softmax; the inference form only - no dropout, no log-sum-exp output). */
+#define CSSHIP_MHA_Q_LOG2E 1
+int csship_mha_relpos_ex(const uint16_t* qkv, const uint16_t* pe_packed, int32_t q_min, int32_t q_max,
+                         uint16_t* out, int32_t B, int32_t T, int32_t H, int32_t flags, csship_stream_t stream);
 
 /* ConvModule.forward + residual (css/models/conformer.py:289-303, 357):
  *   y = x + pw2( relu( BN( dwconv_k( glu( LN(x) ) ) ) ) ),  x,y: f32 [B, T, 256].
@@ -512,14 +523,15 @@ int csship_conformer_forward(const csship_conformer_weights* w, const float* f, 
  * noise mask, which does not enter the loss, is not computed).  x_enc: f32 [B*T, d_model] (csship_conformer_forward
  * with masks == NULL writes it to enc_out); w_perm_packed / bias_perm: the first K*F head rows in the order of
  * css_amd.ops.pack_head_pit (bins 0..255 of speaker 0, of speaker 1, then one tile with bin 256 of every speaker),
- * fragment-packed; f_orig f32 [B, T, >= F] (row stride ld_f); targets: K dense f32 [B, T, F].  loss: 0-dim f32; perm
+ * fragment-packed; f_orig f32 [B, T, >= F] (row stride ld_f); targets: K x f32 [B, T, >= F] (row stride ld_t: 257 dense,
+ * or 260 - csship_stft_ld's 16-byte aligned rows, with which a lane's 16-byte pieces never straddle a line).  loss: 0-dim f32; perm
  * int32 [B, K] (optional); pair_sse f32 [B, K, K] (optional).  Built for K == 2, F == 257, d_model == 256, T >= 64:
  * anything else returns CSSHIP_EUNSUPPORTED (callers then run csship_conformer_forward + csship_pit_mse).
  * Bit-reproducible (fixed-order partial sums, no atomics). */
 size_t csship_head_pit_workspace(int32_t B, int32_t T);
 int csship_head_pit(const float* x_enc, const uint16_t* w_perm_packed, const float* bias_perm, const float* f_orig,
-                    int64_t ld_f, const float* const* targets_host, int32_t B, int32_t T, int32_t F, int32_t K,
-                    int32_t d_model, float* loss, int32_t* perm, float* pair_sse, void* workspace,
+                    int64_t ld_f, const float* const* targets_host, int64_t ld_t, int32_t B, int32_t T, int32_t F,
+                    int32_t K, int32_t d_model, float* loss, int32_t* perm, float* pair_sse, void* workspace,
                     size_t workspace_bytes, csship_stream_t stream);
 
 /* ======================================================================================

@@ -67,6 +67,31 @@ def test_stft_strided_windows(ops):
     assert a.shape == (2, 5, 150, 257) and torch.equal(a, b)
 
 
+def test_stft_padded_rows_and_fused_loss_on_them(ops):
+    """ops.stft(pad_rows=True): [..., :257] views of 260-float (16-byte aligned) rows - the same values bit for bit - and the
+    fused mask head + PIT loss reading the mixture AND its targets through that row stride (csship_head_pit's ld_f / ld_t)
+    gives the same loss, permutations and pair matrix as on dense rows."""
+    from css_amd.models import MODELS
+    B, T = 3, 100
+    mix, src = syn.synthetic_sources(B, 512 + 256 * (T - 1), seed=9)
+    audio = torch.stack([mix, src[0], src[1]], 0).to(DEV)
+    dense = ops.stft(audio, ("mag", "re"))
+    padded = ops.stft(audio, ("mag", "re"), pad_rows=True)
+    assert padded["mag"].shape == (3, B, T, 257) and padded["mag"].stride(-2) == 260 and padded["mag"].stride(-1) == 1
+    assert torch.equal(padded["mag"], dense["mag"]) and torch.equal(padded["re"], dense["re"])
+    conf = dict(attention_dim=256, attention_heads=4, linear_units=1024, num_blocks=1, kernel_size=33, dropout_rate=0.1,
+                relative_pos_emb=True)
+    m = MODELS["Conformer"](257, 257, 2, 1, conf)
+    m.load_state_dict(syn.fill_state_dict(syn.conformer_shapes(num_blocks=1), 5))
+    m = m.to(DEV).eval()
+    with torch.no_grad():
+        a = m.forward_loss(dense["mag"][0], [dense["mag"][1], dense["mag"][2]], want_pairs=True)
+        b = m.forward_loss(padded["mag"][0], [padded["mag"][1], padded["mag"][2]], want_pairs=True)
+        c = m.forward_loss(padded["mag"][0], [padded["mag"][1], dense["mag"][2]], want_pairs=True)   # mixed strides: dense copies
+    for x in (b, c):
+        assert torch.equal(a[0], x[0]) and torch.equal(a[1], x[1]) and torch.equal(a[2], x[2])
+
+
 def test_feature_extractor_golden(ops, golden):
     from css_amd.executor.feature import FeatureExtractor
     g = golden("stft.npz")
@@ -327,6 +352,38 @@ def test_mha_relpos(ops, B, T):
     ref = _ref_attention(qb[0], qb[1], qb[2], bf(pe))
     # P is rounded to bf16 before P.V and the output is stored in bf16: ~2^-8 relative
     assert err(out.float(), ref) < 3e-2
+
+
+@pytest.mark.parametrize("B,T", [(2, 64), (3, 100), (1, 7), (2, 400), (1, 1100)])
+def test_mha_relpos_log2_domain(ops, B, T):
+    """CSSHIP_MHA_Q_LOG2E (the inference forward's form): q carries log2(e) / sqrt(d_k), the band accumulators start at
+    minus the running reference and the exponentials take the accumulators as they are.  Same softmax: checked against
+    the float64 attention of the UNSCALED problem, and against the explicit-scaling kernel on the same values.  The
+    second case plants scores that grow from tile to tile (every tile moves the reference: the rescale branch) and one
+    very large score at the last key."""
+    H = 4
+    LOG2E = 1.4426950408889634
+    for grow in (False, True):
+        qkv = rnd((B, T, 3 * H * 64), 141)
+        qkv[..., : H * 64] *= 0.125
+        if grow:   # every query shares a direction u with every key, and key j's share grows with j: + 30 j / T per score
+            u = rnd((64,), 143)
+            u = (u / u.norm()).repeat(H)
+            qkv[..., : H * 64] += 0.5 * u
+            qkv[..., H * 64: 2 * H * 64] += 60.0 * torch.linspace(0, 1, T)[None, :, None] * u
+            qkv[:, T - 1, H * 64: 2 * H * 64] *= 3.0
+        pe = rnd((2000, 64), 142, 0.3)
+        q2 = qkv.clone()
+        q2[..., : H * 64] *= LOG2E
+        pk = ops.pack_relpos(pe.to(DEV))
+        out2 = ops.mha_relpos(q2.to(DEV).to(torch.bfloat16), pk, H, q_log2e=True)
+        # reference on exactly the operands the kernel sees: bf16(q log2e) / log2e
+        qb2 = bf(q2).view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+        ref = _ref_attention(qb2[0] / LOG2E, qb2[1], qb2[2], bf(pe))
+        assert bool(torch.isfinite(out2.float()).all())
+        assert err(out2.float(), ref) < 3e-2, (grow, err(out2.float(), ref))
+        out1 = ops.mha_relpos(qkv.to(DEV).to(torch.bfloat16), pk, H)
+        assert err(out2.float(), out1.float()) < 4e-2   # (q is rounded to bf16 after a different factor)
 
 
 # ----------------------------------------------------------------------------- conv module
