@@ -66,6 +66,8 @@ def parse_args():
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses cuda:0 (implies --backend gloo)")
     ap.add_argument("--buckets", type=int, default=4, help="train mode: all-reduce chunks in flight")
+    ap.add_argument("--p2p", action="store_true", help="training legs: gradients through css_amd.parallel.P2PAllReduce (the "
+                    "hand-written direct all-reduce over hipIpc peer mappings) instead of RCCL - the A/B for an 8-GPU node")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-step", action="store_true", help="fwd mode: skip the extra training-step measurement")
     ap.add_argument("--fuse-conv", type=int, default=None, help="debug: csship_conformer_weights.fuse_conv override")
@@ -74,6 +76,7 @@ def parse_args():
     ap.add_argument("--blocks", type=int, default=16, help="debug only: anything but 16 is not the headline config")
     ap.add_argument("--overlap-stft", action="store_true", help="debug A/B (measured SLOWER, 1.46 vs 1.43 ms): the two target "
                     "spectrograms on a second stream beside the encoder, joined before the loss kernel")
+    ap.add_argument("--pad-rows", action="store_true", help="debug A/B (measured: no gain): spectrogram rows padded to 260 floats, 16-byte aligned")
     ap.add_argument("--no-q-log2e", action="store_true", help="debug A/B: attention with the explicit exponent scaling")
     ap.add_argument("--no-ln-fold", action="store_true", help="debug A/B: keep the LayerNorm affines out of the weights and "
                     "the q/k/v rows in natural order (the round-2 form of the chain kernel's inputs)")
@@ -130,6 +133,8 @@ def spawn_ranks(n):
 
 def main():
     args = parse_args()
+    if args.p2p:
+        os.environ["CSS_AMD_P2P"] = "1"
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus))
 
@@ -160,6 +165,7 @@ def main():
 
     from css_amd import _lib, ops
     from css_amd.models import MODELS
+    PAD_ROWS = bool(args.pad_rows)
     from css_amd.utils import synthetic as syn
 
     conf = dict(attention_dim=256, attention_heads=4, linear_units=1024, num_blocks=args.blocks, kernel_size=33,
@@ -198,15 +204,15 @@ def main():
             # the 14 us it takes off the critical path), kept as the experiment it was.
             with torch.no_grad():
                 if not args.overlap_stft:
-                    mags = ops.stft(audio, ("mag",), pad_rows=True)["mag"]  # [3,B,T,257]
+                    mags = ops.stft(audio, ("mag",), pad_rows=PAD_ROWS)["mag"]  # [3,B,T,257]
                     loss, perm, _ = model.forward_loss(mags[0], [mags[1], mags[2]])
                     return loss
                 main = torch.cuda.current_stream()
                 side_stream.wait_stream(main)
                 box = {}
                 with torch.cuda.stream(side_stream):
-                    box["t"] = ops.stft(audio[1:3], ("mag",), pad_rows=True)["mag"]   # [2,B,T,257]
-                mix_mag = ops.stft(audio[0], ("mag",), pad_rows=True)["mag"]           # [B,T,257]
+                    box["t"] = ops.stft(audio[1:3], ("mag",), pad_rows=PAD_ROWS)["mag"]   # [2,B,T,257]
+                mix_mag = ops.stft(audio[0], ("mag",), pad_rows=PAD_ROWS)["mag"]           # [B,T,257]
                 loss, perm, _ = model.forward_loss(mix_mag, lambda: [box["t"][0], box["t"][1]],
                                                    before_head=lambda: main.wait_stream(side_stream))
             return loss
@@ -249,7 +255,7 @@ def main():
 
         def features():
             with torch.no_grad():
-                mags = ops.stft(audio, ("mag",), pad_rows=True)["mag"]
+                mags = ops.stft(audio, ("mag",), pad_rows=PAD_ROWS)["mag"]
             return {"mix": mags[0], "source1": mags[1], "source2": mags[2]}
         if args.no_graph:
             from css_amd import parallel
@@ -358,6 +364,8 @@ def main():
                "whole_step_frac": (1.0 if forward_only else 3.0) * B * T * flop_per_frame * args.blocks / 16 / (tdt / tsteps) / PEAK_BF16}
         if not forward_only:
             rec.update({"collective_backend": (backend if world > 1 else None),
+                        "collective": (("p2p-direct (css_amd.parallel.P2PAllReduce)" if args.p2p else "all-reduce of the backend")
+                                       if world > 1 else None),
                         "world_size": dist.get_world_size() if world > 1 else 1,
                         "allreduce_bytes_per_step": int(toptim.flat_grad.numel() * 4) if world > 1 else 0,
                         "allreduce_schedule": ([hi - lo for lo, hi in tstep.plan] if world > 1 else None)})
@@ -366,7 +374,7 @@ def main():
     if args.mode == "fwd" and not args.no_train_step:
         def tfeatures():
             with torch.no_grad():
-                mags = ops.stft(audio, ("mag",), pad_rows=True)["mag"]
+                mags = ops.stft(audio, ("mag",), pad_rows=PAD_ROWS)["mag"]
             return {"mix": mags[0], "source1": mags[1], "source2": mags[2]}
         progress("leg: train-mode forward + PIT")
         train_fwd_rec = train_leg(257, tfeatures, FLOP_PER_FRAME, "STFT-frames/sec (TRAIN-mode fwd+PIT: dropout 0.1, batch-statistics "
@@ -384,7 +392,7 @@ def main():
         def tfeatures7():
             with torch.no_grad():
                 _, f7, _, _ = fe7.forward_tf(x7, want_spectra=False)
-                tg = ops.stft(audio[1:3], ("mag",), pad_rows=True)["mag"]
+                tg = ops.stft(audio[1:3], ("mag",), pad_rows=PAD_ROWS)["mag"]
             return {"mix": f7, "source1": tg[0], "source2": tg[1]}
         progress(f"leg: 7-channel training step ({train_rec.get('ms_per_step', train_rec)} ms 1ch)")
         train7_rec = train_leg(257 * 7, tfeatures7, FLOP_PER_FRAME_7CH, "STFT-frames/sec (training step, 7-channel IPD features "
@@ -407,7 +415,7 @@ def main():
 
         def probe():
             with torch.no_grad():
-                mags = ops.stft(audio, ("mag",), pad_rows=True)["mag"]
+                mags = ops.stft(audio, ("mag",), pad_rows=PAD_ROWS)["mag"]
                 if calib[0]:   # empty brackets queued in the MIDDLE of a step (the stream is busy on both sides of them)
                     lib.csship_debug_timeline_calibrate(C.c_void_p(torch.cuda.current_stream().cuda_stream), 4)
                 model.forward_loss(mags[0], [mags[1], mags[2]])

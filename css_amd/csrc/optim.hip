@@ -7,6 +7,8 @@
 //      guard around optimizer.step() (it only refuses to SAVE a checkpoint after a NaN epoch loss, train.py:313): a
 //      non-finite gradient there poisons the parameters, here it costs one step (the host-side step counter and
 //      the bias corrections still advance).
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace {
@@ -113,6 +115,62 @@ extern "C" int csship_adam_clip(float* params, const float* grads, float* exp_av
   const float bc1 = step > 0 ? 1.f - powf(beta1, (float)step) : 1.f, bc2 = step > 0 ? 1.f - powf(beta2, (float)step) : 1.f;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, n,
                      grad_norm, max_norm, lr, beta1, beta2, eps, bc1, bc2, weight_decay, hyper_dev);
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
+
+// ---- csship_p2p_reduce: out[lo:hi] = scale * sum_j src_j[lo:hi] over up to 8 gradient buffers, summed in the order
+// given (fixed: bit-reproducible).  The sources are the ranks' flat gradient buffers as this process sees them - its own
+// and its peers' through hipIpc mappings (css_amd.parallel.P2PAllReduce): the reduce-scatter half of the direct
+// (one-shot) all-reduce of SURVEY 5.8, which replaces the reference's checkpoint averaging
+// (scripts/python/combine_models.py:55-82).  Every byte is read once with 16-byte loads - on an 8-GPU node the seven remote
+// slices travel over seven different xGMI links at the same time.  `out` may be one of the sources (in place).
+namespace {
+struct P2PReduceArgs {
+  const float* src[8];
+  float* out;
+  int world;
+  long long lo, hi;
+  float scale;
+};
+__global__ __launch_bounds__(256) void p2p_reduce_kernel(P2PReduceArgs a) {
+  const long long stride = (long long)gridDim.x * 256 * 4;
+  long long i = a.lo + ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  for (; i + 3 < a.hi; i += stride) {
+    float4 acc = *reinterpret_cast<const float4*>(a.src[0] + i);
+    for (int j = 1; j < a.world; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(a.src[j] + i);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(a.out + i) = make_float4(acc.x * a.scale, acc.y * a.scale, acc.z * a.scale, acc.w * a.scale);
+  }
+  if (i < a.hi) {  // at most one thread: the last 1..3 elements
+    for (long long k = i; k < a.hi; ++k) {
+      float acc = a.src[0][k];
+      for (int j = 1; j < a.world; ++j) acc += a.src[j][k];
+      a.out[k] = acc * a.scale;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int csship_p2p_reduce(const float* const* srcs_host, int32_t world, int64_t lo, int64_t hi, float scale,
+                                 float* out, csship_stream_t stream) {
+  if (!srcs_host || !out) return CSSHIP_ENULL;
+  if (world < 1 || world > 8 || lo < 0 || hi < lo || (lo & 3)) return CSSHIP_EBADSHAPE;
+  if (hi == lo) return CSSHIP_OK;
+  P2PReduceArgs a{};
+  for (int j = 0; j < world; ++j) {
+    if (!srcs_host[j]) return CSSHIP_ENULL;
+    if (!aligned16(srcs_host[j])) return CSSHIP_EALIGN;
+    a.src[j] = srcs_host[j];
+  }
+  if (!aligned16(out)) return CSSHIP_EALIGN;
+  a.out = out; a.world = world; a.lo = lo; a.hi = hi; a.scale = scale;
+  const long long n4 = (hi - lo + 3) / 4;
+  const unsigned grid = (unsigned)std::min<long long>((n4 + 255) / 256, 2048);
+  hipLaunchKernelGGL(p2p_reduce_kernel, dim3(grid), dim3(256), 0, as_stream(stream), a);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }

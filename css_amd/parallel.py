@@ -7,12 +7,20 @@ ranks -- a single large all-reduce is what the point-to-point xGMI links want (2
 86 MB fp32 for Conformer-base) -- and long-recording inference shards window indices across
 ranks with no collective on the data path.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 
 def is_distributed():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """True when gradients have to be exchanged: an initialised process group with more than one rank.
+    CSS_AMD_DRY_DIST=1 (a rehearsal switch, tests/test_gpu_dist.py) takes the distributed code path with ONE rank as
+    well: every collective of the step is then really issued through the backend (RCCL on a one-GPU box: AVG
+    all-reduces of the real bucket schedule between sub-graph replays) and is an identity."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("CSS_AMD_DRY_DIST") == "1"
 
 
 def shard_range(n_items, rank, world_size):
@@ -150,6 +158,9 @@ def allreduce_segment(flat, lo, hi, handles, average=True):
     producing the rest).  Averaging for backends without AVG happens in ``wait_all``."""
     if not is_distributed() or hi <= lo:
         return
+    if flat.is_cuda and use_p2p() and lo % 4 == 0:   # hand-written direct all-reduce over peer-mapped buffers (off by default)
+        handles.append(p2p_reducer(flat).allreduce_async(lo, hi, average))   # on its own stream; the mean is taken inside
+        return
     if flat.is_cuda and dist.get_backend() == "gloo":  # rehearsal backend: staged through host memory, synchronous
         host = flat[lo:hi].cpu()
         dist.all_reduce(host, op=dist.ReduceOp.SUM)
@@ -163,7 +174,7 @@ def wait_all(handles, flat=None, average=True):
     for h in handles:
         h.wait()
     handles.clear()
-    if flat is not None and average and is_distributed() and dist.get_backend() != "nccl":
+    if flat is not None and average and is_distributed() and dist.get_backend() != "nccl" and not (flat.is_cuda and use_p2p()):
         flat /= dist.get_world_size()
 
 
@@ -262,6 +273,155 @@ def allreduce_plan(flat, plan, average=True, async_handles=None):
         allreduce_segment(flat, lo, hi, handles, average)
     if async_handles is None:
         wait_all(handles, flat, average)
+
+
+class P2PAllReduce:
+    """Direct (one-shot) all-reduce of FusedAdam's flat gradient buffer over peer-mapped memory - the hand-written variant
+    SURVEY 5.8 keeps beside RCCL's collective (replaces scripts/python/combine_models.py:55-82).  OFF by default:
+    ``CSS_AMD_P2P=1`` (or ``args.p2p``) makes allreduce_segment / the trainers use it; what RCCL picks for an 86 MB
+    bucket on an 8-GPU xGMI node and which of the two is faster is an A/B for the first run on such a node.
+
+    A ring all-reduce moves 2 (W-1)/W of the buffer over ONE link per GPU; here every rank reduces ONE 1/W slice, reading
+    it from all W - 1 peers at once over W - 1 different links, and then fetches the other W - 1 reduced slices the same
+    way: 2/W of the buffer per link.  Mechanics, all of it stream-ordered (no in-kernel flags, no cross-device polling):
+      * set-up (once): every rank exports its flat buffer (hipIpc memory handle via torch's CUDA-tensor reductions) and
+        three interprocess events; handles travel through ``dist.all_gather_object``; a small POSIX shared-memory block
+        holds one sequence number per (phase, rank);
+      * per call, three phases.  In each, a rank records its event on its stream, publishes the call's sequence number
+        and - for every peer - waits on the HOST until the peer has published it too (the peer has then ISSUED its
+        record: an interprocess event must be recorded before it is waited for) and makes its stream wait for the
+        peer's event.  (1) "ready": gradients are final -> csship_p2p_reduce sums this rank's slice over all buffers
+        in rank order, in place; (2) "reduced": -> the other slices are copied from their owners; (3) "done": nobody
+        still reads this rank's buffer -> the call returns, the stream may overwrite the gradients.
+    Sums run in rank order 0 .. W-1 on ONE rank per slice, so every rank ends up with the same bits, whatever the timing.
+    Visibility across devices rests on the event semantics of the runtime (a recorded interprocess event releases to
+    system scope, a stream that waited for one acquires): nothing here reads another device's memory except behind such
+    a wait.  Covered on one GPU by two rank processes that share the device (tests/test_gpu_dist.py)."""
+
+    PHASES = 3
+
+    def __init__(self, flat, timeout_s=60.0):
+        import mmap
+        import numpy as np
+        from torch.multiprocessing.reductions import reduce_tensor
+        assert dist.is_initialized() and flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous()
+        if flat.data_ptr() % 16:
+            raise ValueError("P2PAllReduce: the flat buffer must be 16-byte aligned")
+        self.flat, self.rank, self.world = flat, dist.get_rank(), dist.get_world_size()
+        if self.world > 8:
+            raise ValueError("P2PAllReduce: one node, at most 8 ranks")
+        self.timeout_s, self.seq = float(timeout_s), 0
+        dev = flat.device
+        # interprocess events: created by a first record, then exported
+        self.events = [torch.cuda.Event(enable_timing=False, interprocess=True) for _ in range(self.PHASES)]
+        for e in self.events:
+            e.record(torch.cuda.current_stream(dev))
+        torch.cuda.synchronize(dev)
+        mine = {"tensor": reduce_tensor(flat), "events": [e.ipc_handle() for e in self.events], "n": flat.numel()}
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, mine)
+        if any(o["n"] != flat.numel() for o in everyone):
+            raise ValueError("P2PAllReduce: ranks hold gradient buffers of different sizes")
+        self.peers, self.peer_events = [], []
+        for j, o in enumerate(everyone):
+            if j == self.rank:
+                self.peers.append(flat)
+                self.peer_events.append(self.events)
+            else:
+                fn, args = o["tensor"]
+                self.peers.append(fn(*args))          # this process's mapping of rank j's buffer
+                self.peer_events.append([torch.cuda.Event.from_ipc_handle(dev, h) for h in o["events"]])
+        import ctypes as C
+        self._ptrs = (C.c_void_p * self.world)(*[t.data_ptr() for t in self.peers])
+        # sequence numbers [phase][rank] in shared memory (rank 0 names the file)
+        name = [None]
+        if self.rank == 0:
+            name[0] = f"/dev/shm/css_amd_p2p_{os.getpid()}_{id(self) & 0xffffff:x}"
+            with open(name[0], "wb") as fh:
+                fh.write(b"\0" * (8 * self.PHASES * self.world))
+        dist.broadcast_object_list(name, src=0)
+        self._shm_name = name[0]
+        self._fh = open(self._shm_name, "r+b")
+        self._mm = mmap.mmap(self._fh.fileno(), 8 * self.PHASES * self.world)
+        self._seqs = np.frombuffer(self._mm, dtype=np.int64).reshape(self.PHASES, self.world)
+        dist.barrier()
+        if self.rank == 0:
+            os.unlink(self._shm_name)   # every rank has it mapped: the name can go
+
+    def _phase(self, k, stream):
+        """record my event of phase k, publish, and make `stream` wait for every peer's event of this call"""
+        import time
+        self.events[k].record(stream)
+        self._seqs[k, self.rank] = self.seq
+        deadline = time.monotonic() + self.timeout_s
+        for j in range(self.world):
+            if j == self.rank:
+                continue
+            while self._seqs[k, j] < self.seq:
+                if time.monotonic() > deadline:
+                    raise RuntimeError(f"css_amd.P2PAllReduce: rank {j} did not reach phase {k} of call {self.seq} within "
+                                       f"{self.timeout_s:.0f} s (ranks must issue the same all-reduces in the same order)")
+            stream.wait_event(self.peer_events[j][k])
+
+    def allreduce_async(self, lo=0, hi=None, average=True):
+        """The same on this reducer's own stream, ordered behind what the current stream has been given so far (the
+        backward pass goes on beside it); returns a handle whose wait() orders the current stream behind the result."""
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.flat.device)
+        self._side.wait_stream(torch.cuda.current_stream(self.flat.device))
+        with torch.cuda.stream(self._side):
+            self.allreduce(lo, hi, average)
+        return _StreamHandle(self._side)
+
+    def slices(self, lo, hi):
+        """[(lo_j, hi_j)]: the part of [lo, hi) rank j reduces (multiples of 4 floats; the last ranks may get nothing)"""
+        n = hi - lo
+        per = ((n + self.world - 1) // self.world + 3) // 4 * 4
+        return [(min(hi, lo + j * per), min(hi, lo + (j + 1) * per)) for j in range(self.world)]
+
+    def allreduce(self, lo=0, hi=None, average=True):
+        """In-place all-reduce (mean or sum) of flat[lo:hi] on the current stream; lo a multiple of 4."""
+        from ._lib import check, lib
+        hi = self.flat.numel() if hi is None else hi
+        assert 0 <= lo <= hi <= self.flat.numel() and lo % 4 == 0
+        stream = torch.cuda.current_stream(self.flat.device)
+        self.seq += 1
+        sl = self.slices(lo, hi)
+        self._phase(0, stream)                                   # everybody's gradients are final
+        a, b = sl[self.rank]
+        check(lib().csship_p2p_reduce(self._ptrs, self.world, a, b, (1.0 / self.world) if average else 1.0,
+                                      self.flat.data_ptr(), stream.cuda_stream))
+        self._phase(1, stream)                                   # every slice is reduced at its owner
+        for j, (a, b) in enumerate(sl):
+            if j != self.rank and b > a:
+                self.flat[a:b].copy_(self.peers[j][a:b], non_blocking=True)
+        self._phase(2, stream)                                   # nobody reads my buffer any more
+
+
+class _StreamHandle:
+    """what allreduce_async returns: wait() makes the CURRENT stream wait for the communication stream (no host block)"""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def wait(self):
+        torch.cuda.current_stream().wait_stream(self.stream)
+
+
+_P2P = {}
+
+
+def p2p_reducer(flat):
+    """The P2PAllReduce of this flat buffer (built on first use: a collective set-up - every rank must get here)."""
+    key = (flat.data_ptr(), flat.numel())
+    r = _P2P.get(key)
+    if r is None:
+        r = _P2P[key] = P2PAllReduce(flat)
+    return r
+
+
+def use_p2p():
+    return os.environ.get("CSS_AMD_P2P") == "1"
 
 
 def average_parameters(models_state_dicts):

@@ -811,6 +811,14 @@ int csship_lstm_bidir_bwd_dist(const float* gates, const float* c, const float* 
                                float* dgates, int32_t B, int32_t T, int32_t H, void* workspace,
                                size_t workspace_bytes, csship_stream_t stream);
 
+/* ---- csship_p2p_reduce (css_amd/csrc/optim.hip): out[lo:hi] = scale * (src_0 + src_1 + ... + src_{world-1})[lo:hi],
+ * summed in that order (bit-reproducible), for the direct (one-shot) all-reduce of css_amd.parallel.P2PAllReduce
+ * (replaces scripts/python/combine_models.py:55-82): srcs_host is a HOST array of world <= 8 device
+ * pointers - this rank's flat gradient buffer and its peers' buffers as mapped into this process with hipIpc - each
+ * 16-byte aligned; lo a multiple of 4; out may be one of the sources. */
+int csship_p2p_reduce(const float* const* srcs_host, int32_t world, int64_t lo, int64_t hi, float scale, float* out,
+                      csship_stream_t stream);
+
 /* ---- csship_adam_clip (css_amd/csrc/optim.hip): clip_grad_norm_(max_norm) followed by one Adam step
  * (iteration_types.py:17-64) on FLAT f32 buffers of n elements (parameters, gradients, first and second moments), in
  * three launches with no host round trip.  grad_norm (device f32) receives the total 2-norm before clipping; a

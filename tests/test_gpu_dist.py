@@ -139,6 +139,172 @@ sys.exit(0 if ok else 3)
 """
 
 
+DRY_RCCL = r"""
+# ONE rank, backend "nccl" (= RCCL), CSS_AMD_DRY_DIST=1: the distributed forms of the step run for real - the captured
+# step as a chain of sub-graphs with RCCL AVG all-reduces of the bucket schedule issued between the replays (on RCCL's
+# stream, behind events), the eager step with the overlapped reducer - and, the collectives being identities at world
+# size 1, must reproduce the single-process step bit for bit.  What this pins on a one-GPU box: the RCCL process group
+# comes up on ROCm, ReduceOp.AVG exists, asynchronous handles + graph replays + the optimiser graph are ordered
+# correctly, nothing in the distributed path needs more than one device to be exercised.
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["CSS_ROOT"])
+import numpy as np
+from css_amd import parallel
+from css_amd.models import MODELS
+from css_amd.objectives import OBJECTIVES
+from css_amd.optim import FusedAdam
+from css_amd.trainer import GraphedTrainStep
+from css_amd.utils import synthetic as syn
+torch.cuda.set_device(0)
+DEV = "cuda"
+def rnd(shape, seed, scale=1.0):
+    return torch.from_numpy((scale * np.random.RandomState(seed).standard_normal(shape)).astype(np.float32))
+def build():
+    conf = dict(attention_dim=256, attention_heads=4, linear_units=1024, num_blocks=6, kernel_size=33, dropout_rate=0.1,
+                relative_pos_emb=True)
+    m = MODELS["Conformer"](257, 257, 2, 1, conf)
+    m.load_state_dict(syn.fill_state_dict(syn.conformer_shapes(num_blocks=6), 7))
+    return m.to(DEV).train()
+def batch(i):
+    return {"mix": rnd((2, 72, 257), 100 * i).abs().to(DEV), "source1": (rnd((2, 72, 257), 100 * i + 10).abs() * 0.5).to(DEV),
+            "source2": (rnd((2, 72, 257), 100 * i + 20).abs() * 0.5).to(DEV), "ovl": 0.5}
+obj = OBJECTIVES["MSE"].build_objective({})
+def run(form):
+    mm = build()
+    oo = FusedAdam(mm.parameters(), lr=1e-3, max_norm=5.0)
+    losses, extra = [], None
+    if form == "graphed":
+        st = GraphedTrainStep(mm, obj, oo, batch(1), max_norm=5.0, blocks_per_bucket=2)
+        extra = (st.distributed, len(getattr(st, "graphs", [])), list(st.plan))
+        for i in range(1, 5):
+            losses.append(float(st(batch(i))[0]))
+    else:
+        red = parallel.OverlappedGradReducer(mm, oo, blocks_per_bucket=2) if parallel.is_distributed() else None
+        for i in range(1, 5):
+            oo.zero_grad()
+            if red: red.begin()
+            l = obj(mm, batch(i), device=DEV); l.backward()
+            if red: red.finish()
+            oo.step(max_norm=5.0); losses.append(float(l))
+    torch.cuda.synchronize()
+    return oo.flat_param.clone(), losses, extra
+p0, l0, _ = run("eager")                       # no process group: the single-process step
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+assert dist.get_world_size() == 1 and not parallel.is_distributed()
+os.environ["CSS_AMD_DRY_DIST"] = "1"
+assert parallel.is_distributed() and dist.get_backend() == "nccl"
+t = torch.arange(8, device=DEV, dtype=torch.float32)
+dist.all_reduce(t, op=dist.ReduceOp.AVG)       # the op allreduce_flat / allreduce_segment rely on
+assert torch.equal(t.cpu(), torch.arange(8, dtype=torch.float32))
+p1, l1, _ = run("eager")                       # overlapped reducer -> RCCL
+p2, l2, ex = run("graphed")                    # sub-graph chain + RCCL between the replays
+ok = torch.equal(p0, p1) and l0 == l1 and torch.equal(p0, p2) and l0 == l2
+print(f"dry RCCL: eager == single-process {torch.equal(p0, p1)}, graphed == single-process {torch.equal(p0, p2)}; "
+      f"distributed capture {ex[0]}, {ex[1]} sub-graphs, {len(ex[2])} all-reduces per step of "
+      f"{[hi - lo for lo, hi in ex[2]]} floats", flush=True)
+ok = ok and ex[0] and ex[1] >= 3 and len(ex[2]) >= 4
+dist.destroy_process_group()
+sys.exit(0 if ok else 3)
+"""
+
+
+def test_dry_rccl_one_rank_pushes_the_real_collective_schedule(tmp_path):
+    """the RCCL path of the training step exercised on a one-GPU box (world size 1, backend nccl)."""
+    script = tmp_path / "dry.py"
+    script.write_text(DRY_RCCL)
+    env = dict(os.environ, CSS_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.pop("CSS_AMD_DRY_DIST", None)
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    print(out.stdout[-1500:])
+    assert out.returncode == 0, out.stderr[-3000:]
+
+
+P2P_WORKER = r"""
+# Two rank processes SHARING cuda:0 (a one-GPU box): the direct all-reduce over peer-mapped buffers - hipIpc handles of
+# the flat gradient buffers, interprocess events, the host sequence block - against the exact mean in rank order, over
+# repeated calls, odd sizes and sub-stretches; then the overlapped gradient reduction of a real training backward
+# through it (CSS_AMD_P2P=1) against the same step over the gloo path.
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["CSS_ROOT"])
+import numpy as np
+from css_amd import parallel
+from css_amd.models import MODELS
+from css_amd.objectives import OBJECTIVES
+from css_amd.optim import FusedAdam
+from css_amd.utils import synthetic as syn
+dist.init_process_group("gloo")
+rank, ws = dist.get_rank(), dist.get_world_size()
+torch.cuda.set_device(0)
+DEV = "cuda"
+def rnd(shape, seed, scale=1.0):
+    return torch.from_numpy((scale * np.random.RandomState(seed).standard_normal(shape)).astype(np.float32))
+ok = True
+n = 1_000_003 + 1          # not a multiple of the world size x 4
+flat = torch.empty(n, device=DEV)
+red = parallel.P2PAllReduce(flat)
+for call, (lo, hi, avg) in enumerate([(0, n, True), (0, n, False), (4096, 777_777, True), (12, 16, True), (0, n, True), (n - 4, n, False)]):
+    vals = [rnd((n,), 1000 * call + r) for r in range(ws)]
+    flat.copy_(vals[rank].to(DEV))
+    want = vals[rank].clone()
+    acc = vals[0][lo:hi].clone()
+    for r in range(1, ws):
+        acc += vals[r][lo:hi]
+    want[lo:hi] = acc * (1.0 / ws) if avg else acc
+    red.allreduce(lo, hi, avg)
+    torch.cuda.synchronize()
+    same = torch.equal(flat.cpu(), want)
+    ok = ok and same
+    print(f"rank {rank}: p2p all-reduce call {call} [{lo}, {hi}) mean={avg}: exact {same}", flush=True)
+# asynchronous form, twice in a row on different stretches, then wait
+vals = [rnd((n,), 77 + r) for r in range(ws)]
+flat.copy_(vals[rank].to(DEV))
+h = [red.allreduce_async(0, 500_000, True), red.allreduce_async(500_000, n, True)]
+for x in h:
+    x.wait()
+torch.cuda.synchronize()
+want = sum(vals[1:], vals[0].clone()) * (1.0 / ws)
+ok = ok and torch.equal(flat.cpu(), want)
+print(f"rank {rank}: two asynchronous stretches: exact {torch.equal(flat.cpu(), want)}", flush=True)
+dist.barrier()
+# a real backward with the overlapped bucket reducer: P2P path == gloo path, bit for bit (world 2: (a + b) / 2 both ways)
+def build():
+    conf = dict(attention_dim=256, attention_heads=4, linear_units=1024, num_blocks=3, kernel_size=33, dropout_rate=0.1,
+                relative_pos_emb=True)
+    m = MODELS["Conformer"](257, 257, 2, 1, conf)
+    m.load_state_dict(syn.fill_state_dict(syn.conformer_shapes(num_blocks=3), 7))
+    return m.to(DEV).eval()
+def batch(i, r):
+    return {"mix": rnd((2, 40, 257), 100 * i + r).abs().to(DEV), "source1": (rnd((2, 40, 257), 100 * i + 10 + r).abs() * 0.5).to(DEV),
+            "source2": (rnd((2, 40, 257), 100 * i + 20 + r).abs() * 0.5).to(DEV), "ovl": 0.5}
+obj = OBJECTIVES["MSE"].build_objective({})
+grads = {}
+for mode in ("gloo", "p2p"):
+    os.environ["CSS_AMD_P2P"] = "1" if mode == "p2p" else "0"
+    m = build(); m.eval_gradients = True
+    opt = FusedAdam(m.parameters(), lr=1e-3, max_norm=0.0)
+    r_ = parallel.OverlappedGradReducer(m, opt, blocks_per_bucket=1)
+    for it in range(2):
+        opt.zero_grad(); r_.begin(); obj(m, batch(it, rank), device=DEV).backward(); r_.finish()
+    torch.cuda.synchronize()
+    grads[mode] = opt.flat_grad.clone()
+same = torch.equal(grads["gloo"], grads["p2p"])
+ok = ok and same and float(grads["p2p"].abs().max()) > 0
+print(f"rank {rank}: overlapped bucket reduction through P2P == through gloo: {same}", flush=True)
+dist.barrier()
+dist.destroy_process_group()
+sys.exit(0 if ok else 3)
+"""
+
+
+def test_p2p_direct_allreduce_two_ranks_on_one_gpu(tmp_path):
+    """VERDICT r3 item 8 / SURVEY 5.8: the hand-written direct all-reduce over hipIpc peer mappings, functionally, with
+    two rank processes that share the one GPU of the box."""
+    script = tmp_path / "p2p.py"
+    script.write_text(P2P_WORKER)
+    assert _run_ranks(script, port="29549") == [0, 0]
+
+
 def _run_ranks(script, n=2, port="29541"):
     env = dict(os.environ, CSS_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, WORLD_SIZE=str(n))
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(n)]
