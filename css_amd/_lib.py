@@ -21,7 +21,7 @@ class GemmParams(C.Structure):
 
 class ConvWeights(C.Structure):
     _fields_ = [(n, _p) for n in ("ln_g", "ln_b", "pw1_w", "pw1_b", "dw_w", "dw_b", "bn_g", "bn_b",
-                                  "bn_mean", "bn_var", "pw2_w", "pw2_b")]
+                                  "bn_mean", "bn_var", "pw2_w", "pw2_b")] + [("causal", _i32)]
 
 
 class DropoutCfg(C.Structure):  # csship_dropout_cfg

@@ -252,7 +252,8 @@ class ConformerTrain(torch.autograd.Function):
                  "dw_w": dww_all[li], "dw_b": c.dw_conv_1d.bias.detach(),
                  "bn_g": c.BN.weight.detach(), "bn_b": c.BN.bias.detach(),
                  "bn_mean": c.BN.running_mean, "bn_var": c.BN.running_var,
-                 "pw2_w": c.pw_conv_2.weight.detach().view(1), "pw2_b": c.pw_conv_2.bias.detach()}
+                 "pw2_w": c.pw_conv_2.weight.detach().view(1), "pw2_b": c.pw_conv_2.bias.detach(),
+                 "causal": getattr(c, "causal", False)}
             x3, fws = ops.convmod(x2.view(B, T, D), W, K, batch_stats=batch_bn, keep_activations=not batch_bn,
                                   return_workspace=True, drop=ds.cfg(f"{li}.conv.out"), sync=sync_bn)
             x3 = x3.view(M, D)

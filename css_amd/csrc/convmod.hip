@@ -28,7 +28,11 @@ struct ConvArgs {
 
 template <int D, int TT, int KS, int MODE, bool FROMG>
 __global__ __launch_bounds__(2 * D) void convmod_kernel(ConvArgs a) {
-  constexpr int HALO = (KS - 1) / 2, ROWS = TT + KS - 1, NTHR = 2 * D;
+  constexpr int ROWS = TT + KS - 1, NTHR = 2 * D;
+  // frames in front of the tile that the taps reach: (KS-1)/2 for the centred module; the causal module
+  // (conformer.py:265-273, 297-298) looks KS-1 frames back and none ahead - and its input gradient (MODE 3: correlation
+  // with the flipped taps) the other way round.  Everything below indexes the tile relatively: only this mapping differs.
+  const int HALO = a.w.causal ? (MODE == 3 ? 0 : KS - 1) : (KS - 1) / 2;
   __shared__ __attribute__((aligned(16))) float G[ROWS][D];
   const int tid = threadIdx.x;
   const int b = blockIdx.y, t0 = blockIdx.x * TT;

@@ -271,7 +271,9 @@ extern "C" int csship_conformer_forward(const csship_conformer_weights* w, const
   float *x = ws.x0, *y = ws.x1;
   // fuse_conv 0 = default: out-proj + conv module as one kernel in eval mode, separate kernels when BatchNorm needs
   // batch statistics (a grid-wide reduction sits between the convolution and the ReLU then)
-  const int conv_mode = w->fuse_conv != 0 ? w->fuse_conv : (w->bn_mode == 0 ? 3 : 4);
+  bool causal = false;   // (conformer.py:265-273: every block or none) the causal module runs through csship_convmod
+  for (int l = 0; l < w->n_layer; ++l) causal = causal || w->layers[l].conv.causal != 0;
+  const int conv_mode = causal ? 4 : (w->fuse_conv != 0 ? w->fuse_conv : (w->bn_mode == 0 ? 3 : 4));
   if (w->bn_mode == 0 && conv_mode == 1) {
     // optional (measured slower at B=32 x T=400: 83 vs 75 us per block): 3 launches per block.  Row-local operators are chained per 64-row panel (csship_encoder_chain):
     //   [conv back half(l-1) -> FFN_out(l-1) + block LN] -> FFN_in(l) -> pre-LN + q/k/v projection(l)

@@ -1770,6 +1770,7 @@ extern "C" int csship_outproj_conv(const uint16_t* attn_out, const uint16_t* wo_
                                    float* out, const csship_conv_weights* conv, int32_t B, int32_t T, int32_t d_model,
                                    int32_t kernel_size, csship_stream_t stream) {
   if (!attn_out || !wo_packed || !bo || !x || !out || !conv) return CSSHIP_ENULL;
+  if (conv->causal) return CSSHIP_EUNSUPPORTED;  // the fused form is built for the centred stencil (csship_convmod serves the causal one)
   if (!conv->ln_g || !conv->ln_b || !conv->pw1_w || !conv->pw1_b || !conv->dw_w || !conv->dw_b || !conv->bn_g ||
       !conv->bn_b || !conv->bn_mean || !conv->bn_var || !conv->pw2_w || !conv->pw2_b)
     return CSSHIP_ENULL;
@@ -1913,6 +1914,7 @@ static int encoder_chain_impl(const float* x, float* x_out, const float* conv_g,
   if (!aligned16(x) || !aligned16(x_out) || (Cq && (!aligned16(wqkv_packed) || !aligned16(qkv_out)))) return CSSHIP_EALIGN;
   const bool CV = conv_g != nullptr;
   if (CV && (!conv_w || T <= 0 || !aligned16(conv_g) || conv_g == x_out)) return CSSHIP_EBADSHAPE;
+  if (CV && conv_w->causal) return CSSHIP_EUNSUPPORTED;
   ChainArgs a{};
   a.x = x; a.xout = x_out; a.M = M; a.FF = d_ffn; a.NQKV = n_qkv; a.alpha = 0.5f; a.g = conv_g; a.T = T;
   a.stamps = g_csship_stamps;

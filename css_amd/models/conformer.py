@@ -59,22 +59,24 @@ class _SelfAttention(nn.Module):  # conformer.py:197-211
 
 
 class _ConvModule(nn.Module):  # conformer.py:258-287
-    def __init__(self, d, kernel_size):
+    def __init__(self, d, kernel_size, causal=False):
         super().__init__()
         self.layer_norm = nn.LayerNorm(d)
         self.pw_conv_1 = nn.Conv2d(1, 2, 1, 1, 0)
-        self.dw_conv_1d = nn.Conv1d(d, d, kernel_size, 1, padding=(kernel_size - 1) // 2, groups=d)
+        self.causal = bool(causal)   # conformer.py:265-273: padding k - 1, the last k - 1 outputs dropped (:297-298)
+        self.dw_conv_1d = nn.Conv1d(d, d, kernel_size, 1, padding=(kernel_size - 1) if causal else (kernel_size - 1) // 2,
+                                    groups=d)
         self.BN = nn.BatchNorm1d(d)
         self.pw_conv_2 = nn.Conv2d(1, 1, 1, 1, 0)
         self.kernel_size = kernel_size
 
 
 class _EncoderLayer(nn.Module):  # conformer.py:339-346
-    def __init__(self, d_model, n_head, d_ffn, kernel_size, dropout_rate):
+    def __init__(self, d_model, n_head, d_ffn, kernel_size, dropout_rate, causal=False):
         super().__init__()
         self.feed_forward_in = _FeedForward(d_model, d_ffn, dropout_rate)
         self.self_attn = _SelfAttention(n_head, d_model)
-        self.conv = _ConvModule(d_model, kernel_size)
+        self.conv = _ConvModule(d_model, kernel_size, causal)
         self.feed_forward_out = _FeedForward(d_model, d_ffn, dropout_rate)
         self.layer_norm = nn.LayerNorm(d_model)
 
@@ -90,8 +92,10 @@ class ConformerEncoder(nn.Module):  # conformer.py:110-150
     def __init__(self, idim=257, attention_dim=256, attention_heads=4, linear_units=1024, num_blocks=16,
                  kernel_size=33, dropout_rate=0.1, causal=False, relative_pos_emb=True):
         super().__init__()
-        if causal:
-            raise NotImplementedError("causal ConvModule is never used by the reference path")
+        # causal (conformer.py:131, 265-273): no recipe of the reference sets it (Conformer.build_model never passes it),
+        # but the class takes it: every block's conv module then looks kernel_size - 1 frames back and none ahead
+        # (csship_conv_weights.causal; the attention itself stays unmasked, as in the reference)
+        self.causal = bool(causal)
         self.embed = nn.Sequential(nn.Linear(idim, attention_dim), nn.LayerNorm(attention_dim),
                                    nn.Dropout(dropout_rate), nn.ReLU())
         # conformer.py:131-137.  Without relative positions the kernels run against an all-zero position table: the band
@@ -99,7 +103,7 @@ class ConformerEncoder(nn.Module):  # conformer.py:110-150
         # for an option no recipe of the reference selects)
         self.pos_emb = _RelPos(attention_dim // attention_heads, 1000) if relative_pos_emb else None
         self.encoders = nn.Sequential(*[
-            _EncoderLayer(attention_dim, attention_heads, linear_units, kernel_size, dropout_rate)
+            _EncoderLayer(attention_dim, attention_heads, linear_units, kernel_size, dropout_rate, causal)
             for _ in range(num_blocks)])
         self.idim, self.d_model, self.n_head = idim, attention_dim, attention_heads
         self.d_ffn, self.kernel_size = linear_units, kernel_size
@@ -262,6 +266,7 @@ class Conformer(nn.Module):
             L.conv.bn_g, L.conv.bn_b = f32(c.BN.weight), f32(c.BN.bias)
             L.conv.bn_mean, L.conv.bn_var = f32(c.BN.running_mean), f32(c.BN.running_var)
             L.conv.pw2_w, L.conv.pw2_b = f32(c.pw_conv_2.weight), f32(c.pw_conv_2.bias)
+            L.conv.causal = 1 if c.causal else 0
             L.ln_g, L.ln_b = f32(lay.layer_norm.weight), f32(lay.layer_norm.bias)
 
         w = _lib.ConformerWeights()

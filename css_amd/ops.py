@@ -274,9 +274,12 @@ def mha_relpos_probs(qkv, pe_pack, lse, n_head, drop=None):
 def conv_weights_struct(t):
     """t: dict of f32 CUDA tensors keyed like _lib.ConvWeights fields."""
     cw = _lib.ConvWeights()
-    for name, _ in _lib.ConvWeights._fields_:
+    for name, typ in _lib.ConvWeights._fields_:
         v = t.get(name)
-        setattr(cw, name, v.data_ptr() if v is not None else None)
+        if typ is not C.c_void_p:     # "causal": a flag, not a tensor
+            setattr(cw, name, int(bool(v)) if v is not None else 0)
+        else:
+            setattr(cw, name, v.data_ptr() if v is not None else None)
     return cw
 
 

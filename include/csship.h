@@ -388,6 +388,11 @@ typedef struct csship_conv_weights_s {
   const float *dw_w, *dw_b; /* depthwise taps TRANSPOSED to [k, D] (coalesced per-channel reads), bias [D] */
   const float *bn_g, *bn_b, *bn_mean, *bn_var;
   const float *pw2_w, *pw2_b;
+  int32_t causal; /* 0: taps centred on the frame (padding (k-1)/2, conformer.py:274-282); 1: the causal module of
+                   * conformer.py:265-273, 297-298 (tap j of frame t reads frame t + j - (k-1)).  Honoured by csship_convmod*
+                   * and their backward twins; the fused forms (csship_outproj_conv, csship_outproj_glu + csship_conv_from_glu,
+                   * csship_encoder_chain with conv_g) return CSSHIP_EUNSUPPORTED for it and csship_conformer_forward
+                   * takes the separate output projection + csship_convmod instead */
 } csship_conv_weights;
 size_t csship_convmod_workspace(int32_t B, int32_t T, int32_t D);
 int csship_convmod(const float* x, float* y, const csship_conv_weights* w, int32_t B, int32_t T,

@@ -74,8 +74,10 @@ def attention(x, sd, p, n_head, pos_k, drop=_no_drop, site=""):
     return drop(_lin(ctx, sd, p + ".linear_out"), site + ".out")
 
 
-def conv_module(x, sd, p, kernel_size, training_bn=False, drop=_no_drop, site=""):
-    """ConvModule.forward, conformer.py:289-303 (non-causal).
+def conv_module(x, sd, p, kernel_size, training_bn=False, drop=_no_drop, site="", causal=False):
+    """ConvModule.forward, conformer.py:289-303.  causal (conformer.py:265-273, 297-298): the depthwise convolution is
+    padded by kernel_size - 1 on both sides and the last kernel_size - 1 outputs are dropped - tap k of frame t reads
+    frame t + k - (kernel_size - 1).
 
     The two "pointwise convs" are Conv2d(1,2,1) / Conv2d(1,1,1): scalar gains.
     training_bn=True uses batch statistics (biased variance) as BatchNorm1d does
@@ -88,7 +90,9 @@ def conv_module(x, sd, p, kernel_size, training_bn=False, drop=_no_drop, site=""
     g = g.transpose(1, 2)  # [B,D,T]
     D = g.shape[1]
     y = F.conv1d(g, sd[p + ".dw_conv_1d.weight"], sd[p + ".dw_conv_1d.bias"],
-                 padding=(kernel_size - 1) // 2, groups=D)
+                 padding=(kernel_size - 1) if causal else (kernel_size - 1) // 2, groups=D)
+    if causal:
+        y = y[:, :, : -(kernel_size - 1)]
     if training_bn:
         mu = y.mean(dim=(0, 2), keepdim=True)
         var = y.var(dim=(0, 2), unbiased=False, keepdim=True)
@@ -101,11 +105,11 @@ def conv_module(x, sd, p, kernel_size, training_bn=False, drop=_no_drop, site=""
     return drop(y * sd[p + ".pw_conv_2.weight"].reshape(()) + sd[p + ".pw_conv_2.bias"].reshape(()), site + ".out")  # :302
 
 
-def encoder_layer(x, sd, p, n_head, kernel_size, pos_k, training_bn=False, drop=_no_drop, layer=0):
+def encoder_layer(x, sd, p, n_head, kernel_size, pos_k, training_bn=False, drop=_no_drop, layer=0, causal=False):
     """EncoderLayer.forward, conformer.py:348-362."""
     x = x + 0.5 * feed_forward(x, sd, p + ".feed_forward_in", drop, f"{layer}.ffn_in")
     x = x + attention(x, sd, p + ".self_attn", n_head, pos_k, drop, f"{layer}.attn")
-    x = x + conv_module(x, sd, p + ".conv", kernel_size, training_bn, drop, f"{layer}.conv")
+    x = x + conv_module(x, sd, p + ".conv", kernel_size, training_bn, drop, f"{layer}.conv", causal)
     x = x + 0.5 * feed_forward(x, sd, p + ".feed_forward_out", drop, f"{layer}.ffn_out")
     return _ln(x, sd, p + ".layer_norm")
 
@@ -116,22 +120,22 @@ def embed(x, sd, p="conformer.embed", drop=_no_drop):
 
 
 def encoder(x, sd, n_head=4, kernel_size=33, num_blocks=16, relative_pos_emb=True,
-            training_bn=False, p="conformer", drop=_no_drop):
+            training_bn=False, p="conformer", drop=_no_drop, causal=False):
     """ConformerEncoder.forward, conformer.py:152-165."""
     x = embed(x, sd, p + ".embed", drop)
     pos_k = rel_pos_table(sd[p + ".pos_emb.pe_k.weight"], x.shape[1]) if relative_pos_emb else None
     for l in range(num_blocks):
-        x = encoder_layer(x, sd, f"{p}.encoders.{l}", n_head, kernel_size, pos_k, training_bn, drop, l)
+        x = encoder_layer(x, sd, f"{p}.encoders.{l}", n_head, kernel_size, pos_k, training_bn, drop, l, causal)
     return x
 
 
 def forward(f, sd, num_spk=2, num_noise=1, n_head=4, kernel_size=33, num_blocks=16,
-            relative_pos_emb=True, training_bn=False, drop=_no_drop):
+            relative_pos_emb=True, training_bn=False, drop=_no_drop, causal=False):
     """Conformer.forward, conformer.py:83-104 -> (y_pred [N,K,T,F], masks (K+1)x[N,T,F])."""
     if f.dim() == 4:
         f = f.squeeze(0)
     f_orig = f
-    h = encoder(mvn_time(f), sd, n_head, kernel_size, num_blocks, relative_pos_emb, training_bn, drop=drop)
+    h = encoder(mvn_time(f), sd, n_head, kernel_size, num_blocks, relative_pos_emb, training_bn, drop=drop, causal=causal)
     m = torch.relu(_lin(h, sd, "linear"))
     masks = torch.chunk(m, num_spk + num_noise, dim=2)
     y_pred = torch.stack([mk * f_orig for mk in masks[:-1]], dim=1)

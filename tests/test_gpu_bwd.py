@@ -293,9 +293,11 @@ def test_attention_backward(ob):
     assert relerr(dpe, ped.grad) < 1e-2
 
 
-def test_convmod_backward(ob):
+@pytest.mark.parametrize("causal", [False, True])
+def test_convmod_backward(ob, causal):
     """ConvModule backward (LN -> scalar GLU -> depthwise conv -> batch-stat BatchNorm -> ReLU -> affine, + residual)
-    vs float64 autograd of the same formula (conformer.py:289-303,357).  All-f32 kernels: tight tolerance."""
+    vs float64 autograd of the same formula (conformer.py:289-303,357; causal: :265-273, 297-298).  All-f32 kernels:
+    tight tolerance."""
     import torch.nn.functional as F
     from css_amd import ops
     for B, T, D in ((3, 77, 256), (2, 50, 512)):
@@ -310,13 +312,17 @@ def test_convmod_backward(ob):
         xr = x.double().requires_grad_(True)
         a = F.layer_norm(xr, (D,), R["ln_g"], R["ln_b"], 1e-5)
         g = (a * R["pw1_w"][0] + R["pw1_b"][0]) * torch.sigmoid(a * R["pw1_w"][1] + R["pw1_b"][1])
-        c = F.conv1d(g.transpose(1, 2), R["dw"][:, None, :], R["dw_b"], padding=K // 2, groups=D)
+        if causal:
+            c = F.conv1d(g.transpose(1, 2), R["dw"][:, None, :], R["dw_b"], padding=K - 1, groups=D)[:, :, : -(K - 1)]
+        else:
+            c = F.conv1d(g.transpose(1, 2), R["dw"][:, None, :], R["dw_b"], padding=K // 2, groups=D)
         mu, var = c.mean((0, 2), keepdim=True), c.var((0, 2), unbiased=False, keepdim=True)
         zh = (c - mu) / torch.sqrt(var + 1e-5) * R["bn_g"][None, :, None] + R["bn_b"][None, :, None]
         y = xr + (torch.relu(zh) * R["pw2_w"] + R["pw2_b"]).transpose(1, 2)
         y.backward(dy.double())
         W = {k: v.to(DEV) for k, v in P.items() if k != "dw"}
         W["dw_w"] = P["dw"].T.contiguous().to(DEV)                      # the forward takes the taps as [k, D]
+        W["causal"] = causal
         yg, fws = ops.convmod(x.to(DEV), W, K, batch_stats=True, return_workspace=True)
         assert relerr(yg, y.detach()) < 1e-5
         stats = fws.view(torch.float32)[-4 * D:]

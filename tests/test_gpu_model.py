@@ -484,6 +484,55 @@ def test_conformer_without_relative_positions():
     assert err < 6e-2
 
 
+def test_causal_conformer_forward_and_gradients(golden):
+    """ConformerEncoder(causal=True) (conformer.py:131, 265-273): eval forward of a 2-block model against the REFERENCE's
+    own causal encoder (tests/golden/causal.npz, through the head-free oracle for the masks), and train-mode gradients
+    through the explicit backward (causal halo in the conv module's forward, tap-gradient and input-gradient passes)
+    against autograd through the oracle."""
+    from css_amd.models import MODELS
+    from css_amd.objectives import OBJECTIVES
+    import grad_ref
+    conf = dict(attention_dim=256, attention_heads=4, linear_units=1024, num_blocks=2, kernel_size=33, dropout_rate=0.1,
+                relative_pos_emb=True, causal=True)
+    m = MODELS["Conformer"](257, 257, 2, 1, conf)
+    shapes = {k[len("conformer."):]: v for k, v in syn.conformer_shapes(num_blocks=2).items() if k.startswith("conformer.")}
+    sd = {"conformer." + k: v for k, v in syn.fill_state_dict(shapes, 31).items()}
+    sd.update({k: v for k, v in syn.fill_state_dict(syn.conformer_shapes(num_blocks=2), 32).items() if k.startswith("linear.")})
+    assert set(m.state_dict()) == set(sd)      # same keys and shapes as the non-causal model (conformer.py:265-282)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    f = rnd((2, 90, 257), 12).abs()
+    with torch.no_grad():
+        masks, enc = m._forward_masks_hip(f.to(DEV), want_encoder_out=True)
+    g = golden("causal.npz")
+    e_enc = float(((enc.cpu() - torch.from_numpy(g["encoder2"])) ** 2).mean())
+    want = torch.cat(oracle.conformer.forward(f, sd, num_blocks=2, causal=True)[1], -1)
+    noncausal = torch.cat(oracle.conformer.forward(f, sd, num_blocks=2)[1], -1)
+    print(f"[parity] causal encoder vs the reference's causal ConformerEncoder: MSE {e_enc:.3e}; masks vs oracle "
+          f"{mask_mse(masks, want):.3e} (the non-causal model is {mask_mse(noncausal, want):.3e} away)")
+    assert e_enc < 1e-4 and mask_mse(masks, want) < 1e-4 and mask_mse(noncausal, want) > 10 * mask_mse(masks, want)
+    m.train()
+    tg = [(rnd((2, 90, 257), 60 + k).abs() * 0.5).to(DEV) for k in range(2)]
+    obj = OBJECTIVES["MSE"].build_objective({})
+    loss = obj(m, {"mix": f.to(DEV), "source1": tg[0], "source2": tg[1]}, device=DEV)
+    loss.backward()
+    grads = {k: p.grad.clone() for k, p in m.named_parameters()}
+    perm = obj.last_permutation.cpu().tolist()
+    tc = [t.cpu() for t in tg]
+    sdl = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    for v in sdl.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    _, mk = oracle.conformer.forward(f, sdl, num_blocks=2, training_bn=True, causal=True, drop=grad_ref.drop_of(m))
+    grad_ref.pit_loss_with_perm(torch.cat(mk, -1), f, tc, perm).backward()
+    ref = {k: sdl[k].grad for k, _ in m.named_parameters()}
+    err_g, worst = grad_ref.compare(grads, ref)
+    print(f"[parity] causal model: gradients vs oracle autograd {err_g:.3e}, worst {worst[0]} {worst[1]:.3e}")
+    # bf16 operand noise of a 2-block model (measured 3.5e-2; the conv module's own backward, all f32, is held to 2e-4
+    # against float64 in tests/test_gpu_bwd.py::test_convmod_backward[True])
+    assert err_g < 6e-2 and worst[1] < 0.25
+
+
 def test_unsupported_widths_raise_instead_of_falling_back():
     """There is no torch-op arithmetic path in the package: a training forward the backward kernels do not cover raises."""
     from css_amd.models import MODELS

@@ -412,6 +412,21 @@ def test_convmod(ops, B, T, batch_stats):
     assert err(y, ref) < (2e-4 if batch_stats else 5e-5)  # all-fp32 kernel
 
 
+@pytest.mark.parametrize("batch_stats", [False, True])
+def test_convmod_causal_golden(ops, golden, batch_stats):
+    """csship_conv_weights.causal: the causal ConvModule (conformer.py:265-273, 297-298) against the reference's own
+    ConvModule(causal=True) output (tests/golden/causal.npz) and the oracle at a ragged length."""
+    g = golden("causal.npz")
+    sd, dw = _conv_weights(24)
+    dw = dict(dw, causal=True)
+    x = rnd((2, 64, 256), 11)
+    want = torch.from_numpy(g["conv_trainbn" if batch_stats else "conv_eval"])
+    assert err(ops.convmod(x.to(DEV), dw, 33, batch_stats=batch_stats) - x.to(DEV), want) < (2e-4 if batch_stats else 5e-5)
+    x = rnd((3, 101, 256), 44)
+    ref = x + oracle.conformer.conv_module(x, sd, "cv", 33, training_bn=batch_stats, causal=True)
+    assert err(ops.convmod(x.to(DEV), dw, 33, batch_stats=batch_stats), ref) < (2e-4 if batch_stats else 5e-5)
+
+
 def test_convmod_golden(ops, golden):
     g = golden("conformer.npz")
     sd, dw = _conv_weights(24)

@@ -114,6 +114,32 @@ def test_conformer_submodules(golden):
     close(oracle.conformer.encoder_layer(x, sd, "l", H, KS, pos_k), g["layer"], 5e-5)
 
 
+def _causal_encoder_sd():
+    """state_dict of the reference's ConformerEncoder(257, 256, 4, 1024, 2, 33, causal=True) as make_golden_causal.py fills
+    it (keys without the model prefix), re-keyed for oracle.conformer.encoder"""
+    shapes = {k[len("conformer."):]: v for k, v in syn.conformer_shapes(num_blocks=2).items() if k.startswith("conformer.")}
+    return {"conformer." + k: v for k, v in syn.fill_state_dict(shapes, 31).items()}
+
+
+def test_causal_conv_module_and_encoder(golden):
+    """The causal ConvModule (conformer.py:265-273, 297-298) - no recipe of the reference builds it, the class does -
+    against outputs of the reference's own ConvModule(causal=True) / ConformerEncoder(causal=True)
+    (tests/golden/make_golden_causal.py)."""
+    g = golden("causal.npz")
+    x = rnd((2, 64, D), 11)
+    full = syn.conformer_shapes(num_blocks=1)
+    pre = "conformer.encoders.0."
+    conv_shapes = {k[len(pre + "conv."):]: s for k, s in full.items() if k.startswith(pre + "conv.")}
+    sd = _sd(conv_shapes, 24, "cv.")
+    close(oracle.conformer.conv_module(x, sd, "cv", KS, causal=True), g["conv_eval"], 2e-5)
+    close(oracle.conformer.conv_module(x, sd, "cv", KS, training_bn=True, causal=True), g["conv_trainbn"], 5e-5)
+    assert float((oracle.conformer.conv_module(x, sd, "cv", KS) - torch.from_numpy(g["conv_eval"])).abs().max()) > 1e-2
+    f = rnd((2, 90, 257), 12).abs()
+    esd = _causal_encoder_sd()
+    assert sorted(k[len("conformer."):] for k in esd) == list(g["encoder2_keys"])
+    close(oracle.conformer.encoder(oracle.conformer.mvn_time(f), esd, num_blocks=2, causal=True), g["encoder2"], 1e-4)
+
+
 @pytest.mark.parametrize("nb", [2, 16])
 def test_conformer_full(golden, nb):
     g = golden("conformer.npz")
