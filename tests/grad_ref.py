@@ -35,7 +35,8 @@ def oracle_masks(model, f, training_bn, drop=None):
         enc = model.conformer
         _, masks = oracle.conformer.forward(f, sd, num_spk=model.num_spk, num_noise=model.num_noise, n_head=enc.n_head,
                                             kernel_size=enc.kernel_size, num_blocks=len(enc.encoders),
-                                            relative_pos_emb=enc.pos_emb is not None, training_bn=training_bn, **({"drop": drop} if drop is not None else {}))
+                                            relative_pos_emb=enc.pos_emb is not None, training_bn=training_bn,
+                                            causal=bool(getattr(enc, "causal", False)), **({"drop": drop} if drop is not None else {}))
     else:
         _, masks = oracle.blstm.forward(f, sd, num_layers=len(model.blstm.encoders), num_spk=model.num_spk,
                                         num_noise=model.num_noise, **({"drop": drop} if drop is not None else {}))
