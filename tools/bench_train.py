@@ -68,5 +68,5 @@ if trace:
     print("losses", " ".join(f"{x:.9f}" for x in trace))
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
-print(f"train step (hip backward, {a.blocks} blocks): {dt * 1e3:.1f} ms  "
+print(f"train step (hip backward, {a.blocks} blocks): {dt * 1e3:.3f} ms  "
       f"= {12800 / dt / 1e6:.3f} M frames/s   loss {float(loss):.5f}   peak mem {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB")
