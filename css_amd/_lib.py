@@ -211,6 +211,11 @@ def lib():
             raise RuntimeError(
                 f"css_amd: HIP library not found at {LIB_PATH}. Build it (make -C css_amd/csrc); "
                 "there is no CPU fallback for the css hot path.")
+        # torch FIRST: it ships its own libamdhip64, and libcsship.so (linked against the system ROCm's) must bind to the
+        # runtime torch's streams and allocations belong to.  Loaded the other way round (build() then smoke() in one
+        # process, before anything imported torch) the process holds two HIP runtimes and the first launch on a torch
+        # stream fails with hipErrorInvalidHandle-class errors ("kernel launch failed").
+        import torch  # noqa: F401
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)  # AttributeError here = header/library mismatch
