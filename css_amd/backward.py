@@ -68,6 +68,7 @@ def ffn_bwd_fused(x, dy, ln_g, ln_b, b1, w1p, w2tp, w1tp, d_ffn, alpha=0.5, drop
 _NO_BAND = bool(os.environ.get("CSSHIP_NO_BAND"))   # A/B timing: the skewed-dS product over the whole window axis
 _NO_LN_Y = bool(os.environ.get("CSSHIP_NO_LN_Y"))   # A/B timing: LayerNorm(x) for the q/k/v weight gradient by its own launch
 _SPLIT_ATTN_BWD = bool(os.environ.get("CSSHIP_ATTN_BWD_SPLIT"))   # A/B timing: probabilities / softmax backward / dS k as separate launches
+_NO_DVDK = bool(os.environ.get("CSSHIP_NO_DVDK"))   # A/B timing: dV and dK as two general batched products
 
 
 def relpos_window(pe_table_bf, T, maxlen):
@@ -101,7 +102,7 @@ def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000, window=None, probs=
         dsk = torch.zeros((B, T, H, W), dtype=BF, device=qkv.device) if skew_buf is None else skew_buf
         p_v, ds, dsk, dq1, q_rows = ob.mha_bwd_core(qkv, probs[0], probs[1], dao, None, dsk, H, drop=drop_p,
                                                     out=ao.reshape(B * T, H * 64), want_q_rows=True)
-        return _mha_core_products(qkv, g, q, k, do, p_v, ds, dsk, dq1, win, idx, window, dwin_acc, maxlen, q_rows)
+        return _mha_core_products(qkv, g, q, k, do, p_v, ds, dsk, dq1, win, idx, window, dwin_acc, maxlen, q_rows, dao=dao)
     if probs is not None:   # (pe_pack, lse) from the training forward: one attention-shaped kernel recomputes P
         if drop_p is not None:
             p, p_v = ops.mha_relpos_probs(qkv, probs[0], probs[1], H, drop=drop_p)
@@ -119,17 +120,23 @@ def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000, window=None, probs=
         dp = ob.bgemm(do, v)                             # dO v^T           [B,H,T,T]
         ds, dsk = ob.relpos_softmax_bwd(p, dp, T, W)     # dS, and dS skewed onto the window axis [B,T,H,W]
     dq1 = ob.bgemm(ds[..., :T], k, b_kmajor=True)                       # dS k
-    return _mha_core_products(qkv, g, q, k, do, p if p_v is None else p_v, ds, dsk, dq1, win, idx, window, dwin_acc, maxlen)
+    return _mha_core_products(qkv, g, q, k, do, p if p_v is None else p_v, ds, dsk, dq1, win, idx, window, dwin_acc, maxlen,
+                              dao=dao)
 
 
-def _mha_core_products(qkv, g, q, k, do, p_v, ds, dsk, dq1, win, idx, window, dwin_acc, maxlen, q_rows=None):
+def _mha_core_products(qkv, g, q, k, do, p_v, ds, dsk, dq1, win, idx, window, dwin_acc, maxlen, q_rows=None, dao=None):
     """the batched GEMMs behind dS: dV = p_v^T dO, dK = dS^T q, dq = dS_skew pe_window + dq1, d(pe_window) = dS_skew^T q"""
     B, T, _ = qkv.shape
     H, W = g.shape[3], win.shape[0]
     dqkv = torch.empty_like(qkv)
     dq, dk, dv = (dqkv.view(B, T, 3, H, 64)[:, :, i].permute(0, 2, 1, 3) for i in range(3))
-    ob.bgemm(p_v[..., :T], do, a_kmajor=True, b_kmajor=True, out=dv)    # dV = P^T dO
-    ob.bgemm(ds[..., :T], q, a_kmajor=True, b_kmajor=True, out=dk)      # dK = dS^T q
+    streamed = (not _NO_DVDK and dao is not None and p_v.dim() == 4 and p_v.is_contiguous() and ds.is_contiguous()
+                and p_v.shape == ds.shape and p_v.shape[3] % 8 == 0 and dao.is_contiguous())
+    if streamed:   # both in one pass over P' and dS (csship_attn_dvdk)
+        ob.attn_dvdk(p_v, ds, dao.view(B * T, H * 64), qkv, dqkv, H)
+    else:
+        ob.bgemm(p_v[..., :T], do, a_kmajor=True, b_kmajor=True, out=dv)    # dV = P^T dO
+        ob.bgemm(ds[..., :T], q, a_kmajor=True, b_kmajor=True, out=dk)      # dK = dS^T q
     # + dS_skew pe_window; row i of dS_skew is zero outside columns i .. i + T - 1: the product skips those reduction tiles
     ob.bgemm(dsk.permute(0, 2, 1, 3), win[None, None], b_kmajor=True, add=dq1, out=dq, band=0 if _NO_BAND else T - 1)
     if q_rows is None:

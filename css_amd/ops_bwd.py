@@ -448,6 +448,19 @@ def mha_bwd_core(qkv, pe_pack, lse, d_out, d, skew, n_head, drop=None, out=None,
     return (p_v, ds, skew, dq1, q_rows) if want_q_rows else (p_v, ds, skew, dq1)
 
 
+def attn_dvdk(p_v, ds, d_out, qkv, dqkv, n_head):
+    """dV = P'^T dO and dK = dS^T q of the attention in one streaming pass over the two [B,H,T,ldp] bf16 operands
+    (csship_attn_dvdk); writes the k and v thirds of dqkv bf16 [B,T,3*H*64]."""
+    _need(p_v, torch.bfloat16, "p_v"), _need(ds, torch.bfloat16, "ds"), _need(qkv, torch.bfloat16, "qkv")
+    _need(d_out, torch.bfloat16, "d_out"), _need(dqkv, torch.bfloat16, "dqkv")
+    B, T, _ = qkv.shape
+    if not (p_v.is_contiguous() and ds.is_contiguous() and d_out.is_contiguous() and qkv.is_contiguous() and dqkv.is_contiguous()) \
+            or p_v.shape != ds.shape or tuple(p_v.shape[:3]) != (B, n_head, T) or dqkv.shape != qkv.shape:
+        raise RuntimeError("css_amd: attn_dvdk expects dense [B,H,T,ldp] operands and [B,T,3*H*64] projections")
+    check(lib().csship_attn_dvdk(_ptr(p_v), _ptr(ds), p_v.shape[3], _ptr(d_out), _ptr(qkv), _ptr(dqkv), B, T, n_head, _stream()))
+    return dqkv
+
+
 def attn_softmax_bwd(qkv, d_out, p, d, skew, n_head, drop=None):
     """dS = P o (dO v^T - D) -> (dS bf16 like p, skew) ; skew: bf16 [B,T,H,W], zero outside the band, filled in place."""
     _need(qkv, torch.bfloat16, "qkv"), _need(p, torch.bfloat16, "p")

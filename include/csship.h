@@ -816,6 +816,16 @@ int csship_lstm_bidir_bwd_dist(const float* gates, const float* c, const float* 
                                float* dgates, int32_t B, int32_t T, int32_t H, void* workspace,
                                size_t workspace_bytes, csship_stream_t stream);
 
+/* ---- csship_attn_dvdk (css_amd/csrc/attnbwd.hip): the value and key gradients of the attention in one streaming pass over
+ * the two [B, H, T, T] operands the one-pass backward kernel leaves (torch.autograd's two batched matmuls behind
+ * conformer.py:236-253 in the reference):
+ *   dV[b, j, h, :] = sum_i p_v[b, h, i, j] d_out[b, i, h, :]     dK[b, j, h, :] = sum_i ds[b, h, i, j] q[b, i, h, :]
+ * p_v / ds: bf16 [B, H, T, ld_p] (ld_p >= T, a multiple of 8, zeros in [T, ld_p): what csship_mha_relpos_bwd_core writes);
+ * d_out: bf16 [B*T, H*64]; qkv: bf16 [B*T, 3*H*64] (q = the first third, as the forward used it); dqkv: bf16
+ * [B*T, 3*H*64], of which the k and v thirds are written.  f32 accumulation over the queries in ascending order. */
+int csship_attn_dvdk(const uint16_t* p_v, const uint16_t* ds, int64_t ld_p, const uint16_t* d_out, const uint16_t* qkv,
+                     uint16_t* dqkv, int32_t B, int32_t T, int32_t H, csship_stream_t stream);
+
 /* ---- csship_p2p_reduce (css_amd/csrc/optim.hip): out[lo:hi] = scale * (src_0 + src_1 + ... + src_{world-1})[lo:hi],
  * summed in that order (bit-reproducible), for the direct (one-shot) all-reduce of css_amd.parallel.P2PAllReduce
  * (replaces scripts/python/combine_models.py:55-82): srcs_host is a HOST array of world <= 8 device

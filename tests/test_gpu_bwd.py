@@ -505,6 +505,33 @@ def test_attention_backward_core_one_pass(ob, B, T, H, p_drop):
     assert relerr(dq1, ref) < 2e-5
 
 
+@pytest.mark.parametrize("B,H,T", [(2, 4, 100), (1, 4, 7), (3, 2, 65), (2, 4, 400), (1, 8, 1100), (32, 4, 400)])
+def test_attn_dvdk_streaming(ob, B, H, T):
+    """csship_attn_dvdk: dV = P'^T dO and dK = dS^T q in one pass over the two [B,H,T,ldp] operands (the attention's
+    value / key gradients, conformer.py:236-253 under autograd) against float64 on the same bf16 operands; keys split over 1, 2 and 5+ workgroups per head, ragged last blocks."""
+    ldp = (T + 7) // 8 * 8
+    p = torch.zeros(B, H, T, ldp)
+    ds = torch.zeros(B, H, T, ldp)
+    p[..., :T] = torch.softmax(rnd((B, H, T, T), 300), -1)
+    ds[..., :T] = rnd((B, H, T, T), 301, 0.05)
+    qkv = rnd((B, T, 3 * H * 64), 302)
+    dao = rnd((B * T, H * 64), 303)
+    pb, dsb, qb, dob = (x.to(DEV).to(torch.bfloat16).contiguous() for x in (p, ds, qkv, dao))
+    dqkv = torch.full_like(qb, float("nan"))
+    ob.attn_dvdk(pb, dsb, dob, qb, dqkv, H)
+    torch.cuda.synchronize()
+    g = dqkv.view(B, T, 3, H, 64)
+    q = qb.view(B, T, 3, H, 64)[:, :, 0].permute(0, 2, 1, 3).double().cpu()          # [B,H,T,64]
+    do = dob.view(B, T, H, 64).permute(0, 2, 1, 3).double().cpu()
+    dv_ref = pb[..., :T].double().cpu().transpose(-1, -2) @ do
+    dk_ref = dsb[..., :T].double().cpu().transpose(-1, -2) @ q
+    dv = g[:, :, 2].permute(0, 2, 1, 3).double().cpu()
+    dk = g[:, :, 1].permute(0, 2, 1, 3).double().cpu()
+    assert bool(torch.isnan(g[:, :, 0].float()).all())            # the q third is not touched
+    assert bool(torch.isfinite(dv).all()) and bool(torch.isfinite(dk).all())
+    assert relerr(dv, dv_ref) < 6e-3 and relerr(dk, dk_ref) < 6e-3   # bf16 output rounding
+
+
 def test_convmod_backward_next_operand(ob):
     """csship_convmod_bwd_next: the third result is bf16(dropout(dx)) under the next operator's cfg (what
     csship_dropout_apply + the GEMM's rounding give), dx and the parameter gradients unchanged."""
