@@ -11,6 +11,14 @@
 // [32][64] blocks, global -> registers four blocks ahead -> LDS (double buffered, one barrier per block).  All four
 // operands are wanted with the reduction index (the query) inside a lane's fragment, i.e. transposed: they are staged
 // exactly as they lie in memory and read with ds_read_b64_tr_b16 (the V^T read of the forward kernel).
+// Measured (32 x 4 x 400, tools/bench_dvdk.py): 27.7 us against 35.6 us for the two products.  Streaming the same row
+// segments with no other work takes 16.5 us (tools/probes/lds_vmem.hip: 5.0 TB/s at any prefetch depth - 400-byte
+// halves of 800-byte rows; 5.6 TB/s with 512-byte halves of 1024-byte rows), the dO / q blocks add a third to the
+// loads; the rest is the lockstep of the workgroup (tools/dvdk_stamps.py, per block and wave: loads issued 350..1300
+// cycles behind the address unit's back pressure | fragments + MFMAs 520 | LDS stores 400 | barrier 500..1100).
+// Tried and not kept: wave-private staging of P / dS with a barrier per four blocks (30.2 us - whole chunks cost three
+// extra blocks at T = 400), all 24 fragment reads ahead of the MFMAs (no change), padded row strides and aligned key
+// splits (no change), 128-key workgroups (34 us).
 #include <algorithm>
 
 #include "common.hpp"
@@ -119,9 +127,6 @@ __global__ __launch_bounds__(512) void attn_dvdk_kernel(DvDkArgs a) {
 #define DV_STORE(i0, buf, R) /* (the zero rows are made here, next to the use: a select at the load would be sunk to the \
                                  loop's end by hipcc, behind a wait for every load in flight) */ \
   DV_STORE_BODY(i0, buf, R)
-#if defined(DV_PROBE) && DV_PROBE >= 2
-#define DV_STORE_BODY(i0, buf, R) asm volatile("" ::"v"(R.pa), "v"(R.pb), "v"(R.da), "v"(R.db), "v"(R.a));
-#else
 #define DV_STORE_BODY(i0, buf, R)                                       \
   {                                                                     \
     unsigned char* st_ = smem + (buf) * DV_STAGE;                       \
@@ -131,7 +136,6 @@ __global__ __launch_bounds__(512) void attn_dvdk_kernel(DvDkArgs a) {
     *reinterpret_cast<f32x4*>(st_ + DV_PTILE + o_pb) = R.db;            \
     *reinterpret_cast<f32x4*>(st_ + o_a) = (i0) + arow < a.T ? R.a : f32x4{0.f, 0.f, 0.f, 0.f}; \
   }
-#endif
 
   f32x4 dv[4][2], dk[4][2];
 #pragma unroll
@@ -142,19 +146,9 @@ __global__ __launch_bounds__(512) void attn_dvdk_kernel(DvDkArgs a) {
   const int nblk = (a.T + DV_QB - 1) / DV_QB;
   const bool active = 32 * w < kn;                // waves beyond the workgroup's keys only stage
   auto compute = [&](int buf) {
-#if defined(DV_PROBE) && DV_PROBE >= 1   // -DDV_PROBE=1: no fragment reads / MFMAs; 2: no LDS stores either (tools/bench_dvdk.py)
-    return;
-#endif
     if (!active) return;
     const unsigned char* st = smem + buf * DV_STAGE;
     bf16x8 bp[2], bd[2];
-#if defined(DV_PROBE) && DV_PROBE == -2   // MFMAs without the fragment reads
-    bf16x8 pr_;
-    for (int e = 0; e < 8; ++e) pr_[e] = (__bf16)(float)(lane + buf);
-    asm volatile("" : "+v"(pr_));
-#define dv_frag_p(...) pr_
-#define dv_frag_a(...) pr_
-#endif
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
       bp[jt] = dv_frag_p(st, 32 * w + 16 * jt, g, q4, p4);
@@ -164,15 +158,11 @@ __global__ __launch_bounds__(512) void attn_dvdk_kernel(DvDkArgs a) {
     for (int dt = 0; dt < 4; ++dt) {
       const bf16x8 ado = dv_frag_a(st + 2 * DV_PTILE, 16 * dt, g, q4, p4);
       const bf16x8 aq = dv_frag_a(st + 2 * DV_PTILE + DV_ATILE, 16 * dt, g, q4, p4);
-#if defined(DV_PROBE) && DV_PROBE == -1   // fragment reads without the MFMAs
-      asm volatile("" ::"v"(ado), "v"(aq), "v"(bp[0]), "v"(bp[1]), "v"(bd[0]), "v"(bd[1]));
-#else
 #pragma unroll
       for (int jt = 0; jt < 2; ++jt) {
         dv[dt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ado, bp[jt], dv[dt][jt], 0, 0, 0);
         dk[dt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, bd[jt], dk[dt][jt], 0, 0, 0);
       }
-#endif
     }
   };
   DV_LOAD(0, s0)
