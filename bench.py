@@ -73,6 +73,8 @@ def parse_args():
     ap.add_argument("--fuse-conv", type=int, default=None, help="debug: csship_conformer_weights.fuse_conv override")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying the "
                     "step as one captured HIP graph")
+    ap.add_argument("--leg-timeout", type=float, default=300.0, help="N > 1: seconds the training legs (the only part that runs "
+                    "collectives) may take before rank 0 prints the line without them and every rank leaves")
     ap.add_argument("--blocks", type=int, default=16, help="debug only: anything but 16 is not the headline config")
     ap.add_argument("--overlap-stft", action="store_true", help="debug A/B (measured SLOWER, 1.46 vs 1.43 ms): the two target "
                     "spectrograms on a second stream beside the encoder, joined before the loss kernel")
@@ -371,34 +373,6 @@ def main():
                         "allreduce_schedule": ([hi - lo for lo, hi in tstep.plan] if world > 1 else None)})
         return rec
 
-    if args.mode == "fwd" and not args.no_train_step:
-        def tfeatures():
-            with torch.no_grad():
-                mags = ops.stft(audio, ("mag",), pad_rows=PAD_ROWS)["mag"]
-            return {"mix": mags[0], "source1": mags[1], "source2": mags[2]}
-        progress("leg: train-mode forward + PIT")
-        train_fwd_rec = train_leg(257, tfeatures, FLOP_PER_FRAME, "STFT-frames/sec (TRAIN-mode fwd+PIT: dropout 0.1, batch-statistics "
-                                  "BatchNorm, activations kept for the backward; no backward) Conformer-1ch", forward_only=True)
-        progress(f"leg: training step ({train_fwd_rec.get('ms_per_step', train_fwd_rec)} ms train fwd+PIT)")
-        train_rec = train_leg(257, tfeatures, FLOP_PER_FRAME, "STFT-frames/sec (training step: fwd+PIT+bwd+all-reduce+clip/Adam) Conformer-1ch")
-        if train_rec and "error" not in train_rec:
-            train_rec["mode"] = ("train-mode forward (dropout 0.1, batch-statistics BatchNorm) + PIT + explicit backward + "
-                                 "gradient all-reduce (N > 1) + fused clip/Adam; captured HIP graph replay")
-        # configs[2]: the 7-channel training step (IPD features [32, 400, 1799] from raw 7-channel audio, idim 1799)
-        from css_amd.executor.feature import FeatureExtractor
-        x7 = syn.synthetic_multichannel(src, n_ch=7, seed=rank).to(dev)          # [B, 7, n]
-        fe7 = FeatureExtractor(512, 256, True, "1,0;2,0;3,0;4,0;5,0;6,0")
-
-        def tfeatures7():
-            with torch.no_grad():
-                _, f7, _, _ = fe7.forward_tf(x7, want_spectra=False)
-                tg = ops.stft(audio[1:3], ("mag",), pad_rows=PAD_ROWS)["mag"]
-            return {"mix": f7, "source1": tg[0], "source2": tg[1]}
-        progress(f"leg: 7-channel training step ({train_rec.get('ms_per_step', train_rec)} ms 1ch)")
-        train7_rec = train_leg(257 * 7, tfeatures7, FLOP_PER_FRAME_7CH, "STFT-frames/sec (training step, 7-channel IPD features "
-                               "idim 1799: features+fwd+PIT+bwd+all-reduce+clip/Adam) Conformer-7ch (configs[2])")
-        del x7
-
     progress("in-step launch timeline")
     # ---- rooflines from INSIDE the step: one un-captured eval step with the library's launch timeline on
     roof = None
@@ -541,6 +515,86 @@ def main():
         roof["step_kernel_us"] = {k: round(v[0] * v[1] * 1e6, 1) for k, v in tl.items()}
         roof["step_kernel_us_sum"] = round(sum(roof["step_kernel_us"].values()), 1)
 
+    def emit(tf_, tr_, t7_, cpu_, parity_):
+        """rank 0: the ONE JSON line"""
+        frames = world * B * T * args.steps
+        mode_txt = ("eval forward (running-stat BN, no dropout)" if args.mode == "fwd" else
+                    "training step: train-mode forward (batch-stat BN) + PIT + backward + gradient all-reduce + clip/Adam")
+        metric = "STFT-frames/sec (fwd+PIT) Conformer-1ch" if args.mode == "fwd" else \
+            "STFT-frames/sec (training step: fwd+PIT+bwd+all-reduce+Adam) Conformer-1ch"
+        line = {
+            "metric": metric, "value": frames / dt, "unit": "frames/s",
+            "n_gpus": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "Conformer-base 1ch 2-spk fwd+PIT, batch=32x400-frame chunks (configs[1])",
+                       "global_batch": world * B, "frames_per_chunk": T, "num_blocks": args.blocks,
+                       "mode": mode_txt, "parallelism": f"dp{world}",
+                       "launch": "hip-graph replay" if graphed else "eager",
+                       "streams": ("1" if (args.mode != "fwd" or not args.overlap_stft) else
+                                   "2: target-spectrogram STFT beside the encoder, joined before the loss kernel"),
+                       "collective_backend": (backend if world > 1 else None),
+                       "ranks_launched_by": ("launcher" if "TORCHELASTIC_RUN_ID" in os.environ or "GROUP_RANK" in os.environ
+                                             else ("bench.py --gpus" if world > 1 else None))},
+            "per_rank_ms_per_step": per_rank_ms,
+            "roofline": roof, "cpu_baseline": cpu_, "train_fwd_pit": tf_, "train_step": tr_,
+            "train_step_7ch": t7_, "loss": loss_val, "loss_parity": parity_,
+        }
+        print(json.dumps(line))
+        sys.stdout.flush()
+
+    # The training legs run the only collectives of this program (RCCL all-reduce inside the captured step).  With N > 1 they
+    # sit behind a watchdog: should a collective never return, rank 0 still prints the headline line - measured above,
+    # before any collective but the barriers - with the legs marked as timed out, and every rank leaves.
+    legs_done = [False]
+    watchdog = None
+    if world > 1 and args.mode == "fwd" and not args.no_train_step:
+        import threading
+
+        def bail():
+            if legs_done[0]:
+                return
+            print(f"[bench] rank {rank}: the training legs did not finish within {args.leg_timeout} s; leaving without them", file=sys.stderr)
+            if rank == 0:
+                stuck = {"error": f"did not finish within {args.leg_timeout} s (watchdog); the headline above is unaffected"}
+                emit(train_fwd_rec or stuck, train_rec or stuck, train7_rec or stuck, None, None)
+            sys.stderr.flush()
+            os._exit(0)
+        watchdog = threading.Timer(args.leg_timeout, bail)
+        watchdog.daemon = True
+        watchdog.start()
+    if args.mode == "fwd" and not args.no_train_step:
+        def tfeatures():
+            with torch.no_grad():
+                mags = ops.stft(audio, ("mag",), pad_rows=PAD_ROWS)["mag"]
+            return {"mix": mags[0], "source1": mags[1], "source2": mags[2]}
+        progress("leg: train-mode forward + PIT")
+        train_fwd_rec = train_leg(257, tfeatures, FLOP_PER_FRAME, "STFT-frames/sec (TRAIN-mode fwd+PIT: dropout 0.1, batch-statistics "
+                                  "BatchNorm, activations kept for the backward; no backward) Conformer-1ch", forward_only=True)
+        progress(f"leg: training step ({train_fwd_rec.get('ms_per_step', train_fwd_rec)} ms train fwd+PIT)")
+        train_rec = train_leg(257, tfeatures, FLOP_PER_FRAME, "STFT-frames/sec (training step: fwd+PIT+bwd+all-reduce+clip/Adam) Conformer-1ch")
+        if train_rec and "error" not in train_rec:
+            train_rec["mode"] = ("train-mode forward (dropout 0.1, batch-statistics BatchNorm) + PIT + explicit backward + "
+                                 "gradient all-reduce (N > 1) + fused clip/Adam; captured HIP graph replay")
+        # configs[2]: the 7-channel training step (IPD features [32, 400, 1799] from raw 7-channel audio, idim 1799)
+        from css_amd.executor.feature import FeatureExtractor
+        x7 = syn.synthetic_multichannel(src, n_ch=7, seed=rank).to(dev)          # [B, 7, n]
+        fe7 = FeatureExtractor(512, 256, True, "1,0;2,0;3,0;4,0;5,0;6,0")
+
+        def tfeatures7():
+            with torch.no_grad():
+                _, f7, _, _ = fe7.forward_tf(x7, want_spectra=False)
+                tg = ops.stft(audio[1:3], ("mag",), pad_rows=PAD_ROWS)["mag"]
+            return {"mix": f7, "source1": tg[0], "source2": tg[1]}
+        progress(f"leg: 7-channel training step ({train_rec.get('ms_per_step', train_rec)} ms 1ch)")
+        train7_rec = train_leg(257 * 7, tfeatures7, FLOP_PER_FRAME_7CH, "STFT-frames/sec (training step, 7-channel IPD features "
+                               "idim 1799: features+fwd+PIT+bwd+all-reduce+clip/Adam) Conformer-7ch (configs[2])")
+        del x7
+
+    legs_done[0] = True
+    if watchdog is not None:
+        watchdog.cancel()
+
     # ---- CPU baseline: the oracle on one full batch, host cores of this box
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -609,31 +663,7 @@ def main():
                   "margin": 1.0 - rel / LOSS_BUDGET, "ok": bool(rel < LOSS_BUDGET),
                   "what": "PIT-MSE loss of the timed batch: HIP path (bf16 operands) vs the fp32 oracle, SURVEY 8d budget"}
     if rank == 0:
-        frames = world * B * T * args.steps
-        mode_txt = ("eval forward (running-stat BN, no dropout)" if args.mode == "fwd" else
-                    "training step: train-mode forward (batch-stat BN) + PIT + backward + gradient all-reduce + clip/Adam")
-        metric = "STFT-frames/sec (fwd+PIT) Conformer-1ch" if args.mode == "fwd" else \
-            "STFT-frames/sec (training step: fwd+PIT+bwd+all-reduce+Adam) Conformer-1ch"
-        line = {
-            "metric": metric, "value": frames / dt, "unit": "frames/s",
-            "n_gpus": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "Conformer-base 1ch 2-spk fwd+PIT, batch=32x400-frame chunks (configs[1])",
-                       "global_batch": world * B, "frames_per_chunk": T, "num_blocks": args.blocks,
-                       "mode": mode_txt, "parallelism": f"dp{world}",
-                       "launch": "hip-graph replay" if graphed else "eager",
-                       "streams": ("1" if (args.mode != "fwd" or not args.overlap_stft) else
-                                   "2: target-spectrogram STFT beside the encoder, joined before the loss kernel"),
-                       "collective_backend": (backend if world > 1 else None),
-                       "ranks_launched_by": ("launcher" if "TORCHELASTIC_RUN_ID" in os.environ or "GROUP_RANK" in os.environ
-                                             else ("bench.py --gpus" if world > 1 else None))},
-            "per_rank_ms_per_step": per_rank_ms,
-            "roofline": roof, "cpu_baseline": cpu, "train_fwd_pit": train_fwd_rec, "train_step": train_rec,
-            "train_step_7ch": train7_rec, "loss": loss_val, "loss_parity": parity,
-        }
-        print(json.dumps(line))
-        sys.stdout.flush()
+        emit(train_fwd_rec, train_rec, train7_rec, cpu, parity)
         if parity is not None and not parity["ok"]:
             print(f"[bench] PARITY FAILURE: loss {parity['gpu_loss']:.6f} vs oracle {parity['cpu_loss']:.6f}: relative error "
                   f"{parity['rel_err']:.2e} >= {LOSS_BUDGET:.0e}", file=sys.stderr)
