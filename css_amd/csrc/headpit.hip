@@ -16,6 +16,8 @@
 // ~11 B/clk per CU on 200 CUs), not by the 3.4 GFLOP of the head: 20 us, against 20.6 + 14.9 us for the two kernels it
 // replaces.  Measured and rejected: 32-row panels under a 128-register budget (two workgroups per CU so that one's
 // loads travel while the other multiplies): 25 us - the budget spills and every weight fragment feeds half the MFMAs.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace {
@@ -222,6 +224,227 @@ __global__ __launch_bounds__(512) void head_pit_kernel(HeadPitArgs a) {
   }
 }
 
+// ---- the same computation with the matrix work taken out from behind the loss operands (16 waves).  Phase stamps of
+// the kernel above (tools/headpit_stamps.py): every wave requests its 24 pieces of f_orig / the targets and then streams
+// weights - whose fragments return BEHIND those pieces (a wave's loads complete in order), so the matrix passes stand
+// still until the 39.5 MB burst of all workgroups is through HBM (19 000 of a workgroup's 35 000 cycles), and the second
+// pass, the tail tile and the reduction follow with the memory system idle.  Here
+//   * the ReLU'd masks of both speakers go to an LDS tile [2][64 rows][256 bins] f32, and the squared errors are one
+//     sweep over whole rows: every wave owns 4 rows, one 1 KB row of f_orig / a target per load instruction (instead of
+//     16 rows x 64 bytes) and one 1 KB mask row per LDS read;
+//   * waves 8..15 request their rows at kernel entry and do nothing else until the masks are there;
+//   * waves 0..7 turn the encoder rows into the operand panel, run the two passes (two bin tiles each) and, wave 0,
+//     the tail tile - and request their own rows only behind their last weight fragment.
+// The matrix work runs under the burst; behind it are the error sweep and the reduction.
+constexpr int MS_ROW = 1024;                       // bytes of a mask row in LDS (256 bins f32)
+constexpr int MS_TILE = BM * MS_ROW;               // one speaker: 64 KB
+DEV int ms_off(int row, int chunk) { return row * MS_ROW + ((chunk ^ (row & 7)) << 4); }   // 16-byte chunk 0..63
+
+__global__ __launch_bounds__(1024) void head_pit_split_kernel(HeadPitArgs a) {
+  constexpr int NT = 2, K = KSPK, LR = BM / 16;   // LR rows per wave in the error sweep
+  // 32 KB operand panel + 128 KB of masks = the CU's 160 KB; the reduction's scratch lies in the dead panel
+  __shared__ __attribute__((aligned(16))) unsigned char Xs[BM * 512];
+  __shared__ __attribute__((aligned(16))) unsigned char Ms[K * MS_TILE];
+  float (*red)[2 * K * K] = reinterpret_cast<float (*)[2 * K * K]>(Xs);
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, n = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.x * BM;
+  const int bnd = (m0 / a.T + 1) * a.T;           // first row of the panel's second sample (T >= 64: at most two)
+  float sse[2][K][K];
+#pragma unroll
+  for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int j = 0; j < K; ++j) sse[s_][k][j] = 0.f;
+  f4u fo[LR], tg[K][LR];                           // rows 4 wave .. 4 wave + 3, bins 4 lane .. 4 lane + 3
+  auto request_rows = [&]() {
+#pragma unroll
+    for (int i = 0; i < LR; ++i) {
+      const int rc = min(m0 + wave * LR + i, a.M - 1);
+      fo[i] = load4(a.f + (size_t)rc * a.ldf + lane * 4);
+#pragma unroll
+      for (int j = 0; j < K; ++j) tg[j][i] = load4(a.tgt[j] + (size_t)rc * a.ldt + lane * 4);
+    }
+  };
+
+  if (wave >= 8) {
+    request_rows();
+    __builtin_amdgcn_s_barrier();                 // A: operand panel written (waves 0..7)
+  } else {
+    const bf16x8* wbase = a.w + lane;
+    bf16x8 wq[PD][NT];
+#pragma unroll
+    for (int k = 0; k < PD; ++k)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) wq[k][t] = wbase[(size_t)((wave * NT + t) * KS + k) * 64];
+    {  // encoder rows -> bf16 operand panel (8 lanes per row: whole 128-byte lines per load instruction)
+      constexpr int LPR = 512 / BM, NP = 64 / LPR;
+      const int r = tid / LPR, part = tid % LPR;
+      const float* xr = a.x + (size_t)min(m0 + r, a.M - 1) * DM;
+      float4 v[NP];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) v[i] = *reinterpret_cast<const float4*>(xr + (i * LPR + part) * 4);
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int c4 = i * LPR + part;
+        *reinterpret_cast<uint2*>(Xs + panel_off(r, c4 >> 1) + (c4 & 1) * 8) = make_uint2(pack_bf2(v[i].x, v[i].y), pack_bf2(v[i].z, v[i].w));
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                 // A
+#pragma unroll
+    for (int p = 0; p < K; ++p) {
+      const int tile0 = p * 16 + wave * NT;
+      f32x4 acc[NT][RT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float4 bb = *reinterpret_cast<const float4*>(a.bias + (tile0 + t) * 16 + 4 * g);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[t][rt] = f32x4{bb.x, bb.y, bb.z, bb.w};
+      }
+      // next stream: the following pass's tiles, or (after the last pass) the single tail tile for wave 0
+      const bf16x8* wc = wbase + (size_t)tile0 * KS * 64;
+      const bf16x8* wn = p + 1 < K ? wc + (size_t)16 * KS * 64 : wbase + (size_t)(K * 16) * KS * 64;
+      const int nnt = p + 1 < K ? NT : (wave == 0 ? 1 : 0);
+      bf16x8 xa[2][RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) xa[0][rt] = *reinterpret_cast<const bf16x8*>(Xs + panel_off(rt * 16 + n, g));
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        bf16x8 wcur[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) wcur[t] = wq[ks % PD][t];
+        if (ks + PD < KS) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) wq[ks % PD][t] = wc[(size_t)(t * KS + ks + PD) * 64];
+        } else {
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            if (t < nnt) wq[ks % PD][t] = wn[(size_t)(t * KS + ks + PD - KS) * 64];
+        }
+        if (ks + 1 < KS) {
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+            xa[(ks + 1) & 1][rt] = *reinterpret_cast<const bf16x8*>(Xs + panel_off(rt * 16 + n, (ks + 1) * 4 + g));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcur[t], xa[ks & 1][rt], acc[t][rt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // ReLU'd masks of speaker p: lane (n, g) owns bins (wave * 2 + t) * 16 + 4 g .. + 3 of rows 16 rt + n
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int r = rt * 16 + n;
+          *reinterpret_cast<float4*>(Ms + p * MS_TILE + ms_off(r, (wave * NT + t) * 4 + g)) =
+              make_float4(fmaxf(acc[t][rt][0], 0.f), fmaxf(acc[t][rt][1], 0.f), fmaxf(acc[t][rt][2], 0.f), fmaxf(acc[t][rt][3], 0.f));
+        }
+    }
+    // tail: bin 256 of every speaker = rows 0..K-1 of the last tile (wave 0; lanes g == 0 hold them as registers 0..K-1)
+    if (wave == 0) {
+      float ftail[RT], ttail[K][RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const int rc = min(m0 + rt * 16 + n, a.M - 1);
+        ftail[rt] = a.f[(size_t)rc * a.ldf + 256];
+#pragma unroll
+        for (int j = 0; j < K; ++j) ttail[j][rt] = a.tgt[j][(size_t)rc * a.ldt + 256];
+      }
+      f32x4 acc[RT];
+      const float4 bb = *reinterpret_cast<const float4*>(a.bias + K * 16 * 16 + 4 * g);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{bb.x, bb.y, bb.z, bb.w};
+      const bf16x8* wc = wbase + (size_t)(K * 16) * KS * 64;
+      bf16x8 wt[KS];                              // all of the tile's fragments in flight at once (a lone wave)
+#pragma unroll
+      for (int ks = 0; ks < PD; ++ks) wt[ks] = wq[ks][0];
+#pragma unroll
+      for (int ks = PD; ks < KS; ++ks) wt[ks] = wc[(size_t)ks * 64];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const bf16x8 xv = *reinterpret_cast<const bf16x8*>(Xs + panel_off(rt * 16 + n, ks * 4 + g));
+          acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[ks], xv, acc[rt], 0, 0, 0);
+        }
+      }
+      if (g == 0) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int row = m0 + rt * 16 + n;
+          if (row < a.M) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+              const float y = fmaxf(acc[rt][k], 0.f) * ftail[rt];
+#pragma unroll
+              for (int j = 0; j < K; ++j) {
+                const float d = y - ttail[j][rt];
+                if (row < bnd) sse[0][k][j] += d * d;
+                else sse[1][k][j] += d * d;
+              }
+            }
+          }
+        }
+      }
+    }
+    request_rows();                               // behind every weight fragment of this wave
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                   // B: both speakers' masks are in LDS; the operand panel is dead
+  // ---- the error sweep: rows 4 wave .. 4 wave + 3
+#pragma unroll
+  for (int i = 0; i < LR; ++i) {
+    const int r = wave * LR + i, row = m0 + r;
+    float e[K][K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float4 mk = *reinterpret_cast<const float4*>(Ms + k * MS_TILE + ms_off(r, lane));
+      const float mv[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+      for (int j = 0; j < K; ++j) e[k][j] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float y = mv[c] * fo[i].v[c];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          const float d = y - tg[j][i].v[c];
+          e[k][j] += d * d;
+        }
+      }
+    }
+    const float w0 = row < min(bnd, a.M) ? 1.f : 0.f, w1 = (row >= bnd && row < a.M) ? 1.f : 0.f;   // wave-uniform
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        sse[0][k][j] += w0 * e[k][j];
+        sse[1][k][j] += w1 * e[k][j];
+      }
+  }
+  // fixed-order reduction: lanes, then waves, one partial per (workgroup, slot): no atomics
+#pragma unroll
+  for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const float v = wave_sum(sse[s_][k][j]);
+        if (lane == 0) red[wave][(s_ * K + k) * K + j] = v;
+      }
+  __syncthreads();
+  if (tid < 2 * K * K) {
+    float s_ = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s_ += red[w][tid];
+    a.partial[(size_t)blockIdx.x * 2 * K * K + tid] = s_;
+  }
+}
+
 // One thread per sample adds its panels' partials (ascending panel order, double), scans the K! = 2 permutations in
 // itertools order (first minimum wins, like torch.min), then thread 0 averages the samples in order.
 __global__ __launch_bounds__(64) void head_pit_finalize_kernel(const float* __restrict__ partial, int B, int T, int M,
@@ -285,7 +508,9 @@ extern "C" int csship_head_pit(const float* x_enc, const uint16_t* w_perm_packed
   hipStream_t s = as_stream(stream);
   {
     TimelineScope tl(CSSHIP_TL_HEAD, s);
-    hipLaunchKernelGGL(head_pit_kernel, dim3((a.M + BM - 1) / BM), dim3(512), 0, s, a);
+    static const bool one_role = getenv("CSSHIP_HEADPIT_ONE_ROLE") != nullptr;   // A/B: the 8-wave kernel, every wave both roles
+    if (one_role) hipLaunchKernelGGL(head_pit_kernel, dim3((a.M + BM - 1) / BM), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(head_pit_split_kernel, dim3((a.M + BM - 1) / BM), dim3(1024), 0, s, a);
   }
   CSSHIP_CHECK_LAUNCH();
   {
