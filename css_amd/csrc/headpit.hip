@@ -40,12 +40,26 @@ struct HeadPitArgs {
   int M, T;
 };
 
+// -DHP_STAMPS: per-wave cycle stamps of this kernel's phases (tools/headpit_stamps.py, CSSHIP_HEADPIT_ONE_ROLE=1); not
+// part of the product build
+#ifdef HP_STAMPS
+__device__ unsigned* g_hp_stamps = nullptr;
+#define HP_STAMP(k) do { if (lane == 0) stamps[wave][k] = (unsigned)__builtin_readcyclecounter(); } while (0)
+#else
+#define HP_STAMP(k) do {} while (0)
+#endif
+
 __global__ __launch_bounds__(512) void head_pit_kernel(HeadPitArgs a) {
   constexpr int NT = 2, K = KSPK;
   __shared__ __attribute__((aligned(16))) unsigned char Xs[BM * 512];
   __shared__ float red[8][2 * K * K];
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, n = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef HP_STAMPS
+  __shared__ unsigned stamps[8][16];
+  if (tid < 128) stamps[tid >> 4][tid & 15] = 0;
+#endif
+  HP_STAMP(0);
   const int m0 = blockIdx.x * BM;
   const bf16x8* wbase = a.w + lane;
   bf16x8 wq[PD][NT];
@@ -88,7 +102,9 @@ __global__ __launch_bounds__(512) void head_pit_kernel(HeadPitArgs a) {
   }
   // bare barrier behind lgkmcnt(0) only: __syncthreads() would also wait for the 24 loads above (vmcnt(0)) and put
   // their latency in front of the first pass instead of behind it
+  HP_STAMP(1);   // x rows in LDS (this wave's part), f / target loads requested
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  HP_STAMP(2);
 
   float sse[2][K][K];
 #pragma unroll
@@ -141,6 +157,7 @@ __global__ __launch_bounds__(512) void head_pit_kernel(HeadPitArgs a) {
       __builtin_amdgcn_sched_barrier(0);
     }
     // mask p of this lane's bins -> its estimate -> squared errors against every target
+    HP_STAMP(3 + 2 * p);   // pass p: MFMAs issued
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -164,6 +181,7 @@ __global__ __launch_bounds__(512) void head_pit_kernel(HeadPitArgs a) {
           sse[1][p][j] += v1;
         }
       }
+    HP_STAMP(4 + 2 * p);   // pass p: squared errors done
   }
   // tail: bin 256 of every speaker = rows 0..K-1 of the last tile (wave 0; lanes g == 0 hold them as registers 0..K-1)
   if (wave == 0) {
@@ -205,6 +223,7 @@ __global__ __launch_bounds__(512) void head_pit_kernel(HeadPitArgs a) {
       }
     }
   }
+  HP_STAMP(7);     // tail tile (wave 0)
   // fixed-order reduction: lanes (DPP / permlane), waves (LDS), one partial per (workgroup, slot): no atomics
 #pragma unroll
   for (int s_ = 0; s_ < 2; ++s_)
@@ -222,6 +241,11 @@ __global__ __launch_bounds__(512) void head_pit_kernel(HeadPitArgs a) {
     for (int w = 0; w < 8; ++w) s_ += red[w][tid];
     a.partial[(size_t)blockIdx.x * 2 * K * K + tid] = s_;
   }
+  HP_STAMP(8);
+#ifdef HP_STAMPS
+  __syncthreads();
+  if (g_hp_stamps && tid < 128) g_hp_stamps[(size_t)blockIdx.x * 128 + tid] = stamps[tid >> 4][tid & 15];
+#endif
 }
 
 // ---- the same computation with the matrix work taken out from behind the loss operands (16 waves).  Phase stamps of
@@ -482,6 +506,12 @@ __global__ __launch_bounds__(64) void head_pit_finalize_kernel(const float* __re
 }
 
 }  // namespace
+
+#ifdef HP_STAMPS
+extern "C" int csship_debug_headpit_stamps(unsigned* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_hp_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" size_t csship_head_pit_workspace(int32_t B, int32_t T) {
   if (B <= 0 || T <= 0) return 0;

@@ -4,6 +4,7 @@
 python tools/headpit_stamps.py css_amd/csrc/probe/libhp.so"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+os.environ["CSSHIP_HEADPIT_ONE_ROLE"] = "1"   # the stamped kernel is the 8-wave one
 from css_amd import _lib
 _lib.LIB_PATH = os.path.abspath(sys.argv[1])
 import numpy as np, torch
@@ -22,7 +23,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 h = C.CDLL(_lib.LIB_PATH)
 nwg = (B * T + 63) // 64
-buf = torch.zeros((nwg, 16, 16), dtype=torch.int32, device=dev)
+buf = torch.zeros((nwg, 8, 16), dtype=torch.int32, device=dev)
 h.csship_debug_headpit_stamps.argtypes = [C.c_void_p]
 assert h.csship_debug_headpit_stamps(buf.data_ptr()) == 0
 # queue two launches back to back so that the stamped one starts behind work, as in the step
@@ -31,10 +32,10 @@ torch.cuda.synchronize()
 s = buf.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
 names = ["x rows -> LDS, f / target loads requested", "barrier", "pass 0 MFMAs", "pass 0 squared errors", "pass 1 MFMAs",
          "pass 1 squared errors", "tail tile (wave 0)", "reduction + partial store"]
-print(f"{nwg} workgroups; cycles of the stamp clock, median over workgroups; waves 0 / 7 / 15")
+print(f"{nwg} workgroups; cycles of the stamp clock, median over workgroups; waves 0 / 3 / 7")
 for k, nme in enumerate(names):
     d = (s[:, :, k + 1] - s[:, :, k]) & 0xFFFFFFFF
-    print(f"  {nme:48s} " + " ".join(f"{np.median(d[:, w]):7.0f}" for w in (0, 7, 15)))
+    print(f"  {nme:48s} " + " ".join(f"{np.median(d[:, w]):7.0f}" for w in (0, 3, 7)))
 whole = (s[:, :, 8] - s[:, :, 0]) & 0xFFFFFFFF
 print(f"  whole workgroup (wave 0): median {np.median(whole[:, 0]):.0f}  p90 {np.percentile(whole[:, 0], 90):.0f}")
 t0 = s[:, 0, 0].min()
