@@ -500,11 +500,11 @@ def main():
         if fused_pit:
             pdur = tl["head"][0] + tl["pit_finalize"][0]
             pit_bytes = 256 * 4 + 3 * 257 * 4
-            roof["pit"] = {"bound": "hbm", "kernel": "head_pit_kernel (mask head + mask application + pairwise SSE) + finalize",
+            roof["pit"] = {"bound": "hbm", "kernel": "head_pit_split_kernel (mask head + mask application + pairwise SSE) + finalize",
                            "achieved": B * T * pit_bytes / pdur / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
                            "frac": B * T * pit_bytes / pdur / PEAK_HBM, "avg_launch_us": pdur * 1e6,
                            "head_pit_us": tl["head"][0] * 1e6, "finalize_us": tl["pit_finalize"][0] * 1e6,
-                           "bytes_per_frame": pit_bytes, "traffic": traffic_of("head_pit_kernel")}
+                           "bytes_per_frame": pit_bytes, "traffic": traffic_of("head_pit_split_kernel") or traffic_of("head_pit_kernel")}
         else:
             pdur = tl["pit_sse"][0] + tl["pit_finalize"][0]
             pit_bytes = 5 * 257 * 4
