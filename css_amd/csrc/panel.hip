@@ -1537,8 +1537,10 @@ __global__ __launch_bounds__(NW * 64) void outproj_conv_kernel(OcArgs a) {
     *reinterpret_cast<float4*>(Ps + tid * 4) = *reinterpret_cast<const float4*>((tid < DM / 4 ? a.cw.ln_g : a.cw.ln_b - DM) + tid * 4);
 
   // ---- attention-output rows of tile + halo -> bf16 panel (rows outside the utterance / beyond row 81: zero).
-  // Panel loads first, then the residual rows of the row phase are put in flight, then the panel is written: the
-  // barrier below waits for the panel data only, the residual rows land during the GEMM.
+  // The residual rows of the row phase are requested INSIDE the projection's k loop, behind the wave's last weight
+  // fragment: a wave's loads return in order, and requested ahead of the loop (rounds 2-3: "they land during the GEMM")
+  // they held every weight fragment back until the 21 MB of residual rows of all workgroups were through HBM - the GEMM
+  // did not overlap them, it waited for them (16.1 -> 15.4 us per launch).
   uint4 av[NSTAGE];
 #pragma unroll
   for (int k = 0; k < NSTAGE; ++k) {
@@ -1549,16 +1551,17 @@ __global__ __launch_bounds__(NW * 64) void outproj_conv_kernel(OcArgs a) {
   }
   __builtin_amdgcn_sched_barrier(0);
   float4 xres[2][8];  // two passes of 64 rows, 8 lanes per row
+  auto request_residual = [&]() {
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    const int r = pass * 64 + (tid >> 3), t = t0 - OC_HALO + r;
-    const bool ok = r < OC_USED && t >= 0 && t < a.T;
-    const float* xr = a.x1 + (rowb + (ok ? t : 0)) * DM;
+    for (int pass = 0; pass < 2; ++pass) {
+      const int r = pass * 64 + (tid >> 3), t = t0 - OC_HALO + r;
+      const bool ok = r < OC_USED && t >= 0 && t < a.T;
+      const float* xr = a.x1 + (rowb + (ok ? t : 0)) * DM;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      xres[pass][i] = ok ? *reinterpret_cast<const float4*>(xr + (i * 8 + (tid & 7)) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < 8; ++i)
+        xres[pass][i] = ok ? *reinterpret_cast<const float4*>(xr + (i * 8 + (tid & 7)) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
 #pragma unroll
   for (int k = 0; k < NSTAGE; ++k) {
     const int i = tid + k * NW * 64;
@@ -1586,6 +1589,7 @@ __global__ __launch_bounds__(NW * 64) void outproj_conv_kernel(OcArgs a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) wq[ks % PD][t] = ws_[(size_t)(t * KS + ks + PD) * 64];
       }
+      if (ks + PD == KS) request_residual();   // behind the last weight fragment: a wave's loads return in order
       if (ks + 1 < KS) {
 #pragma unroll
         for (int rt = 0; rt < OC_RT; ++rt)
