@@ -28,6 +28,17 @@ constexpr int PANEL_BYTES = BM * DM * 2;
 
 DEV int panel_off(int row, int chunk) { return row * 512 + ((chunk ^ (row & 15)) << 4); }
 
+// Two transposed-accumulator tiles (16 adjacent columns each) as bf16: a lane (row n, g) holds 4 columns of each (8 bytes
+// + 8 bytes, 16 columns apart).  v_permlane16_swap_b32 trades the odd 16-lane rows of one register for the even rows of
+// another: after it a lane holds EIGHT CONSECUTIVE columns of ONE tile - columns 8 (g >> 1) .. + 7 of tile (g & 1) - and
+// the global store is one 16-byte piece per lane (64 contiguous bytes per token row and instruction) instead of two
+// 8-byte ones.  No change to any layout in memory.
+DEV uint4 pair_tiles_bf16(uint2 t0, uint2 t1) {
+  const auto lo = __builtin_amdgcn_permlane16_swap(t0.x, t1.x, false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap(t0.y, t1.y, false, false);
+  return make_uint4(lo[0], hi[0], lo[1], hi[1]);
+}
+
 constexpr int PD = 4;  // weight prefetch distance in k-steps (ring of PD fragment sets per wave)
 #ifdef P_STAMPS  // diagnostic build: wave 0 of every workgroup stores s_memtime at phase boundaries -> g_csship_stamps[wg*32 + i]
 #define P_T(i)                                                                                                  \
@@ -440,6 +451,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
     // pass A: h = dropout(relu(a W1_c^T + b1_c)); keep the (ReLU and dropout) mask, store h
     mma_pass<NT>(h, Xs, n, g, NT, w1c, KS, w2tc, KS, NT, wq);
     unsigned mask = 0u;
+    uint2 hpk[NT][4];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int fcol = c * DM + (wave * NT + t) * 16 + 4 * g;
@@ -450,10 +462,25 @@ __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
                                       make_float4(fmaxf(h[t][rt][0], 0.f), fmaxf(h[t][rt][1], 0.f), fmaxf(h[t][rt][2], 0.f), fmaxf(h[t][rt][3], 0.f)));
         const float v0 = hv.x, v1 = hv.y, v2 = hv.z, v3 = hv.w;
         mask |= ((v0 > 0.f ? 1u : 0u) | (v1 > 0.f ? 2u : 0u) | (v2 > 0.f ? 4u : 0u) | (v3 > 0.f ? 8u : 0u)) << ((t * 4 + rt) * 4);
-        if (row < a.M)
-          *reinterpret_cast<uint2*>(a.h_bf + (size_t)row * a.FF + fcol) = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
+        hpk[t][rt] = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
         h[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
+    }
+    if constexpr (NT == 2) {   // the wave's two tiles -> one 16-byte store per lane and row tile
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        const uint4 pk = pair_tiles_bf16(hpk[0][rt], hpk[1][rt]);
+        const int row = m0 + rt * 16 + n;
+        if (row < a.M) *reinterpret_cast<uint4*>(a.h_bf + (size_t)row * a.FF + c * DM + (wave * NT + (g & 1)) * 16 + (g >> 1) * 8) = pk;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+          const int row = m0 + rt * 16 + n;
+          if (row < a.M) *reinterpret_cast<uint2*>(a.h_bf + (size_t)row * a.FF + c * DM + (wave * NT + t) * 16 + 4 * g) = hpk[t][rt];
+        }
     }
     // pass B: dh = (alpha dy) W2[:, c] masked  -> LDS panel + global
     mma_pass<NT>(h, Ds, n, g, NT, w2tc, KS, w1tc, ks2, NT, wq);
@@ -468,9 +495,24 @@ __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
         const uint2 pk = make_uint2(pack_bf2((mb & 1u) ? h[t][rt][0] * hs_ : 0.f, (mb & 2u) ? h[t][rt][1] * hs_ : 0.f),
                                     pack_bf2((mb & 4u) ? h[t][rt][2] * hs_ : 0.f, (mb & 8u) ? h[t][rt][3] * hs_ : 0.f));
         *reinterpret_cast<uint2*>(gs + panel_off(rt * 16 + n, hc >> 3) + (hc & 7) * 2) = pk;
-        const int row = m0 + rt * 16 + n;
-        if (row < a.M) *reinterpret_cast<uint2*>(a.dh_bf + (size_t)row * a.FF + c * DM + hc) = pk;
+        hpk[t][rt] = pk;
       }
+    }
+    if constexpr (NT == 2) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        const uint4 pk = pair_tiles_bf16(hpk[0][rt], hpk[1][rt]);
+        const int row = m0 + rt * 16 + n;
+        if (row < a.M) *reinterpret_cast<uint4*>(a.dh_bf + (size_t)row * a.FF + c * DM + (wave * NT + (g & 1)) * 16 + (g >> 1) * 8) = pk;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+          const int row = m0 + rt * 16 + n;
+          if (row < a.M) *reinterpret_cast<uint2*>(a.dh_bf + (size_t)row * a.FF + c * DM + (wave * NT + t) * 16 + 4 * g) = hpk[t][rt];
+        }
     }
     __syncthreads();
     // pass C: da += dh W1_c
