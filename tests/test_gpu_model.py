@@ -773,7 +773,7 @@ def test_fused_adam_state_dict_is_torch_adam_compatible():
         FusedAdam([{"params": list(m2.parameters())[:2]}, {"params": list(m2.parameters())[2:]}])
 
 
-@pytest.mark.parametrize("B,T", [(3, 100), (2, 64), (5, 77), (1, 400)])
+@pytest.mark.parametrize("B,T", [(3, 100), (2, 64), (5, 77), (1, 400), (32, 400)])
 def test_forward_loss_fused_head_pit_matches_unfused(B, T):
     """model.forward_loss (csship_head_pit: mask head + mask application + PIT-MSE, masks never written) ==
     ops.pit_mse(model.forward_masks(f), f, targets): pair matrix, permutations and loss; panels that straddle two
