@@ -1146,6 +1146,338 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(ChainArgs a) {
   }
 }
 
+// =============================================================================== chain, static form
+// Same operator chain and the same arithmetic as chain_kernel above, for the shapes the encoder actually runs (whole
+// 64-row panels: M % 64 == 0; q | k | v of 768 columns; d_ffn a multiple of 256 up to 2048): every global memory
+// instruction of the kernel is UNCONDITIONAL and its count is known at compile time.  Why that matters (round 5, the
+// ISA of the first form): hipcc's s_waitcnt insertion merges the pending-load state of the two sides of every branch
+// pessimistically.  The first form had three loads / load groups behind run-time conditions inside its matrix passes -
+// "no prefetch behind the last chunk" (t < nnt with nnt = 0 or NT), "output bias in front of the last W2 pass" and the
+// bounds-checked bias / weight loads of the q | k | v stage - and behind every one of them the compiler had to assume
+// the FEWER-loads path: the W2 pass of every hidden chunk ended on s_waitcnt vmcnt(3) / vmcnt(1) where vmcnt(9) /
+// vmcnt(8) was meant - a wait for weight fragments requested only a k-step earlier, i.e. a full L2 round trip per pass,
+// 8 per launch (the 700-1 000 cycles the W2 passes ran behind the W1 passes in the phase stamps) - and every pass of the
+// q | k | v stage began with s_waitcnt vmcnt(0), draining the whole prefetch ring (14 800 cycles for 3 x 2 048 of MFMA).
+// Here:
+//   * all per-channel parameters (four LayerNorm affines when they are not folded into the weights, hidden / output
+//     biases of both FeedForwards, the q | k | v bias: 13-29 KB) are staged into LDS ONCE at kernel entry by four
+//     unconditional 16-byte loads per thread; accumulators start from ds_read values (no global load - and no wait behind
+//     the in-order weight prefetches - at the start of a pass), LayerNorm prologues read gamma / beta from LDS;
+//   * ONE weight ring for the whole kernel: the last W2 pass of a FeedForward refills the ring with the first four
+//     k-steps of the NEXT stage's stream (a pointer select, not a predicated load), so the global -> register pipeline
+//     never drains between stages and no stage primes its own ring;
+//   * tile counts are template constants (mma_pass_s has no t < nt tests), stores are unpredicated.
+// Anything else (ragged last panel, other widths, the fused conv front end) runs the first form.
+constexpr int CS_FFMAX = 2048;
+constexpr int CS_LN = 8 * DM;                                     // A gamma | beta, final gamma | beta, B gamma | beta, q/k/v gamma | beta
+constexpr int CS_PARAMS = CS_LN + 2 * CS_FFMAX + 2 * DM + 768;    // floats: + b1 A, b2 A, b1 B, b2 B, b q|k|v
+constexpr int CS_DUMP = 256;                                      // where the staging lanes without work write
+
+template <int NT, bool NEXT>
+DEV void mma_pass_s(f32x4 (&acc)[NT][4], const unsigned char* panel, int n, int g, const bf16x8* w, int tstride,
+                    const bf16x8* wn, int nstride, bf16x8 (&wq)[PD][NT]) {
+  bf16x8 xa[2][4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) xa[0][rt] = *reinterpret_cast<const bf16x8*>(panel + panel_off(rt * 16 + n, g));
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    bf16x8 wc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wc[t] = wq[ks % PD][t];
+    if (ks + PD < KS) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) wq[ks % PD][t] = w[(size_t)(t * tstride + ks + PD) * 64];
+    } else if constexpr (NEXT) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) wq[ks % PD][t] = wn[(size_t)(t * nstride + ks + PD - KS) * 64];
+    }
+    if (ks + 1 < KS) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+        xa[(ks + 1) & 1][rt] = *reinterpret_cast<const bf16x8*>(panel + panel_off(rt * 16 + n, (ks + 1) * 4 + g));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+        acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[t], xa[ks & 1][rt], acc[t][rt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// rows_to_panel with gamma / beta in LDS (gam == nullptr: folded into the consuming Linear)
+DEV void rows_to_panel_s(unsigned char* panel, const float4 (&v)[8], const float* gam, const float* bet, int r, int part) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float mean = sum8(s) * (1.f / DM);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+    ss += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+  }
+  const float rstd = rsqrtf(sum8(ss) * (1.f / DM) + 1e-5f);
+  if (gam == nullptr) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c4 = i * 8 + part;
+      *reinterpret_cast<uint2*>(panel + panel_off(r, c4 >> 1) + (c4 & 1) * 8) =
+          make_uint2(pack_bf2((v[i].x - mean) * rstd, (v[i].y - mean) * rstd), pack_bf2((v[i].z - mean) * rstd, (v[i].w - mean) * rstd));
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c4 = i * 8 + part;
+    const float4 gm = *reinterpret_cast<const float4*>(gam + c4 * 4);
+    const float4 bt = *reinterpret_cast<const float4*>(bet + c4 * 4);
+    *reinterpret_cast<uint2*>(panel + panel_off(r, c4 >> 1) + (c4 & 1) * 8) =
+        make_uint2(pack_bf2((v[i].x - mean) * rstd * gm.x + bt.x, (v[i].y - mean) * rstd * gm.y + bt.y),
+                   pack_bf2((v[i].z - mean) * rstd * gm.z + bt.z, (v[i].w - mean) * rstd * gm.w + bt.w));
+  }
+}
+
+// one FeedForward on the register rows, every parameter from LDS; the ring arrives primed with this stage's first four
+// k-steps and leaves primed with next_w's (lane-adjusted pointer at block (tile 0 of this wave, k-step 0), tile stride KS)
+template <int NW, bool FINAL_LN, bool TRAIN>
+DEV void ffn_stage_s(float4 (&v)[8], unsigned char* Xs, unsigned char* Hraw, const float* lng, const float* fing,
+                     const float* b1s, const float* b2s, const FfnW& f, int FF, float alpha, int tid, int rot,
+                     bf16x8 (&wq)[PD][16 / NW], const bf16x8* next_w, unsigned long long* g_stamps_dev, int st0,
+                     const StageTrain& tr) {
+  constexpr int NT = 16 / NW;
+  const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15, r = tid >> 3, part = tid & 7;
+  const int nchunk = FF / DM, ks2 = FF / 32;
+  unsigned char* const Hs0 = Hraw;
+  unsigned char* const Hs1 = Hraw + PANEL_BYTES;
+  const bf16x8* w1s = f.w1 + (size_t)(wave * NT) * KS * 64 + lane;
+  const bf16x8* w2s = f.w2 + (size_t)(wave * NT) * ks2 * 64 + lane;
+  rows_to_panel_s(Xs, v, lng, lng != nullptr ? lng + DM : nullptr, r, part);
+  __syncthreads();  // also: every wave has left the previous stage's Ys reads
+  P_T(st0 + 0)
+  f32x4 o[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) o[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int ci = 0; ci < nchunk; ++ci) {
+    const int c = (ci + rot) % nchunk;
+    f32x4 h[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {  // the bias is the accumulators' initial value
+      const float4 bb = *reinterpret_cast<const float4*>(b1s + c * DM + (wave * NT + t) * 16 + 4 * g);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) h[t][rt] = f32x4{bb.x, bb.y, bb.z, bb.w};
+    }
+    const bf16x8* w1c = w1s + (size_t)c * 16 * KS * 64;
+    const bf16x8* w2c = w2s + (size_t)c * KS * 64;
+    mma_pass_s<NT, true>(h, Xs, n, g, w1c, KS, w2c, ks2, wq);
+    unsigned char* hs = (ci & 1) ? Hs1 : Hs0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int hc = (wave * NT + t) * 16 + 4 * g;
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {  // ReLU on the packed pairs: 2 conversions + 2 integer max per 4 values
+        uint2 pk;
+        if (TRAIN && tr.dh.thresh != 0u) {  // relu, then the hidden activation's dropout (conformer.py:317), element (row, c*256 + hc)
+          const float4 hv = drop_apply4(tr.dh, (unsigned)((tr.m0 + rt * 16 + n) * FF + c * DM + hc),
+                                        make_float4(fmaxf(h[t][rt][0], 0.f), fmaxf(h[t][rt][1], 0.f), fmaxf(h[t][rt][2], 0.f), fmaxf(h[t][rt][3], 0.f)));
+          pk = make_uint2(pack_bf2(hv.x, hv.y), pack_bf2(hv.z, hv.w));
+        } else {
+          pk = make_uint2(relu_bf2(pack_bf2(h[t][rt][0], h[t][rt][1])), relu_bf2(pack_bf2(h[t][rt][2], h[t][rt][3])));
+        }
+        *reinterpret_cast<uint2*>(hs + panel_off(rt * 16 + n, hc >> 3) + (hc & 7) * 2) = pk;
+      }
+    }
+    __syncthreads();
+    // behind the last chunk the ring takes the NEXT stage's first k-steps: a pointer select, the loads stay unconditional
+    const bf16x8* wn = (ci + 1 < nchunk) ? w1s + (size_t)((c + 1) % nchunk) * 16 * KS * 64 : next_w;
+    mma_pass_s<NT, true>(o, hs, n, g, w2c, ks2, wn, KS, wq);
+  }
+  P_T(st0 + 1)
+  __syncthreads();  // every wave is done reading the hidden panels
+  float* ys = reinterpret_cast<float*>(Hraw);
+  float4 b2v[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) b2v[t] = *reinterpret_cast<const float4*>(b2s + (wave * NT + t) * 16 + 4 * g);
+  park_tiles<NT, false>(ys, o, NT, wave * NT * 16, g, n, b2v);
+  __syncthreads();
+  P_T(st0 + 2)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float4 y = *reinterpret_cast<const float4*>(ys + r * YS + (i * 8 + part) * 4);
+    if constexpr (TRAIN) y = drop_apply4(tr.dout, (unsigned)((tr.m0 + r) * DM + (i * 8 + part) * 4), y);  // conformer.py:319
+    v[i] = make_float4(v[i].x + alpha * y.x, v[i].y + alpha * y.y, v[i].z + alpha * y.z, v[i].w + alpha * y.w);
+  }
+  if constexpr (FINAL_LN) {
+    if constexpr (TRAIN) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(tr.pre_ln_out + (size_t)(tr.m0 + r) * DM + (i * 8 + part) * 4) = v[i];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    const float mean = sum8(s) * (1.f / DM);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+      ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float rstd = rsqrtf(sum8(ss) * (1.f / DM) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4 gm = *reinterpret_cast<const float4*>(fing + (i * 8 + part) * 4);
+      const float4 bt = *reinterpret_cast<const float4*>(fing + DM + (i * 8 + part) * 4);
+      v[i].x = v[i].x * rstd * gm.x + bt.x; v[i].y = v[i].y * rstd * gm.y + bt.y;
+      v[i].z = v[i].z * rstd * gm.z + bt.z; v[i].w = v[i].w * rstd * gm.w + bt.w;
+    }
+  }
+}
+
+// one 256-feature pass of the q | k | v projection, written straight from the transposed accumulators
+template <int NT, bool NEXT, bool IL8>
+DEV void qkv_pass_s(const unsigned char* Xs, const float* bq, const bf16x8* wc, bf16x8 (&wq)[PD][NT], unsigned short* qkv,
+                    int m0, int tile0, int n, int g) {
+  f32x4 acc[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const float4 bb = *reinterpret_cast<const float4*>(bq + (tile0 + t) * 16 + 4 * g);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) acc[t][rt] = f32x4{bb.x, bb.y, bb.z, bb.w};
+  }
+  mma_pass_s<NT, NEXT>(acc, Xs, n, g, wc, KS, wc + (size_t)16 * KS * 64, KS, wq);
+  if constexpr (IL8 && NT == 2) {  // a lane's 2 x 4 results are EIGHT CONSECUTIVE features of its token row (ops.pack_frag_il8)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+      *reinterpret_cast<uint4*>(qkv + (size_t)(m0 + rt * 16 + n) * 768 + tile0 * 16 + 8 * g) =
+          make_uint4(pack_bf2(acc[0][rt][0], acc[0][rt][1]), pack_bf2(acc[0][rt][2], acc[0][rt][3]),
+                     pack_bf2(acc[1][rt][0], acc[1][rt][1]), pack_bf2(acc[1][rt][2], acc[1][rt][3]));
+  } else {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+        *reinterpret_cast<uint2*>(qkv + (size_t)(m0 + rt * 16 + n) * 768 + (tile0 + t) * 16 + 4 * g) =
+            make_uint2(pack_bf2(acc[t][rt][0], acc[t][rt][1]), pack_bf2(acc[t][rt][2], acc[t][rt][3]));
+  }
+}
+
+// float4 j of the bias space b1 A (q1) | b2 A (64) | b1 B (q1) | b2 B (64) | b q|k|v (192): where it is read from and
+// where it lands in the LDS parameter block (floats); lanes without work read `dummy` and write the dump block
+struct ParamSrc {
+  const float* p;
+  int dst;
+};
+template <bool HAS_A, bool HAS_B, bool HAS_C>
+DEV ParamSrc param_src(const ChainArgs& a, int j, int q1, const float* dummy, int lane) {
+  const int e1 = q1, e2 = q1 + 64, e3 = 2 * q1 + 64, e4 = 2 * q1 + 128, e5 = 2 * q1 + 320;
+  const float* const bA1 = HAS_A ? a.fa.b1 : nullptr;
+  const float* const bA2 = HAS_A ? a.fa.b2 : nullptr;
+  const float* const bB1 = HAS_B ? a.fb.b1 : nullptr;
+  const float* const bB2 = HAS_B ? a.fb.b2 : nullptr;
+  const float* const bQ = HAS_C ? a.bqkv : nullptr;
+  const float* const base = j < e1 ? bA1 : j < e2 ? bA2 : j < e3 ? bB1 : j < e4 ? bB2 : j < e5 ? bQ : nullptr;
+  const int off = j < e1 ? j : j < e2 ? j - e1 : j < e3 ? j - e2 : j < e4 ? j - e3 : j - e4;
+  const bool ok = base != nullptr;
+  return ParamSrc{ok ? base + off * 4 : dummy, ok ? CS_LN + j * 4 : CS_PARAMS + lane * 4};
+}
+
+template <int NW, bool HAS_A, bool HAS_B, bool HAS_C, bool TRAIN, bool IL8>
+__global__ __launch_bounds__(NW * 64) void chain_s_kernel(ChainArgs a) {
+  static_assert(NW * 64 == 8 * BM, "row phases assume 8 lanes per panel row");
+  static_assert(HAS_A || HAS_B, "at least one FeedForward");
+  static_assert(!HAS_C || HAS_B, "the q | k | v stage follows the block's first FeedForward");
+  constexpr int NT = 16 / NW;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[PANEL_BYTES + YS_BYTES + (CS_PARAMS + CS_DUMP) * 4];
+  unsigned char* const Xs = smem;
+  unsigned char* const Hraw = smem + PANEL_BYTES;
+  float* const Ps = reinterpret_cast<float*>(smem + PANEL_BYTES + YS_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15;
+  const int r = tid >> 3, part = tid & 7;
+  const int m0 = blockIdx.x * BM, row = m0 + r;   // whole panels only: row < M
+  const int FF = a.FF, nchunk = FF / DM;
+  float4 v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(a.x + (size_t)row * DM + (i * 8 + part) * 4);
+
+  // ---- parameters -> LDS: float4 index space [0, 512) = the eight LayerNorm vectors (wave w stages vector w), then
+  // b1 A (FF/4) | b2 A (64) | b1 B (FF/4) | b2 B (64) | b q|k|v (192), three more float4 per thread.  Missing stages and
+  // folded LayerNorms read the residual rows instead (any valid address) and land in the dump block.
+  const float* const dummy = a.x + (size_t)m0 * DM + lane * 4;
+  // (named scalars and branch-free selects: an array written under the if-chain became an alloca, promoted into LDS)
+  const int w8 = __builtin_amdgcn_readfirstlane(wave);
+  const float* p0 = nullptr;
+  if (HAS_A && w8 == 0) p0 = a.fa.ln_g;
+  if (HAS_A && w8 == 1) p0 = a.fa.ln_b;
+  if (HAS_A && w8 == 2) p0 = a.fin_g;
+  if (HAS_A && w8 == 3) p0 = a.fin_b;
+  if (HAS_B && w8 == 4) p0 = a.fb.ln_g;
+  if (HAS_B && w8 == 5) p0 = a.fb.ln_b;
+  if (HAS_C && w8 == 6) p0 = a.qln_g;
+  if (HAS_C && w8 == 7) p0 = a.qln_b;
+  const int pd0 = p0 != nullptr ? tid * 4 : CS_PARAMS + lane * 4;
+  const float4 pv0 = *reinterpret_cast<const float4*>(p0 != nullptr ? p0 + lane * 4 : dummy);
+  const ParamSrc ps1 = param_src<HAS_A, HAS_B, HAS_C>(a, tid, FF >> 2, dummy, lane);
+  const ParamSrc ps2 = param_src<HAS_A, HAS_B, HAS_C>(a, tid + 512, FF >> 2, dummy, lane);
+  const ParamSrc ps3 = param_src<HAS_A, HAS_B, HAS_C>(a, tid + 1024, FF >> 2, dummy, lane);
+  const float4 pv1 = *reinterpret_cast<const float4*>(ps1.p);
+  const float4 pv2 = *reinterpret_cast<const float4*>(ps2.p);
+  const float4 pv3 = *reinterpret_cast<const float4*>(ps3.p);
+  const float* const lnA = Ps, * const finA = Ps + 2 * DM, * const lnB = Ps + 4 * DM, * const lnQ = Ps + 6 * DM;
+  const float* const b1A = Ps + CS_LN, * const b2A = b1A + FF, * const b1B = b2A + DM, * const b2B = b1B + FF, * const bQ = b2B + DM;
+
+  // ---- the ONE weight ring of the kernel, primed with the first stage's first chunk
+  const int rotA = blockIdx.x, rotB = blockIdx.x + 2;
+  const bf16x8* const wA0 = HAS_A ? a.fa.w1 + (size_t)(wave * NT) * KS * 64 + lane + (size_t)(rotA % nchunk) * 16 * KS * 64 : nullptr;
+  const bf16x8* const wB0 = HAS_B ? a.fb.w1 + (size_t)(wave * NT) * KS * 64 + lane + (size_t)(rotB % nchunk) * 16 * KS * 64 : nullptr;
+  const bf16x8* const wC0 = HAS_C ? a.wqkv + (size_t)(wave * NT) * KS * 64 + lane : nullptr;
+  bf16x8 wq[PD][NT];
+  prefetch_first<NT>(wq, HAS_A ? wA0 : wB0, KS, NT);
+  *reinterpret_cast<float4*>(Ps + pd0) = pv0;
+  *reinterpret_cast<float4*>(Ps + ps1.dst) = pv1;
+  *reinterpret_cast<float4*>(Ps + ps2.dst) = pv2;
+  *reinterpret_cast<float4*>(Ps + ps3.dst) = pv3;
+  __syncthreads();
+#ifdef P_STAMPS
+  unsigned long long* const g_stamps_dev = a.stamps;
+#else
+  unsigned long long* const g_stamps_dev = nullptr;
+#endif
+  P_T(0)
+  if constexpr (HAS_A) {
+    const StageTrain ta{TRAIN ? drop_make(a.da_h.seed, a.da_h.stream, a.da_h.p) : Drop{0u, 0u, 1.f},
+                        TRAIN ? drop_make(a.da_o.seed, a.da_o.stream, a.da_o.p) : Drop{0u, 0u, 1.f}, m0, a.M, a.pre_ln_out};
+    ffn_stage_s<NW, true, TRAIN>(v, Xs, Hraw, a.fa.ln_g != nullptr ? lnA : nullptr, finA, b1A, b2A, a.fa, FF, a.alpha, tid, rotA, wq,
+                                 HAS_B ? wB0 : wA0, g_stamps_dev, 1, ta);
+    if constexpr (TRAIN) {  // the next block's input: the backward of its first FeedForward needs it
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(a.ln_out + (size_t)row * DM + (i * 8 + part) * 4) = v[i];
+    }
+  }
+  P_T(4)
+  if constexpr (HAS_B) {
+    const StageTrain tb{TRAIN ? drop_make(a.db_h.seed, a.db_h.stream, a.db_h.p) : Drop{0u, 0u, 1.f},
+                        TRAIN ? drop_make(a.db_o.seed, a.db_o.stream, a.db_o.p) : Drop{0u, 0u, 1.f}, m0, a.M, nullptr};
+    ffn_stage_s<NW, false, TRAIN>(v, Xs, Hraw, a.fb.ln_g != nullptr ? lnB : nullptr, nullptr, b1B, b2B, a.fb, FF, a.alpha, tid, rotB, wq,
+                                  HAS_C ? wC0 : wB0, g_stamps_dev, 5, tb);
+  }
+  P_T(8)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(a.xout + (size_t)row * DM + (i * 8 + part) * 4) = v[i];
+  if constexpr (HAS_C) {
+    rows_to_panel_s(Xs, v, a.qln_g != nullptr ? lnQ : nullptr, a.qln_g != nullptr ? lnQ + DM : nullptr, r, part);
+    __syncthreads();
+    P_T(9)
+    const int t0 = wave * NT;
+    qkv_pass_s<NT, true, IL8>(Xs, bQ, wC0, wq, a.qkv, m0, t0, n, g);
+    qkv_pass_s<NT, true, IL8>(Xs, bQ, wC0 + (size_t)16 * KS * 64, wq, a.qkv, m0, 16 + t0, n, g);
+    qkv_pass_s<NT, false, IL8>(Xs, bQ, wC0 + (size_t)32 * KS * 64, wq, a.qkv, m0, 32 + t0, n, g);
+    P_T(10)
+  }
+}
+
 // =============================================================================== chain, second form
 // NOT the default (csship_encoder_chain runs it with CSSHIP_CHAIN=8 or 4): it is 8 % slower than the first form, and
 // is kept as the measured counter-example to "the row phases and barriers are what is slow" - tools/chain2_stamps.py.
@@ -1975,6 +2307,16 @@ static int encoder_chain_impl(const float* x, float* x_out, const float* conv_g,
   if (Cq) { a.qln_g = qkv_ln_g; a.qln_b = qkv_ln_b; a.wqkv = reinterpret_cast<const bf16x8*>(wqkv_packed); a.bqkv = bqkv; a.qkv = qkv_out; }
   dim3 grid((M + BM - 1) / BM), block(NWAVES * 64);
   hipStream_t s = as_stream(stream);
+  // the static form (chain_s_kernel): whole panels, q | k | v of 768 columns, d_ffn up to 2048, every parameter 16-byte
+  // aligned (they are staged into LDS by float4 loads).  CSSHIP_CHAIN_STATIC=0: the first form everywhere (A/B timing)
+  static const bool use_static = [] { const char* e = getenv("CSSHIP_CHAIN_STATIC"); return e == nullptr || atoi(e) != 0; }();
+  auto al16 = [](const void* p) { return p == nullptr || aligned16(p); };
+  const bool st_ok = use_static && !CV && (M % BM) == 0 && d_ffn <= CS_FFMAX && (!Cq || n_qkv == 768) &&
+                     (!A || (al16(ffn_a->ln_g) && al16(ffn_a->ln_b) && aligned16(ffn_a->b1) && aligned16(ffn_a->b2) &&
+                             aligned16(final_ln_g) && aligned16(final_ln_b) && (ffn_a->ln_g == nullptr) == (ffn_a->ln_b == nullptr))) &&
+                     (!Bs || (al16(ffn_b->ln_g) && al16(ffn_b->ln_b) && aligned16(ffn_b->b1) && aligned16(ffn_b->b2) &&
+                              (ffn_b->ln_g == nullptr) == (ffn_b->ln_b == nullptr))) &&
+                     (!Cq || (al16(qkv_ln_g) && al16(qkv_ln_b) && aligned16(bqkv) && bqkv != nullptr));
   if (train != nullptr) {
     const csship_dropout_cfg none{nullptr, 0u, 0.f};
     auto cfg = [&](const csship_dropout_cfg* c) { return (c && c->seed && c->p > 0.f) ? *c : none; };
@@ -1982,6 +2324,12 @@ static int encoder_chain_impl(const float* x, float* x_out, const float* conv_g,
     a.db_h = cfg(train->drop_b_hidden); a.db_o = cfg(train->drop_b_out);
     a.pre_ln_out = train->pre_ln_out; a.ln_out = train->ln_out;
     if ((A && !ffn_a->ln_g) || (Bs && !ffn_b->ln_g)) return CSSHIP_EUNSUPPORTED;  // folded LayerNorms belong to the inference packing
+    if (st_ok && Bs && Cq && (!A || (a.pre_ln_out != nullptr && a.ln_out != nullptr))) {
+      if (A) hipLaunchKernelGGL((chain_s_kernel<NWAVES, true, true, true, true, false>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((chain_s_kernel<NWAVES, false, true, true, true, false>), grid, block, 0, s, a);
+      CSSHIP_CHECK_LAUNCH();
+      return CSSHIP_OK;
+    }
     if (A && Bs && Cq) hipLaunchKernelGGL((chain_kernel<NWAVES, false, true, true, true, true>), grid, block, 0, s, a);
     else if (!A && Bs && Cq) hipLaunchKernelGGL((chain_kernel<NWAVES, false, false, true, true, true>), grid, block, 0, s, a);
     else return CSSHIP_EUNSUPPORTED;
@@ -2000,6 +2348,17 @@ static int encoder_chain_impl(const float* x, float* x_out, const float* conv_g,
   else return CSSHIP_EUNSUPPORTED;
     if (form == 8) { C2_LAUNCH(8) } else { C2_LAUNCH(4) }
 #undef C2_LAUNCH
+    CSSHIP_CHECK_LAUNCH();
+    return CSSHIP_OK;
+  }
+  if (st_ok && (A || Bs) && (Bs || !Cq)) {
+    const bool il8 = a.qkv_il8 != 0;
+    if (A && Bs && Cq && il8) hipLaunchKernelGGL((chain_s_kernel<NWAVES, true, true, true, false, true>), grid, block, 0, s, a);
+    else if (A && Bs && Cq) hipLaunchKernelGGL((chain_s_kernel<NWAVES, true, true, true, false, false>), grid, block, 0, s, a);
+    else if (!A && Bs && Cq && il8) hipLaunchKernelGGL((chain_s_kernel<NWAVES, false, true, true, false, true>), grid, block, 0, s, a);
+    else if (!A && Bs && Cq) hipLaunchKernelGGL((chain_s_kernel<NWAVES, false, true, true, false, false>), grid, block, 0, s, a);
+    else if (A && !Bs && !Cq) hipLaunchKernelGGL((chain_s_kernel<NWAVES, true, false, false, false, false>), grid, block, 0, s, a);
+    else return CSSHIP_EUNSUPPORTED;
     CSSHIP_CHECK_LAUNCH();
     return CSSHIP_OK;
   }
