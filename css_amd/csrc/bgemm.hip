@@ -515,6 +515,82 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
                                 (!g.bias || ((uintptr_t)g.bias & 15) == 0) &&
                                 (!(g.epi & (CSSHIP_BEPI_MASK_POS | CSSHIP_BEPI_ADD)) ||
                                  ((g.ldaux & 3) == 0 && (xo & 3) == 0 && ((uintptr_t)g.aux & 15) == 0))));
+  if (!to_slab && vec) {
+    // Vector epilogue in TWO phases: every operand the epilogue reads (bias, mask or addend: 16 bytes per piece) is
+    // requested first, then all pieces are finished and stored.  Interleaved - load, use, store, per piece - every piece
+    // was a round trip of its own: the loads sit behind run-time epilogue flags, hipcc's s_waitcnt insertion then assumes
+    // nothing about what is in flight and waits for vmcnt(0) before each use, which also waits for the previous piece's
+    // STORE to be acknowledged (16 dependent round trips per lane in the two position products of the attention backward).
+    float4 bq[NJ], ax[4][NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      bq[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ax[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (g.bias) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int col = n0 + wn * WN + j * 16 + lg * 4;
+        if (col < g.N) bq[j] = *reinterpret_cast<const float4*>(g.bias + col);
+      }
+    }
+    if (g.epi & (CSSHIP_BEPI_MASK_POS | CSSHIP_BEPI_ADD)) {
+      const bool msk = (g.epi & CSSHIP_BEPI_MASK_POS) != 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = m0 + wm * 64 + i * 16 + ln;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int col = n0 + wn * WN + j * 16 + lg * 4;
+          if (row < g.M && col < g.N) {
+            const int64_t ao = xo + (int64_t)row * g.ldaux + col;
+            if (msk) {
+              const uint2 m = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(g.aux) + ao);
+              ax[i][j].x = __uint_as_float(m.x);
+              ax[i][j].y = __uint_as_float(m.y);
+            } else {
+              ax[i][j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.aux) + ao);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = m0 + wm * 64 + i * 16 + ln;
+      if (row >= g.M) continue;
+      const float al = (COLSUM && row < g.head_rows) ? g.alpha_head : g.alpha;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int col = n0 + wn * WN + j * 16 + lg * 4;
+        if (col >= g.N) continue;
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        const float b[4] = {bq[j].x, bq[j].y, bq[j].z, bq[j].w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (g.epi & CSSHIP_BEPI_SCALE_BIAS) ? al * (v[r] + b[r]) : al * v[r] + b[r];
+        if (g.epi & CSSHIP_BEPI_MASK_POS) {
+          const unsigned mx = __float_as_uint(ax[i][j].x), my = __float_as_uint(ax[i][j].y);
+          if (!(__uint_as_float(mx << 16) > 0.f)) v[0] = 0.f;
+          if (!(__uint_as_float(mx & 0xffff0000u) > 0.f)) v[1] = 0.f;
+          if (!(__uint_as_float(my << 16) > 0.f)) v[2] = 0.f;
+          if (!(__uint_as_float(my & 0xffff0000u) > 0.f)) v[3] = 0.f;
+        }
+        if (g.epi & CSSHIP_BEPI_ADD) {
+          v[0] += ax[i][j].x; v[1] += ax[i][j].y; v[2] += ax[i][j].z; v[3] += ax[i][j].w;
+        }
+        if (g.epi & CSSHIP_BEPI_RELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        const int64_t co = coff + (int64_t)row * g.ldc + col;
+        if (obf)
+          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(g.C) + co) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        else
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + co) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  } else {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = m0 + wm * 64 + i * 16 + ln;
@@ -536,51 +612,22 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
         continue;
       }
       const int64_t co = coff + (int64_t)row * g.ldc + col, ao = xo + (int64_t)row * g.ldaux + col;
-      if (vec) {
-        float b[4] = {0.f, 0.f, 0.f, 0.f};
-        if (g.bias) {
-          const float4 bv = *reinterpret_cast<const float4*>(g.bias + col);
-          b[0] = bv.x; b[1] = bv.y; b[2] = bv.z; b[3] = bv.w;
-        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (col + r >= g.N) continue;
+        const float bias = g.bias ? g.bias[col + r] : 0.f;
         const float al = (COLSUM && row < g.head_rows) ? g.alpha_head : g.alpha;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (g.epi & CSSHIP_BEPI_SCALE_BIAS) ? al * (v[r] + b[r]) : al * v[r] + b[r];
+        float x = (g.epi & CSSHIP_BEPI_SCALE_BIAS) ? al * (v[r] + bias) : al * v[r] + bias;
         if (g.epi & CSSHIP_BEPI_MASK_POS) {
-          const uint2 m = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(g.aux) + ao);
-          if (!(__uint_as_float(m.x << 16) > 0.f)) v[0] = 0.f;
-          if (!(__uint_as_float(m.x & 0xffff0000u) > 0.f)) v[1] = 0.f;
-          if (!(__uint_as_float(m.y << 16) > 0.f)) v[2] = 0.f;
-          if (!(__uint_as_float(m.y & 0xffff0000u) > 0.f)) v[3] = 0.f;
+          if (!(bf2f(reinterpret_cast<const unsigned short*>(g.aux)[ao + r]) > 0.f)) x = 0.f;
         }
-        if (g.epi & CSSHIP_BEPI_ADD) {
-          const float4 a4 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.aux) + ao);
-          v[0] += a4.x; v[1] += a4.y; v[2] += a4.z; v[3] += a4.w;
-        }
-        if (g.epi & CSSHIP_BEPI_RELU) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        }
-        if (obf)
-          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(g.C) + co) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-        else
-          *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + co) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (col + r >= g.N) continue;
-          const float bias = g.bias ? g.bias[col + r] : 0.f;
-          const float al = (COLSUM && row < g.head_rows) ? g.alpha_head : g.alpha;
-          float x = (g.epi & CSSHIP_BEPI_SCALE_BIAS) ? al * (v[r] + bias) : al * v[r] + bias;
-          if (g.epi & CSSHIP_BEPI_MASK_POS) {
-            if (!(bf2f(reinterpret_cast<const unsigned short*>(g.aux)[ao + r]) > 0.f)) x = 0.f;
-          }
-          if (g.epi & CSSHIP_BEPI_ADD) x += reinterpret_cast<const float*>(g.aux)[ao + r];
-          if (g.epi & CSSHIP_BEPI_RELU) x = fmaxf(x, 0.f);
-          if (obf) reinterpret_cast<unsigned short*>(g.C)[co + r] = f2bf(x);
-          else reinterpret_cast<float*>(g.C)[co + r] = x;
-        }
+        if (g.epi & CSSHIP_BEPI_ADD) x += reinterpret_cast<const float*>(g.aux)[ao + r];
+        if (g.epi & CSSHIP_BEPI_RELU) x = fmaxf(x, 0.f);
+        if (obf) reinterpret_cast<unsigned short*>(g.C)[co + r] = f2bf(x);
+        else reinterpret_cast<float*>(g.C)[co + r] = x;
       }
     }
+  }
   }
 #ifdef BG_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -40,6 +40,8 @@ DEV uint4 pair_tiles_bf16(uint2 t0, uint2 t1) {
 }
 
 constexpr int PD = 4;  // weight prefetch distance in k-steps (ring of PD fragment sets per wave)
+constexpr int CS_FFMAX = 2048;  // static forms (chain_s_kernel, ffn_bwd_kernel<FULL>): widest FeedForward whose biases fit their LDS block
+constexpr int CS_DUMP = 256;    // floats behind a parameter block where staging lanes without work write
 #ifdef P_STAMPS  // diagnostic build: wave 0 of every workgroup stores s_memtime at phase boundaries -> g_csship_stamps[wg*32 + i]
 #define P_T(i)                                                                                                  \
   {                                                                                                             \
@@ -51,8 +53,15 @@ constexpr int PD = 4;  // weight prefetch distance in k-steps (ring of PD fragme
     }                                                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                          \
   }
+#define P_TQ(v)                                                                       \
+  if (st0 == 1) {                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory");         \
+    __builtin_amdgcn_sched_barrier(0);                                                \
+  }
 #else
 #define P_T(i)
+#define P_TQ(v)
 #endif
 #ifndef P_ABL
 #define P_ABL 0  // diagnostic builds only: bit 0 no weight loads in the k-loop, bit 1 no MFMAs, bit 2 no LDS operand reads,
@@ -368,7 +377,11 @@ struct FfnBwdArgs {
   unsigned short* dyd_bf;             // optional [M, 256]: alpha * dy o output-dropout mask / (1 - p): operand of dW2 / db2
 };
 
-template <int NW>
+// FULL (M % 64 == 0, d_ffn <= 2048: what the encoder runs): no row predicates on loads or stores, and b1 / gamma / beta
+// come from an LDS copy staged once - every global memory instruction of the chunk loop is unconditional, so the
+// s_waitcnt counts of the weight ring are exact (a predicated store in the loop made hipcc assume the path without it
+// and wait for younger loads than the ones it needs; round 5, see chain_s_kernel).
+template <int NW, bool FULL>
 __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
   static_assert(NW * 64 == 8 * BM, "row phases assume 8 lanes per panel row");
   constexpr int NT = 16 / NW;
@@ -376,6 +389,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
   unsigned char* const Xs = XD;
   unsigned char* const Ds = XD + PANEL_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char Graw[2 * PANEL_BYTES + 1024];  // 2 dh panels, later the Ys tile
+  __shared__ __attribute__((aligned(16))) float Pb[FULL ? CS_FFMAX + 2 * DM + CS_DUMP : 4];  // FULL: b1 | gamma | beta | dump
   static_assert(2 * PANEL_BYTES + 1024 >= YS_BYTES, "Ys tile must fit the dh panels");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15;
   const int m0 = blockIdx.x * BM;
@@ -387,12 +401,33 @@ __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
   const Drop dh = drop_make(a.drop_h.seed, a.drop_h.stream, a.drop_h.p);
   const Drop dout = drop_make(a.drop_o.seed, a.drop_o.stream, a.drop_o.p);
   bf16x8 wq[PD][NT];
+  const float* b1p = a.b1;
+  const float* lgp = a.ln_g;
+  const float* lbp = a.ln_b;
+  if constexpr (FULL) {  // parameters -> LDS: float4 j of b1 (FF/4) | gamma (64) | beta (64), two per thread, branch-free
+    const int q1 = a.FF >> 2;
+    const float* const dummy = a.x + (size_t)m0 * DM + lane * 4;
+    float4 pvv[2];
+    int pdd[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int j = tid + 512 * k;
+      const float* const base = j < q1 ? a.b1 : j < q1 + 64 ? a.ln_g : j < q1 + 128 ? a.ln_b : nullptr;
+      const int off = j < q1 ? j : j < q1 + 64 ? j - q1 : j - q1 - 64;
+      pdd[k] = base != nullptr ? (j < q1 ? j * 4 : CS_FFMAX + (j - q1) * 4) : CS_FFMAX + 2 * DM + lane * 4;
+      pvv[k] = *reinterpret_cast<const float4*>(base != nullptr ? base + off * 4 : dummy);
+    }
+    *reinterpret_cast<float4*>(Pb + pdd[0]) = pvv[0];
+    *reinterpret_cast<float4*>(Pb + pdd[1]) = pvv[1];
+    b1p = Pb; lgp = Pb + CS_FFMAX; lbp = Pb + CS_FFMAX + DM;
+    __syncthreads();
+  }
   prefetch_first<NT>(wq, w1s + (size_t)rot * 16 * KS * 64, KS, NT);
 
   // ---- prologue: the two bf16 panels; LN(x) also goes to global for the weight-gradient GEMM
   {
     const int r = tid >> 3, part = tid & 7;
-    const int row = m0 + r, rowc = min(row, a.M - 1);
+    const int row = m0 + r, rowc = FULL ? row : min(row, a.M - 1);
     float4 v[8], d[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -413,18 +448,18 @@ __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int c4 = i * 8 + part;
-      const float4 gm = *reinterpret_cast<const float4*>(a.ln_g + c4 * 4);
-      const float4 bt = *reinterpret_cast<const float4*>(a.ln_b + c4 * 4);
+      const float4 gm = *reinterpret_cast<const float4*>(lgp + c4 * 4);
+      const float4 bt = *reinterpret_cast<const float4*>(lbp + c4 * 4);
       const uint2 av = make_uint2(pack_bf2(v[i].x * rstd * gm.x + bt.x, v[i].y * rstd * gm.y + bt.y),
                                   pack_bf2(v[i].z * rstd * gm.z + bt.z, v[i].w * rstd * gm.w + bt.w));
       *reinterpret_cast<uint2*>(Xs + panel_off(r, c4 >> 1) + (c4 & 1) * 8) = av;
-      if (row < a.M) *reinterpret_cast<uint2*>(a.a_bf + (size_t)row * DM + c4 * 4) = av;
+      if (FULL || row < a.M) *reinterpret_cast<uint2*>(a.a_bf + (size_t)row * DM + c4 * 4) = av;
       // gradient of the FeedForward's (dropped) output: alpha * dy o mask / (1 - p)
       const float4 dd = drop_apply4(dout, (unsigned)((m0 + r) * DM + c4 * 4),
                                     make_float4(a.alpha * d[i].x, a.alpha * d[i].y, a.alpha * d[i].z, a.alpha * d[i].w));
       const uint2 dv = make_uint2(pack_bf2(dd.x, dd.y), pack_bf2(dd.z, dd.w));
       *reinterpret_cast<uint2*>(Ds + panel_off(r, c4 >> 1) + (c4 & 1) * 8) = dv;
-      if (a.dyd_bf != nullptr && row < a.M) *reinterpret_cast<uint2*>(a.dyd_bf + (size_t)row * DM + c4 * 4) = dv;
+      if (a.dyd_bf != nullptr && (FULL || row < a.M)) *reinterpret_cast<uint2*>(a.dyd_bf + (size_t)row * DM + c4 * 4) = dv;
     }
   }
   __syncthreads();
@@ -444,7 +479,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
     f32x4 h[NT][4];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {  // the bias is the accumulators' initial value, as in the forward
-      const float4 bb = *reinterpret_cast<const float4*>(a.b1 + c * DM + (wave * NT + t) * 16 + 4 * g);
+      const float4 bb = *reinterpret_cast<const float4*>(b1p + c * DM + (wave * NT + t) * 16 + 4 * g);
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) h[t][rt] = f32x4{bb.x, bb.y, bb.z, bb.w};
     }
@@ -471,7 +506,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
       for (int rt = 0; rt < 4; ++rt) {
         const uint4 pk = pair_tiles_bf16(hpk[0][rt], hpk[1][rt]);
         const int row = m0 + rt * 16 + n;
-        if (row < a.M) *reinterpret_cast<uint4*>(a.h_bf + (size_t)row * a.FF + c * DM + (wave * NT + (g & 1)) * 16 + (g >> 1) * 8) = pk;
+        if (FULL || row < a.M) *reinterpret_cast<uint4*>(a.h_bf + (size_t)row * a.FF + c * DM + (wave * NT + (g & 1)) * 16 + (g >> 1) * 8) = pk;
       }
     } else {
 #pragma unroll
@@ -479,7 +514,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
           const int row = m0 + rt * 16 + n;
-          if (row < a.M) *reinterpret_cast<uint2*>(a.h_bf + (size_t)row * a.FF + c * DM + (wave * NT + t) * 16 + 4 * g) = hpk[t][rt];
+          if (FULL || row < a.M) *reinterpret_cast<uint2*>(a.h_bf + (size_t)row * a.FF + c * DM + (wave * NT + t) * 16 + 4 * g) = hpk[t][rt];
         }
     }
     // pass B: dh = (alpha dy) W2[:, c] masked  -> LDS panel + global
@@ -503,7 +538,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
       for (int rt = 0; rt < 4; ++rt) {
         const uint4 pk = pair_tiles_bf16(hpk[0][rt], hpk[1][rt]);
         const int row = m0 + rt * 16 + n;
-        if (row < a.M) *reinterpret_cast<uint4*>(a.dh_bf + (size_t)row * a.FF + c * DM + (wave * NT + (g & 1)) * 16 + (g >> 1) * 8) = pk;
+        if (FULL || row < a.M) *reinterpret_cast<uint4*>(a.dh_bf + (size_t)row * a.FF + c * DM + (wave * NT + (g & 1)) * 16 + (g >> 1) * 8) = pk;
       }
     } else {
 #pragma unroll
@@ -511,7 +546,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
           const int row = m0 + rt * 16 + n;
-          if (row < a.M) *reinterpret_cast<uint2*>(a.dh_bf + (size_t)row * a.FF + c * DM + (wave * NT + t) * 16 + 4 * g) = hpk[t][rt];
+          if (FULL || row < a.M) *reinterpret_cast<uint2*>(a.dh_bf + (size_t)row * a.FF + c * DM + (wave * NT + t) * 16 + 4 * g) = hpk[t][rt];
         }
     }
     __syncthreads();
@@ -530,12 +565,15 @@ __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
   }
   __syncthreads();
   const int r = tid >> 3, part = tid & 7;
-  const int row = m0 + r, rowc = min(row, a.M - 1);
-  const bool rvalid = row < a.M;
-  float4 v[8], da[8];
+  const int row = m0 + r, rowc = FULL ? row : min(row, a.M - 1);
+  const bool rvalid = FULL || row < a.M;
+  float4 v[8], da[8], dyv[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     v[i] = *reinterpret_cast<const float4*>(a.x + (size_t)rowc * DM + (i * 8 + part) * 4);
+    // dy is needed by the dx rows below: requested here, all eight at once (read next to its use, behind stores it might
+    // alias, every piece was a load - s_waitcnt vmcnt(0) - store round trip of its own: eight L2 latencies in a row)
+    dyv[i] = *reinterpret_cast<const float4*>(a.dy + (size_t)rowc * DM + (i * 8 + part) * 4);
     da[i] = *reinterpret_cast<const float4*>(ys + r * YS + (i * 8 + part) * 4);
   }
   float s = 0.f;
@@ -553,7 +591,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
   float4 gg[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const float4 gm = *reinterpret_cast<const float4*>(a.ln_g + (i * 8 + part) * 4);
+    const float4 gm = *reinterpret_cast<const float4*>(lgp + (i * 8 + part) * 4);
     v[i].x *= rstd; v[i].y *= rstd; v[i].z *= rstd; v[i].w *= rstd;  // xhat
     if (!rvalid) da[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     gg[i] = make_float4(da[i].x * gm.x, da[i].y * gm.y, da[i].z * gm.z, da[i].w * gm.w);
@@ -569,7 +607,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
   for (int i = 0; i < 8; ++i) {
     const int col = (i * 8 + part) * 4;
     if (rvalid) {
-      const float4 d = *reinterpret_cast<const float4*>(a.dy + (size_t)row * DM + col);
+      const float4 d = dyv[i];
       float4 o4;
       o4.x = d.x + rstd * (gg[i].x - s1 - v[i].x * s2);
       o4.y = d.y + rstd * (gg[i].y - s1 - v[i].y * s2);
@@ -1168,10 +1206,8 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(ChainArgs a) {
 //     never drains between stages and no stage primes its own ring;
 //   * tile counts are template constants (mma_pass_s has no t < nt tests), stores are unpredicated.
 // Anything else (ragged last panel, other widths, the fused conv front end) runs the first form.
-constexpr int CS_FFMAX = 2048;
 constexpr int CS_LN = 8 * DM;                                     // A gamma | beta, final gamma | beta, B gamma | beta, q/k/v gamma | beta
 constexpr int CS_PARAMS = CS_LN + 2 * CS_FFMAX + 2 * DM + 768;    // floats: + b1 A, b2 A, b1 B, b2 B, b q|k|v
-constexpr int CS_DUMP = 256;                                      // where the staging lanes without work write
 
 template <int NT, bool NEXT>
 DEV void mma_pass_s(f32x4 (&acc)[NT][4], const unsigned char* panel, int n, int g, const bf16x8* w, int tstride,
@@ -1263,6 +1299,9 @@ DEV void ffn_stage_s(float4 (&v)[8], unsigned char* Xs, unsigned char* Hraw, con
     for (int rt = 0; rt < 4; ++rt) o[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int ci = 0; ci < nchunk; ++ci) {
     const int c = (ci + rot) % nchunk;
+#ifdef P_STAMPS
+    unsigned long long tq0_ = 0, tq1_ = 0, tq2_ = 0, tq3_ = 0;
+#endif
     f32x4 h[NT][4];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {  // the bias is the accumulators' initial value
@@ -1272,7 +1311,9 @@ DEV void ffn_stage_s(float4 (&v)[8], unsigned char* Xs, unsigned char* Hraw, con
     }
     const bf16x8* w1c = w1s + (size_t)c * 16 * KS * 64;
     const bf16x8* w2c = w2s + (size_t)c * KS * 64;
+    P_TQ(tq0_)
     mma_pass_s<NT, true>(h, Xs, n, g, w1c, KS, w2c, ks2, wq);
+    P_TQ(tq1_)
     unsigned char* hs = (ci & 1) ? Hs1 : Hs0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -1290,10 +1331,23 @@ DEV void ffn_stage_s(float4 (&v)[8], unsigned char* Xs, unsigned char* Hraw, con
         *reinterpret_cast<uint2*>(hs + panel_off(rt * 16 + n, hc >> 3) + (hc & 7) * 2) = pk;
       }
     }
+    P_TQ(tq2_)
     __syncthreads();
+    P_TQ(tq3_)
     // behind the last chunk the ring takes the NEXT stage's first k-steps: a pointer select, the loads stay unconditional
     const bf16x8* wn = (ci + 1 < nchunk) ? w1s + (size_t)((c + 1) % nchunk) * 16 * KS * 64 : next_w;
     mma_pass_s<NT, true>(o, hs, n, g, w2c, ks2, wn, KS, wq);
+#ifdef P_STAMPS
+    if (st0 == 1 && g_stamps_dev != nullptr && (threadIdx.x & 63) == 0) {
+      unsigned long long tq4_;
+      P_TQ(tq4_)
+      const int wv_ = threadIdx.x >> 6;  // wave 0 and wave 7 only: slots 12..15 / 16..19: W1 pass, hidden epilogue, barrier wait, W2 pass
+      if (wv_ == 0 || wv_ == 7) {
+        unsigned long long* d_ = g_stamps_dev + (size_t)blockIdx.x * 32 + 12 + (wv_ == 7 ? 4 : 0);
+        d_[0] += tq1_ - tq0_; d_[1] += tq2_ - tq1_; d_[2] += tq3_ - tq2_; d_[3] += tq4_ - tq3_;
+      }
+    }
+#endif
   }
   P_T(st0 + 1)
   __syncthreads();  // every wave is done reading the hidden panels
@@ -2190,7 +2244,11 @@ extern "C" int csship_ffn_bwd_drop(const float* x, const float* dy, const float*
                reinterpret_cast<const bf16x8*>(w2t_packed), reinterpret_cast<const bf16x8*>(w1t_packed), a_bf16, h_bf16,
                dh_bf16, dx, reinterpret_cast<float*>(workspace), M, d_ffn, alpha,
                drop_hidden ? *drop_hidden : none, drop_out ? *drop_out : none, dyd_bf16};
-  hipLaunchKernelGGL((ffn_bwd_kernel<NWAVES>), dim3(nwg), dim3(NWAVES * 64), 0, as_stream(stream), a);
+  static const bool use_static = [] { const char* e = getenv("CSSHIP_CHAIN_STATIC"); return e == nullptr || atoi(e) != 0; }();
+  if (use_static && (M % BM) == 0 && d_ffn <= CS_FFMAX)
+    hipLaunchKernelGGL((ffn_bwd_kernel<NWAVES, true>), dim3(nwg), dim3(NWAVES * 64), 0, as_stream(stream), a);
+  else
+    hipLaunchKernelGGL((ffn_bwd_kernel<NWAVES, false>), dim3(nwg), dim3(NWAVES * 64), 0, as_stream(stream), a);
   CSSHIP_CHECK_LAUNCH();
   return launch_slab_reduce(reinterpret_cast<const float*>(workspace), nwg, 2 * DM, 2 * DM, 2 * DM, 1.f, nullptr, nullptr, 0,
                             dgamma_dbeta, as_stream(stream), true);
