@@ -143,10 +143,24 @@ __global__ __launch_bounds__(512) void ffnw_kernel(FfnwArgs a) {
   constexpr int PDW = 4, NTM = NTO > 2 ? NTO : 2;  // PDW must divide both k-step counts (ring slot = k-step % PDW across passes)
   constexpr int PANELS = BM * XROWB + 2 * HBYTES, YSB = BM * (D + 4) * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem[PANELS > YSB ? PANELS : YSB];
+  // the hidden bias from LDS (staged once, unconditionally), the ring refilled unconditionally behind the last chunk and
+  // the output bias requested after the loop: a run-time predicate around a global load inside the chunk loop makes
+  // hipcc's s_waitcnt insertion assume the path without it, and the waits of the following k-steps then cover weight
+  // fragments requested a moment ago (round 5, panel.hip chain_s_kernel)
+  constexpr int FFMAX = 2048;
+  __shared__ __attribute__((aligned(16))) float B1s[FFMAX + 256];
   unsigned char* const Xs = smem;
   unsigned char* const Hs = smem + BM * XROWB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15;
   const int m0 = blockIdx.x * BM, nchunk = a.FF / 256, ks2 = a.FF / 32, rot = blockIdx.x % nchunk;
+  const bool b1_lds = a.FF <= FFMAX;   // (wave-uniform; wider FeedForwards keep the global loads)
+  {
+    const int q1 = a.FF >> 2;
+    const bool mine = b1_lds && tid < q1;
+    const float4 bv = *reinterpret_cast<const float4*>(a.b1 + (mine ? tid : 0) * 4);
+    *reinterpret_cast<float4*>(B1s + (mine ? tid * 4 : FFMAX + (lane & 63) * 4)) = bv;
+  }
+  const float* const b1p = b1_lds ? B1s : a.b1;
   const bf16x8* w1s = a.w1 + (size_t)(wave * 2) * KS1 * 64 + lane;    // + chunk c: c * 16 tiles
   const bf16x8* w2s = a.w2 + (size_t)(wave * NTO) * ks2 * 64 + lane;  // + chunk c: k-steps 8c ..
   bf16x8 wq[PDW][NTM];
@@ -183,7 +197,7 @@ __global__ __launch_bounds__(512) void ffnw_kernel(FfnwArgs a) {
     f32x4 h[2][4];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {  // the bias is the accumulators' initial value
-      const float4 bb = *reinterpret_cast<const float4*>(a.b1 + c * 256 + (wave * 2 + t) * 16 + 4 * g);
+      const float4 bb = *reinterpret_cast<const float4*>(b1p + c * 256 + (wave * 2 + t) * 16 + 4 * g);
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) h[t][rt] = f32x4{bb.x, bb.y, bb.z, bb.w};
     }
@@ -201,12 +215,10 @@ __global__ __launch_bounds__(512) void ffnw_kernel(FfnwArgs a) {
     }
     __syncthreads();
     const bf16x8* w1n = w1s + (size_t)((c + 1) % nchunk) * 16 * KS1 * 64;
-    if (ci + 1 == nchunk) {
-#pragma unroll
-      for (int t = 0; t < NTO; ++t) b2v[t] = *reinterpret_cast<const float4*>(a.b2 + (wave * NTO + t) * 16 + 4 * g);
-    }
-    pass_bf16<NTO, 2, 8, HROWB, PDW, NTM>(o, hs, n, g, w2c, ks2, w1n, KS1, ci + 1 < nchunk, wq);
+    pass_bf16<NTO, 2, 8, HROWB, PDW, NTM>(o, hs, n, g, w2c, ks2, w1n, KS1, true, wq);  // (behind the last chunk: a harmless re-read)
   }
+#pragma unroll
+  for (int t = 0; t < NTO; ++t) b2v[t] = *reinterpret_cast<const float4*>(a.b2 + (wave * NTO + t) * 16 + 4 * g);
   __syncthreads();  // every wave is done with the panels: the region becomes the f32 staging tile
   float* ys = reinterpret_cast<float*>(smem);
   park_out<NTO, D>(ys, o, b2v, wave, g, n);
@@ -234,13 +246,23 @@ struct LinwArgs {
   int M, N;
 };
 
-template <int D, bool LN_IN>
+// FULL (M % 64 == 0, N <= 2048): bias from an LDS copy, no row predicates, the ring refilled unconditionally behind the
+// last pass, and linres requests a pass's residual pieces together, ahead of the pass (load - add - store per piece was a
+// round trip per piece): every s_waitcnt of the pass loop is exact (round 5, panel.hip chain_s_kernel)
+template <int D, bool LN_IN, bool FULL>
 __global__ __launch_bounds__(512) void linw_kernel(LinwArgs a) {
   constexpr int KSN = D / 32, XROWB = 2 * D, PDW = 4;
   __shared__ __attribute__((aligned(16))) unsigned char Xs[BM * XROWB];
+  __shared__ __attribute__((aligned(16))) float Bls[FULL ? 2048 : 4];
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, n = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m0 = blockIdx.x * BM, npass = a.N / 256;
+  const float* biasp = a.bias;
+  if constexpr (FULL) {   // N / 4 <= 512 float4: one per thread, clamped (threads beyond N / 4 rewrite the last piece)
+    const int j = min(tid, (a.N >> 2) - 1);
+    *reinterpret_cast<float4*>(Bls + j * 4) = *reinterpret_cast<const float4*>(a.bias + j * 4);
+    biasp = Bls;
+  }
   const bf16x8* ws = a.w + (size_t)(wave * 2) * KSN * 64 + lane;  // + pass p: 16 tiles
   bf16x8 wq[PDW][2];
 #pragma unroll
@@ -271,19 +293,30 @@ __global__ __launch_bounds__(512) void linw_kernel(LinwArgs a) {
     f32x4 acc[2][4];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {  // the bias is the accumulators' initial value
-      const float4 bb = *reinterpret_cast<const float4*>(a.bias + (tile0 + t) * 16 + 4 * g);
+      const float4 bb = *reinterpret_cast<const float4*>(biasp + (tile0 + t) * 16 + 4 * g);
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) acc[t][rt] = f32x4{bb.x, bb.y, bb.z, bb.w};
     }
     const bf16x8* wc = ws + (size_t)p * 16 * KSN * 64;
-    pass_bf16<2, 2, KSN, XROWB, PDW, 2>(acc, Xs, n, g, wc, KSN, wc + (size_t)16 * KSN * 64, KSN, p + 1 < npass, wq);
+    float4 rq[2][4];   // FULL linres: the residual pieces of this pass, requested now
+    if constexpr (FULL && !LN_IN) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+          rq[t][rt] = *reinterpret_cast<const float4*>(a.res + (size_t)(m0 + rt * 16 + n) * a.N + (tile0 + t) * 16 + 4 * g);
+    }
+    if constexpr (FULL)   // behind the last pass the ring re-reads pass 0 (harmless): the loads stay unconditional
+      pass_bf16<2, 2, KSN, XROWB, PDW, 2>(acc, Xs, n, g, wc, KSN, p + 1 < npass ? wc + (size_t)16 * KSN * 64 : ws, KSN, true, wq);
+    else
+      pass_bf16<2, 2, KSN, XROWB, PDW, 2>(acc, Xs, n, g, wc, KSN, wc + (size_t)16 * KSN * 64, KSN, p + 1 < npass, wq);
     if constexpr (LN_IN) {  // interleaved rows: 8 consecutive features per lane, one 16-byte bf16 store per row tile
       unsigned short* o = reinterpret_cast<unsigned short*>(a.out);
       const int f = tile0 * 16 + 8 * g;
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
         const int row = m0 + rt * 16 + n;
-        if (row < a.M)
+        if (FULL || row < a.M)
           *reinterpret_cast<uint4*>(o + (size_t)row * a.N + f) =
               make_uint4(pack_bf2(acc[0][rt][0], acc[0][rt][1]), pack_bf2(acc[0][rt][2], acc[0][rt][3]),
                          pack_bf2(acc[1][rt][0], acc[1][rt][1]), pack_bf2(acc[1][rt][2], acc[1][rt][3]));
@@ -296,8 +329,10 @@ __global__ __launch_bounds__(512) void linw_kernel(LinwArgs a) {
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
           const int row = m0 + rt * 16 + n;
-          if (row < a.M) {
-            const float4 r4 = *reinterpret_cast<const float4*>(a.res + (size_t)row * a.N + f);
+          if (FULL || row < a.M) {
+            float4 r4;
+            if constexpr (FULL) r4 = rq[t][rt];
+            else r4 = *reinterpret_cast<const float4*>(a.res + (size_t)row * a.N + f);
             *reinterpret_cast<float4*>(o + (size_t)row * a.N + f) =
                 make_float4(r4.x + acc[t][rt][0], r4.y + acc[t][rt][1], r4.z + acc[t][rt][2], r4.w + acc[t][rt][3]);
           }
@@ -653,8 +688,11 @@ extern "C" int csship_ln_linear_wide(const float* x, const float* ln_g, const fl
   if (!aligned16(x) || !aligned16(w_il8_packed) || !aligned16(bias_il8) || !aligned16(out_bf16)) return CSSHIP_EALIGN;
   LinwArgs a{x, ln_g, ln_b, reinterpret_cast<const bf16x8*>(w_il8_packed), bias_il8, nullptr, out_bf16, M, N};
   dim3 grid((M + BM - 1) / BM), block(512);
-  if (d_model == 256) hipLaunchKernelGGL((linw_kernel<256, true>), grid, block, 0, as_stream(stream), a);
-  else hipLaunchKernelGGL((linw_kernel<512, true>), grid, block, 0, as_stream(stream), a);
+  const bool full = (M % BM) == 0 && N <= 2048 && aligned16(a.bias);
+  if (d_model == 256 && full) hipLaunchKernelGGL((linw_kernel<256, true, true>), grid, block, 0, as_stream(stream), a);
+  else if (d_model == 256) hipLaunchKernelGGL((linw_kernel<256, true, false>), grid, block, 0, as_stream(stream), a);
+  else if (full) hipLaunchKernelGGL((linw_kernel<512, true, true>), grid, block, 0, as_stream(stream), a);
+  else hipLaunchKernelGGL((linw_kernel<512, true, false>), grid, block, 0, as_stream(stream), a);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }
@@ -667,8 +705,11 @@ extern "C" int csship_linear_res_wide(const uint16_t* a_bf16, const uint16_t* w_
   if (!aligned16(a_bf16) || !aligned16(w_packed) || !aligned16(bias) || !aligned16(res) || !aligned16(out)) return CSSHIP_EALIGN;
   LinwArgs a{a_bf16, nullptr, nullptr, reinterpret_cast<const bf16x8*>(w_packed), bias, res, out, M, d_model};
   dim3 grid((M + BM - 1) / BM), block(512);
-  if (d_model == 256) hipLaunchKernelGGL((linw_kernel<256, false>), grid, block, 0, as_stream(stream), a);
-  else hipLaunchKernelGGL((linw_kernel<512, false>), grid, block, 0, as_stream(stream), a);
+  const bool full = (M % BM) == 0 && d_model <= 2048 && aligned16(a.bias);
+  if (d_model == 256 && full) hipLaunchKernelGGL((linw_kernel<256, false, true>), grid, block, 0, as_stream(stream), a);
+  else if (d_model == 256) hipLaunchKernelGGL((linw_kernel<256, false, false>), grid, block, 0, as_stream(stream), a);
+  else if (full) hipLaunchKernelGGL((linw_kernel<512, false, true>), grid, block, 0, as_stream(stream), a);
+  else hipLaunchKernelGGL((linw_kernel<512, false, false>), grid, block, 0, as_stream(stream), a);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }
