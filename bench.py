@@ -23,7 +23,7 @@ prints ONE JSON line with n_gpus = the world size the collective library reports
 Extra objects on the JSON line (task section 4):
   roofline     measured INSIDE the step: one un-captured step is run with the library's launch timeline on (HIP event
                pairs directly around every kernel launch, on the launch stream); dominant kernel = the encoder chain
-               (chain_kernel<8,0,1,1,1>: FFN_out+LN -> FFN_in -> LN+QKV, 15 launches per step, MFMA bound):
+               (chain_s_kernel<8,1,1,1,0,1>: FFN_out+LN -> FFN_in -> LN+QKV, 15 launches per step, MFMA bound):
                achieved = algorithmic flops (2 x 4*M*256*1024 + 2*M*256*768) / average launch duration; peak = 2.5
                PFLOP/s dense bf16; traffic = HBM bytes per launch from the rocprofv3 PMC passes under profiles/.
                roofline.attention / .outproj_conv (MFMA), .stft / .pit (HBM, 2 052 and 4 108 B/frame) the same way.
@@ -438,7 +438,7 @@ def main():
             if fn.endswith((".hip", ".hpp", ".inc")) and fn != "fft_tables.inc":   # (the generated table is not a source)
                 hsh.update(open(os.path.join(ROOT, "css_amd", "csrc", fn), "rb").read())
         csrc_sha = hsh.hexdigest()[:16]
-        for tp in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        for tp in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tp)
             if os.path.exists(tpath):
                 rec_all = json.load(open(tpath))
@@ -466,10 +466,10 @@ def main():
         flops = 2 * 4.0 * M * 256 * 1024 + 2.0 * M * 256 * 768
         step_flops = B * T * FLOP_PER_FRAME * args.blocks / 16
         roof = {"bound": "mfma",
-                "kernel": f"chain_kernel<8,0,1,1,1> (FFN_out+LN -> FFN_in -> LN+QKV, M=12800; {nl} launches/step)",
+                "kernel": f"chain_s_kernel<8,1,1,1,0,1> (FFN_out+LN -> FFN_in -> LN+QKV, static form, M=12800; {nl} launches/step)",
                 "achieved": flops / dur / 1e12 if dur else None, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                "frac": flops / dur / PEAK_BF16 if dur else None, "traffic": traffic_of("chain_kernel<8, false, true, true, true, false>"),
-                "mfma_busy_pmc": busy_of("chain_kernel<8, false, true, true, true, false>"),
+                "frac": flops / dur / PEAK_BF16 if dur else None, "traffic": traffic_of("chain_s_kernel<8, true, true, true, false, true>"),
+                "mfma_busy_pmc": busy_of("chain_s_kernel<8, true, true, true, false, true>"),
                 "avg_launch_us": dur * 1e6, "flops_per_launch": flops,
                 "timing": "HIP event pair around every in-step launch, minus the measured cost of an empty pair",
                 "bracket_overhead_us": bracket * 1e6, "empty_bracket_us": bracket_measured * 1e6,

@@ -1390,6 +1390,157 @@ DEV void ffn_stage_s(float4 (&v)[8], unsigned char* Xs, unsigned char* Hraw, con
   }
 }
 
+// ---- pipelined form of the stage (chain_s_kernel<..., PIPE>): the hidden epilogue of chunk c (ReLU, bf16 pack, 8-byte LDS
+// stores: 450-600 cycles of VALU / LDS work per chunk with the matrix pipe idle) rides INSIDE the W2 pass of chunk c - 1,
+// one accumulator tile per k-step, so that only the first chunk's epilogue of a FeedForward is exposed.  Pass order
+//   W1(0) | epi(0) B W1(1) | [W2(0) + epi(1)] B W1(2) | [W2(1) + epi(2)] B W1(3) | [W2(2) + epi(3)] B | W2(3)      (B = barrier)
+// - same barrier count, same double-buffered hidden panels (W2(c - 1) reads panel (c - 1) & 1 while epi(c) fills panel
+// c & 1, which W2(c - 2) left before the previous barrier), same registers at the peak (h stays live through a W2 pass,
+// where the first form had it dead; the W1 pass holds h and o either way).  The weight ring follows the new order.
+template <int NT, bool TRAIN>
+DEV void hidden_tile(unsigned char* hs, const f32x4& hv, int row, int hc, const StageTrain& tr, int FF, int c) {
+  uint2 pk;
+  if (TRAIN && tr.dh.thresh != 0u) {  // relu, then the hidden activation's dropout (conformer.py:317), element (row, c*256 + hc)
+    const float4 dv = drop_apply4(tr.dh, (unsigned)((tr.m0 + row) * FF + c * DM + hc),
+                                  make_float4(fmaxf(hv[0], 0.f), fmaxf(hv[1], 0.f), fmaxf(hv[2], 0.f), fmaxf(hv[3], 0.f)));
+    pk = make_uint2(pack_bf2(dv.x, dv.y), pack_bf2(dv.z, dv.w));
+  } else {
+    pk = make_uint2(relu_bf2(pack_bf2(hv[0], hv[1])), relu_bf2(pack_bf2(hv[2], hv[3])));
+  }
+  *reinterpret_cast<uint2*>(hs + panel_off(row, hc >> 3) + (hc & 7) * 2) = pk;
+}
+
+// mma_pass_s with the hidden epilogue of the NEXT chunk as a side job: behind the MFMAs of k-step ks, accumulator tile
+// (t = ks / 4, row tile ks % 4) of h goes to the panel hs_out
+template <int NT, bool TRAIN>
+DEV void mma_pass_epi(f32x4 (&acc)[NT][4], const unsigned char* panel, int n, int g, const bf16x8* w, int tstride,
+                      const bf16x8* wn, int nstride, bf16x8 (&wq)[PD][NT], unsigned char* hs_out, const f32x4 (&h)[NT][4],
+                      int wave, const StageTrain& tr, int FF, int c) {
+  static_assert(NT * 4 == KS, "one accumulator tile per k-step");
+  bf16x8 xa[2][4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) xa[0][rt] = *reinterpret_cast<const bf16x8*>(panel + panel_off(rt * 16 + n, g));
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    bf16x8 wc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wc[t] = wq[ks % PD][t];
+    if (ks + PD < KS) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) wq[ks % PD][t] = w[(size_t)(t * tstride + ks + PD) * 64];
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) wq[ks % PD][t] = wn[(size_t)(t * nstride + ks + PD - KS) * 64];
+    }
+    if (ks + 1 < KS) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+        xa[(ks + 1) & 1][rt] = *reinterpret_cast<const bf16x8*>(panel + panel_off(rt * 16 + n, (ks + 1) * 4 + g));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+        acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[t], xa[ks & 1][rt], acc[t][rt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    hidden_tile<NT, TRAIN>(hs_out, h[ks >> 2][ks & 3], (ks & 3) * 16 + n, (wave * NT + (ks >> 2)) * 16 + 4 * g, tr, FF, c);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int NW, bool FINAL_LN, bool TRAIN>
+DEV void ffn_stage_p(float4 (&v)[8], unsigned char* Xs, unsigned char* Hraw, const float* lng, const float* fing,
+                     const float* b1s, const float* b2s, const FfnW& f, int FF, float alpha, int tid, int rot,
+                     bf16x8 (&wq)[PD][16 / NW], const bf16x8* next_w, unsigned long long* g_stamps_dev, int st0,
+                     const StageTrain& tr) {
+  constexpr int NT = 16 / NW;
+  const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15, r = tid >> 3, part = tid & 7;
+  const int nchunk = FF / DM, ks2 = FF / 32;   // nchunk >= 2 (checked on the host)
+  unsigned char* const Hs0 = Hraw;
+  unsigned char* const Hs1 = Hraw + PANEL_BYTES;
+  const bf16x8* w1s = f.w1 + (size_t)(wave * NT) * KS * 64 + lane;
+  const bf16x8* w2s = f.w2 + (size_t)(wave * NT) * ks2 * 64 + lane;
+  rows_to_panel_s(Xs, v, lng, lng != nullptr ? lng + DM : nullptr, r, part);
+  __syncthreads();  // also: every wave has left the previous stage's Ys reads
+  P_T(st0 + 0)
+  f32x4 o[NT][4], h[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) o[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto chunk_of = [&](int ci) { return (ci + rot) % nchunk; };
+  auto w1_of = [&](int c) { return w1s + (size_t)c * 16 * KS * 64; };
+  auto w2_of = [&](int c) { return w2s + (size_t)c * KS * 64; };
+#define FS_HINIT(C)                                                                                        \
+  _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                         \
+    const float4 bb = *reinterpret_cast<const float4*>(b1s + (C) * DM + (wave * NT + t) * 16 + 4 * g);     \
+    _Pragma("unroll") for (int rt = 0; rt < 4; ++rt) h[t][rt] = f32x4{bb.x, bb.y, bb.z, bb.w};             \
+  }
+  const int c0 = chunk_of(0), c1 = chunk_of(1);
+  FS_HINIT(c0)
+  mma_pass_s<NT, true>(h, Xs, n, g, w1_of(c0), KS, w1_of(c1), KS, wq);
+#pragma unroll
+  for (int q = 0; q < NT * 4; ++q)   // the first chunk's epilogue has no W2 pass to ride in
+    hidden_tile<NT, TRAIN>(Hs0, h[q >> 2][q & 3], (q & 3) * 16 + n, (wave * NT + (q >> 2)) * 16 + 4 * g, tr, FF, c0);
+  __syncthreads();
+  FS_HINIT(c1)
+  mma_pass_s<NT, true>(h, Xs, n, g, w1_of(c1), KS, w2_of(c0), ks2, wq);
+  for (int ci = 1; ci + 1 < nchunk; ++ci) {   // [W2(ci - 1) + epi(ci)] B W1(ci + 1)
+    const int cp = chunk_of(ci - 1), c = chunk_of(ci), cn = chunk_of(ci + 1);
+    mma_pass_epi<NT, TRAIN>(o, ((ci - 1) & 1) ? Hs1 : Hs0, n, g, w2_of(cp), ks2, w1_of(cn), KS, wq, (ci & 1) ? Hs1 : Hs0, h, wave, tr, FF, c);
+    __syncthreads();
+    FS_HINIT(cn)
+    mma_pass_s<NT, true>(h, Xs, n, g, w1_of(cn), KS, w2_of(c), ks2, wq);
+  }
+  {
+    const int ci = nchunk - 1, cp = chunk_of(ci - 1), c = chunk_of(ci);
+    mma_pass_epi<NT, TRAIN>(o, ((ci - 1) & 1) ? Hs1 : Hs0, n, g, w2_of(cp), ks2, w2_of(c), ks2, wq, (ci & 1) ? Hs1 : Hs0, h, wave, tr, FF, c);
+    __syncthreads();
+    mma_pass_s<NT, true>(o, (ci & 1) ? Hs1 : Hs0, n, g, w2_of(c), ks2, next_w, KS, wq);
+  }
+#undef FS_HINIT
+  P_T(st0 + 1)
+  __syncthreads();  // every wave is done reading the hidden panels
+  float* ys = reinterpret_cast<float*>(Hraw);
+  float4 b2v[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) b2v[t] = *reinterpret_cast<const float4*>(b2s + (wave * NT + t) * 16 + 4 * g);
+  park_tiles<NT, false>(ys, o, NT, wave * NT * 16, g, n, b2v);
+  __syncthreads();
+  P_T(st0 + 2)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float4 y = *reinterpret_cast<const float4*>(ys + r * YS + (i * 8 + part) * 4);
+    if constexpr (TRAIN) y = drop_apply4(tr.dout, (unsigned)((tr.m0 + r) * DM + (i * 8 + part) * 4), y);  // conformer.py:319
+    v[i] = make_float4(v[i].x + alpha * y.x, v[i].y + alpha * y.y, v[i].z + alpha * y.z, v[i].w + alpha * y.w);
+  }
+  if constexpr (FINAL_LN) {
+    if constexpr (TRAIN) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(tr.pre_ln_out + (size_t)(tr.m0 + r) * DM + (i * 8 + part) * 4) = v[i];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    const float mean = sum8(s) * (1.f / DM);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+      ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float rstd = rsqrtf(sum8(ss) * (1.f / DM) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4 gm = *reinterpret_cast<const float4*>(fing + (i * 8 + part) * 4);
+      const float4 bt = *reinterpret_cast<const float4*>(fing + DM + (i * 8 + part) * 4);
+      v[i].x = v[i].x * rstd * gm.x + bt.x; v[i].y = v[i].y * rstd * gm.y + bt.y;
+      v[i].z = v[i].z * rstd * gm.z + bt.z; v[i].w = v[i].w * rstd * gm.w + bt.w;
+    }
+  }
+}
+
 // one 256-feature pass of the q | k | v projection, written straight from the transposed accumulators
 template <int NT, bool NEXT, bool IL8>
 DEV void qkv_pass_s(const unsigned char* Xs, const float* bq, const bf16x8* wc, bf16x8 (&wq)[PD][NT], unsigned short* qkv,
@@ -1438,7 +1589,7 @@ DEV ParamSrc param_src(const ChainArgs& a, int j, int q1, const float* dummy, in
   return ParamSrc{ok ? base + off * 4 : dummy, ok ? CS_LN + j * 4 : CS_PARAMS + lane * 4};
 }
 
-template <int NW, bool HAS_A, bool HAS_B, bool HAS_C, bool TRAIN, bool IL8>
+template <int NW, bool HAS_A, bool HAS_B, bool HAS_C, bool TRAIN, bool IL8, bool PIPE = false>
 __global__ __launch_bounds__(NW * 64) void chain_s_kernel(ChainArgs a) {
   static_assert(NW * 64 == 8 * BM, "row phases assume 8 lanes per panel row");
   static_assert(HAS_A || HAS_B, "at least one FeedForward");
@@ -1503,8 +1654,12 @@ __global__ __launch_bounds__(NW * 64) void chain_s_kernel(ChainArgs a) {
   if constexpr (HAS_A) {
     const StageTrain ta{TRAIN ? drop_make(a.da_h.seed, a.da_h.stream, a.da_h.p) : Drop{0u, 0u, 1.f},
                         TRAIN ? drop_make(a.da_o.seed, a.da_o.stream, a.da_o.p) : Drop{0u, 0u, 1.f}, m0, a.M, a.pre_ln_out};
-    ffn_stage_s<NW, true, TRAIN>(v, Xs, Hraw, a.fa.ln_g != nullptr ? lnA : nullptr, finA, b1A, b2A, a.fa, FF, a.alpha, tid, rotA, wq,
-                                 HAS_B ? wB0 : wA0, g_stamps_dev, 1, ta);
+    if constexpr (PIPE)
+      ffn_stage_p<NW, true, TRAIN>(v, Xs, Hraw, a.fa.ln_g != nullptr ? lnA : nullptr, finA, b1A, b2A, a.fa, FF, a.alpha, tid, rotA, wq,
+                                   HAS_B ? wB0 : wA0, g_stamps_dev, 1, ta);
+    else
+      ffn_stage_s<NW, true, TRAIN>(v, Xs, Hraw, a.fa.ln_g != nullptr ? lnA : nullptr, finA, b1A, b2A, a.fa, FF, a.alpha, tid, rotA, wq,
+                                   HAS_B ? wB0 : wA0, g_stamps_dev, 1, ta);
     if constexpr (TRAIN) {  // the next block's input: the backward of its first FeedForward needs it
 #pragma unroll
       for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(a.ln_out + (size_t)row * DM + (i * 8 + part) * 4) = v[i];
@@ -1514,8 +1669,12 @@ __global__ __launch_bounds__(NW * 64) void chain_s_kernel(ChainArgs a) {
   if constexpr (HAS_B) {
     const StageTrain tb{TRAIN ? drop_make(a.db_h.seed, a.db_h.stream, a.db_h.p) : Drop{0u, 0u, 1.f},
                         TRAIN ? drop_make(a.db_o.seed, a.db_o.stream, a.db_o.p) : Drop{0u, 0u, 1.f}, m0, a.M, nullptr};
-    ffn_stage_s<NW, false, TRAIN>(v, Xs, Hraw, a.fb.ln_g != nullptr ? lnB : nullptr, nullptr, b1B, b2B, a.fb, FF, a.alpha, tid, rotB, wq,
-                                  HAS_C ? wC0 : wB0, g_stamps_dev, 5, tb);
+    if constexpr (PIPE)
+      ffn_stage_p<NW, false, TRAIN>(v, Xs, Hraw, a.fb.ln_g != nullptr ? lnB : nullptr, nullptr, b1B, b2B, a.fb, FF, a.alpha, tid, rotB, wq,
+                                    HAS_C ? wC0 : wB0, g_stamps_dev, 5, tb);
+    else
+      ffn_stage_s<NW, false, TRAIN>(v, Xs, Hraw, a.fb.ln_g != nullptr ? lnB : nullptr, nullptr, b1B, b2B, a.fb, FF, a.alpha, tid, rotB, wq,
+                                    HAS_C ? wC0 : wB0, g_stamps_dev, 5, tb);
   }
   P_T(8)
 #pragma unroll
@@ -2411,7 +2570,12 @@ static int encoder_chain_impl(const float* x, float* x_out, const float* conv_g,
   }
   if (st_ok && (A || Bs) && (Bs || !Cq)) {
     const bool il8 = a.qkv_il8 != 0;
-    if (A && Bs && Cq && il8) hipLaunchKernelGGL((chain_s_kernel<NWAVES, true, true, true, false, true>), grid, block, 0, s, a);
+    static const bool use_pipe = [] { const char* e = getenv("CSSHIP_CHAIN_PIPE"); return e == nullptr || atoi(e) != 0; }();
+    const bool pipe = use_pipe && d_ffn >= 2 * DM;
+    if (A && Bs && Cq && il8 && pipe) hipLaunchKernelGGL((chain_s_kernel<NWAVES, true, true, true, false, true, true>), grid, block, 0, s, a);
+    else if (!A && Bs && Cq && il8 && pipe) hipLaunchKernelGGL((chain_s_kernel<NWAVES, false, true, true, false, true, true>), grid, block, 0, s, a);
+    else if (A && !Bs && !Cq && pipe) hipLaunchKernelGGL((chain_s_kernel<NWAVES, true, false, false, false, false, true>), grid, block, 0, s, a);
+    else if (A && Bs && Cq && il8) hipLaunchKernelGGL((chain_s_kernel<NWAVES, true, true, true, false, true>), grid, block, 0, s, a);
     else if (A && Bs && Cq) hipLaunchKernelGGL((chain_s_kernel<NWAVES, true, true, true, false, false>), grid, block, 0, s, a);
     else if (!A && Bs && Cq && il8) hipLaunchKernelGGL((chain_s_kernel<NWAVES, false, true, true, false, true>), grid, block, 0, s, a);
     else if (!A && Bs && Cq) hipLaunchKernelGGL((chain_s_kernel<NWAVES, false, true, true, false, false>), grid, block, 0, s, a);
