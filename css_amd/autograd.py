@@ -26,6 +26,27 @@ _NO_CONV_NEXT = bool(os.environ.get("CSSHIP_NO_CONV_NEXT"))  # A/B timing: dropo
 _NO_DROP_EPI = bool(os.environ.get("CSSHIP_NO_DROP_EPI"))   # A/B timing: output-projection dropout as its own pass
 
 
+_NO_DIRECT = bool(os.environ.get("CSS_AMD_NO_DIRECT_GRAD"))   # A/B timing: every gradient through a temporary + the multi-tensor add
+
+
+def _direct_grad(p):
+    """The preset ``.grad`` view of ``p`` if a gradient may be STORED into it (FusedAdam owns it and it has not been written
+    since the optimiser's last zero_grad(): 0 + g == g), else None.  Claims the view: a second contribution accumulates."""
+    g = p.grad
+    own = getattr(g, "_csship_owner", None) if g is not None else None
+    if _NO_DIRECT or own is None or not p.requires_grad or id(p) in own._dirty or g.dtype != torch.float32 or not g.is_contiguous():
+        return None
+    own._dirty.add(id(p))
+    return g
+
+
+def _mark_written(ps):
+    for p in ps:
+        own = getattr(p.grad, "_csship_owner", None)
+        if own is not None:
+            own._dirty.add(id(p))
+
+
 def _deliver(model, G):
     """Hand the parameter gradients G to autograd.  Parameters whose ``.grad`` already exists (FusedAdam presets them
     as views of its flat gradient buffer) are accumulated in place by ONE multi-tensor add and get None back, instead
@@ -36,6 +57,7 @@ def _deliver(model, G):
     if direct:
         with torch.no_grad():
             torch._foreach_add_([p.grad for p in direct], [G[p].contiguous() for p in direct])
+        _mark_written(direct)
         for p in direct:
             del G[p]
     return tuple(G.get(p) if p.requires_grad else None for p in params)
@@ -53,9 +75,32 @@ def _deliver_group(model, module, G):
     if ps:
         with torch.no_grad():
             torch._foreach_add_([p.grad for p in ps], [G[p].contiguous() for p in ps])
+        _mark_written(ps)
         for p in ps:
             del G[p]
     hook(module)
+
+
+def _skew_buffer(model, shape, device):
+    """The skewed-dS buffer [B, T, H, W] of the attention backward: the kernels write only inside the band (the same
+    positions every layer, every step), everything else must be zero - so it is zeroed ONCE per shape and kept on the
+    model (it was an 82 MB fill per training step).  A step that is being captured must NOT take it from the graph's
+    pool: the pool hands one block to several tensors of a replay in turn, and whoever held the block earlier in the
+    step fills it with its own data on every replay.  It takes the buffer an eager step of the same shape left on the
+    model (GraphedTrainStep's warm-up steps do) and pins it through ``model._skew_captured``, the list the capturer
+    installs and keeps; without either, a captured step fills a fresh buffer every replay, as before."""
+    key = (tuple(shape), str(device))
+    ent = getattr(model, "_skew_cache", None)
+    if torch.cuda.is_current_stream_capturing():
+        keep = getattr(model, "_skew_captured", None)
+        if keep is None or ent is None or ent[0] != key:
+            return torch.zeros(shape, dtype=BF, device=device)
+        keep.append(ent[1])
+        return ent[1]
+    if ent is None or ent[0] != key:
+        ent = (key, torch.zeros(shape, dtype=BF, device=device))
+        model._skew_cache = ent
+    return ent[1]
 
 
 class PitMse(torch.autograd.Function):
@@ -73,7 +118,9 @@ class PitMse(torch.autograd.Function):
     def backward(ctx, grad_loss, _grad_perm):
         masks, f_orig, perm, *targets = ctx.saved_tensors
         g = ops.pit_mse_bwd(masks, f_orig, targets, perm, ctx.n_masks, 1.0)
-        return (g * grad_loss,) + (None,) * (2 + len(targets))
+        # in place: the product keeps the padded row stride of the masks, so the encoder's backward takes it as it is
+        # (`g * grad_loss` came back dense, 771 floats per row, and was copied into an aligned buffer: 2 x 39 MB)
+        return (g.mul_(grad_loss),) + (None,) * (2 + len(targets))
 
 
 def _conformer_pack_plan(model, wide, device):
@@ -310,6 +357,8 @@ class ConformerTrain(torch.autograd.Function):
         G = {}  # parameter -> gradient
 
         def put(p, g):
+            if g is p.grad:   # stored in place by its producer (_direct_grad)
+                return
             g = g.reshape(p.shape)
             if p in G:
                 red.flush()   # the sum reads both gradients
@@ -333,14 +382,15 @@ class ConformerTrain(torch.autograd.Function):
             buf = torch.empty_strided(masks.shape, masks.stride(), dtype=torch.float32, device=masks.device)
             buf.copy_(dm)
             dm = buf
-        dx, dw, db = bw.head_bwd(dm, masks, S["x_enc"], S["wh_bf"])
+        dx, dw, db = bw.head_bwd(dm, masks, S["x_enc"], S["wh_bf"], dw_out=_direct_grad(model.linear.weight),
+                                 db_out=_direct_grad(model.linear.bias))
         put(model.linear.weight, dw), put(model.linear.bias, db)
         red.flush()
         _deliver_group(model, model.linear, G)
         window = bw.relpos_window(S["pe_bf"], T, 1000)
         dwin = None
         # skewed dS buffer shared by all layers: the band positions are the same every layer, the rest stays zero
-        skew_buf = torch.zeros((B, T, H, window[0].shape[0]), dtype=BF, device=masks.device)
+        skew_buf = _skew_buffer(model, (B, T, H, window[0].shape[0]), masks.device)
         ds = S["drop"]
         nlay = len(enc.encoders)
         for li, lay, L in zip(range(nlay - 1, -1, -1), reversed(list(enc.encoders)), reversed(S["layers"])):
@@ -355,9 +405,11 @@ class ConformerTrain(torch.autograd.Function):
                                         m.net[0].bias.detach(), w1_bf, w2_bf, 0.5, drop_hidden=dh, drop_out=do)
                 else:
                     xin, w1p, w2tp, w1tp = L[tag]
+                    # the four big gradients of the FeedForward go straight into their (zeroed) .grad views
+                    outs = tuple(_direct_grad(q) for q in (m.net[0].weight, m.net[0].bias, m.net[3].weight, m.net[3].bias))
                     dxo, g = bw.ffn_bwd_fused(xin, dy, m.layer_norm.weight.detach(), m.layer_norm.bias.detach(),
                                               m.net[0].bias.detach(), w1p, w2tp, w1tp, enc.d_ffn, 0.5,
-                                              drop_hidden=dh, drop_out=do)
+                                              drop_hidden=dh, drop_out=do, outs=outs)
                 for p, gv in zip((m.layer_norm.weight, m.layer_norm.bias, m.net[0].weight, m.net[0].bias,
                                   m.net[3].weight, m.net[3].bias), g):
                     put(p, gv)
@@ -385,7 +437,8 @@ class ConformerTrain(torch.autograd.Function):
             dx, g = bw.mha_bwd(x1, dx, qkv.view(B, T, 3 * D), ao, a.layer_norm.weight.detach(),
                                a.layer_norm.bias.detach(), wqkv_bf, wo_bf, S["pe_bf"], H, scale, window=window,
                                probs=(S["pe_pack"], lse), skew_buf=skew_buf, drop_p=ds.cfg(f"{li}.attn.p"),
-                               drop_out=ds.cfg(f"{li}.attn.out"), dwin_acc=dwin, dyb_bf16=dyb)
+                               drop_out=ds.cfg(f"{li}.attn.out"), dwin_acc=dwin, dyb_bf16=dyb,
+                               dwo_out=_direct_grad(a.linear_out.weight), dbo_out=_direct_grad(a.linear_out.bias))
             dg, dbeta, dwqkv, dbqkv, dwo, dbo, dwin = g   # dwin: the window gradient summed over the blocks so far
             put(a.layer_norm.weight, dg), put(a.layer_norm.bias, dbeta)
             for i, lin in enumerate((a.linear_q, a.linear_k, a.linear_v)):

@@ -14,17 +14,18 @@ from . import ops, ops_bwd as ob
 BF = torch.bfloat16
 
 
-def linear_bwd(dy, x, w_bf, *, need_dx=True, dx_bf16=False, alpha=1.0):
-    """y = x @ w^T + b.  dy: [M, N] f32/bf16, x: [M, K] f32/bf16, w_bf: bf16 [N, K] -> (dx, dw, db)."""
-    dw, db = ob.linear_wgrad(dy, x, alpha)
+def linear_bwd(dy, x, w_bf, *, need_dx=True, dx_bf16=False, alpha=1.0, dw_out=None, db_out=None):
+    """y = x @ w^T + b.  dy: [M, N] f32/bf16, x: [M, K] f32/bf16, w_bf: bf16 [N, K] -> (dx, dw, db).
+    dw_out / db_out: f32 destinations (e.g. the parameters' zeroed .grad views) instead of fresh tensors."""
+    dw, db = ob.linear_wgrad(dy, x, alpha, dw_out=dw_out, db_out=db_out)
     dx = ob.bgemm(dy, w_bf, b_kmajor=True, alpha=alpha, out_bf16=dx_bf16) if need_dx else None
     return dx, dw, db
 
 
-def head_bwd(dmasks, masks, x, w_bf):
+def head_bwd(dmasks, masks, x, w_bf, dw_out=None, db_out=None):
     """masks = relu(x @ w^T + b) (conformer.py:98-99).  dmasks/masks: f32 [M, n_out] (row stride free)."""
     dz = ob.relu_bwd(dmasks, masks)
-    return linear_bwd(dz, x, w_bf)
+    return linear_bwd(dz, x, w_bf, dw_out=dw_out, db_out=db_out)
 
 
 def ffn_bwd(x, dy, ln_g, ln_b, b1, w1_bf, w2_bf, alpha=0.5, drop_hidden=None, drop_out=None):
@@ -52,16 +53,18 @@ def ffn_bwd(x, dy, ln_g, ln_b, b1, w1_bf, w2_bf, alpha=0.5, drop_hidden=None, dr
     return dx, (dg, dbeta, dw1, db1, dw2, db2)
 
 
-def ffn_bwd_fused(x, dy, ln_g, ln_b, b1, w1p, w2tp, w1tp, d_ffn, alpha=0.5, drop_hidden=None, drop_out=None):
+def ffn_bwd_fused(x, dy, ln_g, ln_b, b1, w1p, w2tp, w1tp, d_ffn, alpha=0.5, drop_hidden=None, drop_out=None,
+                  outs=(None, None, None, None)):
     """ffn_bwd with the activation side in ONE row-panel kernel (d_model = 256): LN + hidden recompute, masked dh,
     da and the LayerNorm backward never leave the CU; the four weight / bias gradients are GEMMs / column sums over
     the B*T rows.  w1p / w2tp / w1tp: fragment-packed W1, W2^T, W1^T."""
     dx, dg, dbeta, a, h, dh, dyd = ob.ffn_bwd(x, dy, ln_g, ln_b, w1p, b1, w2tp, w1tp, d_ffn, alpha, drop_hidden, drop_out)
+    dw1_o, db1_o, dw2_o, db2_o = outs   # optional f32 destinations (dW1, db1, dW2, db2), e.g. zeroed .grad views
     if dyd is not None:   # output dropout: the second Linear saw h (dropped) and its gradient is alpha * dy o mask / (1 - p)
-        dw2, db2 = ob.linear_wgrad(dyd, h)
+        dw2, db2 = ob.linear_wgrad(dyd, h, dw_out=dw2_o, db_out=db2_o)
     else:
-        dw2, db2 = ob.linear_wgrad(dy, h, alpha)
-    dw1, db1 = ob.linear_wgrad(dh, a)
+        dw2, db2 = ob.linear_wgrad(dy, h, alpha, dw_out=dw2_o, db_out=db2_o)
+    dw1, db1 = ob.linear_wgrad(dh, a, dw_out=dw1_o, db_out=db1_o)
     return dx, (dg, dbeta, dw1, db1, dw2, db2)
 
 
@@ -154,7 +157,8 @@ def _mha_core_products(qkv, g, q, k, do, p_v, ds, dsk, dq1, win, idx, window, dw
 
 
 def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_scale=0.125, window=None, probs=None,
-            skew_buf=None, fused_softmax_bwd=True, drop_p=None, drop_out=None, dwin_acc=None, dyb_bf16=None):
+            skew_buf=None, fused_softmax_bwd=True, drop_p=None, drop_out=None, dwin_acc=None, dyb_bf16=None,
+            dwo_out=None, dbo_out=None):
     """out = x + attention(LN(x)) @ wo^T + bo  (conformer.py:213-254,356).
 
     wqkv_bf holds the q rows already multiplied by q_scale (as the forward uses them); the returned dwqkv / dbqkv are
@@ -168,7 +172,7 @@ def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_s
         dyb = dyb_bf16
     else:
         dyb = dy if drop_out is None else ops.dropout_apply(dy, drop_out, out=torch.empty_like(dy))
-    dao, dwo, dbo = linear_bwd(dyb, ao, wo_bf, dx_bf16=True)
+    dao, dwo, dbo = linear_bwd(dyb, ao, wo_bf, dx_bf16=True, dw_out=dwo_out, db_out=dbo_out)
     B = qkv.shape[0]
     if drop_p is not None and (probs is None or not fused_softmax_bwd):
         raise NotImplementedError("css_amd: dropout of the attention probabilities needs the attention-shaped backward")

@@ -2542,7 +2542,13 @@ static int encoder_chain_impl(const float* x, float* x_out, const float* conv_g,
     a.pre_ln_out = train->pre_ln_out; a.ln_out = train->ln_out;
     if ((A && !ffn_a->ln_g) || (Bs && !ffn_b->ln_g)) return CSSHIP_EUNSUPPORTED;  // folded LayerNorms belong to the inference packing
     if (st_ok && Bs && Cq && (!A || (a.pre_ln_out != nullptr && a.ln_out != nullptr))) {
-      if (A) hipLaunchKernelGGL((chain_s_kernel<NWAVES, true, true, true, true, false>), grid, block, 0, s, a);
+      // the pipelined stages are OFF for the training form: with the dropout hashes riding in the W2 passes the kernel
+      // needs 264 registers (8 spilled) and measured 10.92 against 10.87 ms per training step; CSSHIP_CHAIN_PIPE_TRAIN=1 runs it
+      static const bool use_pipe_t = [] { const char* e = getenv("CSSHIP_CHAIN_PIPE_TRAIN"); return e != nullptr && atoi(e) != 0; }();
+      const bool pipe_t = use_pipe_t && d_ffn >= 2 * DM;
+      if (A && pipe_t) hipLaunchKernelGGL((chain_s_kernel<NWAVES, true, true, true, true, false, true>), grid, block, 0, s, a);
+      else if (pipe_t) hipLaunchKernelGGL((chain_s_kernel<NWAVES, false, true, true, true, false, true>), grid, block, 0, s, a);
+      else if (A) hipLaunchKernelGGL((chain_s_kernel<NWAVES, true, true, true, true, false>), grid, block, 0, s, a);
       else hipLaunchKernelGGL((chain_s_kernel<NWAVES, false, true, true, true, false>), grid, block, 0, s, a);
       CSSHIP_CHECK_LAUNCH();
       return CSSHIP_OK;

@@ -48,10 +48,16 @@ class FusedAdam(torch.optim.Optimizer):
                 seg.copy_(p.data)
                 p.data = seg
                 p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+                p.grad._csship_owner = self   # lets the explicit backward write a gradient IN PLACE while it is known zero
+        # ids of the parameters whose .grad view has been written since the last zero_grad(): the explicit backward
+        # (css_amd/autograd.py) stores a weight gradient straight into a view that is still zero instead of producing a
+        # temporary and adding it (0 + g == g), and accumulates as before into one that is not
+        self._dirty = set()
 
     def zero_grad(self, set_to_none=False):
         """Gradients stay views of the flat buffer (set_to_none is ignored): one fill."""
         self.flat_grad.zero_()
+        self._dirty.clear()
 
     @torch.no_grad()
     def step(self, closure=None, max_norm=None):

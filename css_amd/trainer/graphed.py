@@ -64,6 +64,10 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         restore()
         self.graph = torch.cuda.CUDAGraph()
+        # buffers outside the graph's pool that the captured backward shares with the eager steps (autograd._skew_buffer:
+        # zero outside what the kernels write, zeroed once by the warm-up steps above): alive as long as this object
+        self._zero_once = []
+        model._skew_captured = self._zero_once
         try:
             if not self.distributed:
                 # thread_local: other threads of this process may touch the runtime during the capture
@@ -77,6 +81,8 @@ class GraphedTrainStep:
         except Exception:   # the capture does not execute anything; put back what the warm-up touched
             restore()
             raise
+        finally:
+            model._skew_captured = None
 
     def _capture_distributed(self, blocks_per_bucket):
         """zero_grad + forward + PIT + backward as sub-graphs cut at the bucket boundaries of parallel.bucket_plan.  The
@@ -132,6 +138,7 @@ class GraphedTrainStep:
         self.graph_opt = None
         self.graphs = []
         self.static = {}
+        self._zero_once = []
 
     def __call__(self, batch):
         """One optimiser step on ``batch``; returns (loss, grad_norm) as 0-dim device tensors of THIS step (they are
