@@ -114,6 +114,8 @@ SIGNATURES = {
     "csship_mha_relpos": (_i32, [_p, _p, _i32, _i32, _p, _i32, _i32, _i32, _p]),
     "csship_mha_relpos_ex": (_i32, [_p, _p, _i32, _i32, _p, _i32, _i32, _i32, _i32, _p]),
     "csship_outproj_conv": (_i32, [_p, _p, _p, _p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _p]),
+    "csship_outproj_conv_train": (_i32, [_p, _p, _p, _p, _p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32,
+                                         _dc, _dc, _p, _p]),
     "csship_ffn_bwd_workspace": (_sz, [_i32]),
     "csship_ffn_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _p, _sz, _p]),
     "csship_mha_relpos_train": (_i32, [_p, _p, _i32, _i32, _p, _p, _i32, _i32, _i32, _p]),

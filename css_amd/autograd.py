@@ -24,6 +24,7 @@ _NO_TRAIN_CHAIN = bool(os.environ.get("CSSHIP_NO_TRAIN_CHAIN"))   # A/B timing: 
 _NO_FFN_LN = bool(os.environ.get("CSSHIP_NO_FFN_LN"))       # A/B timing: the block's final LayerNorm as its own launch
 _NO_CONV_NEXT = bool(os.environ.get("CSSHIP_NO_CONV_NEXT"))  # A/B timing: dropout(dx) for the output projection's backward as its own pass
 _NO_DROP_EPI = bool(os.environ.get("CSSHIP_NO_DROP_EPI"))   # A/B timing: output-projection dropout as its own pass
+_NO_OC_TRAIN = bool(os.environ.get("CSSHIP_NO_OC_TRAIN"))   # A/B timing: output projection and conv module's first kernel as two launches
 
 
 _NO_DIRECT = bool(os.environ.get("CSS_AMD_NO_DIRECT_GRAD"))   # A/B timing: every gradient through a temporary + the multi-tensor add
@@ -282,7 +283,11 @@ class ConformerTrain(torch.autograd.Function):
                                            ln=(a.layer_norm.weight.detach(), a.layer_norm.bias.detach()), out_bf16=True)
             ao, lse = ops.mha_relpos_train(qkv.view(B, T, 3 * D), pe_pack, H, drop=ds.cfg(f"{li}.attn.p"))
             ao = ao.view(M, D)
-            if ds.active and not wide and not _NO_DROP_EPI:   # x2 = x1 + D(ao wo^T + bo): the mask in the projection's epilogue
+            c = lay.conv
+            fused_oc = (batch_bn and not wide and not sync_bn and not _NO_OC_TRAIN and K == 33 and not getattr(c, "causal", False))
+            if fused_oc:
+                pass   # output projection + dropout + residual inside the conv module's first kernel (below)
+            elif ds.active and not wide and not _NO_DROP_EPI:   # x2 = x1 + D(ao wo^T + bo): the mask in the projection's epilogue
                 x2 = ops.panel_linear(ao, wo_p, a.linear_out.bias.detach(), D, residual=x1, drop=ds.cfg(f"{li}.attn.out"))
             elif ds.active:   # the projection without its fused residual, then one add pass
                 y2 = ops.gemm(ao, wo_bf, a.linear_out.bias.detach()) if wide else \
@@ -293,7 +298,6 @@ class ConformerTrain(torch.autograd.Function):
             else:
                 x2 = ops.panel_linear(ao, wo_p, a.linear_out.bias.detach(), D, residual=x1)
             L["mha"] = (x1, qkv, ao, wqkv_bf, wo_bf, scale, lse)
-            c = lay.conv
             W = {"ln_g": c.layer_norm.weight.detach(), "ln_b": c.layer_norm.bias.detach(),
                  "pw1_w": c.pw_conv_1.weight.detach().view(2), "pw1_b": c.pw_conv_1.bias.detach(),
                  "dw_w": dww_all[li], "dw_b": c.dw_conv_1d.bias.detach(),
@@ -301,9 +305,13 @@ class ConformerTrain(torch.autograd.Function):
                  "bn_mean": c.BN.running_mean, "bn_var": c.BN.running_var,
                  "pw2_w": c.pw_conv_2.weight.detach().view(1), "pw2_b": c.pw_conv_2.bias.detach(),
                  "causal": getattr(c, "causal", False)}
-            x3, fws = ops.convmod(x2.view(B, T, D), W, K, batch_stats=batch_bn, keep_activations=not batch_bn,
-                                  return_workspace=True, drop=ds.cfg(f"{li}.conv.out"), sync=sync_bn)
-            x3 = x3.view(M, D)
+            if fused_oc:   # x2 = x1 + D(ao wo^T + bo) and the conv module with batch statistics: three launches instead of five
+                x2, x3, fws = ops.outproj_conv_train(ao, wo_p, a.linear_out.bias.detach(), x1, W, B, T, K,
+                                                     drop_proj=ds.cfg(f"{li}.attn.out"), drop_conv=ds.cfg(f"{li}.conv.out"))
+            else:
+                x3, fws = ops.convmod(x2.view(B, T, D), W, K, batch_stats=batch_bn, keep_activations=not batch_bn,
+                                      return_workspace=True, drop=ds.cfg(f"{li}.conv.out"), sync=sync_bn)
+                x3 = x3.view(M, D)
             L["conv"] = (x2, W, fws)
             if batch_bn:
                 stats = fws.view(torch.float32)[-4 * D:]

@@ -100,6 +100,12 @@ static inline bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>
 int launch_slab_reduce(const float* slabs, int S, int64_t n, int N, int64_t ldc, float alpha, const float* bias,
                        const float* add, int64_t ldadd, float* out, hipStream_t s, bool deferrable = false);
 
+// csship_outproj_conv_train (convmod.hip) = this launch (panel.hip: output projection + dropout + residual, LayerNorm, GLU
+// and the depthwise convolution in one kernel, batch-statistics partials) + the BatchNorm reduce / apply kernels
+int launch_outproj_conv_train(const uint16_t* attn_out, const uint16_t* wo_packed, const float* bo, const float* x,
+                              float* x2_out, const csship_conv_weights& conv, int B, int T, csship_dropout_cfg drop,
+                              float* zbuf, float* partial, int* nblk_out, hipStream_t s);
+
 // Optional in-kernel phase stamps (diagnostic only; nullptr in normal operation): thread 0 of every
 // workgroup stores s_memrealtime (100 MHz) at up to 8 phase boundaries.  Set by csship_debug_stamps().
 extern unsigned long long* g_csship_stamps;

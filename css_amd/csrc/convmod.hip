@@ -691,6 +691,43 @@ extern "C" int csship_convmod_drop(const float* x, float* y, const csship_conv_w
   return run<512, TT512>(a, bn_mode, workspace, as_stream(stream), dc);
 }
 
+extern "C" int csship_outproj_conv_train(const uint16_t* attn_out, const uint16_t* wo_packed, const float* bo, const float* x,
+                                         float* x2_out, float* y, const csship_conv_weights* w, int32_t B, int32_t T,
+                                         int32_t D, int32_t kernel_size, const csship_dropout_cfg* drop_proj,
+                                         const csship_dropout_cfg* drop_conv, void* workspace, csship_stream_t stream) {
+  if (!attn_out || !wo_packed || !bo || !x || !x2_out || !y || !w || !workspace) return CSSHIP_ENULL;
+  if (w->causal) return CSSHIP_EUNSUPPORTED;
+  if (!w->ln_g || !w->ln_b || !w->pw1_w || !w->pw1_b || !w->dw_w || !w->dw_b || !w->bn_g || !w->bn_b || !w->pw2_w || !w->pw2_b)
+    return CSSHIP_ENULL;
+  if (B <= 0 || T <= 0 || B > 65535 || (int64_t)B * T * D > 0xffffffffLL) return CSSHIP_EBADSHAPE;
+  if (kernel_size != 33 || D != 256) return CSSHIP_EUNSUPPORTED;
+  if (x == x2_out || x2_out == y) return CSSHIP_EBADSHAPE;
+  if (!aligned16(attn_out) || !aligned16(wo_packed) || !aligned16(bo) || !aligned16(x) || !aligned16(x2_out) || !aligned16(y) ||
+      !aligned16(w->ln_g) || !aligned16(w->ln_b) || !aligned16(workspace))
+    return CSSHIP_EALIGN;
+  const csship_dropout_cfg none{nullptr, 0u, 0.f};
+  auto cfg = [&](const csship_dropout_cfg* c) { return (c && c->seed && c->p > 0.f) ? *c : none; };
+  hipStream_t s = as_stream(stream);
+  // the workspace csship_convmod(bn_mode 1) would leave (z | partials | f64 sums | scale, shift, mean, var), so that
+  // csship_convmod_bwd* reads it unchanged: the statistics sit behind the partial block of the 32-frame tiling
+  const size_t n = (size_t)B * T * D;
+  const size_t nblk32 = (size_t)((T + TT256 - 1) / TT256) * B * 2;
+  float* zbuf = reinterpret_cast<float*>(workspace);
+  float* partial = zbuf + n;
+  float* scale_shift = partial + nblk32 * 2 * D + 4 * D;
+  int nblk = 0;
+  const int rc = launch_outproj_conv_train(attn_out, wo_packed, bo, x, x2_out, *w, B, T, cfg(drop_proj), zbuf, partial, &nblk, s);
+  if (rc) return rc;
+  if ((size_t)nblk > nblk32) return CSSHIP_EWORKSPACE;   // (50-frame tiles: never more blocks than the 32-frame tiling)
+  hipLaunchKernelGGL(bn_reduce8_kernel, dim3(D / 8), dim3(256), 0, s, partial, nblk, D, (double)B * (double)T, w->bn_g, w->bn_b,
+                     scale_shift);
+  CSSHIP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, x2_out, zbuf, scale_shift, w->pw2_w,
+                     w->pw2_b, y, n / 4, D, cfg(drop_conv));
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
 extern "C" int csship_convmod_stats(const float* x, const csship_conv_weights* w, int32_t B, int32_t T, int32_t D,
                                     int32_t kernel_size, void* workspace, csship_stream_t stream) {
   if (!x || !w || !workspace) return CSSHIP_ENULL;

@@ -2086,6 +2086,9 @@ __global__ __launch_bounds__(NW * 64) void embed_kernel(EmbedArgs a) {
 // 33-tap depthwise convolution, BatchNorm, ReLU, affine and add onto x2 in `out`.  8 tiles x 32 chunks = 256
 // workgroups at T = 400: exactly one round of the chip, one launch per block instead of two, x2 never makes a round
 // trip through a separate buffer.  `out` must not alias x1 (neighbouring workgroups read each other's halo rows).
+#ifndef OC_RES_AT
+#define OC_RES_AT 4   // k-step behind which the residual rows are requested (KS - PD: behind the last weight fragment); -1: behind the loop
+#endif
 constexpr int OC_TT = 50, OC_HALO = 16, OC_USED = OC_TT + 2 * OC_HALO, OC_RT = 6, OC_ROWS = 16 * OC_RT, OC_KS = 33;
 static_assert(OC_USED <= OC_ROWS, "tile + halo must fit the row tiles");
 
@@ -2098,9 +2101,16 @@ struct OcArgs {
   csship_conv_weights cw;
   int B, T;
   unsigned long long* stamps;
+  // TRAIN (csship_outproj_conv_train): the reference's dropout of the projection (conformer.py:254; element index
+  // row * 256 + column as csship_panel_linear_drop), `out` receives x2 itself, the depthwise convolution's output goes
+  // to zbuf [B*T, 256] and its per-channel sum / sum of squares per (workgroup, half tile) to partial [nblk][2][256]
+  // (nblk = 2 * gridDim.x * B): the batch-statistics BatchNorm is finished by bn_reduce8 + bn_apply (convmod.hip)
+  csship_dropout_cfg drop;
+  float* zbuf;
+  float* partial;
 };
 
-template <int NW>
+template <int NW, bool TRAIN = false>
 __global__ __launch_bounds__(NW * 64) void outproj_conv_kernel(OcArgs a) {
   static_assert(NW == 8, "row phases: 8 lanes per row, 64 rows per pass; stencil: 2 threads per channel");
   constexpr int NT = 16 / NW, NSTAGE = OC_ROWS * 32 / (NW * 64);
@@ -2176,7 +2186,7 @@ __global__ __launch_bounds__(NW * 64) void outproj_conv_kernel(OcArgs a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) wq[ks % PD][t] = ws_[(size_t)(t * KS + ks + PD) * 64];
       }
-      if (ks + PD == KS) request_residual();   // behind the last weight fragment: a wave's loads return in order
+      if (OC_RES_AT >= 0 && ks == OC_RES_AT) request_residual();   // behind the last weight fragment: a wave's loads return in order
       if (ks + 1 < KS) {
 #pragma unroll
         for (int rt = 0; rt < OC_RT; ++rt)
@@ -2191,6 +2201,7 @@ __global__ __launch_bounds__(NW * 64) void outproj_conv_kernel(OcArgs a) {
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  if (OC_RES_AT < 0) request_residual();
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int col = (wave * NT + t) * 16 + 4 * g;
@@ -2215,6 +2226,7 @@ __global__ __launch_bounds__(NW * 64) void outproj_conv_kernel(OcArgs a) {
   {
     const float w0 = a.cw.pw1_w[0], w1 = a.cw.pw1_w[1], b0 = a.cw.pw1_b[0], b1 = a.cw.pw1_b[1];
     const int part = tid & 7;
+    const Drop dproj = TRAIN ? drop_make(a.drop.seed, a.drop.stream, a.drop.p) : Drop{0u, 0u, 1.f};
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       const int r = pass * 64 + (tid >> 3);
@@ -2232,7 +2244,8 @@ __global__ __launch_bounds__(NW * 64) void outproj_conv_kernel(OcArgs a) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const float4 xv = xres[pass][i];
-        const float4 pv = *reinterpret_cast<const float4*>(yrow + (i * 8 + part) * 4);
+        float4 pv = *reinterpret_cast<const float4*>(yrow + (i * 8 + part) * 4);
+        if constexpr (TRAIN) pv = drop_apply4(dproj, (unsigned)((rowb + t) * DM + (i * 8 + part) * 4), pv);  // halo rows: the same mask as their owner
         v[i] = make_float4(xv.x + pv.x, xv.y + pv.y, xv.z + pv.z, xv.w + pv.w);
         if (own) *reinterpret_cast<float4*>(X2 + (r - OC_HALO) * DM + (i * 8 + part) * 4) = v[i];
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
@@ -2272,9 +2285,13 @@ __global__ __launch_bounds__(NW * 64) void outproj_conv_kernel(OcArgs a) {
 #pragma unroll
     for (int m = 0; m <= OC_KS; ++m) wp[m] = f2{m < OC_KS ? wk[m] : 0.f, m > 0 ? wk[m - 1] : 0.f};
     const float cb = a.cw.dw_b[c];
-    const float scale = a.cw.bn_g[c] * rsqrtf(a.cw.bn_var[c] + 1e-5f);
-    const float shift = a.cw.bn_b[c] - a.cw.bn_mean[c] * scale;
-    const float pw2w = a.cw.pw2_w[0], pw2b = a.cw.pw2_b[0];
+    float scale = 0.f, shift = 0.f, pw2w = 0.f, pw2b = 0.f;
+    if constexpr (!TRAIN) {
+      scale = a.cw.bn_g[c] * rsqrtf(a.cw.bn_var[c] + 1e-5f);
+      shift = a.cw.bn_b[c] - a.cw.bn_mean[c] * scale;
+      pw2w = a.cw.pw2_w[0];
+      pw2b = a.cw.pw2_b[0];
+    }
     float gv[NG];
 #pragma unroll
     for (int u = 0; u < NG; ++u) gv[u] = Ys[(half * TH + u) * YS + c];
@@ -2288,11 +2305,30 @@ __global__ __launch_bounds__(NW * 64) void outproj_conv_kernel(OcArgs a) {
         const int m = u - 2 * p_;
         if (m >= 0 && m <= OC_KS) o2[p_] = __builtin_elementwise_fma(wp[m], f2{gv[u], gv[u]}, o2[p_]);
       }
+    if constexpr (TRAIN) {
+      // batch statistics: the pre-BatchNorm activations leave as they are (lanes = consecutive channels), with this
+      // thread's share of the channel's sum and sum of squares; x2 stays untouched
+      float lsum = 0.f, lsq = 0.f;
+#pragma unroll
+      for (int j = 0; j < TH; ++j) {
+        const float v = (j & 1) ? o2[j >> 1].y : o2[j >> 1].x;
+        const int t = t0 + half * TH + j;
+        if (t < a.T) {
+          a.zbuf[(rowb + t) * DM + c] = v;
+          lsum += v;
+          lsq += v * v;
+        }
+      }
+      const size_t blk = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + half;
+      a.partial[(blk * 2 + 0) * DM + c] = lsum;
+      a.partial[(blk * 2 + 1) * DM + c] = lsq;
+    } else {
     // the branch is added onto the x2 tile in place (this thread is the only one that touches these elements) ...
 #pragma unroll
     for (int j = 0; j < TH; ++j) {
       const float v = (j & 1) ? o2[j >> 1].y : o2[j >> 1].x;
       X2[(half * TH + j) * DM + c] += fmaxf(v * scale + shift, 0.f) * pw2w + pw2b;
+    }
     }
   }
   __syncthreads();
@@ -2371,8 +2407,21 @@ extern "C" int csship_outproj_conv(const uint16_t* attn_out, const uint16_t* wo_
   if (!aligned16(attn_out) || !aligned16(wo_packed) || !aligned16(bo) || !aligned16(x) || !aligned16(out) ||
       !aligned16(conv->ln_g) || !aligned16(conv->ln_b))
     return CSSHIP_EALIGN;
-  OcArgs a{attn_out, reinterpret_cast<const bf16x8*>(wo_packed), bo, x, out, *conv, B, T, g_csship_stamps};
+  OcArgs a{attn_out, reinterpret_cast<const bf16x8*>(wo_packed), bo, x, out, *conv, B, T, g_csship_stamps,
+           csship_dropout_cfg{nullptr, 0u, 0.f}, nullptr, nullptr};
   hipLaunchKernelGGL((outproj_conv_kernel<NWAVES>), dim3((T + OC_TT - 1) / OC_TT, B), dim3(NWAVES * 64), 0, as_stream(stream), a);
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
+// the TRAIN form's launch, for csship_outproj_conv_train (convmod.hip owns the BatchNorm kernels that finish it)
+int launch_outproj_conv_train(const uint16_t* attn_out, const uint16_t* wo_packed, const float* bo, const float* x,
+                              float* x2_out, const csship_conv_weights& conv, int B, int T, csship_dropout_cfg drop,
+                              float* zbuf, float* partial, int* nblk_out, hipStream_t s) {
+  OcArgs a{attn_out, reinterpret_cast<const bf16x8*>(wo_packed), bo, x, x2_out, conv, B, T, g_csship_stamps, drop, zbuf, partial};
+  const dim3 grid((T + OC_TT - 1) / OC_TT, B);
+  *nblk_out = (int)(grid.x * grid.y * 2);
+  hipLaunchKernelGGL((outproj_conv_kernel<NWAVES, true>), grid, dim3(NWAVES * 64), 0, s, a);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }

@@ -313,6 +313,23 @@ def convmod(x, weights, kernel_size=33, batch_stats=False, return_workspace=Fals
     return (y, ws) if return_workspace else y
 
 
+def outproj_conv_train(attn_out, wo_packed, bo, x, weights, B, T, kernel_size=33, drop_proj=None, drop_conv=None):
+    """Training form of the attention output projection + conv module (csship_outproj_conv_train, d_model 256, centred
+    taps, batch-statistics BatchNorm): x2 = x + D(attn_out Wo^T + bo), y = x2 + ConvModule_train(x2) in three launches.
+    attn_out bf16 [B*T, 256], x f32 [B*T, 256].  Returns (x2, y, workspace): the workspace is the one ops.convmod(...,
+    batch_stats=True, return_workspace=True) returns (ops_bwd.convmod_bwd takes it)."""
+    _need(attn_out, torch.bfloat16, "attn_out"), _need(x, torch.float32, "x")
+    D = x.shape[-1]
+    if not (attn_out.is_contiguous() and x.is_contiguous()) or attn_out.shape != (B * T, D) or x.shape != (B * T, D):
+        raise RuntimeError("css_amd: outproj_conv_train expects dense [B*T, 256] operands")
+    cw = conv_weights_struct(weights)
+    x2, y = torch.empty_like(x), torch.empty_like(x)
+    ws = torch.empty(lib().csship_convmod_workspace(B, T, D), device=x.device, dtype=torch.uint8)
+    check(lib().csship_outproj_conv_train(_ptr(attn_out), _ptr(wo_packed), _ptr(bo), _ptr(x), _ptr(x2), _ptr(y), C.byref(cw),
+                                          B, T, D, kernel_size, drop_proj, drop_conv, _ptr(ws), _stream()))
+    return x2, y, ws
+
+
 def _targets_array(targets, B, T, F, strided=False):
     """HOST array of the targets' device pointers (+ the tensors kept alive).  strided: rows may be padded (stft's
     pad_rows) as long as every target has the same row stride; returns (arr, keep, row stride) then."""

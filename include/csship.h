@@ -619,6 +619,18 @@ int csship_outproj_conv(const uint16_t* attn_out, const uint16_t* wo_packed, con
                         float* out, const csship_conv_weights* conv, int32_t B, int32_t T, int32_t d_model,
                         int32_t kernel_size, csship_stream_t stream);
 
+/* Training form (batch-statistics BatchNorm, the reference's dropouts; replaces csship_panel_linear_drop followed by
+ * csship_convmod_drop(bn_mode 1), conformer.py:254,356 + 289-303,357 under model.train()):
+ *   x2_out = x + D_proj(attn_out Wo^T + bo),   y = x2_out + D_conv(pw2(relu(BN_batch(dwconv(glu(LN(x2_out)))))))
+ * One kernel forms x2, LayerNorm, GLU and the depthwise convolution (pre-BatchNorm activations + per-workgroup partial
+ * statistics), then the BatchNorm reduce and apply kernels of csship_convmod finish.  workspace: csship_convmod_workspace
+ * bytes, left exactly as csship_convmod(bn_mode 1) leaves it (csship_convmod_bwd* take it).  d_model 256, kernel 33,
+ * centred taps; drop_proj indexes [B*T, 256] row-major like csship_panel_linear_drop, drop_conv like csship_convmod_drop. */
+int csship_outproj_conv_train(const uint16_t* attn_out, const uint16_t* wo_packed, const float* bo, const float* x,
+                              float* x2_out, float* y, const csship_conv_weights* w, int32_t B, int32_t T, int32_t d_model,
+                              int32_t kernel_size, const csship_dropout_cfg* drop_proj, const csship_dropout_cfg* drop_conv,
+                              void* workspace, csship_stream_t stream);
+
 /* ---- csship_ffn_bwd (css_amd/csrc/panel.hip): the activation side of the FeedForward backward as ONE row-panel kernel.
  * For out = x + alpha * (relu(LN(x) W1^T + b1) W2^T + b2) and dy = d(out) it produces
  *   a_bf16 = LN(x) [M, 256], h_bf16 = relu(.) [M, d_ffn], dh_bf16 = alpha * (dy W2) o [h > 0] [M, d_ffn]

@@ -412,6 +412,38 @@ def test_convmod(ops, B, T, batch_stats):
     assert err(y, ref) < (2e-4 if batch_stats else 5e-5)  # all-fp32 kernel
 
 
+@pytest.mark.parametrize("B,T,drop", [(2, 64, False), (3, 130, True), (2, 400, True), (1, 7, False)])
+def test_outproj_conv_train_equals_the_two_operators(ops, B, T, drop):
+    """csship_outproj_conv_train (output projection + dropout + residual, LayerNorm, GLU and depthwise convolution in one
+    kernel, then the BatchNorm reduce / apply launches) == csship_panel_linear_drop followed by csship_convmod_drop with
+    batch statistics: same x2, same module output, and the same workspace contents the backward reads (pre-BatchNorm
+    activations and the statistics block); against the oracle (conformer.py:254,356 + 289-303,357, training BatchNorm)
+    without dropout."""
+    from css_amd.dropout import DropState
+    sd, dw = _conv_weights(31)
+    D = 256
+    M = B * T
+    x1 = rnd((M, D), 52).to(DEV)
+    ao = rnd((M, D), 53).to(DEV).to(torch.bfloat16)
+    wo, bo = rnd((D, D), 54, 1 / 16).to(DEV), rnd((D,), 55, 0.1).to(DEV)
+    wp = ops.pack_frag(wo)
+    st = DropState(torch.tensor([11], dtype=torch.int32, device=DEV), 0.1, 0)
+    dp, dc = (st.cfg("2.attn.out"), st.cfg("2.conv.out")) if drop else (None, None)
+    x2, y, ws = ops.outproj_conv_train(ao, wp, bo, x1, dw, B, T, 33, drop_proj=dp, drop_conv=dc)
+    x2_ref = ops.panel_linear(ao, wp, bo, D, residual=x1, drop=dp) if drop else ops.panel_linear(ao, wp, bo, D, residual=x1)
+    y_ref, ws_ref = ops.convmod(x2_ref.view(B, T, D), dw, 33, batch_stats=True, return_workspace=True, drop=dc)
+    assert err(x2, x2_ref) < 1e-6
+    assert err(y, y_ref.view(M, D)) < 2e-5
+    n = M * D
+    z, z_ref = ws.view(torch.float32)[:n], ws_ref.view(torch.float32)[:n]
+    assert err(z, z_ref) < 2e-5
+    assert err(ws.view(torch.float32)[-4 * D:], ws_ref.view(torch.float32)[-4 * D:]) < 2e-5   # scale | shift | mean | var
+    if not drop:
+        x2_o = x1.cpu() + bf(ao.float().cpu()) @ bf(wo.cpu()).t() + bo.cpu()
+        ref = x2_o.view(B, T, D) + oracle.conformer.conv_module(x2_o.view(B, T, D), sd, "cv", 33, training_bn=True)
+        assert err(y.view(B, T, D), ref) < 3e-4
+
+
 @pytest.mark.parametrize("batch_stats", [False, True])
 def test_convmod_causal_golden(ops, golden, batch_stats):
     """csship_conv_weights.causal: the causal ConvModule (conformer.py:265-273, 297-298) against the reference's own
