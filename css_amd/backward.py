@@ -60,11 +60,12 @@ def ffn_bwd_fused(x, dy, ln_g, ln_b, b1, w1p, w2tp, w1tp, d_ffn, alpha=0.5, drop
     the B*T rows.  w1p / w2tp / w1tp: fragment-packed W1, W2^T, W1^T."""
     dx, dg, dbeta, a, h, dh, dyd = ob.ffn_bwd(x, dy, ln_g, ln_b, w1p, b1, w2tp, w1tp, d_ffn, alpha, drop_hidden, drop_out)
     dw1_o, db1_o, dw2_o, db2_o = outs   # optional f32 destinations (dW1, db1, dW2, db2), e.g. zeroed .grad views
-    if dyd is not None:   # output dropout: the second Linear saw h (dropped) and its gradient is alpha * dy o mask / (1 - p)
-        dw2, db2 = ob.linear_wgrad(dyd, h, dw_out=dw2_o, db_out=db2_o)
-    else:
-        dw2, db2 = ob.linear_wgrad(dy, h, alpha, dw_out=dw2_o, db_out=db2_o)
-    dw1, db1 = ob.linear_wgrad(dh, a, dw_out=dw1_o, db_out=db1_o)
+    with ob.paired_reductions():   # the slabs of both products summed by one launch
+        if dyd is not None:   # output dropout: the second Linear saw h (dropped) and its gradient is alpha * dy o mask / (1 - p)
+            dw2, db2 = ob.linear_wgrad(dyd, h, dw_out=dw2_o, db_out=db2_o)
+        else:
+            dw2, db2 = ob.linear_wgrad(dy, h, alpha, dw_out=dw2_o, db_out=db2_o)
+        dw1, db1 = ob.linear_wgrad(dh, a, dw_out=dw1_o, db_out=db1_o)
     return dx, (dg, dbeta, dw1, db1, dw2, db2)
 
 

@@ -833,6 +833,7 @@ struct DeferQueue {
   std::vector<ReduceJob> jobs;
 };
 static thread_local DeferQueue t_defer;
+static thread_local bool t_hold = false;   // csship_reduce_hold: queue EVERY slab reduction, whatever its size
 
 static void queue_job(const float* slabs, int S, int64_t n, int N, int64_t ldc, float alpha, const float* bias,
                       const float* add, int64_t ldadd, float* out, float alpha_head, int head_rows, int kind) {
@@ -855,7 +856,7 @@ static int launch_slab_reduce2(const float* slabs, int S, int64_t n, int N, int6
   // product without reaching HBM; queued for the end of the block they came back from HBM: 112 us per block for 125 MB
   // against 14 launches x 5.7 us (measured).  The size test keeps that true whatever a caller marks.
   static const int64_t defer_max = (int64_t)4 << 20;
-  if (deferrable && t_defer.on && (int64_t)S * (n + n2) * 4 <= defer_max) {  // the same kernel shape as the launch below would pick, later
+  if (t_hold || (deferrable && t_defer.on && (int64_t)S * (n + n2) * 4 <= defer_max)) {  // the same kernel shape as the launch below would pick, later
     const int kind = wide ? 0 : (S >= 32 ? 1 : 2);
     queue_job(slabs, S, n, N, ldc, alpha, bias, add, ldadd, out, alpha_head, head_rows, kind);
     if (n2 > 0) queue_job(slabs2, S, n2, (int)n2, n2, alpha, nullptr, nullptr, 0, out2, alpha_head, head_rows, kind | 4);
@@ -887,6 +888,12 @@ extern "C" int csship_reduce_defer(int32_t on) {
   const int was = t_defer.on ? 1 : 0;
   t_defer.on = on != 0;
   if (!on) t_defer.jobs.clear();  // leaving the mode without a flush (error paths) drops what was queued
+  return was;
+}
+
+extern "C" int csship_reduce_hold(int32_t on) {
+  const int was = t_hold ? 1 : 0;
+  t_hold = on != 0;
   return was;
 }
 

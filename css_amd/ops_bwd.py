@@ -51,10 +51,43 @@ class deferred_reductions:
         return False
 
 
+_hold = {"on": False, "ws": []}
+_NO_PAIR = bool(os.environ.get("CSSHIP_NO_PAIR_REDUCE"))   # A/B timing: every weight gradient's slab reduction as its own launch
+
+
+class paired_reductions:
+    """``with paired_reductions(): dw2 = linear_wgrad(..); dw1 = linear_wgrad(..)``: the slab reductions of the products
+    inside are queued (csship_reduce_hold) and run as ONE launch at the exit - for two weight gradients of one operator
+    (2 x 16 MB of slabs, both still in the last-level cache), not for more (a whole block's slabs came back from HBM).
+    Every product inside gets a workspace of its own, alive until the flush."""
+
+    def __enter__(self):
+        if not _NO_PAIR:
+            lib().csship_reduce_hold(1)
+            _hold["on"] = True
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if _hold["on"]:
+            _hold["on"] = False
+            lib().csship_reduce_hold(0)
+            try:
+                if et is None and lib().csship_reduce_pending():
+                    check(lib().csship_reduce_flush(_stream()))
+                    _deferred_ws.clear()   # (the flush ran every queued job, the deferred small ones included)
+            finally:
+                _hold["ws"].clear()
+        return False
+
+
 def _workspace(nbytes, dev, own=False):
     """Scratch reused across calls on one stream (kernels on a stream run in order).  own: the call's reduction is one
     of the deferrable ones - while reductions are deferred it gets a workspace of its own (the slabs live in it until
     the flush)."""
+    if _hold["on"]:   # a held reduction reads this product's slabs after the NEXT product has run
+        t = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+        _hold["ws"].append(t)
+        return t
     if own and _defer["on"]:
         t = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
         _deferred_ws.append(t)

@@ -603,6 +603,11 @@ int csship_bgemm_wgrad(const void* dY, const void* X, float* dW, float* db, cons
  * are still in the last-level cache.  csship_reduce_defer returns the previous mode; switching the mode off drops
  * anything still queued (error paths).  csship_reduce_pending: queued jobs. */
 int csship_reduce_defer(int32_t on);
+/* csship_reduce_hold(1) .. csship_reduce_hold(0), csship_reduce_flush(): EVERY slab reduction of the calling host thread in
+ * between is queued, whatever its size - for a PAIR of weight-gradient products (a FeedForward's dW1 and dW2: 2 x 16 MB
+ * of slabs, still in the last-level cache when the second product is done) summed by one launch instead of two.  Every
+ * product in between needs a workspace of its own, untouched until the flush.  Returns the previous mode. */
+int csship_reduce_hold(int32_t on);
 int csship_reduce_pending(void);
 int csship_reduce_flush(csship_stream_t stream);
 
