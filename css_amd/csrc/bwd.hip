@@ -26,12 +26,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   for (int64_t row = r0 + w; row < r1; row += 4) {
-    float4 v[VPL], d[VPL];
+    float4 v[VPL], d[VPL], addv[VPL];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       v[i] = *reinterpret_cast<const float4*>(x + row * D + (i * 64 + lane) * 4);
       d[i] = *reinterpret_cast<const float4*>(dy + row * D + (i * 64 + lane) * 4);
+      // the residual gradient with the row, not behind its four reductions (dx may alias dx_add: this row is read before it is written)
+      addv[i] = dx_add ? *reinterpret_cast<const float4*>(dx_add + row * D + (i * 64 + lane) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
       s += v[i].x + v[i].y + v[i].z + v[i].w;
     }
     const float mean = wave_sum(s) * (1.f / D);
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
       r.z = rstd * (d[i].z - s1 - v[i].z * s2);
       r.w = rstd * (d[i].w - s1 - v[i].w * s2);
       if (dx_add) {
-        const float4 a = *reinterpret_cast<const float4*>(dx_add + o);
+        const float4 a = addv[i];
         r.x += a.x; r.y += a.y; r.z += a.z; r.w += a.w;
       }
       *reinterpret_cast<float4*>(dx + o) = r;

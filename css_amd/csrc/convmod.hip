@@ -403,6 +403,7 @@ constexpr int TT256 = 32, TT512 = 32;
 //   pass B1  dg = dc (*) flipped taps                              (convmod_kernel MODE 3)
 //   pass B2  d dw_w, d dw_b partials from g (recomputed) and dc    (convmod_kernel MODE 2)
 //   pass C   row kernel: GLU backward + LayerNorm backward + residual -> dx, d ln, d pw1
+constexpr int BWD_ROWS_C = 16;   // = BWD_ROWS (the launch's rows per workgroup): the unrolled form of the statistics pass
 template <int D>
 __global__ __launch_bounds__(D) void conv_bn_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ z,
                                                               const float* __restrict__ stats,
@@ -416,6 +417,31 @@ __global__ __launch_bounds__(D) void conv_bn_bwd_stats_kernel(const float* __res
   const float w3 = pw2_w[0];
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg, r1 = min(M, r0 + rows_per_wg);
   float s1 = 0.f, s2 = 0.f, dw3 = 0.f, db3 = 0.f;
+  if (rows_per_wg == BWD_ROWS_C) {
+    // all of the workgroup's rows requested at once (clamped addresses, rows beyond M masked): with the loads inside a loop
+    // of run-time length every row was a memory round trip of its own (13.2 us per launch for 26 MB = 2 TB/s); same
+    // summation order
+    float dv[BWD_ROWS_C], zv[BWD_ROWS_C];
+#pragma unroll
+    for (int i = 0; i < BWD_ROWS_C; ++i) {
+      const int64_t r = min(r0 + i, M - 1);
+      dv[i] = dy[r * D + c];
+      zv[i] = z[r * D + c];
+    }
+#pragma unroll
+    for (int i = 0; i < BWD_ROWS_C; ++i) {
+      const int64_t r = r0 + i;
+      float d = r < M ? dv[i] : 0.f;
+      const float zz = zv[i];
+      if (dp.thresh != 0u) d = drop_keep1(dp, (unsigned)(min(r, M - 1) * D + c)) ? d * dp.scale : 0.f;
+      const float zh = zz * sc + sh;
+      const float dzh = zh > 0.f ? d * w3 : 0.f;
+      s1 += dzh;
+      s2 += dzh * (zz - mu) * rstd;
+      dw3 += d * fmaxf(zh, 0.f);
+      db3 += d;
+    }
+  } else
   for (int64_t r = r0; r < r1; ++r) {
     float d = dy[r * D + c];
     const float zz = z[r * D + c];
@@ -455,14 +481,21 @@ __global__ __launch_bounds__(256) void conv_bn_bwd_apply_kernel(const float* __r
   const float4 zz = reinterpret_cast<const float4*>(z)[i];
   const float w3 = pw2_w[0];
   const float dv[4] = {d.x, d.y, d.z, d.w}, zv[4] = {zz.x, zz.y, zz.z, zz.w};
+  // per-channel constants as six 16-byte loads (c is a multiple of 4; they were 24 dword loads per thread beside the two
+  // data loads: the kernel was bound by the rate at which a CU takes wave memory instructions, 3 TB/s)
+  const float4 sc4 = *reinterpret_cast<const float4*>(stats + c), sh4 = *reinterpret_cast<const float4*>(stats + D + c);
+  const float4 mu4 = *reinterpret_cast<const float4*>(stats + 2 * D + c), va4 = *reinterpret_cast<const float4*>(stats + 3 * D + c);
+  const float4 s14 = *reinterpret_cast<const float4*>(sums + c), s24 = *reinterpret_cast<const float4*>(sums + D + c);
+  const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w}, muv[4] = {mu4.x, mu4.y, mu4.z, mu4.w};
+  const float vav[4] = {va4.x, va4.y, va4.z, va4.w}, s1v[4] = {s14.x, s14.y, s14.z, s14.w}, s2v[4] = {s24.x, s24.y, s24.z, s24.w};
   float o[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const float sc = stats[c + q], sh = stats[D + c + q], mu = stats[2 * D + c + q];
-    const float rstd = rsqrtf(stats[3 * D + c + q] + 1e-5f);
+    const float sc = scv[q], sh = shv[q], mu = muv[q];
+    const float rstd = rsqrtf(vav[q] + 1e-5f);
     const float zh = zv[q] * sc + sh;
     const float dzh = zh > 0.f ? dv[q] * w3 : 0.f;
-    o[q] = sc * (dzh - sums[c + q] * inv_n - (zv[q] - mu) * rstd * sums[D + c + q] * inv_n);
+    o[q] = sc * (dzh - s1v[q] * inv_n - (zv[q] - mu) * rstd * s2v[q] * inv_n);
   }
   reinterpret_cast<float4*>(dc)[i] = make_float4(o[0], o[1], o[2], o[3]);
 }
@@ -505,6 +538,7 @@ __global__ __launch_bounds__(256) void glu_ln_bwd_kernel(const float* __restrict
   }
   for (int64_t row = r0 + w; row < r1; row += 4) {
     float v[VPL][4], d[VPL][4];
+    float4 dyv[VPL];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
@@ -513,6 +547,7 @@ __global__ __launch_bounds__(256) void glu_ln_bwd_kernel(const float* __restrict
       v[i][0] = xv.x; v[i][1] = xv.y; v[i][2] = xv.z; v[i][3] = xv.w;
       d[i][0] = gv.x; d[i][1] = gv.y; d[i][2] = gv.z; d[i][3] = gv.w;
       s += (xv.x + xv.y) + (xv.z + xv.w);
+      dyv[i] = *reinterpret_cast<const float4*>(dy + row * D + (i * 64 + lane) * 4);   // with the row, not behind its four reductions
     }
     const float mean = wave_sum(s) * (1.f / D);
     float ss = 0.f;
@@ -550,7 +585,7 @@ __global__ __launch_bounds__(256) void glu_ln_bwd_kernel(const float* __restrict
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       const int64_t o = row * D + (i * 64 + lane) * 4;
-      const float4 a = *reinterpret_cast<const float4*>(dy + o);
+      const float4 a = dyv[i];
       float4 r;
       r.x = a.x + rstd * (d[i][0] - s1 - v[i][0] * s2);
       r.y = a.y + rstd * (d[i][1] - s1 - v[i][1] * s2);
@@ -580,6 +615,7 @@ __global__ __launch_bounds__(256) void glu_ln_bwd_kernel(const float* __restrict
 // rows per workgroup of the row-wise backward passes: short row loops, many waves in flight (these passes are chains of
 // loads and wave reductions, not bandwidth: 64 rows per workgroup left less than one wave per SIMD at 12 800 rows)
 constexpr int BWD_ROWS = 16;
+static_assert(BWD_ROWS == BWD_ROWS_C, "conv_bn_bwd_stats_kernel's unrolled form");
 
 struct BwdLayout {  // carve of the backward workspace (floats)
   size_t dc, dg, part, part_c, sums, total;
