@@ -73,6 +73,7 @@ _NO_BAND = bool(os.environ.get("CSSHIP_NO_BAND"))   # A/B timing: the skewed-dS 
 _NO_LN_Y = bool(os.environ.get("CSSHIP_NO_LN_Y"))   # A/B timing: LayerNorm(x) for the q/k/v weight gradient by its own launch
 _SPLIT_ATTN_BWD = bool(os.environ.get("CSSHIP_ATTN_BWD_SPLIT"))   # A/B timing: probabilities / softmax backward / dS k as separate launches
 _NO_DVDK = bool(os.environ.get("CSSHIP_NO_DVDK"))   # A/B timing: dV and dK as two general batched products
+_NO_PANEL_DX = bool(os.environ.get("CSSHIP_NO_PANEL_DX"))   # A/B timing: the output projection's input gradient by the tiled kernel
 
 
 def relpos_window(pe_table_bf, T, maxlen):
@@ -159,7 +160,7 @@ def _mha_core_products(qkv, g, q, k, do, p_v, ds, dsk, dq1, win, idx, window, dw
 
 def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_scale=0.125, window=None, probs=None,
             skew_buf=None, fused_softmax_bwd=True, drop_p=None, drop_out=None, dwin_acc=None, dyb_bf16=None,
-            dwo_out=None, dbo_out=None):
+            dwo_out=None, dbo_out=None, wo_tp=None):
     """out = x + attention(LN(x)) @ wo^T + bo  (conformer.py:213-254,356).
 
     wqkv_bf holds the q rows already multiplied by q_scale (as the forward uses them); the returned dwqkv / dbqkv are
@@ -173,7 +174,13 @@ def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_s
         dyb = dyb_bf16
     else:
         dyb = dy if drop_out is None else ops.dropout_apply(dy, drop_out, out=torch.empty_like(dy))
-    dao, dwo, dbo = linear_bwd(dyb, ao, wo_bf, dx_bf16=True, dw_out=dwo_out, db_out=dbo_out)
+    if wo_tp is not None and not _NO_PANEL_DX and dyb.dtype == BF and dyb.is_contiguous() and D == 256:
+        # dao = dyb Wo as a row-panel Linear against the fragment-packed Wo^T (a 12 800 x 256 x 256 product is all launch,
+        # first-tile latency and epilogue for the tiled kernel: 17.5 us against ~11)
+        dwo, dbo = ob.linear_wgrad(dyb, ao, dw_out=dwo_out, db_out=dbo_out)
+        dao = ops.panel_linear(dyb, wo_tp, None, D, out_bf16=True)
+    else:
+        dao, dwo, dbo = linear_bwd(dyb, ao, wo_bf, dx_bf16=True, dw_out=dwo_out, db_out=dbo_out)
     B = qkv.shape[0]
     if drop_p is not None and (probs is None or not fused_softmax_bwd):
         raise NotImplementedError("css_amd: dropout of the attention probabilities needs the attention-shaped backward")
