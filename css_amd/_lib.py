@@ -67,9 +67,10 @@ class BgemmParams(C.Structure):
 _dc = C.POINTER(DropoutCfg)
 
 
-class PackJob(C.Structure):  # csship_pack_job (64 bytes)
+class PackJob(C.Structure):  # csship_pack_job (72 bytes)
     _fields_ = [("w", _p), ("row_major", _p), ("frag", _p), ("ld_w", _i64), ("ld_row_major", _i64),
-                ("R", _i32), ("K", _i32), ("dst_row0", _i32), ("Kp", _i32), ("scale", _f32), ("transposed", _i32)]
+                ("R", _i32), ("K", _i32), ("dst_row0", _i32), ("Kp", _i32), ("scale", _f32), ("transposed", _i32),
+                ("k0", _i32), ("Kp_dst", _i32)]
 
 
 A_BF16, A_F32, A_F32_MVN = 0, 1, 2
@@ -172,6 +173,8 @@ SIGNATURES = {
     "csship_ffn_fused_train": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _dc, _dc, _p]),
     "csship_ffn_bwd_drop": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _dc, _dc, _p,
                                     _p, _sz, _p]),
+    "csship_qkv_in_bwd_workspace": (_sz, [_i32]),
+    "csship_qkv_in_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _p, _sz, _p]),
     "csship_mha_relpos_train_drop": (_i32, [_p, _p, _i32, _i32, _p, _p, _i32, _i32, _i32, _dc, _p]),
     "csship_mha_relpos_probs_drop": (_i32, [_p, _p, _i32, _i32, _p, _p, _p, _i64, _i32, _i32, _i32, _dc, _p]),
     "csship_attn_softmax_bwd_drop": (_i32, [_p, _p, _p, _i64, _p, _p, _p, _i32, _i32, _i32, _i32, _dc, _p]),

@@ -153,6 +153,13 @@ def _conformer_pack_plan(model, wide, device):
             plan.add(lin.weight.detach(), scale=a.d_k ** -0.5 if i == 0 else 1.0, row_major=wqkv_bf, frag=wqkv_p,
                      row0=i * D)
         h["wqkv_bf"], h["wqkv_p"] = wqkv_bf, wqkv_p
+        # fragment-packed (scaled) Wqkv^T [D, 3D]: the projection's input gradient as a row-panel kernel (d_model 256)
+        wqkv_tp = None if wide else torch.empty(3 * D * D, dtype=BF, device=device)
+        if not wide:
+            for i, lin in enumerate((a.linear_q, a.linear_k, a.linear_v)):
+                plan.add(lin.weight.detach(), scale=a.d_k ** -0.5 if i == 0 else 1.0, transposed=True, frag=wqkv_tp,
+                         k0=i * D, k_total=3 * D)
+        h["wqkv_tp"] = wqkv_tp
         h["wo_bf"], h["wo_p"] = plan.add(a.linear_out.weight.detach(), want_row_major=True, want_frag=not wide)
         # fragment-packed Wo^T: the input gradient of the output projection as a row-panel Linear (d_model 256)
         h["wo_tp"] = None if wide else plan.add(a.linear_out.weight.detach(), transposed=True, want_frag=True)[1]
@@ -300,7 +307,7 @@ class ConformerTrain(torch.autograd.Function):
             else:
                 x2 = ops.panel_linear(ao, wo_p, a.linear_out.bias.detach(), D, residual=x1)
             L["mha"] = (x1, qkv, ao, wqkv_bf, wo_bf, scale, lse)
-            L["wo_tp"] = wp.get("wo_tp")
+            L["wo_tp"], L["wqkv_tp"] = wp.get("wo_tp"), wp.get("wqkv_tp")
             W = {"ln_g": c.layer_norm.weight.detach(), "ln_b": c.layer_norm.bias.detach(),
                  "pw1_w": c.pw_conv_1.weight.detach().view(2), "pw1_b": c.pw_conv_1.bias.detach(),
                  "dw_w": dww_all[li], "dw_b": c.dw_conv_1d.bias.detach(),
@@ -450,7 +457,7 @@ class ConformerTrain(torch.autograd.Function):
                                probs=(S["pe_pack"], lse), skew_buf=skew_buf, drop_p=ds.cfg(f"{li}.attn.p"),
                                drop_out=ds.cfg(f"{li}.attn.out"), dwin_acc=dwin, dyb_bf16=dyb,
                                dwo_out=_direct_grad(a.linear_out.weight), dbo_out=_direct_grad(a.linear_out.bias),
-                               wo_tp=L.get("wo_tp"))
+                               wo_tp=L.get("wo_tp"), wqkv_tp=L.get("wqkv_tp"))
             dg, dbeta, dwqkv, dbqkv, dwo, dbo, dwin = g   # dwin: the window gradient summed over the blocks so far
             put(a.layer_norm.weight, dg), put(a.layer_norm.bias, dbeta)
             for i, lin in enumerate((a.linear_q, a.linear_k, a.linear_v)):

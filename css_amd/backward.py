@@ -160,7 +160,7 @@ def _mha_core_products(qkv, g, q, k, do, p_v, ds, dsk, dq1, win, idx, window, dw
 
 def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_scale=0.125, window=None, probs=None,
             skew_buf=None, fused_softmax_bwd=True, drop_p=None, drop_out=None, dwin_acc=None, dyb_bf16=None,
-            dwo_out=None, dbo_out=None, wo_tp=None):
+            dwo_out=None, dbo_out=None, wo_tp=None, wqkv_tp=None):
     """out = x + attention(LN(x)) @ wo^T + bo  (conformer.py:213-254,356).
 
     wqkv_bf holds the q rows already multiplied by q_scale (as the forward uses them); the returned dwqkv / dbqkv are
@@ -189,6 +189,11 @@ def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_s
     dq2 = dqkv.view(-1, 3 * D)
     dw = torch.empty((3 * D, D), dtype=torch.float32, device=x.device)
     db = torch.empty(3 * D, dtype=torch.float32, device=x.device)
+    if wqkv_tp is not None and not _NO_PANEL_DX and D == 256 and x.shape[0] % 64 == 0 and dq2.is_contiguous():
+        # da = dqkv Wqkv, the LayerNorm backward, the residual gradient and a = LayerNorm(x) in one row-panel kernel
+        dx, dg, dbeta, a = ob.qkv_in_bwd(dq2, wqkv_tp, x, dy, ln_g, ln_b)
+        ob.linear_wgrad(dq2, a, 1.0, dw_out=dw, db_out=db, head=(D, q_scale))
+        return dx, (dg, dbeta, dw, db, dwo, dbo, dpe)
     da = ob.bgemm(dq2, wqkv_bf, b_kmajor=True)
     # the LayerNorm backward recomputes the normalised rows: it also hands back a = LayerNorm(x), the projection's input
     if D in (256, 512, 1024) and not _NO_LN_Y:

@@ -296,7 +296,8 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const csship_pack_job* 
     *reinterpret_cast<uint4*>(j.row_major + (int64_t)(j.dst_row0 + r) * j.ld_row_major + k) = o;
   if (j.frag) {
     const int rr = j.dst_row0 + r;
-    const int64_t blk = (int64_t)(rr / 16) * (j.Kp / 32) + k / 32;
+    const int kpd = j.Kp_dst > 0 ? j.Kp_dst : j.Kp;   // k-slice [k0, k0 + Kp) of a wider fragment table
+    const int64_t blk = (int64_t)(rr / 16) * (kpd / 32) + (j.k0 + k) / 32;
     *reinterpret_cast<uint4*>(j.frag + (blk * 64 + ((k % 32) / 8) * 16 + (rr % 16)) * 8) = o;
   }
 }

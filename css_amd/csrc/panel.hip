@@ -2472,6 +2472,238 @@ extern "C" int csship_ffn_bwd(const float* x, const float* dy, const float* ln_g
                              stream);
 }
 
+// =============================================================================== q | k | v projection backward (dX side)
+// qkv = LayerNorm(x) Wqkv^T + b is the front of the attention block (conformer.py:213-224); out = x + attention(...).
+// Given dqkv (bf16 [M, 768]) and dy = d(out), ONE kernel per 64-row panel:
+//   da = dqkv Wqkv          24 k-steps over the panel's three 256-column chunks (all three in LDS: 96 KB), the
+//                           fragment-packed Wqkv^T [256, 768] streamed through the weight ring without a pause
+//   dx = dy + LayerNorm-backward(da);  y = LayerNorm(x) as bf16 (second operand of dWqkv = dqkv^T y);
+//   dgamma / dbeta partials per workgroup.
+// Replaces the tiled GEMM (17.5 us) + the LayerNorm-backward row kernel (11.8 us) and the f32 round trip of da between
+// them.  Whole panels only (M % 64 == 0); every global memory instruction is unconditional (see chain_s_kernel).
+struct QkvBwdArgs {
+  const unsigned short* dqkv;
+  const bf16x8* wt;   // packed from Wqkv^T [256, 768] (the q rows of Wqkv carry the forward's 1/sqrt(d_k))
+  const float* x;
+  const float* dy;
+  const float *ln_g, *ln_b;
+  float* dx;
+  unsigned short* y_bf;
+  float* part;        // [nwg][2][256]
+  int M;
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void qkv_in_bwd_kernel(QkvBwdArgs a) {
+  static_assert(NW * 64 == 8 * BM, "row phases assume 8 lanes per panel row");
+  constexpr int NT = 16 / NW;
+  constexpr int KT = 3 * KS;  // 24 k-steps
+  // three bf16 panels (96 KB); later the Ys tile, then da * xhat [64][260] | da [64][256] for the column sums
+  __shared__ __attribute__((aligned(16))) unsigned char Ps[YS_BYTES + 2 * PANEL_BYTES];
+  __shared__ __attribute__((aligned(16))) float Pb[2 * DM + CS_DUMP];  // gamma | beta | dump
+  static_assert(YS_BYTES + 2 * PANEL_BYTES >= 3 * PANEL_BYTES, "the three panels must fit");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15;
+  const int m0 = blockIdx.x * BM;
+  const bf16x8* ws = a.wt + (size_t)(wave * NT) * KT * 64 + lane;
+  bf16x8 wq[PD][NT];
+  // the panel's 96 KB of dqkv and the LayerNorm affine: unconditional 16-byte loads
+  f32x4 pv0[4], pv1[4], pv2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = tid + NW * 64 * j, r = i >> 5, c = i & 31;
+    const unsigned short* src = a.dqkv + (size_t)(m0 + r) * (3 * DM) + c * 8;
+    pv0[j] = *reinterpret_cast<const f32x4*>(src);
+    pv1[j] = *reinterpret_cast<const f32x4*>(src + DM);
+    pv2[j] = *reinterpret_cast<const f32x4*>(src + 2 * DM);
+  }
+  const float4 pg = *reinterpret_cast<const float4*>((tid < 64 ? a.ln_g : a.ln_b) + lane * 4);
+  prefetch_first<NT>(wq, ws, KT, NT);
+  *reinterpret_cast<float4*>(Pb + (tid < 128 ? tid * 4 : 2 * DM + lane * 4)) = pg;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = tid + NW * 64 * j, r = i >> 5, c = i & 31;
+    *reinterpret_cast<f32x4*>(Ps + panel_off(r, c)) = pv0[j];
+    *reinterpret_cast<f32x4*>(Ps + PANEL_BYTES + panel_off(r, c)) = pv1[j];
+    *reinterpret_cast<f32x4*>(Ps + 2 * PANEL_BYTES + panel_off(r, c)) = pv2[j];
+  }
+  __syncthreads();
+
+  f32x4 o[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) o[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int r = tid >> 3, part = tid & 7;
+  const int row = m0 + r;
+  float4 v[8], dyv[8];
+  {
+    bf16x8 xa[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) xa[0][rt] = *reinterpret_cast<const bf16x8*>(Ps + panel_off(rt * 16 + n, g));
+#pragma unroll
+    for (int ks = 0; ks < KT; ++ks) {
+      bf16x8 wc[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) wc[t] = wq[ks % PD][t];
+      if (ks + PD < KT) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) wq[ks % PD][t] = ws[(size_t)(t * KT + ks + PD) * 64];
+      }
+      if (ks == KT - PD) {  // behind the last weight fragments: the x and dy rows of the epilogue
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          v[i] = *reinterpret_cast<const float4*>(a.x + (size_t)row * DM + (i * 8 + part) * 4);
+          dyv[i] = *reinterpret_cast<const float4*>(a.dy + (size_t)row * DM + (i * 8 + part) * 4);
+        }
+      }
+      if (ks + 1 < KT) {
+        const unsigned char* pn = Ps + ((ks + 1) >> 3) * PANEL_BYTES;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+          xa[(ks + 1) & 1][rt] = *reinterpret_cast<const bf16x8*>(pn + panel_off(rt * 16 + n, ((ks + 1) & 7) * 4 + g));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+          o[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[t], xa[ks & 1][rt], o[t][rt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __syncthreads();  // every wave is done reading the panels
+  float* ys = reinterpret_cast<float*>(Ps);
+  {
+    float4 zero[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) zero[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    park_tiles<NT, false>(ys, o, NT, wave * NT * 16, g, n, zero);
+  }
+  __syncthreads();
+  const float* lgp = Pb;
+  const float* lbp = Pb + DM;
+  float4 da[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) da[i] = *reinterpret_cast<const float4*>(ys + r * YS + (i * 8 + part) * 4);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float mean = sum8(s) * (1.f / DM);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+    ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+  }
+  const float rstd = rsqrtf(sum8(ss) * (1.f / DM) + 1e-5f);
+  float s1 = 0.f, s2 = 0.f;
+  float4 gg[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float4 gm = *reinterpret_cast<const float4*>(lgp + (i * 8 + part) * 4);
+    const float4 bt = *reinterpret_cast<const float4*>(lbp + (i * 8 + part) * 4);
+    v[i].x *= rstd; v[i].y *= rstd; v[i].z *= rstd; v[i].w *= rstd;  // xhat
+    *reinterpret_cast<uint2*>(a.y_bf + (size_t)row * DM + (i * 8 + part) * 4) =
+        make_uint2(pack_bf2(v[i].x * gm.x + bt.x, v[i].y * gm.y + bt.y), pack_bf2(v[i].z * gm.z + bt.z, v[i].w * gm.w + bt.w));
+    gg[i] = make_float4(da[i].x * gm.x, da[i].y * gm.y, da[i].z * gm.z, da[i].w * gm.w);
+    s1 += (gg[i].x + gg[i].y) + (gg[i].z + gg[i].w);
+    s2 += (gg[i].x * v[i].x + gg[i].y * v[i].y) + (gg[i].z * v[i].z + gg[i].w * v[i].w);
+  }
+  s1 = sum8(s1) * (1.f / DM);
+  s2 = sum8(s2) * (1.f / DM);
+  __syncthreads();  // all da values are in registers: the Ys tile can be reused for the column sums
+  float* cg = reinterpret_cast<float*>(Ps);             // [64][260] da * xhat
+  float* cb = reinterpret_cast<float*>(Ps + YS_BYTES);  // [64][256] da
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int col = (i * 8 + part) * 4;
+    const float4 d = dyv[i];
+    float4 o4;
+    o4.x = d.x + rstd * (gg[i].x - s1 - v[i].x * s2);
+    o4.y = d.y + rstd * (gg[i].y - s1 - v[i].y * s2);
+    o4.z = d.z + rstd * (gg[i].z - s1 - v[i].z * s2);
+    o4.w = d.w + rstd * (gg[i].w - s1 - v[i].w * s2);
+    *reinterpret_cast<float4*>(a.dx + (size_t)row * DM + col) = o4;
+    *reinterpret_cast<float4*>(cg + r * YS + col) = make_float4(da[i].x * v[i].x, da[i].y * v[i].y, da[i].z * v[i].z, da[i].w * v[i].w);
+    *reinterpret_cast<float4*>(cb + r * DM + col) = da[i];
+  }
+  __syncthreads();
+  {
+    const int col = tid & 255, which = tid >> 8;  // 512 threads: 256 columns x {dgamma, dbeta}
+    float acc = 0.f;
+    if (which == 0) {
+#pragma unroll 8
+      for (int rr = 0; rr < BM; ++rr) acc += cg[rr * YS + col];
+    } else {
+#pragma unroll 8
+      for (int rr = 0; rr < BM; ++rr) acc += cb[rr * DM + col];
+    }
+    a.part[(size_t)blockIdx.x * 2 * DM + which * DM + col] = acc;
+  }
+}
+
+extern "C" size_t csship_qkv_in_bwd_workspace(int32_t M) { return (size_t)((M + BM - 1) / BM) * 2 * DM * sizeof(float); }
+
+extern "C" int csship_qkv_in_bwd(const uint16_t* dqkv, const uint16_t* wqkvT_packed, const float* x, const float* dy,
+                                 const float* ln_g, const float* ln_b, float* dx, uint16_t* y_bf16, float* dgamma_dbeta,
+                                 int32_t M, int32_t d_model, void* workspace, size_t workspace_bytes,
+                                 csship_stream_t stream) {
+  if (!dqkv || !wqkvT_packed || !x || !dy || !ln_g || !ln_b || !dx || !y_bf16 || !dgamma_dbeta || !workspace) return CSSHIP_ENULL;
+  if (M <= 0) return CSSHIP_EBADSHAPE;
+  if (d_model != DM || (M % BM) != 0) return CSSHIP_EUNSUPPORTED;
+  if (!aligned16(dqkv) || !aligned16(wqkvT_packed) || !aligned16(x) || !aligned16(dy) || !aligned16(ln_g) ||
+      !aligned16(ln_b) || !aligned16(dx) || !aligned8(y_bf16))
+    return CSSHIP_EALIGN;
+  const int nwg = M / BM;
+  if (workspace_bytes < (size_t)nwg * 2 * DM * sizeof(float)) return CSSHIP_EWORKSPACE;
+  QkvBwdArgs a{dqkv, reinterpret_cast<const bf16x8*>(wqkvT_packed), x, dy, ln_g, ln_b, dx, y_bf16,
+               reinterpret_cast<float*>(workspace), M};
+  hipLaunchKernelGGL((qkv_in_bwd_kernel<NWAVES>), dim3(nwg), dim3(NWAVES * 64), 0, as_stream(stream), a);
+  CSSHIP_CHECK_LAUNCH();
+  return launch_slab_reduce(reinterpret_cast<const float*>(workspace), nwg, 2 * DM, 2 * DM, 2 * DM, 1.f, nullptr, nullptr, 0,
+                            dgamma_dbeta, as_stream(stream), true);
+}
+
+// out bf16 [M, 256] = a bf16 [M, 256] W^T with no bias, whole panels: the input gradient of a 256 -> 256 Linear against
+// its fragment-packed transpose (the attention output projection's dao = dy Wo).  Accumulators go to global as bf16
+// straight from the MFMA layout (16-byte pieces after the tile pairing), no staged epilogue.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void panel_dx_kernel(const unsigned short* __restrict__ a, const bf16x8* __restrict__ w,
+                                                           unsigned short* __restrict__ out, int64_t ldo) {
+  constexpr int NT = 16 / NW;
+  static_assert(NT == 2, "tile pairing");
+  __shared__ __attribute__((aligned(16))) unsigned char Xs[PANEL_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15;
+  const int m0 = blockIdx.x * BM;
+  const bf16x8* ws = w + (size_t)(wave * NT) * KS * 64 + lane;
+  bf16x8 wq[PD][NT];
+  uint4 pv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = tid + NW * 64 * j, r = i >> 5, c = i & 31;
+    pv[j] = *reinterpret_cast<const uint4*>(a + (size_t)(m0 + r) * DM + c * 8);
+  }
+  prefetch_first<NT>(wq, ws, KS, NT);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = tid + NW * 64 * j, r = i >> 5, c = i & 31;
+    *reinterpret_cast<uint4*>(Xs + panel_off(r, c)) = pv[j];
+  }
+  __syncthreads();
+  f32x4 o[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) o[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  mma_pass_s<NT, false>(o, Xs, n, g, ws, KS, ws, KS, wq);
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    const uint4 pk = pair_tiles_bf16(make_uint2(pack_bf2(o[0][rt][0], o[0][rt][1]), pack_bf2(o[0][rt][2], o[0][rt][3])),
+                                     make_uint2(pack_bf2(o[1][rt][0], o[1][rt][1]), pack_bf2(o[1][rt][2], o[1][rt][3])));
+    *reinterpret_cast<uint4*>(out + (size_t)(m0 + rt * 16 + n) * ldo + (wave * NT + (g & 1)) * 16 + (g >> 1) * 8) = pk;
+  }
+}
+
 extern "C" int csship_panel_linear(const void* a, int32_t prologue, const float* ln_g, const float* ln_b,
                                    const uint16_t* w_packed, const float* bias, const float* residual, int64_t ldr,
                                    float alpha, void* out, int64_t ldo, int32_t M, int32_t N, int32_t d_model,
@@ -2500,6 +2732,14 @@ extern "C" int csship_panel_linear_drop(const void* a, int32_t prologue, const f
              dropping ? drop->seed : nullptr, dropping ? drop->stream : 0u, dropping ? drop->p : 0.f};
   hipStream_t s = as_stream(stream);
   const int key = prologue * 16 + epilogue;
+  static const bool use_static = [] { const char* e = getenv("CSSHIP_CHAIN_STATIC"); return e == nullptr || atoi(e) != 0; }();
+  if (use_static && key == CSSHIP_PRO_BF16 * 16 + CSSHIP_EPI_OUT_BF16 && !bias && N == DM && (M % BM) == 0 && (ldo & 7) == 0) {
+    hipLaunchKernelGGL((panel_dx_kernel<NWAVES>), dim3(M / BM), dim3(NWAVES * 64), 0, s,
+                       reinterpret_cast<const unsigned short*>(a), reinterpret_cast<const bf16x8*>(w_packed),
+                       reinterpret_cast<unsigned short*>(out), ldo);
+    CSSHIP_CHECK_LAUNCH();
+    return CSSHIP_OK;
+  }
   switch (key) {
     case CSSHIP_PRO_LN * 16 + CSSHIP_EPI_OUT_BF16: return launch_linear<CSSHIP_PRO_LN, CSSHIP_EPI_OUT_BF16>(la, s);
     case CSSHIP_PRO_LN * 16 + 0: return launch_linear<CSSHIP_PRO_LN, 0>(la, s);

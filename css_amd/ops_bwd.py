@@ -352,14 +352,15 @@ class PackPlan:
 
     def __init__(self, device):
         self.device = device
-        self.jobs = []      # (w, row_major, frag, scale, transposed, row0)
+        self.jobs = []      # (w, row_major, frag, scale, transposed, row0, k0, k_total)
         self.table = None
         self.ptrs = None
         self.max_chunks = 0
 
     def add(self, w, *, scale=1.0, transposed=False, row_major=None, frag=None, row0=0, want_row_major=False,
-            want_frag=False):
-        """w: f32 [R, K] (transposed=False) or the [K, R] storage of the logical [R, K] weight (transposed=True)."""
+            want_frag=False, k0=0, k_total=0):
+        """w: f32 [R, K] (transposed=False) or the [K, R] storage of the logical [R, K] weight (transposed=True).
+        k0 / k_total: this weight is the k-slice [k0, k0 + K) of a fragment table k_total wide (``frag`` given)."""
         _need(w, torch.float32, "w")
         if w.dim() != 2 or w.stride(1) != 1:
             raise RuntimeError("css_amd: PackPlan needs 2-d weights with contiguous rows")
@@ -368,19 +369,22 @@ class PackPlan:
             row_major = torch.empty((R, (K + 7) // 8 * 8), dtype=torch.bfloat16, device=w.device)
         if want_frag and frag is None:
             frag = torch.empty(((R + 15) // 16 * 16) * ((K + 31) // 32 * 32), dtype=torch.bfloat16, device=w.device)
-        self.jobs.append((w, row_major, frag, float(scale), bool(transposed), int(row0)))
+        if k_total and (frag is None or k0 % 32 or k_total % 32 or K % 32 or k0 + K > k_total or row_major is not None):
+            raise RuntimeError("css_amd: a k-slice job needs its fragment table, whole 32-wide k-steps and no row-major copy")
+        self.jobs.append((w, row_major, frag, float(scale), bool(transposed), int(row0), int(k0), int(k_total)))
         self.table = None
         return row_major, frag
 
     def _build(self):
         arr = (_lib.PackJob * len(self.jobs))()
         self.max_chunks = 0
-        for j, (w, rm, fr, scale, tr, row0) in zip(arr, self.jobs):
+        for j, (w, rm, fr, scale, tr, row0, k0, k_total) in zip(arr, self.jobs):
             R, K = (w.shape[1], w.shape[0]) if tr else w.shape
             Kp = (K + 31) // 32 * 32 if fr is not None else (K + 7) // 8 * 8
             j.w, j.row_major, j.frag = w.data_ptr(), (rm.data_ptr() if rm is not None else None), (fr.data_ptr() if fr is not None else None)
             j.ld_w, j.ld_row_major = w.stride(0), (rm.stride(0) if rm is not None else 0)
             j.R, j.K, j.dst_row0, j.Kp, j.scale, j.transposed = R, K, row0, Kp, scale, int(tr)
+            j.k0, j.Kp_dst = k0, k_total
             self.max_chunks = max(self.max_chunks, ((R + 15) // 16 * 16) * (Kp // 8))
         raw = bytes(arr)
         self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
@@ -440,6 +444,25 @@ def ffn_bwd(x, dy, ln_g, ln_b, w1p, b1, w2tp, w1tp, d_ffn, alpha=0.5, drop_hidde
                                     _ptr(a), _ptr(h), _ptr(dh), _ptr(dx), _ptr(gb), M, D, d_ffn, float(alpha), drop_hidden,
                                     drop_out, _ptr(dyd), _ptr(ws), nws, _stream()))
     return dx, gb[0], gb[1], a, h, dh, dyd
+
+
+def qkv_in_bwd(dqkv, wqkvT_p, x, dy, ln_g, ln_b):
+    """Input side of the q | k | v projection's backward in one kernel (csship_qkv_in_bwd): dqkv bf16 [M, 768],
+    x / dy f32 [M, 256], M % 64 == 0.  Returns (dx, dgamma, dbeta, y) with y = LayerNorm(x) as bf16."""
+    _need(dqkv, torch.bfloat16, "dqkv"), _need(x, torch.float32, "x"), _need(dy, torch.float32, "dy")
+    M, D = x.shape
+    if not (x.is_contiguous() and dy.is_contiguous() and dqkv.is_contiguous()) or dy.shape != x.shape or \
+            dqkv.shape != (M, 3 * D):
+        raise RuntimeError("css_amd: qkv_in_bwd expects dense x, dy [M, 256] and dqkv [M, 768]")
+    dev = x.device
+    y = torch.empty((M, D), dtype=torch.bfloat16, device=dev)
+    dx = torch.empty_like(x)
+    gb = torch.empty((2, D), dtype=torch.float32, device=dev)
+    nws = lib().csship_qkv_in_bwd_workspace(M)
+    ws = _workspace(nws, dev, own=True)
+    check(lib().csship_qkv_in_bwd(_ptr(dqkv), _ptr(wqkvT_p), _ptr(x), _ptr(dy), _ptr(ln_g), _ptr(ln_b), _ptr(dx), _ptr(y),
+                                  _ptr(gb), M, D, _ptr(ws), nws, _stream()))
+    return dx, gb[0], gb[1], y
 
 
 def attn_rowdot(d_out, out, B, T, H):

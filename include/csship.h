@@ -812,9 +812,24 @@ typedef struct csship_pack_job {
   int32_t R, K, dst_row0, Kp;
   float scale;
   int32_t transposed;
+  int32_t k0, Kp_dst;  /* frag only: this job fills the k-slice [k0, k0 + Kp) of a table Kp_dst wide (k0 % 32 == 0);
+                          Kp_dst = 0: the table is Kp wide (k0 must be 0) */
 } csship_pack_job;
 int csship_pack_weights_multi(const csship_pack_job* jobs_device, int32_t n_jobs, int64_t max_chunks,
                               csship_stream_t stream);
+
+/* ---- csship_qkv_in_bwd (css_amd/csrc/panel.hip): the input side of the q | k | v projection's backward in one kernel
+ * per 64-row panel.  Forward (conformer.py:213-224,356): qkv = LayerNorm(x) Wqkv^T + b, out = x + attention(qkv) ...;
+ * given dqkv (bf16 [M, 768]) and dy = d(out) (f32 [M, 256]):
+ *   da = dqkv Wqkv (wqkvT_packed = MFMA fragments of Wqkv^T [256, 768], the q rows of Wqkv carrying the forward's
+ *   1/sqrt(d_k)); dx = dy + LayerNorm-backward(da); y_bf16 = LayerNorm(x) (operand of dWqkv = dqkv^T y);
+ *   dgamma_dbeta = f32 [2, 256].
+ * d_model 256, M % 64 == 0 (CSSHIP_EUNSUPPORTED otherwise: csship_bgemm + csship_layernorm_bwd_y serve those).
+ * dx may alias dy. */
+size_t csship_qkv_in_bwd_workspace(int32_t M);
+int csship_qkv_in_bwd(const uint16_t* dqkv, const uint16_t* wqkvT_packed, const float* x, const float* dy,
+                      const float* ln_g, const float* ln_b, float* dx, uint16_t* y_bf16, float* dgamma_dbeta,
+                      int32_t M, int32_t d_model, void* workspace, size_t workspace_bytes, csship_stream_t stream);
 
 /* ---- BLSTM recurrence, training (css_amd/csrc/lstm.hip).  csship_lstm_bidir_train = csship_lstm_bidir that also keeps
  * the activated gates (i, f, g, o; f32 [B, T, 2, 4H]) and the cell states (f32 [B, T, 2, H]).

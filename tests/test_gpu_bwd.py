@@ -180,6 +180,47 @@ def test_layernorm_bwd_and_relu_bwd(ob):
     assert torch.equal(got.cpu(), torch.where(y > 0, dyy.cpu(), torch.zeros(())))
 
 
+def test_qkv_in_bwd_equals_gemm_plus_layernorm_backward(ob):
+    """csship_qkv_in_bwd: da = dqkv Wqkv (fragments of Wqkv^T packed as three k-slices of one table), the LayerNorm
+    backward, the residual gradient and y = LayerNorm(x) in one kernel vs float64 autograd on the same bf16 operands;
+    also the panel form of a 256 -> 256 input gradient (no bias, bf16 out)"""
+    from css_amd import ops
+    D, M = 256, 640
+    x, dy = rnd((M, D), 21), rnd((M, D), 22)
+    g, b = 1 + 0.1 * rnd((D,), 23), 0.1 * rnd((D,), 24)
+    ws = [rnd((D, D), 25 + i, 0.06) for i in range(3)]
+    dqkv = rnd((M, 3 * D), 29, 0.5).to(torch.bfloat16)
+    scale = 0.125
+    plan = ob.PackPlan(torch.device(DEV))
+    wt = torch.empty(3 * D * D, dtype=torch.bfloat16, device=DEV)
+    wd = [w.to(DEV) for w in ws]
+    for i, w in enumerate(wd):
+        plan.add(w, scale=scale if i == 0 else 1.0, transposed=True, frag=wt, k0=i * D, k_total=3 * D)
+    plan.run()
+    # the same table from one transposed job over the concatenated (scaled) weight
+    wcat = torch.cat([wd[0] * scale, wd[1], wd[2]], 0).contiguous()          # [768, 256]
+    _, wt_one = ob.pack_weight(wcat.t().contiguous(), want_frag=True)           # logical [256, 768]
+    assert torch.equal(wt, wt_one)
+    dx, dg, dbeta, y = ob.qkv_in_bwd(dqkv.to(DEV), wt, x.to(DEV), dy.to(DEV), g.to(DEV), b.to(DEV))
+    da = dqkv.double() @ bf(wcat.cpu()).double()
+    xr = x.double().clone().requires_grad_(True)
+    gr, br = g.double().clone().requires_grad_(True), b.double().clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-5)
+    yr.backward(da)
+    assert relerr(dx, xr.grad + dy.double()) < 2e-5
+    assert relerr(dg, gr.grad) < 2e-5 and relerr(dbeta, br.grad) < 2e-5
+    assert float((y.double().cpu() - yr.detach()).abs().max()) <= 2.0 ** -8 * float(yr.detach().abs().max()) + 1e-6
+    # panel input gradient: dao = dyb Wo against the fragment-packed Wo^T
+    wo = rnd((D, D), 31, 0.06).to(DEV)
+    _, wo_tp = ob.pack_weight(wo.t().contiguous(), want_frag=True)
+    dyb = rnd((M, D), 32).to(torch.bfloat16)
+    dao = ops.panel_linear(dyb.to(DEV), wo_tp, None, D, out_bf16=True)
+    ref = dyb.double() @ bf(wo.cpu()).double()
+    assert float((dao.double().cpu() - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max()) + 1e-6
+    with pytest.raises(RuntimeError):   # whole panels only
+        ob.qkv_in_bwd(dqkv[:100].to(DEV), wt, x[:100].to(DEV), dy[:100].to(DEV), g.to(DEV), b.to(DEV))
+
+
 def test_ffn_and_head_backward(ob):
     """gradients of the FeedForward block and of the mask head vs float64 autograd of the oracle formulas"""
     from css_amd import backward as bw, ops
