@@ -136,6 +136,10 @@ SIGNATURES = {
     "csship_bgemm_wgrad": (_i32, [_p, _p, _p, _p, _p, C.POINTER(BgemmParams), _f32, _i32, _p, _sz, _p]),
     "csship_reduce_defer": (_i32, [_i32]),
     "csship_reduce_hold": (_i32, [_i32]),
+    "csship_wgrad_hold": (_i32, [_i32]),
+    "csship_wgrad_pending": (_i32, []),
+    "csship_wgrad_group_workspace": (_sz, []),
+    "csship_wgrad_flush": (_i32, [_p, _sz, _p]),
     "csship_reduce_pending": (_i32, []),
     "csship_reduce_flush": (_i32, [_p]),
     "csship_colsum_workspace": (_sz, [_i64, _i32]),

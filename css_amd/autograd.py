@@ -385,7 +385,7 @@ class ConformerTrain(torch.autograd.Function):
                 G[p] = g
 
         # the reductions behind the parameter gradients of a block run as ONE launch at its end (ops_bwd.deferred_reductions)
-        with ob.deferred_reductions() as red:
+        with ob.deferred_reductions(group_wgrads=not S["wide"]) as red:
             return ConformerTrain._backward(ctx, grad_masks, model, S, G, put, red)
 
     @staticmethod

@@ -255,8 +255,9 @@ constexpr int GL_STAGES = 4;  // 128 KB of the CU's 160 KB: one workgroup per CU
 #define GL_WAIT_TILE_(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define GL_WAIT_TILE() GL_WAIT_TILE_(16)
 static_assert(8 * (GL_STAGES - 2) == 16, "GL_WAIT_TILE: 8 LDS-DMA instructions per wave and tile, GL_STAGES - 2 newer tiles in flight");
+// one 128 x TN output tile (bx, by) of batch entry / reduction split bz; the kernels below pick the tile
 template <bool A_KM, bool B_KM, bool FAST, bool A_F32, bool B_F32, bool COLSUM = false, int TN = 128, bool GL = false>
-__global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
+DEV void bgemm_tile(const BgemmArgs& g, const int bx, const int by, const int bz) {
   static_assert(TN == 128 || (TN == 64 && FAST), "narrow tiles use the descriptor loaders");
   static_assert(!GL || (A_KM && B_KM && FAST && !A_F32 && !B_F32 && TN == 128), "LDS-DMA path: bf16 k-major operands, 128 x 128 tiles");
   constexpr int NJ = TN / 32, WN = TN / 2;  // 16-column fragments per wave, columns per wave
@@ -271,23 +272,6 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
 #endif
   const int wm = wave >> 1, wn = wave & 1;
   const int lg = lane >> 4, ln = lane & 15;
-  // XCD-aware tile order.  Workgroups go to the 8 XCDs round-robin by their linear id, and every XCD has its own L2:
-  // in the natural order the tiles that share operand rows (all output tiles of one K-split, or of one batch entry)
-  // land on 8 different XCDs and each pulls the same rows through its own L2 (166 MB of L2 fills for 39 MB of
-  // operands in the FeedForward dW product).  Here the workgroups of one XCD walk all tiles of one (batch, split)
-  // slice before the next, so the re-reads hit that XCD's L2.
-  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  {
-    const unsigned tiles = gridDim.x * gridDim.y, nz = gridDim.z;
-    if ((nz & 7) == 0) {
-      const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-      const unsigned xcd = lin & 7, j = lin >> 3;
-      const unsigned t = j % tiles;
-      bz = (j / tiles) * 8 + xcd;
-      bx = t % gridDim.x;
-      by = t / gridDim.x;
-    }
-  }
   const int m0 = by * 128, n0 = bx * TN;
   const int z = bz / g.splits, split = bz % g.splits;
   const int z1 = z / g.nb2, z2 = z % g.nb2;
@@ -640,6 +624,67 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
 #endif
 }
 
+template <bool A_KM, bool B_KM, bool FAST, bool A_F32, bool B_F32, bool COLSUM = false, int TN = 128, bool GL = false>
+__global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
+  // XCD-aware tile order.  Workgroups go to the 8 XCDs round-robin by their linear id, and every XCD has its own L2:
+  // in the natural order the tiles that share operand rows (all output tiles of one K-split, or of one batch entry)
+  // land on 8 different XCDs and each pulls the same rows through its own L2 (166 MB of L2 fills for 39 MB of
+  // operands in the FeedForward dW product).  Here the workgroups of one XCD walk all tiles of one (batch, split)
+  // slice before the next, so the re-reads hit that XCD's L2.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  {
+    const unsigned tiles = gridDim.x * gridDim.y, nz = gridDim.z;
+    if ((nz & 7) == 0) {
+      const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      const unsigned xcd = lin & 7, j = lin >> 3;
+      const unsigned t = j % tiles;
+      bz = (j / tiles) * 8 + xcd;
+      bx = t % gridDim.x;
+      by = t / gridDim.x;
+    }
+  }
+  bgemm_tile<A_KM, B_KM, FAST, A_F32, B_F32, COLSUM, TN, GL>(g, bx, by, bz);
+}
+
+// ---- the weight gradients of a whole encoder block as ONE launch (csship_wgrad_hold / csship_wgrad_flush).
+// Launched one by one, each of the block's six products (four FeedForward weights, q | k | v, the output projection:
+// 64 + 12 + 4 tiles of 128 x 128, all reducing over the same B*T rows) has to cut its reduction into 16-64 pieces to
+// occupy 256 CUs: a workgroup runs 3-12 tiles of k, most of its time is pipeline fill and the 64 KB slab it writes, and
+// the block moves ~200 MB of slabs.  Together they are 80 tiles: three pieces of the reduction fill the chip once,
+// every workgroup streams 67 tiles of k and the slabs shrink to 16 MB.  The table maps workgroup -> (product, split,
+// tile) so that the workgroups of one XCD (linear id mod 8) walk whole (product, split) units: tiles of one unit share
+// operand rows and run in step, so the re-reads hit that XCD's L2.
+constexpr int WG_JOBS = 12, WG_MAXWG = 1024;
+constexpr unsigned short WG_IDLE = 0xFFFFu;
+struct WgJob {
+  const void* A;  // dY  bf16 [K, M] (row stride lda)
+  const void* B;  // X   bf16 [K, N] (row stride ldb)
+  float* C;       // [splits][M * N] slabs
+  float* cs;      // [splits][M] column-sum slabs
+  int M, N, lda, ldb;
+};
+struct WgGroup {
+  WgJob job[WG_JOBS];
+  int K, splits, k_per_split, pad;
+  unsigned short map[WG_MAXWG];  // job << 12 | split << 8 | tile
+};
+
+__global__ __launch_bounds__(256) void bgemm_wgrad_group_kernel(WgGroup G) {
+  const unsigned e = G.map[blockIdx.x];
+  if (e == WG_IDLE) return;
+  const WgJob& J = G.job[e >> 12];
+  BgemmArgs g{};
+  g.A = J.A; g.B = J.B; g.C = J.C;
+  g.M = J.M; g.N = J.N; g.K = G.K;
+  g.lda = J.lda; g.ldb = J.ldb; g.ldc = J.N;
+  g.nb2 = 1; g.splits = G.splits; g.k_per_split = G.k_per_split;
+  g.slab = (int64_t)J.M * J.N;
+  g.alpha = 1.f;
+  g.cs_slab = J.cs;
+  const int tx = J.N >> 7, tile = (int)(e & 255u);
+  bgemm_tile<true, true, true, false, false, true, 128, true>(g, tile % tx, tile / tx, (int)((e >> 8) & 15u));
+}
+
 // out[r, c] = alpha * sum_s slab[s][r, c] (+ bias[c]) (+ add[r, c]); fixed summation order.
 // Workgroup = 64 lanes x V consecutive elements x NW waves; wave w adds slabs w, w+NW, ... with eight loads in flight,
 // then one LDS reduction - short outputs with many slabs (LayerNorm / bias partials) do not serialise on one thread,
@@ -899,6 +944,133 @@ extern "C" int csship_reduce_hold(int32_t on) {
 
 extern "C" int csship_reduce_pending(void) { return (int)t_defer.jobs.size(); }
 
+// ---- grouped weight gradients (bgemm_wgrad_group_kernel): csship_bgemm_wgrad calls made while the hold is on are
+// queued when they fit the LDS-DMA loop (bf16 k-major operands in whole tiles, at most 256 tiles) and share the queue's
+// reduction length; anything else runs at once, as without the hold.
+struct WgradQ {
+  const void* A; const void* B; float* dW; float* db; const void* aux;
+  int M, N, K; int64_t lda, ldb, ldc, ldaux;
+  float alpha, alpha_head; int head_rows, epi;
+};
+static thread_local bool t_wq_on = false;
+static thread_local std::vector<WgradQ> t_wq;
+
+extern "C" int csship_wgrad_hold(int32_t on) {
+  const int was = t_wq_on ? 1 : 0;
+  t_wq_on = on != 0;
+  if (!on) t_wq.clear();  // leaving the mode without a flush (error paths) drops what was queued
+  return was;
+}
+
+extern "C" int csship_wgrad_pending(void) { return (int)t_wq.size(); }
+
+static int wgrad_group_splits(size_t first, size_t count) {
+  int tiles = 0;
+  for (size_t i = first; i < first + count; ++i) tiles += (t_wq[i].M / 128) * (t_wq[i].N / 128);
+  const int kt = t_wq[first].K / BK;
+  int s = tiles > 0 ? 256 / tiles : 2;
+  s = std::max(2, std::min(s, 16));
+  while (s > 2 && (tiles * s > WG_MAXWG - 8 * 32 || kt / s < 8)) --s;
+  return std::min(s, std::max(1, kt));
+}
+
+// the queue is flushed in chunks of at most WG_JOBS products whose tiles x 2 fit the table
+static size_t wgrad_chunk(size_t first) {
+  size_t n = 0;
+  int tiles = 0;
+  while (first + n < t_wq.size() && n < (size_t)WG_JOBS) {
+    const int t = (t_wq[first + n].M / 128) * (t_wq[first + n].N / 128);
+    if (n > 0 && (tiles + t) * 2 > WG_MAXWG - 8 * 32) break;
+    tiles += t;
+    ++n;
+  }
+  return n;
+}
+
+extern "C" size_t csship_wgrad_group_workspace(void) {
+  size_t need = 0;
+  for (size_t at = 0; at < t_wq.size();) {
+    const size_t n = wgrad_chunk(at);
+    const int s = wgrad_group_splits(at, n);
+    size_t b = 0;
+    for (size_t i = at; i < at + n; ++i) b += (size_t)s * ((size_t)t_wq[i].M * t_wq[i].N + t_wq[i].M) * sizeof(float);
+    need += b;   // chunks keep their own slabs: one reduction launch at the end reads them all
+    at += n;
+  }
+  return need;
+}
+
+extern "C" int csship_wgrad_flush(void* workspace, size_t workspace_bytes, csship_stream_t stream) {
+  if (t_wq.empty()) return CSSHIP_OK;
+  if (!workspace || workspace_bytes < csship_wgrad_group_workspace()) {
+    t_wq.clear();
+    return CSSHIP_EWORKSPACE;
+  }
+  hipStream_t s = as_stream(stream);
+  float* ws = reinterpret_cast<float*>(workspace);
+  const bool held = t_hold;
+  int rc = CSSHIP_OK;
+  for (size_t at = 0; at < t_wq.size() && rc == CSSHIP_OK;) {
+    const size_t n = wgrad_chunk(at);
+    const int S = wgrad_group_splits(at, n);
+    WgGroup G{};
+    G.K = t_wq[at].K;
+    G.splits = S;
+    const int kt = G.K / BK;
+    G.k_per_split = ((kt + S - 1) / S) * BK;
+    // (product, split) units, largest first, each to the XCD with the fewest workgroups so far
+    struct Unit { int job, split, tiles; };
+    std::vector<Unit> units;
+    for (size_t i = 0; i < n; ++i) {
+      const WgradQ& q = t_wq[at + i];
+      WgJob& J = G.job[i];
+      J.A = q.A; J.B = q.B; J.M = q.M; J.N = q.N; J.lda = (int)q.lda; J.ldb = (int)q.ldb;
+      J.C = ws;
+      ws += (size_t)S * q.M * q.N;
+      J.cs = ws;
+      ws += (size_t)S * q.M;
+      for (int sp = 0; sp < S; ++sp) units.push_back(Unit{(int)i, sp, (q.M / 128) * (q.N / 128)});
+    }
+    std::stable_sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.tiles > b.tiles; });
+    std::vector<unsigned short> xcd[8];
+    for (const Unit& u : units) {
+      int best = 0;
+      for (int x = 1; x < 8; ++x)
+        if (xcd[x].size() < xcd[best].size()) best = x;
+      for (int t = 0; t < u.tiles; ++t) xcd[best].push_back((unsigned short)(u.job << 12 | u.split << 8 | t));
+    }
+    size_t slots = 0;
+    for (int x = 0; x < 8; ++x) slots = std::max(slots, xcd[x].size());
+    if (slots * 8 > (size_t)WG_MAXWG) {
+      rc = CSSHIP_EBADSHAPE;
+      break;
+    }
+    for (size_t sl = 0; sl < slots; ++sl)
+      for (int x = 0; x < 8; ++x) G.map[sl * 8 + x] = sl < xcd[x].size() ? xcd[x][sl] : WG_IDLE;
+    hipLaunchKernelGGL(bgemm_wgrad_group_kernel, dim3((unsigned)(slots * 8)), dim3(256), 0, s, G);
+    if (hipGetLastError() != hipSuccess) {
+      rc = CSSHIP_ELAUNCH;
+      break;
+    }
+    // the slab sums: queued behind whatever the caller has deferred, one launch for all of them below
+    t_hold = true;
+    for (size_t i = 0; i < n && rc == CSSHIP_OK; ++i) {
+      const WgradQ& q = t_wq[at + i];
+      rc = launch_slab_reduce2(G.job[i].C, S, (int64_t)q.M * q.N, q.N, q.ldc, q.alpha, nullptr,
+                               (q.epi & CSSHIP_BEPI_ADD) ? reinterpret_cast<const float*>(q.aux) : nullptr, q.ldaux, q.dW,
+                               G.job[i].cs, (int64_t)q.M, q.db, s, q.alpha_head, q.head_rows);
+    }
+    t_hold = held;
+    at += n;
+  }
+  t_wq.clear();
+  if (rc != CSSHIP_OK) {
+    t_defer.jobs.clear();
+    return rc;
+  }
+  return csship_reduce_flush(stream);
+}
+
 extern "C" int csship_reduce_flush(csship_stream_t stream) {
   hipStream_t s = as_stream(stream);
   std::vector<ReduceJob>& q = t_defer.jobs;
@@ -979,6 +1151,12 @@ static int bgemm_impl(const void* A, const void* B, void* C, const float* bias, 
     return CSSHIP_EALIGN;
   if (p->lda < (p->a_kmajor ? p->M : p->K) || p->ldb < (p->b_kmajor ? p->N : p->K) || p->ldc < p->N)
     return CSSHIP_EBADSHAPE;
+  if (t_wq_on && colsum_out && !bias && p->splits == 0 && glds_path(p, true) && (p->M / 128) * (p->N / 128) <= 256 &&
+      p->K >= 16 * BK && (p->ldc & 3) == 0 && aligned16(C) && (t_wq.empty() || t_wq[0].K == p->K)) {
+    t_wq.push_back(WgradQ{A, B, reinterpret_cast<float*>(C), colsum_out, aux, p->M, p->N, p->K, p->lda, p->ldb, p->ldc, p->ldaux,
+                          p->alpha, alpha_head, head_rows, p->epilogue});
+    return CSSHIP_OK;
+  }
   const int splits = pick_splits(p, colsum_out != nullptr);
   const int64_t nz = (int64_t)p->batch1 * p->batch2 * splits;
   if (nz > 65535) return CSSHIP_EBADSHAPE;

@@ -16,8 +16,9 @@ _ws_cache = {}
 
 
 _deferred_ws = []   # workspaces of the calls whose reductions are queued (csship_reduce_defer): alive until the flush
-_defer = {"on": False}
+_defer = {"on": False, "group": False, "dev": None}
 _NO_DEFER = bool(os.environ.get("CSSHIP_NO_DEFER"))
+_NO_GROUP = bool(os.environ.get("CSSHIP_NO_GROUP_WGRAD"))   # A/B timing: every weight-gradient product as its own launch
 
 
 class deferred_reductions:
@@ -26,16 +27,30 @@ class deferred_reductions:
     ``flush()`` (include/csship.h, csship_reduce_defer).  Those calls get their own workspace, kept until the flush.  Nobody may read those gradients before the flush; the
     exit flushes what is left (or drops it when an exception is travelling)."""
 
+    def __init__(self, group_wgrads=False):
+        self.group = bool(group_wgrads) and not _NO_GROUP and not _NO_DEFER
+
     def __enter__(self):
         if _NO_DEFER:   # A/B timing: every reduction as its own launch
             self.was = 1
             return self
         self.was = lib().csship_reduce_defer(1)
         _defer["on"] = True
+        if self.group:   # weight-gradient products queued too: one launch per flush (csship_wgrad_hold)
+            self.was_group = lib().csship_wgrad_hold(1)
+            _defer["group"] = True
         return self
 
     def flush(self):
-        if lib().csship_reduce_pending():
+        if lib().csship_wgrad_pending():
+            nws = lib().csship_wgrad_group_workspace()
+            dev = _defer["dev"]
+            key = ("group", dev, torch.cuda.current_stream().cuda_stream)
+            ws = _ws_cache.get(key)
+            if ws is None or ws.numel() < nws:
+                ws = _ws_cache[key] = torch.empty(nws, dtype=torch.uint8, device=dev)
+            check(lib().csship_wgrad_flush(_ptr(ws), nws, _stream()))
+        elif lib().csship_reduce_pending():
             check(lib().csship_reduce_flush(_stream()))
         _deferred_ws.clear()
 
@@ -44,6 +59,9 @@ class deferred_reductions:
             if et is None:
                 self.flush()
         finally:
+            if self.group and not self.was_group:
+                lib().csship_wgrad_hold(0)
+                _defer["group"] = False
             if not self.was:
                 lib().csship_reduce_defer(0)
                 _defer["on"] = False
@@ -62,7 +80,7 @@ class paired_reductions:
     Every product inside gets a workspace of its own, alive until the flush."""
 
     def __enter__(self):
-        if not _NO_PAIR:
+        if not _NO_PAIR and not _defer["group"]:   # (grouped weight gradients: the products themselves are queued)
             lib().csship_reduce_hold(1)
             _hold["on"] = True
         return self
@@ -198,6 +216,9 @@ def linear_wgrad(dy, x, alpha=1.0, dw_out=None, db_out=None, head=None):
                          alpha=float(alpha))
     nws = lib().csship_bgemm_wgrad_workspace(C.byref(p))
     ws = _workspace(nws, dy.device) if nws else None
+    if _defer["group"]:   # the product may be queued until the flush: operands and outputs stay alive till then
+        _deferred_ws.append((dy, x, dw, db))
+        _defer["dev"] = dy.device
     check(lib().csship_bgemm_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), None, C.byref(p),
                                    float(head[1]) if head else 0.0, int(head[0]) if head else 0, _ptr(ws), nws, _stream()))
     return dw, db

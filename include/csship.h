@@ -610,6 +610,18 @@ int csship_reduce_defer(int32_t on);
 int csship_reduce_hold(int32_t on);
 int csship_reduce_pending(void);
 int csship_reduce_flush(csship_stream_t stream);
+/* Grouped weight gradients.  Between csship_wgrad_hold(1) and csship_wgrad_flush() the calling host thread's
+ * csship_bgemm_wgrad calls that fit the LDS-DMA loop (bf16 operands, M and N multiples of 128, K a multiple of 64 and
+ * the same for all of them, at most 256 tiles, no bias) are queued and run by the flush as ONE launch over all their
+ * tiles, the reduction cut only as often as fills the chip once (an encoder block's six products: 80 tiles x 3 pieces
+ * instead of 16-64 pieces each), followed by one reduction launch (csship_reduce_flush, which also runs whatever else
+ * is queued).  Contract: operands and outputs of a queued call stay valid and unread until the flush; its per-call
+ * workspace is not used.  Other calls run at once.  workspace: csship_wgrad_group_workspace() bytes (for what is
+ * queued at that moment).  csship_wgrad_hold returns the previous mode; switching off drops what is still queued. */
+int csship_wgrad_hold(int32_t on);
+int csship_wgrad_pending(void);
+size_t csship_wgrad_group_workspace(void);
+int csship_wgrad_flush(void* workspace, size_t workspace_bytes, csship_stream_t stream);
 
 /* out[c] = alpha * sum_r x[r, c] for x f32 or bf16 [M, N] (row stride ld): the bias gradient of a Linear. */
 size_t csship_colsum_workspace(int64_t M, int32_t N);

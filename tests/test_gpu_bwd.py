@@ -221,6 +221,40 @@ def test_qkv_in_bwd_equals_gemm_plus_layernorm_backward(ob):
         ob.qkv_in_bwd(dqkv[:100].to(DEV), wt, x[:100].to(DEV), dy[:100].to(DEV), g.to(DEV), b.to(DEV))
 
 
+def test_grouped_weight_gradients_equal_the_single_products(ob):
+    """csship_wgrad_hold / csship_wgrad_flush: the weight-gradient products of a block queued and run as ONE launch (the
+    reduction cut 2-3 times instead of 16-64) vs float64 on the same bf16 operands and vs the products one by one; a
+    product that does not fit the grouped loop (f32 operand, ragged width) runs at once inside the scope"""
+    K = 6400
+    shapes = [(1024, 256), (256, 1024), (768, 256), (256, 256), (128, 384)]
+    ops_ = []
+    for i, (M, N) in enumerate(shapes):
+        dy = rnd((K, M), 40 + i, 0.5).to(torch.bfloat16).to(DEV)
+        x = rnd((K, N), 50 + i, 0.5).to(torch.bfloat16).to(DEV)
+        ops_.append((dy, x))
+    single = [ob.linear_wgrad(dy, x, 0.5, head=(64, 0.25)) for dy, x in ops_]
+    odd_dy, odd_x = rnd((K, 72), 60).to(DEV), rnd((K, 200), 61).to(torch.bfloat16).to(DEV)
+    odd_ref = ob.linear_wgrad(odd_dy, odd_x)
+    with ob.deferred_reductions(group_wgrads=True) as red:
+        grouped = [ob.linear_wgrad(dy, x, 0.5, head=(64, 0.25)) for dy, x in ops_]
+        assert ob.lib().csship_wgrad_pending() == len(shapes)
+        odd = ob.linear_wgrad(odd_dy, odd_x)          # not queued
+        assert ob.lib().csship_wgrad_pending() == len(shapes)
+        red.flush()
+        assert ob.lib().csship_wgrad_pending() == 0
+        again = ob.linear_wgrad(*ops_[0], 0.5, head=(64, 0.25))   # left to the exit's flush
+    assert ob.lib().csship_wgrad_pending() == 0
+    assert torch.equal(odd[0], odd_ref[0]) and torch.equal(odd[1], odd_ref[1])
+    for (dy, x), (dw1, db1), (dw2, db2) in zip(ops_, single, grouped):
+        ref = dy.double().cpu().T @ x.double().cpu() * 0.5
+        ref[:64] *= 0.5
+        rb = dy.double().cpu().sum(0) * 0.5
+        rb[:64] *= 0.5
+        assert froerr(dw2, ref) < 2e-6 and froerr(db2, rb) < 2e-6
+        assert froerr(dw2, dw1.double().cpu()) < 2e-6 and froerr(db2, db1.double().cpu()) < 2e-6
+    assert froerr(again[0], single[0][0].double().cpu()) < 2e-6
+
+
 def test_ffn_and_head_backward(ob):
     """gradients of the FeedForward block and of the mask head vs float64 autograd of the oracle formulas"""
     from css_amd import backward as bw, ops
