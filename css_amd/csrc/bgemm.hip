@@ -251,7 +251,7 @@ __device__ unsigned* g_bg_stamps = nullptr;
 // one wave per SIMD (request loads 580 cycles, fragments 380, MFMAs 620, wait + LDS store 364, barrier 144 per
 // 64-deep tile).  The LDS image is lane-linear per wave instruction, so the bank swizzle of km_off is applied to
 // the SOURCE address (XOR is its own inverse).
-constexpr int GL_STAGES = 4;  // 128 KB of the CU's 160 KB: one workgroup per CU, 96 KB of operands in flight
+constexpr int GL_STAGES = 4;  // 128 KB of the CU's 160 KB: one workgroup per CU, 96 KB of operands in flight (5 stages: no faster, measured)
 #define GL_WAIT_TILE_(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define GL_WAIT_TILE() GL_WAIT_TILE_(16)
 static_assert(8 * (GL_STAGES - 2) == 16, "GL_WAIT_TILE: 8 LDS-DMA instructions per wave and tile, GL_STAGES - 2 newer tiles in flight");
@@ -765,7 +765,7 @@ struct ReduceJob {
   const float* add;
   float* out;
   int64_t n, ldc, ldadd;
-  int S, N, head_rows, kind;  // kind: 0 = <4,4,8>, 1 = <1,16,8>, 2 = <1,4,4>; | 4 = tail output
+  int S, N, head_rows, kind;  // kind: 0 = <4,4,8>, 1 = <1,16,8>, 2 = <1,4,4>, 3 = flat (S <= 4); | 4 = tail output
   float alpha, alpha_head;
   int nvb, pad_;              // virtual workgroups
 };
@@ -775,6 +775,33 @@ struct ReduceBatch {
   int njobs;
 };
 
+// at most four slabs of a long output (the grouped weight gradients: 2-3 pieces of the reduction): one thread per four
+// consecutive elements sums them with all loads in flight; the wave-per-slab structure above would issue 32 loads per
+// element group for the three it needs.
+DEV void slab_sum_flat(const ReduceJob& q, int wg, int t, bool tail) {
+  const int64_t i = ((int64_t)wg * 1024 + t) * 4;
+  if (i >= q.n) return;
+  float4 v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4*>(q.slabs + (int64_t)min(k, q.S - 1) * q.n + i);
+  float4 a = v[0];
+#pragma unroll
+  for (int k = 1; k < 4; ++k)
+    if (k < q.S) { a.x += v[k].x; a.y += v[k].y; a.z += v[k].z; a.w += v[k].w; }
+  const int64_t r = i / q.N, c = i % q.N;
+  const float al = (tail ? c : r) < q.head_rows ? q.alpha_head : q.alpha;  // (tail: head_rows % 4 == 0 on this path)
+  float4 o = make_float4(al * a.x, al * a.y, al * a.z, al * a.w);
+  if (q.bias) {
+    const float4 bq = *reinterpret_cast<const float4*>(q.bias + c);
+    o.x += bq.x; o.y += bq.y; o.z += bq.z; o.w += bq.w;
+  }
+  if (q.add) {
+    const float4 ad = *reinterpret_cast<const float4*>(q.add + r * q.ldadd + c);
+    o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
+  }
+  *reinterpret_cast<float4*>(q.out + r * q.ldc + c) = o;
+}
+
 __global__ __launch_bounds__(1024) void slab_reduce_batch_kernel(ReduceBatch b) {
   __shared__ __attribute__((aligned(16))) float red[4][4][64][4];
   int j = 0;
@@ -783,7 +810,9 @@ __global__ __launch_bounds__(1024) void slab_reduce_batch_kernel(ReduceBatch b) 
   const int wg = blockIdx.x - b.first[j], t = threadIdx.x;
   const int kind = q.kind & 3;
   const bool tail = (q.kind & 4) != 0;
-  if (kind == 1) {
+  if (kind == 3) {
+    slab_sum_flat(q, wg, t, tail);
+  } else if (kind == 1) {
     slab_reduce_body<1, 16, 8>(q.slabs, q.S, q.n, q.N, q.ldc, q.alpha, q.bias, q.add, q.ldadd, q.out, q.alpha_head,
                                q.head_rows, tail, wg, t, reinterpret_cast<float(*)[64][1]>(&red[0][0][0][0]));
   } else {
@@ -879,13 +908,14 @@ struct DeferQueue {
 };
 static thread_local DeferQueue t_defer;
 static thread_local bool t_hold = false;   // csship_reduce_hold: queue EVERY slab reduction, whatever its size
+static thread_local bool t_flat = false;   // csship_wgrad_flush: long outputs of at most four slabs take slab_sum_flat
 
 static void queue_job(const float* slabs, int S, int64_t n, int N, int64_t ldc, float alpha, const float* bias,
                       const float* add, int64_t ldadd, float* out, float alpha_head, int head_rows, int kind) {
   ReduceJob j{};
   j.slabs = slabs; j.bias = bias; j.add = add; j.out = out; j.n = n; j.ldc = ldc; j.ldadd = ldadd; j.S = S; j.N = N;
   j.head_rows = head_rows; j.kind = kind; j.alpha = alpha; j.alpha_head = alpha_head;
-  const int v = (kind & 3) == 0 ? 4 : 1;
+  const int v = ((kind & 3) == 0 || (kind & 3) == 3) ? 4 : 1;
   j.nvb = (int)((n / v + 63) / 64);
   t_defer.jobs.push_back(j);
 }
@@ -902,7 +932,9 @@ static int launch_slab_reduce2(const float* slabs, int S, int64_t n, int N, int6
   // against 14 launches x 5.7 us (measured).  The size test keeps that true whatever a caller marks.
   static const int64_t defer_max = (int64_t)4 << 20;
   if (t_hold || (deferrable && t_defer.on && (int64_t)S * (n + n2) * 4 <= defer_max)) {  // the same kernel shape as the launch below would pick, later
-    const int kind = wide ? 0 : (S >= 32 ? 1 : 2);
+    const bool flat = t_flat && wide && S <= 4 && (ldc & 3) == 0 && aligned16(out) && (!bias || aligned16(bias)) &&
+                      (!add || (aligned16(add) && (ldadd & 3) == 0)) && (head_rows & 3) == 0 && aligned16(out2);
+    const int kind = flat ? 3 : wide ? 0 : (S >= 32 ? 1 : 2);
     queue_job(slabs, S, n, N, ldc, alpha, bias, add, ldadd, out, alpha_head, head_rows, kind);
     if (n2 > 0) queue_job(slabs2, S, n2, (int)n2, n2, alpha, nullptr, nullptr, 0, out2, alpha_head, head_rows, kind | 4);
     return CSSHIP_OK;
@@ -1054,6 +1086,7 @@ extern "C" int csship_wgrad_flush(void* workspace, size_t workspace_bytes, csshi
     }
     // the slab sums: queued behind whatever the caller has deferred, one launch for all of them below
     t_hold = true;
+    t_flat = true;
     for (size_t i = 0; i < n && rc == CSSHIP_OK; ++i) {
       const WgradQ& q = t_wq[at + i];
       rc = launch_slab_reduce2(G.job[i].C, S, (int64_t)q.M * q.N, q.N, q.ldc, q.alpha, nullptr,
@@ -1061,6 +1094,7 @@ extern "C" int csship_wgrad_flush(void* workspace, size_t workspace_bytes, csshi
                                G.job[i].cs, (int64_t)q.M, q.db, s, q.alpha_head, q.head_rows);
     }
     t_hold = held;
+    t_flat = false;
     at += n;
   }
   t_wq.clear();
@@ -1081,7 +1115,8 @@ extern "C" int csship_reduce_flush(csship_stream_t stream) {
     for (int j = 0; j < b.njobs; ++j) {
       b.job[j] = q[at + j];
       b.first[j] = wgs;
-      wgs += (b.job[j].kind & 3) == 1 ? b.job[j].nvb : (b.job[j].nvb + 3) / 4;
+      const int k3 = b.job[j].kind & 3;
+      wgs += k3 == 1 ? b.job[j].nvb : k3 == 3 ? (b.job[j].nvb + 15) / 16 : (b.job[j].nvb + 3) / 4;
     }
     b.first[b.njobs] = wgs;
     if (wgs > 0) {
