@@ -930,7 +930,7 @@ static int launch_slab_reduce2(const float* slabs, int S, int64_t n, int N, int6
   // slabs are summed right behind the product, out of the 256 MB MALL, and its scratch is rewritten by the next
   // product without reaching HBM; queued for the end of the block they came back from HBM: 112 us per block for 125 MB
   // against 14 launches x 5.7 us (measured).  The size test keeps that true whatever a caller marks.
-  static const int64_t defer_max = (int64_t)4 << 20;
+  static const int64_t defer_max = (int64_t)8 << 20;
   if (t_hold || (deferrable && t_defer.on && (int64_t)S * (n + n2) * 4 <= defer_max)) {  // the same kernel shape as the launch below would pick, later
     const bool flat = t_flat && wide && S <= 4 && (ldc & 3) == 0 && aligned16(out) && (!bias || aligned16(bias)) &&
                       (!add || (aligned16(add) && (ldadd & 3) == 0)) && (head_rows & 3) == 0 && aligned16(out2);
@@ -1263,7 +1263,10 @@ static int bgemm_impl(const void* A, const void* B, void* C, const float* bias, 
     return launch_slab_reduce2(reinterpret_cast<const float*>(workspace), splits, n, p->N, p->ldc, p->alpha, bias,
                                (p->epilogue & CSSHIP_BEPI_ADD) ? reinterpret_cast<const float*>(aux) : nullptr,
                                p->ldaux, reinterpret_cast<float*>(C), colsum_out ? a.cs_slab : nullptr,
-                               colsum_out ? (int64_t)p->M : 0, colsum_out, s, alpha_head, head_rows);
+                               colsum_out ? (int64_t)p->M : 0, colsum_out, s, alpha_head, head_rows,
+                               // a product accumulated in place (C += ...) is a gradient accumulator nobody reads before
+                               // the block's flush (the relative-position window gradient: 6.5 MB of slabs per block)
+                               !colsum_out && (p->epilogue & CSSHIP_BEPI_ADD) && aux == C);
   }
   return CSSHIP_OK;
 }

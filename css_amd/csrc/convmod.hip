@@ -684,7 +684,8 @@ int run_bwd(const float* x, const float* dy, const csship_conv_weights& w, int B
   hipLaunchKernelGGL((glu_ln_bwd_kernel<D / 256>), dim3(L.nwg_rows), dim3(256), 0, s, x, dg, dy, w.ln_g, w.ln_b, w.pw1_w,
                      w.pw1_b, M, BWD_ROWS, dx, part_c, nx);
   CSSHIP_CHECK_LAUNCH();
-  return launch_slab_reduce(part_c, L.nwg_rows, 2 * D + 4, 2 * D + 4, 2 * D + 4, 1.f, nullptr, nullptr, 0, gC, s);
+  // (parameter gradients only: may join the block's deferred reductions, csship_reduce_defer)
+  return launch_slab_reduce(part_c, L.nwg_rows, 2 * D + 4, 2 * D + 4, 2 * D + 4, 1.f, nullptr, nullptr, 0, gC, s, true);
 }
 
 }  // namespace

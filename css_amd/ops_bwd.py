@@ -181,7 +181,8 @@ def bgemm(a, b, *, a_kmajor=False, b_kmajor=False, out=None, out_bf16=False, alp
                          sX1=bstr(aux)[0] if aux is not None else 0, sX2=bstr(aux)[1] if aux is not None else 0,
                          alpha=float(alpha), band=int(band), band_stride=int(band_stride) if a_kmajor else 0)
     nws = lib().csship_bgemm_workspace(C.byref(p))
-    ws = _workspace(nws, a.device) if nws else None
+    # (a product accumulated in place is a gradient accumulator: its slab sum may wait for the block's flush)
+    ws = _workspace(nws, a.device, own=add is not None and out is not None and add.data_ptr() == out.data_ptr()) if nws else None
     check(lib().csship_bgemm(_ptr(a4), _ptr(b4), _ptr(out), _ptr(bias), _ptr(aux), C.byref(p), _ptr(ws), nws, _stream()))
     return out_ret
 
@@ -321,7 +322,7 @@ def convmod_bwd(x, dy, weights, fwd_ws, kernel_size=33, bn_eval=False, drop=None
     cw = conv_weights_struct(weights)
     dx = torch.empty_like(x)
     nws = lib().csship_convmod_bwd_workspace(B, T, D)
-    ws = _workspace(nws, x.device)
+    ws = _workspace(nws, x.device, own=True)   # (the last pass's partial sums may wait for the block's flush)
     if sync and not bn_eval:  # SyncBatchNorm: the two channel sums of the BN input gradient are over all ranks' rows
         from .parallel import allreduce_sum_
         import torch.distributed as dist
