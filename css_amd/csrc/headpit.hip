@@ -16,6 +16,7 @@
 // ~11 B/clk per CU on 200 CUs), not by the 3.4 GFLOP of the head: 20 us, against 20.6 + 14.9 us for the two kernels it
 // replaces.  Measured and rejected: 32-row panels under a 128-register budget (two workgroups per CU so that one's
 // loads travel while the other multiplies): 25 us - the budget spills and every weight fragment feeds half the MFMAs.
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.hpp"
@@ -38,7 +39,44 @@ struct HeadPitArgs {
   float* partial;        // [n_workgroups][2 slots][K * K]
   int64_t ldf, ldt;
   int M, T;
+  int rpw;               // token rows per workgroup (<= BM; head_pit_split_kernel): rows rpw.. of the 64-row panel are padding
 };
+
+// One thread per sample adds its panels' partials (ascending panel order, double), scans the K! = 2 permutations in
+// itertools order (first minimum wins, like torch.min), then thread 0 averages the samples in order.  Called by all
+// nth threads of one workgroup; best_s: 1024 floats of LDS.
+DEV void pit_finalize_body(const float* __restrict__ partial, int B, int T, int M, double norm, float* __restrict__ loss,
+                           int* __restrict__ perm_out, float* __restrict__ pair_sse, int rpw, int tix, int nth, float* best_s) {
+  constexpr int K = KSPK;
+  for (int b = tix; b < B; b += nth) {
+    double Dm[K][K] = {{0.0, 0.0}, {0.0, 0.0}};
+    const int wg0 = (b * T) / rpw, wg1 = min(((b + 1) * T - 1) / rpw, (M - 1) / rpw);
+    for (int w0 = wg0; w0 <= wg1; w0 += 8) {  // eight panels' partials in flight at a time, added in ascending order
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int wg = min(w0 + u, wg1), sl = b - (wg * rpw) / T;
+        v[u] = *reinterpret_cast<const float4*>(partial + ((size_t)wg * 2 + sl) * K * K);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (w0 + u <= wg1) { Dm[0][0] += (double)v[u].x; Dm[0][1] += (double)v[u].y; Dm[1][0] += (double)v[u].z; Dm[1][1] += (double)v[u].w; }
+    }
+    if (pair_sse)
+      for (int i = 0; i < K * K; ++i) pair_sse[(size_t)b * K * K + i] = (float)Dm[i / K][i % K];
+    const float c0 = (float)((Dm[0][0] + Dm[1][1]) / norm), c1 = (float)((Dm[1][0] + Dm[0][1]) / norm);  // perms (0,1), (1,0)
+    const bool swap = c1 < c0;
+    best_s[b] = swap ? c1 : c0;
+    if (perm_out) { perm_out[b * 2] = swap ? 1 : 0; perm_out[b * 2 + 1] = swap ? 0 : 1; }
+  }
+  __syncthreads();
+  if (tix == 0) {
+    double s = 0.0;
+    for (int b = 0; b < B; ++b) s += (double)best_s[b];
+    *loss = (float)(s / (double)B);
+  }
+}
+
 
 // -DHP_STAMPS: per-wave cycle stamps of this kernel's phases (tools/headpit_stamps.py, CSSHIP_HEADPIT_ONE_ROLE=1); not
 // part of the product build
@@ -272,7 +310,11 @@ __global__ __launch_bounds__(1024) void head_pit_split_kernel(HeadPitArgs a) {
   float (*red)[2 * K * K] = reinterpret_cast<float (*)[2 * K * K]>(Xs);
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, n = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m0 = blockIdx.x * BM;
+  // rpw of the panel's 64 rows are this workgroup's (12 800 rows: 50, so that 256 workgroups - one per CU - share the
+  // loss operands instead of 200 pulling 64 rows each: the kernel is bound by what ONE CU can pull); the rest repeat the
+  // last row in the matrix passes and are left out of the sweep
+  const int rpw = a.rpw;
+  const int m0 = blockIdx.x * rpw;
   const int bnd = (m0 / a.T + 1) * a.T;           // first row of the panel's second sample (T >= 64: at most two)
   float sse[2][K][K];
 #pragma unroll
@@ -285,10 +327,12 @@ __global__ __launch_bounds__(1024) void head_pit_split_kernel(HeadPitArgs a) {
   auto request_rows = [&]() {
 #pragma unroll
     for (int i = 0; i < LR; ++i) {
-      const int rc = min(m0 + wave * LR + i, a.M - 1);
-      fo[i] = load4(a.f + (size_t)rc * a.ldf + lane * 4);
+      if (wave * LR + i < rpw) {                    // wave-uniform
+        const int rc = min(m0 + wave * LR + i, a.M - 1);
+        fo[i] = load4(a.f + (size_t)rc * a.ldf + lane * 4);
 #pragma unroll
-      for (int j = 0; j < K; ++j) tg[j][i] = load4(a.tgt[j] + (size_t)rc * a.ldt + lane * 4);
+        for (int j = 0; j < K; ++j) tg[j][i] = load4(a.tgt[j] + (size_t)rc * a.ldt + lane * 4);
+      }
     }
   };
 
@@ -305,7 +349,7 @@ __global__ __launch_bounds__(1024) void head_pit_split_kernel(HeadPitArgs a) {
     {  // encoder rows -> bf16 operand panel (8 lanes per row: whole 128-byte lines per load instruction)
       constexpr int LPR = 512 / BM, NP = 64 / LPR;
       const int r = tid / LPR, part = tid % LPR;
-      const float* xr = a.x + (size_t)min(m0 + r, a.M - 1) * DM;
+      const float* xr = a.x + (size_t)min(m0 + min(r, rpw - 1), a.M - 1) * DM;
       float4 v[NP];
 #pragma unroll
       for (int i = 0; i < NP; ++i) v[i] = *reinterpret_cast<const float4*>(xr + (i * LPR + part) * 4);
@@ -374,7 +418,7 @@ __global__ __launch_bounds__(1024) void head_pit_split_kernel(HeadPitArgs a) {
       float ftail[RT], ttail[K][RT];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
-        const int rc = min(m0 + rt * 16 + n, a.M - 1);
+        const int rc = min(m0 + min(rt * 16 + n, rpw - 1), a.M - 1);
         ftail[rt] = a.f[(size_t)rc * a.ldf + 256];
 #pragma unroll
         for (int j = 0; j < K; ++j) ttail[j][rt] = a.tgt[j][(size_t)rc * a.ldt + 256];
@@ -401,7 +445,7 @@ __global__ __launch_bounds__(1024) void head_pit_split_kernel(HeadPitArgs a) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
           const int row = m0 + rt * 16 + n;
-          if (row < a.M) {
+          if (row < a.M && rt * 16 + n < rpw) {
 #pragma unroll
             for (int k = 0; k < K; ++k) {
               const float y = fmaxf(acc[rt][k], 0.f) * ftail[rt];
@@ -424,6 +468,7 @@ __global__ __launch_bounds__(1024) void head_pit_split_kernel(HeadPitArgs a) {
 #pragma unroll
   for (int i = 0; i < LR; ++i) {
     const int r = wave * LR + i, row = m0 + r;
+    if (r >= rpw) continue;                        // wave-uniform: a padding row (nothing was loaded for it)
     float e[K][K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -469,40 +514,14 @@ __global__ __launch_bounds__(1024) void head_pit_split_kernel(HeadPitArgs a) {
   }
 }
 
-// One thread per sample adds its panels' partials (ascending panel order, double), scans the K! = 2 permutations in
-// itertools order (first minimum wins, like torch.min), then thread 0 averages the samples in order.
+// (Measured and rejected: the workgroup that arrives last - an agent-scope counter - doing this inside head_pit_split_kernel:
+// 21.0 us against 15.0 + 3.5 for the two launches; the release / acquire fences and the serial tail cost more than the launch.)
 __global__ __launch_bounds__(64) void head_pit_finalize_kernel(const float* __restrict__ partial, int B, int T, int M,
                                                                double norm, float* __restrict__ loss,
-                                                               int* __restrict__ perm_out, float* __restrict__ pair_sse) {
-  constexpr int K = KSPK;
+                                                               int* __restrict__ perm_out, float* __restrict__ pair_sse,
+                                                               int rpw) {
   __shared__ float best_s[1024];
-  for (int b = threadIdx.x; b < B; b += blockDim.x) {
-    double Dm[K][K] = {{0.0, 0.0}, {0.0, 0.0}};
-    const int wg0 = (b * T) / BM, wg1 = min(((b + 1) * T - 1) / BM, (M - 1) / BM);
-    for (int w0 = wg0; w0 <= wg1; w0 += 8) {  // eight panels' partials in flight at a time, added in ascending order
-      float4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int wg = min(w0 + u, wg1), sl = b - (wg * BM) / T;
-        v[u] = *reinterpret_cast<const float4*>(partial + ((size_t)wg * 2 + sl) * K * K);
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (w0 + u <= wg1) { Dm[0][0] += (double)v[u].x; Dm[0][1] += (double)v[u].y; Dm[1][0] += (double)v[u].z; Dm[1][1] += (double)v[u].w; }
-    }
-    if (pair_sse)
-      for (int i = 0; i < K * K; ++i) pair_sse[(size_t)b * K * K + i] = (float)Dm[i / K][i % K];
-    const float c0 = (float)((Dm[0][0] + Dm[1][1]) / norm), c1 = (float)((Dm[1][0] + Dm[0][1]) / norm);  // perms (0,1), (1,0)
-    const bool swap = c1 < c0;
-    best_s[b] = swap ? c1 : c0;
-    if (perm_out) { perm_out[b * 2] = swap ? 1 : 0; perm_out[b * 2 + 1] = swap ? 0 : 1; }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double s = 0.0;
-    for (int b = 0; b < B; ++b) s += (double)best_s[b];
-    *loss = (float)(s / (double)B);
-  }
+  pit_finalize_body(partial, B, T, M, norm, loss, perm_out, pair_sse, rpw, (int)threadIdx.x, 64, best_s);
 }
 
 }  // namespace
@@ -515,7 +534,7 @@ extern "C" int csship_debug_headpit_stamps(unsigned* buf) {
 
 extern "C" size_t csship_head_pit_workspace(int32_t B, int32_t T) {
   if (B <= 0 || T <= 0) return 0;
-  return ((size_t)B * T + BM - 1) / BM * 2 * KSPK * KSPK * sizeof(float);
+  return ((size_t)B * T + 15) / 16 * 2 * KSPK * KSPK * sizeof(float);  // (at least 16 rows per workgroup)
 }
 
 extern "C" int csship_head_pit(const float* x_enc, const uint16_t* w_perm_packed, const float* bias_perm, const float* f_orig,
@@ -536,17 +555,34 @@ extern "C" int csship_head_pit(const float* x_enc, const uint16_t* w_perm_packed
   a.partial = reinterpret_cast<float*>(workspace);
   a.M = B * T; a.T = T;
   hipStream_t s = as_stream(stream);
+  static const bool one_role = getenv("CSSHIP_HEADPIT_ONE_ROLE") != nullptr;   // A/B: the 8-wave kernel, every wave both roles
+  // rows per workgroup: the fewest rounds of one workgroup per CU that 64-row panels would take, the rows spread evenly
+  // over all CUs of those rounds (12 800 rows on 256 CUs: 50 instead of 64 on 200 CUs with 56 idle)
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+  }();
+  static const int rpw_env = [] { const char* e = getenv("CSSHIP_HEADPIT_RPW"); return e ? atoi(e) : 0; }();   // A/B: 64 = whole panels
+  int rpw = BM;
+  if (!one_role) {
+    const int64_t rounds = ((int64_t)a.M + (int64_t)BM * cus - 1) / ((int64_t)BM * cus);
+    rpw = (int)((a.M + rounds * cus - 1) / (rounds * cus));
+    if (rpw_env > 0) rpw = rpw_env;
+    rpw = std::max(16, std::min(rpw, BM));
+  }
+  a.rpw = rpw;
+  const unsigned nwg = (unsigned)((a.M + rpw - 1) / rpw);
   {
     TimelineScope tl(CSSHIP_TL_HEAD, s);
-    static const bool one_role = getenv("CSSHIP_HEADPIT_ONE_ROLE") != nullptr;   // A/B: the 8-wave kernel, every wave both roles
-    if (one_role) hipLaunchKernelGGL(head_pit_kernel, dim3((a.M + BM - 1) / BM), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL(head_pit_split_kernel, dim3((a.M + BM - 1) / BM), dim3(1024), 0, s, a);
+    if (one_role) hipLaunchKernelGGL(head_pit_kernel, dim3(nwg), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(head_pit_split_kernel, dim3(nwg), dim3(1024), 0, s, a);
   }
   CSSHIP_CHECK_LAUNCH();
   {
     TimelineScope tl(CSSHIP_TL_PIT_FINALIZE, s);
     hipLaunchKernelGGL(head_pit_finalize_kernel, dim3(1), dim3(64), 0, s, a.partial, B, T, a.M, (double)K * T * F, loss,
-                       perm, pair_sse);
+                       perm, pair_sse, rpw);
   }
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
