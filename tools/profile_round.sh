@@ -15,6 +15,25 @@ for mode in fwd train; do
   [ $rc -eq 124 ] || [ $rc -eq 137 ] && exit 1
   f=$(ls gpurun_out/prof_$mode/*/*kernel_stats.csv 2>/dev/null | tail -1)
   [ -n "$f" ] && cp "$f" gpurun_out/${tag}_${mode}_kernel_stats.csv
+  # the same averages over the launches of the REPLAYED graph only (back to back: < 1.5 us to both neighbours) - the
+  # stats file above also counts the eager warm-up / capture / timeline-probe launches of the same command, which start
+  # on a drained GPU with cold caches and read ~4-8 % longer
+  t=$(ls gpurun_out/prof_$mode/*/*kernel_trace.csv 2>/dev/null | tail -1)
+  [ -n "$t" ] && TRACE="$t" OUT="gpurun_out/${tag}_${mode}_replay_kernel_avg.csv" python - <<'PY'
+import collections, csv, os
+rows = sorted(csv.DictReader(open(os.environ["TRACE"])), key=lambda r: int(r["Start_Timestamp"]))
+st = [int(r["Start_Timestamp"]) for r in rows]
+en = [int(r["End_Timestamp"]) for r in rows]
+acc = collections.defaultdict(list)
+for i in range(1, len(rows) - 1):
+    if st[i] - en[i - 1] < 1500 and st[i + 1] - en[i] < 1500:
+        acc[rows[i]["Kernel_Name"]].append(en[i] - st[i])
+with open(os.environ["OUT"], "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "ReplayCalls", "AverageNs", "MinNs", "MaxNs"])
+    for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+        w.writerow([k, len(v), round(sum(v) / len(v), 1), min(v), max(v)])
+PY
   grep '^{' gpurun_out/${tag}_bench_$mode.log > gpurun_out/${tag}_bench_${mode}_under_rocprof.json
 done
 i=0
