@@ -24,6 +24,7 @@ _NO_TRAIN_CHAIN = bool(os.environ.get("CSSHIP_NO_TRAIN_CHAIN"))   # A/B timing: 
 _NO_FFN_LN = bool(os.environ.get("CSSHIP_NO_FFN_LN"))       # A/B timing: the block's final LayerNorm as its own launch
 _NO_CONV_NEXT = bool(os.environ.get("CSSHIP_NO_CONV_NEXT"))  # A/B timing: dropout(dx) for the output projection's backward as its own pass
 _NO_DROP_EPI = bool(os.environ.get("CSSHIP_NO_DROP_EPI"))   # A/B timing: output-projection dropout as its own pass
+_NO_LN2 = bool(os.environ.get("CSSHIP_NO_LN2_FUSE"))   # A/B timing: every block's final LayerNorm backward as its own launch
 _NO_OC_TRAIN = bool(os.environ.get("CSSHIP_NO_OC_TRAIN"))   # A/B timing: output projection and conv module's first kernel as two launches
 
 
@@ -411,11 +412,14 @@ class ConformerTrain(torch.autograd.Function):
         skew_buf = _skew_buffer(model, (B, T, H, window[0].shape[0]), masks.device)
         ds = S["drop"]
         nlay = len(enc.encoders)
-        for li, lay, L in zip(range(nlay - 1, -1, -1), reversed(list(enc.encoders)), reversed(S["layers"])):
-            dx, dg, dbeta = ob.layernorm_bwd(L["x4"], dx, lay.layer_norm.weight.detach(), lay.layer_norm.bias.detach())
-            put(lay.layer_norm.weight, dg), put(lay.layer_norm.bias, dbeta)
+        layers = list(enc.encoders)
+        ln_done = False   # this block's final LayerNorm was back-propagated by the block above (ffn_bwd's second LayerNorm)
+        for li, lay, L in zip(range(nlay - 1, -1, -1), reversed(layers), reversed(S["layers"])):
+            if not ln_done:
+                dx, dg, dbeta = ob.layernorm_bwd(L["x4"], dx, lay.layer_norm.weight.detach(), lay.layer_norm.bias.detach())
+                put(lay.layer_norm.weight, dg), put(lay.layer_norm.bias, dbeta)
 
-            def ffn_b(m, tag, dy):
+            def ffn_b(m, tag, dy, ln2=None):
                 dh, do = ds.cfg(f"{li}.{tag}.hidden"), ds.cfg(f"{li}.{tag}.out")
                 if S["wide"]:
                     xin, w1_bf, w2_bf = L[tag]
@@ -427,11 +431,11 @@ class ConformerTrain(torch.autograd.Function):
                     outs = tuple(_direct_grad(q) for q in (m.net[0].weight, m.net[0].bias, m.net[3].weight, m.net[3].bias))
                     dxo, g = bw.ffn_bwd_fused(xin, dy, m.layer_norm.weight.detach(), m.layer_norm.bias.detach(),
                                               m.net[0].bias.detach(), w1p, w2tp, w1tp, enc.d_ffn, 0.5,
-                                              drop_hidden=dh, drop_out=do, outs=outs)
+                                              drop_hidden=dh, drop_out=do, outs=outs, ln2=ln2)
                 for p, gv in zip((m.layer_norm.weight, m.layer_norm.bias, m.net[0].weight, m.net[0].bias,
                                   m.net[3].weight, m.net[3].bias), g):
                     put(p, gv)
-                return dxo
+                return (dxo, g[6:]) if ln2 is not None else dxo
 
             dx = ffn_b(lay.feed_forward_out, "ffn_out", dx)
             x2, W, fws = L["conv"]
@@ -463,7 +467,14 @@ class ConformerTrain(torch.autograd.Function):
             for i, lin in enumerate((a.linear_q, a.linear_k, a.linear_v)):
                 put(lin.weight, dwqkv[i * D:(i + 1) * D]), put(lin.bias, dbqkv[i * D:(i + 1) * D])
             put(a.linear_out.weight, dwo), put(a.linear_out.bias, dbo)
-            dx = ffn_b(lay.feed_forward_in, "ffn_in", dx)
+            # the block's input is the final LayerNorm of the block below: its backward rides in this kernel's epilogue
+            ln_done = li > 0 and not S["wide"] and not _NO_LN2 and M % 64 == 0 and enc.d_ffn <= 2048
+            if ln_done:
+                below, Lb = layers[li - 1], S["layers"][li - 1]
+                dx, (dg2, dbeta2) = ffn_b(lay.feed_forward_in, "ffn_in", dx, ln2=(Lb["x4"], below.layer_norm.weight.detach()))
+                put(below.layer_norm.weight, dg2), put(below.layer_norm.bias, dbeta2)
+            else:
+                dx = ffn_b(lay.feed_forward_in, "ffn_in", dx)
             L.clear()
             red.flush()
             _deliver_group(model, lay, G)

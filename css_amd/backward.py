@@ -54,11 +54,13 @@ def ffn_bwd(x, dy, ln_g, ln_b, b1, w1_bf, w2_bf, alpha=0.5, drop_hidden=None, dr
 
 
 def ffn_bwd_fused(x, dy, ln_g, ln_b, b1, w1p, w2tp, w1tp, d_ffn, alpha=0.5, drop_hidden=None, drop_out=None,
-                  outs=(None, None, None, None)):
+                  outs=(None, None, None, None), ln2=None):
     """ffn_bwd with the activation side in ONE row-panel kernel (d_model = 256): LN + hidden recompute, masked dh,
     da and the LayerNorm backward never leave the CU; the four weight / bias gradients are GEMMs / column sums over
-    the B*T rows.  w1p / w2tp / w1tp: fragment-packed W1, W2^T, W1^T."""
-    dx, dg, dbeta, a, h, dh, dyd = ob.ffn_bwd(x, dy, ln_g, ln_b, w1p, b1, w2tp, w1tp, d_ffn, alpha, drop_hidden, drop_out)
+    the B*T rows.  w1p / w2tp / w1tp: fragment-packed W1, W2^T, W1^T.  ln2 = (x2, gamma2) when x = LayerNorm2(x2): dx
+    comes back as the gradient wrt x2 and the gradient tuple ends with that LayerNorm's (dgamma2, dbeta2)."""
+    res = ob.ffn_bwd(x, dy, ln_g, ln_b, w1p, b1, w2tp, w1tp, d_ffn, alpha, drop_hidden, drop_out, ln2=ln2)
+    dx, dg, dbeta, a, h, dh, dyd = res[:7]
     dw1_o, db1_o, dw2_o, db2_o = outs   # optional f32 destinations (dW1, db1, dW2, db2), e.g. zeroed .grad views
     with ob.paired_reductions():   # the slabs of both products summed by one launch
         if dyd is not None:   # output dropout: the second Linear saw h (dropped) and its gradient is alpha * dy o mask / (1 - p)
@@ -66,7 +68,7 @@ def ffn_bwd_fused(x, dy, ln_g, ln_b, b1, w1p, w2tp, w1tp, d_ffn, alpha=0.5, drop
         else:
             dw2, db2 = ob.linear_wgrad(dy, h, alpha, dw_out=dw2_o, db_out=db2_o)
         dw1, db1 = ob.linear_wgrad(dh, a, dw_out=dw1_o, db_out=db1_o)
-    return dx, (dg, dbeta, dw1, db1, dw2, db2)
+    return dx, (dg, dbeta, dw1, db1, dw2, db2) + tuple(res[7:])
 
 
 _NO_BAND = bool(os.environ.get("CSSHIP_NO_BAND"))   # A/B timing: the skewed-dS product over the whole window axis

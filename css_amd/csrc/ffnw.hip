@@ -433,7 +433,7 @@ DEV f32x4 mx_mfma_ks(const i32x8& w, const i32x8& x, const f32x4& c, unsigned ws
 //   them, into the same registers - the partner wave of the SIMD covers the read latency.
 template <int NT, int NTN, int KSTEPS, int ROWB, int NTM, int XB, int STEP>
 struct PassMx {
-  static DEV void run(f32x4 (&acc)[NT][4], const unsigned char* panel8, const unsigned (&xs)[4], int n, int g,
+  DEV void run(f32x4 (&acc)[NT][4], const unsigned char* panel8, const unsigned (&xs)[4], int n, int g,
                       const WStream& w, int tstride, const WStream& wn, int nstride, bool has_next,
                       const unsigned (&wsc)[NTM][2], i32x8 (&wq)[PDM][NTM], i32x8 (&xa)[XB][4]) {
     if (XB == 2 && STEP + 1 < KSTEPS) {

@@ -375,21 +375,29 @@ struct FfnBwdArgs {
   float alpha;
   csship_dropout_cfg drop_h, drop_o;  // the forward's dropout sites (hidden [M, FF], output [M, 256])
   unsigned short* dyd_bf;             // optional [M, 256]: alpha * dy o output-dropout mask / (1 - p): operand of dW2 / db2
+  // LN2 (optional): x = LayerNorm2(x2) is itself the output of a LayerNorm (the previous block's final one,
+  // conformer.py:360): the epilogue carries dx on through it - dx <- LayerNorm2-backward(dx) - and leaves that
+  // LayerNorm's dgamma / dbeta partials; its own launch (csship_layernorm_bwd) read x2 and dx and wrote dx once more
+  const float* ln2_x;                 // [M, 256] the LayerNorm's input rows
+  const float* ln2_g;
+  float* part2;                       // [nwg][2][256]
 };
 
 // FULL (M % 64 == 0, d_ffn <= 2048: what the encoder runs): no row predicates on loads or stores, and b1 / gamma / beta
 // come from an LDS copy staged once - every global memory instruction of the chunk loop is unconditional, so the
 // s_waitcnt counts of the weight ring are exact (a predicated store in the loop made hipcc assume the path without it
 // and wait for younger loads than the ones it needs; round 5, see chain_s_kernel).
-template <int NW, bool FULL>
+template <int NW, bool FULL, bool LN2 = false>
 __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
+  static_assert(FULL || !LN2, "the fused second LayerNorm backward is built for whole panels");
   static_assert(NW * 64 == 8 * BM, "row phases assume 8 lanes per panel row");
   constexpr int NT = 16 / NW;
+  constexpr bool KEEP_DY = FULL;
   __shared__ __attribute__((aligned(16))) unsigned char XD[2 * PANEL_BYTES];  // a = LN(x) | alpha * dy; later 64 KB of sums
   unsigned char* const Xs = XD;
   unsigned char* const Ds = XD + PANEL_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char Graw[2 * PANEL_BYTES + 1024];  // 2 dh panels, later the Ys tile
-  __shared__ __attribute__((aligned(16))) float Pb[FULL ? CS_FFMAX + 2 * DM + CS_DUMP : 4];  // FULL: b1 | gamma | beta | dump
+  __shared__ __attribute__((aligned(16))) float Pb[FULL ? CS_FFMAX + 3 * DM + CS_DUMP : 4];  // FULL: b1 | gamma | beta | gamma2 | dump
   static_assert(2 * PANEL_BYTES + 1024 >= YS_BYTES, "Ys tile must fit the dh panels");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15;
   const int m0 = blockIdx.x * BM;
@@ -412,9 +420,9 @@ __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int j = tid + 512 * k;
-      const float* const base = j < q1 ? a.b1 : j < q1 + 64 ? a.ln_g : j < q1 + 128 ? a.ln_b : nullptr;
-      const int off = j < q1 ? j : j < q1 + 64 ? j - q1 : j - q1 - 64;
-      pdd[k] = base != nullptr ? (j < q1 ? j * 4 : CS_FFMAX + (j - q1) * 4) : CS_FFMAX + 2 * DM + lane * 4;
+      const float* const base = j < q1 ? a.b1 : j < q1 + 64 ? a.ln_g : j < q1 + 128 ? a.ln_b : (LN2 && j < q1 + 192) ? a.ln2_g : nullptr;
+      const int off = j < q1 ? j : j < q1 + 64 ? j - q1 : j < q1 + 128 ? j - q1 - 64 : j - q1 - 128;
+      pdd[k] = base != nullptr ? (j < q1 ? j * 4 : CS_FFMAX + (j - q1) * 4) : CS_FFMAX + 3 * DM + lane * 4;
       pvv[k] = *reinterpret_cast<const float4*>(base != nullptr ? base + off * 4 : dummy);
     }
     *reinterpret_cast<float4*>(Pb + pdd[0]) = pvv[0];
@@ -425,6 +433,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
   prefetch_first<NT>(wq, w1s + (size_t)rot * 16 * KS * 64, KS, NT);
 
   // ---- prologue: the two bf16 panels; LN(x) also goes to global for the weight-gradient GEMM
+  float4 dyk[KEEP_DY ? 8 : 1];  // KEEP_DY: this thread's dy row pieces stay in registers for the dx epilogue (no second read)
   {
     const int r = tid >> 3, part = tid & 7;
     const int row = m0 + r, rowc = FULL ? row : min(row, a.M - 1);
@@ -433,6 +442,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
     for (int i = 0; i < 8; ++i) {
       v[i] = *reinterpret_cast<const float4*>(a.x + (size_t)rowc * DM + (i * 8 + part) * 4);
       d[i] = *reinterpret_cast<const float4*>(a.dy + (size_t)rowc * DM + (i * 8 + part) * 4);
+      if constexpr (KEEP_DY) dyk[i] = d[i];
     }
     float s = 0.f;
 #pragma unroll
@@ -568,12 +578,15 @@ __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
   const int row = m0 + r, rowc = FULL ? row : min(row, a.M - 1);
   const bool rvalid = FULL || row < a.M;
   float4 v[8], da[8], dyv[8];
+  float4 x2[LN2 ? 8 : 1];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     v[i] = *reinterpret_cast<const float4*>(a.x + (size_t)rowc * DM + (i * 8 + part) * 4);
+    if constexpr (LN2) x2[i] = *reinterpret_cast<const float4*>(a.ln2_x + (size_t)rowc * DM + (i * 8 + part) * 4);
     // dy is needed by the dx rows below: requested here, all eight at once (read next to its use, behind stores it might
     // alias, every piece was a load - s_waitcnt vmcnt(0) - store round trip of its own: eight L2 latencies in a row)
-    dyv[i] = *reinterpret_cast<const float4*>(a.dy + (size_t)rowc * DM + (i * 8 + part) * 4);
+    if constexpr (KEEP_DY) dyv[i] = dyk[i];
+    else dyv[i] = *reinterpret_cast<const float4*>(a.dy + (size_t)rowc * DM + (i * 8 + part) * 4);
     da[i] = *reinterpret_cast<const float4*>(ys + r * YS + (i * 8 + part) * 4);
   }
   float s = 0.f;
@@ -613,7 +626,8 @@ __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
       o4.y = d.y + rstd * (gg[i].y - s1 - v[i].y * s2);
       o4.z = d.z + rstd * (gg[i].z - s1 - v[i].z * s2);
       o4.w = d.w + rstd * (gg[i].w - s1 - v[i].w * s2);
-      *reinterpret_cast<float4*>(a.dx + (size_t)row * DM + col) = o4;
+      if constexpr (LN2) dyv[i] = o4;   // goes on through the second LayerNorm below
+      else *reinterpret_cast<float4*>(a.dx + (size_t)row * DM + col) = o4;
     }
     *reinterpret_cast<float4*>(cg + r * YS + col) = make_float4(da[i].x * v[i].x, da[i].y * v[i].y, da[i].z * v[i].z, da[i].w * v[i].w);
     *reinterpret_cast<float4*>(cb + r * DM + col) = da[i];
@@ -630,6 +644,56 @@ __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
       for (int rr = 0; rr < BM; ++rr) acc += cb[rr * DM + col];
     }
     a.part[(size_t)blockIdx.x * 2 * DM + which * DM + col] = acc;
+  }
+  if constexpr (LN2) {
+    // dx (in dyv) is the gradient of LayerNorm2's output: statistics of its input row, the same three-term formula,
+    // and the column sums of dx o xhat2 / dx through the two staging tiles once more
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += (x2[i].x + x2[i].y) + (x2[i].z + x2[i].w);
+    const float mean2 = sum8(t) * (1.f / DM);
+    float tt = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      x2[i].x -= mean2; x2[i].y -= mean2; x2[i].z -= mean2; x2[i].w -= mean2;
+      tt += (x2[i].x * x2[i].x + x2[i].y * x2[i].y) + (x2[i].z * x2[i].z + x2[i].w * x2[i].w);
+    }
+    const float rstd2 = rsqrtf(sum8(tt) * (1.f / DM) + 1e-5f);
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4 gm = *reinterpret_cast<const float4*>(Pb + CS_FFMAX + 2 * DM + (i * 8 + part) * 4);
+      x2[i].x *= rstd2; x2[i].y *= rstd2; x2[i].z *= rstd2; x2[i].w *= rstd2;  // xhat2
+      gg[i] = make_float4(dyv[i].x * gm.x, dyv[i].y * gm.y, dyv[i].z * gm.z, dyv[i].w * gm.w);
+      t1 += (gg[i].x + gg[i].y) + (gg[i].z + gg[i].w);
+      t2 += (gg[i].x * x2[i].x + gg[i].y * x2[i].y) + (gg[i].z * x2[i].z + gg[i].w * x2[i].w);
+    }
+    t1 = sum8(t1) * (1.f / DM);
+    t2 = sum8(t2) * (1.f / DM);
+    __syncthreads();  // the first column sums have been read
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int col = (i * 8 + part) * 4;
+      float4 o4;
+      o4.x = rstd2 * (gg[i].x - t1 - x2[i].x * t2);
+      o4.y = rstd2 * (gg[i].y - t1 - x2[i].y * t2);
+      o4.z = rstd2 * (gg[i].z - t1 - x2[i].z * t2);
+      o4.w = rstd2 * (gg[i].w - t1 - x2[i].w * t2);
+      *reinterpret_cast<float4*>(a.dx + (size_t)row * DM + col) = o4;
+      *reinterpret_cast<float4*>(cg + r * YS + col) = make_float4(dyv[i].x * x2[i].x, dyv[i].y * x2[i].y, dyv[i].z * x2[i].z, dyv[i].w * x2[i].w);
+      *reinterpret_cast<float4*>(cb + r * DM + col) = dyv[i];
+    }
+    __syncthreads();
+    const int col = tid & 255, which = tid >> 8;
+    float acc = 0.f;
+    if (which == 0) {
+#pragma unroll 8
+      for (int rr = 0; rr < BM; ++rr) acc += cg[rr * YS + col];
+    } else {
+#pragma unroll 8
+      for (int rr = 0; rr < BM; ++rr) acc += cb[rr * DM + col];
+    }
+    a.part2[(size_t)blockIdx.x * 2 * DM + which * DM + col] = acc;
   }
 }
 
@@ -1613,6 +1677,12 @@ __global__ __launch_bounds__(NW * 64) void chain_s_kernel(ChainArgs a) {
   const float* const dummy = a.x + (size_t)m0 * DM + lane * 4;
   // (named scalars and branch-free selects: an array written under the if-chain became an alloca, promoted into LDS)
   const int w8 = __builtin_amdgcn_readfirstlane(wave);
+  // training: the four dropout keys first - each reads its seed word and WAITS for it (s_waitcnt vmcnt(0)); taken between
+  // the stages they drained the weight ring and waited for the row stores in front of them
+  const Drop dAh = TRAIN && HAS_A ? drop_make(a.da_h.seed, a.da_h.stream, a.da_h.p) : Drop{0u, 0u, 1.f};
+  const Drop dAo = TRAIN && HAS_A ? drop_make(a.da_o.seed, a.da_o.stream, a.da_o.p) : Drop{0u, 0u, 1.f};
+  const Drop dBh = TRAIN && HAS_B ? drop_make(a.db_h.seed, a.db_h.stream, a.db_h.p) : Drop{0u, 0u, 1.f};
+  const Drop dBo = TRAIN && HAS_B ? drop_make(a.db_o.seed, a.db_o.stream, a.db_o.p) : Drop{0u, 0u, 1.f};
   const float* p0 = nullptr;
   if (HAS_A && w8 == 0) p0 = a.fa.ln_g;
   if (HAS_A && w8 == 1) p0 = a.fa.ln_b;
@@ -1652,8 +1722,7 @@ __global__ __launch_bounds__(NW * 64) void chain_s_kernel(ChainArgs a) {
 #endif
   P_T(0)
   if constexpr (HAS_A) {
-    const StageTrain ta{TRAIN ? drop_make(a.da_h.seed, a.da_h.stream, a.da_h.p) : Drop{0u, 0u, 1.f},
-                        TRAIN ? drop_make(a.da_o.seed, a.da_o.stream, a.da_o.p) : Drop{0u, 0u, 1.f}, m0, a.M, a.pre_ln_out};
+    const StageTrain ta{dAh, dAo, m0, a.M, a.pre_ln_out};
     if constexpr (PIPE)
       ffn_stage_p<NW, true, TRAIN>(v, Xs, Hraw, a.fa.ln_g != nullptr ? lnA : nullptr, finA, b1A, b2A, a.fa, FF, a.alpha, tid, rotA, wq,
                                    HAS_B ? wB0 : wA0, g_stamps_dev, 1, ta);
@@ -1667,8 +1736,7 @@ __global__ __launch_bounds__(NW * 64) void chain_s_kernel(ChainArgs a) {
   }
   P_T(4)
   if constexpr (HAS_B) {
-    const StageTrain tb{TRAIN ? drop_make(a.db_h.seed, a.db_h.stream, a.db_h.p) : Drop{0u, 0u, 1.f},
-                        TRAIN ? drop_make(a.db_o.seed, a.db_o.stream, a.db_o.p) : Drop{0u, 0u, 1.f}, m0, a.M, nullptr};
+    const StageTrain tb{dBh, dBo, m0, a.M, nullptr};
     if constexpr (PIPE)
       ffn_stage_p<NW, false, TRAIN>(v, Xs, Hraw, a.fb.ln_g != nullptr ? lnB : nullptr, nullptr, b1B, b2B, a.fb, FF, a.alpha, tid, rotB, wq,
                                     HAS_C ? wC0 : wB0, g_stamps_dev, 5, tb);
@@ -2434,6 +2502,20 @@ extern "C" int csship_ffn_bwd_drop(const float* x, const float* dy, const float*
                                    float* dx, float* dgamma_dbeta, int32_t M, int32_t d_model, int32_t d_ffn, float alpha,
                                    const csship_dropout_cfg* drop_hidden, const csship_dropout_cfg* drop_out,
                                    uint16_t* dyd_bf16, void* workspace, size_t workspace_bytes, csship_stream_t stream) {
+  return csship_ffn_bwd_ln(x, dy, ln_g, ln_b, w1_packed, b1, w2t_packed, w1t_packed, a_bf16, h_bf16, dh_bf16, dx, dgamma_dbeta, M,
+                           d_model, d_ffn, alpha, drop_hidden, drop_out, dyd_bf16, nullptr, nullptr, nullptr, workspace,
+                           workspace_bytes, stream);
+}
+
+extern "C" size_t csship_ffn_bwd_ln_workspace(int32_t M) { return 2 * csship_ffn_bwd_workspace(M); }
+
+extern "C" int csship_ffn_bwd_ln(const float* x, const float* dy, const float* ln_g, const float* ln_b,
+                                 const uint16_t* w1_packed, const float* b1, const uint16_t* w2t_packed,
+                                 const uint16_t* w1t_packed, uint16_t* a_bf16, uint16_t* h_bf16, uint16_t* dh_bf16,
+                                 float* dx, float* dgamma_dbeta, int32_t M, int32_t d_model, int32_t d_ffn, float alpha,
+                                 const csship_dropout_cfg* drop_hidden, const csship_dropout_cfg* drop_out,
+                                 uint16_t* dyd_bf16, const float* ln2_x, const float* ln2_g, float* dgamma_dbeta2,
+                                 void* workspace, size_t workspace_bytes, csship_stream_t stream) {
   if (!x || !dy || !ln_g || !ln_b || !w1_packed || !b1 || !w2t_packed || !w1t_packed || !a_bf16 || !h_bf16 || !dh_bf16 ||
       !dx || !dgamma_dbeta || !workspace)
     return CSSHIP_ENULL;
@@ -2447,19 +2529,31 @@ extern "C" int csship_ffn_bwd_drop(const float* x, const float* dy, const float*
   if (workspace_bytes < (size_t)nwg * 2 * DM * sizeof(float)) return CSSHIP_EWORKSPACE;
   if ((int64_t)nwg * BM * d_ffn > 0xffffffffLL) return CSSHIP_EBADSHAPE;  // 32-bit dropout element indices
   if (dyd_bf16 && !aligned8(dyd_bf16)) return CSSHIP_EALIGN;
+  const bool ln2 = ln2_x != nullptr;
+  if (ln2) {  // the second LayerNorm rides in the whole-panel form only
+    if (!ln2_g || !dgamma_dbeta2) return CSSHIP_ENULL;
+    if ((M % BM) != 0 || d_ffn > CS_FFMAX) return CSSHIP_EUNSUPPORTED;
+    if (!aligned16(ln2_x) || !aligned16(ln2_g)) return CSSHIP_EALIGN;
+    if (workspace_bytes < (size_t)nwg * 4 * DM * sizeof(float)) return CSSHIP_EWORKSPACE;
+  }
   const csship_dropout_cfg none{nullptr, 0u, 0.f};
+  float* const part2 = reinterpret_cast<float*>(workspace) + (size_t)nwg * 2 * DM;
   FfnBwdArgs a{x, dy, ln_g, ln_b, reinterpret_cast<const bf16x8*>(w1_packed), b1,
                reinterpret_cast<const bf16x8*>(w2t_packed), reinterpret_cast<const bf16x8*>(w1t_packed), a_bf16, h_bf16,
                dh_bf16, dx, reinterpret_cast<float*>(workspace), M, d_ffn, alpha,
-               drop_hidden ? *drop_hidden : none, drop_out ? *drop_out : none, dyd_bf16};
+               drop_hidden ? *drop_hidden : none, drop_out ? *drop_out : none, dyd_bf16, ln2_x, ln2_g, ln2 ? part2 : nullptr};
   static const bool use_static = [] { const char* e = getenv("CSSHIP_CHAIN_STATIC"); return e == nullptr || atoi(e) != 0; }();
-  if (use_static && (M % BM) == 0 && d_ffn <= CS_FFMAX)
+  if (ln2)
+    hipLaunchKernelGGL((ffn_bwd_kernel<NWAVES, true, true>), dim3(nwg), dim3(NWAVES * 64), 0, as_stream(stream), a);
+  else if (use_static && (M % BM) == 0 && d_ffn <= CS_FFMAX)
     hipLaunchKernelGGL((ffn_bwd_kernel<NWAVES, true>), dim3(nwg), dim3(NWAVES * 64), 0, as_stream(stream), a);
   else
     hipLaunchKernelGGL((ffn_bwd_kernel<NWAVES, false>), dim3(nwg), dim3(NWAVES * 64), 0, as_stream(stream), a);
   CSSHIP_CHECK_LAUNCH();
-  return launch_slab_reduce(reinterpret_cast<const float*>(workspace), nwg, 2 * DM, 2 * DM, 2 * DM, 1.f, nullptr, nullptr, 0,
-                            dgamma_dbeta, as_stream(stream), true);
+  const int rc = launch_slab_reduce(reinterpret_cast<const float*>(workspace), nwg, 2 * DM, 2 * DM, 2 * DM, 1.f, nullptr, nullptr, 0,
+                                    dgamma_dbeta, as_stream(stream), true);
+  if (rc != CSSHIP_OK || !ln2) return rc;
+  return launch_slab_reduce(part2, nwg, 2 * DM, 2 * DM, 2 * DM, 1.f, nullptr, nullptr, 0, dgamma_dbeta2, as_stream(stream), true);
 }
 
 extern "C" int csship_ffn_bwd(const float* x, const float* dy, const float* ln_g, const float* ln_b,

@@ -445,10 +445,12 @@ def lstm_bidir_bwd(gates, c, dy, whhT_packed):
     return dg
 
 
-def ffn_bwd(x, dy, ln_g, ln_b, w1p, b1, w2tp, w1tp, d_ffn, alpha=0.5, drop_hidden=None, drop_out=None):
+def ffn_bwd(x, dy, ln_g, ln_b, w1p, b1, w2tp, w1tp, d_ffn, alpha=0.5, drop_hidden=None, drop_out=None, ln2=None):
     """Activation side of the FeedForward backward in one kernel (csship_ffn_bwd).
     Returns (dx f32 [M,256], dgamma, dbeta, a bf16 [M,256], h bf16 [M,d_ffn], dh bf16 [M,d_ffn], dyd): with dropout
-    cfgs h is the DROPPED hidden activation and dyd (bf16 [M,256]) = alpha * dy o output mask / (1 - p), else None."""
+    cfgs h is the DROPPED hidden activation and dyd (bf16 [M,256]) = alpha * dy o output mask / (1 - p), else None.
+    ln2 = (x2, gamma2) with x = LayerNorm2(x2): dx is carried on through that LayerNorm (csship_ffn_bwd_ln) and the
+    tuple grows by (dgamma2, dbeta2)."""
     _need(x, torch.float32, "x"), _need(dy, torch.float32, "dy")
     M, D = x.shape
     if not (x.is_contiguous() and dy.is_contiguous()) or dy.shape != x.shape:
@@ -459,9 +461,21 @@ def ffn_bwd(x, dy, ln_g, ln_b, w1p, b1, w2tp, w1tp, d_ffn, alpha=0.5, drop_hidde
     dh = torch.empty((M, d_ffn), dtype=torch.bfloat16, device=dev)
     dx = torch.empty_like(x)
     gb = torch.empty((2, D), dtype=torch.float32, device=dev)
+    dyd = torch.empty((M, D), dtype=torch.bfloat16, device=dev) if drop_out is not None else None
+    if ln2 is not None:
+        x2, g2 = ln2
+        _need(x2, torch.float32, "ln2 x")
+        if not x2.is_contiguous() or x2.shape != x.shape:
+            raise RuntimeError("css_amd: ffn_bwd expects the second LayerNorm's input dense and shaped like x")
+        gb2 = torch.empty((2, D), dtype=torch.float32, device=dev)
+        nws = lib().csship_ffn_bwd_ln_workspace(M)
+        ws = _workspace(nws, dev, own=True)
+        check(lib().csship_ffn_bwd_ln(_ptr(x), _ptr(dy), _ptr(ln_g), _ptr(ln_b), _ptr(w1p), _ptr(b1), _ptr(w2tp), _ptr(w1tp),
+                                      _ptr(a), _ptr(h), _ptr(dh), _ptr(dx), _ptr(gb), M, D, d_ffn, float(alpha), drop_hidden,
+                                      drop_out, _ptr(dyd), _ptr(x2), _ptr(g2), _ptr(gb2), _ptr(ws), nws, _stream()))
+        return dx, gb[0], gb[1], a, h, dh, dyd, gb2[0], gb2[1]
     nws = lib().csship_ffn_bwd_workspace(M)
     ws = _workspace(nws, dev, own=True)
-    dyd = torch.empty((M, D), dtype=torch.bfloat16, device=dev) if drop_out is not None else None
     check(lib().csship_ffn_bwd_drop(_ptr(x), _ptr(dy), _ptr(ln_g), _ptr(ln_b), _ptr(w1p), _ptr(b1), _ptr(w2tp), _ptr(w1tp),
                                     _ptr(a), _ptr(h), _ptr(dh), _ptr(dx), _ptr(gb), M, D, d_ffn, float(alpha), drop_hidden,
                                     drop_out, _ptr(dyd), _ptr(ws), nws, _stream()))

@@ -670,6 +670,20 @@ int csship_ffn_bwd_drop(const float* x, const float* dy, const float* ln_g, cons
                         float* dx, float* dgamma_dbeta, int32_t M, int32_t d_model, int32_t d_ffn, float alpha,
                         const csship_dropout_cfg* drop_hidden, const csship_dropout_cfg* drop_out, uint16_t* dyd_bf16,
                         void* workspace, size_t workspace_bytes, csship_stream_t stream);
+/* csship_ffn_bwd_ln: the same with the backward of a SECOND LayerNorm behind it, for x = LayerNorm2(ln2_x) (the input of
+ * a block's first FeedForward is the previous block's final LayerNorm, conformer.py:360): dx receives
+ * LayerNorm2-backward(dx) - the gradient wrt ln2_x - and dgamma_dbeta2 (f32 [2, 256]) that LayerNorm's parameter
+ * gradients; replaces a csship_layernorm_bwd launch and its read of ln2_x and dx.  ln2_x = NULL: csship_ffn_bwd_drop.
+ * Whole 64-row panels only (M % 64 == 0, d_ffn <= 2048; CSSHIP_EUNSUPPORTED otherwise).
+ * Workspace: csship_ffn_bwd_ln_workspace(M). */
+size_t csship_ffn_bwd_ln_workspace(int32_t M);
+int csship_ffn_bwd_ln(const float* x, const float* dy, const float* ln_g, const float* ln_b,
+                      const uint16_t* w1_packed, const float* b1, const uint16_t* w2t_packed,
+                      const uint16_t* w1t_packed, uint16_t* a_bf16, uint16_t* h_bf16, uint16_t* dh_bf16,
+                      float* dx, float* dgamma_dbeta, int32_t M, int32_t d_model, int32_t d_ffn, float alpha,
+                      const csship_dropout_cfg* drop_hidden, const csship_dropout_cfg* drop_out,
+                      uint16_t* dyd_bf16, const float* ln2_x, const float* ln2_g, float* dgamma_dbeta2,
+                      void* workspace, size_t workspace_bytes, csship_stream_t stream);
 
 /* ---- attention, training (css_amd/csrc/attn.hip).  csship_mha_relpos_train = csship_mha_relpos that also returns
  * lse[b, h, i] = log sum_j exp(score[i, j]) (f32 [B, H, T]).  csship_mha_relpos_probs recomputes the softmax for the

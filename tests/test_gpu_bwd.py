@@ -221,6 +221,33 @@ def test_qkv_in_bwd_equals_gemm_plus_layernorm_backward(ob):
         ob.qkv_in_bwd(dqkv[:100].to(DEV), wt, x[:100].to(DEV), dy[:100].to(DEV), g.to(DEV), b.to(DEV))
 
 
+def test_ffn_bwd_carries_dx_through_a_second_layernorm(ob):
+    """csship_ffn_bwd_ln: x = LayerNorm2(x2) (a block's input is the final LayerNorm of the block below): dx and that
+    LayerNorm's dgamma / dbeta from the FeedForward backward kernel's epilogue == csship_ffn_bwd then
+    csship_layernorm_bwd (same formulas on the same f32 rows: equal to rounding of the summation order)"""
+    from css_amd import ops
+    M, D, FF = 640, 256, 1024
+    x2 = rnd((M, D), 71).to(DEV)
+    g2, b2 = (1 + 0.1 * rnd((D,), 72)).to(DEV), (0.1 * rnd((D,), 73)).to(DEV)
+    x = torch.nn.functional.layer_norm(x2, (D,), g2, b2, 1e-5)
+    dy = rnd((M, D), 74, 0.1).to(DEV)
+    G = {"g": (1 + 0.1 * rnd((D,), 75)).to(DEV), "b": (0.1 * rnd((D,), 76)).to(DEV), "w1": rnd((FF, D), 77, 0.06).to(DEV),
+         "b1": rnd((FF,), 78, 0.1).to(DEV), "w2": rnd((D, FF), 79, 0.03).to(DEV)}
+    w1p = ops.pack_frag(G["w1"])
+    w2tp, w1tp = ops.pack_frag(G["w2"].t().contiguous()), ops.pack_frag(G["w1"].t().contiguous())
+    cfg_h, cfg_o = None, None
+    ref = ob.ffn_bwd(x, dy, G["g"], G["b"], w1p, G["b1"], w2tp, w1tp, FF, 0.5, cfg_h, cfg_o)
+    dx_ref, dg2_ref, db2_ref = ob.layernorm_bwd(x2, ref[0], g2, b2)
+    got = ob.ffn_bwd(x, dy, G["g"], G["b"], w1p, G["b1"], w2tp, w1tp, FF, 0.5, cfg_h, cfg_o, ln2=(x2, g2))
+    assert len(got) == 9
+    for a, b in zip(got[1:6], ref[1:6]):       # the FeedForward's own outputs are untouched
+        assert torch.equal(a, b)
+    assert relerr(got[0], dx_ref.double().cpu()) < 1e-5
+    assert relerr(got[7], dg2_ref.double().cpu()) < 1e-5 and relerr(got[8], db2_ref.double().cpu()) < 1e-5
+    with pytest.raises(RuntimeError):           # whole panels only
+        ob.ffn_bwd(x[:100], dy[:100], G["g"], G["b"], w1p, G["b1"], w2tp, w1tp, FF, 0.5, ln2=(x2[:100].contiguous(), g2))
+
+
 def test_grouped_weight_gradients_equal_the_single_products(ob):
     """csship_wgrad_hold / csship_wgrad_flush: the weight-gradient products of a block queued and run as ONE launch (the
     reduction cut 2-3 times instead of 16-64) vs float64 on the same bf16 operands and vs the products one by one; a
