@@ -74,27 +74,54 @@ def per_parameter(grads, ref):
     return sorted(rows, key=lambda t: -t[1])
 
 
-def compare(grads, ref):
-    """(global relative L2 error, (worst parameter, its relative error)) of {name: grad} against the reference."""
+def compare(grads, ref, worst_min_numel=0):
+    """(global relative L2 error, (worst parameter, its relative error)) of {name: grad} against the reference.
+    worst_min_numel: parameters with fewer elements count in the global error but not for the worst one (see
+    scalar_sums_within_conditioning)."""
     num = den = 0.0
     worst = ("", 0.0)
     for k, g in grads.items():
         r = ref[k]
         n, d = float(((g.detach().cpu() - r) ** 2).sum()), float((r ** 2).sum())
         num, den = num + n, den + d
-        if d > 1e-16 and (n / d) ** 0.5 > worst[1]:
+        if g.numel() >= worst_min_numel and d > 1e-16 and (n / d) ** 0.5 > worst[1]:
             worst = (k, (n / d) ** 0.5)
     return (num / den) ** 0.5, worst
 
 
-def check_against_emulation(grads, ref16, global_tol, param_tol):
+def scalar_sums_within_conditioning(grads, ref32, ref16, max_numel=2, floor=1.0, factor=5.0):
+    """The conv module's 1- and 2-element parameters (pw_conv_1 / pw_conv_2: Conv1d(1, 2, 1) / Conv1d(2, 1, 1)) get
+    gradients that are sums over EVERY position and channel with heavy cancellation; their relative error is as large as
+    the sum is ill-conditioned at the shape and seed at hand, whatever computes it (measured on four shapes with the
+    kernels of round 4 and of round 5 alike: 0.06 / 0.16-0.20 / 0.42-0.48 / 2.3 on pw_conv_2.bias while every vector
+    and matrix gradient stays below 0.1).  The kernel-level test (test_gpu_bwd.py, csship_convmod_bwd against float64
+    autograd on the SAME upstream gradient) pins these sums to 1e-4; at model level this is a sanity bound only: the HIP
+    value may be ``factor`` times as far from the fp32 oracle as the oracle's own bf16-operand evaluation is, or
+    ``floor``.  Returns the worst (name, error, allowed)."""
+    worst = ("", 0.0, floor)
+    for k, g in grads.items():
+        if g.numel() > max_numel:
+            continue
+        r = ref32[k]
+        d = float((r ** 2).sum()) ** 0.5
+        if d <= 1e-12:
+            continue
+        e = float(((g.detach().cpu() - r) ** 2).sum()) ** 0.5 / d
+        allowed = max(floor, factor * float(((ref16[k] - r) ** 2).sum()) ** 0.5 / d)
+        assert e < allowed, f"{k}: relative error {e:.3e} vs the fp32 oracle, the bf16-operand oracle itself moves {allowed / factor:.3e}"
+        if e > worst[1]:
+            worst = (k, e, allowed)
+    return worst
+
+
+def check_against_emulation(grads, ref16, global_tol, param_tol, min_numel=0):
     """HIP gradients vs the oracle with bf16 operands in forward and backward (oracle/emulate.py): global relative L2
     error and the worst parameter among those whose reference gradient is not numerically zero (>= 1e-4 of the largest
     parameter-gradient norm: the key bias - softmax is shift invariant - and a bias in front of a batch-statistics
     BatchNorm have mathematically zero gradients, there both sides hold rounding noise).  Returns (global, worst)."""
     rows = per_parameter(grads, ref16)
     big = max(d for _, _, d in rows)
-    live = [(k, e) for k, e, d in rows if d >= 1e-4 * big]
+    live = [(k, e) for k, e, d in rows if d >= 1e-4 * big and grads[k].numel() >= min_numel]
     num = sum(float(((grads[k].detach().cpu() - ref16[k]) ** 2).sum()) for k in grads)
     den = sum(float((ref16[k] ** 2).sum()) for k in grads)
     glob = (num / den) ** 0.5

@@ -408,15 +408,18 @@ def test_conformer_gradients_flow_and_match_oracle_autograd():
     print(f"[parity] ... vs the bf16-operand oracle: global {g16:.3e}, worst live parameter {w16[0]} {w16[1]:.3e}")
 
 
-def test_conformer_hip_backward_matches_oracle_autograd():
+@pytest.mark.parametrize("B,T", [(3, 60), (2, 96), (4, 64)])
+def test_conformer_hip_backward_matches_oracle_autograd(B, T):
     """Training path with the explicit HIP backward (css_amd/autograd.py ConformerTrain, 2 blocks, batch-statistics
     BatchNorm): every parameter gradient vs torch.autograd through the oracle (fp32, training_bn=True) at the same
-    permutation.  bf16 GEMM operands in forward and backward: global relative error bound 3e-2."""
+    permutation.  bf16 GEMM operands in forward and backward: global relative error bound 3e-2.
+    (3, 60): 180 rows, a ragged last panel - the bounds-checked kernels; (2, 96): 192 rows = whole 64-row panels - the
+    static forms the full-size step runs (chain_s_kernel<TRAIN>, ffn_bwd_kernel<FULL, LN2>, qkv_in_bwd_kernel,
+    panel_dx_kernel, the grouped weight gradients)."""
     from css_amd.objectives import OBJECTIVES
     import grad_ref
     m, sd = build(2, 43)
     m.train()
-    B, T = 3, 60
     f = rnd((B, T, 257), 14).abs().to(DEV)
     tg = [(rnd((B, T, 257), 60 + k).abs() * 0.5).to(DEV) for k in range(2)]
     obj = OBJECTIVES["MSE"].build_objective({})
@@ -437,7 +440,8 @@ def test_conformer_hip_backward_matches_oracle_autograd():
     perm = obj.last_permutation.cpu().tolist()
     tc = [t.cpu() for t in tg]
     ref = grad_ref.oracle_param_grads(m, lambda mk: grad_ref.pit_loss_with_perm(mk, f.cpu(), tc, perm), f, training_bn=True)
-    err, worst = grad_ref.compare(grads, ref)
+    strict = (B, T) == (3, 60)   # the shape whose scalar sums happen to be well conditioned: every parameter under one bound
+    err, worst = grad_ref.compare(grads, ref, worst_min_numel=0 if strict else 3)
     print(f"[parity] HIP backward vs oracle autograd: global rel err {err:.3e}, worst {worst[0]} {worst[1]:.3e}")
     assert err < 3e-2
     assert worst[1] < 0.15
@@ -445,7 +449,10 @@ def test_conformer_hip_backward_matches_oracle_autograd():
     # scalar bias - a sum with heavy cancellation over every position; profiles/r03_grad_table.txt)
     ref16 = grad_ref.oracle_param_grads(m, lambda mk: grad_ref.pit_loss_with_perm(mk, f.cpu(), tc, perm), f, training_bn=True,
                                         emulate_bf16=True)
-    g16, w16 = grad_ref.check_against_emulation(grads, ref16, global_tol=2.5e-2, param_tol=0.12)
+    # the conv module's 1- / 2-element parameters: bounded by how ill-conditioned their sums are at THIS shape
+    ws = grad_ref.scalar_sums_within_conditioning(grads, ref, ref16)
+    print(f"[parity] ... scalar conv parameters: worst {ws[0]} {ws[1]:.3e} (allowed {ws[2]:.3e})")
+    g16, w16 = grad_ref.check_against_emulation(grads, ref16, global_tol=2.5e-2, param_tol=0.12, min_numel=0 if strict else 3)
     print(f"[parity] ... vs the bf16-operand oracle: global {g16:.3e}, worst live parameter {w16[0]} {w16[1]:.3e}")
     del ref_state
 
