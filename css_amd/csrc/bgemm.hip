@@ -203,8 +203,13 @@ DEV bf16x8 read_frag(const unsigned char* img, int r0, int ks, int lane) {
 template <int OFF>
 DEV bf16x8 read_frag_km_asm(unsigned lds_addr) {
   s16x4 lo, hi;
+#ifdef GL_NO_READ
+  asm volatile("" : "=v"(lo) : "v"(lds_addr), "n"(OFF));
+  asm volatile("" : "=v"(hi) : "v"(lds_addr), "n"(OFF + 1024));
+#else
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(lds_addr), "n"(OFF));
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(lds_addr), "n"(OFF + 1024));
+#endif
   return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 #define FRAG_WAIT(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]))
@@ -221,7 +226,13 @@ DEV void gl_read_step(bf16x8 (&a)[4], bf16x8 (&b)[4], unsigned st, const unsigne
 // an MFMA inside an asm statement, so the wait states it would insert are ours: an MFMA reading a register a VALU
 // instruction wrote needs 2 - the fragments come from LDS (s_waitcnt), the accumulators are zeroed long before
 // (s_nop after the zeroing), the vector of ones is a constant the compiler may re-create anywhere (s_nop in place).
+// -DGL_NO_MFMA / -DGL_NO_READ / -DGL_NO_DMA: diagnostic builds of the LDS-DMA loop with one of its three streams knocked
+// out (wrong results; tools/probes/wgrad_rate.py times what is left) - not part of the product build
+#ifdef GL_NO_MFMA
+#define GL_MFMA(c, x, y) asm volatile("" : "+a"(c) : "v"(x), "v"(y))
+#else
 #define GL_MFMA(c, x, y) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(x), "v"(y))
+#endif
 template <bool CS>
 DEV void gl_mfma_step(f32x4 (&acc)[4][4], f32x4 (&cs)[4], const bf16x8& ones, const bf16x8 (&a)[4], const bf16x8 (&b)[4]) {
   asm volatile("s_nop 1");  // should hipcc ever copy a fragment (VALU) between its wait and these MFMAs: 2 wait states
@@ -229,6 +240,28 @@ DEV void gl_mfma_step(f32x4 (&acc)[4][4], f32x4 (&cs)[4], const bf16x8& ones, co
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) GL_MFMA(acc[i][j], b[j], a[i]);
+    if constexpr (CS) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(cs[i]) : "v"(ones), "v"(a[i]));
+  }
+}
+
+// The MFMAs of one k-step with the fragment reads of the NEXT k-step between them: one fragment (two transposing reads)
+// behind each of the first eight MFMAs, so the reads are all issued while the matrix pipe works and their latency runs
+// under the last eight.  As two blocks - 16 reads, then 16 MFMAs - the pipe stood idle while a wave (one per SIMD,
+// in-order issue) sent its reads and its LDS-DMA requests: 552 ns per 128 x 128 x 64 tile step on an otherwise idle
+// GPU against 213 ns of MFMA work (tools/probes/wgrad_rate.py).
+template <bool CS, int OFF>
+DEV void gl_mfma_read_step(f32x4 (&acc)[4][4], f32x4 (&cs)[4], const bf16x8& ones, const bf16x8 (&a)[4], const bf16x8 (&b)[4],
+                           bf16x8 (&an)[4], bf16x8 (&bn)[4], unsigned st, const unsigned (&fa)[4], const unsigned (&fb)[4]) {
+  asm volatile("s_nop 1");
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      GL_MFMA(acc[i][j], b[j], a[i]);
+      const int m = i * 4 + j;
+      if (m < 4) an[m] = read_frag_km_asm<OFF>(st + fa[m]);
+      else if (m < 8) bn[m - 4] = read_frag_km_asm<128 * 128 + OFF>(st + fb[m - 4]);
+    }
     if constexpr (CS) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(cs[i]) : "v"(ones), "v"(a[i]));
   }
 }
@@ -263,7 +296,15 @@ DEV void bgemm_tile(const BgemmArgs& g, const int bx, const int by, const int bz
   constexpr int NJ = TN / 32, WN = TN / 2;  // 16-column fragments per wave, columns per wave
   __shared__ __attribute__((aligned(16))) unsigned char smem[(GL ? GL_STAGES : 2) * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = GL ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
+  // GL: 8 waves - waves 0..3 own the four 64 x 64 quarters of the tile (fragment reads and MFMAs only), waves 4..7 do
+  // nothing but issue the LDS-DMA pieces (wave 4 + w the ones wave w used to issue) and wait for them.  One piece costs
+  // its wave 60-180 cycles of issue; issued by the MFMA waves themselves (one wave per SIMD, in order) the eight pieces
+  // per tile step stood in front of the MFMAs: 530 ns per step on an idle GPU against 213 of MFMA work, 492 with the
+  // fragment reads knocked out, 350 with the MFMAs knocked out (tools/probes/wgrad_rate.py, -DGL_NO_*).  A loader
+  // wave shares its SIMD with an MFMA wave and its issue stalls are that wave's alone.
+  const int wave_all = GL ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
+  const bool loader = GL && wave_all >= 4;   // wave-uniform
+  const int wave = GL ? (wave_all & 3) : wave_all;
 #ifdef BG_STAMPS
   __shared__ unsigned stamps[96];
   if (tid < 96) stamps[tid] = 0;
@@ -337,7 +378,11 @@ DEV void bgemm_tile(const BgemmArgs& g, const int bx, const int by, const int bz
       gb[j] = ((unsigned)kl * (unsigned)g.ldb + (unsigned)(n0 + e0)) * 2u;
     }
     auto glds_tile = [&](int k0, unsigned so) {
+#ifdef GL_NO_DMA
+      const bool valid = false;   // every request beyond the descriptor: zeros, no memory traffic
+#else
       const bool valid = k0 < kend;
+#endif
       const unsigned ka = (unsigned)k0 * (unsigned)g.lda * 2u, kb = (unsigned)k0 * (unsigned)g.ldb * 2u;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -367,47 +412,66 @@ DEV void bgemm_tile(const BgemmArgs& g, const int bx, const int by, const int bz
     // The body exists twice, with and without the column-sum MFMAs (a wave-uniform branch inside would sit between asm
     // statements).  Every iteration issues a tile - beyond the reduction range the offsets are outside the descriptor:
     // zeros, no memory traffic - so the vmcnt count is the same everywhere.
+    if (loader) {
+      // tile kt lives in stage kt % GL_STAGES; tiles kt + 1 .. kt + GL_STAGES - 2 may still be in flight when tile kt is
+      // needed (8 pieces per loader wave each), and tile kt + GL_STAGES - 1 goes into the stage tile kt - 1 was read from.
+      // Every iteration issues a tile - beyond the reduction range the offsets are outside the descriptor: zeros, no
+      // memory traffic - so the vmcnt count is the same everywhere.  One barrier per tile step, shared with the MFMA waves.
+      if (nk > 0) {
+#pragma unroll
+        for (int t = 0; t < GL_STAGES - 1; ++t) glds_tile(kbeg + t * BK, t * STAGE);
+        unsigned cur = 0, prev = (GL_STAGES - 1) * STAGE;
+        GL_WAIT_TILE();                // my part of tile 0 has landed
+        __builtin_amdgcn_s_barrier();
+        glds_tile(kbeg + (GL_STAGES - 1) * BK, prev);
+        for (int kt = 1; kt < nk; ++kt) {
+          prev = cur;
+          cur = (cur == (GL_STAGES - 1) * STAGE) ? 0 : cur + STAGE;
+          GL_WAIT_TILE();                // my part of tile kt has landed
+          __builtin_amdgcn_s_barrier();  // all of tile kt is in LDS, and every MFMA wave is done reading tile kt - 1
+          glds_tile(kbeg + (kt + GL_STAGES - 1) * BK, prev);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zero tiles behind the last one
+      }
+      return;  // the loader waves take no part in the epilogue (no barrier follows)
+    }
+    // The MFMA waves' loop in inline assembly statements, which hipcc keeps in source order.  Left to the compiler, the
+    // second k-step's MFMAs get destination tuples shifted against their sources and 48 accumulators travel through
+    // register copies per tile; and the LDS reads would wait for vmcnt(0) (read_frag_km_asm).  Per tile, one barrier:
+    //   barrier | MFMAs of k-step 1 of tile kt - 1 with the reads of k-step 0 of tile kt between them | fragments landed
+    //   | MFMAs of k-step 0 with the reads of k-step 1 between them | fragments landed
+    // The body exists twice, with and without the column-sum MFMAs (a wave-uniform branch inside would sit between asm
+    // statements).
     auto main_loop = [&](auto with_cs) {
       constexpr bool CS = decltype(with_cs)::value;
       bf16x8 a0[4], b0[4], a1[4], b1[4];
       auto read_step0 = [&](unsigned st) { gl_read_step<0>(a0, b0, st, fa, fb); };
-      auto read_step1 = [&](unsigned st) { gl_read_step<32 * 256>(a1, b1, st, fa, fb); };
       auto mfma_step = [&](bf16x8 (&a)[4], bf16x8 (&b)[4]) { gl_mfma_step<CS>(acc, cs, ones, a, b); };
-#pragma unroll
-      for (int t = 0; t < GL_STAGES - 1; ++t) glds_tile(kbeg + t * BK, t * STAGE);
-      // tile kt lives in stage kt % GL_STAGES; tiles kt + 1 .. kt + GL_STAGES - 2 may still be in flight when tile kt is
-      // needed (8 instructions per wave each), and tile kt + GL_STAGES - 1 goes into the stage tile kt - 1 was read from
-      unsigned cur = 0, prev = (GL_STAGES - 1) * STAGE;
-      GL_WAIT_TILE();
-      __builtin_amdgcn_s_barrier();
+      // MFMAs of the k-step held in (a1, b1) while k-step 0 of the tile at st is read into (a0, b0), and the other way round
+      auto mfma1_read0 = [&](unsigned st) { gl_mfma_read_step<CS, 0>(acc, cs, ones, a1, b1, a0, b0, st, fa, fb); };
+      auto mfma0_read1 = [&](unsigned st) { gl_mfma_read_step<CS, 32 * 256>(acc, cs, ones, a0, b0, a1, b1, st, fa, fb); };
+      unsigned cur = 0;
+      __builtin_amdgcn_s_barrier();    // tile 0 is in LDS
       read_step0(smem_lds);
-      glds_tile(kbeg + (GL_STAGES - 1) * BK, prev);
       FRAG_WAIT(0, a0);
       FRAG_WAIT(0, b0);
-      read_step1(smem_lds);
       asm volatile("s_nop 4");  // accumulators zeroed by VALU moves
-      mfma_step(a0, b0);
+      mfma0_read1(smem_lds);
       FRAG_WAIT(0, a1);
       FRAG_WAIT(0, b1);
       for (int kt = 1; kt < nk; ++kt) {
-        prev = cur;
         cur = (cur == (GL_STAGES - 1) * STAGE) ? 0 : cur + STAGE;
-        GL_WAIT_TILE();                // my part of tile kt has landed
         __builtin_amdgcn_s_barrier();  // all of tile kt is in LDS, and every wave is done reading tile kt - 1
-        read_step0(smem_lds + cur);
-        mfma_step(a1, b1);             // k-step 1 of tile kt - 1
-        glds_tile(kbeg + (kt + GL_STAGES - 1) * BK, prev);
+        mfma1_read0(smem_lds + cur);   // k-step 1 of tile kt - 1 | fragments of k-step 0 of tile kt
         FRAG_WAIT(0, a0);
         FRAG_WAIT(0, b0);
-        read_step1(smem_lds + cur);
-        mfma_step(a0, b0);
+        mfma0_read1(smem_lds + cur);
         FRAG_WAIT(0, a1);
         FRAG_WAIT(0, b1);
       }
       mfma_step(a1, b1);
-      // the zero tiles behind the last one; and the MFMA results are read by ordinary instructions next, which
-      // the compiler cannot know to delay
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+      // the MFMA results are read by ordinary instructions next, which the compiler cannot know to delay
+      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     };
     if (nk > 0) {
       if (COLSUM && do_cs) main_loop(std::true_type{});
@@ -616,16 +680,16 @@ DEV void bgemm_tile(const BgemmArgs& g, const int bx, const int by, const int bz
 #ifdef BG_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   STAMP(63);  // result stores drained
-  __syncthreads();
-  if (g_bg_stamps && tid < 96) {
+  if (g_bg_stamps && tid < 64) {  // wave 0 wrote them itself: no barrier (the loader waves of the GL form are gone by now)
     const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     g_bg_stamps[lin * 96 + tid] = stamps[tid];
+    if (tid < 32) g_bg_stamps[lin * 96 + 64 + tid] = stamps[64 + tid];
   }
 #endif
 }
 
 template <bool A_KM, bool B_KM, bool FAST, bool A_F32, bool B_F32, bool COLSUM = false, int TN = 128, bool GL = false>
-__global__ __launch_bounds__(256) void bgemm_kernel(BgemmArgs g) {
+__global__ __launch_bounds__(GL ? 512 : 256) void bgemm_kernel(BgemmArgs g) {
   // XCD-aware tile order.  Workgroups go to the 8 XCDs round-robin by their linear id, and every XCD has its own L2:
   // in the natural order the tiles that share operand rows (all output tiles of one K-split, or of one batch entry)
   // land on 8 different XCDs and each pulls the same rows through its own L2 (166 MB of L2 fills for 39 MB of
@@ -669,7 +733,7 @@ struct WgGroup {
   unsigned short map[WG_MAXWG];  // job << 12 | split << 8 | tile
 };
 
-__global__ __launch_bounds__(256) void bgemm_wgrad_group_kernel(WgGroup G) {
+__global__ __launch_bounds__(512) void bgemm_wgrad_group_kernel(WgGroup G) {
   const unsigned e = G.map[blockIdx.x];
   if (e == WG_IDLE) return;
   const WgJob& J = G.job[e >> 12];
@@ -1079,7 +1143,7 @@ extern "C" int csship_wgrad_flush(void* workspace, size_t workspace_bytes, csshi
     }
     for (size_t sl = 0; sl < slots; ++sl)
       for (int x = 0; x < 8; ++x) G.map[sl * 8 + x] = sl < xcd[x].size() ? xcd[x][sl] : WG_IDLE;
-    hipLaunchKernelGGL(bgemm_wgrad_group_kernel, dim3((unsigned)(slots * 8)), dim3(256), 0, s, G);
+    hipLaunchKernelGGL(bgemm_wgrad_group_kernel, dim3((unsigned)(slots * 8)), dim3(512), 0, s, G);
     if (hipGetLastError() != hipSuccess) {
       rc = CSSHIP_ELAUNCH;
       break;
@@ -1250,7 +1314,7 @@ static int bgemm_impl(const void* A, const void* B, void* C, const float* bias, 
     if (p->a_f32 && p->b_f32) hipLaunchKernelGGL((bgemm_kernel<true, true, true, true, true, true>), grid, dim3(256), 0, s, a);
     else if (p->a_f32) hipLaunchKernelGGL((bgemm_kernel<true, true, true, true, false, true>), grid, dim3(256), 0, s, a);
     else if (p->b_f32) hipLaunchKernelGGL((bgemm_kernel<true, true, true, false, true, true>), grid, dim3(256), 0, s, a);
-    else if (gl) hipLaunchKernelGGL((bgemm_kernel<true, true, true, false, false, true, 128, true>), grid, dim3(256), 0, s, a);
+    else if (gl) hipLaunchKernelGGL((bgemm_kernel<true, true, true, false, false, true, 128, true>), grid, dim3(512), 0, s, a);
     else hipLaunchKernelGGL((bgemm_kernel<true, true, true, false, false, true>), grid, dim3(256), 0, s, a);
   } else if (p->a_kmajor && p->b_kmajor) BG_LAUNCH(true, true);
   else if (p->a_kmajor) BG_LAUNCH(true, false);
