@@ -938,7 +938,7 @@ bool narrow_tile(const csship_bgemm_params* p) {
 bool glds_path(const csship_bgemm_params* p, bool colsum) {
   static const bool off = getenv("CSSHIP_BGEMM_NOGLDS") != nullptr;  // A/B timing
   return !off && colsum && p->a_kmajor && p->b_kmajor && !p->a_f32 && !p->b_f32 && (p->M % 128) == 0 && (p->N % 128) == 0 &&
-         (p->K % BK) == 0 && p->batch1 == 1 && p->batch2 == 1;
+         p->batch1 == 1 && p->batch2 == 1;   // (any K: the rows of the last tile beyond K lie outside the descriptor - zeros)
 }
 
 int pick_splits(const csship_bgemm_params* p, bool colsum = false) {
@@ -946,7 +946,7 @@ int pick_splits(const csship_bgemm_params* p, bool colsum = false) {
   if (glds_path(p, colsum)) {
     // one workgroup per CU (128 KB of LDS): as many slabs as fill the 256 CUs once, in eights for the XCD-aware order
     // (measured, 12 800 rows: 256 x 1024 -> 16 slabs 21 us against 30 us with 24; tools/wgrad_sweep.py)
-    const int tiles = (p->M / 128) * (p->N / 128), kt = p->K / BK;
+    const int tiles = (p->M / 128) * (p->N / 128), kt = (p->K + BK - 1) / BK;
     int s = 256 / tiles;
     if (s >= 8) s &= ~7;
     if (s > kt / 2) s = kt / 2;
@@ -1063,7 +1063,7 @@ extern "C" int csship_wgrad_pending(void) { return (int)t_wq.size(); }
 static int wgrad_group_splits(size_t first, size_t count) {
   int tiles = 0;
   for (size_t i = first; i < first + count; ++i) tiles += (t_wq[i].M / 128) * (t_wq[i].N / 128);
-  const int kt = t_wq[first].K / BK;
+  const int kt = (t_wq[first].K + BK - 1) / BK;
   int s = tiles > 0 ? 256 / tiles : 2;
   s = std::max(2, std::min(s, 16));
   while (s > 2 && (tiles * s > WG_MAXWG - 8 * 32 || kt / s < 8)) --s;
@@ -1112,7 +1112,7 @@ extern "C" int csship_wgrad_flush(void* workspace, size_t workspace_bytes, csshi
     WgGroup G{};
     G.K = t_wq[at].K;
     G.splits = S;
-    const int kt = G.K / BK;
+    const int kt = (G.K + BK - 1) / BK;
     G.k_per_split = ((kt + S - 1) / S) * BK;
     // (product, split) units, largest first, each to the XCD with the fewest workgroups so far
     struct Unit { int job, split, tiles; };

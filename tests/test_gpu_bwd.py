@@ -252,8 +252,12 @@ def test_grouped_weight_gradients_equal_the_single_products(ob):
     """csship_wgrad_hold / csship_wgrad_flush: the weight-gradient products of a block queued and run as ONE launch (the
     reduction cut 2-3 times instead of 16-64) vs float64 on the same bf16 operands and vs the products one by one; a
     product that does not fit the grouped loop (f32 operand, ragged width) runs at once inside the scope"""
-    K = 6400
     shapes = [(1024, 256), (256, 1024), (768, 256), (256, 256), (128, 384)]
+    for K in (6400, 6432, 2008):   # whole 64-row tiles of the reduction; a last tile of 32 rows; of 24 rows
+        _grouped_case(ob, K, shapes)
+
+
+def _grouped_case(ob, K, shapes):
     ops_ = []
     for i, (M, N) in enumerate(shapes):
         dy = rnd((K, M), 40 + i, 0.5).to(torch.bfloat16).to(DEV)

@@ -17,6 +17,8 @@ ap.add_argument("--graph", action="store_true", help="capture the whole step in 
 ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam + clip_grad_norm_ instead of FusedAdam")
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--blocks", type=int, default=16)
+ap.add_argument("--B", type=int, default=32)
+ap.add_argument("--T", type=int, default=400)
 a = ap.parse_args()
 dev = "cuda"
 conf = dict(attention_dim=256, attention_heads=4, linear_units=1024, num_blocks=a.blocks, kernel_size=33,
@@ -31,7 +33,7 @@ else:
     from css_amd.optim import FusedAdam
     opt = FusedAdam(m.parameters(), lr=1e-4, max_norm=5.0)
 g = torch.Generator().manual_seed(0)
-batch = {k: (torch.rand((32, 400, 257), generator=g) * s).to(dev) for k, s in (("mix", 1.0), ("source1", 0.5), ("source2", 0.5))}
+batch = {k: (torch.rand((a.B, a.T, 257), generator=g) * s).to(dev) for k, s in (("mix", 1.0), ("source1", 0.5), ("source2", 0.5))}
 
 
 def step():
@@ -69,4 +71,4 @@ if trace:
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
 print(f"train step (hip backward, {a.blocks} blocks): {dt * 1e3:.3f} ms  "
-      f"= {12800 / dt / 1e6:.3f} M frames/s   loss {float(loss):.5f}   peak mem {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB")
+      f"= {a.B * a.T / dt / 1e6:.3f} M frames/s   loss {float(loss):.5f}   peak mem {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB")
