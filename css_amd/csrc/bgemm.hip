@@ -1041,7 +1041,7 @@ extern "C" int csship_reduce_hold(int32_t on) {
 extern "C" int csship_reduce_pending(void) { return (int)t_defer.jobs.size(); }
 
 // ---- grouped weight gradients (bgemm_wgrad_group_kernel): csship_bgemm_wgrad calls made while the hold is on are
-// queued when they fit the LDS-DMA loop (bf16 k-major operands in whole tiles, at most 256 tiles) and share the queue's
+// queued when they fit the LDS-DMA loop (bf16 k-major operands in whole tiles, at most 96 tiles) and share the queue's
 // reduction length; anything else runs at once, as without the hold.
 struct WgradQ {
   const void* A; const void* B; float* dW; float* db; const void* aux;
@@ -1060,24 +1060,31 @@ extern "C" int csship_wgrad_hold(int32_t on) {
 
 extern "C" int csship_wgrad_pending(void) { return (int)t_wq.size(); }
 
+// (the table holds slots x 8 entries, slots = the fullest XCD's workgroups: at most the average plus one unit - the deal
+// is largest first, each unit to the emptiest XCD - so `tiles x splits + 8 x largest unit` entries always suffice)
 static int wgrad_group_splits(size_t first, size_t count) {
-  int tiles = 0;
-  for (size_t i = first; i < first + count; ++i) tiles += (t_wq[i].M / 128) * (t_wq[i].N / 128);
+  int tiles = 0, maxu = 0;
+  for (size_t i = first; i < first + count; ++i) {
+    const int t = (t_wq[i].M / 128) * (t_wq[i].N / 128);
+    tiles += t;
+    maxu = std::max(maxu, t);
+  }
   const int kt = (t_wq[first].K + BK - 1) / BK;
   int s = tiles > 0 ? 256 / tiles : 2;
   s = std::max(2, std::min(s, 16));
-  while (s > 2 && (tiles * s > WG_MAXWG - 8 * 32 || kt / s < 8)) --s;
+  while (s > 2 && (tiles * s + 8 * maxu > WG_MAXWG || kt / s < 8)) --s;
   return std::min(s, std::max(1, kt));
 }
 
-// the queue is flushed in chunks of at most WG_JOBS products whose tiles x 2 fit the table
+// the queue is flushed in chunks of at most WG_JOBS products whose tiles x 2 (the fewest splits) fit the table
 static size_t wgrad_chunk(size_t first) {
   size_t n = 0;
-  int tiles = 0;
+  int tiles = 0, maxu = 0;
   while (first + n < t_wq.size() && n < (size_t)WG_JOBS) {
     const int t = (t_wq[first + n].M / 128) * (t_wq[first + n].N / 128);
-    if (n > 0 && (tiles + t) * 2 > WG_MAXWG - 8 * 32) break;
+    if (n > 0 && (tiles + t) * 2 + 8 * std::max(maxu, t) > WG_MAXWG) break;
     tiles += t;
+    maxu = std::max(maxu, t);
     ++n;
   }
   return n;
@@ -1250,7 +1257,7 @@ static int bgemm_impl(const void* A, const void* B, void* C, const float* bias, 
     return CSSHIP_EALIGN;
   if (p->lda < (p->a_kmajor ? p->M : p->K) || p->ldb < (p->b_kmajor ? p->N : p->K) || p->ldc < p->N)
     return CSSHIP_EBADSHAPE;
-  if (t_wq_on && colsum_out && !bias && p->splits == 0 && glds_path(p, true) && (p->M / 128) * (p->N / 128) <= 256 &&
+  if (t_wq_on && colsum_out && !bias && p->splits == 0 && glds_path(p, true) && (p->M / 128) * (p->N / 128) <= 96 &&
       p->K >= 16 * BK && (p->ldc & 3) == 0 && aligned16(C) && (t_wq.empty() || t_wq[0].K == p->K)) {
     t_wq.push_back(WgradQ{A, B, reinterpret_cast<float*>(C), colsum_out, aux, p->M, p->N, p->K, p->lda, p->ldb, p->ldc, p->ldaux,
                           p->alpha, alpha_head, head_rows, p->epilogue});

@@ -612,7 +612,7 @@ int csship_reduce_pending(void);
 int csship_reduce_flush(csship_stream_t stream);
 /* Grouped weight gradients.  Between csship_wgrad_hold(1) and csship_wgrad_flush() the calling host thread's
  * csship_bgemm_wgrad calls that fit the LDS-DMA loop (bf16 operands, M and N multiples of 128, K a multiple of 64 and
- * the same for all of them, at most 256 tiles, no bias) are queued and run by the flush as ONE launch over all their
+ * the same for all of them, at most 96 tiles, no bias) are queued and run by the flush as ONE launch over all their
  * tiles, the reduction cut only as often as fills the chip once (an encoder block's six products: 80 tiles x 3 pieces
  * instead of 16-64 pieces each), followed by one reduction launch (csship_reduce_flush, which also runs whatever else
  * is queued).  Contract: operands and outputs of a queued call stay valid and unread until the flush; its per-call

@@ -257,6 +257,23 @@ def test_grouped_weight_gradients_equal_the_single_products(ob):
         _grouped_case(ob, K, shapes)
 
 
+def test_grouped_weight_gradients_large_units(ob):
+    """products of 64 tiles each (whole-XCD units of the workgroup table) and one too large to be queued (128 tiles)"""
+    K = 2048
+    shapes = [(1024, 1024), (1024, 1024), (1024, 1024), (256, 256)]
+    ops_ = [((rnd((K, M), 80 + i, 0.5)).to(torch.bfloat16).to(DEV), (rnd((K, N), 90 + i, 0.5)).to(torch.bfloat16).to(DEV))
+            for i, (M, N) in enumerate(shapes)]
+    big = (rnd((K, 2048), 97, 0.5).to(torch.bfloat16).to(DEV), rnd((K, 1024), 98, 0.5).to(torch.bfloat16).to(DEV))
+    with ob.deferred_reductions(group_wgrads=True):
+        got = [ob.linear_wgrad(dy, x) for dy, x in ops_]
+        assert ob.lib().csship_wgrad_pending() == len(shapes)
+        gbig = ob.linear_wgrad(*big)                      # 128 tiles: runs at once
+        assert ob.lib().csship_wgrad_pending() == len(shapes)
+    for (dy, x), (dw, db) in zip(ops_ + [big], got + [gbig]):
+        assert froerr(dw, dy.double().cpu().T @ x.double().cpu()) < 2e-6
+        assert froerr(db, dy.double().cpu().sum(0)) < 2e-6
+
+
 def _grouped_case(ob, K, shapes):
     ops_ = []
     for i, (M, N) in enumerate(shapes):
