@@ -407,6 +407,8 @@ class ConformerTrain(torch.autograd.Function):
         red.flush()
         _deliver_group(model, model.linear, G)
         window = bw.relpos_window(S["pe_bf"], T, 1000)
+        if T <= 449:   # the transposed window of csship_attn_pos_bwd, once per backward pass
+            window = window + (ob.pe_window_t(window[0], T),)
         dwin = None
         # skewed dS buffer shared by all layers: the band positions are the same every layer, the rest stays zero
         skew_buf = _skew_buffer(model, (B, T, H, window[0].shape[0]), masks.device)

@@ -75,6 +75,7 @@ _NO_BAND = bool(os.environ.get("CSSHIP_NO_BAND"))   # A/B timing: the skewed-dS 
 _NO_LN_Y = bool(os.environ.get("CSSHIP_NO_LN_Y"))   # A/B timing: LayerNorm(x) for the q/k/v weight gradient by its own launch
 _SPLIT_ATTN_BWD = bool(os.environ.get("CSSHIP_ATTN_BWD_SPLIT"))   # A/B timing: probabilities / softmax backward / dS k as separate launches
 _NO_DVDK = bool(os.environ.get("CSSHIP_NO_DVDK"))   # A/B timing: dV and dK as two general batched products
+_NO_POS_FUSED = bool(os.environ.get("CSSHIP_NO_POS_FUSED"))   # A/B timing: the two position products of the attention backward as two tiled products
 _NO_PANEL_DX = bool(os.environ.get("CSSHIP_NO_PANEL_DX"))   # A/B timing: the output projection's input gradient by the tiled kernel
 
 
@@ -100,7 +101,7 @@ def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000, window=None, probs=
     H = n_head
     g = qkv.view(B, T, 3, H, 64)
     q, k, v = (g[:, :, i].permute(0, 2, 1, 3) for i in range(3))  # [B,H,T,64] strided views
-    win, idx = relpos_window(pe_table_bf, T, maxlen) if window is None else window
+    win, idx = relpos_window(pe_table_bf, T, maxlen) if window is None else window[:2]
     W = win.shape[0]
     p_v = None              # operand of dV: the dropped probabilities when the forward dropped them (conformer.py:249)
     do = dao.view(B, T, H, 64).permute(0, 2, 1, 3)
@@ -144,6 +145,13 @@ def _mha_core_products(qkv, g, q, k, do, p_v, ds, dsk, dq1, win, idx, window, dw
     else:
         ob.bgemm(p_v[..., :T], do, a_kmajor=True, b_kmajor=True, out=dv)    # dV = P^T dO
         ob.bgemm(ds[..., :T], q, a_kmajor=True, b_kmajor=True, out=dk)      # dK = dS^T q
+    win_t = window[2] if window is not None and len(window) > 2 else None
+    if (win_t is not None and not _NO_POS_FUSED and T <= 449 and q_rows is not None and dsk.is_contiguous()
+            and dq1.is_contiguous() and dq1.dtype == torch.float32 and tuple(dq1.shape) == (B, H, T, 64)):
+        # both position products in one pass over the skewed dS (csship_attn_pos_bwd)
+        acc = dwin_acc if dwin_acc is not None else torch.zeros((W, 64), dtype=torch.float32, device=qkv.device)
+        ob.attn_pos_bwd(dsk, win_t, q_rows, dq1, dqkv, acc, H)
+        return dqkv, acc
     # + dS_skew pe_window; row i of dS_skew is zero outside columns i .. i + T - 1: the product skips those reduction tiles
     ob.bgemm(dsk.permute(0, 2, 1, 3), win[None, None], b_kmajor=True, add=dq1, out=dq, band=0 if _NO_BAND else T - 1)
     if q_rows is None:

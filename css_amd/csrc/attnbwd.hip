@@ -241,6 +241,206 @@ __global__ __launch_bounds__(512) void attn_dvdk_kernel(DvDkArgs a) {
   }
 }
 
+
+// =============================================================================== the two position products in one pass
+// Behind the one-pass backward kernel the relative-position term leaves two products over the SKEWED dS
+// (dS_skew[b, t, h, w] = dS[b, h, t, j] at w = t - j + T - 1; bf16 [B, T, H, W], zero outside the band w in [t, t + T - 1]):
+//     dq[b, t, h, :]  = dq1[b, h, t, :] + sum_w dS_skew[b, t, h, w] pe_window[w, :]        (conformer.py:236-241)
+//     d pe_window[w, :] += sum_{b, t, h} dS_skew[b, t, h, w] q[b, t, h, :]
+// The tiled batched GEMM took 23.7 + 23.0 us for them at 32 x 4 x 400 (each reads the 41 MB band again at ~2 TB/s
+// through its phase-serial tile loop, the second through 32 reduction slabs and a slab sum).  Here a workgroup owns 64
+// frames of one sample, loads the band of each head ONCE as a [64 frames][<= 512 window rows] LDS tile (1 KB rows,
+// 32-byte groups XORed with a key of the row: the 16-byte row reads of the first product and the transposing reads of
+// the second are both conflict free) and runs both products from it:
+//   * dq^T tiles = pe_window^T (fragments straight from global, the same for every head: loaded once, kept in registers)
+//     x tile rows (ds_read_b128) - transposed product, so a lane owns four features of one frame;
+//   * window-gradient tiles [window row][feature], accumulated in registers over the four heads (4 x 4 tiles per wave):
+//     q^T (a [64][64] block staged like a k-major operand) x tile columns, both through ds_read_b64_tr_b16.
+// The next head's tile travels global -> registers while this head's products run.  Every workgroup leaves its window
+// gradient as one [<= 512][64] f32 partial (its window rows t0 .. t0 + 63 + T - 1); pos_window_reduce_kernel adds the
+// partials that cover a window row in a fixed order (deterministic, no atomics) into the accumulator.
+constexpr int PB_ROWS = 64;               // frames per workgroup
+constexpr int PB_ROWB = 1024;             // bytes of a tile row: 512 window columns
+constexpr int PB_TILE = PB_ROWS * PB_ROWB;  // 64 KB
+constexpr int PB_QROWB = 256;             // bytes of a row of the staged q block (64 features used)
+constexpr int PB_QTILE = PB_ROWS * PB_QROWB;  // 16 KB
+constexpr int PB_MAXKS = 16;              // k-steps of 32 window columns at most
+
+DEV int pb_key(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+DEV int pb_off(int row, int chunk) { return row * PB_ROWB + ((((chunk >> 1) ^ pb_key(row))) << 5) + (chunk & 1) * 16; }   // 16-byte chunk 0..63
+DEV int pb_qoff(int row, int chunk) { return row * PB_QROWB + ((((chunk >> 1) ^ pb_key(row))) << 5) + (chunk & 1) * 16; }  // chunk 0..7
+
+struct PosBwdArgs {
+  const unsigned short* dsk;   // bf16 [B, T, H, ldw]
+  const unsigned short* pet;   // bf16 [64, ldpt]: pe_window^T, zero beyond the window
+  const unsigned short* q;     // bf16 [B*T*H, 64], rows in dS_skew's order
+  const float* dq1;            // f32 [B, H, T, 64]
+  unsigned short* dqkv;        // bf16 [B*T, 3*H*64]: the q third is written
+  float* partial;              // [B * nblk][nwt * 16][64]
+  int64_t ldw, ldpt;
+  int B, T, H, nblk, nks, nwt;
+};
+
+__global__ __launch_bounds__(512) void attn_pos_bwd_kernel(PosBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char Ss[PB_TILE];
+  __shared__ __attribute__((aligned(16))) unsigned char Qs[PB_QTILE];
+  __shared__ __attribute__((aligned(16))) unsigned char Ps[PB_TILE];   // pe_window^T rows w0 .. of all 64 features: the same for every head
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, n = lane & 15;
+  const int v = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x / a.nblk, blk = blockIdx.x - b * a.nblk;
+  const int t0 = blk * PB_ROWS, w0 = t0;           // the block's band starts at window row t0
+  const int D3 = 3 * a.H * 64;
+  const int ncol = min(a.nks * 32, (int)(a.ldw - w0));   // window columns of the tile that exist in memory
+
+  // ---- staging assignment: S tile chunk (row 8 j + (tid >> 6), 16-byte chunk tid & 63), q block chunk (tid >> 3, tid & 7)
+  const int sc = tid & 63, sr0 = tid >> 6;
+  const bool scol_ok = sc * 8 + 8 <= ncol;
+  const int qr = tid >> 3, qc = tid & 7;
+  const bool qrow_ok = t0 + qr < a.T;
+  f32x4 sreg[8], qreg;
+  auto issue_loads = [&](int h) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = 8 * j + sr0;
+      const size_t row = ((size_t)b * a.T + min(t0 + r, a.T - 1)) * a.H + h;
+      sreg[j] = *reinterpret_cast<const f32x4*>(a.dsk + row * a.ldw + w0 + (scol_ok ? sc * 8 : 0));
+    }
+    const size_t qrow = ((size_t)b * a.T + min(t0 + qr, a.T - 1)) * a.H + h;
+    qreg = *reinterpret_cast<const f32x4*>(a.q + qrow * 64 + qc * 8);
+  };
+  auto stage = [&]() {
+    const f32x4 zero{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = 8 * j + sr0;
+      *reinterpret_cast<f32x4*>(Ss + pb_off(r, sc)) = (scol_ok && t0 + r < a.T) ? sreg[j] : zero;
+    }
+    *reinterpret_cast<f32x4*>(Qs + pb_qoff(qr, qc)) = qrow_ok ? qreg : zero;
+  };
+  issue_loads(0);
+
+  const int dt1 = v >> 1, tt0 = (v & 1) * 2;       // first product: feature tile dt1, frame tiles tt0, tt0 + 1
+  {  // the window tile: [64 features][nks * 32 window rows from w0], staged once (held in registers across the heads - 64
+     // per lane - it spilled)
+    const bool pcol_ok = sc * 8 + 8 <= a.nks * 32;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = 8 * j + sr0;
+      const f32x4 x = *reinterpret_cast<const f32x4*>(a.pet + (size_t)r * a.ldpt + w0 + (pcol_ok ? sc * 8 : 0));
+      *reinterpret_cast<f32x4*>(Ps + pb_off(r, sc)) = x;
+    }
+  }
+  f32x4 dw[4][4];                                   // window gradient: window tiles v, v + 8, v + 16, v + 24 x 4 feature tiles
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dw[j][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int h = 0; h < a.H; ++h) {
+    __syncthreads();                                // every wave is done with the previous head's tile
+    stage();
+    // dq1 of this head's two frame tiles, then the next head's tile (the last head re-reads itself: the same number of
+    // loads in flight on every trip)
+    f32x4 d1[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int t = min(t0 + (tt0 + jj) * 16 + n, a.T - 1);
+      d1[jj] = *reinterpret_cast<const f32x4*>(a.dq1 + (((size_t)b * a.H + h) * a.T + t) * 64 + dt1 * 16 + 4 * g);
+    }
+    issue_loads(min(h + 1, a.H - 1));
+    __syncthreads();
+    // ---- first product: dq^T[feature][frame] = pe_window^T x tile rows
+    f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ks = 0; ks < PB_MAXKS; ++ks) {
+      if (ks < a.nks) {
+        const bf16x8 pa = *reinterpret_cast<const bf16x8*>(Ps + pb_off(dt1 * 16 + n, ks * 4 + g));
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const bf16x8 sb = *reinterpret_cast<const bf16x8*>(Ss + pb_off((tt0 + jj) * 16 + n, ks * 4 + g));
+          dq[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, sb, dq[jj], 0, 0, 0);
+        }
+      }
+    }
+    // ---- second product: window gradient [feature][window row] += q^T x tile columns, over the block's 64 frames
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int r0 = ks * 32 + 8 * g + (n >> 2);
+      bf16x8 qa[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const unsigned char* p0 = Qs + r0 * PB_QROWB + ((dt ^ pb_key(r0)) << 5) + (n & 3) * 8;
+        const unsigned char* p1 = Qs + (r0 + 4) * PB_QROWB + ((dt ^ pb_key(r0 + 4)) << 5) + (n & 3) * 8;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p1));
+        qa[dt] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int wt = v + 8 * j;
+        if (wt < a.nwt) {                           // wave-uniform
+          const unsigned char* p0 = Ss + r0 * PB_ROWB + ((wt ^ pb_key(r0)) << 5) + (n & 3) * 8;
+          const unsigned char* p1 = Ss + (r0 + 4) * PB_ROWB + ((wt ^ pb_key(r0 + 4)) << 5) + (n & 3) * 8;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p1));
+          const bf16x8 sb = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) dw[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[dt], sb, dw[j][dt], 0, 0, 0);
+        }
+      }
+    }
+    // ---- dq = dq1 + position term -> the q third of dqkv (lane: features dt1 * 16 + 4 g .. + 3 of frame (tt0 + jj) * 16 + n)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int t = t0 + (tt0 + jj) * 16 + n;
+      if (t < a.T) {
+        const f32x4 r = dq[jj] + d1[jj];
+        *reinterpret_cast<uint2*>(a.dqkv + ((size_t)b * a.T + t) * D3 + h * 64 + dt1 * 16 + 4 * g) =
+            make_uint2(pack_bf2(r[0], r[1]), pack_bf2(r[2], r[3]));
+      }
+    }
+  }
+  // ---- the block's window gradient: rows w0 + wt * 16 + n, features dt * 16 + 4 g .. + 3
+  float* part = a.partial + (size_t)blockIdx.x * a.nwt * 16 * 64;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int wt = v + 8 * j;
+    if (wt < a.nwt) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        *reinterpret_cast<f32x4*>(part + (size_t)(wt * 16 + n) * 64 + dt * 16 + 4 * g) = dw[j][dt];
+    }
+  }
+}
+
+// window row w of the accumulator += the partials of every (sample, block) whose band covers it, samples then blocks in
+// ascending order.  Workgroup = one window row: 16 float4 columns x 16 sample groups, then a fixed-order LDS sum.
+__global__ __launch_bounds__(256) void pos_window_reduce_kernel(const float* __restrict__ partial, int B, int nblk, int nwt,
+                                                                float* __restrict__ dwin) {
+  __shared__ float4 red[16][16];
+  const int w = blockIdx.x, c4 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int span = nwt * 16;
+  // blocks with 64 blk <= w < 64 blk + span
+  const int hi = min(nblk - 1, w / PB_ROWS), lo = w >= span ? (w - span) / PB_ROWS + 1 : 0;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int b = grp; b < B; b += 16)
+    for (int blk = lo; blk <= hi; ++blk) {
+      const float4 x = *reinterpret_cast<const float4*>(partial + (((size_t)b * nblk + blk) * span + (w - blk * PB_ROWS)) * 64 + c4 * 4);
+      acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+    }
+  red[grp][c4] = acc;
+  __syncthreads();
+  if (grp == 0) {
+    float4 t = red[0][c4];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) { t.x += red[k][c4].x; t.y += red[k][c4].y; t.z += red[k][c4].z; t.w += red[k][c4].w; }
+    float4* o = reinterpret_cast<float4*>(dwin + (size_t)w * 64 + c4 * 4);
+    float4 cur = *o;
+    cur.x += t.x; cur.y += t.y; cur.z += t.z; cur.w += t.w;
+    *o = cur;
+  }
+}
+
 }  // namespace
 
 #ifdef DV_STAMPS
@@ -263,6 +463,41 @@ extern "C" int csship_attn_dvdk(const uint16_t* p_v, const uint16_t* ds, int64_t
   if (nwg > 0x7fffffffLL) return CSSHIP_EBADSHAPE;
   DvDkArgs a{p_v, ds, d_out, qkv, dqkv, ld_p, B, T, H, G, KH};
   hipLaunchKernelGGL(attn_dvdk_kernel, dim3((unsigned)nwg), dim3(512), 0, as_stream(stream), a);
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
+extern "C" size_t csship_attn_pos_bwd_workspace(int32_t B, int32_t T) {
+  if (B <= 0 || T <= 0) return 0;
+  const size_t nblk = (size_t)(T + PB_ROWS - 1) / PB_ROWS, nwt = ((size_t)T + PB_ROWS - 1 + 15) / 16;
+  return (size_t)B * nblk * nwt * 16 * 64 * sizeof(float);
+}
+
+extern "C" int csship_attn_pos_bwd(const uint16_t* ds_skew, int64_t ld_w, const uint16_t* pe_window_t, int64_t ld_pt,
+                                   const uint16_t* q_rows, const float* dq1, uint16_t* dqkv, float* dwin_acc, int32_t W,
+                                   int32_t B, int32_t T, int32_t H, void* workspace, size_t workspace_bytes,
+                                   csship_stream_t stream) {
+  if (!ds_skew || !pe_window_t || !q_rows || !dq1 || !dqkv || !dwin_acc || !workspace) return CSSHIP_ENULL;
+  if (B <= 0 || T <= 0 || H <= 0 || W < 2 * T - 1 || ld_w < W || (ld_w & 7) != 0 || (ld_pt & 7) != 0) return CSSHIP_EBADSHAPE;
+  const int nblk = (T + PB_ROWS - 1) / PB_ROWS;
+  const int span = PB_ROWS - 1 + T;                 // window rows a block's band can touch
+  const int nks = (span + 31) / 32, nwt = (span + 15) / 16;
+  if (nks > PB_MAXKS) return CSSHIP_EUNSUPPORTED;   // T <= 449: the tile holds 512 window columns (csship_bgemm serves longer chunks)
+  // the transposed window must cover every k-step of the last block (zero beyond the window); partial rows beyond the
+  // accumulator's W rows are zero (outside every band) and are not added
+  if (ld_pt < (int64_t)(nblk - 1) * PB_ROWS + nks * 32) return CSSHIP_EBADSHAPE;
+  if ((int64_t)B * nblk > 0x7fffffffLL) return CSSHIP_EBADSHAPE;
+  if (!aligned16(ds_skew) || !aligned16(pe_window_t) || !aligned16(q_rows) || !aligned16(dq1) || !aligned8(dqkv) ||
+      !aligned16(dwin_acc) || !aligned16(workspace))
+    return CSSHIP_EALIGN;
+  if (workspace_bytes < csship_attn_pos_bwd_workspace(B, T)) return CSSHIP_EWORKSPACE;
+  PosBwdArgs a{ds_skew, pe_window_t, q_rows, dq1, dqkv, reinterpret_cast<float*>(workspace), ld_w, ld_pt, B, T, H, nblk, nks, nwt};
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(attn_pos_bwd_kernel, dim3((unsigned)(B * nblk)), dim3(512), 0, s, a);
+  CSSHIP_CHECK_LAUNCH();
+  const int rows = std::min(W, (nblk - 1) * PB_ROWS + nwt * 16);
+  hipLaunchKernelGGL(pos_window_reduce_kernel, dim3((unsigned)rows), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), B,
+                     nblk, nwt, dwin_acc);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }

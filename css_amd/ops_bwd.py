@@ -553,6 +553,34 @@ def attn_dvdk(p_v, ds, d_out, qkv, dqkv, n_head):
     return dqkv
 
 
+def pe_window_t(win, T):
+    """pe_window^T for attn_pos_bwd: bf16 [64, ld] with the window's rows as columns, zero beyond them (ld covers every
+    k-step of the last 64-frame block)."""
+    W = win.shape[0]
+    nblk, nks = (T + 63) // 64, (T + 63 + 31) // 32
+    ld = (max(W, (nblk - 1) * 64 + nks * 32) + 7) // 8 * 8
+    out = torch.zeros((win.shape[1], ld), dtype=torch.bfloat16, device=win.device)
+    out[:, :W] = win.t()
+    return out
+
+
+def attn_pos_bwd(dsk, win_t, q_rows, dq1, dqkv, dwin_acc, n_head):
+    """The relative-position term's two gradient products in one pass over the skewed dS (csship_attn_pos_bwd):
+    the q third of dqkv = dq1 + dS_skew pe_window, and dwin_acc (f32 [W, 64]) += dS_skew^T q.  dsk bf16 [B,T,H,W]."""
+    _need(dsk, torch.bfloat16, "dsk"), _need(win_t, torch.bfloat16, "win_t"), _need(q_rows, torch.bfloat16, "q_rows")
+    _need(dq1, torch.float32, "dq1"), _need(dqkv, torch.bfloat16, "dqkv"), _need(dwin_acc, torch.float32, "dwin_acc")
+    B, T, H, W = dsk.shape
+    if not (dsk.is_contiguous() and win_t.is_contiguous() and q_rows.is_contiguous() and dq1.is_contiguous() and
+            dqkv.is_contiguous() and dwin_acc.is_contiguous()) or H != n_head or q_rows.shape != (B * T * H, 64) or \
+            dq1.shape != (B, H, T, 64) or dqkv.shape != (B, T, 3 * H * 64) or dwin_acc.shape != (W, 64) or win_t.shape[0] != 64:
+        raise RuntimeError("css_amd: attn_pos_bwd expects dense dS_skew [B,T,H,W], q rows [B*T*H,64], dq1 [B,H,T,64], dqkv [B,T,3*H*64]")
+    nws = lib().csship_attn_pos_bwd_workspace(B, T)
+    ws = _workspace(nws, dsk.device)
+    check(lib().csship_attn_pos_bwd(_ptr(dsk), W, _ptr(win_t), win_t.shape[1], _ptr(q_rows), _ptr(dq1), _ptr(dqkv), _ptr(dwin_acc),
+                                    W, B, T, H, _ptr(ws), nws, _stream()))
+    return dqkv, dwin_acc
+
+
 def attn_softmax_bwd(qkv, d_out, p, d, skew, n_head, drop=None):
     """dS = P o (dO v^T - D) -> (dS bf16 like p, skew) ; skew: bf16 [B,T,H,W], zero outside the band, filled in place."""
     _need(qkv, torch.bfloat16, "qkv"), _need(p, torch.bfloat16, "p")

@@ -883,6 +883,19 @@ int csship_lstm_bidir_bwd_dist(const float* gates, const float* c, const float* 
  * [B*T, 3*H*64], of which the k and v thirds are written.  f32 accumulation over the queries in ascending order. */
 int csship_attn_dvdk(const uint16_t* p_v, const uint16_t* ds, int64_t ld_p, const uint16_t* d_out, const uint16_t* qkv,
                      uint16_t* dqkv, int32_t B, int32_t T, int32_t H, csship_stream_t stream);
+/* csship_attn_pos_bwd: the two products the relative-position term leaves behind the one-pass backward, in one pass
+ * over the skewed dS (ds_skew: bf16 [B, T, H, ld_w], entry (b, t, h, w) = dS[b, h, t, j] at w = t - j + T - 1, zero
+ * outside w in [t, t + T - 1]; conformer.py:236-241 under torch.autograd):
+ *   dqkv's q third [b, t, h, :] = dq1[b, h, t, :] + sum_w ds_skew[b, t, h, w] pe_window[w, :]     (bf16)
+ *   dwin_acc[w, :]             += sum_{b, t, h} ds_skew[b, t, h, w] q_rows[(b, t, h), :]            (f32 [W, 64], in place)
+ * pe_window_t: bf16 [64, ld_pt] = the window transposed, zero beyond its rows (ld_pt >= 64 (ceil(T / 64) - 1) + 32
+ * ceil((T + 63) / 32)); q_rows: bf16 [B*T*H, 64] in ds_skew's row order; dq1: f32 [B, H, T, 64].  d_k = 64,
+ * T <= 449 (CSSHIP_EUNSUPPORTED beyond: csship_bgemm with band serves longer chunks), W >= 2 T - 1.  Summation order
+ * fixed (deterministic). */
+size_t csship_attn_pos_bwd_workspace(int32_t B, int32_t T);
+int csship_attn_pos_bwd(const uint16_t* ds_skew, int64_t ld_w, const uint16_t* pe_window_t, int64_t ld_pt,
+                        const uint16_t* q_rows, const float* dq1, uint16_t* dqkv, float* dwin_acc, int32_t W, int32_t B,
+                        int32_t T, int32_t H, void* workspace, size_t workspace_bytes, csship_stream_t stream);
 
 /* ---- csship_p2p_reduce (css_amd/csrc/optim.hip): out[lo:hi] = scale * (src_0 + src_1 + ... + src_{world-1})[lo:hi],
  * summed in that order (bit-reproducible), for the direct (one-shot) all-reduce of css_amd.parallel.P2PAllReduce

@@ -257,6 +257,39 @@ def test_grouped_weight_gradients_equal_the_single_products(ob):
         _grouped_case(ob, K, shapes)
 
 
+@pytest.mark.parametrize("B,T,H", [(3, 100, 4), (2, 400, 4), (1, 64, 2), (2, 449, 1), (5, 37, 3)])
+def test_attn_pos_bwd_equals_the_two_products(ob, B, T, H):
+    """csship_attn_pos_bwd: dq = dq1 + dS_skew pe_window and d pe_window += dS_skew^T q in one pass over the skewed dS,
+    vs float64 on the same bf16 operands (the band structure as the one-pass backward kernel leaves it)"""
+    W = (2 * T - 1 + 7) // 8 * 8
+    g = torch.Generator().manual_seed(1000 * B + T)
+    ds = (0.3 * torch.randn(B, H, T, T, generator=g)).to(torch.bfloat16)
+    dsk = torch.zeros(B, T, H, W, dtype=torch.bfloat16)
+    ti = torch.arange(T)
+    w_idx = ti[:, None] - ti[None, :] + T - 1                    # [t, j] -> w
+    for t in range(T):
+        dsk[:, t, :, w_idx[t]] = ds[:, :, t, :]
+    win = torch.zeros(W, 64, dtype=torch.bfloat16)
+    win[:2 * T - 1] = (0.5 * torch.randn(2 * T - 1, 64, generator=g)).to(torch.bfloat16)
+    q = (0.5 * torch.randn(B * T * H, 64, generator=g)).to(torch.bfloat16)
+    dq1 = 0.2 * torch.randn(B, H, T, 64, generator=g)
+    acc0 = 0.1 * torch.randn(W, 64, generator=g)
+    dqkv = torch.zeros(B, T, 3 * H * 64, dtype=torch.bfloat16, device=DEV)
+    acc = acc0.clone().to(DEV)
+    ob.attn_pos_bwd(dsk.to(DEV), ob.pe_window_t(win.to(DEV), T), q.to(DEV), dq1.to(DEV), dqkv, acc, H)
+    ref_dq = dq1.double() + torch.einsum("bthw,wd->bhtd", dsk.double(), win.double())
+    ref_dw = acc0.double() + torch.einsum("bthw,bthd->wd", dsk.double(), q.double().view(B, T, H, 64))
+    got_dq = dqkv.view(B, T, 3, H, 64)[:, :, 0].permute(0, 2, 1, 3).double().cpu()
+    assert float((got_dq - ref_dq).abs().max()) <= 2.0 ** -8 * float(ref_dq.abs().max()) + 1e-6
+    assert froerr(acc, ref_dw) < 2e-6
+    assert torch.count_nonzero(dqkv.view(B, T, 3, H, 64)[:, :, 1:]) == 0     # the k and v thirds are not touched
+    if T == 449:
+        with pytest.raises(RuntimeError):   # 450 frames: the tile would need a 17th k-step
+            ob.attn_pos_bwd(torch.zeros(1, 450, 1, 904, dtype=torch.bfloat16, device=DEV), torch.zeros(64, 1000, dtype=torch.bfloat16, device=DEV),
+                            torch.zeros(450, 64, dtype=torch.bfloat16, device=DEV), torch.zeros(1, 1, 450, 64, device=DEV),
+                            torch.zeros(1, 450, 192, dtype=torch.bfloat16, device=DEV), torch.zeros(904, 64, device=DEV), 1)
+
+
 def test_grouped_weight_gradients_large_units(ob):
     """products of 64 tiles each (whole-XCD units of the workgroup table) and one too large to be queued (128 tiles)"""
     K = 2048
