@@ -411,7 +411,9 @@ class ConformerTrain(torch.autograd.Function):
             window = window + (ob.pe_window_t(window[0], T),)
         dwin = None
         # skewed dS buffer shared by all layers: the band positions are the same every layer, the rest stays zero
-        skew_buf = _skew_buffer(model, (B, T, H, window[0].shape[0]), masks.device)
+        # (not needed - and its 82 MB not allocated - when the position pass skews the row-major dS itself)
+        from_ds = len(window) > 2 and not bw._NO_POS_FUSED and not bw._NO_POS_FROM_DS
+        skew_buf = None if from_ds else _skew_buffer(model, (B, T, H, window[0].shape[0]), masks.device)
         ds = S["drop"]
         nlay = len(enc.encoders)
         layers = list(enc.encoders)

@@ -75,6 +75,7 @@ _NO_BAND = bool(os.environ.get("CSSHIP_NO_BAND"))   # A/B timing: the skewed-dS 
 _NO_LN_Y = bool(os.environ.get("CSSHIP_NO_LN_Y"))   # A/B timing: LayerNorm(x) for the q/k/v weight gradient by its own launch
 _SPLIT_ATTN_BWD = bool(os.environ.get("CSSHIP_ATTN_BWD_SPLIT"))   # A/B timing: probabilities / softmax backward / dS k as separate launches
 _NO_DVDK = bool(os.environ.get("CSSHIP_NO_DVDK"))   # A/B timing: dV and dK as two general batched products
+_NO_POS_FROM_DS = bool(os.environ.get("CSSHIP_NO_POS_FROM_DS"))   # A/B timing: the backward core also writes the skewed dS and the position pass reads that
 _NO_POS_FUSED = bool(os.environ.get("CSSHIP_NO_POS_FUSED"))   # A/B timing: the two position products of the attention backward as two tiled products
 _NO_PANEL_DX = bool(os.environ.get("CSSHIP_NO_PANEL_DX"))   # A/B timing: the output projection's input gradient by the tiled kernel
 
@@ -107,7 +108,9 @@ def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000, window=None, probs=
     do = dao.view(B, T, H, 64).permute(0, 2, 1, 3)
     if probs is not None and ao is not None and not _SPLIT_ATTN_BWD:
         # one pass over the scores: probabilities, softmax backward (row-major and skewed dS) and dS k
-        dsk = torch.zeros((B, T, H, W), dtype=BF, device=qkv.device) if skew_buf is None else skew_buf
+        from_ds = (window is not None and len(window) > 2 and window[2] is not None and T <= 449 and not _NO_POS_FUSED
+                   and not _NO_POS_FROM_DS)   # the position products skew the row-major dS themselves: no skewed copy
+        dsk = None if from_ds else (torch.zeros((B, T, H, W), dtype=BF, device=qkv.device) if skew_buf is None else skew_buf)
         p_v, ds, dsk, dq1, q_rows = ob.mha_bwd_core(qkv, probs[0], probs[1], dao, None, dsk, H, drop=drop_p,
                                                     out=ao.reshape(B * T, H * 64), want_q_rows=True)
         return _mha_core_products(qkv, g, q, k, do, p_v, ds, dsk, dq1, win, idx, window, dwin_acc, maxlen, q_rows, dao=dao)
@@ -146,12 +149,18 @@ def _mha_core_products(qkv, g, q, k, do, p_v, ds, dsk, dq1, win, idx, window, dw
         ob.bgemm(p_v[..., :T], do, a_kmajor=True, b_kmajor=True, out=dv)    # dV = P^T dO
         ob.bgemm(ds[..., :T], q, a_kmajor=True, b_kmajor=True, out=dk)      # dK = dS^T q
     win_t = window[2] if window is not None and len(window) > 2 else None
-    if (win_t is not None and not _NO_POS_FUSED and T <= 449 and q_rows is not None and dsk.is_contiguous()
+    if (win_t is not None and not _NO_POS_FUSED and T <= 449 and q_rows is not None and (dsk is None or dsk.is_contiguous())
             and dq1.is_contiguous() and dq1.dtype == torch.float32 and tuple(dq1.shape) == (B, H, T, 64)):
-        # both position products in one pass over the skewed dS (csship_attn_pos_bwd)
+        # both position products in one pass (csship_attn_pos_bwd): over the skewed dS, or - no skewed copy written -
+        # over the row-major dS, skewed while the kernel stages its tiles
         acc = dwin_acc if dwin_acc is not None else torch.zeros((W, 64), dtype=torch.float32, device=qkv.device)
-        ob.attn_pos_bwd(dsk, win_t, q_rows, dq1, dqkv, acc, H)
+        if dsk is None:
+            ob.attn_pos_bwd_ds(ds, win_t, q_rows, dq1, dqkv, acc, H)
+        else:
+            ob.attn_pos_bwd(dsk, win_t, q_rows, dq1, dqkv, acc, H)
         return dqkv, acc
+    if dsk is None:
+        raise RuntimeError("css_amd: the backward core was asked for no skewed dS, and the fused position pass is off")
     # + dS_skew pe_window; row i of dS_skew is zero outside columns i .. i + T - 1: the product skips those reduction tiles
     ob.bgemm(dsk.permute(0, 2, 1, 3), win[None, None], b_kmajor=True, add=dq1, out=dq, band=0 if _NO_BAND else T - 1)
     if q_rows is None:

@@ -67,7 +67,7 @@ DEV int v_off(int row, int chunk) {  // 16-byte chunk of a 128-byte V row; 32-by
 // of phase changes nothing), so the SIMD's issue port is ~90 % busy.  The next step is fewer, fatter instructions:
 // 32x32x16 MFMAs (half the matrix instructions, 12 + 16 LDS instructions for the rel-shift instead of 48), see DESIGN.md.
 #ifndef A2_ABL
-#define A2_ABL 0  // diagnostic builds only (tools/attn_ablate.sh): bit 0 no band, 1 no softmax, 2 no P.V, 3 no staging, 4 no S
+#define A2_ABL 0  // diagnostic builds only (tools/attn_ablate.sh): bit 0 no band, 1 no softmax, 2 no P.V, 3 no staging, 4 no S; backward: 6 no skewed-dS store, 7 no P' store, 8 no dS store
 #endif
 #ifdef A2_STAMPS  // diagnostic build: per-wave cycle sums of the loop's phases -> stamps[(wg * NW + wave) * 8 + phase]
 #define A2_T(i)                                                                                          \
@@ -679,8 +679,9 @@ extern "C" int csship_mha_relpos_bwd_core(const uint16_t* qkv, const uint16_t* p
                                           uint16_t* p_v_bf16, uint16_t* ds_bf16, uint16_t* ds_skew_bf16, float* dq1,
                                           uint16_t* q_rows, int64_t ld_p, int32_t W, int32_t B, int32_t T, int32_t H,
                                           const csship_dropout_cfg* drop, csship_stream_t stream) {
-  if (!qkv || !pe_packed || !lse || !d_out || (!d && !out) || !p_v_bf16 || !ds_bf16 || !ds_skew_bf16 || !dq1) return CSSHIP_ENULL;
-  if (B <= 0 || T <= 0 || H <= 0 || q_max < q_min || B > 65535 || H > 65535 || ld_p < T || (ld_p & 3) || W < 2 * T - 1)
+  if (!qkv || !pe_packed || !lse || !d_out || (!d && !out) || !p_v_bf16 || !ds_bf16 || !dq1) return CSSHIP_ENULL;
+  if (B <= 0 || T <= 0 || H <= 0 || q_max < q_min || B > 65535 || H > 65535 || ld_p < T || (ld_p & 3) ||
+      (ds_skew_bf16 && W < 2 * T - 1))
     return CSSHIP_EBADSHAPE;
   if (drop && drop->seed && drop->p > 0.f && ld_p != (T + 7) / 8 * 8) return CSSHIP_EBADSHAPE;
   if (!aligned16(qkv) || !aligned16(pe_packed) || !aligned16(d_out) || !aligned8(p_v_bf16) || !aligned8(ds_bf16) ||

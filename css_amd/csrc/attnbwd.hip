@@ -271,7 +271,7 @@ DEV int pb_off(int row, int chunk) { return row * PB_ROWB + ((((chunk >> 1) ^ pb
 DEV int pb_qoff(int row, int chunk) { return row * PB_QROWB + ((((chunk >> 1) ^ pb_key(row))) << 5) + (chunk & 1) * 16; }  // chunk 0..7
 
 struct PosBwdArgs {
-  const unsigned short* dsk;   // bf16 [B, T, H, ldw]
+  const unsigned short* dsk;   // bf16 [B, T, H, ldw]; or (FROM_DS) dS row-major bf16 [B, H, T, ldw]
   const unsigned short* pet;   // bf16 [64, ldpt]: pe_window^T, zero beyond the window
   const unsigned short* q;     // bf16 [B*T*H, 64], rows in dS_skew's order
   const float* dq1;            // f32 [B, H, T, 64]
@@ -281,6 +281,13 @@ struct PosBwdArgs {
   int B, T, H, nblk, nks, nwt;
 };
 
+// FROM_DS: the tile is built from the ROW-MAJOR dS (bf16 [B, H, T, ldw = ld_p]) - no skewed copy exists in memory at all
+// (writing it cost the one-pass backward kernel 11 of its 56 us: 8-byte pieces at 2-byte alignment).  Tile row r, window
+// columns 8 c .. 8 c + 7 are keys j = r + T - 8 - 8 c + 7 .. down to + 0 of frame t0 + r: ONE 16-byte load at a 2-byte
+// aligned address, the eight values reversed in registers (four v_alignbit), keys outside 0 .. T - 1 masked, one aligned
+// 16-byte LDS store - the skew costs no extra pass and no scattered store.  The loads reach up to 14 bytes in front of
+// and behind a row: the caller keeps 16 bytes of slack on both sides of the buffer.
+template <bool FROM_DS>
 __global__ __launch_bounds__(512) void attn_pos_bwd_kernel(PosBwdArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char Ss[PB_TILE];
   __shared__ __attribute__((aligned(16))) unsigned char Qs[PB_QTILE];
@@ -298,22 +305,54 @@ __global__ __launch_bounds__(512) void attn_pos_bwd_kernel(PosBwdArgs a) {
   const int qr = tid >> 3, qc = tid & 7;
   const bool qrow_ok = t0 + qr < a.T;
   f32x4 sreg[8], qreg;
+  struct __attribute__((packed, aligned(2))) U8 { unsigned short v[8]; };
   auto issue_loads = [&](int h) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int r = 8 * j + sr0;
-      const size_t row = ((size_t)b * a.T + min(t0 + r, a.T - 1)) * a.H + h;
-      sreg[j] = *reinterpret_cast<const f32x4*>(a.dsk + row * a.ldw + w0 + (scol_ok ? sc * 8 : 0));
+      if constexpr (FROM_DS) {
+        // (wave-uniform 64-bit base of the head + a 32-bit offset per lane: eight 64-bit row addresses kept across the
+        // heads were what spilled - and a scratch reload waits, in order, behind the tile prefetch)
+        // The base sits 8 elements in front of the head's first row so that the offset is never negative (a chunk may start
+        // up to 7 keys in front of its row: jl >= -7); an unsigned offset of -7 is 4 GB away.
+        const unsigned short* const hb = a.dsk + ((size_t)b * a.H + h) * a.T * a.ldw - 8;
+        const int js = r + a.T - 8 - 8 * sc;                      // key of the chunk's LAST column
+        const int jl = (js > -8 && js < a.T) ? js : 0;            // chunks with no key in range re-read the row's start
+        const unsigned off = (unsigned)(min(t0 + r, a.T - 1) * (int)a.ldw + jl + 8);
+        sreg[j] = __builtin_bit_cast(f32x4, *reinterpret_cast<const U8*>(hb + off));
+      } else {
+        const size_t row = ((size_t)b * a.T + min(t0 + r, a.T - 1)) * a.H + h;
+        sreg[j] = *reinterpret_cast<const f32x4*>(a.dsk + row * a.ldw + w0 + (scol_ok ? sc * 8 : 0));
+      }
     }
     const size_t qrow = ((size_t)b * a.T + min(t0 + qr, a.T - 1)) * a.H + h;
     qreg = *reinterpret_cast<const f32x4*>(a.q + qrow * 64 + qc * 8);
   };
+  // LDS offset of chunk sc of row 8 j + sr0: the swizzle key of that row is (sr0 & 3) | (j & 1) << 2 - two bases, j in the offset
+  const int so_even = pb_off(sr0, sc), so_odd = pb_off(8 + sr0, sc) - 8 * PB_ROWB;
   auto stage = [&]() {
     const f32x4 zero{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int r = 8 * j + sr0;
-      *reinterpret_cast<f32x4*>(Ss + pb_off(r, sc)) = (scol_ok && t0 + r < a.T) ? sreg[j] : zero;
+      const int so = ((j & 1) ? so_odd : so_even) + j * 8 * PB_ROWB;
+      if constexpr (FROM_DS) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 x = __builtin_bit_cast(u32x4, sreg[j]);
+        const int js = r + a.T - 8 - 8 * sc;
+        const bool rok = t0 + r < a.T;
+        u32x4 y;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {   // input elements 2 d (low half), 2 d + 1 (high half) are keys js + 2 d, js + 2 d + 1
+          const unsigned mlo = (rok && (unsigned)(js + 2 * d) < (unsigned)a.T) ? 0x0000ffffu : 0u;
+          const unsigned mhi = (rok && (unsigned)(js + 2 * d + 1) < (unsigned)a.T) ? 0xffff0000u : 0u;
+          const unsigned m = x[d] & (mlo | mhi);
+          y[3 - d] = (m >> 16) | (m << 16);   // reversed order: output element k = input element 7 - k
+        }
+        *reinterpret_cast<u32x4*>(Ss + so) = y;
+      } else {
+        *reinterpret_cast<f32x4*>(Ss + so) = (scol_ok && t0 + r < a.T) ? sreg[j] : zero;
+      }
     }
     *reinterpret_cast<f32x4*>(Qs + pb_qoff(qr, qc)) = qrow_ok ? qreg : zero;
   };
@@ -362,6 +401,16 @@ __global__ __launch_bounds__(512) void attn_pos_bwd_kernel(PosBwdArgs a) {
         }
       }
     }
+    // ---- dq = dq1 + position term -> the q third of dqkv (lane: features dt1 * 16 + 4 g .. + 3 of frame (tt0 + jj) * 16 + n)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int t = t0 + (tt0 + jj) * 16 + n;
+      if (t < a.T) {
+        const f32x4 r = dq[jj] + d1[jj];
+        *reinterpret_cast<uint2*>(a.dqkv + ((size_t)b * a.T + t) * D3 + h * 64 + dt1 * 16 + 4 * g) =
+            make_uint2(pack_bf2(r[0], r[1]), pack_bf2(r[2], r[3]));
+      }
+    }
     // ---- second product: window gradient [feature][window row] += q^T x tile columns, over the block's 64 frames
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -387,16 +436,6 @@ __global__ __launch_bounds__(512) void attn_pos_bwd_kernel(PosBwdArgs a) {
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt) dw[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[dt], sb, dw[j][dt], 0, 0, 0);
         }
-      }
-    }
-    // ---- dq = dq1 + position term -> the q third of dqkv (lane: features dt1 * 16 + 4 g .. + 3 of frame (tt0 + jj) * 16 + n)
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-      const int t = t0 + (tt0 + jj) * 16 + n;
-      if (t < a.T) {
-        const f32x4 r = dq[jj] + d1[jj];
-        *reinterpret_cast<uint2*>(a.dqkv + ((size_t)b * a.T + t) * D3 + h * 64 + dt1 * 16 + 4 * g) =
-            make_uint2(pack_bf2(r[0], r[1]), pack_bf2(r[2], r[3]));
       }
     }
   }
@@ -473,12 +512,34 @@ extern "C" size_t csship_attn_pos_bwd_workspace(int32_t B, int32_t T) {
   return (size_t)B * nblk * nwt * 16 * 64 * sizeof(float);
 }
 
+static int pos_bwd_impl(const uint16_t* ds_skew, int64_t ld_w, const uint16_t* pe_window_t, int64_t ld_pt,
+                        const uint16_t* q_rows, const float* dq1, uint16_t* dqkv, float* dwin_acc, int32_t W,
+                        int32_t B, int32_t T, int32_t H, void* workspace, size_t workspace_bytes,
+                        csship_stream_t stream, bool from_ds);
+
 extern "C" int csship_attn_pos_bwd(const uint16_t* ds_skew, int64_t ld_w, const uint16_t* pe_window_t, int64_t ld_pt,
                                    const uint16_t* q_rows, const float* dq1, uint16_t* dqkv, float* dwin_acc, int32_t W,
                                    int32_t B, int32_t T, int32_t H, void* workspace, size_t workspace_bytes,
                                    csship_stream_t stream) {
+  return pos_bwd_impl(ds_skew, ld_w, pe_window_t, ld_pt, q_rows, dq1, dqkv, dwin_acc, W, B, T, H, workspace, workspace_bytes,
+                      stream, false);
+}
+
+extern "C" int csship_attn_pos_bwd_ds(const uint16_t* ds, int64_t ld_p, const uint16_t* pe_window_t, int64_t ld_pt,
+                                      const uint16_t* q_rows, const float* dq1, uint16_t* dqkv, float* dwin_acc, int32_t W,
+                                      int32_t B, int32_t T, int32_t H, void* workspace, size_t workspace_bytes,
+                                      csship_stream_t stream) {
+  return pos_bwd_impl(ds, ld_p, pe_window_t, ld_pt, q_rows, dq1, dqkv, dwin_acc, W, B, T, H, workspace, workspace_bytes, stream,
+                      true);
+}
+
+static int pos_bwd_impl(const uint16_t* ds_skew, int64_t ld_w, const uint16_t* pe_window_t, int64_t ld_pt,
+                        const uint16_t* q_rows, const float* dq1, uint16_t* dqkv, float* dwin_acc, int32_t W,
+                        int32_t B, int32_t T, int32_t H, void* workspace, size_t workspace_bytes,
+                        csship_stream_t stream, bool from_ds) {
   if (!ds_skew || !pe_window_t || !q_rows || !dq1 || !dqkv || !dwin_acc || !workspace) return CSSHIP_ENULL;
-  if (B <= 0 || T <= 0 || H <= 0 || W < 2 * T - 1 || ld_w < W || (ld_w & 7) != 0 || (ld_pt & 7) != 0) return CSSHIP_EBADSHAPE;
+  if (B <= 0 || T <= 0 || H <= 0 || W < 2 * T - 1 || (ld_pt & 7) != 0) return CSSHIP_EBADSHAPE;
+  if (from_ds ? (ld_w < T) : (ld_w < W || (ld_w & 7) != 0)) return CSSHIP_EBADSHAPE;
   const int nblk = (T + PB_ROWS - 1) / PB_ROWS;
   const int span = PB_ROWS - 1 + T;                 // window rows a block's band can touch
   const int nks = (span + 31) / 32, nwt = (span + 15) / 16;
@@ -487,13 +548,14 @@ extern "C" int csship_attn_pos_bwd(const uint16_t* ds_skew, int64_t ld_w, const 
   // accumulator's W rows are zero (outside every band) and are not added
   if (ld_pt < (int64_t)(nblk - 1) * PB_ROWS + nks * 32) return CSSHIP_EBADSHAPE;
   if ((int64_t)B * nblk > 0x7fffffffLL) return CSSHIP_EBADSHAPE;
-  if (!aligned16(ds_skew) || !aligned16(pe_window_t) || !aligned16(q_rows) || !aligned16(dq1) || !aligned8(dqkv) ||
-      !aligned16(dwin_acc) || !aligned16(workspace))
+  if ((!from_ds && !aligned16(ds_skew)) || ((uintptr_t)ds_skew & 1) || !aligned16(pe_window_t) || !aligned16(q_rows) ||
+      !aligned16(dq1) || !aligned8(dqkv) || !aligned16(dwin_acc) || !aligned16(workspace))
     return CSSHIP_EALIGN;
   if (workspace_bytes < csship_attn_pos_bwd_workspace(B, T)) return CSSHIP_EWORKSPACE;
   PosBwdArgs a{ds_skew, pe_window_t, q_rows, dq1, dqkv, reinterpret_cast<float*>(workspace), ld_w, ld_pt, B, T, H, nblk, nks, nwt};
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(attn_pos_bwd_kernel, dim3((unsigned)(B * nblk)), dim3(512), 0, s, a);
+  if (from_ds) hipLaunchKernelGGL((attn_pos_bwd_kernel<true>), dim3((unsigned)(B * nblk)), dim3(512), 0, s, a);
+  else hipLaunchKernelGGL((attn_pos_bwd_kernel<false>), dim3((unsigned)(B * nblk)), dim3(512), 0, s, a);
   CSSHIP_CHECK_LAUNCH();
   const int rows = std::min(W, (nblk - 1) * PB_ROWS + nwt * 16);
   hipLaunchKernelGGL(pos_window_reduce_kernel, dim3((unsigned)rows), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), B,

@@ -516,7 +516,8 @@ def mha_bwd_core(qkv, pe_pack, lse, d_out, d, skew, n_head, drop=None, out=None,
     (attn_rowdot), or None with ``out`` = the forward's output bf16 [B*T, H*64]: the pass computes it.  want_q_rows:
     also the q rows as bf16 [B*T*H, 64] in skew's row order."""
     _need(qkv, torch.bfloat16, "qkv"), _need(lse, torch.float32, "lse"), _need(d_out, torch.bfloat16, "d_out")
-    _need(skew, torch.bfloat16, "skew")
+    if skew is not None:   # None: no skewed copy is written (attn_pos_bwd_ds skews the row-major dS itself)
+        _need(skew, torch.bfloat16, "skew")
     if d is not None:
         _need(d, torch.float32, "d")
     elif out is None:
@@ -525,18 +526,19 @@ def mha_bwd_core(qkv, pe_pack, lse, d_out, d, skew, n_head, drop=None, out=None,
         _need(out, torch.bfloat16, "out")
     packed, q_min, q_max = pe_pack
     B, T, D3 = qkv.shape
-    if not (qkv.is_contiguous() and d_out.is_contiguous() and lse.is_contiguous() and skew.is_contiguous()) \
+    if not (qkv.is_contiguous() and d_out.is_contiguous() and lse.is_contiguous()) \
+            or (skew is not None and (not skew.is_contiguous() or skew.shape[:3] != (B, T, n_head))) \
             or (d is not None and not d.is_contiguous()) or (out is not None and not out.is_contiguous()) \
-            or D3 != 3 * n_head * 64 or skew.shape[:3] != (B, T, n_head):
+            or D3 != 3 * n_head * 64:
         raise RuntimeError("css_amd: mha_bwd_core expects dense qkv [B,T,3*H*64], d_out [B*T,H*64], skew [B,T,H,W]")
     ldp = (T + 7) // 8 * 8
     p_v = torch.empty(B, n_head, T, ldp, device=qkv.device, dtype=torch.bfloat16)
-    ds = torch.empty_like(p_v)
+    ds = slack_bf16((B, n_head, T, ldp), qkv.device)   # (16 bytes of slack on both sides: attn_pos_bwd_ds)
     dq1 = torch.empty(B, n_head, T, 64, device=qkv.device, dtype=torch.float32)
     q_rows = torch.empty(B * T * n_head, 64, device=qkv.device, dtype=torch.bfloat16) if want_q_rows else None
     check(lib().csship_mha_relpos_bwd_core(_ptr(qkv), _ptr(packed), q_min, q_max, _ptr(lse), _ptr(d_out), _ptr(d),
                                            _ptr(out) if d is None else None, _ptr(p_v), _ptr(ds), _ptr(skew), _ptr(dq1),
-                                           _ptr(q_rows), ldp, skew.shape[3], B, T, n_head, drop, _stream()))
+                                           _ptr(q_rows), ldp, skew.shape[3] if skew is not None else 0, B, T, n_head, drop, _stream()))
     return (p_v, ds, skew, dq1, q_rows) if want_q_rows else (p_v, ds, skew, dq1)
 
 
@@ -562,6 +564,38 @@ def pe_window_t(win, T):
     out = torch.zeros((win.shape[1], ld), dtype=torch.bfloat16, device=win.device)
     out[:, :W] = win.t()
     return out
+
+
+def slack_bf16(shape, device):
+    """A dense bf16 tensor with 16 readable bytes in front of and behind it (csship_attn_pos_bwd_ds reads its rows in
+    16-byte pieces at 2-byte alignment)."""
+    n = 1
+    for d in shape:
+        n *= d
+    flat = torch.empty(n + 16, dtype=torch.bfloat16, device=device)
+    return flat[8:8 + n].view(shape)
+
+
+def attn_pos_bwd_ds(ds, win_t, q_rows, dq1, dqkv, dwin_acc, n_head):
+    """attn_pos_bwd from the ROW-MAJOR dS (bf16 [B,H,T,ldp], allocated by slack_bf16): the kernel skews it while staging,
+    no skewed copy exists (csship_attn_pos_bwd_ds)."""
+    _need(ds, torch.bfloat16, "ds"), _need(win_t, torch.bfloat16, "win_t"), _need(q_rows, torch.bfloat16, "q_rows")
+    _need(dq1, torch.float32, "dq1"), _need(dqkv, torch.bfloat16, "dqkv"), _need(dwin_acc, torch.float32, "dwin_acc")
+    B, H, T, ldp = ds.shape
+    W = dwin_acc.shape[0]
+    st = ds.untyped_storage()
+    lo = ds.storage_offset() * 2
+    if not (ds.is_contiguous() and win_t.is_contiguous() and q_rows.is_contiguous() and dq1.is_contiguous() and
+            dqkv.is_contiguous() and dwin_acc.is_contiguous()) or H != n_head or q_rows.shape != (B * T * H, 64) or \
+            dq1.shape != (B, H, T, 64) or dqkv.shape != (B, T, 3 * H * 64) or dwin_acc.shape[1] != 64 or win_t.shape[0] != 64:
+        raise RuntimeError("css_amd: attn_pos_bwd_ds expects dense dS [B,H,T,ldp], q rows [B*T*H,64], dq1 [B,H,T,64], dqkv [B,T,3*H*64]")
+    if lo < 16 or st.nbytes() - lo - ds.numel() * 2 < 16:
+        raise RuntimeError("css_amd: attn_pos_bwd_ds needs 16 bytes of slack on both sides of dS (ops_bwd.slack_bf16)")
+    nws = lib().csship_attn_pos_bwd_workspace(B, T)
+    ws = _workspace(nws, ds.device)
+    check(lib().csship_attn_pos_bwd_ds(_ptr(ds), ldp, _ptr(win_t), win_t.shape[1], _ptr(q_rows), _ptr(dq1), _ptr(dqkv),
+                                       _ptr(dwin_acc), W, B, T, H, _ptr(ws), nws, _stream()))
+    return dqkv, dwin_acc
 
 
 def attn_pos_bwd(dsk, win_t, q_rows, dq1, dqkv, dwin_acc, n_head):

@@ -893,6 +893,13 @@ int csship_attn_dvdk(const uint16_t* p_v, const uint16_t* ds, int64_t ld_p, cons
  * T <= 449 (CSSHIP_EUNSUPPORTED beyond: csship_bgemm with band serves longer chunks), W >= 2 T - 1.  Summation order
  * fixed (deterministic). */
 size_t csship_attn_pos_bwd_workspace(int32_t B, int32_t T);
+/* csship_attn_pos_bwd_ds: the same from the ROW-MAJOR dS (bf16 [B, H, T, ld_p], the operand of csship_attn_dvdk) - the
+ * kernel skews it while it stages its tiles, so csship_mha_relpos_bwd_core may be called with ds_skew_bf16 = NULL and no
+ * skewed copy is ever written.  The tile loads are 16-byte pieces at 2-byte alignment that reach up to 14 bytes in front
+ * of and behind a row: the caller keeps 16 readable bytes on both sides of the ds buffer. */
+int csship_attn_pos_bwd_ds(const uint16_t* ds, int64_t ld_p, const uint16_t* pe_window_t, int64_t ld_pt,
+                           const uint16_t* q_rows, const float* dq1, uint16_t* dqkv, float* dwin_acc, int32_t W, int32_t B,
+                           int32_t T, int32_t H, void* workspace, size_t workspace_bytes, csship_stream_t stream);
 int csship_attn_pos_bwd(const uint16_t* ds_skew, int64_t ld_w, const uint16_t* pe_window_t, int64_t ld_pt,
                         const uint16_t* q_rows, const float* dq1, uint16_t* dqkv, float* dwin_acc, int32_t W, int32_t B,
                         int32_t T, int32_t H, void* workspace, size_t workspace_bytes, csship_stream_t stream);

@@ -283,6 +283,16 @@ def test_attn_pos_bwd_equals_the_two_products(ob, B, T, H):
     assert float((got_dq - ref_dq).abs().max()) <= 2.0 ** -8 * float(ref_dq.abs().max()) + 1e-6
     assert froerr(acc, ref_dw) < 2e-6
     assert torch.count_nonzero(dqkv.view(B, T, 3, H, 64)[:, :, 1:]) == 0     # the k and v thirds are not touched
+    # the same from the row-major dS (the kernel skews it while staging; 16 bytes of slack around the buffer, here NaN)
+    ldp = (T + 7) // 8 * 8
+    flat = torch.full((B * H * T * ldp + 16,), float("nan"), dtype=torch.bfloat16, device=DEV)
+    dsr = flat[8:8 + B * H * T * ldp].view(B, H, T, ldp)
+    dsr.zero_()
+    dsr[..., :T] = ds.to(DEV)
+    dqkv2 = torch.zeros_like(dqkv)
+    acc2 = acc0.clone().to(DEV)
+    ob.attn_pos_bwd_ds(dsr, ob.pe_window_t(win.to(DEV), T), q.to(DEV), dq1.to(DEV), dqkv2, acc2, H)
+    assert torch.equal(dqkv2, dqkv) and torch.equal(acc2, acc)
     if T == 449:
         with pytest.raises(RuntimeError):   # 450 frames: the tile would need a 17th k-step
             ob.attn_pos_bwd(torch.zeros(1, 450, 1, 904, dtype=torch.bfloat16, device=DEV), torch.zeros(64, 1000, dtype=torch.bfloat16, device=DEV),
