@@ -16,9 +16,15 @@ fa, fb = ffn_w(), ffn_w()
 wq, bq = ops.pack_frag(torch.randn(768, D, device="cuda") / 16), torch.zeros(768, device="cuda")
 out = torch.empty_like(x)
 FOLD = "--fold" in sys.argv
+TRAIN = "--train" in sys.argv     # the training form: dropout 0.1 at all four sites, rows kept for the backward
 if FOLD:
     fa, fb = (None,) + fa[1:], (None,) + fb[1:]
 run = lambda: ops.encoder_chain(x, 1024, ffn_a=fa, final_ln=(g1, b0), ffn_b=fb, qkv=((None if FOLD else (g1, b0)), wq, bq, 768), out=out, flags=1 if FOLD else 0)
+if TRAIN:
+    from css_amd.dropout import DropState
+    dstate = DropState(torch.tensor([1234], dtype=torch.int32, device="cuda"), 0.1, 0)
+    drops = tuple(dstate.cfg(f"0.{t}") for t in ("ffn_out.hidden", "ffn_out.out", "ffn_in.hidden", "ffn_in.out"))
+    run = lambda: ops.encoder_chain_train(x, 1024, fb, ((g1, b0), wq, bq, 768), ffn_a=fa, final_ln=(g1, b0), drops=drops)
 buf = torch.zeros(256, 32, device="cuda", dtype=torch.int64)
 for _ in range(3): run()
 torch.cuda.synchronize()
