@@ -67,6 +67,10 @@ class BgemmParams(C.Structure):
 _dc = C.POINTER(DropoutCfg)
 
 
+class GradJob(C.Structure):  # csship_grad_job (40 bytes)
+    _fields_ = [("src", _p), ("dst", _p), ("n", _i64), ("ld_src", _i64), ("cols", _i32), ("pad_", _i32)]
+
+
 class PackJob(C.Structure):  # csship_pack_job (72 bytes)
     _fields_ = [("w", _p), ("row_major", _p), ("frag", _p), ("ld_w", _i64), ("ld_row_major", _i64),
                 ("R", _i32), ("K", _i32), ("dst_row0", _i32), ("Kp", _i32), ("scale", _f32), ("transposed", _i32),
@@ -136,6 +140,7 @@ SIGNATURES = {
     "csship_bgemm_wgrad": (_i32, [_p, _p, _p, _p, _p, C.POINTER(BgemmParams), _f32, _i32, _p, _sz, _p]),
     "csship_reduce_defer": (_i32, [_i32]),
     "csship_reduce_hold": (_i32, [_i32]),
+    "csship_grad_accumulate": (_i32, [_p, _i32, _p]),
     "csship_wgrad_hold": (_i32, [_i32]),
     "csship_wgrad_pending": (_i32, []),
     "csship_wgrad_group_workspace": (_sz, []),

@@ -57,12 +57,24 @@ def _deliver(model, G):
     direct = [p for p in params if p.requires_grad and p in G and p.grad is not None
               and p.grad.dtype == G[p].dtype and p.grad.is_contiguous()]
     if direct:
-        with torch.no_grad():
-            torch._foreach_add_([p.grad for p in direct], [G[p].contiguous() for p in direct])
+        _accumulate(direct, G)
         _mark_written(direct)
         for p in direct:
             del G[p]
     return tuple(G.get(p) if p.requires_grad else None for p in params)
+
+
+_NO_GRAD_ACC = bool(os.environ.get("CSS_AMD_NO_GRAD_ACC"))   # A/B timing: torch._foreach_add_ (+ contiguous copies) instead
+
+
+def _accumulate(ps, G):
+    """p.grad += G[p] for the parameters ps: one csship_grad_accumulate launch per 96 of them (transposed 2-d views
+    included), torch._foreach_add_ for whatever layout that does not take."""
+    with torch.no_grad():
+        pairs = [(p.grad, G[p]) for p in ps]
+        rest = pairs if _NO_GRAD_ACC else ob.grad_accumulate(pairs)
+        if rest:
+            torch._foreach_add_([d for d, _ in rest], [s.reshape(d.shape).contiguous() for d, s in rest])
 
 
 def _deliver_group(model, module, G):
@@ -75,8 +87,7 @@ def _deliver_group(model, module, G):
     ps = [p for p in module.parameters() if p.requires_grad and p in G and p.grad is not None
           and p.grad.dtype == G[p].dtype and p.grad.is_contiguous()]
     if ps:
-        with torch.no_grad():
-            torch._foreach_add_([p.grad for p in ps], [G[p].contiguous() for p in ps])
+        _accumulate(ps, G)
         _mark_written(ps)
         for p in ps:
             del G[p]
@@ -378,10 +389,13 @@ class ConformerTrain(torch.autograd.Function):
         def put(p, g):
             if g is p.grad:   # stored in place by its producer (_direct_grad)
                 return
-            g = g.reshape(p.shape)
+            # (a transposed 2-d view - the depthwise conv weight, kept [taps, channels] by the kernels - stays a view:
+            # csship_grad_accumulate transposes while it adds; reshape() would copy it)
+            if not (g.dim() == 2 and g.stride(0) == 1 and g.numel() == p.numel() and p not in G and p.grad is not None):
+                g = g.reshape(p.shape)
             if p in G:
                 red.flush()   # the sum reads both gradients
-                G[p] = G[p] + g
+                G[p] = G[p].reshape(p.shape) + g
             else:
                 G[p] = g
 

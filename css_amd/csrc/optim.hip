@@ -92,6 +92,53 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 }  // namespace
 
+// ---- many small gradient tensors added into their destinations by ONE launch (csship_grad_accumulate).  The explicit
+// backward hands ~30 small gradients per encoder block (LayerNorm / conv parameters, q | k | v slices) to the optimiser's
+// flat gradient buffer; as torch._foreach_add_ that is 7 multi-tensor launches of 15 us per step plus a contiguous()
+// copy for every transposed view.  The job table travels in the kernel arguments (by value: a captured step replays it).
+constexpr int GA_JOBS = 96;
+struct GradAccTable {
+  csship_grad_job job[GA_JOBS];
+};
+__global__ __launch_bounds__(256) void grad_accumulate_kernel(GradAccTable t) {
+  const csship_grad_job j = t.job[blockIdx.y];
+  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 >= j.n) return;
+  if (j.cols == 0) {  // contiguous source
+    if (j.n - i0 >= 4 && ((((uintptr_t)j.src | (uintptr_t)j.dst) & 15) == 0)) {
+      const float4 a = *reinterpret_cast<const float4*>(j.src + i0);
+      float4 d = *reinterpret_cast<float4*>(j.dst + i0);
+      d.x += a.x; d.y += a.y; d.z += a.z; d.w += a.w;
+      *reinterpret_cast<float4*>(j.dst + i0) = d;
+    } else {
+      for (int64_t i = i0; i < min(j.n, i0 + 4); ++i) j.dst[i] += j.src[i];
+    }
+  } else {            // dst [n / cols, cols] (dense) += src^T: element (r, c) comes from src[c * ld_src + r]
+    for (int64_t i = i0; i < min(j.n, i0 + 4); ++i) {
+      const int64_t r = i / j.cols, c = i - r * j.cols;
+      j.dst[i] += j.src[c * j.ld_src + r];
+    }
+  }
+}
+
+extern "C" int csship_grad_accumulate(const csship_grad_job* jobs_host, int32_t n_jobs, csship_stream_t stream) {
+  if (n_jobs < 0 || (n_jobs > 0 && !jobs_host)) return CSSHIP_ENULL;
+  for (int at = 0; at < n_jobs; at += GA_JOBS) {
+    GradAccTable t{};
+    const int m = std::min(GA_JOBS, n_jobs - at);
+    int64_t maxn = 0;
+    for (int k = 0; k < m; ++k) {
+      const csship_grad_job& j = jobs_host[at + k];
+      if (!j.src || !j.dst || j.n <= 0 || j.cols < 0 || (j.cols > 0 && (j.n % j.cols) != 0)) return CSSHIP_EBADSHAPE;
+      t.job[k] = j;
+      maxn = std::max(maxn, j.n);
+    }
+    hipLaunchKernelGGL(grad_accumulate_kernel, dim3((unsigned)((maxn + 1023) / 1024), (unsigned)m), dim3(256), 0, as_stream(stream), t);
+    CSSHIP_CHECK_LAUNCH();
+  }
+  return CSSHIP_OK;
+}
+
 extern "C" size_t csship_adam_clip_workspace(int64_t n) {
   return (size_t)((n + SQ_ELEMS - 1) / SQ_ELEMS) * sizeof(float);
 }

@@ -501,6 +501,30 @@ def qkv_in_bwd(dqkv, wqkvT_p, x, dy, ln_g, ln_b):
     return dx, gb[0], gb[1], y
 
 
+def grad_accumulate(pairs):
+    """dst += src for every (dst, src) pair in ONE launch per 96 pairs (csship_grad_accumulate).  dst: dense f32; src: f32
+    with dst's element count, dense in dst's order, or a 2-d [R, C] view with stride(0) == 1 (the transpose of a matrix
+    with dense rows: the depthwise conv weight gradient).  Returns the pairs it could not take (other layouts / dtypes)."""
+    jobs, rest, keep = [], [], []
+    for dst, src in pairs:
+        ok = (dst.dtype == torch.float32 and src.dtype == torch.float32 and dst.is_contiguous() and src.is_cuda and dst.is_cuda
+              and src.numel() == dst.numel() and src.numel() > 0)
+        if ok and src.is_contiguous():
+            jobs.append((src.data_ptr(), dst.data_ptr(), src.numel(), 0, 0))
+        elif ok and src.dim() == 2 and src.stride(0) == 1 and src.stride(1) >= src.shape[0]:
+            jobs.append((src.data_ptr(), dst.data_ptr(), src.numel(), src.stride(1), src.shape[1]))
+        else:
+            rest.append((dst, src))
+            continue
+        keep.append(src)
+    if jobs:
+        arr = (_lib.GradJob * len(jobs))()
+        for a, (sp, dp, n, ld, cols) in zip(arr, jobs):
+            a.src, a.dst, a.n, a.ld_src, a.cols = sp, dp, n, ld, cols
+        check(lib().csship_grad_accumulate(arr, len(jobs), _stream()))
+    return rest
+
+
 def attn_rowdot(d_out, out, B, T, H):
     """D[b,h,i] = sum_d dO[b,i,h,d] * O[b,i,h,d] for bf16 [B*T, H*64] operands -> f32 [B,H,T]."""
     _need(d_out, torch.bfloat16, "d_out"), _need(out, torch.bfloat16, "out")

@@ -912,6 +912,19 @@ int csship_attn_pos_bwd(const uint16_t* ds_skew, int64_t ld_w, const uint16_t* p
 int csship_p2p_reduce(const float* const* srcs_host, int32_t world, int64_t lo, int64_t hi, float scale, float* out,
                       csship_stream_t stream);
 
+/* ---- csship_grad_accumulate (css_amd/csrc/optim.hip): dst += src for a table of small f32 tensors in ONE launch (the
+ * gradients the explicit backward hands to FusedAdam's flat gradient buffer: torch.autograd's AccumulateGrad nodes in the
+ * reference).  cols == 0: src dense, n elements.  cols > 0: dst is a dense [n / cols, cols] matrix and receives the
+ * TRANSPOSE of src, element (r, c) from src[c * ld_src + r] (the depthwise conv weight, kept [taps, channels] by the
+ * kernels).  The table is read on the host and travels in the kernel arguments, so a captured launch replays it. */
+typedef struct csship_grad_job {
+  const float* src;
+  float* dst;
+  int64_t n, ld_src;
+  int32_t cols, pad_;
+} csship_grad_job;
+int csship_grad_accumulate(const csship_grad_job* jobs_host, int32_t n_jobs, csship_stream_t stream);
+
 /* ---- csship_adam_clip (css_amd/csrc/optim.hip): clip_grad_norm_(max_norm) followed by one Adam step
  * (iteration_types.py:17-64) on FLAT f32 buffers of n elements (parameters, gradients, first and second moments), in
  * three launches with no host round trip.  grad_norm (device f32) receives the total 2-norm before clipping; a

@@ -300,6 +300,32 @@ def test_attn_pos_bwd_equals_the_two_products(ob, B, T, H):
                             torch.zeros(1, 450, 192, dtype=torch.bfloat16, device=DEV), torch.zeros(904, 64, device=DEV), 1)
 
 
+def test_grad_accumulate_many_small_tensors(ob):
+    """csship_grad_accumulate: dst += src for a table of tensors in one launch per 96 (dense, odd sizes, unaligned views,
+    a transposed 2-d view), the rest handed back"""
+    g = torch.Generator().manual_seed(5)
+    sizes = [1, 2, 3, 7, 256, 257, 1024, 65536, 33 * 256] + [256] * 120
+    flat = torch.randn(sum((n + 3) // 4 * 4 for n in sizes) + 8, generator=g).to(DEV)
+    ref = flat.clone()
+    pairs, off = [], 0
+    for i, n in enumerate(sizes):
+        dst = flat[off:off + n]
+        src = torch.randn(n + 1, generator=g).to(DEV)[1:] if i % 5 == 0 else torch.randn(n, generator=g).to(DEV)   # (some 4-byte aligned only)
+        if n == 33 * 256:   # the depthwise weight: kept [33, 256], the parameter is [256, 1, 33]
+            m = torch.randn(33, 256, generator=g).to(DEV)
+            src = m.t()
+            ref[off:off + n] += m.t().contiguous().view(-1)
+            dst = dst.view(256, 1, 33)
+        else:
+            ref[off:off + n] += src
+        pairs.append((dst, src))
+        off += (n + 3) // 4 * 4
+    odd = (torch.zeros(4, 6, device=DEV), torch.randn(6, 4, 2, generator=g).to(DEV)[:, :, 0].t())   # stride(0) != 1: not taken
+    rest = ob.grad_accumulate(pairs + [odd])
+    assert len(rest) == 1 and rest[0][0] is odd[0]
+    assert torch.equal(flat, ref)
+
+
 def test_grouped_weight_gradients_large_units(ob):
     """products of 64 tiles each (whole-XCD units of the workgroup table) and one too large to be queued (128 tiles)"""
     K = 2048
