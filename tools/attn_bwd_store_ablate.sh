@@ -1,3 +1,8 @@
+#!/bin/bash
+# What each store stream of the attention backward's one-pass kernel costs (on the GPU box, via gpurun).  Needs the
+# diagnostic builds of tools/attn_ablate.sh: `tools/attn_ablate.sh build 64 128 256 448` (bit 6: no skewed-dS store,
+# bit 7: no P' store, bit 8: no row-major dS store; wrong results by construction - only the kernel's rocprofv3 average
+# under the graphed training step means anything).  Run with CSSHIP_NO_POS_FROM_DS=1 to have the skewed store in the path.
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 for m in base 64 128 256 448; do
   rm -rf gpurun_out/prof_t
