@@ -283,8 +283,11 @@ def test_conformer_training_trajectory_vs_oracle(batch_bn):
     # gradient norms: while the model is far from a stationary point (the first steps, where the clip of 1.0 acts) the two
     # agree to a few per cent; near the plateau the true gradient is a small difference of large per-frame terms and the
     # bf16 operand noise does not cancel with it - not asserted there, the loss curve and the end point are
-    steep = [e for e, r in zip(nrel, ref_norms) if r > 1.0]
-    mid = [e for e, r in zip(nrel, ref_norms) if r > 0.3]
+    # (the descent only - steps 0 - 14: on the plateau the ORACLE's own norm spikes to 0.3 - 0.36 at a step that differs
+    # from run to run of the same CPU code - 16 threads, non-associative reductions - while the HIP column is bit-identical
+    # between runs; a spike on one side only is not an error of the other)
+    steep = [e for e, r in zip(nrel[:15], ref_norms[:15]) if r > 1.0]
+    mid = [e for e, r in zip(nrel[:15], ref_norms[:15]) if r > 0.3]
     assert len(steep) >= 3 and max(steep) < 5e-2 and max(mid) < 0.1
     assert apart / moved < 0.05                          # measured 0.005 / 0.017
 
