@@ -713,7 +713,8 @@ int csship_attn_softmax_bwd_drop(const uint16_t* qkv, const uint16_t* d_out, con
  * pass over the scores (the probabilities never make a round trip through memory on their way to dS):
  *   p_v_bf16  [B,H,T,ld_p] = the operand of dV = p_v^T dO (the probabilities; with dropout mask / (1 - p) o P),
  *   ds_bf16   [B,H,T,ld_p] = dS = P o (mask / (1 - p) o (dO v^T) - d),  ds_skew_bf16 [B,T,H,W] its skewed copy
- *   (csship_relpos_softmax_bwd; zero outside the band: the caller zeroes the buffer once),
+ *   (csship_relpos_softmax_bwd; zero outside the band: the caller zeroes the buffer once) - or NULL: no skewed copy
+ *   is written (csship_attn_pos_bwd_ds skews the row-major dS itself; W is ignored),
  *   dq1       f32 [B,H,T,64] = dS k (the key part of the query gradient).
  * d_out bf16 [B*T, H*64]; d f32 [B,H,T] = rowsum(dO o O) (csship_attn_rowdot) - or NULL with out = the forward's
  * output bf16 [B*T, H*64], from which the pass computes it itself; q_rows (optional) bf16 [B*T*H, 64] receives the q
