@@ -408,14 +408,15 @@ def test_conformer_gradients_flow_and_match_oracle_autograd():
     print(f"[parity] ... vs the bf16-operand oracle: global {g16:.3e}, worst live parameter {w16[0]} {w16[1]:.3e}")
 
 
-@pytest.mark.parametrize("B,T", [(3, 60), (2, 96), (4, 64)])
+@pytest.mark.parametrize("B,T", [(3, 60), (2, 96), (4, 64), (1, 460)])
 def test_conformer_hip_backward_matches_oracle_autograd(B, T):
     """Training path with the explicit HIP backward (css_amd/autograd.py ConformerTrain, 2 blocks, batch-statistics
     BatchNorm): every parameter gradient vs torch.autograd through the oracle (fp32, training_bn=True) at the same
     permutation.  bf16 GEMM operands in forward and backward: global relative error bound 3e-2.
     (3, 60): 180 rows, a ragged last panel - the bounds-checked kernels; (2, 96): 192 rows = whole 64-row panels - the
     static forms the full-size step runs (chain_s_kernel<TRAIN>, ffn_bwd_kernel<FULL, LN2>, qkv_in_bwd_kernel,
-    panel_dx_kernel, the grouped weight gradients)."""
+    panel_dx_kernel, the grouped weight gradients); (1, 460): a chunk longer than the fused position pass takes (449
+    frames) - the skewed dS in memory and the two tiled position products."""
     from css_amd.objectives import OBJECTIVES
     import grad_ref
     m, sd = build(2, 43)
