@@ -153,6 +153,7 @@ SIGNATURES = {
     "csship_layernorm_bwd": (_i32, [_p, _p, _p, _p, _p, _i32, _i64, _i32, _p, _p, _p, _sz, _p]),
     "csship_layernorm_bwd_y": (_i32, [_p, _p, _p, _p, _p, _i32, _i64, _i32, _p, _p, _p, _p, _sz, _p]),
     "csship_relu_bwd": (_i32, [_p, _i64, _p, _i64, _i64, _i32, _p, _i64, _p]),
+    "csship_relu_bwd_bf16": (_i32, [_p, _i64, _p, _i64, _i64, _i32, _p, _i64, _p]),
     "csship_mvn_apply": (_i32, [_p, _i64, _i64, _i64, _i64, _f32, _p, _p, _p, _i64, _p]),
     "csship_relpos_softmax": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p]),
     "csship_attn_rowdot": (_i32, [_p, _p, _i32, _i32, _i32, _p, _p]),

@@ -148,7 +148,9 @@ def _conformer_pack_plan(model, wide, device):
     plan = ob.PackPlan(device)
     ent = {"wide": wide, "device": device, "plan": plan, "layers": []}
     ent["we_bf"] = plan.add(enc.embed[0].weight.detach(), want_row_major=True)[0]
-    ent["wh_bf"], ent["wh_p"] = plan.add(model.linear.weight.detach(), want_row_major=True, want_frag=not wide)
+    wh = model.linear.weight.detach()   # row-major shadow with zero rows up to a multiple of 8 (bw.head_bwd)
+    wh_rm = torch.zeros(((wh.shape[0] + 7) // 8 * 8, (wh.shape[1] + 7) // 8 * 8), dtype=torch.bfloat16, device=device)
+    ent["wh_bf"], ent["wh_p"] = plan.add(wh, row_major=wh_rm, want_frag=not wide)
     for lay in enc.encoders:
         h = {}
         for tag, m in (("ffn_in", lay.feed_forward_in), ("ffn_out", lay.feed_forward_out)):
@@ -368,7 +370,7 @@ class ConformerTrain(torch.autograd.Function):
         ld = (n_out + 3) // 4 * 4
         masks = torch.empty((M, ld), dtype=torch.float32, device=f.device)[:, :n_out]
         if wide:
-            ob.bgemm(x, wh_bf, bias=model.linear.bias.detach(), out=masks)
+            ob.bgemm(x, wh_bf[:n_out], bias=model.linear.bias.detach(), out=masks)
             torch.relu_(masks)
         else:
             ops.panel_linear(x, wh_p, model.linear.bias.detach(), n_out, relu=True, out=masks)
@@ -415,8 +417,10 @@ class ConformerTrain(torch.autograd.Function):
             buf = torch.empty_strided(masks.shape, masks.stride(), dtype=torch.float32, device=masks.device)
             buf.copy_(dm)
             dm = buf
-        dx, dw, db = bw.head_bwd(dm, masks, S["x_enc"], S["wh_bf"], dw_out=_direct_grad(model.linear.weight),
-                                 db_out=_direct_grad(model.linear.bias))
+        padded = S["wh_bf"].shape[0] != masks.shape[1] and not bw._NO_HEAD_PAD   # the products come back wider than the parameters
+        dx, dw, db = bw.head_bwd(dm, masks, S["x_enc"], S["wh_bf"],
+                                 dw_out=None if padded else _direct_grad(model.linear.weight),
+                                 db_out=None if padded else _direct_grad(model.linear.bias))
         put(model.linear.weight, dw), put(model.linear.bias, db)
         red.flush()
         _deliver_group(model, model.linear, G)

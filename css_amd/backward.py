@@ -24,8 +24,15 @@ def linear_bwd(dy, x, w_bf, *, need_dx=True, dx_bf16=False, alpha=1.0, dw_out=No
 
 def head_bwd(dmasks, masks, x, w_bf, dw_out=None, db_out=None):
     """masks = relu(x @ w^T + b) (conformer.py:98-99).  dmasks/masks: f32 [M, n_out] (row stride free)."""
+    n_out = dmasks.shape[1]
+    if w_bf.shape[0] > n_out and w_bf.shape[0] % 8 == 0 and not _NO_HEAD_PAD:
+        # w_bf carries zero rows up to a multiple of 8: dz goes to bf16 rows of that width and both products take the
+        # whole-group kernels (dw_out / db_out cannot: the product is [rows of w_bf, K])
+        dz = ob.relu_bwd_bf16(dmasks, masks, w_bf.shape[0])
+        dx, dw, db = linear_bwd(dz, x, w_bf)
+        return dx, dw[:n_out], db[:n_out]
     dz = ob.relu_bwd(dmasks, masks)
-    return linear_bwd(dz, x, w_bf, dw_out=dw_out, db_out=db_out)
+    return linear_bwd(dz, x, w_bf[:n_out], dw_out=dw_out, db_out=db_out)
 
 
 def ffn_bwd(x, dy, ln_g, ln_b, b1, w1_bf, w2_bf, alpha=0.5, drop_hidden=None, drop_out=None):
@@ -71,6 +78,7 @@ def ffn_bwd_fused(x, dy, ln_g, ln_b, b1, w1p, w2tp, w1tp, d_ffn, alpha=0.5, drop
     return dx, (dg, dbeta, dw1, db1, dw2, db2) + tuple(res[7:])
 
 
+_NO_HEAD_PAD = bool(os.environ.get("CSSHIP_NO_HEAD_PAD"))   # A/B timing: the mask head's backward on f32 dz of width n_out
 _NO_BAND = bool(os.environ.get("CSSHIP_NO_BAND"))   # A/B timing: the skewed-dS product over the whole window axis
 _NO_LN_Y = bool(os.environ.get("CSSHIP_NO_LN_Y"))   # A/B timing: LayerNorm(x) for the q/k/v weight gradient by its own launch
 _SPLIT_ATTN_BWD = bool(os.environ.get("CSSHIP_ATTN_BWD_SPLIT"))   # A/B timing: probabilities / softmax backward / dS k as separate launches

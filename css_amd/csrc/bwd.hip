@@ -163,6 +163,24 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__
   if (c < N) out[row * ldo + c] = y[row * ldy + c] > 0.f ? dy[row * ldd + c] : 0.f;
 }
 
+// ---- the same into bf16 rows zero padded to ldo (even) columns; one wave per row, a column pair per lane and pass
+__global__ __launch_bounds__(256) void relu_bwd_bf16_kernel(const float* __restrict__ dy, int64_t ldd,
+                                                            const float* __restrict__ y, int64_t ldy, int64_t M, int N,
+                                                            unsigned short* __restrict__ out, int ldo) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* dr = dy + row * ldd;
+  const float* yr = y + row * ldy;
+  unsigned* orow = reinterpret_cast<unsigned*>(out + row * (int64_t)ldo);
+  for (int c = 2 * lane; c < ldo; c += 128) {
+    float v0 = 0.f, v1 = 0.f;
+    if (c < N) v0 = yr[c] > 0.f ? dr[c] : 0.f;
+    if (c + 1 < N) v1 = yr[c + 1] > 0.f ? dr[c + 1] : 0.f;
+    orow[c >> 1] = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
+  }
+}
+
 // ---- out_bf16[b*T + t, f] = (max(x, clamp) - mean[b, f]) * rinv[b, f], zero padded to ldo columns
 __global__ __launch_bounds__(256) void mvn_apply_kernel(const float* __restrict__ x, int T, int F, int64_t ldx,
                                                         float clamp_min, const float* __restrict__ mean,
@@ -381,6 +399,18 @@ extern "C" int csship_relu_bwd(const float* dy, int64_t ld_dy, const float* y, i
   if (M <= 0 || N <= 0 || ld_dy < N || ld_y < N || ld_out < N || M * cblocks > 0x7fffffff) return CSSHIP_EBADSHAPE;
   hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)(M * cblocks)), dim3(256), 0, as_stream(stream), dy, ld_dy, y, ld_y,
                      N, cblocks, out, ld_out);
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
+extern "C" int csship_relu_bwd_bf16(const float* dy, int64_t ld_dy, const float* y, int64_t ld_y, int64_t M, int32_t N,
+                                    uint16_t* out_bf16, int64_t ld_out, csship_stream_t stream) {
+  if (!dy || !y || !out_bf16) return CSSHIP_ENULL;
+  if (M <= 0 || N <= 0 || ld_dy < N || ld_y < N || ld_out < N || (ld_out & 1) || ld_out > 0x7fffffff ||
+      (M + 3) / 4 > 0x7fffffff || (reinterpret_cast<uintptr_t>(out_bf16) & 3))
+    return CSSHIP_EBADSHAPE;
+  hipLaunchKernelGGL(relu_bwd_bf16_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, as_stream(stream), dy, ld_dy, y,
+                     ld_y, M, N, out_bf16, (int)ld_out);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }

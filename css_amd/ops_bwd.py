@@ -269,6 +269,17 @@ def relu_bwd(dy, y, out=None):
     return out
 
 
+def relu_bwd_bf16(dy, y, ld_out):
+    """relu_bwd into bf16 [M, ld_out], the columns past dy's width zero (ld_out even)."""
+    _need(dy, torch.float32, "dy"), _need(y, torch.float32, "y")
+    if dy.dim() != 2 or dy.shape != y.shape or dy.stride(1) != 1 or y.stride(1) != 1 or ld_out < dy.shape[1] or ld_out & 1:
+        raise RuntimeError("css_amd: relu_bwd_bf16 expects matching 2-D tensors and an even ld_out >= their width")
+    out = torch.empty((dy.shape[0], ld_out), dtype=torch.bfloat16, device=dy.device)
+    check(lib().csship_relu_bwd_bf16(_ptr(dy), dy.stride(0), _ptr(y), y.stride(0), dy.shape[0], dy.shape[1], _ptr(out),
+                                     ld_out, _stream()))
+    return out
+
+
 def mvn_apply(f, mean, rinv, ld_out=None):
     """bf16 [B*T, ld_out] = MVN(f) (zero padded columns) for f f32 [B, T, F]."""
     _need(f, torch.float32, "f")

@@ -753,6 +753,11 @@ int csship_layernorm_bwd_y(const float* x, const float* dy, const float* gamma, 
 /* out = dy where y > 0, else 0 (mask head ReLU, conformer.py:99); 2-D with row strides; out may alias dy. */
 int csship_relu_bwd(const float* dy, int64_t ld_dy, const float* y, int64_t ld_y, int64_t M, int32_t N,
                     float* out, int64_t ld_out, csship_stream_t stream);
+/* The same into bf16 rows zero padded to ld_out (even, >= N) columns: with ld_out a multiple of 8 the two products of
+ * the mask head's backward (dW = dz^T x over the B*T rows, dx = dz W) take whole 8-element groups although
+ * n_out = 3 * 257 does not. */
+int csship_relu_bwd_bf16(const float* dy, int64_t ld_dy, const float* y, int64_t ld_y, int64_t M, int32_t N,
+                         uint16_t* out_bf16, int64_t ld_out, csship_stream_t stream);
 /* out_bf16[b*T + t, :] = MVN(x) as csship_mvn_stats defines it, zero padded to ld_out columns: the activation operand
  * of the embed weight gradient. */
 int csship_mvn_apply(const float* x, int64_t B, int64_t T, int64_t F, int64_t ldx, float clamp_min,

@@ -429,6 +429,15 @@ def test_ffn_and_head_backward(ob):
     dmg.copy_(dm)
     dx, dw, db = bw.head_bwd(dmg, mg, xe.to(DEV), w.to(DEV).to(torch.bfloat16))
     assert froerr(dx, xr.grad) < tol and froerr(dw, wr.grad) < tol and froerr(db, br.grad) < tol
+    # the training path's route: weight shadow with zero rows to a multiple of 8, dz in bf16 rows of that width
+    wp = torch.zeros((776, D), dtype=torch.bfloat16, device=DEV)
+    wp[:N] = w.to(DEV).to(torch.bfloat16)
+    dz = ob.relu_bwd_bf16(dmg, mg, 776)
+    zr = torch.where(masks.detach() > 0, dm.double(), torch.zeros((), dtype=torch.float64)).float().to(torch.bfloat16)
+    assert torch.equal(dz[:, :N].cpu(), zr) and not dz[:, N:].any()
+    dx2, dw2, db2 = bw.head_bwd(dmg, mg, xe.to(DEV), wp)
+    assert dw2.shape == (N, D) and db2.shape == (N,)
+    assert froerr(dx2, xr.grad) < tol and froerr(dw2, wr.grad) < tol and froerr(db2, br.grad) < tol
 
 
 def _attn_ref(x, P, T, H, maxlen=1000):
