@@ -131,6 +131,7 @@ SIGNATURES = {
     "csship_pit_workspace": (_sz, [_i32, _i32, _i32, _i32]),
     "csship_pit_mse": (_i32, [_p, _i64, _p, _i64, C.POINTER(_p), _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p]),
     "csship_pit_mse_bwd": (_i32, [_p, _i64, _p, _i64, C.POINTER(_p), _p, _i32, _i32, _i32, _i32, _i32, _f32, _p, _p]),
+    "csship_pit_mse_bwd_dev": (_i32, [_p, _i64, _p, _i64, C.POINTER(_p), _p, _i32, _i32, _i32, _i32, _i32, _f32, _p, _p, _p]),
     "csship_apply_masks": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p, _p]),
     "csship_stitch_similarity": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "csship_stitch_connect": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _f32, _p, _p]),

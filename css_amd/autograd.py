@@ -130,10 +130,14 @@ class PitMse(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_loss, _grad_perm):
         masks, f_orig, perm, *targets = ctx.saved_tensors
-        g = ops.pit_mse_bwd(masks, f_orig, targets, perm, ctx.n_masks, 1.0)
-        # in place: the product keeps the padded row stride of the masks, so the encoder's backward takes it as it is
-        # (`g * grad_loss` came back dense, 771 floats per row, and was copied into an aligned buffer: 2 x 39 MB)
-        return (g.mul_(grad_loss),) + (None,) * (2 + len(targets))
+        # the upstream gradient is a device scalar the kernel reads itself (a `g.mul_(grad_loss)` behind it was a second
+        # pass over 39 MB); the product keeps the padded row stride of the masks, so the encoder's backward takes it
+        # as it is
+        if grad_loss.dtype == torch.float32 and grad_loss.numel() == 1 and grad_loss.is_cuda:
+            g = ops.pit_mse_bwd(masks, f_orig, targets, perm, ctx.n_masks, 1.0, grad_loss_dev=grad_loss)
+        else:
+            g = ops.pit_mse_bwd(masks, f_orig, targets, perm, ctx.n_masks, 1.0).mul_(grad_loss)
+        return (g,) + (None,) * (2 + len(targets))
 
 
 def _conformer_pack_plan(model, wide, device):
@@ -237,17 +241,20 @@ class ConformerTrain(torch.autograd.Function):
             ops.dropout_apply(x, ds.cfg("embed"))
         S["we_bf"] = we_bf
         pe = model.position_table()
-        pe_pack = ops.pack_relpos(pe, 1000)
-        S["pe_bf"] = pe.to(BF)
-        S["pe_pack"] = pe_pack
+        # packed table of the forward, bf16 table, window (+ its transpose for csship_attn_pos_bwd up to 449 frames) of
+        # the backward: three launches
+        rt = ob.relpos_tables(pe, T, 1000, want_t=T <= 449)
+        pe_pack = rt["pack"]
+        S["pe_bf"], S["pe_pack"], S["window"] = rt["pe_bf"], pe_pack, rt["window"]
         bn_means, bn_vars, bn_new_m, bn_new_v = [], [], [], []
         # small per-block operands for ALL blocks in a handful of launches (was 3 tiny launches per block): the fused
         # q | k | v bias with the q part pre-scaled, and the depthwise taps as [k][D] (lanes read consecutive channels)
         lays = list(enc.encoders)
         qs = lays[0].self_attn.d_k ** -0.5
-        bqkv_all = torch.cat([torch.stack([l_.self_attn.linear_q.bias.detach() for l_ in lays]) * qs,
-                              torch.stack([l_.self_attn.linear_k.bias.detach() for l_ in lays]),
-                              torch.stack([l_.self_attn.linear_v.bias.detach() for l_ in lays])], 1)
+        bqkv_all = torch.stack([getattr(l_.self_attn, n_).bias.detach() for l_ in lays
+                                for n_ in ("linear_q", "linear_k", "linear_v")]).view(len(lays), 3 * D)
+        bqkv_all.mul_(ob.cached_const(("qscale", f.device.index, D, qs), lambda: torch.cat(
+            [torch.full((D,), qs, dtype=torch.float32, device=f.device), torch.ones(2 * D, dtype=torch.float32, device=f.device)])))
         dww_all = torch.stack([l_.conv.dw_conv_1d.weight.detach().view(D, K) for l_ in lays]).transpose(1, 2).contiguous()
         chained = not wide and not _NO_TRAIN_CHAIN
         carried = None
@@ -424,9 +431,7 @@ class ConformerTrain(torch.autograd.Function):
         put(model.linear.weight, dw), put(model.linear.bias, db)
         red.flush()
         _deliver_group(model, model.linear, G)
-        window = bw.relpos_window(S["pe_bf"], T, 1000)
-        if T <= 449:   # the transposed window of csship_attn_pos_bwd, once per backward pass
-            window = window + (ob.pe_window_t(window[0], T),)
+        window = S["window"]   # (window, its rows in the table[, window^T]): ob.relpos_tables in the forward
         dwin = None
         # skewed dS buffer shared by all layers: the band positions are the same every layer, the rest stays zero
         # (not needed - and its 82 MB not allocated - when the position pass skews the row-major dS itself)

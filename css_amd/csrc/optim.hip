@@ -113,6 +113,12 @@ __global__ __launch_bounds__(256) void grad_accumulate_kernel(GradAccTable t) {
     } else {
       for (int64_t i = i0; i < min(j.n, i0 + 4); ++i) j.dst[i] += j.src[i];
     }
+  } else if (j.cols < 0) {  // dst [n / C, C] (dense), C = -cols, += rows of src ld_src apart
+    const int64_t C = -(int64_t)j.cols;
+    for (int64_t i = i0; i < min(j.n, i0 + 4); ++i) {
+      const int64_t r = i / C;
+      j.dst[i] += j.src[r * j.ld_src + (i - r * C)];
+    }
   } else {            // dst [n / cols, cols] (dense) += src^T: element (r, c) comes from src[c * ld_src + r]
     for (int64_t i = i0; i < min(j.n, i0 + 4); ++i) {
       const int64_t r = i / j.cols, c = i - r * j.cols;
@@ -129,7 +135,9 @@ extern "C" int csship_grad_accumulate(const csship_grad_job* jobs_host, int32_t 
     int64_t maxn = 0;
     for (int k = 0; k < m; ++k) {
       const csship_grad_job& j = jobs_host[at + k];
-      if (!j.src || !j.dst || j.n <= 0 || j.cols < 0 || (j.cols > 0 && (j.n % j.cols) != 0)) return CSSHIP_EBADSHAPE;
+      if (!j.src || !j.dst || j.n <= 0 || j.cols == INT32_MIN || (j.cols != 0 && (j.n % j.cols) != 0) ||
+          (j.cols < 0 && j.ld_src < -(int64_t)j.cols))
+        return CSSHIP_EBADSHAPE;
       t.job[k] = j;
       maxn = std::max(maxn, j.n);
     }

@@ -263,8 +263,9 @@ template <int K>
 __global__ __launch_bounds__(256) void pit_bwd_kernel(const float* __restrict__ masks, int64_t ld_mask,
                                                       const float* __restrict__ f, int64_t ld_f, PitArgs a,
                                                       const int* __restrict__ perm, int n_masks, float coef,
-                                                      float* __restrict__ grad) {
+                                                      const float* __restrict__ gl_dev, float* __restrict__ grad) {
   const int b = blockIdx.y;
+  const float gl = gl_dev ? *gl_dev : 1.f;   // the upstream gradient of the loss, read on the device (x * 1.f is exact)
   const int TF = a.T * a.F;
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= TF) return;
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(256) void pit_bwd_kernel(const float* __restrict__ 
   for (int i = 0; i < K; ++i) {
     const int k = perm[(size_t)b * K + i];
     const float y = masks[row * ld_mask + k * a.F + ff] * fo;
-    grad[row * ld_mask + k * a.F + ff] = coef * (y - a.tgt[i][(size_t)b * TF + e]) * fo;
+    grad[row * ld_mask + k * a.F + ff] = coef * (y - a.tgt[i][(size_t)b * TF + e]) * fo * gl;
   }
   for (int k = K; k < n_masks; ++k) grad[row * ld_mask + k * a.F + ff] = 0.f;
 }
@@ -344,10 +345,23 @@ extern "C" int csship_pit_mse(const float* masks, int64_t ld_mask, const float* 
   return CSSHIP_OK;
 }
 
+extern "C" int csship_pit_mse_bwd_dev(const float* masks, int64_t ld_mask, const float* f_orig, int64_t ld_f,
+                                      const float* const* targets_host, const int32_t* perm, int32_t B, int32_t T,
+                                      int32_t F, int32_t K, int32_t n_masks, float grad_loss,
+                                      const float* grad_loss_dev, float* grad_masks, csship_stream_t stream);
+
 extern "C" int csship_pit_mse_bwd(const float* masks, int64_t ld_mask, const float* f_orig, int64_t ld_f,
                                   const float* const* targets_host, const int32_t* perm, int32_t B, int32_t T,
                                   int32_t F, int32_t K, int32_t n_masks, float grad_loss, float* grad_masks,
                                   csship_stream_t stream) {
+  return csship_pit_mse_bwd_dev(masks, ld_mask, f_orig, ld_f, targets_host, perm, B, T, F, K, n_masks, grad_loss, nullptr,
+                                grad_masks, stream);
+}
+
+extern "C" int csship_pit_mse_bwd_dev(const float* masks, int64_t ld_mask, const float* f_orig, int64_t ld_f,
+                                      const float* const* targets_host, const int32_t* perm, int32_t B, int32_t T,
+                                      int32_t F, int32_t K, int32_t n_masks, float grad_loss,
+                                      const float* grad_loss_dev, float* grad_masks, csship_stream_t stream) {
   if (!masks || !f_orig || !targets_host || !perm || !grad_masks) return CSSHIP_ENULL;
   if (B <= 0 || T <= 0 || F <= 0 || B > 65535 || (int64_t)T * F > 0x7fffffff || n_masks < K) return CSSHIP_EBADSHAPE;
   if (K < 1 || K > MAXK) return CSSHIP_EUNSUPPORTED;
@@ -362,10 +376,10 @@ extern "C" int csship_pit_mse_bwd(const float* masks, int64_t ld_mask, const flo
   dim3 grid((unsigned)(((size_t)T * F + 255) / 256), B);
   hipStream_t s = as_stream(stream);
   switch (K) {
-    case 1: hipLaunchKernelGGL(pit_bwd_kernel<1>, grid, dim3(256), 0, s, masks, ld_mask, f_orig, ld_f, a, perm, n_masks, coef, grad_masks); break;
-    case 2: hipLaunchKernelGGL(pit_bwd_kernel<2>, grid, dim3(256), 0, s, masks, ld_mask, f_orig, ld_f, a, perm, n_masks, coef, grad_masks); break;
-    case 3: hipLaunchKernelGGL(pit_bwd_kernel<3>, grid, dim3(256), 0, s, masks, ld_mask, f_orig, ld_f, a, perm, n_masks, coef, grad_masks); break;
-    case 4: hipLaunchKernelGGL(pit_bwd_kernel<4>, grid, dim3(256), 0, s, masks, ld_mask, f_orig, ld_f, a, perm, n_masks, coef, grad_masks); break;
+    case 1: hipLaunchKernelGGL(pit_bwd_kernel<1>, grid, dim3(256), 0, s, masks, ld_mask, f_orig, ld_f, a, perm, n_masks, coef, grad_loss_dev, grad_masks); break;
+    case 2: hipLaunchKernelGGL(pit_bwd_kernel<2>, grid, dim3(256), 0, s, masks, ld_mask, f_orig, ld_f, a, perm, n_masks, coef, grad_loss_dev, grad_masks); break;
+    case 3: hipLaunchKernelGGL(pit_bwd_kernel<3>, grid, dim3(256), 0, s, masks, ld_mask, f_orig, ld_f, a, perm, n_masks, coef, grad_loss_dev, grad_masks); break;
+    case 4: hipLaunchKernelGGL(pit_bwd_kernel<4>, grid, dim3(256), 0, s, masks, ld_mask, f_orig, ld_f, a, perm, n_masks, coef, grad_loss_dev, grad_masks); break;
     default: return CSSHIP_EUNSUPPORTED;
   }
   CSSHIP_CHECK_LAUNCH();

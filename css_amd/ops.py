@@ -467,14 +467,20 @@ def head_pit(x_enc, w_packed, bias_perm, f_orig, targets, want_pairs=False):
     return loss, perm, pairs
 
 
-def pit_mse_bwd(masks, f_orig, targets, perm, n_masks, grad_loss=1.0):
+def pit_mse_bwd(masks, f_orig, targets, perm, n_masks, grad_loss=1.0, grad_loss_dev=None):
+    """grad_loss_dev: optional 0-dim f32 device tensor, a second factor read by the kernel (an autograd backward's
+    upstream gradient) - the result equals ``pit_mse_bwd(..., grad_loss) * grad_loss_dev`` bit for bit."""
     K = len(targets)
     B, T, F = targets[0].shape
     arr, keep = _targets_array(targets, B, T, F)
+    if grad_loss_dev is not None:
+        _need(grad_loss_dev, torch.float32, "grad_loss_dev")
+        if grad_loss_dev.numel() != 1:
+            raise RuntimeError("css_amd: grad_loss_dev must hold one value")
     # same (possibly padded) row stride as the masks: the kernel addresses both with ld_mask
     grad = torch.empty_strided(masks.shape, masks.stride(), device=masks.device, dtype=masks.dtype)
-    check(lib().csship_pit_mse_bwd(_ptr(masks), masks.stride(1), _ptr(f_orig), f_orig.stride(1), arr, _ptr(perm),
-                                   B, T, F, K, n_masks, float(grad_loss), _ptr(grad), _stream()))
+    check(lib().csship_pit_mse_bwd_dev(_ptr(masks), masks.stride(1), _ptr(f_orig), f_orig.stride(1), arr, _ptr(perm),
+                                       B, T, F, K, n_masks, float(grad_loss), _ptr(grad_loss_dev), _ptr(grad), _stream()))
     return grad
 
 

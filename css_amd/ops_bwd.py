@@ -515,7 +515,7 @@ def qkv_in_bwd(dqkv, wqkvT_p, x, dy, ln_g, ln_b):
 def grad_accumulate(pairs):
     """dst += src for every (dst, src) pair in ONE launch per 96 pairs (csship_grad_accumulate).  dst: dense f32; src: f32
     with dst's element count, dense in dst's order, or a 2-d [R, C] view with stride(0) == 1 (the transpose of a matrix
-    with dense rows: the depthwise conv weight gradient).  Returns the pairs it could not take (other layouts / dtypes)."""
+    with dense rows: the depthwise conv weight gradient) or with rows further apart than C.  Returns the pairs it could not take (other layouts / dtypes)."""
     jobs, rest, keep = [], [], []
     for dst, src in pairs:
         ok = (dst.dtype == torch.float32 and src.dtype == torch.float32 and dst.is_contiguous() and src.is_cuda and dst.is_cuda
@@ -524,6 +524,8 @@ def grad_accumulate(pairs):
             jobs.append((src.data_ptr(), dst.data_ptr(), src.numel(), 0, 0))
         elif ok and src.dim() == 2 and src.stride(0) == 1 and src.stride(1) >= src.shape[0]:
             jobs.append((src.data_ptr(), dst.data_ptr(), src.numel(), src.stride(1), src.shape[1]))
+        elif ok and src.dim() == 2 and src.stride(1) == 1 and src.stride(0) >= src.shape[1]:   # padded row stride
+            jobs.append((src.data_ptr(), dst.data_ptr(), src.numel(), src.stride(0), -src.shape[1]))
         else:
             rest.append((dst, src))
             continue
@@ -588,6 +590,60 @@ def attn_dvdk(p_v, ds, d_out, qkv, dqkv, n_head):
         raise RuntimeError("css_amd: attn_dvdk expects dense [B,H,T,ldp] operands and [B,T,3*H*64] projections")
     check(lib().csship_attn_dvdk(_ptr(p_v), _ptr(ds), p_v.shape[3], _ptr(d_out), _ptr(qkv), _ptr(dqkv), B, T, n_head, _stream()))
     return dqkv
+
+
+_CONST = {}
+
+
+def cached_const(key, build):
+    """Step-invariant index / scale tensors: built once per key, OUTSIDE graph capture only (a tensor allocated while a
+    step is being captured lives in the graph's pool and must not outlive the capture; such a step rebuilds it)."""
+    t = _CONST.get(key)
+    if t is None:
+        t = build()
+        if not torch.cuda.is_current_stream_capturing():
+            _CONST[key] = t
+    return t
+
+
+def relpos_tables(pe, T, maxlen=1000, want_t=True):
+    """Every bf16 form of the relative-position table pe f32 [2*maxlen, 64] that one training step of length T reads,
+    by THREE launches (table + zero row -> bf16 -> one gather through a cached index) instead of the ~27 small torch
+    launches of ops.pack_relpos + backward.relpos_window + pe_window_t, whose results these are bit for bit:
+    {"pe_bf": bf16 table, "pack": (packed, q_min, q_max) of ops.pack_relpos, "window": (window, idx[, window^T]) of
+    backward.relpos_window / pe_window_t}."""
+    _need(pe, torch.float32, "pe")
+    dk = pe.shape[1]
+    if tuple(pe.shape) != (2 * maxlen, 64):
+        raise RuntimeError("css_amd: relpos_tables expects the [2 * maxlen, 64] table")
+    dev = pe.device
+    q_min, q_max = -((maxlen + 15) // 16) - 2, (maxlen + 15) // 16 + 1   # ops.pack_relpos
+    W = (2 * T - 1 + 7) // 8 * 8
+    nblk, nks = (T + 63) // 64, (T + 63 + 31) // 32
+    ld = (max(W, (nblk - 1) * 64 + nks * 32) + 7) // 8 * 8               # pe_window_t
+
+    def build():
+        zero_row = 2 * maxlen
+        E = torch.arange((2 * maxlen + 1) * dk, device=dev).view(2 * maxlen + 1, dk)
+        q, m = torch.arange(q_min, q_max + 1, device=dev), torch.arange(16, device=dev)
+        rel = (16 * q[:, None] + 15 - m[None, :]).clamp(-maxlen, maxlen - 1) + maxlen
+        parts = [E[rel].view(-1, 16, 2, 4, 8).permute(0, 2, 3, 1, 4).reshape(-1)]
+        idx = (torch.arange(2 * T - 1, device=dev) - (T - 1)).clamp(-maxlen, maxlen - 1) + maxlen
+        rows = torch.cat([idx, idx.new_full((W - (2 * T - 1),), zero_row)])
+        parts.append(E[rows].reshape(-1))
+        if want_t:
+            cols = torch.cat([rows, rows.new_full((ld - W,), zero_row)])
+            parts.append(E[cols].t().reshape(-1))
+        return torch.cat(parts), idx, parts[0].numel()
+
+    flat, idx, n_pack = cached_const(("relpos", dev.index, T, maxlen, bool(want_t)), build)
+    zrow = cached_const(("zrow", dev.index, dk), lambda: torch.zeros((1, dk), dtype=torch.float32, device=dev))
+    ext = torch.cat([pe.detach(), zrow]).to(torch.bfloat16)
+    vals = ext.view(-1).index_select(0, flat)
+    window = (vals[n_pack:n_pack + W * dk].view(W, dk), idx)
+    if want_t:
+        window = window + (vals[n_pack + W * dk:].view(dk, ld),)
+    return {"pe_bf": ext[:2 * maxlen], "pack": (vals[:n_pack], int(q_min), int(q_max)), "window": window}
 
 
 def pe_window_t(win, T):

@@ -454,6 +454,15 @@ int csship_pit_mse_bwd(const float* masks, int64_t ld_mask, const float* f_orig,
                        int32_t T, int32_t F, int32_t K, int32_t n_masks, float grad_loss,
                        float* grad_masks, csship_stream_t stream);
 
+/* The same with the upstream gradient of the loss ALSO read from device memory (grad_loss_dev: one f32, may be NULL):
+ * grad_masks = (the above with grad_loss) * *grad_loss_dev, the two factors applied in that order.  An autograd
+ * backward receives d(objective)/d(loss) as a device scalar; multiplying by it afterwards was a second pass over the
+ * B*T*n_masks*F gradient. */
+int csship_pit_mse_bwd_dev(const float* masks, int64_t ld_mask, const float* f_orig, int64_t ld_f,
+                           const float* const* targets_host, const int32_t* perm, int32_t B,
+                           int32_t T, int32_t F, int32_t K, int32_t n_masks, float grad_loss,
+                           const float* grad_loss_dev, float* grad_masks, csship_stream_t stream);
+
 /* ------------------------------------------------------------------ stitching
  * Stitcher.get_stitch / get_connect (css/executor/stitcher.py:14-110).
  *   mags: f32 [W, F, T]; masks: f32 [W, F, T, 3] (spk1, spk2, noise);
@@ -922,7 +931,9 @@ int csship_p2p_reduce(const float* const* srcs_host, int32_t world, int64_t lo, 
  * gradients the explicit backward hands to FusedAdam's flat gradient buffer: torch.autograd's AccumulateGrad nodes in the
  * reference).  cols == 0: src dense, n elements.  cols > 0: dst is a dense [n / cols, cols] matrix and receives the
  * TRANSPOSE of src, element (r, c) from src[c * ld_src + r] (the depthwise conv weight, kept [taps, channels] by the
- * kernels).  The table is read on the host and travels in the kernel arguments, so a captured launch replays it. */
+ * kernels).  cols < 0: dst is a dense [n / C, C] matrix, C = -cols, and src has the same rows ld_src >= C elements apart
+ * (a product written with a padded row stride).  The table is read on the host and travels in the kernel arguments, so
+ * a captured launch replays it. */
 typedef struct csship_grad_job {
   const float* src;
   float* dst;

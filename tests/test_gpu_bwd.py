@@ -302,9 +302,9 @@ def test_attn_pos_bwd_equals_the_two_products(ob, B, T, H):
 
 def test_grad_accumulate_many_small_tensors(ob):
     """csship_grad_accumulate: dst += src for a table of tensors in one launch per 96 (dense, odd sizes, unaligned views,
-    a transposed 2-d view), the rest handed back"""
+    a transposed 2-d view, a view with a padded row stride), the rest handed back"""
     g = torch.Generator().manual_seed(5)
-    sizes = [1, 2, 3, 7, 256, 257, 1024, 65536, 33 * 256] + [256] * 120
+    sizes = [1, 2, 3, 7, 256, 257, 1024, 65536, 33 * 256, 256 * 257] + [256] * 120
     flat = torch.randn(sum((n + 3) // 4 * 4 for n in sizes) + 8, generator=g).to(DEV)
     ref = flat.clone()
     pairs, off = [], 0
@@ -316,6 +316,11 @@ def test_grad_accumulate_many_small_tensors(ob):
             src = m.t()
             ref[off:off + n] += m.t().contiguous().view(-1)
             dst = dst.view(256, 1, 33)
+        elif n == 256 * 257:   # the embed weight gradient: rows 264 floats apart
+            m = torch.randn(256, 264, generator=g).to(DEV)
+            src = m[:, :257]
+            ref[off:off + n] += src.contiguous().view(-1)
+            dst = dst.view(256, 257)
         else:
             ref[off:off + n] += src
         pairs.append((dst, src))
@@ -782,3 +787,39 @@ def test_bgemm_band_hint_skips_only_zero_tiles(ob):
     got2 = ob.bgemm(a2, q_rows, a_kmajor=True, b_kmajor=True, add=acc, splits=Bz, band=T - 1, band_stride=H)
     assert torch.equal(got2, want2)
     assert relerr(got2, a2.float().cpu().double().T @ q_rows.float().cpu().double() + acc.cpu().double()) < 1e-4
+
+
+@pytest.mark.parametrize("T", [37, 400, 449, 460])
+def test_relpos_tables_match_the_separate_packers(ob, T):
+    """one gather through a cached index == ops.pack_relpos + backward.relpos_window + pe_window_t, bit for bit"""
+    from css_amd import backward as bw, ops
+    pe = (torch.randn(2000, 64, generator=torch.Generator().manual_seed(T)) * 0.3).to(DEV)
+    for _ in range(2):   # second pass: the cached index
+        rt = ob.relpos_tables(pe, T, 1000, want_t=T <= 449)
+        pack, qmin, qmax = ops.pack_relpos(pe, 1000)
+        assert rt["pack"][1:] == (qmin, qmax) and torch.equal(rt["pack"][0], pack)
+        assert torch.equal(rt["pe_bf"], pe.to(torch.bfloat16))
+        win, idx = bw.relpos_window(pe.to(torch.bfloat16), T, 1000)
+        assert torch.equal(rt["window"][0], win) and torch.equal(rt["window"][1], idx)
+        assert len(rt["window"]) == (3 if T <= 449 else 2)
+        if T <= 449:
+            assert torch.equal(rt["window"][2], ob.pe_window_t(win, T))
+        for t in (rt["pack"][0], rt["window"][0]) + tuple(rt["window"][2:]):
+            assert t.data_ptr() % 16 == 0
+
+
+def test_pit_backward_with_the_upstream_gradient_on_the_device(ob):
+    """csship_pit_mse_bwd_dev: the kernel's own multiply by the device scalar == a second pass that multiplies, bit for bit"""
+    from css_amd import ops
+    B, T, F, K = 3, 50, 257, 2
+    g = torch.Generator().manual_seed(5)
+    masks = torch.zeros((B, T, 772), device=DEV)[..., :771]
+    masks.copy_(torch.rand(B, T, 771, generator=g))
+    f = torch.rand(B, T, F, generator=g).to(DEV)
+    tg = [torch.rand(B, T, F, generator=g).to(DEV) for _ in range(K)]
+    _, perm, _, _ = ops.pit_mse(masks, f, tg)
+    gl = torch.tensor(0.37, device=DEV)
+    a = ops.pit_mse_bwd(masks, f, tg, perm, 3, 1.0, grad_loss_dev=gl)
+    b = ops.pit_mse_bwd(masks, f, tg, perm, 3, 1.0)
+    assert a.stride() == masks.stride() and torch.equal(a, b * gl) and b.abs().max() > 0
+    assert torch.equal(ops.pit_mse_bwd(masks, f, tg, perm, 3, 1.0, grad_loss_dev=torch.ones((), device=DEV)), b)
