@@ -142,6 +142,7 @@ SIGNATURES = {
     "csship_reduce_defer": (_i32, [_i32]),
     "csship_reduce_hold": (_i32, [_i32]),
     "csship_grad_accumulate": (_i32, [_p, _i32, _p]),
+    "csship_ema_update": (_i32, [_p, _i32, _f32, _f32, _i32, _f32, _p]),
     "csship_wgrad_hold": (_i32, [_i32]),
     "csship_wgrad_pending": (_i32, []),
     "csship_wgrad_group_workspace": (_sz, []),

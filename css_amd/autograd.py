@@ -239,7 +239,7 @@ class ConformerTrain(torch.autograd.Function):
         _, x = ops.layernorm_relu(e, enc.embed[1].weight.detach(), enc.embed[1].bias.detach())
         if ds.active:  # conformer.py:127 drops before the ReLU; relu(drop(v)) == drop(relu(v)) (the scale is positive)
             ops.dropout_apply(x, ds.cfg("embed"))
-        S["we_bf"] = we_bf
+        S["we_bf"], S["fn"] = we_bf, fn   # (the normalised features, 6.7 MB in bf16, kept for the embed weight gradient)
         pe = model.position_table()
         # packed table of the forward, bf16 table, window (+ its transpose for csship_attn_pos_bwd up to 449 frames) of
         # the backward: three launches
@@ -368,9 +368,7 @@ class ConformerTrain(torch.autograd.Function):
             S["layers"].append(L)
         if bn_means:  # BatchNorm1d bookkeeping for all blocks at once (momentum 0.1, unbiased running variance)
             with torch.no_grad():
-                torch._foreach_mul_(bn_means + bn_vars, 0.9)
-                torch._foreach_add_(bn_means, bn_new_m, alpha=0.1)
-                torch._foreach_add_(bn_vars, bn_new_v, alpha=0.1 * M_bn / max(M_bn - 1, 1))
+                ob.ema_update(bn_means, bn_new_m, 0.1, bn_vars, bn_new_v, 0.1 * M_bn / max(M_bn - 1, 1), 0.9)
                 bn_counters(model).add_(1)
         n_out = model.linear.out_features
         wh_bf, wh_p = pack["wh_bf"], pack["wh_p"]
@@ -512,7 +510,7 @@ class ConformerTrain(torch.autograd.Function):
         if ds.active:
             ops.dropout_apply(dx, ds.cfg("embed"))
         dwe, dbe, dg, dbeta = bw.embed_bwd(S["f"], dx, S["mean"], S["rinv"], S["we_bf"], enc.embed[0].bias.detach(),
-                                           enc.embed[1].weight.detach(), enc.embed[1].bias.detach(), e=S["e"])
+                                           enc.embed[1].weight.detach(), enc.embed[1].bias.detach(), e=S["e"], fn=S["fn"])
         put(enc.embed[0].weight, dwe), put(enc.embed[0].bias, dbe)
         put(enc.embed[1].weight, dg), put(enc.embed[1].bias, dbeta)
         red.flush()

@@ -232,11 +232,13 @@ def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_s
     return dx, (dg, dbeta, dw, db, dwo, dbo, dpe)
 
 
-def embed_bwd(f, dy, mean, rinv, w_bf_pad, bias, ln_g, ln_b, e=None):
+def embed_bwd(f, dy, mean, rinv, w_bf_pad, bias, ln_g, ln_b, e=None, fn=None):
     """x = relu(LN(MVN(f) @ w^T + b)) (conformer.py:95,124-129).  f: f32 [B,T,idim]; dy: f32 [M, D].
-    w_bf_pad: bf16 [D, pad8(idim)].  Returns (dw [D, idim], db, dln_g, dln_b); the input needs no gradient."""
+    w_bf_pad: bf16 [D, pad8(idim)].  e / fn: the forward's pre-LN activations / normalised features bf16 [M, Kp], when
+    it kept them.  Returns (dw [D, idim], db, dln_g, dln_b); the input needs no gradient."""
     B, T, F = f.shape
-    fn = ob.mvn_apply(f, mean, rinv, w_bf_pad.shape[1])                  # bf16 [M, Kp]
+    if fn is None:
+        fn = ob.mvn_apply(f, mean, rinv, w_bf_pad.shape[1])              # bf16 [M, Kp]
     if e is None:
         e = ob.bgemm(fn, w_bf_pad, bias=bias)                            # pre-LN activations, recomputed
     de, dg, dbeta = ob.layernorm_bwd(e, dy, ln_g, ln_b, relu=True)

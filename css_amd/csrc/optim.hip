@@ -127,6 +127,33 @@ __global__ __launch_bounds__(256) void grad_accumulate_kernel(GradAccTable t) {
   }
 }
 
+// dst = keep * dst + w * src over a table of dense tensors (the BatchNorm running statistics of all blocks: one launch)
+__global__ __launch_bounds__(256) void ema_update_kernel(GradAccTable t, float keep, float w_head, int n_head, float w_tail) {
+  const csship_grad_job j = t.job[blockIdx.y];
+  const float w = (int)blockIdx.y < n_head ? w_head : w_tail;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < j.n) j.dst[i] = fmaf(w, j.src[i], keep * j.dst[i]);
+}
+
+extern "C" int csship_ema_update(const csship_grad_job* jobs_host, int32_t n_jobs, float keep, float w_head,
+                                 int32_t n_head, float w_tail, csship_stream_t stream) {
+  if (n_jobs < 0 || (n_jobs > 0 && !jobs_host)) return CSSHIP_ENULL;
+  if (n_jobs > GA_JOBS || n_head < 0) return CSSHIP_EBADSHAPE;
+  if (n_jobs == 0) return CSSHIP_OK;
+  GradAccTable t{};
+  int64_t maxn = 0;
+  for (int k = 0; k < n_jobs; ++k) {
+    const csship_grad_job& j = jobs_host[k];
+    if (!j.src || !j.dst || j.n <= 0 || j.cols != 0) return CSSHIP_EBADSHAPE;
+    t.job[k] = j;
+    maxn = std::max(maxn, j.n);
+  }
+  hipLaunchKernelGGL(ema_update_kernel, dim3((unsigned)((maxn + 255) / 256), (unsigned)n_jobs), dim3(256), 0,
+                     as_stream(stream), t, keep, w_head, (int)n_head, w_tail);
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
 extern "C" int csship_grad_accumulate(const csship_grad_job* jobs_host, int32_t n_jobs, csship_stream_t stream) {
   if (n_jobs < 0 || (n_jobs > 0 && !jobs_host)) return CSSHIP_ENULL;
   for (int at = 0; at < n_jobs; at += GA_JOBS) {

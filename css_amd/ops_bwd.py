@@ -538,6 +538,23 @@ def grad_accumulate(pairs):
     return rest
 
 
+def ema_update(dsts_head, srcs_head, w_head, dsts_tail, srcs_tail, w_tail, keep):
+    """dst = keep * dst + w * src for two lists of dense f32 tensors (w_head / w_tail) in ONE launch per 96 tensors
+    (csship_ema_update): BatchNorm's running statistics of every block."""
+    pairs = [(d, s_, True) for d, s_ in zip(dsts_head, srcs_head)] + [(d, s_, False) for d, s_ in zip(dsts_tail, srcs_tail)]
+    for d, s_, _ in pairs:
+        _need(d, torch.float32, "dst"), _need(s_, torch.float32, "src")
+        if not (d.is_contiguous() and s_.is_contiguous() and d.numel() == s_.numel() and d.numel() > 0):
+            raise RuntimeError("css_amd: ema_update takes dense tensors of equal size")
+    for at in range(0, len(pairs), 96):   # (a chunk keeps its head jobs in front: the lists are already in that order)
+        chunk = pairs[at:at + 96]
+        arr = (_lib.GradJob * len(chunk))()
+        for a, (d, s_, _) in zip(arr, chunk):
+            a.src, a.dst, a.n, a.ld_src, a.cols = s_.data_ptr(), d.data_ptr(), d.numel(), 0, 0
+        check(lib().csship_ema_update(arr, len(chunk), float(keep), float(w_head), sum(1 for p in chunk if p[2]),
+                                      float(w_tail), _stream()))
+
+
 def attn_rowdot(d_out, out, B, T, H):
     """D[b,h,i] = sum_d dO[b,i,h,d] * O[b,i,h,d] for bf16 [B*T, H*64] operands -> f32 [B,H,T]."""
     _need(d_out, torch.bfloat16, "d_out"), _need(out, torch.bfloat16, "out")

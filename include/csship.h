@@ -941,6 +941,12 @@ typedef struct csship_grad_job {
   int32_t cols, pad_;
 } csship_grad_job;
 int csship_grad_accumulate(const csship_grad_job* jobs_host, int32_t n_jobs, csship_stream_t stream);
+/* dst = keep * dst + w * src for a table of at most 96 DENSE f32 tensors (cols == 0) in one launch, w = w_head for the
+ * first n_head jobs and w_tail for the rest: the running mean / running variance update of every BatchNorm1d of the
+ * model after a training forward (torch.nn.BatchNorm1d, momentum m: keep = 1 - m, w = m for the means and
+ * m * n / (n - 1) for the variances; conformer.py:293).  Evaluated as fma(w, src, keep * dst). */
+int csship_ema_update(const csship_grad_job* jobs_host, int32_t n_jobs, float keep, float w_head, int32_t n_head,
+                      float w_tail, csship_stream_t stream);
 
 /* ---- csship_adam_clip (css_amd/csrc/optim.hip): clip_grad_norm_(max_norm) followed by one Adam step
  * (iteration_types.py:17-64) on FLAT f32 buffers of n elements (parameters, gradients, first and second moments), in

@@ -823,3 +823,19 @@ def test_pit_backward_with_the_upstream_gradient_on_the_device(ob):
     b = ops.pit_mse_bwd(masks, f, tg, perm, 3, 1.0)
     assert a.stride() == masks.stride() and torch.equal(a, b * gl) and b.abs().max() > 0
     assert torch.equal(ops.pit_mse_bwd(masks, f, tg, perm, 3, 1.0, grad_loss_dev=torch.ones((), device=DEV)), b)
+
+
+def test_ema_update_running_statistics(ob):
+    """csship_ema_update: dst = keep * dst + w * src over a table (BatchNorm running mean / variance of every block)"""
+    g = torch.Generator().manual_seed(9)
+    n = 70   # 140 tensors: two launches
+    means, nm = [torch.randn(256, generator=g).to(DEV) for _ in range(n)], [torch.randn(256, generator=g).to(DEV) for _ in range(n)]
+    vrs, nv = [torch.rand(256, generator=g).to(DEV) for _ in range(n)], [torch.rand(1024, generator=g).to(DEV)[256:512] for _ in range(n)]
+    w_t = 0.1 * 12800 / 12799
+    want_m = [0.9 * a.double() + 0.1 * b.double() for a, b in zip(means, nm)]
+    want_v = [0.9 * a.double() + w_t * b.double() for a, b in zip(vrs, nv)]
+    ob.ema_update(means, nm, 0.1, vrs, nv, w_t, 0.9)
+    for got, want in zip(means + vrs, want_m + want_v):
+        assert torch.allclose(got.double(), want, rtol=3e-7, atol=1e-7)
+    with pytest.raises(RuntimeError):
+        ob.ema_update([means[0]], [nm[0][:128]], 0.1, [], [], 0.1, 0.9)
