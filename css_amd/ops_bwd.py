@@ -609,17 +609,30 @@ def attn_dvdk(p_v, ds, d_out, qkv, dqkv, n_head):
     return dqkv
 
 
-_CONST = {}
+_CONST = {}            # key -> tensor(s), least recently used first
+_CONST_KEEP = set()    # keys a captured graph reads through their address: never evicted
+_CONST_MAX = 64
 
 
 def cached_const(key, build):
     """Step-invariant index / scale tensors: built once per key, OUTSIDE graph capture only (a tensor allocated while a
-    step is being captured lives in the graph's pool and must not outlive the capture; such a step rebuilds it)."""
-    t = _CONST.get(key)
+    step is being captured lives in the graph's pool and must not outlive the capture; such a step rebuilds it).  At
+    most _CONST_MAX entries (variable-length batches would otherwise keep one index per length for ever); an entry a
+    captured graph has read stays - the graph replays its address."""
+    capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+    t = _CONST.pop(key, None)
     if t is None:
         t = build()
-        if not torch.cuda.is_current_stream_capturing():
-            _CONST[key] = t
+        if capturing:
+            return t
+        if len(_CONST) >= _CONST_MAX:
+            for k in list(_CONST):
+                if k not in _CONST_KEEP:
+                    del _CONST[k]
+                    break
+    _CONST[key] = t
+    if capturing:
+        _CONST_KEEP.add(key)
     return t
 
 
@@ -651,7 +664,7 @@ def relpos_tables(pe, T, maxlen=1000, want_t=True):
         if want_t:
             cols = torch.cat([rows, rows.new_full((ld - W,), zero_row)])
             parts.append(E[cols].t().reshape(-1))
-        return torch.cat(parts), idx, parts[0].numel()
+        return torch.cat(parts).to(torch.int32), idx, parts[0].numel()
 
     flat, idx, n_pack = cached_const(("relpos", dev.index, T, maxlen, bool(want_t)), build)
     zrow = cached_const(("zrow", dev.index, dk), lambda: torch.zeros((1, dk), dtype=torch.float32, device=dev))

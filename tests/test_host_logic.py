@@ -288,3 +288,21 @@ def test_bucket_plan_partitions_the_flat_buffer_in_backward_order():
         head_lo = min(offs[i] for i, p in enumerate(params) if any(p is q for q in m.linear.parameters()))
         assert plan[0] == (head_lo, n)
     assert getattr(m, "_grad_bucket_hook", None) is None   # planning leaves no hook behind
+
+
+def test_cached_const_is_bounded_and_keeps_recent_entries():
+    """ops_bwd.cached_const: least recently used entries leave once the table is full; a hit does not rebuild"""
+    from css_amd import ops_bwd as ob
+    saved, keep = dict(ob._CONST), set(ob._CONST_KEEP)
+    ob._CONST.clear(), ob._CONST_KEEP.clear()
+    try:
+        built = []
+        for i in range(ob._CONST_MAX + 5):
+            ob.cached_const(("t", i), lambda i=i: built.append(i) or torch.full((1,), float(i)))
+            ob.cached_const(("t", 0), lambda: built.append(-1) or torch.zeros(1))   # touched every round: stays
+        assert len(ob._CONST) == ob._CONST_MAX and ("t", 0) in ob._CONST and ("t", 1) not in ob._CONST
+        assert -1 not in built and built == list(range(ob._CONST_MAX + 5))
+        assert float(ob.cached_const(("t", ob._CONST_MAX + 4), lambda: torch.zeros(1))) == ob._CONST_MAX + 4
+    finally:
+        ob._CONST.clear(), ob._CONST.update(saved)
+        ob._CONST_KEEP.clear(), ob._CONST_KEEP.update(keep)
