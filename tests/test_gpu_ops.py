@@ -156,6 +156,17 @@ def test_mvn_stats(ops):
     assert err(rinv, 1.0 / (x.std(1) + oracle.feature.EPS)) < 1e-4
 
 
+@pytest.mark.parametrize("T", [2, 16, 400, 512, 513, 700])
+def test_mvn_stats_lengths(ops, T):
+    """rows kept in registers up to 512 frames, the rest re-read; T = 2 leaves most waves without a row"""
+    x = rnd((2, T, 257), 80 + T).abs() + 0.01
+    mean, rinv = ops.mvn_stats(x.to(DEV))
+    assert err(mean, x.mean(1)) < 1e-5
+    assert err(1.0 / rinv, x.std(1) + oracle.feature.EPS) < 1e-5   # (1 / std itself is unbounded for two near-equal frames)
+    again = ops.mvn_stats(x.to(DEV))
+    assert torch.equal(again[0], mean) and torch.equal(again[1], rinv)
+
+
 # ----------------------------------------------------------------------------- LayerNorm / GEMM
 def test_layernorm(ops):
     x = rnd((301, 256), 9) * 2 + 0.5
