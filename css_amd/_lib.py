@@ -89,6 +89,8 @@ MHA_Q_LOG2E = 1
 SIGNATURES = {
     "csship_version": (_i32, []),
     "csship_strerror": (C.c_char_p, [_i32]),
+    "csship_ffn_static_max_ffn": (_i32, []),
+    "csship_attn_pos_bwd_max_t": (_i32, []),
     "csship_stft": (_i32, [_p, _i64, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _p]),
     "csship_stft_ld": (_i32, [_p, _i64, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _p]),
     "csship_stft_logpower": (_i32, [_p, _i64, _i64, _i64, _i64, _i64, _f32, _p, _p]),

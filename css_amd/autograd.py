@@ -36,7 +36,8 @@ def _direct_grad(p):
     since the optimiser's last zero_grad(): 0 + g == g), else None.  Claims the view: a second contribution accumulates."""
     g = p.grad
     own = getattr(g, "_csship_owner", None) if g is not None else None
-    if _NO_DIRECT or own is None or not p.requires_grad or id(p) in own._dirty or g.dtype != torch.float32 or not g.is_contiguous():
+    if (_NO_DIRECT or own is None or not p.requires_grad or id(p) in own._dirty or g.dtype != torch.float32
+            or not g.is_contiguous() or not own.grads_untouched()):
         return None
     own._dirty.add(id(p))
     return g
@@ -47,6 +48,17 @@ def _mark_written(ps):
         own = getattr(p.grad, "_csship_owner", None)
         if own is not None:
             own._dirty.add(id(p))
+
+
+def _owners(ps):
+    """the FusedAdam instances that own the ``.grad`` views of ps, each with whether its buffer was still untouched by
+    torch-side writes (checked BEFORE one of our own follows: FusedAdam.own_write re-arms the check afterwards)"""
+    seen = {}
+    for p in ps:
+        own = getattr(p.grad, "_csship_owner", None) if p.grad is not None else None
+        if own is not None and id(own) not in seen:
+            seen[id(own)] = (own, own.grads_untouched())
+    return list(seen.values())
 
 
 def _deliver(model, G):
@@ -61,7 +73,8 @@ def _deliver(model, G):
         _mark_written(direct)
         for p in direct:
             del G[p]
-    return tuple(G.get(p) if p.requires_grad else None for p in params)
+    # (a leftover may still be the transposed [D, K] view put() keeps for csship_grad_accumulate: autograd wants p.shape)
+    return tuple((G[p].reshape(p.shape) if p in G else None) if p.requires_grad else None for p in params)
 
 
 _NO_GRAD_ACC = bool(os.environ.get("CSS_AMD_NO_GRAD_ACC"))   # A/B timing: torch._foreach_add_ (+ contiguous copies) instead
@@ -74,7 +87,10 @@ def _accumulate(ps, G):
         pairs = [(p.grad, G[p]) for p in ps]
         rest = pairs if _NO_GRAD_ACC else ob.grad_accumulate(pairs)
         if rest:
+            owners = _owners(ps)
             torch._foreach_add_([d for d, _ in rest], [s.reshape(d.shape).contiguous() for d, s in rest])
+            for own, clean in owners:   # our own torch-side write: it must not read as a foreign one
+                own.own_write(clean)
 
 
 def _deliver_group(model, module, G):
@@ -91,7 +107,11 @@ def _deliver_group(model, module, G):
         _mark_written(ps)
         for p in ps:
             del G[p]
+    # the hook may start an in-place all-reduce on a stretch of the flat gradient buffer (a torch-side write of ours)
+    owners = _owners([p for p in module.parameters() if p.grad is not None][:1])
     hook(module)
+    for own, clean in owners:
+        own.own_write(clean)
 
 
 def _skew_buffer(model, shape, device):
@@ -243,7 +263,7 @@ class ConformerTrain(torch.autograd.Function):
         pe = model.position_table()
         # packed table of the forward, bf16 table, window (+ its transpose for csship_attn_pos_bwd up to 449 frames) of
         # the backward: three launches
-        rt = ob.relpos_tables(pe, T, 1000, want_t=T <= 449)
+        rt = ob.relpos_tables(pe, T, 1000, want_t=T <= ob.pos_bwd_max_T())
         pe_pack = rt["pack"]
         S["pe_bf"], S["pe_pack"], S["window"] = rt["pe_bf"], pe_pack, rt["window"]
         bn_means, bn_vars, bn_new_m, bn_new_v = [], [], [], []
@@ -493,7 +513,7 @@ class ConformerTrain(torch.autograd.Function):
                 put(lin.weight, dwqkv[i * D:(i + 1) * D]), put(lin.bias, dbqkv[i * D:(i + 1) * D])
             put(a.linear_out.weight, dwo), put(a.linear_out.bias, dbo)
             # the block's input is the final LayerNorm of the block below: its backward rides in this kernel's epilogue
-            ln_done = li > 0 and not S["wide"] and not _NO_LN2 and M % 64 == 0 and enc.d_ffn <= 2048
+            ln_done = li > 0 and not S["wide"] and not _NO_LN2 and M % 64 == 0 and enc.d_ffn <= ob.ffn_static_max_ffn()
             if ln_done:
                 below, Lb = layers[li - 1], S["layers"][li - 1]
                 dx, (dg2, dbeta2) = ffn_b(lay.feed_forward_in, "ffn_in", dx, ln2=(Lb["x4"], below.layer_norm.weight.detach()))

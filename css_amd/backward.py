@@ -116,7 +116,7 @@ def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000, window=None, probs=
     do = dao.view(B, T, H, 64).permute(0, 2, 1, 3)
     if probs is not None and ao is not None and not _SPLIT_ATTN_BWD:
         # one pass over the scores: probabilities, softmax backward (row-major and skewed dS) and dS k
-        from_ds = (window is not None and len(window) > 2 and window[2] is not None and T <= 449 and not _NO_POS_FUSED
+        from_ds = (window is not None and len(window) > 2 and window[2] is not None and T <= ob.pos_bwd_max_T() and not _NO_POS_FUSED
                    and not _NO_POS_FROM_DS)   # the position products skew the row-major dS themselves: no skewed copy
         dsk = None if from_ds else (torch.zeros((B, T, H, W), dtype=BF, device=qkv.device) if skew_buf is None else skew_buf)
         p_v, ds, dsk, dq1, q_rows = ob.mha_bwd_core(qkv, probs[0], probs[1], dao, None, dsk, H, drop=drop_p,
@@ -157,7 +157,7 @@ def _mha_core_products(qkv, g, q, k, do, p_v, ds, dsk, dq1, win, idx, window, dw
         ob.bgemm(p_v[..., :T], do, a_kmajor=True, b_kmajor=True, out=dv)    # dV = P^T dO
         ob.bgemm(ds[..., :T], q, a_kmajor=True, b_kmajor=True, out=dk)      # dK = dS^T q
     win_t = window[2] if window is not None and len(window) > 2 else None
-    if (win_t is not None and not _NO_POS_FUSED and T <= 449 and q_rows is not None and (dsk is None or dsk.is_contiguous())
+    if (win_t is not None and not _NO_POS_FUSED and T <= ob.pos_bwd_max_T() and q_rows is not None and (dsk is None or dsk.is_contiguous())
             and dq1.is_contiguous() and dq1.dtype == torch.float32 and tuple(dq1.shape) == (B, H, T, 64)):
         # both position products in one pass (csship_attn_pos_bwd): over the skewed dS, or - no skewed copy written -
         # over the row-major dS, skewed while the kernel stages its tiles

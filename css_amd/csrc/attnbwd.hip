@@ -512,6 +512,9 @@ extern "C" size_t csship_attn_pos_bwd_workspace(int32_t B, int32_t T) {
   return (size_t)B * nblk * nwt * 16 * 64 * sizeof(float);
 }
 
+// span = 63 + T window rows must fit PB_MAXKS k-steps of 32
+extern "C" int csship_attn_pos_bwd_max_t(void) { return PB_MAXKS * 32 - (PB_ROWS - 1); }
+
 static int pos_bwd_impl(const uint16_t* ds_skew, int64_t ld_w, const uint16_t* pe_window_t, int64_t ld_pt,
                         const uint16_t* q_rows, const float* dq1, uint16_t* dqkv, float* dwin_acc, int32_t W,
                         int32_t B, int32_t T, int32_t H, void* workspace, size_t workspace_bytes,

@@ -41,6 +41,7 @@ DEV uint4 pair_tiles_bf16(uint2 t0, uint2 t1) {
 
 constexpr int PD = 4;  // weight prefetch distance in k-steps (ring of PD fragment sets per wave)
 constexpr int CS_FFMAX = 2048;  // static forms (chain_s_kernel, ffn_bwd_kernel<FULL>): widest FeedForward whose biases fit their LDS block
+extern "C" int csship_ffn_static_max_ffn(void) { return CS_FFMAX; }
 constexpr int CS_DUMP = 256;    // floats behind a parameter block where staging lanes without work write
 #ifdef P_STAMPS  // diagnostic build: wave 0 of every workgroup stores s_memtime at phase boundaries -> g_csship_stamps[wg*32 + i]
 #define P_T(i)                                                                                                  \

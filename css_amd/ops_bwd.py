@@ -69,6 +69,16 @@ class deferred_reductions:
         return False
 
 
+def pos_bwd_max_T():
+    """longest chunk csship_attn_pos_bwd(_ds) takes (the kernel's own constant, not a copy of it)"""
+    return int(lib().csship_attn_pos_bwd_max_t())
+
+
+def ffn_static_max_ffn():
+    """widest FeedForward of the static row-panel forms (csship_ffn_bwd_ln, the chain kernel's static form)"""
+    return int(lib().csship_ffn_static_max_ffn())
+
+
 _hold = {"on": False, "ws": []}
 _NO_PAIR = bool(os.environ.get("CSSHIP_NO_PAIR_REDUCE"))   # A/B timing: every weight gradient's slab reduction as its own launch
 
@@ -93,6 +103,11 @@ class paired_reductions:
                 if et is None and lib().csship_reduce_pending():
                     check(lib().csship_reduce_flush(_stream()))
                     _deferred_ws.clear()   # (the flush ran every queued job, the deferred small ones included)
+                elif et is not None and not _defer["on"]:
+                    # an exception between the products: the held jobs point at the workspaces freed below.  Outside
+                    # a deferred_reductions scope nobody else drops them (switching the deferred mode off does, and
+                    # restores the mode it found); inside one, the outer scope's error path drops the whole queue.
+                    lib().csship_reduce_defer(lib().csship_reduce_defer(0))
             finally:
                 _hold["ws"].clear()
         return False

@@ -53,11 +53,48 @@ class FusedAdam(torch.optim.Optimizer):
         # (css_amd/autograd.py) stores a weight gradient straight into a view that is still zero instead of producing a
         # temporary and adding it (0 + g == g), and accumulates as before into one that is not
         self._dirty = set()
+        # A store is only right while the view is still zero, and a torch-side write the explicit backward does not
+        # know of (AccumulateGrad of a second loss term on the same parameters, a manual ``p.grad.add_``, gradients a
+        # caller restores) breaks that.  Every ``.grad`` view shares the flat buffer's version counter, which any
+        # in-place torch operation on any of them bumps - kernels that write through raw pointers do not - so "no
+        # foreign write since zero_grad()" is "the counter still reads what zero_grad() left" (grads_untouched()).
+        # AccumulateGrad is caught per parameter as well (post-accumulate hook below).
+        self._grad_version = self.flat_grad._version
+        self._foreign = False
+        import weakref
+        me = weakref.ref(self)
+
+        def written(p):
+            o = me()
+            if o is not None:
+                o._dirty.add(id(p))
+        for p in params:
+            if p.requires_grad:
+                p.register_post_accumulate_grad_hook(written)
 
     def zero_grad(self, set_to_none=False):
         """Gradients stay views of the flat buffer (set_to_none is ignored): one fill."""
         self.flat_grad.zero_()
         self._dirty.clear()
+        self._grad_version = self.flat_grad._version
+        self._foreign = False
+
+    def grads_untouched(self):
+        """True while no torch operation has written into the flat gradient buffer (any ``.grad`` view) since
+        zero_grad() - the condition under which css_amd.autograd may STORE a gradient instead of accumulating it.
+        Once False it stays False until the next zero_grad()."""
+        if self._foreign:
+            return False
+        if self.flat_grad._version != self._grad_version:
+            self._foreign = True
+            return False
+        return True
+
+    def own_write(self, was_untouched):
+        """css_amd's own torch-side writes into the buffer (the multi-tensor add fallback, an overlapped bucket
+        all-reduce) re-arm the check - only if it held right before them."""
+        if was_untouched and not self._foreign:
+            self._grad_version = self.flat_grad._version
 
     @torch.no_grad()
     def step(self, closure=None, max_norm=None):

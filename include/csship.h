@@ -40,6 +40,11 @@ enum {
 
 int csship_version(void);
 const char* csship_strerror(int rc);
+/* Limits of the tuned kernel forms, so that callers gate on the kernels' own constants instead of copies of them:
+ * the widest FeedForward the static row-panel forms take (csship_encoder_chain's static form, csship_ffn_bwd_ln), and
+ * the longest chunk csship_attn_pos_bwd(_ds) takes (longer chunks: CSSHIP_EUNSUPPORTED; the tiled products serve them). */
+int csship_ffn_static_max_ffn(void);
+int csship_attn_pos_bwd_max_t(void);
 
 /* ------------------------------------------------------------------ dropout (training mode)
  * The reference applies nn.Dropout(p) at: the embedding (css/models/conformer.py:127, css/models/blstm.py:147), the
@@ -620,8 +625,9 @@ int csship_reduce_hold(int32_t on);
 int csship_reduce_pending(void);
 int csship_reduce_flush(csship_stream_t stream);
 /* Grouped weight gradients.  Between csship_wgrad_hold(1) and csship_wgrad_flush() the calling host thread's
- * csship_bgemm_wgrad calls that fit the LDS-DMA loop (bf16 operands, M and N multiples of 128, K a multiple of 64 and
- * the same for all of them, at most 96 tiles, no bias) are queued and run by the flush as ONE launch over all their
+ * csship_bgemm_wgrad calls that fit the LDS-DMA loop (bf16 operands, M and N multiples of 128, any K >= 1024 - the rows
+ * of a last 64-deep tile beyond K lie outside the buffer descriptor and read as zeros - the same K for all of them, at
+ * most 96 tiles, no bias) are queued and run by the flush as ONE launch over all their
  * tiles, the reduction cut only as often as fills the chip once (an encoder block's six products: 80 tiles x 3 pieces
  * instead of 16-64 pieces each), followed by one reduction launch (csship_reduce_flush, which also runs whatever else
  * is queued).  Contract: operands and outputs of a queued call stay valid and unread until the flush; its per-call

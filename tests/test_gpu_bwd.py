@@ -545,6 +545,48 @@ def test_convmod_backward(ob, causal):
                 assert relerr(grads[k], v) < 2e-4, k
 
 
+def test_convmod_backward_behind_the_fused_training_forward(ob):
+    """the training forward's fused kernel (csship_outproj_conv_train: output projection + residual +
+    LayerNorm + GLU + depthwise convolution, then the BatchNorm reduce / apply launches) leaves the workspace the conv
+    module's backward reads.  Its gradients - the SCALAR ones included (pw_conv_1 / pw_conv_2: sums with heavy
+    cancellation that the model-level bounds cannot pin) - against float64 autograd of conformer.py:254,356 + 289-303,357
+    on the same bf16-rounded projection operands and the same upstream gradient."""
+    import torch.nn.functional as F
+    from css_amd import ops
+    B, T, D, K = 3, 130, 256, 33
+    M = B * T
+    x1 = rnd((M, D), 71)
+    ao = rnd((M, D), 72).to(torch.bfloat16)
+    wo, bo = rnd((D, D), 73, 1 / 16), rnd((D,), 74, 0.1)
+    dy = rnd((B, T, D), 75, 0.1)
+    P = {"ln_g": 1 + 0.1 * rnd((D,), 63), "ln_b": 0.1 * rnd((D,), 64), "pw1_w": torch.tensor([0.9, -0.7]),
+         "pw1_b": torch.tensor([0.1, 0.2]), "dw": rnd((D, K), 65, 0.2), "dw_b": 0.1 * rnd((D,), 66),
+         "bn_g": 1 + 0.1 * rnd((D,), 67), "bn_b": 0.1 * rnd((D,), 68), "pw2_w": torch.tensor([1.3]),
+         "pw2_b": torch.tensor([-0.2])}
+    R = {k: v.double().requires_grad_(True) for k, v in P.items()}
+    x2r = (x1.double() + ao.double() @ wo.to(torch.bfloat16).double().t() + bo.double()).view(B, T, D).requires_grad_(True)
+    a = F.layer_norm(x2r, (D,), R["ln_g"], R["ln_b"], 1e-5)
+    g = (a * R["pw1_w"][0] + R["pw1_b"][0]) * torch.sigmoid(a * R["pw1_w"][1] + R["pw1_b"][1])
+    c = F.conv1d(g.transpose(1, 2), R["dw"][:, None, :], R["dw_b"], padding=K // 2, groups=D)
+    mu, var = c.mean((0, 2), keepdim=True), c.var((0, 2), unbiased=False, keepdim=True)
+    zh = (c - mu) / torch.sqrt(var + 1e-5) * R["bn_g"][None, :, None] + R["bn_b"][None, :, None]
+    y = x2r + (torch.relu(zh) * R["pw2_w"] + R["pw2_b"]).transpose(1, 2)
+    y.backward(dy.double())
+    W = {k: v.to(DEV) for k, v in P.items() if k != "dw"}
+    W["dw_w"] = P["dw"].T.contiguous().to(DEV)
+    x2, yg, fws = ops.outproj_conv_train(ao.to(DEV), ops.pack_frag(wo.to(DEV)), bo.to(DEV), x1.to(DEV), W, B, T, K)
+    assert relerr(x2.view(B, T, D), x2r.detach()) < 1e-5 and relerr(yg.view(B, T, D), y.detach()) < 1e-4
+    dx, grads = ob.convmod_bwd(x2.view(B, T, D), dy.to(DEV), W, fws, K)
+    assert relerr(dx, x2r.grad) < 2e-4
+    ref = {k: R[k].grad for k in P if k != "dw"}
+    ref["dw_w"] = R["dw"].grad.T
+    for k, v in ref.items():
+        if k == "dw_b":
+            assert float(grads[k].abs().max()) < 1e-5
+        else:
+            assert relerr(grads[k], v) < 3e-4, k
+
+
 def test_fused_adam_clip_matches_torch():
     """csship_adam_clip (clip_grad_norm_ + Adam on flat buffers) vs torch.optim.Adam + clip_grad_norm_, 5 steps,
     clipping active on some steps; and the non-finite-gradient guard."""

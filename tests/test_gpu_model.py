@@ -648,6 +648,56 @@ def test_graphed_train_step_matches_eager():
     assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
 
 
+def test_direct_gradient_stores_respect_foreign_writes():
+    """the explicit backward STORES a weight gradient into FusedAdam's zeroed .grad view instead of
+    accumulating.  Any torch-side write between zero_grad() and that store must switch it back to accumulation:
+    (a) a second loss term on the same parameters whose AccumulateGrad runs in the same backward pass (an L2 penalty),
+    (b) a manual p.grad.add_ before the backward.  Both against the always-additive path (no direct stores)."""
+    from css_amd import autograd as ag
+    from css_amd.objectives import OBJECTIVES
+    from css_amd.optim import FusedAdam
+    obj = OBJECTIVES["MSE"].build_objective({})
+    batch = {"mix": rnd((2, 64, 257), 510).abs().to(DEV), "source1": (rnd((2, 64, 257), 511).abs() * 0.5).to(DEV),
+             "source2": (rnd((2, 64, 257), 512).abs() * 0.5).to(DEV)}
+
+    def run(direct, case):
+        from css_amd import dropout
+        m, _ = build(2, 49)
+        m.train()
+        dropout.set_seed(m, 5)
+        opt = FusedAdam(m.parameters(), lr=1e-3, max_norm=5.0)
+        old = ag._NO_DIRECT
+        ag._NO_DIRECT = not direct
+        try:
+            opt.zero_grad()
+            if case == "manual":
+                for p in m.parameters():
+                    p.grad.add_(0.25)
+                loss = obj(m, batch, device=DEV)
+            elif case == "l2":
+                loss = obj(m, batch, device=DEV) + 1e-1 * sum(p.pow(2).sum() for p in m.parameters())
+            else:
+                loss = obj(m, batch, device=DEV)
+            loss.backward()
+        finally:
+            ag._NO_DIRECT = old
+        torch.cuda.synchronize()
+        return opt.flat_grad.clone(), opt
+
+    base, _ = run(True, "plain")
+    for case in ("l2", "manual"):
+        g_dir, opt = run(True, case)
+        g_add, _ = run(False, case)
+        err = float((g_dir - g_add).abs().max()) / float(g_add.abs().max())
+        moved = float((g_add - base).abs().max())
+        print(f"[parity] direct-grad contract, {case}: max |direct - additive| / max |g| = {err:.2e}; the extra term moves g by {moved:.2e}")
+        assert moved > 1e-3          # the foreign contribution is really there ...
+        assert err < 1e-6            # ... and the store path did not overwrite it
+    # and the fast path is still taken when nothing foreign happened: the views are claimed by stores
+    _, opt = run(True, "plain")
+    assert opt.grads_untouched() and len(opt._dirty) > 0
+
+
 def test_training_does_not_depend_on_host_synchronisation():
     """12 replayed steps with a different learning rate every step, queued without ever synchronising (the host runs
     many steps ahead of the GPU), equal the same steps with a synchronise after each one, bit for bit: the per-step
