@@ -5,9 +5,14 @@ One "step" = one pass of the hot path over one synthetic batch that is already r
     raw audio (mix, source1, source2: 3 x [32, 102 656] f32)
       -> STFT magnitudes (csship_stft)                     [feature.py:45-82]
       -> Conformer-base encoder forward                    [conformer.py:83-97]
-      -> mask head + mask application + PIT-MSE loss, one kernel, masks never written
-                                                           [conformer.py:98-103, mse.py:22-37]
+      -> mask head + mask application + PIT-MSE loss       [conformer.py:98-103, mse.py:22-37]
 Frames counted per step = B*T = 12 800 mixture frames per GPU (the two target spectrograms are work, not frames).
+
+Round 6: configs[1] is a TRAINING configuration and SURVEY 8d asks for "train mode (dropout p = 0.1, BN batch stats) for
+throughput", so `value` is the TRAIN-mode forward + PIT - what iteration_types.py:34-50 runs before loss.backward():
+dropout at every site, batch-statistics BatchNorm, every operator's input kept for the backward, masks materialised for
+the PIT backward.  The eval-mode forward + PIT (running-statistics BatchNorm, no dropout, head + PIT fused, masks never
+written: the function the parity gate checks against the fp32 oracle) rides along as `eval_fwd_pit`.
 
 --mode train times the training step instead: the same forward in TRAIN mode (batch-statistics BatchNorm), PIT-MSE,
 the explicit HIP backward, the gradient all-reduce over RCCL (N > 1) and the fused clip + Adam update
@@ -21,19 +26,26 @@ mode has the gradient all-reduce.  Barrier + synchronize on both sides of the ti
 prints ONE JSON line with n_gpus = the world size the collective library reports and every rank's ms/step.
 
 Extra objects on the JSON line (task section 4):
-  roofline     measured INSIDE the step: one un-captured step is run with the library's launch timeline on (HIP event
-               pairs directly around every kernel launch, on the launch stream); dominant kernel = the encoder chain
-               (chain_s_kernel<8,1,1,1,0,1>: FFN_out+LN -> FFN_in -> LN+QKV, 15 launches per step, MFMA bound):
-               achieved = algorithmic flops (2 x 4*M*256*1024 + 2*M*256*768) / average launch duration; peak = 2.5
-               PFLOP/s dense bf16; traffic = HBM bytes per launch from the rocprofv3 PMC passes under profiles/.
-               roofline.attention / .outproj_conv (MFMA), .stft / .pit (HBM, 2 052 and 4 108 B/frame) the same way.
+  roofline     measured INSIDE the step: un-captured train-mode forward passes run with the library's launch timeline
+               on (HIP event pairs directly around every tagged launch, on the launch stream, minus the measured cost
+               of an empty pair - nothing fitted to the step).  Dominant kernel = the training form of the encoder chain
+               (chain_s_kernel<8,A,B,QKV,TRAIN>: FFN_out+LN -> FFN_in -> LN+QKV with the four dropouts and the saved
+               rows, 15 launches per step, MFMA bound): achieved = algorithmic flops (2 x 4*M*256*1024 + 2*M*256*768)
+               / average launch duration; peak = 2.5 PFLOP/s dense bf16.  `avg_launch_us_rocprof` / `frac_rocprof` =
+               rocprofv3's averages over the replayed launches of this command, committed under profiles/
+               (`rocprof_source`: file + source hash then and now); traffic / mfma_busy_pmc from the committed PMC
+               passes.  roofline.attention / .outproj_conv (MFMA), .stft / .pit (HBM) the same way; step_kernel_us /
+               step_kernel_us_sum / kernel_sum_over_step = where the step's time goes and whether the launches add up.
+  eval_fwd_pit the EVAL-mode forward + PIT of the same batch (rounds 1-5's headline; the parity-checked function), with
+               its own per-kernel records (eval_fwd_pit.roofline) and the parity gate (`loss_parity`: exit code 3).
   cpu_baseline the oracle (fp32 CPU restatement, kind "port") timed on this box's host cores (rank 0, N = 1 only),
                BASELINE.md section 3: 1 warm-up + 3 timed passes of the full batch on all (<= 16) cores, and a second
                leg on ONE thread over a bounded sample (4 of the 32 chunks); CPU model string reported.
   train_step   (default fwd mode) the TRAINING step of the same workload measured in the same run: train-mode forward
                (dropout, batch-statistics BatchNorm), PIT, explicit backward, gradient all-reduce (N > 1), clip + Adam,
                replayed as captured HIP graph(s); ms/step, frames/s, fraction of the bf16 MFMA peak at 3 x the forward
-               FLOPs, and with N > 1 the collective backend, world size and bytes all-reduced per step.
+               FLOPs, and with N > 1 the collective backend, the checked world size, the bytes all-reduced per step and
+               what RCCL logged about its rings and its algorithm / protocol choice per bucket size (`rccl`).
 """
 import argparse
 import json
@@ -69,15 +81,13 @@ def parse_args():
     ap.add_argument("--p2p", action="store_true", help="training legs: gradients through css_amd.parallel.P2PAllReduce (the "
                     "hand-written direct all-reduce over hipIpc peer mappings) instead of RCCL - the A/B for an 8-GPU node")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-train-step", action="store_true", help="fwd mode: skip the extra training-step measurement")
+    ap.add_argument("--no-train-step", action="store_true", help="fwd mode: skip the training-step legs (the eval-mode leg stays)")
     ap.add_argument("--fuse-conv", type=int, default=None, help="debug: csship_conformer_weights.fuse_conv override")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying the "
                     "step as one captured HIP graph")
     ap.add_argument("--leg-timeout", type=float, default=300.0, help="N > 1: seconds the training legs (the only part that runs "
                     "collectives) may take before rank 0 prints the line without them and every rank leaves")
     ap.add_argument("--blocks", type=int, default=16, help="debug only: anything but 16 is not the headline config")
-    ap.add_argument("--overlap-stft", action="store_true", help="debug A/B (measured SLOWER, 1.46 vs 1.43 ms): the two target "
-                    "spectrograms on a second stream beside the encoder, joined before the loss kernel")
     ap.add_argument("--pad-rows", action="store_true", help="debug A/B (measured: no gain): spectrogram rows padded to 260 floats, 16-byte aligned")
     ap.add_argument("--no-q-log2e", action="store_true", help="debug A/B: attention with the explicit exponent scaling")
     ap.add_argument("--no-ln-fold", action="store_true", help="debug A/B: keep the LayerNorm affines out of the weights and "
@@ -144,9 +154,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and rank == 0:
-        print(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s): reporting the launcher's world size",
-              file=sys.stderr)
+    if args.gpus != world:
+        # a line that says n_gpus = N must come from N ranks on N devices: refuse to report anything else
+        raise SystemExit(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): launch "
+                         f"--nproc-per-node {args.gpus}, or let `python bench.py --gpus {args.gpus}` start its own ranks")
     backend = "gloo" if args.same_device else args.backend
     dev_index = 0 if args.same_device else local_rank
     dist = None
@@ -158,9 +169,17 @@ def main():
                              "(--same-device rehearses the rank logic on one GPU over gloo)")
         torch.cuda.set_device(dev_index)
         if backend == "nccl":
+            # which algorithm / protocol RCCL picks for the gradient buckets goes into the line (train_step.rccl): its
+            # INFO log of the INIT and TUNING subsystems, one file per rank, parsed by rank 0 after the training legs
+            if "NCCL_DEBUG" not in os.environ:
+                os.environ["NCCL_DEBUG"] = "INFO"
+                os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,TUNING")
+                os.environ.setdefault("NCCL_DEBUG_FILE", f"/tmp/css_bench_rccl_{os.getpid()}.log")
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group("gloo")
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"[bench] the process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", dev_index)
@@ -193,60 +212,64 @@ def main():
             torch.cuda.synchronize()
 
     graphed = False
-    if args.mode == "fwd":
-        model.eval()
 
-        side_stream = torch.cuda.Stream()
+    def capture(fn):
+        """fn -> a function that replays fn's launches as one captured HIP graph (the step is a fixed sequence of kernel
+        launches on one stream: only the host-side launch work disappears); None when capture is unsupported"""
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                fn()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            # thread_local: other threads of this process (e.g. the RCCL watchdog when world > 1) may touch the
+            # runtime while this thread captures
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                static_out = fn()
 
-        def step():
-            # the metric is forward + PIT loss: inference mode (under autograd the model would run its training
-            # forward, which keeps every operator's input for the backward pass).  --overlap-stft: the two TARGET
-            # spectrograms feed nothing but the loss kernel at the very end, so their STFT can run on a second stream
-            # beside the encoder - measured slower (the HBM-bound kernel disturbs the first chain launch more than
-            # the 14 us it takes off the critical path), kept as the experiment it was.
-            with torch.no_grad():
-                if not args.overlap_stft:
-                    mags = ops.stft(audio, ("mag",), pad_rows=PAD_ROWS)["mag"]  # [3,B,T,257]
-                    loss, perm, _ = model.forward_loss(mags[0], [mags[1], mags[2]])
-                    return loss
-                main = torch.cuda.current_stream()
-                side_stream.wait_stream(main)
-                box = {}
-                with torch.cuda.stream(side_stream):
-                    box["t"] = ops.stft(audio[1:3], ("mag",), pad_rows=PAD_ROWS)["mag"]   # [2,B,T,257]
-                mix_mag = ops.stft(audio[0], ("mag",), pad_rows=PAD_ROWS)["mag"]           # [B,T,257]
-                loss, perm, _ = model.forward_loss(mix_mag, lambda: [box["t"][0], box["t"][1]],
-                                                   before_head=lambda: main.wait_stream(side_stream))
+            def replay():
+                graph.replay()
+                return static_out
+            for _ in range(2):
+                replay()
+            return replay
+        except Exception as e:  # noqa: BLE001  (capture unsupported: keep the eager launches)
+            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
+            return None
+
+    def eval_step():
+        # inference mode: running-statistics BatchNorm, no dropout, nothing kept, head + mask application + PIT in one kernel
+        with torch.no_grad():
+            mags = ops.stft(audio, ("mag",), pad_rows=PAD_ROWS)["mag"]  # [3,B,T,257]
+            loss, perm, _ = model.forward_loss(mags[0], [mags[1], mags[2]])
             return loss
-        eager_step = step
+
+    tmodel = tobj = None
+    if args.mode == "fwd":
+        from css_amd.objectives import OBJECTIVES
+        model.eval()
+        # the headline: the TRAIN-mode forward + PIT on a second instance of the same weights
+        tmodel = MODELS["Conformer"](257, 257, 2, 1, conf)
+        tmodel.load_state_dict(sd)
+        tmodel = tmodel.to(dev).train()
+        tobj = OBJECTIVES["MSE"].build_objective({})
+
+        def train_fwd_step():
+            # what iteration_types.py:34-50 runs before loss.backward(): under autograd the model runs its training
+            # forward (dropout, batch-statistics BatchNorm, every operator's input kept, masks materialised)
+            with torch.no_grad():
+                mags = ops.stft(audio, ("mag",), pad_rows=PAD_ROWS)["mag"]
+            return tobj(tmodel, {"mix": mags[0], "source1": mags[1], "source2": mags[2]}, device=dev).detach()
+        step = train_fwd_step
         for _ in range(args.warmup):
             loss = step()
         torch.cuda.synchronize()  # (the first collective - the barrier in fence() - comes after the capture below)
-        # the step is a fixed sequence of ~55 kernel launches on one stream: capture it once, replay it per step
-        # (same kernels, same inputs resident in HBM; only the host-side launch work disappears)
         if not args.no_graph:
-            try:
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    step()
-                torch.cuda.current_stream().wait_stream(side)
-                torch.cuda.synchronize()
-                graph = torch.cuda.CUDAGraph()
-                # thread_local: other threads of this process (e.g. the RCCL watchdog when world > 1) may touch the
-                # runtime while this thread captures
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    static_loss = step()
-
-                def step():  # noqa: F811
-                    graph.replay()
-                    return static_loss
-                for _ in range(2):
-                    step()
-                graphed = True
-            except Exception as e:  # noqa: BLE001  (capture unsupported: keep the eager launches)
-                print(f"[bench] graph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
-                step = eager_step
+            rep = capture(train_fwd_step)
+            if rep is not None:
+                step, graphed = rep, True
     else:
         from css_amd.objectives import OBJECTIVES
         from css_amd.optim import FusedAdam
@@ -302,9 +325,25 @@ def main():
     loss_val = float(loss)
     progress(f"headline: {dt / args.steps * 1e3:.4f} ms/step")
 
-    # ---- fwd mode: the TRAINING legs of the same workload, same run (SURVEY 8d asks for train-mode throughput;
-    # configs[1]/[2] are training configurations).  With N > 1 the training steps are the path that communicates.
-    train_rec = train7_rec = train_fwd_rec = None
+    # ---- fwd mode: the other legs of the same workload, same run: the eval-mode forward + PIT (the parity-checked
+    # function; the headline of rounds 1-5) and the TRAINING steps (configs[1]/[2] are training configurations; with
+    # N > 1 they are the path that communicates).
+    train_rec = train7_rec = eval_rec = None
+    eval_loss = None
+    if args.mode == "fwd":
+        progress("leg: eval-mode forward + PIT")
+        for _ in range(2):
+            eval_step()
+        torch.cuda.synchronize()
+        erun = (capture(eval_step) if not args.no_graph else None) or eval_step
+        esteps = max(5, args.steps)
+        edt, eper_rank, eout = timed(erun, esteps)
+        eval_loss = float(eout)
+        eval_rec = {"metric": "STFT-frames/sec (EVAL-mode fwd+PIT: running-statistics BatchNorm, no dropout, mask head + mask "
+                              "application + PIT-MSE in one kernel, masks never written) Conformer-1ch",
+                    "ms_per_step": edt / esteps * 1e3, "value": world * B * T / (edt / esteps), "unit": "frames/s", "steps": esteps,
+                    "loss": eval_loss, "per_rank_ms_per_step": eper_rank, "launch": "hip-graph replay" if erun is not eval_step else "eager",
+                    "whole_step_frac": B * T * FLOP_PER_FRAME * args.blocks / 16 / (edt / esteps) / PEAK_BF16}
 
     def all_ranks_ok(ok):
         """A leg that failed on ONE rank must not leave the others waiting in a collective: every rank learns
@@ -315,44 +354,23 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         return bool(flag.item() > 0.5)
 
-    def train_leg(idim, features_fn, flop_per_frame, what, forward_only=False):
-        """One training-mode leg on its own model instance: GraphedTrainStep (forward, PIT, backward, all-reduce, clip +
-        Adam) or, forward_only, the train-mode forward + PIT alone (dropout, batch-statistics BatchNorm, everything the
-        backward needs kept - what iteration_types.py:34-50 runs before loss.backward()), captured and replayed."""
+    def train_leg(idim, features_fn, flop_per_frame, what):
+        """One training-step leg on its own model instance: GraphedTrainStep (train-mode forward, PIT, explicit backward,
+        gradient all-reduce, clip + Adam), captured and replayed."""
         from css_amd.objectives import OBJECTIVES
         from css_amd.optim import FusedAdam
         from css_amd.trainer import GraphedTrainStep
         err, run, tstep, toptim = None, None, None, None
         try:
-            tmodel = MODELS["Conformer"](idim, 257, 2, 1, conf)
-            tmodel.load_state_dict(sd if idim == 257 else syn.fill_state_dict(syn.conformer_shapes(idim=idim, num_blocks=args.blocks), 0))
-            tmodel = tmodel.to(dev).train()
-            tobj = OBJECTIVES["MSE"].build_objective({})
-            if forward_only:
-                static = features_fn()
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    for _ in range(2):
-                        tobj(tmodel, static, device=dev)
-                torch.cuda.current_stream().wait_stream(side)
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    static_loss = tobj(tmodel, static, device=dev).detach()
+            lmodel = MODELS["Conformer"](idim, 257, 2, 1, conf)
+            lmodel.load_state_dict(sd if idim == 257 else syn.fill_state_dict(syn.conformer_shapes(idim=idim, num_blocks=args.blocks), 0))
+            lmodel = lmodel.to(dev).train()
+            lobj = OBJECTIVES["MSE"].build_objective({})
+            toptim = FusedAdam(lmodel.parameters(), lr=1e-4, max_norm=5.0)
+            tstep = GraphedTrainStep(lmodel, lobj, toptim, features_fn(), max_norm=5.0, device=dev, buckets=args.buckets)
 
-                def run():
-                    feats = features_fn()
-                    for k in static:
-                        static[k].copy_(feats[k], non_blocking=True)
-                    g.replay()
-                    return static_loss
-            else:
-                toptim = FusedAdam(tmodel.parameters(), lr=1e-4, max_norm=5.0)
-                tstep = GraphedTrainStep(tmodel, tobj, toptim, features_fn(), max_norm=5.0, device=dev, buckets=args.buckets)
-
-                def run():
-                    return tstep(features_fn())[0]
+            def run():
+                return tstep(features_fn())[0]
         except Exception as e:  # noqa: BLE001  (the headline line must not die with an extra leg)
             err = f"{type(e).__name__}: {e}"
         if not all_ranks_ok(err is None):
@@ -363,170 +381,258 @@ def main():
         tdt, tper_rank, tout = timed(run, tsteps)
         rec = {"metric": what, "ms_per_step": tdt / tsteps * 1e3, "value": world * B * T / (tdt / tsteps), "unit": "frames/s",
                "steps": tsteps, "idim": idim, "loss": float(tout), "per_rank_ms_per_step": tper_rank,
-               "whole_step_frac": (1.0 if forward_only else 3.0) * B * T * flop_per_frame * args.blocks / 16 / (tdt / tsteps) / PEAK_BF16}
-        if not forward_only:
-            rec.update({"collective_backend": (backend if world > 1 else None),
-                        "collective": (("p2p-direct (css_amd.parallel.P2PAllReduce)" if args.p2p else "all-reduce of the backend")
-                                       if world > 1 else None),
-                        "world_size": dist.get_world_size() if world > 1 else 1,
-                        "allreduce_bytes_per_step": int(toptim.flat_grad.numel() * 4) if world > 1 else 0,
-                        "allreduce_schedule": ([hi - lo for lo, hi in tstep.plan] if world > 1 else None)})
+               "whole_step_frac": 3.0 * B * T * flop_per_frame * args.blocks / 16 / (tdt / tsteps) / PEAK_BF16}
+        rec.update({"collective_backend": (backend if world > 1 else None),
+                    "collective": (("p2p-direct (css_amd.parallel.P2PAllReduce)" if args.p2p else "all-reduce of the backend")
+                                   if world > 1 else None),
+                    "world_size": dist.get_world_size() if world > 1 else 1,
+                    "allreduce_bytes_per_step": int(toptim.flat_grad.numel() * 4) if world > 1 else 0,
+                    "allreduce_schedule": ([hi - lo for lo, hi in tstep.plan] if world > 1 else None)})
         return rec
 
     progress("in-step launch timeline")
-    # ---- rooflines from INSIDE the step: one un-captured eval step with the library's launch timeline on
-    roof = None
-    if rank == 0:
+    # ---- rooflines from INSIDE the step: un-captured passes of the step with the library's launch timeline on (HIP event
+    # pairs directly around every tagged launch, on the launch stream), for the headline's train-mode forward and for the
+    # eval forward.  Per-launch time = the bracket's elapsed time AS MEASURED: an upper bound of the kernel's duration,
+    # because the event pair itself costs the launch something - at most what an EMPTY bracket in the middle of the same
+    # passes takes (`empty_bracket_us`; `*_minus_empty_bracket` is the figure with all of it taken off, a lower bound).
+    # Nothing is fitted to the step any more (rounds 4-5 bounded the correction so that the launches summed to 94 / 99 %
+    # of the step, so the sum could never disagree with it): `kernel_sum_over_step` is a free cross-check again (measured:
+    # 1.03 raw, 0.86 with the whole empty bracket off).  Next to every HIP-event figure stands rocprofv3's average over the
+    # replayed launches of the same command (profiles/r06_fwd_replay_kernel_avg.csv, tools/profile_round.sh), with the
+    # source tree's hash at profile time: `source` says which is which.
+    roof = eval_kernels = None
+    TAGS = ("chain", "chain_edge", "attention", "outproj_conv", "embed", "head", "stft", "pit_sse", "pit_finalize", "mvn", "other")
+
+    def launch_timeline(run_pass):
+        """-> ({tag: (seconds per bracket, brackets per pass)}, seconds per empty bracket)"""
         import ctypes as C
         lib = C.CDLL(_lib.LIB_PATH)
         lib.csship_debug_timeline.argtypes = [C.c_int]
         lib.csship_debug_timeline_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
-        was_training = model.training
-        model.eval()
+        lib.csship_debug_timeline_calibrate.argtypes = [C.c_void_p, C.c_int]
         REPS = 3
-
-        calib = [False]
-
-        def probe():
-            with torch.no_grad():
-                mags = ops.stft(audio, ("mag",), pad_rows=PAD_ROWS)["mag"]
-                if calib[0]:   # empty brackets queued in the MIDDLE of a step (the stream is busy on both sides of them)
-                    lib.csship_debug_timeline_calibrate(C.c_void_p(torch.cuda.current_stream().cuda_stream), 4)
-                model.forward_loss(mags[0], [mags[1], mags[2]])
-        probe()
+        run_pass(None)
         torch.cuda.synchronize()
-        # two un-timed steps are queued first and the timeline is switched on while the GPU is still working on them:
+        # two un-timed passes are queued first and the timeline is switched on while the GPU is still working on them:
         # every timed launch then runs back to back behind earlier work, as in the replayed graph (a launch on an idle
         # GPU reads twice as long: cold caches, clock ramp)
-        probe()
-        probe()
-        lib.csship_debug_timeline_calibrate.argtypes = [C.c_void_p, C.c_int]
+        run_pass(None)
+        run_pass(None)
         lib.csship_debug_timeline(1)
-        calib[0] = True
-        for _ in range(REPS):
-            probe()
-        calib[0] = False
+        for _ in range(REPS):   # empty brackets queued in the MIDDLE of a pass (the stream is busy on both sides of them)
+            run_pass(lambda: lib.csship_debug_timeline_calibrate(C.c_void_p(torch.cuda.current_stream().cuda_stream), 4))
         torch.cuda.synchronize()
         ems, en = C.c_double(0), C.c_int(0)
         lib.csship_debug_timeline_read(11, C.byref(ems), C.byref(en))
-        bracket_measured = ems.value * 1e-3 / max(en.value, 1)     # seconds per empty bracket
-        # what a bracket adds to the launch it times is at most an empty bracket's own duration, and cannot be so large
-        # that the kernels would cover less than 99 % of the replayed step: in a rocprofv3 kernel trace of the replayed
-        # graph the kernels stand back to back (0.1-0.3 us between an end and the next begin, 54 launches; the drain of
-        # one kernel and the ramp of the next are INSIDE their durations, as rocprofv3 counts them), so the per-launch
-        # times must add up to the step - with the 94 % of rounds 3-4 they read ~5 % shorter than rocprofv3's
-        # (profiles/r05_fwd_replay_kernel_avg.csv)
-        raw_sum, n_l = 0.0, 0
-        for tag in range(10):
-            ms, n = C.c_double(0), C.c_int(0)
-            lib.csship_debug_timeline_read(tag, C.byref(ms), C.byref(n))
-            raw_sum, n_l = raw_sum + ms.value * 1e-3 / REPS, n_l + n.value // REPS
-        bracket = max(0.0, min(bracket_measured, (raw_sum - 0.99 * dt / args.steps) / max(n_l, 1))) if args.mode == "fwd" else bracket_measured
+        empty = ems.value * 1e-3 / max(en.value, 1)
         tl = {}
-        for tag, name in enumerate(("chain", "chain_edge", "attention", "outproj_conv", "embed", "head", "stft", "pit_sse",
-                                    "pit_finalize", "mvn")):
+        for tag, name in enumerate(TAGS):
             ms, n = C.c_double(0), C.c_int(0)
             lib.csship_debug_timeline_read(tag, C.byref(ms), C.byref(n))
-            # (seconds per launch with the bracket's own cost taken off, launches per step)
-            tl[name] = (max(ms.value * 1e-3 / max(n.value, 1) - bracket, 0.0) if n.value else 0.0, n.value // REPS)
+            tl[name] = (ms.value * 1e-3 / max(n.value, 1) if n.value else 0.0, n.value // REPS)
         lib.csship_debug_timeline(0)
-        if was_training:
-            model.train()
-        M = B * T
-        # HBM traffic / MFMA-busy come from a committed rocprofv3 PMC pass of THIS command (tools/profile_round.sh), not
-        # from this run: the record names the profile and is dropped when the kernel sources changed since it was taken
-        traffic, mfma_busy, pmc_src = {}, {}, None
+        return tl, empty
+
+    def csrc_hash():
         import hashlib
         hsh = hashlib.sha1()
         for fn in sorted(os.listdir(os.path.join(ROOT, "css_amd", "csrc"))):
             if fn.endswith((".hip", ".hpp", ".inc")) and fn != "fft_tables.inc":   # (the generated table is not a source)
                 hsh.update(open(os.path.join(ROOT, "css_amd", "csrc", fn), "rb").read())
-        csrc_sha = hsh.hexdigest()[:16]
-        for tp in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        return hsh.hexdigest()[:16]
+
+    def committed_profiles(csrc_sha):
+        """rocprofv3 figures of the same command, committed under profiles/: replay-only kernel averages (kernel-trace)
+        and the PMC passes (HBM traffic, MFMA busy).  Each carries the source hash it was taken at."""
+        import csv
+        prof = {"replay_avg_us": {}, "traffic": {}, "mfma_busy": {}, "replay_source": None, "pmc_source": None}
+        for tag in ("r06", "r05"):
+            path = os.path.join(ROOT, "profiles", f"{tag}_fwd_replay_kernel_avg.csv")
+            if not os.path.exists(path):
+                continue
+            meta_p = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
+            sha = json.load(open(meta_p)).get("_meta", {}).get("csrc_sha") if os.path.exists(meta_p) else None
+            for r in csv.DictReader(open(path)):
+                nm = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+                prof["replay_avg_us"][nm[:nm.find("(")] if "(" in nm else nm] = float(r["AverageNs"]) / 1e3
+            prof["replay_source"] = {"file": f"profiles/{tag}_fwd_replay_kernel_avg.csv", "csrc_sha_at_profile": sha,
+                                     "csrc_sha_now": csrc_sha, "current": sha == csrc_sha,
+                                     "what": "rocprofv3 --kernel-trace of this command, averages over the launches of the replayed graphs only"}
+            break
+        for tp in ("r06_pmc_traffic.json", "r05_pmc_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tp)
             if os.path.exists(tpath):
                 rec_all = json.load(open(tpath))
                 meta = rec_all.pop("_meta", {})
-                pmc_src = {"file": "profiles/" + tp, "csrc_sha_at_profile": meta.get("csrc_sha"), "csrc_sha_now": csrc_sha,
-                           "current": meta.get("csrc_sha") == csrc_sha}
-                if pmc_src["current"]:
+                prof["pmc_source"] = {"file": "profiles/" + tp, "csrc_sha_at_profile": meta.get("csrc_sha"), "csrc_sha_now": csrc_sha,
+                                      "current": meta.get("csrc_sha") == csrc_sha}
+                if prof["pmc_source"]["current"]:   # (traffic / busy of another build of the kernels would mislead)
                     for name, rec in rec_all.items():
                         if "hbm_bytes_per_launch" in rec:
-                            traffic.setdefault(name, rec["hbm_bytes_per_launch"])
+                            prof["traffic"].setdefault(name, rec["hbm_bytes_per_launch"])
                         if rec.get("mfma_busy_frac") is not None:
-                            mfma_busy.setdefault(name, rec["mfma_busy_frac"])
+                            prof["mfma_busy"].setdefault(name, rec["mfma_busy_frac"])
                 break
+        return prof
 
-        def busy_of(prefix):  # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch duration x 2.4 GHz), committed PMC pass
-            return next((v for name, v in mfma_busy.items() if name.startswith(prefix)), None)
+    def first(dct, prefix):
+        return next((v for name, v in dct.items() if name.startswith(prefix)), None)
 
-        def traffic_of(prefix):
-            for name, v in traffic.items():
-                if name.startswith(prefix):
-                    return v
-            return None
+    def kernel_rooflines(tl, prof, names, training, empty):
+        """the per-kernel roofline records of one forward form (names: kernel-name prefixes in the rocprofv3 files)"""
+        M = B * T
+        out = {}
+
+        def rp(key):   # rocprofv3's replay average for this kernel, microseconds (None without a committed profile)
+            return first(prof["replay_avg_us"], names.get(key, key + "_kernel"))
         dur, nl = tl["chain"]
         # two FeedForwards (4*M*256*1024 each) + the q/k/v projection (2*M*256*768): SURVEY.md 8(d) per-layer figures
         flops = 2 * 4.0 * M * 256 * 1024 + 2.0 * M * 256 * 768
-        step_flops = B * T * FLOP_PER_FRAME * args.blocks / 16
-        roof = {"bound": "mfma",
-                "kernel": f"chain_s_kernel<8,1,1,1,0,1,PIPE> (FFN_out+LN -> FFN_in -> LN+QKV, static pipelined form, M=12800; {nl} launches/step)",
-                "achieved": flops / dur / 1e12 if dur else None, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                "frac": flops / dur / PEAK_BF16 if dur else None, "traffic": traffic_of("chain_s_kernel<8, true, true, true, false, true"),
-                "mfma_busy_pmc": busy_of("chain_s_kernel<8, true, true, true, false, true"),
-                "avg_launch_us": dur * 1e6, "flops_per_launch": flops,
-                "timing": "HIP event pair around every in-step launch, minus the cost of an empty pair (at most the measured one, "
-                          "and such that the launches of a step add up to 99 % of the replayed step: rocprofv3 shows them back to back)",
-                "bracket_overhead_us": bracket * 1e6, "empty_bracket_us": bracket_measured * 1e6,
-                "pmc_source": pmc_src,
-                "whole_step_frac": (step_flops * (3.0 if args.mode == "train" else 1.0)) / (dt / args.steps) / PEAK_BF16}
+        r_us = rp("chain")
+        out["chain"] = {"bound": "mfma", "kernel": f"{names['chain']}> (FFN_out+LN -> FFN_in -> LN+QKV, M=12800; {nl} launches/step)",
+                        "achieved": flops / dur / 1e12 if dur else None, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                        "frac": flops / dur / PEAK_BF16 if dur else None, "avg_launch_us": dur * 1e6, "flops_per_launch": flops,
+                        "source": "hip-events (live: HIP event pair around every in-step launch, as measured - an upper bound of the kernel time)",
+                        "avg_launch_us_minus_empty_bracket": max(dur - empty, 0.0) * 1e6,
+                        "frac_minus_empty_bracket": flops / max(dur - empty, 1e-9) / PEAK_BF16 if dur else None,
+                        "avg_launch_us_rocprof": r_us, "frac_rocprof": flops / (r_us * 1e-6) / PEAK_BF16 if r_us else None,
+                        "traffic": first(prof["traffic"], names["chain"]), "mfma_busy_pmc": first(prof["mfma_busy"], names["chain"])}
         ad, an = tl["attention"]
         aflops = B * 4 * (2.0 * T * T * 64 * 3)  # QK^T + Q.PE^T + P.V over the full T x T, SURVEY 8(d)
-        roof["attention"] = {"bound": "mfma", "kernel": f"mha_fwd_kernel<8> ({an} launches/step)",
-                             "achieved": aflops / ad / 1e12 if ad else None, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                             "frac": aflops / ad / PEAK_BF16 if ad else None, "avg_launch_us": ad * 1e6,
-                             "traffic": traffic_of("mha_fwd_kernel"), "mfma_busy_pmc": busy_of("mha_fwd_kernel")}
+        r_us = rp("attention")
+        out["attention"] = {"bound": "mfma", "kernel": f"{names['attention']}> ({an} launches/step)",
+                            "achieved": aflops / ad / 1e12 if ad else None, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                            "frac": aflops / ad / PEAK_BF16 if ad else None, "avg_launch_us": ad * 1e6,
+                            "avg_launch_us_rocprof": r_us, "frac_rocprof": aflops / (r_us * 1e-6) / PEAK_BF16 if r_us else None,
+                            "traffic": first(prof["traffic"], names["attention"]), "mfma_busy_pmc": first(prof["mfma_busy"], names["attention"])}
         od, on = tl["outproj_conv"]
         oflops = 2.0 * M * 256 * 256 + 2.0 * M * 256 * 33  # output projection + depthwise taps (halo excluded)
-        roof["outproj_conv"] = {"bound": "mixed", "kernel": f"outproj_conv_kernel ({on} launches/step)",
-                                "achieved": oflops / od / 1e12 if od else None, "unit": "TFLOP/s", "avg_launch_us": od * 1e6,
-                                "hbm_algorithmic_GBps": (M * 256 * (2 + 4 + 4)) / od / 1e9 if od else None,
-                                "traffic": traffic_of("outproj_conv_kernel")}
+        r_us = rp("outproj_conv")
+        out["outproj_conv"] = {"bound": "mixed", "kernel": f"{names['outproj_conv']}> ({on} brackets/step" +
+                                                           (", each = the fused kernel + BatchNorm reduce + BatchNorm apply)" if training else ")"),
+                               "achieved": oflops / od / 1e12 if od else None, "unit": "TFLOP/s", "avg_launch_us": od * 1e6,
+                               "avg_launch_us_rocprof": r_us,
+                               "hbm_algorithmic_GBps": (M * 256 * (2 + 4 + 4)) / od / 1e9 if od else None,
+                               "traffic": first(prof["traffic"], names["outproj_conv"])}
         sdur, _ = tl["stft"]
         nfr = 3 * B * T
-        roof["stft"] = {"bound": "hbm", "achieved": nfr * 2052 / sdur / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
-                        "frac": nfr * 2052 / sdur / PEAK_HBM, "avg_launch_us": sdur * 1e6, "bytes_per_frame": 2052,
-                        "traffic": traffic_of("stft_kernel")}
-        # mask head + mask application + PIT-MSE.  Fused (csship_head_pit, the default loss-only path): the masks are never
+        r_us = rp("stft")
+        out["stft"] = {"bound": "hbm", "achieved": nfr * 2052 / sdur / 1e9 if sdur else None, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                       "frac": nfr * 2052 / sdur / PEAK_HBM if sdur else None, "avg_launch_us": sdur * 1e6, "bytes_per_frame": 2052,
+                       "avg_launch_us_rocprof": r_us, "frac_rocprof": nfr * 2052 / (r_us * 1e-6) / PEAK_HBM if r_us else None,
+                       "traffic": first(prof["traffic"], "stft_kernel")}
+        # mask head + mask application + PIT-MSE.  Fused (csship_head_pit, the eval loss-only path): the masks are never
         # written; algorithmic bytes per frame = the encoder row (256 f32) + f_orig and the two targets (3 x 257 f32) =
-        # 4 108 B (+ 0.26 MB of head weights per launch), timed as the fused kernel + the finalize launch.  Unfused
-        # (pit_sse + finalize on materialised masks): SURVEY 8(d)'s 6 168 B/frame minus the unused noise mask.
+        # 4 108 B (+ 0.26 MB of head weights per launch), timed as the fused kernel + the finalize launch.  Materialised
+        # masks (training: the backward reads them): mask head (a GEMM that writes 771 floats per frame) + pit_sse +
+        # finalize on SURVEY 8(d)'s 6 168 B/frame minus the unused noise mask.
         fused_pit = tl["pit_sse"][1] == 0
         if fused_pit:
             pdur = tl["head"][0] + tl["pit_finalize"][0]
             pit_bytes = 256 * 4 + 3 * 257 * 4
-            roof["pit"] = {"bound": "hbm", "kernel": "head_pit_split_kernel (mask head + mask application + pairwise SSE) + finalize",
-                           "achieved": B * T * pit_bytes / pdur / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
-                           "frac": B * T * pit_bytes / pdur / PEAK_HBM, "avg_launch_us": pdur * 1e6,
-                           "head_pit_us": tl["head"][0] * 1e6, "finalize_us": tl["pit_finalize"][0] * 1e6,
-                           "bytes_per_frame": pit_bytes, "traffic": traffic_of("head_pit_split_kernel") or traffic_of("head_pit_kernel")}
+            r_h, r_f = first(prof["replay_avg_us"], "head_pit_split_kernel"), first(prof["replay_avg_us"], "head_pit_finalize_kernel")
+            out["pit"] = {"bound": "hbm", "kernel": "head_pit_split_kernel (mask head + mask application + pairwise SSE) + finalize",
+                          "achieved": B * T * pit_bytes / pdur / 1e9 if pdur else None, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                          "frac": B * T * pit_bytes / pdur / PEAK_HBM if pdur else None, "avg_launch_us": pdur * 1e6,
+                          "head_pit_us": tl["head"][0] * 1e6, "finalize_us": tl["pit_finalize"][0] * 1e6,
+                          "avg_launch_us_rocprof": (r_h + r_f) if (r_h and r_f) else None,
+                          "frac_rocprof": B * T * pit_bytes / ((r_h + r_f) * 1e-6) / PEAK_HBM if (r_h and r_f) else None,
+                          "bytes_per_frame": pit_bytes, "traffic": first(prof["traffic"], "head_pit_split_kernel")}
         else:
             pdur = tl["pit_sse"][0] + tl["pit_finalize"][0]
             pit_bytes = 5 * 257 * 4
-            roof["pit"] = {"bound": "hbm", "achieved": B * T * pit_bytes / pdur / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
-                           "frac": B * T * pit_bytes / pdur / PEAK_HBM, "avg_launch_us": pdur * 1e6,
-                           "sse_us": tl["pit_sse"][0] * 1e6, "finalize_us": tl["pit_finalize"][0] * 1e6,
-                           "bytes_per_frame": pit_bytes, "traffic": traffic_of("pit_sse_kernel")}
-        roof["step_kernel_us"] = {k: round(v[0] * v[1] * 1e6, 1) for k, v in tl.items()}
-        roof["step_kernel_us_sum"] = round(sum(roof["step_kernel_us"].values()), 1)
+            r_s, r_f = first(prof["replay_avg_us"], "pit_sse_kernel"), first(prof["replay_avg_us"], "pit_finalize_kernel")
+            out["pit"] = {"bound": "hbm", "kernel": "pit_sse_kernel + pit_finalize_kernel on materialised masks (mask head: head_us)",
+                          "achieved": B * T * pit_bytes / pdur / 1e9 if pdur else None, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                          "frac": B * T * pit_bytes / pdur / PEAK_HBM if pdur else None, "avg_launch_us": pdur * 1e6,
+                          "sse_us": tl["pit_sse"][0] * 1e6, "finalize_us": tl["pit_finalize"][0] * 1e6, "head_us": tl["head"][0] * 1e6,
+                          "avg_launch_us_rocprof": (r_s + r_f) if (r_s and r_f) else None,
+                          "bytes_per_frame": pit_bytes, "traffic": first(prof["traffic"], "pit_sse_kernel")}
+        out["step_kernel_us"] = {k: round(v[0] * v[1] * 1e6, 1) for k, v in tl.items()}
+        out["step_kernel_us_sum"] = round(sum(out["step_kernel_us"].values()), 1)
+        out["step_kernel_us_sum_minus_empty_brackets"] = round(sum(max(v[0] - empty, 0.0) * v[1] for v in tl.values()) * 1e6, 1)
+        return out
 
-    def emit(tf_, tr_, t7_, cpu_, parity_):
+    if rank == 0 and args.mode == "fwd":
+        sha_now = csrc_hash()
+        prof = committed_profiles(sha_now)
+
+        def train_pass(mid):
+            with torch.no_grad():
+                mags = ops.stft(audio, ("mag",), pad_rows=PAD_ROWS)["mag"]
+            if mid is not None:
+                mid()
+            tobj(tmodel, {"mix": mags[0], "source1": mags[1], "source2": mags[2]}, device=dev)
+
+        def eval_pass(mid):
+            with torch.no_grad():
+                mags = ops.stft(audio, ("mag",), pad_rows=PAD_ROWS)["mag"]
+                if mid is not None:
+                    mid()
+                model.forward_loss(mags[0], [mags[1], mags[2]])
+        tl_t, empty_t = launch_timeline(train_pass)
+        tl_e, empty_e = launch_timeline(eval_pass)
+        step_flops = B * T * FLOP_PER_FRAME * args.blocks / 16
+        kr = kernel_rooflines(tl_t, prof, {"chain": "chain_s_kernel<8, true, true, true, true", "attention": "mha_fwd_kernel<8, true, false, false, false",
+                                           "outproj_conv": "outproj_conv_kernel<8, true"}, training=True, empty=empty_t)
+        roof = dict(kr.pop("chain"))
+        roof["kernel"] = "chain_s_kernel<8,A,B,QKV,TRAIN> " + roof["kernel"][roof["kernel"].find("("):]
+        roof.update(kr)
+        roof.update({"timing": "HIP event pair around every in-step launch of un-captured train-mode forward passes, as measured (upper "
+                               "bound; an empty pair costs empty_bracket_us); *_rocprof = rocprofv3 kernel-trace averages over the replayed "
+                               "launches of this command (committed under profiles/)",
+                     "empty_bracket_us": empty_t * 1e6, "rocprof_source": prof["replay_source"], "pmc_source": prof["pmc_source"],
+                     "step_us": dt / args.steps * 1e6, "kernel_sum_over_step": kr["step_kernel_us_sum"] / (dt / args.steps * 1e6),
+                     "whole_step_frac": step_flops / (dt / args.steps) / PEAK_BF16})
+        eval_kernels = kernel_rooflines(tl_e, prof, {"chain": "chain_s_kernel<8, true, true, true, false, true", "attention": "mha_fwd_kernel<8, false, false, false, true",
+                                                     "outproj_conv": "outproj_conv_kernel<8, false"}, training=False, empty=empty_e)
+        eval_kernels["empty_bracket_us"] = empty_e * 1e6
+        if eval_rec is not None:
+            eval_kernels["kernel_sum_over_step"] = eval_kernels["step_kernel_us_sum"] / (eval_rec["ms_per_step"] * 1e3)
+            eval_rec["roofline"] = eval_kernels
+    elif rank == 0:
+        roof = {"bound": "mfma", "whole_step_frac": 3.0 * B * T * FLOP_PER_FRAME * args.blocks / 16 / (dt / args.steps) / PEAK_BF16,
+                "note": "per-kernel records are part of the default (fwd) mode's line"}
+
+    def rccl_choice():
+        """What RCCL logged about the rings / trees it built and the algorithm + protocol it picked per collective size
+        (NCCL_DEBUG=INFO, subsystems INIT,GRAPH,TUNING, this rank's NCCL_DEBUG_FILE); None on one GPU or over gloo."""
+        path = os.environ.get("NCCL_DEBUG_FILE")
+        if world == 1 or backend != "nccl" or not path or not os.path.exists(path):
+            return None
+        import re
+        info = {"log": path, "version": None, "channels": None, "tuning": []}
+        seen = set()
+        try:
+            for ln in open(path, errors="replace"):
+                m = re.search(r"(RCCL|NCCL) version ([0-9][^\s]*)", ln)
+                if m and not info["version"]:
+                    info["version"] = m.group(0)
+                m = re.search(r"(\d+) coll channels", ln)
+                if m:
+                    info["channels"] = int(m.group(1))
+                m = re.search(r"(\d+) Bytes -> Algo (\d+) proto (\d+)", ln)
+                if m and m.groups() not in seen and len(seen) < 12:
+                    seen.add(m.groups())
+                    algo = {0: "Tree", 1: "Ring", 2: "CollNetDirect", 3: "CollNetChain", 4: "NVLS", 5: "NVLSTree"}.get(int(m.group(2)), m.group(2))
+                    proto = {0: "LL", 1: "LL128", 2: "Simple"}.get(int(m.group(3)), m.group(3))
+                    info["tuning"].append({"bytes": int(m.group(1)), "algo": algo, "proto": proto})
+        except OSError:
+            return None
+        return info
+
+    def emit(ev_, tr_, t7_, cpu_, parity_):
         """rank 0: the ONE JSON line"""
         frames = world * B * T * args.steps
-        mode_txt = ("eval forward (running-stat BN, no dropout)" if args.mode == "fwd" else
+        mode_txt = ("TRAIN-mode forward + PIT: dropout 0.1 at every site, batch-statistics BatchNorm, every operator's input "
+                    "kept for the backward, masks materialised (iteration_types.py:34-50 up to loss.backward()); no backward"
+                    if args.mode == "fwd" else
                     "training step: train-mode forward (batch-stat BN) + PIT + backward + gradient all-reduce + clip/Adam")
         metric = "STFT-frames/sec (fwd+PIT) Conformer-1ch" if args.mode == "fwd" else \
             "STFT-frames/sec (training step: fwd+PIT+bwd+all-reduce+Adam) Conformer-1ch"
+        if tr_ is not None and "error" not in tr_:
+            tr_["rccl"] = rccl_choice()
         line = {
             "metric": metric, "value": frames / dt, "unit": "frames/s",
             "n_gpus": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
@@ -535,14 +641,13 @@ def main():
             "config": {"workload": "Conformer-base 1ch 2-spk fwd+PIT, batch=32x400-frame chunks (configs[1])",
                        "global_batch": world * B, "frames_per_chunk": T, "num_blocks": args.blocks,
                        "mode": mode_txt, "parallelism": f"dp{world}",
-                       "launch": "hip-graph replay" if graphed else "eager",
-                       "streams": ("1" if (args.mode != "fwd" or not args.overlap_stft) else
-                                   "2: target-spectrogram STFT beside the encoder, joined before the loss kernel"),
+                       "launch": "hip-graph replay" if graphed else "eager", "streams": "1",
                        "collective_backend": (backend if world > 1 else None),
+                       "world_size_checked": "torch.distributed world size == --gpus (the run refuses to start otherwise)",
                        "ranks_launched_by": ("launcher" if "TORCHELASTIC_RUN_ID" in os.environ or "GROUP_RANK" in os.environ
                                              else ("bench.py --gpus" if world > 1 else None))},
             "per_rank_ms_per_step": per_rank_ms,
-            "roofline": roof, "cpu_baseline": cpu_, "train_fwd_pit": tf_, "train_step": tr_,
+            "roofline": roof, "cpu_baseline": cpu_, "eval_fwd_pit": ev_, "train_step": tr_,
             "train_step_7ch": t7_, "loss": loss_val, "loss_parity": parity_,
         }
         print(json.dumps(line))
@@ -562,7 +667,7 @@ def main():
             print(f"[bench] rank {rank}: the training legs did not finish within {args.leg_timeout} s; leaving without them", file=sys.stderr)
             if rank == 0:
                 stuck = {"error": f"did not finish within {args.leg_timeout} s (watchdog); the headline above is unaffected"}
-                emit(train_fwd_rec or stuck, train_rec or stuck, train7_rec or stuck, None, None)
+                emit(eval_rec, train_rec or stuck, train7_rec or stuck, None, None)
             sys.stderr.flush()
             os._exit(0)
         watchdog = threading.Timer(args.leg_timeout, bail)
@@ -573,10 +678,7 @@ def main():
             with torch.no_grad():
                 mags = ops.stft(audio, ("mag",), pad_rows=PAD_ROWS)["mag"]
             return {"mix": mags[0], "source1": mags[1], "source2": mags[2]}
-        progress("leg: train-mode forward + PIT")
-        train_fwd_rec = train_leg(257, tfeatures, FLOP_PER_FRAME, "STFT-frames/sec (TRAIN-mode fwd+PIT: dropout 0.1, batch-statistics "
-                                  "BatchNorm, activations kept for the backward; no backward) Conformer-1ch", forward_only=True)
-        progress(f"leg: training step ({train_fwd_rec.get('ms_per_step', train_fwd_rec)} ms train fwd+PIT)")
+        progress("leg: training step")
         train_rec = train_leg(257, tfeatures, FLOP_PER_FRAME, "STFT-frames/sec (training step: fwd+PIT+bwd+all-reduce+clip/Adam) Conformer-1ch")
         if train_rec and "error" not in train_rec:
             train_rec["mode"] = ("train-mode forward (dropout 0.1, batch-statistics BatchNorm) + PIT + explicit backward + "
@@ -659,16 +761,18 @@ def main():
                "single_thread": {"value": nb1 * T / runs1[1], "unit": "frames/s", "cores": 1,
                                  "sample": f"{nb1} of the {B} chunks x T={T} frames: 1 warm-up + 3 timed passes, median",
                                  "seconds_per_pass": [round(r, 3) for r in runs1]},
-               "loss": runs[-1][1], "gpu_loss": loss_val if args.mode == "fwd" else None}
+               "loss": runs[-1][1], "gpu_loss": eval_loss}
 
     parity = None
     if cpu is not None and cpu.get("gpu_loss") is not None:
         rel = abs(cpu["gpu_loss"] - cpu["loss"]) / abs(cpu["loss"])
         parity = {"gpu_loss": cpu["gpu_loss"], "cpu_loss": cpu["loss"], "rel_err": rel, "budget": LOSS_BUDGET,
                   "margin": 1.0 - rel / LOSS_BUDGET, "ok": bool(rel < LOSS_BUDGET),
-                  "what": "PIT-MSE loss of the timed batch: HIP path (bf16 operands) vs the fp32 oracle, SURVEY 8d budget"}
+                  "what": "PIT-MSE loss of the timed batch in EVAL mode (the deterministic function: `eval_fwd_pit`): HIP path (bf16 "
+                          "operands) vs the fp32 oracle, SURVEY 8d budget.  Source of the one-sided difference: DESIGN.md 5 / "
+                          "tests/test_gpu_configs.py::test_config2_eval_16_blocks_full_size_vs_oracle"}
     if rank == 0:
-        emit(train_fwd_rec, train_rec, train7_rec, cpu, parity)
+        emit(eval_rec, train_rec, train7_rec, cpu, parity)
         if parity is not None and not parity["ok"]:
             print(f"[bench] PARITY FAILURE: loss {parity['gpu_loss']:.6f} vs oracle {parity['cpu_loss']:.6f}: relative error "
                   f"{parity['rel_err']:.2e} >= {LOSS_BUDGET:.0e}", file=sys.stderr)

@@ -651,6 +651,7 @@ extern "C" int csship_mha_relpos_train_drop(const uint16_t* qkv, const uint16_t*
   if (!qkv || !pe_packed || !out || !lse) return CSSHIP_ENULL;
   if (B <= 0 || T <= 0 || H <= 0 || q_max < q_min || B > 65535 || H > 65535) return CSSHIP_EBADSHAPE;
   if (!aligned16(qkv) || !aligned16(pe_packed) || !aligned8(out)) return CSSHIP_EALIGN;
+  TimelineScope tl(CSSHIP_TL_ATTN, as_stream(stream));
   return launch_mha_fwd(qkv, pe_packed, q_min, q_max, out, lse, B, T, H, nullptr, as_stream(stream), drop);
 }
 

@@ -181,14 +181,23 @@ enum {
   CSSHIP_TL_NTAGS = 12
 };
 extern bool g_csship_timeline_on;
+extern int g_csship_timeline_depth;   // only the OUTERMOST scope brackets (entry points that call entry points)
 void csship_timeline_push(int tag, hipStream_t s, bool stop);
 struct TimelineScope {
   int tag;
   hipStream_t s;
-  TimelineScope(int tag_, hipStream_t s_) : tag(tag_), s(s_) {
-    if (g_csship_timeline_on) csship_timeline_push(tag, s, false);
+  bool counted, open;
+  TimelineScope(int tag_, hipStream_t s_) : tag(tag_), s(s_), counted(false), open(false) {
+    if (g_csship_timeline_on) {
+      counted = true;
+      if (g_csship_timeline_depth++ == 0) {
+        open = true;
+        csship_timeline_push(tag, s, false);
+      }
+    }
   }
   ~TimelineScope() {
-    if (g_csship_timeline_on) csship_timeline_push(tag, s, true);
+    if (counted) --g_csship_timeline_depth;
+    if (open) csship_timeline_push(tag, s, true);
   }
 };

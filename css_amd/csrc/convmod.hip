@@ -768,6 +768,7 @@ extern "C" int csship_outproj_conv_train(const uint16_t* attn_out, const uint16_
   float* partial = zbuf + n;
   float* scale_shift = partial + nblk32 * 2 * D + 4 * D;
   int nblk = 0;
+  TimelineScope tl(CSSHIP_TL_OUTPROJ_CONV, s);   // three launches: the fused kernel, BatchNorm reduce, BatchNorm apply
   const int rc = launch_outproj_conv_train(attn_out, wo_packed, bo, x, x2_out, *w, B, T, cfg(drop_proj), zbuf, partial, &nblk, s);
   if (rc) return rc;
   if ((size_t)nblk > nblk32) return CSSHIP_EWORKSPACE;   // (50-frame tiles: never more blocks than the 32-frame tiling)

@@ -134,6 +134,7 @@ unsigned long long* g_csship_stamps = nullptr;
 
 // ---- per-launch timeline (see common.hpp)
 bool g_csship_timeline_on = false;
+int g_csship_timeline_depth = 0;
 namespace {
 struct TlRec { int tag; hipEvent_t e0, e1; bool closed; };
 std::vector<TlRec> g_tl;
@@ -157,6 +158,7 @@ void csship_timeline_push(int tag, hipStream_t s, bool stop) {
 extern "C" void csship_debug_timeline(int enable) {
   for (auto& r : g_tl) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   g_tl.clear();
+  g_csship_timeline_depth = 0;
   g_csship_timeline_on = enable != 0;
 }
 // `pairs` empty brackets on `stream` (tag CSSHIP_TL_EMPTY): what a bracket itself adds to the launch it times.

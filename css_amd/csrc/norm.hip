@@ -190,6 +190,7 @@ extern "C" int csship_mvn_stats(const float* x, int64_t B, int64_t T, int64_t F,
   if (!x || !mean || !rinv) return CSSHIP_ENULL;
   if (B <= 0 || T <= 0 || F <= 0 || ldx < F || B > 65535) return CSSHIP_EBADSHAPE;
   dim3 grid((unsigned)((F + 63) / 64), (unsigned)B);
+  TimelineScope tl(CSSHIP_TL_MVN, as_stream(stream));
   hipLaunchKernelGGL(mvn_stats_kernel, grid, dim3(MV_W * 64), 0, as_stream(stream), x, (int)T, (int)F, ldx, clamp_min, eps,
                      mean, rinv);
   CSSHIP_CHECK_LAUNCH();

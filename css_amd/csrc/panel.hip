@@ -2448,6 +2448,7 @@ extern "C" int csship_ffn_fused_train(const float* x, float* out, float* pre_ln_
             reinterpret_cast<const bf16x8*>(w2_packed), b2, final_ln_g, final_ln_b, M, d_ffn, alpha, g_csship_stamps,
             drop_hidden ? *drop_hidden : none, drop_out ? *drop_out : none, pre_ln_out};
   dim3 grid((M + BM - 1) / BM), block(NWAVES * 64);
+  TimelineScope tl(CSSHIP_TL_CHAIN_EDGE, as_stream(stream));   // (the last block's FeedForward of the training forward)
   if (final_ln_g) hipLaunchKernelGGL((ffn_kernel<NWAVES, true>), grid, block, 0, as_stream(stream), a);
   else hipLaunchKernelGGL((ffn_kernel<NWAVES, false>), grid, block, 0, as_stream(stream), a);
   CSSHIP_CHECK_LAUNCH();
@@ -2827,6 +2828,8 @@ extern "C" int csship_panel_linear_drop(const void* a, int32_t prologue, const f
              dropping ? drop->seed : nullptr, dropping ? drop->stream : 0u, dropping ? drop->p : 0.f};
   hipStream_t s = as_stream(stream);
   const int key = prologue * 16 + epilogue;
+  // (bench.py's train-mode timeline: the mask head is the one row-panel Linear whose rows are not a multiple of 256 wide)
+  TimelineScope tl((N % DM) != 0 ? CSSHIP_TL_HEAD : CSSHIP_TL_OTHER, s);
   static const bool use_static = [] { const char* e = getenv("CSSHIP_CHAIN_STATIC"); return e == nullptr || atoi(e) != 0; }();
   if (use_static && key == CSSHIP_PRO_BF16 * 16 + CSSHIP_EPI_OUT_BF16 && !bias && N == DM && (M % BM) == 0 && (ldo & 7) == 0) {
     hipLaunchKernelGGL((panel_dx_kernel<NWAVES>), dim3(M / BM), dim3(NWAVES * 64), 0, s,
@@ -2873,6 +2876,7 @@ extern "C" int csship_encoder_chain_train(const float* x, float* x_out, const cs
   if (!train) return CSSHIP_ENULL;
   if ((int64_t)((M + BM - 1) / BM * BM) * d_ffn > 0xffffffffLL) return CSSHIP_EBADSHAPE;  // 32-bit dropout element indices
   if ((train->pre_ln_out && !aligned16(train->pre_ln_out)) || (train->ln_out && !aligned16(train->ln_out))) return CSSHIP_EALIGN;
+  TimelineScope tl(ffn_a ? CSSHIP_TL_CHAIN : CSSHIP_TL_CHAIN_EDGE, as_stream(stream));   // (bench.py's train-mode timeline)
   return encoder_chain_impl(x, x_out, nullptr, nullptr, 0, ffn_a, final_ln_g, final_ln_b, ffn_b, qkv_ln_g, qkv_ln_b, wqkv_packed,
                             bqkv, qkv_out, M, d_model, d_ffn, n_qkv, 0, stream, train);
 }

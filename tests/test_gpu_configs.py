@@ -61,6 +61,46 @@ def test_config2_training_mode_full_batch_vs_oracle():
     assert mse < 1e-4
 
 
+def test_config2_eval_16_blocks_full_size_vs_oracle():
+    """configs[1] as bench.py runs it - the seed-0 16-block Conformer-base, rank 0's mixtures, 32 x 400 frames, eval mode,
+    features from raw audio, the fused head + PIT kernel - against the oracle at FULL size.
+    The bench line's loss has read +7.8e-4 above the fp32 oracle for three rounds; tools/loss_bias.py
+    (profiles/r06_loss_bias.txt) names the source: bf16 OPERAND rounding, a fixed perturbation of the model that does
+    not average out over the 12 800 frames.  The oracle evaluated with the same operand roundings (oracle/emulate.py)
+    reads +4.5e-4 itself, and the HIP path that rounds exactly those operands (no LayerNorm folding) agrees with it to
+    3e-6; the default path folds the LayerNorm affines into the weights BEFORE rounding them (another rounding of the
+    same weights, of the same size): +3.3e-4 from the emulation.  Asserted here: mask MSE of chunks 0-1 and the loss
+    against fp32 (SURVEY 8d budgets), and the two internal bars against the bf16-operand oracle."""
+    from css_amd import ops
+    from oracle import emulate
+    m, sd = _conformer(16, 0)
+    m.eval()
+    mix, src = syn.synthetic_sources(B, N_SAMPLES, seed=0)
+    audio = torch.stack([mix, src[0], src[1]], 0).to(DEV)
+    with torch.no_grad():
+        mags = ops.stft(audio, ("mag",))["mag"]
+        loss = float(m.forward_loss(mags[0], [mags[1], mags[2]])[0])
+        masks = m.forward_masks(mags[0][:2].contiguous()).cpu()
+        m.no_ln_fold = True
+        loss_nf = float(m.forward_loss(mags[0], [mags[1], mags[2]])[0])
+    torch.set_num_threads(16)
+    o_mag = [oracle.feature.stft(x)[0].transpose(1, 2).contiguous() for x in (mix, src[0], src[1])]
+    with torch.no_grad():
+        y, o_masks = oracle.conformer.forward(o_mag[0], sd, num_blocks=16)
+        l32 = float(oracle.pit.mse_objective(y, o_mag[1], o_mag[2]))
+        with emulate.bf16_operands():
+            y, _ = oracle.conformer.forward(o_mag[0], sd, num_blocks=16)
+        l16 = float(oracle.pit.mse_objective(y, o_mag[1], o_mag[2]))
+    mse = float(((masks - torch.cat(o_masks, -1)[:2]) ** 2).mean())
+    print(f"[parity] config 2 eval, 16 blocks at 32 x 400: mask MSE of chunks 0-1 vs fp32 oracle {mse:.3e}; loss {loss:.7f} "
+          f"(no LayerNorm folding {loss_nf:.7f}) vs fp32 oracle {l32:.7f} (rel {(loss - l32) / l32:+.2e}) and vs the "
+          f"bf16-operand oracle {l16:.7f} (rel {(loss - l16) / l16:+.2e}; unfolded {(loss_nf - l16) / l16:+.2e})")
+    assert mse < 1e-4
+    assert abs(loss - l32) / l32 < 1e-3                 # SURVEY 8d: bf16 operands vs the fp32 reference
+    assert abs(loss_nf - l16) / l16 < 5e-5              # same operand roundings: summation order is all that is left
+    assert abs(loss - l16) / l16 < 6e-4                 # the folded weights: a second rounding of the same size
+
+
 def test_config2_training_step_16_blocks_full_size_is_deterministic():
     """The full Conformer-base training step at 32 x 400: two identical steps from identical state give bit-identical
     loss and gradients (no atomics, fixed reduction orders), everything finite."""
@@ -353,6 +393,55 @@ def test_config5_conformer_large_full_size():
     mse = float(((masks[:1].cpu() - torch.cat(o_masks, -1)) ** 2).mean())
     print(f"[parity] config 5, Conformer-large 18 blocks at 32 x 400: mask MSE of chunk 0 vs oracle {mse:.3e}")
     assert mse < 1e-4
+
+
+def test_config5_fp8_ffn_full_size():
+    """configs[4] in the arithmetic it names, at its FULL size: Conformer-large (d 512 / 8 heads / ffn 2048 / 18 blocks),
+    3 speakers + noise, 32 x 400 frames, every FeedForward on block-scaled fp8 operands (model.fp8_ffn = True ->
+    csship_ffn_mx, v_mfma_scale_f32_16x16x128_f8f6f4); attention stays bf16 (priced, declined).
+    All 32 chunks: bitwise run-to-run determinism, finite, valid K = 3 permutations, batch independence of chunk 0.
+    Chunk 0 against (a) the oracle that emulates the same operand formats (oracle/mxfp8.py) and (b) the fp32 oracle.
+    On these UNTRAINED seeded weights the format itself is far outside the 1e-4 budget (why the switch is opt-in; the
+    trained-checkpoint statement is test_fp8_ffn_meets_the_mask_budget_on_a_trained_checkpoint), and through 18 blocks
+    two evaluations that differ by bf16 rounding elsewhere take different e4m3 rounding decisions, so (a) is bounded
+    relative to (b): the HIP path must be closer to the emulation than the emulation is to fp32."""
+    from css_amd import ops
+    m, sd = _conformer(18, 85, num_spk=3, d=512, h=8, ff=2048)
+    m.eval()
+    m.fp8_ffn = True
+    f = rnd((B, T, 257), 86).abs().to(DEV)
+    tg = [(rnd((B, T, 257), 87 + k).abs() * 0.5).to(DEV) for k in range(3)]
+    with torch.no_grad():
+        masks = m.forward_masks(f)
+        masks_again = m.forward_masks(f)
+        loss, perm, _, _ = ops.pit_mse(masks, f, tg)
+        alone = m.forward_masks(f[:1].contiguous())
+        m.fp8_ffn = False
+        masks16 = m.forward_masks(f[:1].contiguous())
+        loss16 = ops.pit_mse(m.forward_masks(f), f, tg)[0]
+    assert masks.shape == (B, T, 4 * 257) and torch.equal(masks, masks_again)
+    assert bool(torch.isfinite(masks).all()) and bool(torch.isfinite(loss))
+    assert all(sorted(p) == [0, 1, 2] for p in perm.cpu().tolist())
+    assert float(((masks[:1] - alone) ** 2).mean()) < 1e-5      # the hidden-chunk order rotates per panel: not bitwise
+    torch.set_num_threads(16)
+    kw = dict(num_spk=3, n_head=8, num_blocks=18)
+    with torch.no_grad():
+        with oracle.mxfp8.ffn_emulation("bf16"):
+            _, o_emul = oracle.conformer.forward(f[:1].cpu(), sd, **kw)
+        _, o_fp32 = oracle.conformer.forward(f[:1].cpu(), sd, **kw)
+    o_emul, o_fp32 = torch.cat(o_emul, -1), torch.cat(o_fp32, -1)
+    tight = float(((masks[:1].cpu() - o_emul) ** 2).mean())
+    fmt = float(((masks[:1].cpu() - o_fp32) ** 2).mean())
+    emul = float(((o_emul - o_fp32) ** 2).mean())
+    bf16 = float(((masks16.cpu() - o_fp32) ** 2).mean())
+    rel = abs(float(loss) - float(loss16)) / float(loss16)
+    print(f"[parity] config 5 in fp8 (FeedForwards MXFP8, 18 blocks, 32 x 400), chunk 0: vs MXFP8-emulating oracle {tight:.2e}; "
+          f"vs fp32 oracle {fmt:.2e} (emulation vs fp32 {emul:.2e}; bf16 path vs fp32 {bf16:.2e}); PIT loss {float(loss):.5f} "
+          f"vs bf16 path {float(loss16):.5f} (rel {rel:.2e})")
+    assert bf16 < 1e-4
+    assert tight < 0.6 * emul and tight < 0.6 * fmt   # closer to its own emulation than the format is to fp32
+    assert fmt > 3 * bf16 and fmt < 5e-2              # the switch changes the arithmetic, and stays a sane approximation
+    assert rel < 5e-2
 
 
 def _large(blocks, seed):

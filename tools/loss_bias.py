@@ -21,12 +21,14 @@ from css_amd.utils import synthetic as syn
 ap = argparse.ArgumentParser()
 ap.add_argument("--chunks", type=int, default=32)
 ap.add_argument("--blocks", type=int, default=16)
+ap.add_argument("--seed", type=int, default=0, help="weight seed (0 = bench.py's model); the mixtures stay rank 0's")
+ap.add_argument("--quick", action="store_true", help="only: default, no_ln_fold, fp32 oracle, bf16-operand oracle")
 a = ap.parse_args()
 B, T = a.chunks, 400
 N = 512 + 256 * (T - 1)
 conf = dict(attention_dim=256, attention_heads=4, linear_units=1024, num_blocks=a.blocks, kernel_size=33, dropout_rate=0.1,
             relative_pos_emb=True)
-sd = syn.fill_state_dict(syn.conformer_shapes(num_blocks=a.blocks), 0)
+sd = syn.fill_state_dict(syn.conformer_shapes(num_blocks=a.blocks), a.seed)
 mix, src = syn.synthetic_sources(32, N, seed=0)
 mix, src = mix[:B], [s[:B] for s in src]
 audio = torch.stack([mix, src[0], src[1]], 0).cuda()
@@ -49,10 +51,12 @@ def hip(name, **attrs):
 
 
 hip("default (fused head+PIT)")
-hip("materialised masks + pit_sse", no_head_pit=True)
-hip("no_q_log2e", no_q_log2e=True)
+if not a.quick:
+    hip("materialised masks + pit_sse", no_head_pit=True)
+    hip("no_q_log2e", no_q_log2e=True)
 hip("no_ln_fold", no_ln_fold=True)
-hip("any-width kernels", force_generic=True)
+if not a.quick:
+    hip("any-width kernels", force_generic=True)
 
 torch.set_num_threads(min(16, os.cpu_count() or 1))
 o_mag = [oracle.feature.stft(x)[0].transpose(1, 2).contiguous() for x in (mix, src[0], src[1])]
@@ -73,8 +77,9 @@ def ora(name, sd_, ctx=None):
 
 ora("fp32", sd)
 ora("bf16 operands (emulate)", sd, emulate.bf16_operands)
-sd_w = {k: (v.to(torch.bfloat16).float() if (k.endswith(".weight") and v.dim() == 2 and "pe_k" not in k) else v) for k, v in sd.items()}
-ora("fp32 math, bf16 Linear weights", sd_w)
+if not a.quick:
+    sd_w = {k: (v.to(torch.bfloat16).float() if (k.endswith(".weight") and v.dim() == 2 and "pe_k" not in k) else v) for k, v in sd.items()}
+    ora("fp32 math, bf16 Linear weights", sd_w)
 
 ref_loss, ref_masks = out["fp32"]
 rows = []
@@ -84,4 +89,4 @@ for k, (l, mk) in out.items():
     print(f"{k:34s} loss {l:.7f}  rel {(l - ref_loss) / ref_loss:+.3e}  mask MSE (chunks 0-1) {mse:.3e}")
 em_loss = out["bf16 operands (emulate)"][0]
 print(f"HIP default vs bf16-operand oracle: rel {(out['default (fused head+PIT)'][0] - em_loss) / em_loss:+.3e}")
-print(json.dumps({"chunks": B, "blocks": a.blocks, "rows": rows}))
+print(json.dumps({"chunks": B, "blocks": a.blocks, "seed": a.seed, "rows": rows}))

@@ -5,7 +5,7 @@
 #      MFMA busy, LDS
 # Summaries land in gpurun_out/<tag>_*: copy the ones to be judged into profiles/.
 set -u
-tag=${1:-rXX}
+tag=${1:-r06}
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train-step"
 for mode in fwd train; do
