@@ -88,6 +88,7 @@ def parse_args():
     ap.add_argument("--leg-timeout", type=float, default=300.0, help="N > 1: seconds the training legs (the only part that runs "
                     "collectives) may take before rank 0 prints the line without them and every rank leaves")
     ap.add_argument("--blocks", type=int, default=16, help="debug only: anything but 16 is not the headline config")
+    ap.add_argument("--dropout", type=float, default=0.1, help="debug only (what do the dropout masks cost?): anything but 0.1 is not the headline config")
     ap.add_argument("--pad-rows", action="store_true", help="debug A/B (measured: no gain): spectrogram rows padded to 260 floats, 16-byte aligned")
     ap.add_argument("--no-q-log2e", action="store_true", help="debug A/B: attention with the explicit exponent scaling")
     ap.add_argument("--no-ln-fold", action="store_true", help="debug A/B: keep the LayerNorm affines out of the weights and "
@@ -190,7 +191,7 @@ def main():
     from css_amd.utils import synthetic as syn
 
     conf = dict(attention_dim=256, attention_heads=4, linear_units=1024, num_blocks=args.blocks, kernel_size=33,
-                dropout_rate=0.1, relative_pos_emb=True)
+                dropout_rate=args.dropout, relative_pos_emb=True)
     model = MODELS["Conformer"](257, 257, 2, 1, conf)
     sd = syn.fill_state_dict(syn.conformer_shapes(num_blocks=args.blocks), 0)
     model.load_state_dict(sd)

@@ -117,8 +117,13 @@ DEV void stamp(unsigned long long* st, int slot) {
 }
 
 // ---- dropout (training mode only; css/models/conformer.py:127,249,254,302,317,319, css/models/blstm.py:147,158).
-// Counter-based: element e (row-major index in its tensor) of dropout site `stream` is kept iff the 16-bit field
-// (e & 1) of hash32(key + (e >> 1)) is >= thresh, key = hash32(seed ^ stream * 0x9E3779B9), thresh = round(p * 65536).
+// Counter-based: the four elements 4q .. 4q+3 (row-major indices in their tensor) of dropout site `stream` share ONE
+// hash evaluation: w0 = hash32(key + q), w1 = hash_derive(w0); element 4q + f is kept iff field f of (w0 lo16, w0 hi16,
+// w1 lo16, w1 hi16) is >= thresh; key = hash32(seed ^ stream * 0x9E3779B9), thresh = round(p * 65536).
+// (Rounds 2-5 spent one hash32 on every PAIR of elements: the two quarter-rate 32-bit multiplies of the mixer per pair
+// were 0.25 ms of the 2.2 ms train-mode forward, bench.py --dropout 0; the second word now costs one full-rate 24-bit
+// multiply.  tools/dropout_stats.py: keep rate, serial / row / column / cross-stream / intra-group statistics of the
+// new masks are those of the old ones.)
 // Forward and backward regenerate the same mask from (seed, stream, e); nothing is stored.  The seed lives in DEVICE
 // memory so that a captured training step can be replayed with a fresh mask (the host bumps it before each replay).
 // oracle/dropout.py is the numpy statement of the same function (the oracle applies identical masks in the tests).
@@ -133,25 +138,48 @@ DEV unsigned hash32(unsigned x) {  // "lowbias32" avalanche mixer
 struct Drop {  // device-side view of csship_dropout_cfg; thresh == 0 means "no dropout"
   unsigned key, thresh;
   float scale;
+  unsigned tb;   // (thresh ^ 0x8000) in both halves: the threshold of the packed signed comparison (drop_mask_bf4)
 };
 DEV Drop drop_make(const unsigned* seed, unsigned stream, float p) {
-  Drop d{0u, 0u, 1.f};
+  Drop d{0u, 0u, 1.f, 0x80008000u};
   if (seed != nullptr && p > 0.f) {
     d.key = hash32(*seed ^ (stream * 0x9E3779B9u));
     d.thresh = (unsigned)(p * 65536.f + 0.5f);
     d.scale = 65536.f / (float)(65536u - d.thresh);  // 1 / (1 - p_effective)
+    d.tb = ((d.thresh ^ 0x8000u) & 0xffffu) * 0x10001u;
   }
   return d;
 }
-// keep-bits of elements e0 .. e0+3 (e0 even): bit j set = element e0 + j survives
+// second word of a four-element group: one 24-bit multiply (v_mul_u32_u24, full rate) + shift-add + xorshift of the
+// first - not a hash on its own, but its two fields are statistically independent of w0's (tools/dropout_stats.py)
+DEV unsigned hash_derive(unsigned w) {
+  unsigned v = __umul24(w ^ 0x5bd1e995u, 0x85ebcau) + (w >> 11);
+  return v ^ (v >> 14);
+}
+// keep-bits of elements e0 .. e0+3 (e0 a multiple of 4): bit j set = element e0 + j survives
 DEV unsigned drop_keep4(const Drop& d, unsigned e0) {
-  const unsigned h0 = hash32(d.key + (e0 >> 1)), h1 = hash32(d.key + (e0 >> 1) + 1u);
-  return ((h0 & 0xffffu) >= d.thresh ? 1u : 0u) | ((h0 >> 16) >= d.thresh ? 2u : 0u) |
-         ((h1 & 0xffffu) >= d.thresh ? 4u : 0u) | ((h1 >> 16) >= d.thresh ? 8u : 0u);
+  const unsigned w0 = hash32(d.key + (e0 >> 2)), w1 = hash_derive(w0);
+  return ((w0 & 0xffffu) >= d.thresh ? 1u : 0u) | ((w0 >> 16) >= d.thresh ? 2u : 0u) |
+         ((w1 & 0xffffu) >= d.thresh ? 4u : 0u) | ((w1 >> 16) >= d.thresh ? 8u : 0u);
+}
+// the same four decisions as AND-masks for two packed bf16 pairs (0xffff over a kept half): field >= thresh as a packed
+// SIGNED comparison of the biased values - v_xor, v_pk_sub_i16 clamp (saturating: the sign of the difference is exact),
+// v_pk_ashrrev_i16 15, and the and-not is the caller's one v_bitop3: 4 instructions per pair where a compare + select +
+// re-pack per bf16 element took ~14 (the attention's probability dropout: 440 of its 1 335 instructions per key tile)
+DEV unsigned drop_keep_halves(unsigned w, unsigned tb) {
+  const s16x2 f = __builtin_bit_cast(s16x2, w ^ 0x80008000u);
+  const s16x2 d = __builtin_elementwise_sub_sat(f, __builtin_bit_cast(s16x2, tb));
+  const s16x2 neg = d >> (s16x2){15, 15};
+  return ~__builtin_bit_cast(unsigned, neg);
+}
+DEV uint2 drop_mask_bf4(const Drop& d, unsigned e0) {   // e0 a multiple of 4; .x covers elements e0, e0 + 1, .y e0 + 2, e0 + 3
+  const unsigned w0 = hash32(d.key + (e0 >> 2)), w1 = hash_derive(w0);
+  return make_uint2(drop_keep_halves(w0, d.tb), drop_keep_halves(w1, d.tb));
 }
 DEV bool drop_keep1(const Drop& d, unsigned e) {
-  const unsigned h = hash32(d.key + (e >> 1));
-  return ((e & 1u) ? (h >> 16) : (h & 0xffffu)) >= d.thresh;
+  const unsigned w0 = hash32(d.key + (e >> 2));
+  const unsigned w = (e & 2u) ? hash_derive(w0) : w0;
+  return ((e & 1u) ? (w >> 16) : (w & 0xffffu)) >= d.thresh;
 }
 DEV float4 drop_apply4(const Drop& d, unsigned e0, float4 v) {  // v * keep / (1 - p)
   if (d.thresh == 0u) return v;

@@ -50,10 +50,12 @@ int csship_attn_pos_bwd_max_t(void);
  * The reference applies nn.Dropout(p) at: the embedding (css/models/conformer.py:127, css/models/blstm.py:147), the
  * attention probabilities and the attention output (conformer.py:249,254), the end of the ConvModule (:302), both
  * FeedForward linears (:317,319) and every BLSTM layer (blstm.py:158).  Here a mask is a pure function of
- * (seed, stream, element index): element e (row-major index in the dropped tensor) survives iff the 16-bit field
- * (e & 1) of hash32(hash32(seed ^ stream*0x9E3779B9) + (e >> 1)) is >= round(p*65536); survivors are scaled by
- * 65536 / (65536 - round(p*65536)).  hash32 is the "lowbias32" mixer (css_amd/csrc/common.hpp; oracle/dropout.py is
- * its numpy twin).  `seed` points to ONE uint32 in DEVICE memory (read by the kernels, so a captured step can be
+ * (seed, stream, element index): elements 4q .. 4q+3 (row-major indices in the dropped tensor) share the words
+ * w0 = hash32(hash32(seed ^ stream*0x9E3779B9) + q) and w1 = hash_derive(w0); element 4q + f survives iff the 16-bit
+ * field f of (w0 low, w0 high, w1 low, w1 high) is >= round(p*65536); survivors are scaled by
+ * 65536 / (65536 - round(p*65536)).  hash32 is the "lowbias32" mixer, hash_derive one 24-bit multiply + shift-add +
+ * xorshift (css_amd/csrc/common.hpp; oracle/dropout.py is their numpy twin).  Entry points that take a cfg index whole
+ * groups of four (their column counts are multiples of 4).  `seed` points to ONE uint32 in DEVICE memory (read by the kernels, so a captured step can be
  * replayed with new masks); a NULL cfg pointer, a NULL seed or p <= 0 mean "no dropout".  Forward and backward
  * kernels take the same cfg and regenerate the same mask. */
 typedef struct csship_dropout_cfg_s {

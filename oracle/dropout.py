@@ -22,15 +22,27 @@ def hash32(x):
     return x.astype(np.uint64)
 
 
+def hash_derive(w):
+    """second word of a four-element group (css_amd/csrc/common.hpp hash_derive): ((w ^ c) mod 2^24) * m mod 2^32, plus
+    w >> 11, then an xorshift."""
+    w = np.asarray(w, dtype=np.uint64)
+    v = (((w ^ np.uint64(0x5bd1e995)) & np.uint64(0xffffff)) * np.uint64(0x85ebca)) & np.uint64(0xffffffff)
+    v = (v + (w >> np.uint64(11))) & np.uint64(0xffffffff)
+    return v ^ (v >> np.uint64(14))
+
+
 def keep_mask(seed, stream, n, p):
-    """bool [n]: element e survives iff field (e & 1) of hash32(key + (e >> 1)) >= round(p * 65536)."""
+    """bool [n]: elements 4q .. 4q+3 share w0 = hash32(key + q) and w1 = hash_derive(w0); element 4q + f survives iff field
+    f of (w0 lo16, w0 hi16, w1 lo16, w1 hi16) >= round(p * 65536)."""
     thresh = int(p * 65536.0 + 0.5)
     if thresh == 0:
         return np.ones(n, dtype=bool)
     key = int(hash32(np.uint64((int(seed) ^ ((int(stream) * 0x9E3779B9) & 0xffffffff)) & 0xffffffff)))
-    e = np.arange(n, dtype=np.uint64)
-    h = hash32((np.uint64(key) + (e >> np.uint64(1))) & np.uint64(0xffffffff))
-    field = np.where((e & np.uint64(1)) == 1, h >> np.uint64(16), h & np.uint64(0xffff))
+    q = np.arange((n + 3) // 4, dtype=np.uint64)
+    w0 = hash32((np.uint64(key) + q) & np.uint64(0xffffffff))
+    w1 = hash_derive(w0)
+    m16 = np.uint64(0xffff)
+    field = np.stack([w0 & m16, w0 >> np.uint64(16), w1 & m16, w1 >> np.uint64(16)], 1).reshape(-1)[:n]
     return field >= thresh
 
 

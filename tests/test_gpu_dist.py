@@ -330,4 +330,8 @@ def test_bench_launches_its_own_ranks(mode):
     assert len(lines) == 1, out.stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and len(rec["per_rank_ms_per_step"]) == 2 and rec["config"]["global_batch"] == 64
-    assert rec["roofline"]["frac"] > 0 and rec["roofline"]["attention"]["avg_launch_us"] > 0
+    if mode == "fwd":   # the per-kernel records belong to the default mode's line (train-mode forward + PIT, eval leg beside it)
+        assert rec["roofline"]["frac"] > 0 and rec["roofline"]["attention"]["avg_launch_us"] > 0
+        assert rec["eval_fwd_pit"]["ms_per_step"] > 0 and "train-mode" in rec["config"]["mode"].lower()
+    else:
+        assert rec["roofline"]["whole_step_frac"] > 0
