@@ -176,6 +176,13 @@ DEV uint2 drop_mask_bf4(const Drop& d, unsigned e0) {   // e0 a multiple of 4; .
   const unsigned w0 = hash32(d.key + (e0 >> 2)), w1 = hash_derive(w0);
   return make_uint2(drop_keep_halves(w0, d.tb), drop_keep_halves(w1, d.tb));
 }
+// dropout(relu(v)) of four consecutive elements as two packed bf16 pairs: scale, convert, ReLU and mask on the PAIRS
+// (same bits as relu -> select per element -> scale -> convert: a negative value times the positive scale stays negative)
+DEV uint2 drop_relu_pack4(const Drop& d, unsigned e0, float v0, float v1, float v2, float v3) {
+  if (d.thresh == 0u) return make_uint2(relu_bf2(pack_bf2(v0, v1)), relu_bf2(pack_bf2(v2, v3)));   // (wave-uniform)
+  const uint2 m = drop_mask_bf4(d, e0);
+  return make_uint2(relu_bf2(pack_bf2(v0 * d.scale, v1 * d.scale)) & m.x, relu_bf2(pack_bf2(v2 * d.scale, v3 * d.scale)) & m.y);
+}
 DEV bool drop_keep1(const Drop& d, unsigned e) {
   const unsigned w0 = hash32(d.key + (e >> 2));
   const unsigned w = (e & 2u) ? hash_derive(w0) : w0;

@@ -280,9 +280,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_kernel(FfnArgs a) {
       for (int rt = 0; rt < 4; ++rt) {
         uint2 pk;
         if (dh.thresh != 0u) {  // training: relu, then the hidden activation's dropout (conformer.py:317), element (row, c*256 + hc)
-          const float4 v = drop_apply4(dh, (unsigned)((m0 + rt * 16 + n) * a.FF + c * DM + hc),
-                                       make_float4(fmaxf(h[t][rt][0], 0.f), fmaxf(h[t][rt][1], 0.f), fmaxf(h[t][rt][2], 0.f), fmaxf(h[t][rt][3], 0.f)));
-          pk = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+          pk = drop_relu_pack4(dh, (unsigned)((m0 + rt * 16 + n) * a.FF + c * DM + hc), h[t][rt][0], h[t][rt][1], h[t][rt][2], h[t][rt][3]);
         } else {
           pk = make_uint2(relu_bf2(pack_bf2(h[t][rt][0], h[t][rt][1])), relu_bf2(pack_bf2(h[t][rt][2], h[t][rt][3])));
         }
@@ -504,11 +502,11 @@ __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
         const int row = m0 + rt * 16 + n;
-        const float4 hv = drop_apply4(dh, (unsigned)(row * a.FF + fcol),
-                                      make_float4(fmaxf(h[t][rt][0], 0.f), fmaxf(h[t][rt][1], 0.f), fmaxf(h[t][rt][2], 0.f), fmaxf(h[t][rt][3], 0.f)));
-        const float v0 = hv.x, v1 = hv.y, v2 = hv.z, v3 = hv.w;
-        mask |= ((v0 > 0.f ? 1u : 0u) | (v1 > 0.f ? 2u : 0u) | (v2 > 0.f ? 4u : 0u) | (v3 > 0.f ? 8u : 0u)) << ((t * 4 + rt) * 4);
-        hpk[t][rt] = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
+        // dropout(relu(.)) on the packed pairs (drop_relu_pack4; thresh 0 keeps everything); the ReLU-and-dropout mask
+        // of the backward is "the stored bf16 value is not zero"
+        const uint2 pk = drop_relu_pack4(dh, (unsigned)(row * a.FF + fcol), h[t][rt][0], h[t][rt][1], h[t][rt][2], h[t][rt][3]);
+        mask |= (((pk.x & 0xffffu) ? 1u : 0u) | ((pk.x >> 16) ? 2u : 0u) | ((pk.y & 0xffffu) ? 4u : 0u) | ((pk.y >> 16) ? 8u : 0u)) << ((t * 4 + rt) * 4);
+        hpk[t][rt] = pk;
         h[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
@@ -997,9 +995,7 @@ DEV void ffn_stage(float4 (&v)[8], unsigned char* Xs, unsigned char* Hraw, const
       for (int rt = 0; rt < 4; ++rt) {  // ReLU on the packed pairs: 2 conversions + 2 integer max per 4 values
         uint2 pk;
         if (TRAIN && tr.dh.thresh != 0u) {  // relu, then the hidden activation's dropout (conformer.py:317), element (row, c*256 + hc)
-          const float4 hv = drop_apply4(tr.dh, (unsigned)((tr.m0 + rt * 16 + n) * FF + c * DM + hc),
-                                        make_float4(fmaxf(h[t][rt][0], 0.f), fmaxf(h[t][rt][1], 0.f), fmaxf(h[t][rt][2], 0.f), fmaxf(h[t][rt][3], 0.f)));
-          pk = make_uint2(pack_bf2(hv.x, hv.y), pack_bf2(hv.z, hv.w));
+          pk = drop_relu_pack4(tr.dh, (unsigned)((tr.m0 + rt * 16 + n) * FF + c * DM + hc), h[t][rt][0], h[t][rt][1], h[t][rt][2], h[t][rt][3]);
         } else {
           pk = make_uint2(relu_bf2(pack_bf2(h[t][rt][0], h[t][rt][1])), relu_bf2(pack_bf2(h[t][rt][2], h[t][rt][3])));
         }
@@ -1387,9 +1383,7 @@ DEV void ffn_stage_s(float4 (&v)[8], unsigned char* Xs, unsigned char* Hraw, con
       for (int rt = 0; rt < 4; ++rt) {  // ReLU on the packed pairs: 2 conversions + 2 integer max per 4 values
         uint2 pk;
         if (TRAIN && tr.dh.thresh != 0u) {  // relu, then the hidden activation's dropout (conformer.py:317), element (row, c*256 + hc)
-          const float4 hv = drop_apply4(tr.dh, (unsigned)((tr.m0 + rt * 16 + n) * FF + c * DM + hc),
-                                        make_float4(fmaxf(h[t][rt][0], 0.f), fmaxf(h[t][rt][1], 0.f), fmaxf(h[t][rt][2], 0.f), fmaxf(h[t][rt][3], 0.f)));
-          pk = make_uint2(pack_bf2(hv.x, hv.y), pack_bf2(hv.z, hv.w));
+          pk = drop_relu_pack4(tr.dh, (unsigned)((tr.m0 + rt * 16 + n) * FF + c * DM + hc), h[t][rt][0], h[t][rt][1], h[t][rt][2], h[t][rt][3]);
         } else {
           pk = make_uint2(relu_bf2(pack_bf2(h[t][rt][0], h[t][rt][1])), relu_bf2(pack_bf2(h[t][rt][2], h[t][rt][3])));
         }
@@ -1466,9 +1460,7 @@ template <int NT, bool TRAIN>
 DEV void hidden_tile(unsigned char* hs, const f32x4& hv, int row, int hc, const StageTrain& tr, int FF, int c) {
   uint2 pk;
   if (TRAIN && tr.dh.thresh != 0u) {  // relu, then the hidden activation's dropout (conformer.py:317), element (row, c*256 + hc)
-    const float4 dv = drop_apply4(tr.dh, (unsigned)((tr.m0 + row) * FF + c * DM + hc),
-                                  make_float4(fmaxf(hv[0], 0.f), fmaxf(hv[1], 0.f), fmaxf(hv[2], 0.f), fmaxf(hv[3], 0.f)));
-    pk = make_uint2(pack_bf2(dv.x, dv.y), pack_bf2(dv.z, dv.w));
+    pk = drop_relu_pack4(tr.dh, (unsigned)((tr.m0 + row) * FF + c * DM + hc), hv[0], hv[1], hv[2], hv[3]);
   } else {
     pk = make_uint2(relu_bf2(pack_bf2(hv[0], hv[1])), relu_bf2(pack_bf2(hv[2], hv[3])));
   }
