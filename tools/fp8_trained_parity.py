@@ -22,7 +22,8 @@ import oracle  # noqa: E402
 from css_amd.utils import synthetic as syn  # noqa: E402
 
 
-def run(steps=300, blocks=16, verbose=True):
+def trained_model(steps=300, blocks=16, verbose=True):
+    """the recipe's model after `steps` optimiser steps (on the GPU, train mode) and its dataset iterator"""
     from css_amd.datasets import DATASETS
     from css_amd.models import MODELS
     from css_amd.objectives import OBJECTIVES
@@ -42,6 +43,11 @@ def run(steps=300, blocks=16, verbose=True):
         opt.step()
         if verbose and (i % 100 == 0 or i == steps - 1):
             print(f"  train step {i:4d} loss {float(loss):.5f}", flush=True)
+    return m, ds
+
+
+def run(steps=300, blocks=16, verbose=True):
+    m, _ = trained_model(steps, blocks, verbose)
     m.eval()
     sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
     f = torch.from_numpy(np.random.RandomState(11).standard_normal((2, 100, 257)).astype(np.float32)).abs()
