@@ -221,6 +221,9 @@ SIGNATURES = {
     "csship_attn_pos_bwd_workspace": (_sz, [_i32, _i32]),
     "csship_attn_pos_bwd": (_i32, [_p, _i64, _p, _i64, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _sz, _p]),
     "csship_attn_pos_bwd_ds": (_i32, [_p, _i64, _p, _i64, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _sz, _p]),
+    "csship_attn_pos_bwd_ds_parts": (_i32, [_p, _i64, _p, _i64, _p, _i64, _p, _i32, _p, _p, _i32, _i32, _i32, _i32, _p, _sz, _p]),
+    "csship_mha_relpos_bwd_fused_parts": (_i32, [_i32, _i32, _i32]),
+    "csship_mha_relpos_bwd_fused": (_i32, [_p, _p, _i32, _i32, _p, _p, _p, _p, _i64, _p, _p, _i32, _i32, _i32, _dc, _p]),
     "csship_debug_timeline": (None, [_i32]),
     "csship_debug_timeline_read": (_i32, [_i32, C.POINTER(C.c_double), C.POINTER(_i32)]),
     "csship_debug_timeline_calibrate": (None, [_p, _i32]),

@@ -81,6 +81,11 @@ def ffn_bwd_fused(x, dy, ln_g, ln_b, b1, w1p, w2tp, w1tp, d_ffn, alpha=0.5, drop
 _NO_HEAD_PAD = bool(os.environ.get("CSSHIP_NO_HEAD_PAD"))   # A/B timing: the mask head's backward on f32 dz of width n_out
 _NO_BAND = bool(os.environ.get("CSSHIP_NO_BAND"))   # A/B timing: the skewed-dS product over the whole window axis
 _NO_LN_Y = bool(os.environ.get("CSSHIP_NO_LN_Y"))   # A/B timing: LayerNorm(x) for the q/k/v weight gradient by its own launch
+# Round 6: the key-stationary fused pass (csship_mha_relpos_bwd_fused: probabilities recomputed, dS written once, dK / dV in
+# registers, no P' in memory).  OPT-IN: it moves 67 MB where the two kernels it replaces move 177, and measures the same -
+# 66 against 41 + 29 us alone, 8.21 against 8.16 ms per training step (tools/bench_attn_bwd.py, profiles/r06_attn_fb_ablate.txt):
+# with two waves per SIMD both forms are bound by instruction issue, not by bytes.
+_ATTN_FUSED_BWD = bool(os.environ.get("CSSHIP_ATTN_FUSED_BWD"))
 _SPLIT_ATTN_BWD = bool(os.environ.get("CSSHIP_ATTN_BWD_SPLIT"))   # A/B timing: probabilities / softmax backward / dS k as separate launches
 _NO_DVDK = bool(os.environ.get("CSSHIP_NO_DVDK"))   # A/B timing: dV and dK as two general batched products
 _NO_POS_FROM_DS = bool(os.environ.get("CSSHIP_NO_POS_FROM_DS"))   # A/B timing: the backward core also writes the skewed dS and the position pass reads that
@@ -114,6 +119,15 @@ def mha_core_bwd(qkv, dao, pe_table_bf, n_head, maxlen=1000, window=None, probs=
     W = win.shape[0]
     p_v = None              # operand of dV: the dropped probabilities when the forward dropped them (conformer.py:249)
     do = dao.view(B, T, H, 64).permute(0, 2, 1, 3)
+    if (probs is not None and ao is not None and not _SPLIT_ATTN_BWD and _ATTN_FUSED_BWD and window is not None
+            and len(window) > 2 and window[2] is not None and T <= ob.pos_bwd_max_T() and not _NO_POS_FUSED and qkv.is_contiguous()
+            and dao.is_contiguous()):
+        # round 6: ONE key-stationary pass recomputes the probabilities and forms dS (written once), dK, dV (in registers) and
+        # dq1 (a partial per key group); the position pass adds the partials and reads q in place.  No P', no second dS.
+        ds, parts, dqkv = ob.mha_bwd_fused(qkv, probs[0], probs[1], dao, ao.reshape(B * T, H * 64), H, drop=drop_p)
+        acc = dwin_acc if dwin_acc is not None else torch.zeros((window[0].shape[0], 64), dtype=torch.float32, device=qkv.device)
+        ob.attn_pos_bwd_parts(ds, window[2], qkv, parts, dqkv, acc, H)
+        return dqkv, acc
     if probs is not None and ao is not None and not _SPLIT_ATTN_BWD:
         # one pass over the scores: probabilities, softmax backward (row-major and skewed dS) and dS k
         from_ds = (window is not None and len(window) > 2 and window[2] is not None and T <= ob.pos_bwd_max_T() and not _NO_POS_FUSED

@@ -275,6 +275,8 @@ struct PosBwdArgs {
   const unsigned short* pet;   // bf16 [64, ldpt]: pe_window^T, zero beyond the window
   const unsigned short* q;     // bf16 [B*T*H, 64], rows in dS_skew's order
   const float* dq1;            // f32 [B, H, T, 64]
+  int dq1_parts;               // dq1 arrives as this many partials, B*H*T*64 floats apart (csship_mha_relpos_bwd_fused: one per key group)
+  int64_t ldq;                 // elements between the q rows of consecutive frames (H * 64 dense, 3 * H * 64 inside qkv)
   unsigned short* dqkv;        // bf16 [B*T, 3*H*64]: the q third is written
   float* partial;              // [B * nblk][nwt * 16][64]
   int64_t ldw, ldpt;
@@ -325,8 +327,7 @@ __global__ __launch_bounds__(512) void attn_pos_bwd_kernel(PosBwdArgs a) {
         sreg[j] = *reinterpret_cast<const f32x4*>(a.dsk + row * a.ldw + w0 + (scol_ok ? sc * 8 : 0));
       }
     }
-    const size_t qrow = ((size_t)b * a.T + min(t0 + qr, a.T - 1)) * a.H + h;
-    qreg = *reinterpret_cast<const f32x4*>(a.q + qrow * 64 + qc * 8);
+    qreg = *reinterpret_cast<const f32x4*>(a.q + ((size_t)b * a.T + min(t0 + qr, a.T - 1)) * a.ldq + h * 64 + qc * 8);
   };
   // LDS offset of chunk sc of row 8 j + sr0: the swizzle key of that row is (sr0 & 3) | (j & 1) << 2 - two bases, j in the offset
   const int so_even = pb_off(sr0, sc), so_odd = pb_off(8 + sr0, sc) - 8 * PB_ROWB;
@@ -385,6 +386,8 @@ __global__ __launch_bounds__(512) void attn_pos_bwd_kernel(PosBwdArgs a) {
     for (int jj = 0; jj < 2; ++jj) {
       const int t = min(t0 + (tt0 + jj) * 16 + n, a.T - 1);
       d1[jj] = *reinterpret_cast<const f32x4*>(a.dq1 + (((size_t)b * a.H + h) * a.T + t) * 64 + dt1 * 16 + 4 * g);
+      for (int pp = 1; pp < a.dq1_parts; ++pp)   // (kernel-uniform; partials added in order)
+        d1[jj] += *reinterpret_cast<const f32x4*>(a.dq1 + (((size_t)(pp * a.B + b) * a.H + h) * a.T + t) * 64 + dt1 * 16 + 4 * g);
     }
     issue_loads(min(h + 1, a.H - 1));
     __syncthreads();
@@ -518,7 +521,7 @@ extern "C" int csship_attn_pos_bwd_max_t(void) { return PB_MAXKS * 32 - (PB_ROWS
 static int pos_bwd_impl(const uint16_t* ds_skew, int64_t ld_w, const uint16_t* pe_window_t, int64_t ld_pt,
                         const uint16_t* q_rows, const float* dq1, uint16_t* dqkv, float* dwin_acc, int32_t W,
                         int32_t B, int32_t T, int32_t H, void* workspace, size_t workspace_bytes,
-                        csship_stream_t stream, bool from_ds);
+                        csship_stream_t stream, bool from_ds, int dq1_parts = 1, int64_t ld_q = 0);
 
 extern "C" int csship_attn_pos_bwd(const uint16_t* ds_skew, int64_t ld_w, const uint16_t* pe_window_t, int64_t ld_pt,
                                    const uint16_t* q_rows, const float* dq1, uint16_t* dqkv, float* dwin_acc, int32_t W,
@@ -536,10 +539,21 @@ extern "C" int csship_attn_pos_bwd_ds(const uint16_t* ds, int64_t ld_p, const ui
                       true);
 }
 
+extern "C" int csship_attn_pos_bwd_ds_parts(const uint16_t* ds, int64_t ld_p, const uint16_t* pe_window_t, int64_t ld_pt,
+                                            const uint16_t* q, int64_t ld_q, const float* dq1_parts, int32_t n_parts,
+                                            uint16_t* dqkv, float* dwin_acc, int32_t W, int32_t B, int32_t T, int32_t H,
+                                            void* workspace, size_t workspace_bytes, csship_stream_t stream) {
+  if (n_parts < 1 || n_parts > 16) return CSSHIP_EBADSHAPE;
+  if (ld_q < (int64_t)H * 64 || (ld_q & 7) != 0) return CSSHIP_EBADSHAPE;
+  return pos_bwd_impl(ds, ld_p, pe_window_t, ld_pt, q, dq1_parts, dqkv, dwin_acc, W, B, T, H, workspace, workspace_bytes, stream, true,
+                      n_parts, ld_q);
+}
+
 static int pos_bwd_impl(const uint16_t* ds_skew, int64_t ld_w, const uint16_t* pe_window_t, int64_t ld_pt,
                         const uint16_t* q_rows, const float* dq1, uint16_t* dqkv, float* dwin_acc, int32_t W,
                         int32_t B, int32_t T, int32_t H, void* workspace, size_t workspace_bytes,
-                        csship_stream_t stream, bool from_ds) {
+                        csship_stream_t stream, bool from_ds, int dq1_parts, int64_t ld_q) {
+  if (ld_q == 0) ld_q = (int64_t)H * 64;
   if (!ds_skew || !pe_window_t || !q_rows || !dq1 || !dqkv || !dwin_acc || !workspace) return CSSHIP_ENULL;
   if (B <= 0 || T <= 0 || H <= 0 || W < 2 * T - 1 || (ld_pt & 7) != 0) return CSSHIP_EBADSHAPE;
   if (from_ds ? (ld_w < T) : (ld_w < W || (ld_w & 7) != 0)) return CSSHIP_EBADSHAPE;
@@ -555,7 +569,7 @@ static int pos_bwd_impl(const uint16_t* ds_skew, int64_t ld_w, const uint16_t* p
       !aligned16(dq1) || !aligned8(dqkv) || !aligned16(dwin_acc) || !aligned16(workspace))
     return CSSHIP_EALIGN;
   if (workspace_bytes < csship_attn_pos_bwd_workspace(B, T)) return CSSHIP_EWORKSPACE;
-  PosBwdArgs a{ds_skew, pe_window_t, q_rows, dq1, dqkv, reinterpret_cast<float*>(workspace), ld_w, ld_pt, B, T, H, nblk, nks, nwt};
+  PosBwdArgs a{ds_skew, pe_window_t, q_rows, dq1, dq1_parts, ld_q, dqkv, reinterpret_cast<float*>(workspace), ld_w, ld_pt, B, T, H, nblk, nks, nwt};
   hipStream_t s = as_stream(stream);
   if (from_ds) hipLaunchKernelGGL((attn_pos_bwd_kernel<true>), dim3((unsigned)(B * nblk)), dim3(512), 0, s, a);
   else hipLaunchKernelGGL((attn_pos_bwd_kernel<false>), dim3((unsigned)(B * nblk)), dim3(512), 0, s, a);

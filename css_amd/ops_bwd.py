@@ -734,6 +734,51 @@ def attn_pos_bwd_ds(ds, win_t, q_rows, dq1, dqkv, dwin_acc, n_head):
     return dqkv, dwin_acc
 
 
+def mha_bwd_fused(qkv, pe_pack, lse, d_out, out, n_head, drop=None, dqkv=None):
+    """The attention backward up to the window axis in one key-stationary pass (csship_mha_relpos_bwd_fused): recomputes
+    the probabilities from q, k, the packed position blocks and the forward's log-sum-exp and returns (dS bf16
+    [B,H,T,pad8(T)] - with slack_bf16's slack, the operand of attn_pos_bwd_parts -, dq1 partials f32 [G,B,H,T,64], dqkv bf16
+    [B,T,3*H*64] with its k and v thirds written).  No probabilities and no second copy of dS ever reach memory."""
+    _need(qkv, torch.bfloat16, "qkv"), _need(lse, torch.float32, "lse"), _need(d_out, torch.bfloat16, "d_out")
+    _need(out, torch.bfloat16, "out")
+    packed, q_min, q_max = pe_pack
+    B, T, D3 = qkv.shape
+    if not (qkv.is_contiguous() and d_out.is_contiguous() and lse.is_contiguous() and out.is_contiguous()) \
+            or D3 != 3 * n_head * 64 or d_out.numel() != B * T * n_head * 64 or out.numel() != d_out.numel():
+        raise RuntimeError("css_amd: mha_bwd_fused expects dense qkv [B,T,3*H*64], d_out / out [B*T,H*64], lse [B,H,T]")
+    ldp = (T + 7) // 8 * 8
+    ds = slack_bf16((B, n_head, T, ldp), qkv.device)
+    G = lib().csship_mha_relpos_bwd_fused_parts(B, T, n_head)
+    dq1 = torch.empty(G, B, n_head, T, 64, device=qkv.device, dtype=torch.float32)
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv)
+    check(lib().csship_mha_relpos_bwd_fused(_ptr(qkv), _ptr(packed), q_min, q_max, _ptr(lse), _ptr(d_out), _ptr(out), _ptr(ds), ldp,
+                                            _ptr(dq1), _ptr(dqkv), B, T, n_head, drop, _stream()))
+    return ds, dq1, dqkv
+
+
+def attn_pos_bwd_parts(ds, win_t, qkv, dq1_parts, dqkv, dwin_acc, n_head):
+    """attn_pos_bwd_ds behind mha_bwd_fused: dq1 as 1 or 2 partials [G,B,H,T,64] added in the pass, q rows read in place
+    from qkv (csship_attn_pos_bwd_ds_parts)."""
+    _need(ds, torch.bfloat16, "ds"), _need(win_t, torch.bfloat16, "win_t"), _need(qkv, torch.bfloat16, "qkv")
+    _need(dq1_parts, torch.float32, "dq1_parts"), _need(dqkv, torch.bfloat16, "dqkv"), _need(dwin_acc, torch.float32, "dwin_acc")
+    B, H, T, ldp = ds.shape
+    W = dwin_acc.shape[0]
+    st = ds.untyped_storage()
+    lo = ds.storage_offset() * 2
+    if not (ds.is_contiguous() and win_t.is_contiguous() and qkv.is_contiguous() and dq1_parts.is_contiguous() and
+            dqkv.is_contiguous() and dwin_acc.is_contiguous()) or H != n_head or qkv.shape != (B, T, 3 * H * 64) or \
+            tuple(dq1_parts.shape[1:]) != (B, H, T, 64) or dqkv.shape != qkv.shape or dwin_acc.shape[1] != 64 or win_t.shape[0] != 64:
+        raise RuntimeError("css_amd: attn_pos_bwd_parts expects dense dS [B,H,T,ldp], qkv / dqkv [B,T,3*H*64], dq1 parts [G,B,H,T,64]")
+    if lo < 16 or st.nbytes() - lo - ds.numel() * 2 < 16:
+        raise RuntimeError("css_amd: attn_pos_bwd_parts needs 16 bytes of slack on both sides of dS (ops_bwd.slack_bf16)")
+    nws = lib().csship_attn_pos_bwd_workspace(B, T)
+    ws = _workspace(nws, ds.device)
+    check(lib().csship_attn_pos_bwd_ds_parts(_ptr(ds), ldp, _ptr(win_t), win_t.shape[1], _ptr(qkv), 3 * H * 64, _ptr(dq1_parts),
+                                             dq1_parts.shape[0], _ptr(dqkv), _ptr(dwin_acc), W, B, T, H, _ptr(ws), nws, _stream()))
+    return dqkv, dwin_acc
+
+
 def attn_pos_bwd(dsk, win_t, q_rows, dq1, dqkv, dwin_acc, n_head):
     """The relative-position term's two gradient products in one pass over the skewed dS (csship_attn_pos_bwd):
     the q third of dqkv = dq1 + dS_skew pe_window, and dwin_acc (f32 [W, 64]) += dS_skew^T q.  dsk bf16 [B,T,H,W]."""

@@ -926,6 +926,28 @@ int csship_attn_pos_bwd_ds(const uint16_t* ds, int64_t ld_p, const uint16_t* pe_
 int csship_attn_pos_bwd(const uint16_t* ds_skew, int64_t ld_w, const uint16_t* pe_window_t, int64_t ld_pt,
                         const uint16_t* q_rows, const float* dq1, uint16_t* dqkv, float* dwin_acc, int32_t W, int32_t B,
                         int32_t T, int32_t H, void* workspace, size_t workspace_bytes, csship_stream_t stream);
+/* csship_attn_pos_bwd_ds behind csship_mha_relpos_bwd_fused: dq1 arrives as n_parts (1 .. 16) partials f32 [n_parts][B, H, T, 64]
+ * (one per key group) that are added here, and the q rows are read in place from the projection (q: bf16, row (b, t) at
+ * q + (b T + t) ld_q, head h at + 64 h; ld_q = 3 H 64 inside qkv) - no q_rows copy. */
+int csship_attn_pos_bwd_ds_parts(const uint16_t* ds, int64_t ld_p, const uint16_t* pe_window_t, int64_t ld_pt,
+                                 const uint16_t* q, int64_t ld_q, const float* dq1_parts, int32_t n_parts, uint16_t* dqkv,
+                                 float* dwin_acc, int32_t W, int32_t B, int32_t T, int32_t H, void* workspace,
+                                 size_t workspace_bytes, csship_stream_t stream);
+
+/* ---- csship_mha_relpos_bwd_fused (css_amd/csrc/attnfb.hip): the attention backward up to the window axis in ONE
+ * key-stationary pass (replaces csship_mha_relpos_bwd_core + csship_attn_dvdk; conformer.py:229-253 under autograd).
+ * From q | k | v (bf16 [B*T, 3 H 64], q pre-scaled), the packed position blocks, the training forward's log-sum-exp
+ * (f32 [B, H, T]) and output (bf16 [B*T, H 64]) and the output gradient d_out (bf16 [B*T, H 64]) it recomputes the
+ * probabilities and writes: dS (bf16 [B, H, T, ld_p], ld_p a multiple of 8 >= T, columns T .. ld_p - 1 zero) - the one
+ * [B, H, T, T] tensor left in memory, the operand of csship_attn_pos_bwd_ds_parts -, dq1 = dS k as one f32 [B, H, T, 64]
+ * partial per key group (csship_mha_relpos_bwd_fused_parts(B, T, H) of them, contiguous), and dK, dV into the k and v
+ * thirds of dqkv (bf16 [B*T, 3 H 64]).  The probabilities' dropout of the forward is regenerated from `drop` (then
+ * ld_p == pad8(T) and B H T ld_p < 2^32).  d_k = 64.  Deterministic (fixed summation orders, no atomics). */
+int csship_mha_relpos_bwd_fused_parts(int32_t B, int32_t T, int32_t H);
+int csship_mha_relpos_bwd_fused(const uint16_t* qkv, const uint16_t* pe_packed, int32_t q_min, int32_t q_max, const float* lse,
+                                const uint16_t* d_out, const uint16_t* out, uint16_t* ds_bf16, int64_t ld_p, float* dq1_parts,
+                                uint16_t* dqkv, int32_t B, int32_t T, int32_t H, const csship_dropout_cfg* drop,
+                                csship_stream_t stream);
 
 /* ---- csship_p2p_reduce (css_amd/csrc/optim.hip): out[lo:hi] = scale * (src_0 + src_1 + ... + src_{world-1})[lo:hi],
  * summed in that order (bit-reproducible), for the direct (one-shot) all-reduce of css_amd.parallel.P2PAllReduce

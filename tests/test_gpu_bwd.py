@@ -753,6 +753,61 @@ def test_attention_backward_core_one_pass(ob, B, T, H, p_drop):
     assert relerr(dq1, ref) < 2e-5
 
 
+@pytest.mark.parametrize("B,T,H,p_drop", [(2, 400, 4, 0.0), (2, 400, 4, 0.1), (3, 77, 2, 0.0), (1, 150, 4, 0.1), (2, 64, 4, 0.1),
+                                          (1, 449, 4, 0.1), (5, 33, 3, 0.0), (32, 400, 4, 0.1)])
+def test_attention_backward_fused_key_stationary(ob, B, T, H, p_drop):
+    """csship_mha_relpos_bwd_fused (one key-stationary pass: probabilities recomputed, dS out once, dK / dV in registers, dq1
+    as one partial per key group) + csship_attn_pos_bwd_ds_parts against the path of rounds 3-5 (csship_mha_relpos_bwd_core +
+    csship_attn_dvdk + csship_attn_pos_bwd_ds) on the same operands: dS within one bf16 rounding (both form P o (dP - D)
+    from scores whose summation orders differ), dK / dV / dq and the window gradient within the bf16 noise of their
+    operands; and dK, dV, dq1 against float64 products of the kernel's OWN dS / the old path's P' (tight)."""
+    from css_amd import ops
+    from css_amd.dropout import DropState
+    D = H * 64
+    qkv = rnd((B, T, 3 * D), 60, 0.5).to(DEV).to(torch.bfloat16)
+    pe = rnd((2000, 64), 61, 0.3).to(DEV)
+    pe_pack = ops.pack_relpos(pe, 1000)
+    dao = rnd((B * T, D), 62, 0.2).to(DEV).to(torch.bfloat16)
+    cfg = None
+    if p_drop > 0:
+        ds_ = DropState(torch.tensor([1234], dtype=torch.int32, device=DEV), p_drop, 0)
+        cfg = ds_.cfg("0.attn.p")
+    ao, lse = ops.mha_relpos_train(qkv, pe_pack, H, drop=cfg)
+    ao2 = ao.view(B * T, D)
+    # the old path
+    p_v, ds0, _, dq10, q_rows = ob.mha_bwd_core(qkv, pe_pack, lse, dao, None, None, H, drop=cfg, out=ao2, want_q_rows=True)
+    dqkv0 = torch.zeros_like(qkv)
+    ob.attn_dvdk(p_v, ds0, dao, qkv, dqkv0, H)
+    rt = ob.relpos_tables(pe, T, 1000, want_t=True)
+    win, idx, win_t = rt["window"]
+    W = win.shape[0]
+    acc0 = torch.zeros((W, 64), dtype=torch.float32, device=DEV)
+    ob.attn_pos_bwd_ds(ds0, win_t, q_rows, dq10, dqkv0, acc0, H)
+    # the fused pass
+    ds1, parts, dqkv1 = ob.mha_bwd_fused(qkv, pe_pack, lse, dao, ao2, H, drop=cfg, dqkv=torch.zeros_like(qkv))
+    acc1 = torch.zeros((W, 64), dtype=torch.float32, device=DEV)
+    ob.attn_pos_bwd_parts(ds1, win_t, qkv, parts, dqkv1, acc1, H)
+    torch.cuda.synchronize()
+    a, b_ = ds1.float(), ds0.float()
+    assert float((a - b_).abs().max()) <= 2.0 ** -6 * float(b_.abs().max()) and froerr(a, b_.cpu()) < 4e-3
+    assert bool((ds1[..., T:] == 0).all())
+    g = qkv.view(B, T, 3, H, 64)
+    q, k = (g[:, :, i].permute(0, 2, 1, 3).float().cpu().double() for i in (0, 1))
+    do = dao.view(B, T, H, 64).permute(0, 2, 1, 3).float().cpu().double()
+    dsd = ds1[..., :T].float().cpu().double()
+    d1 = dqkv1.view(B, T, 3, H, 64)
+    # tight: the products of the kernel's own dS, and dV against the old path's P' (the same probabilities up to summation order)
+    assert relerr(parts.sum(0), dsd @ k) < 2e-5
+    assert relerr(d1[:, :, 1].permute(0, 2, 1, 3).float(), dsd.transpose(-1, -2) @ q) < 6e-3       # (bf16 output)
+    assert relerr(d1[:, :, 2].permute(0, 2, 1, 3).float(), p_v[..., :T].float().cpu().double().transpose(-1, -2) @ do) < 6e-3
+    # the whole backward against the old path
+    assert froerr(dqkv1.float(), dqkv0.float().cpu()) < 6e-3
+    assert relerr(acc1, acc0.double().cpu()) < 5e-3
+    # deterministic
+    ds2, parts2, dqkv2 = ob.mha_bwd_fused(qkv, pe_pack, lse, dao, ao2, H, drop=cfg, dqkv=torch.zeros_like(qkv))
+    assert torch.equal(ds2, ds1) and torch.equal(parts2, parts) and torch.equal(dqkv2[..., D:], dqkv1[..., D:])
+
+
 @pytest.mark.parametrize("B,H,T", [(2, 4, 100), (1, 4, 7), (3, 2, 65), (2, 4, 400), (1, 8, 1100), (32, 4, 400)])
 def test_attn_dvdk_streaming(ob, B, H, T):
     """csship_attn_dvdk: dV = P'^T dO and dK = dS^T q in one pass over the two [B,H,T,ldp] operands (the attention's

@@ -701,6 +701,32 @@ def test_direct_gradient_stores_respect_foreign_writes():
     assert opt.grads_untouched() and len(opt._dirty) > 0
 
 
+def test_conformer_backward_through_the_fused_attention_pass():
+    """The opt-in key-stationary attention backward (csship_mha_relpos_bwd_fused + csship_attn_pos_bwd_ds_parts, CSSHIP_ATTN_FUSED_BWD=1)
+    through a whole 2-block training step with dropout: every parameter gradient against the default path's (the
+    query-stationary pass + csship_attn_dvdk) - same arithmetic up to summation order and one bf16 rounding of dS."""
+    from css_amd import backward as bw, dropout
+    from css_amd.objectives import OBJECTIVES
+    obj = OBJECTIVES["MSE"].build_objective({})
+    f = rnd((3, 96, 257), 14).abs().to(DEV)
+    tg = [(rnd((3, 96, 257), 60 + k).abs() * 0.5).to(DEV) for k in range(2)]
+    grads = []
+    for fused in (False, True):
+        m, _ = build(2, 43)
+        m.train()
+        dropout.set_seed(m, 9)
+        old = bw._ATTN_FUSED_BWD
+        bw._ATTN_FUSED_BWD = fused
+        try:
+            obj(m, {"mix": f, "source1": tg[0], "source2": tg[1]}, device=DEV).backward()
+        finally:
+            bw._ATTN_FUSED_BWD = old
+        grads.append(torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone())
+    err = float((grads[1] - grads[0]).norm() / grads[0].norm())
+    print(f"[parity] fused attention backward vs the default path, whole-model gradient: relative L2 difference {err:.3e}")
+    assert bool(torch.isfinite(grads[1]).all()) and err < 5e-3
+
+
 def test_training_does_not_depend_on_host_synchronisation():
     """12 replayed steps with a different learning rate every step, queued without ever synchronising (the host runs
     many steps ahead of the GPU), equal the same steps with a synchronise after each one, bit for bit: the per-step
