@@ -35,7 +35,9 @@ class FfnWeights(C.Structure):
 class ChainTrain(C.Structure):  # csship_chain_train
     _fields_ = [("drop_a_hidden", C.POINTER(DropoutCfg)), ("drop_a_out", C.POINTER(DropoutCfg)),
                 ("drop_b_hidden", C.POINTER(DropoutCfg)), ("drop_b_out", C.POINTER(DropoutCfg)),
-                ("pre_ln_out", _p), ("ln_out", _p)]
+                ("pre_ln_out", _p), ("ln_out", _p),
+                ("bn_z", _p), ("bn_x2", _p), ("bn_scale_shift", _p), ("bn_pw2_w", _p), ("bn_pw2_b", _p),
+                ("drop_bn", C.POINTER(DropoutCfg)), ("bn_out", _p)]
 
 
 class MhaWeights(C.Structure):

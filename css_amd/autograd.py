@@ -25,6 +25,7 @@ _NO_FFN_LN = bool(os.environ.get("CSSHIP_NO_FFN_LN"))       # A/B timing: the bl
 _NO_CONV_NEXT = bool(os.environ.get("CSSHIP_NO_CONV_NEXT"))  # A/B timing: dropout(dx) for the output projection's backward as its own pass
 _NO_DROP_EPI = bool(os.environ.get("CSSHIP_NO_DROP_EPI"))   # A/B timing: output-projection dropout as its own pass
 _NO_LN2 = bool(os.environ.get("CSSHIP_NO_LN2_FUSE"))   # A/B timing: every block's final LayerNorm backward as its own launch
+_NO_BN_IN_CHAIN = bool(os.environ.get("CSSHIP_NO_BN_IN_CHAIN"))   # A/B timing: the conv module's BatchNorm-apply pass as its own launch
 _NO_OC_TRAIN = bool(os.environ.get("CSSHIP_NO_OC_TRAIN"))   # A/B timing: output projection and conv module's first kernel as two launches
 
 
@@ -356,9 +357,14 @@ class ConformerTrain(torch.autograd.Function):
                  "bn_mean": c.BN.running_mean, "bn_var": c.BN.running_var,
                  "pw2_w": c.pw_conv_2.weight.detach().view(1), "pw2_b": c.pw_conv_2.bias.detach(),
                  "causal": getattr(c, "causal", False)}
+            # round 6: behind the fused kernel the module's tail (BatchNorm apply, ReLU, affine, dropout, residual) is formed by
+            # the chain kernel that consumes the rows - its prologue reads z and x2 - instead of a launch of its own
+            bn_in_chain = (fused_oc and chained and li + 1 < len(lays) and M % 64 == 0 and FF <= ob.ffn_static_max_ffn()
+                           and not _NO_BN_IN_CHAIN)
             if fused_oc:   # x2 = x1 + D(ao wo^T + bo) and the conv module with batch statistics: three launches instead of five
                 x2, x3, fws = ops.outproj_conv_train(ao, wo_p, a.linear_out.bias.detach(), x1, W, B, T, K,
-                                                     drop_proj=ds.cfg(f"{li}.attn.out"), drop_conv=ds.cfg(f"{li}.conv.out"))
+                                                     drop_proj=ds.cfg(f"{li}.attn.out"), drop_conv=ds.cfg(f"{li}.conv.out"),
+                                                     apply=not bn_in_chain)
             else:
                 x3, fws = ops.convmod(x2.view(B, T, D), W, K, batch_stats=batch_bn, keep_activations=not batch_bn,
                                       return_workspace=True, drop=ds.cfg(f"{li}.conv.out"), sync=sync_bn)
@@ -371,10 +377,17 @@ class ConformerTrain(torch.autograd.Function):
             if chained and li + 1 < len(lays):
                 # this block's last FeedForward + its LayerNorm, the next block's first FeedForward and its LayerNorm +
                 # q | k | v as ONE launch (the inference forward's chain kernel with the dropouts and the saved rows)
-                x1n, qkvn, x4, x = ops.encoder_chain_train(
-                    x3, FF, chain_ffn(li + 1, "ffn_in"), chain_qkv(li + 1), ffn_a=chain_ffn(li, "ffn_out"),
-                    final_ln=(lay.layer_norm.weight.detach(), lay.layer_norm.bias.detach()),
-                    drops=chain_drops(li, "ffn_out") + chain_drops(li + 1, "ffn_in"))
+                if bn_in_chain:
+                    x1n, qkvn, x4, x, x3 = ops.encoder_chain_train(
+                        None, FF, chain_ffn(li + 1, "ffn_in"), chain_qkv(li + 1), ffn_a=chain_ffn(li, "ffn_out"),
+                        final_ln=(lay.layer_norm.weight.detach(), lay.layer_norm.bias.detach()),
+                        drops=chain_drops(li, "ffn_out") + chain_drops(li + 1, "ffn_in"),
+                        bn=(x2, fws, W, ds.cfg(f"{li}.conv.out")))
+                else:
+                    x1n, qkvn, x4, x = ops.encoder_chain_train(
+                        x3, FF, chain_ffn(li + 1, "ffn_in"), chain_qkv(li + 1), ffn_a=chain_ffn(li, "ffn_out"),
+                        final_ln=(lay.layer_norm.weight.detach(), lay.layer_norm.bias.detach()),
+                        drops=chain_drops(li, "ffn_out") + chain_drops(li + 1, "ffn_in"))
                 carried = (x1n, qkvn)
                 L["ffn_out"] = (x3,) + tuple(wp["ffn_out"][i] for i in (0, 2, 3))
             elif wide or _NO_FFN_LN:

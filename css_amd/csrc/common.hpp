@@ -143,7 +143,9 @@ struct Drop {  // device-side view of csship_dropout_cfg; thresh == 0 means "no 
 DEV Drop drop_make(const unsigned* seed, unsigned stream, float p) {
   Drop d{0u, 0u, 1.f, 0x80008000u};
   if (seed != nullptr && p > 0.f) {
-    d.key = hash32(*seed ^ (stream * 0x9E3779B9u));
+    // wave-uniform by construction: kept in SCALAR registers (a chain kernel carries four of these; as vector registers
+    // they were 16 of the 256 a wave has, and the pipelined training form spilled 7)
+    d.key = (unsigned)__builtin_amdgcn_readfirstlane((int)hash32(*seed ^ (stream * 0x9E3779B9u)));
     d.thresh = (unsigned)(p * 65536.f + 0.5f);
     d.scale = 65536.f / (float)(65536u - d.thresh);  // 1 / (1 - p_effective)
     d.tb = ((d.thresh ^ 0x8000u) & 0xffffu) * 0x10001u;

@@ -747,14 +747,14 @@ extern "C" int csship_outproj_conv_train(const uint16_t* attn_out, const uint16_
                                          float* x2_out, float* y, const csship_conv_weights* w, int32_t B, int32_t T,
                                          int32_t D, int32_t kernel_size, const csship_dropout_cfg* drop_proj,
                                          const csship_dropout_cfg* drop_conv, void* workspace, csship_stream_t stream) {
-  if (!attn_out || !wo_packed || !bo || !x || !x2_out || !y || !w || !workspace) return CSSHIP_ENULL;
+  if (!attn_out || !wo_packed || !bo || !x || !x2_out || !w || !workspace) return CSSHIP_ENULL;   // (y NULL: no apply pass)
   if (w->causal) return CSSHIP_EUNSUPPORTED;
   if (!w->ln_g || !w->ln_b || !w->pw1_w || !w->pw1_b || !w->dw_w || !w->dw_b || !w->bn_g || !w->bn_b || !w->pw2_w || !w->pw2_b)
     return CSSHIP_ENULL;
   if (B <= 0 || T <= 0 || B > 65535 || (int64_t)B * T * D > 0xffffffffLL) return CSSHIP_EBADSHAPE;
   if (kernel_size != 33 || D != 256) return CSSHIP_EUNSUPPORTED;
   if (x == x2_out || x2_out == y) return CSSHIP_EBADSHAPE;
-  if (!aligned16(attn_out) || !aligned16(wo_packed) || !aligned16(bo) || !aligned16(x) || !aligned16(x2_out) || !aligned16(y) ||
+  if (!aligned16(attn_out) || !aligned16(wo_packed) || !aligned16(bo) || !aligned16(x) || !aligned16(x2_out) || (y && !aligned16(y)) ||
       !aligned16(w->ln_g) || !aligned16(w->ln_b) || !aligned16(workspace))
     return CSSHIP_EALIGN;
   const csship_dropout_cfg none{nullptr, 0u, 0.f};
@@ -775,6 +775,7 @@ extern "C" int csship_outproj_conv_train(const uint16_t* attn_out, const uint16_
   hipLaunchKernelGGL(bn_reduce8_kernel, dim3(D / 8), dim3(256), 0, s, partial, nblk, D, (double)B * (double)T, w->bn_g, w->bn_b,
                      scale_shift);
   CSSHIP_CHECK_LAUNCH();
+  if (y == nullptr) return CSSHIP_OK;   // the consumer applies the statistics (csship_encoder_chain_train, bn_* fields)
   hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, x2_out, zbuf, scale_shift, w->pw2_w,
                      w->pw2_b, y, n / 4, D, cfg(drop_conv));
   CSSHIP_CHECK_LAUNCH();

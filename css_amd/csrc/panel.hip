@@ -898,6 +898,12 @@ struct ChainArgs {
   csship_dropout_cfg da_h, da_o, db_h, db_o;
   float* pre_ln_out;
   float* ln_out;
+  // BNP (training, behind csship_outproj_conv_train): the kernel's input rows are formed here instead of by a launch of
+  // their own - x3 = x2 + dropout(pw2(relu(z * scale + shift))), the tail of the conv module (conformer.py:298-303) with the
+  // batch statistics csship_outproj_conv_train reduced - and leave as bn_out (the backward keeps them)
+  const float *bn_z, *bn_x2, *bn_ss, *bn_pw2_w, *bn_pw2_b;
+  csship_dropout_cfg d_bn;
+  float* bn_out;
 };
 
 // LayerNorm of the register rows -> bf16 activation panel in LDS.  gam == nullptr: no affine - the caller folded gamma
@@ -1646,8 +1652,9 @@ DEV ParamSrc param_src(const ChainArgs& a, int j, int q1, const float* dummy, in
   return ParamSrc{ok ? base + off * 4 : dummy, ok ? CS_LN + j * 4 : CS_PARAMS + lane * 4};
 }
 
-template <int NW, bool HAS_A, bool HAS_B, bool HAS_C, bool TRAIN, bool IL8, bool PIPE = false>
+template <int NW, bool HAS_A, bool HAS_B, bool HAS_C, bool TRAIN, bool IL8, bool PIPE = false, bool BNP = false>
 __global__ __launch_bounds__(NW * 64) void chain_s_kernel(ChainArgs a) {
+  static_assert(!BNP || (TRAIN && HAS_A), "the batch-statistics prologue belongs to the training chain behind a conv module");
   static_assert(NW * 64 == 8 * BM, "row phases assume 8 lanes per panel row");
   static_assert(HAS_A || HAS_B, "at least one FeedForward");
   static_assert(!HAS_C || HAS_B, "the q | k | v stage follows the block's first FeedForward");
@@ -1660,9 +1667,16 @@ __global__ __launch_bounds__(NW * 64) void chain_s_kernel(ChainArgs a) {
   const int r = tid >> 3, part = tid & 7;
   const int m0 = blockIdx.x * BM, row = m0 + r;   // whole panels only: row < M
   const int FF = a.FF, nchunk = FF / DM;
-  float4 v[8];
+  float4 v[8], zr[BNP ? 8 : 1];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(a.x + (size_t)row * DM + (i * 8 + part) * 4);
+  for (int i = 0; i < 8; ++i) {   // (BNP: the z rows now, the x2 rows behind the barrier - both at once were the kernel's register peak)
+    if constexpr (BNP) zr[i] = *reinterpret_cast<const float4*>(a.bn_z + (size_t)row * DM + (i * 8 + part) * 4);
+    else v[i] = *reinterpret_cast<const float4*>(a.x + (size_t)row * DM + (i * 8 + part) * 4);
+  }
+  // BNP: BatchNorm scale | shift of the 256 channels -> the (still unused) hidden-panel region, one float4 per thread of
+  // waves 0-1, published by the parameter block's barrier below
+  float4 ssv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (BNP) ssv = *reinterpret_cast<const float4*>(a.bn_ss + (tid & 127) * 4);
 
   // ---- parameters -> LDS: float4 index space [0, 512) = the eight LayerNorm vectors (wave w stages vector w), then
   // b1 A (FF/4) | b2 A (64) | b1 B (FF/4) | b2 B (64) | b q|k|v (192), three more float4 per thread.  Missing stages and
@@ -1676,6 +1690,7 @@ __global__ __launch_bounds__(NW * 64) void chain_s_kernel(ChainArgs a) {
   const Drop dAo = TRAIN && HAS_A ? drop_make(a.da_o.seed, a.da_o.stream, a.da_o.p) : Drop{0u, 0u, 1.f};
   const Drop dBh = TRAIN && HAS_B ? drop_make(a.db_h.seed, a.db_h.stream, a.db_h.p) : Drop{0u, 0u, 1.f};
   const Drop dBo = TRAIN && HAS_B ? drop_make(a.db_o.seed, a.db_o.stream, a.db_o.p) : Drop{0u, 0u, 1.f};
+  const Drop dBn = BNP ? drop_make(a.d_bn.seed, a.d_bn.stream, a.d_bn.p) : Drop{0u, 0u, 1.f};
   const float* p0 = nullptr;
   if (HAS_A && w8 == 0) p0 = a.fa.ln_g;
   if (HAS_A && w8 == 1) p0 = a.fa.ln_b;
@@ -1707,7 +1722,30 @@ __global__ __launch_bounds__(NW * 64) void chain_s_kernel(ChainArgs a) {
   *reinterpret_cast<float4*>(Ps + ps1.dst) = pv1;
   *reinterpret_cast<float4*>(Ps + ps2.dst) = pv2;
   *reinterpret_cast<float4*>(Ps + ps3.dst) = pv3;
+  if constexpr (BNP) {
+    if (tid < 128) *reinterpret_cast<float4*>(Hraw + tid * 16) = ssv;
+  }
   __syncthreads();
+  if constexpr (BNP) {   // the conv module's tail on the register rows (bn_apply_kernel's arithmetic, element for element)
+    const float pw = a.bn_pw2_w[0], pb = a.bn_pw2_b[0];
+    const float* const ssl = reinterpret_cast<const float*>(Hraw);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(a.bn_x2 + (size_t)row * DM + (i * 8 + part) * 4);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = (i * 8 + part) * 4;
+      const float4 sc = *reinterpret_cast<const float4*>(ssl + c), sh = *reinterpret_cast<const float4*>(ssl + DM + c);
+      zr[i] = drop_apply4(dBn, (unsigned)((size_t)row * DM + c),
+                          make_float4(fmaxf(zr[i].x * sc.x + sh.x, 0.f) * pw + pb, fmaxf(zr[i].y * sc.y + sh.y, 0.f) * pw + pb,
+                                      fmaxf(zr[i].z * sc.z + sh.z, 0.f) * pw + pb, fmaxf(zr[i].w * sc.w + sh.w, 0.f) * pw + pb));
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v[i] = make_float4(v[i].x + zr[i].x, v[i].y + zr[i].y, v[i].z + zr[i].z, v[i].w + zr[i].w);
+      *reinterpret_cast<float4*>(a.bn_out + (size_t)row * DM + (i * 8 + part) * 4) = v[i];
+    }
+  }
 #ifdef P_STAMPS
   unsigned long long* const g_stamps_dev = a.stamps;
 #else
@@ -2866,6 +2904,7 @@ extern "C" int csship_encoder_chain_train(const float* x, float* x_out, const cs
                                           const float* bqkv, uint16_t* qkv_out, int32_t M, int32_t d_model, int32_t d_ffn,
                                           int32_t n_qkv, const csship_chain_train* train, csship_stream_t stream) {
   if (!train) return CSSHIP_ENULL;
+  if (!x && train->bn_x2) x = train->bn_x2;   // (with the batch-statistics prologue the rows come from bn_x2 / bn_z)
   if ((int64_t)((M + BM - 1) / BM * BM) * d_ffn > 0xffffffffLL) return CSSHIP_EBADSHAPE;  // 32-bit dropout element indices
   if ((train->pre_ln_out && !aligned16(train->pre_ln_out)) || (train->ln_out && !aligned16(train->ln_out))) return CSSHIP_EALIGN;
   TimelineScope tl(ffn_a ? CSSHIP_TL_CHAIN : CSSHIP_TL_CHAIN_EDGE, as_stream(stream));   // (bench.py's train-mode timeline)
@@ -2920,19 +2959,30 @@ static int encoder_chain_impl(const float* x, float* x_out, const float* conv_g,
     a.da_h = cfg(train->drop_a_hidden); a.da_o = cfg(train->drop_a_out);
     a.db_h = cfg(train->drop_b_hidden); a.db_o = cfg(train->drop_b_out);
     a.pre_ln_out = train->pre_ln_out; a.ln_out = train->ln_out;
+    const bool bnp = train->bn_z != nullptr;
+    if (bnp) {
+      if (!train->bn_x2 || !train->bn_scale_shift || !train->bn_pw2_w || !train->bn_pw2_b || !train->bn_out) return CSSHIP_ENULL;
+      if (!aligned16(train->bn_z) || !aligned16(train->bn_x2) || !aligned16(train->bn_scale_shift) || !aligned16(train->bn_out)) return CSSHIP_EALIGN;
+      if ((int64_t)M * DM > 0xffffffffLL) return CSSHIP_EBADSHAPE;
+      a.bn_z = train->bn_z; a.bn_x2 = train->bn_x2; a.bn_ss = train->bn_scale_shift; a.bn_pw2_w = train->bn_pw2_w; a.bn_pw2_b = train->bn_pw2_b;
+      a.d_bn = cfg(train->drop_bn); a.bn_out = train->bn_out;
+    }
     if ((A && !ffn_a->ln_g) || (Bs && !ffn_b->ln_g)) return CSSHIP_EUNSUPPORTED;  // folded LayerNorms belong to the inference packing
     if (st_ok && Bs && Cq && (!A || (a.pre_ln_out != nullptr && a.ln_out != nullptr))) {
       // the pipelined stages are OFF for the training form: with the dropout hashes riding in the W2 passes the kernel
       // needs 264 registers (8 spilled) and measured 10.92 against 10.87 ms per training step; CSSHIP_CHAIN_PIPE_TRAIN=1 runs it
       static const bool use_pipe_t = [] { const char* e = getenv("CSSHIP_CHAIN_PIPE_TRAIN"); return e != nullptr && atoi(e) != 0; }();
       const bool pipe_t = use_pipe_t && d_ffn >= 2 * DM;
-      if (A && pipe_t) hipLaunchKernelGGL((chain_s_kernel<NWAVES, true, true, true, true, false, true>), grid, block, 0, s, a);
+      if (bnp && !A) return CSSHIP_EUNSUPPORTED;
+      if (bnp) hipLaunchKernelGGL((chain_s_kernel<NWAVES, true, true, true, true, false, false, true>), grid, block, 0, s, a);
+      else if (A && pipe_t) hipLaunchKernelGGL((chain_s_kernel<NWAVES, true, true, true, true, false, true>), grid, block, 0, s, a);
       else if (pipe_t) hipLaunchKernelGGL((chain_s_kernel<NWAVES, false, true, true, true, false, true>), grid, block, 0, s, a);
       else if (A) hipLaunchKernelGGL((chain_s_kernel<NWAVES, true, true, true, true, false>), grid, block, 0, s, a);
       else hipLaunchKernelGGL((chain_s_kernel<NWAVES, false, true, true, true, false>), grid, block, 0, s, a);
       CSSHIP_CHECK_LAUNCH();
       return CSSHIP_OK;
     }
+    if (bnp) return CSSHIP_EUNSUPPORTED;   // (the batch-statistics prologue lives in the static form: whole 64-row panels)
     if (A && Bs && Cq) hipLaunchKernelGGL((chain_kernel<NWAVES, false, true, true, true, true>), grid, block, 0, s, a);
     else if (!A && Bs && Cq) hipLaunchKernelGGL((chain_kernel<NWAVES, false, false, true, true, true>), grid, block, 0, s, a);
     else return CSSHIP_EUNSUPPORTED;

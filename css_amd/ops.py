@@ -313,7 +313,7 @@ def convmod(x, weights, kernel_size=33, batch_stats=False, return_workspace=Fals
     return (y, ws) if return_workspace else y
 
 
-def outproj_conv_train(attn_out, wo_packed, bo, x, weights, B, T, kernel_size=33, drop_proj=None, drop_conv=None):
+def outproj_conv_train(attn_out, wo_packed, bo, x, weights, B, T, kernel_size=33, drop_proj=None, drop_conv=None, apply=True):
     """Training form of the attention output projection + conv module (csship_outproj_conv_train, d_model 256, centred
     taps, batch-statistics BatchNorm): x2 = x + D(attn_out Wo^T + bo), y = x2 + ConvModule_train(x2) in three launches.
     attn_out bf16 [B*T, 256], x f32 [B*T, 256].  Returns (x2, y, workspace): the workspace is the one ops.convmod(...,
@@ -323,10 +323,12 @@ def outproj_conv_train(attn_out, wo_packed, bo, x, weights, B, T, kernel_size=33
     if not (attn_out.is_contiguous() and x.is_contiguous()) or attn_out.shape != (B * T, D) or x.shape != (B * T, D):
         raise RuntimeError("css_amd: outproj_conv_train expects dense [B*T, 256] operands")
     cw = conv_weights_struct(weights)
-    x2, y = torch.empty_like(x), torch.empty_like(x)
+    # apply=False: the BatchNorm statistics are reduced into the workspace and the module's tail (BatchNorm apply, ReLU, affine,
+    # dropout, residual) is left to the chain kernel that consumes the rows (encoder_chain_train(bn=...)); y is None then
+    x2, y = torch.empty_like(x), (torch.empty_like(x) if apply else None)
     ws = torch.empty(lib().csship_convmod_workspace(B, T, D), device=x.device, dtype=torch.uint8)
     check(lib().csship_outproj_conv_train(_ptr(attn_out), _ptr(wo_packed), _ptr(bo), _ptr(x), _ptr(x2), _ptr(y), C.byref(cw),
-                                          B, T, D, kernel_size, drop_proj, drop_conv, _ptr(ws), _stream()))
+                                          B, T, D, kernel_size, drop_proj, drop_conv if apply else None, _ptr(ws), _stream()))
     return x2, y, ws
 
 
@@ -721,11 +723,19 @@ def _ffn_struct(ln, w1p, b1, w2p, b2):
     return w
 
 
-def encoder_chain_train(x, d_ffn, ffn_b, qkv, ffn_a=None, final_ln=None, drops=(None, None, None, None)):
+def encoder_chain_train(x, d_ffn, ffn_b, qkv, ffn_a=None, final_ln=None, drops=(None, None, None, None), bn=None):
     """csship_encoder_chain_train on x f32 [M,256] (the training forward through the chain kernel).  ffn_a / ffn_b:
     (ln=(g,b), w1p, b1, w2p, b2); final_ln: (g, b) behind ffn_a; qkv: (ln=(g,b), wqkv_packed, bqkv, n_qkv); drops: dropout
     cfg pointers (a.hidden, a.out, b.hidden, b.out).  Returns (x_out, qkv_bf16, pre_ln_rows, ln_rows) - the last two
-    None without ffn_a."""
+    None without ffn_a.
+    bn = (x2, workspace, weights, drop_conv) behind outproj_conv_train(..., apply=False): x is ignored, the kernel forms its
+    input rows x3 = x2 + dropout(pw2(relu(BatchNorm(z)))) itself (whole 64-row panels only) and a fifth result, x3, is
+    returned."""
+    x3 = None
+    if bn is not None:
+        x2, ws, cwd, drop_conv = bn
+        _need(x2, torch.float32, "x2")
+        x = x2
     _need(x, torch.float32, "x")
     assert x.dim() == 2 and x.is_contiguous() and x.shape[1] == 256
     M = x.shape[0]
@@ -739,11 +749,17 @@ def encoder_chain_train(x, d_ffn, ffn_b, qkv, ffn_a=None, final_ln=None, drops=(
     tr = _lib.ChainTrain()
     tr.drop_a_hidden, tr.drop_a_out, tr.drop_b_hidden, tr.drop_b_out = (d if d is not None else None for d in drops)
     tr.pre_ln_out, tr.ln_out = (pre.data_ptr() if pre is not None else None), (lnr.data_ptr() if lnr is not None else None)
+    if bn is not None:
+        wsf = ws.view(torch.float32)
+        x3 = torch.empty_like(x)
+        tr.bn_z, tr.bn_x2, tr.bn_scale_shift = wsf.data_ptr(), x2.data_ptr(), wsf[-4 * 256:].data_ptr()
+        tr.bn_pw2_w, tr.bn_pw2_b = _need(cwd["pw2_w"], torch.float32, "pw2_w").data_ptr(), _need(cwd["pw2_b"], torch.float32, "pw2_b").data_ptr()
+        tr.drop_bn, tr.bn_out = drop_conv, x3.data_ptr()
     check(lib().csship_encoder_chain_train(
         _ptr(x), _ptr(out), C.byref(fa) if fa is not None else None,
         _ptr(final_ln[0]) if final_ln else None, _ptr(final_ln[1]) if final_ln else None, C.byref(fb),
         _ptr(qkv[0][0]), _ptr(qkv[0][1]), _ptr(qkv[1]), _ptr(qkv[2]), _ptr(q_out), M, 256, d_ffn, n_qkv, C.byref(tr), _stream()))
-    return out, q_out, pre, lnr
+    return (out, q_out, pre, lnr, x3) if bn is not None else (out, q_out, pre, lnr)
 
 
 def encoder_chain(x, d_ffn, ffn_a=None, final_ln=None, ffn_b=None, qkv=None, out=None, flags=0):

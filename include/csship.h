@@ -347,6 +347,14 @@ typedef struct {
   const csship_dropout_cfg *drop_a_hidden, *drop_a_out, *drop_b_hidden, *drop_b_out;  /* NULL = no dropout */
   float* pre_ln_out;  /* optional, with ffn_a: rows in front of the final LayerNorm (f32 [M, 256]) */
   float* ln_out;      /* optional, with ffn_a: rows behind it = stage B's input */
+  /* Optional (bn_z != NULL; needs ffn_a and whole 64-row panels): the kernel forms its own input rows - the tail of the conv
+   * module behind csship_outproj_conv_train(..., y = NULL): x3 = bn_x2 + dropout(pw2_w * relu(bn_z * scale + shift) + pw2_b)
+   * (conformer.py:298-303; bn_z = the workspace's pre-BatchNorm activations, bn_scale_shift = its scale | shift block,
+   * f32 [2 * 256]; drop_bn = the module's final dropout, element index row * 256 + channel) - and writes them to bn_out
+   * (f32 [M, 256]).  `x` is ignored then.  Replaces the BatchNorm-apply launch. */
+  const float *bn_z, *bn_x2, *bn_scale_shift, *bn_pw2_w, *bn_pw2_b;
+  const csship_dropout_cfg* drop_bn;
+  float* bn_out;
 } csship_chain_train;
 int csship_encoder_chain_train(const float* x, float* x_out, const struct csship_ffn_weights_s* ffn_a,
                                const float* final_ln_g, const float* final_ln_b, const struct csship_ffn_weights_s* ffn_b,
@@ -660,6 +668,8 @@ int csship_outproj_conv(const uint16_t* attn_out, const uint16_t* wo_packed, con
  * statistics), then the BatchNorm reduce and apply kernels of csship_convmod finish.  workspace: csship_convmod_workspace
  * bytes, left exactly as csship_convmod(bn_mode 1) leaves it (csship_convmod_bwd* take it).  d_model 256, kernel 33,
  * centred taps; drop_proj indexes [B*T, 256] row-major like csship_panel_linear_drop, drop_conv like csship_convmod_drop. */
+/* (y may be NULL: the BatchNorm statistics are reduced into the workspace, the apply pass is left to the consumer -
+ * csship_encoder_chain_train's bn_* fields) */
 int csship_outproj_conv_train(const uint16_t* attn_out, const uint16_t* wo_packed, const float* bo, const float* x,
                               float* x2_out, float* y, const csship_conv_weights* w, int32_t B, int32_t T, int32_t d_model,
                               int32_t kernel_size, const csship_dropout_cfg* drop_proj, const csship_dropout_cfg* drop_conv,

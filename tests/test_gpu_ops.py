@@ -455,6 +455,41 @@ def test_outproj_conv_train_equals_the_two_operators(ops, B, T, drop):
         assert err(y.view(B, T, D), ref) < 3e-4
 
 
+@pytest.mark.parametrize("B,T,drop", [(2, 64, False), (3, 128, True), (32, 400, True)])
+def test_chain_train_forms_its_own_input_rows_behind_the_conv_module(ops, B, T, drop):
+    """Round 6: csship_encoder_chain_train with the bn_* fields behind csship_outproj_conv_train(..., y = NULL) - the conv
+    module's tail (BatchNorm apply, ReLU, affine, dropout, residual; conformer.py:298-303) in the chain kernel's prologue
+    instead of a launch of its own - against the two-launch form: the rows x3 and every output of the chain BIT FOR BIT (the
+    same arithmetic, element for element)."""
+    from css_amd.dropout import DropState
+    sd, dw = _conv_weights(31)
+    D, FF = 256, 1024
+    M = B * T
+    x1 = rnd((M, D), 52).to(DEV)
+    ao = rnd((M, D), 53).to(DEV).to(torch.bfloat16)
+    wo, bo = rnd((D, D), 54, 1 / 16).to(DEV), rnd((D,), 55, 0.1).to(DEV)
+    wp = ops.pack_frag(wo)
+    st = DropState(torch.tensor([11], dtype=torch.int32, device=DEV), 0.1 if drop else 0.0, 0)
+    g1, b0 = (1 + 0.1 * rnd((D,), 56)).to(DEV), (0.1 * rnd((D,), 57)).to(DEV)
+
+    def ffn_w(seed):
+        return ((g1, b0), ops.pack_frag(rnd((FF, D), seed, 1 / 16).to(DEV)), (0.1 * rnd((FF,), seed + 1)).to(DEV),
+                ops.pack_frag(rnd((D, FF), seed + 2, 1 / 32).to(DEV)), (0.1 * rnd((D,), seed + 3)).to(DEV))
+    fa, fb = ffn_w(60), ffn_w(70)
+    wq, bq = ops.pack_frag(rnd((768, D), 80, 1 / 16).to(DEV)), (0.1 * rnd((768,), 81)).to(DEV)
+    drops = tuple(st.cfg(f"2.{t}") for t in ("ffn_out.hidden", "ffn_out.out", "ffn_in.hidden", "ffn_in.out"))
+    dp, dc = st.cfg("2.attn.out"), st.cfg("2.conv.out")
+    x2a, x3a, wsa = ops.outproj_conv_train(ao, wp, bo, x1, dw, B, T, 33, drop_proj=dp, drop_conv=dc)
+    ref = ops.encoder_chain_train(x3a, FF, fb, ((g1, b0), wq, bq, 768), ffn_a=fa, final_ln=(g1, b0), drops=drops)
+    x2b, none, wsb = ops.outproj_conv_train(ao, wp, bo, x1, dw, B, T, 33, drop_proj=dp, drop_conv=dc, apply=False)
+    assert none is None and torch.equal(x2a, x2b)
+    got = ops.encoder_chain_train(None, FF, fb, ((g1, b0), wq, bq, 768), ffn_a=fa, final_ln=(g1, b0), drops=drops,
+                                  bn=(x2b, wsb, dw, dc))
+    assert torch.equal(got[4], x3a)
+    for a, b in zip(got[:4], ref):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("batch_stats", [False, True])
 def test_convmod_causal_golden(ops, golden, batch_stats):
     """csship_conv_weights.causal: the causal ConvModule (conformer.py:265-273, 297-298) against the reference's own
