@@ -115,6 +115,7 @@ SIGNATURES = {
     "csship_panel_linear": (_i32, [_p, _i32, _p, _p, _p, _p, _p, _i64, _f32, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "csship_panel_linear_drop": (_i32, [_p, _i32, _p, _p, _p, _p, _p, _i64, _f32, _p, _i64, _i32, _i32, _i32, _i32, _dc, _p]),
     "csship_embed": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
+    "csship_embed_train": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _i32, _i32, _i32, _i32, _dc, _p]),
     "csship_outproj_glu": (_i32, [_p, _p, _p, _p, _p, C.POINTER(ConvWeights), _p, _i32, _i32, _p]),
     "csship_encoder_chain_train": (_i32, [_p, _p, C.POINTER(FfnWeights), _p, _p, C.POINTER(FfnWeights), _p, _p, _p, _p, _p,
                                    _i32, _i32, _i32, _i32, C.POINTER(ChainTrain), _p]),

@@ -25,6 +25,7 @@ _NO_FFN_LN = bool(os.environ.get("CSSHIP_NO_FFN_LN"))       # A/B timing: the bl
 _NO_CONV_NEXT = bool(os.environ.get("CSSHIP_NO_CONV_NEXT"))  # A/B timing: dropout(dx) for the output projection's backward as its own pass
 _NO_DROP_EPI = bool(os.environ.get("CSSHIP_NO_DROP_EPI"))   # A/B timing: output-projection dropout as its own pass
 _NO_LN2 = bool(os.environ.get("CSSHIP_NO_LN2_FUSE"))   # A/B timing: every block's final LayerNorm backward as its own launch
+_NO_EMBED_TRAIN = bool(os.environ.get("CSSHIP_NO_EMBED_TRAIN"))   # A/B timing: the training embedding as four launches
 _NO_BN_IN_CHAIN = bool(os.environ.get("CSSHIP_NO_BN_IN_CHAIN"))   # A/B timing: the conv module's BatchNorm-apply pass as its own launch
 _NO_OC_TRAIN = bool(os.environ.get("CSSHIP_NO_OC_TRAIN"))   # A/B timing: output projection and conv module's first kernel as two launches
 
@@ -172,7 +173,15 @@ def _conformer_pack_plan(model, wide, device):
     D = enc.d_model
     plan = ob.PackPlan(device)
     ent = {"wide": wide, "device": device, "plan": plan, "layers": []}
-    ent["we_bf"] = plan.add(enc.embed[0].weight.detach(), want_row_major=True)[0]
+    we = enc.embed[0].weight.detach()
+    ent["we_p"] = None
+    if not wide:   # + the fragment table of the fused training embedding (csship_embed_train): K zero-padded to a multiple of 256
+        kp = (we.shape[1] + 255) // 256 * 256
+        ent["we_p"] = torch.zeros(we.shape[0] * kp, dtype=BF, device=device)
+        ent["we_bf"] = plan.add(we, want_row_major=True)[0]
+        plan.add(we, frag=ent["we_p"], k0=0, k_total=kp)
+    else:
+        ent["we_bf"] = plan.add(we, want_row_major=True)[0]
     wh = model.linear.weight.detach()   # row-major shadow with zero rows up to a multiple of 8 (bw.head_bwd)
     wh_rm = torch.zeros(((wh.shape[0] + 7) // 8 * 8, (wh.shape[1] + 7) // 8 * 8), dtype=torch.bfloat16, device=device)
     ent["wh_bf"], ent["wh_p"] = plan.add(wh, row_major=wh_rm, want_frag=not wide)
@@ -255,11 +264,15 @@ class ConformerTrain(torch.autograd.Function):
         pack = _conformer_pack_plan(model, wide, f.device)
         pack["plan"].run()
         we_bf = pack["we_bf"]
-        fn = ob.mvn_apply(f, mean, rinv, Kp)
-        e = ob.bgemm(fn, we_bf, bias=enc.embed[0].bias.detach())
-        _, x = ops.layernorm_relu(e, enc.embed[1].weight.detach(), enc.embed[1].bias.detach())
-        if ds.active:  # conformer.py:127 drops before the ReLU; relu(drop(v)) == drop(relu(v)) (the scale is positive)
-            ops.dropout_apply(x, ds.cfg("embed"))
+        if pack["we_p"] is not None and not _NO_EMBED_TRAIN:   # MVN + Linear + LayerNorm + ReLU + dropout: one kernel (round 6)
+            x, fn, e = ops.embed_train(f, mean, rinv, pack["we_p"], enc.embed[0].bias.detach(), enc.embed[1].weight.detach(),
+                                       enc.embed[1].bias.detach(), drop=ds.cfg("embed"))
+        else:
+            fn = ob.mvn_apply(f, mean, rinv, Kp)
+            e = ob.bgemm(fn, we_bf, bias=enc.embed[0].bias.detach())
+            _, x = ops.layernorm_relu(e, enc.embed[1].weight.detach(), enc.embed[1].bias.detach())
+            if ds.active:  # conformer.py:127 drops before the ReLU; relu(drop(v)) == drop(relu(v)) (the scale is positive)
+                ops.dropout_apply(x, ds.cfg("embed"))
         S["we_bf"], S["fn"] = we_bf, fn   # (the normalised features, 6.7 MB in bf16, kept for the embed weight gradient)
         pe = model.position_table()
         # packed table of the forward, bf16 table, window (+ its transpose for csship_attn_pos_bwd up to 449 frames) of

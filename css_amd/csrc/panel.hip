@@ -2094,9 +2094,16 @@ struct EmbedArgs {
   float* out;
   int M, T, idim, Kp;
   int64_t ldf;
+  // TRAIN (csship_embed_train): what the backward keeps - the normalised features as the bf16 operand of the weight gradient
+  // (fn_out [M, ldfn], zero beyond idim) and the rows in front of the LayerNorm (e_out f32 [M, 256]) - and the embedding's
+  // dropout (conformer.py:127; relu(drop(v)) == drop(relu(v)): the scale is positive)
+  unsigned short* fn_out;
+  int ldfn;
+  float* e_out;
+  csship_dropout_cfg drop;
 };
 
-template <int NW>
+template <int NW, bool TRAIN = false>
 __global__ __launch_bounds__(NW * 64) void embed_kernel(EmbedArgs a) {
   static_assert(NW * 64 == 8 * BM, "row phases assume 8 lanes per panel row");
   constexpr int NT = 16 / NW;
@@ -2137,7 +2144,11 @@ __global__ __launch_bounds__(NW * 64) void embed_kernel(EmbedArgs a) {
           for (int q = 0; q < 4; ++q) e[q] = (k + q < a.idim) ? (fr[k + q] - a.mean[sb + k + q]) * a.rinv[sb + k + q] : 0.f;
         }
       }
-      *reinterpret_cast<uint2*>(Xs + panel_off(r, c4 >> 1) + (c4 & 1) * 8) = make_uint2(pack_bf2(e[0], e[1]), pack_bf2(e[2], e[3]));
+      const uint2 pk = make_uint2(pack_bf2(e[0], e[1]), pack_bf2(e[2], e[3]));
+      *reinterpret_cast<uint2*>(Xs + panel_off(r, c4 >> 1) + (c4 & 1) * 8) = pk;
+      if constexpr (TRAIN) {
+        if (row < a.M && k < a.ldfn) *reinterpret_cast<uint2*>(a.fn_out + (size_t)row * a.ldfn + k) = pk;
+      }
     }
     __syncthreads();
     const bf16x8* wc = wbase + (size_t)kc * KS * 64;
@@ -2154,6 +2165,9 @@ __global__ __launch_bounds__(NW * 64) void embed_kernel(EmbedArgs a) {
   for (int i = 0; i < 8; ++i) {
     v[i] = *reinterpret_cast<const float4*>(Ys + r * YS + (i * 8 + part) * 4);
     s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    if constexpr (TRAIN) {
+      if (row < a.M) *reinterpret_cast<float4*>(a.e_out + (size_t)row * DM + (i * 8 + part) * 4) = v[i];
+    }
   }
   const float mean = sum8(s) * (1.f / DM);
   float ss = 0.f;
@@ -2163,15 +2177,17 @@ __global__ __launch_bounds__(NW * 64) void embed_kernel(EmbedArgs a) {
     ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
   }
   const float rstd = rsqrtf(sum8(ss) * (1.f / DM) + 1e-5f);
+  const Drop dp = TRAIN ? drop_make(a.drop.seed, a.drop.stream, a.drop.p) : Drop{0u, 0u, 1.f, 0x80008000u};
   if (row < a.M) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int c = (i * 8 + part) * 4;
       const float4 gm = *reinterpret_cast<const float4*>(a.ln_g + c);
       const float4 bt = *reinterpret_cast<const float4*>(a.ln_b + c);
-      *reinterpret_cast<float4*>(a.out + (size_t)row * DM + c) =
-          make_float4(fmaxf(v[i].x * rstd * gm.x + bt.x, 0.f), fmaxf(v[i].y * rstd * gm.y + bt.y, 0.f),
-                      fmaxf(v[i].z * rstd * gm.z + bt.z, 0.f), fmaxf(v[i].w * rstd * gm.w + bt.w, 0.f));
+      float4 y = make_float4(fmaxf(v[i].x * rstd * gm.x + bt.x, 0.f), fmaxf(v[i].y * rstd * gm.y + bt.y, 0.f),
+                             fmaxf(v[i].z * rstd * gm.z + bt.z, 0.f), fmaxf(v[i].w * rstd * gm.w + bt.w, 0.f));
+      if constexpr (TRAIN) y = drop_apply4(dp, (unsigned)((size_t)row * DM + c), y);
+      *reinterpret_cast<float4*>(a.out + (size_t)row * DM + c) = y;
     }
   }
 }
@@ -3038,8 +3054,31 @@ extern "C" int csship_embed(const float* f, int64_t ldf, const float* mvn_mean, 
   if (d_model != DM) return CSSHIP_EUNSUPPORTED;
   if (!aligned16(w_packed) || !aligned16(out) || !aligned16(bias) || !aligned16(ln_g) || !aligned16(ln_b)) return CSSHIP_EALIGN;
   const int Kp = (idim + DM - 1) / DM * DM;
-  EmbedArgs a{f, mvn_mean, mvn_rinv, reinterpret_cast<const bf16x8*>(w_packed), bias, ln_g, ln_b, out, B * T, T, idim, Kp, ldf};
+  EmbedArgs a{f, mvn_mean, mvn_rinv, reinterpret_cast<const bf16x8*>(w_packed), bias, ln_g, ln_b, out, B * T, T, idim, Kp, ldf,
+              nullptr, 0, nullptr, csship_dropout_cfg{nullptr, 0u, 0.f}};
   hipLaunchKernelGGL((embed_kernel<NWAVES>), dim3((B * T + BM - 1) / BM), dim3(NWAVES * 64), 0, as_stream(stream), a);
+  CSSHIP_CHECK_LAUNCH();
+  return CSSHIP_OK;
+}
+
+extern "C" int csship_embed_train(const float* f, int64_t ldf, const float* mvn_mean, const float* mvn_rinv,
+                                  const uint16_t* w_packed, const float* bias, const float* ln_g, const float* ln_b, float* out,
+                                  uint16_t* fn_bf16, int32_t ld_fn, float* e_out, int32_t B, int32_t T, int32_t idim,
+                                  int32_t d_model, const csship_dropout_cfg* drop, csship_stream_t stream) {
+  if (!f || !mvn_mean || !mvn_rinv || !w_packed || !bias || !ln_g || !ln_b || !out || !fn_bf16 || !e_out) return CSSHIP_ENULL;
+  if (B <= 0 || T <= 0 || idim <= 0 || ldf < idim || ld_fn < idim || (ld_fn & 7) != 0 || (int64_t)B * T * DM > 0xffffffffLL)
+    return CSSHIP_EBADSHAPE;
+  if (d_model != DM) return CSSHIP_EUNSUPPORTED;
+  if (!aligned16(w_packed) || !aligned16(out) || !aligned16(bias) || !aligned16(ln_g) || !aligned16(ln_b) || !aligned16(fn_bf16) ||
+      !aligned16(e_out))
+    return CSSHIP_EALIGN;
+  const int Kp = (idim + DM - 1) / DM * DM;
+  if (ld_fn > Kp) return CSSHIP_EBADSHAPE;   // (the kernel writes fn while it builds its K panels)
+  const bool dropping = drop && drop->seed && drop->p > 0.f;
+  EmbedArgs a{f, mvn_mean, mvn_rinv, reinterpret_cast<const bf16x8*>(w_packed), bias, ln_g, ln_b, out, B * T, T, idim, Kp, ldf,
+              fn_bf16, ld_fn, e_out, dropping ? *drop : csship_dropout_cfg{nullptr, 0u, 0.f}};
+  TimelineScope tl(CSSHIP_TL_EMBED, as_stream(stream));
+  hipLaunchKernelGGL((embed_kernel<NWAVES, true>), dim3((B * T + BM - 1) / BM), dim3(NWAVES * 64), 0, as_stream(stream), a);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;
 }

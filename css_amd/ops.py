@@ -723,6 +723,23 @@ def _ffn_struct(ln, w1p, b1, w2p, b2):
     return w
 
 
+def embed_train(f, mean, rinv, w_packed, bias, ln_g, ln_b, drop=None):
+    """Training form of the embedding (csship_embed_train): x0 = dropout(ReLU(LayerNorm(Linear(MVN_time(f))))) from f f32
+    [B,T,idim], one kernel; also returns what the backward keeps.  w_packed: fragment-packed [256, Kp] with Kp = idim rounded
+    up to 256, zero padded.  -> (x0 f32 [B*T,256], fn bf16 [B*T, pad8(idim)], e f32 [B*T,256])."""
+    _need(f, torch.float32, "f")
+    B, T, F = f.shape
+    if f.stride(2) != 1 or f.stride(0) != T * f.stride(1):
+        f = f.contiguous()
+    M, ldfn = B * T, (F + 7) // 8 * 8
+    out = torch.empty((M, 256), dtype=torch.float32, device=f.device)
+    e = torch.empty_like(out)
+    fn = torch.empty((M, ldfn), dtype=torch.bfloat16, device=f.device)
+    check(lib().csship_embed_train(_ptr(f), f.stride(1), _ptr(mean), _ptr(rinv), _ptr(w_packed), _ptr(bias), _ptr(ln_g), _ptr(ln_b),
+                                   _ptr(out), _ptr(fn), ldfn, _ptr(e), B, T, F, 256, drop, _stream()))
+    return out, fn, e
+
+
 def encoder_chain_train(x, d_ffn, ffn_b, qkv, ffn_a=None, final_ln=None, drops=(None, None, None, None), bn=None):
     """csship_encoder_chain_train on x f32 [M,256] (the training forward through the chain kernel).  ffn_a / ffn_b:
     (ln=(g,b), w1p, b1, w2p, b2); final_ln: (g, b) behind ffn_a; qkv: (ln=(g,b), wqkv_packed, bqkv, n_qkv); drops: dropout

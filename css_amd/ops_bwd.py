@@ -417,8 +417,10 @@ class PackPlan:
             row_major = torch.empty((R, (K + 7) // 8 * 8), dtype=torch.bfloat16, device=w.device)
         if want_frag and frag is None:
             frag = torch.empty(((R + 15) // 16 * 16) * ((K + 31) // 32 * 32), dtype=torch.bfloat16, device=w.device)
-        if k_total and (frag is None or k0 % 32 or k_total % 32 or K % 32 or k0 + K > k_total or row_major is not None):
-            raise RuntimeError("css_amd: a k-slice job needs its fragment table, whole 32-wide k-steps and no row-major copy")
+        # (a slice that starts at 0 may end inside a k-step: the job writes zeros up to the step's end, the table beyond it stays
+        # as allocated - zeros for a K-padded table like the embedding's)
+        if k_total and (frag is None or k0 % 32 or k_total % 32 or (K % 32 and k0) or k0 + (K + 31) // 32 * 32 > k_total):
+            raise RuntimeError("css_amd: a k-slice job needs its fragment table and whole 32-wide k-steps")
         self.jobs.append((w, row_major, frag, float(scale), bool(transposed), int(row0), int(k0), int(k_total)))
         self.table = None
         return row_major, frag

@@ -369,6 +369,14 @@ int csship_encoder_chain_train(const float* x, float* x_out, const struct csship
 int csship_embed(const float* f, int64_t ldf, const float* mvn_mean, const float* mvn_rinv,
                  const uint16_t* w_packed, const float* bias, const float* ln_g, const float* ln_b,
                  float* out, int32_t B, int32_t T, int32_t idim, int32_t d_model, csship_stream_t stream);
+/* Training form: the same kernel also leaves what the backward keeps - fn_bf16 = MVN_time(f) as bf16 [B*T, ld_fn] (ld_fn a
+ * multiple of 8 with idim <= ld_fn <= Kp, zero beyond idim: the operand of the embedding's weight gradient) and e_out = the
+ * rows in front of the LayerNorm (f32 [B*T, 256]) - and applies the embedding's dropout (conformer.py:127, element index
+ * row * 256 + column; NULL = none).  Replaces csship_mvn_apply + csship_bgemm + csship_layernorm_relu + csship_dropout_apply. */
+int csship_embed_train(const float* f, int64_t ldf, const float* mvn_mean, const float* mvn_rinv,
+                       const uint16_t* w_packed, const float* bias, const float* ln_g, const float* ln_b, float* out,
+                       uint16_t* fn_bf16, int32_t ld_fn, float* e_out, int32_t B, int32_t T, int32_t idim, int32_t d_model,
+                       const csship_dropout_cfg* drop, csship_stream_t stream);
 
 /* Relative-position multi-head attention core, MultiHeadedAttention.forward
  * (css/models/conformer.py:229-253) with RelativePositionalEncoding

@@ -455,6 +455,36 @@ def test_outproj_conv_train_equals_the_two_operators(ops, B, T, drop):
         assert err(y.view(B, T, D), ref) < 3e-4
 
 
+@pytest.mark.parametrize("B,T,F,drop", [(2, 100, 257, False), (3, 64, 257, True), (2, 70, 1799, True)])
+def test_embed_train_equals_the_four_launches(ops, B, T, F, drop):
+    """csship_embed_train (MVN + Linear + LayerNorm + ReLU + dropout in one kernel, keeping the backward's operands) against
+    csship_mvn_apply + csship_bgemm + csship_layernorm_relu + csship_dropout_apply: the bf16 normalised features bit for
+    bit, the pre-LayerNorm rows and the output within the two GEMMs' summation orders, the same dropout mask."""
+    from css_amd import ops_bwd as ob
+    from css_amd.dropout import DropState
+    D = 256
+    f = rnd((B, T, F), 90).abs().to(DEV)
+    w = rnd((D, F), 91, F ** -0.5).to(DEV)
+    b, g, be = (0.1 * rnd((D,), 92)).to(DEV), (1 + 0.1 * rnd((D,), 93)).to(DEV), (0.1 * rnd((D,), 94)).to(DEV)
+    mean, rinv = ops.mvn_stats(f)
+    kp = (F + 255) // 256 * 256
+    wp = torch.zeros(D, kp, device=DEV)
+    wp[:, :F] = w
+    st = DropState(torch.tensor([7], dtype=torch.int32, device=DEV), 0.1, 0)   # (owns the seed word and the cfg structs)
+    cfg = st.cfg("embed") if drop else None
+    x, fn, e = ops.embed_train(f, mean, rinv, ops.pack_frag(wp), b, g, be, drop=cfg)
+    Kp8 = (F + 7) // 8 * 8
+    fn0 = ob.mvn_apply(f, mean, rinv, Kp8)
+    w_bf, _ = ob.pack_weight(w, want_row_major=True)
+    e0 = ob.bgemm(fn0, w_bf, bias=b)
+    _, x0 = ops.layernorm_relu(e0, g, be)
+    if drop:
+        ops.dropout_apply(x0, cfg)
+    assert torch.equal(fn, fn0)
+    assert err(e, e0) < 2e-5 and err(x, x0) < 1e-4
+    assert torch.equal(x == 0, x0 == 0) or float(((x == 0) != (x0 == 0)).float().mean()) < 1e-4   # same mask (ReLU zeros may flip at 0)
+
+
 @pytest.mark.parametrize("B,T,drop", [(2, 64, False), (3, 128, True), (32, 400, True)])
 def test_chain_train_forms_its_own_input_rows_behind_the_conv_module(ops, B, T, drop):
     """Round 6: csship_encoder_chain_train with the bn_* fields behind csship_outproj_conv_train(..., y = NULL) - the conv
