@@ -21,6 +21,11 @@
 
 namespace {
 
+#ifndef MX_ABL
+#define MX_ABL 0   // diagnostic builds only (tools/ffn_mx_ablate.sh): bit 0 no scaled MFMAs, 1 no weight / scale loads in the loop,
+                   // 2 no hidden quantisation (max, scale, convert, LDS store), 3 no LayerNorm + quantisation prologue,
+                   // 4 no row epilogue (finish_rows), 5 no operand fragment reads from LDS
+#endif
 constexpr int BM = 64;   // token rows per workgroup
 constexpr int PDM = 2;   // MXFP8 weight prefetch distance (128-deep k-steps)
 typedef __attribute__((ext_vector_type(8))) int i32x8;
@@ -404,6 +409,7 @@ template <int ROWB>
 DEV int poff8(int row, int byte) { return row * (ROWB + 32) + byte; }
 template <int ROWB>
 DEV i32x8 lds_frag(const unsigned char* panel8, int row, int ks, int g) {
+  if (MX_ABL & 32) { i32x8 z = {row, ks, g, 0, 0, 0, 0, 0}; return z; }
   const unsigned char* p = panel8 + poff8<ROWB>(row, 16 * g);
   return frag8(*reinterpret_cast<const i32x4*>(p + ks * 128), *reinterpret_cast<const i32x4*>(p + ks * 128 + 64));
 }
@@ -445,7 +451,8 @@ struct PassMx {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt)
-        acc[t][rt] = mx_mfma_ks<STEP>(wq[STEP % PDM][t], xa[STEP % XB][rt], acc[t][rt], wsc[t][STEP >> 1], xs[rt]);
+        if (!(MX_ABL & 1)) acc[t][rt] = mx_mfma_ks<STEP>(wq[STEP % PDM][t], xa[STEP % XB][rt], acc[t][rt], wsc[t][STEP >> 1], xs[rt]);
+        else asm volatile("" : "+v"(acc[t][rt]) : "v"(wq[STEP % PDM][t]), "v"(xa[STEP % XB][rt]));
     // hipcc otherwise interchanges the unrolled nest (all k-steps of row tile 0, then of row tile 1, ...), which makes
     // every k-step's weights and fragments live at once (at d_model 512: ~140 registers spilled per chunk).  An empty
     // asm that "touches" all accumulators of the step ties the independent chains together: k-step major order.
@@ -453,7 +460,8 @@ struct PassMx {
     for (int t = 0; t < NT; ++t)
       asm volatile("" : "+v"(acc[t][0]), "+v"(acc[t][1]), "+v"(acc[t][2]), "+v"(acc[t][3]));
     __builtin_amdgcn_sched_barrier(0);
-    if (STEP + PDM < KSTEPS) {
+    if (MX_ABL & 2) {
+    } else if (STEP + PDM < KSTEPS) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) wq[STEP % PDM][t] = load_frag(w, (unsigned)(t * tstride + (STEP + PDM) * 2));
     } else if (has_next) {
@@ -539,10 +547,12 @@ __global__ __launch_bounds__(512) void ffnmx_kernel(FfnMxArgs a) {
   {  // LayerNorm -> e4m3 operand panel + block scales.  Block i of row r = the i-th piece of its 8 lanes.
     const int r = tid >> 3, part = tid & 7;
     float4 v[D / 32];
+    if (!(MX_ABL & 8)) {
     load_rows<D>(v, a.x, min(m0 + r, a.M - 1), part);
     layernorm_rows<D>(v, a.ln_g, a.ln_b, part);
+    }
 #pragma unroll
-    for (int i = 0; i < D / 32; ++i) {
+    for (int i = 0; i < ((MX_ABL & 8) ? 0 : D / 32); ++i) {
       const float am = max8(fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))));
       const unsigned sb = mx_scale_byte(am);
       const int c4 = i * 8 + part;  // 4-byte piece index in the row
@@ -581,7 +591,7 @@ __global__ __launch_bounds__(512) void ffnmx_kernel(FfnMxArgs a) {
     unsigned char* hb = H8 + (ci & 1) * (HBYTES + SC_BYTES);
     unsigned char* hsc = hb + HBYTES;
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
+    for (int rt = 0; rt < ((MX_ABL & 4) ? 0 : 4); ++rt) {
       float am = 0.f;
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -649,7 +659,7 @@ __global__ __launch_bounds__(512) void ffnmx_kernel(FfnMxArgs a) {
             make_float4(ov[0] + bb.x, ov[1] + bb.y, ov[2] + bb.z, ov[3] + bb.w);
       }
   __syncthreads();
-  finish_rows<D, FINAL_LN>(ys, a.x, a.out, a.fin_g, a.fin_b, m0, a.M, a.alpha, tid);
+  if (!(MX_ABL & 16)) finish_rows<D, FINAL_LN>(ys, a.x, a.out, a.fin_g, a.fin_b, m0, a.M, a.alpha, tid);
 }
 
 }  // namespace
