@@ -54,7 +54,9 @@ def shorten(k):
     short = k.replace("(anonymous namespace)::", "").replace("void ", "")
     return short[:short.find("(")] if "(" in short else short
 dur = {}
-for f in glob.glob("gpurun_out/${tag}_fwd_kernel_stats.csv"):
+# launch durations: the averages over the REPLAYED launches (back to back, as in the timed region); the --stats file (which also
+# counts the eager warm-up / capture launches) only for kernels the replay filter did not see
+for f in glob.glob("gpurun_out/${tag}_fwd_kernel_stats.csv") + glob.glob("gpurun_out/${tag}_fwd_replay_kernel_avg.csv"):
     for r in csv.DictReader(open(f)):
         dur[shorten(r["Name"])] = float(r["AverageNs"])
 out = {}
