@@ -627,6 +627,309 @@ __global__ __launch_bounds__(256) void glu_ln_bwd_kernel(const float* __restrict
     part[(int64_t)blockIdx.x * (2 * D + 4) + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
 
+// ---- passes A', B1, B2 and C as ONE kernel on the forward's tile structure (round 6).  The four launches above move dc
+// (written once, read twice with halo) and dg (written, read) through memory and cost 9 + 12 + 16 + 14 us per block for
+// ~4 us of traffic each; here a workgroup = (batch b, TT frames, all D channels) keeps both in LDS / registers:
+//   0  dc rows of the tile + halo from dy, z and the channel constants (the apply pass, recomputed over the halo) -> LDS
+//   1  thread (channel c, half tile): dg = dc (*) flipped taps -> scratch rows in memory (L2); its own 16 dc values stay in registers
+//   2  g = glu(LayerNorm(x)) rows of the tile + halo -> the same LDS rows (the forward's phase 1, as MODE 2 recomputes it)
+//   3  d dw_w[k][c], d dw_b[c] sums of the half tile from registers; the second half hands its 34 sums over through LDS
+//   4  pass C row-wise, dg read back from its scratch rows (NTHR / TT lanes per row): GLU backward + LayerNorm backward + residual -> dx
+//      (+ the next operator's bf16 operand), column sums of d ln_g | d ln_b through two LDS tiles, d pw1 scalars
+// One LDS buffer of TT + KS + 1 = 66 rows serves every step (67.6 KB at D = 256: two workgroups per CU).
+// Partials: part_b [tile][(KS + 1) D] (as MODE 2 leaves them), part_c [tile][2D + 4] (glu_ln_bwd_kernel's layout, one slab per
+// tile instead of one per 16 rows).
+struct ConvBwdArgs {
+  const float *x, *dy, *z, *stats, *sums;
+  csship_conv_weights w;
+  float inv_n;   // 1 / rows of the batch statistics; 0: running statistics (constants of the graph)
+  float* dx;
+  float* dg;       // [B, T, D] scratch: written in step 1, read back (from L2) by the same workgroup's pass C
+  float *part_b, *part_c;
+  int B, T;
+  csship_dropout_cfg dcfg;
+  NextOut nx;
+};
+
+template <int LR>
+DEV float sum_row_lanes(float v) {  // over aligned groups of LR = 16 / 32 lanes, result in all of them
+  static_assert(LR == 16 || LR == 32, "pass C rows are 16 or 32 lanes");
+  v = sum8(v);
+  v += dpp_mov<DPP_MIRROR>(v);
+  if constexpr (LR == 32) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const unsigned a0 = r[0], a1 = r[1];
+    v = __uint_as_float(a0) + __uint_as_float(a1);
+  }
+  return v;
+}
+
+template <int D, int TT, int KS>
+__global__ __launch_bounds__(2 * D) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_bwd_fused_kernel(ConvBwdArgs a) {
+  constexpr int ROWS = TT + KS - 1, NTHR = 2 * D, C4 = D / 4, LROWS = TT + KS + 1;
+  static_assert(LROWS >= ROWS && LROWS >= 2 * TT, "one buffer for dc / g rows, the dg tile + hand-over block, two column-sum tiles");
+  static_assert(NTHR % C4 == 0 && (ROWS * C4) % NTHR == 0, "whole float4 columns per thread in step 0");
+  __shared__ __attribute__((aligned(16))) float G[LROWS][D];
+  __shared__ float red[NTHR / 64][4];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, t0 = blockIdx.x * TT;
+  const int H3 = a.w.causal ? 0 : (KS - 1) / 2;        // rows of the dc buffer in front of the tile (input gradient: flipped taps)
+  const int H2 = a.w.causal ? KS - 1 : (KS - 1) / 2;   // rows of the g buffer in front of the tile (the forward's halo)
+
+  // ---- step 0: dc = sc * (dzh - S1 / n - zn * S2 / n), dzh = dy o mask / (1 - p) * w3 * [zh > 0]  (conv_bn_bwd_apply_kernel)
+  {
+    const Drop dp = drop_make(a.dcfg.seed, a.dcfg.stream, a.dcfg.p);
+    const int c4 = tid % C4, c = c4 * 4;
+    const float4 sc4 = *reinterpret_cast<const float4*>(a.stats + c), sh4 = *reinterpret_cast<const float4*>(a.stats + D + c);
+    const float4 mu4 = *reinterpret_cast<const float4*>(a.stats + 2 * D + c), va4 = *reinterpret_cast<const float4*>(a.stats + 3 * D + c);
+    const float4 s14 = *reinterpret_cast<const float4*>(a.sums + c), s24 = *reinterpret_cast<const float4*>(a.sums + D + c);
+    const float w3 = a.w.pw2_w[0], inv_n = a.inv_n;
+    const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w}, muv[4] = {mu4.x, mu4.y, mu4.z, mu4.w};
+    const float rsv[4] = {rsqrtf(va4.x + 1e-5f), rsqrtf(va4.y + 1e-5f), rsqrtf(va4.z + 1e-5f), rsqrtf(va4.w + 1e-5f)};
+    const float s1v[4] = {s14.x, s14.y, s14.z, s14.w}, s2v[4] = {s24.x, s24.y, s24.z, s24.w};
+    constexpr int NIT = ROWS * C4 / NTHR, RSTEP = NTHR / C4, NB = 4;   // rows in flight per thread: two batches of 4 x (dy, z)
+    static_assert(NIT % NB == 0, "whole load batches");
+#pragma unroll
+    for (int k0 = 0; k0 < NIT; k0 += NB) {
+      float4 dv[NB], zv[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const int t = t0 - H3 + tid / C4 + (k0 + k) * RSTEP;
+        const size_t i = ((size_t)b * a.T + (t >= 0 && t < a.T ? t : 0)) * C4 + c4;
+        dv[k] = reinterpret_cast<const float4*>(a.dy)[i];
+        zv[k] = reinterpret_cast<const float4*>(a.z)[i];
+      }
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const int row = tid / C4 + (k0 + k) * RSTEP, t = t0 - H3 + row;
+        const bool inside = t >= 0 && t < a.T;
+        const size_t i = ((size_t)b * a.T + (inside ? t : 0)) * C4 + c4;
+        const float4 d4 = drop_apply4(dp, (unsigned)(i * 4), dv[k]);
+        const float d[4] = {d4.x, d4.y, d4.z, d4.w}, zz[4] = {zv[k].x, zv[k].y, zv[k].z, zv[k].w};
+        float o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float zh = zz[q] * scv[q] + shv[q];
+          const float dzh = zh > 0.f ? d[q] * w3 : 0.f;
+          o[q] = inside ? scv[q] * (dzh - s1v[q] * inv_n - (zz[q] - muv[q]) * rsv[q] * s2v[q] * inv_n) : 0.f;
+        }
+        *reinterpret_cast<float4*>(&G[row][c]) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- step 1: dg of this thread's channel and half tile (convmod_kernel MODE 3), its own dc values kept
+  const int c = tid % D, half = tid / D;
+  constexpr int TH = TT / 2;
+  const int tb0 = half * TH;
+  float dcv[TH];
+  {
+    float dcol[TH + KS - 1], wk[KS], dgv[TH];
+#pragma unroll
+    for (int u = 0; u < TH + KS - 1; ++u) dcol[u] = G[tb0 + u][c];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) wk[k] = a.w.dw_w[(KS - 1 - k) * D + c];  // [k][D], flipped
+#pragma unroll
+    for (int j = 0; j < TH; ++j) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < KS; ++k) acc += wk[k] * dcol[j + k];
+      dgv[j] = acc;
+      dcv[j] = a.w.causal ? dcol[j] : dcol[j + (KS - 1) / 2];
+    }
+#pragma unroll
+    for (int j = 0; j < TH; ++j)
+      if (t0 + tb0 + j < a.T) a.dg[((size_t)b * a.T + t0 + tb0 + j) * D + c] = dgv[j];
+  }
+  __syncthreads();  // every thread has its dc column in registers
+
+  // ---- step 2: g = glu(LayerNorm(x)) rows (tile + halo) into the same rows: convmod_kernel's phase 1
+  {
+    const float w0 = a.w.pw1_w[0], w1 = a.w.pw1_w[1], b0 = a.w.pw1_b[0], b1 = a.w.pw1_b[1];
+    constexpr int LPR = D / 32, RPB = NTHR / LPR;
+    static_assert(LPR == 8 || LPR == 16, "row reductions are written for 8 or 16 lanes per row");
+    const int part = tid % LPR;
+#pragma unroll
+    for (int r0 = 0; r0 < ROWS; r0 += RPB) {
+      const int row = r0 + tid / LPR;
+      if (row >= ROWS) break;
+      const int t = t0 - H2 + row;
+      const bool inside = t >= 0 && t < a.T;
+      const float* xr = a.x + ((size_t)b * a.T + (inside ? t : 0)) * D;
+      float4 v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(xr + (i * LPR + part) * 4);
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      s = sum8(s);
+      if constexpr (LPR == 16) s += dpp_mov<DPP_MIRROR>(s);
+      const float mean = s * (1.f / D);
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+        ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+      }
+      ss = sum8(ss);
+      if constexpr (LPR == 16) ss += dpp_mov<DPP_MIRROR>(ss);
+      const float rstd = rsqrtf(ss * (1.f / D) + 1e-5f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int cc = (i * LPR + part) * 4;
+        const float4 gm = *reinterpret_cast<const float4*>(a.w.ln_g + cc);
+        const float4 bt = *reinterpret_cast<const float4*>(a.w.ln_b + cc);
+        float e[4] = {v[i].x * rstd * gm.x + bt.x, v[i].y * rstd * gm.y + bt.y, v[i].z * rstd * gm.z + bt.z,
+                      v[i].w * rstd * gm.w + bt.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          e[q] = inside ? (w0 * e[q] + b0) * __builtin_amdgcn_rcpf(1.f + __expf(-(w1 * e[q] + b1))) : 0.f;
+        *reinterpret_cast<float4*>(&G[row][cc]) = make_float4(e[0], e[1], e[2], e[3]);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- step 3: d dw_w[k][c] = sum_t dc[t][c] * g[t + k - halo][c], d dw_b[c] = sum_t dc[t][c]  (convmod_kernel MODE 2)
+  float sk[KS], sdc = 0.f;
+  {
+    float gv[TH + KS - 1];
+#pragma unroll
+    for (int u = 0; u < TH + KS - 1; ++u) gv[u] = G[tb0 + u][c];
+#pragma unroll
+    for (int j = 0; j < TH; ++j) sdc += dcv[j];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int j = 0; j < TH; ++j) sacc += dcv[j] * gv[j + k];
+      sk[k] = sacc;
+    }
+  }
+  __syncthreads();  // every thread has taken its g rows
+
+  // ---- step 4: the second half tile hands its 34 sums to the first through rows [0, KS + 1); pass C's d ln_g terms go to rows
+  // [KS + 1, KS + 1 + TT), its d ln_b terms to rows [0, TT)
+  float* const X = &G[0][0];
+  constexpr int CA0 = KS + 1;
+  static_assert(CA0 + TT <= LROWS, "the d ln_g tile sits behind the hand-over block");
+  if (half == 1) {
+#pragma unroll
+    for (int k = 0; k < KS; ++k) X[k * D + c] = sk[k];
+    X[KS * D + c] = sdc;
+  }
+  __syncthreads();
+  const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  if (half == 0) {
+    float* out = a.part_b + blk * (KS + 1) * D + c;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) out[k * D] = sk[k] + X[k * D + c];
+    out[KS * D] = sdc + X[KS * D + c];
+  }
+  __syncthreads();  // the hand-over block has been read: rows [0, TT) take pass C's d ln_b terms
+
+  // ---- pass C (glu_ln_bwd_kernel): LR lanes per row, 16 channels per lane as four float4 pieces
+  constexpr int LR = NTHR / TT, NP = D / (4 * LR);
+  static_assert(NP == 4, "16 channels per lane");
+  const int row = tid / LR, part = tid % LR;
+  const int t = t0 + row;
+  const bool valid = t < a.T;
+  const size_t rbase = ((size_t)b * a.T + (valid ? t : a.T - 1)) * D;
+  float xh[NP][4], dd[NP][4];
+  float4 dyv[NP];
+  float sw0 = 0.f, sw1 = 0.f, sb0 = 0.f, sb1 = 0.f, rstd;
+  {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int cc = (i * LR + part) * 4;
+      const float4 xv = *reinterpret_cast<const float4*>(a.x + rbase + cc);
+      dyv[i] = *reinterpret_cast<const float4*>(a.dy + rbase + cc);
+      const float4 gv = *reinterpret_cast<const float4*>(a.dg + rbase + cc);   // (this workgroup's step 1, two barriers ago)
+      xh[i][0] = xv.x; xh[i][1] = xv.y; xh[i][2] = xv.z; xh[i][3] = xv.w;
+      dd[i][0] = gv.x; dd[i][1] = gv.y; dd[i][2] = gv.z; dd[i][3] = gv.w;
+      s += (xv.x + xv.y) + (xv.z + xv.w);
+    }
+    const float mean = sum_row_lanes<LR>(s) * (1.f / D);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        xh[i][q] -= mean;
+        ss += xh[i][q] * xh[i][q];
+      }
+    rstd = rsqrtf(sum_row_lanes<LR>(ss) * (1.f / D) + 1e-5f);
+  }
+  float s1 = 0.f, s2 = 0.f;
+  {
+    const float w0 = a.w.pw1_w[0], w1 = a.w.pw1_w[1], b0 = a.w.pw1_b[0], b1 = a.w.pw1_b[1];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int cc = (i * LR + part) * 4;
+      const float4 g4 = *reinterpret_cast<const float4*>(a.w.ln_g + cc);
+      const float4 b4 = *reinterpret_cast<const float4*>(a.w.ln_b + cc);
+      const float gm[4] = {g4.x, g4.y, g4.z, g4.w}, bt[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float h = xh[i][q] * rstd;
+        const float av = h * gm[q] + bt[q];
+        const float u = w0 * av + b0;
+        const float sg = 1.f / (1.f + __expf(-(w1 * av + b1)));
+        const float dgq = valid ? dd[i][q] : 0.f;
+        const float du = dgq * sg;
+        const float dv = dgq * u * sg * (1.f - sg);
+        sw0 += du * av; sb0 += du; sw1 += dv * av; sb1 += dv;
+        const float da = du * w0 + dv * w1;
+        G[CA0 + row][cc + q] = da * h;
+        G[row][cc + q] = da;
+        const float gg = da * gm[q];
+        xh[i][q] = h;
+        dd[i][q] = gg;
+        s1 += gg;
+        s2 += gg * h;
+      }
+    }
+  }
+  s1 = sum_row_lanes<LR>(s1) * (1.f / D);
+  s2 = sum_row_lanes<LR>(s2) * (1.f / D);
+  if (valid) {
+    const Drop ndrop = drop_make(a.nx.seed, a.nx.stream, a.nx.p);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const size_t o = rbase + (i * LR + part) * 4;
+      const float4 y4 = dyv[i];
+      float4 r;
+      r.x = y4.x + rstd * (dd[i][0] - s1 - xh[i][0] * s2);
+      r.y = y4.y + rstd * (dd[i][1] - s1 - xh[i][1] * s2);
+      r.z = y4.z + rstd * (dd[i][2] - s1 - xh[i][2] * s2);
+      r.w = y4.w + rstd * (dd[i][3] - s1 - xh[i][3] * s2);
+      *reinterpret_cast<float4*>(a.dx + o) = r;
+      if (a.nx.out != nullptr) {  // what the NEXT backward operator multiplies with: mask / (1 - p) o dx, bf16
+        const float4 rd = drop_apply4(ndrop, (unsigned)o, r);
+        *reinterpret_cast<uint2*>(a.nx.out + o) = make_uint2(pack_bf2(rd.x, rd.y), pack_bf2(rd.z, rd.w));
+      }
+    }
+  }
+  sw0 = wave_sum(sw0); sw1 = wave_sum(sw1); sb0 = wave_sum(sb0); sb1 = wave_sum(sb1);
+  if ((tid & 63) == 0) { red[tid >> 6][0] = sw0; red[tid >> 6][1] = sw1; red[tid >> 6][2] = sb0; red[tid >> 6][3] = sb1; }
+  __syncthreads();
+  {
+    float acc = 0.f;  // thread (c, half): column c of d ln_g (half 0) / d ln_b (half 1), rows in order
+#pragma unroll 8
+    for (int rr = 0; rr < TT; ++rr) acc += G[(half == 0 ? CA0 : 0) + rr][c];
+    float* out = a.part_c + blk * (2 * D + 4);
+    out[half * D + c] = acc;
+    if (tid < 4) {
+      float sc = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < NTHR / 64; ++wv) sc += red[wv][tid];
+      out[2 * D + tid] = sc;
+    }
+  }
+}
+
 // rows per workgroup of the row-wise backward passes: short row loops, many waves in flight (these passes are chains of
 // loads and wave reductions, not bandwidth: 64 rows per workgroup left less than one wave per SIMD at 12 800 rows)
 constexpr int BWD_ROWS = 16;
@@ -678,6 +981,20 @@ int run_bwd(const float* x, const float* dy, const csship_conv_weights& w, int B
       if (hipMemcpyAsync(sums, gA, 2 * (size_t)D * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return CSSHIP_ELAUNCH;
       return CSSHIP_OK;
     }
+  }
+  const float inv_n = bn_eval ? 0.f : 1.f / (float)(phase == 2 ? total_rows : (double)M);
+  static const bool unfused = [] { const char* e = getenv("CSSHIP_CONV_BWD_UNFUSED"); return e != nullptr && atoi(e) != 0; }();
+  if (!unfused) {
+    // passes A', B1, B2, C as one launch (conv_bwd_fused_kernel).  Both reductions behind it yield parameter gradients only:
+    // they may wait for the block's flush
+    const int ntile = (T + TT - 1) / TT * B;
+    float* part_b = part;   // (pass A's partials there were consumed by its reduction, which is never deferred)
+    ConvBwdArgs fa{x, dy, z, stats, phase == 2 ? sums : gA, w, inv_n, dx, dg, part_b, part_c, B, T, dcfg, nx};
+    hipLaunchKernelGGL((conv_bwd_fused_kernel<D, TT, 33>), dim3((T + TT - 1) / TT, B), dim3(2 * D), 0, s, fa);
+    CSSHIP_CHECK_LAUNCH();
+    rc = launch_slab_reduce(part_b, ntile, (int64_t)34 * D, 34 * D, (int64_t)34 * D, 1.f, nullptr, nullptr, 0, gB, s, true);
+    if (rc) return rc;
+    return launch_slab_reduce(part_c, ntile, 2 * D + 4, 2 * D + 4, 2 * D + 4, 1.f, nullptr, nullptr, 0, gC, s, true);
   }
   // pass A'
   // running statistics are constants of the graph: no mean / projection terms (1/n -> 0)
