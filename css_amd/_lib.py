@@ -194,6 +194,10 @@ SIGNATURES = {
     "csship_ffn_bwd_ln": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _dc, _dc, _p,
                                   _p, _p, _p, _p, _sz, _p]),
     "csship_qkv_in_bwd_workspace": (_sz, [_i32]),
+    "csship_qkv_ffn_bwd_workspace": (_sz, [_i32]),
+    "csship_qkv_ffn_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p,                                   # dqkv .. attn dgamma | dbeta
+                                  _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,                   # x .. dgamma | dbeta
+                                  _i32, _i32, _i32, _f32, _dc, _dc, _p, _p, _p, _p, _p, _sz, _p]),
     "csship_qkv_in_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _p, _sz, _p]),
     "csship_mha_relpos_train_drop": (_i32, [_p, _p, _i32, _i32, _p, _p, _i32, _i32, _i32, _dc, _p]),
     "csship_mha_relpos_probs_drop": (_i32, [_p, _p, _i32, _i32, _p, _p, _p, _i64, _i32, _i32, _i32, _dc, _p]),

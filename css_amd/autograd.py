@@ -527,22 +527,44 @@ class ConformerTrain(torch.autograd.Function):
             put(c.pw_conv_2.weight, g["pw2_w"]), put(c.pw_conv_2.bias, g["pw2_b"])
             x1, qkv, ao, wqkv_bf, wo_bf, scale, lse = L["mha"]
             a = lay.self_attn
-            dx, g = bw.mha_bwd(x1, dx, qkv.view(B, T, 3 * D), ao, a.layer_norm.weight.detach(),
-                               a.layer_norm.bias.detach(), wqkv_bf, wo_bf, S["pe_bf"], H, scale, window=window,
-                               probs=(S["pe_pack"], lse), skew_buf=skew_buf, drop_p=ds.cfg(f"{li}.attn.p"),
-                               drop_out=ds.cfg(f"{li}.attn.out"), dwin_acc=dwin, dyb_bf16=dyb,
-                               dwo_out=_direct_grad(a.linear_out.weight), dbo_out=_direct_grad(a.linear_out.bias),
-                               wo_tp=L.get("wo_tp"), wqkv_tp=L.get("wqkv_tp"))
+            # the block's input is the final LayerNorm of the block below: its backward rides in the FeedForward backward's epilogue
+            ln_done = li > 0 and not S["wide"] and not _NO_LN2 and M % 64 == 0 and enc.d_ffn <= ob.ffn_static_max_ffn()
+            ln2 = (S["layers"][li - 1]["x4"], layers[li - 1].layer_norm.weight.detach()) if ln_done else None
+            # ... and the FeedForward backward itself rides behind the q | k | v projection's in one kernel where it can
+            ffn_next = None
+            if not S["wide"]:
+                fm = lay.feed_forward_in
+                xin, w1p, w2tp, w1tp = L["ffn_in"]
+                ffn_next = dict(x=xin, ln_g=fm.layer_norm.weight.detach(), ln_b=fm.layer_norm.bias.detach(), b1=fm.net[0].bias.detach(),
+                                w1p=w1p, w2tp=w2tp, w1tp=w1tp, d_ffn=enc.d_ffn, alpha=0.5, drop_hidden=ds.cfg(f"{li}.ffn_in.hidden"),
+                                drop_out=ds.cfg(f"{li}.ffn_in.out"), ln2=ln2)
+                if bw.chained_ffn(x1, L.get("wqkv_tp"), ffn_next):
+                    ffn_next["outs"] = tuple(_direct_grad(q) for q in (fm.net[0].weight, fm.net[0].bias, fm.net[3].weight, fm.net[3].bias))
+                else:
+                    ffn_next = None
+            res = bw.mha_bwd(x1, dx, qkv.view(B, T, 3 * D), ao, a.layer_norm.weight.detach(),
+                             a.layer_norm.bias.detach(), wqkv_bf, wo_bf, S["pe_bf"], H, scale, window=window,
+                             probs=(S["pe_pack"], lse), skew_buf=skew_buf, drop_p=ds.cfg(f"{li}.attn.p"),
+                             drop_out=ds.cfg(f"{li}.attn.out"), dwin_acc=dwin, dyb_bf16=dyb,
+                             dwo_out=_direct_grad(a.linear_out.weight), dbo_out=_direct_grad(a.linear_out.bias),
+                             wo_tp=L.get("wo_tp"), wqkv_tp=L.get("wqkv_tp"), ffn_next=ffn_next)
+            dx, g = res[:2]
             dg, dbeta, dwqkv, dbqkv, dwo, dbo, dwin = g   # dwin: the window gradient summed over the blocks so far
             put(a.layer_norm.weight, dg), put(a.layer_norm.bias, dbeta)
             for i, lin in enumerate((a.linear_q, a.linear_k, a.linear_v)):
                 put(lin.weight, dwqkv[i * D:(i + 1) * D]), put(lin.bias, dbqkv[i * D:(i + 1) * D])
             put(a.linear_out.weight, dwo), put(a.linear_out.bias, dbo)
-            # the block's input is the final LayerNorm of the block below: its backward rides in this kernel's epilogue
-            ln_done = li > 0 and not S["wide"] and not _NO_LN2 and M % 64 == 0 and enc.d_ffn <= ob.ffn_static_max_ffn()
-            if ln_done:
-                below, Lb = layers[li - 1], S["layers"][li - 1]
-                dx, (dg2, dbeta2) = ffn_b(lay.feed_forward_in, "ffn_in", dx, ln2=(Lb["x4"], below.layer_norm.weight.detach()))
+            if ffn_next is not None:   # (dx is already the FeedForward's input gradient)
+                fm, gf = lay.feed_forward_in, res[2]
+                for p, gv in zip((fm.layer_norm.weight, fm.layer_norm.bias, fm.net[0].weight, fm.net[0].bias,
+                                  fm.net[3].weight, fm.net[3].bias), gf):
+                    put(p, gv)
+                if ln_done:
+                    below = layers[li - 1]
+                    put(below.layer_norm.weight, gf[6]), put(below.layer_norm.bias, gf[7])
+            elif ln_done:
+                below = layers[li - 1]
+                dx, (dg2, dbeta2) = ffn_b(lay.feed_forward_in, "ffn_in", dx, ln2=ln2)
                 put(below.layer_norm.weight, dg2), put(below.layer_norm.bias, dbeta2)
             else:
                 dx = ffn_b(lay.feed_forward_in, "ffn_in", dx)

@@ -67,6 +67,11 @@ def ffn_bwd_fused(x, dy, ln_g, ln_b, b1, w1p, w2tp, w1tp, d_ffn, alpha=0.5, drop
     the B*T rows.  w1p / w2tp / w1tp: fragment-packed W1, W2^T, W1^T.  ln2 = (x2, gamma2) when x = LayerNorm2(x2): dx
     comes back as the gradient wrt x2 and the gradient tuple ends with that LayerNorm's (dgamma2, dbeta2)."""
     res = ob.ffn_bwd(x, dy, ln_g, ln_b, w1p, b1, w2tp, w1tp, d_ffn, alpha, drop_hidden, drop_out, ln2=ln2)
+    return _ffn_wgrads(res, dy, alpha, outs)
+
+
+def _ffn_wgrads(res, dy, alpha, outs):
+    """the four weight / bias gradients behind ob.ffn_bwd's (or ob.qkv_ffn_bwd's) activation-side results"""
     dx, dg, dbeta, a, h, dh, dyd = res[:7]
     dw1_o, db1_o, dw2_o, db2_o = outs   # optional f32 destinations (dW1, db1, dW2, db2), e.g. zeroed .grad views
     with ob.paired_reductions():   # the slabs of both products summed by one launch
@@ -201,12 +206,16 @@ def _mha_core_products(qkv, g, q, k, do, p_v, ds, dsk, dq1, win, idx, window, dw
 
 def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_scale=0.125, window=None, probs=None,
             skew_buf=None, fused_softmax_bwd=True, drop_p=None, drop_out=None, dwin_acc=None, dyb_bf16=None,
-            dwo_out=None, dbo_out=None, wo_tp=None, wqkv_tp=None):
+            dwo_out=None, dbo_out=None, wo_tp=None, wqkv_tp=None, ffn_next=None):
     """out = x + attention(LN(x)) @ wo^T + bo  (conformer.py:213-254,356).
 
     wqkv_bf holds the q rows already multiplied by q_scale (as the forward uses them); the returned dwqkv / dbqkv are
     gradients of the UNSCALED parameters.  Returns dx and (ln_g, ln_b, wqkv, bqkv, wo, bo, pe) gradients; with
     ``window`` (from relpos_window) the last one is the gradient of the window rows instead of the whole table.
+    ffn_next: keyword arguments of ffn_bwd_fused (without dy) for the FeedForward whose output x is (the block's
+    feed_forward_in): when the row-panel forms apply, the q | k | v projection's input-side backward and that FeedForward's
+    run as ONE kernel (ob.qkv_ffn_bwd) and the result is (dx of the FeedForward, attention gradients, FeedForward gradients);
+    ``chained_ffn(...)`` says beforehand whether they will.
     """
     D = x.shape[1]
     # training: out = x + D_out(ao wo^T + bo) (conformer.py:254): the branch gradient is dy o mask / (1 - p)
@@ -230,6 +239,17 @@ def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_s
     dq2 = dqkv.view(-1, 3 * D)
     dw = torch.empty((3 * D, D), dtype=torch.float32, device=x.device)
     db = torch.empty(3 * D, dtype=torch.float32, device=x.device)
+    if ffn_next is not None:
+        if not chained_ffn(x, wqkv_tp, ffn_next) or not dq2.is_contiguous():
+            raise RuntimeError("css_amd: mha_bwd(ffn_next=...) outside the shapes of the chained kernel (ask chained_ffn first)")
+        f = dict(ffn_next)
+        outs = f.pop("outs", (None, None, None, None))
+        (dg, dbeta, a), res = ob.qkv_ffn_bwd(dq2, wqkv_tp, x, dy, ln_g, ln_b, f.pop("x"), f.pop("ln_g"), f.pop("ln_b"), f.pop("w1p"),
+                                            f.pop("b1"), f.pop("w2tp"), f.pop("w1tp"), f.pop("d_ffn"), f.pop("alpha", 0.5),
+                                            drop_hidden=f.pop("drop_hidden", None), drop_out=f.pop("drop_out"), ln2=f.pop("ln2", None))
+        ob.linear_wgrad(dq2, a, 1.0, dw_out=dw, db_out=db, head=(D, q_scale))
+        dxf, gf = _ffn_wgrads(res, None, 0.5, outs)
+        return dxf, (dg, dbeta, dw, db, dwo, dbo, dpe), gf
     if wqkv_tp is not None and not _NO_PANEL_DX and D == 256 and x.shape[0] % 64 == 0 and dq2.is_contiguous():
         # da = dqkv Wqkv, the LayerNorm backward, the residual gradient and a = LayerNorm(x) in one row-panel kernel
         dx, dg, dbeta, a = ob.qkv_in_bwd(dq2, wqkv_tp, x, dy, ln_g, ln_b)
@@ -244,6 +264,17 @@ def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_s
         a, _ = ops.layernorm(x, ln_g, ln_b)
     ob.linear_wgrad(dq2, a, 1.0, dw_out=dw, db_out=db, head=(D, q_scale))   # q rows carry the projection's 1/sqrt(d_k)
     return dx, (dg, dbeta, dw, db, dwo, dbo, dpe)
+
+
+_NO_QKV_FFN = bool(os.environ.get("CSSHIP_NO_QKV_FFN"))   # A/B timing: qkv_in_bwd and the FeedForward backward behind it as two launches
+
+
+def chained_ffn(x, wqkv_tp, ffn_next):
+    """will mha_bwd(..., ffn_next=ffn_next) run the chained kernel?  (whole 64-row panels of d_model 256, fragment-packed
+    Wqkv^T, a FeedForward of the static width with its output dropout on)"""
+    return (not _NO_QKV_FFN and not _NO_PANEL_DX and wqkv_tp is not None and x.shape[1] == 256 and x.shape[0] % 64 == 0
+            and ffn_next.get("drop_out") is not None and ffn_next["d_ffn"] <= ob.ffn_static_max_ffn()
+            and ffn_next["d_ffn"] % 256 == 0)
 
 
 def embed_bwd(f, dy, mean, rinv, w_bf_pad, bias, ln_g, ln_b, e=None, fn=None):

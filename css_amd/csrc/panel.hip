@@ -386,17 +386,20 @@ struct FfnBwdArgs {
 // come from an LDS copy staged once - every global memory instruction of the chunk loop is unconditional, so the
 // s_waitcnt counts of the weight ring are exact (a predicated store in the loop made hipcc assume the path without it
 // and wait for younger loads than the ones it needs; round 5, see chain_s_kernel).
-template <int NW, bool FULL, bool LN2 = false>
-__global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
+// LDS of the kernel: XD = a = LN(x) | alpha * dy (two bf16 panels; later 64 KB of column sums), Graw = 2 dh panels (later the Ys
+// tile), Pb = FULL: b1 | gamma | beta | gamma2 | dump.  DYREG: dy arrives in registers (this thread's pieces of row tid >> 3, the
+// row mapping of the prologue) from the stage in front of it in the same kernel (qkv_ffn_bwd_kernel) instead of from memory.
+constexpr int FB_XD_BYTES = 2 * PANEL_BYTES, FB_GRAW_BYTES = 2 * PANEL_BYTES + 1024, FB_PB_FLOATS = CS_FFMAX + 3 * DM + CS_DUMP;
+template <int NW, bool FULL, bool LN2, bool DYREG>
+DEV void ffn_bwd_body(const FfnBwdArgs& a, unsigned char* const XD, unsigned char* const Graw, float* const Pb,
+                      const float4 (&dyin)[8]) {
   static_assert(FULL || !LN2, "the fused second LayerNorm backward is built for whole panels");
+  static_assert(FULL || !DYREG, "the chained form is built for whole panels");
   static_assert(NW * 64 == 8 * BM, "row phases assume 8 lanes per panel row");
   constexpr int NT = 16 / NW;
   constexpr bool KEEP_DY = FULL;
-  __shared__ __attribute__((aligned(16))) unsigned char XD[2 * PANEL_BYTES];  // a = LN(x) | alpha * dy; later 64 KB of sums
   unsigned char* const Xs = XD;
   unsigned char* const Ds = XD + PANEL_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char Graw[2 * PANEL_BYTES + 1024];  // 2 dh panels, later the Ys tile
-  __shared__ __attribute__((aligned(16))) float Pb[FULL ? CS_FFMAX + 3 * DM + CS_DUMP : 4];  // FULL: b1 | gamma | beta | gamma2 | dump
   static_assert(2 * PANEL_BYTES + 1024 >= YS_BYTES, "Ys tile must fit the dh panels");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15;
   const int m0 = blockIdx.x * BM;
@@ -440,7 +443,8 @@ __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       v[i] = *reinterpret_cast<const float4*>(a.x + (size_t)rowc * DM + (i * 8 + part) * 4);
-      d[i] = *reinterpret_cast<const float4*>(a.dy + (size_t)rowc * DM + (i * 8 + part) * 4);
+      if constexpr (DYREG) d[i] = dyin[i];
+      else d[i] = *reinterpret_cast<const float4*>(a.dy + (size_t)rowc * DM + (i * 8 + part) * 4);
       if constexpr (KEEP_DY) dyk[i] = d[i];
     }
     float s = 0.f;
@@ -694,6 +698,15 @@ __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
     }
     a.part2[(size_t)blockIdx.x * 2 * DM + which * DM + col] = acc;
   }
+}
+
+template <int NW, bool FULL, bool LN2 = false>
+__global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char XD[FB_XD_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char Graw[FB_GRAW_BYTES];
+  __shared__ __attribute__((aligned(16))) float Pb[FULL ? FB_PB_FLOATS : 4];
+  float4 none[8];   // (never read: DYREG = false)
+  ffn_bwd_body<NW, FULL, LN2, false>(a, XD, Graw, Pb, none);
 }
 
 // =============================================================================== panel linear
@@ -2635,14 +2648,15 @@ struct QkvBwdArgs {
   int M;
 };
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void qkv_in_bwd_kernel(QkvBwdArgs a) {
+// LDS: Ps = three bf16 panels (96 KB); later the Ys tile, then da * xhat [64][260] | da [64][256] for the column sums;
+// Pb = gamma | beta | dump.  KEEP: dx stays in registers (keep[i] = this thread's pieces of row tid >> 3) for the stage behind
+// it in the same kernel (qkv_ffn_bwd_kernel) instead of going to memory.
+constexpr int QB_PS_BYTES = YS_BYTES + 2 * PANEL_BYTES, QB_PB_FLOATS = 2 * DM + CS_DUMP;
+template <int NW, bool KEEP>
+DEV void qkv_in_bwd_body(const QkvBwdArgs& a, unsigned char* const Ps, float* const Pb, float4 (&keep)[8]) {
   static_assert(NW * 64 == 8 * BM, "row phases assume 8 lanes per panel row");
   constexpr int NT = 16 / NW;
   constexpr int KT = 3 * KS;  // 24 k-steps
-  // three bf16 panels (96 KB); later the Ys tile, then da * xhat [64][260] | da [64][256] for the column sums
-  __shared__ __attribute__((aligned(16))) unsigned char Ps[YS_BYTES + 2 * PANEL_BYTES];
-  __shared__ __attribute__((aligned(16))) float Pb[2 * DM + CS_DUMP];  // gamma | beta | dump
   static_assert(YS_BYTES + 2 * PANEL_BYTES >= 3 * PANEL_BYTES, "the three panels must fit");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15;
   const int m0 = blockIdx.x * BM;
@@ -2765,7 +2779,10 @@ __global__ __launch_bounds__(NW * 64) void qkv_in_bwd_kernel(QkvBwdArgs a) {
     o4.y = d.y + rstd * (gg[i].y - s1 - v[i].y * s2);
     o4.z = d.z + rstd * (gg[i].z - s1 - v[i].z * s2);
     o4.w = d.w + rstd * (gg[i].w - s1 - v[i].w * s2);
-    *reinterpret_cast<float4*>(a.dx + (size_t)row * DM + col) = o4;
+    // (KEEP: the two instantiations contract their float expressions differently here and there - the chained kernel agrees
+    // with the two launches to an ulp of dy, which a bf16 rounding behind it can amplify to a bf16 ulp in a handful of elements)
+    if constexpr (KEEP) keep[i] = o4;
+    else *reinterpret_cast<float4*>(a.dx + (size_t)row * DM + col) = o4;
     *reinterpret_cast<float4*>(cg + r * YS + col) = make_float4(da[i].x * v[i].x, da[i].y * v[i].y, da[i].z * v[i].z, da[i].w * v[i].w);
     *reinterpret_cast<float4*>(cb + r * DM + col) = da[i];
   }
@@ -2782,6 +2799,31 @@ __global__ __launch_bounds__(NW * 64) void qkv_in_bwd_kernel(QkvBwdArgs a) {
     }
     a.part[(size_t)blockIdx.x * 2 * DM + which * DM + col] = acc;
   }
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void qkv_in_bwd_kernel(QkvBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char Ps[QB_PS_BYTES];
+  __shared__ __attribute__((aligned(16))) float Pb[QB_PB_FLOATS];
+  float4 none[8];   // (never written: KEEP = false)
+  qkv_in_bwd_body<NW, false>(a, Ps, Pb, none);
+}
+
+// The q | k | v projection's input-side backward and the FeedForward backward behind it in the backward pass (the block's
+// feed_forward_in, conformer.py:355) as ONE kernel per 64-row panel: dx of the first stage is the dy of the second and has the
+// second's row mapping (8 lanes per row), so it stays in registers - no f32 [M, 256] round trip, one launch, and the
+// FeedForward's prologue finds half of its rows already there.  The two stages share the LDS (the three dqkv panels and the
+// column-sum tiles of the first = the LN(x) | dy panels + the dh panels of the second, byte for byte).
+constexpr int QF_RAW_BYTES = QB_PS_BYTES > FB_XD_BYTES + FB_GRAW_BYTES ? QB_PS_BYTES : FB_XD_BYTES + FB_GRAW_BYTES;
+template <int NW, bool LN2>
+__global__ __launch_bounds__(NW * 64) void qkv_ffn_bwd_kernel(QkvBwdArgs q, FfnBwdArgs f) {
+  __shared__ __attribute__((aligned(16))) unsigned char RAW[QF_RAW_BYTES];
+  __shared__ __attribute__((aligned(16))) float Pb1[QB_PB_FLOATS];
+  __shared__ __attribute__((aligned(16))) float Pb2[FB_PB_FLOATS];
+  float4 dxk[8];
+  qkv_in_bwd_body<NW, true>(q, RAW, Pb1, dxk);
+  __syncthreads();   // the first stage's column sums have been read: its tiles become the second stage's panels
+  ffn_bwd_body<NW, true, LN2, true>(f, RAW, RAW + FB_XD_BYTES, Pb2, dxk);
 }
 
 extern "C" size_t csship_qkv_in_bwd_workspace(int32_t M) { return (size_t)((M + BM - 1) / BM) * 2 * DM * sizeof(float); }
@@ -2804,6 +2846,55 @@ extern "C" int csship_qkv_in_bwd(const uint16_t* dqkv, const uint16_t* wqkvT_pac
   CSSHIP_CHECK_LAUNCH();
   return launch_slab_reduce(reinterpret_cast<const float*>(workspace), nwg, 2 * DM, 2 * DM, 2 * DM, 1.f, nullptr, nullptr, 0,
                             dgamma_dbeta, as_stream(stream), true);
+}
+
+extern "C" size_t csship_qkv_ffn_bwd_workspace(int32_t M) { return (size_t)((M + BM - 1) / BM) * 6 * DM * sizeof(float); }
+
+extern "C" int csship_qkv_ffn_bwd(const uint16_t* dqkv, const uint16_t* wqkvT_packed, const float* x_attn, const float* dy,
+                                  const float* attn_ln_g, const float* attn_ln_b, uint16_t* y_bf16, float* attn_dgamma_dbeta,
+                                  const float* x, const float* ln_g, const float* ln_b, const uint16_t* w1_packed,
+                                  const float* b1, const uint16_t* w2t_packed, const uint16_t* w1t_packed, uint16_t* a_bf16,
+                                  uint16_t* h_bf16, uint16_t* dh_bf16, float* dx, float* dgamma_dbeta, int32_t M,
+                                  int32_t d_model, int32_t d_ffn, float alpha, const csship_dropout_cfg* drop_hidden,
+                                  const csship_dropout_cfg* drop_out, uint16_t* dyd_bf16, const float* ln2_x,
+                                  const float* ln2_g, float* dgamma_dbeta2, void* workspace, size_t workspace_bytes,
+                                  csship_stream_t stream) {
+  if (!dqkv || !wqkvT_packed || !x_attn || !dy || !attn_ln_g || !attn_ln_b || !y_bf16 || !attn_dgamma_dbeta || !x || !ln_g ||
+      !ln_b || !w1_packed || !b1 || !w2t_packed || !w1t_packed || !a_bf16 || !h_bf16 || !dh_bf16 || !dx || !dgamma_dbeta ||
+      !dyd_bf16 || !workspace)
+    return CSSHIP_ENULL;
+  if (M <= 0) return CSSHIP_EBADSHAPE;
+  if (d_model != DM || (M % BM) != 0 || d_ffn <= 0 || (d_ffn % DM) != 0 || d_ffn > CS_FFMAX) return CSSHIP_EUNSUPPORTED;
+  if (!aligned16(dqkv) || !aligned16(wqkvT_packed) || !aligned16(x_attn) || !aligned16(dy) || !aligned16(attn_ln_g) ||
+      !aligned16(attn_ln_b) || !aligned8(y_bf16) || !aligned16(x) || !aligned16(dx) || !aligned16(ln_g) || !aligned16(ln_b) ||
+      !aligned16(b1) || !aligned16(w1_packed) || !aligned16(w2t_packed) || !aligned16(w1t_packed) || !aligned8(a_bf16) ||
+      !aligned8(h_bf16) || !aligned8(dh_bf16) || !aligned8(dyd_bf16))
+    return CSSHIP_EALIGN;
+  const int nwg = M / BM;
+  if (workspace_bytes < csship_qkv_ffn_bwd_workspace(M)) return CSSHIP_EWORKSPACE;
+  if ((int64_t)nwg * BM * d_ffn > 0xffffffffLL) return CSSHIP_EBADSHAPE;  // 32-bit dropout element indices
+  const bool ln2 = ln2_x != nullptr;
+  if (ln2) {
+    if (!ln2_g || !dgamma_dbeta2) return CSSHIP_ENULL;
+    if (!aligned16(ln2_x) || !aligned16(ln2_g)) return CSSHIP_EALIGN;
+  }
+  float* const wsf = reinterpret_cast<float*>(workspace);   // [nwg][2][256] x 3: the FeedForward's, its second LayerNorm's, the q | k | v LayerNorm's
+  float* const part2 = wsf + (size_t)nwg * 2 * DM;
+  float* const partq = wsf + (size_t)nwg * 4 * DM;
+  const csship_dropout_cfg none{nullptr, 0u, 0.f};
+  QkvBwdArgs qa{dqkv, reinterpret_cast<const bf16x8*>(wqkvT_packed), x_attn, dy, attn_ln_g, attn_ln_b, nullptr, y_bf16, partq, M};
+  FfnBwdArgs fa{x, nullptr, ln_g, ln_b, reinterpret_cast<const bf16x8*>(w1_packed), b1,
+                reinterpret_cast<const bf16x8*>(w2t_packed), reinterpret_cast<const bf16x8*>(w1t_packed), a_bf16, h_bf16,
+                dh_bf16, dx, wsf, M, d_ffn, alpha, drop_hidden ? *drop_hidden : none, drop_out ? *drop_out : none, dyd_bf16,
+                ln2_x, ln2_g, ln2 ? part2 : nullptr};
+  if (ln2) hipLaunchKernelGGL((qkv_ffn_bwd_kernel<NWAVES, true>), dim3(nwg), dim3(NWAVES * 64), 0, as_stream(stream), qa, fa);
+  else hipLaunchKernelGGL((qkv_ffn_bwd_kernel<NWAVES, false>), dim3(nwg), dim3(NWAVES * 64), 0, as_stream(stream), qa, fa);
+  CSSHIP_CHECK_LAUNCH();
+  int rc = launch_slab_reduce(partq, nwg, 2 * DM, 2 * DM, 2 * DM, 1.f, nullptr, nullptr, 0, attn_dgamma_dbeta, as_stream(stream), true);
+  if (rc != CSSHIP_OK) return rc;
+  rc = launch_slab_reduce(wsf, nwg, 2 * DM, 2 * DM, 2 * DM, 1.f, nullptr, nullptr, 0, dgamma_dbeta, as_stream(stream), true);
+  if (rc != CSSHIP_OK || !ln2) return rc;
+  return launch_slab_reduce(part2, nwg, 2 * DM, 2 * DM, 2 * DM, 1.f, nullptr, nullptr, 0, dgamma_dbeta2, as_stream(stream), true);
 }
 
 // out bf16 [M, 256] = a bf16 [M, 256] W^T with no bias, whole panels: the input gradient of a 256 -> 256 Linear against

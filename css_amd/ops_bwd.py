@@ -529,6 +529,46 @@ def qkv_in_bwd(dqkv, wqkvT_p, x, dy, ln_g, ln_b):
     return dx, gb[0], gb[1], y
 
 
+def qkv_ffn_bwd(dqkv, wqkvT_p, x_attn, dy, attn_ln_g, attn_ln_b, x, ln_g, ln_b, w1p, b1, w2tp, w1tp, d_ffn, alpha=0.5,
+                drop_hidden=None, drop_out=None, ln2=None):
+    """qkv_in_bwd and the ffn_bwd behind it in the backward pass as ONE kernel (csship_qkv_ffn_bwd): the q | k | v
+    projection's dx is the FeedForward's dy and never leaves the registers.  x_attn / dy: the attention block's input and
+    output gradient; x: the FeedForward's input; the rest as in qkv_in_bwd / ffn_bwd (ln2 included).  M % 64 == 0,
+    d_ffn <= ffn_static_max_ffn(), drop_out given (the FeedForward's dW2 takes dyd: dy itself exists nowhere).
+    Returns ((attn dgamma, attn dbeta, y), ffn_bwd's tuple)."""
+    _need(dqkv, torch.bfloat16, "dqkv"), _need(x_attn, torch.float32, "x_attn"), _need(dy, torch.float32, "dy"), _need(x, torch.float32, "x")
+    M, D = x.shape
+    if not (x.is_contiguous() and dy.is_contiguous() and dqkv.is_contiguous() and x_attn.is_contiguous()) or \
+            dy.shape != x.shape or x_attn.shape != x.shape or dqkv.shape != (M, 3 * D):
+        raise RuntimeError("css_amd: qkv_ffn_bwd expects dense x, x_attn, dy [M, 256] and dqkv [M, 768]")
+    if drop_out is None:
+        raise RuntimeError("css_amd: qkv_ffn_bwd needs the FeedForward's output dropout cfg (dyd is its only copy of dy)")
+    dev = x.device
+    y = torch.empty((M, D), dtype=torch.bfloat16, device=dev)
+    gbq = torch.empty((2, D), dtype=torch.float32, device=dev)
+    a = torch.empty((M, D), dtype=torch.bfloat16, device=dev)
+    h = torch.empty((M, d_ffn), dtype=torch.bfloat16, device=dev)
+    dh = torch.empty((M, d_ffn), dtype=torch.bfloat16, device=dev)
+    dx = torch.empty_like(x)
+    gb = torch.empty((2, D), dtype=torch.float32, device=dev)
+    dyd = torch.empty((M, D), dtype=torch.bfloat16, device=dev)
+    x2 = g2 = gb2 = None
+    if ln2 is not None:
+        x2, g2 = ln2
+        _need(x2, torch.float32, "ln2 x")
+        if not x2.is_contiguous() or x2.shape != x.shape:
+            raise RuntimeError("css_amd: qkv_ffn_bwd expects the second LayerNorm's input dense and shaped like x")
+        gb2 = torch.empty((2, D), dtype=torch.float32, device=dev)
+    nws = lib().csship_qkv_ffn_bwd_workspace(M)
+    ws = _workspace(nws, dev, own=True)
+    check(lib().csship_qkv_ffn_bwd(_ptr(dqkv), _ptr(wqkvT_p), _ptr(x_attn), _ptr(dy), _ptr(attn_ln_g), _ptr(attn_ln_b), _ptr(y),
+                                   _ptr(gbq), _ptr(x), _ptr(ln_g), _ptr(ln_b), _ptr(w1p), _ptr(b1), _ptr(w2tp), _ptr(w1tp),
+                                   _ptr(a), _ptr(h), _ptr(dh), _ptr(dx), _ptr(gb), M, D, d_ffn, float(alpha), drop_hidden,
+                                   drop_out, _ptr(dyd), _ptr(x2), _ptr(g2), _ptr(gb2), _ptr(ws), nws, _stream()))
+    res = (dx, gb[0], gb[1], a, h, dh, dyd) + ((gb2[0], gb2[1]) if ln2 is not None else ())
+    return (gbq[0], gbq[1], y), res
+
+
 def grad_accumulate(pairs):
     """dst += src for every (dst, src) pair in ONE launch per 96 pairs (csship_grad_accumulate).  dst: dense f32; src: f32
     with dst's element count, dense in dst's order, or a 2-d [R, C] view with stride(0) == 1 (the transpose of a matrix

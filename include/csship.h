@@ -898,6 +898,21 @@ int csship_qkv_in_bwd(const uint16_t* dqkv, const uint16_t* wqkvT_packed, const 
                       const float* ln_g, const float* ln_b, float* dx, uint16_t* y_bf16, float* dgamma_dbeta,
                       int32_t M, int32_t d_model, void* workspace, size_t workspace_bytes, csship_stream_t stream);
 
+/* csship_qkv_ffn_bwd (round 6): csship_qkv_in_bwd and the csship_ffn_bwd_ln BEHIND it in the backward pass - the block's
+ * feed_forward_in, whose output x_attn is (conformer.py:355-356, torch.autograd through both in the reference) - as ONE
+ * kernel per 64-row panel: the first stage's dx is the second's dy and stays in registers (no f32 [M, 256] round trip, one
+ * launch less per block).  Arguments: csship_qkv_in_bwd's without dx (x_attn = its x), then csship_ffn_bwd_ln's without
+ * dy.  dyd_bf16 is required (dy itself exists nowhere: dW2 = dyd^T h); ln2_x may be NULL (no second LayerNorm).  d_model 256, M % 64 == 0, d_ffn % 256 == 0, d_ffn <= csship_ffn_static_max_ffn(). */
+size_t csship_qkv_ffn_bwd_workspace(int32_t M);
+int csship_qkv_ffn_bwd(const uint16_t* dqkv, const uint16_t* wqkvT_packed, const float* x_attn, const float* dy,
+                       const float* attn_ln_g, const float* attn_ln_b, uint16_t* y_bf16, float* attn_dgamma_dbeta,
+                       const float* x, const float* ln_g, const float* ln_b, const uint16_t* w1_packed, const float* b1,
+                       const uint16_t* w2t_packed, const uint16_t* w1t_packed, uint16_t* a_bf16, uint16_t* h_bf16,
+                       uint16_t* dh_bf16, float* dx, float* dgamma_dbeta, int32_t M, int32_t d_model, int32_t d_ffn,
+                       float alpha, const csship_dropout_cfg* drop_hidden, const csship_dropout_cfg* drop_out,
+                       uint16_t* dyd_bf16, const float* ln2_x, const float* ln2_g, float* dgamma_dbeta2, void* workspace,
+                       size_t workspace_bytes, csship_stream_t stream);
+
 /* ---- BLSTM recurrence, training (css_amd/csrc/lstm.hip).  csship_lstm_bidir_train = csship_lstm_bidir that also keeps
  * the activated gates (i, f, g, o; f32 [B, T, 2, 4H]) and the cell states (f32 [B, T, 2, H]).
  * csship_lstm_bidir_bwd: back-propagation through time.  dy: f32 [B, T, 2H]; whhT_packed: both directions'

@@ -248,6 +248,53 @@ def test_ffn_bwd_carries_dx_through_a_second_layernorm(ob):
         ob.ffn_bwd(x[:100], dy[:100], G["g"], G["b"], w1p, G["b1"], w2tp, w1tp, FF, 0.5, ln2=(x2[:100].contiguous(), g2))
 
 
+@pytest.mark.parametrize("with_ln2", [False, True])
+def test_qkv_ffn_bwd_equals_the_two_launches(ob, with_ln2):
+    """csship_qkv_ffn_bwd: the q | k | v projection's input-side backward and the FeedForward backward behind it as one
+    kernel (dx of the first = dy of the second, kept in registers) vs csship_qkv_in_bwd then csship_ffn_bwd(_ln) on the
+    same operands with the same dropout sites.  The first stage's own outputs bit for bit; behind the hand-over the two
+    builds of the same formulas may contract their float expressions differently: dy agrees to an ulp, which the bf16
+    rounding of alpha * dy o mask can turn into a bf16 ulp of a handful of dyd / dh elements (measured: 2 and 9 of 180 224 /
+    720 896) and from there into 1e-4-level differences of one row of da - bounds: elementwise for the bf16 operands,
+    5e-4 of the largest element for the f32 results"""
+    from css_amd import ops
+    from css_amd.dropout import DropState
+    M, D, FF = 704, 256, 1024
+    st = DropState(torch.tensor([77], dtype=torch.int32, device=DEV), 0.1, 0)
+    cfg_h, cfg_o = st.cfg("3.ffn_in.hidden"), st.cfg("3.ffn_in.out")
+    x_attn, dy = rnd((M, D), 301).to(DEV), rnd((M, D), 302, 0.1).to(DEV)
+    ag, ab = (1 + 0.1 * rnd((D,), 303)).to(DEV), (0.1 * rnd((D,), 304)).to(DEV)
+    wcat = rnd((3 * D, D), 305, 0.06).to(DEV)
+    _, wt = ob.pack_weight(wcat.t().contiguous(), want_frag=True)
+    dqkv = rnd((M, 3 * D), 306, 0.5).to(torch.bfloat16).to(DEV)
+    x2 = rnd((M, D), 307).to(DEV)
+    g2, b2 = (1 + 0.1 * rnd((D,), 308)).to(DEV), (0.1 * rnd((D,), 309)).to(DEV)
+    x = torch.nn.functional.layer_norm(x2, (D,), g2, b2, 1e-5) if with_ln2 else x2
+    G = {"g": (1 + 0.1 * rnd((D,), 310)).to(DEV), "b": (0.1 * rnd((D,), 311)).to(DEV), "w1": rnd((FF, D), 312, 0.06).to(DEV),
+         "b1": rnd((FF,), 313, 0.1).to(DEV), "w2": rnd((D, FF), 314, 0.03).to(DEV)}
+    w1p = ops.pack_frag(G["w1"])
+    w2tp, w1tp = ops.pack_frag(G["w2"].t().contiguous()), ops.pack_frag(G["w1"].t().contiguous())
+    ln2 = (x2, g2) if with_ln2 else None
+    dx1, dg1, db1, y1 = ob.qkv_in_bwd(dqkv, wt, x_attn, dy, ag, ab)
+    ref = ob.ffn_bwd(x, dx1, G["g"], G["b"], w1p, G["b1"], w2tp, w1tp, FF, 0.5, cfg_h, cfg_o, ln2=ln2)
+    (dg, db, y), got = ob.qkv_ffn_bwd(dqkv, wt, x_attn, dy, ag, ab, x, G["g"], G["b"], w1p, G["b1"], w2tp, w1tp, FF, 0.5,
+                                      drop_hidden=cfg_h, drop_out=cfg_o, ln2=ln2)
+    assert torch.equal(dg, dg1) and torch.equal(db, db1) and torch.equal(y, y1)
+    assert len(got) == len(ref) == (9 if with_ln2 else 7)
+    for i, (a, b) in enumerate(zip(got, ref)):
+        if a.dtype == torch.bfloat16:   # a, h, dh, dyd: a few elements at most, by one bf16 ulp
+            d = (a.float() - b.float()).abs()
+            assert int((d > 0).sum()) <= 64 and float((d / b.float().abs().clamp_min(1e-3)).max()) <= 2.0 ** -7, i
+        else:
+            assert relerr(a, b.double().cpu()) < 5e-4, i   # (measured 1.2e-4: one row of dx)
+    assert float(got[0].abs().max()) > 0 and float(got[5].float().abs().max()) > 0
+    with pytest.raises(RuntimeError):   # whole panels only
+        ob.qkv_ffn_bwd(dqkv[:100], wt, x_attn[:100], dy[:100], ag, ab, x[:100].contiguous(), G["g"], G["b"], w1p, G["b1"], w2tp, w1tp,
+                       FF, 0.5, drop_hidden=cfg_h, drop_out=cfg_o)
+    with pytest.raises(RuntimeError):   # dyd is the only copy of the FeedForward's output gradient
+        ob.qkv_ffn_bwd(dqkv, wt, x_attn, dy, ag, ab, x, G["g"], G["b"], w1p, G["b1"], w2tp, w1tp, FF, 0.5)
+
+
 def test_grouped_weight_gradients_equal_the_single_products(ob):
     """csship_wgrad_hold / csship_wgrad_flush: the weight-gradient products of a block queued and run as ONE launch (the
     reduction cut 2-3 times instead of 16-64) vs float64 on the same bf16 operands and vs the products one by one; a
