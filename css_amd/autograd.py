@@ -63,6 +63,19 @@ def _owners(ps):
     return list(seen.values())
 
 
+# Experiment (round 6): a block's grouped weight-gradient launch + parameter reductions on a second stream (one fork per block,
+# one join at the end of the backward pass) beside the next block's data-gradient chain.  Single-process steps only.
+_WGRAD_SIDE = bool(os.environ.get("CSSHIP_WGRAD_SIDE"))
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = str(device)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
 def _deliver(model, G):
     """Hand the parameter gradients G to autograd.  Parameters whose ``.grad`` already exists (FusedAdam presets them
     as views of its flat gradient buffer) are accumulated in place by ONE multi-tensor add and get None back, instead
@@ -448,6 +461,7 @@ class ConformerTrain(torch.autograd.Function):
                 g = g.reshape(p.shape)
             if p in G:
                 red.flush()   # the sum reads both gradients
+                red.join()
                 G[p] = G[p].reshape(p.shape) + g
             else:
                 G[p] = g
@@ -484,6 +498,7 @@ class ConformerTrain(torch.autograd.Function):
         ds = S["drop"]
         nlay = len(enc.encoders)
         layers = list(enc.encoders)
+        side = _side_stream(masks.device) if _WGRAD_SIDE and not S["wide"] else None
         ln_done = False   # this block's final LayerNorm was back-propagated by the block above (ffn_bwd's second LayerNorm)
         for li, lay, L in zip(range(nlay - 1, -1, -1), reversed(layers), reversed(S["layers"])):
             if not ln_done:
@@ -569,7 +584,10 @@ class ConformerTrain(torch.autograd.Function):
             else:
                 dx = ffn_b(lay.feed_forward_in, "ffn_in", dx)
             L.clear()
-            red.flush()
+            if side is not None and getattr(model, "_grad_bucket_hook", None) is None:
+                red.flush(side=side)   # the block's weight gradients and parameter reductions beside the next block's chain
+            else:
+                red.flush()
             _deliver_group(model, lay, G)
         if enc.pos_emb is not None:
             dpe = torch.zeros_like(enc.pos_emb.pe_k.weight)
@@ -582,6 +600,7 @@ class ConformerTrain(torch.autograd.Function):
         put(enc.embed[0].weight, dwe), put(enc.embed[0].bias, dbe)
         put(enc.embed[1].weight, dg), put(enc.embed[1].bias, dbeta)
         red.flush()
+        red.join()
         return (None, None) + _deliver(model, G)
 
 

@@ -649,6 +649,7 @@ struct ConvBwdArgs {
   int B, T;
   csship_dropout_cfg dcfg;
   NextOut nx;
+  unsigned long long* stamps;   // diagnostic (csship_debug_stamps): phase boundaries of every workgroup
 };
 
 template <int LR>
@@ -676,6 +677,18 @@ __global__ __launch_bounds__(2 * D) __attribute__((amdgpu_waves_per_eu(4, 4))) v
   const int H3 = a.w.causal ? 0 : (KS - 1) / 2;        // rows of the dc buffer in front of the tile (input gradient: flipped taps)
   const int H2 = a.w.causal ? KS - 1 : (KS - 1) / 2;   // rows of the g buffer in front of the tile (the forward's halo)
 
+  // the x rows of step 2 (tile + halo, this thread's 32 channels of row tid / LPR) are requested inside step 0, behind its last
+  // dy / z loads: their latency passes behind the rest of step 0 and step 1
+  constexpr int LPR = D / 32;
+  static_assert(LPR == 8 || LPR == 16, "row reductions are written for 8 or 16 lanes per row");
+  static_assert(NTHR / LPR == ROWS, "one row batch covers the tile + halo");
+  const int xrow = tid / LPR, xpart = tid % LPR;
+  const bool xinside = t0 - H2 + xrow >= 0 && t0 - H2 + xrow < a.T;
+  stamp(a.stamps, 0);
+  constexpr bool PRE = D == 256;   // (D = 512: 1024 threads hold 128 registers each, the rows would spill: requested in step 2)
+  float4 xv[8];
+  const float* const xr = a.x + ((size_t)b * a.T + (xinside ? t0 - H2 + xrow : 0)) * D;
+
   // ---- step 0: dc = sc * (dzh - S1 / n - zn * S2 / n), dzh = dy o mask / (1 - p) * w3 * [zh > 0]  (conv_bn_bwd_apply_kernel)
   {
     const Drop dp = drop_make(a.dcfg.seed, a.dcfg.stream, a.dcfg.p);
@@ -687,6 +700,15 @@ __global__ __launch_bounds__(2 * D) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w}, muv[4] = {mu4.x, mu4.y, mu4.z, mu4.w};
     const float rsv[4] = {rsqrtf(va4.x + 1e-5f), rsqrtf(va4.y + 1e-5f), rsqrtf(va4.z + 1e-5f), rsqrtf(va4.w + 1e-5f)};
     const float s1v[4] = {s14.x, s14.y, s14.z, s14.w}, s2v[4] = {s24.x, s24.y, s24.z, s24.w};
+    // dc = sc * (dzh - S1 / n - (z - mu) * rstd * S2 / n) = k3 * d * [zh > 0] + (c1 * z + c0) with per-channel k3 = sc * w3,
+    // c1 = -sc * rstd * S2 / n, c0 = -sc * S1 / n - c1 * mu: three multiply-adds, a compare and a select per element
+    float k3v[4], c1v[4], c0v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      k3v[q] = scv[q] * w3;
+      c1v[q] = -scv[q] * rsv[q] * s2v[q] * inv_n;
+      c0v[q] = -scv[q] * s1v[q] * inv_n - c1v[q] * muv[q];
+    }
     constexpr int NIT = ROWS * C4 / NTHR, RSTEP = NTHR / C4, NB = 4;   // rows in flight per thread: two batches of 4 x (dy, z)
     static_assert(NIT % NB == 0, "whole load batches");
 #pragma unroll
@@ -699,6 +721,12 @@ __global__ __launch_bounds__(2 * D) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         dv[k] = reinterpret_cast<const float4*>(a.dy)[i];
         zv[k] = reinterpret_cast<const float4*>(a.z)[i];
       }
+      if constexpr (PRE) {
+        if (k0 + NB == NIT) {   // behind the last dy / z requests (loads return in order: in front of them they held step 0 back)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) xv[i] = *reinterpret_cast<const float4*>(xr + (i * LPR + xpart) * 4);
+        }
+      }
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
         const int row = tid / C4 + (k0 + k) * RSTEP, t = t0 - H3 + row;
@@ -710,14 +738,15 @@ __global__ __launch_bounds__(2 * D) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const float zh = zz[q] * scv[q] + shv[q];
-          const float dzh = zh > 0.f ? d[q] * w3 : 0.f;
-          o[q] = inside ? scv[q] * (dzh - s1v[q] * inv_n - (zz[q] - muv[q]) * rsv[q] * s2v[q] * inv_n) : 0.f;
+          const float lin = c1v[q] * zz[q] + c0v[q];
+          o[q] = inside ? (zh > 0.f ? k3v[q] * d[q] + lin : lin) : 0.f;
         }
         *reinterpret_cast<float4*>(&G[row][c]) = make_float4(o[0], o[1], o[2], o[3]);
       }
     }
   }
   __syncthreads();
+  stamp(a.stamps, 1);
 
   // ---- step 1: dg of this thread's channel and half tile (convmod_kernel MODE 3), its own dc values kept
   const int c = tid % D, half = tid / D;
@@ -725,71 +754,66 @@ __global__ __launch_bounds__(2 * D) __attribute__((amdgpu_waves_per_eu(4, 4))) v
   const int tb0 = half * TH;
   float dcv[TH];
   {
-    float dcol[TH + KS - 1], wk[KS], dgv[TH];
-#pragma unroll
-    for (int u = 0; u < TH + KS - 1; ++u) dcol[u] = G[tb0 + u][c];
+    float wk[KS];
 #pragma unroll
     for (int k = 0; k < KS; ++k) wk[k] = a.w.dw_w[(KS - 1 - k) * D + c];  // [k][D], flipped
+    constexpr int TQ = TH / 2;   // two passes of 8 outputs: 40 dc values + 33 taps live beside the prefetched x rows
 #pragma unroll
-    for (int j = 0; j < TH; ++j) {
-      float acc = 0.f;
+    for (int j0 = 0; j0 < TH; j0 += TQ) {
+      float dcol[TQ + KS - 1];
 #pragma unroll
-      for (int k = 0; k < KS; ++k) acc += wk[k] * dcol[j + k];
-      dgv[j] = acc;
-      dcv[j] = a.w.causal ? dcol[j] : dcol[j + (KS - 1) / 2];
+      for (int u = 0; u < TQ + KS - 1; ++u) dcol[u] = G[tb0 + j0 + u][c];
+#pragma unroll
+      for (int j = 0; j < TQ; ++j) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) acc += wk[k] * dcol[j + k];
+        if (t0 + tb0 + j0 + j < a.T) a.dg[((size_t)b * a.T + t0 + tb0 + j0 + j) * D + c] = acc;
+      }
     }
 #pragma unroll
-    for (int j = 0; j < TH; ++j)
-      if (t0 + tb0 + j < a.T) a.dg[((size_t)b * a.T + t0 + tb0 + j) * D + c] = dgv[j];
+    for (int j = 0; j < TH; ++j) dcv[j] = G[tb0 + j + (a.w.causal ? 0 : (KS - 1) / 2)][c];
   }
   __syncthreads();  // every thread has its dc column in registers
+  stamp(a.stamps, 2);
 
-  // ---- step 2: g = glu(LayerNorm(x)) rows (tile + halo) into the same rows: convmod_kernel's phase 1
+  // ---- step 2: g = glu(LayerNorm(x)) rows (tile + halo) into the same rows: convmod_kernel's phase 1 on the prefetched rows
   {
     const float w0 = a.w.pw1_w[0], w1 = a.w.pw1_w[1], b0 = a.w.pw1_b[0], b1 = a.w.pw1_b[1];
-    constexpr int LPR = D / 32, RPB = NTHR / LPR;
-    static_assert(LPR == 8 || LPR == 16, "row reductions are written for 8 or 16 lanes per row");
-    const int part = tid % LPR;
+    if constexpr (!PRE) {
 #pragma unroll
-    for (int r0 = 0; r0 < ROWS; r0 += RPB) {
-      const int row = r0 + tid / LPR;
-      if (row >= ROWS) break;
-      const int t = t0 - H2 + row;
-      const bool inside = t >= 0 && t < a.T;
-      const float* xr = a.x + ((size_t)b * a.T + (inside ? t : 0)) * D;
-      float4 v[8];
+      for (int i = 0; i < 8; ++i) xv[i] = *reinterpret_cast<const float4*>(xr + (i * LPR + xpart) * 4);
+    }
+    float s = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(xr + (i * LPR + part) * 4);
-      float s = 0.f;
+    for (int i = 0; i < 8; ++i) s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
+    s = sum8(s);
+    if constexpr (LPR == 16) s += dpp_mov<DPP_MIRROR>(s);
+    const float mean = s * (1.f / D);
+    float ss = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-      s = sum8(s);
-      if constexpr (LPR == 16) s += dpp_mov<DPP_MIRROR>(s);
-      const float mean = s * (1.f / D);
-      float ss = 0.f;
+    for (int i = 0; i < 8; ++i) {
+      xv[i].x -= mean; xv[i].y -= mean; xv[i].z -= mean; xv[i].w -= mean;
+      ss += (xv[i].x * xv[i].x + xv[i].y * xv[i].y) + (xv[i].z * xv[i].z + xv[i].w * xv[i].w);
+    }
+    ss = sum8(ss);
+    if constexpr (LPR == 16) ss += dpp_mov<DPP_MIRROR>(ss);
+    const float rstd = rsqrtf(ss * (1.f / D) + 1e-5f);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
-        ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
-      }
-      ss = sum8(ss);
-      if constexpr (LPR == 16) ss += dpp_mov<DPP_MIRROR>(ss);
-      const float rstd = rsqrtf(ss * (1.f / D) + 1e-5f);
+    for (int i = 0; i < 8; ++i) {
+      const int cc = (i * LPR + xpart) * 4;
+      const float4 gm = *reinterpret_cast<const float4*>(a.w.ln_g + cc);
+      const float4 bt = *reinterpret_cast<const float4*>(a.w.ln_b + cc);
+      float e[4] = {xv[i].x * rstd * gm.x + bt.x, xv[i].y * rstd * gm.y + bt.y, xv[i].z * rstd * gm.z + bt.z,
+                    xv[i].w * rstd * gm.w + bt.w};
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int cc = (i * LPR + part) * 4;
-        const float4 gm = *reinterpret_cast<const float4*>(a.w.ln_g + cc);
-        const float4 bt = *reinterpret_cast<const float4*>(a.w.ln_b + cc);
-        float e[4] = {v[i].x * rstd * gm.x + bt.x, v[i].y * rstd * gm.y + bt.y, v[i].z * rstd * gm.z + bt.z,
-                      v[i].w * rstd * gm.w + bt.w};
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          e[q] = inside ? (w0 * e[q] + b0) * __builtin_amdgcn_rcpf(1.f + __expf(-(w1 * e[q] + b1))) : 0.f;
-        *reinterpret_cast<float4*>(&G[row][cc]) = make_float4(e[0], e[1], e[2], e[3]);
-      }
+      for (int q = 0; q < 4; ++q)
+        e[q] = xinside ? (w0 * e[q] + b0) * __builtin_amdgcn_rcpf(1.f + __expf(-(w1 * e[q] + b1))) : 0.f;
+      *reinterpret_cast<float4*>(&G[xrow][cc]) = make_float4(e[0], e[1], e[2], e[3]);
     }
   }
   __syncthreads();
+  stamp(a.stamps, 3);
 
   // ---- step 3: d dw_w[k][c] = sum_t dc[t][c] * g[t + k - halo][c], d dw_b[c] = sum_t dc[t][c]  (convmod_kernel MODE 2)
   float sk[KS], sdc = 0.f;
@@ -808,6 +832,7 @@ __global__ __launch_bounds__(2 * D) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     }
   }
   __syncthreads();  // every thread has taken its g rows
+  stamp(a.stamps, 4);
 
   // ---- step 4: the second half tile hands its 34 sums to the first through rows [0, KS + 1); pass C's d ln_g terms go to rows
   // [KS + 1, KS + 1 + TT), its d ln_b terms to rows [0, TT)
@@ -828,6 +853,7 @@ __global__ __launch_bounds__(2 * D) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     out[KS * D] = sdc + X[KS * D + c];
   }
   __syncthreads();  // the hand-over block has been read: rows [0, TT) take pass C's d ln_b terms
+  stamp(a.stamps, 5);
 
   // ---- pass C (glu_ln_bwd_kernel): LR lanes per row, 16 channels per lane as four float4 pieces
   constexpr int LR = NTHR / TT, NP = D / (4 * LR);
@@ -876,7 +902,7 @@ __global__ __launch_bounds__(2 * D) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         const float h = xh[i][q] * rstd;
         const float av = h * gm[q] + bt[q];
         const float u = w0 * av + b0;
-        const float sg = 1.f / (1.f + __expf(-(w1 * av + b1)));
+        const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-(w1 * av + b1)));   // (v_rcp_f32, 1 ulp, as the forward's GLU)
         const float dgq = valid ? dd[i][q] : 0.f;
         const float du = dgq * sg;
         const float dv = dgq * u * sg * (1.f - sg);
@@ -912,6 +938,7 @@ __global__ __launch_bounds__(2 * D) __attribute__((amdgpu_waves_per_eu(4, 4))) v
       }
     }
   }
+  stamp(a.stamps, 6);
   sw0 = wave_sum(sw0); sw1 = wave_sum(sw1); sb0 = wave_sum(sb0); sb1 = wave_sum(sb1);
   if ((tid & 63) == 0) { red[tid >> 6][0] = sw0; red[tid >> 6][1] = sw1; red[tid >> 6][2] = sb0; red[tid >> 6][3] = sb1; }
   __syncthreads();
@@ -928,6 +955,7 @@ __global__ __launch_bounds__(2 * D) __attribute__((amdgpu_waves_per_eu(4, 4))) v
       out[2 * D + tid] = sc;
     }
   }
+  stamp(a.stamps, 7);
 }
 
 // rows per workgroup of the row-wise backward passes: short row loops, many waves in flight (these passes are chains of
@@ -989,7 +1017,7 @@ int run_bwd(const float* x, const float* dy, const csship_conv_weights& w, int B
     // they may wait for the block's flush
     const int ntile = (T + TT - 1) / TT * B;
     float* part_b = part;   // (pass A's partials there were consumed by its reduction, which is never deferred)
-    ConvBwdArgs fa{x, dy, z, stats, phase == 2 ? sums : gA, w, inv_n, dx, dg, part_b, part_c, B, T, dcfg, nx};
+    ConvBwdArgs fa{x, dy, z, stats, phase == 2 ? sums : gA, w, inv_n, dx, dg, part_b, part_c, B, T, dcfg, nx, g_csship_stamps};
     hipLaunchKernelGGL((conv_bwd_fused_kernel<D, TT, 33>), dim3((T + TT - 1) / TT, B), dim3(2 * D), 0, s, fa);
     CSSHIP_CHECK_LAUNCH();
     rc = launch_slab_reduce(part_b, ntile, (int64_t)34 * D, 34 * D, (int64_t)34 * D, 1.f, nullptr, nullptr, 0, gB, s, true);

@@ -29,6 +29,8 @@ class deferred_reductions:
 
     def __init__(self, group_wgrads=False):
         self.group = bool(group_wgrads) and not _NO_GROUP and not _NO_DEFER
+        self.held = []     # flush(side=...): operands / slabs of launches that may still be running on the side stream
+        self.side = None
 
     def __enter__(self):
         if _NO_DEFER:   # A/B timing: every reduction as its own launch
@@ -41,7 +43,20 @@ class deferred_reductions:
             _defer["group"] = True
         return self
 
-    def flush(self):
+    def flush(self, side=None):
+        """side: a second stream - the queued launches produce parameter gradients only, nothing on the data-gradient chain
+        waits for them: they run on ``side`` behind everything the current stream has been given so far, beside what it is
+        given next.  Their operands stay referenced (``held``) until ``join()``, which the caller owes before anyone reads
+        those gradients (and before a stream capture ends)."""
+        if side is not None and (lib().csship_wgrad_pending() or lib().csship_reduce_pending()):
+            ev = torch.cuda.Event()
+            ev.record()
+            side.wait_event(ev)
+            self.side = side
+            self.held.extend(_deferred_ws)
+            with torch.cuda.stream(side):
+                self.flush()
+            return
         if lib().csship_wgrad_pending():
             nws = lib().csship_wgrad_group_workspace()
             dev = _defer["dev"]
@@ -54,10 +69,17 @@ class deferred_reductions:
             check(lib().csship_reduce_flush(_stream()))
         _deferred_ws.clear()
 
+    def join(self):
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+            self.side = None
+        self.held.clear()
+
     def __exit__(self, et, ev, tb):
         try:
             if et is None:
                 self.flush()
+            self.join()
         finally:
             if self.group and not self.was_group:
                 lib().csship_wgrad_hold(0)

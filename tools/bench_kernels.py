@@ -163,6 +163,28 @@ def bench_conv():
         print(f"convmod batch_stats={int(bs)}  {us:8.1f} us  {2 * M * D * 4 / us / 1e3:8.1f} GB/s (x in + y out)")
 
 
+def bench_conv_bwd():
+    """the conv module's backward (csship_convmod_bwd_next: statistics pass + reduce + the fused tile kernel, or the four
+    launches with CSSHIP_CONV_BWD_UNFUSED=1), with the reference's dropout sites on"""
+    from css_amd import ops_bwd as ob
+    from css_amd.dropout import DropState
+    full = syn.conformer_shapes(num_blocks=1)
+    pre = "conformer.encoders.0.conv."
+    sd = syn.fill_state_dict({k[len(pre):]: s for k, s in full.items() if k.startswith(pre)}, 1)
+    w = {"ln_g": sd["layer_norm.weight"], "ln_b": sd["layer_norm.bias"], "pw1_w": sd["pw_conv_1.weight"].reshape(2),
+         "pw1_b": sd["pw_conv_1.bias"], "dw_w": sd["dw_conv_1d.weight"].reshape(256, 33).t(), "dw_b": sd["dw_conv_1d.bias"],
+         "bn_g": sd["BN.weight"], "bn_b": sd["BN.bias"], "bn_mean": sd["BN.running_mean"], "bn_var": sd["BN.running_var"],
+         "pw2_w": sd["pw_conv_2.weight"].reshape(1), "pw2_b": sd["pw_conv_2.bias"]}
+    w = {k: v.contiguous().to(DEV) for k, v in w.items()}
+    x = torch.randn(B, T, D, device=DEV)
+    dy = torch.randn(B, T, D, device=DEV) * 0.1
+    st = DropState(torch.tensor([5], dtype=torch.int32, device=DEV), 0.1, 0)
+    c_out, c_next = st.cfg("0.conv.out"), st.cfg("0.attn.out")
+    _, fws = ops.convmod(x, w, 33, batch_stats=True, return_workspace=True, drop=c_out)
+    us = timeit(lambda: ob.convmod_bwd(x, dy, w, fws, 33, drop=c_out, want_next=True, next_drop=c_next))
+    print(f"convmod_bwd (+ next operand)  {us:8.1f} us  {M * D * (4 * 4 + 2) / us / 1e3:8.1f} GB/s algorithmic (x, dy, z in; dx + bf16 operand out)")
+
+
 def bench_stft():
     n = 512 + 256 * (T - 1)
     a = 0.1 * torch.randn(3, B, n, device=DEV)
@@ -187,7 +209,7 @@ def bench_ln():
     print(f"layernorm  {us:8.1f} us  {M * D * 6 / us / 1e3:8.1f} GB/s")
 
 
-ALL = {"chain": bench_chain, "ffn": bench_ffn, "ffn_bwd": bench_ffn_bwd, "linear": bench_linear, "attn": bench_attn, "attn_bwd": bench_attn_bwd, "conv": bench_conv, "stft": bench_stft,
+ALL = {"chain": bench_chain, "ffn": bench_ffn, "ffn_bwd": bench_ffn_bwd, "linear": bench_linear, "attn": bench_attn, "attn_bwd": bench_attn_bwd, "conv": bench_conv, "conv_bwd": bench_conv_bwd, "stft": bench_stft,
        "pit": bench_pit, "ln": bench_ln}
 
 if __name__ == "__main__":
