@@ -193,6 +193,11 @@ SIGNATURES = {
     "csship_ffn_bwd_ln_workspace": (_sz, [_i32]),
     "csship_ffn_bwd_ln": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _dc, _dc, _p,
                                   _p, _p, _p, _p, _sz, _p]),
+    "csship_ffn_bwd_conv_workspace": (_sz, [_i32]),
+    "csship_ffn_bwd_conv": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _dc, _dc, _p,
+                                   _p, _i32, _i32, _p, _dc, _p, _p, _sz, _p]),
+    "csship_convmod_bwd_after_stats": (_i32, [_p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _dc, _dc, _p, _p,
+                                              _sz, _p]),
     "csship_qkv_in_bwd_workspace": (_sz, [_i32]),
     "csship_qkv_ffn_bwd_workspace": (_sz, [_i32]),
     "csship_qkv_ffn_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p,                                   # dqkv .. attn dgamma | dbeta

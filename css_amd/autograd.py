@@ -65,6 +65,7 @@ def _owners(ps):
 
 # Experiment (round 6): a block's grouped weight-gradient launch + parameter reductions on a second stream (one fork per block,
 # one join at the end of the backward pass) beside the next block's data-gradient chain.  Single-process steps only.
+_NO_FFN_CONV = bool(os.environ.get("CSSHIP_NO_FFN_CONV"))   # A/B timing: the conv module's statistics pass as its own launch
 _WGRAD_SIDE = bool(os.environ.get("CSSHIP_WGRAD_SIDE"))
 _side_streams = {}
 
@@ -505,7 +506,7 @@ class ConformerTrain(torch.autograd.Function):
                 dx, dg, dbeta = ob.layernorm_bwd(L["x4"], dx, lay.layer_norm.weight.detach(), lay.layer_norm.bias.detach())
                 put(lay.layer_norm.weight, dg), put(lay.layer_norm.bias, dbeta)
 
-            def ffn_b(m, tag, dy, ln2=None):
+            def ffn_b(m, tag, dy, ln2=None, conv=None):
                 dh, do = ds.cfg(f"{li}.{tag}.hidden"), ds.cfg(f"{li}.{tag}.out")
                 if S["wide"]:
                     xin, w1_bf, w2_bf = L[tag]
@@ -517,17 +518,28 @@ class ConformerTrain(torch.autograd.Function):
                     outs = tuple(_direct_grad(q) for q in (m.net[0].weight, m.net[0].bias, m.net[3].weight, m.net[3].bias))
                     dxo, g = bw.ffn_bwd_fused(xin, dy, m.layer_norm.weight.detach(), m.layer_norm.bias.detach(),
                                               m.net[0].bias.detach(), w1p, w2tp, w1tp, enc.d_ffn, 0.5,
-                                              drop_hidden=dh, drop_out=do, outs=outs, ln2=ln2)
+                                              drop_hidden=dh, drop_out=do, outs=outs, ln2=ln2, conv=conv)
                 for p, gv in zip((m.layer_norm.weight, m.layer_norm.bias, m.net[0].weight, m.net[0].bias,
                                   m.net[3].weight, m.net[3].bias), g):
                     put(p, gv)
                 return (dxo, g[6:]) if ln2 is not None else dxo
 
-            dx = ffn_b(lay.feed_forward_out, "ffn_out", dx)
             x2, W, fws = L["conv"]
             c = lay.conv
+            # the statistics pass of the conv module's backward rides in the epilogue of the FeedForward backward in front of it
+            cflat = None
+            if (not S["wide"] and not S["sync_bn"] and not _NO_CONV_NEXT and not _NO_FFN_CONV and D == 256 and M % 64 == 0
+                    and enc.d_ffn <= ob.ffn_static_max_ffn() and enc.d_ffn % 256 == 0 and enc.kernel_size == 33):
+                cflat = torch.empty(38 * D + 8, dtype=torch.float32, device=dx.device)
+                dx = ffn_b(lay.feed_forward_out, "ffn_out", dx, conv=(fws, W["pw2_w"], ds.cfg(f"{li}.conv.out"), cflat, B, T))
+            else:
+                dx = ffn_b(lay.feed_forward_out, "ffn_out", dx)
             dyb = None
-            if S["sync_bn"] or _NO_CONV_NEXT:
+            if cflat is not None:
+                dx3, g, dyb = ob.convmod_bwd(x2.view(B, T, D), dx.view(B, T, D), W, fws, enc.kernel_size,
+                                             bn_eval=not S["batch_bn"], drop=ds.cfg(f"{li}.conv.out"), want_next=True,
+                                             next_drop=ds.cfg(f"{li}.attn.out"), flat=cflat, stats_done=True)
+            elif S["sync_bn"] or _NO_CONV_NEXT:
                 dx3, g = ob.convmod_bwd(x2.view(B, T, D), dx.view(B, T, D), W, fws, enc.kernel_size,
                                         bn_eval=not S["batch_bn"], drop=ds.cfg(f"{li}.conv.out"), sync=S["sync_bn"])
             else:   # also the gradient through the attention output's dropout, as the bf16 operand of the two products behind it

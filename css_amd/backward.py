@@ -61,12 +61,13 @@ def ffn_bwd(x, dy, ln_g, ln_b, b1, w1_bf, w2_bf, alpha=0.5, drop_hidden=None, dr
 
 
 def ffn_bwd_fused(x, dy, ln_g, ln_b, b1, w1p, w2tp, w1tp, d_ffn, alpha=0.5, drop_hidden=None, drop_out=None,
-                  outs=(None, None, None, None), ln2=None):
+                  outs=(None, None, None, None), ln2=None, conv=None):
     """ffn_bwd with the activation side in ONE row-panel kernel (d_model = 256): LN + hidden recompute, masked dh,
     da and the LayerNorm backward never leave the CU; the four weight / bias gradients are GEMMs / column sums over
     the B*T rows.  w1p / w2tp / w1tp: fragment-packed W1, W2^T, W1^T.  ln2 = (x2, gamma2) when x = LayerNorm2(x2): dx
-    comes back as the gradient wrt x2 and the gradient tuple ends with that LayerNorm's (dgamma2, dbeta2)."""
-    res = ob.ffn_bwd(x, dy, ln_g, ln_b, w1p, b1, w2tp, w1tp, d_ffn, alpha, drop_hidden, drop_out, ln2=ln2)
+    comes back as the gradient wrt x2 and the gradient tuple ends with that LayerNorm's (dgamma2, dbeta2).  conv: see
+    ob.ffn_bwd (the statistics pass of the conv module in front rides in the kernel's epilogue)."""
+    res = ob.ffn_bwd(x, dy, ln_g, ln_b, w1p, b1, w2tp, w1tp, d_ffn, alpha, drop_hidden, drop_out, ln2=ln2, conv=conv)
     return _ffn_wgrads(res, dy, alpha, outs)
 
 

@@ -106,6 +106,10 @@ int launch_outproj_conv_train(const uint16_t* attn_out, const uint16_t* wo_packe
                               float* x2_out, const csship_conv_weights& conv, int B, int T, csship_dropout_cfg drop,
                               float* zbuf, float* partial, int* nblk_out, hipStream_t s);
 
+// floats from the start of csship_convmod's training workspace (= the pre-BatchNorm activations z [B, T, D]) to its
+// statistics block scale | shift | mean | variance (convmod.hip owns the layout; csship_ffn_bwd_conv reads both)
+size_t convmod_fwd_stats_offset(int B, int T, int D);
+
 // Optional in-kernel phase stamps (diagnostic only; nullptr in normal operation): thread 0 of every
 // workgroup stores s_memrealtime (100 MHz) at up to 8 phase boundaries.  Set by csship_debug_stamps().
 extern unsigned long long* g_csship_stamps;

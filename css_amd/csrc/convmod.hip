@@ -982,7 +982,8 @@ BwdLayout bwd_layout(int B, int T, int D, int TT) {
 
 template <int D, int TT>
 // phase 0: everything; SyncBN: phase 1 = pass A (+ this rank's S1 | S2 copied to the workspace's sums block, which the
-// caller all-reduces), phase 2 = the rest with those sums and the GLOBAL row count
+// caller all-reduces), phase 2 = the rest with those sums and the GLOBAL row count; phase 3 = the rest with the sums pass A's
+// stand-in left in `grads` (csship_convmod_bwd_after_stats)
 int run_bwd(const float* x, const float* dy, const csship_conv_weights& w, int B, int T, const float* fwd_ws, float* dx,
             float* grads, float* ws, int bn_eval, hipStream_t s, csship_dropout_cfg dcfg, int phase = 0,
             double total_rows = 0.0, NextOut nx = NextOut{}) {
@@ -990,8 +991,7 @@ int run_bwd(const float* x, const float* dy, const csship_conv_weights& w, int B
   const int64_t M = (int64_t)B * T;
   const size_t n = (size_t)M * D;
   const float* z = fwd_ws;
-  const int fwd_nblk = ((T + TT - 1) / TT) * B * 2;
-  const float* stats = fwd_ws + n + (size_t)fwd_nblk * 2 * D + 4 * D;
+  const float* stats = fwd_ws + convmod_fwd_stats_offset(B, T, D);
   float *dc = ws + L.dc, *dg = ws + L.dg, *part = ws + L.part, *part_c = ws + L.part_c;
   // grads layout (CSSHIP_CONV_GRADS_*): [bn_b D | bn_g D | pw2_w 1 | pw2_b 1 | pad 2][dw_w 33*D | dw_b D][ln_g D | ln_b D | pw1_w 2 | pw1_b 2]
   float* gA = grads;
@@ -999,7 +999,7 @@ int run_bwd(const float* x, const float* dy, const csship_conv_weights& w, int B
   float* gC = gB + 34 * D;
   float* sums = ws + L.sums;
   int rc = 0;
-  if (phase != 2) {
+  if (phase != 2 && phase != 3) {   // (3: pass A and its reduction were run by the operator in front - csship_ffn_bwd_conv - into gA)
     // pass A
     hipLaunchKernelGGL((conv_bn_bwd_stats_kernel<D>), dim3(L.nwg_rows), dim3(D), 0, s, dy, z, stats, w.pw2_w, M, BWD_ROWS, part, dcfg);
     CSSHIP_CHECK_LAUNCH();
@@ -1049,6 +1049,12 @@ int run_bwd(const float* x, const float* dy, const csship_conv_weights& w, int B
 }
 
 }  // namespace
+
+size_t convmod_fwd_stats_offset(int B, int T, int D) {   // (as run_bwd finds them: z, the tile partials, the f64 sums, then the statistics)
+  const int TT = D == 256 ? TT256 : TT512;
+  const size_t fwd_nblk = (size_t)((T + TT - 1) / TT) * B * 2;
+  return (size_t)B * T * D + fwd_nblk * 2 * D + 4 * (size_t)D;
+}
 
 extern "C" size_t csship_convmod_workspace(int32_t B, int32_t T, int32_t D) {
   const int TT = D == 256 ? TT256 : TT512;
@@ -1195,6 +1201,16 @@ extern "C" int csship_convmod_bwd_next(const float* x, const float* dy, const cs
   if (!dx_next_bf16 || !aligned8(dx_next_bf16)) return dx_next_bf16 ? CSSHIP_EALIGN : CSSHIP_ENULL;
   return convmod_bwd_impl(x, dy, w, B, T, D, kernel_size, fwd_workspace, dx, grads, bn_eval, drop, workspace, workspace_bytes,
                           stream, 0, 0.0, next_drop, dx_next_bf16);
+}
+
+extern "C" int csship_convmod_bwd_after_stats(const float* x, const float* dy, const csship_conv_weights* w, int32_t B,
+                                              int32_t T, int32_t D, int32_t kernel_size, const void* fwd_workspace, float* dx,
+                                              float* grads, int32_t bn_eval, const csship_dropout_cfg* drop,
+                                              const csship_dropout_cfg* next_drop, uint16_t* dx_next_bf16, void* workspace,
+                                              size_t workspace_bytes, csship_stream_t stream) {
+  if (dx_next_bf16 && !aligned8(dx_next_bf16)) return CSSHIP_EALIGN;
+  return convmod_bwd_impl(x, dy, w, B, T, D, kernel_size, fwd_workspace, dx, grads, bn_eval, drop, workspace, workspace_bytes,
+                          stream, 3, 0.0, next_drop, dx_next_bf16);
 }
 
 extern "C" int csship_convmod_bwd_drop(const float* x, const float* dy, const csship_conv_weights* w, int32_t B, int32_t T,

@@ -380,6 +380,14 @@ struct FfnBwdArgs {
   const float* ln2_x;                 // [M, 256] the LayerNorm's input rows
   const float* ln2_g;
   float* part2;                       // [nwg][2][256]
+  // CS (optional): dx is the output gradient of the conv module in front of this FeedForward (the block's feed_forward_out,
+  // conformer.py:357-358): the statistics pass of that module's backward (conv_bn_bwd_stats_kernel, convmod.hip) rides in the
+  // epilogue - per channel S1 = sum dzh, S2 = sum dzh * zn, and the scalars d pw2_w, d pw2_b, as partials per workgroup
+  const float* cs_z;                  // [M, 256] the module's pre-BatchNorm activations
+  const float* cs_stats;              // [4][256] scale | shift | mean | variance
+  const float* cs_pw2_w;
+  csship_dropout_cfg cs_drop;         // the module's output dropout site
+  float* cs_part;                     // [nwg][2 * 256 + 2]
 };
 
 // FULL (M % 64 == 0, d_ffn <= 2048: what the encoder runs): no row predicates on loads or stores, and b1 / gamma / beta
@@ -390,10 +398,11 @@ struct FfnBwdArgs {
 // tile), Pb = FULL: b1 | gamma | beta | gamma2 | dump.  DYREG: dy arrives in registers (this thread's pieces of row tid >> 3, the
 // row mapping of the prologue) from the stage in front of it in the same kernel (qkv_ffn_bwd_kernel) instead of from memory.
 constexpr int FB_XD_BYTES = 2 * PANEL_BYTES, FB_GRAW_BYTES = 2 * PANEL_BYTES + 1024, FB_PB_FLOATS = CS_FFMAX + 3 * DM + CS_DUMP;
-template <int NW, bool FULL, bool LN2, bool DYREG>
+template <int NW, bool FULL, bool LN2, bool DYREG, bool CS = false>
 DEV void ffn_bwd_body(const FfnBwdArgs& a, unsigned char* const XD, unsigned char* const Graw, float* const Pb,
                       const float4 (&dyin)[8]) {
   static_assert(FULL || !LN2, "the fused second LayerNorm backward is built for whole panels");
+  static_assert(!CS || (FULL && !LN2), "the conv module's statistics ride behind a whole-panel FeedForward without a second LayerNorm");
   static_assert(FULL || !DYREG, "the chained form is built for whole panels");
   static_assert(NW * 64 == 8 * BM, "row phases assume 8 lanes per panel row");
   constexpr int NT = 16 / NW;
@@ -422,9 +431,13 @@ DEV void ffn_bwd_body(const FfnBwdArgs& a, unsigned char* const XD, unsigned cha
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int j = tid + 512 * k;
-      const float* const base = j < q1 ? a.b1 : j < q1 + 64 ? a.ln_g : j < q1 + 128 ? a.ln_b : (LN2 && j < q1 + 192) ? a.ln2_g : nullptr;
-      const int off = j < q1 ? j : j < q1 + 64 ? j - q1 : j < q1 + 128 ? j - q1 - 64 : j - q1 - 128;
-      pdd[k] = base != nullptr ? (j < q1 ? j * 4 : CS_FFMAX + (j - q1) * 4) : CS_FFMAX + 3 * DM + lane * 4;
+      // CS: the conv module's scale | shift | mean | variance (256 float4) behind the dump block (FF / 4 + 192 + 256 <= 1024 slots)
+      const bool csj = CS && j >= q1 + 192 && j < q1 + 448;
+      const float* const base = j < q1 ? a.b1 : j < q1 + 64 ? a.ln_g : j < q1 + 128 ? a.ln_b : (LN2 && j < q1 + 192) ? a.ln2_g
+                                : csj ? a.cs_stats : nullptr;
+      const int off = j < q1 ? j : j < q1 + 64 ? j - q1 : j < q1 + 128 ? j - q1 - 64 : csj ? j - q1 - 192 : j - q1 - 128;
+      pdd[k] = csj ? FB_PB_FLOATS + (j - q1 - 192) * 4
+                   : base != nullptr ? (j < q1 ? j * 4 : CS_FFMAX + (j - q1) * 4) : CS_FFMAX + 3 * DM + lane * 4;
       pvv[k] = *reinterpret_cast<const float4*>(base != nullptr ? base + off * 4 : dummy);
     }
     *reinterpret_cast<float4*>(Pb + pdd[0]) = pvv[0];
@@ -582,9 +595,11 @@ DEV void ffn_bwd_body(const FfnBwdArgs& a, unsigned char* const XD, unsigned cha
   const bool rvalid = FULL || row < a.M;
   float4 v[8], da[8], dyv[8];
   float4 x2[LN2 ? 8 : 1];
+  float4 zr[CS ? 8 : 1];   // CS: this thread's pieces of the conv module's z row, requested with the x row
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     v[i] = *reinterpret_cast<const float4*>(a.x + (size_t)rowc * DM + (i * 8 + part) * 4);
+    if constexpr (CS) zr[i] = *reinterpret_cast<const float4*>(a.cs_z + (size_t)rowc * DM + (i * 8 + part) * 4);
     if constexpr (LN2) x2[i] = *reinterpret_cast<const float4*>(a.ln2_x + (size_t)rowc * DM + (i * 8 + part) * 4);
     // dy is needed by the dx rows below: requested here, all eight at once (read next to its use, behind stores it might
     // alias, every piece was a load - s_waitcnt vmcnt(0) - store round trip of its own: eight L2 latencies in a row)
@@ -619,6 +634,8 @@ DEV void ffn_bwd_body(const FfnBwdArgs& a, unsigned char* const XD, unsigned cha
   __syncthreads();  // all da values are in registers: the Ys tile (and Xs / Ds) can be reused for the column sums
   float* cg = reinterpret_cast<float*>(Graw);  // [64][260] da * xhat
   float* cb = reinterpret_cast<float*>(XD);    // [64][256] da       (both panels: 64 KB)
+  float4 t1[CS ? 8 : 1], t2[CS ? 8 : 1];   // CS: dzh and dzh * zn of this thread's pieces
+  float cs_dw3 = 0.f, cs_db3 = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int col = (i * 8 + part) * 4;
@@ -631,6 +648,29 @@ DEV void ffn_bwd_body(const FfnBwdArgs& a, unsigned char* const XD, unsigned cha
       o4.w = d.w + rstd * (gg[i].w - s1 - v[i].w * s2);
       if constexpr (LN2) dyv[i] = o4;   // goes on through the second LayerNorm below
       else *reinterpret_cast<float4*>(a.dx + (size_t)row * DM + col) = o4;
+      if constexpr (CS) {   // conv_bn_bwd_stats_kernel's terms on the dx row just formed (its dy), same element order per row
+        const Drop cdp = drop_make(a.cs_drop.seed, a.cs_drop.stream, a.cs_drop.p);
+        const float* const cst = Pb + FB_PB_FLOATS;   // staged at the kernel's start
+        const float4 sc4 = *reinterpret_cast<const float4*>(cst + col), sh4 = *reinterpret_cast<const float4*>(cst + DM + col);
+        const float4 mu4 = *reinterpret_cast<const float4*>(cst + 2 * DM + col), va4 = *reinterpret_cast<const float4*>(cst + 3 * DM + col);
+        const float w3 = a.cs_pw2_w[0];
+        const float4 d4 = drop_apply4(cdp, (unsigned)(row * DM + col), o4);
+        const float dd[4] = {d4.x, d4.y, d4.z, d4.w}, zz[4] = {zr[i].x, zr[i].y, zr[i].z, zr[i].w};
+        const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w}, muv[4] = {mu4.x, mu4.y, mu4.z, mu4.w};
+        const float rsv[4] = {rsqrtf(va4.x + 1e-5f), rsqrtf(va4.y + 1e-5f), rsqrtf(va4.z + 1e-5f), rsqrtf(va4.w + 1e-5f)};
+        float u1[4], u2[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float zh = zz[q] * scv[q] + shv[q];
+          const float dzh = zh > 0.f ? dd[q] * w3 : 0.f;
+          u1[q] = dzh;
+          u2[q] = dzh * (zz[q] - muv[q]) * rsv[q];
+          cs_dw3 += dd[q] * fmaxf(zh, 0.f);
+          cs_db3 += dd[q];
+        }
+        t1[i] = make_float4(u1[0], u1[1], u1[2], u1[3]);
+        t2[i] = make_float4(u2[0], u2[1], u2[2], u2[3]);
+      }
     }
     *reinterpret_cast<float4*>(cg + r * YS + col) = make_float4(da[i].x * v[i].x, da[i].y * v[i].y, da[i].z * v[i].z, da[i].w * v[i].w);
     *reinterpret_cast<float4*>(cb + r * DM + col) = da[i];
@@ -647,6 +687,38 @@ DEV void ffn_bwd_body(const FfnBwdArgs& a, unsigned char* const XD, unsigned cha
       for (int rr = 0; rr < BM; ++rr) acc += cb[rr * DM + col];
     }
     a.part[(size_t)blockIdx.x * 2 * DM + which * DM + col] = acc;
+  }
+  if constexpr (CS) {
+    // the conv module's S1 | S2 column sums through the two staging tiles once more; its two scalars through the dump block
+    cs_dw3 = wave_sum(cs_dw3);
+    cs_db3 = wave_sum(cs_db3);
+    __syncthreads();  // the first column sums have been read
+    float* const sred = Pb + CS_FFMAX + 3 * DM;   // [NW][2] in the dump block (nobody stages parameters any more)
+    if (lane == 0) { sred[wave * 2] = cs_dw3; sred[wave * 2 + 1] = cs_db3; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int col = (i * 8 + part) * 4;
+      *reinterpret_cast<float4*>(cg + r * YS + col) = t1[i];
+      *reinterpret_cast<float4*>(cb + r * DM + col) = t2[i];
+    }
+    __syncthreads();
+    const int col = tid & 255, which = tid >> 8;
+    float acc = 0.f;
+    if (which == 0) {
+#pragma unroll 8
+      for (int rr = 0; rr < BM; ++rr) acc += cg[rr * YS + col];
+    } else {
+#pragma unroll 8
+      for (int rr = 0; rr < BM; ++rr) acc += cb[rr * DM + col];
+    }
+    float* const out = a.cs_part + (size_t)blockIdx.x * (2 * DM + 2);
+    out[which * DM + col] = acc;
+    if (tid < 2) {
+      float sc = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < NW; ++wv) sc += sred[wv * 2 + tid];
+      out[2 * DM + tid] = sc;
+    }
   }
   if constexpr (LN2) {
     // dx (in dyv) is the gradient of LayerNorm2's output: statistics of its input row, the same three-term formula,
@@ -700,13 +772,13 @@ DEV void ffn_bwd_body(const FfnBwdArgs& a, unsigned char* const XD, unsigned cha
   }
 }
 
-template <int NW, bool FULL, bool LN2 = false>
+template <int NW, bool FULL, bool LN2 = false, bool CS = false>
 __global__ __launch_bounds__(NW * 64) void ffn_bwd_kernel(FfnBwdArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char XD[FB_XD_BYTES];
   __shared__ __attribute__((aligned(16))) unsigned char Graw[FB_GRAW_BYTES];
-  __shared__ __attribute__((aligned(16))) float Pb[FULL ? FB_PB_FLOATS : 4];
+  __shared__ __attribute__((aligned(16))) float Pb[FULL ? FB_PB_FLOATS + (CS ? 4 * DM : 0) : 4];
   float4 none[8];   // (never read: DYREG = false)
-  ffn_bwd_body<NW, FULL, LN2, false>(a, XD, Graw, Pb, none);
+  ffn_bwd_body<NW, FULL, LN2, false, CS>(a, XD, Graw, Pb, none);
 }
 
 // =============================================================================== panel linear
@@ -2615,6 +2687,47 @@ extern "C" int csship_ffn_bwd_ln(const float* x, const float* dy, const float* l
                                     dgamma_dbeta, as_stream(stream), true);
   if (rc != CSSHIP_OK || !ln2) return rc;
   return launch_slab_reduce(part2, nwg, 2 * DM, 2 * DM, 2 * DM, 1.f, nullptr, nullptr, 0, dgamma_dbeta2, as_stream(stream), true);
+}
+
+extern "C" size_t csship_ffn_bwd_conv_workspace(int32_t M) {
+  return csship_ffn_bwd_workspace(M) + (size_t)((M + BM - 1) / BM) * (2 * DM + 2) * sizeof(float);
+}
+
+extern "C" int csship_ffn_bwd_conv(const float* x, const float* dy, const float* ln_g, const float* ln_b,
+                                   const uint16_t* w1_packed, const float* b1, const uint16_t* w2t_packed,
+                                   const uint16_t* w1t_packed, uint16_t* a_bf16, uint16_t* h_bf16, uint16_t* dh_bf16,
+                                   float* dx, float* dgamma_dbeta, int32_t M, int32_t d_model, int32_t d_ffn, float alpha,
+                                   const csship_dropout_cfg* drop_hidden, const csship_dropout_cfg* drop_out,
+                                   uint16_t* dyd_bf16, const void* conv_fwd_workspace, int32_t B, int32_t T,
+                                   const float* conv_pw2_w, const csship_dropout_cfg* conv_drop, float* conv_grads,
+                                   void* workspace, size_t workspace_bytes, csship_stream_t stream) {
+  if (!x || !dy || !ln_g || !ln_b || !w1_packed || !b1 || !w2t_packed || !w1t_packed || !a_bf16 || !h_bf16 || !dh_bf16 ||
+      !dx || !dgamma_dbeta || !workspace || !conv_fwd_workspace || !conv_pw2_w || !conv_grads)
+    return CSSHIP_ENULL;
+  if (M <= 0 || B <= 0 || T <= 0 || (int64_t)B * T != M) return CSSHIP_EBADSHAPE;
+  if (d_model != DM || d_ffn <= 0 || (d_ffn % DM) != 0 || (M % BM) != 0 || d_ffn > CS_FFMAX) return CSSHIP_EUNSUPPORTED;
+  if (!aligned16(x) || !aligned16(dy) || !aligned16(dx) || !aligned16(ln_g) || !aligned16(ln_b) || !aligned16(b1) ||
+      !aligned16(w1_packed) || !aligned16(w2t_packed) || !aligned16(w1t_packed) || !aligned8(a_bf16) || !aligned8(h_bf16) ||
+      !aligned8(dh_bf16) || !aligned16(conv_fwd_workspace) || (dyd_bf16 && !aligned8(dyd_bf16)))
+    return CSSHIP_EALIGN;
+  const int nwg = M / BM;
+  if (workspace_bytes < csship_ffn_bwd_conv_workspace(M)) return CSSHIP_EWORKSPACE;
+  if ((int64_t)nwg * BM * d_ffn > 0xffffffffLL) return CSSHIP_EBADSHAPE;  // 32-bit dropout element indices
+  const csship_dropout_cfg none{nullptr, 0u, 0.f};
+  const bool cdropping = conv_drop && conv_drop->seed && conv_drop->p > 0.f;
+  float* const wsf = reinterpret_cast<float*>(workspace);
+  float* const cs_part = wsf + (size_t)nwg * 2 * DM;
+  const float* const z = reinterpret_cast<const float*>(conv_fwd_workspace);
+  FfnBwdArgs a{x, dy, ln_g, ln_b, reinterpret_cast<const bf16x8*>(w1_packed), b1,
+               reinterpret_cast<const bf16x8*>(w2t_packed), reinterpret_cast<const bf16x8*>(w1t_packed), a_bf16, h_bf16,
+               dh_bf16, dx, wsf, M, d_ffn, alpha, drop_hidden ? *drop_hidden : none, drop_out ? *drop_out : none, dyd_bf16,
+               nullptr, nullptr, nullptr, z, z + convmod_fwd_stats_offset(B, T, DM), conv_pw2_w, cdropping ? *conv_drop : none, cs_part};
+  hipLaunchKernelGGL((ffn_bwd_kernel<NWAVES, true, false, true>), dim3(nwg), dim3(NWAVES * 64), 0, as_stream(stream), a);
+  CSSHIP_CHECK_LAUNCH();
+  // the conv module's sums are read by its own backward right behind this call: reduced at once, like pass A's (never deferred)
+  int rc = launch_slab_reduce(cs_part, nwg, 2 * DM + 2, 2 * DM + 2, 2 * DM + 2, 1.f, nullptr, nullptr, 0, conv_grads, as_stream(stream));
+  if (rc != CSSHIP_OK) return rc;
+  return launch_slab_reduce(wsf, nwg, 2 * DM, 2 * DM, 2 * DM, 1.f, nullptr, nullptr, 0, dgamma_dbeta, as_stream(stream), true);
 }
 
 extern "C" int csship_ffn_bwd(const float* x, const float* dy, const float* ln_g, const float* ln_b,

@@ -357,16 +357,21 @@ def relpos_softmax_bwd(p, dp, T, W):
     return ds, dsk
 
 
-def convmod_bwd(x, dy, weights, fwd_ws, kernel_size=33, bn_eval=False, drop=None, sync=False, want_next=False, next_drop=None):
+def convmod_bwd(x, dy, weights, fwd_ws, kernel_size=33, bn_eval=False, drop=None, sync=False, want_next=False, next_drop=None,
+                flat=None, stats_done=False):
     """Backward of ops.convmod(x, weights, batch_stats=True) (or keep_activations=True with bn_eval=True).  x, dy f32 [B,T,D]; fwd_ws: that call's workspace.
     Returns dx and a dict of f32 gradients keyed like the weights dict (dw_w as [k, D]).  want_next (not with sync): a
     third result bf16 [B*T, D] = dropout(dx) under ``next_drop`` (None: bf16(dx)), the operand of the next operator of the
-    backward pass (csship_convmod_bwd_next)."""
+    backward pass (csship_convmod_bwd_next).  flat + stats_done (not with sync): the gradient buffer in which
+    ffn_bwd(conv=...) already left the statistics pass's sums (csship_convmod_bwd_after_stats)."""
     from .ops import conv_weights_struct
     _need(x, torch.float32, "x"), _need(dy, torch.float32, "dy")
     x, dy = x.contiguous(), dy.contiguous()
     B, T, D = x.shape
-    flat = torch.empty(38 * D + 8, dtype=torch.float32, device=x.device)
+    if stats_done and (flat is None or sync):
+        raise RuntimeError("css_amd: convmod_bwd(stats_done=True) needs the gradient buffer the statistics were left in (no SyncBatchNorm)")
+    if flat is None:
+        flat = torch.empty(38 * D + 8, dtype=torch.float32, device=x.device)
     cw = conv_weights_struct(weights)
     dx = torch.empty_like(x)
     nws = lib().csship_convmod_bwd_workspace(B, T, D)
@@ -379,6 +384,10 @@ def convmod_bwd(x, dy, weights, fwd_ws, kernel_size=33, bn_eval=False, drop=None
         off = lib().csship_convmod_bwd_sums_offset(B, T, D)
         allreduce_sum_(ws[off:off + 8 * D].view(torch.float32))
         check(lib().csship_convmod_bwd_finish(*args, float(B * T * dist.get_world_size()), drop, _ptr(ws), nws, _stream()))
+    elif stats_done:
+        nxt = torch.empty((B * T, D), dtype=torch.bfloat16, device=x.device) if want_next else None
+        check(lib().csship_convmod_bwd_after_stats(_ptr(x), _ptr(dy), C.byref(cw), B, T, D, kernel_size, _ptr(fwd_ws), _ptr(dx),
+                                                   _ptr(flat), int(bn_eval), drop, next_drop, _ptr(nxt), _ptr(ws), nws, _stream()))
     elif want_next:
         nxt = torch.empty((B * T, D), dtype=torch.bfloat16, device=x.device)
         check(lib().csship_convmod_bwd_next(_ptr(x), _ptr(dy), C.byref(cw), B, T, D, kernel_size, _ptr(fwd_ws), _ptr(dx),
@@ -495,8 +504,11 @@ def lstm_bidir_bwd(gates, c, dy, whhT_packed):
     return dg
 
 
-def ffn_bwd(x, dy, ln_g, ln_b, w1p, b1, w2tp, w1tp, d_ffn, alpha=0.5, drop_hidden=None, drop_out=None, ln2=None):
+def ffn_bwd(x, dy, ln_g, ln_b, w1p, b1, w2tp, w1tp, d_ffn, alpha=0.5, drop_hidden=None, drop_out=None, ln2=None, conv=None):
     """Activation side of the FeedForward backward in one kernel (csship_ffn_bwd).
+    conv = (fwd_ws, pw2_w, drop_cfg, flat, B, T) (not with ln2): x is the output of a conv module and dx its output gradient -
+    the statistics pass of that module's backward rides in the epilogue (csship_ffn_bwd_conv) and leaves its sums in ``flat``,
+    the gradient buffer convmod_bwd(..., flat=flat, stats_done=True) then finishes.
     Returns (dx f32 [M,256], dgamma, dbeta, a bf16 [M,256], h bf16 [M,d_ffn], dh bf16 [M,d_ffn], dyd): with dropout
     cfgs h is the DROPPED hidden activation and dyd (bf16 [M,256]) = alpha * dy o output mask / (1 - p), else None.
     ln2 = (x2, gamma2) with x = LayerNorm2(x2): dx is carried on through that LayerNorm (csship_ffn_bwd_ln) and the
@@ -524,6 +536,16 @@ def ffn_bwd(x, dy, ln_g, ln_b, w1p, b1, w2tp, w1tp, d_ffn, alpha=0.5, drop_hidde
                                       _ptr(a), _ptr(h), _ptr(dh), _ptr(dx), _ptr(gb), M, D, d_ffn, float(alpha), drop_hidden,
                                       drop_out, _ptr(dyd), _ptr(x2), _ptr(g2), _ptr(gb2), _ptr(ws), nws, _stream()))
         return dx, gb[0], gb[1], a, h, dh, dyd, gb2[0], gb2[1]
+    if conv is not None:
+        fws, pw2_w, cdrop, flat, B, T = conv
+        if flat.dtype != torch.float32 or not flat.is_contiguous() or flat.numel() < 38 * D + 8 or B * T != M:
+            raise RuntimeError("css_amd: ffn_bwd(conv=...) expects the conv module's f32 gradient buffer [38 D + 8] and M = B * T")
+        nws = lib().csship_ffn_bwd_conv_workspace(M)
+        ws = _workspace(nws, dev, own=True)
+        check(lib().csship_ffn_bwd_conv(_ptr(x), _ptr(dy), _ptr(ln_g), _ptr(ln_b), _ptr(w1p), _ptr(b1), _ptr(w2tp), _ptr(w1tp),
+                                        _ptr(a), _ptr(h), _ptr(dh), _ptr(dx), _ptr(gb), M, D, d_ffn, float(alpha), drop_hidden,
+                                        drop_out, _ptr(dyd), _ptr(fws), B, T, _ptr(pw2_w), cdrop, _ptr(flat), _ptr(ws), nws, _stream()))
+        return dx, gb[0], gb[1], a, h, dh, dyd
     nws = lib().csship_ffn_bwd_workspace(M)
     ws = _workspace(nws, dev, own=True)
     check(lib().csship_ffn_bwd_drop(_ptr(x), _ptr(dy), _ptr(ln_g), _ptr(ln_b), _ptr(w1p), _ptr(b1), _ptr(w2tp), _ptr(w1tp),

@@ -885,6 +885,29 @@ typedef struct csship_pack_job {
 int csship_pack_weights_multi(const csship_pack_job* jobs_device, int32_t n_jobs, int64_t max_chunks,
                               csship_stream_t stream);
 
+/* csship_ffn_bwd_conv (round 6): csship_ffn_bwd_drop for the FeedForward BEHIND a conv module (a block's feed_forward_out,
+ * conformer.py:357-358) whose dx is that module's output gradient: the statistics pass of csship_convmod_bwd (per channel
+ * S1 = sum dzh, S2 = sum dzh * zn, and d pw2_w, d pw2_b; torch.autograd through BatchNorm1d / ReLU / the scalar affine in the
+ * reference, conformer.py:293-301) rides in the kernel's epilogue on the dx rows it has just formed, and its reduction
+ * leaves them where the module's own pass leaves them: the first 2 D + 2 floats of `conv_grads` (CSSHIP_CONV_GRADS layout:
+ * d bn_b | d bn_g | d pw2_w | d pw2_b as S1 | S2 | .. until csship_convmod_bwd_after_stats finishes them).
+ * conv_fwd_workspace: the module's training workspace (csship_convmod bn_mode 1 / 2, csship_outproj_conv_train);
+ * conv_drop: its output dropout site (NULL: none).  M = B * T, M % 64 == 0, d_model 256, d_ffn <= csship_ffn_static_max_ffn().
+ * csship_convmod_bwd_after_stats: csship_convmod_bwd_next (dx_next_bf16 may be NULL) without its statistics pass, reading the
+ * sums from `grads`. */
+size_t csship_ffn_bwd_conv_workspace(int32_t M);
+int csship_ffn_bwd_conv(const float* x, const float* dy, const float* ln_g, const float* ln_b, const uint16_t* w1_packed,
+                        const float* b1, const uint16_t* w2t_packed, const uint16_t* w1t_packed, uint16_t* a_bf16,
+                        uint16_t* h_bf16, uint16_t* dh_bf16, float* dx, float* dgamma_dbeta, int32_t M, int32_t d_model,
+                        int32_t d_ffn, float alpha, const csship_dropout_cfg* drop_hidden, const csship_dropout_cfg* drop_out,
+                        uint16_t* dyd_bf16, const void* conv_fwd_workspace, int32_t B, int32_t T, const float* conv_pw2_w,
+                        const csship_dropout_cfg* conv_drop, float* conv_grads, void* workspace, size_t workspace_bytes,
+                        csship_stream_t stream);
+int csship_convmod_bwd_after_stats(const float* x, const float* dy, const csship_conv_weights* w, int32_t B, int32_t T,
+                                   int32_t D, int32_t kernel_size, const void* fwd_workspace, float* dx, float* grads,
+                                   int32_t bn_eval, const csship_dropout_cfg* drop, const csship_dropout_cfg* next_drop,
+                                   uint16_t* dx_next_bf16, void* workspace, size_t workspace_bytes, csship_stream_t stream);
+
 /* ---- csship_qkv_in_bwd (css_amd/csrc/panel.hip): the input side of the q | k | v projection's backward in one kernel
  * per 64-row panel.  Forward (conformer.py:213-224,356): qkv = LayerNorm(x) Wqkv^T + b, out = x + attention(qkv) ...;
  * given dqkv (bf16 [M, 768]) and dy = d(out) (f32 [M, 256]):

@@ -295,6 +295,46 @@ def test_qkv_ffn_bwd_equals_the_two_launches(ob, with_ln2):
         ob.qkv_ffn_bwd(dqkv, wt, x_attn, dy, ag, ab, x, G["g"], G["b"], w1p, G["b1"], w2tp, w1tp, FF, 0.5)
 
 
+def test_ffn_bwd_carries_the_conv_statistics(ob):
+    """csship_ffn_bwd_conv + csship_convmod_bwd_after_stats: the statistics pass of the conv module's backward in the epilogue
+    of the FeedForward backward in front of it (on the dx rows it has just formed) vs csship_ffn_bwd_drop then
+    csship_convmod_bwd_next: the FeedForward's bf16 operands bit for bit (its f32 rows to the last place), the module's results
+    to the rounding of another summation order of the channel sums (64-row partials instead of 16-row ones)"""
+    from css_amd import ops
+    from css_amd.dropout import DropState
+    B, T, D, FF = 4, 176, 256, 1024
+    M = B * T
+    st = DropState(torch.tensor([31], dtype=torch.int32, device=DEV), 0.1, 0)
+    c_out, c_next, cfg_h, cfg_o = st.cfg("2.conv.out"), st.cfg("2.attn.out"), st.cfg("2.ffn_out.hidden"), st.cfg("2.ffn_out.out")
+    W = {"ln_g": 1 + 0.1 * rnd((D,), 401), "ln_b": 0.1 * rnd((D,), 402), "pw1_w": torch.tensor([0.9, -0.7]),
+         "pw1_b": torch.tensor([0.1, 0.2]), "dw_w": rnd((33, D), 403, 0.2), "dw_b": 0.1 * rnd((D,), 404),
+         "bn_g": 1 + 0.1 * rnd((D,), 405), "bn_b": 0.1 * rnd((D,), 406), "bn_mean": torch.zeros(D), "bn_var": torch.ones(D),
+         "pw2_w": torch.tensor([1.3]), "pw2_b": torch.tensor([-0.2])}
+    W = {k: v.to(DEV) for k, v in W.items()}
+    xc = rnd((B, T, D), 407).to(DEV)
+    y, fws = ops.convmod(xc, W, 33, batch_stats=True, return_workspace=True, drop=c_out)   # the FeedForward's input
+    x = y.view(M, D)
+    dy = rnd((M, D), 408, 0.1).to(DEV)
+    G = {"g": (1 + 0.1 * rnd((D,), 409)).to(DEV), "b": (0.1 * rnd((D,), 410)).to(DEV), "w1": rnd((FF, D), 411, 0.06).to(DEV),
+         "b1": rnd((FF,), 412, 0.1).to(DEV), "w2": rnd((D, FF), 413, 0.03).to(DEV)}
+    w1p = ops.pack_frag(G["w1"])
+    w2tp, w1tp = ops.pack_frag(G["w2"].t().contiguous()), ops.pack_frag(G["w1"].t().contiguous())
+    ref = ob.ffn_bwd(x, dy, G["g"], G["b"], w1p, G["b1"], w2tp, w1tp, FF, 0.5, cfg_h, cfg_o)
+    dx_r, g_r, nx_r = ob.convmod_bwd(xc, ref[0].view(B, T, D), W, fws, 33, drop=c_out, want_next=True, next_drop=c_next)
+    flat = torch.empty(38 * D + 8, dtype=torch.float32, device=DEV)
+    got = ob.ffn_bwd(x, dy, G["g"], G["b"], w1p, G["b1"], w2tp, w1tp, FF, 0.5, cfg_h, cfg_o, conv=(fws, W["pw2_w"], c_out, flat, B, T))
+    for i, (a, b) in enumerate(zip(got, ref)):   # (two builds of the same formulas: the f32 rows may differ in the last place)
+        assert torch.equal(a, b) if a.dtype == torch.bfloat16 else relerr(a, b.double().cpu()) < 1e-6, i
+    dx_g, g_g, nx_g = ob.convmod_bwd(xc, got[0].view(B, T, D), W, fws, 33, drop=c_out, want_next=True, next_drop=c_next,
+                                     flat=flat, stats_done=True)
+    assert relerr(dx_g, dx_r.double().cpu()) < 1e-5
+    for k in g_r:   # (d dw_b is zero in exact arithmetic behind a batch-statistics BatchNorm: an absolute bound)
+        assert float((g_g[k] - g_r[k]).abs().max()) <= 2e-5 * max(float(g_r[k].abs().max()), 1.0), k
+    assert float((nx_g.float() - nx_r.float()).abs().max()) <= 2.0 ** -7 * float(nx_r.float().abs().max())
+    with pytest.raises(RuntimeError):   # the sums live in the caller's gradient buffer
+        ob.convmod_bwd(xc, got[0].view(B, T, D), W, fws, 33, drop=c_out, stats_done=True)
+
+
 def test_grouped_weight_gradients_equal_the_single_products(ob):
     """csship_wgrad_hold / csship_wgrad_flush: the weight-gradient products of a block queued and run as ONE launch (the
     reduction cut 2-3 times instead of 16-64) vs float64 on the same bf16 operands and vs the products one by one; a
