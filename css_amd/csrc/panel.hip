@@ -1597,11 +1597,15 @@ DEV void mma_pass_epi(f32x4 (&acc)[NT][4], const unsigned char* panel, int n, in
   }
 }
 
+// rrow (training form): this thread's pieces of its input row in MEMORY (the stage's input rows are kept for the backward
+// anyway: the thread wrote them itself a stage ago) - the 32 registers of v are dead during the passes, which is what lets the
+// pipelined form (h AND o live through a W2 pass) fit the 256 a wave has; the rows come back behind the last pass's final
+// weight request, under park + barrier.
 template <int NW, bool FINAL_LN, bool TRAIN>
 DEV void ffn_stage_p(float4 (&v)[8], unsigned char* Xs, unsigned char* Hraw, const float* lng, const float* fing,
                      const float* b1s, const float* b2s, const FfnW& f, int FF, float alpha, int tid, int rot,
                      bf16x8 (&wq)[PD][16 / NW], const bf16x8* next_w, unsigned long long* g_stamps_dev, int st0,
-                     const StageTrain& tr) {
+                     const StageTrain& tr, const float* rrow = nullptr) {
   constexpr int NT = 16 / NW;
   const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15, r = tid >> 3, part = tid & 7;
   const int nchunk = FF / DM, ks2 = FF / 32;   // nchunk >= 2 (checked on the host)
@@ -1648,6 +1652,10 @@ DEV void ffn_stage_p(float4 (&v)[8], unsigned char* Xs, unsigned char* Hraw, con
     mma_pass_s<NT, true>(o, (ci & 1) ? Hs1 : Hs0, n, g, w2_of(c), ks2, next_w, KS, wq);
   }
 #undef FS_HINIT
+  if constexpr (TRAIN) {   // (unconditional: a run-time choice would keep v alive through the passes)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(rrow + i * 32);
+  }
   P_T(st0 + 1)
   __syncthreads();  // every wave is done reading the hidden panels
   float* ys = reinterpret_cast<float*>(Hraw);
@@ -1841,7 +1849,8 @@ __global__ __launch_bounds__(NW * 64) void chain_s_kernel(ChainArgs a) {
     const StageTrain ta{dAh, dAo, m0, a.M, a.pre_ln_out};
     if constexpr (PIPE)
       ffn_stage_p<NW, true, TRAIN>(v, Xs, Hraw, a.fa.ln_g != nullptr ? lnA : nullptr, finA, b1A, b2A, a.fa, FF, a.alpha, tid, rotA, wq,
-                                   HAS_B ? wB0 : wA0, g_stamps_dev, 1, ta);
+                                   HAS_B ? wB0 : wA0, g_stamps_dev, 1, ta,
+                                   TRAIN ? (BNP ? a.bn_out : a.x) + (size_t)row * DM + part * 4 : nullptr);
     else
       ffn_stage_s<NW, true, TRAIN>(v, Xs, Hraw, a.fa.ln_g != nullptr ? lnA : nullptr, finA, b1A, b2A, a.fa, FF, a.alpha, tid, rotA, wq,
                                    HAS_B ? wB0 : wA0, g_stamps_dev, 1, ta);
@@ -1855,7 +1864,8 @@ __global__ __launch_bounds__(NW * 64) void chain_s_kernel(ChainArgs a) {
     const StageTrain tb{dBh, dBo, m0, a.M, nullptr};
     if constexpr (PIPE)
       ffn_stage_p<NW, false, TRAIN>(v, Xs, Hraw, a.fb.ln_g != nullptr ? lnB : nullptr, nullptr, b1B, b2B, a.fb, FF, a.alpha, tid, rotB, wq,
-                                    HAS_C ? wC0 : wB0, g_stamps_dev, 5, tb);
+                                    HAS_C ? wC0 : wB0, g_stamps_dev, 5, tb,
+                                    TRAIN ? (HAS_A ? a.ln_out : a.x) + (size_t)row * DM + part * 4 : nullptr);
     else
       ffn_stage_s<NW, false, TRAIN>(v, Xs, Hraw, a.fb.ln_g != nullptr ? lnB : nullptr, nullptr, b1B, b2B, a.fb, FF, a.alpha, tid, rotB, wq,
                                     HAS_C ? wC0 : wB0, g_stamps_dev, 5, tb);
@@ -3194,7 +3204,8 @@ static int encoder_chain_impl(const float* x, float* x_out, const float* conv_g,
       static const bool use_pipe_t = [] { const char* e = getenv("CSSHIP_CHAIN_PIPE_TRAIN"); return e != nullptr && atoi(e) != 0; }();
       const bool pipe_t = use_pipe_t && d_ffn >= 2 * DM;
       if (bnp && !A) return CSSHIP_EUNSUPPORTED;
-      if (bnp) hipLaunchKernelGGL((chain_s_kernel<NWAVES, true, true, true, true, false, false, true>), grid, block, 0, s, a);
+      if (bnp && pipe_t) hipLaunchKernelGGL((chain_s_kernel<NWAVES, true, true, true, true, false, true, true>), grid, block, 0, s, a);
+      else if (bnp) hipLaunchKernelGGL((chain_s_kernel<NWAVES, true, true, true, true, false, false, true>), grid, block, 0, s, a);
       else if (A && pipe_t) hipLaunchKernelGGL((chain_s_kernel<NWAVES, true, true, true, true, false, true>), grid, block, 0, s, a);
       else if (pipe_t) hipLaunchKernelGGL((chain_s_kernel<NWAVES, false, true, true, true, false, true>), grid, block, 0, s, a);
       else if (A) hipLaunchKernelGGL((chain_s_kernel<NWAVES, true, true, true, true, false>), grid, block, 0, s, a);
