@@ -994,6 +994,8 @@ static int launch_slab_reduce2(const float* slabs, int S, int64_t n, int N, int6
   // slabs are summed right behind the product, out of the 256 MB MALL, and its scratch is rewritten by the next
   // product without reaching HBM; queued for the end of the block they came back from HBM: 112 us per block for 125 MB
   // against 14 launches x 5.7 us (measured).  The size test keeps that true whatever a caller marks.
+  // (round 6 re-measured it with ONE set: the conv backward's 14.5 MB of tap-gradient partials queued for the block's batch launch
+  // instead of their own 8 us launch - training step 7.65 -> 7.98 ms)
   static const int64_t defer_max = (int64_t)8 << 20;
   if (t_hold || (deferrable && t_defer.on && (int64_t)S * (n + n2) * 4 <= defer_max)) {  // the same kernel shape as the launch below would pick, later
     const bool flat = t_flat && wide && S <= 4 && (ldc & 3) == 0 && aligned16(out) && (!bias || aligned16(bias)) &&

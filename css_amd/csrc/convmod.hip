@@ -654,9 +654,9 @@ struct ConvBwdArgs {
 
 template <int LR>
 DEV float sum_row_lanes(float v) {  // over aligned groups of LR = 16 / 32 lanes, result in all of them
-  static_assert(LR == 16 || LR == 32, "pass C rows are 16 or 32 lanes");
+  static_assert(LR == 8 || LR == 16 || LR == 32, "pass C rows are 8, 16 or 32 lanes");
   v = sum8(v);
-  v += dpp_mov<DPP_MIRROR>(v);
+  if constexpr (LR >= 16) v += dpp_mov<DPP_MIRROR>(v);
   if constexpr (LR == 32) {
     auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     const unsigned a0 = r[0], a1 = r[1];
@@ -665,29 +665,32 @@ DEV float sum_row_lanes(float v) {  // over aligned groups of LR = 16 / 32 lanes
   return v;
 }
 
+// TT = 32 (the default): 67.6 KB of LDS and <= 128 registers, two workgroups per CU (any T, any B).  TT = 50 (d_model 256 only,
+// opt-in): 102 KB and up to 256 registers, ONE workgroup per CU - meant for launches whose 32-frame tiles outnumber the CUs while
+// their 50-frame tiles do not (32 x 400 frames: 416 tiles leave 160 CUs with two workgroups and 96 with one - 37 us; 256 tiles are
+// one equal round) and measured slower (see run_bwd).  Everything below is written in TT; the row phases round it up to whole
+// lane groups.
 template <int D, int TT, int KS>
-__global__ __launch_bounds__(2 * D) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_bwd_fused_kernel(ConvBwdArgs a) {
-  constexpr int ROWS = TT + KS - 1, NTHR = 2 * D, C4 = D / 4, LROWS = TT + KS + 1;
-  static_assert(LROWS >= ROWS && LROWS >= 2 * TT, "one buffer for dc / g rows, the dg tile + hand-over block, two column-sum tiles");
-  static_assert(NTHR % C4 == 0 && (ROWS * C4) % NTHR == 0, "whole float4 columns per thread in step 0");
-  __shared__ __attribute__((aligned(16))) float G[LROWS][D];
-  __shared__ float red[NTHR / 64][4];
+DEV void conv_bwd_fused_body(const ConvBwdArgs& a, float (*G)[D], float (*red)[4]) {
+  constexpr int ROWS = TT + KS - 1, NTHR = 2 * D, C4 = D / 4;
+  static_assert(NTHR % C4 == 0 && TT % 2 == 0, "whole float4 columns per thread in step 0; two half tiles");
   const int tid = threadIdx.x;
   const int b = blockIdx.y, t0 = blockIdx.x * TT;
   const int H3 = a.w.causal ? 0 : (KS - 1) / 2;        // rows of the dc buffer in front of the tile (input gradient: flipped taps)
   const int H2 = a.w.causal ? KS - 1 : (KS - 1) / 2;   // rows of the g buffer in front of the tile (the forward's halo)
 
-  // the x rows of step 2 (tile + halo, this thread's 32 channels of row tid / LPR) are requested inside step 0, behind its last
-  // dy / z loads: their latency passes behind the rest of step 0 and step 1
-  constexpr int LPR = D / 32;
+  // the x rows of step 2's first row batch (this thread's 32 channels of row tid / LPR) are requested inside step 0, behind its
+  // last dy / z loads: their latency passes behind the rest of step 0 and step 1
+  constexpr int LPR = D / 32, RPB = NTHR / LPR;   // 64 rows per batch
   static_assert(LPR == 8 || LPR == 16, "row reductions are written for 8 or 16 lanes per row");
-  static_assert(NTHR / LPR == ROWS, "one row batch covers the tile + halo");
   const int xrow = tid / LPR, xpart = tid % LPR;
-  const bool xinside = t0 - H2 + xrow >= 0 && t0 - H2 + xrow < a.T;
   stamp(a.stamps, 0);
   constexpr bool PRE = D == 256;   // (D = 512: 1024 threads hold 128 registers each, the rows would spill: requested in step 2)
   float4 xv[8];
-  const float* const xr = a.x + ((size_t)b * a.T + (xinside ? t0 - H2 + xrow : 0)) * D;
+  auto x_row_ptr = [&](int row) {
+    const int t = t0 - H2 + row;
+    return a.x + ((size_t)b * a.T + (t >= 0 && t < a.T ? t : 0)) * D;
+  };
 
   // ---- step 0: dc = sc * (dzh - S1 / n - zn * S2 / n), dzh = dy o mask / (1 - p) * w3 * [zh > 0]  (conv_bn_bwd_apply_kernel)
   {
@@ -709,20 +712,23 @@ __global__ __launch_bounds__(2 * D) __attribute__((amdgpu_waves_per_eu(4, 4))) v
       c1v[q] = -scv[q] * rsv[q] * s2v[q] * inv_n;
       c0v[q] = -scv[q] * s1v[q] * inv_n - c1v[q] * muv[q];
     }
-    constexpr int NIT = ROWS * C4 / NTHR, RSTEP = NTHR / C4, NB = 4;   // rows in flight per thread: two batches of 4 x (dy, z)
-    static_assert(NIT % NB == 0, "whole load batches");
+    // rows in flight per thread: TT = 32 - two batches of 4 x (dy, z) under the 128-register budget; TT = 50 - all 11 at once
+    constexpr int RSTEP = NTHR / C4, NIT = (ROWS + RSTEP - 1) / RSTEP, NB = TT == 32 ? 4 : NIT;
+    constexpr int NBAT = (NIT + NB - 1) / NB;
 #pragma unroll
-    for (int k0 = 0; k0 < NIT; k0 += NB) {
+    for (int bi = 0; bi < NBAT; ++bi) {
+      const int k0 = bi * NB;
       float4 dv[NB], zv[NB];
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
-        const int t = t0 - H3 + tid / C4 + (k0 + k) * RSTEP;
-        const size_t i = ((size_t)b * a.T + (t >= 0 && t < a.T ? t : 0)) * C4 + c4;
+        const int row = tid / C4 + (k0 + k) * RSTEP, t = t0 - H3 + row;
+        const size_t i = ((size_t)b * a.T + (row < ROWS && t >= 0 && t < a.T ? t : 0)) * C4 + c4;
         dv[k] = reinterpret_cast<const float4*>(a.dy)[i];
         zv[k] = reinterpret_cast<const float4*>(a.z)[i];
       }
       if constexpr (PRE) {
-        if (k0 + NB == NIT) {   // behind the last dy / z requests (loads return in order: in front of them they held step 0 back)
+        if (bi + 1 == NBAT) {   // behind the last dy / z requests (loads return in order: in front of them they held step 0 back)
+          const float* const xr = x_row_ptr(xrow);
 #pragma unroll
           for (int i = 0; i < 8; ++i) xv[i] = *reinterpret_cast<const float4*>(xr + (i * LPR + xpart) * 4);
         }
@@ -731,7 +737,7 @@ __global__ __launch_bounds__(2 * D) __attribute__((amdgpu_waves_per_eu(4, 4))) v
       for (int k = 0; k < NB; ++k) {
         const int row = tid / C4 + (k0 + k) * RSTEP, t = t0 - H3 + row;
         const bool inside = t >= 0 && t < a.T;
-        const size_t i = ((size_t)b * a.T + (inside ? t : 0)) * C4 + c4;
+        const size_t i = ((size_t)b * a.T + (row < ROWS && inside ? t : 0)) * C4 + c4;
         const float4 d4 = drop_apply4(dp, (unsigned)(i * 4), dv[k]);
         const float d[4] = {d4.x, d4.y, d4.z, d4.w}, zz[4] = {zv[k].x, zv[k].y, zv[k].z, zv[k].w};
         float o[4];
@@ -741,7 +747,7 @@ __global__ __launch_bounds__(2 * D) __attribute__((amdgpu_waves_per_eu(4, 4))) v
           const float lin = c1v[q] * zz[q] + c0v[q];
           o[q] = inside ? (zh > 0.f ? k3v[q] * d[q] + lin : lin) : 0.f;
         }
-        *reinterpret_cast<float4*>(&G[row][c]) = make_float4(o[0], o[1], o[2], o[3]);
+        if (ROWS % RSTEP == 0 || row < ROWS) *reinterpret_cast<float4*>(&G[row][c]) = make_float4(o[0], o[1], o[2], o[3]);
       }
     }
   }
@@ -757,7 +763,8 @@ __global__ __launch_bounds__(2 * D) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     float wk[KS];
 #pragma unroll
     for (int k = 0; k < KS; ++k) wk[k] = a.w.dw_w[(KS - 1 - k) * D + c];  // [k][D], flipped
-    constexpr int TQ = TH / 2;   // two passes of 8 outputs: 40 dc values + 33 taps live beside the prefetched x rows
+    constexpr int TQ = TH % 8 == 0 ? 8 : 5;   // passes of 8 (or 5) outputs: 40 dc values + 33 taps live beside the prefetched x rows
+    static_assert(TH % TQ == 0, "whole output passes");
 #pragma unroll
     for (int j0 = 0; j0 < TH; j0 += TQ) {
       float dcol[TQ + KS - 1];
@@ -777,39 +784,48 @@ __global__ __launch_bounds__(2 * D) __attribute__((amdgpu_waves_per_eu(4, 4))) v
   __syncthreads();  // every thread has its dc column in registers
   stamp(a.stamps, 2);
 
-  // ---- step 2: g = glu(LayerNorm(x)) rows (tile + halo) into the same rows: convmod_kernel's phase 1 on the prefetched rows
+  // ---- step 2: g = glu(LayerNorm(x)) rows (tile + halo) into the same rows: convmod_kernel's phase 1, 64 rows per batch (the
+  // first batch on the prefetched rows)
   {
     const float w0 = a.w.pw1_w[0], w1 = a.w.pw1_w[1], b0 = a.w.pw1_b[0], b1 = a.w.pw1_b[1];
-    if constexpr (!PRE) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) xv[i] = *reinterpret_cast<const float4*>(xr + (i * LPR + xpart) * 4);
-    }
-    float s = 0.f;
+    for (int r0 = 0; r0 < ROWS; r0 += RPB) {
+      const int row = r0 + xrow;
+      if (ROWS % RPB != 0 && row >= ROWS) break;
+      const int t = t0 - H2 + row;
+      const bool xinside = t >= 0 && t < a.T;
+      if (!PRE || r0 > 0) {
+        const float* const xr = x_row_ptr(row);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
-    s = sum8(s);
-    if constexpr (LPR == 16) s += dpp_mov<DPP_MIRROR>(s);
-    const float mean = s * (1.f / D);
-    float ss = 0.f;
+        for (int i = 0; i < 8; ++i) xv[i] = *reinterpret_cast<const float4*>(xr + (i * LPR + xpart) * 4);
+      }
+      float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      xv[i].x -= mean; xv[i].y -= mean; xv[i].z -= mean; xv[i].w -= mean;
-      ss += (xv[i].x * xv[i].x + xv[i].y * xv[i].y) + (xv[i].z * xv[i].z + xv[i].w * xv[i].w);
-    }
-    ss = sum8(ss);
-    if constexpr (LPR == 16) ss += dpp_mov<DPP_MIRROR>(ss);
-    const float rstd = rsqrtf(ss * (1.f / D) + 1e-5f);
+      for (int i = 0; i < 8; ++i) s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
+      s = sum8(s);
+      if constexpr (LPR == 16) s += dpp_mov<DPP_MIRROR>(s);
+      const float mean = s * (1.f / D);
+      float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int cc = (i * LPR + xpart) * 4;
-      const float4 gm = *reinterpret_cast<const float4*>(a.w.ln_g + cc);
-      const float4 bt = *reinterpret_cast<const float4*>(a.w.ln_b + cc);
-      float e[4] = {xv[i].x * rstd * gm.x + bt.x, xv[i].y * rstd * gm.y + bt.y, xv[i].z * rstd * gm.z + bt.z,
-                    xv[i].w * rstd * gm.w + bt.w};
+      for (int i = 0; i < 8; ++i) {
+        xv[i].x -= mean; xv[i].y -= mean; xv[i].z -= mean; xv[i].w -= mean;
+        ss += (xv[i].x * xv[i].x + xv[i].y * xv[i].y) + (xv[i].z * xv[i].z + xv[i].w * xv[i].w);
+      }
+      ss = sum8(ss);
+      if constexpr (LPR == 16) ss += dpp_mov<DPP_MIRROR>(ss);
+      const float rstd = rsqrtf(ss * (1.f / D) + 1e-5f);
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        e[q] = xinside ? (w0 * e[q] + b0) * __builtin_amdgcn_rcpf(1.f + __expf(-(w1 * e[q] + b1))) : 0.f;
-      *reinterpret_cast<float4*>(&G[xrow][cc]) = make_float4(e[0], e[1], e[2], e[3]);
+      for (int i = 0; i < 8; ++i) {
+        const int cc = (i * LPR + xpart) * 4;
+        const float4 gm = *reinterpret_cast<const float4*>(a.w.ln_g + cc);
+        const float4 bt = *reinterpret_cast<const float4*>(a.w.ln_b + cc);
+        float e[4] = {xv[i].x * rstd * gm.x + bt.x, xv[i].y * rstd * gm.y + bt.y, xv[i].z * rstd * gm.z + bt.z,
+                      xv[i].w * rstd * gm.w + bt.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          e[q] = xinside ? (w0 * e[q] + b0) * __builtin_amdgcn_rcpf(1.f + __expf(-(w1 * e[q] + b1))) : 0.f;
+        *reinterpret_cast<float4*>(&G[row][cc]) = make_float4(e[0], e[1], e[2], e[3]);
+      }
     }
   }
   __syncthreads();
@@ -835,10 +851,9 @@ __global__ __launch_bounds__(2 * D) __attribute__((amdgpu_waves_per_eu(4, 4))) v
   stamp(a.stamps, 4);
 
   // ---- step 4: the second half tile hands its 34 sums to the first through rows [0, KS + 1); pass C's d ln_g terms go to rows
-  // [KS + 1, KS + 1 + TT), its d ln_b terms to rows [0, TT)
+  // [CA0, CA0 + TT), its d ln_b terms to rows [0, TT)
   float* const X = &G[0][0];
-  constexpr int CA0 = KS + 1;
-  static_assert(CA0 + TT <= LROWS, "the d ln_g tile sits behind the hand-over block");
+  constexpr int CA0 = KS + 1 > TT ? KS + 1 : TT;   // behind the hand-over block AND behind the d ln_b rows
   if (half == 1) {
 #pragma unroll
     for (int k = 0; k < KS; ++k) X[k * D + c] = sk[k];
@@ -855,12 +870,14 @@ __global__ __launch_bounds__(2 * D) __attribute__((amdgpu_waves_per_eu(4, 4))) v
   __syncthreads();  // the hand-over block has been read: rows [0, TT) take pass C's d ln_b terms
   stamp(a.stamps, 5);
 
-  // ---- pass C (glu_ln_bwd_kernel): LR lanes per row, 16 channels per lane as four float4 pieces
-  constexpr int LR = NTHR / TT, NP = D / (4 * LR);
-  static_assert(NP == 4, "16 channels per lane");
+  // ---- pass C (glu_ln_bwd_kernel): LR lanes per row (the largest power of two with NTHR / LR >= TT rows), D / LR channels per
+  // lane as float4 pieces
+  constexpr int LR = NTHR / TT >= 32 ? 32 : NTHR / TT >= 16 ? 16 : 8, NP = D / (4 * LR);
+  static_assert(NTHR / LR >= TT && NP * 4 * LR == D, "every tile row has its lane group");
   const int row = tid / LR, part = tid % LR;
   const int t = t0 + row;
-  const bool valid = t < a.T;
+  const bool rowok = NTHR / LR == TT || row < TT;
+  const bool valid = rowok && t < a.T;
   const size_t rbase = ((size_t)b * a.T + (valid ? t : a.T - 1)) * D;
   float xh[NP][4], dd[NP][4];
   float4 dyv[NP];
@@ -870,12 +887,12 @@ __global__ __launch_bounds__(2 * D) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int cc = (i * LR + part) * 4;
-      const float4 xv = *reinterpret_cast<const float4*>(a.x + rbase + cc);
+      const float4 xq = *reinterpret_cast<const float4*>(a.x + rbase + cc);
       dyv[i] = *reinterpret_cast<const float4*>(a.dy + rbase + cc);
-      const float4 gv = *reinterpret_cast<const float4*>(a.dg + rbase + cc);   // (this workgroup's step 1, two barriers ago)
-      xh[i][0] = xv.x; xh[i][1] = xv.y; xh[i][2] = xv.z; xh[i][3] = xv.w;
+      const float4 gv = *reinterpret_cast<const float4*>(a.dg + rbase + cc);   // (this workgroup's step 1, barriers ago)
+      xh[i][0] = xq.x; xh[i][1] = xq.y; xh[i][2] = xq.z; xh[i][3] = xq.w;
       dd[i][0] = gv.x; dd[i][1] = gv.y; dd[i][2] = gv.z; dd[i][3] = gv.w;
-      s += (xv.x + xv.y) + (xv.z + xv.w);
+      s += (xq.x + xq.y) + (xq.z + xq.w);
     }
     const float mean = sum_row_lanes<LR>(s) * (1.f / D);
     float ss = 0.f;
@@ -897,6 +914,7 @@ __global__ __launch_bounds__(2 * D) __attribute__((amdgpu_waves_per_eu(4, 4))) v
       const float4 g4 = *reinterpret_cast<const float4*>(a.w.ln_g + cc);
       const float4 b4 = *reinterpret_cast<const float4*>(a.w.ln_b + cc);
       const float gm[4] = {g4.x, g4.y, g4.z, g4.w}, bt[4] = {b4.x, b4.y, b4.z, b4.w};
+      float caq[4], cbq[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float h = xh[i][q] * rstd;
@@ -908,13 +926,17 @@ __global__ __launch_bounds__(2 * D) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         const float dv = dgq * u * sg * (1.f - sg);
         sw0 += du * av; sb0 += du; sw1 += dv * av; sb1 += dv;
         const float da = du * w0 + dv * w1;
-        G[CA0 + row][cc + q] = da * h;
-        G[row][cc + q] = da;
+        caq[q] = da * h;
+        cbq[q] = da;
         const float gg = da * gm[q];
         xh[i][q] = h;
         dd[i][q] = gg;
         s1 += gg;
         s2 += gg * h;
+      }
+      if (rowok) {
+        *reinterpret_cast<float4*>(&G[CA0 + row][cc]) = make_float4(caq[0], caq[1], caq[2], caq[3]);
+        *reinterpret_cast<float4*>(&G[row][cc]) = make_float4(cbq[0], cbq[1], cbq[2], cbq[3]);
       }
     }
   }
@@ -956,6 +978,23 @@ __global__ __launch_bounds__(2 * D) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     }
   }
   stamp(a.stamps, 7);
+}
+
+template <int TT, int KS>
+constexpr int conv_bwd_lds_rows() { return (KS + 1 > TT ? KS + 1 : TT) + TT > TT + KS - 1 ? (KS + 1 > TT ? KS + 1 : TT) + TT : TT + KS - 1; }
+
+template <int D, int TT, int KS>
+__global__ __launch_bounds__(2 * D) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_bwd_fused_kernel(ConvBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float G[conv_bwd_lds_rows<TT, KS>()][D];
+  __shared__ float red[2 * D / 64][4];
+  conv_bwd_fused_body<D, TT, KS>(a, G, red);
+}
+
+template <int D, int TT, int KS>   // one workgroup per CU: the whole register file
+__global__ __launch_bounds__(2 * D) void conv_bwd_fused1_kernel(ConvBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float G[conv_bwd_lds_rows<TT, KS>()][D];
+  __shared__ float red[2 * D / 64][4];
+  conv_bwd_fused_body<D, TT, KS>(a, G, red);
 }
 
 // rows per workgroup of the row-wise backward passes: short row loops, many waves in flight (these passes are chains of
@@ -1015,10 +1054,23 @@ int run_bwd(const float* x, const float* dy, const csship_conv_weights& w, int B
   if (!unfused) {
     // passes A', B1, B2, C as one launch (conv_bwd_fused_kernel).  Both reductions behind it yield parameter gradients only:
     // they may wait for the block's flush
-    const int ntile = (T + TT - 1) / TT * B;
+    // 50-frame tiles, one workgroup per CU: for launches whose 32-frame tiles are more than one round of the chip (416 at 32 x 400)
+    // while the 50-frame ones are exactly one - built, correct, and slower:
+    constexpr int TT1 = 50;
+    static const int tt_env = [] { const char* e = getenv("CSSHIP_CONV_BWD_TT"); return e ? atoi(e) : 0; }();   // A/B: 32 / 50
+    const int nt32 = (T + TT - 1) / TT, nt50 = (T + TT1 - 1) / TT1;
+    // (measured, 32 x 400 frames: 36.4 us per workgroup - 8 waves alone on a CU leave every phase latency-bound, the row pass 9 us
+    // against 3.8 - and 7.66 against 7.61 ms per training step: opt-in, CSSHIP_CONV_BWD_TT=50)
+    const bool wide_tiles = D == 256 && TT == 32 && tt_env == TT1;
+    const int ntx = wide_tiles ? nt50 : nt32, ntile = ntx * B;
     float* part_b = part;   // (pass A's partials there were consumed by its reduction, which is never deferred)
     ConvBwdArgs fa{x, dy, z, stats, phase == 2 ? sums : gA, w, inv_n, dx, dg, part_b, part_c, B, T, dcfg, nx, g_csship_stamps};
-    hipLaunchKernelGGL((conv_bwd_fused_kernel<D, TT, 33>), dim3((T + TT - 1) / TT, B), dim3(2 * D), 0, s, fa);
+    if constexpr (D == 256) {
+      if (wide_tiles) hipLaunchKernelGGL((conv_bwd_fused1_kernel<D, TT1, 33>), dim3(ntx, B), dim3(2 * D), 0, s, fa);
+      else hipLaunchKernelGGL((conv_bwd_fused_kernel<D, TT, 33>), dim3(ntx, B), dim3(2 * D), 0, s, fa);
+    } else {
+      hipLaunchKernelGGL((conv_bwd_fused_kernel<D, TT, 33>), dim3(ntx, B), dim3(2 * D), 0, s, fa);
+    }
     CSSHIP_CHECK_LAUNCH();
     rc = launch_slab_reduce(part_b, ntile, (int64_t)34 * D, 34 * D, (int64_t)34 * D, 1.f, nullptr, nullptr, 0, gB, s, true);
     if (rc) return rc;
