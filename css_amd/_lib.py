@@ -40,6 +40,21 @@ class ChainTrain(C.Structure):  # csship_chain_train
                 ("drop_bn", C.POINTER(DropoutCfg)), ("bn_out", _p)]
 
 
+class QkvBwdArgs(C.Structure):  # csship_qkv_bwd_args
+    _fields_ = [(n, _p) for n in ("dqkv", "wqkvT_packed", "x", "dy", "ln_g", "ln_b", "y_bf16", "dgamma_dbeta")]
+
+
+class FfnBwdArgs(C.Structure):  # csship_ffn_bwd_args
+    _fields_ = [(n, _p) for n in ("x", "ln_g", "ln_b", "w1_packed", "b1", "w2t_packed", "w1t_packed", "a_bf16", "h_bf16", "dh_bf16",
+                                  "dx", "dgamma_dbeta")] + \
+               [("drop_hidden", C.POINTER(DropoutCfg)), ("drop_out", C.POINTER(DropoutCfg)), ("dyd_bf16", _p),
+                ("ln2_x", _p), ("ln2_g", _p), ("dgamma_dbeta2", _p)]
+
+
+class ConvStatsArgs(C.Structure):  # csship_conv_stats_args
+    _fields_ = [("fwd_workspace", _p), ("B", _i32), ("T", _i32), ("pw2_w", _p), ("drop", C.POINTER(DropoutCfg)), ("grads", _p)]
+
+
 class MhaWeights(C.Structure):
     _fields_ = [(n, _p) for n in ("ln_g", "ln_b", "wqkv", "bqkv", "wo", "bo")]
 
@@ -199,6 +214,9 @@ SIGNATURES = {
     "csship_convmod_bwd_after_stats": (_i32, [_p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _dc, _dc, _p, _p,
                                               _sz, _p]),
     "csship_qkv_in_bwd_workspace": (_sz, [_i32]),
+    "csship_qkv_ffn2_bwd_workspace": (_sz, [_i32]),
+    "csship_qkv_ffn2_bwd": (_i32, [C.POINTER(QkvBwdArgs), C.POINTER(FfnBwdArgs), C.POINTER(FfnBwdArgs), C.POINTER(ConvStatsArgs),
+                                   _i32, _i32, _i32, _f32, _p, _sz, _p]),
     "csship_qkv_ffn_bwd_workspace": (_sz, [_i32]),
     "csship_qkv_ffn_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p,                                   # dqkv .. attn dgamma | dbeta
                                   _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,                   # x .. dgamma | dbeta

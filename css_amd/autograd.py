@@ -501,6 +501,7 @@ class ConformerTrain(torch.autograd.Function):
         layers = list(enc.encoders)
         side = _side_stream(masks.device) if _WGRAD_SIDE and not S["wide"] else None
         ln_done = False   # this block's final LayerNorm was back-propagated by the block above (ffn_bwd's second LayerNorm)
+        pending = None    # (ffn_bwd tuple of this block's feed_forward_out, its conv module's gradient buffer) from the block above
         for li, lay, L in zip(range(nlay - 1, -1, -1), reversed(layers), reversed(S["layers"])):
             if not ln_done:
                 dx, dg, dbeta = ob.layernorm_bwd(L["x4"], dx, lay.layer_norm.weight.detach(), lay.layer_norm.bias.detach())
@@ -528,7 +529,18 @@ class ConformerTrain(torch.autograd.Function):
             c = lay.conv
             # the statistics pass of the conv module's backward rides in the epilogue of the FeedForward backward in front of it
             cflat = None
-            if (not S["wide"] and not S["sync_bn"] and not _NO_CONV_NEXT and not _NO_FFN_CONV and D == 256 and M % 64 == 0
+            if pending is not None:
+                # this block's feed_forward_out already ran as the third stage of the kernel the block above launched: its
+                # weight gradients are queued now, with this block's group
+                res_below, cflat = pending
+                pending = None
+                m = lay.feed_forward_out
+                outs = tuple(_direct_grad(q) for q in (m.net[0].weight, m.net[0].bias, m.net[3].weight, m.net[3].bias))
+                dx, g = bw._ffn_wgrads(res_below, None, 0.5, outs)
+                for p, gv in zip((m.layer_norm.weight, m.layer_norm.bias, m.net[0].weight, m.net[0].bias,
+                                  m.net[3].weight, m.net[3].bias), g):
+                    put(p, gv)
+            elif (not S["wide"] and not S["sync_bn"] and not _NO_CONV_NEXT and not _NO_FFN_CONV and D == 256 and M % 64 == 0
                     and enc.d_ffn <= ob.ffn_static_max_ffn() and enc.d_ffn % 256 == 0 and enc.kernel_size == 33):
                 cflat = torch.empty(38 * D + 8, dtype=torch.float32, device=dx.device)
                 dx = ffn_b(lay.feed_forward_out, "ffn_out", dx, conv=(fws, W["pw2_w"], ds.cfg(f"{li}.conv.out"), cflat, B, T))
@@ -569,13 +581,27 @@ class ConformerTrain(torch.autograd.Function):
                     ffn_next["outs"] = tuple(_direct_grad(q) for q in (fm.net[0].weight, fm.net[0].bias, fm.net[3].weight, fm.net[3].bias))
                 else:
                     ffn_next = None
+            # ... and the feed_forward_out of the block BELOW (its output is that LayerNorm's input) as a third stage, with the
+            # statistics pass of that block's conv module in its epilogue
+            ffn_below = None
+            if (ffn_next is not None and ln_done and bw._QKV_FFN2 and not S["sync_bn"] and not _NO_CONV_NEXT and not _NO_FFN_CONV
+                    and enc.kernel_size == 33 and ds.cfg(f"{li - 1}.ffn_out.out") is not None):
+                bm, Lb = layers[li - 1].feed_forward_out, S["layers"][li - 1]
+                xb, w1pb, w2tpb, w1tpb = Lb["ffn_out"]
+                cflat_b = torch.empty(38 * D + 8, dtype=torch.float32, device=dx.device)
+                ffn_below = (dict(x=xb, ln_g=bm.layer_norm.weight.detach(), ln_b=bm.layer_norm.bias.detach(), b1=bm.net[0].bias.detach(),
+                                  w1p=w1pb, w2tp=w2tpb, w1tp=w1tpb, drop_hidden=ds.cfg(f"{li - 1}.ffn_out.hidden"),
+                                  drop_out=ds.cfg(f"{li - 1}.ffn_out.out")),
+                             (Lb["conv"][2], Lb["conv"][1]["pw2_w"], ds.cfg(f"{li - 1}.conv.out"), cflat_b, B, T))
             res = bw.mha_bwd(x1, dx, qkv.view(B, T, 3 * D), ao, a.layer_norm.weight.detach(),
                              a.layer_norm.bias.detach(), wqkv_bf, wo_bf, S["pe_bf"], H, scale, window=window,
                              probs=(S["pe_pack"], lse), skew_buf=skew_buf, drop_p=ds.cfg(f"{li}.attn.p"),
                              drop_out=ds.cfg(f"{li}.attn.out"), dwin_acc=dwin, dyb_bf16=dyb,
                              dwo_out=_direct_grad(a.linear_out.weight), dbo_out=_direct_grad(a.linear_out.bias),
-                             wo_tp=L.get("wo_tp"), wqkv_tp=L.get("wqkv_tp"), ffn_next=ffn_next)
+                             wo_tp=L.get("wo_tp"), wqkv_tp=L.get("wqkv_tp"), ffn_next=ffn_next, ffn_below=ffn_below)
             dx, g = res[:2]
+            if ffn_below is not None:
+                pending = (res[3], ffn_below[1][3])
             dg, dbeta, dwqkv, dbqkv, dwo, dbo, dwin = g   # dwin: the window gradient summed over the blocks so far
             put(a.layer_norm.weight, dg), put(a.layer_norm.bias, dbeta)
             for i, lin in enumerate((a.linear_q, a.linear_k, a.linear_v)):

@@ -207,7 +207,7 @@ def _mha_core_products(qkv, g, q, k, do, p_v, ds, dsk, dq1, win, idx, window, dw
 
 def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_scale=0.125, window=None, probs=None,
             skew_buf=None, fused_softmax_bwd=True, drop_p=None, drop_out=None, dwin_acc=None, dyb_bf16=None,
-            dwo_out=None, dbo_out=None, wo_tp=None, wqkv_tp=None, ffn_next=None):
+            dwo_out=None, dbo_out=None, wo_tp=None, wqkv_tp=None, ffn_next=None, ffn_below=None):
     """out = x + attention(LN(x)) @ wo^T + bo  (conformer.py:213-254,356).
 
     wqkv_bf holds the q rows already multiplied by q_scale (as the forward uses them); the returned dwqkv / dbqkv are
@@ -216,7 +216,10 @@ def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_s
     ffn_next: keyword arguments of ffn_bwd_fused (without dy) for the FeedForward whose output x is (the block's
     feed_forward_in): when the row-panel forms apply, the q | k | v projection's input-side backward and that FeedForward's
     run as ONE kernel (ob.qkv_ffn_bwd) and the result is (dx of the FeedForward, attention gradients, FeedForward gradients);
-    ``chained_ffn(...)`` says beforehand whether they will.
+    ``chained_ffn(...)`` says beforehand whether they will.  ffn_below (with ffn_next that has ``ln2``): (kwargs of the
+    FeedForward BELOW - the next block of the backward pass' feed_forward_out, whose output is ln2's input -, conv tuple of
+    ob.ffn_bwd): a third stage of the same kernel (ob.qkv_ffn2_bwd); the result grows by that stage's raw ob.ffn_bwd tuple (its
+    weight gradients are the caller's to queue when that block's turn comes).
     """
     D = x.shape[1]
     # training: out = x + D_out(ao wo^T + bo) (conformer.py:254): the branch gradient is dy o mask / (1 - p)
@@ -245,6 +248,12 @@ def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_s
             raise RuntimeError("css_amd: mha_bwd(ffn_next=...) outside the shapes of the chained kernel (ask chained_ffn first)")
         f = dict(ffn_next)
         outs = f.pop("outs", (None, None, None, None))
+        if ffn_below is not None:
+            fb, conv = ffn_below
+            (dg, dbeta, a), res, res_below = ob.qkv_ffn2_bwd(dq2, wqkv_tp, x, dy, ln_g, ln_b, f, fb, conv, f["d_ffn"], f.get("alpha", 0.5))
+            ob.linear_wgrad(dq2, a, 1.0, dw_out=dw, db_out=db, head=(D, q_scale))
+            _, gf = _ffn_wgrads(res, None, 0.5, outs)
+            return res_below[0], (dg, dbeta, dw, db, dwo, dbo, dpe), gf, res_below
         (dg, dbeta, a), res = ob.qkv_ffn_bwd(dq2, wqkv_tp, x, dy, ln_g, ln_b, f.pop("x"), f.pop("ln_g"), f.pop("ln_b"), f.pop("w1p"),
                                             f.pop("b1"), f.pop("w2tp"), f.pop("w1tp"), f.pop("d_ffn"), f.pop("alpha", 0.5),
                                             drop_hidden=f.pop("drop_hidden", None), drop_out=f.pop("drop_out"), ln2=f.pop("ln2", None))
@@ -268,6 +277,10 @@ def mha_bwd(x, dy, qkv, ao, ln_g, ln_b, wqkv_bf, wo_bf, pe_table_bf, n_head, q_s
 
 
 _NO_QKV_FFN = bool(os.environ.get("CSSHIP_NO_QKV_FFN"))   # A/B timing: qkv_in_bwd and the FeedForward backward behind it as two launches
+# ... and the block below's FeedForward backward (+ its conv module's statistics) as a THIRD stage of that kernel (csship_qkv_ffn2_bwd).
+# OPT-IN: measured slower, 7.69-7.81 against 7.64-7.71 ms per training step (profiles/r06_qkv_ffn2_bwd_ab.txt) - 113 us without a
+# launch boundary let the 200 workgroups drift out of step, and their weight streams stop sharing the L2.
+_QKV_FFN2 = bool(os.environ.get("CSSHIP_QKV_FFN2"))
 
 
 def chained_ffn(x, wqkv_tp, ffn_next):

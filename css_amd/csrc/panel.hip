@@ -398,9 +398,12 @@ struct FfnBwdArgs {
 // tile), Pb = FULL: b1 | gamma | beta | gamma2 | dump.  DYREG: dy arrives in registers (this thread's pieces of row tid >> 3, the
 // row mapping of the prologue) from the stage in front of it in the same kernel (qkv_ffn_bwd_kernel) instead of from memory.
 constexpr int FB_XD_BYTES = 2 * PANEL_BYTES, FB_GRAW_BYTES = 2 * PANEL_BYTES + 1024, FB_PB_FLOATS = CS_FFMAX + 3 * DM + CS_DUMP;
-template <int NW, bool FULL, bool LN2, bool DYREG, bool CS = false>
+// KEEPOUT (with LN2): the final dx - the gradient through the second LayerNorm - goes back into dyio instead of memory, for a
+// third stage behind this one in the same kernel (qkv_ffn2_bwd_kernel).
+template <int NW, bool FULL, bool LN2, bool DYREG, bool CS = false, bool KEEPOUT = false>
 DEV void ffn_bwd_body(const FfnBwdArgs& a, unsigned char* const XD, unsigned char* const Graw, float* const Pb,
-                      const float4 (&dyin)[8]) {
+                      float4 (&dyio)[8]) {
+  static_assert(!KEEPOUT || LN2, "the hand-over sits in the second LayerNorm's epilogue");
   static_assert(FULL || !LN2, "the fused second LayerNorm backward is built for whole panels");
   static_assert(!CS || (FULL && !LN2), "the conv module's statistics ride behind a whole-panel FeedForward without a second LayerNorm");
   static_assert(FULL || !DYREG, "the chained form is built for whole panels");
@@ -456,7 +459,7 @@ DEV void ffn_bwd_body(const FfnBwdArgs& a, unsigned char* const XD, unsigned cha
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       v[i] = *reinterpret_cast<const float4*>(a.x + (size_t)rowc * DM + (i * 8 + part) * 4);
-      if constexpr (DYREG) d[i] = dyin[i];
+      if constexpr (DYREG) d[i] = dyio[i];
       else d[i] = *reinterpret_cast<const float4*>(a.dy + (size_t)rowc * DM + (i * 8 + part) * 4);
       if constexpr (KEEP_DY) dyk[i] = d[i];
     }
@@ -754,7 +757,8 @@ DEV void ffn_bwd_body(const FfnBwdArgs& a, unsigned char* const XD, unsigned cha
       o4.y = rstd2 * (gg[i].y - t1 - x2[i].y * t2);
       o4.z = rstd2 * (gg[i].z - t1 - x2[i].z * t2);
       o4.w = rstd2 * (gg[i].w - t1 - x2[i].w * t2);
-      *reinterpret_cast<float4*>(a.dx + (size_t)row * DM + col) = o4;
+      if constexpr (KEEPOUT) dyio[i] = o4;
+      else *reinterpret_cast<float4*>(a.dx + (size_t)row * DM + col) = o4;
       *reinterpret_cast<float4*>(cg + r * YS + col) = make_float4(dyv[i].x * x2[i].x, dyv[i].y * x2[i].y, dyv[i].z * x2[i].z, dyv[i].w * x2[i].w);
       *reinterpret_cast<float4*>(cb + r * DM + col) = dyv[i];
     }
@@ -2949,6 +2953,21 @@ __global__ __launch_bounds__(NW * 64) void qkv_ffn_bwd_kernel(QkvBwdArgs q, FfnB
   ffn_bwd_body<NW, true, LN2, true>(f, RAW, RAW + FB_XD_BYTES, Pb2, dxk);
 }
 
+// ... and the FeedForward backward of the BLOCK BELOW behind that (its feed_forward_out, conformer.py:358-360: the second stage's
+// dx through the block's final LayerNorm is its dy), with the conv module's statistics in its epilogue: three stages, one launch.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void qkv_ffn2_bwd_kernel(QkvBwdArgs q, FfnBwdArgs f1, FfnBwdArgs f2) {
+  __shared__ __attribute__((aligned(16))) unsigned char RAW[QF_RAW_BYTES];
+  __shared__ __attribute__((aligned(16))) float Pb1[QB_PB_FLOATS];
+  __shared__ __attribute__((aligned(16))) float Pb2[FB_PB_FLOATS + 4 * DM];
+  float4 dxk[8];
+  qkv_in_bwd_body<NW, true>(q, RAW, Pb1, dxk);
+  __syncthreads();
+  ffn_bwd_body<NW, true, true, true, false, true>(f1, RAW, RAW + FB_XD_BYTES, Pb2, dxk);
+  __syncthreads();   // the second stage's column sums have been read; its parameter block is restaged by the third
+  ffn_bwd_body<NW, true, false, true, true, false>(f2, RAW, RAW + FB_XD_BYTES, Pb2, dxk);
+}
+
 extern "C" size_t csship_qkv_in_bwd_workspace(int32_t M) { return (size_t)((M + BM - 1) / BM) * 2 * DM * sizeof(float); }
 
 extern "C" int csship_qkv_in_bwd(const uint16_t* dqkv, const uint16_t* wqkvT_packed, const float* x, const float* dy,
@@ -3018,6 +3037,62 @@ extern "C" int csship_qkv_ffn_bwd(const uint16_t* dqkv, const uint16_t* wqkvT_pa
   rc = launch_slab_reduce(wsf, nwg, 2 * DM, 2 * DM, 2 * DM, 1.f, nullptr, nullptr, 0, dgamma_dbeta, as_stream(stream), true);
   if (rc != CSSHIP_OK || !ln2) return rc;
   return launch_slab_reduce(part2, nwg, 2 * DM, 2 * DM, 2 * DM, 1.f, nullptr, nullptr, 0, dgamma_dbeta2, as_stream(stream), true);
+}
+
+extern "C" size_t csship_qkv_ffn2_bwd_workspace(int32_t M) { return (size_t)((M + BM - 1) / BM) * (10 * DM + 2) * sizeof(float); }
+
+extern "C" int csship_qkv_ffn2_bwd(const csship_qkv_bwd_args* q, const csship_ffn_bwd_args* fi, const csship_ffn_bwd_args* fo,
+                                   const csship_conv_stats_args* cv, int32_t M, int32_t d_model, int32_t d_ffn, float alpha,
+                                   void* workspace, size_t workspace_bytes, csship_stream_t stream) {
+  if (!q || !fi || !fo || !cv || !workspace) return CSSHIP_ENULL;
+  if (!q->dqkv || !q->wqkvT_packed || !q->x || !q->dy || !q->ln_g || !q->ln_b || !q->y_bf16 || !q->dgamma_dbeta) return CSSHIP_ENULL;
+  for (const csship_ffn_bwd_args* f : {fi, fo}) {
+    if (!f->x || !f->ln_g || !f->ln_b || !f->w1_packed || !f->b1 || !f->w2t_packed || !f->w1t_packed || !f->a_bf16 || !f->h_bf16 ||
+        !f->dh_bf16 || !f->dgamma_dbeta || !f->dyd_bf16)
+      return CSSHIP_ENULL;
+    if (!aligned16(f->x) || !aligned16(f->ln_g) || !aligned16(f->ln_b) || !aligned16(f->b1) || !aligned16(f->w1_packed) ||
+        !aligned16(f->w2t_packed) || !aligned16(f->w1t_packed) || !aligned8(f->a_bf16) || !aligned8(f->h_bf16) ||
+        !aligned8(f->dh_bf16) || !aligned8(f->dyd_bf16))
+      return CSSHIP_EALIGN;
+  }
+  if (!fi->ln2_x || !fi->ln2_g || !fi->dgamma_dbeta2 || !fo->dx || fo->ln2_x) return CSSHIP_ENULL;   // the chain runs through that LayerNorm
+  if (!cv->fwd_workspace || !cv->pw2_w || !cv->grads) return CSSHIP_ENULL;
+  if (M <= 0 || cv->B <= 0 || cv->T <= 0 || (int64_t)cv->B * cv->T != M) return CSSHIP_EBADSHAPE;
+  if (d_model != DM || (M % BM) != 0 || d_ffn <= 0 || (d_ffn % DM) != 0 || d_ffn > CS_FFMAX) return CSSHIP_EUNSUPPORTED;
+  if (!aligned16(q->dqkv) || !aligned16(q->wqkvT_packed) || !aligned16(q->x) || !aligned16(q->dy) || !aligned16(q->ln_g) ||
+      !aligned16(q->ln_b) || !aligned8(q->y_bf16) || !aligned16(fi->ln2_x) || !aligned16(fi->ln2_g) || !aligned16(fo->dx) ||
+      !aligned16(cv->fwd_workspace))
+    return CSSHIP_EALIGN;
+  const int nwg = M / BM;
+  if (workspace_bytes < csship_qkv_ffn2_bwd_workspace(M)) return CSSHIP_EWORKSPACE;
+  if ((int64_t)nwg * BM * d_ffn > 0xffffffffLL) return CSSHIP_EBADSHAPE;  // 32-bit dropout element indices
+  float* const wsf = reinterpret_cast<float*>(workspace);   // [nwg][2][256] x 4 (FeedForward, its second LayerNorm, q | k | v, the FeedForward below) + [nwg][514]
+  float* const part_i = wsf, * const part_i2 = wsf + (size_t)nwg * 2 * DM, * const part_q = wsf + (size_t)nwg * 4 * DM;
+  float* const part_o = wsf + (size_t)nwg * 6 * DM, * const part_cs = wsf + (size_t)nwg * 8 * DM;
+  const csship_dropout_cfg none{nullptr, 0u, 0.f};
+  auto cfg = [&](const csship_dropout_cfg* d) { return d && d->seed && d->p > 0.f ? *d : none; };
+  const float* const z = reinterpret_cast<const float*>(cv->fwd_workspace);
+  QkvBwdArgs qa{q->dqkv, reinterpret_cast<const bf16x8*>(q->wqkvT_packed), q->x, q->dy, q->ln_g, q->ln_b, nullptr, q->y_bf16, part_q, M};
+  FfnBwdArgs f1{fi->x, nullptr, fi->ln_g, fi->ln_b, reinterpret_cast<const bf16x8*>(fi->w1_packed), fi->b1,
+                reinterpret_cast<const bf16x8*>(fi->w2t_packed), reinterpret_cast<const bf16x8*>(fi->w1t_packed), fi->a_bf16, fi->h_bf16,
+                fi->dh_bf16, nullptr, part_i, M, d_ffn, alpha, cfg(fi->drop_hidden), cfg(fi->drop_out), fi->dyd_bf16, fi->ln2_x, fi->ln2_g,
+                part_i2};
+  FfnBwdArgs f2{fo->x, nullptr, fo->ln_g, fo->ln_b, reinterpret_cast<const bf16x8*>(fo->w1_packed), fo->b1,
+                reinterpret_cast<const bf16x8*>(fo->w2t_packed), reinterpret_cast<const bf16x8*>(fo->w1t_packed), fo->a_bf16, fo->h_bf16,
+                fo->dh_bf16, fo->dx, part_o, M, d_ffn, alpha, cfg(fo->drop_hidden), cfg(fo->drop_out), fo->dyd_bf16, nullptr, nullptr,
+                nullptr, z, z + convmod_fwd_stats_offset(cv->B, cv->T, DM), cv->pw2_w, cfg(cv->drop), part_cs};
+  hipLaunchKernelGGL((qkv_ffn2_bwd_kernel<NWAVES>), dim3(nwg), dim3(NWAVES * 64), 0, as_stream(stream), qa, f1, f2);
+  CSSHIP_CHECK_LAUNCH();
+  // the conv module's sums are read by its own backward right behind this call: reduced at once; the rest are parameter gradients
+  int rc = launch_slab_reduce(part_cs, nwg, 2 * DM + 2, 2 * DM + 2, 2 * DM + 2, 1.f, nullptr, nullptr, 0, cv->grads, as_stream(stream));
+  if (rc != CSSHIP_OK) return rc;
+  const struct { const float* part; float* out; } red[4] = {{part_q, q->dgamma_dbeta}, {part_i, fi->dgamma_dbeta},
+                                                            {part_i2, fi->dgamma_dbeta2}, {part_o, fo->dgamma_dbeta}};
+  for (const auto& r : red) {
+    rc = launch_slab_reduce(r.part, nwg, 2 * DM, 2 * DM, 2 * DM, 1.f, nullptr, nullptr, 0, r.out, as_stream(stream), true);
+    if (rc != CSSHIP_OK) return rc;
+  }
+  return CSSHIP_OK;
 }
 
 // out bf16 [M, 256] = a bf16 [M, 256] W^T with no bias, whole panels: the input gradient of a 256 -> 256 Linear against

@@ -613,6 +613,58 @@ def qkv_ffn_bwd(dqkv, wqkvT_p, x_attn, dy, attn_ln_g, attn_ln_b, x, ln_g, ln_b, 
     return (gbq[0], gbq[1], y), res
 
 
+def qkv_ffn2_bwd(dqkv, wqkvT_p, x_attn, dy, attn_ln_g, attn_ln_b, fin, fout, conv, d_ffn, alpha=0.5):
+    """qkv_ffn_bwd with the FeedForward backward of the block BELOW behind it, the conv module's statistics pass included
+    (csship_qkv_ffn2_bwd: three stages, one launch).  fin / fout: dicts with x, ln_g, ln_b, w1p, b1, w2tp, w1tp, drop_hidden,
+    drop_out (fin also ln2 = (x2, gamma2): the chain runs through that LayerNorm); conv = (fwd_ws, pw2_w, drop_cfg, flat, B, T) as
+    in ffn_bwd.  Returns ((attn dgamma, attn dbeta, y), ffn_bwd's tuple for fin (its dx is None: it never exists), ffn_bwd's tuple
+    for fout)."""
+    _need(dqkv, torch.bfloat16, "dqkv"), _need(x_attn, torch.float32, "x_attn"), _need(dy, torch.float32, "dy")
+    M, D = x_attn.shape
+    fws, pw2_w, cdrop, flat, B, T = conv
+    x2, g2 = fin["ln2"]
+    for t in (x_attn, dy, dqkv, fin["x"], fout["x"], x2):
+        if not t.is_contiguous():
+            raise RuntimeError("css_amd: qkv_ffn2_bwd expects dense rows")
+    if dy.shape != x_attn.shape or fin["x"].shape != x_attn.shape or fout["x"].shape != x_attn.shape or x2.shape != x_attn.shape or \
+            dqkv.shape != (M, 3 * D) or B * T != M:
+        raise RuntimeError("css_amd: qkv_ffn2_bwd expects x_attn, dy, both FeedForward inputs and the LayerNorm's input as [M, 256], dqkv [M, 768], M = B * T")
+    if fin.get("drop_out") is None or fout.get("drop_out") is None:
+        raise RuntimeError("css_amd: qkv_ffn2_bwd needs both FeedForwards' output dropout cfgs (dyd is the only copy of their dy)")
+    if flat.dtype != torch.float32 or not flat.is_contiguous() or flat.numel() < 38 * D + 8:
+        raise RuntimeError("css_amd: qkv_ffn2_bwd expects the conv module's f32 gradient buffer [38 D + 8]")
+    dev = x_attn.device
+    bf = torch.bfloat16
+    y = torch.empty((M, D), dtype=bf, device=dev)
+    gbq = torch.empty((2, D), dtype=torch.float32, device=dev)
+    qa = _lib.QkvBwdArgs(_ptr(dqkv), _ptr(wqkvT_p), _ptr(x_attn), _ptr(dy), _ptr(attn_ln_g), _ptr(attn_ln_b), _ptr(y), _ptr(gbq))
+
+    def block(f, want_dx):
+        a = torch.empty((M, D), dtype=bf, device=dev)
+        h = torch.empty((M, d_ffn), dtype=bf, device=dev)
+        dh = torch.empty((M, d_ffn), dtype=bf, device=dev)
+        dyd = torch.empty((M, D), dtype=bf, device=dev)
+        gb = torch.empty((2, D), dtype=torch.float32, device=dev)
+        dx = torch.empty((M, D), dtype=torch.float32, device=dev) if want_dx else None
+        st = _lib.FfnBwdArgs()
+        st.x, st.ln_g, st.ln_b, st.w1_packed, st.b1 = _ptr(f["x"]), _ptr(f["ln_g"]), _ptr(f["ln_b"]), _ptr(f["w1p"]), _ptr(f["b1"])
+        st.w2t_packed, st.w1t_packed = _ptr(f["w2tp"]), _ptr(f["w1tp"])
+        st.a_bf16, st.h_bf16, st.dh_bf16, st.dx, st.dgamma_dbeta = _ptr(a), _ptr(h), _ptr(dh), _ptr(dx), _ptr(gb)
+        st.drop_hidden, st.drop_out, st.dyd_bf16 = f.get("drop_hidden"), f["drop_out"], _ptr(dyd)
+        return st, (dx, gb[0], gb[1], a, h, dh, dyd)
+
+    fi, res_in = block(fin, False)
+    gb2 = torch.empty((2, D), dtype=torch.float32, device=dev)
+    fi.ln2_x, fi.ln2_g, fi.dgamma_dbeta2 = _ptr(x2), _ptr(g2), _ptr(gb2)
+    fo, res_out = block(fout, True)
+    cv = _lib.ConvStatsArgs(_ptr(fws), B, T, _ptr(pw2_w), cdrop, _ptr(flat))
+    nws = lib().csship_qkv_ffn2_bwd_workspace(M)
+    ws = _workspace(nws, dev, own=True)
+    check(lib().csship_qkv_ffn2_bwd(C.byref(qa), C.byref(fi), C.byref(fo), C.byref(cv), M, D, d_ffn, float(alpha), _ptr(ws), nws,
+                                    _stream()))
+    return (gbq[0], gbq[1], y), res_in + (gb2[0], gb2[1]), res_out
+
+
 def grad_accumulate(pairs):
     """dst += src for every (dst, src) pair in ONE launch per 96 pairs (csship_grad_accumulate).  dst: dense f32; src: f32
     with dst's element count, dense in dst's order, or a 2-d [R, C] view with stride(0) == 1 (the transpose of a matrix

@@ -936,6 +936,31 @@ int csship_qkv_ffn_bwd(const uint16_t* dqkv, const uint16_t* wqkvT_packed, const
                        uint16_t* dyd_bf16, const float* ln2_x, const float* ln2_g, float* dgamma_dbeta2, void* workspace,
                        size_t workspace_bytes, csship_stream_t stream);
 
+/* csship_qkv_ffn2_bwd (round 6): csship_qkv_ffn_bwd with the FeedForward backward of the BLOCK BELOW behind it - that block's
+ * feed_forward_out (conformer.py:358-360): the gradient the second stage carries through the block's final LayerNorm (ln2) is
+ * its dy - including the conv module's statistics pass of csship_ffn_bwd_conv: three stages of one kernel per 64-row panel, two
+ * launches and two f32 [M, 256] round trips less per block than the single operators.  The three argument blocks are the
+ * operands of csship_qkv_in_bwd (without dx), of csship_ffn_bwd_ln (without dy; f_in: ln2_* required, dx unused; f_out_below: dx
+ * required - the conv module's backward reads it -, ln2_* NULL) and of csship_ffn_bwd_conv's conv part.  dyd_bf16 is required in
+ * both FeedForward blocks.  Same shape limits as csship_qkv_ffn_bwd. */
+typedef struct {
+  const uint16_t* dqkv; const uint16_t* wqkvT_packed; const float* x; const float* dy; const float* ln_g; const float* ln_b;
+  uint16_t* y_bf16; float* dgamma_dbeta;
+} csship_qkv_bwd_args;
+typedef struct {
+  const float* x; const float* ln_g; const float* ln_b; const uint16_t* w1_packed; const float* b1; const uint16_t* w2t_packed;
+  const uint16_t* w1t_packed; uint16_t* a_bf16; uint16_t* h_bf16; uint16_t* dh_bf16; float* dx; float* dgamma_dbeta;
+  const csship_dropout_cfg* drop_hidden; const csship_dropout_cfg* drop_out; uint16_t* dyd_bf16;
+  const float* ln2_x; const float* ln2_g; float* dgamma_dbeta2;
+} csship_ffn_bwd_args;
+typedef struct {
+  const void* fwd_workspace; int32_t B, T; const float* pw2_w; const csship_dropout_cfg* drop; float* grads;
+} csship_conv_stats_args;
+size_t csship_qkv_ffn2_bwd_workspace(int32_t M);
+int csship_qkv_ffn2_bwd(const csship_qkv_bwd_args* q, const csship_ffn_bwd_args* f_in, const csship_ffn_bwd_args* f_out_below,
+                        const csship_conv_stats_args* conv_below, int32_t M, int32_t d_model, int32_t d_ffn, float alpha,
+                        void* workspace, size_t workspace_bytes, csship_stream_t stream);
+
 /* ---- BLSTM recurrence, training (css_amd/csrc/lstm.hip).  csship_lstm_bidir_train = csship_lstm_bidir that also keeps
  * the activated gates (i, f, g, o; f32 [B, T, 2, 4H]) and the cell states (f32 [B, T, 2, H]).
  * csship_lstm_bidir_bwd: back-propagation through time.  dy: f32 [B, T, 2H]; whhT_packed: both directions'

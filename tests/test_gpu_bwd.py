@@ -335,6 +335,70 @@ def test_ffn_bwd_carries_the_conv_statistics(ob):
         ob.convmod_bwd(xc, got[0].view(B, T, D), W, fws, 33, drop=c_out, stats_done=True)
 
 
+def test_qkv_ffn2_bwd_equals_the_chain_plus_the_feedforward_below(ob):
+    """csship_qkv_ffn2_bwd: three stages of one kernel - the q | k | v projection's input gradient, the FeedForward backward
+    behind it (through the second LayerNorm) and the FeedForward backward of the block below with its conv module's statistics
+    - vs csship_qkv_ffn_bwd then csship_ffn_bwd_conv on the same operands: first-stage outputs bit for bit, the rest within the
+    bounds of the two-stage test (another build of the same formulas)"""
+    from css_amd import ops
+    from css_amd.dropout import DropState
+    B, T, D, FF = 4, 176, 256, 1024
+    M = B * T
+    st = DropState(torch.tensor([55], dtype=torch.int32, device=DEV), 0.1, 0)
+    cfg = {k: st.cfg(k) for k in ("3.ffn_in.hidden", "3.ffn_in.out", "2.ffn_out.hidden", "2.ffn_out.out", "2.conv.out")}
+    W = {"ln_g": 1 + 0.1 * rnd((D,), 501), "ln_b": 0.1 * rnd((D,), 502), "pw1_w": torch.tensor([0.9, -0.7]),
+         "pw1_b": torch.tensor([0.1, 0.2]), "dw_w": rnd((33, D), 503, 0.2), "dw_b": 0.1 * rnd((D,), 504),
+         "bn_g": 1 + 0.1 * rnd((D,), 505), "bn_b": 0.1 * rnd((D,), 506), "bn_mean": torch.zeros(D), "bn_var": torch.ones(D),
+         "pw2_w": torch.tensor([1.3]), "pw2_b": torch.tensor([-0.2])}
+    W = {k: v.to(DEV) for k, v in W.items()}
+    xc = rnd((B, T, D), 507).to(DEV)
+    x3, fws = ops.convmod(xc, W, 33, batch_stats=True, return_workspace=True, drop=cfg["2.conv.out"])   # the lower FeedForward's input
+    x3 = x3.view(M, D)
+
+    def ffn_params(seed):
+        G = {"ln_g": (1 + 0.1 * rnd((D,), seed)).to(DEV), "ln_b": (0.1 * rnd((D,), seed + 1)).to(DEV),
+             "w1": rnd((FF, D), seed + 2, 0.06).to(DEV), "b1": rnd((FF,), seed + 3, 0.1).to(DEV), "w2": rnd((D, FF), seed + 4, 0.03).to(DEV)}
+        G["w1p"] = ops.pack_frag(G["w1"])
+        G["w2tp"], G["w1tp"] = ops.pack_frag(G["w2"].t().contiguous()), ops.pack_frag(G["w1"].t().contiguous())
+        return G
+    Gi, Go = ffn_params(520), ffn_params(530)
+    x4 = rnd((M, D), 540).to(DEV)                       # the block-final LayerNorm's input (below) ...
+    g2, b2 = (1 + 0.1 * rnd((D,), 541)).to(DEV), (0.1 * rnd((D,), 542)).to(DEV)
+    x = torch.nn.functional.layer_norm(x4, (D,), g2, b2, 1e-5)   # ... and its output: the upper FeedForward's input
+    x_attn, dy = rnd((M, D), 543).to(DEV), rnd((M, D), 544, 0.1).to(DEV)
+    ag, ab = (1 + 0.1 * rnd((D,), 545)).to(DEV), (0.1 * rnd((D,), 546)).to(DEV)
+    _, wt = ob.pack_weight(rnd((3 * D, D), 547, 0.06).to(DEV).t().contiguous(), want_frag=True)
+    dqkv = rnd((M, 3 * D), 548, 0.5).to(torch.bfloat16).to(DEV)
+    # reference: the two-stage kernel, then the lower FeedForward with the conv statistics
+    (dg0, db0, y0), r_in = ob.qkv_ffn_bwd(dqkv, wt, x_attn, dy, ag, ab, x, Gi["ln_g"], Gi["ln_b"], Gi["w1p"], Gi["b1"], Gi["w2tp"], Gi["w1tp"],
+                                          FF, 0.5, drop_hidden=cfg["3.ffn_in.hidden"], drop_out=cfg["3.ffn_in.out"], ln2=(x4, g2))
+    flat0 = torch.zeros(38 * D + 8, dtype=torch.float32, device=DEV)
+    r_out = ob.ffn_bwd(x3, r_in[0], Go["ln_g"], Go["ln_b"], Go["w1p"], Go["b1"], Go["w2tp"], Go["w1tp"], FF, 0.5, cfg["2.ffn_out.hidden"],
+                       cfg["2.ffn_out.out"], conv=(fws, W["pw2_w"], cfg["2.conv.out"], flat0, B, T))
+    fin = dict(x=x, ln_g=Gi["ln_g"], ln_b=Gi["ln_b"], w1p=Gi["w1p"], b1=Gi["b1"], w2tp=Gi["w2tp"], w1tp=Gi["w1tp"],
+               drop_hidden=cfg["3.ffn_in.hidden"], drop_out=cfg["3.ffn_in.out"], ln2=(x4, g2))
+    fout = dict(x=x3, ln_g=Go["ln_g"], ln_b=Go["ln_b"], w1p=Go["w1p"], b1=Go["b1"], w2tp=Go["w2tp"], w1tp=Go["w1tp"],
+                drop_hidden=cfg["2.ffn_out.hidden"], drop_out=cfg["2.ffn_out.out"])
+    flat = torch.zeros(38 * D + 8, dtype=torch.float32, device=DEV)
+    (dg, db, y), g_in, g_out = ob.qkv_ffn2_bwd(dqkv, wt, x_attn, dy, ag, ab, fin, fout, (fws, W["pw2_w"], cfg["2.conv.out"], flat, B, T), FF)
+    assert torch.equal(dg, dg0) and torch.equal(db, db0) and torch.equal(y, y0)
+    assert g_in[0] is None and len(g_in) == 9 and len(g_out) == 7
+
+    def close(a, b, what):
+        if a.dtype == torch.bfloat16:   # (a bf16 flip in one stage moves a row of the next by 1e-4: a few elements, a few ulps)
+            d = (a.float() - b.float()).abs()
+            assert int((d > 0).sum()) <= 512 and float(d.max()) <= 2.0 ** -7 * float(b.float().abs().max()), what
+        else:
+            assert relerr(a, b.double().cpu()) < 5e-4, what
+    for i in range(1, 9):
+        close(g_in[i], r_in[i], ("ffn_in", i))
+    for i in range(7):
+        close(g_out[i], r_out[i], ("ffn_out", i))
+    assert float((flat[:2 * D + 2] - flat0[:2 * D + 2]).abs().max()) <= 5e-4 * float(flat0[:2 * D + 2].abs().max())
+    with pytest.raises(RuntimeError):   # the chain runs through the LayerNorm between the blocks: whole panels only
+        ob.qkv_ffn2_bwd(dqkv[:100], wt, x_attn[:100], dy[:100], ag, ab, fin, fout, (fws, W["pw2_w"], cfg["2.conv.out"], flat, B, T), FF)
+
+
 def test_grouped_weight_gradients_equal_the_single_products(ob):
     """csship_wgrad_hold / csship_wgrad_flush: the weight-gradient products of a block queued and run as ONE launch (the
     reduction cut 2-3 times instead of 16-64) vs float64 on the same bf16 operands and vs the products one by one; a
