@@ -213,6 +213,8 @@ SIGNATURES = {
                                    _p, _i32, _i32, _p, _dc, _p, _p, _sz, _p]),
     "csship_convmod_bwd_after_stats": (_i32, [_p, _p, C.POINTER(ConvWeights), _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _dc, _dc, _p, _p,
                                               _sz, _p]),
+    "csship_reduce_side_stream": (_i32, [_p]),
+    "csship_reduce_side_join": (_i32, [_p]),
     "csship_qkv_in_bwd_workspace": (_sz, [_i32]),
     "csship_qkv_ffn2_bwd_workspace": (_sz, [_i32]),
     "csship_qkv_ffn2_bwd": (_i32, [C.POINTER(QkvBwdArgs), C.POINTER(FfnBwdArgs), C.POINTER(FfnBwdArgs), C.POINTER(ConvStatsArgs),

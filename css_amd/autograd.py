@@ -67,6 +67,8 @@ def _owners(ps):
 # one join at the end of the backward pass) beside the next block's data-gradient chain.  Single-process steps only.
 _NO_FFN_CONV = bool(os.environ.get("CSSHIP_NO_FFN_CONV"))   # A/B timing: the conv module's statistics pass as its own launch
 _WGRAD_SIDE = bool(os.environ.get("CSSHIP_WGRAD_SIDE"))
+# Experiment (round 6): only the small parameter-gradient REDUCTIONS (block flush, conv tap partials, window sums) on the side stream
+_REDUCE_SIDE = bool(os.environ.get("CSSHIP_REDUCE_SIDE"))
 _side_streams = {}
 
 
@@ -463,13 +465,18 @@ class ConformerTrain(torch.autograd.Function):
             if p in G:
                 red.flush()   # the sum reads both gradients
                 red.join()
+                red.rside.join()
                 G[p] = G[p].reshape(p.shape) + g
             else:
                 G[p] = g
 
         # the reductions behind the parameter gradients of a block run as ONE launch at its end (ops_bwd.deferred_reductions)
-        with ob.deferred_reductions(group_wgrads=not S["wide"]) as red:
-            return ConformerTrain._backward(ctx, grad_masks, model, S, G, put, red)
+        side = (_side_stream(grad_masks.device) if _REDUCE_SIDE and not S["wide"] and getattr(model, "_grad_bucket_hook", None) is None
+                else None)
+        with ob.reduce_side_stream(side) as rside:
+            with ob.deferred_reductions(group_wgrads=not S["wide"]) as red:
+                red.rside = rside
+                return ConformerTrain._backward(ctx, grad_masks, model, S, G, put, red)
 
     @staticmethod
     def _backward(ctx, grad_masks, model, S, G, put, red):
@@ -639,6 +646,7 @@ class ConformerTrain(torch.autograd.Function):
         put(enc.embed[1].weight, dg), put(enc.embed[1].bias, dbeta)
         red.flush()
         red.join()
+        red.rside.join()
         return (None, None) + _deliver(model, G)
 
 

@@ -571,11 +571,14 @@ static int pos_bwd_impl(const uint16_t* ds_skew, int64_t ld_w, const uint16_t* p
   if (workspace_bytes < csship_attn_pos_bwd_workspace(B, T)) return CSSHIP_EWORKSPACE;
   PosBwdArgs a{ds_skew, pe_window_t, q_rows, dq1, dq1_parts, ld_q, dqkv, reinterpret_cast<float*>(workspace), ld_w, ld_pt, B, T, H, nblk, nks, nwt};
   hipStream_t s = as_stream(stream);
+  side_join(s);   // (the previous call's window reduction may still read the partials this launch overwrites)
   if (from_ds) hipLaunchKernelGGL((attn_pos_bwd_kernel<true>), dim3((unsigned)(B * nblk)), dim3(512), 0, s, a);
   else hipLaunchKernelGGL((attn_pos_bwd_kernel<false>), dim3((unsigned)(B * nblk)), dim3(512), 0, s, a);
   CSSHIP_CHECK_LAUNCH();
   const int rows = std::min(W, (nblk - 1) * PB_ROWS + nwt * 16);
-  hipLaunchKernelGGL(pos_window_reduce_kernel, dim3((unsigned)rows), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), B,
+  // the window gradient is a parameter gradient (nobody on the data-gradient chain reads it): beside the caller's stream when it has
+  // a side stream; consecutive calls accumulate into dwin_acc in order, on that stream
+  hipLaunchKernelGGL(pos_window_reduce_kernel, dim3((unsigned)rows), dim3(256), 0, side_fork(s), reinterpret_cast<const float*>(workspace), B,
                      nblk, nwt, dwin_acc);
   CSSHIP_CHECK_LAUNCH();
   return CSSHIP_OK;

@@ -984,6 +984,39 @@ static void queue_job(const float* slabs, int S, int64_t n, int N, int64_t ldc, 
   t_defer.jobs.push_back(j);
 }
 
+// ---- side stream for parameter-gradient reductions (see common.hpp)
+static thread_local hipStream_t t_side = nullptr;
+static thread_local hipEvent_t t_side_fork = nullptr, t_side_join = nullptr;
+static thread_local bool t_side_dirty = false;
+
+hipStream_t side_fork(hipStream_t main) {
+  if (t_side == nullptr || t_side == main) return main;
+  if (hipEventRecord(t_side_fork, main) != hipSuccess || hipStreamWaitEvent(t_side, t_side_fork, 0) != hipSuccess) return main;
+  t_side_dirty = true;
+  return t_side;
+}
+
+void side_join(hipStream_t main) {
+  if (t_side == nullptr || !t_side_dirty || t_side == main) return;
+  if (hipEventRecord(t_side_join, t_side) == hipSuccess && hipStreamWaitEvent(main, t_side_join, 0) == hipSuccess) t_side_dirty = false;
+}
+
+extern "C" int csship_reduce_side_stream(csship_stream_t side) {
+  if (side != nullptr && t_side_fork == nullptr) {
+    if (hipEventCreateWithFlags(&t_side_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&t_side_join, hipEventDisableTiming) != hipSuccess)
+      return CSSHIP_ELAUNCH;
+  }
+  t_side = as_stream(side);
+  if (side == nullptr) t_side_dirty = false;
+  return CSSHIP_OK;
+}
+
+extern "C" int csship_reduce_side_join(csship_stream_t main) {
+  side_join(as_stream(main));
+  return CSSHIP_OK;
+}
+
 static int launch_slab_reduce2(const float* slabs, int S, int64_t n, int N, int64_t ldc, float alpha, const float* bias,
                                const float* add, int64_t ldadd, float* out, const float* slabs2, int64_t n2, float* out2,
                                hipStream_t s, float alpha_head = 0.f, int head_rows = 0, bool deferrable = false) {
@@ -1005,6 +1038,7 @@ static int launch_slab_reduce2(const float* slabs, int S, int64_t n, int N, int6
     if (n2 > 0) queue_job(slabs2, S, n2, (int)n2, n2, alpha, nullptr, nullptr, 0, out2, alpha_head, head_rows, kind | 4);
     return CSSHIP_OK;
   }
+  if (deferrable) s = side_fork(s);   // a parameter gradient too large to queue: beside the caller's stream when it has a side stream
   if (wide) {
     const unsigned nb = (unsigned)((n / 4 + 63) / 64), nb2 = (unsigned)((n2 / 4 + 63) / 64);
     hipLaunchKernelGGL((slab_reduce_kernel<4, 4, 8>), dim3(nb + nb2), dim3(256), 0, s, slabs, S, n, N, ldc, alpha, bias, add,
@@ -1106,6 +1140,7 @@ extern "C" size_t csship_wgrad_group_workspace(void) {
 }
 
 extern "C" int csship_wgrad_flush(void* workspace, size_t workspace_bytes, csship_stream_t stream) {
+  side_join(as_stream(stream));   // (the previous flush's reduction may still read the slabs this one's products overwrite)
   if (t_wq.empty()) return CSSHIP_OK;
   if (!workspace || workspace_bytes < csship_wgrad_group_workspace()) {
     t_wq.clear();
@@ -1179,8 +1214,8 @@ extern "C" int csship_wgrad_flush(void* workspace, size_t workspace_bytes, csshi
 }
 
 extern "C" int csship_reduce_flush(csship_stream_t stream) {
-  hipStream_t s = as_stream(stream);
   std::vector<ReduceJob>& q = t_defer.jobs;
+  hipStream_t s = q.empty() ? as_stream(stream) : side_fork(as_stream(stream));   // parameter gradients only: beside the caller's stream
   for (size_t at = 0; at < q.size(); at += RB_MAX) {
     ReduceBatch b{};
     b.njobs = (int)std::min<size_t>(RB_MAX, q.size() - at);

@@ -106,6 +106,13 @@ int launch_outproj_conv_train(const uint16_t* attn_out, const uint16_t* wo_packe
                               float* x2_out, const csship_conv_weights& conv, int B, int T, csship_dropout_cfg drop,
                               float* zbuf, float* partial, int* nblk_out, hipStream_t s);
 
+// Optional side stream for launches that yield PARAMETER gradients only (csship_reduce_side_stream, bgemm.hip; off unless the
+// caller sets it): side_fork makes the side stream wait for everything `main` has been given so far and returns it (or `main`
+// itself when the mode is off); side_join makes `main` wait for everything the side stream has been given (no-op when nothing
+// is outstanding).  Per host thread, like the reduction queues.
+hipStream_t side_fork(hipStream_t main);
+void side_join(hipStream_t main);
+
 // floats from the start of csship_convmod's training workspace (= the pre-BatchNorm activations z [B, T, D]) to its
 // statistics block scale | shift | mean | variance (convmod.hip owns the layout; csship_ffn_bwd_conv reads both)
 size_t convmod_fwd_stats_offset(int B, int T, int D);

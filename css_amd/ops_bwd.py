@@ -31,6 +31,7 @@ class deferred_reductions:
         self.group = bool(group_wgrads) and not _NO_GROUP and not _NO_DEFER
         self.held = []     # flush(side=...): operands / slabs of launches that may still be running on the side stream
         self.side = None
+        self.held_prev, self.held_cur = [], []   # reduce_side_stream(): the last two flushes' slabs
 
     def __enter__(self):
         if _NO_DEFER:   # A/B timing: every reduction as its own launch
@@ -57,6 +58,8 @@ class deferred_reductions:
             with torch.cuda.stream(side):
                 self.flush()
             return
+        if _reduce_side["on"]:   # the launches of this flush may run on the side stream until the NEXT flush has begun (it joins first)
+            self.held_prev, self.held_cur = self.held_cur, list(_deferred_ws)
         if lib().csship_wgrad_pending():
             nws = lib().csship_wgrad_group_workspace()
             dev = _defer["dev"]
@@ -103,6 +106,37 @@ def ffn_static_max_ffn():
 
 _hold = {"on": False, "ws": []}
 _NO_PAIR = bool(os.environ.get("CSSHIP_NO_PAIR_REDUCE"))   # A/B timing: every weight gradient's slab reduction as its own launch
+
+
+_reduce_side = {"on": False}
+
+
+class reduce_side_stream:
+    """``with reduce_side_stream(side):`` - inside, the library's parameter-gradient reductions (the block flushes, reductions too
+    large to queue, the relative-position window sums) run on ``side`` beside the current stream (csship_reduce_side_stream).  The
+    exit joins the current stream with it.  Slabs of a deferred_reductions flush stay referenced for one more flush."""
+
+    def __init__(self, side):
+        self.side = side
+
+    def __enter__(self):
+        if self.side is not None:
+            check(lib().csship_reduce_side_stream(self.side.cuda_stream))
+            _reduce_side["on"] = True
+        return self
+
+    def join(self):
+        if self.side is not None:
+            check(lib().csship_reduce_side_join(_stream()))
+
+    def __exit__(self, et, ev, tb):
+        if self.side is not None:
+            try:
+                self.join()
+            finally:
+                _reduce_side["on"] = False
+                lib().csship_reduce_side_stream(None)
+        return False
 
 
 class paired_reductions:

@@ -936,6 +936,15 @@ int csship_qkv_ffn_bwd(const uint16_t* dqkv, const uint16_t* wqkvT_packed, const
                        uint16_t* dyd_bf16, const float* ln2_x, const float* ln2_g, float* dgamma_dbeta2, void* workspace,
                        size_t workspace_bytes, csship_stream_t stream);
 
+/* csship_reduce_side_stream (round 6, experiment): a second stream of the caller's for launches that yield PARAMETER gradients
+ * only - the flush of the queued reductions, reductions marked deferrable that are too large to queue, the relative-position
+ * window reduction: they run on `side` behind everything the call's own stream has been given so far, beside what it is given
+ * next.  NULL switches the mode off.  Per host thread.  The caller owes csship_reduce_side_join(main) before anyone reads
+ * those gradients (and before a stream capture that saw the side stream ends), and keeps every buffer such a launch reads
+ * alive until then (the library joins by itself before it overwrites its own slabs). */
+int csship_reduce_side_stream(csship_stream_t side);
+int csship_reduce_side_join(csship_stream_t main);
+
 /* csship_qkv_ffn2_bwd (round 6): csship_qkv_ffn_bwd with the FeedForward backward of the BLOCK BELOW behind it - that block's
  * feed_forward_out (conformer.py:358-360): the gradient the second stage carries through the block's final LayerNorm (ln2) is
  * its dy - including the conv module's statistics pass of csship_ffn_bwd_conv: three stages of one kernel per 64-row panel, two
