@@ -19,12 +19,18 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--blocks", type=int, default=16)
 ap.add_argument("--B", type=int, default=32)
 ap.add_argument("--T", type=int, default=400)
+ap.add_argument("--large", action="store_true", help="Conformer-large widths (d_model 512, 8 heads, ffn 2048, 18 blocks; two speakers + noise: "
+                "the MSE objective is written for two sources) through the any-width training path")
 a = ap.parse_args()
 dev = "cuda"
-conf = dict(attention_dim=256, attention_heads=4, linear_units=1024, num_blocks=a.blocks, kernel_size=33,
-            dropout_rate=0.1, relative_pos_emb=True)
+if a.large:
+    a.blocks = 18 if a.blocks == 16 else a.blocks
+    dims = dict(attention_dim=512, attention_heads=8, linear_units=2048)
+else:
+    dims = dict(attention_dim=256, attention_heads=4, linear_units=1024)
+conf = dict(num_blocks=a.blocks, kernel_size=33, dropout_rate=0.1, relative_pos_emb=True, **dims)
 m = MODELS["Conformer"](257, 257, 2, 1, conf)
-m.load_state_dict(syn.fill_state_dict(syn.conformer_shapes(num_blocks=a.blocks), 0))
+m.load_state_dict(syn.fill_state_dict(syn.conformer_shapes(num_blocks=a.blocks, **dims), 0))
 m = m.to(dev).train()
 obj = OBJECTIVES["MSE"].build_objective({})
 if a.torch_adam:
